@@ -1,0 +1,217 @@
+#!/usr/bin/env python3
+"""bench.py -- beam FE solves/s of the batched HIP solve (BASELINE.json metric, config 2).
+
+One "step" = one pass of the hot path over one batch: B = 10 000 straight beams x 100 elements
+(assemble + constrain + factor + solve + recover), inputs resident in HBM.  The K timed steps are
+captured into one HIP graph (launch-bound inner loop) and replayed once inside the timed region.
+
+    python bench.py                      # 1 GPU
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+Multi-GPU: the cases are independent, so each rank solves its own B-beam shard (weak scaling);
+there is NO collective in the data path -- only the barrier / max-over-ranks timing reduction.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and
+`cpu_baseline` objects.  Algorithmic bytes per solve: 4 925 B.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+BYTES_PER_SOLVE = 4925          # I[100]*8 + Fy[101]*8 + fix[101] in; v, theta [101]*8, V, M [100]*8 out
+HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+N_ELEM = 100
+SEED = 20250307
+
+
+def synth_inputs(B, rank, device, inertia):
+    """fixed bridge, 1-4 point loads per beam, UDL -1000, seeded per rank."""
+    rng = np.random.default_rng(SEED + rank)
+    N = N_ELEM + 1
+    rollers = (10, 30, 70, 85, 100)
+    fix = np.zeros(N, dtype=np.uint8)
+    fix[0] = 1
+    fix[[r - 1 for r in rollers]] = 1
+    avail = np.array([n for n in range(2, N) if n not in rollers])
+    k = rng.integers(1, 5, size=B)
+    Fy = np.zeros((B, N))
+    # vectorised draw of k distinct loaded nodes per beam
+    order = np.argsort(rng.random((B, avail.size)), axis=1)[:, :4]
+    vals = rng.uniform(-355857.0, -35585.7, size=(B, 4))
+    for j in range(4):
+        sel = k > j
+        Fy[np.nonzero(sel)[0], avail[order[sel, j]] - 1] = vals[sel, j]
+    if inertia == "uniform":
+        I = np.full((B, N_ELEM), 0.5)
+    elif inertia == "trajectory":
+        I = np.exp(rng.uniform(np.log(3e-3), np.log(0.75), size=(B, N_ELEM)))
+    else:
+        I = np.exp(rng.uniform(np.log(1e-8), np.log(0.5), size=(B, N_ELEM)))
+    t = lambda a, dt=torch.float64: torch.as_tensor(a, dtype=dt, device=device)  # noqa: E731
+    return dict(x=t(np.linspace(0.0, 200.0, N)), E=t(200e9), I=t(I), fix=t(fix, torch.uint8), Fy=t(Fy), wy=t(-1000.0))
+
+
+def cpu_baseline(B_hint):
+    """Oracle (plain-C port, OpenMP over beams) on the host cores, bounded sample (~10-20 s)."""
+    from oracle import beam_oracle as bo
+    from oracle import c_oracle as co
+
+    cores = os.cpu_count() or 1
+    rng = np.random.default_rng(SEED)
+    x = np.linspace(0.0, 200.0, N_ELEM + 1)
+    fix = bo.reference_fix_mask()
+    nb = 20000
+    I, Fy = bo.random_cases(rng, nb, inertia="trajectory")
+    co.solve_beam_batched(x, bo.E_REF, I[:2000], fix, Fy[:2000], bo.UDL_REF, n_threads=cores)  # warm-up
+    t0 = time.perf_counter()
+    co.solve_beam_batched(x, bo.E_REF, I, fix, Fy, bo.UDL_REF, n_threads=cores)
+    dt = time.perf_counter() - t0
+    reps = int(max(1, min(200, 12.0 / max(dt, 1e-4))))
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        co.solve_beam_batched(x, bo.E_REF, I, fix, Fy, bo.UDL_REF, n_threads=cores)
+    dt = time.perf_counter() - t0
+    return {
+        "value": nb * reps / dt,
+        "unit": "beam FE solves/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": f"{reps} x {nb} beams x {N_ELEM} elements, oracle/beam_oracle.c (band Cholesky, OpenMP static over beams), "
+                  f"{dt:.1f} s; OpenSeesPy itself unavailable (un-pinned third-party wheel)",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=10000, help="beams per step per GPU (BASELINE config 2: 10000)")
+    ap.add_argument("--tiling", type=int, default=0, help="lanes per beam (0 = library default)")
+    ap.add_argument("--inertia", default="trajectory", choices=["uniform", "trajectory", "adversarial"])
+    ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a HIP graph")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if args.gpus != world and rank == 0 and world > 1:
+        print(f"warning: --gpus {args.gpus} != WORLD_SIZE {world}", file=sys.stderr)
+
+    import openpystruct_amd as oa
+
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    B, K, W = args.batch, args.steps, args.warmup
+    inp = synth_inputs(B, rank, dev, args.inertia)
+    out = oa.beam_solve(**inp, tiling=args.tiling)     # allocates result buffers once
+    torch.cuda.synchronize()
+
+    def step():
+        oa.beam_solve(**inp, tiling=args.tiling, out=out)
+
+    stream = torch.cuda.Stream(device=dev)
+    graph = None
+    with torch.cuda.stream(stream):
+        for _ in range(W):
+            step()
+        stream.synchronize()
+        if not args.no_graph:
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=stream):
+                for _ in range(K):
+                    step()
+            graph.replay()   # untimed: instantiate + first replay
+            stream.synchronize()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    e0 = torch.cuda.Event(enable_timing=True)
+    e1 = torch.cuda.Event(enable_timing=True)
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    with torch.cuda.stream(stream):
+        e0.record(stream)
+        if graph is not None:
+            graph.replay()
+        else:
+            for _ in range(K):
+                step()
+        e1.record(stream)
+    torch.cuda.synchronize()
+    barrier()
+    wall = time.perf_counter() - t0
+    dev_ms = e0.elapsed_time(e1)                 # HIP events on the launch stream
+    assert int(out.status.abs().sum()) == 0
+
+    if world > 1:
+        tt = torch.tensor([wall, dev_ms], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        wall, dev_ms = float(tt[0]), float(tt[1])
+
+    if rank == 0:
+        kernel_ms = dev_ms / K
+        achieved = BYTES_PER_SOLVE * B / (kernel_ms * 1e-3) / 1e9
+        rec = {
+            "metric": "beam FE solves/s (100-elem, batched)",
+            "value": world * B * K / wall,
+            "unit": "beam FE solves/s",
+            "n_gpus": world,
+            "steps": K,
+            "warmup": W,
+            "ms_per_step": wall * 1e3 / K,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": f"BASELINE config 2: {B} beams x {N_ELEM} elements per GPU per step, fixed 5-roller bridge, "
+                            f"1-4 point loads + UDL, inertia={args.inertia}, shared geometry (4925 B/solve)",
+                "beams_per_step_per_gpu": B,
+                "elements": N_ELEM,
+                "kernel": oa.kernel_name(B, N_ELEM, args.tiling),
+                "launch": "eager" if graph is None else f"one HIP graph of {K} kernel nodes",
+                "parallelism": f"independent shards x{world}, no data-path collective",
+            },
+            "roofline": {
+                "bound": "hbm",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None,
+                "kernel_us": kernel_ms * 1e3,
+                "bytes_per_launch": BYTES_PER_SOLVE * B,
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            rec["cpu_baseline"] = cpu_baseline(B)
+        print(json.dumps(rec))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

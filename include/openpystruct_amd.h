@@ -1,0 +1,95 @@
+/* openpystruct_amd -- C ABI of the MI355X-native batched beam FE solve.
+ *
+ * This is the drop-in boundary of the hot path.  The reference has no FFI of its own for
+ * it: the boundary it crosses is the `openseespy.opensees` command API that
+ * `setup_model` + `generate_sample` drive, one case at a time
+ * (/root/reference/OpenPyStruct_BeamOpt_training_SingleCore.py):
+ *
+ *   ops.wipe / model / node / fix / geomTransf / element('elasticBeamColumn') /
+ *   timeSeries / pattern / load / eleLoad('-beamUniform')            :93-117   (model build)
+ *   ops.system('BandSPD') / numberer / constraints('Plain') / integrator / algorithm /
+ *   ops.analysis('Static') ; ops.analyze(1)                          :120-124, :180-182
+ *   ops.eleResponse(e,'forces')[1], [2]                              :189-190
+ *   ops.nodeDisp(n, 2), ops.nodeDisp(n, 3)                           :224-232
+ *
+ * One call of `ops_beam_solve_batched_f64` replaces that whole command sequence for B
+ * independent cases.  All pointers are DEVICE pointers owned by the caller; nothing is
+ * allocated, copied or synchronised inside; the work is enqueued on `stream`
+ * (a hipStream_t passed as void*; NULL = the default stream).
+ *
+ * Binding examples (ctypes / cgo / JNI): INTEGRATION.md.
+ */
+#ifndef OPENPYSTRUCT_AMD_H
+#define OPENPYSTRUCT_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OPS_AMD_ABI_VERSION 1
+
+/* return codes of the launch functions (per-beam results are in `status`) */
+#define OPS_AMD_OK 0
+#define OPS_AMD_ERR_INVALID_ARG 1   /* null pointer, B < 0, Ne out of range, bad stride */
+#define OPS_AMD_ERR_UNSUPPORTED 2   /* Ne larger than the largest compiled tiling */
+#define OPS_AMD_ERR_LAUNCH 3        /* HIP reported a launch error (see ops_amd_last_error) */
+
+/* fix[] bits per node -- `ops.fix(node, fx, fy, rz)` (SingleCore.py:100-102).  The x
+ * translation decouples from bending on a straight horizontal beam and is ignored. */
+#define OPS_AMD_FIX_UY 1u
+#define OPS_AMD_FIX_RZ 2u
+
+/* Batched static solve of B straight Euler-Bernoulli beams with Ne elements (N = Ne+1 nodes).
+ *
+ * Replaces, per beam: setup_model (SingleCore.py:89-124) + analysis/analyze (:180-182) +
+ * 2*Ne eleResponse calls (:189-190) + 2*N nodeDisp calls (:224-232).
+ *
+ * Batch strides are in ELEMENTS of the array's type; a stride of 0 means "one value /
+ * one row shared by every beam".
+ *
+ *   x      [N] (x_bstride 0) or [B,N]     node coordinates along the beam   (`ops.node`)
+ *   E      scalar (E_bstride 0) or [B,Ne] Young's modulus per element       (`ops.element` arg E)
+ *   I      [B,Ne]  (I_bstride >= Ne)      second moment of area per element (`ops.element` arg Iz)
+ *   fix    [N] (fix_bstride 0) or [B,N]   OPS_AMD_FIX_* bits per node       (`ops.fix`)
+ *   Fy     [B,N]   (Fy_bstride >= N)      nodal transverse point loads      (`ops.load(node,0,F,0)`)
+ *   wy     scalar (wy_bstride 0) or [B,Ne] transverse UDL per element       (`ops.eleLoad -beamUniform Wy`)
+ *
+ * Outputs (dense, row-major):
+ *   v      [B,N]   u_y per node            (`ops.nodeDisp(n, 2)`)
+ *   theta  [B,N]   theta_z per node        (`ops.nodeDisp(n, 3)`)
+ *   V      [B,Ne]  eleResponse(e,'forces')[1]  (global Fy at element node I)
+ *   M      [B,Ne]  eleResponse(e,'forces')[2]  (Mz at element node I)
+ *   status [B]     0 = solved; non-zero = stiffness matrix not positive definite
+ *                  (what `ops.analyze(1)` reports with a non-zero return,
+ *                  MultiCore.py:182-186); outputs of such a beam are NaN.  May be NULL.
+ *
+ * `tiling`: 0 = choose from B and Ne; otherwise lanes-per-beam P in {8, 16, 32, 64}
+ * (64 = one wavefront per beam).  Returns OPS_AMD_OK or an OPS_AMD_ERR_* code.
+ * Never throws, never blocks.
+ */
+int ops_beam_solve_batched_f64(int B, int Ne,
+                               const double* x, long x_bstride,
+                               const double* E, long E_bstride,
+                               const double* I, long I_bstride,
+                               const uint8_t* fix, long fix_bstride,
+                               const double* Fy, long Fy_bstride,
+                               const double* wy, long wy_bstride,
+                               double* v, double* theta, double* V, double* M,
+                               int32_t* status, int tiling, void* stream);
+
+/* Largest Ne a build supports, ABI version, and the text of the last HIP error seen by
+ * this thread (empty string if none). */
+int ops_amd_max_elements(void);
+int ops_amd_abi_version(void);
+const char* ops_amd_last_error(void);
+
+/* Name of the kernel symbol a given (B, Ne, tiling) call dispatches to -- lets profilers
+ * and bench.py find the right row in a rocprofv3 kernel trace. */
+const char* ops_beam_solve_kernel_name(int B, int Ne, int tiling);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OPENPYSTRUCT_AMD_H */

@@ -1,0 +1,7 @@
+"""openpystruct_amd -- MI355X-native batched beam FE solve (the OpenPyStruct data-generation hot path).
+
+Host side in Python over a C-ABI HIP library; see DESIGN.md and INTEGRATION.md.
+"""
+from .beam import BeamSolution, beam_solve, kernel_name  # noqa: F401
+
+__all__ = ["BeamSolution", "beam_solve", "kernel_name"]

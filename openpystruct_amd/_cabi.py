@@ -1,0 +1,57 @@
+"""ctypes binding of the C ABI (include/openpystruct_amd.h).
+
+The product path has NO CPU fallback: if the HIP shared library is missing or cannot be
+loaded this module raises, loudly, instead of computing anything elsewhere.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "lib", "libopenpystruct_amd.so")
+
+# every symbol include/openpystruct_amd.h declares
+EXPORTS = (
+    "ops_beam_solve_batched_f64",
+    "ops_amd_max_elements",
+    "ops_amd_abi_version",
+    "ops_amd_last_error",
+    "ops_beam_solve_kernel_name",
+)
+
+OK, ERR_INVALID_ARG, ERR_UNSUPPORTED, ERR_LAUNCH = 0, 1, 2, 3
+FIX_UY, FIX_RZ = 1, 2
+
+_lib = None
+
+
+class ExtensionMissingError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the HIP library once; raise ExtensionMissingError if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ExtensionMissingError(
+            f"{LIB_PATH} not found: the HIP extension is not built. Run `python -m openpystruct_amd.build` "
+            "(needs hipcc). openpystruct_amd has no CPU fallback for the beam solve."
+        )
+    try:
+        lib = ctypes.CDLL(LIB_PATH)
+    except OSError as e:  # pragma: no cover - depends on the machine
+        raise ExtensionMissingError(f"cannot load {LIB_PATH}: {e}") from e
+    vp, lg, it = ctypes.c_void_p, ctypes.c_long, ctypes.c_int
+    f = lib.ops_beam_solve_batched_f64
+    f.restype = it
+    f.argtypes = [it, it, vp, lg, vp, lg, vp, lg, vp, lg, vp, lg, vp, lg, vp, vp, vp, vp, vp, it, vp]
+    lib.ops_amd_max_elements.restype = it
+    lib.ops_amd_abi_version.restype = it
+    lib.ops_amd_last_error.restype = ctypes.c_char_p
+    lib.ops_beam_solve_kernel_name.restype = ctypes.c_char_p
+    lib.ops_beam_solve_kernel_name.argtypes = [it, it, it]
+    _lib = lib
+    return lib

@@ -1,0 +1,308 @@
+// Batched Euler-Bernoulli beam FE solve for gfx950 (MI355X): assembly, Dirichlet handling,
+// block-tridiagonal Cholesky solve and end-force recovery fused in one kernel.
+//
+// Replaces, for B beams per launch, the per-case command sequence of the reference's
+// `setup_model` + `ops.analyze(1)` + `ops.eleResponse` + `ops.nodeDisp`
+// (/root/reference/OpenPyStruct_BeamOpt_training_SingleCore.py:89-124, :180-190, :224-232).
+// C ABI: include/openpystruct_amd.h.  Arithmetic: beam_math.hpp.  Design: DESIGN.md.
+//
+// Mapping: one 64-lane wavefront per workgroup; P lanes co-operate on one beam
+// (P = 64 is "one wavefront per beam"), each lane owning M consecutive elements whose
+// condensation state lives in its VGPRs.  The wave's inputs (I, Fy rows of its 64/P
+// consecutive beams: contiguous in HBM) are staged through LDS with coalesced loads;
+// the unit-inertia element stiffness tile entries (2E/L, 6E/L^2, 12E/L^3), 1/L and the
+// consistent UDL loads are computed once per workgroup into an LDS table; outputs go
+// back through LDS to coalesced row stores.  FP64 throughout; no MFMA (no dense
+// contraction on this path).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/openpystruct_amd.h"
+#include "beam_math.hpp"
+
+namespace opsamd {
+
+struct BeamParams {
+  int B, Ne;
+  const double* x;  long x_bs;
+  const double* E;  long E_bs;
+  const double* I;  long I_bs;
+  const uint8_t* fix; long fix_bs;
+  const double* Fy; long Fy_bs;
+  const double* wy; long wy_bs;
+  double* v; double* theta; double* V; double* M;
+  int32_t* status;
+};
+
+// lane-local view of the LDS-staged inputs (see beam_math.hpp "Acc")
+struct LdsAcc {
+  const double* t2; const double* t6; const double* t12; const double* trl; const double* tpw; const double* tmw;
+  const double* sI; const double* sF;
+  unsigned long long bits;
+  __device__ __forceinline__ double c2(int i) const { return t2[i]; }
+  __device__ __forceinline__ double c6(int i) const { return t6[i]; }
+  __device__ __forceinline__ double c12(int i) const { return t12[i]; }
+  __device__ __forceinline__ double rL(int i) const { return trl[i]; }
+  __device__ __forceinline__ double pw(int i) const { return tpw[i]; }
+  __device__ __forceinline__ double mw(int i) const { return tmw[i]; }
+  __device__ __forceinline__ double Ie(int i) const { return sI[i]; }
+  __device__ __forceinline__ double Fy(int i) const { return sF[i]; }
+  __device__ __forceinline__ unsigned long long fixbits() const { return bits; }
+};
+
+template <int M>
+struct LaneOut {
+  double* sV; double* sM;   // LDS slots of the lane's elements
+  double v[M], th[M];       // nodal results stay in registers until the element rows are stored
+  __device__ __forceinline__ void elem(int i, double Vv, double Mv) { sV[i] = Vv; sM[i] = Mv; }
+  __device__ __forceinline__ void node(int i, double vv, double tt) { v[i] = vv; th[i] = tt; }
+};
+
+__device__ __forceinline__ double lane_get(double val, int src, bool valid) {
+  const double r = __shfl(val, src, 64);
+  return valid ? r : 0.0;
+}
+__device__ __forceinline__ Sym2 lane_get(const Sym2& s, int src, bool ok) {
+  return Sym2{lane_get(s.a, src, ok), lane_get(s.b, src, ok), lane_get(s.c, src, ok)};
+}
+__device__ __forceinline__ Mat2 lane_get(const Mat2& m, int src, bool ok) {
+  return Mat2{lane_get(m.a, src, ok), lane_get(m.b, src, ok), lane_get(m.c, src, ok), lane_get(m.d, src, ok)};
+}
+__device__ __forceinline__ Vec2 lane_get(const Vec2& u, int src, bool ok) {
+  return Vec2{lane_get(u.x, src, ok), lane_get(u.y, src, ok)};
+}
+
+// SHARED: x, E and wy are the same for every beam (strides 0): one LDS table per workgroup.
+template <int P, int M, bool SHARED>
+__global__ __launch_bounds__(64) void beam_solve_kernel(const BeamParams p) {
+  constexpr int BPW = 64 / P;       // beams per wavefront
+  constexpr int PM = P * M;         // padded nodes per beam (>= N)
+  constexpr int TG = SHARED ? 1 : BPW;
+  __shared__ double s_tab[6][TG][PM];
+  __shared__ double s_a[BPW][PM];   // I      -> M  -> theta
+  __shared__ double s_b[BPW][PM];   // Fy     -> V  -> v
+  __shared__ uint8_t s_fix[BPW][PM + 8];
+  __shared__ int s_bad[BPW];
+
+  const int lane = threadIdx.x;
+  const int Ne = p.Ne, N = p.Ne + 1;
+  const long beam0 = (long)blockIdx.x * BPW;
+
+  // ---- stage 0: element table (unit-inertia stiffness tile entries, 1/L, UDL loads) ----
+  for (int idx = lane; idx < TG * PM; idx += 64) {
+    const int tb = idx / PM, e = idx - tb * PM;
+    long bb = beam0 + tb;
+    if (bb >= p.B) bb = p.B - 1;
+    double c2 = 0.0, c6 = 0.0, c12 = 0.0, rl = 0.0, pw = 0.0, mw = 0.0;
+    if (e < Ne) {
+      const double* xb = p.x + bb * p.x_bs;
+      const double L = xb[e + 1] - xb[e];
+      const double Ee = p.E_bs ? p.E[bb * p.E_bs + e] : p.E[0];
+      const double w = p.wy_bs ? p.wy[bb * p.wy_bs + e] : p.wy[0];
+      rl = fast_rcp(L);
+      c2 = 2.0 * Ee * rl;
+      c6 = 3.0 * c2 * rl;
+      c12 = 2.0 * c6 * rl;
+      pw = 0.5 * w * L;
+      mw = pw * L * (1.0 / 6.0);
+    }
+    s_tab[0][tb][e] = c2;  s_tab[1][tb][e] = c6;  s_tab[2][tb][e] = c12;
+    s_tab[3][tb][e] = rl;  s_tab[4][tb][e] = pw;  s_tab[5][tb][e] = mw;
+  }
+  // ---- stage 1: coalesced row loads of I, Fy, fix into LDS (zero / fixed padding) ----
+#pragma unroll
+  for (int b = 0; b < BPW; ++b) {
+    const long bb = beam0 + b;
+    const bool live = bb < p.B;
+    const double* Ib = p.I + (live ? bb : 0) * p.I_bs;
+    const double* Fb = p.Fy + (live ? bb : 0) * p.Fy_bs;
+    const uint8_t* fb = p.fix + (live ? bb : 0) * p.fix_bs;
+    for (int e = lane; e < PM; e += 64) {
+      s_a[b][e] = (live && e < Ne) ? Ib[e] : 0.0;
+      s_b[b][e] = (live && e < N) ? Fb[e] : 0.0;
+    }
+    for (int e = lane; e < PM + 8; e += 64) s_fix[b][e] = (live && e < N) ? (uint8_t)(fb[e] & 3) : (uint8_t)3;
+  }
+  if (lane < BPW) s_bad[lane] = 0;
+  __syncthreads();
+
+  // ---- stage 2: per-lane condensation of the segment interior ----
+  const int g = lane / P, j = lane - g * P, e0 = j * M;
+  LdsAcc acc;
+  {
+    const int tb = SHARED ? 0 : g;
+    acc.t2 = &s_tab[0][tb][e0];  acc.t6 = &s_tab[1][tb][e0];  acc.t12 = &s_tab[2][tb][e0];
+    acc.trl = &s_tab[3][tb][e0]; acc.tpw = &s_tab[4][tb][e0]; acc.tmw = &s_tab[5][tb][e0];
+    acc.sI = &s_a[g][e0];
+    acc.sF = &s_b[g][e0];
+    unsigned long long bits = 0;
+#pragma unroll
+    for (int i = 0; i <= M; ++i) bits |= (unsigned long long)s_fix[g][e0 + i] << (2 * i);
+    acc.bits = bits;
+  }
+  int bad = 0;
+  SegState<M> st;
+  seg_condense<M>(st, acc, bad);
+
+  // ---- stage 3: interface system over the P lanes of the beam, parallel cyclic reduction ----
+  IfaceRow row;
+  {
+    const bool has_prev = j > 0;
+    const Sym2 pc = lane_get(st.Scc, lane - 1, has_prev);
+    const Vec2 pg = lane_get(st.gc, lane - 1, has_prev);
+    const Mat2 pb = lane_get(st.SLc, lane - 1, has_prev);
+    row = make_row<M>(st, pc, pg, pb, acc.bits);
+  }
+#pragma unroll
+  for (int s = 1; s < P; s *= 2) {
+    const Sym2 G = inv_spd(row.D, bad);
+    const bool okm = j >= s, okp = j + s < P;
+    const Sym2 Gm = lane_get(G, lane - s, okm);
+    const Mat2 Am = lane_get(row.Alow, lane - s, okm);
+    const Vec2 fm = lane_get(row.f, lane - s, okm);
+    const Sym2 Gp = lane_get(G, lane + s, okp);
+    const Mat2 Cp = lane_get(row.Cup, lane + s, okp);
+    const Vec2 fp = lane_get(row.f, lane + s, okp);
+    pcr_step(row, Gm, Am, fm, Gp, Cp, fp);
+  }
+  const Vec2 uL = mul(inv_spd(row.D, bad), row.f);
+  const Vec2 uR = lane_get(uL, lane + 1, j + 1 < P);
+
+  // ---- stage 4: back substitution + end forces; element rows out first ----
+  LaneOut<M> out;
+  out.sV = &s_b[g][e0];
+  out.sM = &s_a[g][e0];
+  seg_backsub<M>(st, acc, uL, uR, out);
+  if (bad) s_bad[g] = 1;
+  __syncthreads();
+
+  const double qnan = __builtin_nan("");
+#pragma unroll
+  for (int b = 0; b < BPW; ++b) {
+    const long bb = beam0 + b;
+    if (bb >= p.B) break;
+    const bool nb = s_bad[b] != 0;
+    for (int e = lane; e < Ne; e += 64) {
+      p.V[bb * Ne + e] = nb ? qnan : s_b[b][e];
+      p.M[bb * Ne + e] = nb ? qnan : s_a[b][e];
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < M; ++i) {
+    s_b[g][e0 + i] = out.v[i];
+    s_a[g][e0 + i] = out.th[i];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int b = 0; b < BPW; ++b) {
+    const long bb = beam0 + b;
+    if (bb >= p.B) break;
+    const bool nb = s_bad[b] != 0;
+    for (int e = lane; e < N; e += 64) {
+      p.v[bb * N + e] = nb ? qnan : s_b[b][e];
+      p.theta[bb * N + e] = nb ? qnan : s_a[b][e];
+    }
+    if (lane == 0 && p.status) p.status[bb] = nb ? 1 : 0;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// host side: tiling choice + launch
+// ------------------------------------------------------------------------------------------
+struct Tiling { int P, M; const char* name_shared; const char* name_general; };
+
+// every compiled (P, M); a tiling serves Ne with Ne + 1 <= P * M
+static const Tiling kTilings[] = {
+    {8, 13, "beam_solve_kernel<8, 13, true>", "beam_solve_kernel<8, 13, false>"},
+    {16, 7, "beam_solve_kernel<16, 7, true>", "beam_solve_kernel<16, 7, false>"},
+    {32, 4, "beam_solve_kernel<32, 4, true>", "beam_solve_kernel<32, 4, false>"},
+    {64, 2, "beam_solve_kernel<64, 2, true>", "beam_solve_kernel<64, 2, false>"},
+    {64, 4, "beam_solve_kernel<64, 4, true>", "beam_solve_kernel<64, 4, false>"},
+    {64, 8, "beam_solve_kernel<64, 8, true>", "beam_solve_kernel<64, 8, false>"},
+    {64, 16, "beam_solve_kernel<64, 16, true>", "beam_solve_kernel<64, 16, false>"},
+};
+static const int kNumTilings = sizeof(kTilings) / sizeof(kTilings[0]);
+
+static const Tiling* choose_tiling(int B, int Ne, int tiling) {
+  const int N = Ne + 1;
+  if (tiling != 0) {
+    for (int t = 0; t < kNumTilings; ++t)
+      if (kTilings[t].P == tiling && kTilings[t].P * kTilings[t].M >= N) return &kTilings[t];
+    return nullptr;
+  }
+  (void)B;
+  // default: 16 lanes per beam where it fits (best at the 10^4-beam batch of BASELINE config 2),
+  // otherwise the narrowest tiling that holds the beam
+  if (N <= 16 * 7) return &kTilings[1];
+  for (int t = 0; t < kNumTilings; ++t)
+    if (kTilings[t].P * kTilings[t].M >= N) return &kTilings[t];
+  return nullptr;
+}
+
+static thread_local char g_last_error[256] = {0};
+
+template <int P, int M>
+static hipError_t launch(const BeamParams& p, bool shared, hipStream_t stream) {
+  constexpr int BPW = 64 / P;
+  const unsigned grid = (unsigned)((p.B + BPW - 1) / BPW);
+  if (shared)
+    hipLaunchKernelGGL((beam_solve_kernel<P, M, true>), dim3(grid), dim3(64), 0, stream, p);
+  else
+    hipLaunchKernelGGL((beam_solve_kernel<P, M, false>), dim3(grid), dim3(64), 0, stream, p);
+  return hipGetLastError();
+}
+
+}  // namespace opsamd
+
+using namespace opsamd;
+
+extern "C" {
+
+int ops_amd_abi_version(void) { return OPS_AMD_ABI_VERSION; }
+int ops_amd_max_elements(void) { return 64 * 16 - 1; }
+const char* ops_amd_last_error(void) { return g_last_error; }
+
+const char* ops_beam_solve_kernel_name(int B, int Ne, int tiling) {
+  const Tiling* t = choose_tiling(B, Ne, tiling);
+  return t ? t->name_shared : "";
+}
+
+int ops_beam_solve_batched_f64(int B, int Ne, const double* x, long x_bstride, const double* E, long E_bstride,
+                               const double* I, long I_bstride, const uint8_t* fix, long fix_bstride,
+                               const double* Fy, long Fy_bstride, const double* wy, long wy_bstride, double* v,
+                               double* theta, double* V, double* M, int32_t* status, int tiling, void* stream) {
+  if (B < 0 || Ne < 1) return OPS_AMD_ERR_INVALID_ARG;
+  if (B == 0) return OPS_AMD_OK;
+  if (!x || !E || !I || !fix || !Fy || !wy || !v || !theta || !V || !M) return OPS_AMD_ERR_INVALID_ARG;
+  if (I_bstride < Ne || Fy_bstride < Ne + 1) return OPS_AMD_ERR_INVALID_ARG;
+  if ((x_bstride != 0 && x_bstride < Ne + 1) || (fix_bstride != 0 && fix_bstride < Ne + 1) ||
+      (E_bstride != 0 && E_bstride < Ne) || (wy_bstride != 0 && wy_bstride < Ne))
+    return OPS_AMD_ERR_INVALID_ARG;
+  if (Ne > ops_amd_max_elements()) return OPS_AMD_ERR_UNSUPPORTED;
+  const Tiling* t = choose_tiling(B, Ne, tiling);
+  if (!t) return tiling ? OPS_AMD_ERR_INVALID_ARG : OPS_AMD_ERR_UNSUPPORTED;
+
+  BeamParams p{B, Ne, x, x_bstride, E, E_bstride, I, I_bstride, fix, fix_bstride, Fy, Fy_bstride,
+               wy, wy_bstride, v, theta, V, M, status};
+  const bool shared = (x_bstride == 0 && E_bstride == 0 && wy_bstride == 0);
+  hipStream_t s = (hipStream_t)stream;
+  hipError_t err = hipSuccess;
+  if (t->P == 8 && t->M == 13) err = launch<8, 13>(p, shared, s);
+  else if (t->P == 16 && t->M == 7) err = launch<16, 7>(p, shared, s);
+  else if (t->P == 32 && t->M == 4) err = launch<32, 4>(p, shared, s);
+  else if (t->P == 64 && t->M == 2) err = launch<64, 2>(p, shared, s);
+  else if (t->P == 64 && t->M == 4) err = launch<64, 4>(p, shared, s);
+  else if (t->P == 64 && t->M == 8) err = launch<64, 8>(p, shared, s);
+  else if (t->P == 64 && t->M == 16) err = launch<64, 16>(p, shared, s);
+  if (err != hipSuccess) {
+    const char* msg = hipGetErrorString(err);
+    int k = 0;
+    for (; msg && msg[k] && k < 255; ++k) g_last_error[k] = msg[k];
+    g_last_error[k] = 0;
+    return OPS_AMD_ERR_LAUNCH;
+  }
+  return OPS_AMD_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,63 @@
+"""Shared test helpers: lane-level emulator binding and comparison utilities."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TILINGS = [(8, 13), (16, 7), (32, 4), (64, 2), (64, 4), (64, 8), (64, 16)]
+_emul = None
+
+
+def emul_lib():
+    """g++ build of tests/csrc/emul_beam.cpp (the kernel's per-lane arithmetic on the CPU; test code only)."""
+    global _emul
+    if _emul is None:
+        src = os.path.join(ROOT, "tests", "csrc", "emul_beam.cpp")
+        hdr = os.path.join(ROOT, "openpystruct_amd", "csrc", "beam_math.hpp")
+        so = os.path.join(ROOT, "tests", "csrc", "libemul_beam.so")
+        if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+            subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-o", so, src])
+        _emul = ctypes.CDLL(so)
+        f = _emul.emul_beam_solve_batched_f64
+        f.restype = ctypes.c_int
+        vp, lg = ctypes.c_void_p, ctypes.c_long
+        f.argtypes = [ctypes.c_int] * 4 + [vp, lg] * 6 + [vp] * 5
+    return _emul
+
+
+def _p(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def emul_solve(P, M, x, E, I, fix, Fy, wy):
+    I = np.ascontiguousarray(I, dtype=np.float64)
+    B, Ne = I.shape
+    N = Ne + 1
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    fix = np.ascontiguousarray(fix, dtype=np.uint8)
+    Fy = np.ascontiguousarray(Fy, dtype=np.float64)
+    E = np.ascontiguousarray(np.atleast_1d(np.asarray(E, dtype=np.float64)))
+    wy = np.ascontiguousarray(np.atleast_1d(np.asarray(wy, dtype=np.float64)))
+    v = np.empty((B, N)); th = np.empty((B, N)); V = np.empty((B, Ne)); M_ = np.empty((B, Ne))
+    st = np.empty(B, dtype=np.int32)
+    rc = emul_lib().emul_beam_solve_batched_f64(
+        P, M, B, Ne, _p(x), N if x.ndim == 2 else 0, _p(E), Ne if E.ndim == 2 else 0, _p(I), Ne,
+        _p(fix), N if fix.ndim == 2 else 0, _p(Fy), N, _p(wy), Ne if wy.ndim == 2 else 0,
+        _p(v), _p(th), _p(V), _p(M_), _p(st))
+    assert rc == 0, rc
+    return v, th, V, M_, st
+
+
+def relerr(a, b):
+    """max |a-b| / max |b| per beam (row), worst row."""
+    a = np.asarray(a); b = np.asarray(b)
+    scale = np.abs(b).max(axis=-1, keepdims=True)
+    scale = np.where(scale > 0, scale, 1.0)
+    return float((np.abs(a - b) / scale).max())
+
+
+def load_golden(path):
+    z = np.load(path)
+    return {k: z[k] for k in z.files}

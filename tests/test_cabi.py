@@ -1,0 +1,64 @@
+"""The C-ABI shared library loads on a machine without a GPU and exports every symbol
+include/openpystruct_amd.h declares (no compute calls here)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from openpystruct_amd import _cabi, build
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    build.build()
+    return _cabi.load()
+
+
+def test_header_symbols_are_exported(lib):
+    hdr = open(os.path.join(ROOT, "include", "openpystruct_amd.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(ops_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(_cabi.EXPORTS)
+    for name in declared:
+        assert getattr(lib, name) is not None
+
+
+def test_introspection_calls(lib):
+    assert lib.ops_amd_abi_version() == 1
+    assert lib.ops_amd_max_elements() >= 100
+    assert b"beam_solve_kernel" in lib.ops_beam_solve_kernel_name(10000, 100, 0)
+    assert lib.ops_beam_solve_kernel_name(10, 5000, 0) == b""
+
+
+def test_argument_validation_without_gpu(lib):
+    # invalid arguments are rejected before any HIP call
+    z = ctypes.c_void_p(0)
+    rc = lib.ops_beam_solve_batched_f64(4, 100, z, 0, z, 0, z, 100, z, 0, z, 101, z, 0, z, z, z, z, z, 0, z)
+    assert rc == _cabi.ERR_INVALID_ARG
+    rc = lib.ops_beam_solve_batched_f64(-1, 100, z, 0, z, 0, z, 100, z, 0, z, 101, z, 0, z, z, z, z, z, 0, z)
+    assert rc == _cabi.ERR_INVALID_ARG
+    rc = lib.ops_beam_solve_batched_f64(0, 100, z, 0, z, 0, z, 100, z, 0, z, 101, z, 0, z, z, z, z, z, 0, z)
+    assert rc == _cabi.OK   # empty batch is a no-op
+
+
+def test_no_cpu_fallback():
+    import torch
+
+    import openpystruct_amd as oa
+
+    I = torch.full((2, 10), 0.1, dtype=torch.float64)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        oa.beam_solve(torch.linspace(0, 1, 11, dtype=torch.float64), 2e11, I, torch.zeros(11, dtype=torch.uint8),
+                      torch.zeros(2, 11, dtype=torch.float64), 0.0)
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "openpystruct_amd")
+    for dp, _, fns in os.walk(pkg):
+        for fn in fns:
+            if fn.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
+                src = open(os.path.join(dp, fn)).read()
+                assert "import oracle" not in src and "from oracle" not in src and "oracle/" not in src, fn

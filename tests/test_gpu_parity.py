@@ -1,0 +1,165 @@
+"""GPU parity tests proper: the HIP kernel, called through the C ABI, against the oracle on the
+same seeded inputs, against the committed golden fixtures, and -- at BASELINE.json's full size
+(10 000 beams x 100 elements) -- through size-independent properties of the linear FE problem.
+
+Tolerances (relative to each beam's max |.|): north_star asks 1e-6 on displacements; the tests
+hold the kernel to the oracle's own eps*cond level, which is far tighter for the reference's
+inertia ranges."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+from oracle import beam_oracle as bo  # noqa: E402
+from oracle import c_oracle as co  # noqa: E402
+from tests.helpers import TILINGS, load_golden, relerr  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def oa():
+    if not torch.cuda.is_available():
+        pytest.fail("no GPU visible: -m gpu tests must run on the MI355X box")
+    import openpystruct_amd as oa_
+    from openpystruct_amd import _cabi
+
+    _cabi.load()   # fail loudly if the HIP extension is missing
+    return oa_
+
+
+def _gpu(a, dtype=torch.float64):
+    return torch.as_tensor(np.ascontiguousarray(a), dtype=dtype, device="cuda")
+
+
+def _solve(oa, x, E, I, fix, Fy, wy, tiling=0):
+    out = oa.beam_solve(_gpu(x), _gpu(E), _gpu(I), _gpu(fix, torch.uint8), _gpu(Fy), _gpu(wy), tiling=tiling)
+    torch.cuda.synchronize()
+    return [t.cpu().numpy() for t in out]
+
+
+P_OF_100 = sorted({p for p, m in TILINGS if p * m >= 101})
+
+
+@pytest.mark.parametrize("tiling", [0] + P_OF_100)
+@pytest.mark.parametrize("name,tol_u,tol_f", [("bridge_uniform", 1e-10, 1e-9), ("bridge_trajectory", 1e-8, 2e-6)])
+def test_golden_fixed_bridge(oa, golden_dir, tiling, name, tol_u, tol_f):
+    g = load_golden(os.path.join(golden_dir, name + ".npz"))
+    v, th, V, M, st = _solve(oa, g["x"], g["E"], g["I"], g["fix"], g["Fy"], g["wy"], tiling)
+    assert (st == 0).all()
+    assert relerr(v, g["v"]) < tol_u and relerr(th, g["theta"]) < tol_u
+    assert relerr(V, g["V"]) < tol_f and relerr(M, g["M"]) < tol_f
+
+
+def test_golden_random_bridge_per_beam_geometry(oa, golden_dir):
+    g = load_golden(os.path.join(golden_dir, "random_bridge.npz"))
+    v, th, V, M, st = _solve(oa, g["x"], g["E"], g["I"], g["fix"], g["Fy"], g["wy"])
+    assert (st == 0).all()
+    assert relerr(v, g["v"]) < 1e-7 and relerr(th, g["theta"]) < 1e-7
+    assert relerr(V, g["V"]) < 1e-5 and relerr(M, g["M"]) < 1e-5
+
+
+def test_golden_adversarial_displacements(oa, golden_dir):
+    # cond(K_ff) up to ~3e8: displacements still inside the 1e-6 contract's cond-aware neighbourhood
+    g = load_golden(os.path.join(golden_dir, "bridge_adversarial.npz"))
+    v, th, V, M, st = _solve(oa, g["x"], g["E"], g["I"], g["fix"], g["Fy"], g["wy"])
+    assert (st == 0).all()
+    assert relerr(v, g["v"]) < 1e-4 and relerr(th, g["theta"]) < 1e-4
+
+
+@pytest.mark.parametrize("B", [1, 3, 4, 5, 63, 64, 65, 2000])
+def test_vs_c_oracle_seeded(oa, B):
+    rng = np.random.default_rng(1000 + B)
+    x = np.linspace(0, 200, 101)
+    fix = bo.reference_fix_mask()
+    I, Fy = bo.random_cases(rng, B, inertia="trajectory")
+    ref = co.solve_beam_batched(x, bo.E_REF, I, fix, Fy, bo.UDL_REF, n_threads=4)
+    v, th, V, M, st = _solve(oa, x, bo.E_REF, I, fix, Fy, bo.UDL_REF)
+    assert (st == 0).all() and (ref[4] == 0).all()
+    assert relerr(v, ref[0]) < 1e-8 and relerr(th, ref[1]) < 1e-8
+    assert relerr(V, ref[2]) < 2e-6 and relerr(M, ref[3]) < 2e-6
+
+
+@pytest.mark.parametrize("Ne", [1, 2, 3, 7, 13, 14, 50, 99, 103, 111, 127, 255, 511, 1023])
+def test_ragged_sizes_nonuniform_mesh(oa, Ne):
+    rng = np.random.default_rng(Ne)
+    N = Ne + 1
+    x = np.sort(rng.uniform(0, 3.0 * Ne, size=N)) + np.arange(N) * 0.5
+    fix = np.zeros(N, dtype=np.uint8); fix[0] = 1; fix[-1] = 1
+    if N > 4:
+        fix[N // 3] = 1
+    if Ne == 1:
+        fix[0] = 3
+    B = 5
+    I = np.exp(rng.uniform(np.log(1e-2), np.log(0.5), size=(B, Ne)))
+    Fy = rng.uniform(-1e5, 0, size=(B, N))
+    E = np.full((B, Ne), 2.0e11) * rng.uniform(0.5, 1.5, size=(B, Ne))     # per-element E and wy paths
+    wy = rng.uniform(-2000, 0, size=(B, Ne))
+    ref = bo.solve_beam_batched(x, E, I, fix, Fy, wy)
+    out = _solve(oa, x, E, I, fix, Fy, wy)
+    K, _ = bo.assemble_beam(x, E[0], I[0], Fy[0], wy[0])
+    free = np.ones(2 * N, dtype=bool); free[0::2] = (fix & 1) == 0; free[1::2] = (fix & 2) == 0
+    tol = max(1e-10, 2e-16 * np.linalg.cond(K[np.ix_(free, free)]))
+    assert (out[4] == 0).all()
+    assert relerr(out[0], ref[0]) < tol and relerr(out[1], ref[1]) < tol
+
+
+def test_clamped_rotation_fix_bit(oa):
+    # OPS_AMD_FIX_RZ: cantilever PL^3/3EI
+    N, L, EI, P = 41, 10.0, 2.0e7, -3.0e3
+    x = np.linspace(0, L, N)
+    fix = np.zeros(N, dtype=np.uint8); fix[0] = 3
+    Fy = np.zeros((2, N)); Fy[:, -1] = P
+    I = np.full((2, N - 1), EI / 2e11)
+    v, th, V, M, st = _solve(oa, x, 2e11, I, fix, Fy, 0.0)
+    assert v[0, -1] == pytest.approx(P * L**3 / (3 * EI), rel=1e-8)
+    assert th[0, -1] == pytest.approx(P * L**2 / (2 * EI), rel=1e-8)
+    assert M[0, 0] == pytest.approx(-P * L, rel=1e-8)
+
+
+def test_status_flags_non_spd(oa):
+    x = np.linspace(0, 10, 11)
+    fix = np.zeros(11, dtype=np.uint8); fix[0] = fix[-1] = 1
+    I = np.full((6, 10), 0.1); I[0, :] = 0.0; I[4, 4] = -0.1
+    Fy = np.zeros((6, 11)); Fy[:, 5] = -1.0
+    v, th, V, M, st = _solve(oa, x, 2e11, I, fix, Fy, 0.0)
+    assert st[0] != 0 and st[4] != 0 and (st[[1, 2, 3, 5]] == 0).all()
+    assert np.isnan(v[0]).all() and np.isnan(v[4]).all() and np.isfinite(v[[1, 2, 3, 5]]).all()
+
+
+@pytest.mark.parametrize("tiling", [0, 8, 64])
+def test_full_size_properties(oa, tiling):
+    """BASELINE config 2 size (10 000 x 100): linearity, 1/I scaling, equilibrium, permutation invariance."""
+    B = 10000
+    rng = np.random.default_rng(20250307)
+    x = np.linspace(0, 200, 101)
+    fix = bo.reference_fix_mask()
+    I, Fy = bo.random_cases(rng, B, inertia="trajectory")
+    _, Fy2 = bo.random_cases(rng, B, inertia="uniform")
+    xg, fg, Ig = _gpu(x), _gpu(fix, torch.uint8), _gpu(I)
+    Eg, wg, zg = _gpu(bo.E_REF), _gpu(bo.UDL_REF), _gpu(0.0)
+    F1, F2 = _gpu(Fy), _gpu(Fy2)
+    a = oa.beam_solve(xg, Eg, Ig, fg, F1, wg, tiling=tiling)
+    b = oa.beam_solve(xg, Eg, Ig, fg, F2, zg, tiling=tiling)
+    c = oa.beam_solve(xg, Eg, Ig, fg, F1 + F2, wg, tiling=tiling)
+    assert int(a.status.abs().sum()) == 0
+    scale = a.v.abs().amax(dim=1, keepdim=True)
+    assert float(((a.v + b.v - c.v).abs() / scale).max()) < 1e-9           # superposition
+    assert float(((a.M + b.M - c.M).abs() / a.M.abs().amax(dim=1, keepdim=True)).max()) < 1e-6
+    d = oa.beam_solve(xg, Eg, Ig * 4.0, fg, F1, wg, tiling=tiling)           # u ~ 1/I, forces unchanged
+    assert float(((a.v - 4.0 * d.v).abs() / scale).max()) < 1e-9
+    assert float(((a.V - d.V).abs() / a.V.abs().amax(dim=1, keepdim=True)).max()) < 1e-6
+    perm = torch.randperm(B, device="cuda")
+    e = oa.beam_solve(xg, Eg, Ig[perm].contiguous(), fg, F1[perm].contiguous(), wg, tiling=tiling)
+    assert torch.equal(e.v, a.v[perm]) and torch.equal(e.M, a.M[perm])     # batch position must not matter
+    # supports really are supports; global vertical equilibrium: sum of reactions = - applied load
+    assert float(a.v[:, fg.bool()].abs().max()) == 0.0
+    # shear jump across every free, unloaded node equals the UDL on one element (statics identity)
+    V = a.V
+    jump = V[:, 1:] - V[:, :-1]                     # nodal equilibrium: V_e - V_{e-1} = w L + F_node (free nodes)
+    free_inner = (fg[1:-1] == 0)
+    expect = bo.UDL_REF * 2.0 + F1[:, 1:-1]
+    err = ((jump - expect)[:, free_inner]).abs().max() / V.abs().max()
+    assert float(err) < 1e-7

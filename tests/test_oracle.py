@@ -1,0 +1,157 @@
+"""Pins the CPU oracle: closed-form Euler-Bernoulli known answers, two independent
+formulations (2-DOF dense vs OpenSees-like 3-DOF banded dpbsv), the plain-C restatement,
+equilibrium identities, and the committed golden fixtures.  (PARITY UNPINNED w.r.t. a live
+OpenSeesPy: see oracle/beam_oracle.py header.)"""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import beam_oracle as bo
+from oracle import c_oracle as co
+from tests.helpers import load_golden, relerr
+
+E = bo.E_REF
+
+
+def _ss(N=101, L=200.0, EI=1e11):
+    x = np.linspace(0, L, N)
+    fix = np.zeros(N, dtype=np.uint8)
+    fix[0] = fix[-1] = 1
+    return x, fix, np.full(N - 1, EI / E)
+
+
+def test_kat_simply_supported_udl():
+    # SURVEY Appendix A.4 sign check: w=-1000, L=200, EI=1e11
+    x, fix, I = _ss()
+    w, L, EI = -1000.0, 200.0, 1e11
+    v, th, V, M, st = bo.solve_beam_dense(x, E, I, fix, np.zeros(101), w)
+    assert st == 0
+    assert v[50] == pytest.approx(5 * w * L**4 / (384 * EI), rel=2e-8)
+    assert th[0] == pytest.approx(w * L**3 / (24 * EI), rel=2e-8)
+    assert V[0] == pytest.approx(-w * L / 2, rel=2e-8)          # +100 000: upward reaction
+    assert M[50] == pytest.approx(w * L**2 / 8, rel=2e-8)       # -5.0e6 at end I of element 51
+    assert abs(M[0]) < 1e-3
+
+
+def test_kat_simply_supported_midspan_point_load():
+    x, fix, I = _ss()
+    P, L, EI = -1.0e5, 200.0, 1e11
+    Fy = np.zeros(101); Fy[50] = P
+    v, th, V, M, st = bo.solve_beam_dense(x, E, I, fix, Fy, 0.0)
+    assert v[50] == pytest.approx(P * L**3 / (48 * EI), rel=2e-8)
+    assert th[0] == pytest.approx(P * L**2 / (16 * EI), rel=2e-8)
+    assert V[0] == pytest.approx(-P / 2, rel=2e-8)
+    assert M[50] == pytest.approx(P * L / 4, rel=2e-8)
+
+
+def test_kat_cantilever_tip_load():
+    # clamped at node 1 (u_y and theta_z fixed), tip load: PL^3/3EI, PL^2/2EI
+    N, L, EI, P = 41, 10.0, 2.0e7, -3.0e3
+    x = np.linspace(0, L, N)
+    fix = np.zeros(N, dtype=np.uint8); fix[0] = 3
+    Fy = np.zeros(N); Fy[-1] = P
+    v, th, V, M, st = bo.solve_beam_dense(x, E, np.full(N - 1, EI / E), fix, Fy, 0.0)
+    assert v[-1] == pytest.approx(P * L**3 / (3 * EI), rel=2e-8)
+    assert th[-1] == pytest.approx(P * L**2 / (2 * EI), rel=2e-8)
+    assert V[0] == pytest.approx(-P, rel=2e-8)
+    assert M[0] == pytest.approx(-P * L, rel=2e-8)   # resisting moment at the clamp (end I)
+
+
+def test_kat_propped_cantilever_udl():
+    # clamped left, roller right, UDL: R_roller = 3wL/8, max |M| at clamp = wL^2/8
+    N, L, EI, w = 65, 16.0, 5.0e8, -2.0e3
+    x = np.linspace(0, L, N)
+    fix = np.zeros(N, dtype=np.uint8); fix[0] = 3; fix[-1] = 1
+    v, th, V, M, st = bo.solve_beam_dense(x, E, np.full(N - 1, EI / E), fix, np.zeros(N), w)
+    assert V[0] == pytest.approx(-5 * w * L / 8, rel=2e-8)
+    assert M[0] == pytest.approx(-w * L**2 / 8, rel=2e-8)          # hogging at the clamp: positive at end I
+    assert th[-1] == pytest.approx(-w * L**3 / (48 * EI), rel=2e-8)
+
+
+def test_kat_two_span_continuous_udl():
+    # two equal spans l, UDL: middle reaction 10wl/8, end reactions 3wl/8, M over middle support = wl^2/8
+    N, l, EI, w = 81, 20.0, 3.0e9, -1.5e3
+    x = np.linspace(0, 2 * l, N)
+    fix = np.zeros(N, dtype=np.uint8); fix[0] = fix[40] = fix[-1] = 1
+    v, th, V, M, st = bo.solve_beam_dense(x, E, np.full(N - 1, EI / E), fix, np.zeros(N), w)
+    assert V[0] == pytest.approx(-3 * w * l / 8, rel=2e-8)
+    assert M[40] == pytest.approx(-w * l**2 / 8, rel=2e-8)   # hogging: positive at end I
+    assert th[40] == pytest.approx(0.0, abs=1e-12)
+
+
+def test_kat_overhang_tip():
+    # reference bridge probe of SURVEY Appendix E
+    x = np.linspace(0, 200, 101)
+    fix = bo.reference_fix_mask()
+    Fy = np.zeros(101); Fy[49] = -355857.0; Fy[19] = -100000.0
+    v, th, V, M, st = bo.solve_beam_dense(x, E, np.full(100, 0.5), fix, Fy, -1000.0)
+    assert v.min() == pytest.approx(-1.634e-2, rel=1e-3)
+    assert v[100] == pytest.approx(9.51e-5, rel=1e-3)
+    assert th[100] == pytest.approx(4.76e-5, rel=2e-3)
+    np.testing.assert_allclose(V[:3], [36417.18, 34417.18, 32417.18], rtol=1e-6)
+    # overhang element 100: statically determinate, V = -w*L_e... free tip
+    assert M[99] == pytest.approx(-(-1000.0) * 2.0**2 / 2, rel=1e-6)   # statically determinate overhang: M at end I = -w*a^2/2
+
+
+def test_equilibrium_and_reactions():
+    rng = np.random.default_rng(5)
+    x = np.linspace(0, 200, 101)
+    fix = bo.reference_fix_mask()
+    I, Fy = bo.random_cases(rng, 8, inertia="trajectory")
+    for b in range(8):
+        K, f = bo.assemble_beam(x, E, I[b], Fy[b], bo.UDL_REF)
+        v, th, V, M, st = bo.solve_beam_dense(x, E, I[b], fix, Fy[b], bo.UDL_REF)
+        u = np.empty(202); u[0::2] = v; u[1::2] = th
+        r = K @ u - f
+        free = np.ones(202, dtype=bool); free[0::2] = fix == 0
+        assert np.abs(r[free]).max() < 1e-6 * np.abs(f).max()
+        # reactions balance the applied load (sum Fy + UDL*L)
+        assert r[~free].sum() == pytest.approx(-(Fy[b].sum() + bo.UDL_REF * 200.0), rel=2e-8)
+
+
+@pytest.mark.parametrize("inertia,tol", [("uniform", 1e-10), ("trajectory", 2e-9)])
+def test_dense_vs_opensees_like_3dof(inertia, tol):
+    """2-DOF dense solve == 3-DOF/node banded dpbsv model with axial DOFs and Wx (296 eq, kd 5)."""
+    rng = np.random.default_rng(11)
+    x = np.linspace(0, 200, 101)
+    fix = bo.reference_fix_mask()
+    I, Fy = bo.random_cases(rng, 6, inertia=inertia)
+    for b in range(6):
+        nodes = np.nonzero(Fy[b])[0] + 1
+        d, f, st, neq, kd = bo.solve_reference_beam_3dof(x, bo.A_REF, E, I[b], bo.ROLLERS_REF, nodes, Fy[b, nodes - 1], bo.UDL_REF)
+        assert (st, neq, kd) == (0, 296, 5)
+        v, th, V, M, st2 = bo.solve_beam_dense(x, E, I[b], fix, Fy[b], bo.UDL_REF)
+        assert relerr(d[:, 1], v) < tol and relerr(d[:, 2], th) < tol
+        assert relerr(f[:, 1], V) < tol * 10 and relerr(f[:, 2], M) < tol * 10
+        # axial UDL quirk (SingleCore.py:117): Fx at node I of element 1 = -N + p0 = +w*L_total... only forces[0] changes
+        assert f[0, 0] == pytest.approx(-bo.UDL_REF * 200.0, rel=2e-8)
+
+
+@pytest.mark.parametrize("name,tol", [("bridge_uniform", 1e-10), ("bridge_trajectory", 5e-9), ("random_bridge", 5e-8)])
+def test_c_oracle_vs_golden(golden_dir, name, tol):
+    g = load_golden(os.path.join(golden_dir, name + ".npz"))
+    v, th, V, M, st = co.solve_beam_batched(g["x"], g["E"], g["I"], g["fix"], g["Fy"], g["wy"], n_threads=2)
+    assert (st == g["status"]).all() and (st == 0).all()
+    assert relerr(v, g["v"]) < tol and relerr(th, g["theta"]) < tol
+    assert relerr(V, g["V"]) < tol * 10 and relerr(M, g["M"]) < tol * 10
+
+
+def test_c_oracle_adversarial_cond_aware(golden_dir):
+    # cond(K) up to ~3e8: tolerance scaled accordingly, reported separately
+    g = load_golden(os.path.join(golden_dir, "bridge_adversarial.npz"))
+    v, th, V, M, st = co.solve_beam_batched(g["x"], g["E"], g["I"], g["fix"], g["Fy"], g["wy"])
+    assert relerr(v, g["v"]) < 1e-4 and relerr(th, g["theta"]) < 1e-4
+
+
+def test_singular_reports_status():
+    # non-positive pivot -> not SPD -> status != 0 (analyze() != 0, MultiCore.py:184).  (A pure
+    # mechanism's last pivot is only ~0 in floating point, so dpbsv cannot be relied on to flag it.)
+    x = np.linspace(0, 10, 11)
+    fix = np.zeros(11, dtype=np.uint8); fix[0] = fix[-1] = 1
+    I = np.full((3, 10), 0.1); I[0, :] = 0.0; I[1, 4] = -0.1
+    Fy = np.zeros((3, 11)); Fy[:, 5] = -1.0
+    st_np = bo.solve_beam_batched(x, E, I, fix, Fy, 0.0)[4]
+    st_c = co.solve_beam_batched(x, E, I, fix, Fy, 0.0)[4]
+    assert st_np[0] != 0 and st_np[1] != 0 and st_np[2] == 0
+    assert st_c[0] != 0 and st_c[1] != 0 and st_c[2] == 0
