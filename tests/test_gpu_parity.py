@@ -162,4 +162,4 @@ def test_full_size_properties(oa, tiling):
     free_inner = (fg[1:-1] == 0)
     expect = bo.UDL_REF * 2.0 + F1[:, 1:-1]
     err = ((jump - expect)[:, free_inner]).abs().max() / V.abs().max()
-    assert float(err) < 1e-7
+    assert float(err) < 2e-6     # element end forces: same bound as the oracle comparison
