@@ -6,11 +6,14 @@
 // lane's left boundary.  The solve is a substructured block-LDL^T (block Cholesky)
 // of the block-tridiagonal stiffness matrix (2x2 blocks: u_y, theta_z per node):
 //
-//   1. seg_condense : frontal elimination of the segment's interior nodes 1..M-1; what is
-//                     left is a 4x4 "super element" on (left, right) boundary nodes
-//   2. make_row     : the P boundary nodes form a P-row block-tridiagonal interface system
-//   3. pcr_step     : parallel cyclic reduction over the P lanes, log2(P) steps
-//   4. seg_backsub  : back substitution of the interior + element end-force recovery
+//   A. seg_condense : frontal elimination of the segment's interior nodes 1..M-1; what is
+//                     left is a 4x4 "super element" on (left, right) boundary nodes.  Only
+//                     the inverse pivot blocks (3 doubles per node) are kept.
+//   B. make_row / pcr_step : the P boundary nodes form a P-row block-tridiagonal interface
+//                     system, solved by parallel cyclic reduction over the P lanes
+//   C. seg_solve    : with both boundary displacements known the interior is a one-sided
+//                     block-Thomas solve: right-hand-side sweep (re-using the stored pivot
+//                     inverses), back substitution, element end-force recovery
 //
 // What it restates: the element, load, constraint and recovery semantics OpenSees applies
 // to the model built by the reference's `setup_model`
@@ -99,82 +102,76 @@ BEAM_HD Vec2 mul(const Sym2& s, const Vec2& u) {
 }
 
 // ---------------------------------------------------------------------------------------
-// Element terms (OpenSees ElasticBeam2d, bending part; SingleCore.py:107, :117).
-//   c2 = 2E/L, c6 = 6E/L^2, c12 = 12E/L^3 (unit-inertia stiffness tile entries, staged in
-//   LDS by the kernel), Ie = element inertia, pw = w L / 2, mw = w L^2 / 12.
-//   fa/ft, fb/fbt: 1.0 when the DOF (u_y / theta_z of node a / b) is free, else 0.0.
+// Element terms (OpenSees ElasticBeam2d, bending part; SingleCore.py:107, :117), UNMASKED:
+//   kA = 12EI/L^3, kB = 6EI/L^2, kC = 4EI/L, kD = 2EI/L from the unit-inertia tile entries
+//   c2 = 2E/L, c6 = 6E/L^2, c12 = 12E/L^3 (staged in LDS by the kernel) times Ie;
+//   k11 = [[kA, kB],[kB, kC]], k12 = [[-kA, kB],[-kB, kD]], k22 = [[kA, -kB],[-kB, kC]];
+//   consistent UDL loads (pw, mw) on node a and (pw, -mw) on node b, pw = wL/2, mw = wL^2/12.
+// Constraints are applied per NODE when the node is eliminated (mask_node / mask_cols /
+// mask_rows): fixed DOFs get an identity row/column and a zero right-hand side.
 // ---------------------------------------------------------------------------------------
-struct ElemK {
-  Sym2 k11, k22;
-  Mat2 k12;      // couples node a (rows) to node b (columns); k21 = k12^T
-  Vec2 fa, fb;   // consistent UDL loads on the free DOFs
-};
+struct ElemK { double kA, kB, kC, kD; };
 
-BEAM_HD ElemK elem_terms(double c2, double c6, double c12, double Ie, double pw, double mw,
-                         double av, double at, double bv, double bt) {
-  const double k2 = c2 * Ie, k4 = k2 + k2, k6 = c6 * Ie, k12 = c12 * Ie;
-  ElemK e;
-  e.k11 = Sym2{av * k12, (av * at) * k6, at * k4};
-  e.k22 = Sym2{bv * k12, -(bv * bt) * k6, bt * k4};
-  e.k12 = Mat2{-(av * bv) * k12, (av * bt) * k6, -(at * bv) * k6, (at * bt) * k2};
-  e.fa = Vec2{av * pw, at * mw};
-  e.fb = Vec2{bv * pw, -(bt * mw)};
-  return e;
+BEAM_HD ElemK elem_k(double c2, double c6, double c12, double Ie) {
+  const double kD = c2 * Ie;
+  return ElemK{c12 * Ie, c6 * Ie, kD + kD, kD};
 }
 
-BEAM_HD double free_flag(unsigned long long bits, int dof) {
-  return ((bits >> dof) & 1ull) ? 0.0 : 1.0;
+struct Flags { double v, t; };  // 1.0 = free, 0.0 = fixed
+BEAM_HD Flags node_flags(unsigned long long bits, int node) {
+  return Flags{((bits >> (2 * node)) & 1ull) ? 0.0 : 1.0, ((bits >> (2 * node + 1)) & 1ull) ? 0.0 : 1.0};
 }
+BEAM_HD Sym2 mask_node(const Sym2& s, const Flags& c) {  // identity on fixed DOFs
+  return Sym2{__builtin_fma(c.v, s.a, 1.0 - c.v), (c.v * c.t) * s.b, __builtin_fma(c.t, s.c, 1.0 - c.t)};
+}
+BEAM_HD Vec2 mask_vec(const Vec2& g, const Flags& c) { return Vec2{c.v * g.x, c.t * g.y}; }
+BEAM_HD Mat2 mask_cols(const Mat2& m, const Flags& c) { return Mat2{m.a * c.v, m.b * c.t, m.c * c.v, m.d * c.t}; }
+BEAM_HD Mat2 mask_rows(const Mat2& m, const Flags& c) { return Mat2{m.a * c.v, m.b * c.v, m.c * c.t, m.d * c.t}; }
 
-// State a lane keeps between condensation and back substitution.
+// State a lane keeps across the phases.
 template <int M>
 struct SegState {
-  // interior nodes 1..M-1 (index 0 unused)
-  Sym2 Ginv[M];   // inverse pivot block
-  Mat2 SLi[M];    // coupling (left boundary rows, node i columns) at elimination time
-  Vec2 g[M];      // right-hand side at elimination time
-  // condensed super element on (left, right) boundary
+  Sym2 Ginv[M];   // inverse pivot blocks of interior nodes 1..M-1 (index 0 unused)
+  // condensed super element on (left, right) boundary nodes, not yet masked for either
   Sym2 SLL, Scc;
   Mat2 SLc;
   Vec2 gL, gc;
 };
 
 // Acc supplies the lane's inputs by LOCAL index:
-//   c2(i), c6(i), c12(i), Ie(i), pw(i), mw(i)   element i in [0, M)
-//   Fy(i)                                        nodal load at local node i in [0, M)
+//   c2(i), c6(i), c12(i), rL(i), Ie(i), pw(i), mw(i)   element i in [0, M)
+//   Fy(i)                                                nodal load at local node i in [0, M)
 //   fixbits()   bit 2i = u_y of local node i fixed, bit 2i+1 = theta_z fixed, i in [0, M]
 template <int M, class Acc>
 BEAM_HD void seg_condense(SegState<M>& s, const Acc& acc, int& bad) {
   const unsigned long long fb = acc.fixbits();
   {
-    const double av = free_flag(fb, 0), at = free_flag(fb, 1);
-    const double bv = free_flag(fb, 2), bt = free_flag(fb, 3);
-    const ElemK e = elem_terms(acc.c2(0), acc.c6(0), acc.c12(0), acc.Ie(0), acc.pw(0), acc.mw(0), av, at, bv, bt);
-    s.SLL = e.k11;
-    s.SLc = e.k12;
-    s.Scc = e.k22;
-    s.gL = Vec2{__builtin_fma(av, acc.Fy(0), e.fa.x), e.fa.y};
-    s.gc = e.fb;
+    const ElemK k = elem_k(acc.c2(0), acc.c6(0), acc.c12(0), acc.Ie(0));
+    s.SLL = Sym2{k.kA, k.kB, k.kC};
+    s.SLc = Mat2{-k.kA, k.kB, -k.kB, k.kD};
+    s.Scc = Sym2{k.kA, -k.kB, k.kC};
+    s.gL = Vec2{acc.pw(0) + acc.Fy(0), acc.mw(0)};
+    s.gc = Vec2{acc.pw(0), -acc.mw(0)};
   }
 #pragma unroll
   for (int i = 1; i < M; ++i) {
-    const double av = free_flag(fb, 2 * i), at = free_flag(fb, 2 * i + 1);
-    const double bv = free_flag(fb, 2 * i + 2), bt = free_flag(fb, 2 * i + 3);
-    const ElemK e = elem_terms(acc.c2(i), acc.c6(i), acc.c12(i), acc.Ie(i), acc.pw(i), acc.mw(i), av, at, bv, bt);
-    // node i is complete: left element (already in Scc/gc) + right element + identity for fixed DOFs
-    const Sym2 Sii{s.Scc.a + e.k11.a + (1.0 - av), s.Scc.b + e.k11.b, s.Scc.c + e.k11.c + (1.0 - at)};
-    const Vec2 gi{s.gc.x + __builtin_fma(av, acc.Fy(i), e.fa.x), s.gc.y + e.fa.y};
+    const Flags c = node_flags(fb, i);
+    const ElemK k = elem_k(acc.c2(i), acc.c6(i), acc.c12(i), acc.Ie(i));
+    const double pw = acc.pw(i), mw = acc.mw(i);
+    // node i is complete: left element (in Scc/gc) + right element; then constrain it
+    const Sym2 Sii = mask_node(Sym2{s.Scc.a + k.kA, s.Scc.b + k.kB, s.Scc.c + k.kC}, c);
+    const Vec2 gi = mask_vec(Vec2{s.gc.x + pw + acc.Fy(i), s.gc.y + mw}, c);
+    const Mat2 SLi = mask_cols(s.SLc, c);                               // left boundary <-> node i
+    const Mat2 Kr = mask_rows(Mat2{-k.kA, k.kB, -k.kB, k.kD}, c);       // node i <-> node i+1
     const Sym2 G = inv_spd(Sii, bad);
     s.Ginv[i] = G;
-    s.SLi[i] = s.SLc;
-    s.g[i] = gi;
-    const Mat2 Pm = mul(s.SLc, G);      // S_Li * Sii^-1
-    const Mat2 Qm = mulT(e.k12, G);     // k21 * Sii^-1
-    s.SLL = sub_mulT(s.SLL, Pm, s.SLc);
+    const Mat2 Pm = mul(SLi, G);     // S_Li * Sii^-1
+    const Mat2 Qm = mulT(Kr, G);     // K_{i+1,i} * Sii^-1
+    s.SLL = sub_mulT(s.SLL, Pm, SLi);
     s.gL = sub_mul(s.gL, Pm, gi);
-    s.SLc = neg_mul(Pm, e.k12);
-    s.Scc = sub_mul(e.k22, Qm, e.k12);
-    s.gc = sub_mul(e.fb, Qm, gi);
+    s.SLc = neg_mul(Pm, Kr);
+    s.Scc = sub_mul(Sym2{k.kA, -k.kB, k.kC}, Qm, Kr);
+    s.gc = sub_mul(Vec2{pw, -mw}, Qm, gi);
   }
 }
 
@@ -185,21 +182,30 @@ struct IfaceRow {
   Vec2 f;
 };
 
-// prevC, prevg, prevB: Scc, gc, SLc of lane j-1 (all zero for lane 0); fixbits of own local node 0.
+// The lane's own coupling to the next boundary node, constrained on both sides; lane j+1
+// receives it (transposed) as its Alow.
 template <int M>
-BEAM_HD IfaceRow make_row(const SegState<M>& s, const Sym2& prevC, const Vec2& prevg, const Mat2& prevB,
-                          unsigned long long fixbits) {
-  const double av = free_flag(fixbits, 0), at = free_flag(fixbits, 1);
+BEAM_HD Mat2 masked_cup(const SegState<M>& s, unsigned long long fixbits) {
+  return mask_cols(mask_rows(s.SLc, node_flags(fixbits, 0)), node_flags(fixbits, M));
+}
+
+// prevC, prevg: Scc, gc of lane j-1; prevCup: masked_cup of lane j-1 (all zero for lane 0).
+template <int M>
+BEAM_HD IfaceRow make_row(const SegState<M>& s, const Mat2& ownCup, const Sym2& prevC, const Vec2& prevg,
+                          const Mat2& prevCup, unsigned long long fixbits) {
+  const Flags c = node_flags(fixbits, 0);
   IfaceRow r;
-  r.D = Sym2{s.SLL.a + prevC.a + (1.0 - av), s.SLL.b + prevC.b, s.SLL.c + prevC.c + (1.0 - at)};
-  r.f = Vec2{s.gL.x + prevg.x, s.gL.y + prevg.y};
-  r.Alow = Mat2{prevB.a, prevB.c, prevB.b, prevB.d};  // B_{j-1}^T
-  r.Cup = s.SLc;
+  r.D = mask_node(Sym2{s.SLL.a + prevC.a, s.SLL.b + prevC.b, s.SLL.c + prevC.c}, c);
+  r.f = mask_vec(Vec2{s.gL.x + prevg.x, s.gL.y + prevg.y}, c);
+  r.Alow = Mat2{prevCup.a, prevCup.c, prevCup.b, prevCup.d};  // transpose
+  r.Cup = ownCup;
   return r;
 }
 
-// One PCR step.  G = own D^-1 is not needed here; Gm/Am/fm come from row j-s and
-// Gp/Cp/fp from row j+s (zeros when that row does not exist).
+// One PCR step.  Gm/Am/fm come from row j-s, Gp/Cp/fp from row j+s (zeros, or anything
+// finite, when that row does not exist: the own coupling towards it is exactly zero).
+// LAST: the couplings are not needed after the final step.
+template <bool LAST>
 BEAM_HD void pcr_step(IfaceRow& r, const Sym2& Gm, const Mat2& Am, const Vec2& fm, const Sym2& Gp,
                       const Mat2& Cp, const Vec2& fp) {
   const Mat2 al = mul(r.Alow, Gm);  // K[j,j-s] D_{j-s}^-1
@@ -207,39 +213,52 @@ BEAM_HD void pcr_step(IfaceRow& r, const Sym2& Gm, const Mat2& Am, const Vec2& f
   // K[j-s,j] = Alow^T and K[j+s,j] = Cup^T by symmetry
   r.D = sub_mulT(sub_mulT(r.D, al, r.Alow), ga, r.Cup);
   r.f = sub_mul(sub_mul(r.f, al, fm), ga, fp);
-  r.Alow = neg_mul(al, Am);
-  r.Cup = neg_mul(ga, Cp);
+  if (!LAST) {
+    r.Alow = neg_mul(al, Am);
+    r.Cup = neg_mul(ga, Cp);
+  }
 }
 
-// Out receives results by LOCAL index: node(i, v, theta) for i in [0, M), elem(i, V, Mz) for i in [0, M).
+// Phase C.  Out receives results by LOCAL index: node(i, v, theta), elem(i, V, Mz), i in [0, M).
 template <int M, class Acc, class Out>
-BEAM_HD void seg_backsub(const SegState<M>& s, const Acc& acc, const Vec2& uL, const Vec2& uR, Out& out) {
+BEAM_HD void seg_solve(const SegState<M>& s, const Acc& acc, const Vec2& uL, const Vec2& uR, Out& out) {
   const unsigned long long fb = acc.fixbits();
+  // right-hand-side sweep with the left boundary displacement prescribed
+  Vec2 h[M];
+  {
+    const ElemK k0 = elem_k(acc.c2(0), acc.c6(0), acc.c12(0), acc.Ie(0));
+    Vec2 carry = sub_mulT(Vec2{acc.pw(0), -acc.mw(0)}, Mat2{-k0.kA, k0.kB, -k0.kB, k0.kD}, uL);
+#pragma unroll
+    for (int i = 1; i < M; ++i) {
+      const Flags c = node_flags(fb, i);
+      const ElemK k = elem_k(acc.c2(i), acc.c6(i), acc.c12(i), acc.Ie(i));
+      const double pw = acc.pw(i), mw = acc.mw(i);
+      h[i] = mask_vec(Vec2{carry.x + pw + acc.Fy(i), carry.y + mw}, c);
+      if (i + 1 < M) {
+        const Mat2 Kr = mask_rows(Mat2{-k.kA, k.kB, -k.kB, k.kD}, c);
+        const Mat2 Qm = mulT(Kr, s.Ginv[i]);
+        carry = sub_mul(Vec2{pw, -mw}, Qm, h[i]);
+      }
+    }
+  }
+  // back substitution + ElasticBeam2d::getResistingForce (eleResponse 'forces' [1], [2])
   Vec2 un = uR;  // displacement of local node i+1
 #pragma unroll
   for (int i = M - 1; i >= 0; --i) {
-    const double c2 = acc.c2(i), c6 = acc.c6(i), c12 = acc.c12(i), Ie = acc.Ie(i);
+    const ElemK k = elem_k(acc.c2(i), acc.c6(i), acc.c12(i), acc.Ie(i));
     Vec2 ui;
     if (i > 0) {
-      const double av = free_flag(fb, 2 * i), at = free_flag(fb, 2 * i + 1);
-      const double bv = free_flag(fb, 2 * i + 2), bt = free_flag(fb, 2 * i + 3);
-      const double k2 = c2 * Ie, k6 = c6 * Ie, k12 = c12 * Ie;
-      const Mat2 K12{-(av * bv) * k12, (av * bt) * k6, -(at * bv) * k6, (at * bt) * k2};
-      Vec2 t = sub_mulT(s.g[i], s.SLi[i], uL);
-      t = sub_mul(t, K12, un);
-      ui = mul(s.Ginv[i], t);
+      const Mat2 Kr = mask_rows(Mat2{-k.kA, k.kB, -k.kB, k.kD}, node_flags(fb, i));
+      ui = mul(s.Ginv[i], sub_mul(h[i], Kr, un));
     } else {
       ui = uL;
     }
-    // ElasticBeam2d::getResistingForce, bending part (eleResponse 'forces' [1], [2])
     {
-      const double rl = acc.rL(i);
-      const double k2 = c2 * Ie, k4 = k2 + k2;
+      const double rl = acc.rL(i), mw = acc.mw(i);
       const double chord = (un.x - ui.x) * rl;
       const double p1 = ui.y - chord, p2 = un.y - chord;
-      const double mw = acc.mw(i);
-      const double q1 = __builtin_fma(k4, p1, __builtin_fma(k2, p2, -mw));
-      const double q2 = __builtin_fma(k2, p1, __builtin_fma(k4, p2, mw));
+      const double q1 = __builtin_fma(k.kC, p1, __builtin_fma(k.kD, p2, -mw));
+      const double q2 = __builtin_fma(k.kD, p1, __builtin_fma(k.kC, p2, mw));
       out.elem(i, __builtin_fma(q1 + q2, rl, -acc.pw(i)), q1);
     }
     out.node(i, ui.x, ui.y);

@@ -58,18 +58,83 @@ struct LaneOut {
   __device__ __forceinline__ void node(int i, double vv, double tt) { v[i] = vv; th[i] = tt; }
 };
 
-__device__ __forceinline__ double lane_get(double val, int src, bool valid) {
-  const double r = __shfl(val, src, 64);
-  return valid ? r : 0.0;
+// ---- cross-lane exchange inside the P-lane group of a beam ------------------------------
+// from_minus<S>(x): value of lane-S (0.0 when j < S); from_plus<S>(x): value of lane+S (0.0 when
+// j + S >= P).  P <= 16: the group lies inside one 16-lane DPP row, so the fetch is a pair of
+// v_mov_b32 with a row_shr / row_shl modifier (bound_ctrl writes 0 for lanes shifted in from outside
+// the row); no LDS crossbar, no wait.  P = 8 shares its row with a second beam and masks the lanes
+// that would read across the group edge.  P >= 32: ds_bpermute (__shfl).
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov(double x) {
+  const unsigned long long u = __builtin_bit_cast(unsigned long long, x);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)u, CTRL, 0xF, 0xF, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(u >> 32), CTRL, 0xF, 0xF, true);
+  return __builtin_bit_cast(double, ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
 }
-__device__ __forceinline__ Sym2 lane_get(const Sym2& s, int src, bool ok) {
-  return Sym2{lane_get(s.a, src, ok), lane_get(s.b, src, ok), lane_get(s.c, src, ok)};
-}
-__device__ __forceinline__ Mat2 lane_get(const Mat2& m, int src, bool ok) {
-  return Mat2{lane_get(m.a, src, ok), lane_get(m.b, src, ok), lane_get(m.c, src, ok), lane_get(m.d, src, ok)};
-}
-__device__ __forceinline__ Vec2 lane_get(const Vec2& u, int src, bool ok) {
-  return Vec2{lane_get(u.x, src, ok), lane_get(u.y, src, ok)};
+
+template <int P>
+struct Xch {
+  template <int S>
+  static __device__ __forceinline__ double from_minus(double x, int lane, int j) {
+    if constexpr (P <= 16 && S < 16) {
+      const double r = dpp_mov<0x110 + S>(x);  // row_shr:S
+      if constexpr (P < 16) return j >= S ? r : 0.0;
+      return r;
+    } else {
+      const double r = __shfl(x, lane - S, 64);
+      return j >= S ? r : 0.0;
+    }
+  }
+  template <int S>
+  static __device__ __forceinline__ double from_plus(double x, int lane, int j) {
+    if constexpr (P <= 16 && S < 16) {
+      const double r = dpp_mov<0x100 + S>(x);  // row_shl:S
+      if constexpr (P < 16) return j + S < P ? r : 0.0;
+      return r;
+    } else {
+      const double r = __shfl(x, lane + S, 64);
+      return j + S < P ? r : 0.0;
+    }
+  }
+  template <int S> static __device__ __forceinline__ Sym2 from_minus(const Sym2& s, int l, int j) {
+    return Sym2{from_minus<S>(s.a, l, j), from_minus<S>(s.b, l, j), from_minus<S>(s.c, l, j)};
+  }
+  template <int S> static __device__ __forceinline__ Mat2 from_minus(const Mat2& m, int l, int j) {
+    return Mat2{from_minus<S>(m.a, l, j), from_minus<S>(m.b, l, j), from_minus<S>(m.c, l, j), from_minus<S>(m.d, l, j)};
+  }
+  template <int S> static __device__ __forceinline__ Vec2 from_minus(const Vec2& u, int l, int j) {
+    return Vec2{from_minus<S>(u.x, l, j), from_minus<S>(u.y, l, j)};
+  }
+  template <int S> static __device__ __forceinline__ Sym2 from_plus(const Sym2& s, int l, int j) {
+    return Sym2{from_plus<S>(s.a, l, j), from_plus<S>(s.b, l, j), from_plus<S>(s.c, l, j)};
+  }
+  template <int S> static __device__ __forceinline__ Mat2 from_plus(const Mat2& m, int l, int j) {
+    return Mat2{from_plus<S>(m.a, l, j), from_plus<S>(m.b, l, j), from_plus<S>(m.c, l, j), from_plus<S>(m.d, l, j)};
+  }
+  template <int S> static __device__ __forceinline__ Vec2 from_plus(const Vec2& u, int l, int j) {
+    return Vec2{from_plus<S>(u.x, l, j), from_plus<S>(u.y, l, j)};
+  }
+};
+
+// parallel cyclic reduction over the P rows of a beam: steps S = 1, 2, 4, ..., P/2
+template <int P, int S>
+__device__ __forceinline__ void pcr_all(IfaceRow& row, int lane, int j, int& bad) {
+  if constexpr (S < P) {
+    using X = Xch<P>;
+    constexpr bool LAST = (2 * S >= P);
+    const Sym2 G = inv_spd(row.D, bad);
+    const Sym2 Gm = X::template from_minus<S>(G, lane, j);
+    const Vec2 fm = X::template from_minus<S>(row.f, lane, j);
+    const Sym2 Gp = X::template from_plus<S>(G, lane, j);
+    const Vec2 fp = X::template from_plus<S>(row.f, lane, j);
+    Mat2 Am{0, 0, 0, 0}, Cp{0, 0, 0, 0};
+    if constexpr (!LAST) {
+      Am = X::template from_minus<S>(row.Alow, lane, j);
+      Cp = X::template from_plus<S>(row.Cup, lane, j);
+    }
+    pcr_step<LAST>(row, Gm, Am, fm, Gp, Cp, fp);
+    pcr_all<P, 2 * S>(row, lane, j, bad);
+  }
 }
 
 // SHARED: x, E and wy are the same for every beam (strides 0): one LDS table per workgroup.
@@ -143,36 +208,29 @@ __global__ __launch_bounds__(64) void beam_solve_kernel(const BeamParams p) {
   int bad = 0;
   SegState<M> st;
   seg_condense<M>(st, acc, bad);
+  // The element data is re-read from LDS in stage 4 instead of being carried in ~16*M VGPRs
+  // across the reduction: the clobber stops the compiler from merging the two sets of loads.
+  __asm__ volatile("" ::: "memory");
 
   // ---- stage 3: interface system over the P lanes of the beam, parallel cyclic reduction ----
+  using X = Xch<P>;
   IfaceRow row;
   {
-    const bool has_prev = j > 0;
-    const Sym2 pc = lane_get(st.Scc, lane - 1, has_prev);
-    const Vec2 pg = lane_get(st.gc, lane - 1, has_prev);
-    const Mat2 pb = lane_get(st.SLc, lane - 1, has_prev);
-    row = make_row<M>(st, pc, pg, pb, acc.bits);
+    const Mat2 cup = masked_cup<M>(st, acc.bits);
+    const Sym2 pc = X::template from_minus<1>(st.Scc, lane, j);
+    const Vec2 pg = X::template from_minus<1>(st.gc, lane, j);
+    const Mat2 pb = X::template from_minus<1>(cup, lane, j);
+    row = make_row<M>(st, cup, pc, pg, pb, acc.bits);
   }
-#pragma unroll
-  for (int s = 1; s < P; s *= 2) {
-    const Sym2 G = inv_spd(row.D, bad);
-    const bool okm = j >= s, okp = j + s < P;
-    const Sym2 Gm = lane_get(G, lane - s, okm);
-    const Mat2 Am = lane_get(row.Alow, lane - s, okm);
-    const Vec2 fm = lane_get(row.f, lane - s, okm);
-    const Sym2 Gp = lane_get(G, lane + s, okp);
-    const Mat2 Cp = lane_get(row.Cup, lane + s, okp);
-    const Vec2 fp = lane_get(row.f, lane + s, okp);
-    pcr_step(row, Gm, Am, fm, Gp, Cp, fp);
-  }
+  pcr_all<P, 1>(row, lane, j, bad);
   const Vec2 uL = mul(inv_spd(row.D, bad), row.f);
-  const Vec2 uR = lane_get(uL, lane + 1, j + 1 < P);
+  const Vec2 uR = X::template from_plus<1>(uL, lane, j);
 
-  // ---- stage 4: back substitution + end forces; element rows out first ----
+  // ---- stage 4: interior solve + end forces; element rows out first ----
   LaneOut<M> out;
   out.sV = &s_b[g][e0];
   out.sM = &s_a[g][e0];
-  seg_backsub<M>(st, acc, uL, uR, out);
+  seg_solve<M>(st, acc, uL, uR, out);
   if (bad) s_bad[g] = 1;
   __syncthreads();
 

@@ -60,17 +60,23 @@ int solve_one(int Ne, const double* x, const double* E, bool E_pe, const double*
     seg_condense<M>(st[j], acc[j], bad);
   }
   std::vector<IfaceRow> row(P), nxt(P);
+  std::vector<Mat2> cup(P);
   const Sym2 z3{0, 0, 0}; const Mat2 z4{0, 0, 0, 0}; const Vec2 z2{0, 0};
+  for (int j = 0; j < P; ++j) cup[j] = masked_cup<M>(st[j], acc[j].bits);
   for (int j = 0; j < P; ++j)
-    row[j] = make_row<M>(st[j], j ? st[j - 1].Scc : z3, j ? st[j - 1].gc : z2, j ? st[j - 1].SLc : z4, acc[j].bits);
+    row[j] = make_row<M>(st[j], cup[j], j ? st[j - 1].Scc : z3, j ? st[j - 1].gc : z2, j ? cup[j - 1] : z4, acc[j].bits);
   for (int s = 1; s < P; s *= 2) {
     std::vector<Sym2> G(P);
     for (int j = 0; j < P; ++j) G[j] = inv_spd(row[j].D, bad);
     for (int j = 0; j < P; ++j) {
       nxt[j] = row[j];
       const bool okm = j >= s, okp = j + s < P;
-      pcr_step(nxt[j], okm ? G[j - s] : z3, okm ? row[j - s].Alow : z4, okm ? row[j - s].f : z2,
-               okp ? G[j + s] : z3, okp ? row[j + s].Cup : z4, okp ? row[j + s].f : z2);
+      if (2 * s < P)
+        pcr_step<false>(nxt[j], okm ? G[j - s] : z3, okm ? row[j - s].Alow : z4, okm ? row[j - s].f : z2,
+                        okp ? G[j + s] : z3, okp ? row[j + s].Cup : z4, okp ? row[j + s].f : z2);
+      else
+        pcr_step<true>(nxt[j], okm ? G[j - s] : z3, z4, okm ? row[j - s].f : z2, okp ? G[j + s] : z3, z4,
+                       okp ? row[j + s].f : z2);
     }
     row = nxt;
   }
@@ -79,7 +85,7 @@ int solve_one(int Ne, const double* x, const double* E, bool E_pe, const double*
   for (int j = 0; j < P; ++j) {
     const int e0 = j * M;
     HostOut out{&ov[e0], &ot[e0], &oV[e0], &oM[e0]};
-    seg_backsub<M>(st[j], acc[j], u[j], j + 1 < P ? u[j + 1] : z2, out);
+    seg_solve<M>(st[j], acc[j], u[j], j + 1 < P ? u[j + 1] : z2, out);
   }
   for (int n = 0; n < N; ++n) { v[n] = bad ? NAN : ov[n]; th[n] = bad ? NAN : ot[n]; }
   for (int e = 0; e < Ne; ++e) { V[e] = bad ? NAN : oV[e]; Mz[e] = bad ? NAN : oM[e]; }
