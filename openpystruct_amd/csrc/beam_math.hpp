@@ -142,6 +142,7 @@ struct SegState {
 //   c2(i), c6(i), c12(i), rL(i), Ie(i), pw(i), mw(i)   element i in [0, M)
 //   Fy(i)                                                nodal load at local node i in [0, M)
 //   fixbits()   bit 2i = u_y of local node i fixed, bit 2i+1 = theta_z fixed, i in [0, M]
+//   fence()     compiler-only memory fence (device) / no-op (host)
 template <int M, class Acc>
 BEAM_HD void seg_condense(SegState<M>& s, const Acc& acc, int& bad) {
   const unsigned long long fb = acc.fixbits();
@@ -155,6 +156,7 @@ BEAM_HD void seg_condense(SegState<M>& s, const Acc& acc, int& bad) {
   }
 #pragma unroll
   for (int i = 1; i < M; ++i) {
+    acc.fence();  // keep element i's loads behind element i-1's: bounds the live registers
     const Flags c = node_flags(fb, i);
     const ElemK k = elem_k(acc.c2(i), acc.c6(i), acc.c12(i), acc.Ie(i));
     const double pw = acc.pw(i), mw = acc.mw(i);
@@ -230,6 +232,7 @@ BEAM_HD void seg_solve(const SegState<M>& s, const Acc& acc, const Vec2& uL, con
     Vec2 carry = sub_mulT(Vec2{acc.pw(0), -acc.mw(0)}, Mat2{-k0.kA, k0.kB, -k0.kB, k0.kD}, uL);
 #pragma unroll
     for (int i = 1; i < M; ++i) {
+      acc.fence();
       const Flags c = node_flags(fb, i);
       const ElemK k = elem_k(acc.c2(i), acc.c6(i), acc.c12(i), acc.Ie(i));
       const double pw = acc.pw(i), mw = acc.mw(i);
@@ -245,6 +248,7 @@ BEAM_HD void seg_solve(const SegState<M>& s, const Acc& acc, const Vec2& uL, con
   Vec2 un = uR;  // displacement of local node i+1
 #pragma unroll
   for (int i = M - 1; i >= 0; --i) {
+    acc.fence();
     const ElemK k = elem_k(acc.c2(i), acc.c6(i), acc.c12(i), acc.Ie(i));
     Vec2 ui;
     if (i > 0) {

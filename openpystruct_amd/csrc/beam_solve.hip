@@ -32,6 +32,10 @@ struct BeamParams {
   const double* wy; long wy_bs;
   double* v; double* theta; double* V; double* M;
   int32_t* status;
+  // host-derived: rows of I/Fy/outputs are dense and every wave's chunk is 16-byte aligned, so
+  // the wave moves its beams as one flat run of 16-byte accesses; magic numbers for idx / Ne, idx / N
+  int dense;
+  unsigned magic_ne, magic_n;
 };
 
 // lane-local view of the LDS-staged inputs (see beam_math.hpp "Acc")
@@ -48,6 +52,7 @@ struct LdsAcc {
   __device__ __forceinline__ double Ie(int i) const { return sI[i]; }
   __device__ __forceinline__ double Fy(int i) const { return sF[i]; }
   __device__ __forceinline__ unsigned long long fixbits() const { return bits; }
+  __device__ __forceinline__ void fence() const { __asm__ volatile("" ::: "memory"); }
 };
 
 template <int M>
@@ -153,6 +158,30 @@ __global__ __launch_bounds__(64) void beam_solve_kernel(const BeamParams p) {
   const int Ne = p.Ne, N = p.Ne + 1;
   const long beam0 = (long)blockIdx.x * BPW;
 
+  constexpr int NPAIR = (BPW * PM / 2 + 63) / 64;   // 16-byte pieces per lane for one staged array
+  const int nb = (p.B - beam0 < BPW) ? (int)(p.B - beam0) : BPW;   // live beams of this wave
+  // ---- stage 1a: issue the wave's global loads first (I, Fy rows of its beams: one contiguous run) ----
+  double2 rI[NPAIR], rF[NPAIR];
+  if (p.dense) {
+    const double* gI = p.I + beam0 * Ne;
+    const double* gF = p.Fy + beam0 * N;
+    const int nI = nb * Ne, nF = nb * N;
+#pragma unroll
+    for (int k = 0; k < NPAIR; ++k) {
+      const int i0 = 2 * (lane + 64 * k);
+      rI[k] = double2{0.0, 0.0};
+      rF[k] = double2{0.0, 0.0};
+      if (i0 + 1 < nI) rI[k] = *reinterpret_cast<const double2*>(gI + i0);
+      else if (i0 < nI) rI[k].x = gI[i0];
+      if (i0 + 1 < nF) rF[k] = *reinterpret_cast<const double2*>(gF + i0);
+      else if (i0 < nF) rF[k].x = gF[i0];
+    }
+  }
+  // zero fill (padding elements / nodes and dead beams); LDS ops of one wave execute in order
+  for (int idx = lane; idx < BPW * PM; idx += 64) {
+    (&s_a[0][0])[idx] = 0.0;
+    (&s_b[0][0])[idx] = 0.0;
+  }
   // ---- stage 0: element table (unit-inertia stiffness tile entries, 1/L, UDL loads) ----
   for (int idx = lane; idx < TG * PM; idx += 64) {
     const int tb = idx / PM, e = idx - tb * PM;
@@ -174,19 +203,41 @@ __global__ __launch_bounds__(64) void beam_solve_kernel(const BeamParams p) {
     s_tab[0][tb][e] = c2;  s_tab[1][tb][e] = c6;  s_tab[2][tb][e] = c12;
     s_tab[3][tb][e] = rl;  s_tab[4][tb][e] = pw;  s_tab[5][tb][e] = mw;
   }
-  // ---- stage 1: coalesced row loads of I, Fy, fix into LDS (zero / fixed padding) ----
+  // ---- stage 1b: constraint bytes, then the staged rows into their padded LDS rows ----
 #pragma unroll
   for (int b = 0; b < BPW; ++b) {
-    const long bb = beam0 + b;
-    const bool live = bb < p.B;
-    const double* Ib = p.I + (live ? bb : 0) * p.I_bs;
-    const double* Fb = p.Fy + (live ? bb : 0) * p.Fy_bs;
-    const uint8_t* fb = p.fix + (live ? bb : 0) * p.fix_bs;
-    for (int e = lane; e < PM; e += 64) {
-      s_a[b][e] = (live && e < Ne) ? Ib[e] : 0.0;
-      s_b[b][e] = (live && e < N) ? Fb[e] : 0.0;
-    }
+    const bool live = b < nb;
+    const uint8_t* fb = p.fix + (live ? beam0 + b : 0) * p.fix_bs;
     for (int e = lane; e < PM + 8; e += 64) s_fix[b][e] = (live && e < N) ? (uint8_t)(fb[e] & 3) : (uint8_t)3;
+  }
+  if (p.dense) {
+#pragma unroll
+    for (int k = 0; k < NPAIR; ++k) {
+      const int i0 = 2 * (lane + 64 * k);
+      if (i0 < nb * Ne) {
+        const int b0 = (int)(((unsigned)i0 * p.magic_ne) >> 20), e = i0 - b0 * Ne;
+        s_a[b0][e] = rI[k].x;
+        if (e + 1 < Ne) s_a[b0][e + 1] = rI[k].y;
+        else if (b0 + 1 < nb) s_a[b0 + 1][0] = rI[k].y;
+      }
+      if (i0 < nb * N) {
+        const int b0 = (int)(((unsigned)i0 * p.magic_n) >> 20), e = i0 - b0 * N;
+        s_b[b0][e] = rF[k].x;
+        if (e + 1 < N) s_b[b0][e + 1] = rF[k].y;
+        else if (b0 + 1 < nb) s_b[b0 + 1][0] = rF[k].y;
+      }
+    }
+  } else {
+#pragma unroll
+    for (int b = 0; b < BPW; ++b) {
+      if (b >= nb) break;
+      const double* Ib = p.I + (beam0 + b) * p.I_bs;
+      const double* Fb = p.Fy + (beam0 + b) * p.Fy_bs;
+      for (int e = lane; e < N; e += 64) {
+        if (e < Ne) s_a[b][e] = Ib[e];
+        s_b[b][e] = Fb[e];
+      }
+    }
   }
   if (lane < BPW) s_bad[lane] = 0;
   __syncthreads();
@@ -235,34 +286,84 @@ __global__ __launch_bounds__(64) void beam_solve_kernel(const BeamParams p) {
   __syncthreads();
 
   const double qnan = __builtin_nan("");
+  // element rows (V in s_b, M in s_a) -> global
+  if (p.dense) {
+    double* gV = p.V + beam0 * Ne;
+    double* gM = p.M + beam0 * Ne;
+    const int nE = nb * Ne;
 #pragma unroll
-  for (int b = 0; b < BPW; ++b) {
-    const long bb = beam0 + b;
-    if (bb >= p.B) break;
-    const bool nb = s_bad[b] != 0;
-    for (int e = lane; e < Ne; e += 64) {
-      p.V[bb * Ne + e] = nb ? qnan : s_b[b][e];
-      p.M[bb * Ne + e] = nb ? qnan : s_a[b][e];
+    for (int k = 0; k < NPAIR; ++k) {
+      const int i0 = 2 * (lane + 64 * k);
+      if (i0 < nE) {
+        const int b0 = (int)(((unsigned)i0 * p.magic_ne) >> 20), e = i0 - b0 * Ne;
+        const bool wrap = e + 1 >= Ne;
+        const int b1 = wrap ? b0 + 1 : b0, e1 = wrap ? 0 : e + 1;
+        double2 vV{s_bad[b0] ? qnan : s_b[b0][e], 0.0}, vM{s_bad[b0] ? qnan : s_a[b0][e], 0.0};
+        if (i0 + 1 < nE) {
+          vV.y = s_bad[b1] ? qnan : s_b[b1][e1];
+          vM.y = s_bad[b1] ? qnan : s_a[b1][e1];
+          *reinterpret_cast<double2*>(gV + i0) = vV;
+          *reinterpret_cast<double2*>(gM + i0) = vM;
+        } else {
+          gV[i0] = vV.x;
+          gM[i0] = vM.x;
+        }
+      }
+    }
+  } else {
+#pragma unroll
+    for (int b = 0; b < BPW; ++b) {
+      if (b >= nb) break;
+      const bool nbad = s_bad[b] != 0;
+      for (int e = lane; e < Ne; e += 64) {
+        p.V[(beam0 + b) * Ne + e] = nbad ? qnan : s_b[b][e];
+        p.M[(beam0 + b) * Ne + e] = nbad ? qnan : s_a[b][e];
+      }
     }
   }
   __syncthreads();
+  // nodal rows: v -> s_b, theta -> s_a -> global
 #pragma unroll
   for (int i = 0; i < M; ++i) {
     s_b[g][e0 + i] = out.v[i];
     s_a[g][e0 + i] = out.th[i];
   }
   __syncthreads();
+  if (p.dense) {
+    double* gv = p.v + beam0 * N;
+    double* gt = p.theta + beam0 * N;
+    const int nN = nb * N;
 #pragma unroll
-  for (int b = 0; b < BPW; ++b) {
-    const long bb = beam0 + b;
-    if (bb >= p.B) break;
-    const bool nb = s_bad[b] != 0;
-    for (int e = lane; e < N; e += 64) {
-      p.v[bb * N + e] = nb ? qnan : s_b[b][e];
-      p.theta[bb * N + e] = nb ? qnan : s_a[b][e];
+    for (int k = 0; k < NPAIR; ++k) {
+      const int i0 = 2 * (lane + 64 * k);
+      if (i0 < nN) {
+        const int b0 = (int)(((unsigned)i0 * p.magic_n) >> 20), e = i0 - b0 * N;
+        const bool wrap = e + 1 >= N;
+        const int b1 = wrap ? b0 + 1 : b0, e1 = wrap ? 0 : e + 1;
+        double2 vv{s_bad[b0] ? qnan : s_b[b0][e], 0.0}, vt{s_bad[b0] ? qnan : s_a[b0][e], 0.0};
+        if (i0 + 1 < nN) {
+          vv.y = s_bad[b1] ? qnan : s_b[b1][e1];
+          vt.y = s_bad[b1] ? qnan : s_a[b1][e1];
+          *reinterpret_cast<double2*>(gv + i0) = vv;
+          *reinterpret_cast<double2*>(gt + i0) = vt;
+        } else {
+          gv[i0] = vv.x;
+          gt[i0] = vt.x;
+        }
+      }
     }
-    if (lane == 0 && p.status) p.status[bb] = nb ? 1 : 0;
+  } else {
+#pragma unroll
+    for (int b = 0; b < BPW; ++b) {
+      if (b >= nb) break;
+      const bool nbad = s_bad[b] != 0;
+      for (int e = lane; e < N; e += 64) {
+        p.v[(beam0 + b) * N + e] = nbad ? qnan : s_b[b][e];
+        p.theta[(beam0 + b) * N + e] = nbad ? qnan : s_a[b][e];
+      }
+    }
   }
+  if (lane < nb && p.status) p.status[beam0 + lane] = s_bad[lane] ? 1 : 0;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -342,7 +443,15 @@ int ops_beam_solve_batched_f64(int B, int Ne, const double* x, long x_bstride, c
   if (!t) return tiling ? OPS_AMD_ERR_INVALID_ARG : OPS_AMD_ERR_UNSUPPORTED;
 
   BeamParams p{B, Ne, x, x_bstride, E, E_bstride, I, I_bstride, fix, fix_bstride, Fy, Fy_bstride,
-               wy, wy_bstride, v, theta, V, M, status};
+               wy, wy_bstride, v, theta, V, M, status, 0, 0u, 0u};
+  {
+    const int bpw = 64 / t->P;
+    const uintptr_t bits = (uintptr_t)I | (uintptr_t)Fy | (uintptr_t)v | (uintptr_t)theta | (uintptr_t)V | (uintptr_t)M;
+    p.dense = (I_bstride == Ne) && (Fy_bstride == Ne + 1) && ((bits & 15u) == 0) &&
+              ((bpw * Ne) % 2 == 0) && ((bpw * (Ne + 1)) % 2 == 0);
+    p.magic_ne = ((1u << 20) + (unsigned)Ne - 1u) / (unsigned)Ne;
+    p.magic_n = ((1u << 20) + (unsigned)Ne) / (unsigned)(Ne + 1);
+  }
   const bool shared = (x_bstride == 0 && E_bstride == 0 && wy_bstride == 0);
   hipStream_t s = (hipStream_t)stream;
   hipError_t err = hipSuccess;

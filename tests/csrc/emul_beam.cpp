@@ -26,6 +26,7 @@ struct HostAcc {
   double Ie(int i) const { return sI[i]; }
   double Fy(int i) const { return sF[i]; }
   unsigned long long fixbits() const { return bits; }
+  void fence() const {}
 };
 struct HostOut {
   double *v, *th, *V, *Mz;
