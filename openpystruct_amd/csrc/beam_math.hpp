@@ -117,16 +117,39 @@ BEAM_HD ElemK elem_k(double c2, double c6, double c12, double Ie) {
   return ElemK{c12 * Ie, c6 * Ie, kD + kD, kD};
 }
 
-struct Flags { double v, t; };  // 1.0 = free, 0.0 = fixed
-BEAM_HD Flags node_flags(unsigned long long bits, int node) {
-  return Flags{((bits >> (2 * node)) & 1ull) ? 0.0 : 1.0, ((bits >> (2 * node + 1)) & 1ull) ? 0.0 : 1.0};
+// Per-node constraint flags.  RZ = false is the fast path for waves in which no node has a fixed
+// rotation (the reference only ever fixes translations: `ops.fix(n, 0|1, 1, 0)`, SingleCore.py:100-102):
+// the rotation flag is the constant 1 and all its multiplications fold away at compile time.
+template <bool RZ>
+struct Flags {
+  double v, dv;   // v: 1.0 free / 0.0 fixed; dv = 1 - v (identity on the fixed diagonal)
+  double t, dt;
+};
+template <bool RZ>
+BEAM_HD Flags<RZ> node_flags(unsigned long long bits, int node) {
+  const bool fv = (bits >> (2 * node)) & 1ull, ft = RZ && ((bits >> (2 * node + 1)) & 1ull);
+  return Flags<RZ>{fv ? 0.0 : 1.0, fv ? 1.0 : 0.0, ft ? 0.0 : 1.0, ft ? 1.0 : 0.0};
 }
-BEAM_HD Sym2 mask_node(const Sym2& s, const Flags& c) {  // identity on fixed DOFs
-  return Sym2{__builtin_fma(c.v, s.a, 1.0 - c.v), (c.v * c.t) * s.b, __builtin_fma(c.t, s.c, 1.0 - c.t)};
+template <bool RZ>
+BEAM_HD Sym2 mask_node(const Sym2& s, const Flags<RZ>& c) {  // identity on fixed DOFs
+  if (RZ) return Sym2{__builtin_fma(c.v, s.a, c.dv), (c.v * c.t) * s.b, __builtin_fma(c.t, s.c, c.dt)};
+  return Sym2{__builtin_fma(c.v, s.a, c.dv), c.v * s.b, s.c};
 }
-BEAM_HD Vec2 mask_vec(const Vec2& g, const Flags& c) { return Vec2{c.v * g.x, c.t * g.y}; }
-BEAM_HD Mat2 mask_cols(const Mat2& m, const Flags& c) { return Mat2{m.a * c.v, m.b * c.t, m.c * c.v, m.d * c.t}; }
-BEAM_HD Mat2 mask_rows(const Mat2& m, const Flags& c) { return Mat2{m.a * c.v, m.b * c.v, m.c * c.t, m.d * c.t}; }
+template <bool RZ>
+BEAM_HD Vec2 mask_vec(const Vec2& g, const Flags<RZ>& c) {
+  if (RZ) return Vec2{c.v * g.x, c.t * g.y};
+  return Vec2{c.v * g.x, g.y};
+}
+template <bool RZ>
+BEAM_HD Mat2 mask_cols(const Mat2& m, const Flags<RZ>& c) {
+  if (RZ) return Mat2{m.a * c.v, m.b * c.t, m.c * c.v, m.d * c.t};
+  return Mat2{m.a * c.v, m.b, m.c * c.v, m.d};
+}
+template <bool RZ>
+BEAM_HD Mat2 mask_rows(const Mat2& m, const Flags<RZ>& c) {
+  if (RZ) return Mat2{m.a * c.v, m.b * c.v, m.c * c.t, m.d * c.t};
+  return Mat2{m.a * c.v, m.b * c.v, m.c, m.d};
+}
 
 // State a lane keeps across the phases.
 template <int M>
@@ -143,7 +166,7 @@ struct SegState {
 //   Fy(i)                                                nodal load at local node i in [0, M)
 //   fixbits()   bit 2i = u_y of local node i fixed, bit 2i+1 = theta_z fixed, i in [0, M]
 //   fence()     compiler-only memory fence (device) / no-op (host)
-template <int M, class Acc>
+template <int M, bool RZ, class Acc>
 BEAM_HD void seg_condense(SegState<M>& s, const Acc& acc, int& bad) {
   const unsigned long long fb = acc.fixbits();
   {
@@ -157,7 +180,7 @@ BEAM_HD void seg_condense(SegState<M>& s, const Acc& acc, int& bad) {
 #pragma unroll
   for (int i = 1; i < M; ++i) {
     acc.fence();  // keep element i's loads behind element i-1's: bounds the live registers
-    const Flags c = node_flags(fb, i);
+    const Flags<RZ> c = node_flags<RZ>(fb, i);
     const ElemK k = elem_k(acc.c2(i), acc.c6(i), acc.c12(i), acc.Ie(i));
     const double pw = acc.pw(i), mw = acc.mw(i);
     // node i is complete: left element (in Scc/gc) + right element; then constrain it
@@ -186,16 +209,16 @@ struct IfaceRow {
 
 // The lane's own coupling to the next boundary node, constrained on both sides; lane j+1
 // receives it (transposed) as its Alow.
-template <int M>
+template <int M, bool RZ>
 BEAM_HD Mat2 masked_cup(const SegState<M>& s, unsigned long long fixbits) {
-  return mask_cols(mask_rows(s.SLc, node_flags(fixbits, 0)), node_flags(fixbits, M));
+  return mask_cols(mask_rows(s.SLc, node_flags<RZ>(fixbits, 0)), node_flags<RZ>(fixbits, M));
 }
 
 // prevC, prevg: Scc, gc of lane j-1; prevCup: masked_cup of lane j-1 (all zero for lane 0).
-template <int M>
+template <int M, bool RZ>
 BEAM_HD IfaceRow make_row(const SegState<M>& s, const Mat2& ownCup, const Sym2& prevC, const Vec2& prevg,
                           const Mat2& prevCup, unsigned long long fixbits) {
-  const Flags c = node_flags(fixbits, 0);
+  const Flags<RZ> c = node_flags<RZ>(fixbits, 0);
   IfaceRow r;
   r.D = mask_node(Sym2{s.SLL.a + prevC.a, s.SLL.b + prevC.b, s.SLL.c + prevC.c}, c);
   r.f = mask_vec(Vec2{s.gL.x + prevg.x, s.gL.y + prevg.y}, c);
@@ -222,7 +245,7 @@ BEAM_HD void pcr_step(IfaceRow& r, const Sym2& Gm, const Mat2& Am, const Vec2& f
 }
 
 // Phase C.  Out receives results by LOCAL index: node(i, v, theta), elem(i, V, Mz), i in [0, M).
-template <int M, class Acc, class Out>
+template <int M, bool RZ, class Acc, class Out>
 BEAM_HD void seg_solve(const SegState<M>& s, const Acc& acc, const Vec2& uL, const Vec2& uR, Out& out) {
   const unsigned long long fb = acc.fixbits();
   // right-hand-side sweep with the left boundary displacement prescribed
@@ -233,7 +256,7 @@ BEAM_HD void seg_solve(const SegState<M>& s, const Acc& acc, const Vec2& uL, con
 #pragma unroll
     for (int i = 1; i < M; ++i) {
       acc.fence();
-      const Flags c = node_flags(fb, i);
+      const Flags<RZ> c = node_flags<RZ>(fb, i);
       const ElemK k = elem_k(acc.c2(i), acc.c6(i), acc.c12(i), acc.Ie(i));
       const double pw = acc.pw(i), mw = acc.mw(i);
       h[i] = mask_vec(Vec2{carry.x + pw + acc.Fy(i), carry.y + mw}, c);
@@ -252,7 +275,7 @@ BEAM_HD void seg_solve(const SegState<M>& s, const Acc& acc, const Vec2& uL, con
     const ElemK k = elem_k(acc.c2(i), acc.c6(i), acc.c12(i), acc.Ie(i));
     Vec2 ui;
     if (i > 0) {
-      const Mat2 Kr = mask_rows(Mat2{-k.kA, k.kB, -k.kB, k.kD}, node_flags(fb, i));
+      const Mat2 Kr = mask_rows(Mat2{-k.kA, k.kB, -k.kB, k.kD}, node_flags<RZ>(fb, i));
       ui = mul(s.Ginv[i], sub_mul(h[i], Kr, un));
     } else {
       ui = uL;

@@ -57,9 +57,13 @@ struct LdsAcc {
 
 template <int M>
 struct LaneOut {
-  double* sV; double* sM;   // LDS slots of the lane's elements
-  double v[M], th[M];       // nodal results stay in registers until the element rows are stored
-  __device__ __forceinline__ void elem(int i, double Vv, double Mv) { sV[i] = Vv; sM[i] = Mv; }
+  double* sV;               // LDS slots (flat, row stride Ne) of the lane's element shears
+  int nE;                   // how many of the lane's M elements exist (e0 + i < Ne)
+  double v[M], th[M], Mz[M];  // the rest stays in registers until the inputs in LDS are dead
+  __device__ __forceinline__ void elem(int i, double Vv, double Mv) {
+    if (i < nE) sV[i] = Vv;
+    Mz[i] = Mv;
+  }
   __device__ __forceinline__ void node(int i, double vv, double tt) { v[i] = vv; th[i] = tt; }
 };
 
@@ -142,52 +146,90 @@ __device__ __forceinline__ void pcr_all(IfaceRow& row, int lane, int j, int& bad
   }
 }
 
+// Stages 2-4 for one lane: condensation, interface reduction, interior solve.  RZ: see Flags<RZ>.
+template <int P, int M, bool RZ>
+__device__ __forceinline__ void solve_lanes(const LdsAcc& acc, int lane, int j, int& bad, LaneOut<M>& out) {
+  using X = Xch<P>;
+  SegState<M> st;
+  seg_condense<M, RZ>(st, acc, bad);
+  // The element data is re-read from LDS in the last stage instead of being carried in ~16*M VGPRs
+  // across the reduction: the clobber stops the compiler from merging the two sets of loads.
+  __asm__ volatile("" ::: "memory");
+  IfaceRow row;
+  {
+    const Mat2 cup = masked_cup<M, RZ>(st, acc.bits);
+    const Sym2 pc = X::template from_minus<1>(st.Scc, lane, j);
+    const Vec2 pg = X::template from_minus<1>(st.gc, lane, j);
+    const Mat2 pb = X::template from_minus<1>(cup, lane, j);
+    row = make_row<M, RZ>(st, cup, pc, pg, pb, acc.bits);
+  }
+  pcr_all<P, 1>(row, lane, j, bad);
+  const Vec2 uL = mul(inv_spd(row.D, bad), row.f);
+  const Vec2 uR = X::template from_plus<1>(uL, lane, j);
+  seg_solve<M, RZ>(st, acc, uL, uR, out);
+}
+
 // SHARED: x, E and wy are the same for every beam (strides 0): one LDS table per workgroup.
+//
+// LDS plan (one 64-lane wavefront per workgroup, BPW = 64/P beams):
+//   s_tab  unit-inertia element tile entries 2E/L, 6E/L^2, 12E/L^3, 1/L, wL/2, wL^2/12 per element
+//   s_a    I in padded rows [BPW][PM]            -> M (flat, row stride Ne) -> theta (flat, stride N)
+//   s_b    Fy flat (row stride N, as in HBM)     -> V (flat, row stride Ne) -> v     (flat, stride N)
+// Padding (nodes >= N, elements >= Ne, beams >= B) is a chain of unit elements on rollers behind a
+// zero-stiffness element: it keeps every pivot positive, touches no real DOF and needs no rotation fix.
+// waves per SIMD the register allocator is asked to leave room for (0 = no request)
+constexpr int waves_per_simd(int P, int M, bool shared) {
+  if (!shared) return 1;   // per-beam geometry tables make those variants LDS-limited anyway
+  return (P == 16 && M == 7) ? 3 : (P == 8 && M == 13) ? 2 : (P == 32 && M == 4) ? 4 : (P == 64 && M == 2) ? 4
+       : (P == 64 && M == 4) ? 3 : 1;
+}
+
 template <int P, int M, bool SHARED>
-__global__ __launch_bounds__(64) void beam_solve_kernel(const BeamParams p) {
+__global__ __launch_bounds__(64, waves_per_simd(P, M, SHARED)) void beam_solve_kernel(const BeamParams p) {
   constexpr int BPW = 64 / P;       // beams per wavefront
   constexpr int PM = P * M;         // padded nodes per beam (>= N)
   constexpr int TG = SHARED ? 1 : BPW;
+  constexpr int NPAIR = (BPW * PM / 2 + 63) / 64;   // 16-byte pieces per lane for one staged array
   __shared__ double s_tab[6][TG][PM];
-  __shared__ double s_a[BPW][PM];   // I      -> M  -> theta
-  __shared__ double s_b[BPW][PM];   // Fy     -> V  -> v
+  __shared__ __attribute__((aligned(16))) double s_a[BPW * PM];
+  __shared__ __attribute__((aligned(16))) double s_b[BPW * PM];
   __shared__ uint8_t s_fix[BPW][PM + 8];
-  __shared__ int s_bad[BPW];
 
   const int lane = threadIdx.x;
   const int Ne = p.Ne, N = p.Ne + 1;
   const long beam0 = (long)blockIdx.x * BPW;
-
-  constexpr int NPAIR = (BPW * PM / 2 + 63) / 64;   // 16-byte pieces per lane for one staged array
   const int nb = (p.B - beam0 < BPW) ? (int)(p.B - beam0) : BPW;   // live beams of this wave
+  const int nE = nb * Ne, nN = nb * N;
+
   // ---- stage 1a: issue the wave's global loads first (I, Fy rows of its beams: one contiguous run) ----
   double2 rI[NPAIR], rF[NPAIR];
   if (p.dense) {
     const double* gI = p.I + beam0 * Ne;
     const double* gF = p.Fy + beam0 * N;
-    const int nI = nb * Ne, nF = nb * N;
 #pragma unroll
     for (int k = 0; k < NPAIR; ++k) {
       const int i0 = 2 * (lane + 64 * k);
-      rI[k] = double2{0.0, 0.0};
+      rI[k] = double2{1.0, 1.0};
       rF[k] = double2{0.0, 0.0};
-      if (i0 + 1 < nI) rI[k] = *reinterpret_cast<const double2*>(gI + i0);
-      else if (i0 < nI) rI[k].x = gI[i0];
-      if (i0 + 1 < nF) rF[k] = *reinterpret_cast<const double2*>(gF + i0);
-      else if (i0 < nF) rF[k].x = gF[i0];
+      if (i0 + 1 < nE) rI[k] = *reinterpret_cast<const double2*>(gI + i0);
+      else if (i0 < nE) rI[k].x = gI[i0];
+      if (i0 + 1 < nN) rF[k] = *reinterpret_cast<const double2*>(gF + i0);
+      else if (i0 < nN) rF[k].x = gF[i0];
     }
   }
-  // zero fill (padding elements / nodes and dead beams); LDS ops of one wave execute in order
+  // padding defaults; LDS operations of one wave execute in order, so later writes win
   for (int idx = lane; idx < BPW * PM; idx += 64) {
-    (&s_a[0][0])[idx] = 0.0;
-    (&s_b[0][0])[idx] = 0.0;
+    s_a[idx] = 1.0;
+    s_b[idx] = 0.0;
   }
   // ---- stage 0: element table (unit-inertia stiffness tile entries, 1/L, UDL loads) ----
   for (int idx = lane; idx < TG * PM; idx += 64) {
     const int tb = idx / PM, e = idx - tb * PM;
     long bb = beam0 + tb;
     if (bb >= p.B) bb = p.B - 1;
-    double c2 = 0.0, c6 = 0.0, c12 = 0.0, rl = 0.0, pw = 0.0, mw = 0.0;
+    // defaults: element Ne has no stiffness, elements beyond it are unit elements (L = 1, EI = 1)
+    const bool pad = e > Ne;
+    double c2 = pad ? 2.0 : 0.0, c6 = pad ? 6.0 : 0.0, c12 = pad ? 12.0 : 0.0, rl = pad ? 1.0 : 0.0, pw = 0.0, mw = 0.0;
     if (e < Ne) {
       const double* xb = p.x + bb * p.x_bs;
       const double L = xb[e + 1] - xb[e];
@@ -203,29 +245,24 @@ __global__ __launch_bounds__(64) void beam_solve_kernel(const BeamParams p) {
     s_tab[0][tb][e] = c2;  s_tab[1][tb][e] = c6;  s_tab[2][tb][e] = c12;
     s_tab[3][tb][e] = rl;  s_tab[4][tb][e] = pw;  s_tab[5][tb][e] = mw;
   }
-  // ---- stage 1b: constraint bytes, then the staged rows into their padded LDS rows ----
+  // ---- stage 1b: constraint bytes (padding: roller), then the staged rows into LDS ----
 #pragma unroll
   for (int b = 0; b < BPW; ++b) {
     const bool live = b < nb;
     const uint8_t* fb = p.fix + (live ? beam0 + b : 0) * p.fix_bs;
-    for (int e = lane; e < PM + 8; e += 64) s_fix[b][e] = (live && e < N) ? (uint8_t)(fb[e] & 3) : (uint8_t)3;
+    for (int e = lane; e < PM + 8; e += 64) s_fix[b][e] = (live && e < N) ? (uint8_t)(fb[e] & 3) : (uint8_t)1;
   }
   if (p.dense) {
 #pragma unroll
     for (int k = 0; k < NPAIR; ++k) {
       const int i0 = 2 * (lane + 64 * k);
-      if (i0 < nb * Ne) {
+      if (i0 < nE) {   // padded rows: (beam, element) of flat index i0 by multiply-shift division
         const int b0 = (int)(((unsigned)i0 * p.magic_ne) >> 20), e = i0 - b0 * Ne;
-        s_a[b0][e] = rI[k].x;
-        if (e + 1 < Ne) s_a[b0][e + 1] = rI[k].y;
-        else if (b0 + 1 < nb) s_a[b0 + 1][0] = rI[k].y;
+        s_a[b0 * PM + e] = rI[k].x;
+        if (e + 1 < Ne) s_a[b0 * PM + e + 1] = rI[k].y;
+        else if (i0 + 1 < nE) s_a[(b0 + 1) * PM] = rI[k].y;
       }
-      if (i0 < nb * N) {
-        const int b0 = (int)(((unsigned)i0 * p.magic_n) >> 20), e = i0 - b0 * N;
-        s_b[b0][e] = rF[k].x;
-        if (e + 1 < N) s_b[b0][e + 1] = rF[k].y;
-        else if (b0 + 1 < nb) s_b[b0 + 1][0] = rF[k].y;
-      }
+      if (i0 < nN) *reinterpret_cast<double2*>(&s_b[i0]) = rF[k];   // flat, as in HBM
     }
   } else {
 #pragma unroll
@@ -234,136 +271,103 @@ __global__ __launch_bounds__(64) void beam_solve_kernel(const BeamParams p) {
       const double* Ib = p.I + (beam0 + b) * p.I_bs;
       const double* Fb = p.Fy + (beam0 + b) * p.Fy_bs;
       for (int e = lane; e < N; e += 64) {
-        if (e < Ne) s_a[b][e] = Ib[e];
-        s_b[b][e] = Fb[e];
+        if (e < Ne) s_a[b * PM + e] = Ib[e];
+        s_b[b * N + e] = Fb[e];
       }
     }
   }
-  if (lane < BPW) s_bad[lane] = 0;
   __syncthreads();
 
-  // ---- stage 2: per-lane condensation of the segment interior ----
+  // ---- stages 2-4: per-lane condensation, interface reduction, interior solve ----
   const int g = lane / P, j = lane - g * P, e0 = j * M;
   LdsAcc acc;
   {
     const int tb = SHARED ? 0 : g;
     acc.t2 = &s_tab[0][tb][e0];  acc.t6 = &s_tab[1][tb][e0];  acc.t12 = &s_tab[2][tb][e0];
     acc.trl = &s_tab[3][tb][e0]; acc.tpw = &s_tab[4][tb][e0]; acc.tmw = &s_tab[5][tb][e0];
-    acc.sI = &s_a[g][e0];
-    acc.sF = &s_b[g][e0];
+    acc.sI = &s_a[g * PM + e0];
+    acc.sF = &s_b[g * N + e0];
     unsigned long long bits = 0;
 #pragma unroll
     for (int i = 0; i <= M; ++i) bits |= (unsigned long long)s_fix[g][e0 + i] << (2 * i);
     acc.bits = bits;
   }
   int bad = 0;
-  SegState<M> st;
-  seg_condense<M>(st, acc, bad);
-  // The element data is re-read from LDS in stage 4 instead of being carried in ~16*M VGPRs
-  // across the reduction: the clobber stops the compiler from merging the two sets of loads.
-  __asm__ volatile("" ::: "memory");
-
-  // ---- stage 3: interface system over the P lanes of the beam, parallel cyclic reduction ----
-  using X = Xch<P>;
-  IfaceRow row;
-  {
-    const Mat2 cup = masked_cup<M>(st, acc.bits);
-    const Sym2 pc = X::template from_minus<1>(st.Scc, lane, j);
-    const Vec2 pg = X::template from_minus<1>(st.gc, lane, j);
-    const Mat2 pb = X::template from_minus<1>(cup, lane, j);
-    row = make_row<M>(st, cup, pc, pg, pb, acc.bits);
-  }
-  pcr_all<P, 1>(row, lane, j, bad);
-  const Vec2 uL = mul(inv_spd(row.D, bad), row.f);
-  const Vec2 uR = X::template from_plus<1>(uL, lane, j);
-
-  // ---- stage 4: interior solve + end forces; element rows out first ----
   LaneOut<M> out;
-  out.sV = &s_b[g][e0];
-  out.sM = &s_a[g][e0];
-  seg_solve<M>(st, acc, uL, uR, out);
-  if (bad) s_bad[g] = 1;
-  __syncthreads();
+  out.sV = &s_b[g * Ne + e0];
+  out.nE = Ne - e0;
+  const bool any_rz = __ballot((acc.bits & 0xAAAAAAAAAAAAAAAAull) != 0ull) != 0ull;   // wave-uniform
+  if (any_rz) solve_lanes<P, M, true>(acc, lane, j, bad, out);
+  else        solve_lanes<P, M, false>(acc, lane, j, bad, out);
 
+  // a beam is bad if any of its P lanes met a non-positive pivot; its outputs become NaN
+  const unsigned long long bal = __ballot(bad != 0);
+  const unsigned long long grp = (P == 64) ? ~0ull : (((1ull << (P % 64)) - 1ull) << (g * P));
+  const bool gbad = (bal & grp) != 0ull;
   const double qnan = __builtin_nan("");
-  // element rows (V in s_b, M in s_a) -> global
+  if (gbad) {
+#pragma unroll
+    for (int i = 0; i < M; ++i) {
+      out.v[i] = qnan; out.th[i] = qnan; out.Mz[i] = qnan;
+      if (i < out.nE) out.sV[i] = qnan;
+    }
+  }
+  if (j == 0 && g < nb && p.status) p.status[beam0 + g] = gbad ? 1 : 0;
+
+  // element rows: V already in s_b (flat, stride Ne); M joins it in s_a now that I is dead
+#pragma unroll
+  for (int i = 0; i < M; ++i)
+    if (i < out.nE) s_a[g * Ne + e0 + i] = out.Mz[i];
+  __syncthreads();
   if (p.dense) {
     double* gV = p.V + beam0 * Ne;
     double* gM = p.M + beam0 * Ne;
-    const int nE = nb * Ne;
 #pragma unroll
     for (int k = 0; k < NPAIR; ++k) {
       const int i0 = 2 * (lane + 64 * k);
-      if (i0 < nE) {
-        const int b0 = (int)(((unsigned)i0 * p.magic_ne) >> 20), e = i0 - b0 * Ne;
-        const bool wrap = e + 1 >= Ne;
-        const int b1 = wrap ? b0 + 1 : b0, e1 = wrap ? 0 : e + 1;
-        double2 vV{s_bad[b0] ? qnan : s_b[b0][e], 0.0}, vM{s_bad[b0] ? qnan : s_a[b0][e], 0.0};
-        if (i0 + 1 < nE) {
-          vV.y = s_bad[b1] ? qnan : s_b[b1][e1];
-          vM.y = s_bad[b1] ? qnan : s_a[b1][e1];
-          *reinterpret_cast<double2*>(gV + i0) = vV;
-          *reinterpret_cast<double2*>(gM + i0) = vM;
-        } else {
-          gV[i0] = vV.x;
-          gM[i0] = vM.x;
-        }
+      if (i0 + 1 < nE) {
+        *reinterpret_cast<double2*>(gV + i0) = *reinterpret_cast<const double2*>(&s_b[i0]);
+        *reinterpret_cast<double2*>(gM + i0) = *reinterpret_cast<const double2*>(&s_a[i0]);
+      } else if (i0 < nE) {
+        gV[i0] = s_b[i0];
+        gM[i0] = s_a[i0];
       }
     }
   } else {
-#pragma unroll
-    for (int b = 0; b < BPW; ++b) {
-      if (b >= nb) break;
-      const bool nbad = s_bad[b] != 0;
-      for (int e = lane; e < Ne; e += 64) {
-        p.V[(beam0 + b) * Ne + e] = nbad ? qnan : s_b[b][e];
-        p.M[(beam0 + b) * Ne + e] = nbad ? qnan : s_a[b][e];
-      }
+    for (int idx = lane; idx < nE; idx += 64) {
+      p.V[beam0 * Ne + idx] = s_b[idx];
+      p.M[beam0 * Ne + idx] = s_a[idx];
     }
   }
   __syncthreads();
-  // nodal rows: v -> s_b, theta -> s_a -> global
+  // nodal rows (flat, stride N)
 #pragma unroll
-  for (int i = 0; i < M; ++i) {
-    s_b[g][e0 + i] = out.v[i];
-    s_a[g][e0 + i] = out.th[i];
-  }
+  for (int i = 0; i < M; ++i)
+    if (e0 + i < N) {
+      s_b[g * N + e0 + i] = out.v[i];
+      s_a[g * N + e0 + i] = out.th[i];
+    }
   __syncthreads();
   if (p.dense) {
     double* gv = p.v + beam0 * N;
     double* gt = p.theta + beam0 * N;
-    const int nN = nb * N;
 #pragma unroll
     for (int k = 0; k < NPAIR; ++k) {
       const int i0 = 2 * (lane + 64 * k);
-      if (i0 < nN) {
-        const int b0 = (int)(((unsigned)i0 * p.magic_n) >> 20), e = i0 - b0 * N;
-        const bool wrap = e + 1 >= N;
-        const int b1 = wrap ? b0 + 1 : b0, e1 = wrap ? 0 : e + 1;
-        double2 vv{s_bad[b0] ? qnan : s_b[b0][e], 0.0}, vt{s_bad[b0] ? qnan : s_a[b0][e], 0.0};
-        if (i0 + 1 < nN) {
-          vv.y = s_bad[b1] ? qnan : s_b[b1][e1];
-          vt.y = s_bad[b1] ? qnan : s_a[b1][e1];
-          *reinterpret_cast<double2*>(gv + i0) = vv;
-          *reinterpret_cast<double2*>(gt + i0) = vt;
-        } else {
-          gv[i0] = vv.x;
-          gt[i0] = vt.x;
-        }
+      if (i0 + 1 < nN) {
+        *reinterpret_cast<double2*>(gv + i0) = *reinterpret_cast<const double2*>(&s_b[i0]);
+        *reinterpret_cast<double2*>(gt + i0) = *reinterpret_cast<const double2*>(&s_a[i0]);
+      } else if (i0 < nN) {
+        gv[i0] = s_b[i0];
+        gt[i0] = s_a[i0];
       }
     }
   } else {
-#pragma unroll
-    for (int b = 0; b < BPW; ++b) {
-      if (b >= nb) break;
-      const bool nbad = s_bad[b] != 0;
-      for (int e = lane; e < N; e += 64) {
-        p.v[(beam0 + b) * N + e] = nbad ? qnan : s_b[b][e];
-        p.theta[(beam0 + b) * N + e] = nbad ? qnan : s_a[b][e];
-      }
+    for (int idx = lane; idx < nN; idx += 64) {
+      p.v[beam0 * N + idx] = s_b[idx];
+      p.theta[beam0 * N + idx] = s_a[idx];
     }
   }
-  if (lane < nb && p.status) p.status[beam0 + lane] = s_bad[lane] ? 1 : 0;
 }
 
 // ------------------------------------------------------------------------------------------

@@ -34,13 +34,16 @@ struct HostOut {
   void node(int i, double a, double b) { v[i] = a; th[i] = b; }
 };
 
-template <int P, int M>
-int solve_one(int Ne, const double* x, const double* E, bool E_pe, const double* I, const uint8_t* fix,
+template <int P, int M, bool RZ>
+int solve_one_rz(int Ne, const double* x, const double* E, bool E_pe, const double* I, const uint8_t* fix,
               const double* Fy, const double* wy, bool w_pe, double* v, double* th, double* V, double* Mz) {
   constexpr int PM = P * M;
   const int N = Ne + 1;
-  std::vector<double> tab(6 * PM, 0.0), sI(PM, 0.0), sF(PM, 0.0), ov(PM), ot(PM), oV(PM), oM(PM);
-  std::vector<uint8_t> sfix(PM + 8, 3);
+  // same padding scheme as the kernel: element Ne has no stiffness, later elements are unit elements
+  // (I = 1) on rollers (fix = 1)
+  std::vector<double> tab(6 * PM, 0.0), sI(PM, 1.0), sF(PM, 0.0), ov(PM), ot(PM), oV(PM), oM(PM);
+  std::vector<uint8_t> sfix(PM + 8, 1);
+  for (int e = Ne + 1; e < PM; ++e) { tab[0 * PM + e] = 2.0; tab[1 * PM + e] = 6.0; tab[2 * PM + e] = 12.0; tab[3 * PM + e] = 1.0; }
   for (int e = 0; e < Ne; ++e) {
     const double L = x[e + 1] - x[e], rl = fast_rcp(L);
     const double Ee = E_pe ? E[e] : E[0], w = w_pe ? wy[e] : wy[0];
@@ -58,14 +61,14 @@ int solve_one(int Ne, const double* x, const double* E, bool E_pe, const double*
     acc[j] = HostAcc{&tab[0 * PM + e0], &tab[1 * PM + e0], &tab[2 * PM + e0], &tab[3 * PM + e0],
                      &tab[4 * PM + e0], &tab[5 * PM + e0], &sI[e0], &sF[e0], 0};
     for (int i = 0; i <= M; ++i) acc[j].bits |= (unsigned long long)sfix[e0 + i] << (2 * i);
-    seg_condense<M>(st[j], acc[j], bad);
+    seg_condense<M, RZ>(st[j], acc[j], bad);
   }
   std::vector<IfaceRow> row(P), nxt(P);
   std::vector<Mat2> cup(P);
   const Sym2 z3{0, 0, 0}; const Mat2 z4{0, 0, 0, 0}; const Vec2 z2{0, 0};
-  for (int j = 0; j < P; ++j) cup[j] = masked_cup<M>(st[j], acc[j].bits);
+  for (int j = 0; j < P; ++j) cup[j] = masked_cup<M, RZ>(st[j], acc[j].bits);
   for (int j = 0; j < P; ++j)
-    row[j] = make_row<M>(st[j], cup[j], j ? st[j - 1].Scc : z3, j ? st[j - 1].gc : z2, j ? cup[j - 1] : z4, acc[j].bits);
+    row[j] = make_row<M, RZ>(st[j], cup[j], j ? st[j - 1].Scc : z3, j ? st[j - 1].gc : z2, j ? cup[j - 1] : z4, acc[j].bits);
   for (int s = 1; s < P; s *= 2) {
     std::vector<Sym2> G(P);
     for (int j = 0; j < P; ++j) G[j] = inv_spd(row[j].D, bad);
@@ -86,11 +89,20 @@ int solve_one(int Ne, const double* x, const double* E, bool E_pe, const double*
   for (int j = 0; j < P; ++j) {
     const int e0 = j * M;
     HostOut out{&ov[e0], &ot[e0], &oV[e0], &oM[e0]};
-    seg_solve<M>(st[j], acc[j], u[j], j + 1 < P ? u[j + 1] : z2, out);
+    seg_solve<M, RZ>(st[j], acc[j], u[j], j + 1 < P ? u[j + 1] : z2, out);
   }
   for (int n = 0; n < N; ++n) { v[n] = bad ? NAN : ov[n]; th[n] = bad ? NAN : ot[n]; }
   for (int e = 0; e < Ne; ++e) { V[e] = bad ? NAN : oV[e]; Mz[e] = bad ? NAN : oM[e]; }
   return bad;
+}
+
+template <int P, int M>
+int solve_one(int Ne, const double* x, const double* E, bool E_pe, const double* I, const uint8_t* fix,
+              const double* Fy, const double* wy, bool w_pe, double* v, double* th, double* V, double* Mz) {
+  bool rz = false;   // the kernel takes the general path when any lane of the wave sees a fixed rotation
+  for (int n = 0; n <= Ne; ++n) rz |= (fix[n] & 2) != 0;
+  return rz ? solve_one_rz<P, M, true>(Ne, x, E, E_pe, I, fix, Fy, wy, w_pe, v, th, V, Mz)
+            : solve_one_rz<P, M, false>(Ne, x, E, E_pe, I, fix, Fy, wy, w_pe, v, th, V, Mz);
 }
 }  // namespace
 
