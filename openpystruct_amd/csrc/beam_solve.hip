@@ -16,6 +16,7 @@
 // contraction on this path).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/openpystruct_amd.h"
 #include "beam_math.hpp"
@@ -35,6 +36,7 @@ struct BeamParams {
   // host-derived: rows of I/Fy/outputs are dense and every wave's chunk is 16-byte aligned, so
   // the wave moves its beams as one flat run of 16-byte accesses; magic numbers for idx / Ne, idx / N
   int dense;
+  int stagger;
   unsigned magic_ne, magic_n;
 };
 
@@ -144,6 +146,16 @@ __device__ __forceinline__ void pcr_all(IfaceRow& row, int lane, int j, int& bad
     pcr_step<LAST>(row, Gm, Am, fm, Gp, Cp, fp);
     pcr_all<P, 2 * S>(row, lane, j, bad);
   }
+}
+
+// Orders LDS traffic inside ONE wavefront (the workgroup is a single wave): LDS instructions of a wave
+// execute in order, so all that is needed is to stop the compiler from moving LDS accesses across this
+// point and to have earlier LDS reads landed in registers.  Unlike __syncthreads() it does not wait for
+// outstanding global stores (vmcnt), which would serialise the store phases behind HBM write latency.
+__device__ __forceinline__ void wave_lds_fence() {
+  __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0) only
+  __asm__ volatile("" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
 }
 
 // Stages 2-4 for one lane: condensation, interface reduction, interior solve.  RZ: see Flags<RZ>.
@@ -277,6 +289,16 @@ __global__ __launch_bounds__(64, waves_per_simd(P, M, SHARED)) void beam_solve_k
     }
   }
   __syncthreads();
+  // Stagger the waves that share a SIMD: distinct issue priorities by hardware wave slot let one wave
+  // run ahead, so its output stores overlap the arithmetic of its neighbours instead of every wave of
+  // the (single-round) grid reaching the store phase at the same time.
+  if (p.stagger) {
+    const unsigned hwid = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | ((4 - 1) << 11));   // HW_REG_HW_ID[3:0] = wave slot
+    const unsigned slot = hwid & 3u;
+    if (slot == 0) __builtin_amdgcn_s_setprio(3);
+    else if (slot == 1) __builtin_amdgcn_s_setprio(2);
+    else if (slot == 2) __builtin_amdgcn_s_setprio(1);
+  }
 
   // ---- stages 2-4: per-lane condensation, interface reduction, interior solve ----
   const int g = lane / P, j = lane - g * P, e0 = j * M;
@@ -318,7 +340,7 @@ __global__ __launch_bounds__(64, waves_per_simd(P, M, SHARED)) void beam_solve_k
 #pragma unroll
   for (int i = 0; i < M; ++i)
     if (i < out.nE) s_a[g * Ne + e0 + i] = out.Mz[i];
-  __syncthreads();
+  wave_lds_fence();
   if (p.dense) {
     double* gV = p.V + beam0 * Ne;
     double* gM = p.M + beam0 * Ne;
@@ -339,7 +361,7 @@ __global__ __launch_bounds__(64, waves_per_simd(P, M, SHARED)) void beam_solve_k
       p.M[beam0 * Ne + idx] = s_a[idx];
     }
   }
-  __syncthreads();
+  wave_lds_fence();
   // nodal rows (flat, stride N)
 #pragma unroll
   for (int i = 0; i < M; ++i)
@@ -347,7 +369,7 @@ __global__ __launch_bounds__(64, waves_per_simd(P, M, SHARED)) void beam_solve_k
       s_b[g * N + e0 + i] = out.v[i];
       s_a[g * N + e0 + i] = out.th[i];
     }
-  __syncthreads();
+  wave_lds_fence();
   if (p.dense) {
     double* gv = p.v + beam0 * N;
     double* gt = p.theta + beam0 * N;
@@ -447,12 +469,13 @@ int ops_beam_solve_batched_f64(int B, int Ne, const double* x, long x_bstride, c
   if (!t) return tiling ? OPS_AMD_ERR_INVALID_ARG : OPS_AMD_ERR_UNSUPPORTED;
 
   BeamParams p{B, Ne, x, x_bstride, E, E_bstride, I, I_bstride, fix, fix_bstride, Fy, Fy_bstride,
-               wy, wy_bstride, v, theta, V, M, status, 0, 0u, 0u};
+               wy, wy_bstride, v, theta, V, M, status, 0, 0, 0u, 0u};
   {
     const int bpw = 64 / t->P;
     const uintptr_t bits = (uintptr_t)I | (uintptr_t)Fy | (uintptr_t)v | (uintptr_t)theta | (uintptr_t)V | (uintptr_t)M;
     p.dense = (I_bstride == Ne) && (Fy_bstride == Ne + 1) && ((bits & 15u) == 0) &&
               ((bpw * Ne) % 2 == 0) && ((bpw * (Ne + 1)) % 2 == 0);
+    { const char* e = getenv("OPS_AMD_STAGGER"); p.stagger = e ? atoi(e) : 1; }
     p.magic_ne = ((1u << 20) + (unsigned)Ne - 1u) / (unsigned)Ne;
     p.magic_n = ((1u << 20) + (unsigned)Ne) / (unsigned)(Ne + 1);
   }
