@@ -9,7 +9,8 @@ import ctypes
 import os
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "lib", "libopenpystruct_amd.so")
+# OPS_AMD_LIB lets A/B kernel experiments point at another build of the same C ABI
+LIB_PATH = os.environ.get("OPS_AMD_LIB") or os.path.join(_PKG, "lib", "libopenpystruct_amd.so")
 
 # every symbol include/openpystruct_amd.h declares
 EXPORTS = (

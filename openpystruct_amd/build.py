@@ -45,6 +45,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
            "-o", LIB + ".tmp"] + SOURCES
     if verbose:
         cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
+    cmd[1:1] = os.environ.get("OPS_AMD_EXTRA_HIPCC_FLAGS", "").split()   # e.g. -DOPS_AMD_TRACE (diagnostic build)
     subprocess.check_call(cmd)
     os.replace(LIB + ".tmp", LIB)
     return LIB

@@ -37,6 +37,7 @@ struct BeamParams {
   // the wave moves its beams as one flat run of 16-byte accesses; magic numbers for idx / Ne, idx / N
   int dense;
   int stagger;
+  unsigned long long* trace;   // diagnostic builds (-DOPS_AMD_TRACE) only
   unsigned magic_ne, magic_n;
 };
 
@@ -208,6 +209,9 @@ __global__ __launch_bounds__(64, waves_per_simd(P, M, SHARED)) void beam_solve_k
   __shared__ uint8_t s_fix[BPW][PM + 8];
 
   const int lane = threadIdx.x;
+#ifdef OPS_AMD_TRACE
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+#endif
   const int Ne = p.Ne, N = p.Ne + 1;
   const long beam0 = (long)blockIdx.x * BPW;
   const int nb = (p.B - beam0 < BPW) ? (int)(p.B - beam0) : BPW;   // live beams of this wave
@@ -289,6 +293,9 @@ __global__ __launch_bounds__(64, waves_per_simd(P, M, SHARED)) void beam_solve_k
     }
   }
   __syncthreads();
+#ifdef OPS_AMD_TRACE
+  const unsigned long long t1 = __builtin_amdgcn_s_memrealtime();
+#endif
   // Stagger the waves that share a SIMD: distinct issue priorities by hardware wave slot let one wave
   // run ahead, so its output stores overlap the arithmetic of its neighbours instead of every wave of
   // the (single-round) grid reaching the store phase at the same time.
@@ -336,6 +343,9 @@ __global__ __launch_bounds__(64, waves_per_simd(P, M, SHARED)) void beam_solve_k
   }
   if (j == 0 && g < nb && p.status) p.status[beam0 + g] = gbad ? 1 : 0;
 
+#ifdef OPS_AMD_TRACE
+  const unsigned long long t2 = __builtin_amdgcn_s_memrealtime();
+#endif
   // element rows: V already in s_b (flat, stride Ne); M joins it in s_a now that I is dead
 #pragma unroll
   for (int i = 0; i < M; ++i)
@@ -390,6 +400,14 @@ __global__ __launch_bounds__(64, waves_per_simd(P, M, SHARED)) void beam_solve_k
       p.theta[beam0 * N + idx] = s_a[idx];
     }
   }
+#ifdef OPS_AMD_TRACE
+  if (p.trace && lane == 0) {   // per-wave phase stamps (100 MHz clock) + hardware id, for scripts/trace_run.py
+    const unsigned long long t3 = __builtin_amdgcn_s_memrealtime();
+    const unsigned hw = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | ((16 - 1) << 11));
+    unsigned long long* q = p.trace + 5 * (unsigned long long)blockIdx.x;
+    q[0] = t0; q[1] = t1; q[2] = t2; q[3] = t3; q[4] = hw;
+  }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------
@@ -469,13 +487,16 @@ int ops_beam_solve_batched_f64(int B, int Ne, const double* x, long x_bstride, c
   if (!t) return tiling ? OPS_AMD_ERR_INVALID_ARG : OPS_AMD_ERR_UNSUPPORTED;
 
   BeamParams p{B, Ne, x, x_bstride, E, E_bstride, I, I_bstride, fix, fix_bstride, Fy, Fy_bstride,
-               wy, wy_bstride, v, theta, V, M, status, 0, 0, 0u, 0u};
+               wy, wy_bstride, v, theta, V, M, status, 0, 0, nullptr, 0u, 0u};
+#ifdef OPS_AMD_TRACE
+  { const char* e = getenv("OPS_AMD_TRACE_PTR"); if (e) p.trace = (unsigned long long*)strtoull(e, nullptr, 0); }
+#endif
   {
     const int bpw = 64 / t->P;
     const uintptr_t bits = (uintptr_t)I | (uintptr_t)Fy | (uintptr_t)v | (uintptr_t)theta | (uintptr_t)V | (uintptr_t)M;
     p.dense = (I_bstride == Ne) && (Fy_bstride == Ne + 1) && ((bits & 15u) == 0) &&
               ((bpw * Ne) % 2 == 0) && ((bpw * (Ne + 1)) % 2 == 0);
-    { const char* e = getenv("OPS_AMD_STAGGER"); p.stagger = e ? atoi(e) : 1; }
+    { const char* e = getenv("OPS_AMD_STAGGER"); p.stagger = e ? atoi(e) : 0; }
     p.magic_ne = ((1u << 20) + (unsigned)Ne - 1u) / (unsigned)Ne;
     p.magic_n = ((1u << 20) + (unsigned)Ne) / (unsigned)(Ne + 1);
   }
