@@ -79,6 +79,39 @@ int ops_beam_solve_batched_f64(int B, int Ne,
                                double* v, double* theta, double* V, double* M,
                                int32_t* status, int tiling, void* stream);
 
+/* Hyper-parameters of the per-case sizing optimiser (module-level constants of the reference,
+ * SingleCore.py:20-44): E, G = E / 2.6, alpha_moment = alpha_shear = 1e-2, lr = 0.01, gamma = 0.98,
+ * tolerance = 5e-3, patience = 5 (MultiCore: 10, GPU script: 1e-2 / 100), max_epochs = 600,
+ * clamp_min = 1e-8, bend_eps = 1e-6 (:195), area_coef = 0.03 (:196); Adam defaults of torch. */
+typedef struct ops_sizing_params {
+  double E, G;
+  double alpha_moment, alpha_shear;
+  double lr, gamma;
+  double beta1, beta2, adam_eps;
+  double clamp_min, bend_eps, area_coef;
+  double tolerance;
+  int32_t patience, max_epochs;
+} ops_sizing_params;
+
+/* One optimiser epoch for B cases (everything after the FE solve in the reference's epoch loop,
+ * SingleCore.py:189-219): float32 rounding of shear/moment, loss, gradient of the explicit I terms,
+ * Adam + ExponentialLR + clamp, early-stop bookkeeping.  Cases with active[b] == 0 are skipped.
+ *
+ *   I            [B,Ne] float32 in/out   the reference's I_tensor (:163)
+ *   I64          [B,Ne] float64 out      widened copy read by the next ops_beam_solve_batched_f64; NOT
+ *                                        refreshed for a case that stops in this call, so the solver keeps
+ *                                        reproducing that case's last solve (records lag I by one step, :239)
+ *   V, M         [B,Ne] float64 in       outputs of the solve of this epoch
+ *   exp_avg, exp_avg_sq [B,Ne] float32   Adam moments (zero-initialised by the caller)
+ *   best_loss    [B] float32 (init +inf), patience_cnt [B] int32 (init 0), epochs_run [B] int32 (init 0),
+ *   active       [B] uint8 (init 1): cleared when patience runs out or max_epochs is reached
+ *   last_loss    [B] float32 out, V32/M32 [B,Ne] float32 out: the recorded `shear_forces` / `bending_moments`
+ * Device pointers, asynchronous on `stream`, nothing allocated.  Ne <= 128. */
+int ops_beam_sizing_step_f32(int B, int Ne, float* I, double* I64, const double* V, const double* M,
+                             float* exp_avg, float* exp_avg_sq, float* best_loss, int32_t* patience_cnt,
+                             int32_t* epochs_run, uint8_t* active, float* last_loss, float* V32, float* M32,
+                             const ops_sizing_params* hp, void* stream);
+
 /* Largest Ne a build supports, ABI version, and the text of the last HIP error seen by
  * this thread (empty string if none). */
 int ops_amd_max_elements(void);

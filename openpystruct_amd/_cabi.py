@@ -15,6 +15,7 @@ LIB_PATH = os.environ.get("OPS_AMD_LIB") or os.path.join(_PKG, "lib", "libopenpy
 # every symbol include/openpystruct_amd.h declares
 EXPORTS = (
     "ops_beam_solve_batched_f64",
+    "ops_beam_sizing_step_f32",
     "ops_amd_max_elements",
     "ops_amd_abi_version",
     "ops_amd_last_error",
@@ -25,6 +26,13 @@ OK, ERR_INVALID_ARG, ERR_UNSUPPORTED, ERR_LAUNCH = 0, 1, 2, 3
 FIX_UY, FIX_RZ = 1, 2
 
 _lib = None
+
+
+class SizingParams(ctypes.Structure):
+    """Mirror of `ops_sizing_params` (include/openpystruct_amd.h)."""
+    _fields_ = [(n, ctypes.c_double) for n in (
+        "E", "G", "alpha_moment", "alpha_shear", "lr", "gamma", "beta1", "beta2", "adam_eps",
+        "clamp_min", "bend_eps", "area_coef", "tolerance")] + [("patience", ctypes.c_int32), ("max_epochs", ctypes.c_int32)]
 
 
 class ExtensionMissingError(RuntimeError):
@@ -49,6 +57,9 @@ def load():
     f = lib.ops_beam_solve_batched_f64
     f.restype = it
     f.argtypes = [it, it, vp, lg, vp, lg, vp, lg, vp, lg, vp, lg, vp, lg, vp, vp, vp, vp, vp, it, vp]
+    g = lib.ops_beam_sizing_step_f32
+    g.restype = it
+    g.argtypes = [it, it] + [vp] * 13 + [ctypes.POINTER(SizingParams), vp]
     lib.ops_amd_max_elements.restype = it
     lib.ops_amd_abi_version.restype = it
     lib.ops_amd_last_error.restype = ctypes.c_char_p

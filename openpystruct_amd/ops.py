@@ -1,0 +1,279 @@
+"""Per-case façade with the `openseespy.opensees` command names the reference calls.
+
+    import openpystruct_amd.ops as ops        # instead of: import openseespy.opensees as ops
+
+Covers exactly the subset `setup_model` + `generate_sample` use
+(/root/reference/OpenPyStruct_BeamOpt_training_SingleCore.py:93-124, :176-190, :224-232):
+wipe, model, node, fix, geomTransf, element('elasticBeamColumn'), timeSeries, pattern, load,
+eleLoad('-beamUniform'), system, numberer, constraints, integrator, algorithm, analysis, analyze,
+eleResponse(e, 'forces'), nodeDisp.  Semantics kept: one process-global domain, 1-based tags,
+`analyze` returns 0 on success and a non-zero code (never an exception) when the stiffness matrix is
+not positive definite, `eleResponse` returns a fresh list of 6 global end forces
+[Fx1, Fy1, Mz1, Fx2, Fy2, Mz2], `nodeDisp(node, dof)` a float (dof 1-based).
+
+The commands only RECORD the model; `analyze(1)` ships it to the GPU as a batch of one through the same
+C ABI as the batched operator (there is no CPU path).  For throughput use `deferred()`: models are
+queued by `analyze` and solved together by `flush()` in one launch -- the per-case API with the batched
+kernel underneath.
+
+Scope: straight beams along x (all nodes on one horizontal line, consecutive tags connected by
+consecutive elements), which is what `setup_model` builds.  Anything else raises NotImplementedError.
+"""
+from __future__ import annotations
+
+from contextlib import contextmanager
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+
+from .beam import beam_solve
+
+_ANALYZE_FAILED = -3   # what OpenSees' StaticAnalysis returns when the solver fails
+
+
+class _Domain:
+    def __init__(self):
+        self.ndm = self.ndf = None
+        self.nodes: Dict[int, tuple] = {}
+        self.fixes: Dict[int, tuple] = {}
+        self.elements: Dict[int, tuple] = {}     # tag -> (ni, nj, A, E, Iz)
+        self.loads: Dict[int, List[float]] = {}  # node -> [Fx, Fy, Mz]
+        self.ele_loads: Dict[int, tuple] = {}    # ele -> (Wy, Wx)
+        self.system = None
+        self.analysis = None
+        self.result = None                       # dict after a successful analyze
+        self.device = torch.device("cuda")
+
+
+_dom = _Domain()
+_queue: Optional[List[_Domain]] = None           # deferred mode
+
+
+def wipe():
+    global _dom
+    dev = _dom.device
+    _dom = _Domain()
+    _dom.device = dev
+
+
+def set_device(device):
+    _dom.device = torch.device(device)
+
+
+def model(*args):
+    a = list(args)
+    if a[:1] != ["basic"] or "-ndm" not in a or "-ndf" not in a:
+        raise ValueError("model('basic', '-ndm', 2, '-ndf', 3) expected")
+    _dom.ndm, _dom.ndf = int(a[a.index("-ndm") + 1]), int(a[a.index("-ndf") + 1])
+    if (_dom.ndm, _dom.ndf) != (2, 3):
+        raise NotImplementedError("only -ndm 2 -ndf 3 (the reference's model, SingleCore.py:93)")
+
+
+def node(tag, x, y):
+    _dom.nodes[int(tag)] = (float(x), float(y))
+
+
+def fix(tag, fx, fy, rz):
+    _dom.fixes[int(tag)] = (int(fx), int(fy), int(rz))
+
+
+def geomTransf(kind, tag, *rest):
+    if kind != "Linear":
+        raise NotImplementedError("geomTransf 'Linear' only (SingleCore.py:105)")
+
+
+def element(kind, tag, *args):
+    if kind != "elasticBeamColumn":
+        raise NotImplementedError("element 'elasticBeamColumn' only (SingleCore.py:107)")
+    ni, nj, A, E, Iz = args[:5]     # (ni, nj, A, E, Iz, transfTag)
+    _dom.elements[int(tag)] = (int(ni), int(nj), float(A), float(E), float(Iz))
+
+
+def timeSeries(kind, tag, *rest):
+    if kind != "Linear":
+        raise NotImplementedError("timeSeries 'Linear' only")
+
+
+def pattern(kind, tag, ts_tag, *rest):
+    if kind != "Plain":
+        raise NotImplementedError("pattern 'Plain' only")
+
+
+def load(node_tag, Fx, Fy, Mz):
+    v = _dom.loads.setdefault(int(node_tag), [0.0, 0.0, 0.0])
+    v[0] += float(Fx); v[1] += float(Fy); v[2] += float(Mz)
+
+
+def eleLoad(*args):
+    a = list(args)
+    if "-ele" not in a or "-type" not in a or "-beamUniform" not in a:
+        raise NotImplementedError("eleLoad('-ele', e, '-type', '-beamUniform', Wy, <Wx>) only (SingleCore.py:117)")
+    e = int(a[a.index("-ele") + 1])
+    vals = [float(t) for t in a[a.index("-beamUniform") + 1:]]
+    wy = vals[0]
+    wx = vals[1] if len(vals) > 1 else 0.0      # the SECOND value is the axial UDL
+    old = _dom.ele_loads.get(e, (0.0, 0.0))
+    _dom.ele_loads[e] = (old[0] + wy, old[1] + wx)
+
+
+def system(kind, *rest):
+    if kind not in ("BandSPD", "BandGeneral", "ProfileSPD", "FullGeneral", "UmfPack", "SparseGeneral"):
+        raise ValueError(kind)
+    _dom.system = kind
+
+
+def numberer(*a): pass
+def constraints(*a): pass
+def integrator(*a): pass
+def algorithm(*a): pass
+
+
+def analysis(kind):
+    if kind != "Static":
+        raise NotImplementedError("analysis 'Static' only")
+    _dom.analysis = kind
+
+
+def _arrays(d: _Domain):
+    tags = sorted(d.nodes)
+    N = len(tags)
+    if N < 2 or tags != list(range(1, N + 1)):
+        raise NotImplementedError("node tags must be 1..N")
+    xy = np.array([d.nodes[t] for t in tags])
+    if np.any(xy[:, 1] != xy[0, 1]) or np.any(np.diff(xy[:, 0]) <= 0):
+        raise NotImplementedError("straight beam along +x only (what setup_model builds)")
+    Ne = N - 1
+    if sorted(d.elements) != list(range(1, Ne + 1)) or any(d.elements[e][:2] != (e, e + 1) for e in d.elements):
+        raise NotImplementedError("element e must connect nodes e and e+1")
+    E = np.array([d.elements[e][3] for e in range(1, Ne + 1)])
+    A = np.array([d.elements[e][2] for e in range(1, Ne + 1)])
+    I = np.array([d.elements[e][4] for e in range(1, Ne + 1)])
+    fixb = np.zeros(N, dtype=np.uint8)
+    fx = np.zeros(N, dtype=bool)
+    for t, (a, b, c) in d.fixes.items():
+        fixb[t - 1] = (1 if b else 0) | (2 if c else 0)
+        fx[t - 1] = bool(a)
+    Fy = np.zeros(N); Fx = np.zeros(N); Mz = np.zeros(N)
+    for t, (a, b, c) in d.loads.items():
+        Fx[t - 1], Fy[t - 1], Mz[t - 1] = a, b, c
+    if np.any(Mz != 0.0):
+        raise NotImplementedError("nodal moments are not on the reference's path (ops.load(node, 0, F, 0), SingleCore.py:113)")
+    wy = np.array([d.ele_loads.get(e, (0.0, 0.0))[0] for e in range(1, Ne + 1)])
+    wx = np.array([d.ele_loads.get(e, (0.0, 0.0))[1] for e in range(1, Ne + 1)])
+    return dict(x=xy[:, 0], E=E, A=A, I=I, fix=fixb, fix_x=fx, Fy=Fy, Fx=Fx, wy=wy, wx=wx)
+
+
+def _axial(a, N):
+    """Axial sub-problem on the host: it decouples on a straight beam and the reference never reads it
+    (SURVEY fact 9); kept so that eleResponse(...)[0], [3] and nodeDisp(n, 1) are OpenSees-like.
+    Supported: exactly one node restrained in x (the pin of `setup_model`)."""
+    x, L = a["x"], np.diff(a["x"])
+    fixed = np.nonzero(a["fix_x"])[0]
+    if fixed.size != 1:
+        return None, None
+    k = int(fixed[0])
+    # tension T just right of node n / just left: integrate applied axial load from the free ends
+    q = a["wx"] * L                                   # total axial load per element
+    T_left = np.zeros(N - 1); T_right = np.zeros(N - 1)   # T at element ends 1 and 2
+    for e in range(N - 1):
+        if e >= k:    # right of the support: everything to the right hangs on this section
+            T_right[e] = q[e + 1:].sum() + a["Fx"][e + 1:].sum()
+            T_left[e] = T_right[e] + q[e]
+        else:         # left of the support
+            T_left[e] = -(q[:e].sum() + a["Fx"][:e + 1].sum())
+            T_right[e] = T_left[e] - q[e]
+    ux = np.zeros(N)
+    strain = 0.5 * (T_left + T_right) / (a["E"] * a["A"])
+    for e in range(k, N - 1):
+        ux[e + 1] = ux[e] + strain[e] * L[e]
+    for e in range(k - 1, -1, -1):
+        ux[e] = ux[e + 1] - strain[e] * L[e]
+    return (T_left, T_right), ux
+
+
+def _finish(d: _Domain, a, v, th, V, M, status):
+    if status != 0:
+        d.result = None
+        return _ANALYZE_FAILED
+    N = len(v)
+    L = np.diff(a["x"])
+    Fy2 = -V - a["wy"] * L
+    M2 = (V + 0.5 * a["wy"] * L) * L - M
+    T, ux = _axial(a, N)
+    Fx1 = -T[0] if T is not None else np.zeros(N - 1)
+    Fx2 = T[1] if T is not None else np.zeros(N - 1)
+    d.result = dict(v=v, th=th, ux=ux if ux is not None else np.zeros(N),
+                    forces=np.stack([Fx1, V, M, Fx2, Fy2, M2], axis=1))
+    return 0
+
+
+def analyze(n_steps=1):
+    """One linear static step (SingleCore.py:182).  Returns 0, or a non-zero code if the system is not SPD."""
+    d = _dom
+    if d.analysis != "Static":
+        return _ANALYZE_FAILED
+    a = _arrays(d)
+    if _queue is not None:
+        d._arrays = a
+        _queue.append(d)
+        return 0
+    dev = d.device
+    t = lambda z, dt=torch.float64: torch.as_tensor(np.ascontiguousarray(z), dtype=dt, device=dev)  # noqa: E731
+    sol = beam_solve(t(a["x"]), t(a["E"][None, :]), t(a["I"][None, :]), t(a["fix"], torch.uint8), t(a["Fy"][None, :]),
+                     t(a["wy"][None, :]))
+    st = int(sol.status[0])     # device sync: the per-case API hands results back as Python scalars
+    return _finish(d, a, sol.v[0].cpu().numpy(), sol.theta[0].cpu().numpy(), sol.V[0].cpu().numpy(),
+                   sol.M[0].cpu().numpy(), st)
+
+
+def eleResponse(ele_tag, what):
+    if what != "forces":
+        raise NotImplementedError("eleResponse(e, 'forces') only (SingleCore.py:189-190)")
+    if _dom.result is None:
+        raise RuntimeError("no committed state: analyze() has not succeeded")
+    return [float(f) for f in _dom.result["forces"][int(ele_tag) - 1]]
+
+
+def nodeDisp(node_tag, dof):
+    if _dom.result is None:
+        raise RuntimeError("no committed state: analyze() has not succeeded")
+    key = {1: "ux", 2: "v", 3: "th"}[int(dof)]
+    return float(_dom.result[key][int(node_tag) - 1])
+
+
+@contextmanager
+def deferred(device=None):
+    """Queue the models that `analyze` is called on and solve them in ONE launch at `flush()` / exit.
+
+        with ops.deferred() as batch:
+            for case in cases:
+                ops.wipe(); setup_model(...); ops.analysis('Static'); ops.analyze(1)
+        results = batch.domains          # each has .result like the global domain after analyze
+
+    All queued models must have the same number of nodes."""
+    global _queue
+
+    class _Batch:
+        domains: List[_Domain] = []
+        codes: List[int] = []
+
+    batch = _Batch()
+    _queue = []
+    try:
+        yield batch
+    finally:
+        q, _queue = _queue, None
+        if q:
+            dev = torch.device(device) if device is not None else q[0].device
+            arrs = [d._arrays for d in q]
+            N = len(arrs[0]["x"])
+            if any(len(a["x"]) != N for a in arrs):
+                raise NotImplementedError("deferred(): all models must have the same number of nodes")
+            st = lambda k: np.stack([a[k] for a in arrs])  # noqa: E731
+            t = lambda z, dt=torch.float64: torch.as_tensor(np.ascontiguousarray(z), dtype=dt, device=dev)  # noqa: E731
+            sol = beam_solve(t(st("x")), t(st("E")), t(st("I")), t(st("fix"), torch.uint8), t(st("Fy")), t(st("wy")))
+            v, th, V, M = (z.cpu().numpy() for z in (sol.v, sol.theta, sol.V, sol.M))
+            status = sol.status.cpu().numpy()
+            batch.domains = q
+            batch.codes = [_finish(d, a, v[i], th[i], V[i], M[i], int(status[i])) for i, (d, a) in enumerate(zip(q, arrs))]

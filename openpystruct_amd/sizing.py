@@ -1,0 +1,284 @@
+"""Batched dataset generation: the reference's `generate_sample` loop for thousands of cases at once.
+
+Mirrors /root/reference/OpenPyStruct_BeamOpt_training_SingleCore.py (and _MultiCore.py):
+  * module-level parameters                 :20-49   -> `SizingConfig` (same names, same defaults)
+  * case randomisation                      :133-160 -> `make_cases`
+  * per-epoch FE solve                      :176-190 -> `beam_solve`            (HIP kernel, csrc/beam_solve.hip)
+  * loss / backward / Adam / clamp / stop   :195-219 -> `ops_beam_sizing_step_f32` (HIP kernel, csrc/sizing_step.hip)
+  * record assembly                         :221-249 -> `generate_dataset` / `records_to_reference_json`
+
+All cases of a shard advance one epoch per (solve, step) pair; finished cases are frozen by the step
+kernel (their solver input is no longer refreshed), so no host round trip is needed per epoch.  The host
+only polls `active.any()` every `poll_every` epochs.  Multi-GPU: cases are independent, every rank owns a
+contiguous slice of the globally seeded case list and nothing is exchanged (MultiCore.py:258 does the
+same with processes).
+"""
+from __future__ import annotations
+
+import ctypes
+import json
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import _cabi
+from .beam import BeamSolution, beam_solve
+
+
+@dataclass
+class SizingConfig:
+    """The reference's module-level constants (SingleCore.py:20-49), same names and defaults."""
+    E: float = 200e9
+    nu: float = 0.3
+    A: float = 0.01
+    L_max: float = 200.0
+    num_nodes: int = 101
+    N_rollers_max: int = 4
+    M_forces_max: int = 4
+    L_min: float = 15
+    max_force: float = -355857.0
+    uniform_udl: float = -1000.0
+    I_0: float = 0.5
+    max_e: int = 600
+    lr: float = 0.01
+    gamma: float = 0.98
+    alpha_moment: float = 1e-2
+    alpha_shear: float = 1e-2
+    tolerance: float = 5e-3
+    patience: int = 5                 # SingleCore passes 5; MultiCore's default argument is 10 (MultiCore.py:130)
+    random_bridge: int = 0
+    roller_nodes: Tuple[int, ...] = (10, 30, 70, 85, 100)   # 1-based (SingleCore.py:62)
+    zero_last_node: bool = False      # MultiCore.py:222-223 forces the last node's rotation / deflection to 0.0
+
+    @property
+    def G(self) -> float:
+        return self.E / (2 * (1 + self.nu))
+
+    @property
+    def min_force(self) -> float:
+        return self.max_force / 10
+
+    @property
+    def num_elements(self) -> int:
+        return self.num_nodes - 1
+
+    def c_params(self) -> "_cabi.SizingParams":
+        return _cabi.SizingParams(
+            E=self.E, G=self.G, alpha_moment=self.alpha_moment, alpha_shear=self.alpha_shear, lr=self.lr,
+            gamma=self.gamma, beta1=0.9, beta2=0.999, adam_eps=1e-8, clamp_min=1e-8, bend_eps=1e-6,
+            area_coef=0.03, tolerance=self.tolerance, patience=self.patience, max_epochs=self.max_e)
+
+
+@dataclass
+class Cases:
+    """Host-side description of a list of cases (what SingleCore.py:133-160 draws per sample)."""
+    node_positions: np.ndarray            # [B, N] (every row equal when random_bridge == 0)
+    L: np.ndarray                         # [B]
+    roller_nodes: List[List[int]]         # 1-based ids per case
+    force_nodes: List[List[int]]
+    force_values: List[List[float]]
+    fix: np.ndarray = field(default=None)  # [B, N] uint8
+    Fy: np.ndarray = field(default=None)   # [B, N]
+
+    def __len__(self):
+        return len(self.roller_nodes)
+
+    def slice(self, lo: int, hi: int) -> "Cases":
+        return Cases(self.node_positions[lo:hi], self.L[lo:hi], self.roller_nodes[lo:hi], self.force_nodes[lo:hi],
+                     self.force_values[lo:hi], self.fix[lo:hi], self.Fy[lo:hi])
+
+
+def make_cases(n_cases: int, cfg: SizingConfig, seed: int = 20250307) -> Cases:
+    """Seeded restatement of the case randomisation (SingleCore.py:133-160).  The reference never seeds
+    `random`; here the WHOLE list is a pure function of (seed, n_cases) so that any sharding of it over
+    ranks gives the same dataset."""
+    rng = np.random.default_rng(seed)
+    N = cfg.num_nodes
+    xs = np.zeros((n_cases, N))
+    Ls = np.zeros(n_cases)
+    rollers, fnodes, fvals = [], [], []
+    fix = np.zeros((n_cases, N), dtype=np.uint8)
+    Fy = np.zeros((n_cases, N))
+    for b in range(n_cases):
+        if cfg.random_bridge == 1:
+            L = cfg.L_min + rng.uniform(0, cfg.L_max)                       # :134
+            avail = list(range(2, N))                                       # :138
+            nr = int(rng.integers(1, cfg.N_rollers_max + 1))                # :139
+            rs = [int(r) for r in rng.choice(avail, size=nr, replace=False)]  # :142-151
+            avail = [n for n in avail if n not in rs]
+        else:
+            L = cfg.L_max
+            rs = list(cfg.roller_nodes)                                     # :153
+            avail = [n for n in range(2, N) if n not in rs]                 # :63-66
+        k = min(int(rng.integers(1, cfg.M_forces_max + 1)), len(avail))     # :157-158
+        fn = [int(n) for n in rng.choice(avail, size=k, replace=False)]     # :159
+        fv = [float(f) for f in rng.uniform(cfg.max_force, cfg.min_force, size=k)]   # :160
+        xs[b] = np.linspace(0, L, N)
+        Ls[b] = L
+        fix[b, 0] = 1                                                       # ops.fix(1, 1, 1, 0), :100
+        for r in rs:
+            fix[b, r - 1] = 1                                               # ops.fix(r, 0, 1, 0), :102
+        for n, f in zip(fn, fv):
+            Fy[b, n - 1] += f                                               # ops.load(n, 0, F, 0), :113
+        rollers.append(rs)
+        fnodes.append(fn)
+        fvals.append(fv)
+    return Cases(xs, Ls, rollers, fnodes, fvals, fix, Fy)
+
+
+def shard_range(n_total: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous case range of `rank`: [rank*n/world, (rank+1)*n/world)."""
+    return (rank * n_total) // world, ((rank + 1) * n_total) // world
+
+
+class SizingState:
+    """Device-resident optimiser state of a shard (what the reference keeps per sample in Python objects)."""
+
+    def __init__(self, cases: Cases, cfg: SizingConfig, device: torch.device):
+        B, N = cases.Fy.shape
+        Ne = N - 1
+        f64 = dict(dtype=torch.float64, device=device)
+        f32 = dict(dtype=torch.float32, device=device)
+        self.B, self.N, self.Ne, self.cfg, self.device = B, N, Ne, cfg, device
+        shared_geom = cfg.random_bridge == 0
+        self.x = torch.as_tensor(cases.node_positions[0] if shared_geom else cases.node_positions, **f64).contiguous()
+        self.fix = torch.as_tensor(cases.fix[0] if shared_geom else cases.fix, dtype=torch.uint8, device=device).contiguous()
+        self.Fy = torch.as_tensor(cases.Fy, **f64).contiguous()
+        self.E = torch.tensor(cfg.E, **f64)
+        self.wy = torch.tensor(cfg.uniform_udl, **f64)
+        self.I = torch.full((B, Ne), cfg.I_0, **f32)                    # I_tensor, :163
+        self.I64 = self.I.double()
+        self.exp_avg = torch.zeros((B, Ne), **f32)
+        self.exp_avg_sq = torch.zeros((B, Ne), **f32)
+        self.best_loss = torch.full((B,), float("inf"), **f32)          # :170
+        self.patience_cnt = torch.zeros((B,), dtype=torch.int32, device=device)
+        self.epochs_run = torch.zeros((B,), dtype=torch.int32, device=device)
+        self.active = torch.ones((B,), dtype=torch.uint8, device=device)
+        self.last_loss = torch.zeros((B,), **f32)
+        self.V32 = torch.zeros((B, Ne), **f32)
+        self.M32 = torch.zeros((B, Ne), **f32)
+        self.sol: Optional[BeamSolution] = None
+        self._hp = cfg.c_params()
+
+    def epoch(self) -> None:
+        """One epoch for every case of the shard: FE solve (:176-190) then optimiser step (:195-219)."""
+        self.sol = beam_solve(self.x, self.E, self.I64, self.fix, self.Fy, self.wy, out=self.sol)
+        lib = _cabi.load()
+        with torch.cuda.device(self.device):
+            rc = lib.ops_beam_sizing_step_f32(
+                self.B, self.Ne, self.I.data_ptr(), self.I64.data_ptr(), self.sol.V.data_ptr(), self.sol.M.data_ptr(),
+                self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(), self.best_loss.data_ptr(),
+                self.patience_cnt.data_ptr(), self.epochs_run.data_ptr(), self.active.data_ptr(),
+                self.last_loss.data_ptr(), self.V32.data_ptr(), self.M32.data_ptr(), ctypes.byref(self._hp),
+                torch.cuda.current_stream(self.device).cuda_stream)
+        if rc != _cabi.OK:
+            raise RuntimeError(f"ops_beam_sizing_step_f32 failed with code {rc}")
+
+
+def optimize_cases(cases: Cases, cfg: SizingConfig, device, poll_every: int = 25, use_graph: bool = True) -> SizingState:
+    """Run the sizing loop of every case to its early stop (or max_e).  Returns the final device state."""
+    device = torch.device(device)
+    st = SizingState(cases, cfg, device)
+    if st.B == 0:
+        return st
+    epochs_done = 0
+    graph = None
+    if use_graph and poll_every > 1:
+        # the epoch body is launch-bound (two short kernels): replay `poll_every` epochs as one HIP graph
+        side = torch.cuda.Stream(device=device)
+        side.wait_stream(torch.cuda.current_stream(device))
+        with torch.cuda.stream(side):
+            st.epoch()                      # warm-up outside capture (allocates the solution buffers)
+            epochs_done = 1
+            side.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=side):
+                for _ in range(poll_every):
+                    st.epoch()
+        torch.cuda.current_stream(device).wait_stream(side)
+    while epochs_done < cfg.max_e:
+        if graph is not None:
+            graph.replay()
+            epochs_done += poll_every
+        else:
+            st.epoch()
+            epochs_done += 1
+            if epochs_done % poll_every:
+                continue
+        if not bool(st.active.any()):       # the only host sync, once per `poll_every` epochs
+            break
+    # a case that is still active here ran out of max_e inside the step kernel already (it clears `active`)
+    torch.cuda.synchronize(device)
+    return st
+
+
+RECORD_KEYS = ("roller_x_locations", "force_x_locations", "force_values", "I_values", "shear_forces",
+               "bending_moments", "node_positions", "roller_nodes", "force_nodes", "num_nodes", "L",
+               "rotations", "deflections")   # SingleCore.py:73-87
+
+
+def generate_dataset(n_cases: int, cfg: Optional[SizingConfig] = None, device="cuda", seed: int = 20250307,
+                     rank: int = 0, world: int = 1, poll_every: int = 25) -> Dict[str, object]:
+    """The reference's `main()` (SingleCore.py:251-264) for this rank's shard: returns the 13 record fields
+    (SingleCore.py:235-249) as tensors / lists, plus `epochs_run`, `status` and the global case ids."""
+    cfg = cfg or SizingConfig()
+    lo, hi = shard_range(n_cases, rank, world)
+    cases = make_cases(n_cases, cfg, seed).slice(lo, hi)
+    st = optimize_cases(cases, cfg, device, poll_every=poll_every)
+    sol = st.sol
+    rot, defl = sol.theta.clone(), sol.v.clone()
+    if cfg.zero_last_node:
+        rot[:, -1] = 0.0
+        defl[:, -1] = 0.0
+    xs = cases.node_positions
+    return {
+        "roller_x_locations": [[float(xs[b, n - 1]) for n in cases.roller_nodes[b]] for b in range(len(cases))],
+        "force_x_locations": [[float(xs[b, n - 1]) for n in cases.force_nodes[b]] for b in range(len(cases))],
+        "force_values": cases.force_values,
+        "I_values": st.I,                         # float32, AFTER the last Adam step (:239)
+        "shear_forces": st.V32,                   # float32, state of the last solve (:240)
+        "bending_moments": st.M32,
+        "node_positions": torch.as_tensor(xs),
+        "roller_nodes": cases.roller_nodes,
+        "force_nodes": cases.force_nodes,
+        "num_nodes": cfg.num_nodes,
+        "L": torch.as_tensor(cases.L),
+        "rotations": rot,
+        "deflections": defl,
+        "epochs_run": st.epochs_run,
+        "status": sol.status,
+        "case_ids": torch.arange(lo, hi),
+    }
+
+
+def records_to_reference_json(rec: Dict[str, object], path: str, drop_failed: bool = True) -> int:
+    """Writes the reference's wire format (SingleCore.py:73-87, :263-264): a JSON object of 13 parallel
+    lists.  `drop_failed` mirrors MultiCore.py:265 (samples whose analysis failed are filtered out)."""
+    B = len(rec["roller_nodes"])
+    status = rec["status"].cpu().numpy() if torch.is_tensor(rec["status"]) else np.zeros(B, dtype=np.int32)
+    keep = [b for b in range(B) if not (drop_failed and status[b] != 0)]
+
+    def rows(t):
+        a = t.detach().cpu().numpy()
+        return [a[b].tolist() for b in keep]
+
+    out = {
+        "roller_x_locations": [rec["roller_x_locations"][b] for b in keep],
+        "force_x_locations": [rec["force_x_locations"][b] for b in keep],
+        "force_values": [rec["force_values"][b] for b in keep],
+        "I_values": rows(rec["I_values"]),
+        "shear_forces": rows(rec["shear_forces"]),
+        "bending_moments": rows(rec["bending_moments"]),
+        "node_positions": rows(rec["node_positions"]),
+        "roller_nodes": [rec["roller_nodes"][b] for b in keep],
+        "force_nodes": [rec["force_nodes"][b] for b in keep],
+        "num_nodes": [int(rec["num_nodes"])] * len(keep),
+        "L": [float(rec["L"][b]) for b in keep],
+        "rotations": rows(rec["rotations"]),
+        "deflections": rows(rec["deflections"]),
+    }
+    with open(path, "w") as f:
+        json.dump(out, f)
+    return len(keep)

@@ -1,0 +1,133 @@
+"""GPU tests of the callers either side of the solve: the OpenSees-command shim (per-case API) and the
+batched sizing loop / dataset generator, against the per-case CPU restatement (oracle/sizing_oracle.py)."""
+import json
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+from oracle import beam_oracle as bo  # noqa: E402
+from oracle import sizing_oracle as so  # noqa: E402
+from tests.helpers import relerr  # noqa: E402
+from tests.test_host_logic import setup_model  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def oa():
+    if not torch.cuda.is_available():
+        pytest.fail("no GPU visible: -m gpu tests must run on the MI355X box")
+    import openpystruct_amd as oa_
+    from openpystruct_amd import _cabi
+    _cabi.load()
+    return oa_
+
+
+def test_ops_shim_drop_in_for_the_reference_epoch(oa):
+    """One epoch body of generate_sample (SingleCore.py:176-190, :224-232) through the shim."""
+    from openpystruct_amd import ops
+    x = np.linspace(0, 200, 101)
+    I = np.full(100, 0.5)
+    ops.wipe()
+    setup_model(I, x, bo.ROLLERS_REF, [50, 20], [-355857.0, -100000.0], bo.A_REF, bo.E_REF, -1000.0)
+    ops.analysis('Static')
+    assert ops.analyze(1) == 0
+    M = np.array([ops.eleResponse(i, 'forces')[2] for i in range(1, 101)])
+    V = np.array([ops.eleResponse(i, 'forces')[1] for i in range(1, 101)])
+    rot = np.array([ops.nodeDisp(i, 3) for i in range(1, 102)])
+    defl = np.array([ops.nodeDisp(i, 2) for i in range(1, 102)])
+    Fy = np.zeros(101); Fy[49] = -355857.0; Fy[19] = -100000.0
+    v, th, Vr, Mr, st = bo.solve_beam_dense(x, bo.E_REF, I, bo.reference_fix_mask(), Fy, -1000.0)
+    assert relerr(defl, v) < 1e-9 and relerr(rot, th) < 1e-9 and relerr(V, Vr) < 1e-8 and relerr(M, Mr) < 1e-8
+    np.testing.assert_allclose(V[:3], [36417.18, 34417.18, 32417.18], rtol=1e-6)   # SURVEY Appendix E probe
+    assert defl.min() == pytest.approx(-1.634e-2, rel=1e-3)
+
+
+def test_ops_shim_failure_code_and_deferred_batch(oa):
+    from openpystruct_amd import ops
+    x = np.linspace(0, 10, 11)
+    ops.wipe()
+    setup_model(np.full(10, -0.1), x, [11], [5], [-1.0], 0.01, 2e11, 0.0)     # negative inertia: not SPD
+    ops.analysis('Static')
+    assert ops.analyze(1) != 0                                               # a code, not an exception (MultiCore.py:182-186)
+    rng = np.random.default_rng(0)
+    with ops.deferred() as batch:
+        Is = []
+        for _ in range(7):
+            I = np.exp(rng.uniform(np.log(3e-3), np.log(0.75), size=10))
+            Is.append(I)
+            ops.wipe()
+            setup_model(I, x, [11], [5], [-1000.0], 0.01, 2e11, -10.0)
+            ops.analysis('Static')
+            assert ops.analyze(1) == 0
+    assert batch.codes == [0] * 7
+    for d, I in zip(batch.domains, Is):
+        fix = np.zeros(11, dtype=np.uint8); fix[0] = fix[10] = 1
+        Fy = np.zeros(11); Fy[4] = -1000.0
+        v, th, V, M, st = bo.solve_beam_dense(x, 2e11, I, fix, Fy, -10.0)
+        assert relerr(d.result["v"], v) < 1e-9 and relerr(d.result["forces"][:, 2], M) < 1e-8
+
+
+@pytest.mark.parametrize("patience", [5, 10])
+def test_sizing_loop_vs_per_case_oracle(oa, patience):
+    """Batched loop (HIP solve + HIP optimiser step) vs the reference's per-case torch-CPU loop restated in
+    oracle/sizing_oracle.py.  float32 optimiser arithmetic: sums are ordered differently on the GPU, so the
+    trajectories agree to float32 round-off accumulated over ~250 Adam steps, not bit for bit."""
+    from openpystruct_amd import sizing
+    cfg = sizing.SizingConfig(patience=patience)
+    n = 6
+    cases = sizing.make_cases(n, cfg, seed=123)
+    st = sizing.optimize_cases(cases, cfg, "cuda", poll_every=20)
+    I = st.I.cpu().numpy(); ep = st.epochs_run.cpu().numpy()
+    V32 = st.V32.cpu().numpy(); M32 = st.M32.cpu().numpy()
+    v = st.sol.v.cpu().numpy(); th = st.sol.theta.cpu().numpy()
+    assert int(st.active.sum()) == 0
+    for b in range(n):
+        ref = so.generate_sample(cases.node_positions[b], cases.roller_nodes[b], cases.force_nodes[b],
+                                 cases.force_values[b], patience=patience)
+        assert abs(int(ep[b]) - ref["epochs_run"]) <= 3, (ep[b], ref["epochs_run"])
+        if int(ep[b]) == ref["epochs_run"]:
+            Iref = np.array(ref["I_values"])
+            assert np.abs(I[b] - Iref).max() / Iref.max() < 2e-3
+            assert relerr(M32[b], np.array(ref["bending_moments"])) < 2e-3      # one-step lag state (SingleCore.py:239-241)
+            assert relerr(v[b], np.array(ref["deflections"])) < 5e-3
+            assert relerr(th[b], np.array(ref["rotations"])) < 5e-3
+    assert 150 < ep.mean() < 450                                               # ~237-255 epochs per sample
+
+
+def test_first_epochs_match_oracle_tightly(oa):
+    """Three optimiser steps from the common start I = 0.5: float32-level agreement with torch's Adam."""
+    from openpystruct_amd import sizing
+    cfg = sizing.SizingConfig(max_e=3)
+    cases = sizing.make_cases(4, cfg, seed=77)
+    st = sizing.optimize_cases(cases, cfg, "cuda", poll_every=1, use_graph=False)
+    assert (st.epochs_run.cpu().numpy() == 3).all() and int(st.active.sum()) == 0
+    for b in range(4):
+        ref = so.generate_sample(cases.node_positions[b], cases.roller_nodes[b], cases.force_nodes[b],
+                                 cases.force_values[b], max_e=3)
+        np.testing.assert_allclose(st.I[b].cpu().numpy(), np.array(ref["I_values"]), rtol=2e-6)
+        np.testing.assert_allclose(st.last_loss[b].item(), ref["final_loss"], rtol=2e-6)
+        # recorded responses belong to the solve BEFORE the last Adam step
+        assert relerr(st.M32[b].cpu().numpy(), np.array(ref["bending_moments"])) < 1e-6
+        assert relerr(st.sol.v[b].cpu().numpy(), np.array(ref["deflections"])) < 1e-6
+
+
+def test_generate_dataset_records_and_json(oa, tmp_path):
+    from openpystruct_amd import sizing
+    cfg = sizing.SizingConfig(max_e=40)
+    rec = sizing.generate_dataset(32, cfg, "cuda", seed=5)                      # BASELINE config 1: 32 cases
+    assert rec["I_values"].shape == (32, 100) and rec["I_values"].dtype == torch.float32
+    assert rec["deflections"].shape == (32, 101) and rec["deflections"].dtype == torch.float64
+    assert int(rec["status"].abs().sum()) == 0 and (rec["epochs_run"] > 0).all()
+    # shards reproduce the same records at any GPU count
+    a = sizing.generate_dataset(32, cfg, "cuda", seed=5, rank=1, world=4)
+    lo, hi = sizing.shard_range(32, 1, 4)
+    assert torch.equal(a["I_values"], rec["I_values"][lo:hi]) and torch.equal(a["deflections"], rec["deflections"][lo:hi])
+    path = str(tmp_path / "training_data_PINN_mini.json")
+    assert sizing.records_to_reference_json(rec, path) == 32
+    d = json.load(open(path))
+    assert tuple(d) == sizing.RECORD_KEYS and len(d["shear_forces"]) == 32 and len(d["rotations"][0]) == 101
+    # MultiCore quirk: last node zeroed (MultiCore.py:222-223)
+    z = sizing.generate_dataset(4, sizing.SizingConfig(max_e=5, zero_last_node=True), "cuda", seed=5)
+    assert float(z["deflections"][:, -1].abs().max()) == 0.0 and float(z["rotations"][:, -1].abs().max()) == 0.0

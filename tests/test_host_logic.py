@@ -1,0 +1,169 @@
+"""Host-side logic that needs no GPU: the OpenSees-command shim's model recording and result assembly,
+the seeded case generator, sharding (including a 2-process gloo run), the reference JSON wire format."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import beam_oracle as bo
+from openpystruct_amd import ops, sizing
+
+
+def setup_model(I_values, node_positions, roller_nodes, force_nodes, force_values, A, E, uniform_udl):
+    """Re-typed command sequence of the reference's setup_model (SingleCore.py:89-124), driving the shim."""
+    ops.model('basic', '-ndm', 2, '-ndf', 3)
+    for i, x in enumerate(node_positions):
+        ops.node(i + 1, x, 0.0)
+    ops.fix(1, 1, 1, 0)
+    for n in roller_nodes:
+        ops.fix(n, 0, 1, 0)
+    ops.geomTransf('Linear', 1)
+    for i in range(len(node_positions) - 1):
+        ops.element('elasticBeamColumn', i + 1, i + 1, i + 2, A, E, float(I_values[i]), 1)
+    ops.timeSeries('Linear', 1)
+    ops.pattern('Plain', 1, 1)
+    for n, f in zip(force_nodes, force_values):
+        ops.load(n, 0.0, f, 0.0)
+    for e in range(1, len(node_positions)):
+        ops.eleLoad('-ele', e, '-type', '-beamUniform', uniform_udl, uniform_udl)
+    ops.system('BandSPD'); ops.numberer('RCM'); ops.constraints('Plain')
+    ops.integrator('LoadControl', 1.0); ops.algorithm('Linear')
+
+
+def test_shim_records_the_reference_model():
+    ops.wipe()
+    x = np.linspace(0, 200, 101)
+    setup_model(np.full(100, 0.5), x, bo.ROLLERS_REF, [50, 20], [-355857.0, -1e5], bo.A_REF, bo.E_REF, -1000.0)
+    a = ops._arrays(ops._dom)
+    assert (a["fix"] == bo.reference_fix_mask()).all() and a["fix_x"].sum() == 1 and a["fix_x"][0]
+    assert a["Fy"][49] == -355857.0 and a["Fy"][19] == -1e5 and a["Fy"].sum() == -455857.0
+    assert (a["wy"] == -1000.0).all() and (a["wx"] == -1000.0).all()     # Wx = Wy quirk, SingleCore.py:117
+    assert a["I"].shape == (100,) and (a["E"] == bo.E_REF).all()
+
+
+def test_shim_result_assembly_matches_3dof_oracle():
+    """eleResponse 6-vectors and nodeDisp(n, 1|2|3) assembled from (v, theta, V, M) == OpenSees-like 3-DOF oracle."""
+    ops.wipe()
+    rng = np.random.default_rng(3)
+    x = np.linspace(0, 200, 101)
+    I = np.exp(rng.uniform(np.log(3e-3), np.log(0.75), size=100))
+    setup_model(I, x, bo.ROLLERS_REF, [50, 20, 77], [-355857.0, -1e5, -5e4], bo.A_REF, bo.E_REF, -1000.0)
+    a = ops._arrays(ops._dom)
+    v, th, V, M, st = bo.solve_beam_dense(x, bo.E_REF, I, a["fix"], a["Fy"], -1000.0)
+    assert ops._finish(ops._dom, a, v, th, V, M, 0) == 0
+    d, f, st3, neq, kd = bo.solve_reference_beam_3dof(x, bo.A_REF, bo.E_REF, I, bo.ROLLERS_REF, [50, 20, 77],
+                                                      [-355857.0, -1e5, -5e4], -1000.0)
+    for e in (1, 2, 37, 100):
+        got = np.array(ops.eleResponse(e, 'forces'))
+        np.testing.assert_allclose(got, f[e - 1], rtol=2e-7, atol=1e-3)
+    for n in (1, 2, 50, 101):
+        assert ops.nodeDisp(n, 2) == pytest.approx(d[n - 1, 1], rel=1e-8, abs=1e-15)
+        assert ops.nodeDisp(n, 3) == pytest.approx(d[n - 1, 2], rel=1e-8, abs=1e-15)
+        assert ops.nodeDisp(n, 1) == pytest.approx(d[n - 1, 0], rel=1e-8, abs=1e-15)
+    assert isinstance(ops.eleResponse(1, 'forces'), list) and ops.eleResponse(1, 'forces') is not ops.eleResponse(1, 'forces')
+
+
+def test_shim_failed_analyze_is_a_code_not_an_exception():
+    ops.wipe()
+    x = np.linspace(0, 10, 11)
+    setup_model(np.full(10, 0.1), x, [11], [5], [-1.0], 0.01, 2e11, 0.0)
+    a = ops._arrays(ops._dom)
+    rc = ops._finish(ops._dom, a, None, None, None, None, 1)
+    assert rc != 0
+    with pytest.raises(RuntimeError):
+        ops.nodeDisp(1, 2)
+
+
+def test_shim_rejects_what_is_not_on_the_path():
+    ops.wipe()
+    with pytest.raises(NotImplementedError):
+        ops.model('basic', '-ndm', 3, '-ndf', 6)
+    with pytest.raises(NotImplementedError):
+        ops.element('truss', 1, 1, 2, 1.0, 1.0)
+    with pytest.raises(NotImplementedError):
+        ops.eleResponse(1, 'stress')
+
+
+def test_make_cases_distribution_and_determinism():
+    cfg = sizing.SizingConfig()
+    a = sizing.make_cases(500, cfg, seed=1)
+    b = sizing.make_cases(500, cfg, seed=1)
+    assert (a.Fy == b.Fy).all() and a.force_nodes == b.force_nodes
+    k = np.array([len(f) for f in a.force_nodes])
+    assert k.min() >= 1 and k.max() <= 4 and set(k) == {1, 2, 3, 4}
+    vals = np.concatenate([np.array(f) for f in a.force_values])
+    assert vals.min() >= cfg.max_force and vals.max() <= cfg.min_force
+    forbidden = set(cfg.roller_nodes) | {1, 101}                    # SingleCore.py:63-66: range(2, num_nodes) minus rollers
+    assert all(not (set(f) & forbidden) and len(set(f)) == len(f) for f in a.force_nodes)
+    assert (a.fix[0] == bo.reference_fix_mask()).all()
+    # random_bridge = 1 (SingleCore.py:133-151)
+    c = sizing.make_cases(200, sizing.SizingConfig(random_bridge=1), seed=2)
+    assert c.L.min() >= 15 and c.L.max() <= 215
+    nr = np.array([len(r) for r in c.roller_nodes])
+    assert nr.min() >= 1 and nr.max() <= 4
+    assert all(not (set(f) & set(r)) for f, r in zip(c.force_nodes, c.roller_nodes))
+
+
+def test_shard_ranges_partition_the_cases():
+    for n, w in [(10, 3), (50000, 8), (7, 8), (32, 1)]:
+        rs = [sizing.shard_range(n, r, w) for r in range(w)]
+        assert rs[0][0] == 0 and rs[-1][1] == n and all(rs[i][1] == rs[i + 1][0] for i in range(w - 1))
+    full = sizing.make_cases(64, sizing.SizingConfig(), seed=5)
+    lo, hi = sizing.shard_range(64, 1, 4)
+    part = full.slice(lo, hi)
+    assert (part.Fy == full.Fy[lo:hi]).all() and part.force_nodes == full.force_nodes[lo:hi]
+
+
+def _gloo_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n = 37
+    lo, hi = sizing.shard_range(n, rank, world)
+    cases = sizing.make_cases(n, sizing.SizingConfig(), seed=9).slice(lo, hi)
+    mine = torch.zeros(n, dtype=torch.float64)
+    mine[lo:hi] = torch.as_tensor(cases.Fy.sum(axis=1))
+    dist.all_reduce(mine)                                  # test-only gather; the data path itself has no collective
+    q.put((rank, mine.numpy()))
+    dist.destroy_process_group()
+
+
+def test_two_rank_shards_reassemble_the_global_case_list():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29000 + os.getpid() % 2000
+    ps = [ctx.Process(target=_gloo_worker, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in ps]
+    outs = [q.get(timeout=120) for _ in ps]
+    [p.join(60) for p in ps]
+    ref = sizing.make_cases(37, sizing.SizingConfig(), seed=9).Fy.sum(axis=1)
+    for _, got in outs:
+        np.testing.assert_array_equal(got, ref)
+
+
+def test_reference_json_wire_format(tmp_path):
+    cfg = sizing.SizingConfig()
+    cases = sizing.make_cases(5, cfg, seed=4)
+    B, N = cases.Fy.shape
+    rec = {
+        "roller_x_locations": [[float(cases.node_positions[b, n - 1]) for n in cases.roller_nodes[b]] for b in range(B)],
+        "force_x_locations": [[float(cases.node_positions[b, n - 1]) for n in cases.force_nodes[b]] for b in range(B)],
+        "force_values": cases.force_values,
+        "I_values": torch.rand(B, N - 1), "shear_forces": torch.rand(B, N - 1), "bending_moments": torch.rand(B, N - 1),
+        "node_positions": torch.as_tensor(cases.node_positions), "roller_nodes": cases.roller_nodes,
+        "force_nodes": cases.force_nodes, "num_nodes": N, "L": torch.as_tensor(cases.L),
+        "rotations": torch.rand(B, N, dtype=torch.float64), "deflections": torch.rand(B, N, dtype=torch.float64),
+        "status": torch.tensor([0, 0, 1, 0, 0], dtype=torch.int32),
+    }
+    path = str(tmp_path / "training_data_PINN_mini.json")
+    kept = sizing.records_to_reference_json(rec, path)
+    assert kept == 4                                                     # failed sample dropped (MultiCore.py:265)
+    d = json.load(open(path))
+    assert tuple(d.keys()) == sizing.RECORD_KEYS                         # SingleCore.py:73-87
+    assert all(len(d[k]) == 4 for k in d)
+    assert d["roller_x_locations"][0] == [18.0, 58.0, 138.0, 168.0, 198.0]
+    assert len(d["I_values"][0]) == 100 and len(d["deflections"][0]) == 101 and d["num_nodes"][0] == 101
