@@ -1,0 +1,173 @@
+"""Dataset -> model tensors for the surrogate training loops (PINN and Transformer-Diffusion).
+
+Tensor-native restatement of the data-prep block the reference copy-pastes into every model script
+(/root/reference/OpenPyStruct_PINN_MultiCase.py:66-120, :198-388;
+ /root/reference/OpenPyStruct_TransformerDiffusionModule_MultiCase.py:72-189, :240-371):
+pad -> group `n_cases` consecutive samples -> permutation split -> per-column standardisation ->
+`mean + c * std` label aggregation over the cases of a group -> standardised targets.
+
+Differences that are deliberate: everything stays in torch tensors on the device the
+records live on (no numpy / sklearn round trip, no per-batch host-to-device copies later), the split
+permutation is seeded, and the standardisation moments can be all-reduced over a process group so that
+every rank of a data-parallel job scales with the GLOBAL statistics although it only holds its shard.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Sequence
+
+import torch
+import torch.distributed as dist
+
+
+def pad_sequences(seqs: Sequence[Sequence[float]], max_length: int, pad_val: float = 0.0) -> torch.Tensor:
+    """Ragged lists -> [len(seqs), max_length] float32 (PINN:66-76)."""
+    out = torch.full((len(seqs), max_length), pad_val, dtype=torch.float32)
+    for i, s in enumerate(seqs):
+        t = torch.as_tensor(s, dtype=torch.float32)[:max_length]
+        out[i, : t.numel()] = t
+    return out
+
+
+def unify_label_with_c(y3: torch.Tensor, c: float = 0.5) -> torch.Tensor:
+    """[G, n_cases, M] -> [G, M]: mean over the cases + c * population std (PINN:79-92)."""
+    return y3.mean(dim=1) + c * y3.std(dim=1, unbiased=False)
+
+
+class StandardScalerT:
+    """Column-wise (x - mean) / std with sklearn's conventions (population variance, zero-variance columns
+    are left unscaled).  `fit` optionally all-reduces count / sum / sum of squares over `group`."""
+
+    def __init__(self):
+        self.mean_: Optional[torch.Tensor] = None
+        self.scale_: Optional[torch.Tensor] = None
+
+    def fit(self, x2: torch.Tensor, group=None, distributed: bool = False) -> "StandardScalerT":
+        x = x2.double()
+        stats = torch.cat([torch.tensor([float(x.shape[0])], dtype=torch.float64, device=x.device), x.sum(0), (x * x).sum(0)])
+        if distributed and dist.is_available() and dist.is_initialized():
+            dist.all_reduce(stats, group=group)
+        n, s, ss = stats[0], stats[1: 1 + x.shape[1]], stats[1 + x.shape[1]:]
+        mean = s / n
+        var = (ss / n - mean * mean).clamp_min(0.0)
+        scale = var.sqrt()
+        # sklearn's _handle_zeros_in_scale: (near-)constant columns keep scale 1
+        scale = torch.where(scale < 10 * torch.finfo(torch.float64).eps * mean.abs().clamp_min(1.0), torch.ones_like(scale), scale)
+        self.mean_, self.scale_ = mean.float(), scale.float()
+        return self
+
+    def transform(self, x: torch.Tensor) -> torch.Tensor:
+        return (x - self.mean_.to(x.device)) / self.scale_.to(x.device)
+
+    def inverse_transform(self, x: torch.Tensor) -> torch.Tensor:
+        return x * self.scale_.to(x.device) + self.mean_.to(x.device)
+
+    def fit_transform_3d(self, x3: torch.Tensor, **kw) -> torch.Tensor:
+        """Fit over the flattened (group, case) axis and transform (PINN:94-108)."""
+        G, C, M = x3.shape
+        self.fit(x3.reshape(G * C, M), **kw)
+        return self.transform(x3.reshape(G * C, M)).reshape(G, C, M)
+
+
+@dataclass
+class SurrogateData:
+    X_train: torch.Tensor      # PINN: [G, n_cases*feat]; TFD: [G, n_cases, feat_padded]
+    Y_train: torch.Tensor      # PINN: [G, nelem + 2*(nelem+1)]; TFD: [G, nelem]
+    X_val: torch.Tensor
+    Y_val: torch.Tensor
+    scalers_inputs: Dict[str, StandardScalerT]
+    scalers_Y: Dict[str, StandardScalerT]
+    min_constraint: torch.Tensor   # 0-dim: min / max of the standardised I targets (PINN:377-378)
+    max_constraint: torch.Tensor
+    feat_dim: int
+    max_lengths: Dict[str, int]
+
+
+INPUT_KEYS = ("roller_x_locations", "force_x_locations", "force_values", "node_positions")   # PINN:198-201
+
+
+def _as_rows(v, width=None) -> torch.Tensor:
+    if torch.is_tensor(v):
+        return v.float()
+    w = width if width is not None else max(len(r) for r in v)
+    return pad_sequences(v, w)
+
+
+def prepare(records: Dict[str, object], *, kind: str = "pinn", n_cases: int = 6, c: float = 0.5, train_split: float = 0.8,
+            nheads: int = 8, seed: int = 0, device=None, distributed: bool = False, group=None,
+            refit_val_scalers: Optional[bool] = None, max_lengths: Optional[Dict[str, int]] = None) -> SurrogateData:
+    """records: the 13-field dataset (lists as in the reference JSON, or tensors from `generate_dataset`).
+
+    kind = "pinn": flat inputs, targets [I, deflections, rotations] (PINN:337-369)
+    kind = "tfd" : sequence inputs padded to a multiple of `nheads`, targets I only (TFD:330-371); the
+                   reference re-fits the input scalers on the validation split (TFD:325-328) -- kept behind
+                   `refit_val_scalers` (default True for "tfd", False for "pinn").
+    With `distributed=True` every rank passes ITS shard of records; moments and constraints are all-reduced."""
+    assert kind in ("pinn", "tfd")
+    if refit_val_scalers is None:
+        refit_val_scalers = kind == "tfd"
+    ml = dict(max_lengths or {})
+    feats = {}
+    for k, short in zip(INPUT_KEYS, ("roller_x", "force_x", "force_values", "node_positions")):
+        v = records[k]
+        if short not in ml:
+            ml[short] = int(v.shape[1]) if torch.is_tensor(v) else max(len(r) for r in v)
+        feats[short] = _as_rows(v, ml[short])
+    if distributed and dist.is_available() and dist.is_initialized():   # agree on the padded widths
+        w = torch.tensor([ml[s] for s in ("roller_x", "force_x", "force_values", "node_positions")], device=device or "cpu")
+        dist.all_reduce(w, op=dist.ReduceOp.MAX, group=group)
+        for s, val in zip(("roller_x", "force_x", "force_values", "node_positions"), w.tolist()):
+            if val != ml[s]:
+                feats[s] = torch.nn.functional.pad(feats[s], (0, val - ml[s]))
+                ml[s] = val
+    I = _as_rows(records["I_values"])
+    targets = {"I": I}
+    if kind == "pinn":
+        targets["deflections"] = _as_rows(records["deflections"])
+        targets["rotations"] = _as_rows(records["rotations"])
+    dev = torch.device(device) if device is not None else I.device
+    S = I.shape[0]
+    G = S // n_cases
+    if G == 0:
+        raise ValueError(f"n_cases={n_cases} > total samples={S}")      # PINN:228-229
+
+    def grouped(t):
+        return t[: G * n_cases].to(dev).reshape(G, n_cases, -1)
+
+    feats = {k: grouped(v) for k, v in feats.items()}
+    targets = {k: grouped(v) for k, v in targets.items()}
+    gen = torch.Generator().manual_seed(seed)
+    perm = torch.randperm(G, generator=gen).to(dev)                      # PINN:261 (unseeded there)
+    n_tr = int(train_split * G)
+    tr, va = perm[:n_tr], perm[n_tr:]
+    kw = dict(distributed=distributed, group=group)
+
+    sc_in = {k: StandardScalerT() for k in feats}
+    Xtr = torch.cat([sc_in[k].fit_transform_3d(feats[k][tr], **kw) for k in feats], dim=2)     # PINN:291-331
+    if refit_val_scalers:
+        Xva = torch.cat([StandardScalerT().fit_transform_3d(feats[k][va], **kw) for k in feats], dim=2)
+    else:
+        Xva = torch.cat([sc_in[k].transform(feats[k][va]) for k in feats], dim=2)
+    feat_dim = Xtr.shape[2]
+    if kind == "pinn":
+        Xtr, Xva = Xtr.reshape(Xtr.shape[0], -1), Xva.reshape(Xva.shape[0], -1)               # PINN:337-338
+    else:
+        pad = (-feat_dim) % nheads                                                             # TFD:170-189
+        if pad:
+            Xtr = torch.nn.functional.pad(Xtr, (0, pad))
+            Xva = torch.nn.functional.pad(Xva, (0, pad))
+        feat_dim += pad
+
+    sc_Y, Ytr, Yva = {}, [], []
+    for k, t in targets.items():
+        ytr, yva = unify_label_with_c(t[tr], c), unify_label_with_c(t[va], c)                   # PINN:341-350
+        sc_Y[k] = StandardScalerT().fit(ytr, **kw)                                              # PINN:353-355
+        Ytr.append(sc_Y[k].transform(ytr))
+        Yva.append(sc_Y[k].transform(yva))
+    nel = targets["I"].shape[2]
+    Ytr, Yva = torch.cat(Ytr, dim=1), torch.cat(Yva, dim=1)
+    mn, mx = Ytr[:, :nel].min(), Ytr[:, :nel].max()                                             # PINN:377-378
+    if distributed and dist.is_available() and dist.is_initialized():
+        dist.all_reduce(mn, op=dist.ReduceOp.MIN, group=group)
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX, group=group)
+    return SurrogateData(Xtr.contiguous(), Ytr.contiguous(), Xva.contiguous(), Yva.contiguous(), sc_in, sc_Y, mn, mx, feat_dim, ml)

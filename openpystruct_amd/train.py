@@ -1,0 +1,208 @@
+"""Data-parallel training loops of the two surrogates (one process per GPU, RCCL all-reduce over xGMI).
+
+Restates the reference's single-device loops
+(/root/reference/OpenPyStruct_PINN_MultiCase.py:741-852,
+ /root/reference/OpenPyStruct_TransformerDiffusionModule_MultiCase.py:722-829):
+per epoch: decaying input noise, shuffled batches, in-batch permutation, autocast forward, loss,
+backward, clip_grad_norm_(1.0), Adam step; then a validation pass, ExponentialLR step, early stopping on
+the validation loss with best-state checkpointing; finally R^2 of the un-standardised inertias.
+
+What is different, and why (DESIGN.md "Training loops"):
+  * bf16 autocast without a GradScaler instead of fp16 + GradScaler (BASELINE config 4; MI355X bf16 MFMA);
+  * the dataset is resident on the GPU: no per-batch host-to-device copies (PINN:749-750) and no per-step
+    `.item()` (PINN:770) -- losses are accumulated on the device and reduced once per epoch;
+  * DistributedDataParallel with ONE gradient bucket (the models are 1.4 - 2.4 MB: a single RCCL all-reduce
+    per step, latency-bound over xGMI) and weak scaling: every rank trains on its own shard with the
+    reference's per-GPU batch size;
+  * early-stop decisions are taken on all-reduced losses, so every rank stops at the same epoch.
+BatchNorm statistics are per rank (as per process in the reference); pass sync_bn=True for SyncBatchNorm.
+"""
+from __future__ import annotations
+
+import copy
+import time
+from dataclasses import dataclass
+from typing import Dict, Optional
+
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+from torch.optim.lr_scheduler import ExponentialLR
+
+from .dataprep import SurrogateData
+from .surrogates import CompositeLoss, FNNWithResidual, ModelOnePassTransformerWithDiffusion, TrainableL1L2Loss
+
+
+@dataclass
+class PinnConfig:
+    """PINN:35-56."""
+    n_cases: int = 6
+    nelem: int = 100
+    box_constraint_coeff: float = 1e-1
+    hidden_units: int = 350
+    dropout_rate: float = 0.5
+    num_blocks: int = 2
+    num_epochs: int = 500
+    batch_size: int = 128
+    patience: int = 10
+    learning_rate: float = 5e-4
+    weight_decay: float = 1e-3
+    train_split: float = 0.8
+    sigma_0: float = 0.01
+    gamma_noise: float = 0.99
+    gamma: float = 0.98
+    initial_alpha: float = 0.5
+    c: float = 0.5
+    penalty_pinn: float = 1.5e-6
+
+
+@dataclass
+class TfdConfig:
+    """TFD:36-60."""
+    n_cases: int = 6
+    nelem: int = 100
+    box_constraint_coeff: float = 5e-1
+    hidden_units: int = 256
+    dropout_rate: float = 0.1
+    num_epochs: int = 500
+    batch_size: int = 512
+    patience: int = 10
+    learning_rate: float = 3e-3
+    weight_decay: float = 1e-4
+    train_split: float = 0.8
+    sigma_0: float = 0.01
+    gamma_noise: float = 0.90
+    gamma: float = 0.95
+    initial_alpha: float = 0.5
+    c: float = 0.5
+    num_transformer_layers: int = 2
+    dim_feedforward: int = 256
+    num_heads: int = 8
+    max_len: int = 512
+    diffusion_hidden_dim: int = 256
+    diffusion_T: int = 512
+
+
+def build_model_and_loss(kind: str, cfg, data: SurrogateData, device):
+    if kind == "pinn":
+        out_dim = cfg.nelem + 2 * (cfg.nelem + 1)
+        model = FNNWithResidual(data.X_train.shape[1], cfg.hidden_units, cfg.num_blocks, out_dim, cfg.dropout_rate)   # PINN:687-693
+        crit = CompositeLoss(cfg.nelem, cfg.nelem + 1, cfg.nelem + 1, cfg.initial_alpha, cfg.box_constraint_coeff,
+                             data.min_constraint, data.max_constraint, cfg.penalty_pinn)                              # PINN:698-699
+    elif kind == "tfd":
+        model = ModelOnePassTransformerWithDiffusion(cfg.n_cases, data.feat_dim, cfg.nelem, cfg.hidden_units,
+                                                     cfg.num_transformer_layers, cfg.num_heads, cfg.dim_feedforward,
+                                                     cfg.dropout_rate, cfg.max_len, cfg.diffusion_hidden_dim, cfg.diffusion_T)  # TFD:664-676
+        crit = TrainableL1L2Loss(cfg.initial_alpha, data.min_constraint, data.max_constraint, cfg.box_constraint_coeff)       # TFD:680
+    else:
+        raise ValueError(kind)
+    return model.to(device), crit.to(device)
+
+
+def r2_score(y_true: torch.Tensor, y_pred: torch.Tensor) -> float:
+    """sklearn.metrics.r2_score on the raveled arrays (PINN:851)."""
+    yt, yp = y_true.double().reshape(-1), y_pred.double().reshape(-1)
+    ss_res = ((yt - yp) ** 2).sum()
+    ss_tot = ((yt - yt.mean()) ** 2).sum()
+    return float(1.0 - ss_res / ss_tot)
+
+
+def _allreduce_mean(t: torch.Tensor, world: int) -> torch.Tensor:
+    if world > 1:
+        dist.all_reduce(t)
+        t /= world
+    return t
+
+
+def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, autocast_dtype=torch.bfloat16,
+                    sync_bn: bool = False, max_epochs: Optional[int] = None, log=None, seed: int = 0) -> Dict[str, object]:
+    """Trains on THIS rank's `data` shard; uses DDP when torch.distributed is initialised with world_size > 1.
+    Returns history, best state dict, validation R^2 (I only) and per-epoch times."""
+    cfg = cfg or (PinnConfig() if kind == "pinn" else TfdConfig())
+    device = torch.device(device)
+    world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+    rank = dist.get_rank() if world > 1 else 0
+    torch.manual_seed(seed)            # identical initial weights on every rank
+    model, crit = build_model_and_loss(kind, cfg, data, device)
+    if sync_bn and world > 1:
+        model = nn.SyncBatchNorm.convert_sync_batchnorm(model)
+    net = model
+    if world > 1:
+        net = nn.parallel.DistributedDataParallel(
+            model, device_ids=[device.index] if device.type == "cuda" else None,
+            bucket_cap_mb=8, gradient_as_bucket_view=True)     # one bucket: the whole model is < 2.4 MB
+    torch.manual_seed(seed + 1 + rank)  # different noise / shuffles per rank
+    opt = torch.optim.Adam(model.parameters(), lr=cfg.learning_rate, weight_decay=cfg.weight_decay)   # loss.alpha NOT included (PINN:696)
+    sched = ExponentialLR(opt, gamma=cfg.gamma)
+    Xtr, Ytr, Xva, Yva = (t.to(device) for t in (data.X_train, data.Y_train, data.X_val, data.Y_val))
+    nb_tr = max(1, (Xtr.shape[0] + cfg.batch_size - 1) // cfg.batch_size)
+    if world > 1:   # every rank must run the same number of steps (collectives inside backward)
+        t = torch.tensor([nb_tr], device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        nb_tr = int(t.item())
+    use_ac = device.type == "cuda" and autocast_dtype is not None
+    hist = {"train": [], "val": [], "epoch_s": []}
+    best_val, best_state, no_improve = float("inf"), None, 0
+    n_epochs = max_epochs if max_epochs is not None else cfg.num_epochs
+    for epoch in range(1, n_epochs + 1):
+        if device.type == "cuda":
+            torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        net.train()
+        noise = cfg.sigma_0 * (cfg.gamma_noise ** epoch)                     # PINN:743
+        order = torch.randperm(Xtr.shape[0], device=device)                  # DataLoader(shuffle=True), PINN:701
+        tot = torch.zeros((), device=device)
+        for b in range(nb_tr):
+            idx = order[b * cfg.batch_size:(b + 1) * cfg.batch_size]
+            idx = idx[torch.randperm(idx.numel(), device=device)]           # permute_data, PINN:753
+            Xb, Yb = Xtr[idx], Ytr[idx]
+            Xb = Xb + torch.randn_like(Xb) * noise                           # PINN:756
+            opt.zero_grad(set_to_none=True)
+            with torch.autocast(device_type=device.type, dtype=autocast_dtype, enabled=use_ac):
+                preds = net(Xb)
+                loss = crit(preds.float(), Yb)
+                if kind == "tfd":
+                    loss = loss + (cfg.initial_alpha - crit.alpha) ** 2       # TFD:743 (constant 0: alpha never trains)
+            loss.backward()                                                  # DDP: bucketed RCCL all-reduce overlaps here
+            torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)          # PINN:766
+            opt.step()
+            tot += loss.detach()
+        train_loss = _allreduce_mean(tot / nb_tr, world)
+        net.eval()
+        vt = torch.zeros((), device=device)
+        nb_va = max(1, (Xva.shape[0] + cfg.batch_size - 1) // cfg.batch_size)
+        with torch.no_grad(), torch.autocast(device_type=device.type, dtype=autocast_dtype, enabled=use_ac):
+            for b in range(nb_va):
+                sl = slice(b * cfg.batch_size, (b + 1) * cfg.batch_size)
+                vt += crit(model(Xva[sl]).float(), Yva[sl])
+        val_loss = _allreduce_mean(vt / nb_va, world)
+        sched.step()                                                         # PINN:788
+        tl, vl = float(train_loss), float(val_loss)                          # the epoch's only host syncs
+        if device.type == "cuda":
+            torch.cuda.synchronize(device)
+        hist["train"].append(tl); hist["val"].append(vl); hist["epoch_s"].append(time.perf_counter() - t0)
+        if vl < best_val:                                                    # PINN:791-799
+            best_val, no_improve = vl, 0
+            best_state = copy.deepcopy(model.state_dict())
+        else:
+            no_improve += 1
+        if log and rank == 0:
+            log(f"Epoch {epoch}/{n_epochs} | Train Loss={tl:.6f}, Val Loss={vl:.6f}, Time={hist['epoch_s'][-1]:.2f}s")
+        if no_improve >= cfg.patience:
+            break
+    if best_state is not None:
+        model.load_state_dict(best_state)
+    model.eval()
+    with torch.no_grad():
+        preds = torch.cat([model(Xva[i:i + cfg.batch_size]).float() for i in range(0, Xva.shape[0], cfg.batch_size)])
+    nel = cfg.nelem
+    sI = data.scalers_Y["I"]
+    p = sI.inverse_transform(preds[:, :nel]).clamp(0.0, 1e10)                # PINN:843-848
+    t = sI.inverse_transform(Yva[:, :nel]).clamp(0.0, 1e10)
+    return {"model": model, "history": hist, "best_val": best_val, "best_state": best_state, "r2_val_I": r2_score(t, p),
+            "epochs": len(hist["train"]), "steps_per_epoch": nb_tr}
+
+
+def save_best(state: Dict[str, torch.Tensor], path: str) -> None:
+    """`torch.save(model.state_dict(), "best_model_*.pth")` (PINN:794, TFD:777)."""
+    torch.save(state, path)

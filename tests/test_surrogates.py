@@ -1,0 +1,170 @@
+"""Surrogate models, losses, data prep and the data-parallel loop on CPU (gloo for the 2-rank cases)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from openpystruct_amd import dataprep, sizing, surrogates, train
+
+
+def _fake_records(S=120, seed=0):
+    """A dataset with the reference's 13-field shape (fixed bridge) without running the FE generator."""
+    cfg = sizing.SizingConfig()
+    cases = sizing.make_cases(S, cfg, seed=seed)
+    g = torch.Generator().manual_seed(seed)
+    xs = cases.node_positions
+    return {
+        "roller_x_locations": [[float(xs[b, n - 1]) for n in cases.roller_nodes[b]] for b in range(S)],
+        "force_x_locations": [[float(xs[b, n - 1]) for n in cases.force_nodes[b]] for b in range(S)],
+        "force_values": cases.force_values,
+        "node_positions": torch.as_tensor(xs),
+        "I_values": torch.rand(S, 100, generator=g) * 0.5 + 0.01,
+        "deflections": torch.randn(S, 101, generator=g, dtype=torch.float64) * 1e-2,
+        "rotations": torch.randn(S, 101, generator=g, dtype=torch.float64) * 1e-3,
+    }
+
+
+def test_parameter_counts_and_state_dict_names():
+    pinn = surrogates.FNNWithResidual(684, 350, 2, 302)
+    assert surrogates.count_parameters(pinn) == 593914
+    keys = set(pinn.state_dict())
+    for k in ("input_fc.weight", "input_norm.running_mean", "residual_blocks.0.0.fc1.weight", "residual_blocks.0.0.conv1.weight",
+              "residual_blocks.0.0.bn1.weight", "residual_blocks.1.1.weight", "output_fc.bias"):
+        assert k in keys
+    tfd = surrogates.ModelOnePassTransformerWithDiffusion(6, 120, 100)
+    assert surrogates.count_parameters(tfd) == 359876
+    keys = set(tfd.state_dict())
+    for k in ("diffusion.mlp.0.weight", "diffusion.mlp.2.bias", "pos_encoder.pe", "cls_token", "fc1.weight", "norm1.weight", "fc2.bias",
+              "transformer_encoder.layers.1.self_attn.in_proj_weight", "transformer_encoder.layers.0.linear2.weight"):
+        assert k in keys
+    assert tuple(tfd(torch.randn(5, 6, 120)).shape) == (5, 100)
+    assert tuple(pinn(torch.randn(5, 684)).shape) == (5, 302)
+    with pytest.raises(AssertionError):
+        tfd(torch.randn(5, 7, 120))                                        # TFD:550-551
+
+
+def test_losses_against_hand_computed_values():
+    p = torch.tensor([[0.0, 2.0, -3.0]]); t = torch.tensor([[1.0, 1.0, 1.0]])
+    crit = surrogates.TrainableL1L2Loss(0.5, torch.tensor(-1.0), torch.tensor(1.5), 0.1)
+    l1 = (1 + 1 + 4) / 3; l2 = (1 + 1 + 16) / 3; pen = (2.0 - 1.5) + (-1.0 + 3.0)
+    assert float(crit(p, t).detach()) == pytest.approx(0.5 * l1 + 0.5 * l2 + 0.1 * pen, rel=1e-6)
+    assert [n for n, _ in crit.named_parameters()] == ["alpha"]           # a Parameter the optimiser never sees (PINN:696)
+    comp = surrogates.CompositeLoss(1, 1, 1, 0.5, 0.0, None, None, penalty_pinn=2.0)
+    val = comp(p, t)   # I: |0-1|; deflection rel |2-1|/1; rotation rel |-3-1|/1
+    assert float(val) == pytest.approx(0.5 * 1 + 0.5 * 1 + 2.0 * (1.0 + 4.0), rel=1e-6)
+
+
+def test_positional_encoding_and_schedule():
+    pe = surrogates.PositionalEncoding(7, max_len=16)                      # odd d_model: last column stays 0
+    assert float(pe.pe[0, :, 6].abs().max()) == 0.0 and float(pe.pe[0, 0, 1]) == 1.0
+    s = surrogates.DiffusionSchedule(512)
+    assert float(s.beta[0]) == pytest.approx(1e-12) and float(s.beta[-1]) == pytest.approx(1e-5)
+    assert 0.997 < float(s.alpha_cumprod[-1]) < 1.0
+
+
+def test_scaler_matches_sklearn_and_numpy():
+    from sklearn.preprocessing import StandardScaler
+    rng = np.random.default_rng(0)
+    a = rng.normal(size=(50, 7)).astype(np.float32); a[:, 3] = 2.5     # zero-variance column
+    sk = StandardScaler().fit(a)
+    mine = dataprep.StandardScalerT().fit(torch.as_tensor(a))
+    np.testing.assert_allclose(mine.transform(torch.as_tensor(a)).numpy(), sk.transform(a), rtol=1e-5, atol=1e-6)
+    y3 = torch.as_tensor(rng.normal(size=(9, 6, 4)).astype(np.float32))
+    ref = y3.numpy().mean(axis=1) + 0.5 * y3.numpy().std(axis=1)          # PINN:79-92
+    np.testing.assert_allclose(dataprep.unify_label_with_c(y3, 0.5).numpy(), ref, rtol=1e-5, atol=1e-6)
+    assert tuple(dataprep.pad_sequences([[1, 2], [3]], 4).shape) == (2, 4)
+
+
+def test_prepare_shapes_pinn_and_tfd():
+    rec = _fake_records(120)
+    d = dataprep.prepare(rec, kind="pinn", seed=1)
+    assert d.X_train.shape == (16, 684) and d.Y_train.shape == (16, 302) and d.X_val.shape == (4, 684)   # 5+4+4+101 = 114; x6
+    assert d.max_lengths == {"roller_x": 5, "force_x": 4, "force_values": 4, "node_positions": 101}
+    assert float(d.min_constraint) == float(d.Y_train[:, :100].min())
+    t = dataprep.prepare(rec, kind="tfd", seed=1)
+    assert t.X_train.shape == (16, 6, 120) and t.Y_train.shape == (16, 100) and t.feat_dim == 120         # padded to 8 heads
+    assert float(t.X_train[:, :, 114:].abs().max()) == 0.0
+    with pytest.raises(ValueError):
+        dataprep.prepare(_fake_records(4), kind="pinn")
+
+
+@pytest.mark.parametrize("kind", ["pinn", "tfd"])
+def test_training_loop_runs_and_early_stops(kind):
+    rec = _fake_records(240, seed=3)
+    d = dataprep.prepare(rec, kind=kind, seed=2)
+    cfg = train.PinnConfig(batch_size=16, patience=2) if kind == "pinn" else train.TfdConfig(batch_size=16, patience=2)
+    out = train.train_surrogate(kind, d, cfg, device="cpu", autocast_dtype=None, max_epochs=4)
+    assert 1 <= out["epochs"] <= 4 and len(out["history"]["val"]) == out["epochs"]
+    assert np.isfinite(out["history"]["train"]).all() and np.isfinite(out["r2_val_I"])
+    assert out["best_state"] is not None and set(out["best_state"]) == set(out["model"].state_dict())
+
+
+def _ddp_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(0)
+    model = surrogates.FNNWithResidual(24, 16, 1, 10, dropout_rate=0.0, use_conv=False, norm_type="layer")   # no BatchNorm: batch statistics are per rank
+    crit = surrogates.CompositeLoss(4, 3, 3, 0.5, 0.0, None, None)         # mean-type terms only
+    X = torch.randn(8, 24, generator=torch.Generator().manual_seed(1)); Y = torch.randn(8, 10, generator=torch.Generator().manual_seed(2))
+    ddp = torch.nn.parallel.DistributedDataParallel(model, bucket_cap_mb=8)
+    sl = slice(rank * 4, rank * 4 + 4)
+    crit(ddp(X[sl]), Y[sl]).backward()
+    g = torch.cat([p.grad.reshape(-1) for p in model.parameters()])
+    # scaler moments all-reduced over the two shards == moments of the whole array
+    sc = dataprep.StandardScalerT().fit(X[sl], distributed=True)
+    q.put((rank, g.numpy(), sc.mean_.numpy(), sc.scale_.numpy()))
+    dist.destroy_process_group()
+
+
+def test_ddp_gradients_equal_single_process_on_concatenated_batch():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31000 + os.getpid() % 2000
+    ps = [ctx.Process(target=_ddp_worker, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in ps]
+    outs = [q.get(timeout=180) for _ in ps]
+    [p.join(60) for p in ps]
+    torch.manual_seed(0)
+    model = surrogates.FNNWithResidual(24, 16, 1, 10, dropout_rate=0.0, use_conv=False, norm_type="layer")   # no BatchNorm: batch statistics are per rank
+    crit = surrogates.CompositeLoss(4, 3, 3, 0.5, 0.0, None, None)
+    X = torch.randn(8, 24, generator=torch.Generator().manual_seed(1)); Y = torch.randn(8, 10, generator=torch.Generator().manual_seed(2))
+    crit(model(X), Y).backward()
+    g = torch.cat([p.grad.reshape(-1) for p in model.parameters()]).numpy()
+    from sklearn.preprocessing import StandardScaler
+    sk = StandardScaler().fit(X.numpy())
+    for _, gr, mean, scale in outs:
+        np.testing.assert_allclose(gr, g, rtol=1e-4, atol=1e-6)
+        np.testing.assert_allclose(mean, sk.mean_, rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(scale, sk.scale_, rtol=1e-5, atol=1e-6)
+
+
+def _ddp_train_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rec = _fake_records(240, seed=3)
+    lo, hi = sizing.shard_range(240, rank, world)
+    shard = {k: (v[lo:hi] if torch.is_tensor(v) else v[lo:hi]) for k, v in rec.items()}
+    d = dataprep.prepare(shard, kind="tfd", seed=2, distributed=True)
+    out = train.train_surrogate("tfd", d, train.TfdConfig(batch_size=8, patience=3), device="cpu", autocast_dtype=None, max_epochs=2)
+    w = torch.cat([p.detach().reshape(-1) for p in out["model"].parameters()])
+    q.put((rank, out["epochs"], out["history"]["val"], float(w.sum()), d.scalers_Y["I"].mean_.numpy()))
+    dist.destroy_process_group()
+
+
+def test_two_rank_training_stays_in_sync():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33000 + os.getpid() % 2000
+    ps = [ctx.Process(target=_ddp_train_worker, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in ps]
+    outs = sorted([q.get(timeout=300) for _ in ps])
+    [p.join(60) for p in ps]
+    (_, e0, v0, w0, m0), (_, e1, v1, w1, m1) = outs
+    assert e0 == e1 and v0 == pytest.approx(v1)              # all-reduced losses: identical early-stop decisions
+    assert w0 == pytest.approx(w1, rel=1e-6)                 # replicas hold the same weights after training
+    np.testing.assert_allclose(m0, m1)                       # global scaler statistics on every rank
