@@ -72,13 +72,15 @@ def cpu_baseline(B_hint):
     rng = np.random.default_rng(SEED)
     x = np.linspace(0.0, 200.0, N_ELEM + 1)
     fix = bo.reference_fix_mask()
-    nb = 20000
-    I, Fy = bo.random_cases(rng, nb, inertia="trajectory")
-    co.solve_beam_batched(x, bo.E_REF, I[:2000], fix, Fy[:2000], bo.UDL_REF, n_threads=cores)  # warm-up
+    nb = int(min(400000, max(20000, 2000 * cores)))          # >= 2000 beams per thread: amortises the parallel region
+    I1, Fy1 = bo.random_cases(rng, 20000, inertia="trajectory")
+    reps_tile = (nb + 19999) // 20000
+    I, Fy = np.tile(I1, (reps_tile, 1))[:nb], np.tile(Fy1, (reps_tile, 1))[:nb]
+    co.solve_beam_batched(x, bo.E_REF, I, fix, Fy, bo.UDL_REF, n_threads=cores)  # warm-up (thread pool, page faults)
     t0 = time.perf_counter()
     co.solve_beam_batched(x, bo.E_REF, I, fix, Fy, bo.UDL_REF, n_threads=cores)
     dt = time.perf_counter() - t0
-    reps = int(max(1, min(200, 12.0 / max(dt, 1e-4))))
+    reps = int(max(1, min(200, 10.0 / max(dt, 1e-4))))
     t0 = time.perf_counter()
     for _ in range(reps):
         co.solve_beam_batched(x, bo.E_REF, I, fix, Fy, bo.UDL_REF, n_threads=cores)
@@ -88,9 +90,27 @@ def cpu_baseline(B_hint):
         "unit": "beam FE solves/s",
         "cores": cores,
         "kind": "port",
-        "sample": f"{reps} x {nb} beams x {N_ELEM} elements, oracle/beam_oracle.c (band Cholesky, OpenMP static over beams), "
+        "sample": f"{reps} x {nb} beams x {N_ELEM} elements, oracle/beam_oracle.c (band Cholesky, OpenMP static over beams, {cores} threads), "
                   f"{dt:.1f} s; OpenSeesPy itself unavailable (un-pinned third-party wheel)",
     }
+
+
+def profiled_traffic(kernel_name, B):
+    """HBM bytes per launch from the newest committed PMC summary of this command (scripts/profile_gpu.sh:
+    separate --pmc passes; FETCH_SIZE / WRITE_SIZE are KiB; FETCH_SIZE x2 for 16-byte coalesced reads on
+    gfx950, MI355X_MICROARCH.md section HBM).  None when no matching profile is committed."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json"))):
+        try:
+            r = json.load(open(f))
+        except Exception:
+            continue
+        if kernel_name in r.get("kernel", "") and int(r.get("dispatch", {}).get("Grid_Size", 0)) == 64 * ((B + 3) // 4):
+            h = r.get("hbm", {})
+            if h.get("FETCH_SIZE_raw") and h.get("WRITE_SIZE_raw"):
+                best = (2.0 * h["FETCH_SIZE_raw"] + h["WRITE_SIZE_raw"]) * 1024.0, os.path.basename(f)
+    return best
 
 
 def main():
@@ -206,6 +226,10 @@ def main():
                 "bytes_per_launch": BYTES_PER_SOLVE * B,
             },
         }
+        tr = profiled_traffic(rec["config"]["kernel"], B)
+        if tr:
+            rec["roofline"]["traffic"] = tr[0]
+            rec["roofline"]["traffic_source"] = f"profiles/{tr[1]} (2*FETCH_SIZE + WRITE_SIZE, KiB)"
         if world == 1 and not args.no_cpu_baseline:
             rec["cpu_baseline"] = cpu_baseline(B)
         print(json.dumps(rec))
