@@ -188,8 +188,6 @@ __device__ __forceinline__ void solve_lanes(const LdsAcc& acc, int lane, int j, 
 //   s_tab  unit-inertia element tile entries 2E/L, 6E/L^2, 12E/L^3, 1/L, wL/2, wL^2/12 per element
 //   s_a    I in padded rows [BPW][PM]            -> M (flat, row stride Ne) -> theta (flat, stride N)
 //   s_b    Fy flat (row stride N, as in HBM)     -> V (flat, row stride Ne) -> v     (flat, stride N)
-// Padding (nodes >= N, elements >= Ne, beams >= B) is a chain of unit elements on rollers behind a
-// zero-stiffness element: it keeps every pivot positive, touches no real DOF and needs no rotation fix.
 // waves per SIMD the register allocator is asked to leave room for (0 = no request)
 constexpr int waves_per_simd(int P, int M, bool shared) {
   if (!shared) return 1;   // per-beam geometry tables make those variants LDS-limited anyway
@@ -197,18 +195,46 @@ constexpr int waves_per_simd(int P, int M, bool shared) {
        : (P == 64 && M == 4) ? 3 : 1;
 }
 
-template <int P, int M, bool SHARED>
+// ---- buffer-resource I/O: hardware bounds checking instead of tail branches --------------------
+// A raw buffer descriptor (base, num_records in bytes) makes out-of-range lanes of a buffer_load return 0
+// and out-of-range lanes of a buffer_store do nothing; offsets are 32-bit, the base sits in SGPRs.
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v2i __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ double2 buf_load_d2(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+  const v4i v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 0);
+  return __builtin_bit_cast(double2, v);
+}
+__device__ __forceinline__ double buf_load_d(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+  const v2i v = __builtin_amdgcn_raw_buffer_load_b64(r, (int)byte_off, 0, 0);
+  return __builtin_bit_cast(double, v);
+}
+__device__ __forceinline__ void buf_store_d2(__amdgpu_buffer_rsrc_t r, unsigned byte_off, double2 x) {
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i, x), r, (int)byte_off, 0, 0);
+}
+__device__ __forceinline__ void buf_store_d(__amdgpu_buffer_rsrc_t r, unsigned byte_off, double x) {
+  __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2i, x), r, (int)byte_off, 0, 0);
+}
+
+// SHARED: x, E and wy are the same for every beam (strides 0): one element table per workgroup.
+// DENSE : rows of I / Fy / outputs are contiguous and every wave's run is 16-byte aligned (host-checked):
+//         the wave moves each of its six streams as one flat run of 16-byte buffer accesses.
+template <int P, int M, bool SHARED, bool DENSE>
 __global__ __launch_bounds__(64, waves_per_simd(P, M, SHARED)) void beam_solve_kernel(const BeamParams p) {
   constexpr int BPW = 64 / P;       // beams per wavefront
   constexpr int PM = P * M;         // padded nodes per beam (>= N)
   constexpr int TG = SHARED ? 1 : BPW;
   constexpr int NPAIR = (BPW * PM / 2 + 63) / 64;   // 16-byte pieces per lane for one staged array
+  constexpr int NT = (TG * PM + 63) / 64;           // table entries per lane
+  constexpr int NF = (PM + 1 + 63) / 64;            // constraint bytes per lane and beam row
   __shared__ double s_tab[6][TG][PM];
   __shared__ __attribute__((aligned(16))) double s_a[BPW * PM];
   __shared__ __attribute__((aligned(16))) double s_b[BPW * PM];
   __shared__ uint8_t s_fix[BPW][PM + 8];
 
-  const int lane = threadIdx.x;
+  const unsigned lane = threadIdx.x;
 #ifdef OPS_AMD_TRACE
   const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -217,68 +243,109 @@ __global__ __launch_bounds__(64, waves_per_simd(P, M, SHARED)) void beam_solve_k
   const int nb = (p.B - beam0 < BPW) ? (int)(p.B - beam0) : BPW;   // live beams of this wave
   const int nE = nb * Ne, nN = nb * N;
 
-  // ---- stage 1a: issue the wave's global loads first (I, Fy rows of its beams: one contiguous run) ----
-  double2 rI[NPAIR], rF[NPAIR];
-  if (p.dense) {
-    const double* gI = p.I + beam0 * Ne;
-    const double* gF = p.Fy + beam0 * N;
+  // ---- stage 1a: every global load is issued before anything waits; cache-resident ones FIRST ----
+  // (vmcnt retires in order: the element-table inputs and the constraint bytes hit in L2 and go out before
+  //  the wave's HBM rows, so the table is computed and written to LDS while the rows are in flight; a load
+  //  inside a divergent `if` would make the compiler wait for it at the join and serialise the prologue.)
+  double tx0[NT], tx1[NT], tE[NT], tw[NT];
+  unsigned char rfix[BPW][NF];
 #pragma unroll
-    for (int k = 0; k < NPAIR; ++k) {
-      const int i0 = 2 * (lane + 64 * k);
-      rI[k] = double2{1.0, 1.0};
-      rF[k] = double2{0.0, 0.0};
-      if (i0 + 1 < nE) rI[k] = *reinterpret_cast<const double2*>(gI + i0);
-      else if (i0 < nE) rI[k].x = gI[i0];
-      if (i0 + 1 < nN) rF[k] = *reinterpret_cast<const double2*>(gF + i0);
-      else if (i0 < nN) rF[k].x = gF[i0];
+  for (int k = 0; k < NT; ++k) {
+    const unsigned idx = lane + 64u * k, tb = SHARED ? 0u : idx / PM, e = idx - tb * PM;
+    long bb = beam0 + (tb < (unsigned)nb ? tb : 0u);
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.x + bb * p.x_bs, (unsigned)N * 8u);
+    tx0[k] = buf_load_d(rx, e * 8u);            // out of range (padding elements) -> 0
+    tx1[k] = buf_load_d(rx, e * 8u + 8u);
+    if (SHARED) {                               // compile-time: scalars through the scalar cache
+      tE[k] = p.E[0];
+      tw[k] = p.wy[0];
+    } else {
+      tE[k] = buf_load_d(make_rsrc(p.E_bs ? p.E + bb * p.E_bs : p.E, p.E_bs ? (unsigned)Ne * 8u : 8u), p.E_bs ? e * 8u : 0u);
+      tw[k] = buf_load_d(make_rsrc(p.wy_bs ? p.wy + bb * p.wy_bs : p.wy, p.wy_bs ? (unsigned)Ne * 8u : 8u), p.wy_bs ? e * 8u : 0u);
     }
   }
-  // padding defaults; LDS operations of one wave execute in order, so later writes win
-  for (int idx = lane; idx < BPW * PM; idx += 64) {
-    s_a[idx] = 1.0;
-    s_b[idx] = 0.0;
-  }
-  // ---- stage 0: element table (unit-inertia stiffness tile entries, 1/L, UDL loads) ----
-  for (int idx = lane; idx < TG * PM; idx += 64) {
-    const int tb = idx / PM, e = idx - tb * PM;
-    long bb = beam0 + tb;
-    if (bb >= p.B) bb = p.B - 1;
-    // defaults: element Ne has no stiffness, elements beyond it are unit elements (L = 1, EI = 1)
-    const bool pad = e > Ne;
-    double c2 = pad ? 2.0 : 0.0, c6 = pad ? 6.0 : 0.0, c12 = pad ? 12.0 : 0.0, rl = pad ? 1.0 : 0.0, pw = 0.0, mw = 0.0;
-    if (e < Ne) {
-      const double* xb = p.x + bb * p.x_bs;
-      const double L = xb[e + 1] - xb[e];
-      const double Ee = p.E_bs ? p.E[bb * p.E_bs + e] : p.E[0];
-      const double w = p.wy_bs ? p.wy[bb * p.wy_bs + e] : p.wy[0];
-      rl = fast_rcp(L);
-      c2 = 2.0 * Ee * rl;
-      c6 = 3.0 * c2 * rl;
-      c12 = 2.0 * c6 * rl;
-      pw = 0.5 * w * L;
-      mw = pw * L * (1.0 / 6.0);
-    }
-    s_tab[0][tb][e] = c2;  s_tab[1][tb][e] = c6;  s_tab[2][tb][e] = c12;
-    s_tab[3][tb][e] = rl;  s_tab[4][tb][e] = pw;  s_tab[5][tb][e] = mw;
-  }
-  // ---- stage 1b: constraint bytes (padding: roller), then the staged rows into LDS ----
 #pragma unroll
   for (int b = 0; b < BPW; ++b) {
-    const bool live = b < nb;
-    const uint8_t* fb = p.fix + (live ? beam0 + b : 0) * p.fix_bs;
-    for (int e = lane; e < PM + 8; e += 64) s_fix[b][e] = (live && e < N) ? (uint8_t)(fb[e] & 3) : (uint8_t)1;
+    const __amdgpu_buffer_rsrc_t rf = make_rsrc(p.fix + (beam0 + (b < nb ? b : 0)) * p.fix_bs, (unsigned)N);
+#pragma unroll
+    for (int k = 0; k < NF; ++k)                // out of range (padding nodes) -> 0 = free
+      rfix[b][k] = __builtin_amdgcn_raw_buffer_load_b8(rf, (int)(lane + 64u * k), 0, 0);
   }
-  if (p.dense) {
+  double2 rI[NPAIR], rF[NPAIR];
+  double tailI = 0.0, tailF = 0.0;              // last element of an odd-length run
+  if (DENSE) {
+    const __amdgpu_buffer_rsrc_t rsI = make_rsrc(p.I + beam0 * Ne, (unsigned)nE * 8u);
+    const __amdgpu_buffer_rsrc_t rsF = make_rsrc(p.Fy + beam0 * N, (unsigned)nN * 8u);
 #pragma unroll
     for (int k = 0; k < NPAIR; ++k) {
-      const int i0 = 2 * (lane + 64 * k);
-      if (i0 < nE) {   // padded rows: (beam, element) of flat index i0 by multiply-shift division
-        const int b0 = (int)(((unsigned)i0 * p.magic_ne) >> 20), e = i0 - b0 * Ne;
+      const unsigned off = (lane + 64u * k) * 16u;
+      rI[k] = buf_load_d2(rsI, off);            // a pair that is not entirely inside the run comes back as 0
+      rF[k] = buf_load_d2(rsF, off);
+    }
+    tailI = buf_load_d(rsI, (unsigned)(nE - 1) * 8u);
+    tailF = buf_load_d(rsF, (unsigned)(nN - 1) * 8u);
+  }
+#ifdef OPS_AMD_TRACE
+  const unsigned long long ta = __builtin_amdgcn_s_memrealtime();   // all loads issued
+#endif
+  // padding defaults (I = 1 for the unit elements of the padding chain, no loads); LDS operations of one
+  // wave execute in order, so the real rows written below win
+#pragma unroll
+  for (int k = 0; k < (BPW * PM + 63) / 64; ++k) {
+    const unsigned idx = lane + 64u * k;
+    if (idx < BPW * PM) {
+      s_a[idx] = 1.0;
+      s_b[idx] = 0.0;
+    }
+  }
+  // ---- stage 0: element table (unit-inertia stiffness tile entries, 1/L, UDL loads) ----
+  // element Ne has no stiffness; the elements beyond it are unit elements (L = 1, EI = 1): together with the
+  // implicit clamp behind the last lane (its right neighbour does not exist: u = 0) the padding is a free
+  // cantilever hanging off nothing -- every pivot positive, no real DOF touched, no constraint flags needed.
+#pragma unroll
+  for (int k = 0; k < NT; ++k) {
+    const unsigned idx = lane + 64u * k, tb = SHARED ? 0u : idx / PM, e = idx - tb * PM;
+    if (idx < (unsigned)(TG * PM)) {
+      const bool real = (int)e < Ne, pad = (int)e > Ne;
+      const double L = tx1[k] - tx0[k];
+      const double rl0 = fast_rcp(real ? L : 1.0);
+      const double c2r = 2.0 * tE[k] * rl0, pwr = 0.5 * tw[k] * L;
+      const double rl = real ? rl0 : (pad ? 1.0 : 0.0);
+      const double c2 = real ? c2r : (pad ? 2.0 : 0.0);
+      const double c6 = 3.0 * c2 * rl, c12 = 2.0 * c6 * rl;
+      const double pw = real ? pwr : 0.0, mw = pw * L * (1.0 / 6.0);
+      s_tab[0][tb][e] = c2;  s_tab[1][tb][e] = c6;  s_tab[2][tb][e] = c12;
+      s_tab[3][tb][e] = rl;  s_tab[4][tb][e] = pw;  s_tab[5][tb][e] = mw;
+    }
+  }
+#ifdef OPS_AMD_TRACE
+  const unsigned long long tb_ = __builtin_amdgcn_s_memrealtime();  // table written
+#endif
+  // ---- stage 1b: constraint bytes, then the staged rows into LDS ----
+#pragma unroll
+  for (int b = 0; b < BPW; ++b)
+#pragma unroll
+    for (int k = 0; k < NF; ++k) {
+      const unsigned e = lane + 64u * k;
+      if (e < PM + 1) s_fix[b][e] = (unsigned char)(rfix[b][k] & 3);
+    }
+  if (DENSE) {
+    const bool oddI = nE & 1, oddF = nN & 1;    // wave-uniform
+#pragma unroll
+    for (int k = 0; k < NPAIR; ++k) {
+      const unsigned i0 = 2u * (lane + 64u * k);
+      // I -> padded rows: (beam, element) of flat index i0 by multiply-shift division
+      const unsigned b0 = (i0 * p.magic_ne) >> 20, e = i0 - b0 * Ne;
+      if ((int)(i0 + 1) < nE) {
         s_a[b0 * PM + e] = rI[k].x;
-        if (e + 1 < Ne) s_a[b0 * PM + e + 1] = rI[k].y;
-        else if (i0 + 1 < nE) s_a[(b0 + 1) * PM] = rI[k].y;
+        if ((int)(e + 1) < Ne) s_a[b0 * PM + e + 1] = rI[k].y;
+        else s_a[(b0 + 1) * PM] = rI[k].y;
+      } else if (oddI && (int)i0 == nE - 1) {
+        s_a[b0 * PM + e] = tailI;
       }
-      if (i0 < nN) *reinterpret_cast<double2*>(&s_b[i0]) = rF[k];   // flat, as in HBM
+      // Fy -> flat, as in HBM
+      if ((int)(i0 + 1) < nN) *reinterpret_cast<double2*>(&s_b[i0]) = rF[k];
+      else if (oddF && (int)i0 == nN - 1) s_b[i0] = tailF;
     }
   } else {
 #pragma unroll
@@ -296,16 +363,6 @@ __global__ __launch_bounds__(64, waves_per_simd(P, M, SHARED)) void beam_solve_k
 #ifdef OPS_AMD_TRACE
   const unsigned long long t1 = __builtin_amdgcn_s_memrealtime();
 #endif
-  // Stagger the waves that share a SIMD: distinct issue priorities by hardware wave slot let one wave
-  // run ahead, so its output stores overlap the arithmetic of its neighbours instead of every wave of
-  // the (single-round) grid reaching the store phase at the same time.
-  if (p.stagger) {
-    const unsigned hwid = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | ((4 - 1) << 11));   // HW_REG_HW_ID[3:0] = wave slot
-    const unsigned slot = hwid & 3u;
-    if (slot == 0) __builtin_amdgcn_s_setprio(3);
-    else if (slot == 1) __builtin_amdgcn_s_setprio(2);
-    else if (slot == 2) __builtin_amdgcn_s_setprio(1);
-  }
 
   // ---- stages 2-4: per-lane condensation, interface reduction, interior solve ----
   const int g = lane / P, j = lane - g * P, e0 = j * M;
@@ -342,28 +399,29 @@ __global__ __launch_bounds__(64, waves_per_simd(P, M, SHARED)) void beam_solve_k
     }
   }
   if (j == 0 && g < nb && p.status) p.status[beam0 + g] = gbad ? 1 : 0;
-
 #ifdef OPS_AMD_TRACE
   const unsigned long long t2 = __builtin_amdgcn_s_memrealtime();
 #endif
+
   // element rows: V already in s_b (flat, stride Ne); M joins it in s_a now that I is dead
 #pragma unroll
   for (int i = 0; i < M; ++i)
     if (i < out.nE) s_a[g * Ne + e0 + i] = out.Mz[i];
   wave_lds_fence();
-  if (p.dense) {
-    double* gV = p.V + beam0 * Ne;
-    double* gM = p.M + beam0 * Ne;
+  if (DENSE) {
+    const __amdgpu_buffer_rsrc_t rV = make_rsrc(p.V + beam0 * Ne, (unsigned)nE * 8u);
+    const __amdgpu_buffer_rsrc_t rM = make_rsrc(p.M + beam0 * Ne, (unsigned)nE * 8u);
 #pragma unroll
     for (int k = 0; k < NPAIR; ++k) {
-      const int i0 = 2 * (lane + 64 * k);
-      if (i0 + 1 < nE) {
-        *reinterpret_cast<double2*>(gV + i0) = *reinterpret_cast<const double2*>(&s_b[i0]);
-        *reinterpret_cast<double2*>(gM + i0) = *reinterpret_cast<const double2*>(&s_a[i0]);
-      } else if (i0 < nE) {
-        gV[i0] = s_b[i0];
-        gM[i0] = s_a[i0];
+      const unsigned i0 = 2u * (lane + 64u * k);
+      if (i0 < BPW * PM) {                      // LDS bound; the buffer descriptor drops pairs beyond the run
+        buf_store_d2(rV, i0 * 8u, *reinterpret_cast<const double2*>(&s_b[i0]));
+        buf_store_d2(rM, i0 * 8u, *reinterpret_cast<const double2*>(&s_a[i0]));
       }
+    }
+    if ((nE & 1) && lane == 0) {
+      buf_store_d(rV, (unsigned)(nE - 1) * 8u, s_b[nE - 1]);
+      buf_store_d(rM, (unsigned)(nE - 1) * 8u, s_a[nE - 1]);
     }
   } else {
     for (int idx = lane; idx < nE; idx += 64) {
@@ -380,19 +438,20 @@ __global__ __launch_bounds__(64, waves_per_simd(P, M, SHARED)) void beam_solve_k
       s_a[g * N + e0 + i] = out.th[i];
     }
   wave_lds_fence();
-  if (p.dense) {
-    double* gv = p.v + beam0 * N;
-    double* gt = p.theta + beam0 * N;
+  if (DENSE) {
+    const __amdgpu_buffer_rsrc_t rv = make_rsrc(p.v + beam0 * N, (unsigned)nN * 8u);
+    const __amdgpu_buffer_rsrc_t rt = make_rsrc(p.theta + beam0 * N, (unsigned)nN * 8u);
 #pragma unroll
     for (int k = 0; k < NPAIR; ++k) {
-      const int i0 = 2 * (lane + 64 * k);
-      if (i0 + 1 < nN) {
-        *reinterpret_cast<double2*>(gv + i0) = *reinterpret_cast<const double2*>(&s_b[i0]);
-        *reinterpret_cast<double2*>(gt + i0) = *reinterpret_cast<const double2*>(&s_a[i0]);
-      } else if (i0 < nN) {
-        gv[i0] = s_b[i0];
-        gt[i0] = s_a[i0];
+      const unsigned i0 = 2u * (lane + 64u * k);
+      if (i0 < BPW * PM) {
+        buf_store_d2(rv, i0 * 8u, *reinterpret_cast<const double2*>(&s_b[i0]));
+        buf_store_d2(rt, i0 * 8u, *reinterpret_cast<const double2*>(&s_a[i0]));
       }
+    }
+    if ((nN & 1) && lane == 0) {
+      buf_store_d(rv, (unsigned)(nN - 1) * 8u, s_b[nN - 1]);
+      buf_store_d(rt, (unsigned)(nN - 1) * 8u, s_a[nN - 1]);
     }
   } else {
     for (int idx = lane; idx < nN; idx += 64) {
@@ -404,8 +463,8 @@ __global__ __launch_bounds__(64, waves_per_simd(P, M, SHARED)) void beam_solve_k
   if (p.trace && lane == 0) {   // per-wave phase stamps (100 MHz clock) + hardware id, for scripts/trace_run.py
     const unsigned long long t3 = __builtin_amdgcn_s_memrealtime();
     const unsigned hw = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | ((16 - 1) << 11));
-    unsigned long long* q = p.trace + 5 * (unsigned long long)blockIdx.x;
-    q[0] = t0; q[1] = t1; q[2] = t2; q[3] = t3; q[4] = hw;
+    unsigned long long* q = p.trace + 8 * (unsigned long long)blockIdx.x;
+    q[0] = t0; q[1] = t1; q[2] = t2; q[3] = t3; q[4] = hw; q[5] = ta; q[6] = tb_; q[7] = tb_;
   }
 #endif
 }
@@ -417,13 +476,13 @@ struct Tiling { int P, M; const char* name_shared; const char* name_general; };
 
 // every compiled (P, M); a tiling serves Ne with Ne + 1 <= P * M
 static const Tiling kTilings[] = {
-    {8, 13, "beam_solve_kernel<8, 13, true>", "beam_solve_kernel<8, 13, false>"},
-    {16, 7, "beam_solve_kernel<16, 7, true>", "beam_solve_kernel<16, 7, false>"},
-    {32, 4, "beam_solve_kernel<32, 4, true>", "beam_solve_kernel<32, 4, false>"},
-    {64, 2, "beam_solve_kernel<64, 2, true>", "beam_solve_kernel<64, 2, false>"},
-    {64, 4, "beam_solve_kernel<64, 4, true>", "beam_solve_kernel<64, 4, false>"},
-    {64, 8, "beam_solve_kernel<64, 8, true>", "beam_solve_kernel<64, 8, false>"},
-    {64, 16, "beam_solve_kernel<64, 16, true>", "beam_solve_kernel<64, 16, false>"},
+    {8, 13, "beam_solve_kernel<8, 13, true, true>", "beam_solve_kernel<8, 13, false, true>"},
+    {16, 7, "beam_solve_kernel<16, 7, true, true>", "beam_solve_kernel<16, 7, false, true>"},
+    {32, 4, "beam_solve_kernel<32, 4, true, true>", "beam_solve_kernel<32, 4, false, true>"},
+    {64, 2, "beam_solve_kernel<64, 2, true, true>", "beam_solve_kernel<64, 2, false, true>"},
+    {64, 4, "beam_solve_kernel<64, 4, true, true>", "beam_solve_kernel<64, 4, false, true>"},
+    {64, 8, "beam_solve_kernel<64, 8, true, true>", "beam_solve_kernel<64, 8, false, true>"},
+    {64, 16, "beam_solve_kernel<64, 16, true, true>", "beam_solve_kernel<64, 16, false, true>"},
 };
 static const int kNumTilings = sizeof(kTilings) / sizeof(kTilings[0]);
 
@@ -449,10 +508,14 @@ template <int P, int M>
 static hipError_t launch(const BeamParams& p, bool shared, hipStream_t stream) {
   constexpr int BPW = 64 / P;
   const unsigned grid = (unsigned)((p.B + BPW - 1) / BPW);
-  if (shared)
-    hipLaunchKernelGGL((beam_solve_kernel<P, M, true>), dim3(grid), dim3(64), 0, stream, p);
+  if (shared && p.dense)
+    hipLaunchKernelGGL((beam_solve_kernel<P, M, true, true>), dim3(grid), dim3(64), 0, stream, p);
+  else if (shared)
+    hipLaunchKernelGGL((beam_solve_kernel<P, M, true, false>), dim3(grid), dim3(64), 0, stream, p);
+  else if (p.dense)
+    hipLaunchKernelGGL((beam_solve_kernel<P, M, false, true>), dim3(grid), dim3(64), 0, stream, p);
   else
-    hipLaunchKernelGGL((beam_solve_kernel<P, M, false>), dim3(grid), dim3(64), 0, stream, p);
+    hipLaunchKernelGGL((beam_solve_kernel<P, M, false, false>), dim3(grid), dim3(64), 0, stream, p);
   return hipGetLastError();
 }
 

@@ -40,9 +40,9 @@ int solve_one_rz(int Ne, const double* x, const double* E, bool E_pe, const doub
   constexpr int PM = P * M;
   const int N = Ne + 1;
   // same padding scheme as the kernel: element Ne has no stiffness, later elements are unit elements
-  // (I = 1) on rollers (fix = 1)
+  // (I = 1), free, hanging on the implicit clamp behind the last lane (u_R = 0)
   std::vector<double> tab(6 * PM, 0.0), sI(PM, 1.0), sF(PM, 0.0), ov(PM), ot(PM), oV(PM), oM(PM);
-  std::vector<uint8_t> sfix(PM + 8, 1);
+  std::vector<uint8_t> sfix(PM + 8, 0);   // padding nodes are free: the chain of unit elements is clamped behind the last lane
   for (int e = Ne + 1; e < PM; ++e) { tab[0 * PM + e] = 2.0; tab[1 * PM + e] = 6.0; tab[2 * PM + e] = 12.0; tab[3 * PM + e] = 1.0; }
   for (int e = 0; e < Ne; ++e) {
     const double L = x[e + 1] - x[e], rl = fast_rcp(L);
