@@ -228,11 +228,9 @@ __global__ __launch_bounds__(64, waves_per_simd(P, M, SHARED)) void beam_solve_k
   constexpr int TG = SHARED ? 1 : BPW;
   constexpr int NPAIR = (BPW * PM / 2 + 63) / 64;   // 16-byte pieces per lane for one staged array
   constexpr int NT = (TG * PM + 63) / 64;           // table entries per lane
-  constexpr int NF = (PM + 1 + 63) / 64;            // constraint bytes per lane and beam row
   __shared__ double s_tab[6][TG][PM];
   __shared__ __attribute__((aligned(16))) double s_a[BPW * PM];
   __shared__ __attribute__((aligned(16))) double s_b[BPW * PM];
-  __shared__ uint8_t s_fix[BPW][PM + 8];
 
   const unsigned lane = threadIdx.x;
 #ifdef OPS_AMD_TRACE
@@ -248,7 +246,6 @@ __global__ __launch_bounds__(64, waves_per_simd(P, M, SHARED)) void beam_solve_k
   //  the wave's HBM rows, so the table is computed and written to LDS while the rows are in flight; a load
   //  inside a divergent `if` would make the compiler wait for it at the join and serialise the prologue.)
   double tx0[NT], tx1[NT], tE[NT], tw[NT];
-  unsigned char rfix[BPW][NF];
 #pragma unroll
   for (int k = 0; k < NT; ++k) {
     const unsigned idx = lane + 64u * k, tb = SHARED ? 0u : idx / PM, e = idx - tb * PM;
@@ -264,12 +261,17 @@ __global__ __launch_bounds__(64, waves_per_simd(P, M, SHARED)) void beam_solve_k
       tw[k] = buf_load_d(make_rsrc(p.wy_bs ? p.wy + bb * p.wy_bs : p.wy, p.wy_bs ? (unsigned)Ne * 8u : 8u), p.wy_bs ? e * 8u : 0u);
     }
   }
+  // constraint bytes of the lane's own M + 1 nodes (L1/L2 hits), straight into the lane's bit field;
+  // nodes >= N (padding) read as 0 = free
+  const int g = lane / P, j = lane - g * P, e0 = j * M;
+  unsigned char rfix[M + 1];
+  {
+    const unsigned row = (g < nb ? (unsigned)g : 0u);
+    const __amdgpu_buffer_rsrc_t rf = make_rsrc(p.fix + beam0 * p.fix_bs, (unsigned)(p.fix_bs ? (nb - 1) * p.fix_bs + N : N));
+    const unsigned base = row * (unsigned)p.fix_bs + (unsigned)e0;
 #pragma unroll
-  for (int b = 0; b < BPW; ++b) {
-    const __amdgpu_buffer_rsrc_t rf = make_rsrc(p.fix + (beam0 + (b < nb ? b : 0)) * p.fix_bs, (unsigned)N);
-#pragma unroll
-    for (int k = 0; k < NF; ++k)                // out of range (padding nodes) -> 0 = free
-      rfix[b][k] = __builtin_amdgcn_raw_buffer_load_b8(rf, (int)(lane + 64u * k), 0, 0);
+    for (int i = 0; i <= M; ++i)
+      rfix[i] = __builtin_amdgcn_raw_buffer_load_b8(rf, (int)(base + i), 0, 0);
   }
   double2 rI[NPAIR], rF[NPAIR];
   double tailI = 0.0, tailF = 0.0;              // last element of an odd-length run
@@ -291,11 +293,11 @@ __global__ __launch_bounds__(64, waves_per_simd(P, M, SHARED)) void beam_solve_k
   // padding defaults (I = 1 for the unit elements of the padding chain, no loads); LDS operations of one
   // wave execute in order, so the real rows written below win
 #pragma unroll
-  for (int k = 0; k < (BPW * PM + 63) / 64; ++k) {
-    const unsigned idx = lane + 64u * k;
-    if (idx < BPW * PM) {
-      s_a[idx] = 1.0;
-      s_b[idx] = 0.0;
+  for (int k = 0; k < NPAIR; ++k) {
+    const unsigned i0 = 2u * (lane + 64u * k);
+    if (k + 1 < NPAIR || i0 < BPW * PM) {       // only the last piece can run past the arrays
+      *reinterpret_cast<double2*>(&s_a[i0]) = double2{1.0, 1.0};
+      *reinterpret_cast<double2*>(&s_b[i0]) = double2{0.0, 0.0};
     }
   }
   // ---- stage 0: element table (unit-inertia stiffness tile entries, 1/L, UDL loads) ----
@@ -321,14 +323,7 @@ __global__ __launch_bounds__(64, waves_per_simd(P, M, SHARED)) void beam_solve_k
 #ifdef OPS_AMD_TRACE
   const unsigned long long tb_ = __builtin_amdgcn_s_memrealtime();  // table written
 #endif
-  // ---- stage 1b: constraint bytes, then the staged rows into LDS ----
-#pragma unroll
-  for (int b = 0; b < BPW; ++b)
-#pragma unroll
-    for (int k = 0; k < NF; ++k) {
-      const unsigned e = lane + 64u * k;
-      if (e < PM + 1) s_fix[b][e] = (unsigned char)(rfix[b][k] & 3);
-    }
+  // ---- stage 1b: the staged rows into LDS ----
   if (DENSE) {
     const bool oddI = nE & 1, oddF = nN & 1;    // wave-uniform
 #pragma unroll
@@ -336,7 +331,9 @@ __global__ __launch_bounds__(64, waves_per_simd(P, M, SHARED)) void beam_solve_k
       const unsigned i0 = 2u * (lane + 64u * k);
       // I -> padded rows: (beam, element) of flat index i0 by multiply-shift division
       const unsigned b0 = (i0 * p.magic_ne) >> 20, e = i0 - b0 * Ne;
-      if ((int)(i0 + 1) < nE) {
+      if (!(Ne & 1)) {                          // wave-uniform: a pair never straddles two rows
+        if ((int)i0 < nE) *reinterpret_cast<double2*>(&s_a[b0 * PM + e]) = rI[k];
+      } else if ((int)(i0 + 1) < nE) {
         s_a[b0 * PM + e] = rI[k].x;
         if ((int)(e + 1) < Ne) s_a[b0 * PM + e + 1] = rI[k].y;
         else s_a[(b0 + 1) * PM] = rI[k].y;
@@ -365,7 +362,6 @@ __global__ __launch_bounds__(64, waves_per_simd(P, M, SHARED)) void beam_solve_k
 #endif
 
   // ---- stages 2-4: per-lane condensation, interface reduction, interior solve ----
-  const int g = lane / P, j = lane - g * P, e0 = j * M;
   LdsAcc acc;
   {
     const int tb = SHARED ? 0 : g;
@@ -375,7 +371,8 @@ __global__ __launch_bounds__(64, waves_per_simd(P, M, SHARED)) void beam_solve_k
     acc.sF = &s_b[g * N + e0];
     unsigned long long bits = 0;
 #pragma unroll
-    for (int i = 0; i <= M; ++i) bits |= (unsigned long long)s_fix[g][e0 + i] << (2 * i);
+    for (int i = 0; i <= M; ++i)   // a node at or beyond N is padding: free (the row's bytes end at N)
+      bits |= (unsigned long long)((e0 + i < N) ? (rfix[i] & 3) : 0) << (2 * i);
     acc.bits = bits;
   }
   int bad = 0;
@@ -391,7 +388,7 @@ __global__ __launch_bounds__(64, waves_per_simd(P, M, SHARED)) void beam_solve_k
   const unsigned long long grp = (P == 64) ? ~0ull : (((1ull << (P % 64)) - 1ull) << (g * P));
   const bool gbad = (bal & grp) != 0ull;
   const double qnan = __builtin_nan("");
-  if (gbad) {
+  if (bal != 0ull && gbad) {                    // first test is wave-uniform: nothing to do in the common case
 #pragma unroll
     for (int i = 0; i < M; ++i) {
       out.v[i] = qnan; out.th[i] = qnan; out.Mz[i] = qnan;
