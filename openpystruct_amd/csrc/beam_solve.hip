@@ -58,17 +58,26 @@ struct LdsAcc {
   __device__ __forceinline__ void fence() const { __asm__ volatile("" ::: "memory"); }
 };
 
+// Results of a lane.  Lanes at the end of a beam own fewer than M real elements / nodes.  Instead of
+// predicating every LDS store, stores are issued for DESCENDING i to slot min(i, last): the surplus ones
+// land on the lane's own last real slot and are overwritten, in order, by the real value (LDS operations
+// of a wave execute in order); a lane with nothing real points at a dummy slot.
 template <int M>
 struct LaneOut {
-  double* sV;               // LDS slots (flat, row stride Ne) of the lane's element shears
-  int nE;                   // how many of the lane's M elements exist (e0 + i < Ne)
+  double* sV;               // LDS slots (flat, row stride Ne) of the lane's element shears (or the dummy slot)
+  unsigned lastE;           // index of the lane's last real element (0 when it has none)
   double v[M], th[M], Mz[M];  // the rest stays in registers until the inputs in LDS are dead
-  __device__ __forceinline__ void elem(int i, double Vv, double Mv) {
-    if (i < nE) sV[i] = Vv;
+  __device__ __forceinline__ void elem(int i, double Vv, double Mv) {   // called for i = M-1 ... 0
+    sV[(unsigned)i < lastE ? (unsigned)i : lastE] = Vv;
     Mz[i] = Mv;
   }
   __device__ __forceinline__ void node(int i, double vv, double tt) { v[i] = vv; th[i] = tt; }
 };
+template <int M>
+__device__ __forceinline__ void lds_store_desc(double* slot, unsigned last, const double (&val)[M]) {
+#pragma unroll
+  for (int i = M - 1; i >= 0; --i) slot[(unsigned)i < last ? (unsigned)i : last] = val[i];
+}
 
 // ---- cross-lane exchange inside the P-lane group of a beam ------------------------------
 // from_minus<S>(x): value of lane-S (0.0 when j < S); from_plus<S>(x): value of lane+S (0.0 when
@@ -231,6 +240,7 @@ __global__ __launch_bounds__(64, waves_per_simd(P, M, SHARED)) void beam_solve_k
   __shared__ double s_tab[6][TG][PM];
   __shared__ __attribute__((aligned(16))) double s_a[BPW * PM];
   __shared__ __attribute__((aligned(16))) double s_b[BPW * PM];
+  __shared__ double s_dummy[2];
 
   const unsigned lane = threadIdx.x;
 #ifdef OPS_AMD_TRACE
@@ -377,8 +387,10 @@ __global__ __launch_bounds__(64, waves_per_simd(P, M, SHARED)) void beam_solve_k
   }
   int bad = 0;
   LaneOut<M> out;
-  out.sV = &s_b[g * Ne + e0];
-  out.nE = Ne - e0;
+  const int cntE = (Ne - e0 < 0) ? 0 : (Ne - e0 < M ? Ne - e0 : M);   // real elements / nodes of this lane
+  const int cntN = (N - e0 < 0) ? 0 : (N - e0 < M ? N - e0 : M);
+  out.sV = cntE ? &s_b[g * Ne + e0] : s_dummy;
+  out.lastE = cntE ? (unsigned)(cntE - 1) : 0u;
   const bool any_rz = __ballot((acc.bits & 0xAAAAAAAAAAAAAAAAull) != 0ull) != 0ull;   // wave-uniform
   if (any_rz) solve_lanes<P, M, true>(acc, lane, j, bad, out);
   else        solve_lanes<P, M, false>(acc, lane, j, bad, out);
@@ -392,7 +404,7 @@ __global__ __launch_bounds__(64, waves_per_simd(P, M, SHARED)) void beam_solve_k
 #pragma unroll
     for (int i = 0; i < M; ++i) {
       out.v[i] = qnan; out.th[i] = qnan; out.Mz[i] = qnan;
-      if (i < out.nE) out.sV[i] = qnan;
+      if (i < cntE) out.sV[i] = qnan;
     }
   }
   if (j == 0 && g < nb && p.status) p.status[beam0 + g] = gbad ? 1 : 0;
@@ -401,9 +413,7 @@ __global__ __launch_bounds__(64, waves_per_simd(P, M, SHARED)) void beam_solve_k
 #endif
 
   // element rows: V already in s_b (flat, stride Ne); M joins it in s_a now that I is dead
-#pragma unroll
-  for (int i = 0; i < M; ++i)
-    if (i < out.nE) s_a[g * Ne + e0 + i] = out.Mz[i];
+  lds_store_desc<M>(cntE ? &s_a[g * Ne + e0] : s_dummy, out.lastE, out.Mz);
   wave_lds_fence();
   if (DENSE) {
     const __amdgpu_buffer_rsrc_t rV = make_rsrc(p.V + beam0 * Ne, (unsigned)nE * 8u);
@@ -411,7 +421,7 @@ __global__ __launch_bounds__(64, waves_per_simd(P, M, SHARED)) void beam_solve_k
 #pragma unroll
     for (int k = 0; k < NPAIR; ++k) {
       const unsigned i0 = 2u * (lane + 64u * k);
-      if (i0 < BPW * PM) {                      // LDS bound; the buffer descriptor drops pairs beyond the run
+      if (k + 1 < NPAIR || i0 < BPW * PM) {     // LDS bound; the buffer descriptor drops pairs beyond the run
         buf_store_d2(rV, i0 * 8u, *reinterpret_cast<const double2*>(&s_b[i0]));
         buf_store_d2(rM, i0 * 8u, *reinterpret_cast<const double2*>(&s_a[i0]));
       }
@@ -428,12 +438,8 @@ __global__ __launch_bounds__(64, waves_per_simd(P, M, SHARED)) void beam_solve_k
   }
   wave_lds_fence();
   // nodal rows (flat, stride N)
-#pragma unroll
-  for (int i = 0; i < M; ++i)
-    if (e0 + i < N) {
-      s_b[g * N + e0 + i] = out.v[i];
-      s_a[g * N + e0 + i] = out.th[i];
-    }
+  lds_store_desc<M>(cntN ? &s_b[g * N + e0] : s_dummy, cntN ? (unsigned)(cntN - 1) : 0u, out.v);
+  lds_store_desc<M>(cntN ? &s_a[g * N + e0] : s_dummy, cntN ? (unsigned)(cntN - 1) : 0u, out.th);
   wave_lds_fence();
   if (DENSE) {
     const __amdgpu_buffer_rsrc_t rv = make_rsrc(p.v + beam0 * N, (unsigned)nN * 8u);
@@ -441,7 +447,7 @@ __global__ __launch_bounds__(64, waves_per_simd(P, M, SHARED)) void beam_solve_k
 #pragma unroll
     for (int k = 0; k < NPAIR; ++k) {
       const unsigned i0 = 2u * (lane + 64u * k);
-      if (i0 < BPW * PM) {
+      if (k + 1 < NPAIR || i0 < BPW * PM) {
         buf_store_d2(rv, i0 * 8u, *reinterpret_cast<const double2*>(&s_b[i0]));
         buf_store_d2(rt, i0 * 8u, *reinterpret_cast<const double2*>(&s_a[i0]));
       }
