@@ -496,9 +496,10 @@ static const Tiling* choose_tiling(int B, int Ne, int tiling) {
       if (kTilings[t].P == tiling && kTilings[t].P * kTilings[t].M >= N) return &kTilings[t];
     return nullptr;
   }
-  (void)B;
-  // default: 16 lanes per beam where it fits (best at the 10^4-beam batch of BASELINE config 2),
-  // otherwise the narrowest tiling that holds the beam
+  // default (measured, profiles/r01_notes.md): 16 lanes per beam while the batch is a single round of
+  // waves (its short waves finish a 10^4-beam launch soonest); 8 lanes per beam (40 % less arithmetic per
+  // beam, two waves per SIMD) once the batch is large enough to keep every SIMD busy for several rounds
+  if (N <= 8 * 13 && B >= 32768) return &kTilings[0];
   if (N <= 16 * 7) return &kTilings[1];
   for (int t = 0; t < kNumTilings; ++t)
     if (kTilings[t].P * kTilings[t].M >= N) return &kTilings[t];
