@@ -115,7 +115,8 @@ def _allreduce_mean(t: torch.Tensor, world: int) -> torch.Tensor:
 
 
 def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, autocast_dtype=torch.bfloat16,
-                    sync_bn: bool = False, max_epochs: Optional[int] = None, log=None, seed: int = 0) -> Dict[str, object]:
+                    sync_bn: bool = False, max_epochs: Optional[int] = None, log=None, seed: int = 0,
+                    use_graph: Optional[bool] = None) -> Dict[str, object]:
     """Trains on THIS rank's `data` shard; uses DDP when torch.distributed is initialised with world_size > 1.
     Returns history, best state dict, validation R^2 (I only) and per-epoch times."""
     cfg = cfg or (PinnConfig() if kind == "pinn" else TfdConfig())
@@ -132,7 +133,14 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
             model, device_ids=[device.index] if device.type == "cuda" else None,
             bucket_cap_mb=8, gradient_as_bucket_view=True)     # one bucket: the whole model is < 2.4 MB
     torch.manual_seed(seed + 1 + rank)  # different noise / shuffles per rank
-    opt = torch.optim.Adam(model.parameters(), lr=cfg.learning_rate, weight_decay=cfg.weight_decay)   # loss.alpha NOT included (PINN:696)
+    on_gpu = device.type == "cuda"
+    if use_graph is None:
+        use_graph = on_gpu and world == 1      # the step is launch-bound (~150 tiny kernels): replay it as one HIP graph
+    # under graph replay the learning rate must live in a device tensor, or the scheduler's updates would
+    # never reach the captured optimiser step
+    lr0 = torch.tensor(cfg.learning_rate, device=device) if use_graph else cfg.learning_rate
+    opt = torch.optim.Adam(model.parameters(), lr=lr0, weight_decay=cfg.weight_decay,
+                           capturable=bool(use_graph), fused=on_gpu)   # loss.alpha NOT included (PINN:696)
     sched = ExponentialLR(opt, gamma=cfg.gamma)
     Xtr, Ytr, Xva, Yva = (t.to(device) for t in (data.X_train, data.Y_train, data.X_val, data.Y_val))
     nb_tr = max(1, (Xtr.shape[0] + cfg.batch_size - 1) // cfg.batch_size)
@@ -142,6 +150,40 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
         nb_tr = int(t.item())
     use_ac = device.type == "cuda" and autocast_dtype is not None
     hist = {"train": [], "val": [], "epoch_s": []}
+
+    def train_step(Xb, Yb, noise_t):
+        Xn = Xb + torch.randn_like(Xb) * noise_t                         # PINN:756
+        opt.zero_grad(set_to_none=False)
+        with torch.autocast(device_type=device.type, dtype=autocast_dtype, enabled=use_ac):
+            preds = net(Xn)
+            loss = crit(preds.float(), Yb)
+            if kind == "tfd":
+                loss = loss + (cfg.initial_alpha - crit.alpha) ** 2       # TFD:743 (constant 0: alpha never trains)
+        loss.backward()                                                  # DDP: bucketed RCCL all-reduce overlaps here
+        torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)          # PINN:766
+        opt.step()
+        return loss.detach()
+
+    graph = None
+    bs = cfg.batch_size
+    if use_graph and Xtr.shape[0] >= bs:
+        # static buffers + a few eager warm-up steps on a side stream, then capture one full-batch step
+        sX, sY = torch.zeros_like(Xtr[:bs]), torch.zeros_like(Ytr[:bs])
+        s_noise = torch.zeros((), device=device)
+        snap = (copy.deepcopy(model.state_dict()), copy.deepcopy(opt.state_dict()))
+        side = torch.cuda.Stream(device=device)
+        side.wait_stream(torch.cuda.current_stream(device))
+        with torch.cuda.stream(side):
+            sX.copy_(Xtr[:bs]); sY.copy_(Ytr[:bs])
+            for _ in range(3):
+                train_step(sX, sY, s_noise)
+            side.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=side):
+                s_loss = train_step(sX, sY, s_noise)
+        torch.cuda.current_stream(device).wait_stream(side)
+        model.load_state_dict(snap[0]); opt.load_state_dict(snap[1])     # the warm-up steps never happened
+
     best_val, best_state, no_improve = float("inf"), None, 0
     n_epochs = max_epochs if max_epochs is not None else cfg.num_epochs
     for epoch in range(1, n_epochs + 1):
@@ -152,21 +194,17 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
         noise = cfg.sigma_0 * (cfg.gamma_noise ** epoch)                     # PINN:743
         order = torch.randperm(Xtr.shape[0], device=device)                  # DataLoader(shuffle=True), PINN:701
         tot = torch.zeros((), device=device)
+        noise_t = torch.tensor(noise, device=device)
         for b in range(nb_tr):
-            idx = order[b * cfg.batch_size:(b + 1) * cfg.batch_size]
-            idx = idx[torch.randperm(idx.numel(), device=device)]           # permute_data, PINN:753
-            Xb, Yb = Xtr[idx], Ytr[idx]
-            Xb = Xb + torch.randn_like(Xb) * noise                           # PINN:756
-            opt.zero_grad(set_to_none=True)
-            with torch.autocast(device_type=device.type, dtype=autocast_dtype, enabled=use_ac):
-                preds = net(Xb)
-                loss = crit(preds.float(), Yb)
-                if kind == "tfd":
-                    loss = loss + (cfg.initial_alpha - crit.alpha) ** 2       # TFD:743 (constant 0: alpha never trains)
-            loss.backward()                                                  # DDP: bucketed RCCL all-reduce overlaps here
-            torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)          # PINN:766
-            opt.step()
-            tot += loss.detach()
+            # `order` is the DataLoader shuffle; permute_data (PINN:753) re-permutes inside the batch, which
+            # changes neither the batch statistics nor the mean loss, so it is folded into `order`
+            idx = order[b * bs:(b + 1) * bs]
+            if graph is not None and idx.numel() == bs:
+                sX.copy_(Xtr[idx]); sY.copy_(Ytr[idx]); s_noise.copy_(noise_t)
+                graph.replay()
+                tot += s_loss
+            else:
+                tot += train_step(Xtr[idx], Ytr[idx], noise_t)
         train_loss = _allreduce_mean(tot / nb_tr, world)
         net.eval()
         vt = torch.zeros((), device=device)
