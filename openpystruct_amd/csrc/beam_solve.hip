@@ -45,6 +45,7 @@ struct BeamParams {
 struct LdsAcc {
   const double* t2; const double* t6; const double* t12; const double* trl; const double* tpw; const double* tmw;
   const double* sI; const double* sF;
+  const double* sZero; int nReal;   // nodal loads: local nodes >= nReal are padding and read *sZero (0.0)
   unsigned long long bits;
   __device__ __forceinline__ double c2(int i) const { return t2[i]; }
   __device__ __forceinline__ double c6(int i) const { return t6[i]; }
@@ -53,7 +54,7 @@ struct LdsAcc {
   __device__ __forceinline__ double pw(int i) const { return tpw[i]; }
   __device__ __forceinline__ double mw(int i) const { return tmw[i]; }
   __device__ __forceinline__ double Ie(int i) const { return sI[i]; }
-  __device__ __forceinline__ double Fy(int i) const { return sF[i]; }
+  __device__ __forceinline__ double Fy(int i) const { return *(i < nReal ? sF + i : sZero); }
   __device__ __forceinline__ unsigned long long fixbits() const { return bits; }
   __device__ __forceinline__ void fence() const { __asm__ volatile("" ::: "memory"); }
 };
@@ -300,15 +301,16 @@ __global__ __launch_bounds__(64, waves_per_simd(P, M, SHARED)) void beam_solve_k
 #ifdef OPS_AMD_TRACE
   const unsigned long long ta = __builtin_amdgcn_s_memrealtime();   // all loads issued
 #endif
-  // padding defaults (I = 1 for the unit elements of the padding chain, no loads); LDS operations of one
-  // wave execute in order, so the real rows written below win
+  // padding defaults: I = 1 for the unit elements of the padding chain (columns Ne .. PM-1 of every row, and
+  // whole rows of beams beyond B); padded nodal loads are read through LdsAcc::Fy's zero slot.  LDS
+  // operations of one wave execute in order, so the real rows written below win.
+  if (lane < 2) s_dummy[lane] = 0.0;
+  if (nb == BPW) {                              // wave-uniform; the common case touches 12 columns per row
 #pragma unroll
-  for (int k = 0; k < NPAIR; ++k) {
-    const unsigned i0 = 2u * (lane + 64u * k);
-    if (k + 1 < NPAIR || i0 < BPW * PM) {       // only the last piece can run past the arrays
-      *reinterpret_cast<double2*>(&s_a[i0]) = double2{1.0, 1.0};
-      *reinterpret_cast<double2*>(&s_b[i0]) = double2{0.0, 0.0};
-    }
+    for (int b = 0; b < BPW; ++b)
+      for (unsigned e = Ne + lane; e < PM; e += 64) s_a[b * PM + e] = 1.0;
+  } else {
+    for (unsigned idx = lane; idx < BPW * PM; idx += 64) s_a[idx] = 1.0;
   }
   // ---- stage 0: element table (unit-inertia stiffness tile entries, 1/L, UDL loads) ----
   // element Ne has no stiffness; the elements beyond it are unit elements (L = 1, EI = 1): together with the
@@ -379,6 +381,8 @@ __global__ __launch_bounds__(64, waves_per_simd(P, M, SHARED)) void beam_solve_k
     acc.trl = &s_tab[3][tb][e0]; acc.tpw = &s_tab[4][tb][e0]; acc.tmw = &s_tab[5][tb][e0];
     acc.sI = &s_a[g * PM + e0];
     acc.sF = &s_b[g * N + e0];
+    acc.sZero = &s_dummy[1];
+    acc.nReal = N - e0;   // may be <= 0 (a lane that owns padding only) or >= M
     unsigned long long bits = 0;
 #pragma unroll
     for (int i = 0; i <= M; ++i)   // a node at or beyond N is padding: free (the row's bytes end at N)

@@ -163,3 +163,19 @@ def test_full_size_properties(oa, tiling):
     expect = bo.UDL_REF * 2.0 + F1[:, 1:-1]
     err = ((jump - expect)[:, free_inner]).abs().max() / V.abs().max()
     assert float(err) < 2e-6     # element end forces: same bound as the oracle comparison
+
+
+def test_nan_loads_do_not_cross_beams(oa):
+    """A beam whose loads are NaN must not contaminate its neighbours in the same wavefront (its row sits
+    next to theirs in LDS): their results stay bit-identical, its own become NaN."""
+    rng = np.random.default_rng(42)
+    x = np.linspace(0, 200, 101)
+    fix = bo.reference_fix_mask()
+    I, Fy = bo.random_cases(rng, 12, inertia="trajectory")
+    clean = _solve(oa, x, bo.E_REF, I, fix, Fy, bo.UDL_REF)
+    Fy2 = Fy.copy(); Fy2[5, :] = np.nan
+    dirty = _solve(oa, x, bo.E_REF, I, fix, Fy2, bo.UDL_REF)
+    keep = [b for b in range(12) if b != 5]
+    for a, d in zip(clean[:4], dirty[:4]):
+        assert np.array_equal(a[keep], d[keep])
+    assert np.isnan(dirty[0][5]).all()
