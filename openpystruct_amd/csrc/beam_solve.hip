@@ -221,11 +221,17 @@ __device__ __forceinline__ double buf_load_d(__amdgpu_buffer_rsrc_t r, unsigned 
   const v2i v = __builtin_amdgcn_raw_buffer_load_b64(r, (int)byte_off, 0, 0);
   return __builtin_bit_cast(double, v);
 }
+// Output stores carry a cache policy (the `aux` immediate: 16 = sc1 write-through, 2 = nt).  Plain stores
+// leave up to an L2's worth of dirty lines behind that the end-of-kernel release has to write back; measured
+// per 10^4-beam launch (A/B, same device, profiles/r01_notes.md): plain 16.4 us, sc1 14.35, sc0+sc1 14.4,
+// nt 15.1; at 2^20 beams nt is the best (969 vs 983 sc1 vs 990 us plain).
+template <int AUX>
 __device__ __forceinline__ void buf_store_d2(__amdgpu_buffer_rsrc_t r, unsigned byte_off, double2 x) {
-  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i, x), r, (int)byte_off, 0, 0);
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i, x), r, (int)byte_off, 0, AUX);
 }
+template <int AUX>
 __device__ __forceinline__ void buf_store_d(__amdgpu_buffer_rsrc_t r, unsigned byte_off, double x) {
-  __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2i, x), r, (int)byte_off, 0, 0);
+  __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2i, x), r, (int)byte_off, 0, AUX);
 }
 
 // SHARED: x, E and wy are the same for every beam (strides 0): one element table per workgroup.
@@ -237,6 +243,7 @@ __global__ __launch_bounds__(64, waves_per_simd(P, M, SHARED)) void beam_solve_k
   constexpr int PM = P * M;         // padded nodes per beam (>= N)
   constexpr int TG = SHARED ? 1 : BPW;
   constexpr int NPAIR = (BPW * PM / 2 + 63) / 64;   // 16-byte pieces per lane for one staged array
+  constexpr int ST = (P <= 8) ? 2 : 16;             // store policy: nt for the large-batch tiling, sc1 otherwise
   constexpr int NT = (TG * PM + 63) / 64;           // table entries per lane
   __shared__ double s_tab[6][TG][PM];
   __shared__ __attribute__((aligned(16))) double s_a[BPW * PM];
@@ -426,13 +433,13 @@ __global__ __launch_bounds__(64, waves_per_simd(P, M, SHARED)) void beam_solve_k
     for (int k = 0; k < NPAIR; ++k) {
       const unsigned i0 = 2u * (lane + 64u * k);
       if (k + 1 < NPAIR || i0 < BPW * PM) {     // LDS bound; the buffer descriptor drops pairs beyond the run
-        buf_store_d2(rV, i0 * 8u, *reinterpret_cast<const double2*>(&s_b[i0]));
-        buf_store_d2(rM, i0 * 8u, *reinterpret_cast<const double2*>(&s_a[i0]));
+        buf_store_d2<ST>(rV, i0 * 8u, *reinterpret_cast<const double2*>(&s_b[i0]));
+        buf_store_d2<ST>(rM, i0 * 8u, *reinterpret_cast<const double2*>(&s_a[i0]));
       }
     }
     if ((nE & 1) && lane == 0) {
-      buf_store_d(rV, (unsigned)(nE - 1) * 8u, s_b[nE - 1]);
-      buf_store_d(rM, (unsigned)(nE - 1) * 8u, s_a[nE - 1]);
+      buf_store_d<ST>(rV, (unsigned)(nE - 1) * 8u, s_b[nE - 1]);
+      buf_store_d<ST>(rM, (unsigned)(nE - 1) * 8u, s_a[nE - 1]);
     }
   } else {
     for (int idx = lane; idx < nE; idx += 64) {
@@ -452,13 +459,13 @@ __global__ __launch_bounds__(64, waves_per_simd(P, M, SHARED)) void beam_solve_k
     for (int k = 0; k < NPAIR; ++k) {
       const unsigned i0 = 2u * (lane + 64u * k);
       if (k + 1 < NPAIR || i0 < BPW * PM) {
-        buf_store_d2(rv, i0 * 8u, *reinterpret_cast<const double2*>(&s_b[i0]));
-        buf_store_d2(rt, i0 * 8u, *reinterpret_cast<const double2*>(&s_a[i0]));
+        buf_store_d2<ST>(rv, i0 * 8u, *reinterpret_cast<const double2*>(&s_b[i0]));
+        buf_store_d2<ST>(rt, i0 * 8u, *reinterpret_cast<const double2*>(&s_a[i0]));
       }
     }
     if ((nN & 1) && lane == 0) {
-      buf_store_d(rv, (unsigned)(nN - 1) * 8u, s_b[nN - 1]);
-      buf_store_d(rt, (unsigned)(nN - 1) * 8u, s_a[nN - 1]);
+      buf_store_d<ST>(rv, (unsigned)(nN - 1) * 8u, s_b[nN - 1]);
+      buf_store_d<ST>(rt, (unsigned)(nN - 1) * 8u, s_a[nN - 1]);
     }
   } else {
     for (int idx = lane; idx < nN; idx += 64) {
