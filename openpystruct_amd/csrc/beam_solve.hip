@@ -418,7 +418,8 @@ __global__ __launch_bounds__(64, waves_per_simd(P, M, SHARED)) void beam_solve_k
       if (i < cntE) out.sV[i] = qnan;
     }
   }
-  if (j == 0 && g < nb && p.status) p.status[beam0 + g] = gbad ? 1 : 0;
+  if (j == 0 && g < nb && p.status)   // write-through like the other outputs
+    __hip_atomic_store(&p.status[beam0 + g], gbad ? 1 : 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #ifdef OPS_AMD_TRACE
   const unsigned long long t2 = __builtin_amdgcn_s_memrealtime();
 #endif
