@@ -76,14 +76,14 @@ def cpu_baseline(B_hint):
     I1, Fy1 = bo.random_cases(rng, 20000, inertia="trajectory")
     reps_tile = (nb + 19999) // 20000
     I, Fy = np.tile(I1, (reps_tile, 1))[:nb], np.tile(Fy1, (reps_tile, 1))[:nb]
-    co.solve_beam_batched(x, bo.E_REF, I, fix, Fy, bo.UDL_REF, n_threads=cores)  # warm-up (thread pool, page faults)
+    out = co.solve_beam_batched(x, bo.E_REF, I, fix, Fy, bo.UDL_REF, n_threads=cores)  # warm-up (thread pool, page faults)
     t0 = time.perf_counter()
-    co.solve_beam_batched(x, bo.E_REF, I, fix, Fy, bo.UDL_REF, n_threads=cores)
+    co.solve_beam_batched(x, bo.E_REF, I, fix, Fy, bo.UDL_REF, n_threads=cores, out=out)
     dt = time.perf_counter() - t0
     reps = int(max(1, min(200, 10.0 / max(dt, 1e-4))))
     t0 = time.perf_counter()
     for _ in range(reps):
-        co.solve_beam_batched(x, bo.E_REF, I, fix, Fy, bo.UDL_REF, n_threads=cores)
+        co.solve_beam_batched(x, bo.E_REF, I, fix, Fy, bo.UDL_REF, n_threads=cores, out=out)
     dt = time.perf_counter() - t0
     return {
         "value": nb * reps / dt,

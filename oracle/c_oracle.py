@@ -34,7 +34,7 @@ def _p(a):
     return a.ctypes.data_as(ctypes.c_void_p)
 
 
-def solve_beam_batched(x, E, I, fix, Fy, wy, n_threads: int = 1):
+def solve_beam_batched(x, E, I, fix, Fy, wy, n_threads: int = 1, out=None):
     """Same broadcasting rules as oracle.beam_oracle.solve_beam_batched / the C-ABI."""
     I = np.ascontiguousarray(I, dtype=np.float64)
     B, Ne = I.shape
@@ -45,11 +45,9 @@ def solve_beam_batched(x, E, I, fix, Fy, wy, n_threads: int = 1):
     wy = np.ascontiguousarray(np.atleast_1d(np.asarray(wy, dtype=np.float64)))
     Fy = np.ascontiguousarray(Fy, dtype=np.float64)
     assert Fy.shape == (B, N)
-    v = np.empty((B, N))
-    th = np.empty((B, N))
-    V = np.empty((B, Ne))
-    M = np.empty((B, Ne))
-    st = np.empty(B, dtype=np.int32)
+    if out is None:
+        out = (np.empty((B, N)), np.empty((B, N)), np.empty((B, Ne)), np.empty((B, Ne)), np.empty(B, dtype=np.int32))
+    v, th, V, M, st = out      # pass `out` to reuse result buffers (no page faults inside a timed region)
     lib().oracle_beam_solve_batched_f64(
         B, Ne,
         _p(x), N if x.ndim == 2 else 0,
