@@ -112,6 +112,22 @@ int ops_beam_sizing_step_f32(int B, int Ne, float* I, double* I64, const double*
                              int32_t* epochs_run, uint8_t* active, float* last_loss, float* V32, float* M32,
                              const ops_sizing_params* hp, void* stream);
 
+/* Matrix-free FE residual for physics losses (an addition: the reference's "PINN" has no FE operator).
+ *   r = D (K(I) u - f):  rv, rt [B,N]; D zeroes the fixed DOFs; f = Fy + consistent beamUniform loads.
+ * Same argument meaning / strides as ops_beam_solve_batched_f64; I, Fy, v, theta, rv, rt dense. */
+int ops_beam_residual_f64(int B, int Ne, const double* x, long x_bstride, const double* E, long E_bstride,
+                          const double* I, const uint8_t* fix, long fix_bstride, const double* Fy,
+                          const double* wy, long wy_bstride, const double* v, const double* theta,
+                          double* rv, double* rt, void* stream);
+
+/* Vector-Jacobian product of the residual: given g = dL/dr (gv, gt [B,N]) returns
+ *   dv, dt [B,N] = K(I) D g   (dL/du)      dI [B,Ne] = (D g)_e^T (dk_e/dI_e) u_e   (dL/dI)
+ * scratch_v, scratch_t [B,N]: caller-provided work space (holds D g). */
+int ops_beam_residual_vjp_f64(int B, int Ne, const double* x, long x_bstride, const double* E, long E_bstride,
+                              const double* I, const uint8_t* fix, long fix_bstride, const double* v,
+                              const double* theta, const double* gv, const double* gt, double* scratch_v,
+                              double* scratch_t, double* dv, double* dt, double* dI, void* stream);
+
 /* Largest Ne a build supports, ABI version, and the text of the last HIP error seen by
  * this thread (empty string if none). */
 int ops_amd_max_elements(void);

@@ -16,6 +16,8 @@ LIB_PATH = os.environ.get("OPS_AMD_LIB") or os.path.join(_PKG, "lib", "libopenpy
 EXPORTS = (
     "ops_beam_solve_batched_f64",
     "ops_beam_sizing_step_f32",
+    "ops_beam_residual_f64",
+    "ops_beam_residual_vjp_f64",
     "ops_amd_max_elements",
     "ops_amd_abi_version",
     "ops_amd_last_error",
@@ -60,6 +62,12 @@ def load():
     g = lib.ops_beam_sizing_step_f32
     g.restype = it
     g.argtypes = [it, it] + [vp] * 13 + [ctypes.POINTER(SizingParams), vp]
+    r = lib.ops_beam_residual_f64
+    r.restype = it
+    r.argtypes = [it, it, vp, lg, vp, lg, vp, vp, lg, vp, vp, lg, vp, vp, vp, vp, vp]
+    rj = lib.ops_beam_residual_vjp_f64
+    rj.restype = it
+    rj.argtypes = [it, it, vp, lg, vp, lg, vp, vp, lg] + [vp] * 10
     lib.ops_amd_max_elements.restype = it
     lib.ops_amd_abi_version.restype = it
     lib.ops_amd_last_error.restype = ctypes.c_char_p

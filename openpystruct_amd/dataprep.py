@@ -81,6 +81,8 @@ class SurrogateData:
     max_constraint: torch.Tensor
     feat_dim: int
     max_lengths: Dict[str, int]
+    Fy_train: Optional[torch.Tensor] = None   # [G, N] nodal loads per training group (n_cases == 1 only): physics loss
+    Fy_val: Optional[torch.Tensor] = None
 
 
 INPUT_KEYS = ("roller_x_locations", "force_x_locations", "force_values", "node_positions")   # PINN:198-201
@@ -170,4 +172,15 @@ def prepare(records: Dict[str, object], *, kind: str = "pinn", n_cases: int = 6,
     if distributed and dist.is_available() and dist.is_initialized():
         dist.all_reduce(mn, op=dist.ReduceOp.MIN, group=group)
         dist.all_reduce(mx, op=dist.ReduceOp.MAX, group=group)
-    return SurrogateData(Xtr.contiguous(), Ytr.contiguous(), Xva.contiguous(), Yva.contiguous(), sc_in, sc_Y, mn, mx, feat_dim, ml)
+    Fy_tr = Fy_va = None
+    if n_cases == 1 and "force_nodes" in records and "force_values" in records:
+        # dense nodal load vectors of every case, for the FE-residual physics term (physics.py)
+        Nn = int(records["num_nodes"]) if not isinstance(records["num_nodes"], (list, tuple)) else int(records["num_nodes"][0])
+        Fy = torch.zeros((G, Nn), dtype=torch.float64)
+        for b in range(G):
+            for n, f in zip(records["force_nodes"][b], records["force_values"][b]):
+                Fy[b, int(n) - 1] += float(f)
+        Fy = Fy.to(dev)
+        Fy_tr, Fy_va = Fy[tr].contiguous(), Fy[va].contiguous()
+    return SurrogateData(Xtr.contiguous(), Ytr.contiguous(), Xva.contiguous(), Yva.contiguous(), sc_in, sc_Y, mn, mx, feat_dim, ml,
+                         Fy_tr, Fy_va)

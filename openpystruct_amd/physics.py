@@ -1,0 +1,92 @@
+"""FE-residual physics loss for the surrogates (north_star: "physics-loss via HIP FE residual").
+
+The reference's PINN has no physics operator: its "physics" is a relative-L1 fit of regressed deflections
+and rotations (/root/reference/OpenPyStruct_PINN_MultiCase.py:646-652).  This module adds
+the real thing as an optional term: for predicted inertias I and nodal displacements (v, theta) of a case,
+
+    r = D (K(I) u - f)          (free-DOF equilibrium residual; same element / load / constraint semantics
+                                 as the solver, HIP kernels in csrc/beam_residual.hip)
+
+with a custom autograd Function whose backward is the matching HIP vector-Jacobian product
+(dL/du = K D g, dL/dI_e = (D g)_e^T dk_e/dI_e u_e).  `fe_residual_loss` scales the residual row-wise by the
+diagonal of K (Jacobi scaling), so that it is dimensionless and commensurate with the data terms.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _cabi
+
+
+def _f64(t, dev):
+    return torch.as_tensor(t, dtype=torch.float64, device=dev).contiguous()
+
+
+class _FEResidual(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, I, v, theta, x, E, fix, Fy, wy):
+        lib = _cabi.load()
+        if not I.is_cuda:
+            raise RuntimeError("fe_residual needs GPU tensors: openpystruct_amd has no CPU fallback")
+        dev = I.device
+        I, v, theta = (t.detach().to(torch.float64).contiguous() for t in (I, v, theta))
+        B, Ne = I.shape
+        N = Ne + 1
+        rv, rt = torch.empty_like(v), torch.empty_like(theta)
+        s = torch.cuda.current_stream(dev).cuda_stream
+        rc = lib.ops_beam_residual_f64(B, Ne, x.data_ptr(), N if x.dim() == 2 else 0, E.data_ptr(), Ne if E.numel() != 1 else 0,
+                                       I.data_ptr(), fix.data_ptr(), N if fix.dim() == 2 else 0, Fy.data_ptr(), wy.data_ptr(),
+                                       Ne if wy.numel() != 1 else 0, v.data_ptr(), theta.data_ptr(), rv.data_ptr(), rt.data_ptr(), s)
+        if rc != _cabi.OK:
+            raise RuntimeError(f"ops_beam_residual_f64 failed with code {rc}")
+        ctx.save_for_backward(I, v, theta, x, E, fix)
+        return rv, rt
+
+    @staticmethod
+    def backward(ctx, gv, gt):
+        lib = _cabi.load()
+        I, v, theta, x, E, fix = ctx.saved_tensors
+        dev = I.device
+        B, Ne = I.shape
+        N = Ne + 1
+        gv, gt = gv.to(torch.float64).contiguous(), gt.to(torch.float64).contiguous()
+        sv, st_ = torch.empty_like(v), torch.empty_like(v)
+        dv, dt, dI = torch.empty_like(v), torch.empty_like(v), torch.empty_like(I)
+        s = torch.cuda.current_stream(dev).cuda_stream
+        rc = lib.ops_beam_residual_vjp_f64(B, Ne, x.data_ptr(), N if x.dim() == 2 else 0, E.data_ptr(), Ne if E.numel() != 1 else 0,
+                                           I.data_ptr(), fix.data_ptr(), N if fix.dim() == 2 else 0, v.data_ptr(), theta.data_ptr(),
+                                           gv.data_ptr(), gt.data_ptr(), sv.data_ptr(), st_.data_ptr(), dv.data_ptr(), dt.data_ptr(),
+                                           dI.data_ptr(), s)
+        if rc != _cabi.OK:
+            raise RuntimeError(f"ops_beam_residual_vjp_f64 failed with code {rc}")
+        return dI, dv, dt, None, None, None, None, None
+
+
+def fe_residual(I, v, theta, x, E, fix, Fy, wy):
+    """r_v, r_theta [B,N] = D (K(I) [v; theta] - f); differentiable w.r.t. I, v, theta (float64 inside)."""
+    dev = I.device
+    return _FEResidual.apply(I, v, theta, _f64(x, dev), _f64(E, dev), torch.as_tensor(fix, dtype=torch.uint8, device=dev).contiguous(),
+                             _f64(Fy, dev), _f64(wy, dev))
+
+
+def stiffness_diagonal(I, x, E):
+    """diag(K(I)) as (d_v, d_theta) [B,N] (torch ops; used for the Jacobi scaling of the residual)."""
+    dev = I.device
+    x, E = _f64(x, dev), _f64(E, dev)
+    L = (x[..., 1:] - x[..., :-1])
+    EI = E * I.to(torch.float64)
+    k12, k4 = 12.0 * EI / L ** 3, 4.0 * EI / L
+    z = torch.zeros_like(k12[:, :1])
+    dv = torch.cat([k12, z], 1) + torch.cat([z, k12], 1)
+    dth = torch.cat([k4, z], 1) + torch.cat([z, k4], 1)
+    return dv, dth
+
+
+def fe_residual_loss(I, v, theta, x, E, fix, Fy, wy):
+    """mean over free DOFs of (r_i / K_ii)^2 relative to the mean squared displacement: dimensionless."""
+    rv, rt = fe_residual(I, v, theta, x, E, fix, Fy, wy)
+    dv, dth = stiffness_diagonal(I.detach(), x, E)
+    ev, et = rv / dv, rt / dth                      # displacement-like errors
+    scale = (v.detach().to(torch.float64) ** 2).mean() + 1e-30
+    scale_t = (theta.detach().to(torch.float64) ** 2).mean() + 1e-30
+    return (ev ** 2).mean() / scale + (et ** 2).mean() / scale_t

@@ -99,6 +99,17 @@ def build_model_and_loss(kind: str, cfg, data: SurrogateData, device):
     return model.to(device), crit.to(device)
 
 
+@dataclass
+class PhysicsTerm:
+    """Optional FE-residual term for the PINN (physics.py).  Needs per-case targets (cfg.n_cases == 1, so that
+    predicted inertias and displacements belong to ONE load case) and `data.Fy_train`."""
+    weight: float
+    x: torch.Tensor        # [N] node coordinates
+    E: float
+    fix: torch.Tensor      # [N] uint8
+    wy: float
+
+
 def r2_score(y_true: torch.Tensor, y_pred: torch.Tensor) -> float:
     """sklearn.metrics.r2_score on the raveled arrays (PINN:851)."""
     yt, yp = y_true.double().reshape(-1), y_pred.double().reshape(-1)
@@ -116,7 +127,7 @@ def _allreduce_mean(t: torch.Tensor, world: int) -> torch.Tensor:
 
 def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, autocast_dtype=torch.bfloat16,
                     sync_bn: bool = False, max_epochs: Optional[int] = None, log=None, seed: int = 0,
-                    use_graph: Optional[bool] = None) -> Dict[str, object]:
+                    use_graph: Optional[bool] = None, physics: Optional[PhysicsTerm] = None) -> Dict[str, object]:
     """Trains on THIS rank's `data` shard; uses DDP when torch.distributed is initialised with world_size > 1.
     Returns history, best state dict, validation R^2 (I only) and per-epoch times."""
     cfg = cfg or (PinnConfig() if kind == "pinn" else TfdConfig())
@@ -151,7 +162,23 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
     use_ac = device.type == "cuda" and autocast_dtype is not None
     hist = {"train": [], "val": [], "epoch_s": []}
 
-    def train_step(Xb, Yb, noise_t):
+    if physics is not None:
+        if kind != "pinn" or cfg.n_cases != 1 or data.Fy_train is None:
+            raise ValueError("the FE-residual term needs kind='pinn', n_cases == 1 and data.Fy_train (per-case loads)")
+        from .physics import fe_residual_loss
+        use_graph = False                       # the physics term indexes per-batch loads eagerly
+        Fy_tr = data.Fy_train.to(device)
+        sI, sD, sR = data.scalers_Y["I"], data.scalers_Y["deflections"], data.scalers_Y["rotations"]
+        px, pfix = physics.x.to(device), physics.fix.to(device)
+
+    def physics_loss(preds, rows):
+        nel = cfg.nelem
+        I_p = sI.inverse_transform(preds[:, :nel]).clamp_min(1e-8)
+        v_p = sD.inverse_transform(preds[:, nel:2 * nel + 1])
+        t_p = sR.inverse_transform(preds[:, 2 * nel + 1:])
+        return fe_residual_loss(I_p, v_p, t_p, px, physics.E, pfix, Fy_tr[rows], physics.wy)
+
+    def train_step(Xb, Yb, noise_t, rows=None):
         Xn = Xb + torch.randn_like(Xb) * noise_t                         # PINN:756
         opt.zero_grad(set_to_none=False)
         with torch.autocast(device_type=device.type, dtype=autocast_dtype, enabled=use_ac):
@@ -159,6 +186,8 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
             loss = crit(preds.float(), Yb)
             if kind == "tfd":
                 loss = loss + (cfg.initial_alpha - crit.alpha) ** 2       # TFD:743 (constant 0: alpha never trains)
+        if physics is not None:
+            loss = loss + physics.weight * physics_loss(preds.float(), rows).float()
         loss.backward()                                                  # DDP: bucketed RCCL all-reduce overlaps here
         torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)          # PINN:766
         opt.step()
@@ -204,7 +233,7 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
                 graph.replay()
                 tot += s_loss
             else:
-                tot += train_step(Xtr[idx], Ytr[idx], noise_t)
+                tot += train_step(Xtr[idx], Ytr[idx], noise_t, idx)
         train_loss = _allreduce_mean(tot / nb_tr, world)
         net.eval()
         vt = torch.zeros((), device=device)
