@@ -106,7 +106,7 @@ typedef struct ops_sizing_params {
  *   best_loss    [B] float32 (init +inf), patience_cnt [B] int32 (init 0), epochs_run [B] int32 (init 0),
  *   active       [B] uint8 (init 1): cleared when patience runs out or max_epochs is reached
  *   last_loss    [B] float32 out, V32/M32 [B,Ne] float32 out: the recorded `shear_forces` / `bending_moments`
- * Device pointers, asynchronous on `stream`, nothing allocated.  Ne <= 128. */
+ * Device pointers, asynchronous on `stream`, nothing allocated.  Ne <= 512. */
 int ops_beam_sizing_step_f32(int B, int Ne, float* I, double* I64, const double* V, const double* M,
                              float* exp_avg, float* exp_avg_sq, float* best_loss, int32_t* patience_cnt,
                              int32_t* epochs_run, uint8_t* active, float* last_loss, float* V32, float* M32,
@@ -127,6 +127,22 @@ int ops_beam_residual_vjp_f64(int B, int Ne, const double* x, long x_bstride, co
                               const double* I, const uint8_t* fix, long fix_bstride, const double* v,
                               const double* theta, const double* gv, const double* gt, double* scratch_v,
                               double* scratch_t, double* dv, double* dt, double* dI, void* stream);
+
+/* Batched 2-D frame solve (3 DOF per node; SURVEY 8(f1), BASELINE config 5): replaces, for B frames that share one
+ * topology, `setup_frame_model` + `ops.analyze(1)` + `ops.eleResponse(e,'forces')` of
+ * OpenPyStruct_FrameOpt_Discrete_Beta.py:75-139, :151, :181-183.  Host-prepared, shared by the batch:
+ *   elem_geo [Ne,3] (L, cos, sin), elem_EA [Ne], elem_E [Ne], elem_w [Ne,2] (beamUniform Wy, Wx: local transverse, axial),
+ *   elem_eq [Ne,6] / node_eq [Nn,3]: equation numbers (PlainHandler: -1 for constrained DOFs), n_eq, half_bandwidth.
+ * Per frame: I [B,Ne]; loads [Nn,3] (loads_bstride 0) or [B,Nn,3] (`ops.load(node, Fx, Fy, Mz)`).
+ * Outputs: disp [B,Nn,3], forces [B,Ne,6] (global resisting forces = eleResponse 'forces'), V / M [B,Ne] = forces[..,1] /
+ * forces[..,2] (FR:151-153), status [B] (non-zero: not positive definite, outputs NaN).
+ * The band matrix lives in LDS: n_eq * (half_bandwidth + 2) * 8 bytes must fit 160 KB and half_bandwidth <= 63,
+ * otherwise OPS_AMD_ERR_UNSUPPORTED. */
+int ops_frame_solve_batched_f64(int B, int n_nodes, int n_elems, int n_eq, int half_bandwidth,
+                                const double* elem_geo, const double* elem_EA, const double* elem_E,
+                                const double* elem_w, const int32_t* elem_eq, const int32_t* node_eq,
+                                const double* I, const double* loads, long loads_bstride, double* disp,
+                                double* forces, double* V, double* M, int32_t* status, void* stream);
 
 /* Largest Ne a build supports, ABI version, and the text of the last HIP error seen by
  * this thread (empty string if none). */

@@ -18,6 +18,7 @@ EXPORTS = (
     "ops_beam_sizing_step_f32",
     "ops_beam_residual_f64",
     "ops_beam_residual_vjp_f64",
+    "ops_frame_solve_batched_f64",
     "ops_amd_max_elements",
     "ops_amd_abi_version",
     "ops_amd_last_error",
@@ -68,6 +69,9 @@ def load():
     rj = lib.ops_beam_residual_vjp_f64
     rj.restype = it
     rj.argtypes = [it, it, vp, lg, vp, lg, vp, vp, lg] + [vp] * 10
+    fr = lib.ops_frame_solve_batched_f64
+    fr.restype = it
+    fr.argtypes = [it] * 5 + [vp] * 8 + [lg] + [vp] * 6
     lib.ops_amd_max_elements.restype = it
     lib.ops_amd_abi_version.restype = it
     lib.ops_amd_last_error.restype = ctypes.c_char_p

@@ -14,7 +14,7 @@
 // so the solver's outputs of a finished case stay those of its LAST solve (the reference records
 // shear/moment/displacements one Adam step behind I_values, :189-208 vs :239).
 //
-// Mapping: one 64-lane wavefront per case, lane e handles elements e and e+64 (HBM-bound
+// Mapping: one 64-lane wavefront per case, lane e handles elements e, e+64, ... (Ne <= 512) (HBM-bound
 // elementwise work, coalesced rows, wave-level DPP/shuffle reduction for the loss).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -47,11 +47,12 @@ __global__ __launch_bounds__(256) void sizing_step_kernel(int B, int Ne, float* 
   const float bc2s = (float)sqrt(1.0 - pow(hp.beta2, (double)(t + 1)));
   const float step_size = lr_t / bc1;
   float lsum_I = 0.f, lsum_b = 0.f, lsum_s = 0.f;
-  float Inew[2], Iold[2];
-  for (int k = 0; k < 2; ++k) {
+  constexpr int KMAX = 8;               // Ne <= 512
+  float Inew[KMAX];
+#pragma unroll
+  for (int k = 0; k < KMAX; ++k) {
     const int e = lane + 64 * k;
     Inew[k] = 0.f;
-    Iold[k] = 0.f;
     if (e < Ne) {
       const long o = b * Ne + e;
       const float Ie = I[o];
@@ -76,7 +77,6 @@ __global__ __launch_bounds__(256) void sizing_step_kernel(int B, int Ne, float* 
       In = fmaxf(In, (float)hp.clamp_min);
       I[o] = In;
       Inew[k] = In;
-      Iold[k] = Ie;
     }
   }
   const float loss = wave_sum(lsum_I) + (float)hp.alpha_moment * wave_sum(lsum_b) + (float)hp.alpha_shear * wave_sum(lsum_s);
@@ -86,7 +86,8 @@ __global__ __launch_bounds__(256) void sizing_step_kernel(int B, int Ne, float* 
   if (loss < best - (float)hp.tolerance) { best = loss; cnt = 0; } else { cnt += 1; }
   const bool stop = (cnt >= hp.patience) || (t + 1 >= hp.max_epochs);
   if (!stop) {
-    for (int k = 0; k < 2; ++k) {
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
       const int e = lane + 64 * k;
       if (e < Ne) I64[b * Ne + e] = (double)Inew[k];   // what the next solve reads
     }
@@ -98,7 +99,6 @@ __global__ __launch_bounds__(256) void sizing_step_kernel(int B, int Ne, float* 
     last_loss[b] = loss;
     if (stop) active[b] = 0;
   }
-  (void)Iold;
 }
 
 }  // namespace opsamd
@@ -107,7 +107,7 @@ extern "C" int ops_beam_sizing_step_f32(int B, int Ne, float* I, double* I64, co
                                         float* exp_avg, float* exp_avg_sq, float* best_loss, int32_t* patience_cnt,
                                         int32_t* epochs_run, uint8_t* active, float* last_loss, float* V32, float* M32,
                                         const ops_sizing_params* hp, void* stream) {
-  if (B < 0 || Ne < 1 || Ne > 128) return Ne > 128 ? OPS_AMD_ERR_UNSUPPORTED : OPS_AMD_ERR_INVALID_ARG;
+  if (B < 0 || Ne < 1 || Ne > 512) return Ne > 512 ? OPS_AMD_ERR_UNSUPPORTED : OPS_AMD_ERR_INVALID_ARG;
   if (B == 0) return OPS_AMD_OK;
   if (!I || !I64 || !V || !M || !exp_avg || !exp_avg_sq || !best_loss || !patience_cnt || !epochs_run || !active ||
       !last_loss || !V32 || !M32 || !hp)

@@ -1,0 +1,178 @@
+"""Batched 2-D frame analysis and sizing: the host side of SURVEY 8(f1) / BASELINE config 5.
+
+Mirrors /root/reference/OpenPyStruct_FrameOpt_Discrete_Beta.py:
+  * grid geometry, element order (columns first, then beams), supports, loads   FR:50-69, :75-139 -> `grid_frame`
+  * `setup_frame_model` + `ops.analyze(1)` + `ops.eleResponse(e,'forces')`        FR:75-139, :151, :181-183 -> `frame_solve`
+  * loss (bending eps 1e-8, "shear" = global Fy even for columns), Adam without a scheduler, early stop
+                                                                                  FR:141-206 -> `optimize_frames`
+One topology (coordinates, connectivity, constraints) is prepared once on the host -- equation numbers as
+OpenSees' PlainHandler + a node-order numberer would give them, half bandwidth -- and shared by the batch;
+frames differ in their inertia vectors (and optionally loads).  The solve is the HIP kernel in
+csrc/frame_solve.hip behind `ops_frame_solve_batched_f64`; there is no CPU path.
+"""
+from __future__ import annotations
+
+import ctypes
+from dataclasses import dataclass
+from typing import NamedTuple, Optional
+
+import numpy as np
+import torch
+
+from . import _cabi
+
+
+@dataclass
+class FrameConfig:
+    """FR:17-44."""
+    bay_width: float = 6.0
+    story_height: float = 3.0
+    E: float = 200e9
+    nu: float = 0.3
+    A: float = 0.02
+    I0: float = 5e-4
+    alpha_moment: float = 1e-2
+    alpha_shear: float = 1e-2
+    k: float = 0.03
+    lateral_load: float = 1e4
+    vertical_load: float = -1e4
+    num_epochs: int = 5000
+    lr: float = 0.005
+    tolerance: float = 1e-3
+    patience: int = 10
+
+    @property
+    def G(self):
+        return self.E / (2 * (1 + self.nu))
+
+
+class FrameTopology:
+    """Shared description of a frame: what `setup_frame_model` rebuilds every epoch, minus the inertias."""
+
+    def __init__(self, coords, conn, fix3, A, E, wy, wx, nodal_loads, device="cuda"):
+        coords = np.asarray(coords, dtype=np.float64)
+        conn = np.asarray(conn, dtype=np.int64)
+        fix3 = np.asarray(fix3).astype(bool)
+        self.Nn, self.Ne = coords.shape[0], conn.shape[0]
+        d = coords[conn[:, 1]] - coords[conn[:, 0]]
+        L = np.hypot(d[:, 0], d[:, 1])
+        geo = np.stack([L, d[:, 0] / L, d[:, 1] / L], axis=1)
+        node_eq = -np.ones((self.Nn, 3), dtype=np.int32)
+        node_eq[~fix3] = np.arange(int((~fix3).sum()), dtype=np.int32)       # node order (row-major on a grid)
+        elem_eq = np.concatenate([node_eq[conn[:, 0]], node_eq[conn[:, 1]]], axis=1)
+        span = [int(q[q >= 0].max() - q[q >= 0].min()) for q in elem_eq if (q >= 0).any()]
+        self.n_eq, self.kd = int((~fix3).sum()), max(span) if span else 0
+        Ev = np.broadcast_to(np.asarray(E, dtype=np.float64), (self.Ne,))
+        Av = np.broadcast_to(np.asarray(A, dtype=np.float64), (self.Ne,))
+        w = np.stack([np.broadcast_to(np.asarray(wy, dtype=np.float64), (self.Ne,)),
+                      np.broadcast_to(np.asarray(wx, dtype=np.float64), (self.Ne,))], axis=1)
+        self.coords, self.conn, self.fix3 = coords, conn, fix3
+        self.A, self.E, self.wy, self.wx = Av.copy(), Ev.copy(), w[:, 0].copy(), w[:, 1].copy()
+        self.nodal_loads = np.asarray(nodal_loads, dtype=np.float64).reshape(self.Nn, 3)
+        dev = torch.device(device)
+        t = lambda a, dt: torch.as_tensor(np.ascontiguousarray(a), dtype=dt, device=dev)  # noqa: E731
+        self.device = dev
+        self.d_geo, self.d_EA, self.d_E, self.d_w = t(geo, torch.float64), t(Ev * Av, torch.float64), t(Ev, torch.float64), t(w, torch.float64)
+        self.d_elem_eq, self.d_node_eq = t(elem_eq, torch.int32), t(node_eq, torch.int32)
+        self.d_loads = t(self.nodal_loads, torch.float64)
+
+    def lds_bytes(self) -> int:
+        return (self.n_eq * (self.kd + 1) + self.n_eq) * 8
+
+
+def grid_frame(num_bays: int, num_stories: int, cfg: Optional[FrameConfig] = None, device="cuda") -> FrameTopology:
+    """The reference's rectangular frame (FR:50-69, :84-131): nodes row by row from the ground, columns then
+    beams, ground row fully fixed, lateral loads on the left column line, beamUniform(w, w) on the beams."""
+    cfg = cfg or FrameConfig()
+    nb1 = num_bays + 1
+    coords = np.array([(j * cfg.bay_width, i * cfg.story_height) for i in range(num_stories + 1) for j in range(nb1)])
+    cols = [(i * nb1 + j, (i + 1) * nb1 + j) for i in range(num_stories) for j in range(nb1)]                  # FR:101-107
+    beams = [(i * nb1 + j, i * nb1 + j + 1) for i in range(1, num_stories + 1) for j in range(num_bays)]      # FR:110-116
+    conn = np.array(cols + beams)
+    fix3 = np.zeros((coords.shape[0], 3), dtype=bool)
+    fix3[coords[:, 1] == 0.0] = True                                                                           # FR:96-98
+    loads = np.zeros((coords.shape[0], 3))
+    loads[(coords[:, 0] == 0.0) & (coords[:, 1] != 0.0), 0] = cfg.lateral_load                                 # FR:126-128
+    w = np.zeros(len(conn)); w[len(cols):] = cfg.vertical_load                                                 # FR:130-131 (Wy = Wx)
+    return FrameTopology(coords, conn, fix3, cfg.A, cfg.E, w, w, loads, device)
+
+
+class FrameSolution(NamedTuple):
+    disp: torch.Tensor      # [B, Nn, 3]
+    forces: torch.Tensor    # [B, Ne, 6]  eleResponse(e, 'forces')
+    V: torch.Tensor         # [B, Ne]     forces[..., 1]  (FR:152)
+    M: torch.Tensor         # [B, Ne]     forces[..., 2]  (FR:153)
+    status: torch.Tensor    # [B] int32
+
+
+def frame_solve(topo: FrameTopology, I: torch.Tensor, loads: Optional[torch.Tensor] = None,
+                out: Optional[FrameSolution] = None) -> FrameSolution:
+    lib = _cabi.load()
+    if not torch.is_tensor(I) or not I.is_cuda:
+        raise RuntimeError("frame_solve needs GPU tensors: openpystruct_amd has no CPU fallback")
+    if I.dtype != torch.float64 or I.dim() != 2 or I.shape[1] != topo.Ne:
+        raise ValueError(f"I must be float64 [B, {topo.Ne}]")
+    I = I.contiguous()
+    B = I.shape[0]
+    dev = I.device
+    if loads is None:
+        loads, lbs = topo.d_loads, 0
+    else:
+        loads = loads.to(torch.float64).contiguous()
+        lbs = topo.Nn * 3 if loads.dim() == 3 else 0
+    if out is None:
+        f64 = dict(dtype=torch.float64, device=dev)
+        out = FrameSolution(torch.empty((B, topo.Nn, 3), **f64), torch.empty((B, topo.Ne, 6), **f64),
+                            torch.empty((B, topo.Ne), **f64), torch.empty((B, topo.Ne), **f64),
+                            torch.empty((B,), dtype=torch.int32, device=dev))
+    with torch.cuda.device(dev):
+        rc = lib.ops_frame_solve_batched_f64(
+            B, topo.Nn, topo.Ne, topo.n_eq, topo.kd, topo.d_geo.data_ptr(), topo.d_EA.data_ptr(), topo.d_E.data_ptr(),
+            topo.d_w.data_ptr(), topo.d_elem_eq.data_ptr(), topo.d_node_eq.data_ptr(), I.data_ptr(), loads.data_ptr(), lbs,
+            out.disp.data_ptr(), out.forces.data_ptr(), out.V.data_ptr(), out.M.data_ptr(), out.status.data_ptr(),
+            torch.cuda.current_stream(dev).cuda_stream)
+    if rc == _cabi.ERR_UNSUPPORTED:
+        raise NotImplementedError(f"frame too large for the LDS-resident band solver: n_eq={topo.n_eq}, half bandwidth={topo.kd} "
+                                  f"({topo.lds_bytes()} B > 160 KB)")
+    if rc != _cabi.OK:
+        raise RuntimeError(f"ops_frame_solve_batched_f64 failed with code {rc}")
+    return out
+
+
+def optimize_frames(topo: FrameTopology, B: int, cfg: Optional[FrameConfig] = None, I0: Optional[torch.Tensor] = None,
+                    max_epochs: Optional[int] = None, poll_every: int = 25):
+    """FR:163-206 for B frames at once (same topology; `I0` [B,Ne] lets them start from different designs).
+    Adam(lr) with NO scheduler (gamma = 1), loss with `+1e-8` in the bending term (FR:155), early stop
+    tolerance 1e-3 / patience 10.  Returns (I float32 [B,Ne], solution of the last solve, epochs_run)."""
+    cfg = cfg or FrameConfig()
+    lib = _cabi.load()
+    dev = topo.device
+    Ne = topo.Ne
+    f32 = dict(dtype=torch.float32, device=dev)
+    I = (I0.to(**f32).clone() if I0 is not None else torch.full((B, Ne), cfg.I0, **f32))
+    I64 = I.double()
+    ea, es = torch.zeros((B, Ne), **f32), torch.zeros((B, Ne), **f32)
+    best = torch.full((B,), float("inf"), **f32)
+    cnt = torch.zeros((B,), dtype=torch.int32, device=dev)
+    ep = torch.zeros((B,), dtype=torch.int32, device=dev)
+    active = torch.ones((B,), dtype=torch.uint8, device=dev)
+    last = torch.zeros((B,), **f32)
+    V32, M32 = torch.zeros((B, Ne), **f32), torch.zeros((B, Ne), **f32)
+    n_max = max_epochs if max_epochs is not None else cfg.num_epochs
+    hp = _cabi.SizingParams(E=cfg.E, G=cfg.G, alpha_moment=cfg.alpha_moment, alpha_shear=cfg.alpha_shear, lr=cfg.lr, gamma=1.0,
+                            beta1=0.9, beta2=0.999, adam_eps=1e-8, clamp_min=1e-8, bend_eps=1e-8, area_coef=cfg.k,
+                            tolerance=cfg.tolerance, patience=cfg.patience, max_epochs=n_max)
+    sol = None
+    for e in range(n_max):
+        sol = frame_solve(topo, I64, out=sol)
+        with torch.cuda.device(dev):
+            rc = lib.ops_beam_sizing_step_f32(B, Ne, I.data_ptr(), I64.data_ptr(), sol.V.data_ptr(), sol.M.data_ptr(), ea.data_ptr(),
+                                              es.data_ptr(), best.data_ptr(), cnt.data_ptr(), ep.data_ptr(), active.data_ptr(),
+                                              last.data_ptr(), V32.data_ptr(), M32.data_ptr(), ctypes.byref(hp),
+                                              torch.cuda.current_stream(dev).cuda_stream)
+        if rc != _cabi.OK:
+            raise RuntimeError(f"ops_beam_sizing_step_f32 failed with code {rc}")
+        if (e + 1) % poll_every == 0 and not bool(active.any()):
+            break
+    torch.cuda.synchronize(dev)
+    return I, sol, ep
