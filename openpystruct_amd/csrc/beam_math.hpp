@@ -151,6 +151,15 @@ BEAM_HD Mat2 mask_rows(const Mat2& m, const Flags<RZ>& c) {
   return Mat2{m.a * c.v, m.b * c.v, m.c, m.d};
 }
 
+// Inverse of the constrained pivot block, PROJECTED onto the free DOFs: fixed DOFs get a unit pivot for the
+// factorisation (identity row/column, so the pivot test passes) and a ZERO row/column in the returned inverse.
+template <bool RZ>
+BEAM_HD Sym2 proj_inv(const Sym2& s, const Flags<RZ>& c, int& bad) {
+  const Sym2 g = inv_spd(mask_node(s, c), bad);   // off-diagonal already zero when a DOF is fixed
+  if (RZ) return Sym2{c.v * g.a, g.b, c.t * g.c};
+  return Sym2{c.v * g.a, g.b, g.c};
+}
+
 // State a lane keeps across the phases.
 template <int M>
 struct SegState {
@@ -183,16 +192,16 @@ BEAM_HD void seg_condense(SegState<M>& s, const Acc& acc, int& bad) {
     const Flags<RZ> c = node_flags<RZ>(fb, i);
     const ElemK k = elem_k(acc.c2(i), acc.c6(i), acc.c12(i), acc.Ie(i));
     const double pw = acc.pw(i), mw = acc.mw(i);
-    // node i is complete: left element (in Scc/gc) + right element; then constrain it
-    const Sym2 Sii = mask_node(Sym2{s.Scc.a + k.kA, s.Scc.b + k.kB, s.Scc.c + k.kC}, c);
-    const Vec2 gi = mask_vec(Vec2{s.gc.x + pw + acc.Fy(i), s.gc.y + mw}, c);
-    const Mat2 SLi = mask_cols(s.SLc, c);                               // left boundary <-> node i
-    const Mat2 Kr = mask_rows(Mat2{-k.kA, k.kB, -k.kB, k.kD}, c);       // node i <-> node i+1
-    const Sym2 G = inv_spd(Sii, bad);
+    // node i is complete: left element (in Scc/gc) + right element.  Its constraints enter ONLY through
+    // the projected inverse G (zero rows/columns on fixed DOFs): S_Li G, K_{i+1,i} G and G h then ignore the
+    // fixed DOFs by themselves, so couplings and right-hand sides need no masking.
+    const Sym2 G = proj_inv(Sym2{s.Scc.a + k.kA, s.Scc.b + k.kB, s.Scc.c + k.kC}, c, bad);
+    const Vec2 gi{s.gc.x + pw + acc.Fy(i), s.gc.y + mw};
+    const Mat2 Kr{-k.kA, k.kB, -k.kB, k.kD};                             // node i <-> node i+1
     s.Ginv[i] = G;
-    const Mat2 Pm = mul(SLi, G);     // S_Li * Sii^-1
-    const Mat2 Qm = mulT(Kr, G);     // K_{i+1,i} * Sii^-1
-    s.SLL = sub_mulT(s.SLL, Pm, SLi);
+    const Mat2 Pm = mul(s.SLc, G);   // S_Li * G
+    const Mat2 Qm = mulT(Kr, G);     // K_{i+1,i} * G
+    s.SLL = sub_mulT(s.SLL, Pm, s.SLc);
     s.gL = sub_mul(s.gL, Pm, gi);
     s.SLc = neg_mul(Pm, Kr);
     s.Scc = sub_mul(Sym2{k.kA, -k.kB, k.kC}, Qm, Kr);
@@ -247,8 +256,8 @@ BEAM_HD void pcr_step(IfaceRow& r, const Sym2& Gm, const Mat2& Am, const Vec2& f
 // Phase C.  Out receives results by LOCAL index: node(i, v, theta), elem(i, V, Mz), i in [0, M).
 template <int M, bool RZ, class Acc, class Out>
 BEAM_HD void seg_solve(const SegState<M>& s, const Acc& acc, const Vec2& uL, const Vec2& uR, Out& out) {
-  const unsigned long long fb = acc.fixbits();
-  // right-hand-side sweep with the left boundary displacement prescribed
+  (void)acc.fixbits();
+  // right-hand-side sweep with the left boundary displacement prescribed (no masks: see seg_condense)
   Vec2 h[M];
   {
     const ElemK k0 = elem_k(acc.c2(0), acc.c6(0), acc.c12(0), acc.Ie(0));
@@ -256,14 +265,12 @@ BEAM_HD void seg_solve(const SegState<M>& s, const Acc& acc, const Vec2& uL, con
 #pragma unroll
     for (int i = 1; i < M; ++i) {
       acc.fence();
-      const Flags<RZ> c = node_flags<RZ>(fb, i);
-      const ElemK k = elem_k(acc.c2(i), acc.c6(i), acc.c12(i), acc.Ie(i));
       const double pw = acc.pw(i), mw = acc.mw(i);
-      h[i] = mask_vec(Vec2{carry.x + pw + acc.Fy(i), carry.y + mw}, c);
+      h[i] = Vec2{carry.x + pw + acc.Fy(i), carry.y + mw};
       if (i + 1 < M) {
-        const Mat2 Kr = mask_rows(Mat2{-k.kA, k.kB, -k.kB, k.kD}, c);
-        const Mat2 Qm = mulT(Kr, s.Ginv[i]);
-        carry = sub_mul(Vec2{pw, -mw}, Qm, h[i]);
+        const ElemK k = elem_k(acc.c2(i), acc.c6(i), acc.c12(i), acc.Ie(i));
+        const Vec2 y = mul(s.Ginv[i], h[i]);
+        carry = sub_mulT(Vec2{pw, -mw}, Mat2{-k.kA, k.kB, -k.kB, k.kD}, y);
       }
     }
   }
@@ -275,8 +282,7 @@ BEAM_HD void seg_solve(const SegState<M>& s, const Acc& acc, const Vec2& uL, con
     const ElemK k = elem_k(acc.c2(i), acc.c6(i), acc.c12(i), acc.Ie(i));
     Vec2 ui;
     if (i > 0) {
-      const Mat2 Kr = mask_rows(Mat2{-k.kA, k.kB, -k.kB, k.kD}, node_flags<RZ>(fb, i));
-      ui = mul(s.Ginv[i], sub_mul(h[i], Kr, un));
+      ui = mul(s.Ginv[i], sub_mul(h[i], Mat2{-k.kA, k.kB, -k.kB, k.kD}, un));
     } else {
       ui = uL;
     }
