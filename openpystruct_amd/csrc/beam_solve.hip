@@ -36,7 +36,6 @@ struct BeamParams {
   // host-derived: rows of I/Fy/outputs are dense and every wave's chunk is 16-byte aligned, so
   // the wave moves its beams as one flat run of 16-byte accesses; magic numbers for idx / Ne, idx / N
   int dense;
-  int stagger;
   unsigned long long* trace;   // diagnostic builds (-DOPS_AMD_TRACE) only
   unsigned magic_ne, magic_n;
 };
@@ -566,7 +565,7 @@ int ops_beam_solve_batched_f64(int B, int Ne, const double* x, long x_bstride, c
   if (!t) return tiling ? OPS_AMD_ERR_INVALID_ARG : OPS_AMD_ERR_UNSUPPORTED;
 
   BeamParams p{B, Ne, x, x_bstride, E, E_bstride, I, I_bstride, fix, fix_bstride, Fy, Fy_bstride,
-               wy, wy_bstride, v, theta, V, M, status, 0, 0, nullptr, 0u, 0u};
+               wy, wy_bstride, v, theta, V, M, status, 0, nullptr, 0u, 0u};
 #ifdef OPS_AMD_TRACE
   { const char* e = getenv("OPS_AMD_TRACE_PTR"); if (e) p.trace = (unsigned long long*)strtoull(e, nullptr, 0); }
 #endif
@@ -575,7 +574,6 @@ int ops_beam_solve_batched_f64(int B, int Ne, const double* x, long x_bstride, c
     const uintptr_t bits = (uintptr_t)I | (uintptr_t)Fy | (uintptr_t)v | (uintptr_t)theta | (uintptr_t)V | (uintptr_t)M;
     p.dense = (I_bstride == Ne) && (Fy_bstride == Ne + 1) && ((bits & 15u) == 0) &&
               ((bpw * Ne) % 2 == 0) && ((bpw * (Ne + 1)) % 2 == 0);
-    { const char* e = getenv("OPS_AMD_STAGGER"); p.stagger = e ? atoi(e) : 0; }
     p.magic_ne = ((1u << 20) + (unsigned)Ne - 1u) / (unsigned)Ne;
     p.magic_n = ((1u << 20) + (unsigned)Ne) / (unsigned)(Ne + 1);
   }
