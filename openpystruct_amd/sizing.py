@@ -91,41 +91,50 @@ class Cases:
 
 
 def make_cases(n_cases: int, cfg: SizingConfig, seed: int = 20250307) -> Cases:
-    """Seeded restatement of the case randomisation (SingleCore.py:133-160).  The reference never seeds
-    `random`; here the WHOLE list is a pure function of (seed, n_cases) so that any sharding of it over
-    ranks gives the same dataset."""
+    """Seeded, vectorised restatement of the case randomisation (SingleCore.py:133-160): same distributions
+    (1..4 distinct loaded nodes from the available ones, values U(max_force, min_force); with
+    random_bridge = 1: L = L_min + U(0, L_max), 1..4 distinct rollers from nodes 2..N-1).  The reference never
+    seeds `random`; here the WHOLE list is a pure function of (seed, n_cases), so any sharding of it over ranks
+    gives the same dataset."""
     rng = np.random.default_rng(seed)
-    N = cfg.num_nodes
-    xs = np.zeros((n_cases, N))
-    Ls = np.zeros(n_cases)
-    rollers, fnodes, fvals = [], [], []
-    fix = np.zeros((n_cases, N), dtype=np.uint8)
-    Fy = np.zeros((n_cases, N))
-    for b in range(n_cases):
-        if cfg.random_bridge == 1:
-            L = cfg.L_min + rng.uniform(0, cfg.L_max)                       # :134
-            avail = list(range(2, N))                                       # :138
-            nr = int(rng.integers(1, cfg.N_rollers_max + 1))                # :139
-            rs = [int(r) for r in rng.choice(avail, size=nr, replace=False)]  # :142-151
-            avail = [n for n in avail if n not in rs]
-        else:
-            L = cfg.L_max
-            rs = list(cfg.roller_nodes)                                     # :153
-            avail = [n for n in range(2, N) if n not in rs]                 # :63-66
-        k = min(int(rng.integers(1, cfg.M_forces_max + 1)), len(avail))     # :157-158
-        fn = [int(n) for n in rng.choice(avail, size=k, replace=False)]     # :159
-        fv = [float(f) for f in rng.uniform(cfg.max_force, cfg.min_force, size=k)]   # :160
-        xs[b] = np.linspace(0, L, N)
-        Ls[b] = L
-        fix[b, 0] = 1                                                       # ops.fix(1, 1, 1, 0), :100
-        for r in rs:
-            fix[b, r - 1] = 1                                               # ops.fix(r, 0, 1, 0), :102
-        for n, f in zip(fn, fv):
-            Fy[b, n - 1] += f                                               # ops.load(n, 0, F, 0), :113
-        rollers.append(rs)
-        fnodes.append(fn)
-        fvals.append(fv)
-    return Cases(xs, Ls, rollers, fnodes, fvals, fix, Fy)
+    N, B = cfg.num_nodes, n_cases
+    cand = np.arange(2, N)                                   # 1-based candidates: range(2, num_nodes), :63 / :138
+    if cfg.random_bridge == 1:
+        Ls = cfg.L_min + rng.uniform(0, cfg.L_max, size=B)                                   # :134
+        nr = rng.integers(1, cfg.N_rollers_max + 1, size=B)                                  # :139
+        r_order = np.argsort(rng.random((B, cand.size)), axis=1)[:, : cfg.N_rollers_max]     # distinct picks, :142-151
+        r_nodes = cand[r_order]                                                              # [B, 4]
+        r_used = np.arange(cfg.N_rollers_max)[None, :] < nr[:, None]
+    else:
+        Ls = np.full(B, cfg.L_max)
+        r_nodes = np.tile(np.asarray(cfg.roller_nodes), (B, 1))                              # :153
+        r_used = np.ones_like(r_nodes, dtype=bool)
+    is_roller = np.zeros((B, N + 1), dtype=bool)
+    rows = np.repeat(np.arange(B), r_nodes.shape[1]).reshape(B, -1)
+    is_roller[rows[r_used], r_nodes[r_used]] = True
+    # loaded nodes: distinct draws among the candidates that are not rollers (:157-159)
+    score = rng.random((B, cand.size))
+    score[is_roller[:, cand]] = 2.0                                                          # rollers sort last
+    f_order = np.argsort(score, axis=1)[:, : cfg.M_forces_max]
+    f_nodes = cand[f_order]
+    n_avail = cand.size - is_roller[:, cand].sum(axis=1)
+    k = np.minimum(rng.integers(1, cfg.M_forces_max + 1, size=B), n_avail)                   # :157-158
+    f_used = np.arange(cfg.M_forces_max)[None, :] < k[:, None]
+    f_vals = rng.uniform(cfg.max_force, cfg.min_force, size=(B, cfg.M_forces_max))           # :160
+    xs = np.linspace(0.0, 1.0, N)[None, :] * Ls[:, None]
+    if cfg.random_bridge != 1:
+        xs[:] = np.linspace(0, cfg.L_max, N)                                                 # bit-identical to SingleCore.py:59
+    fix = np.zeros((B, N), dtype=np.uint8)
+    fix[:, 0] = 1                                                                            # ops.fix(1, 1, 1, 0), :100
+    fix[is_roller[:, 1:]] = 1                                                                # ops.fix(r, 0, 1, 0), :102
+    Fy = np.zeros((B, N))
+    frows = np.repeat(np.arange(B), cfg.M_forces_max).reshape(B, -1)
+    Fy[frows[f_used], f_nodes[f_used] - 1] = f_vals[f_used]                                  # ops.load(n, 0, F, 0), :113
+    def ragged(a, used):   # rows of `a` restricted to `used`, as Python lists (row-major order is kept)
+        flat, ends = a[used].tolist(), np.cumsum(used.sum(axis=1)).tolist()
+        return [flat[lo:hi] for lo, hi in zip([0] + ends[:-1], ends)]
+
+    return Cases(xs, Ls, ragged(r_nodes, r_used), ragged(f_nodes, f_used), ragged(f_vals, f_used), fix, Fy)
 
 
 def shard_range(n_total: int, rank: int, world: int) -> Tuple[int, int]:
