@@ -116,7 +116,7 @@ def profiled_traffic(kernel_name, B):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--steps", type=int, default=500)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=10000, help="beams per step per GPU (BASELINE config 2: 10000)")
     ap.add_argument("--tiling", type=int, default=0, help="lanes per beam (0 = library default)")
@@ -132,7 +132,13 @@ def main():
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # nccl (= RCCL) in production; OPS_AMD_BENCH_BACKEND=gloo lets a 1-GPU box dry-run the N > 1 control path
+        backend = os.environ.get("OPS_AMD_BENCH_BACKEND", "nccl")
+        local_rank %= max(1, torch.cuda.device_count())
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     if args.gpus != world and rank == 0 and world > 1:
         print(f"warning: --gpus {args.gpus} != WORLD_SIZE {world}", file=sys.stderr)
 
@@ -155,16 +161,21 @@ def main():
             step()
         stream.synchronize()
         if not args.no_graph:
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph, stream=stream):
-                for _ in range(K):
-                    step()
-            graph.replay()   # untimed: instantiate + first replay
-            stream.synchronize()
+            try:
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph, stream=stream):
+                    for _ in range(K):
+                        step()
+                graph.replay()   # untimed: instantiate + first replay
+                stream.synchronize()
+            except Exception as e:   # keep the bench alive: eager launches measure the same kernel, with host gaps
+                print(f"warning: HIP graph capture failed ({e}); falling back to eager launches", file=sys.stderr)
+                graph = None
+                torch.cuda.synchronize()
 
     def barrier():
         if world > 1:
-            dist.barrier()
+            dist.barrier(device_ids=[local_rank]) if dist.get_backend() == "nccl" else dist.barrier()
 
     e0 = torch.cuda.Event(enable_timing=True)
     e1 = torch.cuda.Event(enable_timing=True)
