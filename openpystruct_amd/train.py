@@ -11,11 +11,15 @@ What is different, and why (DESIGN.md "Training loops"):
   * bf16 autocast without a GradScaler instead of fp16 + GradScaler (BASELINE config 4; MI355X bf16 MFMA);
   * the dataset is resident on the GPU: no per-batch host-to-device copies (PINN:749-750) and no per-step
     `.item()` (PINN:770) -- losses are accumulated on the device and reduced once per epoch;
-  * DistributedDataParallel with ONE gradient bucket (the models are 1.4 - 2.4 MB: a single RCCL all-reduce
-    per step, latency-bound over xGMI) and weak scaling: every rank trains on its own shard with the
-    reference's per-GPU batch size;
+  * data parallelism by hand instead of the DistributedDataParallel wrapper: every parameter's .grad is a
+    view into ONE flat float32 buffer (the models are 1.4 - 2.4 MB), which is all-reduced with a single
+    RCCL call per step (latency-bound over xGMI; nothing to bucket or overlap at this size).  That keeps the
+    step capturable: [noise, forward, loss, backward] and [scale, clip, Adam] are two HIP graphs with the one
+    collective between them, so the multi-GPU step costs three launches, like the single-GPU one costs one.
+    Weak scaling: every rank trains on its own shard with the reference's per-GPU batch size;
   * early-stop decisions are taken on all-reduced losses, so every rank stops at the same epoch.
-BatchNorm statistics are per rank (as per process in the reference); pass sync_bn=True for SyncBatchNorm.
+BatchNorm batch statistics are per rank (as per process in the reference; pass sync_bn=True for SyncBatchNorm);
+the running statistics are averaged over ranks at the end of every epoch so that the replicas stay identical.
 """
 from __future__ import annotations
 
@@ -139,14 +143,17 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
     if sync_bn and world > 1:
         model = nn.SyncBatchNorm.convert_sync_batchnorm(model)
     net = model
-    if world > 1:
-        net = nn.parallel.DistributedDataParallel(
-            model, device_ids=[device.index] if device.type == "cuda" else None,
-            bucket_cap_mb=8, gradient_as_bucket_view=True)     # one bucket: the whole model is < 2.4 MB
+    # one flat gradient buffer; every .grad is a view into it (autograd accumulates in place)
+    params = [q for q in model.parameters()]
+    flat = torch.zeros(sum(q.numel() for q in params), device=device, dtype=torch.float32)
+    off = 0
+    for q in params:
+        q.grad = flat[off:off + q.numel()].view_as(q)
+        off += q.numel()
     torch.manual_seed(seed + 1 + rank)  # different noise / shuffles per rank
     on_gpu = device.type == "cuda"
     if use_graph is None:
-        use_graph = on_gpu and world == 1      # the step is launch-bound (~150 tiny kernels): replay it as one HIP graph
+        use_graph = on_gpu                     # the step is launch-bound (~150 tiny kernels): replay it as HIP graphs
     # under graph replay the learning rate must live in a device tensor, or the scheduler's updates would
     # never reach the captured optimiser step
     lr0 = torch.tensor(cfg.learning_rate, device=device) if use_graph else cfg.learning_rate
@@ -178,9 +185,10 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
         t_p = sR.inverse_transform(preds[:, 2 * nel + 1:])
         return fe_residual_loss(I_p, v_p, t_p, px, physics.E, pfix, Fy_tr[rows], physics.wy)
 
-    def train_step(Xb, Yb, noise_t, rows=None):
+    def fwd_bwd(Xb, Yb, noise_t, rows=None):
+        """Segment A: local gradients of the mean batch loss into `flat`."""
         Xn = Xb + torch.randn_like(Xb) * noise_t                         # PINN:756
-        opt.zero_grad(set_to_none=False)
+        flat.zero_()                                                     # optimizer.zero_grad()
         with torch.autocast(device_type=device.type, dtype=autocast_dtype, enabled=use_ac):
             preds = net(Xn)
             loss = crit(preds.float(), Yb)
@@ -188,15 +196,28 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
                 loss = loss + (cfg.initial_alpha - crit.alpha) ** 2       # TFD:743 (constant 0: alpha never trains)
         if physics is not None:
             loss = loss + physics.weight * physics_loss(preds.float(), rows).float()
-        loss.backward()                                                  # DDP: bucketed RCCL all-reduce overlaps here
-        torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)          # PINN:766
-        opt.step()
+        loss.backward()
         return loss.detach()
 
-    graph = None
+    def apply_update():
+        """Segment B: average over ranks, clip, Adam."""
+        if world > 1:
+            flat.div_(world)
+        torch.nn.utils.clip_grad_norm_(params, 1.0)                      # PINN:766
+        opt.step()
+
+    def train_step(Xb, Yb, noise_t, rows=None):
+        loss = fwd_bwd(Xb, Yb, noise_t, rows)
+        if world > 1:
+            dist.all_reduce(flat)                                        # the step's only collective (RCCL over xGMI)
+        apply_update()
+        return loss
+
+    graph = graph_b = None
     bs = cfg.batch_size
     if use_graph and Xtr.shape[0] >= bs:
-        # static buffers + a few eager warm-up steps on a side stream, then capture one full-batch step
+        # static buffers + a few eager warm-up steps on a side stream, then capture one full-batch step:
+        # world == 1 -> one graph; world > 1 -> [fwd_bwd] graph, eager all-reduce, [apply_update] graph
         sX, sY = torch.zeros_like(Xtr[:bs]), torch.zeros_like(Ytr[:bs])
         s_noise = torch.zeros((), device=device)
         snap = (copy.deepcopy(model.state_dict()), copy.deepcopy(opt.state_dict()))
@@ -205,11 +226,18 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
         with torch.cuda.stream(side):
             sX.copy_(Xtr[:bs]); sY.copy_(Ytr[:bs])
             for _ in range(3):
-                train_step(sX, sY, s_noise)
+                fwd_bwd(sX, sY, s_noise)
+                apply_update()                   # warm-up only: no collective needed for capture-readiness
             side.synchronize()
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph, stream=side):
-                s_loss = train_step(sX, sY, s_noise)
+                s_loss = fwd_bwd(sX, sY, s_noise)
+                if world == 1:
+                    apply_update()
+            if world > 1:
+                graph_b = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph_b, stream=side):
+                    apply_update()
         torch.cuda.current_stream(device).wait_stream(side)
         model.load_state_dict(snap[0]); opt.load_state_dict(snap[1])     # the warm-up steps never happened
 
@@ -231,10 +259,18 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
             if graph is not None and idx.numel() == bs:
                 sX.copy_(Xtr[idx]); sY.copy_(Ytr[idx]); s_noise.copy_(noise_t)
                 graph.replay()
+                if graph_b is not None:
+                    dist.all_reduce(flat)
+                    graph_b.replay()
                 tot += s_loss
             else:
                 tot += train_step(Xtr[idx], Ytr[idx], noise_t, idx)
         train_loss = _allreduce_mean(tot / nb_tr, world)
+        if world > 1:   # BatchNorm running statistics are per rank during the epoch: average them before evaluating
+            for buf in model.buffers():
+                if buf.is_floating_point():
+                    dist.all_reduce(buf)
+                    buf.div_(world)
         net.eval()
         vt = torch.zeros((), device=device)
         nb_va = max(1, (Xva.shape[0] + cfg.batch_size - 1) // cfg.batch_size)

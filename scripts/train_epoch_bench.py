@@ -28,10 +28,15 @@ def main():
     ap.add_argument("--gen-epochs", type=int, default=600, help="max_e of the sizing loop used to generate the data")
     a = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1")); rank = int(os.environ.get("RANK", "0")); lr = int(os.environ.get("LOCAL_RANK", "0"))
+    lr %= max(1, torch.cuda.device_count())
     torch.cuda.set_device(lr)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", lr))
+        backend = os.environ.get("OPS_AMD_BENCH_BACKEND", "nccl")   # gloo: dry-run of the N > 1 path on a 1-GPU box
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", lr))
+        else:
+            dist.init_process_group(backend)
     dev = torch.device("cuda", lr)
     t0 = time.perf_counter()
     rec = sizing.generate_dataset(a.cases * world, sizing.SizingConfig(max_e=a.gen_epochs), dev, rank=rank, world=world)
