@@ -1,5 +1,5 @@
 // Batched 2-D elastic frame solve (3 DOF per node): assembly of rotated ElasticBeam2d stiffness matrices,
-// banded LDL^T factorisation, substitution and global end-force recovery, one workgroup per frame with the
+// banded LDL^T factorisation, substitution and global end-force recovery, one 1024-thread workgroup per frame with the
 // band matrix resident in LDS.
 //
 // SURVEY section 8(f1) / BASELINE config 5: generalises the beam path to the model built by
@@ -47,7 +47,11 @@ __device__ __forceinline__ void elem_global_k(double L, double c, double s, doub
     for (int q = 0; q < 6; ++q) k[r][q] = v[r][q];
 }
 
-__global__ __launch_bounds__(256) void frame_solve_kernel(const FrameParams p) {
+// FRAME_THREADS: 256 for narrow bands (more workgroups per CU, cheaper barriers: 1.5e7 5x5 frames/s vs 5.4e6 with
+// 1024), 1024 for wide ones (the trailing update of a column, up to 63 * 64 / 2 pairs, in one pass: 7.9e5 10x10
+// frames/s vs 6.6e5 with 256).
+template <int FRAME_THREADS>
+__global__ __launch_bounds__(FRAME_THREADS) void frame_solve_kernel(const FrameParams p) {
   extern __shared__ double lds[];
   const int n = p.n_eq, kd = p.kd, ld = kd + 1;
   double* ab = lds;                  // [n][ld]
@@ -56,12 +60,12 @@ __global__ __launch_bounds__(256) void frame_solve_kernel(const FrameParams p) {
   const int tid = threadIdx.x;
   const long b = blockIdx.x;
   if (tid == 0) s_bad = 0;
-  for (int i = tid; i < n * ld + n; i += 256) lds[i] = 0.0;
+  for (int i = tid; i < n * ld + n; i += FRAME_THREADS) lds[i] = 0.0;
   __syncthreads();
 
   // ---- assembly: one thread per element, LDS atomics (elements sharing a node collide) ----
   const double* Ib = p.I + b * p.Ne;
-  for (int e = tid; e < p.Ne; e += 256) {
+  for (int e = tid; e < p.Ne; e += FRAME_THREADS) {
     const double L = p.elem_geo[3 * e], c = p.elem_geo[3 * e + 1], s = p.elem_geo[3 * e + 2];
     double k[6][6];
     elem_global_k(L, c, s, p.elem_EA[e], p.elem_E[e] * Ib[e], k);
@@ -81,7 +85,7 @@ __global__ __launch_bounds__(256) void frame_solve_kernel(const FrameParams p) {
     }
   }
   const double* lb = p.loads + b * p.loads_bs;
-  for (int i = tid; i < p.Nn * 3; i += 256) {
+  for (int i = tid; i < p.Nn * 3; i += FRAME_THREADS) {
     const int q = p.node_eq[i];
     if (q >= 0) atomicAdd(&rhs[q], lb[i]);
   }
@@ -97,7 +101,7 @@ __global__ __launch_bounds__(256) void frame_solve_kernel(const FrameParams p) {
     const int c = 1 + (tid & 63);
     if (c <= kmax) {
       const double lc = ab[(size_t)j * ld + c] * rd;
-      for (int r = 1 + (tid >> 6); r <= c; r += 4)
+      for (int r = 1 + (tid >> 6); r <= c; r += FRAME_THREADS / 64)
         ab[(size_t)(j + r) * ld + (c - r)] -= ab[(size_t)j * ld + r] * lc;
     }
     __syncthreads();
@@ -110,7 +114,7 @@ __global__ __launch_bounds__(256) void frame_solve_kernel(const FrameParams p) {
     if (k <= kmax) rhs[j + k] -= ab[(size_t)j * ld + k] * rd * yj;
     __syncthreads();
   }
-  for (int j = tid; j < n; j += 256) rhs[j] /= ab[(size_t)j * ld];
+  for (int j = tid; j < n; j += FRAME_THREADS) rhs[j] /= ab[(size_t)j * ld];
   __syncthreads();
   for (int j = n - 1; j >= 0; --j) {   // x_j = z_j - sum_k (L_{j+k,j}) x_{j+k}: one wave reduces the <= kd terms
     if (tid < 64) {
@@ -125,12 +129,12 @@ __global__ __launch_bounds__(256) void frame_solve_kernel(const FrameParams p) {
   const bool bad = s_bad != 0;
   const double qnan = __builtin_nan("");
   // ---- nodal displacements ----
-  for (int i = tid; i < p.Nn * 3; i += 256) {
+  for (int i = tid; i < p.Nn * 3; i += FRAME_THREADS) {
     const int q = p.node_eq[i];
     p.disp[b * (long)p.Nn * 3 + i] = bad ? qnan : (q >= 0 ? rhs[q] : 0.0);
   }
   // ---- element end forces (ElasticBeam2d::getResistingForce through LinearCrdTransf2d), global ----
-  for (int e = tid; e < p.Ne; e += 256) {
+  for (int e = tid; e < p.Ne; e += FRAME_THREADS) {
     const double L = p.elem_geo[3 * e], c = p.elem_geo[3 * e + 1], s = p.elem_geo[3 * e + 2];
     const double EA = p.elem_EA[e], EI = p.elem_E[e] * Ib[e], wy = p.elem_w[2 * e], wx = p.elem_w[2 * e + 1];
     double ug[6];
@@ -168,12 +172,16 @@ extern "C" int ops_frame_solve_batched_f64(int B, int n_nodes, int n_elems, int 
   if (lds_bytes > 160 * 1024 - 64) return OPS_AMD_ERR_UNSUPPORTED;   // band must fit the CU's LDS
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)frame_solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64) != hipSuccess)
+    if (hipFuncSetAttribute((const void*)frame_solve_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64) != hipSuccess ||
+        hipFuncSetAttribute((const void*)frame_solve_kernel<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64) != hipSuccess)
       return OPS_AMD_ERR_LAUNCH;
     attr_set = true;
   }
   const FrameParams p{B, n_nodes, n_elems, n_eq, half_bandwidth, elem_geo, elem_EA, elem_E, elem_w, elem_eq, node_eq,
                       I, loads, loads_bstride, disp, forces, V, M, status};
-  hipLaunchKernelGGL(frame_solve_kernel, dim3((unsigned)B), dim3(256), lds_bytes, (hipStream_t)stream, p);
+  if (half_bandwidth > 24)
+    hipLaunchKernelGGL(frame_solve_kernel<1024>, dim3((unsigned)B), dim3(1024), lds_bytes, (hipStream_t)stream, p);
+  else
+    hipLaunchKernelGGL(frame_solve_kernel<256>, dim3((unsigned)B), dim3(256), lds_bytes, (hipStream_t)stream, p);
   return hipGetLastError() == hipSuccess ? OPS_AMD_OK : OPS_AMD_ERR_LAUNCH;
 }
