@@ -176,10 +176,15 @@ def prepare(records: Dict[str, object], *, kind: str = "pinn", n_cases: int = 6,
     if n_cases == 1 and "force_nodes" in records and "force_values" in records:
         # dense nodal load vectors of every case, for the FE-residual physics term (physics.py)
         Nn = int(records["num_nodes"]) if not isinstance(records["num_nodes"], (list, tuple)) else int(records["num_nodes"][0])
-        Fy = torch.zeros((G, Nn), dtype=torch.float64)
-        for b in range(G):
-            for n, f in zip(records["force_nodes"][b], records["force_values"][b]):
-                Fy[b, int(n) - 1] += float(f)
+        fn, fv = records["force_nodes"], records["force_values"]
+        if torch.is_tensor(fn):       # zero-padded tensors (generate_dataset): slot 0 of the scratch row swallows the padding
+            Fy = torch.zeros((G, Nn + 1), dtype=torch.float64, device=fn.device).scatter_add_(
+                1, fn[:G].long(), fv[:G].to(torch.float64))[:, 1:]
+        else:
+            Fy = torch.zeros((G, Nn), dtype=torch.float64)
+            for b in range(G):
+                for n, f in zip(fn[b], fv[b]):
+                    Fy[b, int(n) - 1] += float(f)
         Fy = Fy.to(dev)
         Fy_tr, Fy_va = Fy[tr].contiguous(), Fy[va].contiguous()
     return SurrogateData(Xtr.contiguous(), Ytr.contiguous(), Xva.contiguous(), Yva.contiguous(), sc_in, sc_Y, mn, mx, feat_dim, ml,

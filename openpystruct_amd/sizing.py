@@ -17,7 +17,7 @@ from __future__ import annotations
 
 import ctypes
 import json
-from dataclasses import dataclass, field
+from dataclasses import dataclass
 from typing import Dict, List, Optional, Tuple
 
 import numpy as np
@@ -71,70 +71,90 @@ class SizingConfig:
             area_coef=0.03, tolerance=self.tolerance, patience=self.patience, max_epochs=self.max_e)
 
 
-@dataclass
 class Cases:
-    """Host-side description of a list of cases (what SingleCore.py:133-160 draws per sample)."""
-    node_positions: np.ndarray            # [B, N] (every row equal when random_bridge == 0)
-    L: np.ndarray                         # [B]
-    roller_nodes: List[List[int]]         # 1-based ids per case
-    force_nodes: List[List[int]]
-    force_values: List[List[float]]
-    fix: np.ndarray = field(default=None)  # [B, N] uint8
-    Fy: np.ndarray = field(default=None)   # [B, N]
+    """A list of cases (what SingleCore.py:133-160 draws per sample) as tensors on one device: ragged per-case
+    lists are stored zero-padded with their counts; the Python-list views the reference's records use
+    (`roller_nodes`, `force_nodes`, `force_values`) are materialised lazily."""
+
+    def __init__(self, node_positions, L, roller_nodes_t, n_rollers, force_nodes_t, n_forces, force_values_t, fix, Fy):
+        self.node_positions = node_positions      # [B, N] f64 (every row equal when random_bridge == 0)
+        self.L = L                                # [B] f64
+        self.roller_nodes_t = roller_nodes_t      # [B, R] int64, 1-based ids, 0 = unused slot
+        self.n_rollers = n_rollers                # [B] int64
+        self.force_nodes_t = force_nodes_t        # [B, F] int64, 1-based ids, 0 = unused slot
+        self.n_forces = n_forces                  # [B] int64
+        self.force_values_t = force_values_t      # [B, F] f64, 0.0 in unused slots
+        self.fix = fix                            # [B, N] uint8
+        self.Fy = Fy                              # [B, N] f64
+        self._lists = {}
 
     def __len__(self):
-        return len(self.roller_nodes)
+        return int(self.Fy.shape[0])
 
     def slice(self, lo: int, hi: int) -> "Cases":
-        return Cases(self.node_positions[lo:hi], self.L[lo:hi], self.roller_nodes[lo:hi], self.force_nodes[lo:hi],
-                     self.force_values[lo:hi], self.fix[lo:hi], self.Fy[lo:hi])
+        return Cases(*(t[lo:hi] for t in (self.node_positions, self.L, self.roller_nodes_t, self.n_rollers, self.force_nodes_t,
+                                          self.n_forces, self.force_values_t, self.fix, self.Fy)))
+
+    def _ragged(self, name, t, n):
+        if name not in self._lists:
+            rows, cnt = t.cpu().tolist(), n.cpu().tolist()
+            self._lists[name] = [r[:c] for r, c in zip(rows, cnt)]
+        return self._lists[name]
+
+    @property
+    def roller_nodes(self) -> List[List[int]]:
+        return self._ragged("r", self.roller_nodes_t, self.n_rollers)
+
+    @property
+    def force_nodes(self) -> List[List[int]]:
+        return self._ragged("f", self.force_nodes_t, self.n_forces)
+
+    @property
+    def force_values(self) -> List[List[float]]:
+        return self._ragged("v", self.force_values_t, self.n_forces)
 
 
-def make_cases(n_cases: int, cfg: SizingConfig, seed: int = 20250307) -> Cases:
-    """Seeded, vectorised restatement of the case randomisation (SingleCore.py:133-160): same distributions
-    (1..4 distinct loaded nodes from the available ones, values U(max_force, min_force); with
-    random_bridge = 1: L = L_min + U(0, L_max), 1..4 distinct rollers from nodes 2..N-1).  The reference never
-    seeds `random`; here the WHOLE list is a pure function of (seed, n_cases), so any sharding of it over ranks
-    gives the same dataset."""
-    rng = np.random.default_rng(seed)
-    N, B = cfg.num_nodes, n_cases
-    cand = np.arange(2, N)                                   # 1-based candidates: range(2, num_nodes), :63 / :138
+def make_cases(n_cases: int, cfg: SizingConfig, seed: int = 20250307, device="cpu") -> Cases:
+    """Seeded, vectorised restatement of the case randomisation (SingleCore.py:133-160), generated directly on
+    `device` (BASELINE config 3: "dataset generated on-GPU"): same distributions -- 1..4 distinct loaded nodes
+    from the available ones, values U(max_force, min_force); with random_bridge = 1: L = L_min + U(0, L_max),
+    1..4 distinct rollers from nodes 2..N-1.  The reference never seeds `random`; here the WHOLE list is a pure
+    function of (seed, n_cases, device type), so any sharding of it over ranks gives the same dataset."""
+    dev = torch.device(device)
+    g = torch.Generator(device=dev).manual_seed(seed)
+    N, B, R, F = cfg.num_nodes, n_cases, cfg.N_rollers_max, cfg.M_forces_max
+    f64 = dict(dtype=torch.float64, device=dev)
+    cand = torch.arange(2, N, device=dev)                      # 1-based candidates: range(2, num_nodes), :63 / :138
+    rand = lambda *shape: torch.rand(*shape, generator=g, **f64)   # noqa: E731
     if cfg.random_bridge == 1:
-        Ls = cfg.L_min + rng.uniform(0, cfg.L_max, size=B)                                   # :134
-        nr = rng.integers(1, cfg.N_rollers_max + 1, size=B)                                  # :139
-        r_order = np.argsort(rng.random((B, cand.size)), axis=1)[:, : cfg.N_rollers_max]     # distinct picks, :142-151
-        r_nodes = cand[r_order]                                                              # [B, 4]
-        r_used = np.arange(cfg.N_rollers_max)[None, :] < nr[:, None]
+        Ls = cfg.L_min + rand(B) * cfg.L_max                                                   # :134
+        nr = torch.randint(1, R + 1, (B,), generator=g, device=dev)                            # :139
+        r_nodes = cand[torch.argsort(rand(B, cand.numel()), dim=1)[:, :R]]                     # distinct picks, :142-151
+        r_used = torch.arange(R, device=dev)[None, :] < nr[:, None]
     else:
-        Ls = np.full(B, cfg.L_max)
-        r_nodes = np.tile(np.asarray(cfg.roller_nodes), (B, 1))                              # :153
-        r_used = np.ones_like(r_nodes, dtype=bool)
-    is_roller = np.zeros((B, N + 1), dtype=bool)
-    rows = np.repeat(np.arange(B), r_nodes.shape[1]).reshape(B, -1)
-    is_roller[rows[r_used], r_nodes[r_used]] = True
+        Ls = torch.full((B,), cfg.L_max, **f64)
+        r_nodes = torch.tensor(cfg.roller_nodes, device=dev).expand(B, -1)                     # :153
+        r_used = torch.ones_like(r_nodes, dtype=torch.bool)
+        nr = r_used.sum(dim=1)
+    r_nodes = r_nodes * r_used                                  # unused slots -> 0 (a node id that does not exist)
+    is_roller = torch.zeros((B, N + 1), dtype=torch.bool, device=dev).scatter_(1, r_nodes, True)
+    is_roller[:, 0] = False
     # loaded nodes: distinct draws among the candidates that are not rollers (:157-159)
-    score = rng.random((B, cand.size))
-    score[is_roller[:, cand]] = 2.0                                                          # rollers sort last
-    f_order = np.argsort(score, axis=1)[:, : cfg.M_forces_max]
-    f_nodes = cand[f_order]
-    n_avail = cand.size - is_roller[:, cand].sum(axis=1)
-    k = np.minimum(rng.integers(1, cfg.M_forces_max + 1, size=B), n_avail)                   # :157-158
-    f_used = np.arange(cfg.M_forces_max)[None, :] < k[:, None]
-    f_vals = rng.uniform(cfg.max_force, cfg.min_force, size=(B, cfg.M_forces_max))           # :160
-    xs = np.linspace(0.0, 1.0, N)[None, :] * Ls[:, None]
-    if cfg.random_bridge != 1:
-        xs[:] = np.linspace(0, cfg.L_max, N)                                                 # bit-identical to SingleCore.py:59
-    fix = np.zeros((B, N), dtype=np.uint8)
-    fix[:, 0] = 1                                                                            # ops.fix(1, 1, 1, 0), :100
-    fix[is_roller[:, 1:]] = 1                                                                # ops.fix(r, 0, 1, 0), :102
-    Fy = np.zeros((B, N))
-    frows = np.repeat(np.arange(B), cfg.M_forces_max).reshape(B, -1)
-    Fy[frows[f_used], f_nodes[f_used] - 1] = f_vals[f_used]                                  # ops.load(n, 0, F, 0), :113
-    def ragged(a, used):   # rows of `a` restricted to `used`, as Python lists (row-major order is kept)
-        flat, ends = a[used].tolist(), np.cumsum(used.sum(axis=1)).tolist()
-        return [flat[lo:hi] for lo, hi in zip([0] + ends[:-1], ends)]
-
-    return Cases(xs, Ls, ragged(r_nodes, r_used), ragged(f_nodes, f_used), ragged(f_vals, f_used), fix, Fy)
+    score = rand(B, cand.numel()).masked_fill_(is_roller[:, 2:N], 2.0)                         # rollers sort last
+    f_nodes = cand[torch.argsort(score, dim=1)[:, :F]]
+    n_avail = cand.numel() - is_roller[:, 2:N].sum(dim=1)
+    k = torch.minimum(torch.randint(1, F + 1, (B,), generator=g, device=dev), n_avail)        # :157-158
+    f_used = torch.arange(F, device=dev)[None, :] < k[:, None]
+    f_vals = (cfg.max_force + rand(B, F) * (cfg.min_force - cfg.max_force)) * f_used           # :160
+    f_nodes = f_nodes * f_used
+    if cfg.random_bridge == 1:
+        xs = torch.linspace(0.0, 1.0, N, **f64)[None, :] * Ls[:, None]
+    else:
+        xs = torch.linspace(0, cfg.L_max, N, **f64).expand(B, -1).contiguous()                # SingleCore.py:59
+    fix = is_roller[:, 1:].to(torch.uint8)                                                     # ops.fix(r, 0, 1, 0), :102
+    fix[:, 0] = 1                                                                              # ops.fix(1, 1, 1, 0), :100
+    Fy = torch.zeros((B, N + 1), **f64).scatter_add_(1, f_nodes, f_vals)[:, 1:].contiguous()   # ops.load(n, 0, F, 0), :113
+    return Cases(xs, Ls, r_nodes, nr, f_nodes, k, f_vals, fix, Fy)
 
 
 def shard_range(n_total: int, rank: int, world: int) -> Tuple[int, int]:
@@ -152,9 +172,9 @@ class SizingState:
         f32 = dict(dtype=torch.float32, device=device)
         self.B, self.N, self.Ne, self.cfg, self.device = B, N, Ne, cfg, device
         shared_geom = cfg.random_bridge == 0
-        self.x = torch.as_tensor(cases.node_positions[0] if shared_geom else cases.node_positions, **f64).contiguous()
-        self.fix = torch.as_tensor(cases.fix[0] if shared_geom else cases.fix, dtype=torch.uint8, device=device).contiguous()
-        self.Fy = torch.as_tensor(cases.Fy, **f64).contiguous()
+        self.x = (cases.node_positions[0] if shared_geom else cases.node_positions).to(**f64).contiguous()
+        self.fix = (cases.fix[0] if shared_geom else cases.fix).to(dtype=torch.uint8, device=device).contiguous()
+        self.Fy = cases.Fy.to(**f64).contiguous()
         self.E = torch.tensor(cfg.E, **f64)
         self.wy = torch.tensor(cfg.uniform_udl, **f64)
         self.I = torch.full((B, Ne), cfg.I_0, **f32)                    # I_tensor, :163
@@ -234,7 +254,7 @@ def generate_dataset(n_cases: int, cfg: Optional[SizingConfig] = None, device="c
     (SingleCore.py:235-249) as tensors / lists, plus `epochs_run`, `status` and the global case ids."""
     cfg = cfg or SizingConfig()
     lo, hi = shard_range(n_cases, rank, world)
-    cases = make_cases(n_cases, cfg, seed).slice(lo, hi)
+    cases = make_cases(n_cases, cfg, seed, device=device).slice(lo, hi)     # generated on the GPU, sliced per rank
     st = optimize_cases(cases, cfg, device, poll_every=poll_every)
     sol = st.sol
     rot, defl = sol.theta.clone(), sol.v.clone()
@@ -242,20 +262,25 @@ def generate_dataset(n_cases: int, cfg: Optional[SizingConfig] = None, device="c
         rot[:, -1] = 0.0
         defl[:, -1] = 0.0
     xs = cases.node_positions
+    x_at = lambda nodes: torch.gather(xs, 1, (nodes - 1).clamp_min(0)) * (nodes > 0)   # noqa: E731  zero-padded like the ids
     return {
-        "roller_x_locations": [[float(xs[b, n - 1]) for n in cases.roller_nodes[b]] for b in range(len(cases))],
-        "force_x_locations": [[float(xs[b, n - 1]) for n in cases.force_nodes[b]] for b in range(len(cases))],
-        "force_values": cases.force_values,
+        # ragged fields as zero-padded tensors + counts: exactly the arrays the reference's pad_sequences builds
+        # (PINN:66-76); `records_to_reference_json` turns them back into the ragged lists of the wire format
+        "roller_x_locations": x_at(cases.roller_nodes_t),
+        "force_x_locations": x_at(cases.force_nodes_t),
+        "force_values": cases.force_values_t,
         "I_values": st.I,                         # float32, AFTER the last Adam step (:239)
         "shear_forces": st.V32,                   # float32, state of the last solve (:240)
         "bending_moments": st.M32,
-        "node_positions": torch.as_tensor(xs),
-        "roller_nodes": cases.roller_nodes,
-        "force_nodes": cases.force_nodes,
+        "node_positions": xs,
+        "roller_nodes": cases.roller_nodes_t,
+        "force_nodes": cases.force_nodes_t,
         "num_nodes": cfg.num_nodes,
-        "L": torch.as_tensor(cases.L),
+        "L": cases.L,
         "rotations": rot,
         "deflections": defl,
+        "n_rollers": cases.n_rollers,
+        "n_forces": cases.n_forces,
         "epochs_run": st.epochs_run,
         "status": sol.status,
         "case_ids": torch.arange(lo, hi),
@@ -264,27 +289,36 @@ def generate_dataset(n_cases: int, cfg: Optional[SizingConfig] = None, device="c
 
 def records_to_reference_json(rec: Dict[str, object], path: str, drop_failed: bool = True) -> int:
     """Writes the reference's wire format (SingleCore.py:73-87, :263-264): a JSON object of 13 parallel
-    lists.  `drop_failed` mirrors MultiCore.py:265 (samples whose analysis failed are filtered out)."""
-    B = len(rec["roller_nodes"])
-    status = rec["status"].cpu().numpy() if torch.is_tensor(rec["status"]) else np.zeros(B, dtype=np.int32)
+    lists.  `drop_failed` mirrors MultiCore.py:265 (samples whose analysis failed are filtered out).
+    Ragged fields may be Python lists or zero-padded tensors with `n_rollers` / `n_forces` counts."""
+    B = int(rec["I_values"].shape[0])
+    status = rec["status"].cpu().numpy() if torch.is_tensor(rec.get("status")) else np.zeros(B, dtype=np.int32)
     keep = [b for b in range(B) if not (drop_failed and status[b] != 0)]
 
     def rows(t):
         a = t.detach().cpu().numpy()
         return [a[b].tolist() for b in keep]
 
+    def ragged(key, count_key):
+        v = rec[key]
+        if not torch.is_tensor(v):
+            return [v[b] for b in keep]
+        a, n = v.detach().cpu().tolist(), rec[count_key].cpu().tolist()
+        return [a[b][: n[b]] for b in keep]
+
+    Lall = rec["L"].cpu().tolist() if torch.is_tensor(rec["L"]) else list(rec["L"])
     out = {
-        "roller_x_locations": [rec["roller_x_locations"][b] for b in keep],
-        "force_x_locations": [rec["force_x_locations"][b] for b in keep],
-        "force_values": [rec["force_values"][b] for b in keep],
+        "roller_x_locations": ragged("roller_x_locations", "n_rollers"),
+        "force_x_locations": ragged("force_x_locations", "n_forces"),
+        "force_values": ragged("force_values", "n_forces"),
         "I_values": rows(rec["I_values"]),
         "shear_forces": rows(rec["shear_forces"]),
         "bending_moments": rows(rec["bending_moments"]),
         "node_positions": rows(rec["node_positions"]),
-        "roller_nodes": [rec["roller_nodes"][b] for b in keep],
-        "force_nodes": [rec["force_nodes"][b] for b in keep],
+        "roller_nodes": ragged("roller_nodes", "n_rollers"),
+        "force_nodes": ragged("force_nodes", "n_forces"),
         "num_nodes": [int(rec["num_nodes"])] * len(keep),
-        "L": [float(rec["L"][b]) for b in keep],
+        "L": [float(Lall[b]) for b in keep],
         "rotations": rows(rec["rotations"]),
         "deflections": rows(rec["deflections"]),
     }

@@ -84,7 +84,7 @@ def test_sizing_loop_vs_per_case_oracle(oa, patience):
     v = st.sol.v.cpu().numpy(); th = st.sol.theta.cpu().numpy()
     assert int(st.active.sum()) == 0
     for b in range(n):
-        ref = so.generate_sample(cases.node_positions[b], cases.roller_nodes[b], cases.force_nodes[b],
+        ref = so.generate_sample(cases.node_positions[b].numpy(), cases.roller_nodes[b], cases.force_nodes[b],
                                  cases.force_values[b], patience=patience)
         assert abs(int(ep[b]) - ref["epochs_run"]) <= 3, (ep[b], ref["epochs_run"])
         if int(ep[b]) == ref["epochs_run"]:
@@ -104,7 +104,7 @@ def test_first_epochs_match_oracle_tightly(oa):
     st = sizing.optimize_cases(cases, cfg, "cuda", poll_every=1, use_graph=False)
     assert (st.epochs_run.cpu().numpy() == 3).all() and int(st.active.sum()) == 0
     for b in range(4):
-        ref = so.generate_sample(cases.node_positions[b], cases.roller_nodes[b], cases.force_nodes[b],
+        ref = so.generate_sample(cases.node_positions[b].numpy(), cases.roller_nodes[b], cases.force_nodes[b],
                                  cases.force_values[b], max_e=3)
         np.testing.assert_allclose(st.I[b].cpu().numpy(), np.array(ref["I_values"]), rtol=2e-6)
         np.testing.assert_allclose(st.last_loss[b].item(), ref["final_loss"], rtol=2e-6)
@@ -128,6 +128,8 @@ def test_generate_dataset_records_and_json(oa, tmp_path):
     assert sizing.records_to_reference_json(rec, path) == 32
     d = json.load(open(path))
     assert tuple(d) == sizing.RECORD_KEYS and len(d["shear_forces"]) == 32 and len(d["rotations"][0]) == 101
+    assert d["roller_x_locations"][0] == [18.0, 58.0, 138.0, 168.0, 198.0] and 1 <= len(d["force_values"][0]) <= 4
+    assert len(d["force_x_locations"][3]) == len(d["force_nodes"][3]) == int(rec["n_forces"][3])
     # MultiCore quirk: last node zeroed (MultiCore.py:222-223)
     z = sizing.generate_dataset(4, sizing.SizingConfig(max_e=5, zero_last_node=True), "cuda", seed=5)
     assert float(z["deflections"][:, -1].abs().max()) == 0.0 and float(z["rotations"][:, -1].abs().max()) == 0.0

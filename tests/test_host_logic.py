@@ -90,18 +90,22 @@ def test_make_cases_distribution_and_determinism():
     cfg = sizing.SizingConfig()
     a = sizing.make_cases(500, cfg, seed=1)
     b = sizing.make_cases(500, cfg, seed=1)
-    assert (a.Fy == b.Fy).all() and a.force_nodes == b.force_nodes
+    assert torch.equal(a.Fy, b.Fy) and a.force_nodes == b.force_nodes
     k = np.array([len(f) for f in a.force_nodes])
     assert k.min() >= 1 and k.max() <= 4 and set(k) == {1, 2, 3, 4}
     vals = np.concatenate([np.array(f) for f in a.force_values])
     assert vals.min() >= cfg.max_force and vals.max() <= cfg.min_force
     forbidden = set(cfg.roller_nodes) | {1, 101}                    # SingleCore.py:63-66: range(2, num_nodes) minus rollers
     assert all(not (set(f) & forbidden) and len(set(f)) == len(f) for f in a.force_nodes)
-    assert (a.fix[0] == bo.reference_fix_mask()).all()
+    assert (a.fix[0].numpy() == bo.reference_fix_mask()).all()
+    # Fy is the scatter of the ragged lists
+    b0 = np.zeros(101); b0[np.array(a.force_nodes[0]) - 1] = a.force_values[0]
+    np.testing.assert_array_equal(a.Fy[0].numpy(), b0)
     # random_bridge = 1 (SingleCore.py:133-151)
     c = sizing.make_cases(200, sizing.SizingConfig(random_bridge=1), seed=2)
-    assert c.L.min() >= 15 and c.L.max() <= 215
+    assert float(c.L.min()) >= 15 and float(c.L.max()) <= 215
     nr = np.array([len(r) for r in c.roller_nodes])
+    assert all(int(c.fix[b].sum()) == 1 + len(c.roller_nodes[b]) for b in range(200))
     assert nr.min() >= 1 and nr.max() <= 4
     assert all(not (set(f) & set(r)) for f, r in zip(c.force_nodes, c.roller_nodes))
 
@@ -113,7 +117,7 @@ def test_shard_ranges_partition_the_cases():
     full = sizing.make_cases(64, sizing.SizingConfig(), seed=5)
     lo, hi = sizing.shard_range(64, 1, 4)
     part = full.slice(lo, hi)
-    assert (part.Fy == full.Fy[lo:hi]).all() and part.force_nodes == full.force_nodes[lo:hi]
+    assert torch.equal(part.Fy, full.Fy[lo:hi]) and part.force_nodes == full.force_nodes[lo:hi]
 
 
 def _gloo_worker(rank, world, port, q):
@@ -125,7 +129,7 @@ def _gloo_worker(rank, world, port, q):
     lo, hi = sizing.shard_range(n, rank, world)
     cases = sizing.make_cases(n, sizing.SizingConfig(), seed=9).slice(lo, hi)
     mine = torch.zeros(n, dtype=torch.float64)
-    mine[lo:hi] = torch.as_tensor(cases.Fy.sum(axis=1))
+    mine[lo:hi] = cases.Fy.sum(dim=1)
     dist.all_reduce(mine)                                  # test-only gather; the data path itself has no collective
     q.put((rank, mine.numpy()))
     dist.destroy_process_group()
@@ -140,7 +144,7 @@ def test_two_rank_shards_reassemble_the_global_case_list():
     [p.start() for p in ps]
     outs = [q.get(timeout=120) for _ in ps]
     [p.join(60) for p in ps]
-    ref = sizing.make_cases(37, sizing.SizingConfig(), seed=9).Fy.sum(axis=1)
+    ref = sizing.make_cases(37, sizing.SizingConfig(), seed=9).Fy.sum(dim=1).numpy()
     for _, got in outs:
         np.testing.assert_array_equal(got, ref)
 
@@ -149,13 +153,14 @@ def test_reference_json_wire_format(tmp_path):
     cfg = sizing.SizingConfig()
     cases = sizing.make_cases(5, cfg, seed=4)
     B, N = cases.Fy.shape
+    xs = cases.node_positions.numpy()
     rec = {
-        "roller_x_locations": [[float(cases.node_positions[b, n - 1]) for n in cases.roller_nodes[b]] for b in range(B)],
-        "force_x_locations": [[float(cases.node_positions[b, n - 1]) for n in cases.force_nodes[b]] for b in range(B)],
+        "roller_x_locations": [[float(xs[b, n - 1]) for n in cases.roller_nodes[b]] for b in range(B)],
+        "force_x_locations": [[float(xs[b, n - 1]) for n in cases.force_nodes[b]] for b in range(B)],
         "force_values": cases.force_values,
         "I_values": torch.rand(B, N - 1), "shear_forces": torch.rand(B, N - 1), "bending_moments": torch.rand(B, N - 1),
-        "node_positions": torch.as_tensor(cases.node_positions), "roller_nodes": cases.roller_nodes,
-        "force_nodes": cases.force_nodes, "num_nodes": N, "L": torch.as_tensor(cases.L),
+        "node_positions": cases.node_positions, "roller_nodes": cases.roller_nodes,
+        "force_nodes": cases.force_nodes, "num_nodes": N, "L": cases.L,
         "rotations": torch.rand(B, N, dtype=torch.float64), "deflections": torch.rand(B, N, dtype=torch.float64),
         "status": torch.tensor([0, 0, 1, 0, 0], dtype=torch.int32),
     }

@@ -13,12 +13,12 @@ def _fake_records(S=120, seed=0):
     cfg = sizing.SizingConfig()
     cases = sizing.make_cases(S, cfg, seed=seed)
     g = torch.Generator().manual_seed(seed)
-    xs = cases.node_positions
+    xs = cases.node_positions.numpy()
     return {
         "roller_x_locations": [[float(xs[b, n - 1]) for n in cases.roller_nodes[b]] for b in range(S)],
         "force_x_locations": [[float(xs[b, n - 1]) for n in cases.force_nodes[b]] for b in range(S)],
         "force_values": cases.force_values,
-        "node_positions": torch.as_tensor(xs),
+        "node_positions": cases.node_positions,
         "I_values": torch.rand(S, 100, generator=g) * 0.5 + 0.01,
         "deflections": torch.randn(S, 101, generator=g, dtype=torch.float64) * 1e-2,
         "rotations": torch.randn(S, 101, generator=g, dtype=torch.float64) * 1e-3,
