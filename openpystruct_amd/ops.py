@@ -17,7 +17,9 @@ queued by `analyze` and solved together by `flush()` in one launch -- the per-ca
 kernel underneath.
 
 Scope: straight beams along x (all nodes on one horizontal line, consecutive tags connected by
-consecutive elements), which is what `setup_model` builds.  Anything else raises NotImplementedError.
+consecutive elements: what `setup_model` builds) go to the batched beam kernel; any other 2-D frame of
+`elasticBeamColumn`s (what `setup_frame_model` of OpenPyStruct_FrameOpt_Discrete_Beta.py:75-139 builds) goes to
+the frame kernel.  Other element types / analyses raise NotImplementedError.
 """
 from __future__ import annotations
 
@@ -135,6 +137,49 @@ def analysis(kind):
     _dom.analysis = kind
 
 
+def _is_straight_beam(d: _Domain) -> bool:
+    tags = sorted(d.nodes)
+    N = len(tags)
+    if N < 2 or tags != list(range(1, N + 1)):
+        return False
+    xy = np.array([d.nodes[t] for t in tags])
+    if np.any(xy[:, 1] != xy[0, 1]) or np.any(np.diff(xy[:, 0]) <= 0):
+        return False
+    return sorted(d.elements) == list(range(1, N)) and all(d.elements[e][:2] == (e, e + 1) for e in d.elements)
+
+
+def _analyze_frame(d: _Domain):
+    """General 2-D frame (what `setup_frame_model` builds, OpenPyStruct_FrameOpt_Discrete_Beta.py:75-139):
+    the batched frame kernel with a batch of one."""
+    from .frames import FrameTopology, frame_solve
+    tags = sorted(d.nodes)
+    N = len(tags)
+    if tags != list(range(1, N + 1)) or sorted(d.elements) != list(range(1, len(d.elements) + 1)):
+        raise NotImplementedError("node and element tags must be 1..N / 1..Ne")
+    coords = np.array([d.nodes[t] for t in tags])
+    Ne = len(d.elements)
+    conn = np.array([[d.elements[e][0] - 1, d.elements[e][1] - 1] for e in range(1, Ne + 1)])
+    A = np.array([d.elements[e][2] for e in range(1, Ne + 1)])
+    E = np.array([d.elements[e][3] for e in range(1, Ne + 1)])
+    I = np.array([d.elements[e][4] for e in range(1, Ne + 1)])
+    fix3 = np.zeros((N, 3), dtype=bool)
+    for t, f in d.fixes.items():
+        fix3[t - 1] = [bool(v) for v in f]
+    loads = np.zeros((N, 3))
+    for t, f in d.loads.items():
+        loads[t - 1] = f
+    wy = np.array([d.ele_loads.get(e, (0.0, 0.0))[0] for e in range(1, Ne + 1)])
+    wx = np.array([d.ele_loads.get(e, (0.0, 0.0))[1] for e in range(1, Ne + 1)])
+    topo = FrameTopology(coords, conn, fix3, A, E, wy, wx, loads, device=d.device)
+    sol = frame_solve(topo, torch.as_tensor(I[None, :], dtype=torch.float64, device=d.device))
+    if int(sol.status[0]) != 0:
+        d.result = None
+        return _ANALYZE_FAILED
+    disp = sol.disp[0].cpu().numpy()
+    d.result = dict(ux=disp[:, 0], v=disp[:, 1], th=disp[:, 2], forces=sol.forces[0].cpu().numpy())
+    return 0
+
+
 def _arrays(d: _Domain):
     tags = sorted(d.nodes)
     N = len(tags)
@@ -213,6 +258,10 @@ def analyze(n_steps=1):
     d = _dom
     if d.analysis != "Static":
         return _ANALYZE_FAILED
+    if not _is_straight_beam(d):
+        if _queue is not None:
+            raise NotImplementedError("deferred(): straight beams only")
+        return _analyze_frame(d)
     a = _arrays(d)
     if _queue is not None:
         d._arrays = a

@@ -73,3 +73,45 @@ def test_frame_sizing_loop_runs_like_the_reference():
     I, sol, ep = frames.optimize_frames(topo, 8, max_epochs=400)
     assert (ep.cpu().numpy() > 5).all() and float(I.min()) >= 1e-8 and int(sol.status.abs().sum()) == 0
     assert torch.allclose(I[0], I[7])          # identical problems -> identical trajectories, whatever the batch slot
+
+
+def test_ops_shim_runs_setup_frame_model():
+    """The reference's frame script drives the same command API (FR:75-139, :151, :181-183): re-typed here."""
+    from openpystruct_amd import frames, ops
+    cfg = frames.FrameConfig()
+    bays, stories = 3, 2
+    nb1 = bays + 1
+    coords = {i * nb1 + j + 1: (j * cfg.bay_width, i * cfg.story_height) for i in range(stories + 1) for j in range(nb1)}
+    n_cols, n_beams = stories * nb1, stories * bays
+    I = np.full(n_cols + n_beams, cfg.I0) * np.linspace(0.5, 2.0, n_cols + n_beams)
+    ops.wipe()
+    ops.model('basic', '-ndm', 2, '-ndf', 3)
+    ops.geomTransf('Linear', 1)
+    for tag, (x, y) in coords.items():
+        ops.node(tag, x, y)
+    for tag, (x, y) in coords.items():
+        if y == 0.0:
+            ops.fix(tag, 1, 1, 1)
+    e = 1
+    for i in range(stories):
+        for j in range(nb1):
+            ops.element('elasticBeamColumn', e, i * nb1 + j + 1, (i + 1) * nb1 + j + 1, cfg.A, cfg.E, float(I[e - 1]), 1); e += 1
+    for i in range(1, stories + 1):
+        for j in range(bays):
+            ops.element('elasticBeamColumn', e, i * nb1 + j + 1, i * nb1 + j + 2, cfg.A, cfg.E, float(I[e - 1]), 1); e += 1
+    ops.timeSeries('Linear', 1); ops.pattern('Plain', 1, 1)
+    for tag, (x, y) in coords.items():
+        if x == 0.0 and y != 0.0:
+            ops.load(tag, cfg.lateral_load, 0.0, 0.0)
+    for ele in range(n_cols + 1, n_cols + n_beams + 1):
+        ops.eleLoad('-ele', ele, '-type', '-beamUniform', cfg.vertical_load, cfg.vertical_load)
+    ops.system('BandGeneral'); ops.numberer('RCM'); ops.constraints('Plain'); ops.integrator('LoadControl', 1.0)
+    ops.algorithm('Newton'); ops.analysis('Static')
+    assert ops.analyze(1) == 0
+    topo = frames.grid_frame(bays, stories, cfg, device="cpu")
+    d, f, st, _, _ = _oracle(topo, I)
+    for ele in (1, n_cols, n_cols + 1, n_cols + n_beams):
+        np.testing.assert_allclose(ops.eleResponse(ele, 'forces'), f[ele - 1], rtol=1e-7, atol=1e-6 * np.abs(f).max())
+    for n in (5, 8, 12):
+        for dof in (1, 2, 3):
+            assert ops.nodeDisp(n, dof) == pytest.approx(d[n - 1, dof - 1], rel=1e-7, abs=1e-12)
