@@ -113,6 +113,26 @@ def profiled_traffic(kernel_name, B):
     return best
 
 
+def surrogate_epoch_times(dev, rank, world, epochs, cases=50000):
+    """Second half of BASELINE.json's metric: PINN / TFD epoch time (weak scaling: `cases` generated cases and the
+    reference's batch size per GPU).  Returns a dict for the JSON line; never raises."""
+    try:
+        from openpystruct_amd import dataprep, sizing, train
+        t0 = time.perf_counter()
+        rec = sizing.generate_dataset(cases * world, sizing.SizingConfig(), dev, rank=rank, world=world)
+        torch.cuda.synchronize()
+        out = {"generate_s": time.perf_counter() - t0, "cases_per_gpu": cases, "fe_solves_per_gpu": int(rec["epochs_run"].sum())}
+        for kind in ("pinn", "tfd"):
+            d = dataprep.prepare(rec, kind=kind, device=dev, distributed=world > 1)
+            r = train.train_surrogate(kind, d, device=dev, max_epochs=epochs)
+            ep = r["history"]["epoch_s"][1:] or r["history"]["epoch_s"]
+            out[kind] = {"epoch_s": sum(ep) / len(ep), "steps_per_epoch": r["steps_per_epoch"], "train_groups_per_gpu": int(d.X_train.shape[0]),
+                         "dtype": "bf16"}
+        return out
+    except Exception as e:   # the FE line must survive whatever happens here
+        return {"error": repr(e)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -123,6 +143,9 @@ def main():
     ap.add_argument("--inertia", default="trajectory", choices=["uniform", "trajectory", "adversarial"])
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a HIP graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--train-epochs", type=int, default=None,
+                    help="also time N PINN / TFD training epochs on 50 000 generated cases per GPU (second half of the "
+                         "BASELINE metric); default: 5 at --gpus 1, off for N > 1 unless given")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -201,6 +224,9 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         wall, dev_ms = float(tt[0]), float(tt[1])
 
+    n_train = args.train_epochs if args.train_epochs is not None else (5 if world == 1 else 0)
+    epochs_info = surrogate_epoch_times(dev, rank, world, n_train) if n_train > 0 else None
+
     if rank == 0:
         kernel_ms = dev_ms / K
         achieved = BYTES_PER_SOLVE * B / (kernel_ms * 1e-3) / 1e9
@@ -241,6 +267,8 @@ def main():
         if tr:
             rec["roofline"]["traffic"] = tr[0]
             rec["roofline"]["traffic_source"] = f"profiles/{tr[1]} (2*FETCH_SIZE + WRITE_SIZE, KiB)"
+        if epochs_info is not None:
+            rec["surrogate_epochs"] = epochs_info
         if world == 1 and not args.no_cpu_baseline:
             rec["cpu_baseline"] = cpu_baseline(B)
         print(json.dumps(rec))
