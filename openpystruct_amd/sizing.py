@@ -64,6 +64,17 @@ class SizingConfig:
     def num_elements(self) -> int:
         return self.num_nodes - 1
 
+    @classmethod
+    def beam_opt(cls) -> "SizingConfig":
+        """The single-case optimiser script's constants (OpenPyStruct_BeamOpt.py:23-48): UDL -5000, 1000 epochs,
+        tolerance 1e-2, patience 10; its cases come from `make_beam_opt_cases`."""
+        return cls(uniform_udl=-5000.0, max_e=1000, tolerance=1e-2, patience=10)
+
+    @classmethod
+    def gpu_script(cls) -> "SizingConfig":
+        """OpenPyStruct_BeamOpt_training_GPU.py:50-51: tolerance 1e-2, patience 100 (otherwise as SingleCore)."""
+        return cls(tolerance=1e-2, patience=100)
+
     def c_params(self) -> "_cabi.SizingParams":
         return _cabi.SizingParams(
             E=self.E, G=self.G, alpha_moment=self.alpha_moment, alpha_shear=self.alpha_shear, lr=self.lr,
@@ -157,6 +168,47 @@ def make_cases(n_cases: int, cfg: SizingConfig, seed: int = 20250307, device="cp
     return Cases(xs, Ls, r_nodes, nr, f_nodes, k, f_vals, fix, Fy)
 
 
+def make_beam_opt_cases(n_cases: int, cfg: Optional[SizingConfig] = None, seed: int = 20250307, device="cpu",
+                        n_rollers: int = 5, m_forces: int = 5, min_spacing: int = 15) -> Cases:
+    """Cases as OpenPyStruct_BeamOpt.py:55-80 draws its single one: `n_rollers` rollers among nodes 2..N-1 whose
+    node numbers differ by at least `min_spacing` (BO:57-76 compares node ids with L_min), then `m_forces` loads
+    on distinct free nodes with values U(0.5, 1) * max_force (BO:78-80).  Sequential rejection sampling per case,
+    seeded; fixed 200 m geometry."""
+    cfg = cfg or SizingConfig.beam_opt()
+    rng = np.random.default_rng(seed)
+    N = cfg.num_nodes
+    cand = np.arange(2, N)
+    R = np.zeros((n_cases, n_rollers), dtype=np.int64)
+    Fn = np.zeros((n_cases, m_forces), dtype=np.int64)
+    Fv = np.zeros((n_cases, m_forces))
+    for b in range(n_cases):
+        while True:      # BO:66-76 can dead-end (no node left at distance >= 15): restart the case then
+            rollers = [int(rng.choice(cand))]
+            ok = True
+            for _ in range(1, n_rollers):
+                free = [n for n in cand if all(abs(n - r) >= min_spacing for r in rollers)]
+                if not free:
+                    ok = False
+                    break
+                rollers.append(int(rng.choice(free)))
+            if ok:
+                break
+        avail = [n for n in cand if n not in rollers]                              # BO:78
+        fn = rng.choice(avail, size=min(m_forces, len(avail)), replace=False)      # BO:79
+        R[b], Fn[b, : len(fn)] = rollers, fn
+        Fv[b, : len(fn)] = rng.uniform(cfg.max_force, 0.5 * cfg.max_force, size=len(fn))   # BO:80
+    dev = torch.device(device)
+    r_nodes, f_nodes = torch.as_tensor(R, device=dev), torch.as_tensor(Fn, device=dev)
+    f_vals = torch.as_tensor(Fv, device=dev)
+    B = n_cases
+    xs = torch.linspace(0, cfg.L_max, N, dtype=torch.float64, device=dev).expand(B, -1).contiguous()
+    fix = torch.zeros((B, N + 1), dtype=torch.uint8, device=dev).scatter_(1, r_nodes, 1)[:, 1:].contiguous()
+    fix[:, 0] = 1
+    Fy = torch.zeros((B, N + 1), dtype=torch.float64, device=dev).scatter_add_(1, f_nodes, f_vals)[:, 1:].contiguous()
+    return Cases(xs, torch.full((B,), cfg.L_max, dtype=torch.float64, device=dev), r_nodes,
+                 torch.full((B,), n_rollers, dtype=torch.int64, device=dev), f_nodes, (f_nodes > 0).sum(dim=1), f_vals, fix, Fy)
+
+
 def shard_range(n_total: int, rank: int, world: int) -> Tuple[int, int]:
     """Contiguous case range of `rank`: [rank*n/world, (rank+1)*n/world)."""
     return (rank * n_total) // world, ((rank + 1) * n_total) // world
@@ -171,9 +223,11 @@ class SizingState:
         f64 = dict(dtype=torch.float64, device=device)
         f32 = dict(dtype=torch.float32, device=device)
         self.B, self.N, self.Ne, self.cfg, self.device = B, N, Ne, cfg, device
-        shared_geom = cfg.random_bridge == 0
+        # one shared row when every case has the same geometry / supports (the kernel's shared-table fast path)
+        shared_geom = bool((cases.node_positions == cases.node_positions[:1]).all())
+        shared_fix = bool((cases.fix == cases.fix[:1]).all())
         self.x = (cases.node_positions[0] if shared_geom else cases.node_positions).to(**f64).contiguous()
-        self.fix = (cases.fix[0] if shared_geom else cases.fix).to(dtype=torch.uint8, device=device).contiguous()
+        self.fix = (cases.fix[0] if shared_fix else cases.fix).to(dtype=torch.uint8, device=device).contiguous()
         self.Fy = cases.Fy.to(**f64).contiguous()
         self.E = torch.tensor(cfg.E, **f64)
         self.wy = torch.tensor(cfg.uniform_udl, **f64)
