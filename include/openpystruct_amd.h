@@ -22,6 +22,7 @@
 #ifndef OPENPYSTRUCT_AMD_H
 #define OPENPYSTRUCT_AMD_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -136,13 +137,16 @@ int ops_beam_residual_vjp_f64(int B, int Ne, const double* x, long x_bstride, co
  * Per frame: I [B,Ne]; loads [Nn,3] (loads_bstride 0) or [B,Nn,3] (`ops.load(node, Fx, Fy, Mz)`).
  * Outputs: disp [B,Nn,3], forces [B,Ne,6] (global resisting forces = eleResponse 'forces'), V / M [B,Ne] = forces[..,1] /
  * forces[..,2] (FR:151-153), status [B] (non-zero: not positive definite, outputs NaN).
- * The band matrix lives in LDS: n_eq * (half_bandwidth + 2) * 8 bytes must fit 160 KB and half_bandwidth <= 63,
- * otherwise OPS_AMD_ERR_UNSUPPORTED. */
+ * half_bandwidth <= 63.  When the band (n_eq * (half_bandwidth + 2) * 8 bytes) fits 160 KB of LDS it lives there and
+ * `workspace` may be NULL; larger frames (BASELINE config 5: ~500 elements) keep it in a caller-provided device
+ * workspace of ops_frame_workspace_bytes(B, n_eq, half_bandwidth) bytes and factorise through a sliding LDS window. */
 int ops_frame_solve_batched_f64(int B, int n_nodes, int n_elems, int n_eq, int half_bandwidth,
                                 const double* elem_geo, const double* elem_EA, const double* elem_E,
                                 const double* elem_w, const int32_t* elem_eq, const int32_t* node_eq,
                                 const double* I, const double* loads, long loads_bstride, double* disp,
-                                double* forces, double* V, double* M, int32_t* status, void* stream);
+                                double* forces, double* V, double* M, int32_t* status, void* workspace,
+                                size_t workspace_bytes, void* stream);
+size_t ops_frame_workspace_bytes(int B, int n_eq, int half_bandwidth);
 
 /* Largest Ne a build supports, ABI version, and the text of the last HIP error seen by
  * this thread (empty string if none). */

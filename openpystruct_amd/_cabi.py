@@ -19,6 +19,7 @@ EXPORTS = (
     "ops_beam_residual_f64",
     "ops_beam_residual_vjp_f64",
     "ops_frame_solve_batched_f64",
+    "ops_frame_workspace_bytes",
     "ops_amd_max_elements",
     "ops_amd_abi_version",
     "ops_amd_last_error",
@@ -71,7 +72,9 @@ def load():
     rj.argtypes = [it, it, vp, lg, vp, lg, vp, vp, lg] + [vp] * 10
     fr = lib.ops_frame_solve_batched_f64
     fr.restype = it
-    fr.argtypes = [it] * 5 + [vp] * 8 + [lg] + [vp] * 6
+    fr.argtypes = [it] * 5 + [vp] * 8 + [lg] + [vp] * 6 + [ctypes.c_size_t, vp]
+    lib.ops_frame_workspace_bytes.restype = ctypes.c_size_t
+    lib.ops_frame_workspace_bytes.argtypes = [it, it, it]
     lib.ops_amd_max_elements.restype = it
     lib.ops_amd_abi_version.restype = it
     lib.ops_amd_last_error.restype = ctypes.c_char_p

@@ -125,15 +125,22 @@ def frame_solve(topo: FrameTopology, I: torch.Tensor, loads: Optional[torch.Tens
         out = FrameSolution(torch.empty((B, topo.Nn, 3), **f64), torch.empty((B, topo.Ne, 6), **f64),
                             torch.empty((B, topo.Ne), **f64), torch.empty((B, topo.Ne), **f64),
                             torch.empty((B,), dtype=torch.int32, device=dev))
+    ws_bytes = int(lib.ops_frame_workspace_bytes(B, topo.n_eq, topo.kd))
+    ws = None
+    if ws_bytes:       # band too large for LDS: HBM workspace, cached on the topology
+        ws = getattr(topo, "_ws", None)
+        if ws is None or ws.numel() < ws_bytes or ws.device != dev:
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+            topo._ws = ws
     with torch.cuda.device(dev):
         rc = lib.ops_frame_solve_batched_f64(
             B, topo.Nn, topo.Ne, topo.n_eq, topo.kd, topo.d_geo.data_ptr(), topo.d_EA.data_ptr(), topo.d_E.data_ptr(),
             topo.d_w.data_ptr(), topo.d_elem_eq.data_ptr(), topo.d_node_eq.data_ptr(), I.data_ptr(), loads.data_ptr(), lbs,
             out.disp.data_ptr(), out.forces.data_ptr(), out.V.data_ptr(), out.M.data_ptr(), out.status.data_ptr(),
-            torch.cuda.current_stream(dev).cuda_stream)
+            ws.data_ptr() if ws is not None else None, ws_bytes, torch.cuda.current_stream(dev).cuda_stream)
     if rc == _cabi.ERR_UNSUPPORTED:
-        raise NotImplementedError(f"frame too large for the LDS-resident band solver: n_eq={topo.n_eq}, half bandwidth={topo.kd} "
-                                  f"({topo.lds_bytes()} B > 160 KB)")
+        raise NotImplementedError(f"frame too large: n_eq={topo.n_eq}, half bandwidth={topo.kd} (half bandwidth <= 63 and a "
+                                  f"(kd+2)-column window plus two n_eq vectors must fit 160 KB of LDS)")
     if rc != _cabi.OK:
         raise RuntimeError(f"ops_frame_solve_batched_f64 failed with code {rc}")
     return out

@@ -61,9 +61,30 @@ def test_frame_status_and_unsupported_size():
     sol = frames.frame_solve(topo, I)
     st = sol.status.cpu().numpy()
     assert st[1] != 0 and st[0] == 0 and st[2] == 0 and torch.isnan(sol.disp[1]).all() and torch.isfinite(sol.disp[0]).all()
-    big = frames.grid_frame(20, 20)
+    big = frames.grid_frame(21, 3)             # half bandwidth 3 * 22 + 2 = 68 > 63
     with pytest.raises(NotImplementedError):
         frames.frame_solve(big, torch.full((1, big.Ne), 5e-4, dtype=torch.float64, device="cuda"))
+
+
+@pytest.mark.parametrize("bays,stories", [(15, 16), (13, 13), (18, 20)])
+def test_large_frames_band_in_hbm_workspace(bays, stories):
+    """BASELINE config 5 size (15 x 16 = 496 elements): the band no longer fits LDS and streams through a window."""
+    from openpystruct_amd import _cabi, frames
+    topo = frames.grid_frame(bays, stories)
+    B = 3
+    assert int(_cabi.load().ops_frame_workspace_bytes(B, topo.n_eq, topo.kd)) == B * (topo.n_eq * (topo.kd + 2)) * 8
+    rng = np.random.default_rng(bays)
+    I = np.exp(rng.uniform(np.log(1e-4), np.log(5e-3), size=(B, topo.Ne)))
+    sol = frames.frame_solve(topo, torch.as_tensor(I, device="cuda"))
+    torch.cuda.synchronize()
+    assert int(sol.status.abs().sum()) == 0
+    for b in range(B):
+        d, f, st, neq, kd = _oracle(topo, I[b])
+        assert relerr(sol.disp[b].cpu().numpy().ravel(), d.ravel()) < 1e-7
+        assert relerr(sol.forces[b].cpu().numpy().ravel(), f.ravel()) < 1e-6
+    # second call re-uses the workspace; assembly uses float atomics, so equality is to rounding, not bitwise
+    sol2 = frames.frame_solve(topo, torch.as_tensor(I, device="cuda"))
+    assert relerr(sol2.disp.cpu().numpy().reshape(B, -1), sol.disp.cpu().numpy().reshape(B, -1)) < 1e-9
 
 
 def test_frame_sizing_loop_runs_like_the_reference():
