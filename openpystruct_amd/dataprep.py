@@ -101,11 +101,12 @@ def prepare(records: Dict[str, object], *, kind: str = "pinn", n_cases: int = 6,
     """records: the 13-field dataset (lists as in the reference JSON, or tensors from `generate_dataset`).
 
     kind = "pinn": flat inputs, targets [I, deflections, rotations] (PINN:337-369)
+    kind = "fnn" : flat inputs, targets I only (the FNN sibling: same prep as PINN without the displacement targets)
     kind = "tfd" : sequence inputs padded to a multiple of `nheads`, targets I only (TFD:330-371); the
                    reference re-fits the input scalers on the validation split (TFD:325-328) -- kept behind
                    `refit_val_scalers` (default True for "tfd", False for "pinn").
     With `distributed=True` every rank passes ITS shard of records; moments and constraints are all-reduced."""
-    assert kind in ("pinn", "tfd")
+    assert kind in ("pinn", "tfd", "fnn")
     if refit_val_scalers is None:
         refit_val_scalers = kind == "tfd"
     ml = dict(max_lengths or {})
@@ -151,7 +152,7 @@ def prepare(records: Dict[str, object], *, kind: str = "pinn", n_cases: int = 6,
     else:
         Xva = torch.cat([sc_in[k].transform(feats[k][va]) for k in feats], dim=2)
     feat_dim = Xtr.shape[2]
-    if kind == "pinn":
+    if kind in ("pinn", "fnn"):
         Xtr, Xva = Xtr.reshape(Xtr.shape[0], -1), Xva.reshape(Xva.shape[0], -1)               # PINN:337-338
     else:
         pad = (-feat_dim) % nheads                                                             # TFD:170-189

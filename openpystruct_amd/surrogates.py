@@ -192,5 +192,42 @@ class ModelOnePassTransformerWithDiffusion(nn.Module):
         return self.fc2(self.dropout(torch.relu(self.norm1(self.fc1(x[:, 0, :])))))
 
 
+# ------------------------------------------------------------------------------------------------
+# FNN: the plain residual MLP sibling -- same data prep and loop as the TFD model (targets: I only)
+# ------------------------------------------------------------------------------------------------
+class FNNResidualBlock(nn.Module):
+    """LayerNorm(x + dropout(leaky(fc1(x)))) then LeakyReLU (/root/reference/OpenPyStruct_FNN_MultiCase.py:330-351);
+    the reference's unused `hidden_dim` argument is kept for signature compatibility."""
+
+    def __init__(self, input_dim, hidden_dim, dropout_rate):
+        super().__init__()
+        self.fc1 = nn.Linear(input_dim, input_dim)
+        self.LeakyReLU = nn.LeakyReLU(0.01)
+        self.dropout = nn.Dropout(dropout_rate)
+        self.norm = nn.LayerNorm(input_dim)
+
+    def forward(self, x):
+        return self.LeakyReLU(self.norm(self.dropout(self.LeakyReLU(self.fc1(x))) + x))
+
+
+class FNNPlain(nn.Module):
+    """input_fc -> LeakyReLU -> dropout -> n x FNNResidualBlock -> output_fc (FNN:353-380); in the reference this
+    class is also called FNNWithResidual -- renamed here because the PINN script's class of that name differs."""
+
+    def __init__(self, input_dim, hidden_dim, num_residual_blocks, output_dim, dropout_rate):
+        super().__init__()
+        self.input_fc = nn.Linear(input_dim, hidden_dim)
+        self.LeakyReLU = nn.LeakyReLU(0.01)
+        self.dropout = nn.Dropout(dropout_rate)
+        self.residual_blocks = nn.ModuleList(FNNResidualBlock(hidden_dim, hidden_dim * 2, dropout_rate) for _ in range(num_residual_blocks))
+        self.output_fc = nn.Linear(hidden_dim, output_dim)
+
+    def forward(self, x):
+        out = self.dropout(self.LeakyReLU(self.input_fc(x)))
+        for block in self.residual_blocks:
+            out = block(out)
+        return self.output_fc(out)
+
+
 def count_parameters(m: nn.Module) -> int:
     return sum(p.numel() for p in m.parameters())

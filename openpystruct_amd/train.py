@@ -34,7 +34,7 @@ import torch.nn as nn
 from torch.optim.lr_scheduler import ExponentialLR
 
 from .dataprep import SurrogateData
-from .surrogates import CompositeLoss, FNNWithResidual, ModelOnePassTransformerWithDiffusion, TrainableL1L2Loss
+from .surrogates import CompositeLoss, FNNPlain, FNNWithResidual, ModelOnePassTransformerWithDiffusion, TrainableL1L2Loss
 
 
 @dataclass
@@ -87,6 +87,28 @@ class TfdConfig:
     diffusion_T: int = 512
 
 
+@dataclass
+class FnnConfig:
+    """/root/reference/OpenPyStruct_FNN_MultiCase.py:35-52 (num_blocks = 3 is unused there: the model is built with 4)."""
+    n_cases: int = 6
+    nelem: int = 100
+    box_constraint_coeff: float = 5e-1
+    hidden_units: int = 128
+    dropout_rate: float = 0.5
+    num_residual_blocks: int = 4
+    num_epochs: int = 500
+    batch_size: int = 128
+    patience: int = 10
+    learning_rate: float = 2e-4
+    weight_decay: float = 1e-2
+    train_split: float = 0.8
+    sigma_0: float = 0.03
+    gamma_noise: float = 0.97
+    gamma: float = 0.99
+    initial_alpha: float = 0.5
+    c: float = 1.0
+
+
 def build_model_and_loss(kind: str, cfg, data: SurrogateData, device):
     if kind == "pinn":
         out_dim = cfg.nelem + 2 * (cfg.nelem + 1)
@@ -98,6 +120,9 @@ def build_model_and_loss(kind: str, cfg, data: SurrogateData, device):
                                                      cfg.num_transformer_layers, cfg.num_heads, cfg.dim_feedforward,
                                                      cfg.dropout_rate, cfg.max_len, cfg.diffusion_hidden_dim, cfg.diffusion_T)  # TFD:664-676
         crit = TrainableL1L2Loss(cfg.initial_alpha, data.min_constraint, data.max_constraint, cfg.box_constraint_coeff)       # TFD:680
+    elif kind == "fnn":
+        model = FNNPlain(data.X_train.shape[1], cfg.hidden_units, cfg.num_residual_blocks, cfg.nelem, cfg.dropout_rate)
+        crit = TrainableL1L2Loss(cfg.initial_alpha, data.min_constraint, data.max_constraint, cfg.box_constraint_coeff)
     else:
         raise ValueError(kind)
     return model.to(device), crit.to(device)
@@ -134,7 +159,7 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
                     use_graph: Optional[bool] = None, physics: Optional[PhysicsTerm] = None) -> Dict[str, object]:
     """Trains on THIS rank's `data` shard; uses DDP when torch.distributed is initialised with world_size > 1.
     Returns history, best state dict, validation R^2 (I only) and per-epoch times."""
-    cfg = cfg or (PinnConfig() if kind == "pinn" else TfdConfig())
+    cfg = cfg or {"pinn": PinnConfig, "tfd": TfdConfig, "fnn": FnnConfig}[kind]()
     device = torch.device(device)
     world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
     rank = dist.get_rank() if world > 1 else 0
@@ -192,8 +217,8 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
         with torch.autocast(device_type=device.type, dtype=autocast_dtype, enabled=use_ac):
             preds = net(Xn)
             loss = crit(preds.float(), Yb)
-            if kind == "tfd":
-                loss = loss + (cfg.initial_alpha - crit.alpha) ** 2       # TFD:743 (constant 0: alpha never trains)
+            if kind in ("tfd", "fnn"):
+                loss = loss + (cfg.initial_alpha - crit.alpha) ** 2       # TFD:743 / FNN (constant 0: alpha never trains)
         if physics is not None:
             loss = loss + physics.weight * physics_loss(preds.float(), rows).float()
         loss.backward()

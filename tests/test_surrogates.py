@@ -42,6 +42,11 @@ def test_parameter_counts_and_state_dict_names():
     assert tuple(pinn(torch.randn(5, 684)).shape) == (5, 302)
     with pytest.raises(AssertionError):
         tfd(torch.randn(5, 7, 120))                                        # TFD:550-551
+    fnn = surrogates.FNNPlain(684, 128, 4, 100, 0.5)                       # FNN:472-478
+    # 684*128+128 input, 4 x (128*128+128 fc1 + 2*128 LayerNorm), 128*100+100 output
+    assert surrogates.count_parameters(fnn) == 684 * 128 + 128 + 4 * (128 * 128 + 128 + 256) + 128 * 100 + 100
+    assert {"input_fc.weight", "residual_blocks.3.fc1.bias", "residual_blocks.0.norm.weight", "output_fc.weight"} <= set(fnn.state_dict())
+    assert tuple(fnn(torch.randn(5, 684)).shape) == (5, 100)
 
 
 def test_losses_against_hand_computed_values():
@@ -85,15 +90,17 @@ def test_prepare_shapes_pinn_and_tfd():
     t = dataprep.prepare(rec, kind="tfd", seed=1)
     assert t.X_train.shape == (16, 6, 120) and t.Y_train.shape == (16, 100) and t.feat_dim == 120         # padded to 8 heads
     assert float(t.X_train[:, :, 114:].abs().max()) == 0.0
+    f = dataprep.prepare(rec, kind="fnn", seed=1, c=1.0)
+    assert f.X_train.shape == (16, 684) and f.Y_train.shape == (16, 100) and torch.equal(f.X_train, d.X_train)
     with pytest.raises(ValueError):
         dataprep.prepare(_fake_records(4), kind="pinn")
 
 
-@pytest.mark.parametrize("kind", ["pinn", "tfd"])
+@pytest.mark.parametrize("kind", ["pinn", "tfd", "fnn"])
 def test_training_loop_runs_and_early_stops(kind):
     rec = _fake_records(240, seed=3)
     d = dataprep.prepare(rec, kind=kind, seed=2)
-    cfg = train.PinnConfig(batch_size=16, patience=2) if kind == "pinn" else train.TfdConfig(batch_size=16, patience=2)
+    cfg = {"pinn": train.PinnConfig, "tfd": train.TfdConfig, "fnn": train.FnnConfig}[kind](batch_size=16, patience=2)
     out = train.train_surrogate(kind, d, cfg, device="cpu", autocast_dtype=None, max_epochs=4)
     assert 1 <= out["epochs"] <= 4 and len(out["history"]["val"]) == out["epochs"]
     assert np.isfinite(out["history"]["train"]).all() and np.isfinite(out["r2_val_I"])
