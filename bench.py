@@ -95,6 +95,21 @@ def cpu_baseline(B_hint):
     }
 
 
+def stream_copy_gbs(dev, mib=1024, reps=10):
+    """Achievable HBM rate on THIS box (report the fraction against the nominal peak and against a
+    measured copy): device-to-device copy of `mib` MiB, read + write bytes over the HIP-event time."""
+    src = torch.empty(mib << 20, dtype=torch.uint8, device=dev)
+    dst = torch.empty_like(src)
+    dst.copy_(src)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        dst.copy_(src)
+    e1.record()
+    torch.cuda.synchronize(dev)
+    return 2.0 * (mib << 20) * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
+
+
 def profiled_traffic(kernel_name, B):
     """HBM bytes per launch from the newest committed PMC summary of this command (scripts/profile_gpu.sh:
     separate --pmc passes; FETCH_SIZE / WRITE_SIZE are KiB; FETCH_SIZE x2 for 16-byte coalesced reads on
@@ -263,6 +278,9 @@ def main():
                 "bytes_per_launch": BYTES_PER_SOLVE * B,
             },
         }
+        copy = stream_copy_gbs(dev)
+        rec["roofline"]["stream_copy"] = copy
+        rec["roofline"]["frac_of_stream_copy"] = achieved / copy
         tr = profiled_traffic(rec["config"]["kernel"], B)
         if tr:
             rec["roofline"]["traffic"] = tr[0]

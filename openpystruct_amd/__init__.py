@@ -3,5 +3,6 @@
 Host side in Python over a C-ABI HIP library; see DESIGN.md and INTEGRATION.md.
 """
 from .beam import BeamSolution, beam_solve, kernel_name  # noqa: F401
+from . import torch_op  # noqa: F401  (registers torch.ops.openpystruct_amd.beam_solve)
 
 __all__ = ["BeamSolution", "beam_solve", "kernel_name"]

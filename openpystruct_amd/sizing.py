@@ -379,3 +379,56 @@ def records_to_reference_json(rec: Dict[str, object], path: str, drop_failed: bo
     with open(path, "w") as f:
         json.dump(out, f)
     return len(keep)
+
+
+def records_from_reference_json(path: str) -> Dict[str, object]:
+    """Reads the reference's wire format back (the `json.load` at PINN:192-196 / TFD:240-244): the 13 parallel lists,
+    with the fixed-width fields as tensors and the ragged ones zero-padded + counted, i.e. the shape
+    `generate_dataset` returns and `dataprep.prepare` consumes.  Raises KeyError on a missing field."""
+    with open(path) as f:
+        d = json.load(f)
+    missing = [k for k in RECORD_KEYS if k not in d]
+    if missing:
+        raise KeyError(f"{path}: missing record fields {missing}")
+    B = len(d["I_values"])
+
+    def padded(key, dtype):
+        w = max((len(r) for r in d[key]), default=0)
+        t = torch.zeros((B, w), dtype=dtype)
+        for b, r in enumerate(d[key]):
+            t[b, : len(r)] = torch.as_tensor(r, dtype=dtype)
+        return t
+
+    rec: Dict[str, object] = {
+        "roller_x_locations": padded("roller_x_locations", torch.float64),
+        "force_x_locations": padded("force_x_locations", torch.float64),
+        "force_values": padded("force_values", torch.float64),
+        "roller_nodes": padded("roller_nodes", torch.int64),
+        "force_nodes": padded("force_nodes", torch.int64),
+        "n_rollers": torch.tensor([len(r) for r in d["roller_nodes"]], dtype=torch.int64),
+        "n_forces": torch.tensor([len(r) for r in d["force_nodes"]], dtype=torch.int64),
+        "I_values": torch.tensor(d["I_values"], dtype=torch.float32),
+        "shear_forces": torch.tensor(d["shear_forces"], dtype=torch.float32),
+        "bending_moments": torch.tensor(d["bending_moments"], dtype=torch.float32),
+        "node_positions": torch.tensor(d["node_positions"], dtype=torch.float64),
+        "rotations": torch.tensor(d["rotations"], dtype=torch.float64),
+        "deflections": torch.tensor(d["deflections"], dtype=torch.float64),
+        "L": torch.tensor(d["L"], dtype=torch.float64),
+        "num_nodes": int(d["num_nodes"][0]) if B else 0,
+        "status": torch.zeros(B, dtype=torch.int32),
+    }
+    return rec
+
+
+def save_records(rec: Dict[str, object], path: str) -> None:
+    """Binary fast path for datasets that stay inside this package: one `torch.save` of the record
+    tensors moved to the host -- 200 000 cases are ~0.5 GB here against several GB of JSON text."""
+    torch.save({k: (v.detach().cpu() if torch.is_tensor(v) else v) for k, v in rec.items()}, path)
+
+
+def load_records(path: str, device="cpu") -> Dict[str, object]:
+    rec = torch.load(path, map_location=device, weights_only=True)
+    missing = [k for k in RECORD_KEYS if k not in rec]
+    if missing:
+        raise KeyError(f"{path}: missing record fields {missing}")
+    return rec

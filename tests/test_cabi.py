@@ -62,3 +62,20 @@ def test_product_never_imports_oracle():
             if fn.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
                 src = open(os.path.join(dp, fn)).read()
                 assert "import oracle" not in src and "from oracle" not in src and "oracle/" not in src, fn
+
+
+def test_torch_library_op_is_registered_gpu_only():
+    import torch
+    import openpystruct_amd  # noqa: F401
+    from torch._subclasses.fake_tensor import FakeTensorMode
+    op = torch.ops.openpystruct_amd.beam_solve
+    with FakeTensorMode():
+        I = torch.empty(7, 100, dtype=torch.float64)
+        v, th, V, M, st = op(torch.empty(101, dtype=torch.float64), torch.empty((), dtype=torch.float64), I,
+                             torch.empty(101, dtype=torch.uint8), torch.empty(7, 101, dtype=torch.float64),
+                             torch.empty((), dtype=torch.float64))
+    assert v.shape == (7, 101) and th.shape == (7, 101) and V.shape == (7, 100) and M.shape == (7, 100)
+    assert st.shape == (7,) and st.dtype == torch.int32
+    with pytest.raises(NotImplementedError):            # no CPU kernel behind the operator
+        op(torch.zeros(3, dtype=torch.float64), torch.ones((), dtype=torch.float64), torch.ones(1, 2, dtype=torch.float64),
+           torch.zeros(3, dtype=torch.uint8), torch.zeros(1, 3, dtype=torch.float64), torch.zeros((), dtype=torch.float64))

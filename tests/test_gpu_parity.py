@@ -239,3 +239,27 @@ def test_large_random_bridge_batch_vs_c_oracle(oa):
     # soft cantilever): compare where the oracle itself is trustworthy, relative to each beam's scale
     assert np.median(np.abs(v[ok] - ref[0][ok]).max(axis=1) / np.abs(ref[0][ok]).max(axis=1)) < 1e-7   # eps * cond, cond ~ 1e7-1e9
     assert relerr(v[ok], ref[0][ok]) < 1e-5
+
+
+def test_torch_library_operator_matches_beam_solve_and_captures(oa):
+    rng = np.random.default_rng(77)
+    I, Fy = bo.random_cases(rng, 300, inertia="trajectory")
+    args = (_gpu(np.linspace(0, 200, 101)), torch.tensor(bo.E_REF, dtype=torch.float64, device="cuda"), _gpu(I),
+            _gpu(bo.reference_fix_mask(), torch.uint8), _gpu(Fy), torch.tensor(bo.UDL_REF, dtype=torch.float64, device="cuda"))
+    ref = oa.beam_solve(*args)
+    got = torch.ops.openpystruct_amd.beam_solve(*args)
+    for a, b in zip(got, ref):
+        assert torch.equal(a, b)
+    # inside a HIP graph (the operator allocates its outputs from the graph's private pool)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        torch.ops.openpystruct_amd.beam_solve(*args)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            out = torch.ops.openpystruct_amd.beam_solve(*args)
+    torch.cuda.current_stream().wait_stream(side)
+    args[2].mul_(2.0)                                   # twice the inertia: half the deflection, same forces
+    g.replay()
+    torch.cuda.synchronize()
+    assert float(relerr(out[0].cpu().numpy(), 0.5 * ref.v.cpu().numpy())) < 1e-9

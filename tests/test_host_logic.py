@@ -172,3 +172,41 @@ def test_reference_json_wire_format(tmp_path):
     assert all(len(d[k]) == 4 for k in d)
     assert d["roller_x_locations"][0] == [18.0, 58.0, 138.0, 168.0, 198.0]
     assert len(d["I_values"][0]) == 100 and len(d["deflections"][0]) == 101 and d["num_nodes"][0] == 101
+    # ... and back: the reader returns the tensor form generate_dataset produces, prepare() accepts both forms alike
+    back = sizing.records_from_reference_json(path)
+    keep = [0, 1, 3, 4]
+    assert torch.equal(back["I_values"], rec["I_values"][keep]) and torch.equal(back["deflections"], rec["deflections"][keep])
+    assert back["roller_nodes"].tolist() == [cases.roller_nodes[b] for b in keep] and back["n_forces"].tolist() == [len(cases.force_nodes[b]) for b in keep]
+    assert back["force_values"][0, : len(cases.force_values[0])].tolist() == list(cases.force_values[0]) and back["num_nodes"] == N
+    binp = str(tmp_path / "records.pt")
+    sizing.save_records(back, binp)
+    again = sizing.load_records(binp)
+    assert all(torch.equal(again[k], back[k]) if torch.is_tensor(back[k]) else again[k] == back[k] for k in back)
+    json.dump({"I_values": []}, open(path, "w"))
+    with pytest.raises(KeyError):
+        sizing.records_from_reference_json(path)
+
+
+def test_prepare_accepts_json_lists_and_reader_tensors_alike(tmp_path):
+    from openpystruct_amd import dataprep
+    cfg = sizing.SizingConfig()
+    cases = sizing.make_cases(36, cfg, seed=6)
+    B, N = cases.Fy.shape
+    xs = cases.node_positions.numpy()
+    g = torch.Generator().manual_seed(0)
+    rec = {
+        "roller_x_locations": [[float(xs[b, n - 1]) for n in cases.roller_nodes[b]] for b in range(B)],
+        "force_x_locations": [[float(xs[b, n - 1]) for n in cases.force_nodes[b]] for b in range(B)],
+        "force_values": cases.force_values, "I_values": torch.rand(B, N - 1, generator=g),
+        "shear_forces": torch.rand(B, N - 1, generator=g), "bending_moments": torch.rand(B, N - 1, generator=g),
+        "node_positions": cases.node_positions, "roller_nodes": cases.roller_nodes, "force_nodes": cases.force_nodes,
+        "num_nodes": N, "L": cases.L, "rotations": torch.rand(B, N, dtype=torch.float64, generator=g),
+        "deflections": torch.rand(B, N, dtype=torch.float64, generator=g),
+    }
+    path = str(tmp_path / "d.json")
+    sizing.records_to_reference_json(rec, path)
+    as_lists = json.load(open(path))                     # what the reference's scripts hold after json.load
+    as_tensors = sizing.records_from_reference_json(path)
+    a = dataprep.prepare(as_lists, kind="pinn", seed=3)
+    b = dataprep.prepare(as_tensors, kind="pinn", seed=3)
+    assert torch.allclose(a.X_train, b.X_train, atol=1e-6) and torch.allclose(a.Y_val, b.Y_val, atol=1e-6)
