@@ -83,6 +83,8 @@ class SurrogateData:
     max_lengths: Dict[str, int]
     Fy_train: Optional[torch.Tensor] = None   # [G, N] nodal loads per training group (n_cases == 1 only): physics loss
     Fy_val: Optional[torch.Tensor] = None
+    v_train: Optional[torch.Tensor] = None    # [G, N] recorded deflections / rotations (float64, unscaled; n_cases == 1 only):
+    theta_train: Optional[torch.Tensor] = None  # the displacement field the I-only models' physics term tests K(I_pred) against
 
 
 INPUT_KEYS = ("roller_x_locations", "force_x_locations", "force_values", "node_positions")   # PINN:198-201
@@ -188,5 +190,10 @@ def prepare(records: Dict[str, object], *, kind: str = "pinn", n_cases: int = 6,
                     Fy[b, int(n) - 1] += float(f)
         Fy = Fy.to(dev)
         Fy_tr, Fy_va = Fy[tr].contiguous(), Fy[va].contiguous()
+    v_tr = th_tr = None
+    if n_cases == 1 and "deflections" in records and "rotations" in records:
+        as64 = lambda v: (v.to(torch.float64) if torch.is_tensor(v) else pad_sequences(v, len(v[0])).to(torch.float64))  # noqa: E731
+        v_tr = as64(records["deflections"])[:G].to(dev)[tr].contiguous()
+        th_tr = as64(records["rotations"])[:G].to(dev)[tr].contiguous()
     return SurrogateData(Xtr.contiguous(), Ytr.contiguous(), Xva.contiguous(), Yva.contiguous(), sc_in, sc_Y, mn, mx, feat_dim, ml,
-                         Fy_tr, Fy_va)
+                         Fy_tr, Fy_va, v_tr, th_tr)

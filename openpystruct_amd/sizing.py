@@ -337,6 +337,9 @@ def generate_dataset(n_cases: int, cfg: Optional[SizingConfig] = None, device="c
         "n_forces": cases.n_forces,
         "epochs_run": st.epochs_run,
         "status": sol.status,
+        # not a reference field: the float64 inertias the recorded V / M / rotations / deflections were solved with
+        # (the state BEFORE the last Adam step; `I_values` is the state after it -- the reference's one-step lag)
+        "I_solved": st.I64,
         "case_ids": torch.arange(lo, hi),
     }
 

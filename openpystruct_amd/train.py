@@ -130,8 +130,12 @@ def build_model_and_loss(kind: str, cfg, data: SurrogateData, device):
 
 @dataclass
 class PhysicsTerm:
-    """Optional FE-residual term for the PINN (physics.py).  Needs per-case targets (cfg.n_cases == 1, so that
-    predicted inertias and displacements belong to ONE load case) and `data.Fy_train`."""
+    """Optional FE-residual term (physics.py; BASELINE configs 3-4).  Needs per-case targets (cfg.n_cases == 1, so that
+    inertias and displacements belong to ONE load case) and `data.Fy_train`.
+    PINN: r = K(I_pred) u_pred - f on the model's own (I, v, theta) outputs.
+    TFD / FNN (I-only outputs): r = K(I_pred) u_rec - f with the displacement field recorded in the dataset
+    (`data.v_train`, `data.theta_train`): zero when the predicted inertias reproduce the recorded response.  The
+    records must keep the last node's values (SizingConfig.zero_last_node = False: MultiCore.py:222-223 zeroes them)."""
     weight: float
     x: torch.Tensor        # [N] node coordinates
     E: float
@@ -195,19 +199,28 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
     hist = {"train": [], "val": [], "epoch_s": []}
 
     if physics is not None:
-        if kind != "pinn" or cfg.n_cases != 1 or data.Fy_train is None:
-            raise ValueError("the FE-residual term needs kind='pinn', n_cases == 1 and data.Fy_train (per-case loads)")
+        if cfg.n_cases != 1 or data.Fy_train is None:
+            raise ValueError("the FE-residual term needs n_cases == 1 and data.Fy_train (per-case loads)")
+        if kind != "pinn" and data.v_train is None:
+            raise ValueError("the FE-residual term of an I-only model needs the recorded displacements (data.v_train)")
         from .physics import fe_residual_loss
         use_graph = False                       # the physics term indexes per-batch loads eagerly
         Fy_tr = data.Fy_train.to(device)
-        sI, sD, sR = data.scalers_Y["I"], data.scalers_Y["deflections"], data.scalers_Y["rotations"]
+        sI = data.scalers_Y["I"]
+        if kind == "pinn":
+            sD, sR = data.scalers_Y["deflections"], data.scalers_Y["rotations"]
+        else:
+            v_rec, t_rec = data.v_train.to(device), data.theta_train.to(device)
         px, pfix = physics.x.to(device), physics.fix.to(device)
 
     def physics_loss(preds, rows):
         nel = cfg.nelem
         I_p = sI.inverse_transform(preds[:, :nel]).clamp_min(1e-8)
-        v_p = sD.inverse_transform(preds[:, nel:2 * nel + 1])
-        t_p = sR.inverse_transform(preds[:, 2 * nel + 1:])
+        if kind == "pinn":
+            v_p = sD.inverse_transform(preds[:, nel:2 * nel + 1])
+            t_p = sR.inverse_transform(preds[:, 2 * nel + 1:])
+        else:
+            v_p, t_p = v_rec[rows], t_rec[rows]
         return fe_residual_loss(I_p, v_p, t_p, px, physics.E, pfix, Fy_tr[rows], physics.wy)
 
     def fwd_bwd(Xb, Yb, noise_t, rows=None):

@@ -97,3 +97,29 @@ def test_pinn_training_with_the_fe_residual_term():
     assert out["epochs"] == 2 and np.isfinite(out["history"]["train"]).all()
     base = train.train_surrogate("pinn", d, cfg, device="cuda", max_epochs=2)
     assert out["history"]["train"][0] != base["history"]["train"][0]       # the term is really in the loss
+
+
+@pytest.mark.parametrize("kind", ["tfd", "fnn"])
+def test_i_only_models_train_with_the_fe_residual_of_the_recorded_field(kind):
+    """BASELINE config 4: the I-only surrogates take their physics loss from K(I_pred) u_recorded - f (HIP residual kernels)."""
+    from openpystruct_amd import dataprep, physics, sizing, train
+    cfg_s = sizing.SizingConfig(max_e=20)
+    rec = sizing.generate_dataset(256, cfg_s, "cuda", seed=5)
+    d = dataprep.prepare(rec, kind=kind, n_cases=1, seed=0, device="cuda")
+    assert d.v_train is not None and d.v_train.shape == (204, 101) and d.v_train.dtype == torch.float64
+    x = torch.linspace(0, 200, 101, dtype=torch.float64)
+    fix = torch.as_tensor(bo.reference_fix_mask())
+    # the recorded field belongs to the inertias one Adam step BEFORE the recorded ones (the reference's lag): zero
+    # residual for those, and already a visible one for the recorded `I_values`
+    I_rec = rec["I_solved"]
+    args = (rec["deflections"], rec["rotations"], x.cuda(), cfg_s.E, fix.cuda(), None, cfg_s.uniform_udl)
+    Fy = torch.zeros((256, 102), dtype=torch.float64, device="cuda").scatter_add_(1, rec["force_nodes"].long(), rec["force_values"].double())[:, 1:]
+    l_true = float(physics.fe_residual_loss(I_rec, args[0], args[1], args[2], args[3], args[4], Fy, args[6]))
+    l_wrong = float(physics.fe_residual_loss(rec["I_values"].double(), args[0], args[1], args[2], args[3], args[4], Fy, args[6]))
+    assert l_true < 1e-6 * l_wrong
+    cfg = (train.TfdConfig if kind == "tfd" else train.FnnConfig)(n_cases=1, batch_size=64)
+    phys = train.PhysicsTerm(weight=1e-3, x=x, E=cfg_s.E, fix=fix, wy=cfg_s.uniform_udl)
+    out = train.train_surrogate(kind, d, cfg, device="cuda", max_epochs=2, physics=phys)
+    base = train.train_surrogate(kind, d, cfg, device="cuda", max_epochs=2)
+    assert out["epochs"] == 2 and np.isfinite(out["history"]["train"]).all()
+    assert out["history"]["train"][0] != base["history"]["train"][0]
