@@ -1,6 +1,6 @@
 // Batched 2-D elastic frame solve (3 DOF per node): assembly of rotated ElasticBeam2d stiffness matrices,
-// banded LDL^T factorisation, substitution and global end-force recovery, one 1024-thread workgroup per frame with the
-// band matrix resident in LDS.
+// banded LDL^T factorisation (three columns per workgroup barrier), substitution and global end-force recovery, one
+// workgroup per frame with the band matrix resident in LDS.
 //
 // SURVEY section 8(f1) / BASELINE config 5: generalises the beam path to the model built by
 // `setup_frame_model` (/root/reference/OpenPyStruct_FrameOpt_Discrete_Beta.py:75-139): columns and beams of
@@ -11,12 +11,23 @@
 //
 // All frames of a launch share one topology (node coordinates, connectivity, constraints, equation numbers:
 // prepared once on the host, `openpystruct_amd/frames.py`) and differ in the element inertias and loads.
-// LDS: ab[n_eq][kd+1] (lower band, column j holds A[j..j+kd][j]) + rhs[n_eq]; n_eq * (kd + 2) * 8 B <= 160 KB.
-// The factorisation is LDS-bandwidth / barrier bound (n_eq * kd^2 / 2 FMAs, one barrier per column), not HBM
-// bound: ~15 KB of HBM traffic per frame.
+// LDS: ab[n3][ld] (lower band, column j holds A[j..j+kd][j]; n3 = n_eq rounded up to 3, ld = kd + 1 rounded up to
+// even so that the diagonal walks of the sweeps hit distinct banks) + rhs[n3]; n3 * (ld + 1) * 8 B <= 160 KB.
+// The factorisation is LDS-latency / barrier bound (n_eq * kd^2 / 2 FMAs behind n_eq / 3 barriers), not HBM bound:
+// ~15 KB of HBM traffic per frame.
+//
+// Block steps.  Columns j, j+1, j+2 are eliminated together: every thread factors the 3 x 3 pivot block P
+// redundantly (scalar LDL^T of P: the same pivots, in the same order, as the column-by-column algorithm, so the
+// result differs from it by rounding only), and applies the rank-3 update  A[R][C] -= B_R P^-1 B_C^T  to the one or
+// two window entries (R, C) it owns for the whole factorisation.  The panel B (rows j+3 .. j+2+kd of the three
+// columns) is left in place UNSCALED; the factored pivot (1/d1, l21, l31, 1/d2, l32, 1/d3) replaces P one step later.
+// Forward substitution rides along in the last wave; backward substitution is done by wave 0 alone, in "axpy" form
+// (each solved block is subtracted from the <= kd earlier right-hand sides), with wave-local LDS ordering instead of
+// workgroup barriers.
 #include <hip/hip_runtime.h>
 #include <stddef.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/openpystruct_amd.h"
 
@@ -36,7 +47,18 @@ struct FrameParams {
   double* forces;            // [B,Ne,6]
   double* V; double* M;      // [B,Ne] = forces[:, :, 1], forces[:, :, 2] (what the sizing loss reads, FR:151-153)
   int32_t* status;
+  unsigned long long* trace;   // diagnostic builds (-DOPS_AMD_FRAME_TRACE) only
 };
+
+#ifdef OPS_AMD_FRAME_TRACE
+#define FRAME_STAMP(slot, wait)                                                                         \
+  if (p.trace && blockIdx.x == 0 && (tid == 0 || tid == 128) && j < 3 * 40) {                        \
+    if (wait) __builtin_amdgcn_s_waitcnt(0xC07F);                                                        \
+    s_trace[((tid == 128 ? 0 : 1) * 40 + j / 3) * 4 + slot] = clock64();                                   \
+  }
+#else
+#define FRAME_STAMP(slot, wait)
+#endif
 
 __device__ __forceinline__ void elem_global_k(double L, double c, double s, double EA, double EI, double k[6][6]) {
   const double a = EA / L, b12 = 12.0 * EI / (L * L * L), b6 = 6.0 * EI / (L * L), b4 = 4.0 * EI / L, b2 = 2.0 * EI / L;
@@ -48,94 +70,139 @@ __device__ __forceinline__ void elem_global_k(double L, double c, double s, doub
     for (int q = 0; q < 6; ++q) k[r][q] = v[r][q];
 }
 
-// FRAME_THREADS: 256 for narrow bands (more workgroups per CU, cheaper barriers: 1.5e7 5x5 frames/s vs 5.4e6 with
-// 1024), 1024 for wide ones (the trailing update of a column, up to 63 * 64 / 2 pairs, in one pass: 7.9e5 10x10
-// frames/s vs 6.6e5 with 256).
-template <int FRAME_THREADS>
-__global__ __launch_bounds__(FRAME_THREADS) void frame_solve_kernel(const FrameParams p) {
-  extern __shared__ double lds[];
-  const int n = p.n_eq, kd = p.kd, ld = kd + 1;
-  double* ab = lds;                  // [n][ld]
-  double* rhs = lds + (size_t)n * ld;  // [n]
-  __shared__ int s_bad;
-  const int tid = threadIdx.x;
-  const long b = blockIdx.x;
-  if (tid == 0) s_bad = 0;
-  for (int i = tid; i < n * ld + n; i += FRAME_THREADS) lds[i] = 0.0;
-  __syncthreads();
+constexpr int FRAME_PP = 4;   // window entries per thread, at most (kd <= 63: 2016 pairs <= 2 * 1024)
 
-  // ---- assembly: one thread per element, LDS atomics (elements sharing a node collide) ----
-  const double* Ib = p.I + b * p.Ne;
-  for (int e = tid; e < p.Ne; e += FRAME_THREADS) {
-    const double L = p.elem_geo[3 * e], c = p.elem_geo[3 * e + 1], s = p.elem_geo[3 * e + 2];
-    double k[6][6];
-    elem_global_k(L, c, s, p.elem_EA[e], p.elem_E[e] * Ib[e], k);
-    const double wy = p.elem_w[2 * e], wx = p.elem_w[2 * e + 1];
-    // consistent loads (ElasticBeam2d::addLoad beamUniform), local -> global
-    const double pl[6] = {wx * L / 2, wy * L / 2, wy * L * L / 12, wx * L / 2, wy * L / 2, -wy * L * L / 12};
-    const double pg[6] = {c * pl[0] - s * pl[1], s * pl[0] + c * pl[1], pl[2], c * pl[3] - s * pl[4], s * pl[3] + c * pl[4], pl[5]};
-    int eq[6];
-    for (int r = 0; r < 6; ++r) eq[r] = p.elem_eq[6 * e + r];
-    for (int r = 0; r < 6; ++r) {
-      if (eq[r] < 0) continue;
-      atomicAdd(&rhs[eq[r]], pg[r]);
-      for (int q = 0; q < 6; ++q) {
-        if (eq[q] < 0 || eq[q] > eq[r]) continue;          // lower triangle: row eq[r] >= column eq[q]
-        atomicAdd(&ab[(size_t)eq[q] * ld + (eq[r] - eq[q])], k[r][q]);
-      }
-    }
-  }
-  const double* lb = p.loads + b * p.loads_bs;
-  for (int i = tid; i < p.Nn * 3; i += FRAME_THREADS) {
-    const int q = p.node_eq[i];
-    if (q >= 0) atomicAdd(&rhs[q], lb[i]);
-  }
-  __syncthreads();
+__host__ __device__ inline int frame_ld(int kd) { return (kd + 2) & ~1; }
+__host__ __device__ inline int frame_n3(int n) { return (n + 2) / 3 * 3; }
 
-  // ---- band LDL^T, right-looking: column j holds d_j = ab[j][0] and the UNSCALED entries L_kj d_j ----
-  for (int j = 0; j < n; ++j) {
-    const double d = ab[(size_t)j * ld];
-    if (!(d > 0.0)) { if (tid == 0) s_bad = 1; }
-    const double rd = 1.0 / d;
-    const int kmax = (kd < n - 1 - j) ? kd : n - 1 - j;
-    // pairs (r, c), 1 <= r <= c <= kmax: A[j+c][j+r] -= A[j+r][j] A[j+c][j] / d
-    const int c = 1 + (tid & 63);
-    if (c <= kmax) {
-      const double lc = ab[(size_t)j * ld + c] * rd;
-      for (int r = 1 + (tid >> 6); r <= c; r += FRAME_THREADS / 64)
-        ab[(size_t)(j + r) * ld + (c - r)] -= ab[(size_t)j * ld + r] * lc;
+__device__ __forceinline__ double frcp(double d) {   // v_rcp_f64 + two Newton steps (full precision, normal range)
+  double r = __builtin_amdgcn_rcp(d);
+  double e = __builtin_fma(-d, r, 1.0);
+  r = __builtin_fma(r, e, r);
+  e = __builtin_fma(-d, r, 1.0);
+  return __builtin_fma(r, e, r);
+}
+
+struct Pivot3 {   // LDL^T of the 3 x 3 pivot block
+  double rd1, l21, l31, rd2, l32, rd3;
+  bool bad;
+};
+__device__ __forceinline__ Pivot3 pivot_factor(double p11, double p21, double p31, double p22, double p32, double p33) {
+  Pivot3 f;
+  f.rd1 = frcp(p11);
+  f.l21 = p21 * f.rd1;
+  f.l31 = p31 * f.rd1;
+  const double d2 = __builtin_fma(-f.l21, p21, p22);
+  f.rd2 = frcp(d2);
+  const double u32 = __builtin_fma(-f.l31, p21, p32);
+  f.l32 = u32 * f.rd2;
+  const double d3 = __builtin_fma(-f.l32, u32, __builtin_fma(-f.l31, p31, p33));
+  f.rd3 = frcp(d3);
+  f.bad = !(p11 > 0.0) || !(d2 > 0.0) || !(d3 > 0.0);
+  return f;
+}
+// w = P^-1 b
+__device__ __forceinline__ void pivot_solve(const Pivot3& f, double b1, double b2, double b3, double& w1, double& w2, double& w3) {
+  const double y2 = __builtin_fma(-f.l21, b1, b2);
+  const double y3 = __builtin_fma(-f.l32, y2, __builtin_fma(-f.l31, b1, b3));
+  w3 = y3 * f.rd3;
+  w2 = __builtin_fma(-f.l32, w3, y2 * f.rd2);
+  w1 = __builtin_fma(-f.l31, w3, __builtin_fma(-f.l21, w2, b1 * f.rd1));
+}
+
+__device__ __forceinline__ double readlane_f64(double v, int lane) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane), hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+  return __hiloint2double(hi, lo);
+}
+
+// Look-ahead of the factorisation, run by ONE wave while the others update the window: the next pivot block
+// P' = P_next - B_top P^-1 B_top^T (B_top: the first three window rows), one entry per lane 0..5, gathered with
+// readlane, factored, and written over P_next as (1/d1, l21, l31, 1/d2, l32, 1/d3) -- lane i owns slot i.
+// c0, c1, c2: the three columns of the current block, n0/n1/n2: the three columns of the next one.
+__device__ __forceinline__ bool lookahead_pivot(const Pivot3& f, const double* c0, const double* c1, const double* c2,
+                                                double* n0, double* n1, double* n2, int kd, int dl) {
+  const int er = dl == 0 ? 0 : (dl == 1 || dl == 3) ? 1 : 2, ec = dl < 3 ? 0 : dl < 5 ? 1 : 2;
+  const double a0 = (3 + er <= kd) ? c0[3 + er] : 0.0, a1 = (2 + er <= kd) ? c1[2 + er] : 0.0, a2 = c2[1 + er];
+  const double b0 = (3 + ec <= kd) ? c0[3 + ec] : 0.0, b1 = (2 + ec <= kd) ? c1[2 + ec] : 0.0, b2 = c2[1 + ec];
+  double w1, w2, w3;
+  pivot_solve(f, b0, b1, b2, w1, w2, w3);
+  double* slot = (ec == 0 ? n0 : ec == 1 ? n1 : n2) + (er - ec);
+  const double pn = __builtin_fma(-a0, w1, __builtin_fma(-a1, w2, __builtin_fma(-a2, w3, *slot)));
+  const Pivot3 fn = pivot_factor(readlane_f64(pn, 0), readlane_f64(pn, 1), readlane_f64(pn, 2), readlane_f64(pn, 3),
+                                 readlane_f64(pn, 4), readlane_f64(pn, 5));
+  if (dl < 6) *slot = dl == 0 ? fn.rd1 : dl == 1 ? fn.l21 : dl == 2 ? fn.l31 : dl == 3 ? fn.rd2 : dl == 4 ? fn.l32 : fn.rd3;
+  return fn.bad;
+}
+// the first block: nothing to subtract
+__device__ __forceinline__ bool first_pivot(double* n0, double* n1, double* n2, int dl) {
+  const Pivot3 fn = pivot_factor(n0[0], n0[1], n0[2], n1[0], n1[1], n2[0]);
+  __asm__ volatile("" ::: "memory");
+  double* slot = (dl < 3 ? n0 : dl < 5 ? n1 : n2) + (dl < 3 ? dl : dl < 5 ? dl - 3 : 0);
+  if (dl < 6) *slot = dl == 0 ? fn.rd1 : dl == 1 ? fn.l21 : dl == 2 ? fn.l31 : dl == 3 ? fn.rd2 : dl == 4 ? fn.l32 : fn.rd3;
+  return fn.bad;
+}
+__device__ __forceinline__ Pivot3 load_pivot(const double* c0, const double* c1, const double* c2) {
+  Pivot3 f;
+  f.rd1 = c0[0]; f.l21 = c0[1]; f.l31 = c0[2]; f.rd2 = c1[0]; f.l32 = c1[1]; f.rd3 = c2[0]; f.bad = false;
+  return f;
+}
+
+// wave-local LDS ordering (one wave's LDS operations execute in order; this pins the compiler and the counter)
+__device__ __forceinline__ void wave_lds_fence() {
+  __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0)
+  __asm__ volatile("" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+}
+
+// the window entries a thread owns: (r, c), 0 <= c <= r < kd, enumerated column-major so that a wave's targets and
+// panel reads are consecutive LDS words
+struct Pairs {
+  int r[FRAME_PP], c[FRAME_PP];
+  bool on[FRAME_PP];
+};
+__device__ __forceinline__ Pairs own_pairs(int tid, int T, int kd, int pp_use) {
+  Pairs q;
+#pragma unroll
+  for (int k = 0; k < FRAME_PP; ++k) {
+    int rem = tid + k * T, c = 0;
+    while (c < kd && rem >= kd - c) { rem -= kd - c; ++c; }
+    q.on[k] = tid >= 0 && (k < pp_use) && c < kd;
+    q.c[k] = c;
+    q.r[k] = c + rem;
+  }
+  return q;
+}
+
+// element stiffness + consistent loads of element e into a band `ab` / right-hand side `rhs` (LDS or HBM atomics)
+__device__ __forceinline__ void assemble_element(const FrameParams& p, const double* Ib, int e, double* ab, double* rhs, int ld) {
+  const double L = p.elem_geo[3 * e], c = p.elem_geo[3 * e + 1], s = p.elem_geo[3 * e + 2];
+  double k[6][6];
+  elem_global_k(L, c, s, p.elem_EA[e], p.elem_E[e] * Ib[e], k);
+  const double wy = p.elem_w[2 * e], wx = p.elem_w[2 * e + 1];
+  // consistent loads (ElasticBeam2d::addLoad beamUniform), local -> global
+  const double pl[6] = {wx * L / 2, wy * L / 2, wy * L * L / 12, wx * L / 2, wy * L / 2, -wy * L * L / 12};
+  const double pg[6] = {c * pl[0] - s * pl[1], s * pl[0] + c * pl[1], pl[2], c * pl[3] - s * pl[4], s * pl[3] + c * pl[4], pl[5]};
+  int eq[6];
+  for (int r = 0; r < 6; ++r) eq[r] = p.elem_eq[6 * e + r];
+  for (int r = 0; r < 6; ++r) {
+    if (eq[r] < 0) continue;
+    atomicAdd(&rhs[eq[r]], pg[r]);
+    for (int q = 0; q < 6; ++q) {
+      if (eq[q] < 0 || eq[q] > eq[r]) continue;          // lower triangle: row eq[r] >= column eq[q]
+      atomicAdd(&ab[(long)eq[q] * ld + (eq[r] - eq[q])], k[r][q]);
     }
-    __syncthreads();
   }
-  // ---- forward substitution (unit lower), diagonal scaling, backward substitution ----
-  for (int j = 0; j < n; ++j) {
-    const double yj = rhs[j], rd = 1.0 / ab[(size_t)j * ld];
-    const int kmax = (kd < n - 1 - j) ? kd : n - 1 - j;
-    const int k = 1 + tid;
-    if (k <= kmax) rhs[j + k] -= ab[(size_t)j * ld + k] * rd * yj;
-    __syncthreads();
-  }
-  for (int j = tid; j < n; j += FRAME_THREADS) rhs[j] /= ab[(size_t)j * ld];
-  __syncthreads();
-  for (int j = n - 1; j >= 0; --j) {   // x_j = z_j - sum_k (L_{j+k,j}) x_{j+k}: one wave reduces the <= kd terms
-    if (tid < 64) {
-      const int kmax = (kd < n - 1 - j) ? kd : n - 1 - j;
-      double acc = 0.0;
-      for (int k = 1 + tid; k <= kmax; k += 64) acc += ab[(size_t)j * ld + k] * rhs[j + k];
-      for (int sft = 32; sft >= 1; sft >>= 1) acc += __shfl_xor(acc, sft, 64);
-      if (tid == 0) rhs[j] -= acc / ab[(size_t)j * ld];
-    }
-    __syncthreads();
-  }
-  const bool bad = s_bad != 0;
+}
+
+// nodal displacements and global element end forces (ElasticBeam2d::getResistingForce through LinearCrdTransf2d)
+__device__ __forceinline__ void write_results(const FrameParams& p, long b, const double* rhs, bool bad, int tid, int T) {
   const double qnan = __builtin_nan("");
-  // ---- nodal displacements ----
-  for (int i = tid; i < p.Nn * 3; i += FRAME_THREADS) {
+  for (int i = tid; i < p.Nn * 3; i += T) {
     const int q = p.node_eq[i];
     p.disp[b * (long)p.Nn * 3 + i] = bad ? qnan : (q >= 0 ? rhs[q] : 0.0);
   }
-  // ---- element end forces (ElasticBeam2d::getResistingForce through LinearCrdTransf2d), global ----
-  for (int e = tid; e < p.Ne; e += FRAME_THREADS) {
+  const double* Ib = p.I + b * p.Ne;
+  for (int e = tid; e < p.Ne; e += T) {
     const double L = p.elem_geo[3 * e], c = p.elem_geo[3 * e + 1], s = p.elem_geo[3 * e + 2];
     const double EA = p.elem_EA[e], EI = p.elem_E[e] * Ib[e], wy = p.elem_w[2 * e], wx = p.elem_w[2 * e + 1];
     double ug[6];
@@ -153,160 +220,275 @@ __global__ __launch_bounds__(FRAME_THREADS) void frame_solve_kernel(const FrameP
     p.M[b * (long)p.Ne + e] = bad ? qnan : f[2];
   }
   if (tid == 0 && p.status) p.status[b] = bad ? 1 : 0;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// LDS-resident band.  blockDim.x = T: enough threads for one (or, for kd > 43, two) window entries each, plus the
+// forward-substitution wave.
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void frame_solve_kernel(const FrameParams p, int pp_use) {
+  extern __shared__ double lds[];
+  const int n = p.n_eq, kd = p.kd, ld = frame_ld(kd), n3 = frame_n3(n);
+  double* ab = lds;                     // [n3][ld]
+  double* rhs = lds + (size_t)n3 * ld;  // [n3]
+  __shared__ int s_bad;
+#ifdef OPS_AMD_FRAME_TRACE
+  __shared__ unsigned long long s_trace[2 * 40 * 4];
+#endif
+  const int tid = threadIdx.x, T = blockDim.x;
+  const long b = blockIdx.x;
+  if (tid == 0) s_bad = 0;
+  for (int i = tid; i < n3 * ld + n3; i += T) lds[i] = 0.0;
+  __syncthreads();
+  if (tid < n3 - n) ab[(size_t)(n + tid) * ld] = 1.0;       // padding equations: x = 0
+  const double* Ib = p.I + b * p.Ne;
+  for (int e = tid; e < p.Ne; e += T) assemble_element(p, Ib, e, ab, rhs, ld);
+  const double* lb = p.loads + b * p.loads_bs;
+  for (int i = tid; i < p.Nn * 3; i += T) {
+    const int q = p.node_eq[i];
+    if (q >= 0) atomicAdd(&rhs[q], lb[i]);
+  }
+  // wave 0 (the oldest, and raised: it is the serial chain of every step): look-ahead pivot; wave 1: forward
+  // substitution; waves 2..: the window entries
+  const Pairs own = own_pairs(tid - 128, T - 128, kd, pp_use);
+  const bool look = tid < 64;
+  const int fl = tid - 64;
+  if (__builtin_amdgcn_readfirstlane(tid) < 64) __builtin_amdgcn_s_setprio(3);
+  __syncthreads();
+  if (look && first_pivot(ab, ab + ld, ab + 2 * ld, tid) && tid == 0) s_bad = 1;
+  __syncthreads();
+
+  // ---- factorisation, three columns per barrier ----
+  for (int j = 0; j < n3; j += 3) {
+    double* c0 = ab + (size_t)j * ld;
+    double* c1 = c0 + ld;
+    double* c2 = c1 + ld;
+    FRAME_STAMP(0, false)
+    const Pivot3 f = load_pivot(c0, c1, c2);
+    FRAME_STAMP(1, true)
+    if (look) {
+      if (j + 3 < n3 && lookahead_pivot(f, c0, c1, c2, c2 + ld, c2 + 2 * ld, c2 + 3 * ld, kd, tid) && tid == 0) s_bad = 1;
+    } else if (fl < 64 && fl < kd && j + 3 + fl < n3) {     // f_X -= B_X P^-1 f_P
+      const double a0 = (3 + fl <= kd) ? c0[3 + fl] : 0.0, a1 = (2 + fl <= kd) ? c1[2 + fl] : 0.0, a2 = c2[1 + fl];
+      double w1, w2, w3;
+      pivot_solve(f, rhs[j], rhs[j + 1], rhs[j + 2], w1, w2, w3);
+      rhs[j + 3 + fl] = __builtin_fma(-a0, w1, __builtin_fma(-a1, w2, __builtin_fma(-a2, w3, rhs[j + 3 + fl])));
+    }
+#pragma unroll
+    for (int k = 0; k < FRAME_PP; ++k) {
+      const int r = own.r[k], c = own.c[k];
+      if (own.on[k] && r >= 3 && j + 3 + r < n3) {            // r < 3: the next pivot block, the look-ahead wave's
+        // panel rows R = j+3+r and C = j+3+c; column j+q holds them at offsets 3+r-q (outside the band: zero)
+        const double a0 = (3 + r <= kd) ? c0[3 + r] : 0.0, a1 = (2 + r <= kd) ? c1[2 + r] : 0.0, a2 = c2[1 + r];
+        const double b0 = (3 + c <= kd) ? c0[3 + c] : 0.0, b1 = (2 + c <= kd) ? c1[2 + c] : 0.0, b2 = c2[1 + c];
+        double w1, w2, w3;
+        pivot_solve(f, b0, b1, b2, w1, w2, w3);
+        double* t = ab + (size_t)(j + 3 + c) * ld + (r - c);
+        *t = __builtin_fma(-a0, w1, __builtin_fma(-a1, w2, __builtin_fma(-a2, w3, *t)));
+      }
+    }
+    FRAME_STAMP(2, true)
+    __syncthreads();
+    FRAME_STAMP(3, false)
+  }
+  if (__builtin_amdgcn_readfirstlane(tid) < 64) __builtin_amdgcn_s_setprio(0);
+  // ---- backward substitution: wave 0, no workgroup barriers ----
+  if (tid < 64) {
+    const int lane = tid;
+    for (int k = n3 - 3; k >= 0; k -= 3) {
+      const double* c0 = ab + (size_t)k * ld;
+      const Pivot3 f = load_pivot(c0, c0 + ld, c0 + 2 * ld);
+      const double z1 = rhs[k], z2 = rhs[k + 1], z3 = rhs[k + 2];
+      const int e = k - 1 - lane;        // earlier equation; rows k, k+1, k+2 sit at offsets 1+lane, 2+lane, 3+lane
+      const bool on = lane < kd && e >= 0;
+      const double* ce = ab + (size_t)(on ? e : 0) * ld;
+      const double a0 = on ? ce[1 + lane] : 0.0, a1 = (on && 2 + lane <= kd) ? ce[2 + lane] : 0.0,
+                   a2 = (on && 3 + lane <= kd) ? ce[3 + lane] : 0.0, re = rhs[on ? e : 0];
+      double x1, x2, x3;
+      pivot_solve(f, z1, z2, z3, x1, x2, x3);
+      if (on) rhs[e] = __builtin_fma(-a0, x1, __builtin_fma(-a1, x2, __builtin_fma(-a2, x3, re)));
+      if (lane == 0) { rhs[k] = x1; rhs[k + 1] = x2; rhs[k + 2] = x3; }
+      wave_lds_fence();
+    }
+  }
+  __syncthreads();
+#ifdef OPS_AMD_FRAME_TRACE
+  if (p.trace && blockIdx.x == 0) for (int i = tid; i < 2 * 40 * 4; i += T) p.trace[i] = s_trace[i];
+#endif
+  write_results(p, b, rhs, s_bad != 0, tid, T);
 }
 
 // ------------------------------------------------------------------------------------------------------
 // Frames whose band does not fit LDS (BASELINE config 5: ~500 elements): the assembled band lives in a
-// caller-provided HBM workspace (ws[b] = band n_eq x (kd+1) followed by the right-hand side n_eq) and the
-// factorisation slides a (kd+2)-column window through LDS: the right-looking update of column j only touches
-// columns j+1 .. j+kd.  Column j leaves the window as a finished L column (written back over the assembled
-// one), column j+kd+1 is prefetched into the slot column j-1 vacated one step earlier, so there is still ONE
-// barrier per column.  Forward substitution rides along; backward substitution streams the L columns back in
-// blocks.
+// caller-provided HBM workspace (ws[b] = band n3 x ld followed by the right-hand side n3) and the factorisation
+// slides a (kd+6)-column ring through LDS: block step j touches columns j .. j+2+kd.  The three finished columns
+// (panel unscaled, factored pivot in the place of P) go back to HBM during their own step, the next three come
+// into the slots the previous block vacated, so there is still one barrier per block.  Forward substitution rides
+// along; backward substitution streams the columns back in chunks (waves 1.. prefetch, wave 0 substitutes in
+// dot-product form: a block's own three columns hold everything it needs).
 // ------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void frame_assemble_kernel(const FrameParams p, double* __restrict__ ws) {
   const long b = blockIdx.y;
-  const int ld = p.kd + 1;
-  double* ab = ws + b * ((long)p.n_eq * ld + p.n_eq);
-  double* rhs = ab + (long)p.n_eq * ld;
+  const int ld = frame_ld(p.kd), n3 = frame_n3(p.n_eq);
+  double* ab = ws + b * ((long)n3 * ld + n3);
+  double* rhs = ab + (long)n3 * ld;
   const int t = blockIdx.x * 256 + threadIdx.x;
-  const double* Ib = p.I + b * p.Ne;
-  if (t < p.Ne) {
-    const int e = t;
-    const double L = p.elem_geo[3 * e], c = p.elem_geo[3 * e + 1], s = p.elem_geo[3 * e + 2];
-    double k[6][6];
-    elem_global_k(L, c, s, p.elem_EA[e], p.elem_E[e] * Ib[e], k);
-    const double wy = p.elem_w[2 * e], wx = p.elem_w[2 * e + 1];
-    const double pl[6] = {wx * L / 2, wy * L / 2, wy * L * L / 12, wx * L / 2, wy * L / 2, -wy * L * L / 12};
-    const double pg[6] = {c * pl[0] - s * pl[1], s * pl[0] + c * pl[1], pl[2], c * pl[3] - s * pl[4], s * pl[3] + c * pl[4], pl[5]};
-    int eq[6];
-    for (int r = 0; r < 6; ++r) eq[r] = p.elem_eq[6 * e + r];
-    for (int r = 0; r < 6; ++r) {
-      if (eq[r] < 0) continue;
-      atomicAdd(&rhs[eq[r]], pg[r]);
-      for (int q = 0; q < 6; ++q) {
-        if (eq[q] < 0 || eq[q] > eq[r]) continue;
-        atomicAdd(&ab[(long)eq[q] * ld + (eq[r] - eq[q])], k[r][q]);
-      }
-    }
-  }
+  if (t < p.Ne) assemble_element(p, p.I + b * p.Ne, t, ab, rhs, ld);
   if (t < p.Nn * 3) {
     const int q = p.node_eq[t];
     if (q >= 0) atomicAdd(&rhs[q], (p.loads + b * p.loads_bs)[t]);
   }
+  if (t < n3 - p.n_eq) ab[(long)(p.n_eq + t) * ld] = 1.0;
 }
 
-__global__ __launch_bounds__(1024) void frame_factor_big_kernel(const FrameParams p, double* __restrict__ ws) {
+constexpr int FRAME_CH = 24;   // columns per chunk of the backward sweep (8 blocks)
+
+__global__ __launch_bounds__(1024) void frame_factor_big_kernel(const FrameParams p, double* __restrict__ ws, int pp_use) {
   extern __shared__ double lds[];
-  const int n = p.n_eq, kd = p.kd, ld = kd + 1, W = kd + 2;
+  const int n = p.n_eq, kd = p.kd, ld = frame_ld(kd), n3 = frame_n3(n), W = kd + 6;
   double* win = lds;                       // [W][ld]   ring of columns, slot = column % W
-  double* rhs = win + (size_t)W * ld;      // [n]
-  double* dinv = rhs + n;                  // [n]       1 / d_j
-  double* blk = dinv + n;                  // [2][BLK][ld] column blocks of the backward sweep
-  constexpr int BLK = 16;
+  double* rhs = win + (size_t)W * ld;      // [n3]
+  double* blk = rhs + n3;                  // [2][FRAME_CH][ld] column chunks of the backward sweep
   __shared__ int s_bad;
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, T = blockDim.x;
   const long b = blockIdx.x;
-  double* ab = ws + b * ((long)n * ld + n);
-  const double* rhs_g = ab + (long)n * ld;
+  double* ab = ws + b * ((long)n3 * ld + n3);
+  const double* rhs_g = ab + (long)n3 * ld;
   if (tid == 0) s_bad = 0;
-  for (int i = tid; i < n; i += 1024) rhs[i] = rhs_g[i];
-  for (int i = tid; i < (kd + 1) * ld && i < n * ld; i += 1024) win[i] = ab[i];   // columns 0..kd: slot = column
+  for (int i = tid; i < n3; i += T) rhs[i] = rhs_g[i];
+  for (int i = tid; i < (kd + 3) * ld && i < n3 * ld; i += T) win[i] = ab[i];   // columns 0 .. kd+2: slot = column
+  const Pairs own = own_pairs(tid - 128, T - 128, kd, pp_use);
+  const bool look = tid < 64;
+  const int fl = tid - 64;
+  if (__builtin_amdgcn_readfirstlane(tid) < 64) __builtin_amdgcn_s_setprio(3);
   __syncthreads();
-  for (int j = 0; j < n; ++j) {
-    const double* colj = win + (size_t)(j % W) * ld;
-    const double d = colj[0];
-    if (!(d > 0.0)) { if (tid == 0) s_bad = 1; }
-    const double rd = 1.0 / d;
-    const int kmax = (kd < n - 1 - j) ? kd : n - 1 - j;
-    // finished column j back to HBM; column j+kd+1 into the slot column j-1 left (not touched in this step)
+  if (look && first_pivot(win, win + ld, win + 2 * ld, tid) && tid == 0) s_bad = 1;
+  __syncthreads();
+  for (int j = 0; j < n3; j += 3) {
+    double* c0 = win + (size_t)(j % W) * ld;
+    double* c1 = win + (size_t)((j + 1) % W) * ld;
+    double* c2 = win + (size_t)((j + 2) % W) * ld;
+    const Pivot3 f = load_pivot(c0, c1, c2);
+    // finished columns j..j+2 (panel unscaled, pivot factored) back to HBM; columns j+kd+3.. into the slots block j-3 left
     double pre = 0.0;
-    const int cin = j + kd + 1;
-    if (tid < ld) {
-      ab[(long)j * ld + tid] = colj[tid];
-      if (cin < n) pre = ab[(long)cin * ld + tid];
+    int cin = 0;
+    const bool mover = tid >= 128 && tid < 128 + 3 * ld;
+    if (mover) {
+      const int q = (tid - 128) / ld, t = (tid - 128) % ld;
+      ab[(long)(j + q) * ld + t] = win[(size_t)((j + q) % W) * ld + t];
+      cin = j + kd + 3 + q;
+      if (cin < n3) pre = ab[(long)cin * ld + t];
     }
-    if (tid == 0) dinv[j] = rd;
-    // forward substitution rides along (unit lower factor): threads 64.. so that the update pairs keep wave 0..
-    if (tid >= 1024 - 64) {
-      const int k = 1 + (tid - (1024 - 64));
-      if (k <= kmax) rhs[j + k] -= colj[k] * rd * rhs[j];
+    if (look) {
+      if (j + 3 < n3 && lookahead_pivot(f, c0, c1, c2, win + (size_t)((j + 3) % W) * ld, win + (size_t)((j + 4) % W) * ld,
+                                        win + (size_t)((j + 5) % W) * ld, kd, tid) && tid == 0) s_bad = 1;
+    } else if (fl < 64 && fl < kd && j + 3 + fl < n3) {
+      const double a0 = (3 + fl <= kd) ? c0[3 + fl] : 0.0, a1 = (2 + fl <= kd) ? c1[2 + fl] : 0.0, a2 = c2[1 + fl];
+      double w1, w2, w3;
+      pivot_solve(f, rhs[j], rhs[j + 1], rhs[j + 2], w1, w2, w3);
+      rhs[j + 3 + fl] = __builtin_fma(-a0, w1, __builtin_fma(-a1, w2, __builtin_fma(-a2, w3, rhs[j + 3 + fl])));
     }
-    const int c = 1 + (tid & 63);
-    if (c <= kmax) {
-      const double lc = colj[c] * rd;
-      for (int r = 1 + (tid >> 6); r <= c; r += 16)
-        win[(size_t)((j + r) % W) * ld + (c - r)] -= colj[r] * lc;
+#pragma unroll
+    for (int k = 0; k < FRAME_PP; ++k) {
+      const int r = own.r[k], c = own.c[k];
+      if (own.on[k] && r >= 3 && j + 3 + r < n3) {
+        const double a0 = (3 + r <= kd) ? c0[3 + r] : 0.0, a1 = (2 + r <= kd) ? c1[2 + r] : 0.0, a2 = c2[1 + r];
+        const double b0 = (3 + c <= kd) ? c0[3 + c] : 0.0, b1 = (2 + c <= kd) ? c1[2 + c] : 0.0, b2 = c2[1 + c];
+        double w1, w2, w3;
+        pivot_solve(f, b0, b1, b2, w1, w2, w3);
+        double* t = win + (size_t)((j + 3 + c) % W) * ld + (r - c);
+        *t = __builtin_fma(-a0, w1, __builtin_fma(-a1, w2, __builtin_fma(-a2, w3, *t)));
+      }
     }
-    if (tid < ld && cin < n) win[(size_t)(cin % W) * ld + tid] = pre;
+    if (mover && cin < n3) win[(size_t)(cin % W) * ld + (tid - 128) % ld] = pre;
     __syncthreads();
   }
-  for (int i = tid; i < n; i += 1024) rhs[i] *= dinv[i];
-  __syncthreads();
-  // backward substitution: L columns stream back in blocks of BLK (waves 1.. prefetch, wave 0 substitutes)
-  const int nblk = (n + BLK - 1) / BLK;
-  for (int i = tid; i < BLK * ld; i += 1024) {      // last block first
-    const int col = (nblk - 1) * BLK + i / ld;
-    blk[i] = col < n ? ab[(long)col * ld + i % ld] : 0.0;
+  if (__builtin_amdgcn_readfirstlane(tid) < 64) __builtin_amdgcn_s_setprio(0);
+  // backward substitution, chunks of FRAME_CH columns, last chunk first
+  const int nch = (n3 + FRAME_CH - 1) / FRAME_CH;
+  for (int i = tid; i < FRAME_CH * ld; i += T) {
+    const int col = (nch - 1) * FRAME_CH + i / ld;
+    blk[i] = col < n3 ? ab[(long)col * ld + i % ld] : 0.0;
   }
   __syncthreads();
-  for (int kb = nblk - 1; kb >= 0; --kb) {
-    double* cur = blk + (size_t)((nblk - 1 - kb) & 1) * BLK * ld;
-    double* nxt = blk + (size_t)((nblk - kb) & 1) * BLK * ld;
+  for (int kb = nch - 1; kb >= 0; --kb) {
+    const double* cur = blk + (size_t)((nch - 1 - kb) & 1) * FRAME_CH * ld;
+    double* nxt = blk + (size_t)((nch - kb) & 1) * FRAME_CH * ld;
     if (tid >= 64 && kb > 0) {
-      for (int i = tid - 64; i < BLK * ld; i += 1024 - 64) nxt[i] = ab[(long)((kb - 1) * BLK + i / ld) * ld + i % ld];
+      for (int i = tid - 64; i < FRAME_CH * ld; i += T - 64) nxt[i] = ab[(long)((kb - 1) * FRAME_CH + i / ld) * ld + i % ld];
     }
     if (tid < 64) {
-      for (int jj = BLK - 1; jj >= 0; --jj) {
-        const int j = kb * BLK + jj;
-        if (j >= n) continue;
-        const int kmax = (kd < n - 1 - j) ? kd : n - 1 - j;
-        double acc = 0.0;
-        for (int k = 1 + tid; k <= kmax; k += 64) acc += cur[jj * ld + k] * rhs[j + k];
-        for (int sft = 32; sft >= 1; sft >>= 1) acc += __shfl_xor(acc, sft, 64);
-        if (tid == 0) rhs[j] -= acc * dinv[j];
-        __builtin_amdgcn_s_waitcnt(0xC07F);
-        __asm__ volatile("" ::: "memory");
-        __builtin_amdgcn_wave_barrier();
+      const int lane = tid;
+      for (int jj = FRAME_CH - 3; jj >= 0; jj -= 3) {
+        const int k = kb * FRAME_CH + jj;
+        if (k >= n3) continue;
+        const double* c0 = cur + (size_t)jj * ld;
+        const double* c1 = c0 + ld;
+        const double* c2 = c1 + ld;
+        // z_q = y_q - sum_X A[X][k+q] x_X over the window rows X = k+3+lane
+        const int X = k + 3 + lane;
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+        if (lane < kd && X < n3) {
+          const double xX = rhs[X];
+          s0 = (3 + lane <= kd) ? c0[3 + lane] * xX : 0.0;
+          s1 = (2 + lane <= kd) ? c1[2 + lane] * xX : 0.0;
+          s2 = c2[1 + lane] * xX;
+        }
+        for (int sft = 32; sft >= 1; sft >>= 1) {
+          s0 += __shfl_xor(s0, sft, 64);
+          s1 += __shfl_xor(s1, sft, 64);
+          s2 += __shfl_xor(s2, sft, 64);
+        }
+        const Pivot3 f = load_pivot(c0, c1, c2);
+        double x1, x2, x3;
+        pivot_solve(f, rhs[k] - s0, rhs[k + 1] - s1, rhs[k + 2] - s2, x1, x2, x3);
+        wave_lds_fence();
+        if (lane == 0) { rhs[k] = x1; rhs[k + 1] = x2; rhs[k + 2] = x3; }
+        wave_lds_fence();
       }
     }
     __syncthreads();
   }
-  const bool bad = s_bad != 0;
-  const double qnan = __builtin_nan("");
-  for (int i = tid; i < p.Nn * 3; i += 1024) {
-    const int q = p.node_eq[i];
-    p.disp[b * (long)p.Nn * 3 + i] = bad ? qnan : (q >= 0 ? rhs[q] : 0.0);
-  }
-  const double* Ib = p.I + b * p.Ne;
-  for (int e = tid; e < p.Ne; e += 1024) {
-    const double L = p.elem_geo[3 * e], c = p.elem_geo[3 * e + 1], s = p.elem_geo[3 * e + 2];
-    const double EA = p.elem_EA[e], EI = p.elem_E[e] * Ib[e], wy = p.elem_w[2 * e], wx = p.elem_w[2 * e + 1];
-    double ug[6];
-    for (int r = 0; r < 6; ++r) { const int q = p.elem_eq[6 * e + r]; ug[r] = q >= 0 ? rhs[q] : 0.0; }
-    const double ul[6] = {c * ug[0] + s * ug[1], -s * ug[0] + c * ug[1], ug[2], c * ug[3] + s * ug[4], -s * ug[3] + c * ug[4], ug[5]};
-    const double chord = (ul[4] - ul[1]) / L;
-    const double q0 = EA / L * (ul[3] - ul[0]) - wx * L / 2;
-    const double q1 = 4 * EI / L * (ul[2] - chord) + 2 * EI / L * (ul[5] - chord) - wy * L * L / 12;
-    const double q2 = 2 * EI / L * (ul[2] - chord) + 4 * EI / L * (ul[5] - chord) + wy * L * L / 12;
-    const double pl[6] = {-q0 - wx * L, (q1 + q2) / L - wy * L / 2, q1, q0, -(q1 + q2) / L - wy * L / 2, q2};
-    const double f[6] = {c * pl[0] - s * pl[1], s * pl[0] + c * pl[1], pl[2], c * pl[3] - s * pl[4], s * pl[3] + c * pl[4], pl[5]};
-    double* fo = p.forces + (b * (long)p.Ne + e) * 6;
-    for (int r = 0; r < 6; ++r) fo[r] = bad ? qnan : f[r];
-    p.V[b * (long)p.Ne + e] = bad ? qnan : f[1];
-    p.M[b * (long)p.Ne + e] = bad ? qnan : f[2];
-  }
-  if (tid == 0 && p.status) p.status[b] = bad ? 1 : 0;
+  write_results(p, b, rhs, s_bad != 0, tid, T);
 }
 
 }  // namespace opsamd
 
 using namespace opsamd;
 
+#ifdef OPS_AMD_FRAME_TRACE
+static const size_t LDS_MAX = 160 * 1024 - 64 - 4096;   // room for the stamp buffer
+#else
+static const size_t LDS_MAX = 160 * 1024 - 64;
+#endif
+
+static size_t frame_lds_resident_bytes(int n_eq, int kd) {
+  return ((size_t)frame_n3(n_eq) * frame_ld(kd) + frame_n3(n_eq)) * sizeof(double);
+}
+
+// workgroup size and window entries per thread: two service waves (look-ahead, forward substitution) + the entry owners
+static void frame_threads(int kd, int* T, int* pp_use) {
+  const int npairs = kd * (kd + 1) / 2;
+  auto threads = [&](int pp) { return ((npairs + pp - 1) / pp + 63) / 64 * 64 + 128; };
+  int pp = 2;                                   // two entries per thread: fewer waves per barrier, more workgroups per CU
+  while (threads(pp) > 1024 && pp < FRAME_PP) ++pp;
+  // tuning knob for experiments: OPS_AMD_FRAME_PP = entries per thread
+  if (const char* e = getenv("OPS_AMD_FRAME_PP")) {
+    const int v = atoi(e);
+    if (v >= 1 && v <= FRAME_PP && threads(v) <= 1024) pp = v;
+  }
+  *pp_use = pp;
+  *T = threads(pp) < 192 ? 192 : threads(pp);
+}
+
+static int eff_kd(int half_bandwidth) { return half_bandwidth < 3 ? 3 : half_bandwidth; }   // a block step's band covers its own pivot
+
+static bool force_ws() { const char* e = getenv("OPS_AMD_FRAME_FORCE_WS"); return e && atoi(e) != 0; }
+
 extern "C" size_t ops_frame_workspace_bytes(int B, int n_eq, int half_bandwidth) {
-  const size_t lds_bytes = ((size_t)n_eq * (half_bandwidth + 1) + n_eq) * sizeof(double);
-  if (lds_bytes <= 160 * 1024 - 64) return 0;   // the band lives in LDS
-  return (size_t)B * ((size_t)n_eq * (half_bandwidth + 1) + n_eq) * sizeof(double);
+  half_bandwidth = eff_kd(half_bandwidth);
+  if (frame_lds_resident_bytes(n_eq, half_bandwidth) <= LDS_MAX && !force_ws()) return 0;   // the band lives in LDS
+  return (size_t)B * frame_lds_resident_bytes(n_eq, half_bandwidth);
 }
 
 extern "C" int ops_frame_solve_batched_f64(int B, int n_nodes, int n_elems, int n_eq, int half_bandwidth,
@@ -319,35 +501,38 @@ extern "C" int ops_frame_solve_batched_f64(int B, int n_nodes, int n_elems, int 
   if (B == 0) return OPS_AMD_OK;
   if (!elem_geo || !elem_EA || !elem_E || !elem_w || !elem_eq || !node_eq || !I || !loads || !disp || !forces || !V || !M)
     return OPS_AMD_ERR_INVALID_ARG;
-  if (half_bandwidth > 63) return OPS_AMD_ERR_UNSUPPORTED;    // one 64-lane row of update columns
-  const size_t lds_bytes = ((size_t)n_eq * (half_bandwidth + 1) + n_eq) * sizeof(double);
+  if (half_bandwidth > 63) return OPS_AMD_ERR_UNSUPPORTED;    // the window rows of a block step are one 64-lane wave
+  const int kd = eff_kd(half_bandwidth);
+  const size_t lds_bytes = frame_lds_resident_bytes(n_eq, kd);
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)frame_solve_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64) != hipSuccess ||
-        hipFuncSetAttribute((const void*)frame_solve_kernel<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64) != hipSuccess ||
-        hipFuncSetAttribute((const void*)frame_factor_big_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64) != hipSuccess)
+    if (hipFuncSetAttribute((const void*)frame_solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX) != hipSuccess ||
+        hipFuncSetAttribute((const void*)frame_factor_big_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX) != hipSuccess)
       return OPS_AMD_ERR_LAUNCH;
     attr_set = true;
   }
-  const FrameParams p{B, n_nodes, n_elems, n_eq, half_bandwidth, elem_geo, elem_EA, elem_E, elem_w, elem_eq, node_eq,
-                      I, loads, loads_bstride, disp, forces, V, M, status};
-  if (lds_bytes > 160 * 1024 - 64) {
-    // band in the HBM workspace, sliding LDS window
-    const int ld = half_bandwidth + 1;
-    const size_t need = ops_frame_workspace_bytes(B, n_eq, half_bandwidth);
-    const size_t lds2 = ((size_t)(half_bandwidth + 2) * ld + 2 * (size_t)n_eq + 2 * 16 * (size_t)ld) * sizeof(double);
-    if (lds2 > 160 * 1024 - 64) return OPS_AMD_ERR_UNSUPPORTED;
+  FrameParams p{B, n_nodes, n_elems, n_eq, kd, elem_geo, elem_EA, elem_E, elem_w, elem_eq, node_eq,
+                I, loads, loads_bstride, disp, forces, V, M, status, nullptr};
+#ifdef OPS_AMD_FRAME_TRACE
+  if (const char* e = getenv("OPS_AMD_FRAME_TRACE_PTR")) p.trace = (unsigned long long*)strtoull(e, nullptr, 10);
+#endif
+  int T, pp_use;
+  frame_threads(kd, &T, &pp_use);
+  hipStream_t s = (hipStream_t)stream;
+  if (lds_bytes > LDS_MAX || force_ws()) {
+    // band in the HBM workspace, sliding LDS ring
+    const int ld = frame_ld(kd), n3 = frame_n3(n_eq);
+    const size_t need = (size_t)B * lds_bytes;
+    const size_t lds2 = ((size_t)(kd + 6) * ld + (size_t)n3 + 2 * (size_t)FRAME_CH * ld) * sizeof(double);
+    if (lds2 > LDS_MAX) return OPS_AMD_ERR_UNSUPPORTED;
     if (!workspace || workspace_bytes < need) return OPS_AMD_ERR_INVALID_ARG;
-    hipStream_t s = (hipStream_t)stream;
     if (hipMemsetAsync(workspace, 0, need, s) != hipSuccess) return OPS_AMD_ERR_LAUNCH;
     const int work = n_elems > n_nodes * 3 ? n_elems : n_nodes * 3;
+    if (T < 128 + 3 * ld) T = (128 + 3 * ld + 63) / 64 * 64;   // the column movers sit behind the two service waves
     hipLaunchKernelGGL(frame_assemble_kernel, dim3((unsigned)((work + 255) / 256), (unsigned)B), dim3(256), 0, s, p, (double*)workspace);
-    hipLaunchKernelGGL(frame_factor_big_kernel, dim3((unsigned)B), dim3(1024), lds2, s, p, (double*)workspace);
+    hipLaunchKernelGGL(frame_factor_big_kernel, dim3((unsigned)B), dim3((unsigned)T), lds2, s, p, (double*)workspace, pp_use);
     return hipGetLastError() == hipSuccess ? OPS_AMD_OK : OPS_AMD_ERR_LAUNCH;
   }
-  if (half_bandwidth > 24)
-    hipLaunchKernelGGL(frame_solve_kernel<1024>, dim3((unsigned)B), dim3(1024), lds_bytes, (hipStream_t)stream, p);
-  else
-    hipLaunchKernelGGL(frame_solve_kernel<256>, dim3((unsigned)B), dim3(256), lds_bytes, (hipStream_t)stream, p);
+  hipLaunchKernelGGL(frame_solve_kernel, dim3((unsigned)B), dim3((unsigned)T), lds_bytes, s, p, pp_use);
   return hipGetLastError() == hipSuccess ? OPS_AMD_OK : OPS_AMD_ERR_LAUNCH;
 }

@@ -70,14 +70,15 @@ class FrameTopology:
         self.A, self.E, self.wy, self.wx = Av.copy(), Ev.copy(), w[:, 0].copy(), w[:, 1].copy()
         self.nodal_loads = np.asarray(nodal_loads, dtype=np.float64).reshape(self.Nn, 3)
         dev = torch.device(device)
-        t = lambda a, dt: torch.as_tensor(np.ascontiguousarray(a), dtype=dt, device=dev)  # noqa: E731
+        t = lambda a, dt: torch.as_tensor(np.array(a), dtype=dt, device=dev)  # noqa: E731
         self.device = dev
         self.d_geo, self.d_EA, self.d_E, self.d_w = t(geo, torch.float64), t(Ev * Av, torch.float64), t(Ev, torch.float64), t(w, torch.float64)
         self.d_elem_eq, self.d_node_eq = t(elem_eq, torch.int32), t(node_eq, torch.int32)
         self.d_loads = t(self.nodal_loads, torch.float64)
 
     def lds_bytes(self) -> int:
-        return (self.n_eq * (self.kd + 1) + self.n_eq) * 8
+        n3, ld = (self.n_eq + 2) // 3 * 3, (max(self.kd, 3) + 2) & ~1     # csrc/frame_solve.hip: frame_n3, frame_ld
+        return (n3 * ld + n3) * 8
 
 
 def grid_frame(num_bays: int, num_stories: int, cfg: Optional[FrameConfig] = None, device="cuda") -> FrameTopology:
