@@ -19,6 +19,7 @@ from __future__ import annotations
 
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -148,12 +149,65 @@ def surrogate_epoch_times(dev, rank, world, epochs, cases=50000):
         return {"error": repr(e)}
 
 
+def bench_frames(args, rank, local_rank, world, dev):
+    """BASELINE config 5 (not the default workload): B frames of 15 x 16 bays x stories (496 elements, 768 equations,
+    half bandwidth 50) per GPU per step, independent shards, no collective."""
+    import torch.distributed as dist
+    from openpystruct_amd import frames
+
+    bays, stories = (int(v) for v in args.frame.split("x"))
+    topo = frames.grid_frame(bays, stories, device=dev)
+    B, K, W = args.batch if args.batch != 10000 else 1024, args.steps, args.warmup
+    g = torch.Generator(device=dev).manual_seed(20250307 + rank)
+    I = torch.exp(torch.empty((B, topo.Ne), dtype=torch.float64, device=dev).uniform_(math.log(1e-4), math.log(5e-3), generator=g))
+    sol = frames.frame_solve(topo, I)
+    for _ in range(W):
+        frames.frame_solve(topo, I, out=sol)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier(device_ids=[local_rank]) if dist.get_backend() == "nccl" else dist.barrier()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(K):
+        frames.frame_solve(topo, I, out=sol)
+    e1.record()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier(device_ids=[local_rank]) if dist.get_backend() == "nccl" else dist.barrier()
+    wall = time.perf_counter() - t0
+    dev_ms = e0.elapsed_time(e1)
+    assert int(sol.status.abs().sum()) == 0
+    if world > 1:
+        tt = torch.tensor([wall, dev_ms], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        wall, dev_ms = float(tt[0]), float(tt[1])
+    if rank == 0:
+        bytes_per = 8 * (topo.Ne + 3 * topo.Nn + 8 * topo.Ne)      # I in; disp, forces, V, M out
+        achieved = bytes_per * B / (dev_ms / K * 1e-3) / 1e9
+        print(json.dumps({
+            "metric": f"frame FE solves/s ({topo.Ne}-elem, batched)", "value": world * B * K / wall, "unit": "frame FE solves/s",
+            "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": wall * 1e3 / K, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"BASELINE config 5: {B} frames of {bays}x{stories} bays x stories ({topo.Ne} elements, {topo.n_eq} "
+                                   f"equations, half bandwidth {topo.kd}) per GPU per step", "frames_per_step_per_gpu": B,
+                       "band_bytes_per_frame": topo.lds_bytes(), "parallelism": f"independent shards x{world}, no data-path collective"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None, "note": "latency-bound band factorisation (DESIGN.md section 8 f1), not an HBM-bound kernel"},
+        }), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=500)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=10000, help="beams per step per GPU (BASELINE config 2: 10000)")
+    ap.add_argument("--workload", default="beams", choices=["beams", "frames"],
+                    help="beams = BASELINE config 2 (the headline metric); frames = config 5 (batched 2-D frame solve)")
+    ap.add_argument("--frame", default="15x16", help="bays x stories of the frames workload")
     ap.add_argument("--tiling", type=int, default=0, help="lanes per beam (0 = library default)")
     ap.add_argument("--inertia", default="trajectory", choices=["uniform", "trajectory", "adversarial"])
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a HIP graph")
@@ -185,6 +239,8 @@ def main():
 
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    if args.workload == "frames":
+        return bench_frames(args, rank, local_rank, world, dev)
     B, K, W = args.batch, args.steps, args.warmup
     inp = synth_inputs(B, rank, dev, args.inertia)
     out = oa.beam_solve(**inp, tiling=args.tiling)     # allocates result buffers once
