@@ -327,21 +327,64 @@ __global__ __launch_bounds__(1024) void frame_solve_kernel(const FrameParams p, 
 // along; backward substitution streams the columns back in chunks (waves 1.. prefetch, wave 0 substitutes in
 // dot-product form: a block's own three columns hold everything it needs).
 // ------------------------------------------------------------------------------------------------------
+// Assembly for the workspace path: one workgroup per frame builds the band slab by slab (FRAME_SLAB columns at a time)
+// in LDS with ds_add_f64 and streams each finished slab to HBM with plain coalesced stores -- no global atomics and no
+// memset of the workspace (first version: 0.52 ms of a 1.8 ms launch for 1024 frames of 15 x 16).
+constexpr int FRAME_SLAB = 128;
+
 __global__ __launch_bounds__(256) void frame_assemble_kernel(const FrameParams p, double* __restrict__ ws) {
-  const long b = blockIdx.y;
-  const int ld = frame_ld(p.kd), n3 = frame_n3(p.n_eq);
+  extern __shared__ double lds[];
+  const long b = blockIdx.x;
+  const int ld = frame_ld(p.kd), n3 = frame_n3(p.n_eq), tid = threadIdx.x;
+  double* slab = lds;                          // [FRAME_SLAB][ld]
+  double* rhs = lds + (size_t)FRAME_SLAB * ld;   // [n3]
   double* ab = ws + b * ((long)n3 * ld + n3);
-  double* rhs = ab + (long)n3 * ld;
-  const int t = blockIdx.x * 256 + threadIdx.x;
-  if (t < p.Ne) assemble_element(p, p.I + b * p.Ne, t, ab, rhs, ld);
-  if (t < p.Nn * 3) {
-    const int q = p.node_eq[t];
-    if (q >= 0) atomicAdd(&rhs[q], (p.loads + b * p.loads_bs)[t]);
+  const double* Ib = p.I + b * p.Ne;
+  for (int i = tid; i < n3; i += 256) rhs[i] = 0.0;
+  for (int c0 = 0; c0 < n3; c0 += FRAME_SLAB) {
+    const int nc = (n3 - c0 < FRAME_SLAB) ? n3 - c0 : FRAME_SLAB;
+    for (int i = tid; i < nc * ld; i += 256) slab[i] = 0.0;
+    __syncthreads();
+    if (tid < nc && c0 + tid >= p.n_eq) slab[(size_t)tid * ld] = 1.0;     // padding equations
+    for (int e = tid; e < p.Ne; e += 256) {
+      int eq[6], lo = 1 << 30, hi = -1;
+      for (int r = 0; r < 6; ++r) {
+        eq[r] = p.elem_eq[6 * e + r];
+        if (eq[r] >= 0) { lo = eq[r] < lo ? eq[r] : lo; hi = eq[r] > hi ? eq[r] : hi; }
+      }
+      if (hi < c0 || lo >= c0 + nc) continue;                              // no column of this element in the slab
+      const double L = p.elem_geo[3 * e], c = p.elem_geo[3 * e + 1], s = p.elem_geo[3 * e + 2];
+      double k[6][6];
+      elem_global_k(L, c, s, p.elem_EA[e], p.elem_E[e] * Ib[e], k);
+      const double wy = p.elem_w[2 * e], wx = p.elem_w[2 * e + 1];
+      const double pl[6] = {wx * L / 2, wy * L / 2, wy * L * L / 12, wx * L / 2, wy * L / 2, -wy * L * L / 12};
+      const double pg[6] = {c * pl[0] - s * pl[1], s * pl[0] + c * pl[1], pl[2], c * pl[3] - s * pl[4], s * pl[3] + c * pl[4], pl[5]};
+      for (int q = 0; q < 6; ++q) {
+        if (eq[q] < c0 || eq[q] >= c0 + nc) continue;                      // column eq[q] belongs to this slab
+        atomicAdd(&rhs[eq[q]], pg[q]);                                     // each equation's load once: with its own column
+        for (int r = 0; r < 6; ++r)
+          if (eq[r] >= eq[q]) atomicAdd(&slab[(size_t)(eq[q] - c0) * ld + (eq[r] - eq[q])], k[r][q]);
+      }
+    }
+    __syncthreads();
+    for (int i = tid; i < nc * ld; i += 256) ab[(long)c0 * ld + i] = slab[i];
+    __syncthreads();
   }
-  if (t < n3 - p.n_eq) ab[(long)(p.n_eq + t) * ld] = 1.0;
+  const double* lb = p.loads + b * p.loads_bs;
+  for (int i = tid; i < p.Nn * 3; i += 256) {
+    const int q = p.node_eq[i];
+    if (q >= 0) atomicAdd(&rhs[q], lb[i]);
+  }
+  __syncthreads();
+  for (int i = tid; i < n3; i += 256) ab[(long)n3 * ld + i] = rhs[i];
 }
 
 constexpr int FRAME_CH = 24;   // columns per chunk of the backward sweep (8 blocks)
+constexpr int FRAME_PD = 4;    // block steps between issuing a column load and needing it in LDS
+
+// workgroup barrier that waits for this wave's LDS operations only: __syncthreads() would also drain vmcnt, i.e. put
+// the HBM latency of the column write-back and of the prefetch on every block step
+__device__ __forceinline__ void lds_barrier() { __asm__ volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 __global__ __launch_bounds__(1024) void frame_factor_big_kernel(const FrameParams p, double* __restrict__ ws, int pp_use) {
   extern __shared__ double lds[];
@@ -364,45 +407,62 @@ __global__ __launch_bounds__(1024) void frame_factor_big_kernel(const FrameParam
   __syncthreads();
   if (look && first_pivot(win, win + ld, win + 2 * ld, tid) && tid == 0) s_bad = 1;
   __syncthreads();
-  for (int j = 0; j < n3; j += 3) {
-    double* c0 = win + (size_t)(j % W) * ld;
-    double* c1 = win + (size_t)((j + 1) % W) * ld;
-    double* c2 = win + (size_t)((j + 2) % W) * ld;
-    const Pivot3 f = load_pivot(c0, c1, c2);
-    // finished columns j..j+2 (panel unscaled, pivot factored) back to HBM; columns j+kd+3.. into the slots block j-3 left
-    double pre = 0.0;
-    int cin = 0;
-    const bool mover = tid >= 128 && tid < 128 + 3 * ld;
-    if (mover) {
-      const int q = (tid - 128) / ld, t = (tid - 128) % ld;
-      ab[(long)(j + q) * ld + t] = win[(size_t)((j + q) % W) * ld + t];
-      cin = j + kd + 3 + q;
-      if (cin < n3) pre = ab[(long)cin * ld + t];
-    }
-    if (look) {
-      if (j + 3 < n3 && lookahead_pivot(f, c0, c1, c2, win + (size_t)((j + 3) % W) * ld, win + (size_t)((j + 4) % W) * ld,
-                                        win + (size_t)((j + 5) % W) * ld, kd, tid) && tid == 0) s_bad = 1;
-    } else if (fl < 64 && fl < kd && j + 3 + fl < n3) {
-      const double a0 = (3 + fl <= kd) ? c0[3 + fl] : 0.0, a1 = (2 + fl <= kd) ? c1[2 + fl] : 0.0, a2 = c2[1 + fl];
-      double w1, w2, w3;
-      pivot_solve(f, rhs[j], rhs[j + 1], rhs[j + 2], w1, w2, w3);
-      rhs[j + 3 + fl] = __builtin_fma(-a0, w1, __builtin_fma(-a1, w2, __builtin_fma(-a2, w3, rhs[j + 3 + fl])));
-    }
+  // column movers: thread (q, t) carries entry t of the q-th column of a block.  Loads run FRAME_PD block steps ahead
+  // through a rotating register queue; the per-step barrier waits for LDS only (lds_barrier), never for HBM.
+  const bool mover = tid >= 128 && tid < 128 + 3 * ld;
+  const int mq = mover ? (tid - 128) / ld : 0, mt = mover ? (tid - 128) % ld : 0;
+  double pre[FRAME_PD];
 #pragma unroll
-    for (int k = 0; k < FRAME_PP; ++k) {
-      const int r = own.r[k], c = own.c[k];
-      if (own.on[k] && r >= 3 && j + 3 + r < n3) {
-        const double a0 = (3 + r <= kd) ? c0[3 + r] : 0.0, a1 = (2 + r <= kd) ? c1[2 + r] : 0.0, a2 = c2[1 + r];
-        const double b0 = (3 + c <= kd) ? c0[3 + c] : 0.0, b1 = (2 + c <= kd) ? c1[2 + c] : 0.0, b2 = c2[1 + c];
-        double w1, w2, w3;
-        pivot_solve(f, b0, b1, b2, w1, w2, w3);
-        double* t = win + (size_t)((j + 3 + c) % W) * ld + (r - c);
-        *t = __builtin_fma(-a0, w1, __builtin_fma(-a1, w2, __builtin_fma(-a2, w3, *t)));
+  for (int i = 0; i < FRAME_PD - 1; ++i) {
+    const int cin = kd + 3 + 3 * i + mq;
+    pre[i] = ab[(long)(cin < n3 ? cin : n3 - 1) * ld + mt];
+  }
+  pre[FRAME_PD - 1] = 0.0;
+  for (int j0 = 0; j0 < n3; j0 += 3 * FRAME_PD) {
+#pragma unroll
+    for (int u = 0; u < FRAME_PD; ++u) {
+      const int j = j0 + 3 * u;
+      if (j < n3) {
+        double* c0 = win + (size_t)(j % W) * ld;
+        double* c1 = win + (size_t)((j + 1) % W) * ld;
+        double* c2 = win + (size_t)((j + 2) % W) * ld;
+        const Pivot3 f = load_pivot(c0, c1, c2);
+        // finished columns j..j+2 (panel unscaled, pivot factored) back to HBM; columns j+kd+3.. (loaded FRAME_PD-1
+        // steps ago) into the slots block j-3 left; the load for step j+3*(FRAME_PD-1) goes out
+        const double landed = pre[u];
+        if (mover) {
+          ab[(long)(j + mq) * ld + mt] = win[(size_t)((j + mq) % W) * ld + mt];
+          const int cnext = j + kd + 3 + 3 * (FRAME_PD - 1) + mq;
+          pre[(u + FRAME_PD - 1) % FRAME_PD] = ab[(long)(cnext < n3 ? cnext : n3 - 1) * ld + mt];
+        }
+        if (look) {
+          if (j + 3 < n3 && lookahead_pivot(f, c0, c1, c2, win + (size_t)((j + 3) % W) * ld, win + (size_t)((j + 4) % W) * ld,
+                                            win + (size_t)((j + 5) % W) * ld, kd, tid) && tid == 0) s_bad = 1;
+        } else if (fl < 64 && fl < kd && j + 3 + fl < n3) {
+          const double a0 = (3 + fl <= kd) ? c0[3 + fl] : 0.0, a1 = (2 + fl <= kd) ? c1[2 + fl] : 0.0, a2 = c2[1 + fl];
+          double w1, w2, w3;
+          pivot_solve(f, rhs[j], rhs[j + 1], rhs[j + 2], w1, w2, w3);
+          rhs[j + 3 + fl] = __builtin_fma(-a0, w1, __builtin_fma(-a1, w2, __builtin_fma(-a2, w3, rhs[j + 3 + fl])));
+        }
+#pragma unroll
+        for (int k = 0; k < FRAME_PP; ++k) {
+          const int r = own.r[k], c = own.c[k];
+          if (own.on[k] && r >= 3 && j + 3 + r < n3) {
+            const double a0 = (3 + r <= kd) ? c0[3 + r] : 0.0, a1 = (2 + r <= kd) ? c1[2 + r] : 0.0, a2 = c2[1 + r];
+            const double b0 = (3 + c <= kd) ? c0[3 + c] : 0.0, b1 = (2 + c <= kd) ? c1[2 + c] : 0.0, b2 = c2[1 + c];
+            double w1, w2, w3;
+            pivot_solve(f, b0, b1, b2, w1, w2, w3);
+            double* t = win + (size_t)((j + 3 + c) % W) * ld + (r - c);
+            *t = __builtin_fma(-a0, w1, __builtin_fma(-a1, w2, __builtin_fma(-a2, w3, *t)));
+          }
+        }
+        const int cin = j + kd + 3 + mq;
+        if (mover && cin < n3) win[(size_t)(cin % W) * ld + mt] = landed;
+        lds_barrier();
       }
     }
-    if (mover && cin < n3) win[(size_t)(cin % W) * ld + (tid - 128) % ld] = pre;
-    __syncthreads();
   }
+  __syncthreads();                       // the written-back columns are read again below
   if (__builtin_amdgcn_readfirstlane(tid) < 64) __builtin_amdgcn_s_setprio(0);
   // backward substitution, chunks of FRAME_CH columns, last chunk first
   const int nch = (n3 + FRAME_CH - 1) / FRAME_CH;
@@ -507,6 +567,7 @@ extern "C" int ops_frame_solve_batched_f64(int B, int n_nodes, int n_elems, int 
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)frame_solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX) != hipSuccess ||
+        hipFuncSetAttribute((const void*)frame_assemble_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX) != hipSuccess ||
         hipFuncSetAttribute((const void*)frame_factor_big_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX) != hipSuccess)
       return OPS_AMD_ERR_LAUNCH;
     attr_set = true;
@@ -526,10 +587,9 @@ extern "C" int ops_frame_solve_batched_f64(int B, int n_nodes, int n_elems, int 
     const size_t lds2 = ((size_t)(kd + 6) * ld + (size_t)n3 + 2 * (size_t)FRAME_CH * ld) * sizeof(double);
     if (lds2 > LDS_MAX) return OPS_AMD_ERR_UNSUPPORTED;
     if (!workspace || workspace_bytes < need) return OPS_AMD_ERR_INVALID_ARG;
-    if (hipMemsetAsync(workspace, 0, need, s) != hipSuccess) return OPS_AMD_ERR_LAUNCH;
-    const int work = n_elems > n_nodes * 3 ? n_elems : n_nodes * 3;
     if (T < 128 + 3 * ld) T = (128 + 3 * ld + 63) / 64 * 64;   // the column movers sit behind the two service waves
-    hipLaunchKernelGGL(frame_assemble_kernel, dim3((unsigned)((work + 255) / 256), (unsigned)B), dim3(256), 0, s, p, (double*)workspace);
+    const size_t lds_asm = ((size_t)FRAME_SLAB * ld + (size_t)n3) * sizeof(double);
+    hipLaunchKernelGGL(frame_assemble_kernel, dim3((unsigned)B), dim3(256), lds_asm, s, p, (double*)workspace);
     hipLaunchKernelGGL(frame_factor_big_kernel, dim3((unsigned)B), dim3((unsigned)T), lds2, s, p, (double*)workspace, pp_use);
     return hipGetLastError() == hipSuccess ? OPS_AMD_OK : OPS_AMD_ERR_LAUNCH;
   }
