@@ -258,7 +258,7 @@ def main():
         if not args.no_graph:
             try:
                 graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph, stream=stream):
+                with torch.cuda.graph(graph, stream=stream, capture_error_mode="thread_local"):
                     for _ in range(K):
                         step()
                 graph.replay()   # untimed: instantiate + first replay

@@ -277,7 +277,7 @@ def optimize_cases(cases: Cases, cfg: SizingConfig, device, poll_every: int = 25
             epochs_done = 1
             side.synchronize()
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph, stream=side):
+            with torch.cuda.graph(graph, stream=side, capture_error_mode="thread_local"):
                 for _ in range(poll_every):
                     st.epoch()
         torch.cuda.current_stream(device).wait_stream(side)

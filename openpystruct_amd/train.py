@@ -267,15 +267,21 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
                 fwd_bwd(sX, sY, s_noise)
                 apply_update()                   # warm-up only: no collective needed for capture-readiness
             side.synchronize()
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph, stream=side):
-                s_loss = fwd_bwd(sX, sY, s_noise)
-                if world == 1:
-                    apply_update()
-            if world > 1:
-                graph_b = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph_b, stream=side):
-                    apply_update()
+            try:
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph, stream=side, capture_error_mode="thread_local"):
+                    s_loss = fwd_bwd(sX, sY, s_noise)
+                    if world == 1:
+                        apply_update()
+                if world > 1:
+                    graph_b = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(graph_b, stream=side, capture_error_mode="thread_local"):
+                        apply_update()
+            except Exception as e:          # same arithmetic eagerly; the step is then launch-bound
+                if log:
+                    log(f"HIP graph capture failed ({e!r}); training eagerly")
+                graph = graph_b = None
+                torch.cuda.synchronize(device)
         torch.cuda.current_stream(device).wait_stream(side)
         model.load_state_dict(snap[0]); opt.load_state_dict(snap[1])     # the warm-up steps never happened
 
