@@ -24,6 +24,91 @@ import torch.nn.functional as F
 # ------------------------------------------------------------------------------------------------
 # PINN: residual MLP
 # ------------------------------------------------------------------------------------------------
+import os as _os
+# Opt-in (OPS_AMD_PINN_FUSED_STENCIL=1): measured on MI355X the fused pair is NOT faster end to end (PINN epoch 0.0562 s vs
+# 0.0545 s with the framework modules, same run) although it replaces ~0.3 ms of kernels per step by 0.17 ms: the
+# conv/BN branch of a ResidualBlock is independent of the fc1 -> fc2 branch and the HIP graph runs the two concurrently,
+# so it is off the step's critical path (profiles/r01_notes.md).
+_FUSED_STENCIL = _os.environ.get('OPS_AMD_PINN_FUSED_STENCIL', '0') == '1'
+
+
+class _StencilBN(torch.autograd.Function):
+    """csrc/stencil_bn.hip behind autograd: one launch forward, one backward (GPU float32 tensors only)."""
+
+    @staticmethod
+    def forward(ctx, x, cw, cb, gamma, beta, bn, training):
+        from . import _cabi
+        lib = _cabi.load()
+        x = x.contiguous()
+        B, Fd = x.shape
+        z = torch.empty_like(x)
+        save = torch.empty(2, dtype=torch.float32, device=x.device)
+        cw3 = cw.reshape(3)
+        with torch.cuda.device(x.device):
+            rc = lib.ops_stencil3_bn1_fwd_f32(B, Fd, x.data_ptr(), cw3.data_ptr(), cb.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                                              float(bn.eps), float(bn.momentum), int(training), bn.running_mean.data_ptr(),
+                                              bn.running_var.data_ptr(), bn.num_batches_tracked.data_ptr() if training else None,
+                                              z.data_ptr(), save.data_ptr(), torch.cuda.current_stream(x.device).cuda_stream)
+        if rc != _cabi.OK:
+            raise RuntimeError(f"ops_stencil3_bn1_fwd_f32 failed with code {rc}")
+        ctx.save_for_backward(x, cw3, cb, gamma, save)
+        ctx.training = bool(training)
+        ctx.cw_shape = cw.shape
+        return z
+
+    @staticmethod
+    def backward(ctx, g):
+        from . import _cabi
+        lib = _cabi.load()
+        x, cw3, cb, gamma, save = ctx.saved_tensors
+        g = g.contiguous().float()
+        dx = torch.empty_like(x)
+        dp = torch.empty(6, dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            rc = lib.ops_stencil3_bn1_bwd_f32(x.shape[0], x.shape[1], x.data_ptr(), g.data_ptr(), cw3.data_ptr(), cb.data_ptr(),
+                                              gamma.data_ptr(), save.data_ptr(), int(ctx.training), dx.data_ptr(), dp.data_ptr(),
+                                              torch.cuda.current_stream(x.device).cuda_stream)
+        if rc != _cabi.OK:
+            raise RuntimeError(f"ops_stencil3_bn1_bwd_f32 failed with code {rc}")
+        return dx, dp[0:3].reshape(ctx.cw_shape), dp[3:4], dp[4:5], dp[5:6], None, None
+
+
+def stencil_bn(x: torch.Tensor, conv: nn.Conv1d, bn: nn.BatchNorm1d, training: bool) -> torch.Tensor:
+    """`bn(conv(x.unsqueeze(1))).squeeze(1)` for Conv1d(1,1,3,padding=1) + BatchNorm1d(1): the fused HIP kernel on the GPU,
+    the tensor-op restatement below elsewhere (CPU tests) -- both with the modules' parameters and buffers."""
+    fused = (x.is_cuda and x.dim() == 2 and x.numel() <= (1 << 22) and bn.momentum is not None and bn.track_running_stats
+             and conv.weight.dtype == torch.float32)
+    if not fused:
+        return conv3_bn_single_channel(x, conv, bn, training)
+    z = _StencilBN.apply(x.float(), conv.weight, conv.bias, bn.weight, bn.bias, bn, training)
+    # under autocast the library pair hands back the autocast dtype (Conv1d runs in it, BatchNorm keeps it): do the same, so
+    # that everything downstream runs exactly the kernels it runs with the modules
+    return z.to(torch.get_autocast_dtype("cuda")) if torch.is_autocast_enabled("cuda") else z
+
+
+def conv3_bn_single_channel(x: torch.Tensor, conv: nn.Conv1d, bn: nn.BatchNorm1d, training: bool) -> torch.Tensor:
+    """Tensor-op restatement of the fused kernel (CPU path and numerical reference of the tests): a 3-tap stencil and
+    a whole-tensor normalisation with the modules' arithmetic (biased batch variance for the normalisation, unbiased for
+    `running_var`, momentum update, `num_batches_tracked`)."""
+    w = conv.weight.reshape(3).float()
+    xf = x.float()
+    xp = F.pad(xf, (1, 1))
+    y = conv.bias.float() + w[0] * xp[:, :-2] + w[1] * xf + w[2] * xp[:, 2:]
+    if training or not bn.track_running_stats:
+        var, mean = torch.var_mean(y, unbiased=False)
+        if bn.track_running_stats:
+            with torch.no_grad():
+                n = y.numel()
+                m = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked + 1)
+                bn.running_mean.mul_(1.0 - m).add_(mean.detach().reshape(1) * m)
+                bn.running_var.mul_(1.0 - m).add_(var.detach().reshape(1) * (m * n / max(n - 1, 1)))
+                bn.num_batches_tracked += 1
+    else:
+        mean, var = bn.running_mean.reshape(()), bn.running_var.reshape(())
+    scale = torch.rsqrt(var + bn.eps) * bn.weight.reshape(())
+    return torch.addcmul(bn.bias.reshape(()) - mean * scale, y, scale)
+
+
 class ResidualBlock(nn.Module):
     """x + fc2(dropout(leaky(fc1(x)))) + BN1(conv1(x)): a bottleneck MLP path and a width-3 Conv1d path
     over the feature axis, both added to the identity (PINN:425-452)."""
@@ -42,7 +127,11 @@ class ResidualBlock(nn.Module):
     def forward(self, x):
         out = self.fc2(self.dropout(self.Leaky(self.fc1(x))))
         if self.use_conv:
-            out = out + self.bn1(self.conv1(x.unsqueeze(1))).squeeze(1)
+            if (self.conv1.kernel_size == (3,) and self.conv1.padding == (1,) and self.bn1.affine and self.conv1.bias is not None
+                    and _FUSED_STENCIL):
+                out = out + stencil_bn(x, self.conv1, self.bn1, self.training)
+            else:
+                out = out + self.bn1(self.conv1(x.unsqueeze(1))).squeeze(1)
         return out + x
 
 

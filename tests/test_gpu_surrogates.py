@@ -22,3 +22,35 @@ def test_generate_prepare_train_on_gpu(kind):
     out = train.train_surrogate(kind, d, cfg, device="cuda", max_epochs=2)
     assert out["epochs"] == 2 and np.isfinite(out["history"]["train"]).all() and np.isfinite(out["history"]["val"]).all()
     assert np.isfinite(out["r2_val_I"])
+
+
+@pytest.mark.parametrize("B,F", [(128, 350), (7, 5), (1, 1), (513, 129)])
+def test_fused_stencil_batchnorm_kernel_vs_library_modules(B, F):
+    """csrc/stencil_bn.hip (forward + backward, training and eval) == nn.Conv1d(1,1,3,padding=1) + nn.BatchNorm1d(1)."""
+    from openpystruct_amd import surrogates
+    torch.manual_seed(B + F)
+    conv, bn = torch.nn.Conv1d(1, 1, 3, padding=1).cuda(), torch.nn.BatchNorm1d(1).cuda()
+    with torch.no_grad():
+        bn.weight.fill_(1.3); bn.bias.fill_(-0.2)
+    conv2, bn2 = torch.nn.Conv1d(1, 1, 3, padding=1).cuda(), torch.nn.BatchNorm1d(1).cuda()
+    conv2.load_state_dict(conv.state_dict()); bn2.load_state_dict(bn.state_dict())
+    for step in range(3):
+        x = torch.randn(B, F, device="cuda", requires_grad=True); x2 = x.detach().clone().requires_grad_(True)
+        a = surrogates.stencil_bn(x, conv, bn, True)
+        b = surrogates.conv3_bn_single_channel(x2, conv2, bn2, True) if B * F > 1 else None
+        if b is None:
+            assert torch.isfinite(a).all()      # a single value: variance 0, z = beta
+            continue
+        assert torch.allclose(a, b, atol=2e-5, rtol=1e-5)
+        g = torch.randn_like(a)
+        a.backward(g); b.backward(g)
+        assert torch.allclose(x.grad, x2.grad, atol=2e-5, rtol=1e-4)
+        for p, q in zip(list(conv.parameters()) + list(bn.parameters()), list(conv2.parameters()) + list(bn2.parameters())):
+            assert torch.allclose(p.grad, q.grad, atol=5e-3, rtol=1e-3), (p.grad, q.grad)   # d(conv bias) is 0 up to rounding
+            p.grad = None; q.grad = None
+    if B * F > 1:
+        assert torch.allclose(bn.running_mean, bn2.running_mean, atol=1e-6) and torch.allclose(bn.running_var, bn2.running_var, atol=1e-6)
+        assert int(bn.num_batches_tracked) == int(bn2.num_batches_tracked) == 3
+        x = torch.randn(B, F, device="cuda")
+        ref = bn2.eval()(conv2(x.unsqueeze(1))).squeeze(1)
+        assert torch.allclose(surrogates.stencil_bn(x, conv, bn, False), ref, atol=2e-5, rtol=1e-5)

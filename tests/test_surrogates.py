@@ -175,3 +175,28 @@ def test_two_rank_training_stays_in_sync():
     assert e0 == e1 and v0 == pytest.approx(v1)              # all-reduced losses: identical early-stop decisions
     assert w0 == pytest.approx(w1, rel=1e-6)                 # replicas hold the same weights after training
     np.testing.assert_allclose(m0, m1)                       # global scaler statistics on every rank
+
+
+def test_stencil_batchnorm_path_equals_the_library_modules():
+    """ResidualBlock's Conv1d(1,1,3)+BatchNorm1d(1) fast path == nn.Conv1d / nn.BatchNorm1d: outputs, gradients, buffers."""
+    torch.manual_seed(0)
+    conv, bn = torch.nn.Conv1d(1, 1, 3, padding=1), torch.nn.BatchNorm1d(1)
+    with torch.no_grad():
+        bn.weight.fill_(1.3); bn.bias.fill_(-0.2)
+    conv2, bn2 = (type(m)(*a) for m, a in ((conv, (1, 1, 3)), (bn, (1,))))
+    conv2 = torch.nn.Conv1d(1, 1, 3, padding=1); conv2.load_state_dict(conv.state_dict()); bn2.load_state_dict(bn.state_dict())
+    for step in range(3):
+        x = torch.randn(16, 35, requires_grad=True); x2 = x.detach().clone().requires_grad_(True)
+        a = surrogates.conv3_bn_single_channel(x, conv, bn, True)
+        b = bn2(conv2(x2.unsqueeze(1))).squeeze(1)
+        assert torch.allclose(a, b, atol=1e-5)
+        g = torch.randn_like(a)
+        a.backward(g); b.backward(g)
+        assert torch.allclose(x.grad, x2.grad, atol=1e-5)
+        for p, q in zip(list(conv.parameters()) + list(bn.parameters()), list(conv2.parameters()) + list(bn2.parameters())):
+            assert torch.allclose(p.grad, q.grad, atol=1e-4, rtol=1e-4)
+            p.grad = None; q.grad = None
+    assert torch.allclose(bn.running_mean, bn2.running_mean, atol=1e-6) and torch.allclose(bn.running_var, bn2.running_var, atol=1e-6)
+    assert int(bn.num_batches_tracked) == int(bn2.num_batches_tracked) == 3
+    x = torch.randn(5, 35)
+    assert torch.allclose(surrogates.conv3_bn_single_channel(x, conv, bn, False), bn2.eval()(conv2(x.unsqueeze(1))).squeeze(1), atol=1e-5)
