@@ -150,16 +150,22 @@ size_t ops_frame_workspace_bytes(int B, int n_eq, int half_bandwidth);
 
 /* Fused 3-tap stencil + single-channel batch normalisation of a [B,F] float32 tensor: the PINN ResidualBlock's
  * `bn1(conv1(x.unsqueeze(1))).squeeze(1)` (Conv1d(1,1,3,padding=1) + BatchNorm1d(1),
- * OpenPyStruct_PINN_MultiCase.py:425-452) in one launch per direction; B*F <= 2^22.
+ * OpenPyStruct_PINN_MultiCase.py:425-452) in two launches forward, three backward; B*F <= 2^26.
+ * `workspace`: ops_stencil3_bn1_workspace_bytes() bytes of device memory (per-workgroup partial sums; the backward call
+ * may reuse the forward call's).  z / grad_z are float32 or, with the *_is_bf16 flags, bfloat16 (the autocast dtype the
+ * framework pair returns): x, parameters, statistics and dx stay float32.
  *   fwd: z = gamma (y - mean) invstd + beta, y = w0 x[i-1] + w1 x[i] + w2 x[i+1] + b; training != 0: batch statistics,
  *        running_mean / running_var momentum update (unbiased variance), *num_batches_tracked += 1 (may be NULL);
  *        training == 0: running statistics.  save[2] receives (mean, invstd) for the backward pass.
  *   bwd: dx [B,F] and dparams[6] = d(w0, w1, w2, b, gamma, beta) from grad_z; `training` as in the forward pass. */
 int ops_stencil3_bn1_fwd_f32(int B, int F, const float* x, const float* conv_w, const float* conv_b, const float* gamma,
                              const float* beta, float eps, float momentum, int training, float* running_mean,
-                             float* running_var, long long* num_batches_tracked, float* z, float* save, void* stream);
-int ops_stencil3_bn1_bwd_f32(int B, int F, const float* x, const float* grad_z, const float* conv_w, const float* conv_b,
-                             const float* gamma, const float* save, int training, float* dx, float* dparams, void* stream);
+                             float* running_var, long long* num_batches_tracked, void* z, int z_is_bf16, float* save,
+                             void* workspace, void* stream);
+int ops_stencil3_bn1_bwd_f32(int B, int F, const float* x, const void* grad_z, int grad_is_bf16, const float* conv_w, const float* conv_b,
+                             const float* gamma, const float* save, int training, float* dx, float* dparams, void* workspace,
+                             void* stream);
+size_t ops_stencil3_bn1_workspace_bytes(void);
 
 /* Largest Ne a build supports, ABI version, and the text of the last HIP error seen by
  * this thread (empty string if none). */

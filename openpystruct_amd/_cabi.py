@@ -22,6 +22,7 @@ EXPORTS = (
     "ops_frame_workspace_bytes",
     "ops_stencil3_bn1_fwd_f32",
     "ops_stencil3_bn1_bwd_f32",
+    "ops_stencil3_bn1_workspace_bytes",
     "ops_amd_max_elements",
     "ops_amd_abi_version",
     "ops_amd_last_error",
@@ -79,9 +80,10 @@ def load():
     lib.ops_frame_workspace_bytes.argtypes = [it, it, it]
     fl = ctypes.c_float
     lib.ops_stencil3_bn1_fwd_f32.restype = it
-    lib.ops_stencil3_bn1_fwd_f32.argtypes = [it, it, vp, vp, vp, vp, vp, fl, fl, it, vp, vp, vp, vp, vp, vp]
+    lib.ops_stencil3_bn1_fwd_f32.argtypes = [it, it, vp, vp, vp, vp, vp, fl, fl, it, vp, vp, vp, vp, it, vp, vp, vp]
     lib.ops_stencil3_bn1_bwd_f32.restype = it
-    lib.ops_stencil3_bn1_bwd_f32.argtypes = [it, it, vp, vp, vp, vp, vp, vp, it, vp, vp, vp]
+    lib.ops_stencil3_bn1_bwd_f32.argtypes = [it, it, vp, vp, it, vp, vp, vp, vp, it, vp, vp, vp, vp]
+    lib.ops_stencil3_bn1_workspace_bytes.restype = ctypes.c_size_t
     lib.ops_amd_max_elements.restype = it
     lib.ops_amd_abi_version.restype = it
     lib.ops_amd_last_error.restype = ctypes.c_char_p

@@ -25,33 +25,34 @@ import torch.nn.functional as F
 # PINN: residual MLP
 # ------------------------------------------------------------------------------------------------
 import os as _os
-# Opt-in (OPS_AMD_PINN_FUSED_STENCIL=1): measured on MI355X the fused pair is NOT faster end to end (PINN epoch 0.0562 s vs
-# 0.0545 s with the framework modules, same run) although it replaces ~0.3 ms of kernels per step by 0.17 ms: the
-# conv/BN branch of a ResidualBlock is independent of the fc1 -> fc2 branch and the HIP graph runs the two concurrently,
-# so it is off the step's critical path (profiles/r01_notes.md).
-_FUSED_STENCIL = _os.environ.get('OPS_AMD_PINN_FUSED_STENCIL', '0') == '1'
+# ResidualBlock's Conv1d(1,1,3) + BatchNorm1d(1) pair through csrc/stencil_bn.hip (default) or through the framework modules
+# (OPS_AMD_PINN_FUSED_STENCIL=0, the A/B switch).  Measured on MI355X, same run: PINN epoch 0.0497 s fused vs 0.0541 s with
+# the modules; the step graph 0.870 vs 0.938 ms (profiles/r01_notes.md).
+_FUSED_STENCIL = _os.environ.get('OPS_AMD_PINN_FUSED_STENCIL', '1') == '1'
 
 
 class _StencilBN(torch.autograd.Function):
     """csrc/stencil_bn.hip behind autograd: one launch forward, one backward (GPU float32 tensors only)."""
 
     @staticmethod
-    def forward(ctx, x, cw, cb, gamma, beta, bn, training):
+    def forward(ctx, x, cw, cb, gamma, beta, bn, training, out_bf16):
         from . import _cabi
         lib = _cabi.load()
         x = x.contiguous()
         B, Fd = x.shape
-        z = torch.empty_like(x)
+        z = torch.empty_like(x, dtype=torch.bfloat16 if out_bf16 else torch.float32)
         save = torch.empty(2, dtype=torch.float32, device=x.device)
+        ws = torch.empty(int(lib.ops_stencil3_bn1_workspace_bytes()), dtype=torch.uint8, device=x.device)
         cw3 = cw.reshape(3)
         with torch.cuda.device(x.device):
             rc = lib.ops_stencil3_bn1_fwd_f32(B, Fd, x.data_ptr(), cw3.data_ptr(), cb.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
                                               float(bn.eps), float(bn.momentum), int(training), bn.running_mean.data_ptr(),
                                               bn.running_var.data_ptr(), bn.num_batches_tracked.data_ptr() if training else None,
-                                              z.data_ptr(), save.data_ptr(), torch.cuda.current_stream(x.device).cuda_stream)
+                                              z.data_ptr(), int(out_bf16), save.data_ptr(), ws.data_ptr(),
+                                              torch.cuda.current_stream(x.device).cuda_stream)
         if rc != _cabi.OK:
             raise RuntimeError(f"ops_stencil3_bn1_fwd_f32 failed with code {rc}")
-        ctx.save_for_backward(x, cw3, cb, gamma, save)
+        ctx.save_for_backward(x, cw3, cb, gamma, save, ws)
         ctx.training = bool(training)
         ctx.cw_shape = cw.shape
         return z
@@ -60,30 +61,34 @@ class _StencilBN(torch.autograd.Function):
     def backward(ctx, g):
         from . import _cabi
         lib = _cabi.load()
-        x, cw3, cb, gamma, save = ctx.saved_tensors
-        g = g.contiguous().float()
+        x, cw3, cb, gamma, save, ws = ctx.saved_tensors
+        g = g.contiguous()
+        if g.dtype not in (torch.float32, torch.bfloat16):
+            g = g.float()
         dx = torch.empty_like(x)
         dp = torch.empty(6, dtype=torch.float32, device=x.device)
         with torch.cuda.device(x.device):
-            rc = lib.ops_stencil3_bn1_bwd_f32(x.shape[0], x.shape[1], x.data_ptr(), g.data_ptr(), cw3.data_ptr(), cb.data_ptr(),
+            rc = lib.ops_stencil3_bn1_bwd_f32(x.shape[0], x.shape[1], x.data_ptr(), g.data_ptr(), int(g.dtype == torch.bfloat16),
+                                              cw3.data_ptr(), cb.data_ptr(),
                                               gamma.data_ptr(), save.data_ptr(), int(ctx.training), dx.data_ptr(), dp.data_ptr(),
-                                              torch.cuda.current_stream(x.device).cuda_stream)
+                                              ws.data_ptr(), torch.cuda.current_stream(x.device).cuda_stream)
         if rc != _cabi.OK:
             raise RuntimeError(f"ops_stencil3_bn1_bwd_f32 failed with code {rc}")
-        return dx, dp[0:3].reshape(ctx.cw_shape), dp[3:4], dp[4:5], dp[5:6], None, None
+        return dx, dp[0:3].reshape(ctx.cw_shape), dp[3:4], dp[4:5], dp[5:6], None, None, None
 
 
 def stencil_bn(x: torch.Tensor, conv: nn.Conv1d, bn: nn.BatchNorm1d, training: bool) -> torch.Tensor:
     """`bn(conv(x.unsqueeze(1))).squeeze(1)` for Conv1d(1,1,3,padding=1) + BatchNorm1d(1): the fused HIP kernel on the GPU,
     the tensor-op restatement below elsewhere (CPU tests) -- both with the modules' parameters and buffers."""
-    fused = (x.is_cuda and x.dim() == 2 and x.numel() <= (1 << 22) and bn.momentum is not None and bn.track_running_stats
+    fused = (x.is_cuda and x.dim() == 2 and x.numel() <= (1 << 26) and bn.momentum is not None and bn.track_running_stats
              and conv.weight.dtype == torch.float32)
     if not fused:
         return conv3_bn_single_channel(x, conv, bn, training)
-    z = _StencilBN.apply(x.float(), conv.weight, conv.bias, bn.weight, bn.bias, bn, training)
     # under autocast the library pair hands back the autocast dtype (Conv1d runs in it, BatchNorm keeps it): do the same, so
-    # that everything downstream runs exactly the kernels it runs with the modules
-    return z.to(torch.get_autocast_dtype("cuda")) if torch.is_autocast_enabled("cuda") else z
+    # that everything downstream runs exactly the kernels it runs with the modules; bfloat16 is written by the kernel itself
+    ac = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else None
+    z = _StencilBN.apply(x.float(), conv.weight, conv.bias, bn.weight, bn.bias, bn, training, ac == torch.bfloat16)
+    return z.to(ac) if ac is not None and z.dtype != ac else z
 
 
 def conv3_bn_single_channel(x: torch.Tensor, conv: nn.Conv1d, bn: nn.BatchNorm1d, training: bool) -> torch.Tensor:
