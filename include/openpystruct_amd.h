@@ -167,6 +167,16 @@ int ops_stencil3_bn1_bwd_f32(int B, int F, const float* x, const void* grad_z, i
                              void* stream);
 size_t ops_stencil3_bn1_workspace_bytes(void);
 
+/* Gradient clipping + Adam over flat float32 buffers of n values (the optimiser step of the surrogate training loops:
+ * `clip_grad_norm_(params, max_norm)` + `optim.Adam(lr, weight_decay)`, OpenPyStruct_PINN_MultiCase.py:696, :766-768) in
+ * two launches.  grads are scaled by grad_scale first (1 / world_size after a sum all-reduce); `lr` and `step` are device
+ * scalars (step is advanced by the call); max_norm <= 0 disables clipping; weight decay is torch's L2 form (g += wd p).
+ * `workspace`: ops_flat_adam_workspace_bytes() bytes. */
+int ops_flat_clip_adam_step_f32(long n, float* params, const float* grads, float* exp_avg, float* exp_avg_sq, const float* lr,
+                                int32_t* step, float max_norm, float grad_scale, float beta1, float beta2, float eps,
+                                float weight_decay, void* workspace, void* stream);
+size_t ops_flat_adam_workspace_bytes(void);
+
 /* Largest Ne a build supports, ABI version, and the text of the last HIP error seen by
  * this thread (empty string if none). */
 int ops_amd_max_elements(void);

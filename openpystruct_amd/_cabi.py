@@ -23,6 +23,8 @@ EXPORTS = (
     "ops_stencil3_bn1_fwd_f32",
     "ops_stencil3_bn1_bwd_f32",
     "ops_stencil3_bn1_workspace_bytes",
+    "ops_flat_clip_adam_step_f32",
+    "ops_flat_adam_workspace_bytes",
     "ops_amd_max_elements",
     "ops_amd_abi_version",
     "ops_amd_last_error",
@@ -84,6 +86,9 @@ def load():
     lib.ops_stencil3_bn1_bwd_f32.restype = it
     lib.ops_stencil3_bn1_bwd_f32.argtypes = [it, it, vp, vp, it, vp, vp, vp, vp, it, vp, vp, vp, vp]
     lib.ops_stencil3_bn1_workspace_bytes.restype = ctypes.c_size_t
+    lib.ops_flat_clip_adam_step_f32.restype = it
+    lib.ops_flat_clip_adam_step_f32.argtypes = [lg, vp, vp, vp, vp, vp, vp, fl, fl, fl, fl, fl, fl, vp, vp]
+    lib.ops_flat_adam_workspace_bytes.restype = ctypes.c_size_t
     lib.ops_amd_max_elements.restype = it
     lib.ops_amd_abi_version.restype = it
     lib.ops_amd_last_error.restype = ctypes.c_char_p

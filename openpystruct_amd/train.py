@@ -109,6 +109,50 @@ class FnnConfig:
     c: float = 1.0
 
 
+class FlatClipAdam:
+    """`clip_grad_norm_(params, max_norm)` + `torch.optim.Adam(lr, weight_decay)` as two HIP launches over flat buffers
+    (csrc/flat_adam.hip).  The parameters are re-homed into one flat float32 buffer (each `p.data` becomes a view of it),
+    next to the flat gradient buffer the training loop already all-reduces; `lr` and the step count are device scalars,
+    so a captured HIP graph follows the scheduler."""
+
+    def __init__(self, params, flat_grad: torch.Tensor, lr: float, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0,
+                 max_norm: float = 1.0):
+        from . import _cabi
+        self._cabi, self._lib = _cabi, _cabi.load()
+        dev = flat_grad.device
+        self.p = torch.empty_like(flat_grad)
+        off = 0
+        with torch.no_grad():
+            for q in params:
+                n = q.numel()
+                self.p[off:off + n].copy_(q.reshape(-1))
+                q.data = self.p[off:off + n].view_as(q)
+                off += n
+        assert off == flat_grad.numel()
+        self.g = flat_grad
+        self.m, self.v = torch.zeros_like(flat_grad), torch.zeros_like(flat_grad)
+        self.lr = torch.tensor(float(lr), dtype=torch.float32, device=dev)
+        self.step_count = torch.zeros((), dtype=torch.int32, device=dev)
+        self.ws = torch.empty(int(self._lib.ops_flat_adam_workspace_bytes()), dtype=torch.uint8, device=dev)
+        self.betas, self.eps, self.weight_decay, self.max_norm = betas, eps, weight_decay, max_norm
+
+    def step(self, grad_scale: float = 1.0) -> None:
+        dev = self.g.device
+        with torch.cuda.device(dev):
+            rc = self._lib.ops_flat_clip_adam_step_f32(self.g.numel(), self.p.data_ptr(), self.g.data_ptr(), self.m.data_ptr(),
+                                                       self.v.data_ptr(), self.lr.data_ptr(), self.step_count.data_ptr(), self.max_norm,
+                                                       grad_scale, self.betas[0], self.betas[1], self.eps, self.weight_decay,
+                                                       self.ws.data_ptr(), torch.cuda.current_stream(dev).cuda_stream)
+        if rc != self._cabi.OK:
+            raise RuntimeError(f"ops_flat_clip_adam_step_f32 failed with code {rc}")
+
+    def state_dict(self):
+        return {"m": self.m.clone(), "v": self.v.clone(), "step": self.step_count.clone(), "lr": self.lr.clone()}
+
+    def load_state_dict(self, sd) -> None:
+        self.m.copy_(sd["m"]); self.v.copy_(sd["v"]); self.step_count.copy_(sd["step"]); self.lr.copy_(sd["lr"])
+
+
 def build_model_and_loss(kind: str, cfg, data: SurrogateData, device):
     if kind == "pinn":
         out_dim = cfg.nelem + 2 * (cfg.nelem + 1)
@@ -185,10 +229,12 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
         use_graph = on_gpu                     # the step is launch-bound (~150 tiny kernels): replay it as HIP graphs
     # under graph replay the learning rate must live in a device tensor, or the scheduler's updates would
     # never reach the captured optimiser step
-    lr0 = torch.tensor(cfg.learning_rate, device=device) if use_graph else cfg.learning_rate
-    opt = torch.optim.Adam(model.parameters(), lr=lr0, weight_decay=cfg.weight_decay,
-                           capturable=bool(use_graph), fused=on_gpu)   # loss.alpha NOT included (PINN:696)
-    sched = ExponentialLR(opt, gamma=cfg.gamma)
+    if on_gpu:      # clip + Adam over the flat buffers in two HIP launches; loss.alpha NOT included (PINN:696)
+        opt = FlatClipAdam(params, flat, cfg.learning_rate, weight_decay=cfg.weight_decay, max_norm=1.0)
+        sched = None
+    else:
+        opt = torch.optim.Adam(model.parameters(), lr=cfg.learning_rate, weight_decay=cfg.weight_decay)
+        sched = ExponentialLR(opt, gamma=cfg.gamma)
     Xtr, Ytr, Xva, Yva = (t.to(device) for t in (data.X_train, data.Y_train, data.X_val, data.Y_val))
     nb_tr = max(1, (Xtr.shape[0] + cfg.batch_size - 1) // cfg.batch_size)
     if world > 1:   # every rank must run the same number of steps (collectives inside backward)
@@ -239,6 +285,9 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
 
     def apply_update():
         """Segment B: average over ranks, clip, Adam."""
+        if on_gpu:
+            opt.step(grad_scale=1.0 / world)                             # average, clip (PINN:766), Adam
+            return
         if world > 1:
             flat.div_(world)
         torch.nn.utils.clip_grad_norm_(params, 1.0)                      # PINN:766
@@ -323,7 +372,10 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
                 sl = slice(b * cfg.batch_size, (b + 1) * cfg.batch_size)
                 vt += crit(model(Xva[sl]).float(), Yva[sl])
         val_loss = _allreduce_mean(vt / nb_va, world)
-        sched.step()                                                         # PINN:788
+        if sched is not None:
+            sched.step()                                                     # PINN:788
+        else:
+            opt.lr.mul_(cfg.gamma)                                           # ExponentialLR on the device scalar
         tl, vl = float(train_loss), float(val_loss)                          # the epoch's only host syncs
         if device.type == "cuda":
             torch.cuda.synchronize(device)

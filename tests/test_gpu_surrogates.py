@@ -71,3 +71,32 @@ def test_fused_stencil_batchnorm_under_autocast_returns_bf16_like_the_modules():
     g = torch.randn_like(a)
     a.backward(g); b.backward(g)
     assert x.grad.dtype == torch.float32 and torch.allclose(x.grad, x2.grad, atol=5e-2, rtol=5e-2)
+
+
+@pytest.mark.parametrize("gscale,wd,scale", [(1.0, 0.0, 1.0), (0.5, 1e-2, 50.0), (1.0, 1e-2, 1e-3)])
+def test_flat_clip_adam_equals_torch_clip_plus_adam(gscale, wd, scale):
+    """csrc/flat_adam.hip == clip_grad_norm_(1.0) + torch.optim.Adam over several steps (clipping active and inactive)."""
+    from openpystruct_amd import train
+    torch.manual_seed(1)
+    shapes = [(37, 11), (11,), (5, 3, 2), (1,)]
+    ps = [torch.nn.Parameter(torch.randn(s, device="cuda")) for s in shapes]
+    ref = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+    flat = torch.zeros(sum(p.numel() for p in ps), device="cuda")
+    off = 0
+    for p in ps:
+        p.grad = flat[off:off + p.numel()].view_as(p); off += p.numel()
+    opt = train.FlatClipAdam(ps, flat, 1e-2, weight_decay=wd, max_norm=1.0)
+    ropt = torch.optim.Adam(ref, lr=1e-2, weight_decay=wd)
+    for step in range(6):
+        gs = [torch.randn(s, device="cuda") * scale for s in shapes]
+        flat.copy_(torch.cat([g.reshape(-1) for g in gs]))
+        for r, g in zip(ref, gs):
+            r.grad = g * gscale
+        torch.nn.utils.clip_grad_norm_(ref, 1.0)
+        ropt.step()
+        opt.step(grad_scale=gscale)
+        if step == 2:
+            opt.lr.mul_(0.5); ropt.param_groups[0]["lr"] *= 0.5
+    for p, r in zip(ps, ref):
+        assert torch.allclose(p, r, atol=2e-6, rtol=1e-5), float((p - r).abs().max())
+    assert int(opt.step_count) == 6
