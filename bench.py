@@ -86,11 +86,35 @@ def cpu_baseline(B_hint):
     for _ in range(reps):
         co.solve_beam_batched(x, bo.E_REF, I, fix, Fy, bo.UDL_REF, n_threads=cores, out=out)
     dt = time.perf_counter() - t0
+    # the reference's per-sample loop (MultiCore.py generate_sample: sequential FE solve + torch-CPU Adam per epoch) on ONE
+    # core, a few samples: what one worker of its process pool delivers (the pool scales this by the number of workers)
+    gen = None
+    try:
+        import torch as _t
+        from oracle import sizing_oracle as so
+        nthr = _t.get_num_threads()
+        _t.set_num_threads(1)
+        rs = np.random.default_rng(SEED + 1)
+        cand = [n for n in range(2, 101) if n not in bo.ROLLERS_REF]
+        t1 = time.perf_counter()
+        ep = 0
+        ns = 3
+        for _ in range(ns):
+            k = int(rs.integers(1, 5))
+            rec = so.generate_sample(x, bo.ROLLERS_REF, rs.choice(cand, size=k, replace=False), rs.uniform(bo.MAX_FORCE, bo.MIN_FORCE, size=k))
+            ep += int(rec["epochs_run"]) if "epochs_run" in rec else 0
+        d1 = time.perf_counter() - t1
+        _t.set_num_threads(nthr)
+        gen = {"samples_per_s_per_core": ns / d1, "samples": ns, "seconds": d1, "mean_epochs_per_sample": ep / ns,
+               "what": "oracle/sizing_oracle.py: per-sample loop of the reference (FE solve through the C port + torch CPU autograd / Adam), 1 thread"}
+    except Exception as e:   # the FE baseline must survive
+        gen = {"error": repr(e)}
     return {
         "value": nb * reps / dt,
         "unit": "beam FE solves/s",
         "cores": cores,
         "kind": "port",
+        "generator": gen,
         "sample": f"{reps} x {nb} beams x {N_ELEM} elements, oracle/beam_oracle.c (band Cholesky, OpenMP static over beams, {cores} threads), "
                   f"{dt:.1f} s; OpenSeesPy itself unavailable (un-pinned third-party wheel)",
     }
