@@ -72,7 +72,9 @@ __device__ __forceinline__ void elem_global_k(double L, double c, double s, doub
 
 constexpr int FRAME_PP = 4;   // window entries per thread, at most (kd <= 63: 2016 pairs <= 2 * 1024)
 
-__host__ __device__ inline int frame_ld(int kd) { return (kd + 2) & ~1; }
+// kd + 3 offsets per column (rounded to even): offsets kd+1, kd+2 are never written and read as the zeros that lie outside
+// the band, so the panel reads of a block step need no guards
+__host__ __device__ inline int frame_ld(int kd) { return (kd + 4) & ~1; }
 __host__ __device__ inline int frame_n3(int n) { return (n + 2) / 3 * 3; }
 
 __device__ __forceinline__ double frcp(double d) {   // v_rcp_f64 + two Newton steps (full precision, normal range)
@@ -122,8 +124,8 @@ __device__ __forceinline__ double readlane_f64(double v, int lane) {
 __device__ __forceinline__ bool lookahead_pivot(const Pivot3& f, const double* c0, const double* c1, const double* c2,
                                                 double* n0, double* n1, double* n2, int kd, int dl) {
   const int er = dl == 0 ? 0 : (dl == 1 || dl == 3) ? 1 : 2, ec = dl < 3 ? 0 : dl < 5 ? 1 : 2;
-  const double a0 = (3 + er <= kd) ? c0[3 + er] : 0.0, a1 = (2 + er <= kd) ? c1[2 + er] : 0.0, a2 = c2[1 + er];
-  const double b0 = (3 + ec <= kd) ? c0[3 + ec] : 0.0, b1 = (2 + ec <= kd) ? c1[2 + ec] : 0.0, b2 = c2[1 + ec];
+  const double a0 = c0[3 + er], a1 = c1[2 + er], a2 = c2[1 + er];
+  const double b0 = c0[3 + ec], b1 = c1[2 + ec], b2 = c2[1 + ec];
   double w1, w2, w3;
   pivot_solve(f, b0, b1, b2, w1, w2, w3);
   double* slot = (ec == 0 ? n0 : ec == 1 ? n1 : n2) + (er - ec);
@@ -166,9 +168,9 @@ __device__ __forceinline__ Pairs own_pairs(int tid, int T, int kd, int pp_use) {
   for (int k = 0; k < FRAME_PP; ++k) {
     int rem = tid + k * T, c = 0;
     while (c < kd && rem >= kd - c) { rem -= kd - c; ++c; }
-    q.on[k] = tid >= 0 && (k < pp_use) && c < kd;
     q.c[k] = c;
     q.r[k] = c + rem;
+    q.on[k] = tid >= 0 && (k < pp_use) && c < kd && q.r[k] >= 3;   // r < 3: the next pivot block, the look-ahead wave's
   }
   return q;
 }
@@ -269,7 +271,7 @@ __global__ __launch_bounds__(1024) void frame_solve_kernel(const FrameParams p, 
     if (look) {
       if (j + 3 < n3 && lookahead_pivot(f, c0, c1, c2, c2 + ld, c2 + 2 * ld, c2 + 3 * ld, kd, tid) && tid == 0) s_bad = 1;
     } else if (fl < 64 && fl < kd && j + 3 + fl < n3) {     // f_X -= B_X P^-1 f_P
-      const double a0 = (3 + fl <= kd) ? c0[3 + fl] : 0.0, a1 = (2 + fl <= kd) ? c1[2 + fl] : 0.0, a2 = c2[1 + fl];
+      const double a0 = c0[3 + fl], a1 = c1[2 + fl], a2 = c2[1 + fl];
       double w1, w2, w3;
       pivot_solve(f, rhs[j], rhs[j + 1], rhs[j + 2], w1, w2, w3);
       rhs[j + 3 + fl] = __builtin_fma(-a0, w1, __builtin_fma(-a1, w2, __builtin_fma(-a2, w3, rhs[j + 3 + fl])));
@@ -277,10 +279,10 @@ __global__ __launch_bounds__(1024) void frame_solve_kernel(const FrameParams p, 
 #pragma unroll
     for (int k = 0; k < FRAME_PP; ++k) {
       const int r = own.r[k], c = own.c[k];
-      if (own.on[k] && r >= 3 && j + 3 + r < n3) {            // r < 3: the next pivot block, the look-ahead wave's
+      if (own.on[k] && j + 3 + r < n3) {
         // panel rows R = j+3+r and C = j+3+c; column j+q holds them at offsets 3+r-q (outside the band: zero)
-        const double a0 = (3 + r <= kd) ? c0[3 + r] : 0.0, a1 = (2 + r <= kd) ? c1[2 + r] : 0.0, a2 = c2[1 + r];
-        const double b0 = (3 + c <= kd) ? c0[3 + c] : 0.0, b1 = (2 + c <= kd) ? c1[2 + c] : 0.0, b2 = c2[1 + c];
+        const double a0 = c0[3 + r], a1 = c1[2 + r], a2 = c2[1 + r];
+        const double b0 = c0[3 + c], b1 = c1[2 + c], b2 = c2[1 + c];
         double w1, w2, w3;
         pivot_solve(f, b0, b1, b2, w1, w2, w3);
         double* t = ab + (size_t)(j + 3 + c) * ld + (r - c);
@@ -302,8 +304,8 @@ __global__ __launch_bounds__(1024) void frame_solve_kernel(const FrameParams p, 
       const int e = k - 1 - lane;        // earlier equation; rows k, k+1, k+2 sit at offsets 1+lane, 2+lane, 3+lane
       const bool on = lane < kd && e >= 0;
       const double* ce = ab + (size_t)(on ? e : 0) * ld;
-      const double a0 = on ? ce[1 + lane] : 0.0, a1 = (on && 2 + lane <= kd) ? ce[2 + lane] : 0.0,
-                   a2 = (on && 3 + lane <= kd) ? ce[3 + lane] : 0.0, re = rhs[on ? e : 0];
+      const double a0 = on ? ce[1 + lane] : 0.0, a1 = on ? ce[2 + lane] : 0.0,
+                   a2 = on ? ce[3 + lane] : 0.0, re = rhs[on ? e : 0];
       double x1, x2, x3;
       pivot_solve(f, z1, z2, z3, x1, x2, x3);
       if (on) rhs[e] = __builtin_fma(-a0, x1, __builtin_fma(-a1, x2, __builtin_fma(-a2, x3, re)));
@@ -439,7 +441,7 @@ __global__ __launch_bounds__(1024) void frame_factor_big_kernel(const FrameParam
           if (j + 3 < n3 && lookahead_pivot(f, c0, c1, c2, win + (size_t)((j + 3) % W) * ld, win + (size_t)((j + 4) % W) * ld,
                                             win + (size_t)((j + 5) % W) * ld, kd, tid) && tid == 0) s_bad = 1;
         } else if (fl < 64 && fl < kd && j + 3 + fl < n3) {
-          const double a0 = (3 + fl <= kd) ? c0[3 + fl] : 0.0, a1 = (2 + fl <= kd) ? c1[2 + fl] : 0.0, a2 = c2[1 + fl];
+          const double a0 = c0[3 + fl], a1 = c1[2 + fl], a2 = c2[1 + fl];
           double w1, w2, w3;
           pivot_solve(f, rhs[j], rhs[j + 1], rhs[j + 2], w1, w2, w3);
           rhs[j + 3 + fl] = __builtin_fma(-a0, w1, __builtin_fma(-a1, w2, __builtin_fma(-a2, w3, rhs[j + 3 + fl])));
@@ -447,9 +449,9 @@ __global__ __launch_bounds__(1024) void frame_factor_big_kernel(const FrameParam
 #pragma unroll
         for (int k = 0; k < FRAME_PP; ++k) {
           const int r = own.r[k], c = own.c[k];
-          if (own.on[k] && r >= 3 && j + 3 + r < n3) {
-            const double a0 = (3 + r <= kd) ? c0[3 + r] : 0.0, a1 = (2 + r <= kd) ? c1[2 + r] : 0.0, a2 = c2[1 + r];
-            const double b0 = (3 + c <= kd) ? c0[3 + c] : 0.0, b1 = (2 + c <= kd) ? c1[2 + c] : 0.0, b2 = c2[1 + c];
+          if (own.on[k] && j + 3 + r < n3) {
+            const double a0 = c0[3 + r], a1 = c1[2 + r], a2 = c2[1 + r];
+            const double b0 = c0[3 + c], b1 = c1[2 + c], b2 = c2[1 + c];
             double w1, w2, w3;
             pivot_solve(f, b0, b1, b2, w1, w2, w3);
             double* t = win + (size_t)((j + 3 + c) % W) * ld + (r - c);
@@ -490,8 +492,8 @@ __global__ __launch_bounds__(1024) void frame_factor_big_kernel(const FrameParam
         double s0 = 0.0, s1 = 0.0, s2 = 0.0;
         if (lane < kd && X < n3) {
           const double xX = rhs[X];
-          s0 = (3 + lane <= kd) ? c0[3 + lane] * xX : 0.0;
-          s1 = (2 + lane <= kd) ? c1[2 + lane] * xX : 0.0;
+          s0 = c0[3 + lane] * xX;
+          s1 = c1[2 + lane] * xX;
           s2 = c2[1 + lane] * xX;
         }
         for (int sft = 32; sft >= 1; sft >>= 1) {

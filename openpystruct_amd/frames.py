@@ -77,7 +77,7 @@ class FrameTopology:
         self.d_loads = t(self.nodal_loads, torch.float64)
 
     def lds_bytes(self) -> int:
-        n3, ld = (self.n_eq + 2) // 3 * 3, (max(self.kd, 3) + 2) & ~1     # csrc/frame_solve.hip: frame_n3, frame_ld
+        n3, ld = (self.n_eq + 2) // 3 * 3, (max(self.kd, 3) + 4) & ~1     # csrc/frame_solve.hip: frame_n3, frame_ld
         return (n3 * ld + n3) * 8
 
 
