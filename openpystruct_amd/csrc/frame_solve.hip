@@ -60,8 +60,16 @@ struct FrameParams {
 #define FRAME_STAMP(slot, wait)
 #endif
 
+__device__ __forceinline__ double frcp(double d) {   // v_rcp_f64 + two Newton steps (full precision, normal range)
+  double r = __builtin_amdgcn_rcp(d);
+  double e = __builtin_fma(-d, r, 1.0);
+  r = __builtin_fma(r, e, r);
+  e = __builtin_fma(-d, r, 1.0);
+  return __builtin_fma(r, e, r);
+}
+
 __device__ __forceinline__ void elem_global_k(double L, double c, double s, double EA, double EI, double k[6][6]) {
-  const double a = EA / L, b12 = 12.0 * EI / (L * L * L), b6 = 6.0 * EI / (L * L), b4 = 4.0 * EI / L, b2 = 2.0 * EI / L;
+  const double rL = frcp(L), a = EA * rL, b2 = 2.0 * EI * rL, b4 = 2.0 * b2, b6 = 3.0 * b2 * rL, b12 = 2.0 * b6 * rL;
   const double kxx = a * c * c + b12 * s * s, kxy = (a - b12) * c * s, kyy = a * s * s + b12 * c * c;
   const double kxt = -b6 * s, kyt = b6 * c;
   const double v[6][6] = {{kxx, kxy, kxt, -kxx, -kxy, kxt},  {kxy, kyy, kyt, -kxy, -kyy, kyt},   {kxt, kyt, b4, -kxt, -kyt, b2},
@@ -76,14 +84,6 @@ constexpr int FRAME_PP = 4;   // window entries per thread, at most (kd <= 63: 2
 // the band, so the panel reads of a block step need no guards
 __host__ __device__ inline int frame_ld(int kd) { return (kd + 4) & ~1; }
 __host__ __device__ inline int frame_n3(int n) { return (n + 2) / 3 * 3; }
-
-__device__ __forceinline__ double frcp(double d) {   // v_rcp_f64 + two Newton steps (full precision, normal range)
-  double r = __builtin_amdgcn_rcp(d);
-  double e = __builtin_fma(-d, r, 1.0);
-  r = __builtin_fma(r, e, r);
-  e = __builtin_fma(-d, r, 1.0);
-  return __builtin_fma(r, e, r);
-}
 
 struct Pivot3 {   // LDL^T of the 3 x 3 pivot block
   double rd1, l21, l31, rd2, l32, rd3;
@@ -210,11 +210,11 @@ __device__ __forceinline__ void write_results(const FrameParams& p, long b, cons
     double ug[6];
     for (int r = 0; r < 6; ++r) { const int q = p.elem_eq[6 * e + r]; ug[r] = q >= 0 ? rhs[q] : 0.0; }
     const double ul[6] = {c * ug[0] + s * ug[1], -s * ug[0] + c * ug[1], ug[2], c * ug[3] + s * ug[4], -s * ug[3] + c * ug[4], ug[5]};
-    const double chord = (ul[4] - ul[1]) / L;
-    const double q0 = EA / L * (ul[3] - ul[0]) - wx * L / 2;
-    const double q1 = 4 * EI / L * (ul[2] - chord) + 2 * EI / L * (ul[5] - chord) - wy * L * L / 12;
-    const double q2 = 2 * EI / L * (ul[2] - chord) + 4 * EI / L * (ul[5] - chord) + wy * L * L / 12;
-    const double pl[6] = {-q0 - wx * L, (q1 + q2) / L - wy * L / 2, q1, q0, -(q1 + q2) / L - wy * L / 2, q2};
+    const double rL = frcp(L), chord = (ul[4] - ul[1]) * rL, b2 = 2 * EI * rL, fem = wy * L * L * (1.0 / 12.0);
+    const double q0 = EA * rL * (ul[3] - ul[0]) - wx * L / 2;
+    const double q1 = 2 * b2 * (ul[2] - chord) + b2 * (ul[5] - chord) - fem;
+    const double q2 = b2 * (ul[2] - chord) + 2 * b2 * (ul[5] - chord) + fem;
+    const double pl[6] = {-q0 - wx * L, (q1 + q2) * rL - wy * L / 2, q1, q0, -(q1 + q2) * rL - wy * L / 2, q2};
     const double f[6] = {c * pl[0] - s * pl[1], s * pl[0] + c * pl[1], pl[2], c * pl[3] - s * pl[4], s * pl[3] + c * pl[4], pl[5]};
     double* fo = p.forces + (b * (long)p.Ne + e) * 6;
     for (int r = 0; r < 6; ++r) fo[r] = bad ? qnan : f[r];
