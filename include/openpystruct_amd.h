@@ -137,7 +137,7 @@ int ops_beam_residual_vjp_f64(int B, int Ne, const double* x, long x_bstride, co
  * Per frame: I [B,Ne]; loads [Nn,3] (loads_bstride 0) or [B,Nn,3] (`ops.load(node, Fx, Fy, Mz)`).
  * Outputs: disp [B,Nn,3], forces [B,Ne,6] (global resisting forces = eleResponse 'forces'), V / M [B,Ne] = forces[..,1] /
  * forces[..,2] (FR:151-153), status [B] (non-zero: not positive definite, outputs NaN).
- * half_bandwidth <= 63.  When the band (n_eq * (half_bandwidth + 2) * 8 bytes) fits 160 KB of LDS it lives there and
+ * half_bandwidth <= 63.  When the band (about n_eq * (half_bandwidth + 5) * 8 bytes) fits 160 KB of LDS it lives there and
  * `workspace` may be NULL; larger frames (BASELINE config 5: ~500 elements) keep it in a caller-provided device
  * workspace of ops_frame_workspace_bytes(B, n_eq, half_bandwidth) bytes and factorise through a sliding LDS window. */
 int ops_frame_solve_batched_f64(int B, int n_nodes, int n_elems, int n_eq, int half_bandwidth,

@@ -141,7 +141,7 @@ def frame_solve(topo: FrameTopology, I: torch.Tensor, loads: Optional[torch.Tens
             ws.data_ptr() if ws is not None else None, ws_bytes, torch.cuda.current_stream(dev).cuda_stream)
     if rc == _cabi.ERR_UNSUPPORTED:
         raise NotImplementedError(f"frame too large: n_eq={topo.n_eq}, half bandwidth={topo.kd} (half bandwidth <= 63 and a "
-                                  f"(kd+2)-column window plus two n_eq vectors must fit 160 KB of LDS)")
+                                  f"(kd+6)-column ring, one n_eq vector and two 24-column chunks must fit 160 KB of LDS)")
     if rc != _cabi.OK:
         raise RuntimeError(f"ops_frame_solve_batched_f64 failed with code {rc}")
     return out
