@@ -177,6 +177,17 @@ int ops_flat_clip_adam_step_f32(long n, float* params, const float* grads, float
                                 float weight_decay, void* workspace, void* stream);
 size_t ops_flat_adam_workspace_bytes(void);
 
+/* Training loss of the surrogates, value and gradient w.r.t. the predictions in one pass (two launches):
+ * TrainableL1L2Loss on the first nI columns of preds/targets [B,C] (OpenPyStruct_PINN_MultiCase.py:549-601) -- alpha is a
+ * device scalar, clamped to [1e-6, 1]; min/max_constraint device scalars or NULL; box_weight = penalty_weight --, plus
+ * CompositeLoss's relative-L1 terms (PINN:603-653, weight rel_penalty, eps 1e-8) over the next nD and the remaining
+ * C - nI - nD columns, plus (alpha0 - alpha)^2 (TFD:743; pass NaN for none).  preds / grad: float32, or bfloat16 with preds_is_bf16;
+ * `grad` = d loss / d preds; `workspace`: ops_surrogate_loss_workspace_bytes() bytes. */
+int ops_surrogate_loss_grad_f32(int B, int C, int nI, int nD, const void* preds, int preds_is_bf16, const float* targets,
+                                const float* alpha, float alpha0, const float* min_constraint, const float* max_constraint,
+                                float box_weight, float rel_penalty, float* loss, void* grad, void* workspace, void* stream);
+size_t ops_surrogate_loss_workspace_bytes(void);
+
 /* Largest Ne a build supports, ABI version, and the text of the last HIP error seen by
  * this thread (empty string if none). */
 int ops_amd_max_elements(void);

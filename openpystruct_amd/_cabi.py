@@ -25,6 +25,8 @@ EXPORTS = (
     "ops_stencil3_bn1_workspace_bytes",
     "ops_flat_clip_adam_step_f32",
     "ops_flat_adam_workspace_bytes",
+    "ops_surrogate_loss_grad_f32",
+    "ops_surrogate_loss_workspace_bytes",
     "ops_amd_max_elements",
     "ops_amd_abi_version",
     "ops_amd_last_error",
@@ -89,6 +91,9 @@ def load():
     lib.ops_flat_clip_adam_step_f32.restype = it
     lib.ops_flat_clip_adam_step_f32.argtypes = [lg, vp, vp, vp, vp, vp, vp, fl, fl, fl, fl, fl, fl, vp, vp]
     lib.ops_flat_adam_workspace_bytes.restype = ctypes.c_size_t
+    lib.ops_surrogate_loss_grad_f32.restype = it
+    lib.ops_surrogate_loss_grad_f32.argtypes = [it, it, it, it, vp, it, vp, vp, fl, vp, vp, fl, fl, vp, vp, vp, vp]
+    lib.ops_surrogate_loss_workspace_bytes.restype = ctypes.c_size_t
     lib.ops_amd_max_elements.restype = it
     lib.ops_amd_abi_version.restype = it
     lib.ops_amd_last_error.restype = ctypes.c_char_p

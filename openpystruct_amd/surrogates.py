@@ -208,6 +208,58 @@ class CompositeLoss(nn.Module):
         return loss_I + self.penalty_pinn * phys
 
 
+class _FusedLoss(torch.autograd.Function):
+    """csrc/fused_loss.hip: loss value and d loss / d preds in one pass; backward only scales the stored gradient."""
+
+    @staticmethod
+    def forward(ctx, preds, targets, alpha, alpha0, minc, maxc, box_w, rel_pen, nI, nD):
+        from . import _cabi
+        lib = _cabi.load()
+        if preds.dtype not in (torch.float32, torch.bfloat16):
+            preds = preds.float()
+        preds = preds.contiguous()
+        targets = targets.contiguous()
+        B, C = preds.shape
+        dev = preds.device
+        grad = torch.empty_like(preds)
+        loss = torch.empty((), dtype=torch.float32, device=dev)
+        ws = torch.empty(int(lib.ops_surrogate_loss_workspace_bytes()), dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            rc = lib.ops_surrogate_loss_grad_f32(B, C, nI, nD, preds.data_ptr(), int(preds.dtype == torch.bfloat16), targets.data_ptr(),
+                                                 alpha.data_ptr(), float(alpha0), minc.data_ptr() if minc is not None else None,
+                                                 maxc.data_ptr() if maxc is not None else None, float(box_w), float(rel_pen),
+                                                 loss.data_ptr(), grad.data_ptr(), ws.data_ptr(), torch.cuda.current_stream(dev).cuda_stream)
+        if rc != _cabi.OK:
+            raise RuntimeError(f"ops_surrogate_loss_grad_f32 failed with code {rc}")
+        ctx.save_for_backward(grad)
+        return loss
+
+    @staticmethod
+    def backward(ctx, go):
+        (grad,) = ctx.saved_tensors
+        return (grad * go.to(grad.dtype),) + (None,) * 9
+
+
+def fused_loss(crit: nn.Module, preds: torch.Tensor, targets: torch.Tensor, alpha0: float = None) -> torch.Tensor:
+    """`crit(preds.float(), targets)` (+ `(alpha0 - alpha)^2` when alpha0 is given) for a CompositeLoss or a
+    TrainableL1L2Loss through the fused HIP kernel: ~80 framework kernel nodes per training step become 3.  GPU tensors
+    only; the gradient w.r.t. the loss's own `alpha` is not produced (no optimiser ever holds it: PINN:696, TFD:678)."""
+    if isinstance(crit, CompositeLoss):
+        l1l2, nI, nD, rel = crit.l1l2_loss, crit.nelem, crit.deflection_dim, crit.penalty_pinn
+    else:
+        l1l2, nI, nD, rel = crit, preds.shape[1], 0, 0.0
+    dev = preds.device
+
+    def scalar(v):
+        if v is None:
+            return None
+        return (v if torch.is_tensor(v) else torch.tensor(float(v))).to(device=dev, dtype=torch.float32).reshape(())
+
+    a = l1l2.alpha.detach()
+    return _FusedLoss.apply(preds, targets.to(torch.float32), a, float("nan") if alpha0 is None else float(alpha0),   # NaN: no alpha term
+                            scalar(l1l2.min_constraint), scalar(l1l2.max_constraint), l1l2.penalty_weight, rel, nI, nD)
+
+
 # ------------------------------------------------------------------------------------------------
 # TFD: diffusion front end + transformer encoder over [CLS] + n_cases tokens
 # ------------------------------------------------------------------------------------------------

@@ -24,6 +24,7 @@ the running statistics are averaged over ranks at the end of every epoch so that
 from __future__ import annotations
 
 import copy
+import os
 import time
 from dataclasses import dataclass
 from typing import Dict, Optional
@@ -34,7 +35,7 @@ import torch.nn as nn
 from torch.optim.lr_scheduler import ExponentialLR
 
 from .dataprep import SurrogateData
-from .surrogates import CompositeLoss, FNNPlain, FNNWithResidual, ModelOnePassTransformerWithDiffusion, TrainableL1L2Loss
+from .surrogates import fused_loss, CompositeLoss, FNNPlain, FNNWithResidual, ModelOnePassTransformerWithDiffusion, TrainableL1L2Loss
 
 
 @dataclass
@@ -107,6 +108,9 @@ class FnnConfig:
     gamma: float = 0.99
     initial_alpha: float = 0.5
     c: float = 1.0
+
+
+_FUSED_LOSS = os.environ.get("OPS_AMD_FUSED_LOSS", "1") == "1"      # A/B switch: 0 = the nn.Module losses
 
 
 class FlatClipAdam:
@@ -275,9 +279,12 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
         flat.zero_()                                                     # optimizer.zero_grad()
         with torch.autocast(device_type=device.type, dtype=autocast_dtype, enabled=use_ac):
             preds = net(Xn)
-            loss = crit(preds.float(), Yb)
-            if kind in ("tfd", "fnn"):
-                loss = loss + (cfg.initial_alpha - crit.alpha) ** 2       # TFD:743 / FNN (constant 0: alpha never trains)
+            if on_gpu and _FUSED_LOSS:       # value + d/d preds in one HIP pass instead of ~80 framework kernel nodes
+                loss = fused_loss(crit, preds, Yb, alpha0=cfg.initial_alpha if kind in ("tfd", "fnn") else None)
+            else:
+                loss = crit(preds.float(), Yb)
+                if kind in ("tfd", "fnn"):
+                    loss = loss + (cfg.initial_alpha - crit.alpha) ** 2   # TFD:743 / FNN (constant 0: alpha never trains)
         if physics is not None:
             loss = loss + physics.weight * physics_loss(preds.float(), rows).float()
         loss.backward()
@@ -300,7 +307,14 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
         apply_update()
         return loss
 
-    graph = graph_b = None
+    def val_batch(Xb, Yb):
+        with torch.no_grad(), torch.autocast(device_type=device.type, dtype=autocast_dtype, enabled=use_ac):
+            preds = model(Xb)
+            if on_gpu and _FUSED_LOSS:
+                return fused_loss(crit, preds, Yb)
+            return crit(preds.float(), Yb)
+
+    graph = graph_b = vgraph = None
     bs = cfg.batch_size
     if use_graph and Xtr.shape[0] >= bs:
         # static buffers + a few eager warm-up steps on a side stream, then capture one full-batch step:
@@ -333,6 +347,28 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
                 torch.cuda.synchronize(device)
         torch.cuda.current_stream(device).wait_stream(side)
         model.load_state_dict(snap[0]); opt.load_state_dict(snap[1])     # the warm-up steps never happened
+        # the validation pass as a graph too: one full batch in eval mode, loss accumulated into v_acc
+        if graph is not None and Xva.shape[0] >= bs:
+            vX, vY = torch.zeros_like(Xva[:bs]), torch.zeros_like(Yva[:bs])
+            v_acc = torch.zeros((), device=device)
+            net.eval()
+            try:
+                side.wait_stream(torch.cuda.current_stream(device))
+                with torch.cuda.stream(side), torch.no_grad():
+                    vX.copy_(Xva[:bs]); vY.copy_(Yva[:bs])
+                    for _ in range(2):
+                        val_batch(vX, vY)
+                    side.synchronize()
+                    vgraph = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(vgraph, stream=side, capture_error_mode="thread_local"):
+                        v_acc += val_batch(vX, vY)
+                torch.cuda.current_stream(device).wait_stream(side)
+            except Exception as e:
+                if log:
+                    log(f"HIP graph capture of the validation pass failed ({e!r}); evaluating eagerly")
+                vgraph = None
+                torch.cuda.synchronize(device)
+            net.train()
 
     best_val, best_state, no_improve = float("inf"), None, 0
     n_epochs = max_epochs if max_epochs is not None else cfg.num_epochs
@@ -367,10 +403,16 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
         net.eval()
         vt = torch.zeros((), device=device)
         nb_va = max(1, (Xva.shape[0] + cfg.batch_size - 1) // cfg.batch_size)
-        with torch.no_grad(), torch.autocast(device_type=device.type, dtype=autocast_dtype, enabled=use_ac):
-            for b in range(nb_va):
-                sl = slice(b * cfg.batch_size, (b + 1) * cfg.batch_size)
-                vt += crit(model(Xva[sl]).float(), Yva[sl])
+        for b in range(nb_va):
+            sl = slice(b * cfg.batch_size, (b + 1) * cfg.batch_size)
+            if vgraph is not None and Xva[sl].shape[0] == bs:
+                vX.copy_(Xva[sl]); vY.copy_(Yva[sl])
+                vgraph.replay()
+            else:
+                vt += val_batch(Xva[sl], Yva[sl])
+        if vgraph is not None:
+            vt += v_acc
+            v_acc.zero_()
         val_loss = _allreduce_mean(vt / nb_va, world)
         if sched is not None:
             sched.step()                                                     # PINN:788

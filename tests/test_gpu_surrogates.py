@@ -100,3 +100,46 @@ def test_flat_clip_adam_equals_torch_clip_plus_adam(gscale, wd, scale):
     for p, r in zip(ps, ref):
         assert torch.allclose(p, r, atol=2e-6, rtol=1e-5), float((p - r).abs().max())
     assert int(opt.step_count) == 6
+
+
+@pytest.mark.parametrize("kind,dtype", [("composite", torch.float32), ("composite", torch.bfloat16), ("plain", torch.float32),
+                                        ("plain_noconstraint", torch.float32)])
+def test_fused_loss_value_and_gradient_equal_the_modules(kind, dtype):
+    from openpystruct_amd import surrogates
+    torch.manual_seed(5)
+    B = 128
+    if kind == "composite":
+        crit = surrogates.CompositeLoss(100, 101, 101, 0.5, 0.1, torch.tensor(-1.2, device="cuda"), torch.tensor(1.1, device="cuda")).cuda()
+        C = 302
+    else:
+        mn, mx = (None, None) if kind == "plain_noconstraint" else (torch.tensor(-1.0, device="cuda"), torch.tensor(0.9, device="cuda"))
+        crit = surrogates.TrainableL1L2Loss(0.3, mn, mx, 0.5).cuda()
+        C = 100
+    p = (torch.randn(B, C, device="cuda") * 1.5).to(dtype).requires_grad_(True)
+    t = torch.randn(B, C, device="cuda"); t[0, :5] = 0.0
+    p2 = p.detach().clone().requires_grad_(True)
+    a0 = 0.3 if kind != "composite" else None
+    lf = surrogates.fused_loss(crit, p, t, alpha0=a0)
+    lr = crit(p2.float(), t) + (0.0 if a0 is None else (a0 - crit.alpha) ** 2)
+    assert float(lf) == pytest.approx(float(lr), rel=2e-5)
+    (lf * 2.0).backward(); (lr * 2.0).backward()
+    tol = dict(atol=1e-7, rtol=1e-4) if dtype == torch.float32 else dict(atol=1e-3, rtol=2e-2)
+    big = p2.grad.abs() > 1e3            # relative-error terms divide by |t| + 1e-8: compare those relatively only
+    assert torch.allclose(p.grad.float()[~big], p2.grad.float()[~big], **tol)
+    assert torch.allclose(p.grad.float()[big], p2.grad.float()[big], rtol=2e-2)
+
+
+def test_graph_validation_pass_equals_an_eager_module_evaluation():
+    """The captured validation graph + fused loss report the loss the plain modules compute for the returned weights."""
+    from openpystruct_amd import dataprep, sizing, train
+    rec = sizing.generate_dataset(3000, sizing.SizingConfig(max_e=30), "cuda", seed=21)
+    d = dataprep.prepare(rec, kind="pinn", seed=0, device="cuda")
+    cfg = train.PinnConfig(batch_size=32)
+    out = train.train_surrogate("pinn", d, cfg, device="cuda", max_epochs=1)
+    model = out["model"].eval()
+    _, crit = train.build_model_and_loss("pinn", cfg, d, torch.device("cuda"))
+    nb, tot = 0, 0.0
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        for i in range(0, d.X_val.shape[0], 32):
+            tot += float(crit(model(d.X_val[i:i + 32]).float(), d.Y_val[i:i + 32])); nb += 1
+    assert out["history"]["val"][0] == pytest.approx(tot / nb, rel=2e-3)
