@@ -80,6 +80,14 @@ int ops_beam_solve_batched_f64(int B, int Ne,
                                double* v, double* theta, double* V, double* M,
                                int32_t* status, int tiling, void* stream);
 
+/* The sizing loop's per-epoch solve (SingleCore.py:176-190 reads only eleResponse inside the loop; the displacements are
+ * read once, after it, :224-232): same arguments, element end forces only (no v / theta traffic), and an optional
+ * `active` mask [B] -- a wavefront whose beams are all inactive (early-stopped cases) returns immediately. */
+int ops_beam_solve_forces_f64(int B, int Ne, const double* x, long x_bstride, const double* E, long E_bstride,
+                              const double* I, long I_bstride, const uint8_t* fix, long fix_bstride,
+                              const double* Fy, long Fy_bstride, const double* wy, long wy_bstride, double* V, double* M,
+                              int32_t* status, const uint8_t* active, int tiling, void* stream);
+
 /* Hyper-parameters of the per-case sizing optimiser (module-level constants of the reference,
  * SingleCore.py:20-44): E, G = E / 2.6, alpha_moment = alpha_shear = 1e-2, lr = 0.01, gamma = 0.98,
  * tolerance = 5e-3, patience = 5 (MultiCore: 10, GPU script: 1e-2 / 100), max_epochs = 600,
@@ -107,6 +115,7 @@ typedef struct ops_sizing_params {
  *   best_loss    [B] float32 (init +inf), patience_cnt [B] int32 (init 0), epochs_run [B] int32 (init 0),
  *   active       [B] uint8 (init 1): cleared when patience runs out or max_epochs is reached
  *   last_loss    [B] float32 out, V32/M32 [B,Ne] float32 out: the recorded `shear_forces` / `bending_moments`
+ *                (both may be NULL: a caller that re-solves once after the loop rounds V / M itself)
  * Device pointers, asynchronous on `stream`, nothing allocated.  Ne <= 512. */
 int ops_beam_sizing_step_f32(int B, int Ne, float* I, double* I64, const double* V, const double* M,
                              float* exp_avg, float* exp_avg_sq, float* best_loss, int32_t* patience_cnt,

@@ -15,6 +15,7 @@ LIB_PATH = os.environ.get("OPS_AMD_LIB") or os.path.join(_PKG, "lib", "libopenpy
 # every symbol include/openpystruct_amd.h declares
 EXPORTS = (
     "ops_beam_solve_batched_f64",
+    "ops_beam_solve_forces_f64",
     "ops_beam_sizing_step_f32",
     "ops_beam_residual_f64",
     "ops_beam_residual_vjp_f64",
@@ -68,6 +69,9 @@ def load():
     f = lib.ops_beam_solve_batched_f64
     f.restype = it
     f.argtypes = [it, it, vp, lg, vp, lg, vp, lg, vp, lg, vp, lg, vp, lg, vp, vp, vp, vp, vp, it, vp]
+    ff = lib.ops_beam_solve_forces_f64
+    ff.restype = it
+    ff.argtypes = [it, it, vp, lg, vp, lg, vp, lg, vp, lg, vp, lg, vp, lg, vp, vp, vp, vp, it, vp]
     g = lib.ops_beam_sizing_step_f32
     g.restype = it
     g.argtypes = [it, it] + [vp] * 13 + [ctypes.POINTER(SizingParams), vp]

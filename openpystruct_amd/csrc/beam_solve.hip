@@ -33,6 +33,7 @@ struct BeamParams {
   const double* wy; long wy_bs;
   double* v; double* theta; double* V; double* M;
   int32_t* status;
+  const uint8_t* active;       // optional [B]: a wave whose beams are all inactive returns at once (sizing epochs)
   // host-derived: rows of I/Fy/outputs are dense and every wave's chunk is 16-byte aligned, so
   // the wave moves its beams as one flat run of 16-byte accesses; magic numbers for idx / Ne, idx / N
   int dense;
@@ -257,6 +258,11 @@ __global__ __launch_bounds__(64, waves_per_simd(P, M, SHARED)) void beam_solve_k
   const long beam0 = (long)blockIdx.x * BPW;
   const int nb = (p.B - beam0 < BPW) ? (int)(p.B - beam0) : BPW;   // live beams of this wave
   const int nE = nb * Ne, nN = nb * N;
+  if (p.active) {                   // wave-uniform: finished cases of a sizing run cost one scalar load
+    unsigned any = 0;
+    for (int b = 0; b < nb; ++b) any |= p.active[beam0 + b];
+    if (!any) return;
+  }
 
   // ---- stage 1a: every global load is issued before anything waits; cache-resident ones FIRST ----
   // (vmcnt retires in order: the element-table inputs and the constraint bytes hit in L2 and go out before
@@ -447,6 +453,7 @@ __global__ __launch_bounds__(64, waves_per_simd(P, M, SHARED)) void beam_solve_k
       p.M[beam0 * Ne + idx] = s_a[idx];
     }
   }
+  if (!p.v) return;                 // forces-only call (wave-uniform): the sizing epochs never read displacements
   wave_lds_fence();
   // nodal rows (flat, stride N)
   lds_store_desc<M>(cntN ? &s_b[g * N + e0] : s_dummy, cntN ? (unsigned)(cntN - 1) : 0u, out.v);
@@ -549,13 +556,13 @@ const char* ops_beam_solve_kernel_name(int B, int Ne, int tiling) {
   return t ? t->name_shared : "";
 }
 
-int ops_beam_solve_batched_f64(int B, int Ne, const double* x, long x_bstride, const double* E, long E_bstride,
-                               const double* I, long I_bstride, const uint8_t* fix, long fix_bstride,
-                               const double* Fy, long Fy_bstride, const double* wy, long wy_bstride, double* v,
-                               double* theta, double* V, double* M, int32_t* status, int tiling, void* stream) {
+static int solve_impl(int B, int Ne, const double* x, long x_bstride, const double* E, long E_bstride,
+                      const double* I, long I_bstride, const uint8_t* fix, long fix_bstride,
+                      const double* Fy, long Fy_bstride, const double* wy, long wy_bstride, double* v,
+                      double* theta, double* V, double* M, int32_t* status, const uint8_t* active, int tiling, void* stream) {
   if (B < 0 || Ne < 1) return OPS_AMD_ERR_INVALID_ARG;
   if (B == 0) return OPS_AMD_OK;
-  if (!x || !E || !I || !fix || !Fy || !wy || !v || !theta || !V || !M) return OPS_AMD_ERR_INVALID_ARG;
+  if (!x || !E || !I || !fix || !Fy || !wy || !V || !M || ((v == nullptr) != (theta == nullptr))) return OPS_AMD_ERR_INVALID_ARG;
   if (I_bstride < Ne || Fy_bstride < Ne + 1) return OPS_AMD_ERR_INVALID_ARG;
   if ((x_bstride != 0 && x_bstride < Ne + 1) || (fix_bstride != 0 && fix_bstride < Ne + 1) ||
       (E_bstride != 0 && E_bstride < Ne) || (wy_bstride != 0 && wy_bstride < Ne))
@@ -565,7 +572,7 @@ int ops_beam_solve_batched_f64(int B, int Ne, const double* x, long x_bstride, c
   if (!t) return tiling ? OPS_AMD_ERR_INVALID_ARG : OPS_AMD_ERR_UNSUPPORTED;
 
   BeamParams p{B, Ne, x, x_bstride, E, E_bstride, I, I_bstride, fix, fix_bstride, Fy, Fy_bstride,
-               wy, wy_bstride, v, theta, V, M, status, 0, nullptr, 0u, 0u};
+               wy, wy_bstride, v, theta, V, M, status, active, 0, nullptr, 0u, 0u};
 #ifdef OPS_AMD_TRACE
   { const char* e = getenv("OPS_AMD_TRACE_PTR"); if (e) p.trace = (unsigned long long*)strtoull(e, nullptr, 0); }
 #endif
@@ -595,6 +602,23 @@ int ops_beam_solve_batched_f64(int B, int Ne, const double* x, long x_bstride, c
     return OPS_AMD_ERR_LAUNCH;
   }
   return OPS_AMD_OK;
+}
+
+int ops_beam_solve_batched_f64(int B, int Ne, const double* x, long x_bstride, const double* E, long E_bstride,
+                               const double* I, long I_bstride, const uint8_t* fix, long fix_bstride,
+                               const double* Fy, long Fy_bstride, const double* wy, long wy_bstride, double* v,
+                               double* theta, double* V, double* M, int32_t* status, int tiling, void* stream) {
+  if (B > 0 && Ne >= 1 && (!v || !theta)) return OPS_AMD_ERR_INVALID_ARG;
+  return solve_impl(B, Ne, x, x_bstride, E, E_bstride, I, I_bstride, fix, fix_bstride, Fy, Fy_bstride, wy, wy_bstride, v, theta, V, M,
+                    status, nullptr, tiling, stream);
+}
+
+int ops_beam_solve_forces_f64(int B, int Ne, const double* x, long x_bstride, const double* E, long E_bstride,
+                              const double* I, long I_bstride, const uint8_t* fix, long fix_bstride,
+                              const double* Fy, long Fy_bstride, const double* wy, long wy_bstride, double* V, double* M,
+                              int32_t* status, const uint8_t* active, int tiling, void* stream) {
+  return solve_impl(B, Ne, x, x_bstride, E, E_bstride, I, I_bstride, fix, fix_bstride, Fy, Fy_bstride, wy, wy_bstride, nullptr, nullptr,
+                    V, M, status, active, tiling, stream);
 }
 
 }  // extern "C"

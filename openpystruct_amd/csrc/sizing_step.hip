@@ -57,8 +57,7 @@ __global__ __launch_bounds__(256) void sizing_step_kernel(int B, int Ne, float* 
       const long o = b * Ne + e;
       const float Ie = I[o];
       const float m = (float)M[o], v = (float)V[o];      // torch.tensor(..., dtype=float32)
-      V32[o] = v;
-      M32[o] = m;
+      if (V32) { V32[o] = v; M32[o] = m; }                            // wave-uniform: the generator rounds them once, at the end
       const float den_b = twoE * Ie + (float)hp.bend_eps;              // 2*E*I + 1e-6
       const float sq = sqrtf(Ie);                                      // I ** 0.5
       const float den_s = Gf * ((float)hp.area_coef * sq);             // G * (0.03 * I**0.5)
@@ -110,7 +109,7 @@ extern "C" int ops_beam_sizing_step_f32(int B, int Ne, float* I, double* I64, co
   if (B < 0 || Ne < 1 || Ne > 512) return Ne > 512 ? OPS_AMD_ERR_UNSUPPORTED : OPS_AMD_ERR_INVALID_ARG;
   if (B == 0) return OPS_AMD_OK;
   if (!I || !I64 || !V || !M || !exp_avg || !exp_avg_sq || !best_loss || !patience_cnt || !epochs_run || !active ||
-      !last_loss || !V32 || !M32 || !hp)
+      !last_loss || ((V32 == nullptr) != (M32 == nullptr)) || !hp)
     return OPS_AMD_ERR_INVALID_ARG;
   const unsigned grid = (unsigned)((B + 3) / 4);
   hipLaunchKernelGGL(opsamd::sizing_step_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, B, Ne, I, I64, V, M,

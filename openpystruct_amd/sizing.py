@@ -240,24 +240,41 @@ class SizingState:
         self.epochs_run = torch.zeros((B,), dtype=torch.int32, device=device)
         self.active = torch.ones((B,), dtype=torch.uint8, device=device)
         self.last_loss = torch.zeros((B,), **f32)
-        self.V32 = torch.zeros((B, Ne), **f32)
-        self.M32 = torch.zeros((B, Ne), **f32)
+        self.V32: Optional[torch.Tensor] = None      # set by finalize()
+        self.M32: Optional[torch.Tensor] = None
         self.sol: Optional[BeamSolution] = None
+        self._V = torch.empty((B, Ne), **f64)         # element end forces of the epoch's solve
+        self._M = torch.empty((B, Ne), **f64)
+        self._status = torch.zeros((B,), dtype=torch.int32, device=device)
         self._hp = cfg.c_params()
 
     def epoch(self) -> None:
-        """One epoch for every case of the shard: FE solve (:176-190) then optimiser step (:195-219)."""
-        self.sol = beam_solve(self.x, self.E, self.I64, self.fix, self.Fy, self.wy, out=self.sol)
+        """One epoch for every case of the shard: FE solve (:176-190) then optimiser step (:195-219).  Inside the loop
+        the reference reads only eleResponse: the solve writes forces only and skips wavefronts of finished cases."""
         lib = _cabi.load()
+        N, Ne = self.N, self.Ne
         with torch.cuda.device(self.device):
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+            rc = lib.ops_beam_solve_forces_f64(
+                self.B, Ne, self.x.data_ptr(), N if self.x.dim() == 2 else 0, self.E.data_ptr(), 0, self.I64.data_ptr(), Ne,
+                self.fix.data_ptr(), N if self.fix.dim() == 2 else 0, self.Fy.data_ptr(), N, self.wy.data_ptr(), 0,
+                self._V.data_ptr(), self._M.data_ptr(), self._status.data_ptr(), self.active.data_ptr(), 0, stream)
+            if rc != _cabi.OK:
+                raise RuntimeError(f"ops_beam_solve_forces_f64 failed with code {rc}: {lib.ops_amd_last_error().decode()}")
             rc = lib.ops_beam_sizing_step_f32(
-                self.B, self.Ne, self.I.data_ptr(), self.I64.data_ptr(), self.sol.V.data_ptr(), self.sol.M.data_ptr(),
+                self.B, Ne, self.I.data_ptr(), self.I64.data_ptr(), self._V.data_ptr(), self._M.data_ptr(),
                 self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(), self.best_loss.data_ptr(),
                 self.patience_cnt.data_ptr(), self.epochs_run.data_ptr(), self.active.data_ptr(),
-                self.last_loss.data_ptr(), self.V32.data_ptr(), self.M32.data_ptr(), ctypes.byref(self._hp),
-                torch.cuda.current_stream(self.device).cuda_stream)
+                self.last_loss.data_ptr(), None, None, ctypes.byref(self._hp), stream)
         if rc != _cabi.OK:
             raise RuntimeError(f"ops_beam_sizing_step_f32 failed with code {rc}")
+
+    def finalize(self) -> None:
+        """What the reference reads after the loop (:224-232) and records (:239-249): the state of every case's LAST
+        solve.  `I64` froze when a case stopped, so one full solve reproduces it -- displacements included -- and the
+        float32 roundings of shear / moment (:189-190) are taken from it."""
+        self.sol = beam_solve(self.x, self.E, self.I64, self.fix, self.Fy, self.wy, out=self.sol)
+        self.V32, self.M32 = self.sol.V.float(), self.sol.M.float()
 
 
 def optimize_cases(cases: Cases, cfg: SizingConfig, device, poll_every: int = 25, use_graph: bool = True) -> SizingState:
@@ -293,6 +310,7 @@ def optimize_cases(cases: Cases, cfg: SizingConfig, device, poll_every: int = 25
         if not bool(st.active.any()):       # the only host sync, once per `poll_every` epochs
             break
     # a case that is still active here ran out of max_e inside the step kernel already (it clears `active`)
+    st.finalize()
     torch.cuda.synchronize(device)
     return st
 

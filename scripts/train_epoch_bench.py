@@ -44,7 +44,7 @@ def main():
     t_gen = time.perf_counter() - t0
     solves = int(rec["epochs_run"].sum())
     d = dataprep.prepare(rec, kind=a.kind, device=dev, distributed=world > 1)
-    out = train.train_surrogate(a.kind, d, device=dev, max_epochs=a.epochs, log=(lambda m: print(m, file=sys.stderr)) if rank == 0 else None)
+    out = train.train_surrogate(a.kind, d, device=dev, max_epochs=a.epochs, autocast_dtype=(None if os.environ.get("AC", "1") == "0" else torch.bfloat16), log=(lambda m: print(m, file=sys.stderr)) if rank == 0 else None)
     ep = out["history"]["epoch_s"][1:] or out["history"]["epoch_s"]
     if rank == 0:
         print(json.dumps({"metric": f"{a.kind} epoch time", "value": sum(ep) / len(ep), "unit": "s", "n_gpus": world,
