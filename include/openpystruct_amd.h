@@ -87,6 +87,11 @@ int ops_beam_solve_forces_f64(int B, int Ne, const double* x, long x_bstride, co
                               const double* I, long I_bstride, const uint8_t* fix, long fix_bstride,
                               const double* Fy, long Fy_bstride, const double* wy, long wy_bstride, double* V, double* M,
                               int32_t* status, const uint8_t* active, int tiling, void* stream);
+/* ... and with the forces already rounded to float32 rows (what SingleCore.py:189-190 does with them): half the bytes. */
+int ops_beam_solve_forces_f32(int B, int Ne, const double* x, long x_bstride, const double* E, long E_bstride,
+                              const double* I, long I_bstride, const uint8_t* fix, long fix_bstride,
+                              const double* Fy, long Fy_bstride, const double* wy, long wy_bstride, float* V32, float* M32,
+                              int32_t* status, const uint8_t* active, int tiling, void* stream);
 
 /* Hyper-parameters of the per-case sizing optimiser (module-level constants of the reference,
  * SingleCore.py:20-44): E, G = E / 2.6, alpha_moment = alpha_shear = 1e-2, lr = 0.01, gamma = 0.98,
@@ -121,6 +126,14 @@ int ops_beam_sizing_step_f32(int B, int Ne, float* I, double* I64, const double*
                              float* exp_avg, float* exp_avg_sq, float* best_loss, int32_t* patience_cnt,
                              int32_t* epochs_run, uint8_t* active, float* last_loss, float* V32, float* M32,
                              const ops_sizing_params* hp, void* stream);
+/* The same step reading the float32 rows written by ops_beam_solve_forces_f32 (they ARE the recorded V32 / M32).
+ * `schedule` (device, [max_epochs, 2] float32, or NULL): per-epoch step size and sqrt(1 - beta2^(t+1)) as tabulated on
+ * the host by ops_sizing_schedule_f32 -- without it every wavefront evaluates three double-precision pow(). */
+int ops_beam_sizing_step_vm32_f32(int B, int Ne, float* I, double* I64, const float* V32, const float* M32,
+                                  float* exp_avg, float* exp_avg_sq, float* best_loss, int32_t* patience_cnt,
+                                  int32_t* epochs_run, uint8_t* active, float* last_loss, const ops_sizing_params* hp,
+                                  const float* schedule, void* stream);
+void ops_sizing_schedule_f32(const ops_sizing_params* hp, float* schedule_host /* [max_epochs, 2] */);
 
 /* Matrix-free FE residual for physics losses (an addition: the reference's "PINN" has no FE operator).
  *   r = D (K(I) u - f):  rv, rt [B,N]; D zeroes the fixed DOFs; f = Fy + consistent beamUniform loads.

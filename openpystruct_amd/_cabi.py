@@ -16,6 +16,9 @@ LIB_PATH = os.environ.get("OPS_AMD_LIB") or os.path.join(_PKG, "lib", "libopenpy
 EXPORTS = (
     "ops_beam_solve_batched_f64",
     "ops_beam_solve_forces_f64",
+    "ops_beam_solve_forces_f32",
+    "ops_beam_sizing_step_vm32_f32",
+    "ops_sizing_schedule_f32",
     "ops_beam_sizing_step_f32",
     "ops_beam_residual_f64",
     "ops_beam_residual_vjp_f64",
@@ -72,6 +75,12 @@ def load():
     ff = lib.ops_beam_solve_forces_f64
     ff.restype = it
     ff.argtypes = [it, it, vp, lg, vp, lg, vp, lg, vp, lg, vp, lg, vp, lg, vp, vp, vp, vp, it, vp]
+    lib.ops_beam_solve_forces_f32.restype = it
+    lib.ops_beam_solve_forces_f32.argtypes = ff.argtypes
+    lib.ops_beam_sizing_step_vm32_f32.restype = it
+    lib.ops_beam_sizing_step_vm32_f32.argtypes = [it, it] + [vp] * 11 + [ctypes.POINTER(SizingParams), vp, vp]
+    lib.ops_sizing_schedule_f32.restype = None
+    lib.ops_sizing_schedule_f32.argtypes = [ctypes.POINTER(SizingParams), vp]
     g = lib.ops_beam_sizing_step_f32
     g.restype = it
     g.argtypes = [it, it] + [vp] * 13 + [ctypes.POINTER(SizingParams), vp]

@@ -34,6 +34,7 @@ struct BeamParams {
   double* v; double* theta; double* V; double* M;
   int32_t* status;
   const uint8_t* active;       // optional [B]: a wave whose beams are all inactive returns at once (sizing epochs)
+  int f32_forces;              // V / M point to float rows (the sizing loop rounds them to float32 anyway, SingleCore.py:189-190)
   // host-derived: rows of I/Fy/outputs are dense and every wave's chunk is 16-byte aligned, so
   // the wave moves its beams as one flat run of 16-byte accesses; magic numbers for idx / Ne, idx / N
   int dense;
@@ -432,6 +433,28 @@ __global__ __launch_bounds__(64, waves_per_simd(P, M, SHARED)) void beam_solve_k
   // element rows: V already in s_b (flat, stride Ne); M joins it in s_a now that I is dead
   lds_store_desc<M>(cntE ? &s_a[g * Ne + e0] : s_dummy, out.lastE, out.Mz);
   wave_lds_fence();
+  if (p.f32_forces) {               // wave-uniform; forces-only by construction (host-checked)
+    float* V32 = reinterpret_cast<float*>(p.V) + beam0 * Ne;
+    float* M32 = reinterpret_cast<float*>(p.M) + beam0 * Ne;
+    if (DENSE) {
+      const __amdgpu_buffer_rsrc_t rV = make_rsrc(V32, (unsigned)nE * 4u);
+      const __amdgpu_buffer_rsrc_t rM = make_rsrc(M32, (unsigned)nE * 4u);
+#pragma unroll
+      for (int k = 0; k < NPAIR; ++k) {
+        const unsigned i0 = 2u * (lane + 64u * k);
+        if (k + 1 < NPAIR || i0 < BPW * PM) {
+          const double2 dv = *reinterpret_cast<const double2*>(&s_b[i0]), dm = *reinterpret_cast<const double2*>(&s_a[i0]);
+          const float2 fv = make_float2((float)dv.x, (float)dv.y), fm = make_float2((float)dm.x, (float)dm.y);
+          __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2i, fv), rV, (int)(i0 * 4u), 0, ST);
+          __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2i, fm), rM, (int)(i0 * 4u), 0, ST);
+        }
+      }
+      if ((nE & 1) && lane == 0) { V32[nE - 1] = (float)s_b[nE - 1]; M32[nE - 1] = (float)s_a[nE - 1]; }
+    } else {
+      for (int idx = lane; idx < nE; idx += 64) { V32[idx] = (float)s_b[idx]; M32[idx] = (float)s_a[idx]; }
+    }
+    return;
+  }
   if (DENSE) {
     const __amdgpu_buffer_rsrc_t rV = make_rsrc(p.V + beam0 * Ne, (unsigned)nE * 8u);
     const __amdgpu_buffer_rsrc_t rM = make_rsrc(p.M + beam0 * Ne, (unsigned)nE * 8u);
@@ -559,7 +582,8 @@ const char* ops_beam_solve_kernel_name(int B, int Ne, int tiling) {
 static int solve_impl(int B, int Ne, const double* x, long x_bstride, const double* E, long E_bstride,
                       const double* I, long I_bstride, const uint8_t* fix, long fix_bstride,
                       const double* Fy, long Fy_bstride, const double* wy, long wy_bstride, double* v,
-                      double* theta, double* V, double* M, int32_t* status, const uint8_t* active, int tiling, void* stream) {
+                      double* theta, double* V, double* M, int32_t* status, const uint8_t* active, int f32_forces, int tiling,
+                      void* stream) {
   if (B < 0 || Ne < 1) return OPS_AMD_ERR_INVALID_ARG;
   if (B == 0) return OPS_AMD_OK;
   if (!x || !E || !I || !fix || !Fy || !wy || !V || !M || ((v == nullptr) != (theta == nullptr))) return OPS_AMD_ERR_INVALID_ARG;
@@ -572,7 +596,7 @@ static int solve_impl(int B, int Ne, const double* x, long x_bstride, const doub
   if (!t) return tiling ? OPS_AMD_ERR_INVALID_ARG : OPS_AMD_ERR_UNSUPPORTED;
 
   BeamParams p{B, Ne, x, x_bstride, E, E_bstride, I, I_bstride, fix, fix_bstride, Fy, Fy_bstride,
-               wy, wy_bstride, v, theta, V, M, status, active, 0, nullptr, 0u, 0u};
+               wy, wy_bstride, v, theta, V, M, status, active, f32_forces, 0, nullptr, 0u, 0u};
 #ifdef OPS_AMD_TRACE
   { const char* e = getenv("OPS_AMD_TRACE_PTR"); if (e) p.trace = (unsigned long long*)strtoull(e, nullptr, 0); }
 #endif
@@ -610,7 +634,7 @@ int ops_beam_solve_batched_f64(int B, int Ne, const double* x, long x_bstride, c
                                double* theta, double* V, double* M, int32_t* status, int tiling, void* stream) {
   if (B > 0 && Ne >= 1 && (!v || !theta)) return OPS_AMD_ERR_INVALID_ARG;
   return solve_impl(B, Ne, x, x_bstride, E, E_bstride, I, I_bstride, fix, fix_bstride, Fy, Fy_bstride, wy, wy_bstride, v, theta, V, M,
-                    status, nullptr, tiling, stream);
+                    status, nullptr, 0, tiling, stream);
 }
 
 int ops_beam_solve_forces_f64(int B, int Ne, const double* x, long x_bstride, const double* E, long E_bstride,
@@ -618,7 +642,15 @@ int ops_beam_solve_forces_f64(int B, int Ne, const double* x, long x_bstride, co
                               const double* Fy, long Fy_bstride, const double* wy, long wy_bstride, double* V, double* M,
                               int32_t* status, const uint8_t* active, int tiling, void* stream) {
   return solve_impl(B, Ne, x, x_bstride, E, E_bstride, I, I_bstride, fix, fix_bstride, Fy, Fy_bstride, wy, wy_bstride, nullptr, nullptr,
-                    V, M, status, active, tiling, stream);
+                    V, M, status, active, 0, tiling, stream);
+}
+
+int ops_beam_solve_forces_f32(int B, int Ne, const double* x, long x_bstride, const double* E, long E_bstride,
+                              const double* I, long I_bstride, const uint8_t* fix, long fix_bstride,
+                              const double* Fy, long Fy_bstride, const double* wy, long wy_bstride, float* V32, float* M32,
+                              int32_t* status, const uint8_t* active, int tiling, void* stream) {
+  return solve_impl(B, Ne, x, x_bstride, E, E_bstride, I, I_bstride, fix, fix_bstride, Fy, Fy_bstride, wy, wy_bstride, nullptr, nullptr,
+                    reinterpret_cast<double*>(V32), reinterpret_cast<double*>(M32), status, active, 1, tiling, stream);
 }
 
 }  // extern "C"

@@ -29,23 +29,33 @@ __device__ __forceinline__ float wave_sum(float x) {
   return x;
 }
 
+template <typename TVM>   // double: the solver's rows; float: rows the solver already rounded (ops_beam_solve_forces_f32)
 __global__ __launch_bounds__(256) void sizing_step_kernel(int B, int Ne, float* __restrict__ I, double* __restrict__ I64,
-                                                          const double* __restrict__ V, const double* __restrict__ M,
+                                                          const TVM* __restrict__ V, const TVM* __restrict__ M,
                                                           float* __restrict__ exp_avg, float* __restrict__ exp_avg_sq,
                                                           float* __restrict__ best_loss, int32_t* __restrict__ patience_cnt,
                                                           int32_t* __restrict__ epochs_run, uint8_t* __restrict__ active,
                                                           float* __restrict__ last_loss, float* __restrict__ V32,
-                                                          float* __restrict__ M32, const ops_sizing_params hp) {
+                                                          float* __restrict__ M32, const ops_sizing_params hp,
+                                                          const float* __restrict__ schedule) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const long b = (long)blockIdx.x * 4 + wave;
   if (b >= B) return;
   if (!active[b]) return;   // wave-uniform
   const int t = epochs_run[b];          // 0-based epoch of this case == optimiser step count so far
   const float twoE = (float)(2.0 * hp.E), Gf = (float)hp.G;
-  const float lr_t = (float)(hp.lr * pow(hp.gamma, (double)t));
-  const float bc1 = (float)(1.0 - pow(hp.beta1, (double)(t + 1)));
-  const float bc2s = (float)sqrt(1.0 - pow(hp.beta2, (double)(t + 1)));
-  const float step_size = lr_t / bc1;
+  // step_size = lr gamma^t / (1 - beta1^(t+1)) and sqrt(1 - beta2^(t+1)): three double-precision pow() per wavefront cost
+  // more than the rest of the kernel (0.33 ms of a 0.4 ms epoch at 2e5 cases); callers may pass them tabulated per epoch
+  float step_size, bc2s;
+  if (schedule) {
+    step_size = schedule[2 * t];
+    bc2s = schedule[2 * t + 1];
+  } else {
+    const float lr_t = (float)(hp.lr * pow(hp.gamma, (double)t));
+    const float bc1 = (float)(1.0 - pow(hp.beta1, (double)(t + 1)));
+    bc2s = (float)sqrt(1.0 - pow(hp.beta2, (double)(t + 1)));
+    step_size = lr_t / bc1;
+  }
   float lsum_I = 0.f, lsum_b = 0.f, lsum_s = 0.f;
   constexpr int KMAX = 8;               // Ne <= 512
   float Inew[KMAX];
@@ -112,7 +122,32 @@ extern "C" int ops_beam_sizing_step_f32(int B, int Ne, float* I, double* I64, co
       !last_loss || ((V32 == nullptr) != (M32 == nullptr)) || !hp)
     return OPS_AMD_ERR_INVALID_ARG;
   const unsigned grid = (unsigned)((B + 3) / 4);
-  hipLaunchKernelGGL(opsamd::sizing_step_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, B, Ne, I, I64, V, M,
-                     exp_avg, exp_avg_sq, best_loss, patience_cnt, epochs_run, active, last_loss, V32, M32, *hp);
+  hipLaunchKernelGGL(opsamd::sizing_step_kernel<double>, dim3(grid), dim3(256), 0, (hipStream_t)stream, B, Ne, I, I64, V, M,
+                     exp_avg, exp_avg_sq, best_loss, patience_cnt, epochs_run, active, last_loss, V32, M32, *hp, (const float*)nullptr);
+  return hipGetLastError() == hipSuccess ? OPS_AMD_OK : OPS_AMD_ERR_LAUNCH;
+}
+
+// schedule[2 t] = (float)(lr gamma^t) / (float)(1 - beta1^(t+1)), schedule[2 t + 1] = (float)sqrt(1 - beta2^(t+1)), t < max_epochs
+extern "C" void ops_sizing_schedule_f32(const ops_sizing_params* hp, float* schedule_host) {
+  for (int t = 0; t < hp->max_epochs; ++t) {
+    const float lr_t = (float)(hp->lr * pow(hp->gamma, (double)t));
+    const float bc1 = (float)(1.0 - pow(hp->beta1, (double)(t + 1)));
+    schedule_host[2 * t] = lr_t / bc1;
+    schedule_host[2 * t + 1] = (float)sqrt(1.0 - pow(hp->beta2, (double)(t + 1)));
+  }
+}
+
+extern "C" int ops_beam_sizing_step_vm32_f32(int B, int Ne, float* I, double* I64, const float* V32, const float* M32,
+                                             float* exp_avg, float* exp_avg_sq, float* best_loss, int32_t* patience_cnt,
+                                             int32_t* epochs_run, uint8_t* active, float* last_loss, const ops_sizing_params* hp,
+                                             const float* schedule, void* stream) {
+  if (B < 0 || Ne < 1 || Ne > 512) return Ne > 512 ? OPS_AMD_ERR_UNSUPPORTED : OPS_AMD_ERR_INVALID_ARG;
+  if (B == 0) return OPS_AMD_OK;
+  if (!I || !I64 || !V32 || !M32 || !exp_avg || !exp_avg_sq || !best_loss || !patience_cnt || !epochs_run || !active || !last_loss || !hp)
+    return OPS_AMD_ERR_INVALID_ARG;
+  const unsigned grid = (unsigned)((B + 3) / 4);
+  hipLaunchKernelGGL(opsamd::sizing_step_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, B, Ne, I, I64, V32, M32,
+                     exp_avg, exp_avg_sq, best_loss, patience_cnt, epochs_run, active, last_loss, (float*)nullptr, (float*)nullptr, *hp,
+                     schedule);
   return hipGetLastError() == hipSuccess ? OPS_AMD_OK : OPS_AMD_ERR_LAUNCH;
 }

@@ -243,10 +243,13 @@ class SizingState:
         self.V32: Optional[torch.Tensor] = None      # set by finalize()
         self.M32: Optional[torch.Tensor] = None
         self.sol: Optional[BeamSolution] = None
-        self._V = torch.empty((B, Ne), **f64)         # element end forces of the epoch's solve
-        self._M = torch.empty((B, Ne), **f64)
+        self._V = torch.empty((B, Ne), **f32)         # element end forces of the epoch's solve, rounded like :189-190
+        self._M = torch.empty((B, Ne), **f32)
         self._status = torch.zeros((B,), dtype=torch.int32, device=device)
         self._hp = cfg.c_params()
+        sched = np.zeros((max(int(cfg.max_e), 1), 2), dtype=np.float32)          # per-epoch step size / bias correction
+        _cabi.load().ops_sizing_schedule_f32(ctypes.byref(self._hp), sched.ctypes.data)
+        self._schedule = torch.as_tensor(sched, device=device)
 
     def epoch(self) -> None:
         """One epoch for every case of the shard: FE solve (:176-190) then optimiser step (:195-219).  Inside the loop
@@ -255,19 +258,19 @@ class SizingState:
         N, Ne = self.N, self.Ne
         with torch.cuda.device(self.device):
             stream = torch.cuda.current_stream(self.device).cuda_stream
-            rc = lib.ops_beam_solve_forces_f64(
+            rc = lib.ops_beam_solve_forces_f32(
                 self.B, Ne, self.x.data_ptr(), N if self.x.dim() == 2 else 0, self.E.data_ptr(), 0, self.I64.data_ptr(), Ne,
                 self.fix.data_ptr(), N if self.fix.dim() == 2 else 0, self.Fy.data_ptr(), N, self.wy.data_ptr(), 0,
                 self._V.data_ptr(), self._M.data_ptr(), self._status.data_ptr(), self.active.data_ptr(), 0, stream)
             if rc != _cabi.OK:
-                raise RuntimeError(f"ops_beam_solve_forces_f64 failed with code {rc}: {lib.ops_amd_last_error().decode()}")
-            rc = lib.ops_beam_sizing_step_f32(
+                raise RuntimeError(f"ops_beam_solve_forces_f32 failed with code {rc}: {lib.ops_amd_last_error().decode()}")
+            rc = lib.ops_beam_sizing_step_vm32_f32(
                 self.B, Ne, self.I.data_ptr(), self.I64.data_ptr(), self._V.data_ptr(), self._M.data_ptr(),
                 self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(), self.best_loss.data_ptr(),
                 self.patience_cnt.data_ptr(), self.epochs_run.data_ptr(), self.active.data_ptr(),
-                self.last_loss.data_ptr(), None, None, ctypes.byref(self._hp), stream)
+                self.last_loss.data_ptr(), ctypes.byref(self._hp), self._schedule.data_ptr(), stream)
         if rc != _cabi.OK:
-            raise RuntimeError(f"ops_beam_sizing_step_f32 failed with code {rc}")
+            raise RuntimeError(f"ops_beam_sizing_step_vm32_f32 failed with code {rc}")
 
     def finalize(self) -> None:
         """What the reference reads after the loop (:224-232) and records (:239-249): the state of every case's LAST

@@ -155,3 +155,32 @@ def test_beam_opt_variant_against_oracle(oa):
         if int(ep[b]) == ref["epochs_run"]:
             Iref = np.array(ref["I_values"])
             assert np.abs(st.I[b].cpu().numpy() - Iref).max() / Iref.max() < 3e-3
+
+
+def test_forces_only_entry_points_match_the_full_solve_and_honour_the_mask(oa):
+    """ops_beam_solve_forces_f64 / _f32: same V, M as the full solve (f32: rounded), inactive wavefronts untouched."""
+    import ctypes
+    from openpystruct_amd import _cabi
+    lib = _cabi.load()
+    rng = np.random.default_rng(5)
+    B, Ne, N = 37, 100, 101
+    I, Fy = bo.random_cases(rng, B, inertia="trajectory")
+    dev = "cuda"
+    x = torch.linspace(0, 200, N, dtype=torch.float64, device=dev)
+    fix = torch.as_tensor(bo.reference_fix_mask(), device=dev)
+    It, Ft = torch.as_tensor(I, device=dev), torch.as_tensor(Fy, device=dev)
+    E = torch.tensor(bo.E_REF, dtype=torch.float64, device=dev); wy = torch.tensor(bo.UDL_REF, dtype=torch.float64, device=dev)
+    ref = oa.beam_solve(x, E, It, fix, Ft, wy)
+    active = torch.ones(B, dtype=torch.uint8, device=dev); active[16:32] = 0       # wavefronts 4..7 of the 16-lane tiling: all inactive
+    for f32 in (False, True):
+        dt = torch.float32 if f32 else torch.float64
+        V = torch.full((B, Ne), -7.0, dtype=dt, device=dev); M = torch.full((B, Ne), -7.0, dtype=dt, device=dev)
+        st = torch.zeros(B, dtype=torch.int32, device=dev)
+        fn = lib.ops_beam_solve_forces_f32 if f32 else lib.ops_beam_solve_forces_f64
+        rc = fn(B, Ne, x.data_ptr(), 0, E.data_ptr(), 0, It.data_ptr(), Ne, fix.data_ptr(), 0, Ft.data_ptr(), N, wy.data_ptr(), 0,
+                V.data_ptr(), M.data_ptr(), st.data_ptr(), active.data_ptr(), 16, torch.cuda.current_stream().cuda_stream)
+        assert rc == _cabi.OK
+        torch.cuda.synchronize()
+        live = torch.ones(B, dtype=torch.bool, device=dev); live[16:32] = False
+        assert torch.equal(V[live], ref.V[live].to(dt)) and torch.equal(M[live], ref.M[live].to(dt))
+        assert bool((V[~live] == -7.0).all()) and bool((M[~live] == -7.0).all())
