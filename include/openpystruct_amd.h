@@ -135,6 +135,16 @@ int ops_beam_sizing_step_vm32_f32(int B, int Ne, float* I, double* I64, const fl
                                   const float* schedule, void* stream);
 void ops_sizing_schedule_f32(const ops_sizing_params* hp, float* schedule_host /* [max_epochs, 2] */);
 
+/* One WHOLE epoch of the reference's per-sample loop for B cases in one launch (SingleCore.py:176-219): the FE solve on
+ * I64 followed, in the same wavefront and on the forces it still holds in LDS, by the optimiser step above -- shear and
+ * moment never travel through HBM (the epoch moves ~48 instead of ~65 bytes per element).  Arguments as in
+ * ops_beam_solve_batched_f64 (geometry, supports, loads; I64 rows are dense) and ops_beam_sizing_step_vm32_f32 (state). */
+int ops_beam_sizing_epoch_f32(int B, int Ne, const double* x, long x_bstride, const double* E, long E_bstride,
+                              const uint8_t* fix, long fix_bstride, const double* Fy, long Fy_bstride, const double* wy,
+                              long wy_bstride, float* I, double* I64, float* exp_avg, float* exp_avg_sq, float* best_loss,
+                              int32_t* patience_cnt, int32_t* epochs_run, uint8_t* active, float* last_loss,
+                              const ops_sizing_params* hp, const float* schedule, int32_t* status, int tiling, void* stream);
+
 /* Matrix-free FE residual for physics losses (an addition: the reference's "PINN" has no FE operator).
  *   r = D (K(I) u - f):  rv, rt [B,N]; D zeroes the fixed DOFs; f = Fy + consistent beamUniform loads.
  * Same argument meaning / strides as ops_beam_solve_batched_f64; I, Fy, v, theta, rv, rt dense. */

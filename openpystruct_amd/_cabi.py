@@ -19,6 +19,7 @@ EXPORTS = (
     "ops_beam_solve_forces_f32",
     "ops_beam_sizing_step_vm32_f32",
     "ops_sizing_schedule_f32",
+    "ops_beam_sizing_epoch_f32",
     "ops_beam_sizing_step_f32",
     "ops_beam_residual_f64",
     "ops_beam_residual_vjp_f64",
@@ -81,6 +82,8 @@ def load():
     lib.ops_beam_sizing_step_vm32_f32.argtypes = [it, it] + [vp] * 11 + [ctypes.POINTER(SizingParams), vp, vp]
     lib.ops_sizing_schedule_f32.restype = None
     lib.ops_sizing_schedule_f32.argtypes = [ctypes.POINTER(SizingParams), vp]
+    lib.ops_beam_sizing_epoch_f32.restype = it
+    lib.ops_beam_sizing_epoch_f32.argtypes = [it, it, vp, lg, vp, lg, vp, lg, vp, lg, vp, lg] + [vp] * 9 + [ctypes.POINTER(SizingParams), vp, vp, it, vp]
     g = lib.ops_beam_sizing_step_f32
     g.restype = it
     g.argtypes = [it, it] + [vp] * 13 + [ctypes.POINTER(SizingParams), vp]

@@ -20,6 +20,7 @@
 
 #include "../../include/openpystruct_amd.h"
 #include "beam_math.hpp"
+#include "sizing_math.hpp"
 
 namespace opsamd {
 
@@ -238,8 +239,10 @@ __device__ __forceinline__ void buf_store_d(__amdgpu_buffer_rsrc_t r, unsigned b
 // SHARED: x, E and wy are the same for every beam (strides 0): one element table per workgroup.
 // DENSE : rows of I / Fy / outputs are contiguous and every wave's run is 16-byte aligned (host-checked):
 //         the wave moves each of its six streams as one flat run of 16-byte buffer accesses.
-template <int P, int M, bool SHARED, bool DENSE>
-__global__ __launch_bounds__(64, waves_per_simd(P, M, SHARED)) void beam_solve_kernel(const BeamParams p) {
+// SIZING: after the solve the wave runs the optimiser epoch of its cases on the forces it still holds in LDS
+//         (sizing_math.hpp) instead of writing them out: the fused solve + step of the dataset generator.
+template <int P, int M, bool SHARED, bool DENSE, bool SIZING>
+__device__ __forceinline__ void beam_body(const BeamParams& p, const SizingArgs* sz) {
   constexpr int BPW = 64 / P;       // beams per wavefront
   constexpr int PM = P * M;         // padded nodes per beam (>= N)
   constexpr int TG = SHARED ? 1 : BPW;
@@ -433,6 +436,24 @@ __global__ __launch_bounds__(64, waves_per_simd(P, M, SHARED)) void beam_solve_k
   // element rows: V already in s_b (flat, stride Ne); M joins it in s_a now that I is dead
   lds_store_desc<M>(cntE ? &s_a[g * Ne + e0] : s_dummy, out.lastE, out.Mz);
   wave_lds_fence();
+  if constexpr (SIZING) {           // V in s_b, M in s_a (flat, stride Ne): one optimiser epoch per live, active case
+    // every case's state loads go out before the first one is used (a wave holds BPW cases: one HBM latency, not BPW)
+    CaseRegs<2> cr[BPW];            // host-checked: Ne <= 128
+    bool on[BPW];
+#pragma unroll
+    for (int gb = 0; gb < BPW; ++gb) {
+      on[gb] = gb < nb && sz->active[beam0 + gb] != 0;     // wave-uniform
+      if (on[gb]) load_case<2>((int)lane, beam0 + gb, Ne, *sz, cr[gb]);
+    }
+#pragma unroll
+    for (int gb = 0; gb < BPW; ++gb) {
+      if (!on[gb]) continue;
+      const double* Vb = &s_b[gb * Ne];
+      const double* Mb = &s_a[gb * Ne];
+      step_case<2>((int)lane, beam0 + gb, Ne, *sz, cr[gb], [&](int e) { return (float)Vb[e]; }, [&](int e) { return (float)Mb[e]; });
+    }
+    return;
+  }
   if (p.f32_forces) {               // wave-uniform; forces-only by construction (host-checked)
     float* V32 = reinterpret_cast<float*>(p.V) + beam0 * Ne;
     float* M32 = reinterpret_cast<float*>(p.M) + beam0 * Ne;
@@ -513,6 +534,16 @@ __global__ __launch_bounds__(64, waves_per_simd(P, M, SHARED)) void beam_solve_k
 #endif
 }
 
+template <int P, int M, bool SHARED, bool DENSE>
+__global__ __launch_bounds__(64, waves_per_simd(P, M, SHARED)) void beam_solve_kernel(const BeamParams p) {
+  beam_body<P, M, SHARED, DENSE, false>(p, nullptr);
+}
+
+template <int P, int M, bool SHARED, bool DENSE>
+__global__ __launch_bounds__(64, waves_per_simd(P, M, SHARED)) void beam_sizing_epoch_kernel(const BeamParams p, const SizingArgs sz) {
+  beam_body<P, M, SHARED, DENSE, true>(p, &sz);
+}
+
 // ------------------------------------------------------------------------------------------
 // host side: tiling choice + launch
 // ------------------------------------------------------------------------------------------
@@ -564,6 +595,21 @@ static hipError_t launch(const BeamParams& p, bool shared, hipStream_t stream) {
   return hipGetLastError();
 }
 
+template <int P, int M>
+static hipError_t launch_sizing(const BeamParams& p, const SizingArgs& sz, bool shared, hipStream_t stream) {
+  constexpr int BPW = 64 / P;
+  const unsigned grid = (unsigned)((p.B + BPW - 1) / BPW);
+  if (shared && p.dense)
+    hipLaunchKernelGGL((beam_sizing_epoch_kernel<P, M, true, true>), dim3(grid), dim3(64), 0, stream, p, sz);
+  else if (shared)
+    hipLaunchKernelGGL((beam_sizing_epoch_kernel<P, M, true, false>), dim3(grid), dim3(64), 0, stream, p, sz);
+  else if (p.dense)
+    hipLaunchKernelGGL((beam_sizing_epoch_kernel<P, M, false, true>), dim3(grid), dim3(64), 0, stream, p, sz);
+  else
+    hipLaunchKernelGGL((beam_sizing_epoch_kernel<P, M, false, false>), dim3(grid), dim3(64), 0, stream, p, sz);
+  return hipGetLastError();
+}
+
 }  // namespace opsamd
 
 using namespace opsamd;
@@ -583,10 +629,10 @@ static int solve_impl(int B, int Ne, const double* x, long x_bstride, const doub
                       const double* I, long I_bstride, const uint8_t* fix, long fix_bstride,
                       const double* Fy, long Fy_bstride, const double* wy, long wy_bstride, double* v,
                       double* theta, double* V, double* M, int32_t* status, const uint8_t* active, int f32_forces, int tiling,
-                      void* stream) {
+                      void* stream, const SizingArgs* sz = nullptr) {
   if (B < 0 || Ne < 1) return OPS_AMD_ERR_INVALID_ARG;
   if (B == 0) return OPS_AMD_OK;
-  if (!x || !E || !I || !fix || !Fy || !wy || !V || !M || ((v == nullptr) != (theta == nullptr))) return OPS_AMD_ERR_INVALID_ARG;
+  if (!x || !E || !I || !fix || !Fy || !wy || ((!V || !M) && !sz) || ((v == nullptr) != (theta == nullptr))) return OPS_AMD_ERR_INVALID_ARG;
   if (I_bstride < Ne || Fy_bstride < Ne + 1) return OPS_AMD_ERR_INVALID_ARG;
   if ((x_bstride != 0 && x_bstride < Ne + 1) || (fix_bstride != 0 && fix_bstride < Ne + 1) ||
       (E_bstride != 0 && E_bstride < Ne) || (wy_bstride != 0 && wy_bstride < Ne))
@@ -611,7 +657,16 @@ static int solve_impl(int B, int Ne, const double* x, long x_bstride, const doub
   const bool shared = (x_bstride == 0 && E_bstride == 0 && wy_bstride == 0);
   hipStream_t s = (hipStream_t)stream;
   hipError_t err = hipSuccess;
-  if (t->P == 8 && t->M == 13) err = launch<8, 13>(p, shared, s);
+  if (sz) {
+    if (t->P == 8 && t->M == 13) err = launch_sizing<8, 13>(p, *sz, shared, s);
+    else if (t->P == 16 && t->M == 7) err = launch_sizing<16, 7>(p, *sz, shared, s);
+    else if (t->P == 32 && t->M == 4) err = launch_sizing<32, 4>(p, *sz, shared, s);
+    else if (t->P == 64 && t->M == 2) err = launch_sizing<64, 2>(p, *sz, shared, s);
+    else if (t->P == 64 && t->M == 4) err = launch_sizing<64, 4>(p, *sz, shared, s);
+    else if (t->P == 64 && t->M == 8) err = launch_sizing<64, 8>(p, *sz, shared, s);
+    else return OPS_AMD_ERR_UNSUPPORTED;
+  }
+  else if (t->P == 8 && t->M == 13) err = launch<8, 13>(p, shared, s);
   else if (t->P == 16 && t->M == 7) err = launch<16, 7>(p, shared, s);
   else if (t->P == 32 && t->M == 4) err = launch<32, 4>(p, shared, s);
   else if (t->P == 64 && t->M == 2) err = launch<64, 2>(p, shared, s);
@@ -643,6 +698,22 @@ int ops_beam_solve_forces_f64(int B, int Ne, const double* x, long x_bstride, co
                               int32_t* status, const uint8_t* active, int tiling, void* stream) {
   return solve_impl(B, Ne, x, x_bstride, E, E_bstride, I, I_bstride, fix, fix_bstride, Fy, Fy_bstride, wy, wy_bstride, nullptr, nullptr,
                     V, M, status, active, 0, tiling, stream);
+}
+
+int ops_beam_sizing_epoch_f32(int B, int Ne, const double* x, long x_bstride, const double* E, long E_bstride,
+                              const uint8_t* fix, long fix_bstride, const double* Fy, long Fy_bstride, const double* wy,
+                              long wy_bstride, float* I, double* I64, float* exp_avg, float* exp_avg_sq, float* best_loss,
+                              int32_t* patience_cnt, int32_t* epochs_run, uint8_t* active, float* last_loss,
+                              const ops_sizing_params* hp, const float* schedule, int32_t* status, int tiling, void* stream) {
+  if (Ne > 128) return OPS_AMD_ERR_UNSUPPORTED;       // two elements per lane in the fused step
+  if (!I || !I64 || !exp_avg || !exp_avg_sq || !best_loss || !patience_cnt || !epochs_run || !active || !last_loss || !hp)
+    return OPS_AMD_ERR_INVALID_ARG;
+  const SizingArgs sz{I, I64, exp_avg, exp_avg_sq, best_loss, patience_cnt, epochs_run, active, last_loss, nullptr, nullptr, *hp, schedule};
+  // the fused kernel carries the cases' optimiser state in registers next to the solve: the 16-lane tiling (three waves
+  // per SIMD) beats the 8-lane one at every batch size here (2e5 cases: 0.095 vs 0.104 s), unlike the plain solve
+  if (tiling == 0 && Ne + 1 <= 16 * 7) tiling = 16;
+  return solve_impl(B, Ne, x, x_bstride, E, E_bstride, I64, Ne, fix, fix_bstride, Fy, Fy_bstride, wy, wy_bstride, nullptr, nullptr,
+                    nullptr, nullptr, status, active, 0, tiling, stream, &sz);
 }
 
 int ops_beam_solve_forces_f32(int B, int Ne, const double* x, long x_bstride, const double* E, long E_bstride,

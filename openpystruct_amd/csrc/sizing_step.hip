@@ -20,94 +20,21 @@
 #include <stdint.h>
 
 #include "../../include/openpystruct_amd.h"
+#include "sizing_math.hpp"
 
 namespace opsamd {
 
-__device__ __forceinline__ float wave_sum(float x) {
-#pragma unroll
-  for (int s = 32; s >= 1; s >>= 1) x += __shfl_xor(x, s, 64);
-  return x;
-}
 
 template <typename TVM>   // double: the solver's rows; float: rows the solver already rounded (ops_beam_solve_forces_f32)
-__global__ __launch_bounds__(256) void sizing_step_kernel(int B, int Ne, float* __restrict__ I, double* __restrict__ I64,
-                                                          const TVM* __restrict__ V, const TVM* __restrict__ M,
-                                                          float* __restrict__ exp_avg, float* __restrict__ exp_avg_sq,
-                                                          float* __restrict__ best_loss, int32_t* __restrict__ patience_cnt,
-                                                          int32_t* __restrict__ epochs_run, uint8_t* __restrict__ active,
-                                                          float* __restrict__ last_loss, float* __restrict__ V32,
-                                                          float* __restrict__ M32, const ops_sizing_params hp,
-                                                          const float* __restrict__ schedule) {
+__global__ __launch_bounds__(256) void sizing_step_kernel(int B, int Ne, const TVM* __restrict__ V, const TVM* __restrict__ M,
+                                                          const SizingArgs a) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const long b = (long)blockIdx.x * 4 + wave;
   if (b >= B) return;
-  if (!active[b]) return;   // wave-uniform
-  const int t = epochs_run[b];          // 0-based epoch of this case == optimiser step count so far
-  const float twoE = (float)(2.0 * hp.E), Gf = (float)hp.G;
-  // step_size = lr gamma^t / (1 - beta1^(t+1)) and sqrt(1 - beta2^(t+1)): three double-precision pow() per wavefront cost
-  // more than the rest of the kernel (0.33 ms of a 0.4 ms epoch at 2e5 cases); callers may pass them tabulated per epoch
-  float step_size, bc2s;
-  if (schedule) {
-    step_size = schedule[2 * t];
-    bc2s = schedule[2 * t + 1];
-  } else {
-    const float lr_t = (float)(hp.lr * pow(hp.gamma, (double)t));
-    const float bc1 = (float)(1.0 - pow(hp.beta1, (double)(t + 1)));
-    bc2s = (float)sqrt(1.0 - pow(hp.beta2, (double)(t + 1)));
-    step_size = lr_t / bc1;
-  }
-  float lsum_I = 0.f, lsum_b = 0.f, lsum_s = 0.f;
-  constexpr int KMAX = 8;               // Ne <= 512
-  float Inew[KMAX];
-#pragma unroll
-  for (int k = 0; k < KMAX; ++k) {
-    const int e = lane + 64 * k;
-    Inew[k] = 0.f;
-    if (e < Ne) {
-      const long o = b * Ne + e;
-      const float Ie = I[o];
-      const float m = (float)M[o], v = (float)V[o];      // torch.tensor(..., dtype=float32)
-      if (V32) { V32[o] = v; M32[o] = m; }                            // wave-uniform: the generator rounds them once, at the end
-      const float den_b = twoE * Ie + (float)hp.bend_eps;              // 2*E*I + 1e-6
-      const float sq = sqrtf(Ie);                                      // I ** 0.5
-      const float den_s = Gf * ((float)hp.area_coef * sq);             // G * (0.03 * I**0.5)
-      lsum_I += Ie;
-      lsum_b += (m * m) / den_b;
-      lsum_s += (v * v) / den_s;
-      // d/dI: 1 - a_M * M^2 * 2E / den_b^2 - a_V * V^2 / den_s^2 * G * 0.03 * 0.5 / sqrt(I)
-      const float g = 1.0f - (float)hp.alpha_moment * ((m * m) / (den_b * den_b)) * twoE -
-                      (float)hp.alpha_shear * ((v * v) / (den_s * den_s)) * (Gf * (float)hp.area_coef * (0.5f / sq));
-      const float ea = (float)hp.beta1 * exp_avg[o] + (1.0f - (float)hp.beta1) * g;
-      const float es = (float)hp.beta2 * exp_avg_sq[o] + (1.0f - (float)hp.beta2) * g * g;
-      exp_avg[o] = ea;
-      exp_avg_sq[o] = es;
-      const float denom = sqrtf(es) / bc2s + (float)hp.adam_eps;
-      float In = Ie - step_size * (ea / denom);
-      In = fmaxf(In, (float)hp.clamp_min);
-      I[o] = In;
-      Inew[k] = In;
-    }
-  }
-  const float loss = wave_sum(lsum_I) + (float)hp.alpha_moment * wave_sum(lsum_b) + (float)hp.alpha_shear * wave_sum(lsum_s);
-  // early stopping (SingleCore.py:211-219), decided identically by every lane
-  float best = best_loss[b];
-  int cnt = patience_cnt[b];
-  if (loss < best - (float)hp.tolerance) { best = loss; cnt = 0; } else { cnt += 1; }
-  const bool stop = (cnt >= hp.patience) || (t + 1 >= hp.max_epochs);
-  if (!stop) {
-#pragma unroll
-    for (int k = 0; k < KMAX; ++k) {
-      const int e = lane + 64 * k;
-      if (e < Ne) I64[b * Ne + e] = (double)Inew[k];   // what the next solve reads
-    }
-  }
-  if (lane == 0) {
-    best_loss[b] = best;
-    patience_cnt[b] = cnt;
-    epochs_run[b] = t + 1;
-    last_loss[b] = loss;
-    if (stop) active[b] = 0;
-  }
+  if (!a.active[b]) return;   // wave-uniform
+  const TVM* Vb = V + b * Ne;
+  const TVM* Mb = M + b * Ne;
+  sizing_case(lane, b, Ne, a, [&](int e) { return (float)Vb[e]; }, [&](int e) { return (float)Mb[e]; });
 }
 
 }  // namespace opsamd
@@ -122,8 +49,8 @@ extern "C" int ops_beam_sizing_step_f32(int B, int Ne, float* I, double* I64, co
       !last_loss || ((V32 == nullptr) != (M32 == nullptr)) || !hp)
     return OPS_AMD_ERR_INVALID_ARG;
   const unsigned grid = (unsigned)((B + 3) / 4);
-  hipLaunchKernelGGL(opsamd::sizing_step_kernel<double>, dim3(grid), dim3(256), 0, (hipStream_t)stream, B, Ne, I, I64, V, M,
-                     exp_avg, exp_avg_sq, best_loss, patience_cnt, epochs_run, active, last_loss, V32, M32, *hp, (const float*)nullptr);
+  const opsamd::SizingArgs a{I, I64, exp_avg, exp_avg_sq, best_loss, patience_cnt, epochs_run, active, last_loss, V32, M32, *hp, nullptr};
+  hipLaunchKernelGGL(opsamd::sizing_step_kernel<double>, dim3(grid), dim3(256), 0, (hipStream_t)stream, B, Ne, V, M, a);
   return hipGetLastError() == hipSuccess ? OPS_AMD_OK : OPS_AMD_ERR_LAUNCH;
 }
 
@@ -146,8 +73,7 @@ extern "C" int ops_beam_sizing_step_vm32_f32(int B, int Ne, float* I, double* I6
   if (!I || !I64 || !V32 || !M32 || !exp_avg || !exp_avg_sq || !best_loss || !patience_cnt || !epochs_run || !active || !last_loss || !hp)
     return OPS_AMD_ERR_INVALID_ARG;
   const unsigned grid = (unsigned)((B + 3) / 4);
-  hipLaunchKernelGGL(opsamd::sizing_step_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, B, Ne, I, I64, V32, M32,
-                     exp_avg, exp_avg_sq, best_loss, patience_cnt, epochs_run, active, last_loss, (float*)nullptr, (float*)nullptr, *hp,
-                     schedule);
+  const opsamd::SizingArgs a{I, I64, exp_avg, exp_avg_sq, best_loss, patience_cnt, epochs_run, active, last_loss, nullptr, nullptr, *hp, schedule};
+  hipLaunchKernelGGL(opsamd::sizing_step_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, B, Ne, V32, M32, a);
   return hipGetLastError() == hipSuccess ? OPS_AMD_OK : OPS_AMD_ERR_LAUNCH;
 }

@@ -16,6 +16,7 @@ same with processes).
 from __future__ import annotations
 
 import ctypes
+import os
 import json
 from dataclasses import dataclass
 from typing import Dict, List, Optional, Tuple
@@ -214,6 +215,10 @@ def shard_range(n_total: int, rank: int, world: int) -> Tuple[int, int]:
     return (rank * n_total) // world, ((rank + 1) * n_total) // world
 
 
+_FUSED_EPOCH = os.environ.get("OPS_AMD_SIZING_FUSED", "1") == "1"     # A/B switch: 0 = separate solve and step launches
+_EPOCH_TILING = int(os.environ.get("OPS_AMD_SIZING_TILING", "0"))      # lanes per beam of the fused epoch kernel (0 = library default)
+
+
 class SizingState:
     """Device-resident optimiser state of a shard (what the reference keeps per sample in Python objects)."""
 
@@ -256,6 +261,19 @@ class SizingState:
         the reference reads only eleResponse: the solve writes forces only and skips wavefronts of finished cases."""
         lib = _cabi.load()
         N, Ne = self.N, self.Ne
+        if _FUSED_EPOCH and Ne <= 128:
+            # solve + optimiser step in ONE launch: the wavefront that solved a case steps it on the forces it still holds in LDS
+            with torch.cuda.device(self.device):
+                rc = lib.ops_beam_sizing_epoch_f32(
+                    self.B, Ne, self.x.data_ptr(), N if self.x.dim() == 2 else 0, self.E.data_ptr(), 0,
+                    self.fix.data_ptr(), N if self.fix.dim() == 2 else 0, self.Fy.data_ptr(), N, self.wy.data_ptr(), 0,
+                    self.I.data_ptr(), self.I64.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(),
+                    self.best_loss.data_ptr(), self.patience_cnt.data_ptr(), self.epochs_run.data_ptr(), self.active.data_ptr(),
+                    self.last_loss.data_ptr(), ctypes.byref(self._hp), self._schedule.data_ptr(), self._status.data_ptr(), _EPOCH_TILING,
+                    torch.cuda.current_stream(self.device).cuda_stream)
+            if rc != _cabi.OK:
+                raise RuntimeError(f"ops_beam_sizing_epoch_f32 failed with code {rc}: {lib.ops_amd_last_error().decode()}")
+            return
         with torch.cuda.device(self.device):
             stream = torch.cuda.current_stream(self.device).cuda_stream
             rc = lib.ops_beam_solve_forces_f32(
