@@ -294,7 +294,9 @@ class SizingState:
         """What the reference reads after the loop (:224-232) and records (:239-249): the state of every case's LAST
         solve.  `I64` froze when a case stopped, so one full solve reproduces it -- displacements included -- and the
         float32 roundings of shear / moment (:189-190) are taken from it."""
-        self.sol = beam_solve(self.x, self.E, self.I64, self.fix, self.Fy, self.wy, out=self.sol)
+        # same tiling as the epochs, whatever the shard size: the records do not depend on how many GPUs share the cases
+        til = 16 if (_FUSED_EPOCH and self.N <= 112 and _EPOCH_TILING == 0) else _EPOCH_TILING
+        self.sol = beam_solve(self.x, self.E, self.I64, self.fix, self.Fy, self.wy, tiling=til, out=self.sol)
         self.V32, self.M32 = self.sol.V.float(), self.sol.M.float()
 
 

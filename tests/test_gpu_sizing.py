@@ -184,3 +184,16 @@ def test_forces_only_entry_points_match_the_full_solve_and_honour_the_mask(oa):
         live = torch.ones(B, dtype=torch.bool, device=dev); live[16:32] = False
         assert torch.equal(V[live], ref.V[live].to(dt)) and torch.equal(M[live], ref.M[live].to(dt))
         assert bool((V[~live] == -7.0).all()) and bool((M[~live] == -7.0).all())
+
+
+def test_records_do_not_depend_on_the_shard_size_across_the_tiling_threshold(oa):
+    """40 000 cases on one GPU (a batch the plain solve would tile with 8 lanes) vs the same cases as two shards of
+    20 000: the epoch kernel and the final solve use one tiling, so the records are bitwise the same."""
+    from openpystruct_amd import sizing
+    cfg = sizing.SizingConfig(max_e=12)
+    whole = sizing.generate_dataset(40000, cfg, "cuda", seed=9)
+    for r in range(2):
+        part = sizing.generate_dataset(40000, cfg, "cuda", seed=9, rank=r, world=2)
+        lo, hi = sizing.shard_range(40000, r, 2)
+        for k in ("I_values", "shear_forces", "bending_moments", "deflections", "rotations", "epochs_run"):
+            assert torch.equal(part[k], whole[k][lo:hi]), k
