@@ -202,11 +202,12 @@ size_t ops_stencil3_bn1_workspace_bytes(void);
 /* Gradient clipping + Adam over flat float32 buffers of n values (the optimiser step of the surrogate training loops:
  * `clip_grad_norm_(params, max_norm)` + `optim.Adam(lr, weight_decay)`, OpenPyStruct_PINN_MultiCase.py:696, :766-768) in
  * two launches.  grads are scaled by grad_scale first (1 / world_size after a sum all-reduce); `lr` and `step` are device
- * scalars (step is advanced by the call); max_norm <= 0 disables clipping; weight decay is torch's L2 form (g += wd p).
+ * scalars (step is advanced by the call); max_norm <= 0 disables clipping; weight decay is torch's L2 form (g += wd p)
+ * or, with decoupled_weight_decay, AdamW's (p *= 1 - lr wd).
  * `workspace`: ops_flat_adam_workspace_bytes() bytes. */
 int ops_flat_clip_adam_step_f32(long n, float* params, const float* grads, float* exp_avg, float* exp_avg_sq, const float* lr,
                                 int32_t* step, float max_norm, float grad_scale, float beta1, float beta2, float eps,
-                                float weight_decay, void* workspace, void* stream);
+                                float weight_decay, int decoupled_weight_decay, void* workspace, void* stream);
 size_t ops_flat_adam_workspace_bytes(void);
 
 /* Training loss of the surrogates, value and gradient w.r.t. the predictions in one pass (two launches):

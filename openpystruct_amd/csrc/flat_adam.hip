@@ -9,6 +9,7 @@
 //
 //   pass 1: per-workgroup partial sums of (g * grad_scale)^2 (no atomics, nothing to zero); thread 0 advances the step
 //   pass 2: clip = min(1, max_norm / (||g|| + 1e-6));  g' = clip * grad_scale * g + weight_decay * p   (L2 form, as torch)
+//           (decoupled: p *= 1 - lr wd first and g' = clip * grad_scale * g -- torch.optim.AdamW, the GNN script's optimiser)
 //           m = b1 m + (1-b1) g';  v = b2 v + (1-b2) g'^2;  p -= lr / (1-b1^t) * m / (sqrt(v) / sqrt(1-b2^t) + eps)
 // `lr` and the step counter are device scalars so that a captured HIP graph sees the scheduler's updates.
 #include <hip/hip_runtime.h>
@@ -44,7 +45,7 @@ __global__ __launch_bounds__(FA_THREADS) void flat_grad_norm_kernel(long n, cons
 __global__ __launch_bounds__(FA_THREADS) void flat_adam_kernel(long n, float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                                 float* __restrict__ v, const float* __restrict__ lr, const int32_t* __restrict__ step,
                                                                 const double* __restrict__ part, int nparts, float max_norm, float grad_scale,
-                                                                float beta1, float beta2, float eps, float weight_decay) {
+                                                                float beta1, float beta2, float eps, float weight_decay, int decoupled) {
   double tot = 0.0;
   for (int k = 0; k < nparts; ++k) tot += part[k];
   const float norm = (float)sqrt(tot);
@@ -55,8 +56,10 @@ __global__ __launch_bounds__(FA_THREADS) void flat_adam_kernel(long n, float* __
   const float bc1 = (float)(1.0 - pow((double)beta1, t)), bc2s = (float)sqrt(1.0 - pow((double)beta2, t));
   const float step_size = lr[0] / bc1;
   for (long i = (long)blockIdx.x * FA_THREADS + threadIdx.x; i < n; i += (long)gridDim.x * FA_THREADS) {
-    const float pi = p[i];
-    const float gi = __builtin_fmaf(weight_decay, pi, g[i] * gs);
+    float pi = p[i];
+    float gi = g[i] * gs;
+    if (decoupled) pi *= 1.0f - lr[0] * weight_decay;      // AdamW: p *= 1 - lr wd, the gradient stays clean
+    else gi = __builtin_fmaf(weight_decay, pi, gi);        // Adam: L2 term in the gradient
     const float mi = __builtin_fmaf(beta1, m[i], (1.0f - beta1) * gi);
     const float vi = __builtin_fmaf(beta2, v[i], (1.0f - beta2) * gi * gi);
     m[i] = mi;
@@ -73,7 +76,7 @@ extern "C" size_t ops_flat_adam_workspace_bytes(void) { return (size_t)FA_NORM_B
 
 extern "C" int ops_flat_clip_adam_step_f32(long n, float* params, const float* grads, float* exp_avg, float* exp_avg_sq, const float* lr,
                                            int32_t* step, float max_norm, float grad_scale, float beta1, float beta2, float eps,
-                                           float weight_decay, void* workspace, void* stream) {
+                                           float weight_decay, int decoupled_weight_decay, void* workspace, void* stream) {
   if (n < 1 || !params || !grads || !exp_avg || !exp_avg_sq || !lr || !step || !workspace) return OPS_AMD_ERR_INVALID_ARG;
   hipStream_t s = (hipStream_t)stream;
   long nb = (n + FA_THREADS - 1) / FA_THREADS;
@@ -81,6 +84,6 @@ extern "C" int ops_flat_clip_adam_step_f32(long n, float* params, const float* g
   hipLaunchKernelGGL(flat_grad_norm_kernel, dim3(nparts), dim3(FA_THREADS), 0, s, n, grads, grad_scale, (double*)workspace, step);
   if (nb > 4096) nb = 4096;
   hipLaunchKernelGGL(flat_adam_kernel, dim3((unsigned)nb), dim3(FA_THREADS), 0, s, n, params, grads, exp_avg, exp_avg_sq, lr, step,
-                     (const double*)workspace, nparts, max_norm, grad_scale, beta1, beta2, eps, weight_decay);
+                     (const double*)workspace, nparts, max_norm, grad_scale, beta1, beta2, eps, weight_decay, decoupled_weight_decay);
   return hipGetLastError() == hipSuccess ? OPS_AMD_OK : OPS_AMD_ERR_LAUNCH;
 }

@@ -104,13 +104,15 @@ def prepare(records: Dict[str, object], *, kind: str = "pinn", n_cases: int = 6,
 
     kind = "pinn": flat inputs, targets [I, deflections, rotations] (PINN:337-369)
     kind = "fnn" : flat inputs, targets I only (the FNN sibling: same prep as PINN without the displacement targets)
+    kind = "gnn" : as "fnn", but the reference re-fits the input scalers on the validation split (GNN:196-199)
+    kind = "fno" : sequence inputs [G, n_cases, feat] without head padding, validation scaled with the training scalers (FNO:277-286)
     kind = "tfd" : sequence inputs padded to a multiple of `nheads`, targets I only (TFD:330-371); the
                    reference re-fits the input scalers on the validation split (TFD:325-328) -- kept behind
                    `refit_val_scalers` (default True for "tfd", False for "pinn").
     With `distributed=True` every rank passes ITS shard of records; moments and constraints are all-reduced."""
-    assert kind in ("pinn", "tfd", "fnn")
+    assert kind in ("pinn", "tfd", "fnn", "gnn", "fno")
     if refit_val_scalers is None:
-        refit_val_scalers = kind == "tfd"
+        refit_val_scalers = kind in ("tfd", "gnn")
     ml = dict(max_lengths or {})
     feats = {}
     for k, short in zip(INPUT_KEYS, ("roller_x", "force_x", "force_values", "node_positions")):
@@ -154,10 +156,10 @@ def prepare(records: Dict[str, object], *, kind: str = "pinn", n_cases: int = 6,
     else:
         Xva = torch.cat([sc_in[k].transform(feats[k][va]) for k in feats], dim=2)
     feat_dim = Xtr.shape[2]
-    if kind in ("pinn", "fnn"):
+    if kind in ("pinn", "fnn", "gnn"):
         Xtr, Xva = Xtr.reshape(Xtr.shape[0], -1), Xva.reshape(Xva.shape[0], -1)               # PINN:337-338
     else:
-        pad = (-feat_dim) % nheads                                                             # TFD:170-189
+        pad = (-feat_dim) % (1 if kind == "fno" else nheads)                                   # TFD:170-189; FNO: nheads 1
         if pad:
             Xtr = torch.nn.functional.pad(Xtr, (0, pad))
             Xva = torch.nn.functional.pad(Xva, (0, pad))

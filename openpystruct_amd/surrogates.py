@@ -375,5 +375,137 @@ class FNNPlain(nn.Module):
         return self.output_fc(out)
 
 
+# ------------------------------------------------------------------------------------------------
+# GNN: encoder MLP + GCN layers over the chain of elements (/root/reference/OpenPyStruct_GNN_MultiCase_Beta.py)
+# ------------------------------------------------------------------------------------------------
+def chain_adjacency(n: int) -> torch.Tensor:
+    """D^-1/2 A D^-1/2 of the path graph on n nodes (GNN:249-262): tridiagonal, zero diagonal."""
+    A = torch.zeros((n, n), dtype=torch.float32)
+    i = torch.arange(n - 1)
+    A[i, i + 1] = 1.0
+    A[i + 1, i] = 1.0
+    d = torch.pow(A.sum(dim=1) + 1e-8, -0.5)
+    return A * d.unsqueeze(0) * d.unsqueeze(1)
+
+
+class GCNLayer(nn.Module):
+    """A_hat @ (x W) (GNN:264-286).  A_hat of a chain is tridiagonal with a zero diagonal, so the product is two shifted,
+    scaled copies of xW -- 2 n d multiply-adds instead of the dense n^2 d contraction of the reference's einsum."""
+
+    def __init__(self, in_dim, out_dim):
+        super().__init__()
+        self.linear = nn.Linear(in_dim, out_dim, bias=False)
+
+    def forward(self, x, A_hat):
+        Wx = self.linear(x)                                              # [B, n, d]
+        lo = torch.diagonal(A_hat, -1).to(Wx.dtype).view(1, -1, 1)      # A[i+1, i]: node i+1 gathers from node i
+        up = torch.diagonal(A_hat, 1).to(Wx.dtype).view(1, -1, 1)       # A[i, i+1]: node i gathers from node i+1
+        out = F.pad(Wx[:, :-1] * lo, (0, 0, 1, 0))
+        return out + F.pad(Wx[:, 1:] * up, (0, 0, 0, 1))
+
+
+class ChainGNN(nn.Module):
+    """encoder MLP -> [B, n_elem, d] -> num_gnn_layers x (LayerNorm, GCN, dropout, residual) -> Linear(d, 1) (GNN:288-349)."""
+
+    def __init__(self, enc_in_dim, n_elem, enc_hidden_dim, gnn_hidden_dim, num_gnn_layers, dropout):
+        super().__init__()
+        self.n_elem, self.gnn_hidden_dim = n_elem, gnn_hidden_dim
+        self.register_buffer("A_hat", chain_adjacency(n_elem))
+        self.encoder = nn.Sequential(nn.Linear(enc_in_dim, enc_hidden_dim), nn.ReLU(), nn.Linear(enc_hidden_dim, n_elem * gnn_hidden_dim))
+        self.gcn_layers = nn.ModuleList(GCNLayer(gnn_hidden_dim, gnn_hidden_dim) for _ in range(num_gnn_layers))
+        self.norms = nn.ModuleList(nn.LayerNorm(gnn_hidden_dim) for _ in range(num_gnn_layers))
+        self.drops = nn.ModuleList(nn.Dropout(dropout) for _ in range(num_gnn_layers))
+        self.out_layer = nn.Linear(gnn_hidden_dim, 1)
+
+    def forward(self, x):
+        out = self.encoder(x).view(x.size(0), self.n_elem, self.gnn_hidden_dim)
+        for gcn, norm, drop in zip(self.gcn_layers, self.norms, self.drops):
+            out = out + drop(gcn(norm(out), self.A_hat))
+        return self.out_layer(out).squeeze(-1)
+
+
+# ------------------------------------------------------------------------------------------------
+# FNO: Fourier layers over the n_cases axis (SURVEY 8 f3; /root/reference/OpenPyStruct_FNO_MultiCase_Beta.py)
+# ------------------------------------------------------------------------------------------------
+class SpectralConv1d(nn.Module):
+    """The reference's Fourier layer (FNO:340-403), including what its einsum really computes: with the weights
+    unsqueezed to [1, in, out, modes] and the index string "bim, iojm -> bojm" the size-1 axis broadcasts against the input
+    channels, the product is summed over them, and the following `.sum(dim=2)` sums the weights over THEIR second axis:
+        out_ft[b, o, m] = (sum_i x_ft[b, i, m]) * (sum_j W[o, j, m])          (complex product, W = w_real + i w_imag)
+    -- a rank-one mixing, not a channel-mixing matrix per mode.  Restated in that closed form (in * out fewer multiplies);
+    the signal is n_cases = 6 samples long, so the real DFT and its inverse are two tiny matrices instead of an FFT call."""
+
+    def __init__(self, in_channels, out_channels, modes):
+        super().__init__()
+        self.in_channels, self.out_channels, self.modes = in_channels, out_channels, modes
+        self.scale = 1.0 / (in_channels * out_channels)
+        self.weights_real = nn.Parameter(self.scale * torch.rand(in_channels, out_channels, modes))
+        self.weights_imag = nn.Parameter(self.scale * torch.rand(in_channels, out_channels, modes))
+
+    @staticmethod
+    def _dft(n, m, device, dtype):
+        k = torch.arange(m, device=device, dtype=torch.float64).view(1, m)
+        t = torch.arange(n, device=device, dtype=torch.float64).view(n, 1)
+        ang = 2.0 * math.pi * t * k / n
+        fc, fs = torch.cos(ang), -torch.sin(ang)                        # rfft: X_k = sum_t x_t (cos - i sin)
+        # irfft of a spectrum that is zero beyond mode m-1: x_t = (1/n) [X_0 + 2 sum_{0<k<n/2} (Re X_k cos - Im X_k sin) + Nyquist]
+        w = torch.full((m,), 2.0, device=device, dtype=torch.float64)
+        w[0] = 1.0
+        if n % 2 == 0 and m - 1 == n // 2:
+            w[-1] = 1.0
+        ic, is_ = (torch.cos(ang) * w / n).t(), (-torch.sin(ang) * w / n).t()    # [m, n]
+        if n % 2 == 0 and m - 1 == n // 2:
+            is_[-1] = 0.0                                                # irfft ignores the imaginary part of the Nyquist bin
+        is_[0] = 0.0                                                     # ... and of the DC bin
+        return fc.to(dtype), fs.to(dtype), ic.to(dtype), is_.to(dtype)
+
+    def forward(self, x):
+        B, C, n = x.shape
+        m = min(self.modes, n // 2 + 1)
+        fc, fs, ic, is_ = self._dft(n, m, x.device, x.dtype)
+        s = x.sum(dim=1)                                                 # [B, n]: the einsum's sum over input channels
+        sr, si = s @ fc, s @ fs                                          # [B, m]
+        wr, wi = self.weights_real[:, :, :m].sum(dim=1), self.weights_imag[:, :, :m].sum(dim=1)     # [C, m]
+        out_r = sr.unsqueeze(1) * wr.unsqueeze(0) - si.unsqueeze(1) * wi.unsqueeze(0)               # [B, C, m]
+        out_i = sr.unsqueeze(1) * wi.unsqueeze(0) + si.unsqueeze(1) * wr.unsqueeze(0)
+        return out_r @ ic + out_i @ is_                                  # [B, C, n]
+
+
+class FNOBlock1d(nn.Module):
+    """gelu(BatchNorm(spectral(x) + pointwise(x))) (FNO:405-426)."""
+
+    def __init__(self, width, modes):
+        super().__init__()
+        self.conv = SpectralConv1d(width, width, modes)
+        self.w = nn.Conv1d(width, width, 1)
+        self.bn = nn.BatchNorm1d(width)
+
+    def forward(self, x):
+        pw = torch.einsum("oc,bcn->bon", self.w.weight.squeeze(-1), x) + self.w.bias.view(1, -1, 1)   # 1x1 conv as a GEMM
+        return F.gelu(self.bn(self.conv(x) + pw))
+
+
+class FNO1dModel(nn.Module):
+    """fc0 lifts the features of every case to `width` channels, FNO blocks along the n_cases axis, flatten, MLP head
+    (FNO:428-495).  The head's inner dropout uses the SCRIPT-level `dropout_rate` there, which equals `dropout`."""
+
+    def __init__(self, n_cases, feat_dim, n_elem, fno_modes, fno_width, num_fno_layers=4, hidden_units=512, dropout=0.1):
+        super().__init__()
+        self.n_cases, self.feat_dim, self.n_elem = n_cases, feat_dim, n_elem
+        self.fc0 = nn.Linear(feat_dim, fno_width)
+        self.fno_blocks = nn.ModuleList(FNOBlock1d(fno_width, fno_modes) for _ in range(num_fno_layers))
+        self.dropout = nn.Dropout(dropout)
+        self.fc_out = nn.Sequential(nn.Linear(fno_width * n_cases, hidden_units), nn.LeakyReLU(0.1), nn.Dropout(dropout),
+                                    nn.Linear(hidden_units, n_elem))
+
+    def forward(self, x):
+        B, Nc, Fd = x.shape
+        assert Nc == self.n_cases and Fd == self.feat_dim, f"Input shape {tuple(x.shape)} does not match (B, {self.n_cases}, {self.feat_dim})."
+        x = self.fc0(x).transpose(-1, -2)                                # [B, width, n_cases]
+        for block in self.fno_blocks:
+            x = block(x)
+        return self.fc_out(self.dropout(x.reshape(B, -1)))
+
+
 def count_parameters(m: nn.Module) -> int:
     return sum(p.numel() for p in m.parameters())

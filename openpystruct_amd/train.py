@@ -35,7 +35,7 @@ import torch.nn as nn
 from torch.optim.lr_scheduler import ExponentialLR
 
 from .dataprep import SurrogateData
-from .surrogates import fused_loss, CompositeLoss, FNNPlain, FNNWithResidual, ModelOnePassTransformerWithDiffusion, TrainableL1L2Loss
+from .surrogates import fused_loss, ChainGNN, CompositeLoss, FNO1dModel, FNNPlain, FNNWithResidual, ModelOnePassTransformerWithDiffusion, TrainableL1L2Loss
 
 
 @dataclass
@@ -120,7 +120,7 @@ class FlatClipAdam:
     so a captured HIP graph follows the scheduler."""
 
     def __init__(self, params, flat_grad: torch.Tensor, lr: float, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0,
-                 max_norm: float = 1.0):
+                 max_norm: float = 1.0, decoupled: bool = False):
         from . import _cabi
         self._cabi, self._lib = _cabi, _cabi.load()
         dev = flat_grad.device
@@ -138,7 +138,7 @@ class FlatClipAdam:
         self.lr = torch.tensor(float(lr), dtype=torch.float32, device=dev)
         self.step_count = torch.zeros((), dtype=torch.int32, device=dev)
         self.ws = torch.empty(int(self._lib.ops_flat_adam_workspace_bytes()), dtype=torch.uint8, device=dev)
-        self.betas, self.eps, self.weight_decay, self.max_norm = betas, eps, weight_decay, max_norm
+        self.betas, self.eps, self.weight_decay, self.max_norm, self.decoupled = betas, eps, weight_decay, max_norm, decoupled
 
     def step(self, grad_scale: float = 1.0) -> None:
         dev = self.g.device
@@ -146,7 +146,7 @@ class FlatClipAdam:
             rc = self._lib.ops_flat_clip_adam_step_f32(self.g.numel(), self.p.data_ptr(), self.g.data_ptr(), self.m.data_ptr(),
                                                        self.v.data_ptr(), self.lr.data_ptr(), self.step_count.data_ptr(), self.max_norm,
                                                        grad_scale, self.betas[0], self.betas[1], self.eps, self.weight_decay,
-                                                       self.ws.data_ptr(), torch.cuda.current_stream(dev).cuda_stream)
+                                                       int(self.decoupled), self.ws.data_ptr(), torch.cuda.current_stream(dev).cuda_stream)
         if rc != self._cabi.OK:
             raise RuntimeError(f"ops_flat_clip_adam_step_f32 failed with code {rc}")
 
@@ -155,6 +155,53 @@ class FlatClipAdam:
 
     def load_state_dict(self, sd) -> None:
         self.m.copy_(sd["m"]); self.v.copy_(sd["v"]); self.step_count.copy_(sd["step"]); self.lr.copy_(sd["lr"])
+
+
+@dataclass
+class GnnConfig:
+    """/root/reference/OpenPyStruct_GNN_MultiCase_Beta.py:38-55 (AdamW, no alpha term, :394, :437-446)."""
+    n_cases: int = 6
+    nelem: int = 100
+    box_constraint_coeff: float = 5e-1
+    encoder_hidden_dim: int = 128
+    gnn_hidden_dim: int = 128
+    num_gnn_layers: int = 2
+    dropout_rate: float = 0.5
+    num_epochs: int = 500
+    batch_size: int = 512
+    patience: int = 10
+    learning_rate: float = 3e-3
+    weight_decay: float = 1e-2
+    train_split: float = 0.8
+    sigma_0: float = 0.01
+    gamma_noise: float = 0.99
+    gamma: float = 0.975
+    initial_alpha: float = 0.5
+    c: float = 0.5
+
+
+@dataclass
+class FnoConfig:
+    """/root/reference/OpenPyStruct_FNO_MultiCase_Beta.py:34-58 (Adam, autocast disabled, alpha term, :561, :613-617)."""
+    n_cases: int = 6
+    nelem: int = 100
+    box_constraint_coeff: float = 5e-1
+    hidden_units: int = 512
+    dropout_rate: float = 0.1
+    num_fno_layers: int = 4
+    num_epochs: int = 500
+    batch_size: int = 512
+    patience: int = 10
+    learning_rate: float = 3e-3
+    weight_decay: float = 1e-6
+    train_split: float = 0.8
+    sigma_0: float = 0.01
+    gamma_noise: float = 0.95
+    gamma: float = 0.975
+    initial_alpha: float = 0.5
+    c: float = 0.5
+    fno_modes: int = 4
+    fno_width: int = 128
 
 
 def build_model_and_loss(kind: str, cfg, data: SurrogateData, device):
@@ -168,6 +215,13 @@ def build_model_and_loss(kind: str, cfg, data: SurrogateData, device):
                                                      cfg.num_transformer_layers, cfg.num_heads, cfg.dim_feedforward,
                                                      cfg.dropout_rate, cfg.max_len, cfg.diffusion_hidden_dim, cfg.diffusion_T)  # TFD:664-676
         crit = TrainableL1L2Loss(cfg.initial_alpha, data.min_constraint, data.max_constraint, cfg.box_constraint_coeff)       # TFD:680
+    elif kind == "gnn":
+        model = ChainGNN(data.X_train.shape[1], cfg.nelem, cfg.encoder_hidden_dim, cfg.gnn_hidden_dim, cfg.num_gnn_layers, cfg.dropout_rate)
+        crit = TrainableL1L2Loss(cfg.initial_alpha, data.min_constraint, data.max_constraint, cfg.box_constraint_coeff)
+    elif kind == "fno":
+        model = FNO1dModel(cfg.n_cases, data.feat_dim, cfg.nelem, cfg.fno_modes, cfg.fno_width, cfg.num_fno_layers, cfg.hidden_units,
+                           cfg.dropout_rate)
+        crit = TrainableL1L2Loss(cfg.initial_alpha, data.min_constraint, data.max_constraint, cfg.box_constraint_coeff)
     elif kind == "fnn":
         model = FNNPlain(data.X_train.shape[1], cfg.hidden_units, cfg.num_residual_blocks, cfg.nelem, cfg.dropout_rate)
         crit = TrainableL1L2Loss(cfg.initial_alpha, data.min_constraint, data.max_constraint, cfg.box_constraint_coeff)
@@ -211,7 +265,10 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
                     use_graph: Optional[bool] = None, physics: Optional[PhysicsTerm] = None) -> Dict[str, object]:
     """Trains on THIS rank's `data` shard; uses DDP when torch.distributed is initialised with world_size > 1.
     Returns history, best state dict, validation R^2 (I only) and per-epoch times."""
-    cfg = cfg or {"pinn": PinnConfig, "tfd": TfdConfig, "fnn": FnnConfig}[kind]()
+    cfg = cfg or {"pinn": PinnConfig, "tfd": TfdConfig, "fnn": FnnConfig, "gnn": GnnConfig, "fno": FnoConfig}[kind]()
+    alpha_term = kind in ("tfd", "fnn", "fno")          # (initial_alpha - alpha)^2 in the training loss (TFD:743, FNO:615)
+    if kind == "fno":
+        autocast_dtype = None                           # FNO:613 runs with autocast disabled
     device = torch.device(device)
     world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
     rank = dist.get_rank() if world > 1 else 0
@@ -234,10 +291,11 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
     # under graph replay the learning rate must live in a device tensor, or the scheduler's updates would
     # never reach the captured optimiser step
     if on_gpu:      # clip + Adam over the flat buffers in two HIP launches; loss.alpha NOT included (PINN:696)
-        opt = FlatClipAdam(params, flat, cfg.learning_rate, weight_decay=cfg.weight_decay, max_norm=1.0)
+        opt = FlatClipAdam(params, flat, cfg.learning_rate, weight_decay=cfg.weight_decay, max_norm=1.0, decoupled=kind == "gnn")
         sched = None
     else:
-        opt = torch.optim.Adam(model.parameters(), lr=cfg.learning_rate, weight_decay=cfg.weight_decay)
+        opt = (torch.optim.AdamW if kind == "gnn" else torch.optim.Adam)(model.parameters(), lr=cfg.learning_rate,   # GNN:394
+                                                                         weight_decay=cfg.weight_decay)
         sched = ExponentialLR(opt, gamma=cfg.gamma)
     Xtr, Ytr, Xva, Yva = (t.to(device) for t in (data.X_train, data.Y_train, data.X_val, data.Y_val))
     nb_tr = max(1, (Xtr.shape[0] + cfg.batch_size - 1) // cfg.batch_size)
@@ -280,10 +338,10 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
         with torch.autocast(device_type=device.type, dtype=autocast_dtype, enabled=use_ac):
             preds = net(Xn)
             if on_gpu and _FUSED_LOSS:       # value + d/d preds in one HIP pass instead of ~80 framework kernel nodes
-                loss = fused_loss(crit, preds, Yb, alpha0=cfg.initial_alpha if kind in ("tfd", "fnn") else None)
+                loss = fused_loss(crit, preds, Yb, alpha0=cfg.initial_alpha if alpha_term else None)
             else:
                 loss = crit(preds.float(), Yb)
-                if kind in ("tfd", "fnn"):
+                if alpha_term:
                     loss = loss + (cfg.initial_alpha - crit.alpha) ** 2   # TFD:743 / FNN (constant 0: alpha never trains)
         if physics is not None:
             loss = loss + physics.weight * physics_loss(preds.float(), rows).float()

@@ -7,7 +7,7 @@ pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
 
 
-@pytest.mark.parametrize("kind", ["pinn", "tfd", "fnn"])
+@pytest.mark.parametrize("kind", ["pinn", "tfd", "fnn", "gnn", "fno"])
 def test_generate_prepare_train_on_gpu(kind):
     if not torch.cuda.is_available():
         pytest.fail("no GPU visible")
@@ -18,7 +18,7 @@ def test_generate_prepare_train_on_gpu(kind):
     assert d.X_train.is_cuda and d.X_train.shape[0] == 80
     if kind == "pinn":
         assert d.X_train.shape[1] == 684 and d.Y_train.shape[1] == 302
-    cfg = {"pinn": train.PinnConfig, "tfd": train.TfdConfig, "fnn": train.FnnConfig}[kind](batch_size=32)
+    cfg = {"pinn": train.PinnConfig, "tfd": train.TfdConfig, "fnn": train.FnnConfig, "gnn": train.GnnConfig, "fno": train.FnoConfig}[kind](batch_size=32)
     out = train.train_surrogate(kind, d, cfg, device="cuda", max_epochs=2)
     assert out["epochs"] == 2 and np.isfinite(out["history"]["train"]).all() and np.isfinite(out["history"]["val"]).all()
     assert np.isfinite(out["r2_val_I"])
@@ -73,8 +73,9 @@ def test_fused_stencil_batchnorm_under_autocast_returns_bf16_like_the_modules():
     assert x.grad.dtype == torch.float32 and torch.allclose(x.grad, x2.grad, atol=5e-2, rtol=5e-2)
 
 
-@pytest.mark.parametrize("gscale,wd,scale", [(1.0, 0.0, 1.0), (0.5, 1e-2, 50.0), (1.0, 1e-2, 1e-3)])
-def test_flat_clip_adam_equals_torch_clip_plus_adam(gscale, wd, scale):
+@pytest.mark.parametrize("gscale,wd,scale,decoupled", [(1.0, 0.0, 1.0, False), (0.5, 1e-2, 50.0, False), (1.0, 1e-2, 1e-3, False),
+                                                       (1.0, 1e-2, 1.0, True), (0.5, 0.3, 50.0, True)])
+def test_flat_clip_adam_equals_torch_clip_plus_adam(gscale, wd, scale, decoupled):
     """csrc/flat_adam.hip == clip_grad_norm_(1.0) + torch.optim.Adam over several steps (clipping active and inactive)."""
     from openpystruct_amd import train
     torch.manual_seed(1)
@@ -85,8 +86,8 @@ def test_flat_clip_adam_equals_torch_clip_plus_adam(gscale, wd, scale):
     off = 0
     for p in ps:
         p.grad = flat[off:off + p.numel()].view_as(p); off += p.numel()
-    opt = train.FlatClipAdam(ps, flat, 1e-2, weight_decay=wd, max_norm=1.0)
-    ropt = torch.optim.Adam(ref, lr=1e-2, weight_decay=wd)
+    opt = train.FlatClipAdam(ps, flat, 1e-2, weight_decay=wd, max_norm=1.0, decoupled=decoupled)
+    ropt = (torch.optim.AdamW if decoupled else torch.optim.Adam)(ref, lr=1e-2, weight_decay=wd)
     for step in range(6):
         gs = [torch.randn(s, device="cuda") * scale for s in shapes]
         flat.copy_(torch.cat([g.reshape(-1) for g in gs]))

@@ -96,11 +96,12 @@ def test_prepare_shapes_pinn_and_tfd():
         dataprep.prepare(_fake_records(4), kind="pinn")
 
 
-@pytest.mark.parametrize("kind", ["pinn", "tfd", "fnn"])
+@pytest.mark.parametrize("kind", ["pinn", "tfd", "fnn", "gnn", "fno"])
 def test_training_loop_runs_and_early_stops(kind):
     rec = _fake_records(240, seed=3)
     d = dataprep.prepare(rec, kind=kind, seed=2)
-    cfg = {"pinn": train.PinnConfig, "tfd": train.TfdConfig, "fnn": train.FnnConfig}[kind](batch_size=16, patience=2)
+    cfg = {"pinn": train.PinnConfig, "tfd": train.TfdConfig, "fnn": train.FnnConfig, "gnn": train.GnnConfig,
+           "fno": train.FnoConfig}[kind](batch_size=16, patience=2)
     out = train.train_surrogate(kind, d, cfg, device="cpu", autocast_dtype=None, max_epochs=4)
     assert 1 <= out["epochs"] <= 4 and len(out["history"]["val"]) == out["epochs"]
     assert np.isfinite(out["history"]["train"]).all() and np.isfinite(out["r2_val_I"])
@@ -200,3 +201,46 @@ def test_stencil_batchnorm_path_equals_the_library_modules():
     assert int(bn.num_batches_tracked) == int(bn2.num_batches_tracked) == 3
     x = torch.randn(5, 35)
     assert torch.allclose(surrogates.conv3_bn_single_channel(x, conv, bn, False), bn2.eval()(conv2(x.unsqueeze(1))).squeeze(1), atol=1e-5)
+
+
+def test_chain_gnn_stencil_equals_the_dense_adjacency_product():
+    """GCNLayer's two shifted copies == einsum('ij,bjd->bid', A_hat, xW) of GNN:264-286; names and sizes as the reference."""
+    torch.manual_seed(0)
+    g = surrogates.ChainGNN(684, 100, 128, 128, 2, 0.0).eval()
+    A = g.A_hat
+    assert float(A.diagonal().abs().max()) == 0.0 and float(A[0, 1]) == pytest.approx(1 / np.sqrt(2), rel=1e-6) and float(A[5, 6]) == pytest.approx(0.5, rel=1e-6)
+    x = torch.randn(3, 684)
+    h = g.encoder(x).view(3, 100, 128)
+    for gcn, norm in zip(g.gcn_layers, g.norms):
+        h = h + torch.einsum("ij,bjd->bid", A, gcn.linear(norm(h)))
+    assert torch.allclose(g(x), g.out_layer(h).squeeze(-1), atol=1e-5)
+    assert surrogates.count_parameters(g) == 684 * 128 + 128 + 128 * 12800 + 12800 + 2 * (128 * 128 + 256) + 129
+    assert {"A_hat", "encoder.0.weight", "encoder.2.bias", "gcn_layers.1.linear.weight", "norms.0.weight", "out_layer.bias"} <= set(g.state_dict())
+
+
+@pytest.mark.parametrize("n,modes", [(6, 4), (6, 3), (7, 4), (5, 2), (8, 5)])
+def test_spectral_conv_closed_form_equals_the_literal_einsum_over_rfft(n, modes):
+    """SpectralConv1d == rfft -> the reference's broadcasting einsum + sum(dim=2) -> zero-pad -> irfft (FNO:356-403)."""
+    torch.manual_seed(n * 10 + modes)
+    sc = surrogates.SpectralConv1d(8, 8, modes)
+    x = torch.randn(5, 8, n)
+    x_ft = torch.fft.rfft(x, n=n)[:, :, :modes]
+    w_r, w_i = sc.weights_real.unsqueeze(0), sc.weights_imag.unsqueeze(0)
+    o_r = (torch.einsum("bim, iojm -> bojm", x_ft.real, w_r) - torch.einsum("bim, iojm -> bojm", x_ft.imag, w_i)).sum(dim=2)
+    o_i = (torch.einsum("bim, iojm -> bojm", x_ft.real, w_i) + torch.einsum("bim, iojm -> bojm", x_ft.imag, w_r)).sum(dim=2)
+    lit = torch.fft.irfft(torch.nn.functional.pad(torch.complex(o_r, o_i), (0, n // 2 + 1 - modes)), n=n)
+    assert torch.allclose(sc(x), lit, atol=1e-5)
+
+
+def test_fno_model_shapes_names_and_prep():
+    f = surrogates.FNO1dModel(6, 114, 100, 4, 128, 4, 512, 0.1).eval()
+    assert tuple(f(torch.randn(4, 6, 114)).shape) == (4, 100)
+    keys = set(f.state_dict())
+    assert {"fc0.weight", "fno_blocks.0.conv.weights_real", "fno_blocks.3.w.weight", "fno_blocks.1.bn.running_var", "fc_out.0.weight", "fc_out.3.bias"} <= keys
+    assert tuple(f.state_dict()["fno_blocks.0.w.weight"].shape) == (128, 128, 1)
+    assert surrogates.count_parameters(f) == 114 * 128 + 128 + 4 * (2 * 128 * 128 * 4 + 128 * 128 + 128 + 256) + 768 * 512 + 512 + 512 * 100 + 100
+    rec = _fake_records(120)
+    d = dataprep.prepare(rec, kind="fno", seed=1)
+    assert d.X_train.shape == (16, 6, 114) and d.feat_dim == 114 and d.Y_train.shape == (16, 100)     # no head padding (nheads 1)
+    g = dataprep.prepare(rec, kind="gnn", seed=1)
+    assert g.X_train.shape == (16, 684) and g.Y_train.shape == (16, 100)
