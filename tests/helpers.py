@@ -61,3 +61,28 @@ def relerr(a, b):
 def load_golden(path):
     z = np.load(path)
     return {k: z[k] for k in z.files}
+
+
+def free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def run_ranks(target, world, timeout):
+    """Spawn `world` daemon processes running target(rank, world, port, queue); return their queue items.  Children are
+    terminated whatever happens, so a failed rank can never leave the test run hanging at interpreter exit."""
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = free_port()
+    ps = [ctx.Process(target=target, args=(r, world, port, q), daemon=True) for r in range(world)]
+    [p.start() for p in ps]
+    try:
+        return [q.get(timeout=timeout) for _ in ps]
+    finally:
+        for p in ps:
+            p.join(10)
+            if p.is_alive():
+                p.terminate()

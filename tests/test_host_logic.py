@@ -124,7 +124,7 @@ def _gloo_worker(rank, world, port, q):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=__import__("datetime").timedelta(seconds=120))
     n = 37
     lo, hi = sizing.shard_range(n, rank, world)
     cases = sizing.make_cases(n, sizing.SizingConfig(), seed=9).slice(lo, hi)
@@ -136,14 +136,8 @@ def _gloo_worker(rank, world, port, q):
 
 
 def test_two_rank_shards_reassemble_the_global_case_list():
-    import torch.multiprocessing as mp
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = 29000 + os.getpid() % 2000
-    ps = [ctx.Process(target=_gloo_worker, args=(r, 2, port, q)) for r in range(2)]
-    [p.start() for p in ps]
-    outs = [q.get(timeout=120) for _ in ps]
-    [p.join(60) for p in ps]
+    from tests.helpers import run_ranks
+    outs = run_ranks(_gloo_worker, 2, timeout=180)
     ref = sizing.make_cases(37, sizing.SizingConfig(), seed=9).Fy.sum(dim=1).numpy()
     for _, got in outs:
         np.testing.assert_array_equal(got, ref)

@@ -111,7 +111,7 @@ def test_training_loop_runs_and_early_stops(kind):
 def _ddp_worker(rank, world, port, q):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=__import__("datetime").timedelta(seconds=120))
     torch.manual_seed(0)
     model = surrogates.FNNWithResidual(24, 16, 1, 10, dropout_rate=0.0, use_conv=False, norm_type="layer")   # no BatchNorm: batch statistics are per rank
     crit = surrogates.CompositeLoss(4, 3, 3, 0.5, 0.0, None, None)         # mean-type terms only
@@ -127,14 +127,8 @@ def _ddp_worker(rank, world, port, q):
 
 
 def test_ddp_gradients_equal_single_process_on_concatenated_batch():
-    import torch.multiprocessing as mp
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = 31000 + os.getpid() % 2000
-    ps = [ctx.Process(target=_ddp_worker, args=(r, 2, port, q)) for r in range(2)]
-    [p.start() for p in ps]
-    outs = [q.get(timeout=180) for _ in ps]
-    [p.join(60) for p in ps]
+    from tests.helpers import run_ranks
+    outs = run_ranks(_ddp_worker, 2, timeout=240)
     torch.manual_seed(0)
     model = surrogates.FNNWithResidual(24, 16, 1, 10, dropout_rate=0.0, use_conv=False, norm_type="layer")   # no BatchNorm: batch statistics are per rank
     crit = surrogates.CompositeLoss(4, 3, 3, 0.5, 0.0, None, None)
@@ -152,7 +146,7 @@ def test_ddp_gradients_equal_single_process_on_concatenated_batch():
 def _ddp_train_worker(rank, world, port, q):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=__import__("datetime").timedelta(seconds=120))
     rec = _fake_records(240, seed=3)
     lo, hi = sizing.shard_range(240, rank, world)
     shard = {k: (v[lo:hi] if torch.is_tensor(v) else v[lo:hi]) for k, v in rec.items()}
@@ -164,14 +158,8 @@ def _ddp_train_worker(rank, world, port, q):
 
 
 def test_two_rank_training_stays_in_sync():
-    import torch.multiprocessing as mp
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = 33000 + os.getpid() % 2000
-    ps = [ctx.Process(target=_ddp_train_worker, args=(r, 2, port, q)) for r in range(2)]
-    [p.start() for p in ps]
-    outs = sorted([q.get(timeout=300) for _ in ps])
-    [p.join(60) for p in ps]
+    from tests.helpers import run_ranks
+    outs = sorted(run_ranks(_ddp_train_worker, 2, timeout=400))
     (_, e0, v0, w0, m0), (_, e1, v1, w1, m1) = outs
     assert e0 == e1 and v0 == pytest.approx(v1)              # all-reduced losses: identical early-stop decisions
     assert w0 == pytest.approx(w1, rel=1e-6)                 # replicas hold the same weights after training
