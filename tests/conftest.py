@@ -10,9 +10,6 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
-    # a stuck rendezvous or kernel must fail its test, not hang the run (pytest-timeout, when installed)
-    if config.pluginmanager.hasplugin("timeout") and not getattr(config.option, "timeout", None):
-        config.option.timeout = 600
 
 
 @pytest.fixture(scope="session")
