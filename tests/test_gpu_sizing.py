@@ -197,3 +197,23 @@ def test_records_do_not_depend_on_the_shard_size_across_the_tiling_threshold(oa)
         lo, hi = sizing.shard_range(40000, r, 2)
         for k in ("I_values", "shear_forces", "bending_moments", "deflections", "rotations", "epochs_run"):
             assert torch.equal(part[k], whole[k][lo:hi]), k
+
+
+def test_random_bridges_through_the_sizing_loop(oa, monkeypatch):
+    """random_bridge = 1 (SingleCore.py:133-151): per-case span, node coordinates and supports -- the per-beam-geometry
+    variants of the fused epoch kernel -- against the per-sample oracle, and against the two-launch epoch."""
+    from openpystruct_amd import sizing
+    cfg = sizing.SizingConfig(random_bridge=1, max_e=4)
+    cases = sizing.make_cases(9, cfg, seed=31)
+    st = sizing.optimize_cases(cases, cfg, "cuda", poll_every=1, use_graph=False)
+    torch.cuda.synchronize()
+    assert int(st.sol.status.abs().sum()) == 0 and (st.epochs_run.cpu().numpy() == 4).all()
+    for b in range(9):
+        ref = so.generate_sample(cases.node_positions[b].numpy(), cases.roller_nodes[b], cases.force_nodes[b],
+                                 cases.force_values[b], max_e=4)
+        np.testing.assert_allclose(st.I[b].cpu().numpy(), np.array(ref["I_values"]), rtol=5e-6)
+        assert relerr(st.M32[b].cpu().numpy(), np.array(ref["bending_moments"])) < 1e-6
+        assert relerr(st.sol.v[b].cpu().numpy(), np.array(ref["deflections"])) < 1e-6
+    monkeypatch.setattr(sizing, "_FUSED_EPOCH", False)
+    st2 = sizing.optimize_cases(cases, cfg, "cuda", poll_every=1, use_graph=False)
+    assert torch.equal(st2.epochs_run, st.epochs_run) and torch.allclose(st2.I, st.I, rtol=1e-6, atol=0.0)
