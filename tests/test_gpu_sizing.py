@@ -217,3 +217,20 @@ def test_random_bridges_through_the_sizing_loop(oa, monkeypatch):
     monkeypatch.setattr(sizing, "_FUSED_EPOCH", False)
     st2 = sizing.optimize_cases(cases, cfg, "cuda", poll_every=1, use_graph=False)
     assert torch.equal(st2.epochs_run, st.epochs_run) and torch.allclose(st2.I, st.I, rtol=1e-6, atol=0.0)
+
+
+@pytest.mark.parametrize("num_nodes", [41, 129, 151, 301])
+def test_other_mesh_sizes_through_the_sizing_loop(oa, num_nodes):
+    """Ne <= 128 runs the fused epoch kernel, larger meshes the two-launch epoch: both against the per-sample oracle."""
+    from openpystruct_amd import sizing
+    rollers = tuple(r for r in (10, 30, 70, 85, 100) if r < num_nodes - 1) or (num_nodes // 2,)
+    cfg = sizing.SizingConfig(num_nodes=num_nodes, roller_nodes=rollers, max_e=3)
+    cases = sizing.make_cases(5, cfg, seed=num_nodes)
+    st = sizing.optimize_cases(cases, cfg, "cuda", poll_every=1, use_graph=False)
+    torch.cuda.synchronize()
+    assert int(st.sol.status.abs().sum()) == 0
+    for b in range(5):
+        ref = so.generate_sample(cases.node_positions[b].numpy(), cases.roller_nodes[b], cases.force_nodes[b],
+                                 cases.force_values[b], max_e=3)
+        np.testing.assert_allclose(st.I[b].cpu().numpy(), np.array(ref["I_values"]), rtol=5e-6)
+        assert relerr(st.sol.v[b].cpu().numpy(), np.array(ref["deflections"])) < 1e-6
