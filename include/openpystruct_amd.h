@@ -203,11 +203,12 @@ size_t ops_stencil3_bn1_workspace_bytes(void);
  * `clip_grad_norm_(params, max_norm)` + `optim.Adam(lr, weight_decay)`, OpenPyStruct_PINN_MultiCase.py:696, :766-768) in
  * two launches.  grads are scaled by grad_scale first (1 / world_size after a sum all-reduce); `lr` and `step` are device
  * scalars (step is advanced by the call); max_norm <= 0 disables clipping; weight decay is torch's L2 form (g += wd p)
- * or, with decoupled_weight_decay, AdamW's (p *= 1 - lr wd).
+ * or, with decoupled_weight_decay, AdamW's (p *= 1 - lr wd).  params_bf16 (optional, n bfloat16 values): refreshed with the
+ * rounded new parameters, so that bf16 GEMMs of the next step need no per-step cast kernels.
  * `workspace`: ops_flat_adam_workspace_bytes() bytes. */
 int ops_flat_clip_adam_step_f32(long n, float* params, const float* grads, float* exp_avg, float* exp_avg_sq, const float* lr,
                                 int32_t* step, float max_norm, float grad_scale, float beta1, float beta2, float eps,
-                                float weight_decay, int decoupled_weight_decay, void* workspace, void* stream);
+                                float weight_decay, int decoupled_weight_decay, void* params_bf16, void* workspace, void* stream);
 size_t ops_flat_adam_workspace_bytes(void);
 
 /* Training loss of the surrogates, value and gradient w.r.t. the predictions in one pass (two launches):

@@ -105,7 +105,7 @@ def load():
     lib.ops_stencil3_bn1_bwd_f32.argtypes = [it, it, vp, vp, it, vp, vp, vp, vp, it, vp, vp, vp, vp]
     lib.ops_stencil3_bn1_workspace_bytes.restype = ctypes.c_size_t
     lib.ops_flat_clip_adam_step_f32.restype = it
-    lib.ops_flat_clip_adam_step_f32.argtypes = [lg, vp, vp, vp, vp, vp, vp, fl, fl, fl, fl, fl, fl, it, vp, vp]
+    lib.ops_flat_clip_adam_step_f32.argtypes = [lg, vp, vp, vp, vp, vp, vp, fl, fl, fl, fl, fl, fl, it, vp, vp, vp]
     lib.ops_flat_adam_workspace_bytes.restype = ctypes.c_size_t
     lib.ops_surrogate_loss_grad_f32.restype = it
     lib.ops_surrogate_loss_grad_f32.argtypes = [it, it, it, it, vp, it, vp, vp, fl, vp, vp, fl, fl, vp, vp, vp, vp]

@@ -45,7 +45,8 @@ __global__ __launch_bounds__(FA_THREADS) void flat_grad_norm_kernel(long n, cons
 __global__ __launch_bounds__(FA_THREADS) void flat_adam_kernel(long n, float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                                 float* __restrict__ v, const float* __restrict__ lr, const int32_t* __restrict__ step,
                                                                 const double* __restrict__ part, int nparts, float max_norm, float grad_scale,
-                                                                float beta1, float beta2, float eps, float weight_decay, int decoupled) {
+                                                                float beta1, float beta2, float eps, float weight_decay, int decoupled,
+                                                                uint16_t* __restrict__ shadow) {
   double tot = 0.0;
   for (int k = 0; k < nparts; ++k) tot += part[k];
   const float norm = (float)sqrt(tot);
@@ -64,7 +65,13 @@ __global__ __launch_bounds__(FA_THREADS) void flat_adam_kernel(long n, float* __
     const float vi = __builtin_fmaf(beta2, v[i], (1.0f - beta2) * gi * gi);
     m[i] = mi;
     v[i] = vi;
-    p[i] = pi - step_size * (mi / (sqrtf(vi) / bc2s + eps));
+    const float pn = pi - step_size * (mi / (sqrtf(vi) / bc2s + eps));
+    p[i] = pn;
+    if (shadow) {                      // bfloat16 copy of the parameters (round to nearest even) for the GEMMs of the next step
+      uint32_t u = __float_as_uint(pn);
+      u += 0x7fffu + ((u >> 16) & 1u);
+      shadow[i] = (uint16_t)(u >> 16);
+    }
   }
 }
 
@@ -76,7 +83,8 @@ extern "C" size_t ops_flat_adam_workspace_bytes(void) { return (size_t)FA_NORM_B
 
 extern "C" int ops_flat_clip_adam_step_f32(long n, float* params, const float* grads, float* exp_avg, float* exp_avg_sq, const float* lr,
                                            int32_t* step, float max_norm, float grad_scale, float beta1, float beta2, float eps,
-                                           float weight_decay, int decoupled_weight_decay, void* workspace, void* stream) {
+                                           float weight_decay, int decoupled_weight_decay, void* params_bf16, void* workspace,
+                                           void* stream) {
   if (n < 1 || !params || !grads || !exp_avg || !exp_avg_sq || !lr || !step || !workspace) return OPS_AMD_ERR_INVALID_ARG;
   hipStream_t s = (hipStream_t)stream;
   long nb = (n + FA_THREADS - 1) / FA_THREADS;
@@ -84,6 +92,7 @@ extern "C" int ops_flat_clip_adam_step_f32(long n, float* params, const float* g
   hipLaunchKernelGGL(flat_grad_norm_kernel, dim3(nparts), dim3(FA_THREADS), 0, s, n, grads, grad_scale, (double*)workspace, step);
   if (nb > 4096) nb = 4096;
   hipLaunchKernelGGL(flat_adam_kernel, dim3((unsigned)nb), dim3(FA_THREADS), 0, s, n, params, grads, exp_avg, exp_avg_sq, lr, step,
-                     (const double*)workspace, nparts, max_norm, grad_scale, beta1, beta2, eps, weight_decay, decoupled_weight_decay);
+                     (const double*)workspace, nparts, max_norm, grad_scale, beta1, beta2, eps, weight_decay, decoupled_weight_decay,
+                     (uint16_t*)params_bf16);
   return hipGetLastError() == hipSuccess ? OPS_AMD_OK : OPS_AMD_ERR_LAUNCH;
 }

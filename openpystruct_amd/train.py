@@ -139,6 +139,18 @@ class FlatClipAdam:
         self.step_count = torch.zeros((), dtype=torch.int32, device=dev)
         self.ws = torch.empty(int(self._lib.ops_flat_adam_workspace_bytes()), dtype=torch.uint8, device=dev)
         self.betas, self.eps, self.weight_decay, self.max_norm, self.decoupled = betas, eps, weight_decay, max_norm, decoupled
+        self.p_bf16: Optional[torch.Tensor] = None      # bfloat16 shadow of the parameters (enable_shadow)
+
+    def enable_shadow(self) -> torch.Tensor:
+        """A bfloat16 copy of the flat parameter buffer that every step refreshes in the Adam kernel itself: layers that
+        run their GEMMs in bfloat16 read it instead of casting their float32 weights in every forward pass."""
+        if self.p_bf16 is None:
+            self.p_bf16 = self.p.to(torch.bfloat16)
+        return self.p_bf16
+
+    def refresh_shadow(self) -> None:
+        if self.p_bf16 is not None:
+            self.p_bf16.copy_(self.p)
 
     def step(self, grad_scale: float = 1.0) -> None:
         dev = self.g.device
@@ -146,7 +158,8 @@ class FlatClipAdam:
             rc = self._lib.ops_flat_clip_adam_step_f32(self.g.numel(), self.p.data_ptr(), self.g.data_ptr(), self.m.data_ptr(),
                                                        self.v.data_ptr(), self.lr.data_ptr(), self.step_count.data_ptr(), self.max_norm,
                                                        grad_scale, self.betas[0], self.betas[1], self.eps, self.weight_decay,
-                                                       int(self.decoupled), self.ws.data_ptr(), torch.cuda.current_stream(dev).cuda_stream)
+                                                       int(self.decoupled), self.p_bf16.data_ptr() if self.p_bf16 is not None else None,
+                                                       self.ws.data_ptr(), torch.cuda.current_stream(dev).cuda_stream)
         if rc != self._cabi.OK:
             raise RuntimeError(f"ops_flat_clip_adam_step_f32 failed with code {rc}")
 
@@ -202,6 +215,81 @@ class FnoConfig:
     c: float = 0.5
     fno_modes: int = 4
     fno_width: int = 128
+
+
+class _ShadowLinearFn(torch.autograd.Function):
+    """y = x W^T + b with W, b taken from the optimiser's bfloat16 shadow; the weight / bias gradients are not returned to
+    autograd but left (in bfloat16) in `stash`, from where ONE multi-tensor copy moves all of them into the flat float32
+    gradient buffer.  Same arithmetic as nn.Linear under bf16 autocast (bf16 operands, fp32 accumulation, bf16 results),
+    without its per-step kernels: weight cast, bias cast, gradient cast back and accumulate -- four per parameter."""
+
+    @staticmethod
+    def forward(ctx, x, w_sh, b_sh, stash, iw, ib, anchor):
+        # `anchor` (the layer's float32 weight Parameter) is not read: it makes autograd record the node even when x
+        # needs no gradient (first layer); its own gradient slot stays None -- the gradients travel through `stash`
+        xb = x if x.dtype == torch.bfloat16 else x.to(torch.bfloat16)
+        x2 = xb.reshape(-1, xb.shape[-1])
+        y = torch.addmm(b_sh, x2, w_sh.t()) if b_sh is not None else x2 @ w_sh.t()
+        ctx.save_for_backward(x2, w_sh)
+        ctx.stash, ctx.iw, ctx.ib, ctx.xshape, ctx.xdtype = stash, iw, ib, x.shape, x.dtype
+        return y.reshape(*x.shape[:-1], w_sh.shape[0])
+
+    @staticmethod
+    def backward(ctx, gy):
+        x2, w_sh = ctx.saved_tensors
+        g2 = gy.reshape(-1, gy.shape[-1])
+        if g2.dtype != torch.bfloat16:
+            g2 = g2.to(torch.bfloat16)
+        ctx.stash[ctx.iw] = g2.t() @ x2
+        if ctx.ib is not None:
+            ctx.stash[ctx.ib] = g2.sum(0)
+        gx = None
+        if ctx.needs_input_grad[0]:
+            gx = (g2 @ w_sh).reshape(ctx.xshape)
+            if gx.dtype != ctx.xdtype:
+                gx = gx.to(ctx.xdtype)
+        return gx, None, None, None, None, None, None
+
+
+def enable_shadow_linears(model: nn.Module, opt: "FlatClipAdam", params, flat: torch.Tensor):
+    """Routes every plain nn.Linear of `model` through _ShadowLinearFn.  Returns (stash, grad_views, patched modules)."""
+    import types
+    sh = opt.enable_shadow()
+    offs, off = {}, 0
+    for q in params:
+        offs[id(q)] = off
+        off += q.numel()
+    stash, dst, patched = [], [], []
+    for mod in model.modules():
+        if type(mod) is not nn.Linear or id(mod.weight) not in offs:
+            continue
+        ow = offs[id(mod.weight)]
+        w_sh = sh[ow:ow + mod.weight.numel()].view_as(mod.weight)
+        iw = len(stash); stash.append(None); dst.append(flat[ow:ow + mod.weight.numel()].view_as(mod.weight))
+        b_sh, ib = None, None
+        if mod.bias is not None:
+            ob = offs[id(mod.bias)]
+            b_sh = sh[ob:ob + mod.bias.numel()]
+            ib = len(stash); stash.append(None); dst.append(flat[ob:ob + mod.bias.numel()])
+
+        def fwd(self, x, w_sh=w_sh, b_sh=b_sh, iw=iw, ib=ib):
+            if not x.is_cuda:
+                return F_linear(x, self.weight, self.bias)
+            return _ShadowLinearFn.apply(x, w_sh, b_sh, stash, iw, ib, self.weight)
+
+        mod.forward = types.MethodType(fwd, mod)
+        patched.append(mod)
+    return stash, dst, patched
+
+
+def disable_shadow_linears(patched) -> None:
+    for mod in patched:
+        if "forward" in mod.__dict__:
+            del mod.__dict__["forward"]
+
+
+F_linear = torch.nn.functional.linear
+_SHADOW_LINEAR = os.environ.get("OPS_AMD_SHADOW_LINEAR", "1") == "1"   # A/B switch: 0 = nn.Linear under autocast
 
 
 def build_model_and_loss(kind: str, cfg, data: SurrogateData, device):
@@ -284,6 +372,7 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
     for q in params:
         q.grad = flat[off:off + q.numel()].view_as(q)
         off += q.numel()
+    g_stash, g_dst, patched = [], [], []
     torch.manual_seed(seed + 1 + rank)  # different noise / shuffles per rank
     on_gpu = device.type == "cuda"
     if use_graph is None:
@@ -293,6 +382,8 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
     if on_gpu:      # clip + Adam over the flat buffers in two HIP launches; loss.alpha NOT included (PINN:696)
         opt = FlatClipAdam(params, flat, cfg.learning_rate, weight_decay=cfg.weight_decay, max_norm=1.0, decoupled=kind == "gnn")
         sched = None
+        if _SHADOW_LINEAR and autocast_dtype == torch.bfloat16:
+            g_stash, g_dst, patched = enable_shadow_linears(model, opt, params, flat)
     else:
         opt = (torch.optim.AdamW if kind == "gnn" else torch.optim.Adam)(model.parameters(), lr=cfg.learning_rate,   # GNN:394
                                                                          weight_decay=cfg.weight_decay)
@@ -346,6 +437,8 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
         if physics is not None:
             loss = loss + physics.weight * physics_loss(preds.float(), rows).float()
         loss.backward()
+        if g_stash:                      # the shadow-linear weight / bias gradients: one multi-tensor cast-and-copy into `flat`
+            torch._foreach_copy_(g_dst, g_stash)
         return loss.detach()
 
     def apply_update():
@@ -405,6 +498,8 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
                 torch.cuda.synchronize(device)
         torch.cuda.current_stream(device).wait_stream(side)
         model.load_state_dict(snap[0]); opt.load_state_dict(snap[1])     # the warm-up steps never happened
+        if on_gpu:
+            opt.refresh_shadow()
         # the validation pass as a graph too: one full batch in eval mode, loss accumulated into v_acc
         if graph is not None and Xva.shape[0] >= bs:
             vX, vY = torch.zeros_like(Xva[:bs]), torch.zeros_like(Yva[:bs])
@@ -489,6 +584,7 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
             log(f"Epoch {epoch}/{n_epochs} | Train Loss={tl:.6f}, Val Loss={vl:.6f}, Time={hist['epoch_s'][-1]:.2f}s")
         if no_improve >= cfg.patience:
             break
+    disable_shadow_linears(patched)      # the returned model is a plain module again
     if best_state is not None:
         model.load_state_dict(best_state)
     model.eval()

@@ -144,3 +144,22 @@ def test_graph_validation_pass_equals_an_eager_module_evaluation():
         for i in range(0, d.X_val.shape[0], 32):
             tot += float(crit(model(d.X_val[i:i + 32]).float(), d.Y_val[i:i + 32])); nb += 1
     assert out["history"]["val"][0] == pytest.approx(tot / nb, rel=2e-3)
+
+
+def test_shadow_linear_path_trains_like_nn_linear_under_autocast(monkeypatch):
+    """bf16 shadow weights + stashed gradients (train._ShadowLinearFn) vs nn.Linear under autocast: same seeds, same data ->
+    the same loss trajectory up to bf16 rounding order; the returned model is a plain module again."""
+    from openpystruct_amd import dataprep, sizing, train
+    rec = sizing.generate_dataset(3000, sizing.SizingConfig(max_e=30), "cuda", seed=4)
+    d = dataprep.prepare(rec, kind="fnn", seed=0, device="cuda")
+    cfg = train.FnnConfig(batch_size=64, dropout_rate=0.0)
+    hist = {}
+    for flag in (True, False):
+        monkeypatch.setattr(train, "_SHADOW_LINEAR", flag)
+        out = train.train_surrogate("fnn", d, cfg, device="cuda", max_epochs=3, seed=7)
+        hist[flag] = out["history"]
+        assert all("forward" not in m.__dict__ for m in out["model"].modules())
+    for a, b in zip(hist[True]["train"], hist[False]["train"]):
+        assert a == pytest.approx(b, rel=3e-2)
+    for a, b in zip(hist[True]["val"], hist[False]["val"]):
+        assert a == pytest.approx(b, rel=3e-2)
