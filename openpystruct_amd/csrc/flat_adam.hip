@@ -23,7 +23,8 @@ constexpr int FA_THREADS = 256;
 constexpr int FA_NORM_BLOCKS = 128;
 
 __global__ __launch_bounds__(FA_THREADS) void flat_grad_norm_kernel(long n, const float* __restrict__ g, float grad_scale,
-                                                                     double* __restrict__ part, int32_t* __restrict__ step) {
+                                                                     double* __restrict__ part, int32_t* __restrict__ step, float beta1,
+                                                                     float beta2) {
   __shared__ double s_red[FA_THREADS / 64];
   float acc = 0.0f;
   for (long i = (long)blockIdx.x * FA_THREADS + threadIdx.x; i < n; i += (long)gridDim.x * FA_THREADS) {
@@ -38,7 +39,12 @@ __global__ __launch_bounds__(FA_THREADS) void flat_grad_norm_kernel(long n, cons
     double t = 0.0;
     for (int w = 0; w < FA_THREADS / 64; ++w) t += s_red[w];
     part[blockIdx.x] = t;
-    if (blockIdx.x == 0) step[0] += 1;
+    if (blockIdx.x == 0) {               // advance the step and tabulate its bias corrections ONCE (two double pow() per thread of
+      const int st = step[0] + 1;        // the update kernel had cost more than its memory traffic)
+      step[0] = st;
+      part[FA_NORM_BLOCKS] = 1.0 - pow((double)beta1, (double)st);
+      part[FA_NORM_BLOCKS + 1] = sqrt(1.0 - pow((double)beta2, (double)st));
+    }
   }
 }
 
@@ -53,8 +59,7 @@ __global__ __launch_bounds__(FA_THREADS) void flat_adam_kernel(long n, float* __
   float clip = max_norm > 0.0f ? max_norm / (norm + 1e-6f) : 1.0f;      // torch.nn.utils.clip_grad_norm_
   clip = clip < 1.0f ? clip : 1.0f;
   const float gs = clip * grad_scale;
-  const double t = (double)step[0];
-  const float bc1 = (float)(1.0 - pow((double)beta1, t)), bc2s = (float)sqrt(1.0 - pow((double)beta2, t));
+  const float bc1 = (float)part[FA_NORM_BLOCKS], bc2s = (float)part[FA_NORM_BLOCKS + 1];
   const float step_size = lr[0] / bc1;
   for (long i = (long)blockIdx.x * FA_THREADS + threadIdx.x; i < n; i += (long)gridDim.x * FA_THREADS) {
     float pi = p[i];
@@ -79,7 +84,7 @@ __global__ __launch_bounds__(FA_THREADS) void flat_adam_kernel(long n, float* __
 
 using namespace opsamd;
 
-extern "C" size_t ops_flat_adam_workspace_bytes(void) { return (size_t)FA_NORM_BLOCKS * sizeof(double); }
+extern "C" size_t ops_flat_adam_workspace_bytes(void) { return (size_t)(FA_NORM_BLOCKS + 2) * sizeof(double); }
 
 extern "C" int ops_flat_clip_adam_step_f32(long n, float* params, const float* grads, float* exp_avg, float* exp_avg_sq, const float* lr,
                                            int32_t* step, float max_norm, float grad_scale, float beta1, float beta2, float eps,
@@ -89,7 +94,8 @@ extern "C" int ops_flat_clip_adam_step_f32(long n, float* params, const float* g
   hipStream_t s = (hipStream_t)stream;
   long nb = (n + FA_THREADS - 1) / FA_THREADS;
   const int nparts = (int)(nb < FA_NORM_BLOCKS ? nb : FA_NORM_BLOCKS);
-  hipLaunchKernelGGL(flat_grad_norm_kernel, dim3(nparts), dim3(FA_THREADS), 0, s, n, grads, grad_scale, (double*)workspace, step);
+  hipLaunchKernelGGL(flat_grad_norm_kernel, dim3(nparts), dim3(FA_THREADS), 0, s, n, grads, grad_scale, (double*)workspace, step, beta1,
+                     beta2);
   if (nb > 4096) nb = 4096;
   hipLaunchKernelGGL(flat_adam_kernel, dim3((unsigned)nb), dim3(FA_THREADS), 0, s, n, params, grads, exp_avg, exp_avg_sq, lr, step,
                      (const double*)workspace, nparts, max_norm, grad_scale, beta1, beta2, eps, weight_decay, decoupled_weight_decay,

@@ -74,10 +74,12 @@ __global__ __launch_bounds__(FL_THREADS) void fused_loss_kernel(int B, int C, in
 
 __global__ void fused_loss_finish_kernel(int B, int C, int nI, int nD, const double* __restrict__ part, int G, const float* __restrict__ alpha_p,
                                          float alpha0, float w, float penalty, float* __restrict__ loss) {
-  if (threadIdx.x != 0) return;
-  double t[5] = {0, 0, 0, 0, 0};
-  for (int g = 0; g < G; ++g)
+  double t[5] = {0, 0, 0, 0, 0};      // one wave: lane g sums partials g, g + 64, ...; butterfly over the lanes
+  for (int g = threadIdx.x; g < G; g += 64)
     for (int k = 0; k < 5; ++k) t[k] += part[g * 5 + k];
+  for (int k = 0; k < 5; ++k)
+    for (int s = 32; s >= 1; s >>= 1) t[k] += __shfl_xor(t[k], s, 64);
+  if (threadIdx.x != 0) return;
   const double alpha = fmin(fmax((double)alpha_p[0], 1e-6), 1.0);
   const int nR = C - nI - nD;
   const double nIe = (double)B * nI;

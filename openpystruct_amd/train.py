@@ -534,12 +534,15 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
         order = torch.randperm(Xtr.shape[0], device=device)                  # DataLoader(shuffle=True), PINN:701
         tot = torch.zeros((), device=device)
         noise_t = torch.tensor(noise, device=device)
+        if graph is not None:
+            s_noise.copy_(noise_t)                                           # constant within the epoch
         for b in range(nb_tr):
             # `order` is the DataLoader shuffle; permute_data (PINN:753) re-permutes inside the batch, which
             # changes neither the batch statistics nor the mean loss, so it is folded into `order`
             idx = order[b * bs:(b + 1) * bs]
             if graph is not None and idx.numel() == bs:
-                sX.copy_(Xtr[idx]); sY.copy_(Ytr[idx]); s_noise.copy_(noise_t)
+                torch.index_select(Xtr, 0, idx, out=sX)                      # gather straight into the graph's input buffers
+                torch.index_select(Ytr, 0, idx, out=sY)
                 graph.replay()
                 if graph_b is not None:
                     dist.all_reduce(flat)
