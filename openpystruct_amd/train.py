@@ -403,26 +403,36 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
         if kind != "pinn" and data.v_train is None:
             raise ValueError("the FE-residual term of an I-only model needs the recorded displacements (data.v_train)")
         from .physics import fe_residual_loss
-        use_graph = False                       # the physics term indexes per-batch loads eagerly
         Fy_tr = data.Fy_train.to(device)
         sI = data.scalers_Y["I"]
         if kind == "pinn":
             sD, sR = data.scalers_Y["deflections"], data.scalers_Y["rotations"]
         else:
             v_rec, t_rec = data.v_train.to(device), data.theta_train.to(device)
-        px, pfix = physics.x.to(device), physics.fix.to(device)
+        px, pfix = physics.x.to(device=device, dtype=torch.float64), physics.fix.to(device=device, dtype=torch.uint8)
+        pE = torch.tensor(float(physics.E), dtype=torch.float64, device=device)      # device scalars: nothing crosses PCIe
+        pwy = torch.tensor(float(physics.wy), dtype=torch.float64, device=device)    # inside a captured step
 
-    def physics_loss(preds, rows):
+    def physics_inputs(rows, out=None):
+        """Per-batch loads (and, for the I-only models, recorded displacement fields); `out`: the graph's static buffers."""
+        srcs = (Fy_tr,) if kind == "pinn" else (Fy_tr, v_rec, t_rec)
+        if out is None:
+            return tuple(t[rows] for t in srcs)
+        for t, o in zip(srcs, out):
+            torch.index_select(t, 0, rows, out=o)
+        return out
+
+    def physics_loss(preds, pin):
         nel = cfg.nelem
         I_p = sI.inverse_transform(preds[:, :nel]).clamp_min(1e-8)
         if kind == "pinn":
             v_p = sD.inverse_transform(preds[:, nel:2 * nel + 1])
             t_p = sR.inverse_transform(preds[:, 2 * nel + 1:])
         else:
-            v_p, t_p = v_rec[rows], t_rec[rows]
-        return fe_residual_loss(I_p, v_p, t_p, px, physics.E, pfix, Fy_tr[rows], physics.wy)
+            v_p, t_p = pin[1], pin[2]
+        return fe_residual_loss(I_p, v_p, t_p, px, pE, pfix, pin[0], pwy)
 
-    def fwd_bwd(Xb, Yb, noise_t, rows=None):
+    def fwd_bwd(Xb, Yb, noise_t, pin=None):
         """Segment A: local gradients of the mean batch loss into `flat`."""
         Xn = Xb + torch.randn_like(Xb) * noise_t                         # PINN:756
         flat.zero_()                                                     # optimizer.zero_grad()
@@ -435,7 +445,7 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
                 if alpha_term:
                     loss = loss + (cfg.initial_alpha - crit.alpha) ** 2   # TFD:743 / FNN (constant 0: alpha never trains)
         if physics is not None:
-            loss = loss + physics.weight * physics_loss(preds.float(), rows).float()
+            loss = loss + physics.weight * physics_loss(preds.float(), pin).float()
         loss.backward()
         if g_stash:                      # the shadow-linear weight / bias gradients: one multi-tensor cast-and-copy into `flat`
             torch._foreach_copy_(g_dst, g_stash)
@@ -452,7 +462,7 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
         opt.step()
 
     def train_step(Xb, Yb, noise_t, rows=None):
-        loss = fwd_bwd(Xb, Yb, noise_t, rows)
+        loss = fwd_bwd(Xb, Yb, noise_t, physics_inputs(rows) if physics is not None else None)
         if world > 1:
             dist.all_reduce(flat)                                        # the step's only collective (RCCL over xGMI)
         apply_update()
@@ -472,19 +482,24 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
         # world == 1 -> one graph; world > 1 -> [fwd_bwd] graph, eager all-reduce, [apply_update] graph
         sX, sY = torch.zeros_like(Xtr[:bs]), torch.zeros_like(Ytr[:bs])
         s_noise = torch.zeros((), device=device)
+        sP = None
+        if physics is not None:                  # static per-batch physics inputs, gathered before every replay
+            sP = tuple(torch.zeros_like(t[:bs]) for t in physics_inputs(torch.arange(bs, device=device)))
         snap = (copy.deepcopy(model.state_dict()), copy.deepcopy(opt.state_dict()))
         side = torch.cuda.Stream(device=device)
         side.wait_stream(torch.cuda.current_stream(device))
         with torch.cuda.stream(side):
             sX.copy_(Xtr[:bs]); sY.copy_(Ytr[:bs])
+            if sP is not None:
+                physics_inputs(torch.arange(bs, device=device), out=sP)
             for _ in range(3):
-                fwd_bwd(sX, sY, s_noise)
+                fwd_bwd(sX, sY, s_noise, sP)
                 apply_update()                   # warm-up only: no collective needed for capture-readiness
             side.synchronize()
             try:
                 graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(graph, stream=side, capture_error_mode="thread_local"):
-                    s_loss = fwd_bwd(sX, sY, s_noise)
+                    s_loss = fwd_bwd(sX, sY, s_noise, sP)
                     if world == 1:
                         apply_update()
                 if world > 1:
@@ -543,6 +558,8 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
             if graph is not None and idx.numel() == bs:
                 torch.index_select(Xtr, 0, idx, out=sX)                      # gather straight into the graph's input buffers
                 torch.index_select(Ytr, 0, idx, out=sY)
+                if sP is not None:
+                    physics_inputs(idx, out=sP)
                 graph.replay()
                 if graph_b is not None:
                     dist.all_reduce(flat)
