@@ -173,6 +173,16 @@ def surrogate_epoch_times(dev, rank, world, epochs, cases=50000):
             ep = r["history"]["epoch_s"][1:] or r["history"]["epoch_s"]
             out[kind] = {"epoch_s": sum(ep) / len(ep), "steps_per_epoch": r["steps_per_epoch"], "train_groups_per_gpu": int(d.X_train.shape[0]),
                          "dtype": "bf16"}
+        # BASELINE config 4: the TFD surrogate with the physics loss through the HIP FE-residual kernels.  The residual needs
+        # per-case targets (n_cases = 1: 40 000 training rows per GPU instead of 6 666 groups), see DESIGN.md section 8
+        scfg = sizing.SizingConfig()
+        phys = train.PhysicsTerm(weight=1e-3, x=torch.linspace(0, scfg.L_max, scfg.num_nodes, dtype=torch.float64), E=scfg.E,
+                                 fix=sizing.make_cases(1, scfg).fix[0], wy=scfg.uniform_udl)
+        d1 = dataprep.prepare(rec, kind="tfd", n_cases=1, device=dev, distributed=world > 1)
+        r = train.train_surrogate("tfd", d1, train.TfdConfig(n_cases=1), device=dev, max_epochs=max(2, epochs - 2), physics=phys)
+        ep = r["history"]["epoch_s"][1:] or r["history"]["epoch_s"]
+        out["tfd_physics"] = {"epoch_s": sum(ep) / len(ep), "steps_per_epoch": r["steps_per_epoch"], "train_rows_per_gpu": int(d1.X_train.shape[0]),
+                              "dtype": "bf16", "n_cases": 1}
         return out
     except Exception as e:   # the FE line must survive whatever happens here
         return {"error": repr(e)}
