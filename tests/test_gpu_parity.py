@@ -263,3 +263,46 @@ def test_torch_library_operator_matches_beam_solve_and_captures(oa):
     g.replay()
     torch.cuda.synchronize()
     assert float(relerr(out[0].cpu().numpy(), 0.5 * ref.v.cpu().numpy())) < 1e-9
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_support_patterns_sizes_and_tilings(oa, seed):
+    """Random meshes (1..60 elements), random per-beam support patterns incl. fixed rotations and fully clamped nodes,
+    random loads and section data, every tiling that fits: displacements vs the dense oracle to eps * cond."""
+    rng = np.random.default_rng(9000 + seed)
+    Ne = int(rng.integers(1, 61))
+    N = Ne + 1
+    B = 11
+    x = np.cumsum(rng.uniform(0.2, 3.0, size=N))
+    fix = np.zeros((B, N), dtype=np.uint8)
+    for b in range(B):
+        k = int(rng.integers(1, 5))
+        nodes = rng.choice(N, size=min(k, N), replace=False)
+        fix[b, nodes] = rng.integers(1, 4, size=nodes.size)                    # uy, rz or both
+        if not (fix[b] & 1).any():
+            fix[b, nodes[0]] |= 1                                              # some vertical support
+        if ((fix[b] & 1).sum() < 2) and not ((fix[b] == 3).any()):
+            fix[b, nodes[0]] = 3                                               # one vertical support only: clamp it
+    I = np.exp(rng.uniform(np.log(1e-3), np.log(0.5), size=(B, Ne)))
+    E = 2.0e11 * rng.uniform(0.5, 1.5, size=(B, Ne))
+    Fy = rng.uniform(-1e5, 1e4, size=(B, N)) * (rng.random((B, N)) < 0.3)
+    wy = rng.uniform(-2000, 0, size=(B, Ne))
+    xb = np.tile(x, (B, 1))
+    ref = [bo.solve_beam_dense(x, E[b], I[b], fix[b], Fy[b], wy[b]) for b in range(B)]
+    conds = []
+    for b in range(B):
+        K, _ = bo.assemble_beam(x, E[b], I[b], Fy[b], wy[b])
+        free = np.ones(2 * N, dtype=bool); free[0::2] = (fix[b] & 1) == 0; free[1::2] = (fix[b] & 2) == 0
+        conds.append(np.linalg.cond(K[np.ix_(free, free)]) if free.any() else 1.0)
+    for tiling in (0, 8, 16, 32, 64):
+        if tiling and tiling * {8: 13, 16: 7, 32: 4, 64: 16}[tiling] < N:
+            continue
+        v, th, V, M, st = _solve(oa, xb, E, I, fix, Fy, wy, tiling=tiling)
+        assert (st == 0).all()
+        for b in range(B):
+            tol = max(1e-9, 5e-16 * conds[b])
+            sc = max(np.abs(ref[b][0]).max(), 1e-300)
+            assert np.abs(v[b] - ref[b][0]).max() / sc < tol, (tiling, b, Ne)
+            sct = max(np.abs(ref[b][1]).max(), 1e-300)
+            assert np.abs(th[b] - ref[b][1]).max() / sct < tol, (tiling, b, Ne)
+            assert (v[b][(fix[b] & 1) != 0] == 0.0).all() and (th[b][(fix[b] & 2) != 0] == 0.0).all()
