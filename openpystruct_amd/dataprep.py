@@ -199,3 +199,30 @@ def prepare(records: Dict[str, object], *, kind: str = "pinn", n_cases: int = 6,
         th_tr = as64(records["rotations"])[:G].to(dev)[tr].contiguous()
     return SurrogateData(Xtr.contiguous(), Ytr.contiguous(), Xva.contiguous(), Yva.contiguous(), sc_in, sc_Y, mn, mx, feat_dim, ml,
                          Fy_tr, Fy_va, v_tr, th_tr)
+
+
+def user_inputs(data: SurrogateData, kind: str, roller_x, force_x, force_values, node_positions, nheads: int = 8) -> torch.Tensor:
+    """The inference front end of the model scripts (`scale_user_inputs` + `build_user_input_no_agg`, FNN:138-183, :647-657;
+    PINN:861-...): n_cases lists per feature -> zero-padded to the training widths, scaled with the TRAINING scalers,
+    concatenated per case and flattened ("pinn", "fnn", "gnn") or kept as a sequence ("tfd": padded to a multiple of
+    `nheads`; "fno").  Returns X of one sample, on the scalers' device: [1, n_cases * feat] or [1, n_cases, feat]."""
+    names = ("roller_x", "force_x", "force_values", "node_positions")
+    cols = []
+    for name, seqs in zip(names, (roller_x, force_x, force_values, node_positions)):
+        sc = data.scalers_inputs[name]
+        t = pad_sequences(seqs, data.max_lengths[name]).to(sc.mean_.device)
+        cols.append(sc.transform(t))
+    X = torch.cat(cols, dim=1)                                   # [n_cases, feat]
+    if kind in ("pinn", "fnn", "gnn"):
+        return X.reshape(1, -1)
+    pad = (-X.shape[1]) % (1 if kind == "fno" else nheads)
+    if pad:
+        X = torch.nn.functional.pad(X, (0, pad))
+    return X.unsqueeze(0)
+
+
+def predicted_inertia(data: SurrogateData, preds: torch.Tensor) -> torch.Tensor:
+    """Standardised model output -> second moments of area: `scaler_Y.inverse_transform` on the inertia columns (FNN:692)."""
+    sc = data.scalers_Y["I"]
+    n = sc.mean_.numel()
+    return sc.inverse_transform(preds[..., :n].float())

@@ -232,3 +232,22 @@ def test_fno_model_shapes_names_and_prep():
     assert d.X_train.shape == (16, 6, 114) and d.feat_dim == 114 and d.Y_train.shape == (16, 100)     # no head padding (nheads 1)
     g = dataprep.prepare(rec, kind="gnn", seed=1)
     assert g.X_train.shape == (16, 684) and g.Y_train.shape == (16, 100)
+
+
+def test_user_input_front_end_scales_like_training_rows():
+    """dataprep.user_inputs == the training-time scaling applied to the same raw lists; predicted_inertia inverts scaler_Y."""
+    rec = _fake_records(120, seed=5)
+    for kind in ("pinn", "tfd", "fno"):
+        d = dataprep.prepare(rec, kind=kind, seed=1)
+        g0 = list(range(6))                                      # raw rows of some group
+        args = [[rec["roller_x_locations"][i] for i in g0], [rec["force_x_locations"][i] for i in g0],
+                [rec["force_values"][i] for i in g0], [rec["node_positions"][i].tolist() for i in g0]]
+        X = dataprep.user_inputs(d, kind, *args)
+        assert X.shape[0] == 1 and X.shape[1:] == d.X_train.shape[1:]
+        # the same numbers by hand for the first feature of the first case
+        sc = d.scalers_inputs["roller_x"]
+        first = (args[0][0][0] - float(sc.mean_[0])) / float(sc.scale_[0])
+        assert float(X.reshape(-1)[0]) == pytest.approx(first, rel=1e-5)
+    y = d.Y_train[:3]
+    back = dataprep.predicted_inertia(d, y)
+    assert torch.allclose(d.scalers_Y["I"].transform(back), y[:, :100], atol=1e-5)
