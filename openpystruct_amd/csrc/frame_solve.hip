@@ -529,10 +529,13 @@ static size_t frame_lds_resident_bytes(int n_eq, int kd) {
 }
 
 // workgroup size and window entries per thread: two service waves (look-ahead, forward substitution) + the entry owners
-static void frame_threads(int kd, int* T, int* pp_use) {
+static void frame_threads(int kd, bool resident, int* T, int* pp_use) {
   const int npairs = kd * (kd + 1) / 2;
   auto threads = [&](int pp) { return ((npairs + pp - 1) / pp + 63) / 64 * 64 + 128; };
-  int pp = 2;                                   // two entries per thread: fewer waves per barrier, more workgroups per CU
+  // entries per thread (fewer waves per barrier, more workgroups per CU), measured (profiles/r01_notes.md): four where
+  // several workgroups share a CU -- narrow bands (5x5: 3.5e7 vs 3.15e7/s) and the workspace path (15x16: 9.4e5 vs
+  // 8.55e5/s) --, two for the one-workgroup-per-CU frames in between (10x10: 2.44e6 vs 2.40e6/s)
+  int pp = (!resident || kd <= 24) ? 4 : 2;
   while (threads(pp) > 1024 && pp < FRAME_PP) ++pp;
   // tuning knob for experiments: OPS_AMD_FRAME_PP = entries per thread
   if (const char* e = getenv("OPS_AMD_FRAME_PP")) {
@@ -580,7 +583,7 @@ extern "C" int ops_frame_solve_batched_f64(int B, int n_nodes, int n_elems, int 
   if (const char* e = getenv("OPS_AMD_FRAME_TRACE_PTR")) p.trace = (unsigned long long*)strtoull(e, nullptr, 10);
 #endif
   int T, pp_use;
-  frame_threads(kd, &T, &pp_use);
+  frame_threads(kd, !(lds_bytes > LDS_MAX || force_ws()), &T, &pp_use);
   hipStream_t s = (hipStream_t)stream;
   if (lds_bytes > LDS_MAX || force_ws()) {
     // band in the HBM workspace, sliding LDS ring
