@@ -42,6 +42,27 @@ def test_argument_validation_without_gpu(lib):
     assert rc == _cabi.ERR_INVALID_ARG
     rc = lib.ops_beam_solve_batched_f64(0, 100, z, 0, z, 0, z, 100, z, 0, z, 101, z, 0, z, z, z, z, z, 0, z)
     assert rc == _cabi.OK   # empty batch is a no-op
+    # the other entry points: NULL pointers / bad sizes are refused the same way
+    hp = _cabi.SizingParams(E=2e11, G=7.7e10, alpha_moment=1e-2, alpha_shear=1e-2, lr=0.01, gamma=0.98, beta1=0.9, beta2=0.999,
+                            adam_eps=1e-8, clamp_min=1e-8, bend_eps=1e-6, area_coef=0.03, tolerance=5e-3, patience=5, max_epochs=10)
+    assert lib.ops_beam_solve_forces_f64(4, 100, z, 0, z, 0, z, 100, z, 0, z, 101, z, 0, z, z, z, z, 0, z) == _cabi.ERR_INVALID_ARG
+    assert lib.ops_beam_solve_forces_f32(4, 100, z, 0, z, 0, z, 100, z, 0, z, 101, z, 0, z, z, z, z, 0, z) == _cabi.ERR_INVALID_ARG
+    assert lib.ops_beam_sizing_step_f32(4, 100, *([z] * 13), ctypes.byref(hp), z) == _cabi.ERR_INVALID_ARG
+    assert lib.ops_beam_sizing_step_f32(4, 600, *([z] * 13), ctypes.byref(hp), z) == _cabi.ERR_UNSUPPORTED
+    assert lib.ops_beam_sizing_step_vm32_f32(4, 100, *([z] * 11), ctypes.byref(hp), z, z) == _cabi.ERR_INVALID_ARG
+    assert lib.ops_beam_sizing_epoch_f32(4, 100, z, 0, z, 0, z, 0, z, 101, z, 0, *([z] * 9), ctypes.byref(hp), z, z, 0, z) == _cabi.ERR_INVALID_ARG
+    assert lib.ops_beam_sizing_epoch_f32(4, 200, z, 0, z, 0, z, 0, z, 201, z, 0, *([z] * 9), ctypes.byref(hp), z, z, 0, z) == _cabi.ERR_UNSUPPORTED
+    assert lib.ops_frame_solve_batched_f64(2, 4, 3, 6, 5, *([z] * 8), 0, *([z] * 6), 0, z) == _cabi.ERR_INVALID_ARG
+    assert lib.ops_frame_workspace_bytes(3, 330, 35) == 0 and lib.ops_frame_workspace_bytes(3, 768, 50) > 0
+    assert lib.ops_stencil3_bn1_fwd_f32(2, 3, z, z, z, z, z, 1e-5, 0.1, 1, z, z, z, z, 0, z, z, z) == _cabi.ERR_INVALID_ARG
+    assert lib.ops_stencil3_bn1_bwd_f32(2, 3, z, z, 0, z, z, z, z, 1, z, z, z, z) == _cabi.ERR_INVALID_ARG
+    assert lib.ops_flat_clip_adam_step_f32(10, z, z, z, z, z, z, 1.0, 1.0, 0.9, 0.999, 1e-8, 0.0, 0, z, z, z) == _cabi.ERR_INVALID_ARG
+    assert lib.ops_surrogate_loss_grad_f32(2, 3, 3, 0, z, 0, z, z, 0.5, z, z, 0.1, 0.0, z, z, z, z) == _cabi.ERR_INVALID_ARG
+    assert lib.ops_beam_residual_f64(2, 3, *([z, 0] * 2), z, z, 0, z, z, 0, z, z, z, z, z) == _cabi.ERR_INVALID_ARG
+    sched = (ctypes.c_float * 20)()
+    lib.ops_sizing_schedule_f32(ctypes.byref(hp), ctypes.cast(sched, ctypes.c_void_p))       # host-only helper
+    assert sched[0] == pytest.approx(0.01 / (1 - 0.9), rel=1e-6) and sched[1] == pytest.approx((1 - 0.999) ** 0.5, rel=1e-6)
+    assert sched[2] == pytest.approx(0.01 * 0.98 / (1 - 0.81), rel=1e-6)
 
 
 def test_no_cpu_fallback():
