@@ -14,7 +14,7 @@ every rank of a data-parallel job scales with the GLOBAL statistics although it 
 from __future__ import annotations
 
 from dataclasses import dataclass
-from typing import Dict, List, Optional, Sequence
+from typing import Dict, Optional, Sequence
 
 import torch
 import torch.distributed as dist

@@ -15,6 +15,7 @@ noise/denoise pass is active in eval mode too; CompositeLoss's "physics" terms a
 from __future__ import annotations
 
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -24,15 +25,14 @@ import torch.nn.functional as F
 # ------------------------------------------------------------------------------------------------
 # PINN: residual MLP
 # ------------------------------------------------------------------------------------------------
-import os as _os
 # ResidualBlock's Conv1d(1,1,3) + BatchNorm1d(1) pair through csrc/stencil_bn.hip (default) or through the framework modules
 # (OPS_AMD_PINN_FUSED_STENCIL=0, the A/B switch).  Measured on MI355X, same run: PINN epoch 0.0497 s fused vs 0.0541 s with
 # the modules; the step graph 0.870 vs 0.938 ms (profiles/r01_notes.md).
-_FUSED_STENCIL = _os.environ.get('OPS_AMD_PINN_FUSED_STENCIL', '1') == '1'
+_FUSED_STENCIL = os.environ.get("OPS_AMD_PINN_FUSED_STENCIL", "1") == "1"
 
 
 class _StencilBN(torch.autograd.Function):
-    """csrc/stencil_bn.hip behind autograd: one launch forward, one backward (GPU float32 tensors only)."""
+    """csrc/stencil_bn.hip behind autograd: two launches forward, three backward (GPU tensors only)."""
 
     @staticmethod
     def forward(ctx, x, cw, cb, gamma, beta, bn, training, out_bf16):
