@@ -155,3 +155,87 @@ def test_singular_reports_status():
     st_c = co.solve_beam_batched(x, E, I, fix, Fy, 0.0)[4]
     assert st_np[0] != 0 and st_np[1] != 0 and st_np[2] == 0
     assert st_c[0] != 0 and st_c[1] != 0 and st_c[2] == 0
+
+
+def test_kat_reference_bridge_by_the_three_moment_equation():
+    """The reference's own bridge (pin at x = 0, rollers at nodes 10, 30, 70, 85, 100 of a 200 m / 100-element beam, 2 m
+    overhang; SingleCore.py:58-62) under its UDL alone, uniform EI: support moments from Clapeyron's three-moment equation
+    -- an analysis that shares nothing with the FE formulation -- against the oracle's element end moments and reactions."""
+    q = 1000.0                                            # |uniform_udl|, downward
+    xs = np.array([0.0, 18.0, 58.0, 138.0, 168.0, 198.0])  # supports: 2 m * (node - 1)
+    Ls = np.diff(xs)                                      # spans 18, 40, 80, 30, 30
+    a = 200.0 - xs[-1]                                    # overhang
+    M0, M5 = 0.0, -q * a * a / 2.0                        # sagging positive: free rotation at the pin, cantilever root moment
+    # M_{i-1} L_i + 2 M_i (L_i + L_{i+1}) + M_{i+1} L_{i+1} = -q (L_i^3 + L_{i+1}^3) / 4,  i = 1..4
+    A = np.zeros((4, 4)); rhs = np.zeros(4)
+    for k, i in enumerate(range(1, 5)):
+        Ll, Lr = Ls[i - 1], Ls[i]
+        A[k, k] = 2.0 * (Ll + Lr)
+        if k > 0: A[k, k - 1] = Ll
+        if k < 3: A[k, k + 1] = Lr
+        rhs[k] = -q * (Ll ** 3 + Lr ** 3) / 4.0
+    rhs[3] -= Ls[4] * M5
+    rhs[0] -= Ls[0] * M0
+    Ms = np.concatenate([[M0], np.linalg.solve(A, rhs), [M5]])       # bending moments over the six supports
+    # reactions from span equilibrium: shear just right / left of each support
+    Vr = [q * Ls[i] / 2.0 + (Ms[i + 1] - Ms[i]) / Ls[i] for i in range(5)]          # left end of span i (upward on the beam)
+    Vl = [q * Ls[i] / 2.0 - (Ms[i + 1] - Ms[i]) / Ls[i] for i in range(5)]          # right end of span i
+    R = np.array([Vr[0]] + [Vl[i - 1] + Vr[i] for i in range(1, 5)] + [Vl[4] + q * a])
+    assert R.sum() == pytest.approx(q * 200.0, rel=1e-12)
+
+    x = np.linspace(0.0, 200.0, 101)
+    fix = bo.reference_fix_mask()
+    EI = bo.E_REF * bo.I0_REF
+    v, th, V, M, st = bo.solve_beam_dense(x, bo.E_REF, np.full(100, bo.I0_REF), fix, np.zeros(101), -q)
+    assert st == 0
+    nodes = [1, 10, 30, 70, 85, 100]                      # 1-based support nodes
+    # eleResponse 'forces'[2] at end I of element e (= node e) is MINUS the sagging-positive bending moment there
+    for n, Mb in zip(nodes[1:], Ms[1:]):
+        assert -M[n - 1] == pytest.approx(Mb, rel=2e-8), (n, -M[n - 1], Mb)
+    # reactions: jump of the element end shears across a support node (forces[1] of element n minus -forces of element n-1)
+    d3, f3, st3, _, _ = bo.solve_reference_beam_3dof(x, bo.A_REF, bo.E_REF, np.full(100, bo.I0_REF), bo.ROLLERS_REF, [], [], -q)
+    Fy1, Fy2 = f3[:, 1], f3[:, 4]
+    for n, Rn in zip(nodes, R):
+        react = Fy1[n - 1] + (Fy2[n - 2] if n >= 2 else 0.0)    # sum of the element end forces meeting at the node = support reaction
+        assert react == pytest.approx(Rn, rel=2e-8), (n, react, Rn)
+    assert abs(EI) > 0
+
+
+def test_kat_reference_bridge_with_point_loads_by_the_three_moment_equation():
+    """Same bridge with the UDL plus two of the generator's point loads (SingleCore.py:157-160) at nodes 20 and 50."""
+    q = 1000.0
+    xs = np.array([0.0, 18.0, 58.0, 138.0, 168.0, 198.0])
+    Ls = np.diff(xs)
+    a_ov = 2.0
+    loads = [(20, 3.0e5), (50, 1.2e5)]                    # (node, downward magnitude)
+    M0, M5 = 0.0, -q * a_ov * a_ov / 2.0
+
+    def span_terms(i):
+        """6 A abar / L (moment-area term seen from the span's LEFT support) and 6 A bbar / L (from its RIGHT one)."""
+        L = Ls[i]
+        tl = tr = q * L ** 3 / 4.0
+        for n, P in loads:
+            xp = 2.0 * (n - 1)
+            if xs[i] < xp < xs[i + 1]:
+                a, b = xp - xs[i], xs[i + 1] - xp
+                tl += P * a * (L * L - a * a) / L
+                tr += P * b * (L * L - b * b) / L
+        return tl, tr
+
+    A = np.zeros((4, 4)); rhs = np.zeros(4)
+    for k, i in enumerate(range(1, 5)):
+        Ll, Lr = Ls[i - 1], Ls[i]
+        A[k, k] = 2.0 * (Ll + Lr)
+        if k > 0: A[k, k - 1] = Ll
+        if k < 3: A[k, k + 1] = Lr
+        rhs[k] = -(span_terms(i - 1)[0] + span_terms(i)[1])
+    rhs[3] -= Ls[4] * M5
+    Ms = np.concatenate([[M0], np.linalg.solve(A, rhs), [M5]])
+    x = np.linspace(0.0, 200.0, 101)
+    Fy = np.zeros(101)
+    for n, P in loads:
+        Fy[n - 1] -= P
+    v, th, V, M, st = bo.solve_beam_dense(x, bo.E_REF, np.full(100, bo.I0_REF), bo.reference_fix_mask(), Fy, -q)
+    assert st == 0
+    for n, Mb in zip([10, 30, 70, 85, 100], Ms[1:]):
+        assert -M[n - 1] == pytest.approx(Mb, rel=2e-8), (n, -M[n - 1], Mb)
