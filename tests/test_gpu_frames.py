@@ -194,3 +194,23 @@ def test_tiny_bandwidth_cantilever_chain():
         assert int(sol.status.abs().sum()) == 0 and kd == topo.kd
         assert relerr(sol.disp[0].cpu().numpy().ravel(), d.ravel()) < 1e-8
         assert relerr(sol.forces[1].cpu().numpy().ravel(), f.ravel()) < 1e-7
+
+
+def test_l_shaped_cantilever_closed_form_on_the_gpu():
+    """Statically determinate L (clamped column + arm, vertical tip load): the HIP frame solve against the closed form."""
+    from openpystruct_amd import frames
+    h, a, P = 4.0, 3.0, -2.0e4
+    E, A, I = 2.0e11, 8.0e-3, 3.0e-5
+    nc, na = 8, 6
+    coords = np.array([(0.0, h * i / nc) for i in range(nc + 1)] + [(a * j / na, h) for j in range(1, na + 1)])
+    conn = np.array([(i, i + 1) for i in range(nc + na)])
+    fix3 = np.zeros((len(coords), 3), dtype=bool); fix3[0] = True
+    loads = np.zeros((len(coords), 3)); loads[-1, 1] = P
+    topo = frames.FrameTopology(coords, conn, fix3, A, E, 0.0, 0.0, loads, "cuda")
+    sol = frames.frame_solve(topo, torch.full((3, len(conn)), I, dtype=torch.float64, device="cuda"))
+    d = sol.disp[1].cpu().numpy(); f = sol.forces[2].cpu().numpy()
+    EI, EA = E * I, E * A
+    assert d[nc, 1] == pytest.approx(P * h / EA, rel=1e-9) and d[nc, 2] == pytest.approx(P * a * h / EI, rel=1e-9)
+    assert d[nc, 0] == pytest.approx(-P * a * h * h / (2 * EI), rel=1e-9)
+    assert d[-1, 1] == pytest.approx(P * h / EA + d[nc, 2] * a + P * a ** 3 / (3 * EI), rel=1e-9)
+    assert f[0, 1] == pytest.approx(-P, rel=1e-9) and f[0, 2] == pytest.approx(-P * a, rel=1e-9)

@@ -239,3 +239,28 @@ def test_kat_reference_bridge_with_point_loads_by_the_three_moment_equation():
     assert st == 0
     for n, Mb in zip([10, 30, 70, 85, 100], Ms[1:]):
         assert -M[n - 1] == pytest.approx(Mb, rel=2e-8), (n, -M[n - 1], Mb)
+
+
+def test_kat_frame_oracle_l_shaped_cantilever():
+    """The 3-DOF frame oracle on a statically determinate L: column (0,0)-(0,h) clamped at its base, arm (0,h)-(a,h), vertical
+    tip load P.  Closed form: column under axial P and constant moment P a; arm as a cantilever on the rotated column top."""
+    h, a, P = 4.0, 3.0, -2.0e4
+    E, A, I = 2.0e11, 8.0e-3, 3.0e-5
+    nc, na = 8, 6
+    coords = [(0.0, h * i / nc) for i in range(nc + 1)] + [(a * j / na, h) for j in range(1, na + 1)]
+    conn = [(i, i + 1) for i in range(nc + na)]
+    fix3 = np.zeros((len(coords), 3), dtype=np.int64); fix3[0] = 1
+    loads = np.zeros((len(coords), 3)); loads[-1, 1] = P
+    d, f, st, neq, kd = bo.solve_model_3dof(np.array(coords), np.array(conn), A, E, np.full(len(conn), I), fix3, loads)
+    assert st == 0
+    EI, EA = E * I, E * A
+    top = d[nc]
+    Mc = P * a                                            # constant moment in the column (about z, from the tip load)
+    assert top[1] == pytest.approx(P * h / EA, rel=1e-9)                  # axial shortening
+    assert top[2] == pytest.approx(Mc * h / EI, rel=1e-9)                 # rotation of the column top
+    assert top[0] == pytest.approx(-Mc * h * h / (2 * EI), rel=1e-9)      # sway: a clockwise top rotation moves it to +x for P < 0
+    tip = d[-1]
+    assert tip[1] == pytest.approx(P * h / EA + top[2] * a + P * a ** 3 / (3 * EI), rel=1e-9)
+    assert tip[0] == pytest.approx(top[0], rel=1e-9, abs=1e-15)           # the arm carries no axial force
+    # base reactions through the element end forces of the first column element: global (Fx, Fy, Mz) at node 0
+    assert f[0, 1] == pytest.approx(-P, rel=1e-9) and f[0, 2] == pytest.approx(-P * a, rel=1e-9) and abs(f[0, 0]) < 1e-6 * abs(P)
