@@ -306,3 +306,25 @@ def test_random_support_patterns_sizes_and_tilings(oa, seed):
             sct = max(np.abs(ref[b][1]).max(), 1e-300)
             assert np.abs(th[b] - ref[b][1]).max() / sct < tol, (tiling, b, Ne)
             assert (v[b][(fix[b] & 1) != 0] == 0.0).all() and (th[b][(fix[b] & 2) != 0] == 0.0).all()
+
+
+@pytest.mark.parametrize("tiling", [0, 8, 16, 32, 64])
+def test_reference_bridge_support_moments_by_the_three_moment_equation(oa, tiling):
+    """The HIP solve of the reference's bridge under its UDL against Clapeyron's three-moment equation -- no oracle involved."""
+    q = 1000.0
+    xs = np.array([0.0, 18.0, 58.0, 138.0, 168.0, 198.0]); Ls = np.diff(xs)
+    M5 = -q * 2.0 * 2.0 / 2.0
+    A = np.zeros((4, 4)); rhs = np.zeros(4)
+    for k, i in enumerate(range(1, 5)):
+        A[k, k] = 2.0 * (Ls[i - 1] + Ls[i])
+        if k > 0: A[k, k - 1] = Ls[i - 1]
+        if k < 3: A[k, k + 1] = Ls[i]
+        rhs[k] = -q * (Ls[i - 1] ** 3 + Ls[i] ** 3) / 4.0
+    rhs[3] -= Ls[4] * M5
+    Ms = np.concatenate([np.linalg.solve(A, rhs), [M5]])
+    x = np.linspace(0.0, 200.0, 101)
+    v, th, V, M, st = _solve(oa, x, bo.E_REF, np.full((9, 100), bo.I0_REF), bo.reference_fix_mask(), np.zeros((9, 101)), -q, tiling=tiling)
+    assert (st == 0).all()
+    for n, Mb in zip([10, 30, 70, 85, 100], Ms):
+        assert -M[4, n - 1] == pytest.approx(Mb, rel=5e-8), (n, -M[4, n - 1], Mb)
+    assert np.abs(v[:, [0, 9, 29, 69, 84, 99]]).max() == 0.0
