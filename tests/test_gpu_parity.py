@@ -328,3 +328,24 @@ def test_reference_bridge_support_moments_by_the_three_moment_equation(oa, tilin
     for n, Mb in zip([10, 30, 70, 85, 100], Ms):
         assert -M[4, n - 1] == pytest.approx(Mb, rel=5e-8), (n, -M[4, n - 1], Mb)
     assert np.abs(v[:, [0, 9, 29, 69, 84, 99]]).max() == 0.0
+
+
+@pytest.mark.parametrize("tiling", [0, 8, 32])
+def test_mirror_symmetry(oa, tiling):
+    """Solving the mirrored beam (x -> L - x, element and node arrays reversed) gives the mirrored field:
+    v reversed, theta reversed with the opposite sign -- the lanes see completely different segments."""
+    rng = np.random.default_rng(5150)
+    B, Ne, N = 64, 100, 101
+    x = np.cumsum(np.concatenate([[0.0], rng.uniform(0.5, 3.5, size=Ne)]))
+    fix = np.zeros(N, dtype=np.uint8); fix[[3, 27, 55, 80, 97]] = 1; fix[12] = 3
+    I = np.exp(rng.uniform(np.log(3e-3), np.log(0.75), size=(B, Ne)))
+    Fy = rng.uniform(-3e5, 0.0, size=(B, N)) * (rng.random((B, N)) < 0.05)
+    wy = rng.uniform(-2000.0, 0.0, size=(B, Ne))
+    E = np.full((B, Ne), bo.E_REF)
+    a = _solve(oa, x, E, I, fix, Fy, wy, tiling=tiling)
+    xm = (x[-1] - x)[::-1].copy()
+    b = _solve(oa, xm, E[:, ::-1].copy(), I[:, ::-1].copy(), fix[::-1].copy(), Fy[:, ::-1].copy(), wy[:, ::-1].copy(), tiling=tiling)
+    assert (a[4] == 0).all() and (b[4] == 0).all()
+    sv = np.abs(a[0]).max(axis=1, keepdims=True); st = np.abs(a[1]).max(axis=1, keepdims=True)
+    assert (np.abs(b[0][:, ::-1] - a[0]) / sv).max() < 2e-8          # two different elimination orders: eps * cond apart
+    assert (np.abs(b[1][:, ::-1] + a[1]) / st).max() < 2e-8
