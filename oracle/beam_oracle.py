@@ -5,8 +5,11 @@ PARITY UNPINNED: the arithmetic of the reference's hot path lives in the third-p
 which is neither vendored under /root/reference nor importable in this image, and the
 reference has no tests, golden vectors or data files.  This oracle therefore restates
 the published OpenSees semantics selected by the reference's call sites and is pinned
-only by (1) closed-form Euler-Bernoulli known answers, (2) two independent
-formulations in this file agreeing with each other, (3) equilibrium identities.
+only by (1) closed-form Euler-Bernoulli known answers -- among them the reference's own
+six-support bridge by Clapeyron's three-moment equation, and an L-shaped cantilever for the
+frame formulation (tests/test_oracle.py) --, (2) two independent formulations in this file
+agreeing with each other, (3) equilibrium identities.  tests/test_openseespy_live.py runs
+the reference's command sequence against the real module wherever it can be imported.
 
 Only `tests/`, `__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline` leg may import
 this module.  The product package (`openpystruct_amd/`) never does.
