@@ -222,6 +222,14 @@ int ops_surrogate_loss_grad_f32(int B, int C, int nI, int nD, const void* preds,
                                 float box_weight, float rel_penalty, float* loss, void* grad, void* workspace, void* stream);
 size_t ops_surrogate_loss_workspace_bytes(void);
 
+/* MEASURED ALTERNATIVE to ops_beam_solve_batched_f64 (not used by the product): one lane per beam, sequential block-Thomas
+ * per lane, factor in an HBM workspace of ops_beam_solve_lane_workspace_bytes(B, Ne) bytes.  Shared x [N], E / wy scalars,
+ * fix [N]; dense I [B,Ne], Fy [B,N] and outputs.  Kept so that the design choice of DESIGN.md 4.1 rests on a measurement. */
+int ops_beam_solve_lane_per_beam_f64(int B, int Ne, const double* x, const double* E, const double* I, const uint8_t* fix,
+                                     const double* Fy, const double* wy, double* v, double* theta, double* V, double* M,
+                                     int32_t* status, void* workspace, size_t workspace_bytes, void* stream);
+size_t ops_beam_solve_lane_workspace_bytes(int B, int Ne);
+
 /* Largest Ne a build supports, ABI version, and the text of the last HIP error seen by
  * this thread (empty string if none). */
 int ops_amd_max_elements(void);

@@ -32,6 +32,8 @@ EXPORTS = (
     "ops_flat_adam_workspace_bytes",
     "ops_surrogate_loss_grad_f32",
     "ops_surrogate_loss_workspace_bytes",
+    "ops_beam_solve_lane_per_beam_f64",
+    "ops_beam_solve_lane_workspace_bytes",
     "ops_amd_max_elements",
     "ops_amd_abi_version",
     "ops_amd_last_error",
@@ -110,6 +112,10 @@ def load():
     lib.ops_surrogate_loss_grad_f32.restype = it
     lib.ops_surrogate_loss_grad_f32.argtypes = [it, it, it, it, vp, it, vp, vp, fl, vp, vp, fl, fl, vp, vp, vp, vp]
     lib.ops_surrogate_loss_workspace_bytes.restype = ctypes.c_size_t
+    lib.ops_beam_solve_lane_per_beam_f64.restype = it
+    lib.ops_beam_solve_lane_per_beam_f64.argtypes = [it, it] + [vp] * 12 + [ctypes.c_size_t, vp]
+    lib.ops_beam_solve_lane_workspace_bytes.restype = ctypes.c_size_t
+    lib.ops_beam_solve_lane_workspace_bytes.argtypes = [it, it]
     lib.ops_amd_max_elements.restype = it
     lib.ops_amd_abi_version.restype = it
     lib.ops_amd_last_error.restype = ctypes.c_char_p
