@@ -344,11 +344,14 @@ RECORD_KEYS = ("roller_x_locations", "force_x_locations", "force_values", "I_val
 
 
 def generate_dataset(n_cases: int, cfg: Optional[SizingConfig] = None, device="cuda", seed: int = 20250307,
-                     rank: int = 0, world: int = 1, poll_every: int = 25) -> Dict[str, object]:
+                     rank: int = 0, world: int = 1, poll_every: int = 25,
+                     case_range: Optional[Tuple[int, int]] = None) -> Dict[str, object]:
     """The reference's `main()` (SingleCore.py:251-264) for this rank's shard: returns the 13 record fields
     (SingleCore.py:235-249) as tensors / lists, plus `epochs_run`, `status` and the global case ids."""
     cfg = cfg or SizingConfig()
     lo, hi = shard_range(n_cases, rank, world)
+    if case_range is not None:               # a sub-range of this rank's shard (generate_dataset_to_files)
+        lo, hi = lo + case_range[0], min(hi, lo + case_range[1])
     cases = make_cases(n_cases, cfg, seed, device=device).slice(lo, hi)     # generated on the GPU, sliced per rank
     st = optimize_cases(cases, cfg, device, poll_every=poll_every)
     sol = st.sol
@@ -476,3 +479,38 @@ def load_records(path: str, device="cpu") -> Dict[str, object]:
     if missing:
         raise KeyError(f"{path}: missing record fields {missing}")
     return rec
+
+
+def generate_dataset_to_files(n_cases: int, out_dir: str, cfg: Optional[SizingConfig] = None, device="cuda", seed: int = 20250307,
+                              rank: int = 0, world: int = 1, chunk: int = 100000, resume: bool = True) -> List[str]:
+    """`generate_dataset` for this rank's shard, flushed chunk by chunk (`save_records`) so that an interrupted run keeps
+    what it has -- the reference writes ONE json at the very end (SingleCore.py:263) and loses everything on a crash
+    (SURVEY section 5).  With `resume`, chunks whose file exists are skipped; the case list is a pure function of
+    (seed, n_cases), so the files of any run / any GPU count tile the same dataset.  Returns the chunk files in order."""
+    os.makedirs(out_dir, exist_ok=True)
+    lo, hi = shard_range(n_cases, rank, world)
+    files = []
+    for c0 in range(0, hi - lo, chunk):
+        c1 = min(c0 + chunk, hi - lo)
+        path = os.path.join(out_dir, f"records_{lo + c0:09d}_{lo + c1:09d}.pt")
+        files.append(path)
+        if resume and os.path.exists(path):
+            continue
+        rec = generate_dataset(n_cases, cfg, device, seed, rank, world, case_range=(c0, c1))
+        save_records(rec, path + ".tmp")
+        os.replace(path + ".tmp", path)          # a file either is complete or does not exist
+    return files
+
+
+def concat_records(records: List[Dict[str, object]]) -> Dict[str, object]:
+    """Chunks (as loaded by `load_records`) -> one record set in the tensor form `dataprep.prepare` consumes."""
+    out: Dict[str, object] = {}
+    for k, v in records[0].items():
+        if torch.is_tensor(v) and v.dim() > 0:
+            width = max(r[k].shape[1] for r in records) if v.dim() == 2 else None
+            parts = [torch.nn.functional.pad(r[k], (0, width - r[k].shape[1])) if width is not None and r[k].shape[1] < width else r[k]
+                     for r in records]
+            out[k] = torch.cat(parts, dim=0)
+        else:
+            out[k] = v
+    return out

@@ -1,6 +1,7 @@
 """GPU tests of the callers either side of the solve: the OpenSees-command shim (per-case API) and the
 batched sizing loop / dataset generator, against the per-case CPU restatement (oracle/sizing_oracle.py)."""
 import json
+import os
 
 import numpy as np
 import pytest
@@ -234,3 +235,21 @@ def test_other_mesh_sizes_through_the_sizing_loop(oa, num_nodes):
                                  cases.force_values[b], max_e=3)
         np.testing.assert_allclose(st.I[b].cpu().numpy(), np.array(ref["I_values"]), rtol=5e-6)
         assert relerr(st.sol.v[b].cpu().numpy(), np.array(ref["deflections"])) < 1e-6
+
+
+def test_chunked_generation_resumes_and_tiles_the_same_dataset(oa, tmp_path):
+    """generate_dataset_to_files: chunk files, atomic replace, resume skips finished chunks, chunks == the one-shot dataset."""
+    from openpystruct_amd import sizing
+    cfg = sizing.SizingConfig(max_e=8)
+    whole = sizing.generate_dataset(500, cfg, "cuda", seed=12)
+    d = str(tmp_path / "chunks")
+    files = sizing.generate_dataset_to_files(500, d, cfg, "cuda", seed=12, chunk=200)
+    assert [os.path.basename(f) for f in files] == ["records_000000000_000000200.pt", "records_000000200_000000400.pt",
+                                                     "records_000000400_000000500.pt"]
+    mtimes = [os.path.getmtime(f) for f in files]
+    os.remove(files[1])                                    # "crash" after the first chunk of a second run
+    files2 = sizing.generate_dataset_to_files(500, d, cfg, "cuda", seed=12, chunk=200)
+    assert files2 == files and os.path.getmtime(files[0]) == mtimes[0] and os.path.getmtime(files[2]) == mtimes[2]
+    rec = sizing.concat_records([sizing.load_records(f, device="cuda") for f in files])
+    for k in ("I_values", "deflections", "bending_moments", "force_nodes", "epochs_run", "case_ids"):
+        assert torch.equal(rec[k], whole[k].to(rec[k].device)), k
