@@ -99,7 +99,8 @@ def _as_rows(v, width=None) -> torch.Tensor:
 
 def prepare(records: Dict[str, object], *, kind: str = "pinn", n_cases: int = 6, c: float = 0.5, train_split: float = 0.8,
             nheads: int = 8, seed: int = 0, device=None, distributed: bool = False, group=None,
-            refit_val_scalers: Optional[bool] = None, max_lengths: Optional[Dict[str, int]] = None) -> SurrogateData:
+            refit_val_scalers: Optional[bool] = None, max_lengths: Optional[Dict[str, int]] = None,
+            perm: Optional[torch.Tensor] = None) -> SurrogateData:
     """records: the 13-field dataset (lists as in the reference JSON, or tensors from `generate_dataset`).
 
     kind = "pinn": flat inputs, targets [I, deflections, rotations] (PINN:337-369)
@@ -109,7 +110,8 @@ def prepare(records: Dict[str, object], *, kind: str = "pinn", n_cases: int = 6,
     kind = "tfd" : sequence inputs padded to a multiple of `nheads`, targets I only (TFD:330-371); the
                    reference re-fits the input scalers on the validation split (TFD:325-328) -- kept behind
                    `refit_val_scalers` (default True for "tfd", False for "pinn").
-    With `distributed=True` every rank passes ITS shard of records; moments and constraints are all-reduced."""
+    With `distributed=True` every rank passes ITS shard of records; moments and constraints are all-reduced.
+    `perm`: the group permutation of the split (PINN:261 draws it from numpy's global generator); default: seeded randperm."""
     assert kind in ("pinn", "tfd", "fnn", "gnn", "fno")
     if refit_val_scalers is None:
         refit_val_scalers = kind in ("tfd", "gnn")
@@ -143,8 +145,12 @@ def prepare(records: Dict[str, object], *, kind: str = "pinn", n_cases: int = 6,
 
     feats = {k: grouped(v) for k, v in feats.items()}
     targets = {k: grouped(v) for k, v in targets.items()}
-    gen = torch.Generator().manual_seed(seed)
-    perm = torch.randperm(G, generator=gen).to(dev)                      # PINN:261 (unseeded there)
+    if perm is None:
+        gen = torch.Generator().manual_seed(seed)
+        perm = torch.randperm(G, generator=gen)                          # PINN:261 (unseeded there)
+    perm = torch.as_tensor(perm, dtype=torch.long).to(dev)
+    if perm.numel() != G or not torch.equal(perm.sort().values, torch.arange(G, device=dev)):
+        raise ValueError("perm must be a permutation of the group indices")
     n_tr = int(train_split * G)
     tr, va = perm[:n_tr], perm[n_tr:]
     kw = dict(distributed=distributed, group=group)
@@ -152,7 +158,9 @@ def prepare(records: Dict[str, object], *, kind: str = "pinn", n_cases: int = 6,
     sc_in = {k: StandardScalerT() for k in feats}
     Xtr = torch.cat([sc_in[k].fit_transform_3d(feats[k][tr], **kw) for k in feats], dim=2)     # PINN:291-331
     if refit_val_scalers:
-        Xva = torch.cat([StandardScalerT().fit_transform_3d(feats[k][va], **kw) for k in feats], dim=2)
+        # TFD:325-328 / GNN:196-199 call fit_transform on the SAME scaler objects: from here on `scalers_inputs` -- what the
+        # scripts' inference front end scales user inputs with -- holds the VALIDATION statistics (pinned by the fixtures)
+        Xva = torch.cat([sc_in[k].fit_transform_3d(feats[k][va], **kw) for k in feats], dim=2)
     else:
         Xva = torch.cat([sc_in[k].transform(feats[k][va]) for k in feats], dim=2)
     feat_dim = Xtr.shape[2]

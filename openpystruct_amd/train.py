@@ -350,9 +350,13 @@ def _allreduce_mean(t: torch.Tensor, world: int) -> torch.Tensor:
 
 def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, autocast_dtype=torch.bfloat16,
                     sync_bn: bool = False, max_epochs: Optional[int] = None, log=None, seed: int = 0,
-                    use_graph: Optional[bool] = None, physics: Optional[PhysicsTerm] = None) -> Dict[str, object]:
+                    use_graph: Optional[bool] = None, physics: Optional[PhysicsTerm] = None,
+                    init_fn=None, batch_order=None) -> Dict[str, object]:
     """Trains on THIS rank's `data` shard; uses DDP when torch.distributed is initialised with world_size > 1.
-    Returns history, best state dict, validation R^2 (I only) and per-epoch times."""
+    Returns history, best state dict, validation R^2 (I only) and per-epoch times.
+    `init_fn(model)`: called once on the freshly built model (load a checkpoint, deterministic test weights).
+    `batch_order(epoch) -> LongTensor[n_train]`: the epoch's sample order instead of a random permutation (the
+    reference's DataLoader shuffle, PINN:701, is unseeded; the golden-fixture tests replay the order it drew)."""
     cfg = cfg or {"pinn": PinnConfig, "tfd": TfdConfig, "fnn": FnnConfig, "gnn": GnnConfig, "fno": FnoConfig}[kind]()
     alpha_term = kind in ("tfd", "fnn", "fno")          # (initial_alpha - alpha)^2 in the training loss (TFD:743, FNO:615)
     if kind == "fno":
@@ -362,6 +366,8 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
     rank = dist.get_rank() if world > 1 else 0
     torch.manual_seed(seed)            # identical initial weights on every rank
     model, crit = build_model_and_loss(kind, cfg, data, device)
+    if init_fn is not None:
+        init_fn(model)
     if sync_bn and world > 1:
         model = nn.SyncBatchNorm.convert_sync_batchnorm(model)
     net = model
@@ -546,7 +552,10 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
         t0 = time.perf_counter()
         net.train()
         noise = cfg.sigma_0 * (cfg.gamma_noise ** epoch)                     # PINN:743
-        order = torch.randperm(Xtr.shape[0], device=device)                  # DataLoader(shuffle=True), PINN:701
+        if batch_order is not None:
+            order = torch.as_tensor(batch_order(epoch), dtype=torch.long).reshape(-1).to(device)
+        else:
+            order = torch.randperm(Xtr.shape[0], device=device)              # DataLoader(shuffle=True), PINN:701
         tot = torch.zeros((), device=device)
         noise_t = torch.tensor(noise, device=device)
         if graph is not None:
