@@ -239,11 +239,14 @@ BEAM_HD IfaceRow make_row(const SegState<M>& s, const Mat2& ownCup, const Sym2& 
 // One PCR step.  Gm/Am/fm come from row j-s, Gp/Cp/fp from row j+s (zeros, or anything
 // finite, when that row does not exist: the own coupling towards it is exactly zero).
 // LAST: the couplings are not needed after the final step.
-template <bool LAST>
+// KEEP: the two multipliers of the step are handed back (al_out, ga_out) so that further right-hand sides
+// (interface refinement, pcr_rhs_step) can be reduced without redoing the matrix part.
+template <bool LAST, bool KEEP = false>
 BEAM_HD void pcr_step(IfaceRow& r, const Sym2& Gm, const Mat2& Am, const Vec2& fm, const Sym2& Gp,
-                      const Mat2& Cp, const Vec2& fp) {
+                      const Mat2& Cp, const Vec2& fp, Mat2* al_out = nullptr, Mat2* ga_out = nullptr) {
   const Mat2 al = mul(r.Alow, Gm);  // K[j,j-s] D_{j-s}^-1
   const Mat2 ga = mul(r.Cup, Gp);   // K[j,j+s] D_{j+s}^-1
+  if (KEEP) { *al_out = al; *ga_out = ga; }
   // K[j-s,j] = Alow^T and K[j+s,j] = Cup^T by symmetry
   r.D = sub_mulT(sub_mulT(r.D, al, r.Alow), ga, r.Cup);
   r.f = sub_mul(sub_mul(r.f, al, fm), ga, fp);
@@ -251,6 +254,34 @@ BEAM_HD void pcr_step(IfaceRow& r, const Sym2& Gm, const Mat2& Am, const Vec2& f
     r.Alow = neg_mul(al, Am);
     r.Cup = neg_mul(ga, Cp);
   }
+}
+
+// ---------------------------------------------------------------------------------------
+// Interface refinement.  PCR solves every boundary node on its own, so the rounding errors of neighbouring
+// boundary displacements (relative size eps * cond) are INDEPENDENT; a direct band solver's are correlated
+// (smooth).  End forces are stiffness x displacement differences: with short segments (M <= 4) the element
+// stiffness 12EI/L^3 multiplies those independent errors directly.  One or two steps of iterative refinement
+// on the P-row interface system -- residual of the ORIGINAL rows in double precision, correction by the stored
+// PCR multipliers (right-hand side only: 8 fma + 4 exchanged doubles per level) -- make the boundary
+// displacements mutually consistent to the residual's rounding level eps * |D| |u|, i.e. restore the local
+// equilibrium that a sequential elimination has by construction.
+// ---------------------------------------------------------------------------------------
+// Refinement steps the product runs for a tiling of P lanes per beam.  Measured against a 50-digit solution
+// (tests/golden/force_truth.npz, profiles/r02_notes.md): without refinement the end forces of the P >= 32 tilings
+// are up to 5e2 x (M = 8), 1e5 x (M = 4) and 1e7 x (M = 2) worse than the band solver's on the adversarial inertia
+// range; ONE step brings every tiling within 8x of it.  P <= 16 (M >= 7, the 100-element tilings) is at the band
+// solver's level already and runs none -- the hot configuration pays nothing.
+constexpr int iface_refine_steps(int P) { return P >= 32 ? 1 : 0; }
+// r = f - (Alow u_{j-1} + D u_j + Cup u_{j+1}) of an unreduced interface row
+BEAM_HD Vec2 iface_residual(const IfaceRow& r0, const Vec2& um, const Vec2& u, const Vec2& up) {
+  Vec2 r = sub_mul(sub_mul(r0.f, r0.Alow, um), r0.Cup, up);
+  r.x = __builtin_fma(-r0.D.a, u.x, __builtin_fma(-r0.D.b, u.y, r.x));
+  r.y = __builtin_fma(-r0.D.b, u.x, __builtin_fma(-r0.D.c, u.y, r.y));
+  return r;
+}
+// one PCR level applied to a right-hand side only (rm / rp: the vector of row j-s / j+s, zero when absent)
+BEAM_HD Vec2 pcr_rhs_step(const Vec2& r, const Mat2& al, const Mat2& ga, const Vec2& rm, const Vec2& rp) {
+  return sub_mul(sub_mul(r, al, rm), ga, rp);
 }
 
 // Phase C.  Out receives results by LOCAL index: node(i, v, theta), elem(i, V, Mz), i in [0, M).

@@ -140,9 +140,12 @@ struct Xch {
   }
 };
 
-// parallel cyclic reduction over the P rows of a beam: steps S = 1, 2, 4, ..., P/2
-template <int P, int S>
-__device__ __forceinline__ void pcr_all(IfaceRow& row, int lane, int j, int& bad) {
+// parallel cyclic reduction over the P rows of a beam: steps S = 1, 2, 4, ..., P/2.  KEEP: the multipliers of
+// every level stay in registers (al[lv], ga[lv]) for the right-hand-side-only passes of the interface refinement.
+constexpr int pcr_levels(int P) { return P <= 1 ? 0 : 1 + pcr_levels(P / 2); }
+
+template <int P, int S, bool KEEP, int LV = 0>
+__device__ __forceinline__ void pcr_all(IfaceRow& row, int lane, int j, int& bad, Mat2* al, Mat2* ga) {
   if constexpr (S < P) {
     using X = Xch<P>;
     constexpr bool LAST = (2 * S >= P);
@@ -156,8 +159,21 @@ __device__ __forceinline__ void pcr_all(IfaceRow& row, int lane, int j, int& bad
       Am = X::template from_minus<S>(row.Alow, lane, j);
       Cp = X::template from_plus<S>(row.Cup, lane, j);
     }
-    pcr_step<LAST>(row, Gm, Am, fm, Gp, Cp, fp);
-    pcr_all<P, 2 * S>(row, lane, j, bad);
+    pcr_step<LAST, KEEP>(row, Gm, Am, fm, Gp, Cp, fp, KEEP ? &al[LV] : nullptr, KEEP ? &ga[LV] : nullptr);
+    pcr_all<P, 2 * S, KEEP, LV + 1>(row, lane, j, bad, al, ga);
+  }
+}
+
+// the stored PCR levels applied to a right-hand side only (interface refinement, beam_math.hpp)
+template <int P, int S, int LV = 0>
+__device__ __forceinline__ Vec2 pcr_rhs_all(Vec2 r, int lane, int j, const Mat2* al, const Mat2* ga) {
+  if constexpr (S < P) {
+    using X = Xch<P>;
+    const Vec2 rm = X::template from_minus<S>(r, lane, j);
+    const Vec2 rp = X::template from_plus<S>(r, lane, j);
+    return pcr_rhs_all<P, 2 * S, LV + 1>(pcr_rhs_step(r, al[LV], ga[LV], rm, rp), lane, j, al, ga);
+  } else {
+    return r;
   }
 }
 
@@ -188,9 +204,25 @@ __device__ __forceinline__ void solve_lanes(const LdsAcc& acc, int lane, int j, 
     const Mat2 pb = X::template from_minus<1>(cup, lane, j);
     row = make_row<M, RZ>(st, cup, pc, pg, pb, acc.bits);
   }
-  pcr_all<P, 1>(row, lane, j, bad);
-  const Vec2 uL = mul(inv_spd(row.D, bad), row.f);
-  const Vec2 uR = X::template from_plus<1>(uL, lane, j);
+  constexpr int REF = iface_refine_steps(P);       // short segments: boundary displacements made mutually consistent
+  constexpr int LV = pcr_levels(P);
+  Mat2 al[REF ? LV : 1], ga[REF ? LV : 1];
+  IfaceRow row0;
+  if constexpr (REF > 0) row0 = row;               // unreduced row: the refinement's residual
+  pcr_all<P, 1, (REF > 0)>(row, lane, j, bad, al, ga);
+  const Sym2 Gfin = inv_spd(row.D, bad);
+  Vec2 uL = mul(Gfin, row.f);
+  Vec2 uR = X::template from_plus<1>(uL, lane, j);
+  if constexpr (REF > 0) {
+#pragma unroll
+    for (int it = 0; it < REF; ++it) {
+      const Vec2 um = X::template from_minus<1>(uL, lane, j);
+      const Vec2 r = pcr_rhs_all<P, 1>(iface_residual(row0, um, uL, uR), lane, j, al, ga);
+      const Vec2 d = mul(Gfin, r);
+      uL.x += d.x; uL.y += d.y;
+      uR = X::template from_plus<1>(uL, lane, j);
+    }
+  }
   seg_solve<M, RZ>(st, acc, uL, uR, out);
 }
 
@@ -203,8 +235,9 @@ __device__ __forceinline__ void solve_lanes(const LdsAcc& acc, int lane, int j, 
 // waves per SIMD the register allocator is asked to leave room for (0 = no request)
 constexpr int waves_per_simd(int P, int M, bool shared) {
   if (!shared) return 1;   // per-beam geometry tables make those variants LDS-limited anyway
-  return (P == 16 && M == 7) ? 3 : (P == 8 && M == 13) ? 2 : (P == 32 && M == 4) ? 4 : (P == 64 && M == 2) ? 4
-       : (P == 64 && M == 4) ? 3 : 1;
+  // the P >= 32 tilings keep their PCR multipliers for the interface refinement (+80 .. 96 VGPRs)
+  return (P == 16 && M == 7) ? 3 : (P == 8 && M == 13) ? 2 : (P == 32 && M == 4) ? 2 : (P == 64 && M == 2) ? 2
+       : (P == 64 && M == 4) ? 2 : 1;
 }
 
 // ---- buffer-resource I/O: hardware bounds checking instead of tail branches --------------------

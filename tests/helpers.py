@@ -86,3 +86,17 @@ def run_ranks(target, world, timeout):
             p.join(10)
             if p.is_alive():
                 p.terminate()
+
+
+def kappa_scaled(x, E, I, fix):
+    """cond(D^-1/2 K_ff D^-1/2), D = diag(K_ff): the Jacobi-scaled condition number of one beam's free-DOF stiffness
+    matrix -- what governs the rounding error of a Cholesky-type elimination in any order (van der Sluis)."""
+    from oracle import beam_oracle as bo
+    x = np.asarray(x, dtype=np.float64)
+    N = x.shape[0]
+    K, _ = bo.assemble_beam(x, E, I, np.zeros(N), 0.0)
+    fix = np.asarray(fix).astype(np.int64)
+    free = np.ones(2 * N, dtype=bool); free[0::2] = (fix & 1) == 0; free[1::2] = (fix & 2) == 0
+    Kf = K[np.ix_(free, free)]
+    d = 1.0 / np.sqrt(np.diag(Kf))
+    return float(np.linalg.cond(Kf * d[:, None] * d[None, :]))
