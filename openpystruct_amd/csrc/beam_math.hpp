@@ -9,8 +9,8 @@
 //   A. seg_condense : frontal elimination of the segment's interior nodes 1..M-1; what is
 //                     left is a 4x4 "super element" on (left, right) boundary nodes.  Only
 //                     the inverse pivot blocks (3 doubles per node) are kept.
-//   B. make_row / pcr_step : the P boundary nodes form a P-row block-tridiagonal interface
-//                     system, solved by parallel cyclic reduction over the P lanes
+//   B. make_row / cr_eliminate / cr_back : the P boundary nodes form a P-row block-tridiagonal interface
+//                     system, solved by cyclic reduction over the P lanes
 //   C. seg_solve    : with both boundary displacements known the interior is a one-sided
 //                     block-Thomas solve: right-hand-side sweep (re-using the stored pivot
 //                     inverses), back substitution, element end-force recovery
@@ -236,52 +236,51 @@ BEAM_HD IfaceRow make_row(const SegState<M>& s, const Mat2& ownCup, const Sym2& 
   return r;
 }
 
-// One PCR step.  Gm/Am/fm come from row j-s, Gp/Cp/fp from row j+s (zeros, or anything
+// ---------------------------------------------------------------------------------------
+// Interface solve: CYCLIC REDUCTION over the P rows of a beam (levels s = 1, 2, 4, ..., P/2).
+//
+// At level s the rows j = s (mod 2s) are eliminated: they FREEZE (their equation now couples them to rows
+// j -+ s only), and the rows j = 0 (mod 2s) absorb them (cr_eliminate: the Schur-complement update).  After the
+// last level row 0 stands alone; then, level by level downwards, every frozen row is solved from ITS OWN
+// frozen equation with its two neighbours known (cr_back).  That is the block Cholesky factorisation of the
+// interface matrix in nested-dissection order followed by forward/back substitution -- like the band solver the
+// reference calls (LAPACK dpbsv behind system('BandSPD'), SingleCore.py:120) it is backward stable, and every
+// boundary displacement satisfies an equilibrium equation with its neighbours to rounding level.
+//
+// r01 used PARALLEL cyclic reduction (every row reduced to a 2x2 system of its own).  Same elimination
+// arithmetic, but the P solutions carry INDEPENDENT rounding errors of relative size eps * kappa; end forces are
+// stiffness x displacement differences, and wherever a whole segment is stiff the condensed segment stiffness
+// multiplied those independent errors directly: measured against a 50-digit solution (tests/golden/force_truth.npz)
+// up to 1e3 x (16 lanes x 7 elements, adversarial inertias), 1e5 x (M = 4) and 1e7 x (M = 2) the band solver's
+// own force error.  With cyclic reduction every tiling is within 8 x of it (tests/test_force_truth.py).
+// On a SIMD machine both variants execute the same instructions per level (idle rows are masked, not skipped);
+// the back substitution adds 8 exchanged doubles + 12 fma per level, about a fifth of a level's elimination cost.
+// ---------------------------------------------------------------------------------------
+BEAM_HD bool cr_active(int j, int s) { return (j & (2 * s - 1)) == 0; }   // row j absorbs rows j -+ s at level s
+BEAM_HD bool cr_frozen(int j, int s) { return (j & (2 * s - 1)) == s; }   // row j is eliminated at level s
+
+// Level-s update of an ACTIVE row.  Gm/Am/fm come from row j-s, Gp/Cp/fp from row j+s (zeros, or anything
 // finite, when that row does not exist: the own coupling towards it is exactly zero).
-// LAST: the couplings are not needed after the final step.
-// KEEP: the two multipliers of the step are handed back (al_out, ga_out) so that further right-hand sides
-// (interface refinement, pcr_rhs_step) can be reduced without redoing the matrix part.
-template <bool LAST, bool KEEP = false>
-BEAM_HD void pcr_step(IfaceRow& r, const Sym2& Gm, const Mat2& Am, const Vec2& fm, const Sym2& Gp,
-                      const Mat2& Cp, const Vec2& fp, Mat2* al_out = nullptr, Mat2* ga_out = nullptr) {
-  const Mat2 al = mul(r.Alow, Gm);  // K[j,j-s] D_{j-s}^-1
-  const Mat2 ga = mul(r.Cup, Gp);   // K[j,j+s] D_{j+s}^-1
-  if (KEEP) { *al_out = al; *ga_out = ga; }
-  // K[j-s,j] = Alow^T and K[j+s,j] = Cup^T by symmetry
-  r.D = sub_mulT(sub_mulT(r.D, al, r.Alow), ga, r.Cup);
-  r.f = sub_mul(sub_mul(r.f, al, fm), ga, fp);
-  if (!LAST) {
-    r.Alow = neg_mul(al, Am);
-    r.Cup = neg_mul(ga, Cp);
-  }
+// LAST: the couplings are not needed after the final level.
+// One side of the update: absorb the neighbour row at distance s on the `Aside` coupling (G, Afar, fn: that row's inverse
+// pivot, ITS coupling further out in the same direction, its right-hand side).  Aside becomes the coupling at distance 2s.
+template <bool LAST>
+BEAM_HD void cr_absorb(Sym2& D, Vec2& f, Mat2& Aside, const Sym2& G, const Mat2& Afar, const Vec2& fn) {
+  const Mat2 al = mul(Aside, G);    // K[j,j-+s] D_{j-+s}^-1
+  D = sub_mulT(D, al, Aside);       // K[j-+s,j] = Aside^T by symmetry
+  f = sub_mul(f, al, fn);
+  if (!LAST) Aside = neg_mul(al, Afar);
+}
+template <bool LAST>
+BEAM_HD void cr_eliminate(IfaceRow& r, const Sym2& Gm, const Mat2& Am, const Vec2& fm, const Sym2& Gp,
+                          const Mat2& Cp, const Vec2& fp) {
+  cr_absorb<LAST>(r.D, r.f, r.Alow, Gm, Am, fm);
+  cr_absorb<LAST>(r.D, r.f, r.Cup, Gp, Cp, fp);
 }
 
-// ---------------------------------------------------------------------------------------
-// Interface refinement.  PCR solves every boundary node on its own, so the rounding errors of neighbouring
-// boundary displacements (relative size eps * cond) are INDEPENDENT; a direct band solver's are correlated
-// (smooth).  End forces are stiffness x displacement differences: with short segments (M <= 4) the element
-// stiffness 12EI/L^3 multiplies those independent errors directly.  One or two steps of iterative refinement
-// on the P-row interface system -- residual of the ORIGINAL rows in double precision, correction by the stored
-// PCR multipliers (right-hand side only: 8 fma + 4 exchanged doubles per level) -- make the boundary
-// displacements mutually consistent to the residual's rounding level eps * |D| |u|, i.e. restore the local
-// equilibrium that a sequential elimination has by construction.
-// ---------------------------------------------------------------------------------------
-// Refinement steps the product runs for a tiling of P lanes per beam.  Measured against a 50-digit solution
-// (tests/golden/force_truth.npz, profiles/r02_notes.md): without refinement the end forces of the P >= 32 tilings
-// are up to 5e2 x (M = 8), 1e5 x (M = 4) and 1e7 x (M = 2) worse than the band solver's on the adversarial inertia
-// range; ONE step brings every tiling within 8x of it.  P <= 16 (M >= 7, the 100-element tilings) is at the band
-// solver's level already and runs none -- the hot configuration pays nothing.
-constexpr int iface_refine_steps(int P) { return P >= 32 ? 1 : 0; }
-// r = f - (Alow u_{j-1} + D u_j + Cup u_{j+1}) of an unreduced interface row
-BEAM_HD Vec2 iface_residual(const IfaceRow& r0, const Vec2& um, const Vec2& u, const Vec2& up) {
-  Vec2 r = sub_mul(sub_mul(r0.f, r0.Alow, um), r0.Cup, up);
-  r.x = __builtin_fma(-r0.D.a, u.x, __builtin_fma(-r0.D.b, u.y, r.x));
-  r.y = __builtin_fma(-r0.D.b, u.x, __builtin_fma(-r0.D.c, u.y, r.y));
-  return r;
-}
-// one PCR level applied to a right-hand side only (rm / rp: the vector of row j-s / j+s, zero when absent)
-BEAM_HD Vec2 pcr_rhs_step(const Vec2& r, const Mat2& al, const Mat2& ga, const Vec2& rm, const Vec2& rp) {
-  return sub_mul(sub_mul(r, al, rm), ga, rp);
+// A frozen row solved from its own equation: u_j = D^-1 (f - Alow u_{j-s} - Cup u_{j+s}); G = D^-1.
+BEAM_HD Vec2 cr_back(const IfaceRow& r, const Sym2& G, const Vec2& um, const Vec2& up) {
+  return mul(G, sub_mul(sub_mul(r.f, r.Alow, um), r.Cup, up));
 }
 
 // Phase C.  Out receives results by LOCAL index: node(i, v, theta), elem(i, V, Mz), i in [0, M).

@@ -140,40 +140,40 @@ struct Xch {
   }
 };
 
-// parallel cyclic reduction over the P rows of a beam: steps S = 1, 2, 4, ..., P/2.  KEEP: the multipliers of
-// every level stay in registers (al[lv], ga[lv]) for the right-hand-side-only passes of the interface refinement.
-constexpr int pcr_levels(int P) { return P <= 1 ? 0 : 1 + pcr_levels(P / 2); }
-
-template <int P, int S, bool KEEP, int LV = 0>
-__device__ __forceinline__ void pcr_all(IfaceRow& row, int lane, int j, int& bad, Mat2* al, Mat2* ga) {
+// cyclic reduction over the P rows of a beam (beam_math.hpp): levels S = 1, 2, 4, ..., P/2.  Every lane runs
+// the exchange (a DPP / bpermute fetch must not sit inside a divergent region: disabled source lanes read as 0);
+// only the rows that are active at the level apply the update -- exec-masked, the others keep their frozen row.
+template <int P, int S>
+__device__ __forceinline__ void cr_forward(IfaceRow& row, int lane, int j, int& bad) {
   if constexpr (S < P) {
     using X = Xch<P>;
     constexpr bool LAST = (2 * S >= P);
     const Sym2 G = inv_spd(row.D, bad);
-    const Sym2 Gm = X::template from_minus<S>(G, lane, j);
-    const Vec2 fm = X::template from_minus<S>(row.f, lane, j);
-    const Sym2 Gp = X::template from_plus<S>(G, lane, j);
-    const Vec2 fp = X::template from_plus<S>(row.f, lane, j);
-    Mat2 Am{0, 0, 0, 0}, Cp{0, 0, 0, 0};
-    if constexpr (!LAST) {
-      Am = X::template from_minus<S>(row.Alow, lane, j);
-      Cp = X::template from_plus<S>(row.Cup, lane, j);
+    const bool act = cr_active(j, S);
+    {   // the two sides one after the other: half the exchange registers live at a time
+      const Sym2 Gm = X::template from_minus<S>(G, lane, j);
+      const Vec2 fm = X::template from_minus<S>(row.f, lane, j);
+      Mat2 Am{0, 0, 0, 0};
+      if constexpr (!LAST) Am = X::template from_minus<S>(row.Alow, lane, j);
+      const Vec2 fp = X::template from_plus<S>(row.f, lane, j);      // fetched before the minus side rewrites row.f
+      if (act) cr_absorb<LAST>(row.D, row.f, row.Alow, Gm, Am, fm);
+      const Sym2 Gp = X::template from_plus<S>(G, lane, j);
+      Mat2 Cp{0, 0, 0, 0};
+      if constexpr (!LAST) Cp = X::template from_plus<S>(row.Cup, lane, j);
+      if (act) cr_absorb<LAST>(row.D, row.f, row.Cup, Gp, Cp, fp);
     }
-    pcr_step<LAST, KEEP>(row, Gm, Am, fm, Gp, Cp, fp, KEEP ? &al[LV] : nullptr, KEEP ? &ga[LV] : nullptr);
-    pcr_all<P, 2 * S, KEEP, LV + 1>(row, lane, j, bad, al, ga);
+    cr_forward<P, 2 * S>(row, lane, j, bad);
   }
 }
-
-// the stored PCR levels applied to a right-hand side only (interface refinement, beam_math.hpp)
-template <int P, int S, int LV = 0>
-__device__ __forceinline__ Vec2 pcr_rhs_all(Vec2 r, int lane, int j, const Mat2* al, const Mat2* ga) {
-  if constexpr (S < P) {
+// back substitution from the top level down: the rows frozen at level S take their neighbours' displacements
+template <int P, int S>
+__device__ __forceinline__ void cr_backward(const IfaceRow& row, const Sym2& G, Vec2& u, int lane, int j) {
+  if constexpr (S >= 1) {
     using X = Xch<P>;
-    const Vec2 rm = X::template from_minus<S>(r, lane, j);
-    const Vec2 rp = X::template from_plus<S>(r, lane, j);
-    return pcr_rhs_all<P, 2 * S, LV + 1>(pcr_rhs_step(r, al[LV], ga[LV], rm, rp), lane, j, al, ga);
-  } else {
-    return r;
+    const Vec2 um = X::template from_minus<S>(u, lane, j);
+    const Vec2 up = X::template from_plus<S>(u, lane, j);
+    if (cr_frozen(j, S)) u = cr_back(row, G, um, up);
+    cr_backward<P, S / 2>(row, G, u, lane, j);
   }
 }
 
@@ -189,9 +189,11 @@ __device__ __forceinline__ void wave_lds_fence() {
 
 // Stages 2-4 for one lane: condensation, interface reduction, interior solve.  RZ: see Flags<RZ>.
 template <int P, int M, bool RZ>
-__device__ __forceinline__ void solve_lanes(const LdsAcc& acc, int lane, int j, int& bad, LaneOut<M>& out) {
+__device__ __forceinline__ void solve_lanes(const LdsAcc& acc, int lane, int j, int& bad, LaneOut<M>& out, double* sVrows,
+                                            double* sDummy, int Ne) {
   using X = Xch<P>;
   SegState<M> st;
+  __asm__ volatile("" ::: "memory");   // no LDS read of either RZ variant is hoisted above the (wave-uniform) choice between them
   seg_condense<M, RZ>(st, acc, bad);
   // The element data is re-read from LDS in the last stage instead of being carried in ~16*M VGPRs
   // across the reduction: the clobber stops the compiler from merging the two sets of loads.
@@ -204,24 +206,21 @@ __device__ __forceinline__ void solve_lanes(const LdsAcc& acc, int lane, int j, 
     const Mat2 pb = X::template from_minus<1>(cup, lane, j);
     row = make_row<M, RZ>(st, cup, pc, pg, pb, acc.bits);
   }
-  constexpr int REF = iface_refine_steps(P);       // short segments: boundary displacements made mutually consistent
-  constexpr int LV = pcr_levels(P);
-  Mat2 al[REF ? LV : 1], ga[REF ? LV : 1];
-  IfaceRow row0;
-  if constexpr (REF > 0) row0 = row;               // unreduced row: the refinement's residual
-  pcr_all<P, 1, (REF > 0)>(row, lane, j, bad, al, ga);
-  const Sym2 Gfin = inv_spd(row.D, bad);
-  Vec2 uL = mul(Gfin, row.f);
-  Vec2 uR = X::template from_plus<1>(uL, lane, j);
-  if constexpr (REF > 0) {
-#pragma unroll
-    for (int it = 0; it < REF; ++it) {
-      const Vec2 um = X::template from_minus<1>(uL, lane, j);
-      const Vec2 r = pcr_rhs_all<P, 1>(iface_residual(row0, um, uL, uR), lane, j, al, ga);
-      const Vec2 d = mul(Gfin, r);
-      uL.x += d.x; uL.y += d.y;
-      uR = X::template from_plus<1>(uL, lane, j);
-    }
+  cr_forward<P, 1>(row, lane, j, bad);
+  const Sym2 G = inv_spd(row.D, bad);              // every lane's own (frozen, or for row 0 fully reduced) pivot block
+  Vec2 uL = mul(G, row.f);                         // meaningful for row 0; the others are overwritten level by level
+  if (j != 0) uL = Vec2{0.0, 0.0};
+  cr_backward<P, P / 2>(row, G, uL, lane, j);
+  const Vec2 uR = X::template from_plus<1>(uL, lane, j);
+  __asm__ volatile("" ::: "memory");               // the interior solve's LDS reads stay behind the interface solve
+  {  // where the lane's shears go: derived from an OPAQUE copy of the lane id, so that nothing computed for it in the
+     // prologue has to stay in a register (or in scratch) across condensation and interface solve
+    unsigned lz = (unsigned)lane;
+    __asm__ volatile("" : "+v"(lz));
+    const int gz = lz / P, e0z = (int)(lz - gz * P) * M;
+    const int cntE = (Ne - e0z < 0) ? 0 : (Ne - e0z < M ? Ne - e0z : M);
+    out.sV = cntE ? sVrows + gz * Ne + e0z : sDummy;
+    out.lastE = cntE ? (unsigned)(cntE - 1) : 0u;
   }
   seg_solve<M, RZ>(st, acc, uL, uR, out);
 }
@@ -235,9 +234,8 @@ __device__ __forceinline__ void solve_lanes(const LdsAcc& acc, int lane, int j, 
 // waves per SIMD the register allocator is asked to leave room for (0 = no request)
 constexpr int waves_per_simd(int P, int M, bool shared) {
   if (!shared) return 1;   // per-beam geometry tables make those variants LDS-limited anyway
-  // the P >= 32 tilings keep their PCR multipliers for the interface refinement (+80 .. 96 VGPRs)
-  return (P == 16 && M == 7) ? 3 : (P == 8 && M == 13) ? 2 : (P == 32 && M == 4) ? 2 : (P == 64 && M == 2) ? 2
-       : (P == 64 && M == 4) ? 2 : 1;
+  return (P == 16 && M == 7) ? 3 : (P == 8 && M == 13) ? 2 : (P == 32 && M == 4) ? 3 : (P == 64 && M == 2) ? 3
+       : (P == 64 && M == 4) ? 3 : 1;
 }
 
 // ---- buffer-resource I/O: hardware bounds checking instead of tail branches --------------------
@@ -439,18 +437,20 @@ __device__ __forceinline__ void beam_body(const BeamParams& p, const SizingArgs*
     acc.bits = bits;
   }
   int bad = 0;
-  LaneOut<M> out;
-  const int cntE = (Ne - e0 < 0) ? 0 : (Ne - e0 < M ? Ne - e0 : M);   // real elements / nodes of this lane
-  const int cntN = (N - e0 < 0) ? 0 : (N - e0 < M ? N - e0 : M);
-  out.sV = cntE ? &s_b[g * Ne + e0] : s_dummy;
-  out.lastE = cntE ? (unsigned)(cntE - 1) : 0u;
+  LaneOut<M> out;                   // sV / lastE: set by solve_lanes right before the interior solve
   const bool any_rz = __ballot((acc.bits & 0xAAAAAAAAAAAAAAAAull) != 0ull) != 0ull;   // wave-uniform
-  if (any_rz) solve_lanes<P, M, true>(acc, lane, j, bad, out);
-  else        solve_lanes<P, M, false>(acc, lane, j, bad, out);
+  if (any_rz) solve_lanes<P, M, true>(acc, lane, j, bad, out, s_b, s_dummy, Ne);
+  else        solve_lanes<P, M, false>(acc, lane, j, bad, out, s_b, s_dummy, Ne);
+  // the epilogue's lane geometry from an opaque copy of the lane id (see solve_lanes): recomputed, not kept
+  unsigned lane_e = lane;
+  __asm__ volatile("" : "+v"(lane_e));
+  const int g_e = lane_e / P, j_e = (int)(lane_e - g_e * P), e0_e = j_e * M;
+  const int cntE = (Ne - e0_e < 0) ? 0 : (Ne - e0_e < M ? Ne - e0_e : M);   // real elements / nodes of this lane
+  const int cntN = (N - e0_e < 0) ? 0 : (N - e0_e < M ? N - e0_e : M);
 
   // a beam is bad if any of its P lanes met a non-positive pivot; its outputs become NaN
   const unsigned long long bal = __ballot(bad != 0);
-  const unsigned long long grp = (P == 64) ? ~0ull : (((1ull << (P % 64)) - 1ull) << (g * P));
+  const unsigned long long grp = (P == 64) ? ~0ull : (((1ull << (P % 64)) - 1ull) << (g_e * P));
   const bool gbad = (bal & grp) != 0ull;
   const double qnan = __builtin_nan("");
   if (bal != 0ull && gbad) {                    // first test is wave-uniform: nothing to do in the common case
@@ -460,14 +460,14 @@ __device__ __forceinline__ void beam_body(const BeamParams& p, const SizingArgs*
       if (i < cntE) out.sV[i] = qnan;
     }
   }
-  if (j == 0 && g < nb && p.status)   // write-through like the other outputs
-    __hip_atomic_store(&p.status[beam0 + g], gbad ? 1 : 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (j_e == 0 && g_e < nb && p.status)   // write-through like the other outputs
+    __hip_atomic_store(&p.status[beam0 + g_e], gbad ? 1 : 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #ifdef OPS_AMD_TRACE
   const unsigned long long t2 = __builtin_amdgcn_s_memrealtime();
 #endif
 
   // element rows: V already in s_b (flat, stride Ne); M joins it in s_a now that I is dead
-  lds_store_desc<M>(cntE ? &s_a[g * Ne + e0] : s_dummy, out.lastE, out.Mz);
+  lds_store_desc<M>(cntE ? &s_a[g_e * Ne + e0_e] : s_dummy, out.lastE, out.Mz);
   wave_lds_fence();
   if constexpr (SIZING) {           // V in s_b, M in s_a (flat, stride Ne): one optimiser epoch per live, active case
     // every case's state loads go out before the first one is used (a wave holds BPW cases: one HBM latency, not BPW)
@@ -476,14 +476,14 @@ __device__ __forceinline__ void beam_body(const BeamParams& p, const SizingArgs*
 #pragma unroll
     for (int gb = 0; gb < BPW; ++gb) {
       on[gb] = gb < nb && sz->active[beam0 + gb] != 0;     // wave-uniform
-      if (on[gb]) load_case<2>((int)lane, beam0 + gb, Ne, *sz, cr[gb]);
+      if (on[gb]) load_case<2>((int)lane_e, beam0 + gb, Ne, *sz, cr[gb]);
     }
 #pragma unroll
     for (int gb = 0; gb < BPW; ++gb) {
       if (!on[gb]) continue;
       const double* Vb = &s_b[gb * Ne];
       const double* Mb = &s_a[gb * Ne];
-      step_case<2>((int)lane, beam0 + gb, Ne, *sz, cr[gb], [&](int e) { return (float)Vb[e]; }, [&](int e) { return (float)Mb[e]; });
+      step_case<2>((int)lane_e, beam0 + gb, Ne, *sz, cr[gb], [&](int e) { return (float)Vb[e]; }, [&](int e) { return (float)Mb[e]; });
     }
     return;
   }
@@ -495,7 +495,7 @@ __device__ __forceinline__ void beam_body(const BeamParams& p, const SizingArgs*
       const __amdgpu_buffer_rsrc_t rM = make_rsrc(M32, (unsigned)nE * 4u);
 #pragma unroll
       for (int k = 0; k < NPAIR; ++k) {
-        const unsigned i0 = 2u * (lane + 64u * k);
+        const unsigned i0 = 2u * (lane_e + 64u * k);
         if (k + 1 < NPAIR || i0 < BPW * PM) {
           const double2 dv = *reinterpret_cast<const double2*>(&s_b[i0]), dm = *reinterpret_cast<const double2*>(&s_a[i0]);
           const float2 fv = make_float2((float)dv.x, (float)dv.y), fm = make_float2((float)dm.x, (float)dm.y);
@@ -503,9 +503,9 @@ __device__ __forceinline__ void beam_body(const BeamParams& p, const SizingArgs*
           __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2i, fm), rM, (int)(i0 * 4u), 0, ST);
         }
       }
-      if ((nE & 1) && lane == 0) { V32[nE - 1] = (float)s_b[nE - 1]; M32[nE - 1] = (float)s_a[nE - 1]; }
+      if ((nE & 1) && lane_e == 0) { V32[nE - 1] = (float)s_b[nE - 1]; M32[nE - 1] = (float)s_a[nE - 1]; }
     } else {
-      for (int idx = lane; idx < nE; idx += 64) { V32[idx] = (float)s_b[idx]; M32[idx] = (float)s_a[idx]; }
+      for (int idx = lane_e; idx < nE; idx += 64) { V32[idx] = (float)s_b[idx]; M32[idx] = (float)s_a[idx]; }
     }
     return;
   }
@@ -514,18 +514,18 @@ __device__ __forceinline__ void beam_body(const BeamParams& p, const SizingArgs*
     const __amdgpu_buffer_rsrc_t rM = make_rsrc(p.M + beam0 * Ne, (unsigned)nE * 8u);
 #pragma unroll
     for (int k = 0; k < NPAIR; ++k) {
-      const unsigned i0 = 2u * (lane + 64u * k);
+      const unsigned i0 = 2u * (lane_e + 64u * k);
       if (k + 1 < NPAIR || i0 < BPW * PM) {     // LDS bound; the buffer descriptor drops pairs beyond the run
         buf_store_d2<ST>(rV, i0 * 8u, *reinterpret_cast<const double2*>(&s_b[i0]));
         buf_store_d2<ST>(rM, i0 * 8u, *reinterpret_cast<const double2*>(&s_a[i0]));
       }
     }
-    if ((nE & 1) && lane == 0) {
+    if ((nE & 1) && lane_e == 0) {
       buf_store_d<ST>(rV, (unsigned)(nE - 1) * 8u, s_b[nE - 1]);
       buf_store_d<ST>(rM, (unsigned)(nE - 1) * 8u, s_a[nE - 1]);
     }
   } else {
-    for (int idx = lane; idx < nE; idx += 64) {
+    for (int idx = lane_e; idx < nE; idx += 64) {
       p.V[beam0 * Ne + idx] = s_b[idx];
       p.M[beam0 * Ne + idx] = s_a[idx];
     }
@@ -533,32 +533,32 @@ __device__ __forceinline__ void beam_body(const BeamParams& p, const SizingArgs*
   if (!p.v) return;                 // forces-only call (wave-uniform): the sizing epochs never read displacements
   wave_lds_fence();
   // nodal rows (flat, stride N)
-  lds_store_desc<M>(cntN ? &s_b[g * N + e0] : s_dummy, cntN ? (unsigned)(cntN - 1) : 0u, out.v);
-  lds_store_desc<M>(cntN ? &s_a[g * N + e0] : s_dummy, cntN ? (unsigned)(cntN - 1) : 0u, out.th);
+  lds_store_desc<M>(cntN ? &s_b[g_e * N + e0_e] : s_dummy, cntN ? (unsigned)(cntN - 1) : 0u, out.v);
+  lds_store_desc<M>(cntN ? &s_a[g_e * N + e0_e] : s_dummy, cntN ? (unsigned)(cntN - 1) : 0u, out.th);
   wave_lds_fence();
   if (DENSE) {
     const __amdgpu_buffer_rsrc_t rv = make_rsrc(p.v + beam0 * N, (unsigned)nN * 8u);
     const __amdgpu_buffer_rsrc_t rt = make_rsrc(p.theta + beam0 * N, (unsigned)nN * 8u);
 #pragma unroll
     for (int k = 0; k < NPAIR; ++k) {
-      const unsigned i0 = 2u * (lane + 64u * k);
+      const unsigned i0 = 2u * (lane_e + 64u * k);
       if (k + 1 < NPAIR || i0 < BPW * PM) {
         buf_store_d2<ST>(rv, i0 * 8u, *reinterpret_cast<const double2*>(&s_b[i0]));
         buf_store_d2<ST>(rt, i0 * 8u, *reinterpret_cast<const double2*>(&s_a[i0]));
       }
     }
-    if ((nN & 1) && lane == 0) {
+    if ((nN & 1) && lane_e == 0) {
       buf_store_d<ST>(rv, (unsigned)(nN - 1) * 8u, s_b[nN - 1]);
       buf_store_d<ST>(rt, (unsigned)(nN - 1) * 8u, s_a[nN - 1]);
     }
   } else {
-    for (int idx = lane; idx < nN; idx += 64) {
+    for (int idx = lane_e; idx < nN; idx += 64) {
       p.v[beam0 * N + idx] = s_b[idx];
       p.theta[beam0 * N + idx] = s_a[idx];
     }
   }
 #ifdef OPS_AMD_TRACE
-  if (p.trace && lane == 0) {   // per-wave phase stamps (100 MHz clock) + hardware id, for scripts/trace_run.py
+  if (p.trace && lane_e == 0) {   // per-wave phase stamps (100 MHz clock) + hardware id, for scripts/trace_run.py
     const unsigned long long t3 = __builtin_amdgcn_s_memrealtime();
     const unsigned hw = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | ((16 - 1) << 11));
     unsigned long long* q = p.trace + 8 * (unsigned long long)blockIdx.x;

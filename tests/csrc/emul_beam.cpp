@@ -35,12 +35,6 @@ struct HostOut {
   void node(int i, double a, double b) { v[i] = a; th[i] = b; }
 };
 
-// refinement steps per tiling: the product's rule (beam_math.hpp iface_refine_steps) unless EMUL_REFINE overrides it
-int refine_steps(int P) {
-  const char* e = getenv("EMUL_REFINE");
-  return e ? atoi(e) : iface_refine_steps(P);
-}
-
 template <int P, int M, bool RZ>
 int solve_one_rz(int Ne, const double* x, const double* E, bool E_pe, const double* I, const uint8_t* fix,
               const double* Fy, const double* wy, bool w_pe, double* v, double* th, double* V, double* Mz) {
@@ -76,40 +70,30 @@ int solve_one_rz(int Ne, const double* x, const double* E, bool E_pe, const doub
   for (int j = 0; j < P; ++j) cup[j] = masked_cup<M, RZ>(st[j], acc[j].bits);
   for (int j = 0; j < P; ++j)
     row[j] = make_row<M, RZ>(st[j], cup[j], j ? st[j - 1].Scc : z3, j ? st[j - 1].gc : z2, j ? cup[j - 1] : z4, acc[j].bits);
-  const std::vector<IfaceRow> row0 = row;                    // unreduced rows: residuals of the refinement
-  const int refine = refine_steps(P);
-  std::vector<std::vector<Mat2>> AL, GA;                     // per level, per row: the PCR multipliers
+  // cyclic reduction (beam_math.hpp): forward levels, then the frozen rows back from the top level
   for (int s = 1; s < P; s *= 2) {
     std::vector<Sym2> G(P);
-    std::vector<Mat2> al(P), ga(P);
     for (int j = 0; j < P; ++j) G[j] = inv_spd(row[j].D, bad);
+    nxt = row;
     for (int j = 0; j < P; ++j) {
-      nxt[j] = row[j];
+      if (!cr_active(j, s)) continue;
       const bool okm = j >= s, okp = j + s < P;
       if (2 * s < P)
-        pcr_step<false, true>(nxt[j], okm ? G[j - s] : z3, okm ? row[j - s].Alow : z4, okm ? row[j - s].f : z2,
-                              okp ? G[j + s] : z3, okp ? row[j + s].Cup : z4, okp ? row[j + s].f : z2, &al[j], &ga[j]);
+        cr_eliminate<false>(nxt[j], okm ? G[j - s] : z3, okm ? row[j - s].Alow : z4, okm ? row[j - s].f : z2,
+                            okp ? G[j + s] : z3, okp ? row[j + s].Cup : z4, okp ? row[j + s].f : z2);
       else
-        pcr_step<true, true>(nxt[j], okm ? G[j - s] : z3, z4, okm ? row[j - s].f : z2, okp ? G[j + s] : z3, z4,
-                             okp ? row[j + s].f : z2, &al[j], &ga[j]);
+        cr_eliminate<true>(nxt[j], okm ? G[j - s] : z3, z4, okm ? row[j - s].f : z2, okp ? G[j + s] : z3, z4,
+                           okp ? row[j + s].f : z2);
     }
     row = nxt;
-    AL.push_back(al); GA.push_back(ga);
   }
-  std::vector<Vec2> u(P);
+  std::vector<Vec2> u(P, z2);
   std::vector<Sym2> Gf(P);
-  for (int j = 0; j < P; ++j) { Gf[j] = inv_spd(row[j].D, bad); u[j] = mul(Gf[j], row[j].f); }
-  for (int it = 0; it < refine; ++it) {                      // interface refinement (beam_math.hpp)
-    std::vector<Vec2> r(P), rn(P);
-    for (int j = 0; j < P; ++j) r[j] = iface_residual(row0[j], j ? u[j - 1] : z2, u[j], j + 1 < P ? u[j + 1] : z2);
-    int lv = 0;
-    for (int s = 1; s < P; s *= 2, ++lv) {
-      for (int j = 0; j < P; ++j)
-        rn[j] = pcr_rhs_step(r[j], AL[lv][j], GA[lv][j], j >= s ? r[j - s] : z2, j + s < P ? r[j + s] : z2);
-      r = rn;
-    }
-    for (int j = 0; j < P; ++j) { const Vec2 d = mul(Gf[j], r[j]); u[j].x += d.x; u[j].y += d.y; }
-  }
+  for (int j = 0; j < P; ++j) Gf[j] = inv_spd(row[j].D, bad);
+  u[0] = mul(Gf[0], row[0].f);
+  for (int s = P / 2; s >= 1; s /= 2)
+    for (int j = 0; j < P; ++j)
+      if (cr_frozen(j, s)) u[j] = cr_back(row[j], Gf[j], j >= s ? u[j - s] : z2, j + s < P ? u[j + s] : z2);
   for (int j = 0; j < P; ++j) {
     const int e0 = j * M;
     HostOut out{&ov[e0], &ot[e0], &oV[e0], &oM[e0]};
