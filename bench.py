@@ -70,6 +70,7 @@ def cpu_baseline(B_hint):
     from oracle import c_oracle as co
 
     cores = os.cpu_count() or 1
+    gen = generator_baseline(cores)       # forks: before the OpenMP runtime of the FE leg has any threads
     rng = np.random.default_rng(SEED)
     x = np.linspace(0.0, 200.0, N_ELEM + 1)
     fix = bo.reference_fix_mask()
@@ -86,29 +87,6 @@ def cpu_baseline(B_hint):
     for _ in range(reps):
         co.solve_beam_batched(x, bo.E_REF, I, fix, Fy, bo.UDL_REF, n_threads=cores, out=out)
     dt = time.perf_counter() - t0
-    # the reference's per-sample loop (MultiCore.py generate_sample: sequential FE solve + torch-CPU Adam per epoch) on ONE
-    # core, a few samples: what one worker of its process pool delivers (the pool scales this by the number of workers)
-    gen = None
-    try:
-        import torch as _t
-        from oracle import sizing_oracle as so
-        nthr = _t.get_num_threads()
-        _t.set_num_threads(1)
-        rs = np.random.default_rng(SEED + 1)
-        cand = [n for n in range(2, 101) if n not in bo.ROLLERS_REF]
-        t1 = time.perf_counter()
-        ep = 0
-        ns = 3
-        for _ in range(ns):
-            k = int(rs.integers(1, 5))
-            rec = so.generate_sample(x, bo.ROLLERS_REF, rs.choice(cand, size=k, replace=False), rs.uniform(bo.MAX_FORCE, bo.MIN_FORCE, size=k))
-            ep += int(rec["epochs_run"]) if "epochs_run" in rec else 0
-        d1 = time.perf_counter() - t1
-        _t.set_num_threads(nthr)
-        gen = {"samples_per_s_per_core": ns / d1, "samples": ns, "seconds": d1, "mean_epochs_per_sample": ep / ns,
-               "what": "oracle/sizing_oracle.py: per-sample loop of the reference (FE solve through the C port + torch CPU autograd / Adam), 1 thread"}
-    except Exception as e:   # the FE baseline must survive
-        gen = {"error": repr(e)}
     return {
         "value": nb * reps / dt,
         "unit": "beam FE solves/s",
@@ -118,6 +96,44 @@ def cpu_baseline(B_hint):
         "sample": f"{reps} x {nb} beams x {N_ELEM} elements, oracle/beam_oracle.c (band Cholesky, OpenMP static over beams, {cores} threads), "
                   f"{dt:.1f} s; OpenSeesPy itself unavailable (un-pinned third-party wheel)",
     }
+
+
+def _gen_one(seed):
+    """One sample of the reference's per-sample loop (MultiCore.py:130-240 `generate_sample`: sequential FE solve + torch-CPU
+    autograd / Adam per epoch, patience 10) in a pool worker, one thread."""
+    import torch as _t
+    from oracle import beam_oracle as bo
+    from oracle import sizing_oracle as so
+    _t.set_num_threads(1)
+    rs = np.random.default_rng(seed)
+    x = np.linspace(0.0, 200.0, N_ELEM + 1)
+    cand = [n for n in range(2, 101) if n not in bo.ROLLERS_REF]
+    k = int(rs.integers(1, 5))
+    rec = so.generate_sample(x, bo.ROLLERS_REF, rs.choice(cand, size=k, replace=False), rs.uniform(bo.MAX_FORCE, bo.MIN_FORCE, size=k),
+                             patience=10, zero_last_node=True)
+    return int(rec["epochs_run"])
+
+
+def generator_baseline(cores):
+    """CPU counterpart of MultiCore.py's main (MC:242-283): a process pool of `n_jobs` workers (the reference hard-codes 22,
+    MC:52; here every host core), a batch of samples handed out one per task, every sample the sequential per-epoch loop.
+    Must run BEFORE this process touches the GPU (fork).  Bounded: 2 samples per core, at most 500 (= one MC batch)."""
+    try:
+        import multiprocessing as mp
+        n = int(min(500, max(8, 2 * cores)))
+        ctx = mp.get_context("fork")
+        t0 = time.perf_counter()
+        with ctx.Pool(processes=cores) as pool:
+            pool.map(_gen_one, [SEED + 7], chunksize=1)                    # pool start-up + first-call costs stay outside
+            t1 = time.perf_counter()
+            ep = pool.map(_gen_one, [SEED + 100 + i for i in range(n)], chunksize=1)
+            dt = time.perf_counter() - t1
+        return {"samples_per_s": n / dt, "samples_per_s_per_core": n / dt / cores, "samples": n, "seconds": dt, "n_jobs": cores,
+                "pool_startup_s": t1 - t0, "mean_epochs_per_sample": float(np.mean(ep)),
+                "what": "process pool of n_jobs workers, one batch of samples, per-sample sequential loop of the reference "
+                        "(MultiCore.py:242-283 structure; FE solve through the C port, torch CPU autograd / Adam, 1 thread per worker)"}
+    except Exception as e:   # the FE baseline must survive
+        return {"error": repr(e)}
 
 
 def stream_copy_gbs(dev, mib=1024, reps=10):
@@ -251,6 +267,9 @@ def main():
     ap.add_argument("--inertia", default="trajectory", choices=["uniform", "trajectory", "adversarial"])
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a HIP graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sets", type=int, default=1, help="distinct input/output buffer sets the timed launches rotate over "
+                                                        "(1 = BASELINE workload; 16 = the cache-defeating variant, for profiling)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the `cold` and `saturating` sub-records")
     ap.add_argument("--train-epochs", type=int, default=None,
                     help="also time N PINN / TFD training epochs on 50 000 generated cases per GPU (second half of the "
                          "BASELINE metric: data-parallel over the N ranks, one RCCL all-reduce per step); default: 5 at --gpus 1, "
@@ -276,88 +295,113 @@ def main():
 
     import openpystruct_amd as oa
 
+    # the CPU legs run first: the generator leg forks a process pool, which must happen before this process touches the GPU
+    cpu = None
+    if world == 1 and not args.no_cpu_baseline and args.workload == "beams":
+        cpu = cpu_baseline(args.batch)
+
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if args.workload == "frames":
         return bench_frames(args, rank, local_rank, world, dev)
     B, K, W = args.batch, args.steps, args.warmup
-    inp = synth_inputs(B, rank, dev, args.inertia)
-    out = oa.beam_solve(**inp, tiling=args.tiling)     # allocates result buffers once
-    torch.cuda.synchronize()
-
-    def step():
-        oa.beam_solve(**inp, tiling=args.tiling, out=out)
-
-    stream = torch.cuda.Stream(device=dev)
-    graph = None
-    with torch.cuda.stream(stream):
-        for _ in range(W):
-            step()
-        stream.synchronize()
-        if not args.no_graph:
-            try:
-                graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph, stream=stream, capture_error_mode="thread_local"):
-                    for _ in range(K):
-                        step()
-                graph.replay()   # untimed: instantiate + first replay
-                stream.synchronize()
-            except Exception as e:   # keep the bench alive: eager launches measure the same kernel, with host gaps
-                print(f"warning: HIP graph capture failed ({e}); falling back to eager launches", file=sys.stderr)
-                graph = None
-                torch.cuda.synchronize()
 
     def barrier():
         if world > 1:
             dist.barrier(device_ids=[local_rank]) if dist.get_backend() == "nccl" else dist.barrier()
 
-    e0 = torch.cuda.Event(enable_timing=True)
-    e1 = torch.cuda.Event(enable_timing=True)
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    with torch.cuda.stream(stream):
-        e0.record(stream)
-        if graph is not None:
-            graph.replay()
-        else:
-            for _ in range(K):
-                step()
-        e1.record(stream)
-    torch.cuda.synchronize()
-    barrier()
-    wall = time.perf_counter() - t0
-    dev_ms = e0.elapsed_time(e1)                 # HIP events on the launch stream
-    assert int(out.status.abs().sum()) == 0
+    def measure(Bm, Km, Wm, n_sets, tiling):
+        """K launches over `Bm` beams, rotating over `n_sets` distinct input / output buffer sets, captured in ONE HIP
+        graph and replayed once between two HIP events on the launch stream.  Barriers and host synchronisation sit
+        strictly OUTSIDE the event pair.  Returns (event ms, wall s, kernel name, launch mode)."""
+        base = synth_inputs(Bm, rank, dev, args.inertia)
+        sets = [base]
+        for k in range(1, n_sets):      # distinct HBM: same geometry, rolled case order (values stay inside the distribution)
+            sets.append(dict(base, I=base["I"].roll(k, 0).contiguous(), Fy=base["Fy"].roll(k, 0).contiguous()))
+        outs = [oa.beam_solve(**st, tiling=tiling) for st in sets]       # allocates result buffers once per set
+        torch.cuda.synchronize()
+        stream = torch.cuda.Stream(device=dev)
+        graph = None
+        with torch.cuda.stream(stream):
+            for i in range(Wm):
+                oa.beam_solve(**sets[i % n_sets], tiling=tiling, out=outs[i % n_sets])
+            stream.synchronize()
+            if not args.no_graph:
+                try:
+                    graph = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(graph, stream=stream, capture_error_mode="thread_local"):
+                        for i in range(Km):
+                            oa.beam_solve(**sets[i % n_sets], tiling=tiling, out=outs[i % n_sets])
+                    graph.replay()   # untimed: instantiate + first replay
+                    stream.synchronize()
+                except Exception as e:   # keep the bench alive: eager launches measure the same kernel, with host gaps
+                    print(f"warning: HIP graph capture failed ({e}); falling back to eager launches", file=sys.stderr)
+                    graph = None
+                    torch.cuda.synchronize()
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        with torch.cuda.stream(stream):
+            e0.record(stream)
+            if graph is not None:
+                graph.replay()
+            else:
+                for i in range(Km):
+                    oa.beam_solve(**sets[i % n_sets], tiling=tiling, out=outs[i % n_sets])
+            e1.record(stream)
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t0          # host clock around the same region, BEFORE the closing barrier
+        barrier()
+        dev_ms = e0.elapsed_time(e1)             # HIP events on the launch stream
+        for o in outs:
+            assert int(o.status.abs().sum()) == 0
+        if world > 1:
+            tt = torch.tensor([wall, dev_ms], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            wall, dev_ms = float(tt[0]), float(tt[1])
+        del outs, sets
+        return dev_ms, wall, oa.kernel_name(Bm, N_ELEM, tiling), ("eager" if graph is None else f"one HIP graph of {Km} kernel nodes")
 
-    if world > 1:
-        tt = torch.tensor([wall, dev_ms], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        wall, dev_ms = float(tt[0]), float(tt[1])
+    def sub_record(Bm, Km, n_sets, tiling, what):
+        dev_ms, wall, kname, mode = measure(Bm, Km, min(W, 2 * n_sets), n_sets, tiling)
+        us = dev_ms / Km * 1e3
+        ach = BYTES_PER_SOLVE * Bm / (us * 1e-6) / 1e9
+        return {"what": what, "beams_per_launch_per_gpu": Bm, "launches": Km, "buffer_sets": n_sets,
+                "distinct_bytes": n_sets * BYTES_PER_SOLVE * Bm, "kernel": kname, "kernel_us": us,
+                "value": world * Bm * Km / (dev_ms * 1e-3), "achieved": ach, "frac": ach / HBM_PEAK_GBS, "launch": mode}
+
+    dev_ms, wall, kname, mode = measure(B, K, W, max(1, args.sets), args.tiling)
 
     if rank == 0:
         kernel_ms = dev_ms / K
         achieved = BYTES_PER_SOLVE * B / (kernel_ms * 1e-3) / 1e9
         rec = {
             "metric": "beam FE solves/s (100-elem, batched)",
-            "value": world * B * K / wall,
+            # whole-job rate over the max-over-ranks HIP-event time of the K captured launches (barriers outside the
+            # event pair: a 50-100 us barrier must not leak into a sub-millisecond timed region); host clock alongside
+            "value": world * B * K / (dev_ms * 1e-3),
             "unit": "beam FE solves/s",
             "n_gpus": world,
             "steps": K,
             "warmup": W,
-            "ms_per_step": wall * 1e3 / K,
+            "ms_per_step": kernel_ms,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
+            "value_host_clock": world * B * K / wall,
+            "ms_per_step_host_clock": wall * 1e3 / K,
             "config": {
                 "workload": f"BASELINE config 2: {B} beams x {N_ELEM} elements per GPU per step, fixed 5-roller bridge, "
                             f"1-4 point loads + UDL, inertia={args.inertia}, shared geometry (4925 B/solve)",
                 "beams_per_step_per_gpu": B,
                 "elements": N_ELEM,
-                "kernel": oa.kernel_name(B, N_ELEM, args.tiling),
-                "launch": "eager" if graph is None else f"one HIP graph of {K} kernel nodes",
+                "kernel": kname,
+                "launch": mode,
+                "buffer_sets": max(1, args.sets),
                 "parallelism": f"independent shards x{world}, no data-path collective",
             },
             "roofline": {
@@ -371,17 +415,28 @@ def main():
                 "bytes_per_launch": BYTES_PER_SOLVE * B,
             },
         }
+    else:
+        rec = None
+    # sub-records (every rank runs them: the timing reduction inside is collective)
+    extras = {}
+    if not args.no_extras and args.sets <= 1 and B == 10000:
+        # cold: the same 10^4-beam launch over 16 distinct buffer sets (788 MB > the 256 MiB Infinity Cache): no read of the
+        # timed region can be served by a cache that the previous replay filled -- the HBM claim without cache residency
+        extras["cold"] = sub_record(B, max(32, min(K, 512) // 16 * 16), 16, args.tiling,
+                                    "10^4-beam launches rotating over 16 distinct input/output sets (cache-defeating)")
+        # saturating: SURVEY 8(d) asks for B = 2^20 next to the contract batch (one round of waves at 10^4 beams)
+        extras["saturating"] = sub_record(1 << 20, 10, 1, args.tiling, "2^20 beams per launch (5.2 GB per launch: HBM-resident by size)")
+    if rank == 0:
+        rec.update(extras)
         copy = stream_copy_gbs(dev)
         rec["roofline"]["stream_copy"] = copy
-        rec["roofline"]["frac_of_stream_copy"] = achieved / copy
+        rec["roofline"]["frac_of_stream_copy"] = rec["roofline"]["achieved"] / copy
         tr = profiled_traffic(rec["config"]["kernel"], B)
         if tr:
             rec["roofline"]["traffic"] = tr[0]
             rec["roofline"]["traffic_source"] = f"profiles/{tr[1]} (2*FETCH_SIZE + WRITE_SIZE, KiB)"
-        if world == 1 and not args.no_cpu_baseline:
-            rec["cpu_baseline"] = cpu_baseline(B)
-    else:
-        rec = None
+        if cpu is not None:
+            rec["cpu_baseline"] = cpu
 
     # second half of the metric, AFTER the FE record is complete.  Guard for N > 1: if a collective in the training
     # part ever stalls, rank 0 still prints the (already measured) FE line and every rank leaves.
@@ -393,7 +448,7 @@ def main():
             if rank == 0:
                 rec["surrogate_epochs"] = {"error": "timed out after 420 s"}
                 print(json.dumps(rec), flush=True)
-            os._exit(0)
+            os._exit(3)          # a stalled collective is a failure: the FE line is out, the exit code says so
 
         guard = threading.Timer(420.0, bail)
         guard.daemon = True
