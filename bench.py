@@ -69,7 +69,7 @@ def cpu_baseline(B_hint):
     from oracle import beam_oracle as bo
     from oracle import c_oracle as co
 
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     gen = generator_baseline(cores)       # forks: before the OpenMP runtime of the FE leg has any threads
     rng = np.random.default_rng(SEED)
     x = np.linspace(0.0, 200.0, N_ELEM + 1)
@@ -114,13 +114,37 @@ def _gen_one(seed):
     return int(rec["epochs_run"])
 
 
+def usable_cores():
+    """Host cores this process may actually use: min(os.cpu_count(), scheduler affinity, cgroup CPU quota)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(math.ceil(int(txt[0]) / int(txt[1])))))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                    n = min(n, max(1, int(math.ceil(q / per))))
+            break
+        except Exception:
+            continue
+    return n
+
+
 def generator_baseline(cores):
     """CPU counterpart of MultiCore.py's main (MC:242-283): a process pool of `n_jobs` workers (the reference hard-codes 22,
     MC:52; here every host core), a batch of samples handed out one per task, every sample the sequential per-epoch loop.
-    Must run BEFORE this process touches the GPU (fork).  Bounded: 2 samples per core, at most 500 (= one MC batch)."""
+    Must run BEFORE this process touches the GPU (fork).  Bounded: 2 samples per usable core, at most 256 (half an MC batch of 500)."""
     try:
         import multiprocessing as mp
-        n = int(min(500, max(8, 2 * cores)))
+        n = int(min(256, max(8, 2 * cores)))
         ctx = mp.get_context("fork")
         t0 = time.perf_counter()
         with ctx.Pool(processes=cores) as pool:
@@ -151,18 +175,24 @@ def stream_copy_gbs(dev, mib=1024, reps=10):
     return 2.0 * (mib << 20) * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
 
 
-def profiled_traffic(kernel_name, B):
+def profiled_traffic(kernel_name, B, hint=""):
     """HBM bytes per launch from the newest committed PMC summary of this command (scripts/profile_gpu.sh:
     separate --pmc passes; FETCH_SIZE / WRITE_SIZE are KiB; FETCH_SIZE x2 for 16-byte coalesced reads on
-    gfx950, MI355X_MICROARCH.md section HBM).  None when no matching profile is committed."""
+    gfx950, MI355X_MICROARCH.md section HBM).  `hint`: substring of the profile's file name (hot / cold / sat) that
+    tells runs of the same kernel and grid apart.  None when no matching profile is committed."""
     import glob
+    import re
     best = None
+    m = re.search(r"<(\d+),", kernel_name)
+    bpw = 64 // int(m.group(1)) if m else 4
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json"))):
         try:
             r = json.load(open(f))
         except Exception:
             continue
-        if kernel_name in r.get("kernel", "") and int(r.get("dispatch", {}).get("Grid_Size", 0)) == 64 * ((B + 3) // 4):
+        if hint and hint not in os.path.basename(f):
+            continue
+        if kernel_name in r.get("kernel", "") and int(r.get("dispatch", {}).get("Grid_Size", 0)) == 64 * ((B + bpw - 1) // bpw):
             h = r.get("hbm", {})
             if h.get("FETCH_SIZE_raw") and h.get("WRITE_SIZE_raw"):
                 best = (2.0 * h["FETCH_SIZE_raw"] + h["WRITE_SIZE_raw"]) * 1024.0, os.path.basename(f)
@@ -431,10 +461,16 @@ def main():
         copy = stream_copy_gbs(dev)
         rec["roofline"]["stream_copy"] = copy
         rec["roofline"]["frac_of_stream_copy"] = rec["roofline"]["achieved"] / copy
-        tr = profiled_traffic(rec["config"]["kernel"], B)
+        tr = profiled_traffic(rec["config"]["kernel"], B, "hot" if args.sets <= 1 else "cold") or profiled_traffic(rec["config"]["kernel"], B)
         if tr:
             rec["roofline"]["traffic"] = tr[0]
             rec["roofline"]["traffic_source"] = f"profiles/{tr[1]} (2*FETCH_SIZE + WRITE_SIZE, KiB)"
+        for key, hint in (("cold", "cold"), ("saturating", "sat")):
+            if key in rec:
+                tr = profiled_traffic(rec[key]["kernel"], rec[key]["beams_per_launch_per_gpu"], hint)
+                rec[key]["traffic"] = tr[0] if tr else None
+                if tr:
+                    rec[key]["traffic_source"] = f"profiles/{tr[1]}"
         if cpu is not None:
             rec["cpu_baseline"] = cpu
 
