@@ -80,6 +80,13 @@ def beam_solve(x, E, I, fix, Fy, wy, *, tiling: int = 0, out: Optional[BeamSolut
             torch.empty((B, Ne), dtype=torch.float64, device=dev),
             torch.empty((B,), dtype=torch.int32, device=dev),
         )
+    else:       # caller-owned result buffers: raw pointers go to the kernel, so shape / dtype / device / layout are checked here
+        for name, t, shape, dt in (("out.v", out.v, (B, N), torch.float64), ("out.theta", out.theta, (B, N), torch.float64),
+                                   ("out.V", out.V, (B, Ne), torch.float64), ("out.M", out.M, (B, Ne), torch.float64),
+                                   ("out.status", out.status, (B,), torch.int32)):
+            if tuple(t.shape) != shape or t.dtype != dt or t.device != dev or not t.is_contiguous():
+                raise ValueError(f"{name} must be a contiguous {dt} tensor of shape {shape} on {dev}, "
+                                 f"got {tuple(t.shape)} {t.dtype} on {t.device}")
     with torch.cuda.device(dev):
         stream = torch.cuda.current_stream(dev).cuda_stream
         rc = lib.ops_beam_solve_batched_f64(

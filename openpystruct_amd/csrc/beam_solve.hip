@@ -613,6 +613,13 @@ static const Tiling* choose_tiling(int B, int Ne, int tiling) {
 
 static thread_local char g_last_error[256] = {0};
 
+// shared by every translation unit of the library (ops_amd_last_error reports it)
+void set_last_error(const char* msg) {
+  int k = 0;
+  for (; msg && msg[k] && k < 255; ++k) g_last_error[k] = msg[k];
+  g_last_error[k] = 0;
+}
+
 template <int P, int M>
 static hipError_t launch(const BeamParams& p, bool shared, hipStream_t stream) {
   constexpr int BPW = 64 / P;
@@ -707,10 +714,7 @@ static int solve_impl(int B, int Ne, const double* x, long x_bstride, const doub
   else if (t->P == 64 && t->M == 8) err = launch<64, 8>(p, shared, s);
   else if (t->P == 64 && t->M == 16) err = launch<64, 16>(p, shared, s);
   if (err != hipSuccess) {
-    const char* msg = hipGetErrorString(err);
-    int k = 0;
-    for (; msg && msg[k] && k < 255; ++k) g_last_error[k] = msg[k];
-    g_last_error[k] = 0;
+    set_last_error(hipGetErrorString(err));
     return OPS_AMD_ERR_LAUNCH;
   }
   return OPS_AMD_OK;

@@ -29,7 +29,12 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include <atomic>
+
 #include "../../include/openpystruct_amd.h"
+
+namespace opsamd { void set_last_error(const char* msg); }   // beam_solve.hip: what ops_amd_last_error() reports
+static inline void set_frame_error(const char* msg) { opsamd::set_last_error(msg); }
 
 namespace opsamd {
 
@@ -569,13 +574,20 @@ extern "C" int ops_frame_solve_batched_f64(int B, int n_nodes, int n_elems, int 
   if (half_bandwidth > 63) return OPS_AMD_ERR_UNSUPPORTED;    // the window rows of a block step are one 64-lane wave
   const int kd = eff_kd(half_bandwidth);
   const size_t lds_bytes = frame_lds_resident_bytes(n_eq, kd);
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)frame_solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX) != hipSuccess ||
-        hipFuncSetAttribute((const void*)frame_assemble_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX) != hipSuccess ||
-        hipFuncSetAttribute((const void*)frame_factor_big_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX) != hipSuccess)
-      return OPS_AMD_ERR_LAUNCH;
-    attr_set = true;
+  {
+    // the dynamic-LDS limit is a per-DEVICE function attribute: set once per device this thread-safe way (a process may
+    // drive several GPUs: ops.set_device / FrameTopology(device=...))
+    static std::atomic<unsigned long long> attr_done{0};
+    int devid = 0;
+    if (hipGetDevice(&devid) != hipSuccess || devid < 0 || devid >= 64) return OPS_AMD_ERR_LAUNCH;
+    const unsigned long long bit = 1ull << devid;
+    if (!(attr_done.load(std::memory_order_acquire) & bit)) {
+      hipError_t e = hipFuncSetAttribute((const void*)frame_solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX);
+      if (e == hipSuccess) e = hipFuncSetAttribute((const void*)frame_assemble_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX);
+      if (e == hipSuccess) e = hipFuncSetAttribute((const void*)frame_factor_big_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX);
+      if (e != hipSuccess) { set_frame_error(hipGetErrorString(e)); return OPS_AMD_ERR_LAUNCH; }
+      attr_done.fetch_or(bit, std::memory_order_release);      // idempotent: two threads racing here both set the same value
+    }
   }
   FrameParams p{B, n_nodes, n_elems, n_eq, kd, elem_geo, elem_EA, elem_E, elem_w, elem_eq, node_eq,
                 I, loads, loads_bstride, disp, forces, V, M, status, nullptr};

@@ -30,13 +30,22 @@ class _FEResidual(torch.autograd.Function):
             raise RuntimeError("fe_residual needs GPU tensors: openpystruct_amd has no CPU fallback")
         dev = I.device
         I, v, theta = (t.detach().to(torch.float64).contiguous() for t in (I, v, theta))
+        if I.dim() != 2:
+            raise ValueError("I must be [B, Ne]")
         B, Ne = I.shape
         N = Ne + 1
+        for name, t, shape in (("v", v, (B, N)), ("theta", theta, (B, N)), ("Fy", Fy, (B, N))):
+            if tuple(t.shape) != shape or t.device != dev or t.dtype != torch.float64 or not t.is_contiguous():
+                raise ValueError(f"{name} must be a contiguous float64 [{shape[0]}, {shape[1]}] tensor on {dev}, got {tuple(t.shape)} {t.dtype} on {t.device}")
+        for name, t in (("x", x), ("E", E), ("fix", fix), ("wy", wy)):
+            if t.device != dev:
+                raise ValueError(f"{name} is on {t.device}, expected {dev}")
         rv, rt = torch.empty_like(v), torch.empty_like(theta)
-        s = torch.cuda.current_stream(dev).cuda_stream
-        rc = lib.ops_beam_residual_f64(B, Ne, x.data_ptr(), N if x.dim() == 2 else 0, E.data_ptr(), Ne if E.numel() != 1 else 0,
-                                       I.data_ptr(), fix.data_ptr(), N if fix.dim() == 2 else 0, Fy.data_ptr(), wy.data_ptr(),
-                                       Ne if wy.numel() != 1 else 0, v.data_ptr(), theta.data_ptr(), rv.data_ptr(), rt.data_ptr(), s)
+        with torch.cuda.device(dev):                  # the launch goes to I's device, whatever the current one is
+            s = torch.cuda.current_stream(dev).cuda_stream
+            rc = lib.ops_beam_residual_f64(B, Ne, x.data_ptr(), N if x.dim() == 2 else 0, E.data_ptr(), Ne if E.numel() != 1 else 0,
+                                           I.data_ptr(), fix.data_ptr(), N if fix.dim() == 2 else 0, Fy.data_ptr(), wy.data_ptr(),
+                                           Ne if wy.numel() != 1 else 0, v.data_ptr(), theta.data_ptr(), rv.data_ptr(), rt.data_ptr(), s)
         if rc != _cabi.OK:
             raise RuntimeError(f"ops_beam_residual_f64 failed with code {rc}")
         ctx.save_for_backward(I, v, theta, x, E, fix)
@@ -52,11 +61,12 @@ class _FEResidual(torch.autograd.Function):
         gv, gt = gv.to(torch.float64).contiguous(), gt.to(torch.float64).contiguous()
         sv, st_ = torch.empty_like(v), torch.empty_like(v)
         dv, dt, dI = torch.empty_like(v), torch.empty_like(v), torch.empty_like(I)
-        s = torch.cuda.current_stream(dev).cuda_stream
-        rc = lib.ops_beam_residual_vjp_f64(B, Ne, x.data_ptr(), N if x.dim() == 2 else 0, E.data_ptr(), Ne if E.numel() != 1 else 0,
-                                           I.data_ptr(), fix.data_ptr(), N if fix.dim() == 2 else 0, v.data_ptr(), theta.data_ptr(),
-                                           gv.data_ptr(), gt.data_ptr(), sv.data_ptr(), st_.data_ptr(), dv.data_ptr(), dt.data_ptr(),
-                                           dI.data_ptr(), s)
+        with torch.cuda.device(dev):
+            s = torch.cuda.current_stream(dev).cuda_stream
+            rc = lib.ops_beam_residual_vjp_f64(B, Ne, x.data_ptr(), N if x.dim() == 2 else 0, E.data_ptr(), Ne if E.numel() != 1 else 0,
+                                               I.data_ptr(), fix.data_ptr(), N if fix.dim() == 2 else 0, v.data_ptr(), theta.data_ptr(),
+                                               gv.data_ptr(), gt.data_ptr(), sv.data_ptr(), st_.data_ptr(), dv.data_ptr(), dt.data_ptr(),
+                                               dI.data_ptr(), s)
         if rc != _cabi.OK:
             raise RuntimeError(f"ops_beam_residual_vjp_f64 failed with code {rc}")
         return dI, dv, dt, None, None, None, None, None

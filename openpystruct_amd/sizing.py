@@ -103,9 +103,12 @@ class Cases:
     def __len__(self):
         return int(self.Fy.shape[0])
 
+    def tensors(self):
+        return (self.node_positions, self.L, self.roller_nodes_t, self.n_rollers, self.force_nodes_t, self.n_forces,
+                self.force_values_t, self.fix, self.Fy)
+
     def slice(self, lo: int, hi: int) -> "Cases":
-        return Cases(*(t[lo:hi] for t in (self.node_positions, self.L, self.roller_nodes_t, self.n_rollers, self.force_nodes_t,
-                                          self.n_forces, self.force_values_t, self.fix, self.Fy)))
+        return Cases(*(t[lo:hi] for t in self.tensors()))
 
     def _ragged(self, name, t, n):
         if name not in self._lists:
@@ -126,14 +129,34 @@ class Cases:
         return self._ragged("v", self.force_values_t, self.n_forces)
 
 
-def make_cases(n_cases: int, cfg: SizingConfig, seed: int = 20250307, device="cpu") -> Cases:
-    """Seeded, vectorised restatement of the case randomisation (SingleCore.py:133-160), generated directly on
-    `device` (BASELINE config 3: "dataset generated on-GPU"): same distributions -- 1..4 distinct loaded nodes
-    from the available ones, values U(max_force, min_force); with random_bridge = 1: L = L_min + U(0, L_max),
-    1..4 distinct rollers from nodes 2..N-1.  The reference never seeds `random`; here the WHOLE list is a pure
-    function of (seed, n_cases, device type), so any sharding of it over ranks gives the same dataset."""
+CASE_BLOCK = 16384      # the case list is drawn in blocks of this many cases, block b from the seed (seed, b)
+
+
+def make_cases(n_cases: int, cfg: SizingConfig, seed: int = 20250307, device="cpu", lo: int = 0, hi: Optional[int] = None) -> Cases:
+    """Cases [lo, hi) (default: all) of the globally seeded case list of `n_cases` cases.  The list is drawn in blocks of
+    CASE_BLOCK cases, block b from its own generator seeded with (seed, b): case i is a pure function of (seed, i, device type)
+    -- independent of n_cases, of the range asked for and of how many ranks or chunks share the list -- and a range costs
+    O(hi - lo + CASE_BLOCK), not O(n_cases) (chunked generation of 10^7 cases no longer draws the whole list per chunk)."""
+    hi = n_cases if hi is None else min(hi, n_cases)
+    lo = max(0, min(lo, hi))
+    parts = []
+    for b in range(lo // CASE_BLOCK, max(lo // CASE_BLOCK + 1, (hi + CASE_BLOCK - 1) // CASE_BLOCK)):
+        blk = _make_case_block(cfg, seed * 1000003 + b, device)
+        a, e = max(lo, b * CASE_BLOCK) - b * CASE_BLOCK, min(hi, (b + 1) * CASE_BLOCK) - b * CASE_BLOCK
+        parts.append(blk.slice(a, max(a, e)))
+    if len(parts) == 1:
+        return parts[0]
+    return Cases(*(torch.cat(ts, dim=0) for ts in zip(*(p.tensors() for p in parts))))
+
+
+def _make_case_block(cfg: SizingConfig, seed: int, device) -> Cases:
+    """One block of CASE_BLOCK cases: seeded, vectorised restatement of the case randomisation (SingleCore.py:133-160),
+    generated directly on `device` (BASELINE config 3: "dataset generated on-GPU"): same distributions -- 1..4 distinct
+    loaded nodes from the available ones, values U(max_force, min_force); with random_bridge = 1: L = L_min + U(0, L_max),
+    1..4 distinct rollers from nodes 2..N-1.  The reference never seeds `random`."""
     dev = torch.device(device)
     g = torch.Generator(device=dev).manual_seed(seed)
+    n_cases = CASE_BLOCK
     N, B, R, F = cfg.num_nodes, n_cases, cfg.N_rollers_max, cfg.M_forces_max
     f64 = dict(dtype=torch.float64, device=dev)
     cand = torch.arange(2, N, device=dev)                      # 1-based candidates: range(2, num_nodes), :63 / :138
@@ -216,7 +239,17 @@ def shard_range(n_total: int, rank: int, world: int) -> Tuple[int, int]:
 
 
 _FUSED_EPOCH = os.environ.get("OPS_AMD_SIZING_FUSED", "1") == "1"     # A/B switch: 0 = separate solve and step launches
-_EPOCH_TILING = int(os.environ.get("OPS_AMD_SIZING_TILING", "0"))      # lanes per beam of the fused epoch kernel (0 = library default)
+_EPOCH_TILING = int(os.environ.get("OPS_AMD_SIZING_TILING", "0"))      # lanes per beam of the sizing loop's solves (0 = rule below)
+
+
+def sizing_tiling(n_nodes: int) -> int:
+    """Lanes per beam of EVERY solve of the sizing loop (fused or not, per-epoch and final): a function of the mesh size only.
+    The library's own default switches from 16 to 8 lanes at 32 768 beams per launch; roundings -- hence early-stop epochs
+    and records -- would then depend on how many ranks or chunks share the cases.  16 lanes while they fit (N <= 112),
+    otherwise 0 = the library's first fitting tiling, which depends on N alone."""
+    if _EPOCH_TILING:
+        return _EPOCH_TILING
+    return 16 if n_nodes <= 16 * 7 else 0
 
 
 class SizingState:
@@ -269,7 +302,7 @@ class SizingState:
                     self.fix.data_ptr(), N if self.fix.dim() == 2 else 0, self.Fy.data_ptr(), N, self.wy.data_ptr(), 0,
                     self.I.data_ptr(), self.I64.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(),
                     self.best_loss.data_ptr(), self.patience_cnt.data_ptr(), self.epochs_run.data_ptr(), self.active.data_ptr(),
-                    self.last_loss.data_ptr(), ctypes.byref(self._hp), self._schedule.data_ptr(), self._status.data_ptr(), _EPOCH_TILING,
+                    self.last_loss.data_ptr(), ctypes.byref(self._hp), self._schedule.data_ptr(), self._status.data_ptr(), sizing_tiling(N),
                     torch.cuda.current_stream(self.device).cuda_stream)
             if rc != _cabi.OK:
                 raise RuntimeError(f"ops_beam_sizing_epoch_f32 failed with code {rc}: {lib.ops_amd_last_error().decode()}")
@@ -279,7 +312,7 @@ class SizingState:
             rc = lib.ops_beam_solve_forces_f32(
                 self.B, Ne, self.x.data_ptr(), N if self.x.dim() == 2 else 0, self.E.data_ptr(), 0, self.I64.data_ptr(), Ne,
                 self.fix.data_ptr(), N if self.fix.dim() == 2 else 0, self.Fy.data_ptr(), N, self.wy.data_ptr(), 0,
-                self._V.data_ptr(), self._M.data_ptr(), self._status.data_ptr(), self.active.data_ptr(), 0, stream)
+                self._V.data_ptr(), self._M.data_ptr(), self._status.data_ptr(), self.active.data_ptr(), sizing_tiling(N), stream)
             if rc != _cabi.OK:
                 raise RuntimeError(f"ops_beam_solve_forces_f32 failed with code {rc}: {lib.ops_amd_last_error().decode()}")
             rc = lib.ops_beam_sizing_step_vm32_f32(
@@ -295,8 +328,7 @@ class SizingState:
         solve.  `I64` froze when a case stopped, so one full solve reproduces it -- displacements included -- and the
         float32 roundings of shear / moment (:189-190) are taken from it."""
         # same tiling as the epochs, whatever the shard size: the records do not depend on how many GPUs share the cases
-        til = 16 if (_FUSED_EPOCH and self.N <= 112 and _EPOCH_TILING == 0) else _EPOCH_TILING
-        self.sol = beam_solve(self.x, self.E, self.I64, self.fix, self.Fy, self.wy, tiling=til, out=self.sol)
+        self.sol = beam_solve(self.x, self.E, self.I64, self.fix, self.Fy, self.wy, tiling=sizing_tiling(self.N), out=self.sol)
         self.V32, self.M32 = self.sol.V.float(), self.sol.M.float()
 
 
@@ -352,7 +384,7 @@ def generate_dataset(n_cases: int, cfg: Optional[SizingConfig] = None, device="c
     lo, hi = shard_range(n_cases, rank, world)
     if case_range is not None:               # a sub-range of this rank's shard (generate_dataset_to_files)
         lo, hi = lo + case_range[0], min(hi, lo + case_range[1])
-    cases = make_cases(n_cases, cfg, seed, device=device).slice(lo, hi)     # generated on the GPU, sliced per rank
+    cases = make_cases(n_cases, cfg, seed, device=device, lo=lo, hi=hi)     # generated on the GPU: only the blocks this range touches
     st = optimize_cases(cases, cfg, device, poll_every=poll_every)
     sol = st.sol
     rot, defl = sol.theta.clone(), sol.v.clone()
@@ -485,8 +517,9 @@ def generate_dataset_to_files(n_cases: int, out_dir: str, cfg: Optional[SizingCo
                               rank: int = 0, world: int = 1, chunk: int = 100000, resume: bool = True) -> List[str]:
     """`generate_dataset` for this rank's shard, flushed chunk by chunk (`save_records`) so that an interrupted run keeps
     what it has -- the reference writes ONE json at the very end (SingleCore.py:263) and loses everything on a crash
-    (SURVEY section 5).  With `resume`, chunks whose file exists are skipped; the case list is a pure function of
-    (seed, n_cases), so the files of any run / any GPU count tile the same dataset.  Returns the chunk files in order."""
+    (SURVEY section 5).  With `resume`, chunks whose file exists are skipped after checking that the file records the same
+    (seed, n_cases, configuration); case i is a pure function of (seed, i), so the files of any run / any GPU count tile the
+    same dataset.  Returns the chunk files in order."""
     os.makedirs(out_dir, exist_ok=True)
     lo, hi = shard_range(n_cases, rank, world)
     files = []
@@ -494,9 +527,14 @@ def generate_dataset_to_files(n_cases: int, out_dir: str, cfg: Optional[SizingCo
         c1 = min(c0 + chunk, hi - lo)
         path = os.path.join(out_dir, f"records_{lo + c0:09d}_{lo + c1:09d}.pt")
         files.append(path)
+        meta = {"seed": int(seed), "n_cases": int(n_cases), "cfg": repr(cfg or SizingConfig()), "range": [lo + c0, lo + c1]}
         if resume and os.path.exists(path):
+            have = torch.load(path, map_location="cpu", weights_only=True).get("meta")
+            if have != meta:      # a file of another dataset (seed / size / configuration): never mix silently
+                raise ValueError(f"{path} was generated with {have}, this run is {meta}; use another out_dir or resume=False")
             continue
         rec = generate_dataset(n_cases, cfg, device, seed, rank, world, case_range=(c0, c1))
+        rec["meta"] = meta
         save_records(rec, path + ".tmp")
         os.replace(path + ".tmp", path)          # a file either is complete or does not exist
     return files

@@ -97,6 +97,27 @@ def test_sizing_loop_vs_per_case_oracle(oa, patience):
     assert 150 < ep.mean() < 450                                               # ~237-255 epochs per sample
 
 
+def test_gpu_script_variant_vs_per_case_oracle(oa):
+    """`SizingConfig.gpu_script()` = OpenPyStruct_BeamOpt_training_GPU.py:50-51 (tolerance 1e-2, patience 100): with a patience
+    of 100 the loop runs to within a few epochs of max_e = 600 or stops ~100 epochs after the last 1e-2 improvement."""
+    from openpystruct_amd import sizing
+    cfg = sizing.SizingConfig.gpu_script()
+    assert cfg.tolerance == 1e-2 and cfg.patience == 100
+    n = 3
+    cases = sizing.make_cases(n, cfg, seed=321)
+    st = sizing.optimize_cases(cases, cfg, "cuda", poll_every=25)
+    ep = st.epochs_run.cpu().numpy()
+    assert int(st.active.sum()) == 0
+    for b in range(n):
+        ref = so.generate_sample(cases.node_positions[b].numpy(), cases.roller_nodes[b], cases.force_nodes[b],
+                                 cases.force_values[b], patience=cfg.patience, tolerance=cfg.tolerance)
+        assert abs(int(ep[b]) - ref["epochs_run"]) <= 3, (ep[b], ref["epochs_run"])
+        assert ref["epochs_run"] > 250          # patience 100: far beyond the ~250 epochs of the patience-5 script
+        if int(ep[b]) == ref["epochs_run"]:
+            Iref = np.array(ref["I_values"])
+            assert np.abs(st.I[b].cpu().numpy() - Iref).max() / Iref.max() < 3e-3
+
+
 def test_first_epochs_match_oracle_tightly(oa):
     """Three optimiser steps from the common start I = 0.5: float32-level agreement with torch's Adam."""
     from openpystruct_amd import sizing
