@@ -521,6 +521,8 @@ __global__ __launch_bounds__(1024) void frame_factor_big_kernel(const FrameParam
 
 }  // namespace opsamd
 
+#include "frame_wave.hpp"
+
 using namespace opsamd;
 
 #ifdef OPS_AMD_FRAME_TRACE
@@ -555,8 +557,33 @@ static int eff_kd(int half_bandwidth) { return half_bandwidth < 3 ? 3 : half_ban
 
 static bool force_ws() { const char* e = getenv("OPS_AMD_FRAME_FORCE_WS"); return e && atoi(e) != 0; }
 
+// kd <= 55: the wave-per-frame kernel (frame_wave.hpp); OPS_AMD_FRAME_LEGACY=1 keeps the r01 workgroup-per-frame kernels (A/B)
+static bool use_wave_kernel(int kd) {
+  const char* e = getenv("OPS_AMD_FRAME_LEGACY");
+  return kd <= 55 && !(e && atoi(e) != 0);
+}
+
+template <int W>
+static hipError_t launch_wave(const FrameParams& p, double* ws, hipStream_t s) {
+  static std::atomic<unsigned long long> done{0};
+  int devid = 0;
+  hipError_t e = hipGetDevice(&devid);
+  if (e != hipSuccess) return e;
+  const size_t lds = 4 * fw_lds_doubles(p.n_eq, W) * sizeof(double);
+  if (lds > 160 * 1024 - 64) return hipErrorInvalidValue;
+  const unsigned long long bit = 1ull << (devid & 63);
+  if (!(done.load(std::memory_order_acquire) & bit)) {
+    e = hipFuncSetAttribute((const void*)frame_wave_kernel<W>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
+    if (e != hipSuccess) return e;
+    done.fetch_or(bit, std::memory_order_release);
+  }
+  hipLaunchKernelGGL(frame_wave_kernel<W>, dim3((unsigned)((p.B + 3) / 4)), dim3(256), lds, s, p, ws);
+  return hipGetLastError();
+}
+
 extern "C" size_t ops_frame_workspace_bytes(int B, int n_eq, int half_bandwidth) {
   half_bandwidth = eff_kd(half_bandwidth);
+  if (use_wave_kernel(half_bandwidth)) return (size_t)B * fw_frame_doubles(n_eq, half_bandwidth) * sizeof(double);
   if (frame_lds_resident_bytes(n_eq, half_bandwidth) <= LDS_MAX && !force_ws()) return 0;   // the band lives in LDS
   return (size_t)B * frame_lds_resident_bytes(n_eq, half_bandwidth);
 }
@@ -594,9 +621,30 @@ extern "C" int ops_frame_solve_batched_f64(int B, int n_nodes, int n_elems, int 
 #ifdef OPS_AMD_FRAME_TRACE
   if (const char* e = getenv("OPS_AMD_FRAME_TRACE_PTR")) p.trace = (unsigned long long*)strtoull(e, nullptr, 10);
 #endif
+  hipStream_t s = (hipStream_t)stream;
+  if (use_wave_kernel(kd)) {
+    const int W = fw_width(kd);
+    const size_t need = (size_t)B * fw_frame_doubles(n_eq, kd) * sizeof(double);
+    if (!workspace || workspace_bytes < need) return OPS_AMD_ERR_INVALID_ARG;
+    const size_t lds_asm = ((size_t)FW_SLAB * W + (size_t)n_eq) * sizeof(double);
+    if (lds_asm > LDS_MAX) return OPS_AMD_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(frame_assemble_rows_kernel, dim3((unsigned)B), dim3(256), lds_asm, s, p, (double*)workspace, W);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) {
+      switch (W) {
+        case 16: e = launch_wave<16>(p, (double*)workspace, s); break;
+        case 24: e = launch_wave<24>(p, (double*)workspace, s); break;
+        case 36: e = launch_wave<36>(p, (double*)workspace, s); break;
+        case 52: e = launch_wave<52>(p, (double*)workspace, s); break;
+        default: e = launch_wave<56>(p, (double*)workspace, s); break;
+      }
+    }
+    if (e == hipErrorInvalidValue) return OPS_AMD_ERR_UNSUPPORTED;
+    if (e != hipSuccess) { set_frame_error(hipGetErrorString(e)); return OPS_AMD_ERR_LAUNCH; }
+    return OPS_AMD_OK;
+  }
   int T, pp_use;
   frame_threads(kd, !(lds_bytes > LDS_MAX || force_ws()), &T, &pp_use);
-  hipStream_t s = (hipStream_t)stream;
   if (lds_bytes > LDS_MAX || force_ws()) {
     // band in the HBM workspace, sliding LDS ring
     const int ld = frame_ld(kd), n3 = frame_n3(n_eq);

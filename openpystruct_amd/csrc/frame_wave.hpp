@@ -1,0 +1,273 @@
+// Batched 2-D frame solve, second generation: ONE WAVEFRONT PER FRAME, the band window resident in REGISTERS.
+// (included by frame_solve.hip; FrameParams, frcp, elem_global_k, write_results come from there)
+//
+// Same arithmetic as the band solver the reference selects for `setup_frame_model`
+// (/root/reference/OpenPyStruct_FrameOpt_Discrete_Beta.py:134 `system('BandGeneral')` on an SPD matrix; restated as the
+// column-by-column band LDL^T that LAPACK dpbsv performs): pivots in equation order, no pivoting.
+//
+// Why: the r01 kernels (one 320..1024-thread workgroup per frame, band in LDS, three columns per workgroup barrier) ran at
+// ~2 % of the FP64 vector rate: every window entry cost four LDS operations per fused multiply-add and every block step a
+// ~1 400-cycle serial chain behind a barrier.  Here a frame is a single wave, so there are no barriers at all, and the
+// kd x kd window never touches LDS:
+//
+//   * lane (R mod 64) OWNS ROW R of the band while it is inside the window (kd <= 55 < 64 rows are in flight at a time);
+//     entry A[R][C] sits in that lane's register  reg[C mod W]  (W >= kd + 1, a compile-time constant): the register
+//     index is the same for every lane, so the kernel is unrolled W-fold over (column mod W) and needs no dynamic register
+//     indexing;
+//   * step j: the pivot is one v_readlane, every window lane scales its own entry (l = A[R][j] / d_j), the unscaled column
+//     goes through a 64-entry LDS line as a BROADCAST (one ds_write + kd/2 conflict-free 16-byte broadcast reads), and
+//     each lane updates its row:  reg[C mod W] -= l * A[C][j]  -- one FMA per column of the window, operands in registers;
+//   * forward substitution rides along (one readlane + one FMA); column j of L leaves with ONE coalesced store, into the
+//     place of the assembled row j it no longer needs (the factor overwrites the band in the HBM workspace);
+//   * rows enter the window in groups of 8: the group's 8 x W doubles are contiguous in the workspace, fetched by the whole
+//     wave one group ahead, parked in LDS, and moved into the owners' registers when their lanes fall free;
+//   * backward substitution is the mirror image ("axpy" form): lane (R mod 64) carries w_R, x_j is one readlane, every
+//     lane reads ITS column of L as one contiguous run over kd consecutive steps (sector reuse in L1).
+//
+// Bound: HBM.  Per frame the workspace is written once by the assembly, read once and rewritten by the factorisation, read
+// once by the backward sweep: 4 n W 8 bytes (10 x 10 bays: 380 KB; 15 x 16: 1.28 MB) -- DESIGN.md section 8 f1 has the
+// measured numbers.  No MFMA: the update is rank-1 per column on a window that slides by one column per step; a
+// 16-column panel (what v_mfma_f64_16x16x4_f64 tiles would need to keep their tile <-> lane mapping fixed) is as wide as
+// the whole band of the reference's frames (kd = 3 (bays + 1) + 2 <= 35) and its panel factorisation is the serial part.
+#pragma once
+
+namespace opsamd {
+
+constexpr int FW_G = 8;     // rows per load group
+
+__host__ __device__ inline int fw_width(int kd) {           // compiled register-window widths
+  return kd < 16 ? 16 : kd < 24 ? 24 : kd < 36 ? 36 : kd < 52 ? 52 : 56;
+}
+__host__ __device__ inline int fw_rows(int n) { return n + 64 + 2 * FW_G; }      // allocated rows: unguarded group prefetch
+__host__ __device__ inline size_t fw_frame_doubles(int n, int kd) { return (size_t)fw_rows(n) * (fw_width(kd) + 1); }
+constexpr int FW_CB = 72;   // broadcast line: entry `rel` at index rel + 1 (pairs (t, t + 1), t odd, are 16-byte aligned), two buffers
+__host__ __device__ inline size_t fw_lds_doubles(int n, int W) { return ((2 * FW_CB + (size_t)FW_G * (W + 1) + (size_t)(n + 64)) + 1) & ~(size_t)1; }
+
+__device__ __forceinline__ double fw_readlane(double v, int lane) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane), hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+  return __hiloint2double(hi, lo);
+}
+// LDS operations of one wave execute in order; this pins the compiler and lands earlier reads
+__device__ __forceinline__ void fw_fence() {
+  __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0)
+  __asm__ volatile("" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+}
+
+// ---- assembly into the ROW-major workspace layout: row R holds A[R][C] at offset C mod W (C in R-kd .. R) ----
+constexpr int FW_SLAB = 96;   // rows per LDS slab of the assembly kernel
+
+__global__ __launch_bounds__(256) void frame_assemble_rows_kernel(const FrameParams p, double* __restrict__ ws, int W) {
+  extern __shared__ double lds[];
+  const long b = blockIdx.x;
+  const int n = p.n_eq, tid = threadIdx.x;
+  double* slab = lds;                             // [FW_SLAB][W]
+  double* rhs = lds + (size_t)FW_SLAB * W;        // [n]
+  double* rows = ws + b * fw_frame_doubles(n, p.kd);
+  double* rhs_g = rows + (size_t)fw_rows(n) * W;
+  const double* Ib = p.I + b * p.Ne;
+  for (int i = tid; i < n; i += 256) rhs[i] = 0.0;
+  for (int r0 = 0; r0 < n; r0 += FW_SLAB) {
+    const int nr = (n - r0 < FW_SLAB) ? n - r0 : FW_SLAB;
+    for (int i = tid; i < nr * W; i += 256) slab[i] = 0.0;
+    __syncthreads();
+    for (int e = tid; e < p.Ne; e += 256) {
+      int eq[6], lo = 1 << 30, hi = -1;
+      for (int r = 0; r < 6; ++r) {
+        eq[r] = p.elem_eq[6 * e + r];
+        if (eq[r] >= 0) { lo = eq[r] < lo ? eq[r] : lo; hi = eq[r] > hi ? eq[r] : hi; }
+      }
+      if (hi < r0 || lo >= r0 + nr) continue;                              // no row of this element in the slab
+      const double L = p.elem_geo[3 * e], c = p.elem_geo[3 * e + 1], s = p.elem_geo[3 * e + 2];
+      double k[6][6];
+      elem_global_k(L, c, s, p.elem_EA[e], p.elem_E[e] * Ib[e], k);
+      const double wy = p.elem_w[2 * e], wx = p.elem_w[2 * e + 1];
+      const double pl[6] = {wx * L / 2, wy * L / 2, wy * L * L / 12, wx * L / 2, wy * L / 2, -wy * L * L / 12};
+      const double pg[6] = {c * pl[0] - s * pl[1], s * pl[0] + c * pl[1], pl[2], c * pl[3] - s * pl[4], s * pl[3] + c * pl[4], pl[5]};
+      for (int r = 0; r < 6; ++r) {
+        if (eq[r] < r0 || eq[r] >= r0 + nr) continue;                      // row eq[r] belongs to this slab
+        atomicAdd(&rhs[eq[r]], pg[r]);                                     // each equation's load once: with its own row
+        for (int q = 0; q < 6; ++q)
+          if (eq[q] >= 0 && eq[q] <= eq[r]) atomicAdd(&slab[(size_t)(eq[r] - r0) * W + (eq[q] % W)], k[r][q]);
+      }
+    }
+    __syncthreads();
+    for (int i = tid; i < nr * W; i += 256) rows[(size_t)r0 * W + i] = slab[i];
+    __syncthreads();
+  }
+  const double* lb = p.loads + b * p.loads_bs;
+  for (int i = tid; i < p.Nn * 3; i += 256) {
+    const int q = p.node_eq[i];
+    if (q >= 0) atomicAdd(&rhs[q], lb[i]);
+  }
+  __syncthreads();
+  for (int i = tid; i < n; i += 256) rhs_g[i] = rhs[i];
+}
+
+// ---- the solve: one wave per frame ----
+template <int W>
+struct FwState {
+  double reg[W];     // own row: A[R][C] at index C mod W
+  double y;          // own right-hand side (forward), own w / x (backward)
+};
+
+// one factorisation step; S = j mod W at compile time
+template <int W, int S>
+__device__ __forceinline__ void fw_step(FwState<W>& st, int j, int lane, int n, int kd, double* __restrict__ colbuf,
+                                        double* __restrict__ Lc, double* __restrict__ xs, int& bad) {
+  const int rel = (lane - j) & 63, R = j + rel;
+  const bool inwin = rel >= 1 && rel <= kd && R < n;
+  const double a = st.reg[S];
+  const double d = fw_readlane(a, j & 63);
+  const double rd = frcp(d);
+  bad |= !(d > 0.0);
+  const double l = inwin ? a * rd : 0.0;
+  double* cb = colbuf + (j & 1) * FW_CB;                    // double-buffered broadcast line
+  cb[rel + 1] = inwin ? a : 0.0;
+  const double zj = fw_readlane(st.y, j & 63);              // the pivot row's right-hand side is final
+  fw_fence();
+  if (inwin) Lc[(size_t)j * W + (rel - 1)] = l;             // column j of L: one coalesced store
+  if (rel == 0) xs[j] = zj * rd;                            // w_j = z_j / d_j
+  st.y = __builtin_fma(-l, zj, st.y);
+#pragma unroll
+  for (int t = 1; t < W; t += 2) {                          // reg[(S + t) mod W] -= l * A[j + t][j], two per 16-byte broadcast read
+    const double2 ac = *reinterpret_cast<const double2*>(cb + t + 1);
+    st.reg[(S + t) % W] = __builtin_fma(-l, ac.x, st.reg[(S + t) % W]);
+    if (t + 1 < W) st.reg[(S + t + 1) % W] = __builtin_fma(-l, ac.y, st.reg[(S + t + 1) % W]);
+  }
+}
+
+// move one staged group (rows g0 .. g0 + G - 1: parked in `stage`) into the registers of the lanes that own them
+template <int W>
+__device__ __forceinline__ void fw_take_group(FwState<W>& st, int g0, int lane, const double* __restrict__ stage) {
+  const int slot = (lane - g0) & 63;                        // row g0 + slot belongs to this lane when slot < G
+  if (slot < FW_G) {
+    const double* r = stage + (size_t)slot * (W + 1);
+#pragma unroll
+    for (int c = 0; c < W; ++c) st.reg[c] = r[c];
+    st.y = r[W];
+  }
+}
+
+template <int W>
+__device__ __forceinline__ void frame_wave_body(const FrameParams& p, double* __restrict__ wsf, double* __restrict__ lds, int lane, long b) {
+  constexpr int G = FW_G, K = (G * W + 63) / 64;
+  const int n = p.n_eq, kd = p.kd;
+  const int KG = (kd + G - 1) / G * G;                      // registers hold the rows below j + KG + G at step j
+  double* colbuf = lds;                                     // [2][FW_CB]
+  double* stage = lds + 2 * FW_CB;                          // [G][W + 1]: rows + right-hand sides of one group
+  double* xs = stage + (size_t)G * (W + 1);                 // [n + 64]: w, then x
+  double* rows = wsf;                                       // [fw_rows(n)][W], overwritten column by column with L
+  const double* rhs_g = wsf + (size_t)fw_rows(n) * W;
+  FwState<W> st;
+#pragma unroll
+  for (int c = 0; c < W; ++c) st.reg[c] = 0.0;
+  st.y = 0.0;
+  int bad = 0;
+
+  double tmp[K], tmpy;
+  auto fetch = [&](int g0) {                                // group g0: G x W contiguous doubles + G right-hand sides
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const int idx = lane + 64 * k;
+      tmp[k] = (idx < G * W) ? rows[(size_t)g0 * W + idx] : 0.0;
+    }
+    tmpy = (lane < G && g0 + lane < n) ? rhs_g[g0 + lane] : 0.0;
+  };
+  auto park = [&]() {                                       // fetched group -> LDS stage (row-major, pitch W + 1)
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const int idx = lane + 64 * k;
+      if (idx < G * W) stage[(idx / W) * (W + 1) + idx % W] = tmp[k];
+    }
+    if (lane < G) stage[lane * (W + 1) + W] = tmpy;
+  };
+  // prologue: rows [0, KG + G) into registers, the next group parked, the one after in flight
+  for (int g0 = 0; g0 < KG + G; g0 += G) {
+    fetch(g0);
+    park();
+    fw_fence();
+    fw_take_group<W>(st, g0, lane, stage);
+    fw_fence();
+  }
+  fetch(KG + G);
+  park();
+  fw_fence();
+  fetch(KG + 2 * G);
+
+  // ---- factorisation + forward substitution ----
+  for (int j0 = 0; j0 < n; j0 += W) {
+    auto boundary = [&](int j) {                            // j % G == 0, j > 0: rows [j + KG, j + KG + G) enter
+      fw_take_group<W>(st, j + KG, lane, stage);
+      fw_fence();
+      park();                                               // the group fetched one boundary ago
+      fw_fence();
+      fetch(j + KG + 2 * G);
+    };
+    // W-fold unrolled: the register index of column j is j mod W
+#define FW_STEP(S_)                                                                   \
+    if constexpr ((S_) < W) {                                                         \
+      const int j = j0 + (S_);                                                        \
+      if (j < n) {                                                                    \
+        if (j > 0 && (j % G) == 0) boundary(j);                                       \
+        fw_step<W, (S_)>(st, j, lane, n, kd, colbuf, rows, xs, bad);                  \
+      }                                                                               \
+    }
+#define FW_STEP8(S_) FW_STEP(S_) FW_STEP(S_ + 1) FW_STEP(S_ + 2) FW_STEP(S_ + 3) FW_STEP(S_ + 4) FW_STEP(S_ + 5) FW_STEP(S_ + 6) FW_STEP(S_ + 7)
+    FW_STEP8(0) FW_STEP8(8) FW_STEP8(16) FW_STEP8(24) FW_STEP8(32) FW_STEP8(40) FW_STEP8(48)
+#undef FW_STEP8
+#undef FW_STEP
+  }
+  fw_fence();
+
+  // ---- backward substitution, axpy form: lane (R mod 64) carries w_R while R is within kd of the current column ----
+  // x_j = w_j - sum_{R > j} L[R][j] x_R, processed as: x_j is final when step j starts; rows i = j - kd .. j - 1 then take
+  // w_i -= L[j][i] x_j.  Row i enters the window (picks up w_i from LDS) at step j = i + kd; the last kd rows start inside.
+  constexpr int PD = 8;                                     // L entries are fetched PD steps ahead
+  double wreg;
+  {
+    const int i = n - 1 - ((n - 1 - lane) & 63);            // the row of [n - 64, n - 1] that this lane owns
+    wreg = i >= 0 ? xs[i] : 0.0;
+  }
+  double lq[PD];
+  auto lfetch = [&](int j) -> double {                      // L[j][i] for this lane's row i = j - rel, rel in 1..kd
+    const int rel = (j - lane) & 63, i = j - rel;
+    return (j >= 0 && rel >= 1 && rel <= kd && i >= 0) ? rows[(size_t)i * W + (rel - 1)] : 0.0;
+  };
+#pragma unroll
+  for (int u = 0; u < PD; ++u) lq[u] = lfetch(n - 1 - u);
+  for (int jb = n - 1; jb >= 0; jb -= PD) {
+#pragma unroll
+    for (int u = 0; u < PD; ++u) {
+      const int j = jb - u;
+      if (j >= 0) {
+        const int rel = (j - lane) & 63, ent = j - kd;
+        const double went = xs[ent >= 0 ? ent : 0];         // broadcast read; used by the one lane whose row enters now
+        if (rel == kd && ent >= 0) wreg = went;
+        const double xj = fw_readlane(wreg, j & 63);
+        const double lv = lq[u];
+        lq[u] = lfetch(j - PD);
+        if (rel != 0) wreg = __builtin_fma(-lv, xj, wreg);  // lanes outside the window: lv = 0
+        if (rel == 0) xs[j] = xj;
+      }
+    }
+  }
+  fw_fence();
+  write_results(p, b, xs, bad != 0, lane, 64);
+}
+
+// waves per SIMD the register allocator is asked to make room for (the kernel is latency-bound per wave: rcp chain, LDS
+// round trip of the broadcast line): 2 W VGPRs of window + ~55
+constexpr int fw_waves(int W) { return W <= 36 ? 1 : W <= 52 ? 3 : 2; }   // measured: only the 52-wide window gains (170 -> 168 VGPRs: 3 waves)
+
+template <int W>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(fw_waves(W))))
+void frame_wave_kernel(const FrameParams p, double* __restrict__ ws) {
+  extern __shared__ double lds[];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const long b = (long)blockIdx.x * 4 + wave;
+  if (b >= p.B) return;
+  frame_wave_body<W>(p, ws + b * fw_frame_doubles(p.n_eq, p.kd), lds + (size_t)wave * fw_lds_doubles(p.n_eq, W), lane, b);
+}
+
+}  // namespace opsamd

@@ -72,7 +72,7 @@ def test_large_frames_band_in_hbm_workspace(bays, stories):
     from openpystruct_amd import _cabi, frames
     topo = frames.grid_frame(bays, stories)
     B = 3
-    assert int(_cabi.load().ops_frame_workspace_bytes(B, topo.n_eq, topo.kd)) == B * topo.lds_bytes() > 0   # one band + rhs per frame
+    assert int(_cabi.load().ops_frame_workspace_bytes(B, topo.n_eq, topo.kd)) >= B * topo.lds_bytes() > 0   # one band + rhs per frame
     rng = np.random.default_rng(bays)
     I = np.exp(rng.uniform(np.log(1e-4), np.log(5e-3), size=(B, topo.Ne)))
     sol = frames.frame_solve(topo, torch.as_tensor(I, device="cuda"))
