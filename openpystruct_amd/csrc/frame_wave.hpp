@@ -126,7 +126,9 @@ __device__ __forceinline__ void fw_step(FwState<W>& st, int j, int lane, int n, 
   cb[rel + 1] = inwin ? a : 0.0;
   const double zj = fw_readlane(st.y, j & 63);              // the pivot row's right-hand side is final
   fw_fence();
+#ifndef FW_SKIP_LSTORE                                     // (phase ablation builds, scripts/frame_phase_ab.sh)
   if (inwin) Lc[(size_t)j * W + (rel - 1)] = l;             // column j of L: one coalesced store
+#endif
   if (rel == 0) xs[j] = zj * rd;                            // w_j = z_j / d_j
   st.y = __builtin_fma(-l, zj, st.y);
 #pragma unroll
@@ -236,7 +238,11 @@ __device__ __forceinline__ void frame_wave_body(const FrameParams& p, double* __
   };
 #pragma unroll
   for (int u = 0; u < PD; ++u) lq[u] = lfetch(n - 1 - u);
+#ifdef FW_SKIP_BACKWARD
+  for (int jb = -1; jb >= 0; jb -= PD) {
+#else
   for (int jb = n - 1; jb >= 0; jb -= PD) {
+#endif
 #pragma unroll
     for (int u = 0; u < PD; ++u) {
       const int j = jb - u;
