@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define OPS_AMD_ABI_VERSION 1
+#define OPS_AMD_ABI_VERSION 2
 
 /* return codes of the launch functions (per-beam results are in `status`) */
 #define OPS_AMD_OK 0
@@ -136,12 +136,16 @@ int ops_beam_sizing_step_vm32_f32(int B, int Ne, float* I, double* I64, const fl
 void ops_sizing_schedule_f32(const ops_sizing_params* hp, float* schedule_host /* [max_epochs, 2] */);
 
 /* One WHOLE epoch of the reference's per-sample loop for B cases in one launch (SingleCore.py:176-219): the FE solve on
- * I64 followed, in the same wavefront and on the forces it still holds in LDS, by the optimiser step above -- shear and
- * moment never travel through HBM (the epoch moves ~48 instead of ~65 bytes per element).  Arguments as in
- * ops_beam_solve_batched_f64 (geometry, supports, loads; I64 rows are dense) and ops_beam_sizing_step_vm32_f32 (state). */
+ * the float32 inertias I (widened to double while they are staged: `I_tensor[i].item()`, :107) followed, in the same
+ * wavefront and on the forces it still holds in LDS, by the optimiser step above -- shear and moment never travel through
+ * HBM and no widened copy of I is kept (ABI 2; the epoch moves ~32 bytes per element: I 4+4, moments 8+8, loads 8).
+ *   I_last  [B,Ne] float32 out: written ONCE per case, in the call in which it stops (patience or max_epochs): the
+ *           inertias its last solve ran on.  The reference records shear / moment / displacements of that solve next to
+ *           the I of one Adam step later (:189-208 vs :239); a caller reproduces them with one solve on (double)I_last.
+ * Other arguments as in ops_beam_solve_batched_f64 (geometry, supports, loads) and ops_beam_sizing_step_vm32_f32 (state). */
 int ops_beam_sizing_epoch_f32(int B, int Ne, const double* x, long x_bstride, const double* E, long E_bstride,
                               const uint8_t* fix, long fix_bstride, const double* Fy, long Fy_bstride, const double* wy,
-                              long wy_bstride, float* I, double* I64, float* exp_avg, float* exp_avg_sq, float* best_loss,
+                              long wy_bstride, float* I, float* I_last, float* exp_avg, float* exp_avg_sq, float* best_loss,
                               int32_t* patience_cnt, int32_t* epochs_run, uint8_t* active, float* last_loss,
                               const ops_sizing_params* hp, const float* schedule, int32_t* status, int tiling, void* stream);
 

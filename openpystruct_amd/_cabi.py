@@ -9,6 +9,7 @@ import ctypes
 import os
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
+ABI_VERSION = 2      # include/openpystruct_amd.h OPS_AMD_ABI_VERSION
 # OPS_AMD_LIB lets A/B kernel experiments point at another build of the same C ABI
 LIB_PATH = os.environ.get("OPS_AMD_LIB") or os.path.join(_PKG, "lib", "libopenpystruct_amd.so")
 
@@ -121,5 +122,8 @@ def load():
     lib.ops_amd_last_error.restype = ctypes.c_char_p
     lib.ops_beam_solve_kernel_name.restype = ctypes.c_char_p
     lib.ops_beam_solve_kernel_name.argtypes = [it, it, it]
+    if lib.ops_amd_abi_version() != ABI_VERSION:     # a stale build of another ABI must not be driven with today's argument lists
+        raise ExtensionMissingError(f"{LIB_PATH} has C-ABI version {lib.ops_amd_abi_version()}, "
+                                    f"this package needs {ABI_VERSION}: rebuild with `python -m openpystruct_amd.build --force`")
     _lib = lib
     return lib

@@ -34,6 +34,7 @@ struct BeamParams {
   const double* wy; long wy_bs;
   double* v; double* theta; double* V; double* M;
   int32_t* status;
+  const float* I32;            // sizing epochs: the inertias are float32 rows (dense, stride Ne), widened while staging; I unused
   const uint8_t* active;       // optional [B]: a wave whose beams are all inactive returns at once (sizing epochs)
   int f32_forces;              // V / M point to float rows (the sizing loop rounds them to float32 anyway, SingleCore.py:189-190)
   // host-derived: rows of I/Fy/outputs are dense and every wave's chunk is 16-byte aligned, so
@@ -334,15 +335,27 @@ __device__ __forceinline__ void beam_body(const BeamParams& p, const SizingArgs*
   double2 rI[NPAIR], rF[NPAIR];
   double tailI = 0.0, tailF = 0.0;              // last element of an odd-length run
   if (DENSE) {
-    const __amdgpu_buffer_rsrc_t rsI = make_rsrc(p.I + beam0 * Ne, (unsigned)nE * 8u);
     const __amdgpu_buffer_rsrc_t rsF = make_rsrc(p.Fy + beam0 * N, (unsigned)nN * 8u);
+    if constexpr (SIZING) {                     // float32 inertias (the reference's I_tensor): 8-byte pairs, widened in registers
+      const __amdgpu_buffer_rsrc_t rsI = make_rsrc(p.I32 + beam0 * Ne, (unsigned)nE * 4u);
 #pragma unroll
-    for (int k = 0; k < NPAIR; ++k) {
-      const unsigned off = (lane + 64u * k) * 16u;
-      rI[k] = buf_load_d2(rsI, off);            // a pair that is not entirely inside the run comes back as 0
-      rF[k] = buf_load_d2(rsF, off);
+      for (int k = 0; k < NPAIR; ++k) {
+        const unsigned off = (lane + 64u * k) * 8u;
+        const float2 f = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rsI, (int)off, 0, 0));
+        rI[k] = make_double2((double)f.x, (double)f.y);
+        rF[k] = buf_load_d2(rsF, off * 2u);
+      }
+      tailI = (double)__builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsI, (int)((unsigned)(nE - 1) * 4u), 0, 0));
+    } else {
+      const __amdgpu_buffer_rsrc_t rsI = make_rsrc(p.I + beam0 * Ne, (unsigned)nE * 8u);
+#pragma unroll
+      for (int k = 0; k < NPAIR; ++k) {
+        const unsigned off = (lane + 64u * k) * 16u;
+        rI[k] = buf_load_d2(rsI, off);          // a pair that is not entirely inside the run comes back as 0
+        rF[k] = buf_load_d2(rsF, off);
+      }
+      tailI = buf_load_d(rsI, (unsigned)(nE - 1) * 8u);
     }
-    tailI = buf_load_d(rsI, (unsigned)(nE - 1) * 8u);
     tailF = buf_load_d(rsF, (unsigned)(nN - 1) * 8u);
   }
 #ifdef OPS_AMD_TRACE
@@ -407,10 +420,12 @@ __device__ __forceinline__ void beam_body(const BeamParams& p, const SizingArgs*
 #pragma unroll
     for (int b = 0; b < BPW; ++b) {
       if (b >= nb) break;
-      const double* Ib = p.I + (beam0 + b) * p.I_bs;
       const double* Fb = p.Fy + (beam0 + b) * p.Fy_bs;
       for (int e = lane; e < N; e += 64) {
-        if (e < Ne) s_a[b * PM + e] = Ib[e];
+        if (e < Ne) {
+          if constexpr (SIZING) s_a[b * PM + e] = (double)p.I32[(beam0 + b) * Ne + e];
+          else s_a[b * PM + e] = p.I[(beam0 + b) * p.I_bs + e];
+        }
         s_b[b * N + e] = Fb[e];
       }
     }
@@ -672,7 +687,7 @@ static int solve_impl(int B, int Ne, const double* x, long x_bstride, const doub
                       void* stream, const SizingArgs* sz = nullptr) {
   if (B < 0 || Ne < 1) return OPS_AMD_ERR_INVALID_ARG;
   if (B == 0) return OPS_AMD_OK;
-  if (!x || !E || !I || !fix || !Fy || !wy || ((!V || !M) && !sz) || ((v == nullptr) != (theta == nullptr))) return OPS_AMD_ERR_INVALID_ARG;
+  if (!x || !E || (!I && !sz) || !fix || !Fy || !wy || ((!V || !M) && !sz) || ((v == nullptr) != (theta == nullptr))) return OPS_AMD_ERR_INVALID_ARG;
   if (I_bstride < Ne || Fy_bstride < Ne + 1) return OPS_AMD_ERR_INVALID_ARG;
   if ((x_bstride != 0 && x_bstride < Ne + 1) || (fix_bstride != 0 && fix_bstride < Ne + 1) ||
       (E_bstride != 0 && E_bstride < Ne) || (wy_bstride != 0 && wy_bstride < Ne))
@@ -682,13 +697,14 @@ static int solve_impl(int B, int Ne, const double* x, long x_bstride, const doub
   if (!t) return tiling ? OPS_AMD_ERR_INVALID_ARG : OPS_AMD_ERR_UNSUPPORTED;
 
   BeamParams p{B, Ne, x, x_bstride, E, E_bstride, I, I_bstride, fix, fix_bstride, Fy, Fy_bstride,
-               wy, wy_bstride, v, theta, V, M, status, active, f32_forces, 0, nullptr, 0u, 0u};
+               wy, wy_bstride, v, theta, V, M, status, sz ? sz->I : nullptr, active, f32_forces, 0, nullptr, 0u, 0u};
 #ifdef OPS_AMD_TRACE
   { const char* e = getenv("OPS_AMD_TRACE_PTR"); if (e) p.trace = (unsigned long long*)strtoull(e, nullptr, 0); }
 #endif
   {
     const int bpw = 64 / t->P;
-    const uintptr_t bits = (uintptr_t)I | (uintptr_t)Fy | (uintptr_t)v | (uintptr_t)theta | (uintptr_t)V | (uintptr_t)M;
+    // 16-byte aligned rows (8-byte for the float32 inertias of the sizing epoch, which are read in 8-byte pairs)
+    const uintptr_t bits = (uintptr_t)I | (uintptr_t)Fy | (uintptr_t)v | (uintptr_t)theta | (uintptr_t)V | (uintptr_t)M | (sz ? 2 * (uintptr_t)sz->I : 0);
     p.dense = (I_bstride == Ne) && (Fy_bstride == Ne + 1) && ((bits & 15u) == 0) &&
               ((bpw * Ne) % 2 == 0) && ((bpw * (Ne + 1)) % 2 == 0);
     p.magic_ne = ((1u << 20) + (unsigned)Ne - 1u) / (unsigned)Ne;
@@ -739,17 +755,17 @@ int ops_beam_solve_forces_f64(int B, int Ne, const double* x, long x_bstride, co
 
 int ops_beam_sizing_epoch_f32(int B, int Ne, const double* x, long x_bstride, const double* E, long E_bstride,
                               const uint8_t* fix, long fix_bstride, const double* Fy, long Fy_bstride, const double* wy,
-                              long wy_bstride, float* I, double* I64, float* exp_avg, float* exp_avg_sq, float* best_loss,
+                              long wy_bstride, float* I, float* I_last, float* exp_avg, float* exp_avg_sq, float* best_loss,
                               int32_t* patience_cnt, int32_t* epochs_run, uint8_t* active, float* last_loss,
                               const ops_sizing_params* hp, const float* schedule, int32_t* status, int tiling, void* stream) {
   if (Ne > 128) return OPS_AMD_ERR_UNSUPPORTED;       // two elements per lane in the fused step
-  if (!I || !I64 || !exp_avg || !exp_avg_sq || !best_loss || !patience_cnt || !epochs_run || !active || !last_loss || !hp)
+  if (!I || !I_last || !exp_avg || !exp_avg_sq || !best_loss || !patience_cnt || !epochs_run || !active || !last_loss || !hp)
     return OPS_AMD_ERR_INVALID_ARG;
-  const SizingArgs sz{I, I64, exp_avg, exp_avg_sq, best_loss, patience_cnt, epochs_run, active, last_loss, nullptr, nullptr, *hp, schedule};
+  const SizingArgs sz{I, nullptr, I_last, exp_avg, exp_avg_sq, best_loss, patience_cnt, epochs_run, active, last_loss, nullptr, nullptr, *hp, schedule};
   // the fused kernel carries the cases' optimiser state in registers next to the solve: the 16-lane tiling (three waves
   // per SIMD) beats the 8-lane one at every batch size here (2e5 cases: 0.095 vs 0.104 s), unlike the plain solve
   if (tiling == 0 && Ne + 1 <= 16 * 7) tiling = 16;
-  return solve_impl(B, Ne, x, x_bstride, E, E_bstride, I64, Ne, fix, fix_bstride, Fy, Fy_bstride, wy, wy_bstride, nullptr, nullptr,
+  return solve_impl(B, Ne, x, x_bstride, E, E_bstride, nullptr, Ne, fix, fix_bstride, Fy, Fy_bstride, wy, wy_bstride, nullptr, nullptr,
                     nullptr, nullptr, status, active, 0, tiling, stream, &sz);
 }
 

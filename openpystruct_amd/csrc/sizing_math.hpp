@@ -10,7 +10,8 @@
 namespace opsamd {
 
 struct SizingArgs {
-  float* I; double* I64;
+  float* I; double* I64;            // I64 (optional): widened copy for a separate solve kernel, frozen when a case stops
+  float* I_last;                    // optional: the inertias a case's LAST solve used (written once, when it stops)
   float* exp_avg; float* exp_avg_sq;
   float* best_loss; int32_t* patience_cnt; int32_t* epochs_run; uint8_t* active; float* last_loss;
   float* V32; float* M32;            // optional records of the rounded forces (NULL: the caller rounds them later)
@@ -102,11 +103,18 @@ __device__ __forceinline__ void step_case(int lane, long b, int Ne, const Sizing
   int cnt = r.cnt;
   if (loss < best - (float)hp.tolerance) { best = loss; cnt = 0; } else { cnt += 1; }
   const bool stop = (cnt >= hp.patience) || (t + 1 >= hp.max_epochs);
-  if (!stop) {
+  if (a.I64 && !stop) {
 #pragma unroll
     for (int k = 0; k < K; ++k) {
       const int e = lane + 64 * k;
-      if (e < Ne) a.I64[b * Ne + e] = (double)Inew[k];   // what the next solve reads
+      if (e < Ne) a.I64[b * Ne + e] = (double)Inew[k];   // what the next (separate) solve reads
+    }
+  }
+  if (a.I_last && stop) {                                // the fused epoch keeps no widened copy: it records, once, the
+#pragma unroll                                           // float32 inertias this last solve ran on (one-step lag, :239)
+    for (int k = 0; k < K; ++k) {
+      const int e = lane + 64 * k;
+      if (e < Ne) a.I_last[b * Ne + e] = r.I[k];
     }
   }
   if (lane == 0) {

@@ -49,7 +49,7 @@ extern "C" int ops_beam_sizing_step_f32(int B, int Ne, float* I, double* I64, co
       !last_loss || ((V32 == nullptr) != (M32 == nullptr)) || !hp)
     return OPS_AMD_ERR_INVALID_ARG;
   const unsigned grid = (unsigned)((B + 3) / 4);
-  const opsamd::SizingArgs a{I, I64, exp_avg, exp_avg_sq, best_loss, patience_cnt, epochs_run, active, last_loss, V32, M32, *hp, nullptr};
+  const opsamd::SizingArgs a{I, I64, nullptr, exp_avg, exp_avg_sq, best_loss, patience_cnt, epochs_run, active, last_loss, V32, M32, *hp, nullptr};
   hipLaunchKernelGGL(opsamd::sizing_step_kernel<double>, dim3(grid), dim3(256), 0, (hipStream_t)stream, B, Ne, V, M, a);
   return hipGetLastError() == hipSuccess ? OPS_AMD_OK : OPS_AMD_ERR_LAUNCH;
 }
@@ -73,7 +73,7 @@ extern "C" int ops_beam_sizing_step_vm32_f32(int B, int Ne, float* I, double* I6
   if (!I || !I64 || !V32 || !M32 || !exp_avg || !exp_avg_sq || !best_loss || !patience_cnt || !epochs_run || !active || !last_loss || !hp)
     return OPS_AMD_ERR_INVALID_ARG;
   const unsigned grid = (unsigned)((B + 3) / 4);
-  const opsamd::SizingArgs a{I, I64, exp_avg, exp_avg_sq, best_loss, patience_cnt, epochs_run, active, last_loss, nullptr, nullptr, *hp, schedule};
+  const opsamd::SizingArgs a{I, I64, nullptr, exp_avg, exp_avg_sq, best_loss, patience_cnt, epochs_run, active, last_loss, nullptr, nullptr, *hp, schedule};
   hipLaunchKernelGGL(opsamd::sizing_step_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, B, Ne, V32, M32, a);
   return hipGetLastError() == hipSuccess ? OPS_AMD_OK : OPS_AMD_ERR_LAUNCH;
 }

@@ -270,7 +270,10 @@ class SizingState:
         self.E = torch.tensor(cfg.E, **f64)
         self.wy = torch.tensor(cfg.uniform_udl, **f64)
         self.I = torch.full((B, Ne), cfg.I_0, **f32)                    # I_tensor, :163
-        self.I64 = self.I.double()
+        # fused epochs keep no widened copy: the kernel records, once per case, the float32 inertias of its last solve
+        self._fused = _FUSED_EPOCH and Ne <= 128
+        self.I_last = torch.full((B, Ne), cfg.I_0, **f32) if self._fused else None
+        self.I64 = None if self._fused else self.I.double()      # separate solve + step launches: the solver's input
         self.exp_avg = torch.zeros((B, Ne), **f32)
         self.exp_avg_sq = torch.zeros((B, Ne), **f32)
         self.best_loss = torch.full((B,), float("inf"), **f32)          # :170
@@ -294,13 +297,13 @@ class SizingState:
         the reference reads only eleResponse: the solve writes forces only and skips wavefronts of finished cases."""
         lib = _cabi.load()
         N, Ne = self.N, self.Ne
-        if _FUSED_EPOCH and Ne <= 128:
+        if self._fused:
             # solve + optimiser step in ONE launch: the wavefront that solved a case steps it on the forces it still holds in LDS
             with torch.cuda.device(self.device):
                 rc = lib.ops_beam_sizing_epoch_f32(
                     self.B, Ne, self.x.data_ptr(), N if self.x.dim() == 2 else 0, self.E.data_ptr(), 0,
                     self.fix.data_ptr(), N if self.fix.dim() == 2 else 0, self.Fy.data_ptr(), N, self.wy.data_ptr(), 0,
-                    self.I.data_ptr(), self.I64.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(),
+                    self.I.data_ptr(), self.I_last.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(),
                     self.best_loss.data_ptr(), self.patience_cnt.data_ptr(), self.epochs_run.data_ptr(), self.active.data_ptr(),
                     self.last_loss.data_ptr(), ctypes.byref(self._hp), self._schedule.data_ptr(), self._status.data_ptr(), sizing_tiling(N),
                     torch.cuda.current_stream(self.device).cuda_stream)
@@ -325,9 +328,11 @@ class SizingState:
 
     def finalize(self) -> None:
         """What the reference reads after the loop (:224-232) and records (:239-249): the state of every case's LAST
-        solve.  `I64` froze when a case stopped, so one full solve reproduces it -- displacements included -- and the
+        solve.  `I64` (separate launches) froze when a case stopped / `I_last` (fused epochs) recorded its inertias, so one full solve reproduces it -- displacements included -- and the
         float32 roundings of shear / moment (:189-190) are taken from it."""
         # same tiling as the epochs, whatever the shard size: the records do not depend on how many GPUs share the cases
+        if self._fused:
+            self.I64 = self.I_last.double()
         self.sol = beam_solve(self.x, self.E, self.I64, self.fix, self.Fy, self.wy, tiling=sizing_tiling(self.N), out=self.sol)
         self.V32, self.M32 = self.sol.V.float(), self.sol.M.float()
 

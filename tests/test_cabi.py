@@ -27,7 +27,7 @@ def test_header_symbols_are_exported(lib):
 
 
 def test_introspection_calls(lib):
-    assert lib.ops_amd_abi_version() == 1
+    assert lib.ops_amd_abi_version() == 2      # 2: ops_beam_sizing_epoch_f32 takes I_last (float32) instead of I64
     assert lib.ops_amd_max_elements() >= 100
     assert b"beam_solve_kernel" in lib.ops_beam_solve_kernel_name(10000, 100, 0)
     assert lib.ops_beam_solve_kernel_name(10, 5000, 0) == b""
