@@ -7,6 +7,10 @@ TFD   (/root/reference/OpenPyStruct_TransformerDiffusionModule_MultiCase.py):
     PositionalEncoding :383-417, DiffusionSchedule :419-427, DiffusionModule :429-478,
     ModelOnePassTransformerWithDiffusion :480-575 (359 876 parameters), TrainableL1L2Loss :581-633.
 
+PINNED to the reference: tests/golden/surrogate_*.npz hold what the reference's own classes, losses and training loops
+computed (tests/golden/make_surrogate_golden.py executes the five scripts in the build container); tests/test_surrogate_golden.py
+compares every module here -- on the CPU and, with the fused HIP pieces on, on the MI355X -- with those numbers.
+
 Module and parameter names follow the reference so that its checkpoints (`best_model_fnn_residual.pth`,
 `best_model_onepass.pth`, PINN:794 / TFD:777) load with `load_state_dict`.  Quirks kept on purpose
 (SURVEY Appendix C): the loss's `alpha` is a Parameter that no optimiser ever sees; the diffusion

@@ -397,6 +397,10 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
     Xtr, Ytr, Xva, Yva = (t.to(device) for t in (data.X_train, data.Y_train, data.X_val, data.Y_val))
     nb_tr = max(1, (Xtr.shape[0] + cfg.batch_size - 1) // cfg.batch_size)
     if world > 1:   # every rank must run the same number of steps (collectives inside backward)
+        # a one-row tail batch makes train-mode BatchNorm raise (as in the reference's single process); on one rank of a
+        # data-parallel job that exception would leave the other ranks waiting in the step's all-reduce: drop such a tail
+        if Xtr.shape[0] % cfg.batch_size == 1 and nb_tr > 1 and any(isinstance(m, nn.modules.batchnorm._BatchNorm) for m in model.modules()):
+            nb_tr -= 1
         t = torch.tensor([nb_tr], device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
         nb_tr = int(t.item())

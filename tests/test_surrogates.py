@@ -166,6 +166,38 @@ def test_two_rank_training_stays_in_sync():
     np.testing.assert_allclose(m0, m1)                       # global scaler statistics on every rank
 
 
+def _ddp_train_worker_uneven(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=__import__("datetime").timedelta(seconds=180))
+    n = 311                                                # shards of 77 / 78 / 78 / 78 samples -> 12 / 13 / 13 / 13 groups -> 9 / 10 / 10 / 10 training groups
+    rec = _fake_records(n, seed=3)
+    lo, hi = sizing.shard_range(n, rank, world)
+    shard = {k: (v[lo:hi] if torch.is_tensor(v) else v[lo:hi]) for k, v in rec.items()}
+    d = dataprep.prepare(shard, kind="pinn", seed=2 + rank, distributed=True)
+    out = train.train_surrogate("pinn", d, train.PinnConfig(batch_size=4, patience=3), device="cpu", autocast_dtype=None, max_epochs=2)
+    w = torch.cat([p.detach().reshape(-1) for p in out["model"].parameters()])
+    bn = torch.cat([b.detach().double().reshape(-1) for b in out["model"].buffers() if b.is_floating_point()])
+    q.put((rank, out["epochs"], out["steps_per_epoch"], out["history"]["val"], float(w.double().sum()), float(bn.sum()),
+           int(d.X_train.shape[0]), float(d.min_constraint)))
+    dist.destroy_process_group()
+
+
+def test_four_rank_training_with_uneven_shards_stays_in_sync():
+    """world_size 4, shards that do not divide evenly (6 666 groups / (4 x 128) in the real run): every rank runs the same
+    number of steps (the minimum over ranks), stops at the same epoch, ends with the same weights and BatchNorm buffers."""
+    from tests.helpers import run_ranks
+    outs = sorted(run_ranks(_ddp_train_worker_uneven, 4, timeout=600))
+    sizes = [o[6] for o in outs]
+    assert len(set(sizes)) > 1                              # the shards really are uneven
+    assert len({o[1] for o in outs}) == 1 and len({o[2] for o in outs}) == 1
+    assert outs[0][2] == 2                                  # 9 groups / batch 4: the one-row tail is dropped (BatchNorm), 10 -> 3: min = 2
+    for o in outs[1:]:
+        assert o[3] == pytest.approx(outs[0][3])            # all-reduced validation losses
+        assert o[4] == pytest.approx(outs[0][4], rel=1e-6) and o[5] == pytest.approx(outs[0][5], rel=1e-6)
+        assert o[7] == pytest.approx(outs[0][7])            # box constraint: global minimum on every rank
+
+
 def test_stencil_batchnorm_path_equals_the_library_modules():
     """ResidualBlock's Conv1d(1,1,3)+BatchNorm1d(1) fast path == nn.Conv1d / nn.BatchNorm1d: outputs, gradients, buffers."""
     torch.manual_seed(0)
