@@ -244,6 +244,25 @@ const char* ops_amd_last_error(void);
  * and bench.py find the right row in a rocprofv3 kernel trace. */
 const char* ops_beam_solve_kernel_name(int B, int Ne, int tiling);
 
+/* Fused [x1 + x2 + x3] -> BatchNorm1d (train: batch statistics over the B rows, running statistics updated with the unbiased
+ * variance, num_batches_tracked += 1; eval: running statistics) -> optional LeakyReLU(slope) -> optional dropout(p), one
+ * launch per direction: the elementwise tails of the PINN's residual MLP (PINN_MultiCase.py:425-452, :519-541).
+ * Activations [B,F] float32 or bfloat16 (act_is_bf16); gamma == NULL switches the normalisation off (activation + dropout
+ * only).  x2 / x3 may be NULL.  Training saves z_save [B,F] (the summed input; may be NULL when x2 == x3 == NULL: x1 is it),
+ * mean_save / rstd_save [F] and the keep mask [B,F] bytes.  call_counter: two uint64 of device memory (zero-initialised)
+ * that the kernel advances itself, so that a replayed HIP graph draws fresh dropout masks.
+ * Backward: dz [B,F] = gradient w.r.t. every addend; dgamma / dbeta [F] are ASSIGNED (point them at the parameters'
+ * gradient slices: no accumulate kernels). */
+int ops_fused_bn_act_fwd(int B, int F, const void* x1, const void* x2, const void* x3, int act_is_bf16,
+                         const float* gamma, const float* beta, float eps, float momentum, int training,
+                         float* running_mean, float* running_var, long long* num_batches_tracked,
+                         float slope, int use_act, float p_drop, unsigned long long seed,
+                         unsigned long long* call_counter, void* y, void* z_save, float* mean_save,
+                         float* rstd_save, uint8_t* mask, void* stream);
+int ops_fused_bn_act_bwd(int B, int F, const void* dy, int act_is_bf16, const void* z, const float* mean, const float* rstd,
+                         const float* gamma, const float* beta, float slope, int use_act, float p_drop, const uint8_t* mask,
+                         void* dz, float* dgamma, float* dbeta, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -37,6 +37,8 @@ EXPORTS = (
     "ops_beam_solve_lane_workspace_bytes",
     "ops_amd_max_elements",
     "ops_amd_abi_version",
+    "ops_fused_bn_act_fwd",
+    "ops_fused_bn_act_bwd",
     "ops_amd_last_error",
     "ops_beam_solve_kernel_name",
 )
@@ -113,6 +115,11 @@ def load():
     lib.ops_surrogate_loss_grad_f32.restype = it
     lib.ops_surrogate_loss_grad_f32.argtypes = [it, it, it, it, vp, it, vp, vp, fl, vp, vp, fl, fl, vp, vp, vp, vp]
     lib.ops_surrogate_loss_workspace_bytes.restype = ctypes.c_size_t
+    ull = ctypes.c_ulonglong
+    lib.ops_fused_bn_act_fwd.restype = it
+    lib.ops_fused_bn_act_fwd.argtypes = [it, it, vp, vp, vp, it, vp, vp, fl, fl, it, vp, vp, vp, fl, it, fl, ull, vp, vp, vp, vp, vp, vp, vp]
+    lib.ops_fused_bn_act_bwd.restype = it
+    lib.ops_fused_bn_act_bwd.argtypes = [it, it, vp, it, vp, vp, vp, vp, vp, fl, it, fl, vp, vp, vp, vp, vp]
     lib.ops_beam_solve_lane_per_beam_f64.restype = it
     lib.ops_beam_solve_lane_per_beam_f64.argtypes = [it, it] + [vp] * 12 + [ctypes.c_size_t, vp]
     lib.ops_beam_solve_lane_workspace_bytes.restype = ctypes.c_size_t

@@ -118,6 +118,89 @@ def conv3_bn_single_channel(x: torch.Tensor, conv: nn.Conv1d, bn: nn.BatchNorm1d
     return torch.addcmul(bn.bias.reshape(()) - mean * scale, y, scale)
 
 
+# ------------------------------------------------------------------------------------------------
+# fused elementwise tails (csrc/fused_bn.hip): [x1 + x2 + x3] -> BatchNorm1d -> LeakyReLU -> dropout in ONE launch each way
+# (OPS_AMD_PINN_FUSED_TAILS=0: the framework's modules, the A/B switch).  107 -> ~60 kernel nodes per captured PINN step.
+# ------------------------------------------------------------------------------------------------
+_FUSED_TAILS = os.environ.get("OPS_AMD_PINN_FUSED_TAILS", "1") == "1"
+
+
+class _FusedTail(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x1, x2, x3, gamma, beta, bn, slope, use_act, p_drop, training, counter, seed, direct):
+        from . import _cabi
+        lib = _cabi.load()
+        dev = x1.device
+        dt = torch.bfloat16 if any(t is not None and t.dtype == torch.bfloat16 for t in (x1, x2, x3)) else torch.float32
+        xs = [None if t is None else (t if t.dtype == dt else t.to(dt)).contiguous() for t in (x1, x2, x3)]
+        B, F = xs[0].shape
+        y = torch.empty((B, F), dtype=dt, device=dev)
+        has_bn = gamma is not None
+        need_z = training and (xs[1] is not None or xs[2] is not None)
+        z = torch.empty((B, F), dtype=dt, device=dev) if need_z else None
+        mean = torch.empty(F, dtype=torch.float32, device=dev) if (has_bn and training) else None
+        rstd = torch.empty(F, dtype=torch.float32, device=dev) if (has_bn and training) else None
+        drop = training and p_drop > 0.0
+        mask = torch.empty((B, F), dtype=torch.uint8, device=dev) if drop else None
+        ptr = lambda t: t.data_ptr() if t is not None else None   # noqa: E731
+        track = has_bn and bn.track_running_stats
+        with torch.cuda.device(dev):
+            rc = lib.ops_fused_bn_act_fwd(
+                B, F, ptr(xs[0]), ptr(xs[1]), ptr(xs[2]), int(dt == torch.bfloat16), ptr(gamma), ptr(beta),
+                float(bn.eps) if has_bn else 0.0, float(bn.momentum) if has_bn and bn.momentum is not None else 0.1, int(training),
+                ptr(bn.running_mean) if track else None, ptr(bn.running_var) if track else None,
+                ptr(bn.num_batches_tracked) if (track and training) else None, float(slope), int(use_act), float(p_drop if drop else 0.0),
+                int(seed) & 0xFFFFFFFFFFFFFFFF, ptr(counter) if drop else None, y.data_ptr(), ptr(z), ptr(mean), ptr(rstd), ptr(mask),
+                torch.cuda.current_stream(dev).cuda_stream)
+        if rc != _cabi.OK:
+            raise RuntimeError(f"ops_fused_bn_act_fwd failed with code {rc}")
+        ctx.save_for_backward(z if need_z else xs[0], mean, rstd, gamma, beta, mask)
+        ctx.cfg = (float(slope), int(use_act), float(p_drop if drop else 0.0), dt, direct, [t is not None for t in (x1, x2, x3)],
+                   [None if t is None else t.dtype for t in (x1, x2, x3)])
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        from . import _cabi
+        lib = _cabi.load()
+        z, mean, rstd, gamma, beta, mask = ctx.saved_tensors
+        slope, use_act, p_drop, dt, direct, present, dtypes = ctx.cfg
+        dev = gy.device
+        gy = (gy if gy.dtype == dt else gy.to(dt)).contiguous()
+        B, F = gy.shape
+        dz = torch.empty_like(gy)
+        has_bn = gamma is not None
+        if has_bn:
+            if direct:       # the parameters' gradient slices of the caller's flat buffer: assigned by the kernel, no accumulate nodes
+                dg, db = gamma.grad, beta.grad
+            else:
+                dg, db = torch.empty_like(gamma), torch.empty_like(beta)
+        ptr = lambda t: t.data_ptr() if t is not None else None   # noqa: E731
+        with torch.cuda.device(dev):
+            rc = lib.ops_fused_bn_act_bwd(B, F, gy.data_ptr(), int(dt == torch.bfloat16), z.data_ptr(), ptr(mean), ptr(rstd), ptr(gamma),
+                                          ptr(beta), slope, use_act, p_drop, ptr(mask), dz.data_ptr(), ptr(dg) if has_bn else None,
+                                          ptr(db) if has_bn else None, torch.cuda.current_stream(dev).cuda_stream)
+        if rc != _cabi.OK:
+            raise RuntimeError(f"ops_fused_bn_act_bwd failed with code {rc}")
+        gx = [None if not pr else (dz if d == dt else dz.to(d)) for pr, d in zip(present, dtypes)]
+        return (gx[0], gx[1], gx[2], None if (not has_bn or direct) else dg, None if (not has_bn or direct) else db,
+                None, None, None, None, None, None, None, None)
+
+
+def fused_tail(x1, x2=None, x3=None, bn: nn.BatchNorm1d = None, act_slope=None, p_drop: float = 0.0, training: bool = True,
+               counter: torch.Tensor = None, seed: int = 0, direct_param_grads: bool = False) -> torch.Tensor:
+    """`dropout(leaky_relu(bn(x1 + x2 + x3)))` for 2-D GPU tensors through csrc/fused_bn.hip (any stage optional: bn None = no
+    normalisation, act_slope None = no activation, p_drop 0 = no dropout).  `counter`: int64[2] device tensor that the kernel
+    advances (fresh dropout masks under HIP-graph replay).  `direct_param_grads`: write d gamma / d beta straight into
+    `bn.weight.grad` / `bn.bias.grad` (they must exist and be zeroed by the caller every step: the training loop's flat buffer)."""
+    if bn is not None and (not bn.affine or bn.weight.dtype != torch.float32):
+        raise ValueError("fused_tail needs an affine float32 BatchNorm1d")
+    gamma, beta = (bn.weight, bn.bias) if bn is not None else (None, None)
+    direct = bool(direct_param_grads and bn is not None and bn.weight.grad is not None and bn.bias.grad is not None)
+    return _FusedTail.apply(x1, x2, x3, gamma, beta, bn, 0.0 if act_slope is None else float(act_slope), act_slope is not None,
+                            float(p_drop), bool(training), counter, seed, direct)
+
+
 class ResidualBlock(nn.Module):
     """x + fc2(dropout(leaky(fc1(x)))) + BN1(conv1(x)): a bottleneck MLP path and a width-3 Conv1d path
     over the feature axis, both added to the identity (PINN:425-452)."""
@@ -163,10 +246,34 @@ class FNNWithResidual(nn.Module):
             for _ in range(num_residual_blocks))
         self.output_fc = nn.Linear(hidden_dim, output_dim)
 
+    # the training loop sets this when every parameter gradient is a view of its flat buffer that it zeroes each step:
+    # the fused tails then write d gamma / d beta there themselves (no accumulate kernels)
+    direct_param_grads = False
+
+    def _fused_ok(self, x):
+        return (_FUSED_TAILS and x.is_cuda and x.dim() == 2 and self.norm_type == "batch" and type(self.input_norm) is nn.BatchNorm1d and
+                all(isinstance(b[0], ResidualBlock) and b[0].conv1.kernel_size == (3,) if b[0].use_conv else True for b in self.residual_blocks))
+
     def forward(self, x):
-        out = self.dropout(self.Leaky(self.input_norm(self.input_fc(x))))
-        for block in self.residual_blocks:
-            out = block(out)
+        if not self._fused_ok(x):
+            out = self.dropout(self.Leaky(self.input_norm(self.input_fc(x))))
+            for block in self.residual_blocks:
+                out = block(out)
+            return self.output_fc(out)
+        # GPU path: GEMMs through the framework (or the bf16 shadow linears), every elementwise tail one launch each way
+        if getattr(self, "_drop_counter", None) is None or self._drop_counter.device != x.device:
+            self._drop_counter = torch.zeros(2, dtype=torch.int64, device=x.device)
+            self._drop_seed = int(torch.initial_seed()) & 0x7FFFFFFFFFFFFFFF
+        tr, cnt, sd, dg = self.training, self._drop_counter, self._drop_seed, self.direct_param_grads
+        out = fused_tail(self.input_fc(x), None, None, self.input_norm, self.Leaky.negative_slope, self.dropout.p, tr, cnt, sd, dg)
+        for k, block in enumerate(self.residual_blocks):
+            rb, norm = block[0], block[1]
+            h = fused_tail(rb.fc1(out), None, None, None, rb.Leaky.negative_slope, rb.dropout.p, tr, cnt, sd + 2 * k + 1)
+            m = rb.fc2(h)
+            if rb.use_conv:
+                out = fused_tail(m, stencil_bn(out, rb.conv1, rb.bn1, tr), out, norm, None, 0.0, tr, cnt, sd, dg)
+            else:
+                out = fused_tail(m, out, None, norm, None, 0.0, tr, cnt, sd, dg)
         return self.output_fc(out)
 
 

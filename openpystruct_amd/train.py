@@ -379,6 +379,8 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
         q.grad = flat[off:off + q.numel()].view_as(q)
         off += q.numel()
     g_stash, g_dst, patched = [], [], []
+    if hasattr(model, "direct_param_grads"):   # fused tails (csrc/fused_bn.hip) write BatchNorm parameter gradients into `flat` themselves
+        model.direct_param_grads = device.type == "cuda"
     torch.manual_seed(seed + 1 + rank)  # different noise / shuffles per rank
     on_gpu = device.type == "cuda"
     if use_graph is None:
@@ -618,6 +620,8 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
         if no_improve >= cfg.patience:
             break
     disable_shadow_linears(patched)      # the returned model is a plain module again
+    if hasattr(model, "direct_param_grads"):
+        model.direct_param_grads = False
     if best_state is not None:
         model.load_state_dict(best_state)
     model.eval()

@@ -163,3 +163,64 @@ def test_shadow_linear_path_trains_like_nn_linear_under_autocast(monkeypatch):
         assert a == pytest.approx(b, rel=3e-2)
     for a, b in zip(hist[True]["val"], hist[False]["val"]):
         assert a == pytest.approx(b, rel=3e-2)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("n_add,act", [(1, True), (3, False), (2, True)])
+def test_fused_tail_matches_the_framework_modules(dtype, n_add, act):
+    """csrc/fused_bn.hip ([x1 + x2 + x3] -> BatchNorm1d -> LeakyReLU, dropout 0) against nn.BatchNorm1d + leaky_relu: outputs,
+    input gradients, parameter gradients, running statistics (PINN_MultiCase.py:425-452, :519-541 tails)."""
+    from openpystruct_amd import surrogates as S
+    torch.manual_seed(0)
+    B, F = 128, 350
+    bn, ref = torch.nn.BatchNorm1d(F).cuda(), torch.nn.BatchNorm1d(F).cuda()
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5); bn.bias.uniform_(-0.3, 0.3)
+    ref.load_state_dict(bn.state_dict())
+    xs = [torch.randn(B, F, device="cuda").mul_(1.0 + k).add_(0.3 * k).to(dtype).requires_grad_(True) for k in range(n_add)]
+    xr = [x.detach().clone().float().requires_grad_(True) for x in xs]
+    y = S.fused_tail(*xs, *([None] * (3 - n_add)), bn=bn, act_slope=0.01 if act else None, p_drop=0.0, training=True,
+                     counter=torch.zeros(2, dtype=torch.int64, device="cuda"))
+    zr = sum(xr)
+    yr = ref(zr)
+    if act:
+        yr = torch.nn.functional.leaky_relu(yr, 0.01)
+    tol = 1e-5 if dtype == torch.float32 else 2e-2
+    assert y.dtype == dtype and float((y.float() - yr).abs().max() / yr.abs().max()) < tol
+    g = torch.randn(B, F, device="cuda")
+    y.backward(g.to(dtype)); yr.backward(g)
+    for a, b in zip(xs, xr):
+        assert float((a.grad.float() - b.grad).abs().max() / b.grad.abs().max()) < (2e-5 if dtype == torch.float32 else 3e-2)
+    assert float((bn.weight.grad - ref.weight.grad).abs().max() / ref.weight.grad.abs().max()) < (2e-5 if dtype == torch.float32 else 3e-2)
+    assert float((bn.bias.grad - ref.bias.grad).abs().max() / ref.bias.grad.abs().max()) < (2e-5 if dtype == torch.float32 else 3e-2)
+    assert torch.allclose(bn.running_mean, ref.running_mean, atol=1e-3 if dtype == torch.bfloat16 else 1e-6)
+    assert torch.allclose(bn.running_var, ref.running_var, rtol=2e-2 if dtype == torch.bfloat16 else 1e-5)
+    assert int(bn.num_batches_tracked) == int(ref.num_batches_tracked) == 1
+    # eval mode: running statistics, no dropout
+    bn.eval(); ref.eval()
+    ye = S.fused_tail(xs[0].detach(), None, None, bn=bn, act_slope=None, p_drop=0.5, training=False)
+    assert float((ye.float() - ref(xr[0].detach())).abs().max()) < (1e-5 if dtype == torch.float32 else 5e-2)
+
+
+def test_fused_tail_dropout_is_bernoulli_and_redrawn_on_graph_replay():
+    from openpystruct_amd import surrogates as S
+    B, F, p = 128, 350, 0.5
+    x = torch.ones(B, F, device="cuda", requires_grad=True)
+    cnt = torch.zeros(2, dtype=torch.int64, device="cuda")
+    y = S.fused_tail(x, None, None, bn=None, act_slope=0.01, p_drop=p, training=True, counter=cnt, seed=7)
+    keep = (y != 0).float().mean().item()
+    assert abs(keep - (1 - p)) < 0.02 and torch.allclose(y[y != 0], torch.full_like(y[y != 0], 1 / (1 - p)))
+    y.sum().backward()
+    assert torch.equal((x.grad != 0), (y != 0)) and int(cnt[0]) == 1 and int(cnt[1]) == 0
+    # a captured launch draws a new mask on every replay (the counter lives in device memory)
+    xs = torch.ones(B, F, device="cuda")
+    side = torch.cuda.Stream(); side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        S.fused_tail(xs, None, None, bn=None, act_slope=None, p_drop=p, training=True, counter=cnt, seed=7)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            out = S.fused_tail(xs, None, None, bn=None, act_slope=None, p_drop=p, training=True, counter=cnt, seed=7)
+    torch.cuda.current_stream().wait_stream(side)
+    g.replay(); torch.cuda.synchronize(); a = out.clone()
+    g.replay(); torch.cuda.synchronize(); b = out.clone()
+    assert not torch.equal(a, b) and abs((b != 0).float().mean().item() - 0.5) < 0.02
