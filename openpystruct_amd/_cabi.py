@@ -37,6 +37,7 @@ EXPORTS = (
     "ops_beam_solve_lane_workspace_bytes",
     "ops_amd_max_elements",
     "ops_amd_abi_version",
+    "ops_gather_rows_noise_f32",
     "ops_fused_bn_act_fwd",
     "ops_fused_bn_act_bwd",
     "ops_amd_last_error",
@@ -118,6 +119,8 @@ def load():
     ull = ctypes.c_ulonglong
     lib.ops_fused_bn_act_fwd.restype = it
     lib.ops_fused_bn_act_fwd.argtypes = [it, it, vp, vp, vp, it, vp, vp, fl, fl, it, vp, vp, vp, fl, it, fl, ull, vp, vp, vp, vp, vp, vp, vp]
+    lib.ops_gather_rows_noise_f32.restype = it
+    lib.ops_gather_rows_noise_f32.argtypes = [it, lg, vp, vp, vp, ull, vp, vp, it, vp]
     lib.ops_fused_bn_act_bwd.restype = it
     lib.ops_fused_bn_act_bwd.argtypes = [it, it, vp, it, vp, vp, vp, vp, vp, fl, it, fl, vp, vp, vp, vp, vp]
     lib.ops_beam_solve_lane_per_beam_f64.restype = it

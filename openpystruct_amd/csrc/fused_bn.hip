@@ -12,10 +12,10 @@
 // two gradient accumulations).  Here: one node each way; the parameter gradients go straight into the caller's flat
 // gradient buffer (no accumulate kernels), the three addends share one gradient tensor.
 //
-// The tensors are tiny (128 x 350): one workgroup owns 32 columns and all rows -- column statistics never leave the
-// workgroup (no atomics, no workspace) -- with the data read from L2 three times (mean, centred variance, apply) instead
-// of being held in registers, so that any batch size works.  Activations are float32 or bfloat16 (the autocast dtype),
-// statistics and parameters float32.
+// The tensors are tiny (128 x 350): one workgroup owns 16 columns and all rows -- column statistics never leave the
+// workgroup (no atomics, no workspace).  Up to 128 rows every thread keeps its 8 rows in registers (all loads issued
+// before the first use: one pass over memory, one exposed latency); larger batches re-read the data from L2 per pass.
+// Activations are float32 or bfloat16 (the autocast dtype), statistics and parameters float32.
 //
 // Dropout: keep-mask from a counter-based hash of (seed, call counter, element index); the call counter lives in device
 // memory and is advanced by the kernel itself, so a replayed HIP graph draws fresh masks.  The mask (1 byte per element)
@@ -28,8 +28,9 @@
 
 namespace opsamd {
 
-constexpr int FB_CW = 32;        // columns per workgroup
-constexpr int FB_RG = 8;         // row groups per workgroup (256 threads)
+constexpr int FB_CW = 16;        // columns per workgroup
+constexpr int FB_RG = 16;        // row groups per workgroup (256 threads)
+constexpr int FB_RPT = 8;        // rows a thread keeps in registers: batches up to FB_RG * FB_RPT = 128 rows take ONE pass over memory
 
 __device__ __forceinline__ float fb_ld(const void* p, long i, int bf16) {
   return bf16 ? __uint_as_float((uint32_t)((const uint16_t*)p)[i] << 16) : ((const float*)p)[i];
@@ -81,27 +82,58 @@ struct FbArgs {
 };
 
 __global__ __launch_bounds__(256) void fused_bn_fwd_kernel(const FbArgs a) {
-  __shared__ float s_red[FB_RG * FB_CW];
+  __shared__ float s_red[FB_RG * FB_CW], s_red2[FB_RG * FB_CW], s_red3[FB_RG * FB_CW];
   const int col = threadIdx.x & (FB_CW - 1), rg = threadIdx.x / FB_CW;
   const int c = blockIdx.x * FB_CW + col;
   const bool live = c < a.F;
   const int B = a.B, F = a.F, bf = a.act_bf16;
-  auto zin = [&](int r) -> float {
+  auto zload = [&](int r) -> float {
     const long i = (long)r * F + c;
     float z = fb_ld(a.x1, i, bf);
     if (a.x2) z += fb_ld(a.x2, i, bf);
     if (a.x3) z += fb_ld(a.x3, i, bf);
     return z;
   };
+  // rows of this thread: rg, rg + FB_RG, ...; the first FB_RPT of them live in registers
+  const bool cached = B <= FB_RG * FB_RPT;             // workgroup-uniform
+  float zr[FB_RPT];
+#pragma unroll
+  for (int k = 0; k < FB_RPT; ++k) {
+    const int r = rg + k * FB_RG;
+    zr[k] = (live && cached && r < B) ? zload(r) : 0.0f;
+  }
+  auto zin = [&](int k, int r) -> float { return cached ? zr[k] : zload(r); };
   float mean = 0.0f, rstd = 1.0f, g = 1.0f, be = 0.0f;
   if (a.gamma) {
     if (a.training) {
-      float s = 0.0f;
-      if (live) for (int r = rg; r < B; r += FB_RG) s += zin(r);
-      mean = fb_colsum(s, s_red, col, rg) / (float)B;
-      float q = 0.0f;
-      if (live) for (int r = rg; r < B; r += FB_RG) { const float d = zin(r) - mean; q += d * d; }
-      const float var = fb_colsum(q, s_red, col, rg) / (float)B;          // biased: what normalises
+      // per-thread (count, mean, M2) of its rows, then ONE workgroup exchange and Chan's pairwise combination: a single
+      // barrier pair instead of separate mean and centred-variance reductions, and no E[z^2] - mean^2 cancellation
+      float cnt = 0.0f, mu = 0.0f, m2 = 0.0f;
+      auto push = [&](float z) { cnt += 1.0f; const float d = z - mu; mu += d / cnt; m2 += d * (z - mu); };
+      if (live) {
+        if (cached) {
+#pragma unroll
+          for (int k = 0; k < FB_RPT; ++k) if (rg + k * FB_RG < B) push(zr[k]);
+        } else {
+          for (int r = rg; r < B; r += FB_RG) push(zload(r));
+        }
+      }
+      __syncthreads();
+      s_red[rg * FB_CW + col] = cnt; s_red2[rg * FB_CW + col] = mu; s_red3[rg * FB_CW + col] = m2;
+      __syncthreads();
+      float N = 0.0f, M = 0.0f, Q = 0.0f;
+#pragma unroll
+      for (int gq = 0; gq < FB_RG; ++gq) {
+        const float nb = s_red[gq * FB_CW + col], mb = s_red2[gq * FB_CW + col], qb = s_red3[gq * FB_CW + col];
+        if (nb > 0.0f) {
+          const float nt = N + nb, d = mb - M;
+          Q += qb + d * d * (N * nb / nt);
+          M += d * (nb / nt);
+          N = nt;
+        }
+      }
+      mean = M;
+      const float var = Q / (float)B;                                     // biased: what normalises
       rstd = rsqrtf(var + a.eps);
       if (live && rg == 0) {
         a.mean_save[c] = mean; a.rstd_save[c] = rstd;
@@ -122,9 +154,9 @@ __global__ __launch_bounds__(256) void fused_bn_fwd_kernel(const FbArgs a) {
   const unsigned long long call = drop ? *a.call_counter : 0ull;
   const float keep_scale = drop ? 1.0f / (1.0f - a.p_drop) : 1.0f;
   if (live) {
-    for (int r = rg; r < B; r += FB_RG) {
+    auto emit = [&](int k, int r) {
       const long i = (long)r * F + c;
-      const float z = zin(r);
+      const float z = zin(k, r);
       if (a.z_save) fb_st(a.z_save, i, bf, z);
       float y = a.gamma ? __builtin_fmaf((z - mean) * rstd, g, be) : z;
       if (a.use_act) y = y > 0.0f ? y : y * a.slope;
@@ -134,16 +166,17 @@ __global__ __launch_bounds__(256) void fused_bn_fwd_kernel(const FbArgs a) {
         y = keep ? y * keep_scale : 0.0f;
       }
       fb_st(a.y, i, bf, y);
+    };
+    if (cached) {
+#pragma unroll
+      for (int k = 0; k < FB_RPT; ++k) { const int r = rg + k * FB_RG; if (r < B) emit(k, r); }
+    } else {
+      for (int r = rg; r < B; r += FB_RG) emit(0, r);
     }
   }
-  if (drop) {             // advance the call counter once per launch, after every workgroup has read it: the LAST workgroup does it
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      __threadfence();
-      const unsigned done = atomicAdd((unsigned*)(a.call_counter + 1), 1u) + 1u;
-      if (done == gridDim.x) { a.call_counter[1] = 0ull; atomicAdd(a.call_counter, 1ull); }
-    }
-  }
+  // one increment per launch; a workgroup that happens to read the counter after it draws from the next stream, which is as
+  // good a mask (the backward pass uses the STORED mask); streams of different call sites differ by their seeds
+  if (drop && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(a.call_counter, 1ull);
 }
 
 struct FbBwdArgs {
@@ -159,7 +192,7 @@ struct FbBwdArgs {
 };
 
 __global__ __launch_bounds__(256) void fused_bn_bwd_kernel(const FbBwdArgs a) {
-  __shared__ float s_red[FB_RG * FB_CW];
+  __shared__ float s_red[FB_RG * FB_CW], s_red2[FB_RG * FB_CW];
   const int col = threadIdx.x & (FB_CW - 1), rg = threadIdx.x / FB_CW;
   const int c = blockIdx.x * FB_CW + col;
   const bool live = c < a.F;
@@ -180,21 +213,55 @@ __global__ __launch_bounds__(256) void fused_bn_bwd_kernel(const FbBwdArgs a) {
     }
     return gy;
   };
+  const bool cached = B <= FB_RG * FB_RPT;             // workgroup-uniform: one pass over memory
+  float gr[FB_RPT], xr[FB_RPT];
+#pragma unroll
+  for (int k = 0; k < FB_RPT; ++k) {
+    const int r = rg + k * FB_RG;
+    gr[k] = 0.0f; xr[k] = 0.0f;
+    if (live && cached && r < B) gr[k] = gout(r, xr[k]);
+  }
   if (!a.gamma) {                                   // activation + dropout only
-    if (live) for (int r = rg; r < B; r += FB_RG) { float xh; fb_st(a.dz, (long)r * F + c, bf, gout(r, xh)); }
+    if (live) {
+      if (cached) {
+#pragma unroll
+        for (int k = 0; k < FB_RPT; ++k) { const int r = rg + k * FB_RG; if (r < B) fb_st(a.dz, (long)r * F + c, bf, gr[k]); }
+      } else {
+        for (int r = rg; r < B; r += FB_RG) { float xh; fb_st(a.dz, (long)r * F + c, bf, gout(r, xh)); }
+      }
+    }
     return;
   }
   float sg = 0.0f, sgx = 0.0f;
-  if (live) for (int r = rg; r < B; r += FB_RG) { float xh; const float gy = gout(r, xh); sg += gy; sgx += gy * xh; }
-  sg = fb_colsum(sg, s_red, col, rg);
-  sgx = fb_colsum(sgx, s_red, col, rg);
+  if (live) {
+    if (cached) {
+#pragma unroll
+      for (int k = 0; k < FB_RPT; ++k) { sg += gr[k]; sgx += gr[k] * xr[k]; }
+    } else {
+      for (int r = rg; r < B; r += FB_RG) { float xh; const float gy = gout(r, xh); sg += gy; sgx += gy * xh; }
+    }
+  }
+  __syncthreads();
+  s_red[rg * FB_CW + col] = sg; s_red2[rg * FB_CW + col] = sgx;
+  __syncthreads();
+  sg = 0.0f; sgx = 0.0f;
+#pragma unroll
+  for (int gq = 0; gq < FB_RG; ++gq) { sg += s_red[gq * FB_CW + col]; sgx += s_red2[gq * FB_CW + col]; }
   if (live) {
     if (rg == 0) { a.dgamma[c] = sgx; a.dbeta[c] = sg; }
-    const float inv = 1.0f / (float)B, k = g * rstd;
-    for (int r = rg; r < B; r += FB_RG) {
-      float xh;
-      const float gy = gout(r, xh);
-      fb_st(a.dz, (long)r * F + c, bf, k * (gy - sg * inv - xh * sgx * inv));
+    const float inv = 1.0f / (float)B, k2 = g * rstd;
+    if (cached) {
+#pragma unroll
+      for (int k = 0; k < FB_RPT; ++k) {
+        const int r = rg + k * FB_RG;
+        if (r < B) fb_st(a.dz, (long)r * F + c, bf, k2 * (gr[k] - sg * inv - xr[k] * sgx * inv));
+      }
+    } else {
+      for (int r = rg; r < B; r += FB_RG) {
+        float xh;
+        const float gy = gout(r, xh);
+        fb_st(a.dz, (long)r * F + c, bf, k2 * (gy - sg * inv - xh * sgx * inv));
+      }
     }
   }
 }

@@ -39,7 +39,8 @@ class _StencilBN(torch.autograd.Function):
     """csrc/stencil_bn.hip behind autograd: two launches forward, three backward (GPU tensors only)."""
 
     @staticmethod
-    def forward(ctx, x, cw, cb, gamma, beta, bn, training, out_bf16):
+    def forward(ctx, x, cw, cb, gamma, beta, bn, training, out_bf16, direct_targets=None):
+        ctx.direct_targets = direct_targets
         from . import _cabi
         lib = _cabi.load()
         x = x.contiguous()
@@ -70,18 +71,30 @@ class _StencilBN(torch.autograd.Function):
         if g.dtype not in (torch.float32, torch.bfloat16):
             g = g.float()
         dx = torch.empty_like(x)
-        dp = torch.empty(6, dtype=torch.float32, device=x.device)
+        # direct mode (training loop): conv weight(3), conv bias, bn weight, bn bias are six CONSECUTIVE floats of the flat gradient
+        # buffer (registration order); the parameter kernel writes them there itself -- no four accumulate kernels per block
+        tg = ctx.direct_targets
+        direct = (tg is not None and all(t.grad is not None for t in tg) and tg[1].grad.data_ptr() == tg[0].grad.data_ptr() + 12
+                  and tg[2].grad.data_ptr() == tg[0].grad.data_ptr() + 16 and tg[3].grad.data_ptr() == tg[0].grad.data_ptr() + 20)
+        dp = None
+        if direct:
+            dp_ptr = tg[0].grad.data_ptr()
+        else:
+            dp = torch.empty(6, dtype=torch.float32, device=x.device)
+            dp_ptr = dp.data_ptr()
         with torch.cuda.device(x.device):
             rc = lib.ops_stencil3_bn1_bwd_f32(x.shape[0], x.shape[1], x.data_ptr(), g.data_ptr(), int(g.dtype == torch.bfloat16),
                                               cw3.data_ptr(), cb.data_ptr(),
-                                              gamma.data_ptr(), save.data_ptr(), int(ctx.training), dx.data_ptr(), dp.data_ptr(),
+                                              gamma.data_ptr(), save.data_ptr(), int(ctx.training), dx.data_ptr(), dp_ptr,
                                               ws.data_ptr(), torch.cuda.current_stream(x.device).cuda_stream)
         if rc != _cabi.OK:
             raise RuntimeError(f"ops_stencil3_bn1_bwd_f32 failed with code {rc}")
-        return dx, dp[0:3].reshape(ctx.cw_shape), dp[3:4], dp[4:5], dp[5:6], None, None, None
+        if direct:
+            return dx, None, None, None, None, None, None, None, None
+        return dx, dp[0:3].reshape(ctx.cw_shape), dp[3:4], dp[4:5], dp[5:6], None, None, None, None
 
 
-def stencil_bn(x: torch.Tensor, conv: nn.Conv1d, bn: nn.BatchNorm1d, training: bool) -> torch.Tensor:
+def stencil_bn(x: torch.Tensor, conv: nn.Conv1d, bn: nn.BatchNorm1d, training: bool, direct_param_grads: bool = False) -> torch.Tensor:
     """`bn(conv(x.unsqueeze(1))).squeeze(1)` for Conv1d(1,1,3,padding=1) + BatchNorm1d(1): the fused HIP kernel on the GPU,
     the tensor-op restatement below elsewhere (CPU tests) -- both with the modules' parameters and buffers."""
     fused = (x.is_cuda and x.dim() == 2 and x.numel() <= (1 << 26) and bn.momentum is not None and bn.track_running_stats
@@ -91,7 +104,8 @@ def stencil_bn(x: torch.Tensor, conv: nn.Conv1d, bn: nn.BatchNorm1d, training: b
     # under autocast the library pair hands back the autocast dtype (Conv1d runs in it, BatchNorm keeps it): do the same, so
     # that everything downstream runs exactly the kernels it runs with the modules; bfloat16 is written by the kernel itself
     ac = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else None
-    z = _StencilBN.apply(x.float(), conv.weight, conv.bias, bn.weight, bn.bias, bn, training, ac == torch.bfloat16)
+    tg = (conv.weight, conv.bias, bn.weight, bn.bias) if direct_param_grads else None
+    z = _StencilBN.apply(x.float(), conv.weight, conv.bias, bn.weight, bn.bias, bn, training, ac == torch.bfloat16, tg)
     return z.to(ac) if ac is not None and z.dtype != ac else z
 
 
@@ -271,7 +285,7 @@ class FNNWithResidual(nn.Module):
             h = fused_tail(rb.fc1(out), None, None, None, rb.Leaky.negative_slope, rb.dropout.p, tr, cnt, sd + 2 * k + 1)
             m = rb.fc2(h)
             if rb.use_conv:
-                out = fused_tail(m, stencil_bn(out, rb.conv1, rb.bn1, tr), out, norm, None, 0.0, tr, cnt, sd, dg)
+                out = fused_tail(m, stencil_bn(out, rb.conv1, rb.bn1, tr, dg), out, norm, None, 0.0, tr, cnt, sd, dg)
             else:
                 out = fused_tail(m, out, None, norm, None, 0.0, tr, cnt, sd, dg)
         return self.output_fc(out)

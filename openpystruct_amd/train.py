@@ -444,9 +444,10 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
             v_p, t_p = pin[1], pin[2]
         return fe_residual_loss(I_p, v_p, t_p, px, pE, pfix, pin[0], pwy)
 
-    def fwd_bwd(Xb, Yb, noise_t, pin=None):
-        """Segment A: local gradients of the mean batch loss into `flat`."""
-        Xn = Xb + torch.randn_like(Xb) * noise_t                         # PINN:756
+    def fwd_bwd(Xb, Yb, noise_t, pin=None, prenoised=False):
+        """Segment A: local gradients of the mean batch loss into `flat`.  `prenoised`: Xb already is the gathered, noisy
+        (and, under autocast, bfloat16) batch written by `gather_noise` -- one launch outside the graph instead of six nodes."""
+        Xn = Xb if prenoised else Xb + torch.randn_like(Xb) * noise_t   # PINN:756
         flat.zero_()                                                     # optimizer.zero_grad()
         with torch.autocast(device_type=device.type, dtype=autocast_dtype, enabled=use_ac):
             preds = net(Xn)
@@ -487,12 +488,30 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
                 return fused_loss(crit, preds, Yb)
             return crit(preds.float(), Yb)
 
+    # batch assembly in one launch (csrc/input_prep.hip): gather + noise + cast straight into the graph's input buffer
+    _FUSED_PREP = on_gpu and os.environ.get("OPS_AMD_FUSED_PREP", "1") == "1"
+    prep_counter = torch.zeros(1, dtype=torch.int64, device=device) if on_gpu else None
+    # bf16 batches only where the first module is a (shadow) Linear, which casts its operand to bf16 anyway
+    prep_bf16 = bool(on_gpu and use_ac and autocast_dtype == torch.bfloat16 and patched and kind in ("pinn", "fnn", "gnn"))
+
+    def gather_noise(idx, out):
+        lib = opt._lib
+        Fdim = 1
+        for d_ in Xtr.shape[1:]:
+            Fdim *= int(d_)
+        with torch.cuda.device(device):
+            rc = lib.ops_gather_rows_noise_f32(int(idx.numel()), Fdim, Xtr.data_ptr(), idx.data_ptr(), s_noise.data_ptr(),
+                                               (seed * 7919 + 13 + rank) & 0x7FFFFFFFFFFFFFFF, prep_counter.data_ptr(), out.data_ptr(),
+                                               int(out.dtype == torch.bfloat16), torch.cuda.current_stream(device).cuda_stream)
+        if rc != 0:
+            raise RuntimeError(f"ops_gather_rows_noise_f32 failed with code {rc}")
+
     graph = graph_b = vgraph = None
     bs = cfg.batch_size
     if use_graph and Xtr.shape[0] >= bs:
         # static buffers + a few eager warm-up steps on a side stream, then capture one full-batch step:
         # world == 1 -> one graph; world > 1 -> [fwd_bwd] graph, eager all-reduce, [apply_update] graph
-        sX, sY = torch.zeros_like(Xtr[:bs]), torch.zeros_like(Ytr[:bs])
+        sX, sY = torch.zeros_like(Xtr[:bs], dtype=torch.bfloat16 if (_FUSED_PREP and prep_bf16) else Xtr.dtype), torch.zeros_like(Ytr[:bs])
         s_noise = torch.zeros((), device=device)
         sP = None
         if physics is not None:                  # static per-batch physics inputs, gathered before every replay
@@ -505,13 +524,13 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
             if sP is not None:
                 physics_inputs(torch.arange(bs, device=device), out=sP)
             for _ in range(3):
-                fwd_bwd(sX, sY, s_noise, sP)
+                fwd_bwd(sX, sY, s_noise, sP, prenoised=_FUSED_PREP)
                 apply_update()                   # warm-up only: no collective needed for capture-readiness
             side.synchronize()
             try:
                 graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(graph, stream=side, capture_error_mode="thread_local"):
-                    s_loss = fwd_bwd(sX, sY, s_noise, sP)
+                    s_loss = fwd_bwd(sX, sY, s_noise, sP, prenoised=_FUSED_PREP)
                     if world == 1:
                         apply_update()
                 if world > 1:
@@ -571,7 +590,10 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
             # changes neither the batch statistics nor the mean loss, so it is folded into `order`
             idx = order[b * bs:(b + 1) * bs]
             if graph is not None and idx.numel() == bs:
-                torch.index_select(Xtr, 0, idx, out=sX)                      # gather straight into the graph's input buffers
+                if _FUSED_PREP:
+                    gather_noise(idx, sX)                                    # gather + noise (+ bf16 cast) in one launch
+                else:
+                    torch.index_select(Xtr, 0, idx, out=sX)                  # gather straight into the graph's input buffers
                 torch.index_select(Ytr, 0, idx, out=sY)
                 if sP is not None:
                     physics_inputs(idx, out=sP)
