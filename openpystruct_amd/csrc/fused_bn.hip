@@ -92,6 +92,9 @@ __global__ __launch_bounds__(256) void fused_bn_fwd_kernel(const FbArgs a) {
     float z = fb_ld(a.x1, i, bf);
     if (a.x2) z += fb_ld(a.x2, i, bf);
     if (a.x3) z += fb_ld(a.x3, i, bf);
+    // bfloat16 activations: normalise the value that is SAVED for the backward pass (the sum rounded to bfloat16), so that the
+    // LeakyReLU sees the same pre-activation sign in both directions (and the framework's bf16 sum is what it would see too)
+    if (bf && (a.x2 || a.x3)) z = __uint_as_float((uint32_t)fb_f2bf(z) << 16);
     return z;
   };
   // rows of this thread: rg, rg + FB_RG, ...; the first FB_RPT of them live in registers
