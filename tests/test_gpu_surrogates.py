@@ -196,8 +196,9 @@ def test_fused_tail_matches_the_framework_modules(dtype, n_add, act):
             # (with several addends the sum itself is rounded to bf16, as the framework's bf16 adds would: ~0.3 % of the
             #  pre-activations change sign against the float32 reference, each such entry is off by a factor 100 = 1 / slope)
             assert float((a.grad.float() - b.grad).norm() / b.grad.norm()) < (3e-2 if n_add == 1 or not act else 1e-1)
-    assert float((bn.weight.grad - ref.weight.grad).abs().max() / ref.weight.grad.abs().max()) < (2e-5 if dtype == torch.float32 else 3e-2)
-    assert float((bn.bias.grad - ref.bias.grad).abs().max() / ref.bias.grad.abs().max()) < (2e-5 if dtype == torch.float32 else 3e-2)
+    tol_p = 2e-5 if dtype == torch.float32 else (3e-2 if n_add == 1 or not act else 1e-1)     # same sign flips, summed over a column
+    assert float((bn.weight.grad - ref.weight.grad).abs().max() / ref.weight.grad.abs().max()) < tol_p
+    assert float((bn.bias.grad - ref.bias.grad).abs().max() / ref.bias.grad.abs().max()) < tol_p
     assert torch.allclose(bn.running_mean, ref.running_mean, atol=1e-3 if dtype == torch.bfloat16 else 1e-6)
     assert torch.allclose(bn.running_var, ref.running_var, rtol=2e-2 if dtype == torch.bfloat16 else 1e-5)
     assert int(bn.num_batches_tracked) == int(ref.num_batches_tracked) == 1
