@@ -120,15 +120,36 @@ def eleLoad(*args):
 
 
 def system(kind, *rest):
+    """Every system of equations is solved by the same positive-pivot band LDL^T (the kernels' only factorisation): exact for
+    the SPD stiffness matrices of the reference's models under ANY of these names.  A general-matrix solver (`BandGeneral` =
+    LAPACK dgbsv, FR:134) would also get through an indefinite but non-singular matrix -- a mechanism held by a negative
+    stiffness, which the reference's commands cannot build; here `analyze` reports failure for it (non-zero return, like a
+    singular matrix)."""
     if kind not in ("BandSPD", "BandGeneral", "ProfileSPD", "FullGeneral", "UmfPack", "SparseGeneral"):
         raise ValueError(kind)
     _dom.system = kind
 
 
-def numberer(*a): pass
-def constraints(*a): pass
-def integrator(*a): pass
-def algorithm(*a): pass
+# analysis-object commands: only what is equivalent to ONE linear static solve with constrained DOFs dropped is accepted
+# (SingleCore.py:121-124, FR:135-138); anything else would silently change the meaning of analyze(1), so it raises
+def numberer(kind="RCM", *a):
+    if kind not in ("RCM", "Plain", "AMD"):          # a numbering only permutes equations: results are identical
+        raise NotImplementedError(f"numberer {kind!r}")
+
+
+def constraints(kind="Plain", *a):
+    if kind not in ("Plain", "Transformation"):      # homogeneous single-point constraints: both drop the constrained DOFs
+        raise NotImplementedError(f"constraints {kind!r}: only homogeneous fixities are modelled (SingleCore.py:100-102, :122)")
+
+
+def integrator(kind="LoadControl", *a):
+    if kind != "LoadControl" or (a and float(a[0]) != 1.0):
+        raise NotImplementedError(f"integrator {kind!r} {a!r}: one load step to load factor 1.0 (SingleCore.py:123)")
+
+
+def algorithm(kind="Linear", *a):
+    if kind not in ("Linear", "Newton", "ModifiedNewton"):   # a linear problem: Newton converges in its first iteration (FR:138)
+        raise NotImplementedError(f"algorithm {kind!r}")
 
 
 def analysis(kind):

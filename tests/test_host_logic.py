@@ -204,3 +204,16 @@ def test_prepare_accepts_json_lists_and_reader_tensors_alike(tmp_path):
     a = dataprep.prepare(as_lists, kind="pinn", seed=3)
     b = dataprep.prepare(as_tensors, kind="pinn", seed=3)
     assert torch.allclose(a.X_train, b.X_train, atol=1e-6) and torch.allclose(a.Y_val, b.Y_val, atol=1e-6)
+
+
+def test_analysis_object_commands_reject_what_they_cannot_honour():
+    """the analysis-object commands are accepted only in the forms that mean 'one linear static solve'."""
+    from openpystruct_amd import ops
+    ops.numberer('RCM'); ops.constraints('Plain'); ops.integrator('LoadControl', 1.0); ops.algorithm('Linear'); ops.algorithm('Newton')
+    ops.system('BandSPD'); ops.system('BandGeneral')
+    for bad in (lambda: ops.constraints('Penalty', 1e12, 1e12), lambda: ops.integrator('LoadControl', 0.1),
+                lambda: ops.integrator('DisplacementControl', 1, 2, 0.1), lambda: ops.algorithm('BFGS'), lambda: ops.analysis('Transient')):
+        with pytest.raises(NotImplementedError):
+            bad()
+    with pytest.raises(ValueError):
+        ops.system('Mumps')
