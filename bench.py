@@ -275,9 +275,9 @@ def bench_frames(args, rank, local_rank, world, dev):
         from openpystruct_amd import _cabi
         ws_frame = int(_cabi.load().ops_frame_workspace_bytes(1, topo.n_eq, topo.kd))
         io_frame = 8 * (topo.Ne + 3 * topo.Nn + 8 * topo.Ne)       # I in; disp, forces, V, M out
-        # the band / factor workspace is written by the assembly, read and rewritten (L over A) by the factorisation and
-        # read once more by the backward sweep: ~4 passes over it per frame, plus the inputs / outputs
-        bytes_per = 4 * ws_frame + io_frame
+        # the factor workspace is written once by the factorisation (the assembly is fused: the assembled band never exists
+        # in HBM) and read once by the backward sweep: 2 passes over it per frame, plus the inputs / outputs
+        bytes_per = 2 * ws_frame + io_frame
         achieved = bytes_per * B / (dev_ms / K * 1e-3) / 1e9
         flops = 2.0 * topo.n_eq * topo.kd * topo.kd / 2.0            # band LDL^T multiply-adds (n kd^2 / 2), counted as 2 flop
         print(json.dumps({
@@ -290,7 +290,7 @@ def bench_frames(args, rank, local_rank, world, dev):
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": None, "bytes_per_frame": bytes_per,
                          "fp64_vector_frac": flops * B / (dev_ms / K * 1e-3) / 78.6e12,
-                         "note": "wave-per-frame band LDL^T, window in registers (csrc/frame_wave.hpp): 4 passes over the band workspace"},
+                         "note": "wave-per-frame band LDL^T, window in registers, assembly fused (csrc/frame_wave.hpp): 2 passes over the factor workspace"},
         }), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -563,6 +563,9 @@ static bool use_wave_kernel(int kd) {
   return kd <= 55 && !(e && atoi(e) != 0);
 }
 
+// the assembly fused into the solve (plan built per call, frame_wave.hpp); OPS_AMD_FRAME_FUSED_ASM=0: separate assembly kernel (A/B)
+static bool fused_assembly() { const char* e = getenv("OPS_AMD_FRAME_FUSED_ASM"); return !(e && atoi(e) == 0); }
+
 template <int W>
 static hipError_t launch_wave(const FrameParams& p, double* ws, hipStream_t s) {
   static std::atomic<unsigned long long> done{0};
@@ -573,17 +576,30 @@ static hipError_t launch_wave(const FrameParams& p, double* ws, hipStream_t s) {
   if (lds > 160 * 1024 - 64) return hipErrorInvalidValue;
   const unsigned long long bit = 1ull << (devid & 63);
   if (!(done.load(std::memory_order_acquire) & bit)) {
-    e = hipFuncSetAttribute((const void*)frame_wave_kernel<W>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
+    e = hipFuncSetAttribute((const void*)frame_wave_kernel<W, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)frame_wave_kernel<W, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
     if (e != hipSuccess) return e;
     done.fetch_or(bit, std::memory_order_release);
   }
-  hipLaunchKernelGGL(frame_wave_kernel<W>, dim3((unsigned)((p.B + 3) / 4)), dim3(256), lds, s, p, ws);
+  void* plan_base = (char*)ws + (size_t)p.B * fw_frame_doubles(p.n_eq, p.kd) * sizeof(double);
+  const FwPlan pl = fw_plan_at(plan_base, p.n_eq, p.Ne);
+  const dim3 grid((unsigned)((p.B + 3) / 4));
+  if (fused_assembly()) {
+    if ((size_t)p.n_eq * sizeof(int) > 64 * 1024) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(frame_plan_kernel, dim3(1), dim3(1024), (size_t)p.n_eq * sizeof(int), s, p, W, plan_base);
+    hipLaunchKernelGGL((frame_wave_kernel<W, true>), grid, dim3(256), lds, s, p, ws, pl);
+  } else {
+    const size_t lds_asm = ((size_t)FW_SLAB * W + (size_t)p.n_eq) * sizeof(double);
+    hipLaunchKernelGGL(frame_assemble_rows_kernel, dim3((unsigned)p.B), dim3(256), lds_asm, s, p, ws, W);
+    hipLaunchKernelGGL((frame_wave_kernel<W, false>), grid, dim3(256), lds, s, p, ws, pl);
+  }
   return hipGetLastError();
 }
 
 extern "C" size_t ops_frame_workspace_bytes(int B, int n_eq, int half_bandwidth) {
   half_bandwidth = eff_kd(half_bandwidth);
-  if (use_wave_kernel(half_bandwidth)) return (size_t)B * fw_frame_doubles(n_eq, half_bandwidth) * sizeof(double);
+  if (use_wave_kernel(half_bandwidth))     // per frame: band / factor rows; once: the assembly plan (at most 21 entries and 72 coefficients per element)
+    return B == 0 ? 0 : (size_t)B * fw_frame_doubles(n_eq, half_bandwidth) * sizeof(double) + fw_plan_bytes(n_eq, 4 * n_eq + 64);
   if (frame_lds_resident_bytes(n_eq, half_bandwidth) <= LDS_MAX && !force_ws()) return 0;   // the band lives in LDS
   return (size_t)B * frame_lds_resident_bytes(n_eq, half_bandwidth);
 }
@@ -624,13 +640,12 @@ extern "C" int ops_frame_solve_batched_f64(int B, int n_nodes, int n_elems, int 
   hipStream_t s = (hipStream_t)stream;
   if (use_wave_kernel(kd)) {
     const int W = fw_width(kd);
-    const size_t need = (size_t)B * fw_frame_doubles(n_eq, kd) * sizeof(double);
+    const size_t need = (size_t)B * fw_frame_doubles(n_eq, kd) * sizeof(double) + fw_plan_bytes(n_eq, n_elems);
     if (!workspace || workspace_bytes < need) return OPS_AMD_ERR_INVALID_ARG;
     const size_t lds_asm = ((size_t)FW_SLAB * W + (size_t)n_eq) * sizeof(double);
     if (lds_asm > LDS_MAX) return OPS_AMD_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(frame_assemble_rows_kernel, dim3((unsigned)B), dim3(256), lds_asm, s, p, (double*)workspace, W);
-    hipError_t e = hipGetLastError();
-    if (e == hipSuccess) {
+    hipError_t e = hipSuccess;
+    {
       switch (W) {
         case 16: e = launch_wave<16>(p, (double*)workspace, s); break;
         case 24: e = launch_wave<24>(p, (double*)workspace, s); break;

@@ -104,6 +104,87 @@ __global__ __launch_bounds__(256) void frame_assemble_rows_kernel(const FramePar
   for (int i = tid; i < n; i += 256) rhs_g[i] = rhs[i];
 }
 
+// ---- assembly plan: the topology-only part of the assembly, built once per call ----
+// Row R of the band is  sum over its incident element entries (e, r, q):  ka[e][r][q] + I_e * kb[e][r][q]  at column slot
+// eq[q] mod W (ka: the axial part of the rotated ElasticBeam2d matrix, kb: the bending part per unit inertia -- both
+// independent of the frame), and its right-hand side is rhs_base[R] (consistent beamUniform loads, FR:131) + the nodal load
+// of its DOF.  With the plan the solve kernel builds every 8-row group directly in its LDS parking area one group ahead of
+// need: the assembled band never exists in HBM (r02 first version: assembly kernel writes it, solve kernel reads it back =
+// half of the solve's memory traffic and 20 % of its time).
+struct FwPlan {
+  const int* row_ptr;        // [n + 1]
+  const int* eq_dof;         // [n]   index into loads[Nn*3]
+  const uint2* ent;          // [row_ptr[n]]  .x = element, .y = kidx (r*6+q) | slot << 8 | row << 16
+  const double* ka;          // [Ne*36]
+  const double* kb;          // [Ne*36]
+  const double* rhs_base;    // [n]
+};
+__host__ __device__ inline size_t fw_plan_bytes(int n, int Ne) {
+  return (size_t)(((n + 2) / 2) * 2 + ((n + 1) / 2) * 2) * 4 + (size_t)Ne * 21 * 8 + (size_t)Ne * 72 * 8 + (size_t)n * 8;
+}
+__host__ __device__ inline FwPlan fw_plan_at(void* base, int n, int Ne) {
+  char* q = (char*)base;
+  FwPlan pl;
+  pl.row_ptr = (const int*)q;  q += (size_t)(((n + 2) / 2) * 2) * 4;
+  pl.eq_dof = (const int*)q;   q += (size_t)(((n + 1) / 2) * 2) * 4;
+  pl.ent = (const uint2*)q;    q += (size_t)Ne * 21 * 8;
+  pl.ka = (const double*)q;    q += (size_t)Ne * 36 * 8;
+  pl.kb = (const double*)q;    q += (size_t)Ne * 36 * 8;
+  pl.rhs_base = (const double*)q;
+  return pl;
+}
+
+__global__ __launch_bounds__(1024) void frame_plan_kernel(const FrameParams p, int W, void* plan_base) {
+  extern __shared__ int s_cnt[];            // [n] counts, then cursors
+  const FwPlan pl = fw_plan_at(plan_base, p.n_eq, p.Ne);
+  int* row_ptr = const_cast<int*>(pl.row_ptr);
+  int* eq_dof = const_cast<int*>(pl.eq_dof);
+  uint2* ent = const_cast<uint2*>(pl.ent);
+  double* ka = const_cast<double*>(pl.ka);
+  double* kb = const_cast<double*>(pl.kb);
+  double* rhs_base = const_cast<double*>(pl.rhs_base);
+  const int n = p.n_eq, tid = threadIdx.x, T = blockDim.x;
+  for (int i = tid; i < n; i += T) { s_cnt[i] = 0; rhs_base[i] = 0.0; }
+  __syncthreads();
+  for (int i = tid; i < p.Nn * 3; i += T) { const int q = p.node_eq[i]; if (q >= 0) eq_dof[q] = i; }
+  for (int e = tid; e < p.Ne; e += T) {
+    const double L = p.elem_geo[3 * e], c = p.elem_geo[3 * e + 1], s = p.elem_geo[3 * e + 2];
+    double k[6][6];
+    elem_global_k(L, c, s, p.elem_EA[e], 0.0, k);
+    for (int r = 0; r < 6; ++r) for (int q = 0; q < 6; ++q) ka[e * 36 + r * 6 + q] = k[r][q];
+    elem_global_k(L, c, s, 0.0, p.elem_E[e], k);
+    for (int r = 0; r < 6; ++r) for (int q = 0; q < 6; ++q) kb[e * 36 + r * 6 + q] = k[r][q];
+    const double wy = p.elem_w[2 * e], wx = p.elem_w[2 * e + 1];
+    const double pl6[6] = {wx * L / 2, wy * L / 2, wy * L * L / 12, wx * L / 2, wy * L / 2, -wy * L * L / 12};
+    const double pg[6] = {c * pl6[0] - s * pl6[1], s * pl6[0] + c * pl6[1], pl6[2], c * pl6[3] - s * pl6[4], s * pl6[3] + c * pl6[4], pl6[5]};
+    for (int r = 0; r < 6; ++r) {
+      const int er = p.elem_eq[6 * e + r];
+      if (er < 0) continue;
+      atomicAdd(&rhs_base[er], pg[r]);
+      for (int q = 0; q < 6; ++q) { const int eq = p.elem_eq[6 * e + q]; if (eq >= 0 && eq <= er) atomicAdd(&s_cnt[er], 1); }
+    }
+  }
+  __syncthreads();
+  if (tid == 0) {                            // exclusive scan (n <= a few thousand)
+    int acc = 0;
+    for (int i = 0; i < n; ++i) { const int c0 = s_cnt[i]; row_ptr[i] = acc; s_cnt[i] = acc; acc += c0; }
+    row_ptr[n] = acc;
+  }
+  __syncthreads();
+  for (int e = tid; e < p.Ne; e += T)
+    for (int r = 0; r < 6; ++r) {
+      const int er = p.elem_eq[6 * e + r];
+      if (er < 0) continue;
+      for (int q = 0; q < 6; ++q) {
+        const int eq = p.elem_eq[6 * e + q];
+        if (eq >= 0 && eq <= er) {
+          const int pos = atomicAdd(&s_cnt[er], 1);
+          ent[pos] = make_uint2((unsigned)e, (unsigned)(r * 6 + q) | ((unsigned)(eq % W) << 8) | ((unsigned)er << 16));
+        }
+      }
+    }
+}
+
 // ---- the solve: one wave per frame ----
 template <int W>
 struct FwState {
@@ -151,8 +232,9 @@ __device__ __forceinline__ void fw_take_group(FwState<W>& st, int g0, int lane, 
   }
 }
 
-template <int W>
-__device__ __forceinline__ void frame_wave_body(const FrameParams& p, double* __restrict__ wsf, double* __restrict__ lds, int lane, long b) {
+template <int W, bool FUSED>
+__device__ __forceinline__ void frame_wave_body(const FrameParams& p, double* __restrict__ wsf, double* __restrict__ lds, int lane, long b,
+                                                const FwPlan& pl) {
   constexpr int G = FW_G, K = (G * W + 63) / 64;
   const int n = p.n_eq, kd = p.kd;
   const int KG = (kd + G - 1) / G * G;                      // registers hold the rows below j + KG + G at step j
@@ -160,29 +242,70 @@ __device__ __forceinline__ void frame_wave_body(const FrameParams& p, double* __
   double* stage = lds + 2 * FW_CB;                          // [G][W + 1]: rows + right-hand sides of one group
   double* xs = stage + (size_t)G * (W + 1);                 // [n + 64]: w, then x
   double* rows = wsf;                                       // [fw_rows(n)][W], overwritten column by column with L
-  const double* rhs_g = wsf + (size_t)fw_rows(n) * W;
+  const double* rhs_g = wsf + (size_t)fw_rows(n) * W;       // (unfused path)
+  (void)rhs_g;
   FwState<W> st;
 #pragma unroll
   for (int c = 0; c < W; ++c) st.reg[c] = 0.0;
   st.y = 0.0;
   int bad = 0;
 
-  double tmp[K], tmpy;
-  auto fetch = [&](int g0) {                                // group g0: G x W contiguous doubles + G right-hand sides
-#pragma unroll
-    for (int k = 0; k < K; ++k) {
-      const int idx = lane + 64 * k;
-      tmp[k] = (idx < G * W) ? rows[(size_t)g0 * W + idx] : 0.0;
-    }
-    tmpy = (lane < G && g0 + lane < n) ? rhs_g[g0 + lane] : 0.0;
+  constexpr int KE = 3;                                      // plan entries a lane carries between fetch and park (8 rows x 24 / 64)
+  double tmp[FUSED ? KE : K], tmpy;
+  int tslot[FUSED ? KE : 1], tbeg = 0, tend = 0;
+  const double* Ib = p.I + b * p.Ne;
+  const double* lb = p.loads + b * p.loads_bs;
+  auto entry = [&](int i, int g0, int& slot) -> double {    // value and LDS slot of plan entry i (a row of group g0)
+    const uint2 en = pl.ent[i];
+    const int kidx = en.y & 0xFF, c = (en.y >> 8) & 0xFF, R = (int)(en.y >> 16);
+    slot = (R - g0) * (W + 1) + c;
+    return __builtin_fma(Ib[en.x], pl.kb[en.x * 36 + kidx], pl.ka[en.x * 36 + kidx]);
   };
-  auto park = [&]() {                                       // fetched group -> LDS stage (row-major, pitch W + 1)
+  auto fetch = [&](int g0) {                                // group g0: G rows + right-hand sides, one group ahead of need
+    if constexpr (FUSED) {
+      const int r0 = g0 < n ? g0 : n, r1 = g0 + G < n ? g0 + G : n;
+      tbeg = pl.row_ptr[r0]; tend = pl.row_ptr[r1];
 #pragma unroll
-    for (int k = 0; k < K; ++k) {
-      const int idx = lane + 64 * k;
-      if (idx < G * W) stage[(idx / W) * (W + 1) + idx % W] = tmp[k];
+      for (int k = 0; k < KE; ++k) {
+        const int i = tbeg + lane + 64 * k;
+        tslot[k] = 0;
+        tmp[k] = (i < tend) ? entry(i, g0, tslot[k]) : 0.0;
+      }
+      tmpy = (lane < G && g0 + lane < n) ? pl.rhs_base[g0 + lane] + lb[pl.eq_dof[g0 + lane]] : 0.0;
+      tbeg = g0;                                            // park() needs the group's first row for the overflow loop
+    } else {
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        const int idx = lane + 64 * k;
+        tmp[k] = (idx < G * W) ? rows[(size_t)g0 * W + idx] : 0.0;
+      }
+      tmpy = (lane < G && g0 + lane < n) ? rhs_g[g0 + lane] : 0.0;
     }
-    if (lane < G) stage[lane * (W + 1) + W] = tmpy;
+  };
+  auto park = [&]() {                                       // the fetched group -> LDS stage (row-major, pitch W + 1)
+    if constexpr (FUSED) {
+      for (int i = lane; i < G * (W + 1); i += 64) stage[i] = 0.0;
+      fw_fence();
+      const int g0 = tbeg, r0 = g0 < n ? g0 : n;
+      const int e0 = pl.row_ptr[r0];
+#pragma unroll
+      for (int k = 0; k < KE; ++k)
+        if (e0 + lane + 64 * k < tend) atomicAdd(&stage[tslot[k]], tmp[k]);
+      for (int i = e0 + lane + 64 * KE; i < tend; i += 64) {      // nodes with more than four elements: not prefetched
+        int slot;
+        const double v = entry(i, g0, slot);
+        atomicAdd(&stage[slot], v);
+      }
+      fw_fence();
+      if (lane < G) stage[lane * (W + 1) + W] = tmpy;
+    } else {
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        const int idx = lane + 64 * k;
+        if (idx < G * W) stage[(idx / W) * (W + 1) + idx % W] = tmp[k];
+      }
+      if (lane < G) stage[lane * (W + 1) + W] = tmpy;
+    }
   };
   // prologue: rows [0, KG + G) into registers, the next group parked, the one after in flight
   for (int g0 = 0; g0 < KG + G; g0 += G) {
@@ -266,14 +389,14 @@ __device__ __forceinline__ void frame_wave_body(const FrameParams& p, double* __
 // round trip of the broadcast line): 2 W VGPRs of window + ~55
 constexpr int fw_waves(int W) { return W <= 36 ? 1 : W <= 52 ? 3 : 2; }   // measured: only the 52-wide window gains (170 -> 168 VGPRs: 3 waves)
 
-template <int W>
+template <int W, bool FUSED>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(fw_waves(W))))
-void frame_wave_kernel(const FrameParams p, double* __restrict__ ws) {
+void frame_wave_kernel(const FrameParams p, double* __restrict__ ws, const FwPlan pl) {
   extern __shared__ double lds[];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const long b = (long)blockIdx.x * 4 + wave;
   if (b >= p.B) return;
-  frame_wave_body<W>(p, ws + b * fw_frame_doubles(p.n_eq, p.kd), lds + (size_t)wave * fw_lds_doubles(p.n_eq, W), lane, b);
+  frame_wave_body<W, FUSED>(p, ws + b * fw_frame_doubles(p.n_eq, p.kd), lds + (size_t)wave * fw_lds_doubles(p.n_eq, W), lane, b, pl);
 }
 
 }  // namespace opsamd
