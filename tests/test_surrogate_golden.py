@@ -230,6 +230,18 @@ def test_loop_matches_reference_cpu(kind, records):
 # ----------------------------------------------------------------------------------------------------------------
 @pytest.mark.gpu
 @pytest.mark.parametrize("kind", KINDS)
+def test_dataprep_matches_reference_on_the_gpu(kind, records):
+    """`dataprep.prepare(device="cuda")`: the tensor-native prep runs on the device the records live on (a12)."""
+    g = gold(kind)
+    d = prep(kind, records, g, device="cuda")
+    for name, got in (("X_train_tensor", d.X_train), ("Y_train_tensor", d.Y_train), ("X_val_tensor", d.X_val), ("Y_val_tensor", d.Y_val)):
+        want = g[name]
+        assert got.is_cuda and tuple(got.shape) == want.shape, name
+        assert float(np.abs(got.cpu().numpy() - want).max()) <= 2e-6 * max(1.0, float(np.abs(want).max())), name
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", KINDS)
 def test_modules_match_reference_gpu_fp32(kind, records):
     _forward_checks(kind, records, "cuda", 2e-5, 3e-4)
 
