@@ -352,7 +352,7 @@ def main():
         if world > 1:
             dist.barrier(device_ids=[local_rank]) if dist.get_backend() == "nccl" else dist.barrier()
 
-    def measure(Bm, Km, Wm, n_sets, tiling):
+    def measure(Bm, Km, Wm, n_sets, tiling, stream_out=False):
         """K launches over `Bm` beams, rotating over `n_sets` distinct input / output buffer sets, captured in ONE HIP
         graph and replayed once between two HIP events on the launch stream.  Barriers and host synchronisation sit
         strictly OUTSIDE the event pair.  Returns (event ms, wall s, kernel name, launch mode)."""
@@ -360,20 +360,20 @@ def main():
         sets = [base]
         for k in range(1, n_sets):      # distinct HBM: same geometry, rolled case order (values stay inside the distribution)
             sets.append(dict(base, I=base["I"].roll(k, 0).contiguous(), Fy=base["Fy"].roll(k, 0).contiguous()))
-        outs = [oa.beam_solve(**st, tiling=tiling) for st in sets]       # allocates result buffers once per set
+        outs = [oa.beam_solve(**st, tiling=tiling, stream_out=stream_out) for st in sets]       # allocates result buffers once per set
         torch.cuda.synchronize()
         stream = torch.cuda.Stream(device=dev)
         graph = None
         with torch.cuda.stream(stream):
             for i in range(Wm):
-                oa.beam_solve(**sets[i % n_sets], tiling=tiling, out=outs[i % n_sets])
+                oa.beam_solve(**sets[i % n_sets], tiling=tiling, out=outs[i % n_sets], stream_out=stream_out)
             stream.synchronize()
             if not args.no_graph:
                 try:
                     graph = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(graph, stream=stream, capture_error_mode="thread_local"):
                         for i in range(Km):
-                            oa.beam_solve(**sets[i % n_sets], tiling=tiling, out=outs[i % n_sets])
+                            oa.beam_solve(**sets[i % n_sets], tiling=tiling, out=outs[i % n_sets], stream_out=stream_out)
                     graph.replay()   # untimed: instantiate + first replay
                     stream.synchronize()
                 except Exception as e:   # keep the bench alive: eager launches measure the same kernel, with host gaps
@@ -391,7 +391,7 @@ def main():
                 graph.replay()
             else:
                 for i in range(Km):
-                    oa.beam_solve(**sets[i % n_sets], tiling=tiling, out=outs[i % n_sets])
+                    oa.beam_solve(**sets[i % n_sets], tiling=tiling, out=outs[i % n_sets], stream_out=stream_out)
             e1.record(stream)
         torch.cuda.synchronize()
         wall = time.perf_counter() - t0          # host clock around the same region, BEFORE the closing barrier
@@ -406,8 +406,8 @@ def main():
         del outs, sets
         return dev_ms, wall, oa.kernel_name(Bm, N_ELEM, tiling), ("eager" if graph is None else f"one HIP graph of {Km} kernel nodes")
 
-    def sub_record(Bm, Km, n_sets, tiling, what):
-        dev_ms, wall, kname, mode = measure(Bm, Km, min(W, 2 * n_sets), n_sets, tiling)
+    def sub_record(Bm, Km, n_sets, tiling, what, stream_out=False):
+        dev_ms, wall, kname, mode = measure(Bm, Km, min(W, 2 * n_sets), n_sets, tiling, stream_out)
         us = dev_ms / Km * 1e3
         ach = BYTES_PER_SOLVE * Bm / (us * 1e-6) / 1e9
         return {"what": what, "beams_per_launch_per_gpu": Bm, "launches": Km, "buffer_sets": n_sets,
@@ -466,6 +466,9 @@ def main():
         # timed region can be served by a cache that the previous replay filled -- the HBM claim without cache residency
         extras["cold"] = sub_record(B, max(32, min(K, 512) // 16 * 16), 16, args.tiling,
                                     "10^4-beam launches rotating over 16 distinct input/output sets (cache-defeating)")
+        # the same, as a caller that KNOWS it is streaming would call it: OPS_AMD_TILING_STREAM_OUT (non-temporal result stores)
+        extras["cold_stream_out"] = sub_record(B, max(32, min(K, 512) // 16 * 16), 16, args.tiling,
+                                               "as `cold`, with the C ABI's streaming-output flag (non-temporal stores)", stream_out=True)
         # saturating: SURVEY 8(d) asks for B = 2^20 next to the contract batch (one round of waves at 10^4 beams)
         extras["saturating"] = sub_record(1 << 20, 10, 1, args.tiling, "2^20 beams per launch (5.2 GB per launch: HBM-resident by size)")
     if rank == 0:
@@ -477,7 +480,7 @@ def main():
         if tr:
             rec["roofline"]["traffic"] = tr[0]
             rec["roofline"]["traffic_source"] = f"profiles/{tr[1]} (2*FETCH_SIZE + WRITE_SIZE, KiB)"
-        for key, hint in (("cold", "cold"), ("saturating", "sat")):
+        for key, hint in (("cold", "cold"), ("cold_stream_out", "cold"), ("saturating", "sat")):
             if key in rec:
                 tr = profiled_traffic(rec[key]["kernel"], rec[key]["beams_per_launch_per_gpu"], hint)
                 rec[key]["traffic"] = tr[0] if tr else None

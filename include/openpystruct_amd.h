@@ -67,9 +67,13 @@ extern "C" {
  *                  MultiCore.py:182-186); outputs of such a beam are NaN.  May be NULL.
  *
  * `tiling`: 0 = choose from B and Ne; otherwise lanes-per-beam P in {8, 16, 32, 64}
- * (64 = one wavefront per beam).  Returns OPS_AMD_OK or an OPS_AMD_ERR_* code.
+ * (64 = one wavefront per beam); OR-ed with OPS_AMD_TILING_STREAM_OUT the results are written with
+ * non-temporal stores: for callers that cycle through more output than the 256 MiB Infinity Cache
+ * holds (measured at 10^4 beams: cache-resident buffers 13.8 us default / 15.4 us streaming, HBM-resident
+ * buffers 18.4 / 15.8 us; profiles/r02_notes.md).  Returns OPS_AMD_OK or an OPS_AMD_ERR_* code.
  * Never throws, never blocks.
  */
+#define OPS_AMD_TILING_STREAM_OUT 0x100
 int ops_beam_solve_batched_f64(int B, int Ne,
                                const double* x, long x_bstride,
                                const double* E, long E_bstride,

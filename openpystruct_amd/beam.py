@@ -35,14 +35,18 @@ def _dev_f64(t, device, name):
     return t.contiguous()
 
 
-def beam_solve(x, E, I, fix, Fy, wy, *, tiling: int = 0, out: Optional[BeamSolution] = None) -> BeamSolution:
+TILING_STREAM_OUT = 0x100     # include/openpystruct_amd.h OPS_AMD_TILING_STREAM_OUT
+
+
+def beam_solve(x, E, I, fix, Fy, wy, *, tiling: int = 0, out: Optional[BeamSolution] = None, stream_out: bool = False) -> BeamSolution:
     """Solve B straight Euler-Bernoulli beams (Ne elements, N = Ne + 1 nodes) on the GPU.
 
     x    [N] or [B,N]      node coordinates            I    [B,Ne]  element second moments of area
     E    scalar or [B,Ne]  Young's modulus             fix  [N] or [B,N] uint8, bit0 = u_y fixed, bit1 = theta_z fixed
     Fy   [B,N]             nodal point loads           wy   scalar or [B,Ne] transverse UDL (beamUniform Wy)
 
-    Asynchronous on the current stream of I's device; `out` lets callers reuse result buffers.
+    Asynchronous on the current stream of I's device; `out` lets callers reuse result buffers; `stream_out`: non-temporal
+    result stores, for callers cycling through more output than the 256 MiB Infinity Cache holds.
     """
     lib = _cabi.load()
     if not torch.is_tensor(I) or not I.is_cuda:
@@ -98,7 +102,7 @@ def beam_solve(x, E, I, fix, Fy, wy, *, tiling: int = 0, out: Optional[BeamSolut
             Fy.data_ptr(), N,
             wy.data_ptr(), Ne if wy.numel() != 1 else 0,
             out.v.data_ptr(), out.theta.data_ptr(), out.V.data_ptr(), out.M.data_ptr(),
-            out.status.data_ptr(), int(tiling), stream,
+            out.status.data_ptr(), int(tiling) | (TILING_STREAM_OUT if stream_out else 0), stream,
         )
     if rc != _cabi.OK:
         raise RuntimeError(f"ops_beam_solve_batched_f64 failed with code {rc}: {lib.ops_amd_last_error().decode()}")

@@ -18,6 +18,8 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "../../include/openpystruct_amd.h"
 #include "beam_math.hpp"
 #include "sizing_math.hpp"
@@ -36,6 +38,7 @@ struct BeamParams {
   int32_t* status;
   const float* I32;            // sizing epochs: the inertias are float32 rows (dense, stride Ne), widened while staging; I unused
   const uint8_t* active;       // optional [B]: a wave whose beams are all inactive returns at once (sizing epochs)
+  int stream_out;              // OPS_AMD_TILING_STREAM_OUT: non-temporal output stores (buffers that will not be re-read from cache)
   int f32_forces;              // V / M point to float rows (the sizing loop rounds them to float32 anyway, SingleCore.py:189-190)
   // host-derived: rows of I/Fy/outputs are dense and every wave's chunk is 16-byte aligned, so
   // the wave moves its beams as one flat run of 16-byte accesses; magic numbers for idx / Ne, idx / N
@@ -279,7 +282,11 @@ __device__ __forceinline__ void beam_body(const BeamParams& p, const SizingArgs*
   constexpr int PM = P * M;         // padded nodes per beam (>= N)
   constexpr int TG = SHARED ? 1 : BPW;
   constexpr int NPAIR = (BPW * PM / 2 + 63) / 64;   // 16-byte pieces per lane for one staged array
+#ifdef OPS_AMD_ST                                   // A/B builds of the output store policy (scripts/store_policy_ab.sh)
+  constexpr int ST = OPS_AMD_ST;
+#else
   constexpr int ST = (P <= 8) ? 2 : 16;             // store policy: nt for the large-batch tiling, sc1 otherwise
+#endif
   constexpr int NT = (TG * PM + 63) / 64;           // table entries per lane
   __shared__ double s_tab[6][TG][PM];
   __shared__ __attribute__((aligned(16))) double s_a[BPW * PM];
@@ -524,21 +531,28 @@ __device__ __forceinline__ void beam_body(const BeamParams& p, const SizingArgs*
     }
     return;
   }
-  if (DENSE) {
-    const __amdgpu_buffer_rsrc_t rV = make_rsrc(p.V + beam0 * Ne, (unsigned)nE * 8u);
-    const __amdgpu_buffer_rsrc_t rM = make_rsrc(p.M + beam0 * Ne, (unsigned)nE * 8u);
+  // two rows of doubles (s_b -> ra, s_a -> rb) of n values each, 16-byte stores with cache policy AUX
+  auto store_rows = [&](auto aux, const __amdgpu_buffer_rsrc_t ra, const __amdgpu_buffer_rsrc_t rb, int n_) {
+    constexpr int AUX = decltype(aux)::value;
 #pragma unroll
     for (int k = 0; k < NPAIR; ++k) {
       const unsigned i0 = 2u * (lane_e + 64u * k);
       if (k + 1 < NPAIR || i0 < BPW * PM) {     // LDS bound; the buffer descriptor drops pairs beyond the run
-        buf_store_d2<ST>(rV, i0 * 8u, *reinterpret_cast<const double2*>(&s_b[i0]));
-        buf_store_d2<ST>(rM, i0 * 8u, *reinterpret_cast<const double2*>(&s_a[i0]));
+        buf_store_d2<AUX>(ra, i0 * 8u, *reinterpret_cast<const double2*>(&s_b[i0]));
+        buf_store_d2<AUX>(rb, i0 * 8u, *reinterpret_cast<const double2*>(&s_a[i0]));
       }
     }
-    if ((nE & 1) && lane_e == 0) {
-      buf_store_d<ST>(rV, (unsigned)(nE - 1) * 8u, s_b[nE - 1]);
-      buf_store_d<ST>(rM, (unsigned)(nE - 1) * 8u, s_a[nE - 1]);
+    if ((n_ & 1) && lane_e == 0) {
+      buf_store_d<AUX>(ra, (unsigned)(n_ - 1) * 8u, s_b[n_ - 1]);
+      buf_store_d<AUX>(rb, (unsigned)(n_ - 1) * 8u, s_a[n_ - 1]);
     }
+  };
+  const bool nt_out = p.stream_out != 0 && ST != 2;          // wave-uniform
+  if (DENSE) {
+    const __amdgpu_buffer_rsrc_t rV = make_rsrc(p.V + beam0 * Ne, (unsigned)nE * 8u);
+    const __amdgpu_buffer_rsrc_t rM = make_rsrc(p.M + beam0 * Ne, (unsigned)nE * 8u);
+    if (nt_out) store_rows(std::integral_constant<int, 2>{}, rV, rM, nE);
+    else        store_rows(std::integral_constant<int, ST>{}, rV, rM, nE);
   } else {
     for (int idx = lane_e; idx < nE; idx += 64) {
       p.V[beam0 * Ne + idx] = s_b[idx];
@@ -554,18 +568,8 @@ __device__ __forceinline__ void beam_body(const BeamParams& p, const SizingArgs*
   if (DENSE) {
     const __amdgpu_buffer_rsrc_t rv = make_rsrc(p.v + beam0 * N, (unsigned)nN * 8u);
     const __amdgpu_buffer_rsrc_t rt = make_rsrc(p.theta + beam0 * N, (unsigned)nN * 8u);
-#pragma unroll
-    for (int k = 0; k < NPAIR; ++k) {
-      const unsigned i0 = 2u * (lane_e + 64u * k);
-      if (k + 1 < NPAIR || i0 < BPW * PM) {
-        buf_store_d2<ST>(rv, i0 * 8u, *reinterpret_cast<const double2*>(&s_b[i0]));
-        buf_store_d2<ST>(rt, i0 * 8u, *reinterpret_cast<const double2*>(&s_a[i0]));
-      }
-    }
-    if ((nN & 1) && lane_e == 0) {
-      buf_store_d<ST>(rv, (unsigned)(nN - 1) * 8u, s_b[nN - 1]);
-      buf_store_d<ST>(rt, (unsigned)(nN - 1) * 8u, s_a[nN - 1]);
-    }
+    if (nt_out) store_rows(std::integral_constant<int, 2>{}, rv, rt, nN);
+    else        store_rows(std::integral_constant<int, ST>{}, rv, rt, nN);
   } else {
     for (int idx = lane_e; idx < nN; idx += 64) {
       p.v[beam0 * N + idx] = s_b[idx];
@@ -676,7 +680,7 @@ int ops_amd_max_elements(void) { return 64 * 16 - 1; }
 const char* ops_amd_last_error(void) { return g_last_error; }
 
 const char* ops_beam_solve_kernel_name(int B, int Ne, int tiling) {
-  const Tiling* t = choose_tiling(B, Ne, tiling);
+  const Tiling* t = choose_tiling(B, Ne, tiling & ~OPS_AMD_TILING_STREAM_OUT);
   return t ? t->name_shared : "";
 }
 
@@ -693,11 +697,13 @@ static int solve_impl(int B, int Ne, const double* x, long x_bstride, const doub
       (E_bstride != 0 && E_bstride < Ne) || (wy_bstride != 0 && wy_bstride < Ne))
     return OPS_AMD_ERR_INVALID_ARG;
   if (Ne > ops_amd_max_elements()) return OPS_AMD_ERR_UNSUPPORTED;
+  const int stream_out = (tiling & OPS_AMD_TILING_STREAM_OUT) ? 1 : 0;
+  tiling &= ~OPS_AMD_TILING_STREAM_OUT;
   const Tiling* t = choose_tiling(B, Ne, tiling);
   if (!t) return tiling ? OPS_AMD_ERR_INVALID_ARG : OPS_AMD_ERR_UNSUPPORTED;
 
   BeamParams p{B, Ne, x, x_bstride, E, E_bstride, I, I_bstride, fix, fix_bstride, Fy, Fy_bstride,
-               wy, wy_bstride, v, theta, V, M, status, sz ? sz->I : nullptr, active, f32_forces, 0, nullptr, 0u, 0u};
+               wy, wy_bstride, v, theta, V, M, status, sz ? sz->I : nullptr, active, stream_out, f32_forces, 0, nullptr, 0u, 0u};
 #ifdef OPS_AMD_TRACE
   { const char* e = getenv("OPS_AMD_TRACE_PTR"); if (e) p.trace = (unsigned long long*)strtoull(e, nullptr, 0); }
 #endif

@@ -403,3 +403,20 @@ def test_lane_per_beam_alternative_matches_the_product_kernel(oa, B, Ne):
     orc = bo.solve_beam_batched(x, bo.E_REF, I[:nb], fix, Fy[:nb], bo.UDL_REF)
     for got, prod, want, tol in zip(outs, (ref.v, ref.theta, ref.V, ref.M), orc[:4], (tu, tu, 30 * tu, 30 * tu)):
         assert relerr(got[:nb].cpu().numpy(), want) < tol and relerr(prod[:nb].cpu().numpy(), want) < tol
+
+
+def test_stream_out_flag_gives_identical_results(oa):
+    """OPS_AMD_TILING_STREAM_OUT only changes the cache policy of the result stores: bit-identical outputs, same kernel."""
+    rng = np.random.default_rng(11)
+    x = np.linspace(0, 200, 101)
+    fix = bo.reference_fix_mask()
+    I, Fy = bo.random_cases(rng, 37, inertia="trajectory")
+    args = (_gpu(x), _gpu(bo.E_REF), _gpu(I), _gpu(fix, torch.uint8), _gpu(Fy), _gpu(bo.UDL_REF))
+    for til in (0, 8, 16, 64):
+        a = oa.beam_solve(*args, tiling=til)
+        b = oa.beam_solve(*args, tiling=til, stream_out=True)
+        torch.cuda.synchronize()
+        for p, q in zip(a, b):
+            assert torch.equal(p, q)
+    from openpystruct_amd import _cabi
+    assert _cabi.load().ops_beam_solve_kernel_name(10000, 100, 0x100) == _cabi.load().ops_beam_solve_kernel_name(10000, 100, 0)
