@@ -251,7 +251,10 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, un
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
 }
 __device__ __forceinline__ double2 buf_load_d2(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
-  const v4i v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 0);
+#ifndef OPS_AMD_LD_AUX
+#define OPS_AMD_LD_AUX 0
+#endif
+  const v4i v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, OPS_AMD_LD_AUX);   // row loads (A/B: -DOPS_AMD_LD_AUX=2 nt)
   return __builtin_bit_cast(double2, v);
 }
 __device__ __forceinline__ double buf_load_d(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
