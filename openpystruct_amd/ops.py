@@ -169,10 +169,9 @@ def _is_straight_beam(d: _Domain) -> bool:
     return sorted(d.elements) == list(range(1, N)) and all(d.elements[e][:2] == (e, e + 1) for e in d.elements)
 
 
-def _analyze_frame(d: _Domain):
-    """General 2-D frame (what `setup_frame_model` builds, OpenPyStruct_FrameOpt_Discrete_Beta.py:75-139):
-    the batched frame kernel with a batch of one."""
-    from .frames import FrameTopology, frame_solve
+def _frame_arrays(d: _Domain):
+    """The recorded domain as the arrays of a general 2-D frame (what `setup_frame_model` builds,
+    OpenPyStruct_FrameOpt_Discrete_Beta.py:75-139)."""
     tags = sorted(d.nodes)
     N = len(tags)
     if tags != list(range(1, N + 1)) or sorted(d.elements) != list(range(1, len(d.elements) + 1)):
@@ -191,14 +190,33 @@ def _analyze_frame(d: _Domain):
         loads[t - 1] = f
     wy = np.array([d.ele_loads.get(e, (0.0, 0.0))[0] for e in range(1, Ne + 1)])
     wx = np.array([d.ele_loads.get(e, (0.0, 0.0))[1] for e in range(1, Ne + 1)])
-    topo = FrameTopology(coords, conn, fix3, A, E, wy, wx, loads, device=d.device)
-    sol = frame_solve(topo, torch.as_tensor(I[None, :], dtype=torch.float64, device=d.device))
-    if int(sol.status[0]) != 0:
+    return dict(coords=coords, conn=conn, fix3=fix3, A=A, E=E, wy=wy, wx=wx, loads=loads, I=I)
+
+
+def _frame_finish(d: _Domain, disp, forces, status):
+    if status != 0:
         d.result = None
         return _ANALYZE_FAILED
-    disp = sol.disp[0].cpu().numpy()
-    d.result = dict(ux=disp[:, 0], v=disp[:, 1], th=disp[:, 2], forces=sol.forces[0].cpu().numpy())
+    d.result = dict(ux=disp[:, 0], v=disp[:, 1], th=disp[:, 2], forces=forces)
     return 0
+
+
+def _solve_frames(arrs, device):
+    """Frames of ONE topology (same nodes, connectivity, fixities, sections, element loads), different inertias and nodal
+    loads: one launch of the batched frame kernel."""
+    from .frames import FrameTopology, frame_solve
+    a0 = arrs[0]
+    topo = FrameTopology(a0["coords"], a0["conn"], a0["fix3"], a0["A"], a0["E"], a0["wy"], a0["wx"], a0["loads"], device=device)
+    I = torch.as_tensor(np.stack([a["I"] for a in arrs]), dtype=torch.float64, device=device)
+    loads = torch.as_tensor(np.stack([a["loads"] for a in arrs]), dtype=torch.float64, device=device)
+    sol = frame_solve(topo, I, loads=loads)
+    return sol.disp.cpu().numpy(), sol.forces.cpu().numpy(), sol.status.cpu().numpy()
+
+
+def _analyze_frame(d: _Domain):
+    """General 2-D frame: the batched frame kernel with a batch of one."""
+    disp, forces, status = _solve_frames([_frame_arrays(d)], d.device)
+    return _frame_finish(d, disp[0], forces[0], int(status[0]))
 
 
 def _arrays(d: _Domain):
@@ -280,8 +298,10 @@ def analyze(n_steps=1):
     if d.analysis != "Static":
         return _ANALYZE_FAILED
     if not _is_straight_beam(d):
-        if _queue is not None:
-            raise NotImplementedError("deferred(): straight beams only")
+        if _queue is not None:          # deferred: frames of equal topology are solved in one launch at flush
+            d._frame = _frame_arrays(d)
+            _queue.append(d)
+            return 0
         return _analyze_frame(d)
     a = _arrays(d)
     if _queue is not None:
@@ -321,7 +341,8 @@ def deferred(device=None):
                 ops.wipe(); setup_model(...); ops.analysis('Static'); ops.analyze(1)
         results = batch.domains          # each has .result like the global domain after analyze
 
-    All queued models must have the same number of nodes."""
+    Queued straight beams must have the same number of nodes; queued frames are grouped by topology (one launch per group,
+    inertias and nodal loads per frame)."""
     global _queue
 
     class _Batch:
@@ -336,14 +357,31 @@ def deferred(device=None):
         q, _queue = _queue, None
         if q:
             dev = torch.device(device) if device is not None else q[0].device
-            arrs = [d._arrays for d in q]
-            N = len(arrs[0]["x"])
-            if any(len(a["x"]) != N for a in arrs):
-                raise NotImplementedError("deferred(): all models must have the same number of nodes")
-            st = lambda k: np.stack([a[k] for a in arrs])  # noqa: E731
-            t = lambda z, dt=torch.float64: torch.as_tensor(np.ascontiguousarray(z), dtype=dt, device=dev)  # noqa: E731
-            sol = beam_solve(t(st("x")), t(st("E")), t(st("I")), t(st("fix"), torch.uint8), t(st("Fy")), t(st("wy")))
-            v, th, V, M = (z.cpu().numpy() for z in (sol.v, sol.theta, sol.V, sol.M))
-            status = sol.status.cpu().numpy()
             batch.domains = q
-            batch.codes = [_finish(d, a, v[i], th[i], V[i], M[i], int(status[i])) for i, (d, a) in enumerate(zip(q, arrs))]
+            codes = [None] * len(q)
+            beams = [i for i, d in enumerate(q) if getattr(d, "_frame", None) is None]
+            frames_ = [i for i, d in enumerate(q) if getattr(d, "_frame", None) is not None]
+            if beams:
+                arrs = [q[i]._arrays for i in beams]
+                N = len(arrs[0]["x"])
+                if any(len(a["x"]) != N for a in arrs):
+                    raise NotImplementedError("deferred(): all beam models must have the same number of nodes")
+                st = lambda k: np.stack([a[k] for a in arrs])  # noqa: E731
+                t = lambda z, dt=torch.float64: torch.as_tensor(np.ascontiguousarray(z), dtype=dt, device=dev)  # noqa: E731
+                sol = beam_solve(t(st("x")), t(st("E")), t(st("I")), t(st("fix"), torch.uint8), t(st("Fy")), t(st("wy")))
+                v, th, V, M = (z.cpu().numpy() for z in (sol.v, sol.theta, sol.V, sol.M))
+                status = sol.status.cpu().numpy()
+                for k, i in enumerate(beams):
+                    codes[i] = _finish(q[i], arrs[k], v[k], th[k], V[k], M[k], int(status[k]))
+            # frames: one launch per distinct topology (the frame script rebuilds the SAME frame every epoch, FR:178-183)
+            groups = {}
+            for i in frames_:
+                f = q[i]._frame
+                key = (f["coords"].tobytes(), f["conn"].tobytes(), f["fix3"].tobytes(), f["A"].tobytes(), f["E"].tobytes(),
+                       f["wy"].tobytes(), f["wx"].tobytes())
+                groups.setdefault(key, []).append(i)
+            for idxs in groups.values():
+                disp, forces, status = _solve_frames([q[i]._frame for i in idxs], dev)
+                for k, i in enumerate(idxs):
+                    codes[i] = _frame_finish(q[i], disp[k], forces[k], int(status[k]))
+            batch.codes = codes

@@ -247,3 +247,53 @@ def test_frame_sizing_loop_vs_per_frame_oracle(bays, stories):
         assert abs(int(ep[b]) - ref[b]["epochs_run"]) <= 3, (b, ep[b], ref[b]["epochs_run"])
         # the last solve's forces: the state BEFORE the last step (one-step lag, as in the beam scripts)
         np.testing.assert_allclose(I[b].cpu().numpy(), ref[b]["I"], rtol=2e-3)
+
+
+def _build_grid_frame_through_the_shim(ops, cfg, bays, stories, I, lateral):
+    nb1 = bays + 1
+    coords = {i * nb1 + j + 1: (j * cfg.bay_width, i * cfg.story_height) for i in range(stories + 1) for j in range(nb1)}
+    n_cols, n_beams = stories * nb1, stories * bays
+    ops.wipe()
+    ops.model('basic', '-ndm', 2, '-ndf', 3)
+    ops.geomTransf('Linear', 1)
+    for tag, (x, y) in coords.items():
+        ops.node(tag, x, y)
+    for tag, (x, y) in coords.items():
+        if y == 0.0:
+            ops.fix(tag, 1, 1, 1)
+    e = 1
+    for i in range(stories):
+        for j in range(nb1):
+            ops.element('elasticBeamColumn', e, i * nb1 + j + 1, (i + 1) * nb1 + j + 1, cfg.A, cfg.E, float(I[e - 1]), 1); e += 1
+    for i in range(1, stories + 1):
+        for j in range(bays):
+            ops.element('elasticBeamColumn', e, i * nb1 + j + 1, i * nb1 + j + 2, cfg.A, cfg.E, float(I[e - 1]), 1); e += 1
+    ops.timeSeries('Linear', 1); ops.pattern('Plain', 1, 1)
+    for tag, (x, y) in coords.items():
+        if x == 0.0 and y != 0.0:
+            ops.load(tag, lateral, 0.0, 0.0)
+    for ele in range(n_cols + 1, n_cols + n_beams + 1):
+        ops.eleLoad('-ele', ele, '-type', '-beamUniform', cfg.vertical_load, cfg.vertical_load)
+    ops.system('BandGeneral'); ops.numberer('RCM'); ops.constraints('Plain'); ops.integrator('LoadControl', 1.0)
+    ops.algorithm('Newton'); ops.analysis('Static')
+    return ops.analyze(1)
+
+
+def test_ops_shim_deferred_batches_frames_by_topology():
+    """`ops.deferred()` around the frame script's command sequence: frames of one topology (different inertias AND nodal
+    loads) go out in one launch, a second topology in another; every queued domain gets its own results."""
+    from openpystruct_amd import frames, ops
+    cfg = frames.FrameConfig()
+    rng = np.random.default_rng(3)
+    specs = [(3, 2, 1.0e4), (3, 2, 2.5e4), (2, 2, 1.0e4), (3, 2, -0.7e4), (2, 2, 3.0e4)]
+    Is = [np.full(s * (b + 1) + s * b, cfg.I0) * rng.uniform(0.5, 2.0, size=s * (b + 1) + s * b) for b, s, _ in specs]
+    with ops.deferred() as batch:
+        for (b, s, lat), I in zip(specs, Is):
+            assert _build_grid_frame_through_the_shim(ops, cfg, b, s, I, lat) == 0
+    assert batch.codes == [0] * len(specs) and len(batch.domains) == len(specs)
+    for (b, s, lat), I, dom in zip(specs, Is, batch.domains):
+        c2 = frames.FrameConfig(lateral_load=lat)
+        topo = frames.grid_frame(b, s, c2, device="cpu")
+        d, f, st, _, _ = _oracle(topo, I)
+        np.testing.assert_allclose(dom.result["forces"], f, rtol=1e-7, atol=1e-6 * np.abs(f).max())
+        np.testing.assert_allclose(dom.result["v"], d[:, 1], rtol=1e-7, atol=1e-12)
