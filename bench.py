@@ -273,7 +273,7 @@ def bench_frames(args, rank, local_rank, world, dev):
         wall, dev_ms = float(tt[0]), float(tt[1])
     if rank == 0:
         from openpystruct_amd import _cabi
-        ws_frame = int(_cabi.load().ops_frame_workspace_bytes(1, topo.n_eq, topo.kd))
+        ws_frame = int(_cabi.load().ops_frame_workspace_bytes(2, topo.n_eq, topo.kd)) - int(_cabi.load().ops_frame_workspace_bytes(1, topo.n_eq, topo.kd))   # per frame (the call-wide assembly plan excluded)
         io_frame = 8 * (topo.Ne + 3 * topo.Nn + 8 * topo.Ne)       # I in; disp, forces, V, M out
         # the factor workspace is written once by the factorisation (the assembly is fused: the assembled band never exists
         # in HBM) and read once by the backward sweep: 2 passes over it per frame, plus the inputs / outputs
