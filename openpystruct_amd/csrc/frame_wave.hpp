@@ -47,6 +47,22 @@ __device__ __forceinline__ double fw_readlane(double v, int lane) {
   const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane), hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
   return __hiloint2double(hi, lo);
 }
+// sum over the 64 lanes, result in every lane: DPP butterflies inside the 16-lane rows (quad_perm, row_half_mirror,
+// row_mirror: no LDS), then the four row totals through SGPRs
+template <int CTRL>
+__device__ __forceinline__ double fw_dpp(double x) {
+  const unsigned long long u = __builtin_bit_cast(unsigned long long, x);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)u, CTRL, 0xF, 0xF, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(u >> 32), CTRL, 0xF, 0xF, true);
+  return __builtin_bit_cast(double, ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
+}
+__device__ __forceinline__ double fw_wave_sum(double v) {
+  v += fw_dpp<0xB1>(v);      // quad_perm [1,0,3,2]
+  v += fw_dpp<0x4E>(v);      // quad_perm [2,3,0,1]
+  v += fw_dpp<0x141>(v);     // row_half_mirror
+  v += fw_dpp<0x140>(v);     // row_mirror: every lane holds its row's total
+  return (fw_readlane(v, 0) + fw_readlane(v, 16)) + (fw_readlane(v, 32) + fw_readlane(v, 48));
+}
 // LDS operations of one wave execute in order; this pins the compiler and lands earlier reads
 __device__ __forceinline__ void fw_fence() {
   __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0)
@@ -345,6 +361,35 @@ __device__ __forceinline__ void frame_wave_body(const FrameParams& p, double* __
   }
   fw_fence();
 
+  // ---- backward substitution, dot form (W >= 36): x_j = w_j - sum_t L[j+t][j] x_{j+t}; lane (R mod 64) holds x_R; column j
+  // of L is ONE coalesced load (fetched eight steps ahead), the sum a DPP / readlane wave reduction.  Measured against the
+  // axpy form below (every lane walks its own column of L: up to kd distinct cache lines per load instruction):
+  // 15 x 16: 5.56 -> 4.46 ms per 12 288 frames, 10 x 10: 2.48 -> 2.35 ms per 16 384; 5 x 5 (kd = 20): 2 % slower, keeps axpy ----
+  if constexpr (W >= 36) {
+    constexpr int PDD = 8;
+    double xr = 0.0, cq[PDD];
+    auto cfetch = [&](int j) -> double {
+      const int rel = (lane - j) & 63;
+      return (j >= 0 && rel >= 1 && rel <= kd && j + rel < n) ? rows[(size_t)j * W + (rel - 1)] : 0.0;
+    };
+#pragma unroll
+    for (int u = 0; u < PDD; ++u) cq[u] = cfetch(n - 1 - u);
+    for (int jb = n - 1; jb >= 0; jb -= PDD) {
+#pragma unroll
+      for (int u = 0; u < PDD; ++u) {
+        const int j = jb - u;
+        if (j >= 0) {
+          const double s_ = fw_wave_sum(cq[u] * xr);
+          cq[u] = cfetch(j - PDD);
+          const double xj = xs[j] - s_;
+          if (((lane - j) & 63) == 0) { xr = xj; xs[j] = xj; }
+        }
+      }
+    }
+    fw_fence();
+    write_results(p, b, xs, bad != 0, lane, 64);
+    return;
+  }
   // ---- backward substitution, axpy form: lane (R mod 64) carries w_R while R is within kd of the current column ----
   // x_j = w_j - sum_{R > j} L[R][j] x_R, processed as: x_j is final when step j starts; rows i = j - kd .. j - 1 then take
   // w_i -= L[j][i] x_j.  Row i enters the window (picks up w_i from LDS) at step j = i + kd; the last kd rows start inside.
