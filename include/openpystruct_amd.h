@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define OPS_AMD_ABI_VERSION 2
+#define OPS_AMD_ABI_VERSION 3
 
 /* return codes of the launch functions (per-beam results are in `status`) */
 #define OPS_AMD_OK 0
@@ -273,6 +273,91 @@ int ops_fused_bn_act_bwd(int B, int F, const void* dy, int act_is_bf16, const vo
  * device memory advanced by the call (NULL: a fixed stream). */
 int ops_gather_rows_noise_f32(int B, long F, const float* X, const long long* idx, const float* sigma, unsigned long long seed,
                               unsigned long long* counter, void* out, int out_is_bf16, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Layer blocks of the PINN's residual MLP (PINN_MultiCase.py:395-541) for batches of up to 128 rows: ONE launch per
+ * Linear -> [+ Conv1d/BatchNorm1d(1) stencil + residual] -> BatchNorm1d -> LeakyReLU -> dropout, and one per backward
+ * counterpart (bf16 MFMA, fp32 accumulation and statistics).  csrc/mlp_block.hip; host side: openpystruct_amd/pinn_fused.py.
+ *
+ * Layout contract.  Every activation / gradient matrix X [B, F] lives twice, bfloat16, zero outside the live B x F corner:
+ *   row-major  X  [128, ld]        ld >= F rounded up to 32 (the GEMM's reduction runs over whole 32-column steps)
+ *   transposed Xt [F rounded up to 32, 128]
+ * and every weight W [N, K] twice as well: Wp [N rounded up to 16, K rounded up to 32] and Wtp [K r.u. 16, N r.u. 32]
+ * (ops_mlp_repack_weights writes both from the float32 parameters).  All leading dimensions are multiples of 8 elements.
+ * -----------------------------------------------------------------------------------------------------------------*/
+#define OPS_MLP_MAX_ROWS 128
+/* tails (`tail`): what follows the product in the same launch */
+#define OPS_MLP_TAIL_NONE 0            /* Y = A W^T + bias                                            (output layer) */
+#define OPS_MLP_TAIL_ACT_DROP 1        /* dropout(LeakyReLU(.))                                       (block fc1) */
+#define OPS_MLP_TAIL_BN_ACT_DROP 2     /* dropout(LeakyReLU(BatchNorm1d(.)))                          (input layer) */
+#define OPS_MLP_TAIL_BN 3              /* BatchNorm1d(.)                                              (block fc2 + norm) */
+#define OPS_MLP_TAIL_BWD_ACT_DROP 4    /* gradient through TAIL_ACT_DROP of the layer below; dbias = column sums */
+#define OPS_MLP_TAIL_BWD_BN 5          /* gradient through TAIL_BN of the layer below; dgamma, dbeta, dbias */
+#define OPS_MLP_TAIL_BWD_BN_ACT_DROP 6 /* gradient through TAIL_BN_ACT_DROP of the layer below; dgamma, dbeta, dbias */
+/* addends (`add_mode`) joined to the product before the tail */
+#define OPS_MLP_ADD_NONE 0
+#define OPS_MLP_ADD_FWD_BLOCK 1        /* + bn1(conv1(O)) + O: the ResidualBlock's stencil path and identity (O = block input) */
+#define OPS_MLP_ADD_BWD_BLOCK 2        /* + dZ + conv1^T(bn1 backward(dZ)): the gradient the block input receives from them */
+/* side jobs (`side`): per-workgroup partial sums for the whole-tensor BatchNorm1d(1), consumed by the NEXT launch */
+#define OPS_MLP_SIDE_NONE 0
+#define OPS_MLP_SIDE_FWD_STENCIL_STATS 1
+#define OPS_MLP_SIDE_BWD_STENCIL_SUMS 2
+
+typedef struct ops_mlp_strip_args {
+  int32_t B, N, K;                 /* live rows (1..128), output columns, reduction length */
+  int32_t tail, add_mode, side;
+  const void* A; int32_t lda;      /* [128, lda] bfloat16 */
+  const void* W; int32_t ldw;      /* [N r.u. 16, ldw] bfloat16: forward Wp of the layer, backward Wtp of the layer above */
+  const float* bias;               /* [N] float32 or NULL (forward tails; rounded to bfloat16 as autocast does) */
+  void* Y; int32_t ldy; void* Yt;  /* result, both layouts (Yt may be NULL) */
+  /* BatchNorm1d of the tail: forward writes mean / rstd / Zt (the pre-normalisation values, transposed), backward reads them */
+  const float* gamma; const float* beta; float eps, momentum;
+  float* running_mean; float* running_var; long long* num_batches_tracked;
+  float* mean; float* rstd; void* Zt;
+  const void* Yref_t;              /* backward of an activation/dropout tail: that layer's forward OUTPUT, transposed */
+  float slope, p_drop;
+  unsigned long long seed; unsigned long long* call_counter;   /* dropout stream (device counter advanced by the launch) */
+  float* dgamma; float* dbeta; float* dbias;                    /* ASSIGNED */
+  /* stencil path: Conv1d(1,1,3,padding=1) + BatchNorm1d(1) over the block input O [B, No] */
+  const void* Ot; int32_t No;      /* transposed block input */
+  const void* dZt;                 /* ADD_BWD_BLOCK / SIDE_BWD: gradient at the block's sum, transposed */
+  const float* conv_w; const float* conv_b; const float* sgamma; const float* sbeta; float seps, smomentum;
+  float* srunning_mean; float* srunning_var; long long* snum_batches_tracked;
+  float* ssave;                    /* [2] mean, 1/std of the stencil normalisation (forward writes, backward reads) */
+  double* spart; int32_t spart_rows; /* partial sums: SIDE_* writes gridDim rows, ADD_* reads spart_rows rows (2 or 12 doubles each) */
+  float* sdparams;                 /* [6] ASSIGNED by ADD_BWD_BLOCK: d conv_w[3], d conv_b, d gamma, d beta */
+} ops_mlp_strip_args;
+
+/* One strip launch: workgroup = 128 rows x 16 output columns.  Returns OPS_AMD_ERR_INVALID_ARG on a broken layout contract. */
+int ops_mlp_strip_launch(const ops_mlp_strip_args* args, void* stream);
+/* doubles of `spart` a launch with `side` needs for N output columns */
+size_t ops_mlp_spart_doubles(int N);
+
+/* All weight gradients of a step in one launch: out_i [N_i, K_i] float32 (ASSIGNED, row stride ldo_i) = At_i [N_i r.u. 32, 128] x
+ * Bt_i [K_i r.u. 32, 128]^T, the transposed layouts of the layer's output gradient and of its input. */
+typedef struct ops_mlp_wgrad_problem {
+  const void* At; const void* Bt; float* out; int32_t N, K, ldo;
+} ops_mlp_wgrad_problem;
+#define OPS_MLP_MAX_WGRAD 8
+int ops_mlp_wgrad_group(int nprob, const ops_mlp_wgrad_problem* problems, void* stream);
+
+/* Wp / Wtp of up to 8 weight matrices from the float32 parameters W_i [N_i, K_i] in one launch. */
+typedef struct ops_mlp_repack_entry {
+  const float* W; int32_t N, K; void* Wp; int32_t ldw; void* Wtp; int32_t ldwt;
+} ops_mlp_repack_entry;
+int ops_mlp_repack_weights(int nmat, const ops_mlp_repack_entry* entries, void* stream);
+
+/* ops_gather_rows_noise_f32 writing the layout above: out [128, ld] and out_t [F r.u. 32, 128] bfloat16, rows >= B zeroed. */
+int ops_mlp_gather_noise(int B, int F, const float* X, const long long* idx, const float* sigma, unsigned long long seed,
+                         unsigned long long* counter, void* out, int ld, void* out_t, void* stream);
+
+/* ops_surrogate_loss_grad_f32 on that layout: preds [128, ldp] bfloat16 -> loss (one float), grad [128, ldg] and grad_t
+ * [C r.u. 32, 128] bfloat16, dbias [C] (column sums of the gradient: the output layer's bias gradient, ASSIGNED).
+ * `workspace`: ops_mlp_loss_workspace_bytes() bytes, zero-initialised ONCE by the caller (the launch leaves it zeroed). */
+int ops_mlp_loss_grad(int B, int C, int nI, int nD, const void* preds, int ldp, const float* targets, const float* alpha, float alpha0,
+                      const float* min_constraint, const float* max_constraint, float box_weight, float rel_penalty, float* loss,
+                      void* grad, int ldg, void* grad_t, float* dbias, void* workspace, void* stream);
+size_t ops_mlp_loss_workspace_bytes(void);
 
 #ifdef __cplusplus
 }

@@ -9,7 +9,7 @@ import ctypes
 import os
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-ABI_VERSION = 2      # include/openpystruct_amd.h OPS_AMD_ABI_VERSION
+ABI_VERSION = 3      # include/openpystruct_amd.h OPS_AMD_ABI_VERSION
 # OPS_AMD_LIB lets A/B kernel experiments point at another build of the same C ABI
 LIB_PATH = os.environ.get("OPS_AMD_LIB") or os.path.join(_PKG, "lib", "libopenpystruct_amd.so")
 
@@ -42,6 +42,13 @@ EXPORTS = (
     "ops_fused_bn_act_bwd",
     "ops_amd_last_error",
     "ops_beam_solve_kernel_name",
+    "ops_mlp_strip_launch",
+    "ops_mlp_spart_doubles",
+    "ops_mlp_wgrad_group",
+    "ops_mlp_repack_weights",
+    "ops_mlp_gather_noise",
+    "ops_mlp_loss_grad",
+    "ops_mlp_loss_workspace_bytes",
 )
 
 OK, ERR_INVALID_ARG, ERR_UNSUPPORTED, ERR_LAUNCH = 0, 1, 2, 3
@@ -55,6 +62,44 @@ class SizingParams(ctypes.Structure):
     _fields_ = [(n, ctypes.c_double) for n in (
         "E", "G", "alpha_moment", "alpha_shear", "lr", "gamma", "beta1", "beta2", "adam_eps",
         "clamp_min", "bend_eps", "area_coef", "tolerance")] + [("patience", ctypes.c_int32), ("max_epochs", ctypes.c_int32)]
+
+
+# layer blocks of the PINN training step (include/openpystruct_amd.h, csrc/mlp_block.hip)
+MLP_MAX_ROWS = 128
+MLP_TAIL_NONE, MLP_TAIL_ACT_DROP, MLP_TAIL_BN_ACT_DROP, MLP_TAIL_BN = 0, 1, 2, 3
+MLP_TAIL_BWD_ACT_DROP, MLP_TAIL_BWD_BN, MLP_TAIL_BWD_BN_ACT_DROP = 4, 5, 6
+MLP_ADD_NONE, MLP_ADD_FWD_BLOCK, MLP_ADD_BWD_BLOCK = 0, 1, 2
+MLP_SIDE_NONE, MLP_SIDE_FWD_STENCIL_STATS, MLP_SIDE_BWD_STENCIL_SUMS = 0, 1, 2
+MLP_MAX_WGRAD = 8
+
+
+class MlpStripArgs(ctypes.Structure):
+    """Mirror of `ops_mlp_strip_args`."""
+    _vp, _i, _f = ctypes.c_void_p, ctypes.c_int32, ctypes.c_float
+    _fields_ = [("B", _i), ("N", _i), ("K", _i), ("tail", _i), ("add_mode", _i), ("side", _i),
+                ("A", _vp), ("lda", _i), ("W", _vp), ("ldw", _i), ("bias", _vp),
+                ("Y", _vp), ("ldy", _i), ("Yt", _vp),
+                ("gamma", _vp), ("beta", _vp), ("eps", _f), ("momentum", _f),
+                ("running_mean", _vp), ("running_var", _vp), ("num_batches_tracked", _vp),
+                ("mean", _vp), ("rstd", _vp), ("Zt", _vp), ("Yref_t", _vp),
+                ("slope", _f), ("p_drop", _f), ("seed", ctypes.c_ulonglong), ("call_counter", _vp),
+                ("dgamma", _vp), ("dbeta", _vp), ("dbias", _vp),
+                ("Ot", _vp), ("No", _i), ("dZt", _vp),
+                ("conv_w", _vp), ("conv_b", _vp), ("sgamma", _vp), ("sbeta", _vp), ("seps", _f), ("smomentum", _f),
+                ("srunning_mean", _vp), ("srunning_var", _vp), ("snum_batches_tracked", _vp),
+                ("ssave", _vp), ("spart", _vp), ("spart_rows", _i), ("sdparams", _vp)]
+
+
+class MlpWgradProblem(ctypes.Structure):
+    """Mirror of `ops_mlp_wgrad_problem`."""
+    _fields_ = [("At", ctypes.c_void_p), ("Bt", ctypes.c_void_p), ("out", ctypes.c_void_p), ("N", ctypes.c_int32), ("K", ctypes.c_int32),
+                ("ldo", ctypes.c_int32)]
+
+
+class MlpRepackEntry(ctypes.Structure):
+    """Mirror of `ops_mlp_repack_entry`."""
+    _fields_ = [("W", ctypes.c_void_p), ("N", ctypes.c_int32), ("K", ctypes.c_int32), ("Wp", ctypes.c_void_p), ("ldw", ctypes.c_int32),
+                ("Wtp", ctypes.c_void_p), ("ldwt", ctypes.c_int32)]
 
 
 class ExtensionMissingError(RuntimeError):
@@ -127,6 +172,19 @@ def load():
     lib.ops_beam_solve_lane_per_beam_f64.argtypes = [it, it] + [vp] * 12 + [ctypes.c_size_t, vp]
     lib.ops_beam_solve_lane_workspace_bytes.restype = ctypes.c_size_t
     lib.ops_beam_solve_lane_workspace_bytes.argtypes = [it, it]
+    lib.ops_mlp_strip_launch.restype = it
+    lib.ops_mlp_strip_launch.argtypes = [ctypes.POINTER(MlpStripArgs), vp]
+    lib.ops_mlp_spart_doubles.restype = ctypes.c_size_t
+    lib.ops_mlp_spart_doubles.argtypes = [it]
+    lib.ops_mlp_wgrad_group.restype = it
+    lib.ops_mlp_wgrad_group.argtypes = [it, ctypes.POINTER(MlpWgradProblem), vp]
+    lib.ops_mlp_repack_weights.restype = it
+    lib.ops_mlp_repack_weights.argtypes = [it, ctypes.POINTER(MlpRepackEntry), vp]
+    lib.ops_mlp_gather_noise.restype = it
+    lib.ops_mlp_gather_noise.argtypes = [it, it, vp, vp, vp, ull, vp, vp, it, vp, vp]
+    lib.ops_mlp_loss_grad.restype = it
+    lib.ops_mlp_loss_grad.argtypes = [it, it, it, it, vp, it, vp, vp, fl, vp, vp, fl, fl, vp, vp, it, vp, vp, vp, vp]
+    lib.ops_mlp_loss_workspace_bytes.restype = ctypes.c_size_t
     lib.ops_amd_max_elements.restype = it
     lib.ops_amd_abi_version.restype = it
     lib.ops_amd_last_error.restype = ctypes.c_char_p

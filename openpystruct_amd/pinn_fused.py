@@ -1,0 +1,274 @@
+"""The PINN's training step as 17 launches: host side of csrc/mlp_block.hip.
+
+`FNNWithResidual` (/root/reference/OpenPyStruct_PINN_MultiCase.py:454-541) + `CompositeLoss` (:603-653), forward AND backward,
+for batches of up to 128 rows, without autograd: every `Linear -> [stencil + residual] -> BatchNorm1d -> LeakyReLU -> dropout`
+group is one launch, so is each backward counterpart, all weight gradients are one grouped launch, and every parameter
+gradient is written straight into the training loop's flat gradient buffer.  The module itself stays the owner of the
+parameters and BatchNorm buffers (the launches read and update them in place); evaluation keeps using the module.
+
+    repack | input | (fc1, fc2+stencil+norm) x blocks | output | loss || d output | (d fc2, d fc1) x blocks | weight gradients
+
+Layout contract (include/openpystruct_amd.h): every activation / gradient exists row-major [128, ld] and transposed
+[F r.u. 32, 128] in bfloat16, zero outside the live corner; the buffers below are zero-initialised once and the launches
+only ever write zeros into dead rows / columns.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from typing import List
+
+import torch
+import torch.nn as nn
+
+from . import _cabi
+from .surrogates import CompositeLoss, FNNWithResidual, ResidualBlock
+
+ENABLED = os.environ.get("OPS_AMD_PINN_LAYER_BLOCKS", "1") == "1"      # A/B switch: 0 = autograd over the fused tails
+
+
+def _ru(v: int, m: int) -> int:
+    return (v + m - 1) // m * m
+
+
+def eligible(model: nn.Module, crit: nn.Module, batch_size: int) -> bool:
+    """The launches cover exactly the reference's configuration family: BatchNorm1d norms, blocks with the 3-tap Conv1d
+    path, batches of up to 128 rows, float32 parameters."""
+    if not (ENABLED and isinstance(model, FNNWithResidual) and isinstance(crit, CompositeLoss)):
+        return False
+    if model.norm_type != "batch" or type(model.input_norm) is not nn.BatchNorm1d or batch_size > _cabi.MLP_MAX_ROWS:
+        return False
+    if len(model.residual_blocks) < 1:
+        return False
+    for blk in model.residual_blocks:
+        rb, norm = blk[0], blk[1]
+        if not (isinstance(rb, ResidualBlock) and rb.use_conv and rb.conv1.kernel_size == (3,) and rb.conv1.padding == (1,)
+                and rb.conv1.bias is not None and type(norm) is nn.BatchNorm1d and rb.bn1.affine and rb.bn1.track_running_stats):
+            return False
+    for bn in [model.input_norm] + [b[1] for b in model.residual_blocks] + [b[0].bn1 for b in model.residual_blocks]:
+        if not (bn.affine and bn.track_running_stats and bn.momentum is not None):
+            return False
+    return all(p.dtype == torch.float32 and p.is_cuda for p in model.parameters())
+
+
+class PinnFusedStep:
+    """Buffers and launch descriptors of one model; `gather()` assembles a batch, `fwd_bwd(B, targets)` leaves the loss in
+    `self.loss` and the gradients of the mean batch loss in the parameters' `.grad` (views of the caller's flat buffer)."""
+
+    def __init__(self, model: FNNWithResidual, crit: CompositeLoss, seed: int = 0):
+        self.lib = _cabi.load()
+        self.model, self.crit = model, crit
+        dev = next(model.parameters()).device
+        self.dev = dev
+        for p in model.parameters():
+            if p.grad is None or p.grad.dtype != torch.float32 or not p.grad.is_contiguous():
+                raise ValueError("every parameter needs a contiguous float32 .grad (the training loop's flat buffer)")
+        R = _cabi.MLP_MAX_ROWS
+        bf = torch.bfloat16
+        self.F_in = model.input_fc.in_features
+        self.H = model.input_fc.out_features
+        self.C = model.output_fc.out_features
+        self.nblk = len(model.residual_blocks)
+        self.Hh = model.residual_blocks[0][0].fc1.out_features
+        self._keep: List[object] = []
+
+        def act(F):     # row-major [128, ld] + transposed [F r.u. 32, 128]
+            return (torch.zeros(R, _ru(F, 32), dtype=bf, device=dev), torch.zeros(_ru(F, 32), R, dtype=bf, device=dev))
+
+        def tr(F):
+            return torch.zeros(_ru(F, 32), R, dtype=bf, device=dev)
+
+        def wpair(lin: nn.Linear):
+            N, K = lin.weight.shape
+            return (torch.zeros(_ru(N, 16), _ru(K, 32), dtype=bf, device=dev), torch.zeros(_ru(K, 16), _ru(N, 32), dtype=bf, device=dev))
+
+        H, Hh, C, Fi = self.H, self.Hh, self.C, self.F_in
+        self.x, self.xt = act(Fi)
+        self.o = [act(H) for _ in range(self.nblk + 1)]            # o[0] = input layer output, o[k] = block k output
+        self.v0t = tr(H)                                           # input layer: pre-normalisation values
+        self.h = [act(Hh) for _ in range(self.nblk)]
+        self.zt = [tr(H) for _ in range(self.nblk)]                # block sums before the norm
+        self.preds = torch.zeros(R, _ru(C, 32), dtype=bf, device=dev)
+        self.gp, self.gpt = act(C)                                 # d loss / d preds
+        self.dz = [act(H) for _ in range(self.nblk + 1)]           # dz[0] = gradient at input_fc's output, dz[k] = at block k's sum
+        self.dh = [act(Hh) for _ in range(self.nblk)]
+        f32 = lambda n: torch.zeros(n, dtype=torch.float32, device=dev)      # noqa: E731
+        self.mean = [f32(H) for _ in range(self.nblk + 1)]
+        self.rstd = [f32(H) for _ in range(self.nblk + 1)]
+        self.ssave = [f32(2) for _ in range(self.nblk)]
+        nsp = int(self.lib.ops_mlp_spart_doubles(max(H, Hh)))
+        self.spart_f = [torch.zeros(nsp, dtype=torch.float64, device=dev) for _ in range(self.nblk)]
+        self.spart_b = [torch.zeros(nsp, dtype=torch.float64, device=dev) for _ in range(self.nblk)]
+        self.loss = torch.zeros((), dtype=torch.float32, device=dev)
+        self.loss_ws = torch.zeros(int(self.lib.ops_mlp_loss_workspace_bytes()), dtype=torch.uint8, device=dev)
+        self.drop_counter = torch.zeros(2, dtype=torch.int64, device=dev)
+        self.prep_counter = torch.zeros(1, dtype=torch.int64, device=dev)
+        self.seed = int(seed) & 0x7FFFFFFFFFFFFFFF
+
+        lins = [model.input_fc] + [l for b in model.residual_blocks for l in (b[0].fc1, b[0].fc2)] + [model.output_fc]
+        if len(lins) > _cabi.MLP_MAX_WGRAD:
+            raise ValueError("too many Linear layers for one grouped launch")
+        self.wp = {id(l): wpair(l) for l in lins}
+        ent = (_cabi.MlpRepackEntry * len(lins))()
+        for e, l in zip(ent, lins):
+            wp, wtp = self.wp[id(l)]
+            e.W, e.N, e.K = l.weight.data_ptr(), l.weight.shape[0], l.weight.shape[1]
+            e.Wp, e.ldw, e.Wtp, e.ldwt = wp.data_ptr(), wp.shape[1], wtp.data_ptr(), wtp.shape[1]
+        self._repack = ent
+
+        l1l2 = crit.l1l2_loss
+        self._alpha = l1l2.alpha.detach()
+        sc = lambda v: None if v is None else (v if torch.is_tensor(v) else torch.tensor(float(v))).to(device=dev, dtype=torch.float32).reshape(())   # noqa: E731
+        self._minc, self._maxc = sc(l1l2.min_constraint), sc(l1l2.max_constraint)
+        self._build()
+
+    # ---- launch descriptors (built once: every pointer is stable, so the sequence can be captured in a HIP graph) ----
+    def _strip(self, **kw) -> _cabi.MlpStripArgs:
+        a = _cabi.MlpStripArgs()
+        for k, v in kw.items():
+            if torch.is_tensor(v):
+                self._keep.append(v)
+                v = v.data_ptr()
+            setattr(a, k, v)
+        return a
+
+    def _bn_fwd(self, bn: nn.BatchNorm1d, i: int):
+        return dict(gamma=bn.weight, beta=bn.bias, eps=float(bn.eps), momentum=float(bn.momentum), running_mean=bn.running_mean,
+                    running_var=bn.running_var, num_batches_tracked=bn.num_batches_tracked, mean=self.mean[i], rstd=self.rstd[i])
+
+    def _bn_bwd(self, bn: nn.BatchNorm1d, i: int):
+        return dict(gamma=bn.weight, beta=bn.bias, eps=float(bn.eps), mean=self.mean[i], rstd=self.rstd[i], dgamma=bn.weight.grad,
+                    dbeta=bn.bias.grad)
+
+    def _stencil(self, rb: ResidualBlock, k: int):
+        return dict(conv_w=rb.conv1.weight, conv_b=rb.conv1.bias, sgamma=rb.bn1.weight, sbeta=rb.bn1.bias, seps=float(rb.bn1.eps),
+                    smomentum=float(rb.bn1.momentum), srunning_mean=rb.bn1.running_mean, srunning_var=rb.bn1.running_var,
+                    snum_batches_tracked=rb.bn1.num_batches_tracked, ssave=self.ssave[k], No=self.H)
+
+    def _build(self) -> None:
+        m, C = self.model, _cabi
+        H, Hh, Fi, Co = self.H, self.Hh, self.F_in, self.C
+        G1 = (Hh + 15) // 16                                     # workgroups of an fc1-shaped launch = rows of partial sums
+        slope, pd = float(m.Leaky.negative_slope), float(m.dropout.p)
+        fwd, bwd = [], []
+        wp, wtp = self.wp[id(m.input_fc)]
+        fwd.append(self._strip(N=H, K=Fi, tail=C.MLP_TAIL_BN_ACT_DROP, A=self.x, lda=self.x.shape[1], W=wp, ldw=wp.shape[1],
+                               bias=m.input_fc.bias, Y=self.o[0][0], ldy=self.o[0][0].shape[1], Yt=self.o[0][1], Zt=self.v0t,
+                               slope=slope, p_drop=pd, seed=self.seed, call_counter=self.drop_counter, **self._bn_fwd(m.input_norm, 0)))
+        for k, blk in enumerate(m.residual_blocks):
+            rb, norm = blk[0], blk[1]
+            o_in, o_in_t = self.o[k]
+            w1, _ = self.wp[id(rb.fc1)]
+            w2, _ = self.wp[id(rb.fc2)]
+            fwd.append(self._strip(N=Hh, K=H, tail=C.MLP_TAIL_ACT_DROP, side=C.MLP_SIDE_FWD_STENCIL_STATS, A=o_in, lda=o_in.shape[1], W=w1,
+                                   ldw=w1.shape[1], bias=rb.fc1.bias, Y=self.h[k][0], ldy=self.h[k][0].shape[1], Yt=self.h[k][1],
+                                   slope=float(rb.Leaky.negative_slope), p_drop=float(rb.dropout.p), seed=self.seed + 2 * k + 1,
+                                   call_counter=self.drop_counter, Ot=o_in_t, spart=self.spart_f[k], **self._stencil(rb, k)))
+            fwd.append(self._strip(N=H, K=Hh, tail=C.MLP_TAIL_BN, add_mode=C.MLP_ADD_FWD_BLOCK, A=self.h[k][0], lda=self.h[k][0].shape[1],
+                                   W=w2, ldw=w2.shape[1], bias=rb.fc2.bias, Y=self.o[k + 1][0], ldy=self.o[k + 1][0].shape[1],
+                                   Yt=self.o[k + 1][1], Zt=self.zt[k], Ot=o_in_t, spart=self.spart_f[k], spart_rows=G1,
+                                   **self._bn_fwd(norm, k + 1), **self._stencil(rb, k)))
+        wo, wot = self.wp[id(m.output_fc)]
+        o_last = self.o[self.nblk]
+        fwd.append(self._strip(N=Co, K=H, tail=C.MLP_TAIL_NONE, A=o_last[0], lda=o_last[0].shape[1], W=wo, ldw=wo.shape[1],
+                               bias=m.output_fc.bias, Y=self.preds, ldy=self.preds.shape[1]))
+        # backward: d preds -> gradient at the last block's sum (through its norm)
+        last_blk = m.residual_blocks[self.nblk - 1]
+        bwd.append(self._strip(N=H, K=Co, tail=C.MLP_TAIL_BWD_BN, A=self.gp, lda=self.gp.shape[1], W=wot, ldw=wot.shape[1],
+                               Y=self.dz[self.nblk][0], ldy=self.dz[self.nblk][0].shape[1], Yt=self.dz[self.nblk][1], Zt=self.zt[self.nblk - 1],
+                               dbias=last_blk[0].fc2.bias.grad, **self._bn_bwd(last_blk[1], self.nblk)))
+        for k in range(self.nblk - 1, -1, -1):
+            rb = m.residual_blocks[k][0]
+            o_in, o_in_t = self.o[k]
+            dzk, dzk_t = self.dz[k + 1]
+            _, w1t = self.wp[id(rb.fc1)]
+            _, w2t = self.wp[id(rb.fc2)]
+            bwd.append(self._strip(N=Hh, K=H, tail=C.MLP_TAIL_BWD_ACT_DROP, side=C.MLP_SIDE_BWD_STENCIL_SUMS, A=dzk, lda=dzk.shape[1], W=w2t,
+                                   ldw=w2t.shape[1], Y=self.dh[k][0], ldy=self.dh[k][0].shape[1], Yt=self.dh[k][1], Yref_t=self.h[k][1],
+                                   slope=float(rb.Leaky.negative_slope), p_drop=float(rb.dropout.p), dbias=rb.fc1.bias.grad, Ot=o_in_t,
+                                   dZt=dzk_t, spart=self.spart_b[k], **self._stencil(rb, k)))
+            if k > 0:
+                prev = m.residual_blocks[k - 1]
+                tail = dict(tail=C.MLP_TAIL_BWD_BN, Zt=self.zt[k - 1], dbias=prev[0].fc2.bias.grad, **self._bn_bwd(prev[1], k))
+            else:
+                tail = dict(tail=C.MLP_TAIL_BWD_BN_ACT_DROP, Zt=self.v0t, Yref_t=self.o[0][1], slope=slope, p_drop=pd,
+                            dbias=m.input_fc.bias.grad, **self._bn_bwd(m.input_norm, 0))
+            if rb.conv1.bias.grad.data_ptr() != rb.conv1.weight.grad.data_ptr() + 12 or rb.bn1.weight.grad.data_ptr() != \
+                    rb.conv1.weight.grad.data_ptr() + 16 or rb.bn1.bias.grad.data_ptr() != rb.conv1.weight.grad.data_ptr() + 20:
+                raise ValueError("conv1.weight/.bias and bn1.weight/.bias gradients must be six consecutive floats of the flat buffer")
+            bwd.append(self._strip(N=H, K=Hh, add_mode=C.MLP_ADD_BWD_BLOCK, A=self.dh[k][0], lda=self.dh[k][0].shape[1], W=w1t,
+                                   ldw=w1t.shape[1], Y=self.dz[k][0], ldy=self.dz[k][0].shape[1], Yt=self.dz[k][1], Ot=o_in_t, dZt=dzk_t,
+                                   spart=self.spart_b[k], spart_rows=G1, sdparams=rb.conv1.weight.grad, **tail, **self._stencil(rb, k)))
+        self._fwd, self._bwd = fwd, bwd
+        # grouped weight gradients
+        probs = []
+        probs.append((self.gpt, o_last[1], m.output_fc.weight))
+        for k in range(self.nblk):
+            rb = m.residual_blocks[k][0]
+            probs.append((self.dz[k + 1][1], self.h[k][1], rb.fc2.weight))
+            probs.append((self.dh[k][1], self.o[k][1], rb.fc1.weight))
+        probs.append((self.dz[0][1], self.xt, m.input_fc.weight))
+        wg = (_cabi.MlpWgradProblem * len(probs))()
+        for e, (at, bt, w) in zip(wg, probs):
+            e.At, e.Bt, e.out, e.N, e.K, e.ldo = at.data_ptr(), bt.data_ptr(), w.grad.data_ptr(), w.shape[0], w.shape[1], w.shape[1]
+        self._wgrad = wg
+        covered = sum(p.numel() for p in m.parameters())
+        named = sum(l.weight.numel() + l.bias.numel() for l in [m.input_fc, m.output_fc] + [x for b in m.residual_blocks for x in (b[0].fc1, b[0].fc2)])
+        named += sum(2 * bn.weight.numel() for bn in [m.input_norm] + [b[1] for b in m.residual_blocks]) + 6 * self.nblk
+        if covered != named:
+            raise ValueError("the model has parameters the layer-block launches do not cover")
+
+    def _check(self, rc: int, what: str) -> None:
+        if rc != _cabi.OK:
+            raise RuntimeError(f"{what} failed with code {rc}: {self.lib.ops_amd_last_error().decode()}")
+
+    # ---- the step ----
+    def gather(self, X: torch.Tensor, idx: torch.Tensor, sigma: torch.Tensor, seed: int) -> int:
+        """x <- X[idx] + sigma * N(0, 1), both layouts (PINN:748-756).  Returns the number of live rows."""
+        B = int(idx.numel())
+        s = torch.cuda.current_stream(self.dev).cuda_stream
+        with torch.cuda.device(self.dev):
+            self._check(self.lib.ops_mlp_gather_noise(B, self.F_in, X.data_ptr(), idx.data_ptr(), sigma.data_ptr() if sigma is not None else None,
+                                                      int(seed) & 0x7FFFFFFFFFFFFFFF, self.prep_counter.data_ptr(), self.x.data_ptr(),
+                                                      self.x.shape[1], self.xt.data_ptr(), s), "ops_mlp_gather_noise")
+        return B
+
+    def set_input(self, Xb: torch.Tensor) -> int:
+        """Tests / eager callers: a ready batch [B, F_in] instead of gather()."""
+        B = Xb.shape[0]
+        self.x.zero_(); self.xt.zero_()
+        xb = Xb.to(torch.bfloat16)
+        self.x[:B, :self.F_in] = xb
+        self.xt[:self.F_in, :B] = xb.t()
+        return B
+
+    def forward(self, B: int, stream=None) -> None:
+        s = stream if stream is not None else torch.cuda.current_stream(self.dev).cuda_stream
+        self._check(self.lib.ops_mlp_repack_weights(len(self._repack), self._repack, s), "ops_mlp_repack_weights")
+        for a in self._fwd:
+            a.B = B
+            self._check(self.lib.ops_mlp_strip_launch(ctypes.byref(a), s), "ops_mlp_strip_launch (forward)")
+
+    def fwd_bwd(self, B: int, targets: torch.Tensor) -> torch.Tensor:
+        """Loss of the batch in x (mean over its B rows) and all parameter gradients.  targets: [>= B, C] float32, contiguous."""
+        crit, l1l2 = self.crit, self.crit.l1l2_loss
+        if B < 2:
+            raise ValueError("Expected more than 1 value per channel when training (BatchNorm1d batch statistics)")
+        s = torch.cuda.current_stream(self.dev).cuda_stream
+        with torch.cuda.device(self.dev):
+            self.forward(B, s)
+            self._check(self.lib.ops_mlp_loss_grad(B, self.C, crit.nelem, crit.deflection_dim, self.preds.data_ptr(), self.preds.shape[1],
+                                                   targets.data_ptr(), self._alpha.data_ptr(), float("nan"),
+                                                   self._minc.data_ptr() if self._minc is not None else None,
+                                                   self._maxc.data_ptr() if self._maxc is not None else None, float(l1l2.penalty_weight),
+                                                   float(crit.penalty_pinn), self.loss.data_ptr(), self.gp.data_ptr(), self.gp.shape[1],
+                                                   self.gpt.data_ptr(), self.model.output_fc.bias.grad.data_ptr(), self.loss_ws.data_ptr(), s),
+                        "ops_mlp_loss_grad")
+            for a in self._bwd:
+                a.B = B
+                self._check(self.lib.ops_mlp_strip_launch(ctypes.byref(a), s), "ops_mlp_strip_launch (backward)")
+            self._check(self.lib.ops_mlp_wgrad_group(len(self._wgrad), self._wgrad, s), "ops_mlp_wgrad_group")
+        return self.loss
+
+    def predictions(self, B: int) -> torch.Tensor:
+        return self.preds[:B, :self.C]

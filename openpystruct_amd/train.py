@@ -396,6 +396,13 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
         opt = (torch.optim.AdamW if kind == "gnn" else torch.optim.Adam)(model.parameters(), lr=cfg.learning_rate,   # GNN:394
                                                                          weight_decay=cfg.weight_decay)
         sched = ExponentialLR(opt, gamma=cfg.gamma)
+    # PINN: forward + loss + backward as 17 hand-written launches without autograd (pinn_fused.py / csrc/mlp_block.hip);
+    # the module keeps owning parameters and buffers, evaluation keeps running it
+    engine = None
+    if on_gpu and kind == "pinn" and autocast_dtype == torch.bfloat16 and physics is None and not (sync_bn and world > 1):
+        from . import pinn_fused
+        if pinn_fused.eligible(model, crit, cfg.batch_size):
+            engine = pinn_fused.PinnFusedStep(model, crit, seed=seed * 7919 + 101 + rank)
     Xtr, Ytr, Xva, Yva = (t.to(device) for t in (data.X_train, data.Y_train, data.X_val, data.Y_val))
     nb_tr = max(1, (Xtr.shape[0] + cfg.batch_size - 1) // cfg.batch_size)
     if world > 1:   # every rank must run the same number of steps (collectives inside backward)
@@ -447,6 +454,8 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
     def fwd_bwd(Xb, Yb, noise_t, pin=None, prenoised=False):
         """Segment A: local gradients of the mean batch loss into `flat`.  `prenoised`: Xb already is the gathered, noisy
         (and, under autocast, bfloat16) batch written by `gather_noise` -- one launch outside the graph instead of six nodes."""
+        if engine is not None:           # the batch sits in the engine's buffers (engine.gather); every gradient is assigned
+            return engine.fwd_bwd(int(Yb.shape[0]), Yb)
         Xn = Xb if prenoised else Xb + torch.randn_like(Xb) * noise_t   # PINN:756
         flat.zero_()                                                     # optimizer.zero_grad()
         with torch.autocast(device_type=device.type, dtype=autocast_dtype, enabled=use_ac):
@@ -475,6 +484,9 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
         opt.step()
 
     def train_step(Xb, Yb, noise_t, rows=None):
+        if engine is not None:
+            engine.gather(Xtr, rows, noise_t, engine_seed)
+            Yb = Yb.contiguous()
         loss = fwd_bwd(Xb, Yb, noise_t, physics_inputs(rows) if physics is not None else None)
         if world > 1:
             dist.all_reduce(flat)                                        # the step's only collective (RCCL over xGMI)
@@ -494,7 +506,12 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
     # bf16 batches only where the first module is a (shadow) Linear, which casts its operand to bf16 anyway
     prep_bf16 = bool(on_gpu and use_ac and autocast_dtype == torch.bfloat16 and patched and kind in ("pinn", "fnn", "gnn"))
 
+    engine_seed = (seed * 7919 + 13 + rank) & 0x7FFFFFFFFFFFFFFF
+
     def gather_noise(idx, out):
+        if engine is not None:           # straight into the engine's two layouts
+            engine.gather(Xtr, idx, s_noise, engine_seed)
+            return
         lib = opt._lib
         Fdim = 1
         for d_ in Xtr.shape[1:]:
@@ -523,6 +540,8 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
             sX.copy_(Xtr[:bs]); sY.copy_(Ytr[:bs])
             if sP is not None:
                 physics_inputs(torch.arange(bs, device=device), out=sP)
+            if engine is not None:
+                engine.gather(Xtr, torch.arange(bs, device=device), s_noise, engine_seed)
             for _ in range(3):
                 fwd_bwd(sX, sY, s_noise, sP, prenoised=_FUSED_PREP)
                 apply_update()                   # warm-up only: no collective needed for capture-readiness
@@ -590,7 +609,7 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
             # changes neither the batch statistics nor the mean loss, so it is folded into `order`
             idx = order[b * bs:(b + 1) * bs]
             if graph is not None and idx.numel() == bs:
-                if _FUSED_PREP:
+                if _FUSED_PREP or engine is not None:
                     gather_noise(idx, sX)                                    # gather + noise (+ bf16 cast) in one launch
                 else:
                     torch.index_select(Xtr, 0, idx, out=sX)                  # gather straight into the graph's input buffers

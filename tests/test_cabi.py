@@ -27,7 +27,7 @@ def test_header_symbols_are_exported(lib):
 
 
 def test_introspection_calls(lib):
-    assert lib.ops_amd_abi_version() == 2      # 2: ops_beam_sizing_epoch_f32 takes I_last (float32) instead of I64
+    assert lib.ops_amd_abi_version() == 3      # 2: ops_beam_sizing_epoch_f32 takes I_last (float32) instead of I64; 3: ops_mlp_* layer blocks
     assert lib.ops_amd_max_elements() >= 100
     assert b"beam_solve_kernel" in lib.ops_beam_solve_kernel_name(10000, 100, 0)
     assert lib.ops_beam_solve_kernel_name(10, 5000, 0) == b""
@@ -61,6 +61,19 @@ def test_argument_validation_without_gpu(lib):
     assert lib.ops_flat_clip_adam_step_f32(10, z, z, z, z, z, z, 1.0, 1.0, 0.9, 0.999, 1e-8, 0.0, 0, z, z, z) == _cabi.ERR_INVALID_ARG
     assert lib.ops_surrogate_loss_grad_f32(2, 3, 3, 0, z, 0, z, z, 0.5, z, z, 0.1, 0.0, z, z, z, z) == _cabi.ERR_INVALID_ARG
     assert lib.ops_beam_residual_f64(2, 3, *([z, 0] * 2), z, z, 0, z, z, 0, z, z, z, z, z) == _cabi.ERR_INVALID_ARG
+    # layer blocks of the PINN step: broken layout contracts are refused on the host
+    a = _cabi.MlpStripArgs()
+    assert lib.ops_mlp_strip_launch(None, z) == _cabi.ERR_INVALID_ARG and lib.ops_mlp_strip_launch(a, z) == _cabi.ERR_INVALID_ARG
+    a.B, a.N, a.K, a.A, a.lda, a.W, a.ldw, a.Y, a.ldy = 129, 16, 32, 64, 32, 64, 32, 64, 32
+    assert lib.ops_mlp_strip_launch(a, z) == _cabi.ERR_INVALID_ARG       # more rows than a workgroup owns
+    a.B, a.lda = 128, 24
+    assert lib.ops_mlp_strip_launch(a, z) == _cabi.ERR_INVALID_ARG       # reduction not padded to whole 32-column steps
+    assert lib.ops_mlp_spart_doubles(350) >= 22 * 12
+    assert lib.ops_mlp_wgrad_group(0, None, z) == _cabi.ERR_INVALID_ARG and lib.ops_mlp_wgrad_group(9, (_cabi.MlpWgradProblem * 9)(), z) == _cabi.ERR_INVALID_ARG
+    assert lib.ops_mlp_repack_weights(1, (_cabi.MlpRepackEntry * 1)(), z) == _cabi.ERR_INVALID_ARG
+    assert lib.ops_mlp_gather_noise(200, 684, z, z, z, 1, z, z, 704, z, z) == _cabi.ERR_INVALID_ARG
+    assert lib.ops_mlp_loss_grad(128, 302, 100, 101, z, 320, z, z, 0.5, z, z, 0.1, 0.0, z, z, 320, z, z, z, z) == _cabi.ERR_INVALID_ARG
+    assert lib.ops_mlp_loss_workspace_bytes() > 0
     sched = (ctypes.c_float * 20)()
     lib.ops_sizing_schedule_f32(ctypes.byref(hp), ctypes.cast(sched, ctypes.c_void_p))       # host-only helper
     assert sched[0] == pytest.approx(0.01 / (1 - 0.9), rel=1e-6) and sched[1] == pytest.approx((1 - 0.999) ** 0.5, rel=1e-6)
