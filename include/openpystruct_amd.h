@@ -279,11 +279,16 @@ int ops_gather_rows_noise_f32(int B, long F, const float* X, const long long* id
  * Linear -> [+ Conv1d/BatchNorm1d(1) stencil + residual] -> BatchNorm1d -> LeakyReLU -> dropout, and one per backward
  * counterpart (bf16 MFMA, fp32 accumulation and statistics).  csrc/mlp_block.hip; host side: openpystruct_amd/pinn_fused.py.
  *
- * Layout contract.  Every activation / gradient matrix X [B, F] lives twice, bfloat16, zero outside the live B x F corner:
- *   row-major  X  [128, ld]        ld >= F rounded up to 32 (the GEMM's reduction runs over whole 32-column steps)
- *   transposed Xt [F rounded up to 32, 128]
- * and every weight W [N, K] twice as well: Wp [N rounded up to 16, K rounded up to 32] and Wtp [K r.u. 16, N r.u. 32]
- * (ops_mlp_repack_weights writes both from the float32 parameters).  All leading dimensions are multiples of 8 elements.
+ * Layout contract.  Operands are stored FRAGMENT-TILED: a [rows, K] bfloat16 matrix (rows padded to 16, K to 32, KS = K / 32) is
+ * a sequence of 1 KB tiles, tile (row >> 4, k >> 5) at tile index (row >> 4) * KS + (k >> 5), each in MFMA lane order:
+ *     element (row, k)  ->  tile * 512 + ((k >> 3) & 3) * 128 + (row & 15) * 8 + (k & 7)          [elements]
+ * so that one wave-wide 16-byte load is the A / B fragment of v_mfma_f32_16x16x32_bf16 (lane = (k >> 3 & 3) << 4 | row & 15).
+ * Every activation / gradient matrix X [B, F] lives twice, zero outside the live B x F corner:
+ *   X  : rows = batch row (128), K = ld columns, ld >= F rounded up to 32          ("[128, ld]" below)
+ *   Xt : rows = column of X (F rounded up to 32), K = 128 batch rows               ("[F r.u. 32, 128]" below)
+ * and every weight W [N, K] twice as well: Wp (rows = N r.u. 16, K r.u. 32) and Wtp (rows = K r.u. 16, N r.u. 32);
+ * ops_mlp_repack_weights and ops_flat_clip_adam_step_repack_f32 write both from the float32 parameters.  All `ld*` arguments
+ * are the padded K of the tiled matrix (multiples of 32).  openpystruct_amd/pinn_fused.py: to_tiled / from_tiled.
  * -----------------------------------------------------------------------------------------------------------------*/
 #define OPS_MLP_MAX_ROWS 128
 /* tails (`tail`): what follows the product in the same launch */
@@ -294,11 +299,13 @@ int ops_gather_rows_noise_f32(int B, long F, const float* X, const long long* id
 #define OPS_MLP_TAIL_BWD_ACT_DROP 4    /* gradient through TAIL_ACT_DROP of the layer below; dbias = column sums */
 #define OPS_MLP_TAIL_BWD_BN 5          /* gradient through TAIL_BN of the layer below; dgamma, dbeta, dbias */
 #define OPS_MLP_TAIL_BWD_BN_ACT_DROP 6 /* gradient through TAIL_BN_ACT_DROP of the layer below; dgamma, dbeta, dbias */
+#define OPS_MLP_TAIL_LOSS 7            /* output layer + training loss: predictions -> P, Y / Yt = d loss / d predictions, dbias */
 /* addends (`add_mode`) joined to the product before the tail */
 #define OPS_MLP_ADD_NONE 0
 #define OPS_MLP_ADD_FWD_BLOCK 1        /* + bn1(conv1(O)) + O: the ResidualBlock's stencil path and identity (O = block input) */
 #define OPS_MLP_ADD_BWD_BLOCK 2        /* + dZ + conv1^T(bn1 backward(dZ)): the gradient the block input receives from them */
-/* side jobs (`side`): per-workgroup partial sums for the whole-tensor BatchNorm1d(1), consumed by the NEXT launch */
+/* side jobs (`side`): partial sums for the whole-tensor BatchNorm1d(1), collected by extra workgroups of this launch (one per 8
+ * columns of O) and consumed by the NEXT launch's ADD_* */
 #define OPS_MLP_SIDE_NONE 0
 #define OPS_MLP_SIDE_FWD_STENCIL_STATS 1
 #define OPS_MLP_SIDE_BWD_STENCIL_SUMS 2
@@ -324,14 +331,21 @@ typedef struct ops_mlp_strip_args {
   const float* conv_w; const float* conv_b; const float* sgamma; const float* sbeta; float seps, smomentum;
   float* srunning_mean; float* srunning_var; long long* snum_batches_tracked;
   float* ssave;                    /* [2] mean, 1/std of the stencil normalisation (forward writes, backward reads) */
-  double* spart; int32_t spart_rows; /* partial sums: SIDE_* writes gridDim rows, ADD_* reads spart_rows rows (2 or 12 doubles each) */
+  double* spart;                   /* ops_mlp_spart_doubles(No) doubles: SIDE_* writes them, ADD_* of the next launch reads them */
   float* sdparams;                 /* [6] ASSIGNED by ADD_BWD_BLOCK: d conv_w[3], d conv_b, d gamma, d beta */
+  /* TAIL_LOSS: the loss of ops_surrogate_loss_grad_f32 on the N = C columns of this product */
+  void* P; int32_t ldp;            /* predictions [128, ldp] bfloat16 (may be NULL) */
+  const float* targets_t;          /* [N, 128] float32, TRANSPOSED targets (ops_mlp_gather_noise writes them), rows >= B ignored */
+  int32_t nI, nD;
+  const float* alpha; float alpha0; const float* min_constraint; const float* max_constraint; float box_weight, rel_penalty;
+  float* loss; void* loss_ws;      /* one float; ops_mlp_loss_workspace_bytes() bytes zeroed ONCE by the caller */
+  float* loss_sum;                 /* optional: += loss (a running total the caller zeroes, e.g. per epoch) */
 } ops_mlp_strip_args;
 
 /* One strip launch: workgroup = 128 rows x 16 output columns.  Returns OPS_AMD_ERR_INVALID_ARG on a broken layout contract. */
 int ops_mlp_strip_launch(const ops_mlp_strip_args* args, void* stream);
-/* doubles of `spart` a launch with `side` needs for N output columns */
-size_t ops_mlp_spart_doubles(int N);
+/* doubles of `spart` for a block input of No columns (No <= 512) */
+size_t ops_mlp_spart_doubles(int No);
 
 /* All weight gradients of a step in one launch: out_i [N_i, K_i] float32 (ASSIGNED, row stride ldo_i) = At_i [N_i r.u. 32, 128] x
  * Bt_i [K_i r.u. 32, 128]^T, the transposed layouts of the layer's output gradient and of its input. */
@@ -346,17 +360,20 @@ typedef struct ops_mlp_repack_entry {
   const float* W; int32_t N, K; void* Wp; int32_t ldw; void* Wtp; int32_t ldwt;
 } ops_mlp_repack_entry;
 int ops_mlp_repack_weights(int nmat, const ops_mlp_repack_entry* entries, void* stream);
+/* ops_flat_clip_adam_step_f32 that also refreshes those copies (every entry's W must point into `params`): the training step
+ * needs no repack launch. */
+int ops_flat_clip_adam_step_repack_f32(long n, float* params, const float* grads, float* exp_avg, float* exp_avg_sq, const float* lr,
+                                       int32_t* step, float max_norm, float grad_scale, float beta1, float beta2, float eps,
+                                       float weight_decay, int decoupled_weight_decay, void* params_bf16, void* workspace,
+                                       int nmat, const ops_mlp_repack_entry* entries, void* stream);
 
-/* ops_gather_rows_noise_f32 writing the layout above: out [128, ld] and out_t [F r.u. 32, 128] bfloat16, rows >= B zeroed. */
+/* ops_gather_rows_noise_f32 writing the layout above: out (rows = batch, K = ld) and out_t (rows = F r.u. 32, K = 128) bfloat16,
+ * rows >= B zeroed; and, when Y [n, C] float32 is given, the batch's targets TRANSPOSED: targets_t [C, 128] = Y[idx]^T. */
 int ops_mlp_gather_noise(int B, int F, const float* X, const long long* idx, const float* sigma, unsigned long long seed,
-                         unsigned long long* counter, void* out, int ld, void* out_t, void* stream);
+                         unsigned long long* counter, void* out, int ld, void* out_t, const float* Y, int C, float* targets_t,
+                         void* stream);
 
-/* ops_surrogate_loss_grad_f32 on that layout: preds [128, ldp] bfloat16 -> loss (one float), grad [128, ldg] and grad_t
- * [C r.u. 32, 128] bfloat16, dbias [C] (column sums of the gradient: the output layer's bias gradient, ASSIGNED).
- * `workspace`: ops_mlp_loss_workspace_bytes() bytes, zero-initialised ONCE by the caller (the launch leaves it zeroed). */
-int ops_mlp_loss_grad(int B, int C, int nI, int nD, const void* preds, int ldp, const float* targets, const float* alpha, float alpha0,
-                      const float* min_constraint, const float* max_constraint, float box_weight, float rel_penalty, float* loss,
-                      void* grad, int ldg, void* grad_t, float* dbias, void* workspace, void* stream);
+/* bytes of ops_mlp_strip_args.loss_ws (TAIL_LOSS) */
 size_t ops_mlp_loss_workspace_bytes(void);
 
 #ifdef __cplusplus

@@ -46,8 +46,8 @@ EXPORTS = (
     "ops_mlp_spart_doubles",
     "ops_mlp_wgrad_group",
     "ops_mlp_repack_weights",
+    "ops_flat_clip_adam_step_repack_f32",
     "ops_mlp_gather_noise",
-    "ops_mlp_loss_grad",
     "ops_mlp_loss_workspace_bytes",
 )
 
@@ -67,7 +67,7 @@ class SizingParams(ctypes.Structure):
 # layer blocks of the PINN training step (include/openpystruct_amd.h, csrc/mlp_block.hip)
 MLP_MAX_ROWS = 128
 MLP_TAIL_NONE, MLP_TAIL_ACT_DROP, MLP_TAIL_BN_ACT_DROP, MLP_TAIL_BN = 0, 1, 2, 3
-MLP_TAIL_BWD_ACT_DROP, MLP_TAIL_BWD_BN, MLP_TAIL_BWD_BN_ACT_DROP = 4, 5, 6
+MLP_TAIL_BWD_ACT_DROP, MLP_TAIL_BWD_BN, MLP_TAIL_BWD_BN_ACT_DROP, MLP_TAIL_LOSS = 4, 5, 6, 7
 MLP_ADD_NONE, MLP_ADD_FWD_BLOCK, MLP_ADD_BWD_BLOCK = 0, 1, 2
 MLP_SIDE_NONE, MLP_SIDE_FWD_STENCIL_STATS, MLP_SIDE_BWD_STENCIL_SUMS = 0, 1, 2
 MLP_MAX_WGRAD = 8
@@ -87,7 +87,9 @@ class MlpStripArgs(ctypes.Structure):
                 ("Ot", _vp), ("No", _i), ("dZt", _vp),
                 ("conv_w", _vp), ("conv_b", _vp), ("sgamma", _vp), ("sbeta", _vp), ("seps", _f), ("smomentum", _f),
                 ("srunning_mean", _vp), ("srunning_var", _vp), ("snum_batches_tracked", _vp),
-                ("ssave", _vp), ("spart", _vp), ("spart_rows", _i), ("sdparams", _vp)]
+                ("ssave", _vp), ("spart", _vp), ("sdparams", _vp),
+                ("P", _vp), ("ldp", _i), ("targets_t", _vp), ("nI", _i), ("nD", _i), ("alpha", _vp), ("alpha0", _f),
+                ("min_constraint", _vp), ("max_constraint", _vp), ("box_weight", _f), ("rel_penalty", _f), ("loss", _vp), ("loss_ws", _vp), ("loss_sum", _vp)]
 
 
 class MlpWgradProblem(ctypes.Structure):
@@ -180,10 +182,11 @@ def load():
     lib.ops_mlp_wgrad_group.argtypes = [it, ctypes.POINTER(MlpWgradProblem), vp]
     lib.ops_mlp_repack_weights.restype = it
     lib.ops_mlp_repack_weights.argtypes = [it, ctypes.POINTER(MlpRepackEntry), vp]
+    lib.ops_flat_clip_adam_step_repack_f32.restype = it
+    lib.ops_flat_clip_adam_step_repack_f32.argtypes = [lg, vp, vp, vp, vp, vp, vp, fl, fl, fl, fl, fl, fl, it, vp, vp, it,
+                                                       ctypes.POINTER(MlpRepackEntry), vp]
     lib.ops_mlp_gather_noise.restype = it
-    lib.ops_mlp_gather_noise.argtypes = [it, it, vp, vp, vp, ull, vp, vp, it, vp, vp]
-    lib.ops_mlp_loss_grad.restype = it
-    lib.ops_mlp_loss_grad.argtypes = [it, it, it, it, vp, it, vp, vp, fl, vp, vp, fl, fl, vp, vp, it, vp, vp, vp, vp]
+    lib.ops_mlp_gather_noise.argtypes = [it, it, vp, vp, vp, ull, vp, vp, it, vp, vp, it, vp, vp]
     lib.ops_mlp_loss_workspace_bytes.restype = ctypes.c_size_t
     lib.ops_amd_max_elements.restype = it
     lib.ops_amd_abi_version.restype = it

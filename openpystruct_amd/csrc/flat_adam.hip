@@ -20,7 +20,7 @@
 namespace opsamd {
 
 constexpr int FA_THREADS = 256;
-constexpr int FA_NORM_BLOCKS = 128;
+constexpr int FA_NORM_BLOCKS = 128;     // <= FA_THREADS: the update reads one partial sum per thread
 
 __global__ __launch_bounds__(FA_THREADS) void flat_grad_norm_kernel(long n, const float* __restrict__ g, float grad_scale,
                                                                      double* __restrict__ part, int32_t* __restrict__ step, float beta1,
@@ -48,23 +48,42 @@ __global__ __launch_bounds__(FA_THREADS) void flat_grad_norm_kernel(long n, cons
   }
 }
 
+// bf16 copies of up to 8 weight matrices in the layout of csrc/mlp_block.hip (padded, plain and transposed), refreshed by the
+// update itself: the PINN's layer-block launches read them, no separate repack launch per step
+struct AdamRepack {
+  int nmat;
+  long off[OPS_MLP_MAX_WGRAD];        // first element of matrix i in the flat parameter buffer
+  int N[OPS_MLP_MAX_WGRAD], K[OPS_MLP_MAX_WGRAD], ldw[OPS_MLP_MAX_WGRAD], ldwt[OPS_MLP_MAX_WGRAD];
+  uint16_t* Wp[OPS_MLP_MAX_WGRAD];
+  uint16_t* Wtp[OPS_MLP_MAX_WGRAD];
+};
+
+template <bool REPACK>
 __global__ __launch_bounds__(FA_THREADS) void flat_adam_kernel(long n, float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                                 float* __restrict__ v, const float* __restrict__ lr, const int32_t* __restrict__ step,
                                                                 const double* __restrict__ part, int nparts, float max_norm, float grad_scale,
                                                                 float beta1, float beta2, float eps, float weight_decay, int decoupled,
-                                                                uint16_t* __restrict__ shadow) {
+                                                                uint16_t* __restrict__ shadow, const AdamRepack rp) {
+  // ||g||^2 from the norm pass's partial sums: one load per thread (nparts <= FA_NORM_BLOCKS <= FA_THREADS), not a serial chain
+  __shared__ double s_red[FA_THREADS / 64];
+  double d = (int)threadIdx.x < nparts ? part[threadIdx.x] : 0.0;
+  for (int s = 32; s >= 1; s >>= 1) d += __shfl_xor(d, s, 64);
+  if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = d;
+  const float bc1 = (float)part[FA_NORM_BLOCKS], bc2s = (float)part[FA_NORM_BLOCKS + 1];
+  const float lr0 = lr[0];
+  __syncthreads();
   double tot = 0.0;
-  for (int k = 0; k < nparts; ++k) tot += part[k];
+#pragma unroll
+  for (int w = 0; w < FA_THREADS / 64; ++w) tot += s_red[w];
   const float norm = (float)sqrt(tot);
   float clip = max_norm > 0.0f ? max_norm / (norm + 1e-6f) : 1.0f;      // torch.nn.utils.clip_grad_norm_
   clip = clip < 1.0f ? clip : 1.0f;
   const float gs = clip * grad_scale;
-  const float bc1 = (float)part[FA_NORM_BLOCKS], bc2s = (float)part[FA_NORM_BLOCKS + 1];
-  const float step_size = lr[0] / bc1;
+  const float step_size = lr0 / bc1;
   for (long i = (long)blockIdx.x * FA_THREADS + threadIdx.x; i < n; i += (long)gridDim.x * FA_THREADS) {
     float pi = p[i];
     float gi = g[i] * gs;
-    if (decoupled) pi *= 1.0f - lr[0] * weight_decay;      // AdamW: p *= 1 - lr wd, the gradient stays clean
+    if (decoupled) pi *= 1.0f - lr0 * weight_decay;        // AdamW: p *= 1 - lr wd, the gradient stays clean
     else gi = __builtin_fmaf(weight_decay, pi, gi);        // Adam: L2 term in the gradient
     const float mi = __builtin_fmaf(beta1, m[i], (1.0f - beta1) * gi);
     const float vi = __builtin_fmaf(beta2, v[i], (1.0f - beta2) * gi * gi);
@@ -72,10 +91,25 @@ __global__ __launch_bounds__(FA_THREADS) void flat_adam_kernel(long n, float* __
     v[i] = vi;
     const float pn = pi - step_size * (mi / (sqrtf(vi) / bc2s + eps));
     p[i] = pn;
-    if (shadow) {                      // bfloat16 copy of the parameters (round to nearest even) for the GEMMs of the next step
+    if (shadow || REPACK) {            // bfloat16 copy of the parameters (round to nearest even) for the GEMMs of the next step
       uint32_t u = __float_as_uint(pn);
       u += 0x7fffu + ((u >> 16) & 1u);
-      shadow[i] = (uint16_t)(u >> 16);
+      const uint16_t h = (uint16_t)(u >> 16);
+      if (shadow) shadow[i] = h;
+      if (REPACK) {
+#pragma unroll
+        for (int q = 0; q < OPS_MLP_MAX_WGRAD; ++q)
+          if (q < rp.nmat) {
+            const long le = i - rp.off[q];
+            if (le >= 0 && le < (long)rp.N[q] * rp.K[q]) {
+              const int r = (int)(le / rp.K[q]), c = (int)(le - (long)r * rp.K[q]);
+              // fragment-tiled storage (csrc/mlp_block.hip mb_toff): tile (row >> 4, k >> 5) = 512 elements in MFMA lane order
+              const int ksw = rp.ldw[q] >> 5, kst = rp.ldwt[q] >> 5;
+              rp.Wp[q][((long)(r >> 4) * ksw + (c >> 5)) * 512 + ((c >> 3) & 3) * 128 + (r & 15) * 8 + (c & 7)] = h;
+              rp.Wtp[q][((long)(c >> 4) * kst + (r >> 5)) * 512 + ((r >> 3) & 3) * 128 + (c & 15) * 8 + (r & 7)] = h;
+            }
+          }
+      }
     }
   }
 }
@@ -86,10 +120,9 @@ using namespace opsamd;
 
 extern "C" size_t ops_flat_adam_workspace_bytes(void) { return (size_t)(FA_NORM_BLOCKS + 2) * sizeof(double); }
 
-extern "C" int ops_flat_clip_adam_step_f32(long n, float* params, const float* grads, float* exp_avg, float* exp_avg_sq, const float* lr,
-                                           int32_t* step, float max_norm, float grad_scale, float beta1, float beta2, float eps,
-                                           float weight_decay, int decoupled_weight_decay, void* params_bf16, void* workspace,
-                                           void* stream) {
+static int adam_step(long n, float* params, const float* grads, float* exp_avg, float* exp_avg_sq, const float* lr, int32_t* step,
+                     float max_norm, float grad_scale, float beta1, float beta2, float eps, float weight_decay, int decoupled_weight_decay,
+                     void* params_bf16, void* workspace, void* stream, const AdamRepack* rp) {
   if (n < 1 || !params || !grads || !exp_avg || !exp_avg_sq || !lr || !step || !workspace) return OPS_AMD_ERR_INVALID_ARG;
   hipStream_t s = (hipStream_t)stream;
   long nb = (n + FA_THREADS - 1) / FA_THREADS;
@@ -97,8 +130,40 @@ extern "C" int ops_flat_clip_adam_step_f32(long n, float* params, const float* g
   hipLaunchKernelGGL(flat_grad_norm_kernel, dim3(nparts), dim3(FA_THREADS), 0, s, n, grads, grad_scale, (double*)workspace, step, beta1,
                      beta2);
   if (nb > 4096) nb = 4096;
-  hipLaunchKernelGGL(flat_adam_kernel, dim3((unsigned)nb), dim3(FA_THREADS), 0, s, n, params, grads, exp_avg, exp_avg_sq, lr, step,
-                     (const double*)workspace, nparts, max_norm, grad_scale, beta1, beta2, eps, weight_decay, decoupled_weight_decay,
-                     (uint16_t*)params_bf16);
+  if (rp)
+    hipLaunchKernelGGL(flat_adam_kernel<true>, dim3((unsigned)nb), dim3(FA_THREADS), 0, s, n, params, grads, exp_avg, exp_avg_sq, lr, step,
+                       (const double*)workspace, nparts, max_norm, grad_scale, beta1, beta2, eps, weight_decay, decoupled_weight_decay,
+                       (uint16_t*)params_bf16, *rp);
+  else
+    hipLaunchKernelGGL(flat_adam_kernel<false>, dim3((unsigned)nb), dim3(FA_THREADS), 0, s, n, params, grads, exp_avg, exp_avg_sq, lr, step,
+                       (const double*)workspace, nparts, max_norm, grad_scale, beta1, beta2, eps, weight_decay, decoupled_weight_decay,
+                       (uint16_t*)params_bf16, AdamRepack{});
   return hipGetLastError() == hipSuccess ? OPS_AMD_OK : OPS_AMD_ERR_LAUNCH;
+}
+
+extern "C" int ops_flat_clip_adam_step_f32(long n, float* params, const float* grads, float* exp_avg, float* exp_avg_sq, const float* lr,
+                                           int32_t* step, float max_norm, float grad_scale, float beta1, float beta2, float eps,
+                                           float weight_decay, int decoupled_weight_decay, void* params_bf16, void* workspace,
+                                           void* stream) {
+  return adam_step(n, params, grads, exp_avg, exp_avg_sq, lr, step, max_norm, grad_scale, beta1, beta2, eps, weight_decay,
+                   decoupled_weight_decay, params_bf16, workspace, stream, nullptr);
+}
+
+extern "C" int ops_flat_clip_adam_step_repack_f32(long n, float* params, const float* grads, float* exp_avg, float* exp_avg_sq, const float* lr,
+                                                  int32_t* step, float max_norm, float grad_scale, float beta1, float beta2, float eps,
+                                                  float weight_decay, int decoupled_weight_decay, void* params_bf16, void* workspace,
+                                                  int nmat, const ops_mlp_repack_entry* entries, void* stream) {
+  if (nmat < 1 || nmat > OPS_MLP_MAX_WGRAD || !entries || !params) return OPS_AMD_ERR_INVALID_ARG;
+  AdamRepack rp{};
+  rp.nmat = nmat;
+  for (int i = 0; i < nmat; ++i) {
+    const ops_mlp_repack_entry& e = entries[i];
+    if (!e.W || !e.Wp || !e.Wtp || e.N < 1 || e.K < 1 || e.ldw % 32 || e.ldwt % 32 || e.ldw < (e.K + 31) / 32 * 32 || e.ldwt < (e.N + 31) / 32 * 32) return OPS_AMD_ERR_INVALID_ARG;
+    const long off = e.W - params;
+    if (off < 0 || off + (long)e.N * e.K > n) return OPS_AMD_ERR_INVALID_ARG;      // the matrix must live inside the flat buffer
+    rp.off[i] = off; rp.N[i] = e.N; rp.K[i] = e.K; rp.ldw[i] = e.ldw; rp.ldwt[i] = e.ldwt;
+    rp.Wp[i] = (uint16_t*)e.Wp; rp.Wtp[i] = (uint16_t*)e.Wtp;
+  }
+  return adam_step(n, params, grads, exp_avg, exp_avg_sq, lr, step, max_norm, grad_scale, beta1, beta2, eps, weight_decay,
+                   decoupled_weight_decay, params_bf16, workspace, stream, &rp);
 }

@@ -6,7 +6,7 @@
 //
 // one launch per Linear WITH everything that follows it up to the next Linear, and one per backward counterpart -- the
 // captured step of that model was 63 kernel nodes (17 library GEMMs of 5.5-19 us for 8-30 MFLOP each, the elementwise tails,
-// the stencil's five kernels, casts, bias reductions; profiles/r02_train_pinn_trace.txt) and becomes 17.
+// the stencil's five kernels, casts, bias reductions; profiles/r02_train_pinn_trace.txt) and becomes 15.
 //
 // Shape of the work.  The batch is 128 rows and the layers are 684/350/175/302 wide: every matrix fits in L2, every product is
 // a few MFLOP -- launch and latency bound, not MFMA bound.  What decides the step time is the NUMBER of dependent launches and the
@@ -17,12 +17,16 @@
 //     no LDS staging -- which needs both operands contiguous along the reduction index.  Hence the layout contract of
 //     include/openpystruct_amd.h: activations, gradients and weights each exist row-major AND transposed, zero-padded to
 //     whole 32-column steps; producing the second copy costs the producer one extra store of a tile it already holds;
-//   * all fragment loads of a reduction chunk (up to 24 steps of 32) are issued before the first MFMA: one exposed latency;
+//   * the fragment loads of up to 16 reduction steps (512 columns) are in flight before the first MFMA, and EVERYTHING the epilogue
+//     reads (bias, normalisation parameters, saved values, residual / stencil neighbourhoods, targets, partial sums) is requested
+//     before them: one exposed memory latency per launch (a kernel's inputs were written by the previous launch on other XCDs, so
+//     they come from the Infinity Cache, not from this XCD's L2: ~2 us per dependent round trip);
 //   * the epilogue re-maps the 128 x 16 tile through LDS to "32 lanes per column": column sums are half-wave butterflies, the
 //     transposed copies of the other operands (residual, saved pre-normalisation values, forward outputs for the
 //     activation/dropout masks) are read and written coalesced;
-//   * the ResidualBlock's single-channel BatchNorm1d(1) normalises over the WHOLE tensor: its sums are collected as a side job
-//     by the launch before the one that needs them (per-workgroup partial sums in a workspace, no atomics, no extra launch);
+//   * the ResidualBlock's single-channel BatchNorm1d(1) normalises over the WHOLE tensor: its sums are collected by extra
+//     workgroups of the launch before the one that needs them (partial sums in a workspace, no atomics, no extra launch);
+//   * the output layer's launch evaluates the training loss and its gradient on the tile it holds (no loss launch);
 //   * the six weight gradients of the step are one grouped launch at the end (all operands are still resident).
 // Arithmetic: bf16 operands, fp32 accumulation, layer outputs rounded to bf16 -- what nn.Linear under bf16 autocast does;
 // statistics, normalisation and parameter gradients in fp32 (stencil sums in fp64).
@@ -35,7 +39,11 @@
 
 namespace opsamd {
 
+#ifdef MB_EXP          // stand-alone experiment builds (scratch/mlp_exp.py)
+inline void set_last_error(const char*) {}
+#else
 void set_last_error(const char* msg);   // beam_solve.hip: what ops_amd_last_error() reports
+#endif
 
 typedef __bf16 mb_bf16x8 __attribute__((ext_vector_type(8)));
 typedef float mb_f32x4 __attribute__((ext_vector_type(4)));
@@ -53,8 +61,15 @@ __device__ __forceinline__ uint16_t mb_f2bf(float f) {
   return (uint16_t)(u >> 16);
 }
 __device__ __forceinline__ float mb_round(float f) { return mb_bf2f(mb_f2bf(f)); }
-// element (row r, column c) of a transposed bf16 matrix [cols, 128]
-__device__ __forceinline__ float mb_ldt(const void* p, int c, int r) { return mb_bf2f(((const uint16_t*)p)[(long)c * MB_ROWS + r]); }
+// Fragment-tiled storage of a [rows, K] bf16 matrix (rows padded to 16, K to 32; KS = K / 32): tile (rows >> 4, k >> 5) is 1 KB,
+// stored in MFMA lane order -- lane = ((k >> 3) & 3) << 4 | (row & 15) holds 8 consecutive k -- so one wave-wide 16-byte load IS
+// the A / B fragment of `v_mfma_f32_16x16x32_bf16` and touches 8 whole cache lines (row-major storage: 16 half lines per load,
+// measured 2-4x the time per reduction step; profiles/r02_notes.md).
+__device__ __forceinline__ long mb_toff(int row, int k, int KS) {
+  return ((long)(row >> 4) * KS + (k >> 5)) * 512 + ((k >> 3) & 3) * 128 + (row & 15) * 8 + (k & 7);
+}
+// element (row r, column c) of a matrix whose TRANSPOSED copy [cols, 128] is stored tiled (rows = c, k = r, KS = 4)
+__device__ __forceinline__ float mb_ldt(const void* p, int c, int r) { return mb_bf2f(((const uint16_t*)p)[mb_toff(c, r, MB_ROWS / 32)]); }
 // sum over the 32 lanes that share a column (a half wave)
 __device__ __forceinline__ float mb_hsum(float v) {
 #pragma unroll
@@ -76,23 +91,38 @@ __device__ __forceinline__ float mb_uniform(uint64_t seed, uint64_t call, uint64
 }
 
 // ---- the product: one 16 x 16 tile per wave, reduction in steps of 32, fragments straight from global memory ----
-// lane l holds A[row l&15][k = 8 (l>>4) + j] and B[k][col l&15] (j = 0..7): 16 contiguous bytes of a row of either operand.
-// KCH steps are loaded before the first MFMA of the chunk; steps past KS re-read the last step (a hot line) and are skipped.
-template <int KCH>
+// lane l holds A[row l&15][k = 8 (l>>4) + j] and B[k][col l&15] (j = 0..7): 16 contiguous bytes of a row of either operand, and
+// in the tiled storage the 64 lanes' 16 bytes are one contiguous KB.
+// Chunks of MB_KCH steps, double buffered: the loads of chunk i + 1 are in flight while chunk i multiplies, and both of the first
+// two chunks (up to 16 steps = 512 columns) are requested before the first MFMA.  Steps past KS re-read the last step (a hot
+// line) and are skipped.
+constexpr int MB_KCH = 8;
+
+__device__ __forceinline__ void mb_load_chunk(uint4 (&fa)[MB_KCH], uint4 (&fb)[MB_KCH], const uint16_t* __restrict__ a_lane,
+                                              const uint16_t* __restrict__ b_lane, int k0, int KS) {
+#pragma unroll
+  for (int j = 0; j < MB_KCH; ++j) {
+    const int ks = k0 + j < KS ? k0 + j : KS - 1;
+    fa[j] = *(const uint4*)(a_lane + ks * 512);
+    fb[j] = *(const uint4*)(b_lane + ks * 512);
+  }
+}
+__device__ __forceinline__ mb_f32x4 mb_mfma_chunk(mb_f32x4 acc, const uint4 (&fa)[MB_KCH], const uint4 (&fb)[MB_KCH], int k0, int KS) {
+#pragma unroll
+  for (int j = 0; j < MB_KCH; ++j)
+    if (k0 + j < KS)      // wave-uniform
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mb_bf16x8, fa[j]), __builtin_bit_cast(mb_bf16x8, fb[j]), acc, 0, 0, 0);
+  return acc;
+}
 __device__ __forceinline__ mb_f32x4 mb_tile_product(const uint16_t* __restrict__ a_lane, const uint16_t* __restrict__ b_lane, int KS) {
   mb_f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
-  for (int k0 = 0; k0 < KS; k0 += KCH) {
-    uint4 fa[KCH], fb[KCH];
-#pragma unroll
-    for (int j = 0; j < KCH; ++j) {
-      const int ks = k0 + j < KS ? k0 + j : KS - 1;
-      fa[j] = *(const uint4*)(a_lane + ks * 32);
-      fb[j] = *(const uint4*)(b_lane + ks * 32);
-    }
-#pragma unroll
-    for (int j = 0; j < KCH; ++j)
-      if (k0 + j < KS)      // wave-uniform
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mb_bf16x8, fa[j]), __builtin_bit_cast(mb_bf16x8, fb[j]), acc, 0, 0, 0);
+  uint4 fa0[MB_KCH], fb0[MB_KCH], fa1[MB_KCH], fb1[MB_KCH];
+  mb_load_chunk(fa0, fb0, a_lane, b_lane, 0, KS);
+  for (int k0 = 0; k0 < KS; k0 += 2 * MB_KCH) {
+    if (k0 + MB_KCH < KS) mb_load_chunk(fa1, fb1, a_lane, b_lane, k0 + MB_KCH, KS);
+    acc = mb_mfma_chunk(acc, fa0, fb0, k0, KS);
+    if (k0 + 2 * MB_KCH < KS) mb_load_chunk(fa0, fb0, a_lane, b_lane, k0 + 2 * MB_KCH, KS);
+    if (k0 + MB_KCH < KS) acc = mb_mfma_chunk(acc, fa1, fb1, k0 + MB_KCH, KS);
   }
   return acc;
 }
@@ -123,55 +153,190 @@ __device__ __forceinline__ void mb_block_sum(double (&v)[NV], double* s_red /*[8
     }
 }
 
-template <int KCH>
-__global__ __launch_bounds__(MB_THREADS) void mlp_strip_kernel(const ops_mlp_strip_args a) {
+constexpr int MB_SIDE_COLS = 8;             // columns of the block input per side-job workgroup
+constexpr int MB_MAX_SIDE = 64;             // side-job workgroups (= rows of partial sums) a launch may have: No <= 512
+constexpr int ML_MAXG = 64;                 // strips of a TAIL_LOSS launch: C <= 1024
+
+// ---- side job: partial sums for the whole-tensor BatchNorm1d(1) of the stencil path over 8 columns of the block input ----
+// 1024 elements per workgroup, two per thread, every load independent: one exposed latency.
+__device__ __forceinline__ void mb_side_job(const ops_mlp_strip_args& a, int row, double* s_red) {
+  const int tid = threadIdx.x, r = tid & (MB_ROWS - 1), cj = tid >> 7;
+  const int B = a.B, No = a.No;
+  const float w0 = a.conv_w[0], w1 = a.conv_w[1], w2 = a.conv_w[2], cb = a.conv_b[0];
+  const bool bwd = a.side == OPS_MLP_SIDE_BWD_STENCIL_SUMS;
+  float xs[2][3], gi[2];
+  bool live[2];
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const int cc = row * MB_SIDE_COLS + cj + 4 * e;
+    live[e] = cc < No && r < B;
+    xs[e][0] = (live[e] && cc > 0) ? mb_ldt(a.Ot, cc - 1, r) : 0.0f;
+    xs[e][1] = live[e] ? mb_ldt(a.Ot, cc, r) : 0.0f;
+    xs[e][2] = (live[e] && cc + 1 < No) ? mb_ldt(a.Ot, cc + 1, r) : 0.0f;
+    gi[e] = (live[e] && bwd) ? mb_ldt(a.dZt, cc, r) : 0.0f;
+  }
+  if (!bwd) {
+    float p0 = 0.0f, p1 = 0.0f;
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+      if (live[e]) {
+        const float y = __builtin_fmaf(w0, xs[e][0], __builtin_fmaf(w1, xs[e][1], __builtin_fmaf(w2, xs[e][2], cb)));
+        p0 += y;
+        p1 = __builtin_fmaf(y, y, p1);
+      }
+    double acc[2] = {(double)p0, (double)p1};
+    mb_block_sum<2>(acc, s_red);
+    if (tid == 0) { a.spart[row * 2] = acc[0]; a.spart[row * 2 + 1] = acc[1]; }
+  } else {
+    // 0: sum g   1: sum g yhat   2: sum yhat   3..5: sum g x_s   6..8: sum x_s   9..11: sum yhat x_s   (x_s = O shifted by s - 1)
+    const float mean_s = a.ssave[0], inv_s = a.ssave[1];
+    float t[MB_NSUM];
+#pragma unroll
+    for (int k = 0; k < MB_NSUM; ++k) t[k] = 0.0f;
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+      if (live[e]) {
+        const float conv = __builtin_fmaf(w0, xs[e][0], __builtin_fmaf(w1, xs[e][1], __builtin_fmaf(w2, xs[e][2], cb)));
+        const float yh = (conv - mean_s) * inv_s;
+        t[0] += gi[e];
+        t[1] = __builtin_fmaf(gi[e], yh, t[1]);
+        t[2] += yh;
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+          t[3 + s] = __builtin_fmaf(gi[e], xs[e][s], t[3 + s]);
+          t[6 + s] += xs[e][s];
+          t[9 + s] = __builtin_fmaf(yh, xs[e][s], t[9 + s]);
+        }
+      }
+    double acc[MB_NSUM];
+#pragma unroll
+    for (int k = 0; k < MB_NSUM; ++k) acc[k] = (double)t[k];
+    mb_block_sum<MB_NSUM>(acc, s_red);
+    if (tid == 0)
+#pragma unroll
+      for (int k = 0; k < MB_NSUM; ++k) a.spart[row * MB_NSUM + k] = acc[k];
+  }
+}
+
+__global__ __launch_bounds__(MB_THREADS) void mlp_strip_kernel(const ops_mlp_strip_args a, const int nstrips) {
   __shared__ float s_t[MB_ROWS][MB_COLS + 1];
   __shared__ __attribute__((aligned(16))) uint16_t s_y[MB_ROWS][MB_COLS];
+  __shared__ __attribute__((aligned(16))) uint16_t s_z[MB_ROWS][MB_COLS];
   __shared__ double s_red[(MB_THREADS / 64) * MB_NSUM];
+  __shared__ double s_tot[16];
+  __shared__ bool s_last;
+  if ((int)blockIdx.x >= nstrips) {      // workgroup-uniform
+    mb_side_job(a, (int)blockIdx.x - nstrips, s_red);
+    return;
+  }
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int n0 = blockIdx.x * MB_COLS;
-  const int B = a.B, N = a.N;
+  const int B = a.B, N = a.N, No = a.No;
+  const bool fwd = a.tail <= OPS_MLP_TAIL_BN || a.tail == OPS_MLP_TAIL_LOSS;
+  const bool has_bn = a.tail == OPS_MLP_TAIL_BN || a.tail == OPS_MLP_TAIL_BN_ACT_DROP || a.tail == OPS_MLP_TAIL_BWD_BN ||
+                      a.tail == OPS_MLP_TAIL_BWD_BN_ACT_DROP;
+  const bool act_bwd = a.tail == OPS_MLP_TAIL_BWD_ACT_DROP || a.tail == OPS_MLP_TAIL_BWD_BN_ACT_DROP;
+  // epilogue mapping: 32 lanes per column, 4 rows per lane
+  const int cl = tid >> 5, q = tid & 31, c = n0 + cl;
+  const bool clive = c < N;
+  bool rl[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) rl[i] = clive && q + 32 * i < B;
+
+  // ---- phase 0: everything the epilogue reads is requested BEFORE the product's operands (one exposed latency per launch) ----
+  float bias = 0.0f, g = 1.0f, be = 0.0f, mean_c = 0.0f, rstd_c = 1.0f;
+  if (clive) {
+    if (fwd && a.bias) bias = a.bias[c];
+    if (has_bn) {
+      g = a.gamma[c]; be = a.beta[c];
+      if (!fwd) { mean_c = a.mean[c]; rstd_c = a.rstd[c]; }
+    }
+  }
+  float po[5][4], pg[3][4], pz[4], py[4], pt[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = q + 32 * i;
+#pragma unroll
+    for (int d = 0; d < 5; ++d) po[d][i] = 0.0f;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) pg[d][i] = 0.0f;
+    pz[i] = 0.0f; py[i] = 0.0f; pt[i] = 0.0f;
+    if (rl[i]) {
+      if (a.add_mode != OPS_MLP_ADD_NONE) {
+        const int lo = a.add_mode == OPS_MLP_ADD_FWD_BLOCK ? 1 : 0, hi = a.add_mode == OPS_MLP_ADD_FWD_BLOCK ? 3 : 4;
+#pragma unroll
+        for (int d = 0; d < 5; ++d) {
+          const int qq = c + d - 2;
+          if (d >= lo && d <= hi && qq >= 0 && qq < No) po[d][i] = mb_ldt(a.Ot, qq, r);
+        }
+        if (a.add_mode == OPS_MLP_ADD_BWD_BLOCK)
+#pragma unroll
+          for (int d = 0; d < 3; ++d) {
+            const int qq = c + d - 1;
+            if (qq >= 0 && qq < No) pg[d][i] = mb_ldt(a.dZt, qq, r);
+          }
+      }
+      if (has_bn && !fwd) pz[i] = mb_ldt(a.Zt, c, r);
+      if (act_bwd) py[i] = mb_ldt(a.Yref_t, c, r);
+      if (a.tail == OPS_MLP_TAIL_LOSS) pt[i] = a.targets_t[(long)c * MB_ROWS + r];
+    }
+  }
+  // partial sums of the stencil normalisation: lane = row of partials, wave = which sum (workgroup 0 needs all twelve backward)
+  double pp0 = 0.0, pp1 = 0.0;
+  if (a.add_mode != OPS_MLP_ADD_NONE) {
+    const int rows = (No + MB_SIDE_COLS - 1) / MB_SIDE_COLS, NS = fwd ? 2 : MB_NSUM;
+    if (lane < rows) {
+      if (wave < 2 || (blockIdx.x == 0 && wave < NS)) pp0 = a.spart[lane * NS + wave];
+      if (blockIdx.x == 0 && wave + 8 < NS) pp1 = a.spart[lane * NS + wave + 8];
+    }
+  }
+  float sc_w0 = 0.0f, sc_w1 = 0.0f, sc_w2 = 0.0f, sc_b = 0.0f, sc_g = 0.0f, sc_be = 0.0f, sv_mean = 0.0f, sv_inv = 1.0f;
+  if (a.add_mode != OPS_MLP_ADD_NONE) {
+    sc_w0 = a.conv_w[0]; sc_w1 = a.conv_w[1]; sc_w2 = a.conv_w[2]; sc_b = a.conv_b[0]; sc_g = a.sgamma[0]; sc_be = a.sbeta[0];
+    if (a.add_mode == OPS_MLP_ADD_BWD_BLOCK) { sv_mean = a.ssave[0]; sv_inv = a.ssave[1]; }
+  }
+  const unsigned long long call = (fwd && a.p_drop > 0.0f && a.call_counter) ? *a.call_counter : 0ull;
 
   // ---- product ----
   {
+#if defined(MB_EXP) && MB_EXP == 2
+    const int KS = 1;
+#else
     const int KS = (a.K + 31) >> 5;
-    const uint16_t* ap = (const uint16_t*)a.A + (long)(wave * 16 + (lane & 15)) * a.lda + 8 * (lane >> 4);
-    const uint16_t* bp = (const uint16_t*)a.W + (long)(n0 + (lane & 15)) * a.ldw + 8 * (lane >> 4);
-    const mb_f32x4 acc = mb_tile_product<KCH>(ap, bp, KS);
+#endif
+    // tile (row block, step) = 1 KB in lane order: this wave's row block of A, this strip's row block of W
+    const uint16_t* ap = (const uint16_t*)a.A + (long)wave * (a.lda >> 5) * 512 + lane * 8;
+    const uint16_t* bp = (const uint16_t*)a.W + (long)blockIdx.x * (a.ldw >> 5) * 512 + lane * 8;
+#if defined(MB_EXP) && MB_EXP == 1
+    const mb_f32x4 acc = {(float)(ap - bp), (float)KS, 0.0f, 0.0f};
+#else
+    const mb_f32x4 acc = mb_tile_product(ap, bp, KS);
+#endif
     // C layout: column lane & 15, rows 4 (lane >> 4) + i
 #pragma unroll
     for (int i = 0; i < 4; ++i) s_t[wave * 16 + (lane >> 4) * 4 + i][lane & 15] = acc[i];
   }
+  if (a.add_mode != OPS_MLP_ADD_NONE) {
+    pp0 = mb_wsum_d(pp0); pp1 = mb_wsum_d(pp1);
+    if (lane == 0) { s_tot[wave] = pp0; s_tot[wave + 8] = pp1; }
+  }
   __syncthreads();
 
-  // ---- epilogue: 32 lanes per column, 4 rows per lane ----
-  const int cl = tid >> 5, q = tid & 31, c = n0 + cl;
-  const bool clive = c < N;
+  // ---- epilogue ----
   float v[4];
-  bool rl[4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int r = q + 32 * i;
-    rl[i] = clive && r < B;
-    v[i] = s_t[r][cl];
-  }
+  for (int i = 0; i < 4; ++i) v[i] = s_t[q + 32 * i][cl];
   const float invB = 1.0f / (float)B;
-  const bool fwd = a.tail <= OPS_MLP_TAIL_BN;
-  const bool has_bn = a.tail == OPS_MLP_TAIL_BN || a.tail == OPS_MLP_TAIL_BN_ACT_DROP || a.tail == OPS_MLP_TAIL_BWD_BN ||
-                      a.tail == OPS_MLP_TAIL_BWD_BN_ACT_DROP;
   const float keep_scale = a.p_drop > 0.0f ? 1.0f / (1.0f - a.p_drop) : 1.0f;
-  float g = 1.0f, be = 0.0f;
-  if (has_bn && clive) { g = a.gamma[c]; be = a.beta[c]; }
+  float lacc[5] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};      // TAIL_LOSS: sum |d|_I, sum d^2_I, sum box penalty, sum rel_d, sum rel_r
 
   if (fwd) {
-    const float bias = (clive && a.bias) ? mb_round(a.bias[c]) : 0.0f;
+    const float bias_b = mb_round(bias);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) v[i] = rl[i] ? mb_round(v[i] + bias) : 0.0f;       // the Linear's bf16 output
+    for (int i = 0; i < 4; ++i) v[i] = rl[i] ? mb_round(v[i] + bias_b) : 0.0f;       // the Linear's bf16 output
     if (a.add_mode == OPS_MLP_ADD_FWD_BLOCK) {
       // whole-tensor statistics of conv1(O) from the previous launch's partial sums
-      double s0 = 0.0, s1 = 0.0;
-      for (int p = 0; p < a.spart_rows; ++p) { s0 += a.spart[p * 2]; s1 += a.spart[p * 2 + 1]; }
-      const double n = (double)B * (double)a.No, m = s0 / n, var = fmax(s1 / n - m * m, 0.0);
+      const double n = (double)B * (double)No, m = s_tot[0] / n, var = fmax(s_tot[1] / n - m * m, 0.0);
       const float mean_s = (float)m, inv_s = (float)(1.0 / sqrt(var + (double)a.seps));
       if (blockIdx.x == 0 && tid == 0) {
         a.ssave[0] = mean_s; a.ssave[1] = inv_s;
@@ -179,15 +344,13 @@ __global__ __launch_bounds__(MB_THREADS) void mlp_strip_kernel(const ops_mlp_str
         a.srunning_var[0] = (1.0f - a.smomentum) * a.srunning_var[0] + a.smomentum * (float)(var * n / (n > 1.0 ? n - 1.0 : 1.0));
         if (a.snum_batches_tracked) a.snum_batches_tracked[0] += 1;
       }
-      const float w0 = a.conv_w[0], w1 = a.conv_w[1], w2 = a.conv_w[2], cb = a.conv_b[0];
-      const float scale = a.sgamma[0] * inv_s, shift = a.sbeta[0] - mean_s * scale;
+      const float scale = sc_g * inv_s, shift = sc_be - mean_s * scale;
 #pragma unroll
       for (int i = 0; i < 4; ++i)
         if (rl[i]) {
-          const int r = q + 32 * i;
-          const float o = mb_ldt(a.Ot, c, r);
-          const float s = mb_round(__builtin_fmaf(mb_conv_at(a.Ot, a.No, c, r, w0, w1, w2, cb), scale, shift));
-          v[i] = mb_round(v[i] + s + o);
+          const float conv = __builtin_fmaf(sc_w0, po[1][i], __builtin_fmaf(sc_w1, po[2][i], __builtin_fmaf(sc_w2, po[3][i], sc_b)));
+          const float s = mb_round(__builtin_fmaf(conv, scale, shift));
+          v[i] = mb_round(v[i] + s + po[2][i]);
         }
     }
     if (has_bn) {
@@ -209,16 +372,14 @@ __global__ __launch_bounds__(MB_THREADS) void mlp_strip_kernel(const ops_mlp_str
         }
       }
       if (blockIdx.x == 0 && tid == 0 && a.num_batches_tracked) a.num_batches_tracked[0] += 1;
-      uint16_t* zt = (uint16_t*)a.Zt;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        zt[(long)c * MB_ROWS + q + 32 * i] = mb_f2bf(v[i]);  // exact: v is a bf16 value
+        s_z[q + 32 * i][cl] = mb_f2bf(v[i]);                 // exact: v is a bf16 value; leaves with the results below
         v[i] = rl[i] ? __builtin_fmaf((v[i] - mean) * rstd, g, be) : 0.0f;
       }
     }
     if (a.tail == OPS_MLP_TAIL_ACT_DROP || a.tail == OPS_MLP_TAIL_BN_ACT_DROP) {
       const bool drop = a.p_drop > 0.0f;
-      const unsigned long long call = drop ? *a.call_counter : 0ull;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         float y = v[i] > 0.0f ? v[i] : v[i] * a.slope;
@@ -229,69 +390,103 @@ __global__ __launch_bounds__(MB_THREADS) void mlp_strip_kernel(const ops_mlp_str
         v[i] = y;
       }
     }
+    if (a.tail == OPS_MLP_TAIL_LOSS) {
+      // the predictions leave through LDS first, then v becomes d loss / d predictions
+      if (a.P) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) s_y[q + 32 * i][cl] = mb_f2bf(v[i]);
+        __syncthreads();
+        if (tid < 2 * MB_ROWS) {
+          const int r = tid >> 1, h = tid & 1;
+          *(uint4*)((uint16_t*)a.P + (long)r * a.ldp + n0 + 8 * h) = *(const uint4*)&s_y[r][8 * h];
+        }
+        __syncthreads();
+      }
+      const float alpha = fminf(fmaxf(a.alpha[0], 1e-6f), 1.0f);
+      const bool has_min = a.min_constraint != nullptr, has_max = a.max_constraint != nullptr;
+      const float lo = has_min ? a.min_constraint[0] : 0.0f, hi = has_max ? a.max_constraint[0] : 0.0f;
+      const int nI = a.nI, nD = a.nD, nR = N - nI - nD;
+      const float inv_nI = 1.0f / ((float)B * (float)nI), inv_nD = nD > 0 ? 1.0f / ((float)B * (float)nD) : 0.0f,
+                  inv_nR = nR > 0 ? 1.0f / ((float)B * (float)nR) : 0.0f;
+      const float w = a.box_weight, penalty = a.rel_penalty, eps = 1e-8f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float gg = 0.0f;
+        if (rl[i]) {
+          const float p = v[i], t = pt[i], d = p - t, sg = d > 0.0f ? 1.0f : (d < 0.0f ? -1.0f : 0.0f);
+          if (c < nI) {
+            lacc[0] += fabsf(d);
+            lacc[1] = __builtin_fmaf(d, d, lacc[1]);
+            gg = (alpha * sg + (1.0f - alpha) * 2.0f * d) * inv_nI;
+            if (has_min && p < lo) { lacc[2] += lo - p; gg -= w; }
+            if (has_max && p > hi) { lacc[2] += p - hi; gg += w; }
+          } else {
+            const float den = fabsf(t) + eps, rel = fabsf(d) / den;
+            if (c < nI + nD) { lacc[3] += rel; gg = penalty * sg / den * inv_nD; }
+            else { lacc[4] += rel; gg = penalty * sg / den * inv_nR; }
+          }
+        }
+        v[i] = gg;
+      }
+      float sb = 0.0f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) sb += mb_round(v[i]);
+      sb = mb_hsum(sb);
+      if (clive && q == 0 && a.dbias) a.dbias[c] = sb;
+    }
   } else {
 #pragma unroll
     for (int i = 0; i < 4; ++i) v[i] = rl[i] ? mb_round(v[i]) : 0.0f;              // the input gradient's bf16 value
     if (a.add_mode == OPS_MLP_ADD_BWD_BLOCK) {
       // + dZ (identity path) + conv1^T( bn1 backward (dZ) ) (stencil path); the whole-tensor means from the partial sums
-      double t0 = 0.0, t1 = 0.0;
-      for (int p = 0; p < a.spart_rows; ++p) { t0 += a.spart[p * MB_NSUM]; t1 += a.spart[p * MB_NSUM + 1]; }
-      const double n = (double)B * (double)a.No;
-      const float mg = (float)(t0 / n), mgy = (float)(t1 / n);
-      const float mean_s = a.ssave[0], inv_s = a.ssave[1], kk = a.sgamma[0] * inv_s;
-      const float w0 = a.conv_w[0], w1 = a.conv_w[1], w2 = a.conv_w[2], cb = a.conv_b[0];
+      const double n = (double)B * (double)No;
+      const float mg = (float)(s_tot[0] / n), mgy = (float)(s_tot[1] / n);
+      const float kk = sc_g * sv_inv;
       if (blockIdx.x == 0 && tid == 0) {
-        double t[MB_NSUM];
-        for (int k = 0; k < MB_NSUM; ++k) t[k] = 0.0;
-        for (int p = 0; p < a.spart_rows; ++p)
-          for (int k = 0; k < MB_NSUM; ++k) t[k] += a.spart[p * MB_NSUM + k];
         // dy = kk (g - mg - yhat mgy):  sum dy x_s = kk (sum g x_s - mg sum x_s - mgy sum yhat x_s);  sum dy likewise with x_s = 1
         for (int s = 0; s < 3; ++s)
-          a.sdparams[s] = (float)((double)kk * (t[3 + s] - (double)mg * t[6 + s] - (double)mgy * t[9 + s]));
-        a.sdparams[3] = (float)((double)kk * (t[0] - (double)mg * n - (double)mgy * t[2]));
-        a.sdparams[4] = (float)t[1];        // d gamma = sum g yhat
-        a.sdparams[5] = (float)t[0];        // d beta  = sum g
+          a.sdparams[s] = (float)((double)kk * (s_tot[3 + s] - (double)mg * s_tot[6 + s] - (double)mgy * s_tot[9 + s]));
+        a.sdparams[3] = (float)((double)kk * (s_tot[0] - (double)mg * n - (double)mgy * s_tot[2]));
+        a.sdparams[4] = (float)s_tot[1];        // d gamma = sum g yhat
+        a.sdparams[5] = (float)s_tot[0];        // d beta  = sum g
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i)
         if (rl[i]) {
-          const int r = q + 32 * i;
           float dy[3];
 #pragma unroll
-          for (int d = -1; d <= 1; ++d) {
-            const int qq = c + d;
-            if (qq >= 0 && qq < a.No) {
-              const float yh = (mb_conv_at(a.Ot, a.No, qq, r, w0, w1, w2, cb) - mean_s) * inv_s;
-              dy[d + 1] = kk * (mb_ldt(a.dZt, qq, r) - mg - yh * mgy);
+          for (int d = 0; d < 3; ++d) {
+            const int qq = c + d - 1;
+            if (qq >= 0 && qq < No) {
+              // columns outside [0, No) were prefetched as 0: the stencil's zero padding
+              const float conv = __builtin_fmaf(sc_w0, po[d][i], __builtin_fmaf(sc_w1, po[d + 1][i], __builtin_fmaf(sc_w2, po[d + 2][i], sc_b)));
+              const float yh = (conv - sv_mean) * sv_inv;
+              dy[d] = kk * (pg[d][i] - mg - yh * mgy);
             } else {
-              dy[d + 1] = 0.0f;
+              dy[d] = 0.0f;
             }
           }
-          const float sdx = __builtin_fmaf(w0, dy[2], __builtin_fmaf(w1, dy[1], w2 * dy[0]));
-          v[i] = mb_round(v[i] + mb_ldt(a.dZt, c, r) + sdx);
+          const float sdx = __builtin_fmaf(sc_w0, dy[2], __builtin_fmaf(sc_w1, dy[1], sc_w2 * dy[0]));
+          v[i] = mb_round(v[i] + pg[1][i] + sdx);
         }
     }
-    if (a.tail == OPS_MLP_TAIL_BWD_ACT_DROP || a.tail == OPS_MLP_TAIL_BWD_BN_ACT_DROP) {
+    if (act_bwd) {
       // mask and LeakyReLU branch from the saved forward output: 0 = dropped, sign = sign of the pre-activation
 #pragma unroll
       for (int i = 0; i < 4; ++i)
-        if (rl[i]) {
-          const float y = mb_ldt(a.Yref_t, c, q + 32 * i);
-          v[i] *= y == 0.0f ? 0.0f : (y > 0.0f ? keep_scale : a.slope * keep_scale);
-        }
+        if (rl[i]) v[i] *= py[i] == 0.0f ? 0.0f : (py[i] > 0.0f ? keep_scale : a.slope * keep_scale);
     }
     if (has_bn) {
-      const float mean = clive ? a.mean[c] : 0.0f, rstd = clive ? a.rstd[c] : 1.0f;
       float xh[4], sg = 0.0f, sgx = 0.0f;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        xh[i] = rl[i] ? (mb_ldt(a.Zt, c, q + 32 * i) - mean) * rstd : 0.0f;
+        xh[i] = rl[i] ? (pz[i] - mean_c) * rstd_c : 0.0f;
         sg += v[i];
         sgx = __builtin_fmaf(v[i], xh[i], sgx);
       }
       sg = mb_hsum(sg); sgx = mb_hsum(sgx);
       if (clive && q == 0) { a.dgamma[c] = sgx; a.dbeta[c] = sg; }
-      const float k2 = g * rstd;
+      const float k2 = g * rstd_c;
 #pragma unroll
       for (int i = 0; i < 4; ++i) v[i] = rl[i] ? k2 * (v[i] - sg * invB - xh[i] * sgx * invB) : 0.0f;
     }
@@ -304,73 +499,65 @@ __global__ __launch_bounds__(MB_THREADS) void mlp_strip_kernel(const ops_mlp_str
     }
   }
 
-  // ---- results: transposed copy from the registers (a lane's rows are contiguous there), row-major copy through LDS ----
-  uint16_t yb[4];
+  // ---- results through LDS, 16-byte chunks in the tiled layout: threads 0..255 the row-major copy (row, 8 columns), threads
+  // 256..511 the transposed copy (column, 8 rows); the saved pre-normalisation values likewise (transposed only) ----
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    yb[i] = rl[i] ? mb_f2bf(v[i]) : (uint16_t)0;
-    s_y[q + 32 * i][cl] = yb[i];
-  }
-  if (a.Yt) {
-    uint16_t* yt = (uint16_t*)a.Yt;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) yt[(long)c * MB_ROWS + q + 32 * i] = yb[i];
-  }
+  for (int i = 0; i < 4; ++i) s_y[q + 32 * i][cl] = rl[i] ? mb_f2bf(v[i]) : (uint16_t)0;
   __syncthreads();
   if (tid < 2 * MB_ROWS) {
     const int r = tid >> 1, h = tid & 1;
-    *(uint4*)((uint16_t*)a.Y + (long)r * a.ldy + n0 + 8 * h) = *(const uint4*)&s_y[r][8 * h];
+    *(uint4*)((uint16_t*)a.Y + mb_toff(r, n0 + 8 * h, a.ldy >> 5)) = *(const uint4*)&s_y[r][8 * h];
+  } else if (a.Yt) {
+    const int u = tid - 2 * MB_ROWS, c2 = u & 15, gq = u >> 4;
+    uint16_t t8[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) t8[j] = s_y[8 * gq + j][c2];
+    *(uint4*)((uint16_t*)a.Yt + mb_toff(n0 + c2, 8 * gq, MB_ROWS / 32)) = *(const uint4*)t8;
+  }
+  if (fwd && has_bn && tid < 2 * MB_ROWS) {
+    const int c2 = tid & 15, gq = tid >> 4;
+    uint16_t t8[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) t8[j] = s_z[8 * gq + j][c2];
+    *(uint4*)((uint16_t*)a.Zt + mb_toff(n0 + c2, 8 * gq, MB_ROWS / 32)) = *(const uint4*)t8;
   }
   if (fwd && a.p_drop > 0.0f && (a.tail == OPS_MLP_TAIL_ACT_DROP || a.tail == OPS_MLP_TAIL_BN_ACT_DROP) && blockIdx.x == 0 && tid == 0)
     atomicAdd(a.call_counter, 1ull);       // one increment per launch (a late reader draws from the next stream: as good a mask)
 
-  // ---- side job: partial sums for the whole-tensor BatchNorm1d(1) of the stencil path, over this workgroup's column slice ----
-  if (a.side != OPS_MLP_SIDE_NONE) {
-    const int cs = (a.No + (int)gridDim.x - 1) / (int)gridDim.x, c0 = blockIdx.x * cs;
-    const float w0 = a.conv_w[0], w1 = a.conv_w[1], w2 = a.conv_w[2], cb = a.conv_b[0];
-    if (a.side == OPS_MLP_SIDE_FWD_STENCIL_STATS) {
-      float p0 = 0.0f, p1 = 0.0f;
-      for (int e = tid; e < cs * MB_ROWS; e += MB_THREADS) {
-        const int cc = c0 + e / MB_ROWS, r = e % MB_ROWS;
-        if (cc < a.No && r < B) {
-          const float y = mb_conv_at(a.Ot, a.No, cc, r, w0, w1, w2, cb);
-          p0 += y;
-          p1 = __builtin_fmaf(y, y, p1);
-        }
+  if (a.tail == OPS_MLP_TAIL_LOSS) {
+    // loss value: per-strip partial sums; the strip that arrives last adds them (one wave, one partial row per lane)
+    double* part = (double*)a.loss_ws;
+    unsigned int* done = (unsigned int*)(part + ML_MAXG * 5);
+    double accd[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) accd[k] = (double)lacc[k];
+    mb_block_sum<5>(accd, s_red);
+    if (tid == 0) {
+#pragma unroll
+      for (int k = 0; k < 5; ++k) part[blockIdx.x * 5 + k] = accd[k];
+      __threadfence();
+      s_last = atomicAdd(done, 1u) == (unsigned)nstrips - 1u;
+    }
+    __syncthreads();
+    if (s_last && wave == 0) {
+      __threadfence();
+      double t[5];
+#pragma unroll
+      for (int k = 0; k < 5; ++k) t[k] = lane < nstrips ? __builtin_nontemporal_load(&part[lane * 5 + k]) : 0.0;
+#pragma unroll
+      for (int k = 0; k < 5; ++k) t[k] = mb_wsum_d(t[k]);
+      if (lane == 0) {
+        const double al = fmin(fmax((double)a.alpha[0], 1e-6), 1.0);
+        const int nI = a.nI, nD = a.nD, nR = N - nI - nD;
+        const double nIe = (double)B * nI;
+        double val = al * t[0] / nIe + (1.0 - al) * t[1] / nIe + (double)a.box_weight * t[2];
+        if (nD > 0) val += (double)a.rel_penalty * t[3] / ((double)B * nD);
+        if (nR > 0) val += (double)a.rel_penalty * t[4] / ((double)B * nR);
+        const double da = a.alpha0 == a.alpha0 ? (double)a.alpha0 - (double)a.alpha[0] : 0.0;      // NaN alpha0: no such term
+        a.loss[0] = (float)(val + da * da);
+        if (a.loss_sum) a.loss_sum[0] += (float)(val + da * da);      // the epoch's running total (the caller zeroes it)
+        *done = 0u;                        // ready for the next launch (graph replay)
       }
-      double acc[2] = {(double)p0, (double)p1};
-      mb_block_sum<2>(acc, s_red);
-      if (tid == 0) { a.spart[blockIdx.x * 2] = acc[0]; a.spart[blockIdx.x * 2 + 1] = acc[1]; }
-    } else {
-      // 0: sum g   1: sum g yhat   2: sum yhat   3..5: sum g x_s   6..8: sum x_s   9..11: sum yhat x_s   (x_s = O shifted by s - 1)
-      const float mean_s = a.ssave[0], inv_s = a.ssave[1];
-      float t[MB_NSUM];
-#pragma unroll
-      for (int k = 0; k < MB_NSUM; ++k) t[k] = 0.0f;
-      for (int e = tid; e < cs * MB_ROWS; e += MB_THREADS) {
-        const int cc = c0 + e / MB_ROWS, r = e % MB_ROWS;
-        if (cc < a.No && r < B) {
-          const float xs[3] = {cc > 0 ? mb_ldt(a.Ot, cc - 1, r) : 0.0f, mb_ldt(a.Ot, cc, r), cc + 1 < a.No ? mb_ldt(a.Ot, cc + 1, r) : 0.0f};
-          const float conv = __builtin_fmaf(w0, xs[0], __builtin_fmaf(w1, xs[1], __builtin_fmaf(w2, xs[2], cb)));
-          const float yh = (conv - mean_s) * inv_s, gi = mb_ldt(a.dZt, cc, r);
-          t[0] += gi;
-          t[1] = __builtin_fmaf(gi, yh, t[1]);
-          t[2] += yh;
-#pragma unroll
-          for (int s = 0; s < 3; ++s) {
-            t[3 + s] = __builtin_fmaf(gi, xs[s], t[3 + s]);
-            t[6 + s] += xs[s];
-            t[9 + s] = __builtin_fmaf(yh, xs[s], t[9 + s]);
-          }
-        }
-      }
-      double acc[MB_NSUM];
-#pragma unroll
-      for (int k = 0; k < MB_NSUM; ++k) acc[k] = (double)t[k];
-      mb_block_sum<MB_NSUM>(acc, s_red);
-      if (tid == 0)
-#pragma unroll
-        for (int k = 0; k < MB_NSUM; ++k) a.spart[blockIdx.x * MB_NSUM + k] = acc[k];
     }
   }
 }
@@ -389,15 +576,16 @@ __global__ __launch_bounds__(64) void mlp_wgrad_kernel(const WgradTable tb) {
   const ops_mlp_wgrad_problem pr = tb.p[pi];
   const int t = (int)blockIdx.x - tb.tile0[pi], tn = t / tb.tiles_k[pi], tk = t % tb.tiles_k[pi];
   const int lane = threadIdx.x;
-  const uint16_t* ap = (const uint16_t*)pr.At + (long)(tn * 32 + (lane & 15)) * MB_ROWS + 8 * (lane >> 4);
-  const uint16_t* bp = (const uint16_t*)pr.Bt + (long)(tk * 32 + (lane & 15)) * MB_ROWS + 8 * (lane >> 4);
+  // tiled storage, KS = 4: row block rb is 4 consecutive KB
+  const uint16_t* ap = (const uint16_t*)pr.At + (long)(tn * 2) * 4 * 512 + lane * 8;
+  const uint16_t* bp = (const uint16_t*)pr.Bt + (long)(tk * 2) * 4 * 512 + lane * 8;
   uint4 fa[2][4], fb[2][4];
 #pragma unroll
   for (int h = 0; h < 2; ++h)
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      fa[h][ks] = *(const uint4*)(ap + h * 16 * MB_ROWS + ks * 32);
-      fb[h][ks] = *(const uint4*)(bp + h * 16 * MB_ROWS + ks * 32);
+      fa[h][ks] = *(const uint4*)(ap + (h * 4 + ks) * 512);
+      fb[h][ks] = *(const uint4*)(bp + (h * 4 + ks) * 512);
     }
   mb_f32x4 acc[2][2];
 #pragma unroll
@@ -439,8 +627,8 @@ __global__ __launch_bounds__(256) void mlp_repack_kernel(const RepackTable tb) {
     const long le = e - tb.e0[mi];
     const int n = (int)(le / m.K), k = (int)(le - (long)n * m.K);
     const uint16_t h = mb_f2bf(m.W[le]);
-    ((uint16_t*)m.Wp)[(long)n * m.ldw + k] = h;
-    ((uint16_t*)m.Wtp)[(long)k * m.ldwt + n] = h;
+    ((uint16_t*)m.Wp)[mb_toff(n, k, m.ldw >> 5)] = h;
+    ((uint16_t*)m.Wtp)[mb_toff(k, n, m.ldwt >> 5)] = h;
   }
 }
 
@@ -454,15 +642,44 @@ __device__ __forceinline__ uint64_t mb_mix(uint64_t z) {
 __global__ __launch_bounds__(256) void mlp_gather_noise_kernel(int B, int F, const float* __restrict__ X, const long long* __restrict__ idx,
                                                                 const float* __restrict__ sigma, unsigned long long seed,
                                                                 unsigned long long* __restrict__ counter, uint16_t* __restrict__ out, int ld,
-                                                                uint16_t* __restrict__ out_t) {
-  __shared__ uint16_t s_tile[32][MB_ROWS + 2];
-  const int f0 = blockIdx.x * 32, fl = threadIdx.x & 31, f = f0 + fl;
+                                                                uint16_t* __restrict__ out_t, int nfb, const float* __restrict__ Ysrc, int C,
+                                                                float* __restrict__ yout_t) {
+  __shared__ __attribute__((aligned(16))) uint16_t s_tile[32][MB_ROWS + 8];     // [feature][row]
+  __shared__ float s_tt[32][MB_ROWS + 1];
+  const int fl = threadIdx.x & 31;
+  // 16 rows per thread: all row indices first, then all 16 gathers -- two exposed latencies, not thirty-two
+  long src[16];
+  float xv[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const int b = (threadIdx.x >> 5) + 8 * j;
+    src[j] = b < B ? (long)idx[b] : -1;
+  }
+  if ((int)blockIdx.x >= nfb) {
+    // targets: yout_t [C, 128] float32 (transposed: the loss tail reads a column's rows contiguously), rows >= B zero
+    const int c0 = ((int)blockIdx.x - nfb) * 32, c = c0 + fl;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) xv[j] = (src[j] >= 0 && c < C) ? Ysrc[src[j] * (long)C + c] : 0.0f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) s_tt[fl][(threadIdx.x >> 5) + 8 * j] = xv[j];
+    __syncthreads();
+    for (int e = threadIdx.x; e < 32 * MB_ROWS; e += 256) {
+      const int cc = e / MB_ROWS, b = e % MB_ROWS;
+      if (c0 + cc < C) yout_t[(long)(c0 + cc) * MB_ROWS + b] = s_tt[cc][b];
+    }
+    return;
+  }
+  const int f0 = blockIdx.x * 32, f = f0 + fl;
   const float sg = sigma ? *sigma : 0.0f;
   const unsigned long long call = counter ? *counter : 0ull;
-  for (int b = threadIdx.x >> 5; b < MB_ROWS; b += 8) {
+#pragma unroll
+  for (int j = 0; j < 16; ++j) xv[j] = (src[j] >= 0 && f < F) ? X[src[j] * (long)F + f] : 0.0f;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const int b = (threadIdx.x >> 5) + 8 * j;
     uint16_t h = 0;
     if (b < B && f < F) {
-      float v = X[idx[b] * (long)F + f];
+      float v = xv[j];
       if (sg != 0.0f) {
         const uint64_t hh = mb_mix(seed + 0x9E3779B97F4A7C15ull * (call + 1) + (uint64_t)((long)b * F + f) * 0xD1B54A32D192ED03ull);
         const float u1 = ((float)(hh >> 40) + 1.0f) * (1.0f / 16777216.0f);          // (0, 1]
@@ -471,94 +688,26 @@ __global__ __launch_bounds__(256) void mlp_gather_noise_kernel(int B, int F, con
       }
       h = mb_f2bf(v);
     }
-    if (f < ld) out[(long)b * ld + f] = h;
     s_tile[fl][b] = h;
   }
   __syncthreads();
-  for (int e = threadIdx.x; e < 32 * MB_ROWS; e += 256) {
-    const int ff = e / MB_ROWS, b = e % MB_ROWS;
-    out_t[(long)(f0 + ff) * MB_ROWS + b] = s_tile[ff][b];
+  // both tiled copies in 16-byte chunks: 512 chunks (row, 8 features) of x and 512 chunks (feature, 8 rows) of x^T, two each per thread
+#pragma unroll
+  for (int rep = 0; rep < 2; ++rep) {
+    const int u = threadIdx.x + 256 * rep;
+    {
+      const int b = u >> 2, fg = u & 3;                       // row b, features f0 + 8 fg ..
+      uint16_t t8[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) t8[j] = s_tile[8 * fg + j][b];
+      *(uint4*)(out + mb_toff(b, f0 + 8 * fg, ld >> 5)) = *(const uint4*)t8;
+    }
+    {
+      const int ff = u & 31, bg = u >> 5;                     // feature f0 + ff, rows 8 bg ..
+      *(uint4*)(out_t + mb_toff(f0 + ff, 8 * bg, MB_ROWS / 32)) = *(const uint4*)&s_tile[ff][8 * bg];
+    }
   }
   if (counter && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(counter, 1ull);
-}
-
-// ---- training loss on the layout: value, gradient (both layouts), output-bias gradient; last workgroup adds the partials ----
-constexpr int ML_MAXG = 64;
-
-__global__ __launch_bounds__(MB_THREADS) void mlp_loss_kernel(int B, int C, int nI, int nD, const uint16_t* __restrict__ preds, int ldp,
-                                                               const float* __restrict__ targets, const float* __restrict__ alpha_p, float alpha0,
-                                                               const float* __restrict__ minc, const float* __restrict__ maxc, float w,
-                                                               float penalty, float eps, float* __restrict__ loss, uint16_t* __restrict__ grad,
-                                                               int ldg, uint16_t* __restrict__ grad_t, float* __restrict__ dbias,
-                                                               double* __restrict__ part, unsigned int* __restrict__ done) {
-  __shared__ __attribute__((aligned(16))) uint16_t s_y[MB_ROWS][MB_COLS];
-  __shared__ double s_red[(MB_THREADS / 64) * 5];
-  __shared__ bool s_last;
-  const int tid = threadIdx.x, cl = tid >> 5, q = tid & 31, n0 = blockIdx.x * MB_COLS, c = n0 + cl;
-  const float alpha = fminf(fmaxf(alpha_p[0], 1e-6f), 1.0f);
-  const bool has_min = minc != nullptr, has_max = maxc != nullptr;
-  const float lo = has_min ? minc[0] : 0.0f, hi = has_max ? maxc[0] : 0.0f;
-  const int nR = C - nI - nD;
-  const float inv_nI = 1.0f / ((float)B * (float)nI), inv_nD = nD > 0 ? 1.0f / ((float)B * (float)nD) : 0.0f,
-              inv_nR = nR > 0 ? 1.0f / ((float)B * (float)nR) : 0.0f;
-  float acc[5] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};      // sum |d|_I, sum d^2_I, sum box penalty, sum rel_d, sum rel_r
-  float sb = 0.0f;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int r = q + 32 * i;
-    uint16_t gb = 0;
-    if (c < C && r < B) {
-      const float p = mb_bf2f(preds[(long)r * ldp + c]);
-      const float t = targets[(long)r * C + c], d = p - t, sg = d > 0.0f ? 1.0f : (d < 0.0f ? -1.0f : 0.0f);
-      float g;
-      if (c < nI) {
-        acc[0] += fabsf(d);
-        acc[1] = __builtin_fmaf(d, d, acc[1]);
-        g = (alpha * sg + (1.0f - alpha) * 2.0f * d) * inv_nI;
-        if (has_min && p < lo) { acc[2] += lo - p; g -= w; }
-        if (has_max && p > hi) { acc[2] += p - hi; g += w; }
-      } else {
-        const float den = fabsf(t) + eps, rel = fabsf(d) / den;
-        if (c < nI + nD) { acc[3] += rel; g = penalty * sg / den * inv_nD; }
-        else { acc[4] += rel; g = penalty * sg / den * inv_nR; }
-      }
-      gb = mb_f2bf(g);
-      sb += mb_bf2f(gb);
-    }
-    s_y[r][cl] = gb;
-    grad_t[(long)c * MB_ROWS + r] = gb;
-  }
-  sb = mb_hsum(sb);
-  if (c < C && q == 0) dbias[c] = sb;
-  double accd[5];
-#pragma unroll
-  for (int k = 0; k < 5; ++k) accd[k] = (double)acc[k];
-  mb_block_sum<5>(accd, s_red);       // (contains the barriers that publish s_y)
-  if (tid < 2 * MB_ROWS) {
-    const int r = tid >> 1, h = tid & 1;
-    *(uint4*)(grad + (long)r * ldg + n0 + 8 * h) = *(const uint4*)&s_y[r][8 * h];
-  }
-  if (tid == 0) {
-#pragma unroll
-    for (int k = 0; k < 5; ++k) part[blockIdx.x * 5 + k] = accd[k];
-    __threadfence();
-    s_last = atomicAdd(done, 1u) == gridDim.x - 1;
-  }
-  __syncthreads();
-  if (s_last && tid == 0) {
-    __threadfence();
-    double t[5] = {0, 0, 0, 0, 0};
-    for (int gq = 0; gq < (int)gridDim.x; ++gq)
-      for (int k = 0; k < 5; ++k) t[k] += ((volatile double*)part)[gq * 5 + k];
-    const double al = fmin(fmax((double)alpha_p[0], 1e-6), 1.0);
-    const double nIe = (double)B * nI;
-    double v = al * t[0] / nIe + (1.0 - al) * t[1] / nIe + (double)w * t[2];
-    if (nD > 0) v += (double)penalty * t[3] / ((double)B * nD);
-    if (nR > 0) v += (double)penalty * t[4] / ((double)B * nR);
-    const double da = alpha0 == alpha0 ? (double)alpha0 - (double)alpha_p[0] : 0.0;      // NaN alpha0: no such term
-    loss[0] = (float)(v + da * da);
-    *done = 0u;                        // ready for the next launch (graph replay)
-  }
 }
 
 }  // namespace opsamd
@@ -567,34 +716,42 @@ using namespace opsamd;
 
 static inline int ru(int v, int m) { return (v + m - 1) / m * m; }
 
-extern "C" size_t ops_mlp_spart_doubles(int N) { return (size_t)((N + MB_COLS - 1) / MB_COLS) * MB_NSUM; }
+extern "C" size_t ops_mlp_spart_doubles(int No) { return (size_t)((No + MB_SIDE_COLS - 1) / MB_SIDE_COLS) * MB_NSUM; }
 
 extern "C" int ops_mlp_strip_launch(const ops_mlp_strip_args* args, void* stream) {
   if (!args) return OPS_AMD_ERR_INVALID_ARG;
   const ops_mlp_strip_args& a = *args;
   if (a.B < 1 || a.B > MB_ROWS || a.N < 1 || a.K < 1 || !a.A || !a.W || !a.Y) return OPS_AMD_ERR_INVALID_ARG;
-  if (a.lda % 8 || a.ldw % 8 || a.ldy % 8 || a.lda < ru(a.K, 32) || a.ldw < ru(a.K, 32) || a.ldy < ru(a.N, MB_COLS)) return OPS_AMD_ERR_INVALID_ARG;
+  if (a.lda % 32 || a.ldw % 32 || a.ldy % 32 || a.lda < ru(a.K, 32) || a.ldw < ru(a.K, 32) || a.ldy < ru(a.N, 32)) return OPS_AMD_ERR_INVALID_ARG;
   if (((uintptr_t)a.A | (uintptr_t)a.W | (uintptr_t)a.Y) & 15) return OPS_AMD_ERR_INVALID_ARG;
-  if (a.tail < OPS_MLP_TAIL_NONE || a.tail > OPS_MLP_TAIL_BWD_BN_ACT_DROP) return OPS_AMD_ERR_INVALID_ARG;
+  if (a.tail < OPS_MLP_TAIL_NONE || a.tail > OPS_MLP_TAIL_LOSS) return OPS_AMD_ERR_INVALID_ARG;
   const bool bn = a.tail == OPS_MLP_TAIL_BN || a.tail == OPS_MLP_TAIL_BN_ACT_DROP || a.tail == OPS_MLP_TAIL_BWD_BN || a.tail == OPS_MLP_TAIL_BWD_BN_ACT_DROP;
-  const bool bwd = a.tail >= OPS_MLP_TAIL_BWD_ACT_DROP;
+  const bool bwd = a.tail >= OPS_MLP_TAIL_BWD_ACT_DROP && a.tail <= OPS_MLP_TAIL_BWD_BN_ACT_DROP;
   if (bn && (!a.gamma || !a.beta || !a.mean || !a.rstd || !a.Zt)) return OPS_AMD_ERR_INVALID_ARG;
   if (bn && bwd && (!a.dgamma || !a.dbeta)) return OPS_AMD_ERR_INVALID_ARG;
   if ((a.tail == OPS_MLP_TAIL_BWD_ACT_DROP || a.tail == OPS_MLP_TAIL_BWD_BN_ACT_DROP) && !a.Yref_t) return OPS_AMD_ERR_INVALID_ARG;
   if ((a.tail == OPS_MLP_TAIL_ACT_DROP || a.tail == OPS_MLP_TAIL_BN_ACT_DROP) && a.p_drop > 0.0f && (!a.call_counter || a.p_drop >= 1.0f))
     return OPS_AMD_ERR_INVALID_ARG;
+  const int nstrips = (a.N + MB_COLS - 1) / MB_COLS;
+  if (a.tail == OPS_MLP_TAIL_LOSS) {
+    if (!a.targets_t || !a.alpha || !a.loss || !a.loss_ws || !a.Yt || a.nI < 1 || a.nD < 0 || a.nI + a.nD > a.N || nstrips > ML_MAXG) return OPS_AMD_ERR_INVALID_ARG;
+    if (a.P && (a.ldp % 8 || a.ldp < ru(a.N, MB_COLS) || ((uintptr_t)a.P & 15))) return OPS_AMD_ERR_INVALID_ARG;
+  }
+  int nside = 0;
   if (a.add_mode != OPS_MLP_ADD_NONE || a.side != OPS_MLP_SIDE_NONE) {
     if (!a.Ot || a.No < 1 || !a.conv_w || !a.conv_b || !a.sgamma || !a.sbeta || !a.ssave || !a.spart) return OPS_AMD_ERR_INVALID_ARG;
-    if (a.add_mode == OPS_MLP_ADD_FWD_BLOCK && (bwd || a.No != a.N || !a.srunning_mean || !a.srunning_var || a.spart_rows < 1)) return OPS_AMD_ERR_INVALID_ARG;
-    if (a.add_mode == OPS_MLP_ADD_BWD_BLOCK && (!bwd || a.No != a.N || !a.dZt || !a.sdparams || a.spart_rows < 1)) return OPS_AMD_ERR_INVALID_ARG;
+    if (a.No > MB_MAX_SIDE * MB_SIDE_COLS) return OPS_AMD_ERR_UNSUPPORTED;
+    if (a.add_mode == OPS_MLP_ADD_FWD_BLOCK && (bwd || a.No != a.N || !a.srunning_mean || !a.srunning_var)) return OPS_AMD_ERR_INVALID_ARG;
+    if (a.add_mode == OPS_MLP_ADD_BWD_BLOCK && (!bwd || a.No != a.N || !a.dZt || !a.sdparams)) return OPS_AMD_ERR_INVALID_ARG;
     if (a.side == OPS_MLP_SIDE_BWD_STENCIL_SUMS && !a.dZt) return OPS_AMD_ERR_INVALID_ARG;
+    if (a.side != OPS_MLP_SIDE_NONE) {
+      if (a.add_mode != OPS_MLP_ADD_NONE) return OPS_AMD_ERR_INVALID_ARG;      // one workspace: a launch either fills or reads it
+      nside = (a.No + MB_SIDE_COLS - 1) / MB_SIDE_COLS;
+    }
   }
-  const int KS = (a.K + 31) / 32;
-  const dim3 grid((unsigned)((a.N + MB_COLS - 1) / MB_COLS)), block(MB_THREADS);
+  const dim3 grid((unsigned)(nstrips + nside)), block(MB_THREADS);
   hipStream_t s = (hipStream_t)stream;
-  if (KS <= 8) hipLaunchKernelGGL(mlp_strip_kernel<8>, grid, block, 0, s, a);
-  else if (KS <= 12) hipLaunchKernelGGL(mlp_strip_kernel<12>, grid, block, 0, s, a);
-  else hipLaunchKernelGGL(mlp_strip_kernel<24>, grid, block, 0, s, a);
+  hipLaunchKernelGGL(mlp_strip_kernel, grid, block, 0, s, a, nstrips);
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) { set_last_error(hipGetErrorString(e)); return OPS_AMD_ERR_LAUNCH; }
   return OPS_AMD_OK;
@@ -628,7 +785,7 @@ extern "C" int ops_mlp_repack_weights(int nmat, const ops_mlp_repack_entry* entr
   long tot = 0;
   for (int i = 0; i < nmat; ++i) {
     const ops_mlp_repack_entry& m = entries[i];
-    if (!m.W || !m.Wp || !m.Wtp || m.N < 1 || m.K < 1 || m.ldw < ru(m.K, 32) || m.ldwt < ru(m.N, 32)) return OPS_AMD_ERR_INVALID_ARG;
+    if (!m.W || !m.Wp || !m.Wtp || m.N < 1 || m.K < 1 || m.ldw % 32 || m.ldwt % 32 || m.ldw < ru(m.K, 32) || m.ldwt < ru(m.N, 32)) return OPS_AMD_ERR_INVALID_ARG;
     tb.m[i] = m;
     tb.e0[i] = tot;
     tot += (long)m.N * m.K;
@@ -643,31 +800,16 @@ extern "C" int ops_mlp_repack_weights(int nmat, const ops_mlp_repack_entry* entr
 }
 
 extern "C" int ops_mlp_gather_noise(int B, int F, const float* X, const long long* idx, const float* sigma, unsigned long long seed,
-                                    unsigned long long* counter, void* out, int ld, void* out_t, void* stream) {
-  if (B < 1 || B > MB_ROWS || F < 1 || !X || !idx || !out || !out_t || ld % 8 || ld < ru(F, 32)) return OPS_AMD_ERR_INVALID_ARG;
-  hipLaunchKernelGGL(mlp_gather_noise_kernel, dim3((unsigned)((F + 31) / 32)), dim3(256), 0, (hipStream_t)stream, B, F, X, idx, sigma, seed,
-                     counter, (uint16_t*)out, ld, (uint16_t*)out_t);
+                                    unsigned long long* counter, void* out, int ld, void* out_t, const float* Y, int C, float* targets_t,
+                                    void* stream) {
+  if (B < 1 || B > MB_ROWS || F < 1 || !X || !idx || !out || !out_t || ld % 32 || ld < ru(F, 32)) return OPS_AMD_ERR_INVALID_ARG;
+  if (Y && (C < 1 || !targets_t)) return OPS_AMD_ERR_INVALID_ARG;
+  const int nfb = (F + 31) / 32, ntb = Y ? (C + 31) / 32 : 0;
+  hipLaunchKernelGGL(mlp_gather_noise_kernel, dim3((unsigned)(nfb + ntb)), dim3(256), 0, (hipStream_t)stream, B, F, X, idx, sigma, seed,
+                     counter, (uint16_t*)out, ld, (uint16_t*)out_t, nfb, Y, C, targets_t);
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) { set_last_error(hipGetErrorString(e)); return OPS_AMD_ERR_LAUNCH; }
   return OPS_AMD_OK;
 }
 
 extern "C" size_t ops_mlp_loss_workspace_bytes(void) { return (size_t)ML_MAXG * 5 * sizeof(double) + 16; }
-
-extern "C" int ops_mlp_loss_grad(int B, int C, int nI, int nD, const void* preds, int ldp, const float* targets, const float* alpha, float alpha0,
-                                 const float* min_constraint, const float* max_constraint, float box_weight, float rel_penalty, float* loss,
-                                 void* grad, int ldg, void* grad_t, float* dbias, void* workspace, void* stream) {
-  if (B < 1 || B > MB_ROWS || C < 1 || nI < 1 || nD < 0 || nI + nD > C || !preds || !targets || !alpha || !loss || !grad || !grad_t || !dbias ||
-      !workspace)
-    return OPS_AMD_ERR_INVALID_ARG;
-  const int G = (C + MB_COLS - 1) / MB_COLS;
-  if (G > ML_MAXG || ldp < C || ldg % 8 || ldg < ru(C, MB_COLS) || ((uintptr_t)grad & 15)) return OPS_AMD_ERR_INVALID_ARG;
-  double* part = (double*)workspace;
-  unsigned int* done = (unsigned int*)(part + ML_MAXG * 5);
-  hipLaunchKernelGGL(mlp_loss_kernel, dim3((unsigned)G), dim3(MB_THREADS), 0, (hipStream_t)stream, B, C, nI, nD, (const uint16_t*)preds, ldp, targets,
-                     alpha, alpha0, min_constraint, max_constraint, box_weight, rel_penalty, 1e-8f, loss, (uint16_t*)grad, ldg, (uint16_t*)grad_t,
-                     dbias, part, done);
-  const hipError_t e = hipGetLastError();
-  if (e != hipSuccess) { set_last_error(hipGetErrorString(e)); return OPS_AMD_ERR_LAUNCH; }
-  return OPS_AMD_OK;
-}

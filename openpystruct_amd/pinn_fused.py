@@ -1,4 +1,4 @@
-"""The PINN's training step as 17 launches: host side of csrc/mlp_block.hip.
+"""The PINN's training step as 15 launches: host side of csrc/mlp_block.hip.
 
 `FNNWithResidual` (/root/reference/OpenPyStruct_PINN_MultiCase.py:454-541) + `CompositeLoss` (:603-653), forward AND backward,
 for batches of up to 128 rows, without autograd: every `Linear -> [stencil + residual] -> BatchNorm1d -> LeakyReLU -> dropout`
@@ -6,11 +6,11 @@ group is one launch, so is each backward counterpart, all weight gradients are o
 gradient is written straight into the training loop's flat gradient buffer.  The module itself stays the owner of the
 parameters and BatchNorm buffers (the launches read and update them in place); evaluation keeps using the module.
 
-    repack | input | (fc1, fc2+stencil+norm) x blocks | output | loss || d output | (d fc2, d fc1) x blocks | weight gradients
+    gather | input | (fc1, fc2+stencil+norm) x blocks | output+loss || d output | (d fc2, d fc1) x blocks | weight gradients | norm | Adam+repack
 
-Layout contract (include/openpystruct_amd.h): every activation / gradient exists row-major [128, ld] and transposed
-[F r.u. 32, 128] in bfloat16, zero outside the live corner; the buffers below are zero-initialised once and the launches
-only ever write zeros into dead rows / columns.
+Layout contract (include/openpystruct_amd.h): every activation / gradient exists as X (rows = batch) and as Xt (rows =
+columns of X) in bfloat16, both FRAGMENT-TILED (1 KB tiles in MFMA lane order: `to_tiled` / `from_tiled`), zero outside the
+live corner; the buffers below are zero-initialised once and the launches only ever write zeros into dead rows / columns.
 """
 from __future__ import annotations
 
@@ -29,6 +29,19 @@ ENABLED = os.environ.get("OPS_AMD_PINN_LAYER_BLOCKS", "1") == "1"      # A/B swi
 
 def _ru(v: int, m: int) -> int:
     return (v + m - 1) // m * m
+
+
+def to_tiled(x: torch.Tensor) -> torch.Tensor:
+    """[rows, K] (rows % 16 == 0, K % 32 == 0) -> the fragment-tiled storage: tile (row >> 4, k >> 5) of 512 elements, inside it
+    element (row, k) at ((k >> 3) & 3) * 128 + (row & 15) * 8 + (k & 7)."""
+    R, K = x.shape
+    return x.reshape(R // 16, 16, K // 32, 4, 8).permute(0, 2, 3, 1, 4).contiguous().reshape(R, K)
+
+
+def from_tiled(t: torch.Tensor) -> torch.Tensor:
+    """Inverse of `to_tiled` (t carries the logical shape [rows, K] of the matrix it stores)."""
+    R, K = t.shape
+    return t.reshape(R // 16, K // 32, 4, 16, 8).permute(0, 3, 1, 2, 4).contiguous().reshape(R, K)
 
 
 def eligible(model: nn.Module, crit: nn.Module, batch_size: int) -> bool:
@@ -96,10 +109,12 @@ class PinnFusedStep:
         self.mean = [f32(H) for _ in range(self.nblk + 1)]
         self.rstd = [f32(H) for _ in range(self.nblk + 1)]
         self.ssave = [f32(2) for _ in range(self.nblk)]
-        nsp = int(self.lib.ops_mlp_spart_doubles(max(H, Hh)))
+        nsp = int(self.lib.ops_mlp_spart_doubles(H))
         self.spart_f = [torch.zeros(nsp, dtype=torch.float64, device=dev) for _ in range(self.nblk)]
         self.spart_b = [torch.zeros(nsp, dtype=torch.float64, device=dev) for _ in range(self.nblk)]
         self.loss = torch.zeros((), dtype=torch.float32, device=dev)
+        self.loss_sum = torch.zeros((), dtype=torch.float32, device=dev)       # += loss per step; the caller zeroes it (per epoch)
+        self.targets_t = torch.zeros(C, R, dtype=torch.float32, device=dev)    # the batch's targets, transposed
         self.loss_ws = torch.zeros(int(self.lib.ops_mlp_loss_workspace_bytes()), dtype=torch.uint8, device=dev)
         self.drop_counter = torch.zeros(2, dtype=torch.int64, device=dev)
         self.prep_counter = torch.zeros(1, dtype=torch.int64, device=dev)
@@ -121,11 +136,14 @@ class PinnFusedStep:
         sc = lambda v: None if v is None else (v if torch.is_tensor(v) else torch.tensor(float(v))).to(device=dev, dtype=torch.float32).reshape(())   # noqa: E731
         self._minc, self._maxc = sc(l1l2.min_constraint), sc(l1l2.max_constraint)
         self._build()
+        self.repack_now()
 
     # ---- launch descriptors (built once: every pointer is stable, so the sequence can be captured in a HIP graph) ----
     def _strip(self, **kw) -> _cabi.MlpStripArgs:
         a = _cabi.MlpStripArgs()
         for k, v in kw.items():
+            if v is None:
+                continue
             if torch.is_tensor(v):
                 self._keep.append(v)
                 v = v.data_ptr()
@@ -148,7 +166,6 @@ class PinnFusedStep:
     def _build(self) -> None:
         m, C = self.model, _cabi
         H, Hh, Fi, Co = self.H, self.Hh, self.F_in, self.C
-        G1 = (Hh + 15) // 16                                     # workgroups of an fc1-shaped launch = rows of partial sums
         slope, pd = float(m.Leaky.negative_slope), float(m.dropout.p)
         fwd, bwd = [], []
         wp, wtp = self.wp[id(m.input_fc)]
@@ -166,12 +183,17 @@ class PinnFusedStep:
                                    call_counter=self.drop_counter, Ot=o_in_t, spart=self.spart_f[k], **self._stencil(rb, k)))
             fwd.append(self._strip(N=H, K=Hh, tail=C.MLP_TAIL_BN, add_mode=C.MLP_ADD_FWD_BLOCK, A=self.h[k][0], lda=self.h[k][0].shape[1],
                                    W=w2, ldw=w2.shape[1], bias=rb.fc2.bias, Y=self.o[k + 1][0], ldy=self.o[k + 1][0].shape[1],
-                                   Yt=self.o[k + 1][1], Zt=self.zt[k], Ot=o_in_t, spart=self.spart_f[k], spart_rows=G1,
+                                   Yt=self.o[k + 1][1], Zt=self.zt[k], Ot=o_in_t, spart=self.spart_f[k],
                                    **self._bn_fwd(norm, k + 1), **self._stencil(rb, k)))
         wo, wot = self.wp[id(m.output_fc)]
         o_last = self.o[self.nblk]
-        fwd.append(self._strip(N=Co, K=H, tail=C.MLP_TAIL_NONE, A=o_last[0], lda=o_last[0].shape[1], W=wo, ldw=wo.shape[1],
-                               bias=m.output_fc.bias, Y=self.preds, ldy=self.preds.shape[1]))
+        crit, l1l2 = self.crit, self.crit.l1l2_loss
+        fwd.append(self._strip(N=Co, K=H, tail=C.MLP_TAIL_LOSS, A=o_last[0], lda=o_last[0].shape[1], W=wo, ldw=wo.shape[1],
+                               bias=m.output_fc.bias, Y=self.gp, ldy=self.gp.shape[1], Yt=self.gpt, P=self.preds, ldp=self.preds.shape[1],
+                               nI=crit.nelem, nD=crit.deflection_dim, alpha=self._alpha, alpha0=float("nan"), min_constraint=self._minc,
+                               max_constraint=self._maxc, box_weight=float(l1l2.penalty_weight), rel_penalty=float(crit.penalty_pinn),
+                               loss=self.loss, loss_ws=self.loss_ws, loss_sum=self.loss_sum, targets_t=self.targets_t,
+                               dbias=m.output_fc.bias.grad))
         # backward: d preds -> gradient at the last block's sum (through its norm)
         last_blk = m.residual_blocks[self.nblk - 1]
         bwd.append(self._strip(N=H, K=Co, tail=C.MLP_TAIL_BWD_BN, A=self.gp, lda=self.gp.shape[1], W=wot, ldw=wot.shape[1],
@@ -198,7 +220,7 @@ class PinnFusedStep:
                 raise ValueError("conv1.weight/.bias and bn1.weight/.bias gradients must be six consecutive floats of the flat buffer")
             bwd.append(self._strip(N=H, K=Hh, add_mode=C.MLP_ADD_BWD_BLOCK, A=self.dh[k][0], lda=self.dh[k][0].shape[1], W=w1t,
                                    ldw=w1t.shape[1], Y=self.dz[k][0], ldy=self.dz[k][0].shape[1], Yt=self.dz[k][1], Ot=o_in_t, dZt=dzk_t,
-                                   spart=self.spart_b[k], spart_rows=G1, sdparams=rb.conv1.weight.grad, **tail, **self._stencil(rb, k)))
+                                   spart=self.spart_b[k], sdparams=rb.conv1.weight.grad, **tail, **self._stencil(rb, k)))
         self._fwd, self._bwd = fwd, bwd
         # grouped weight gradients
         probs = []
@@ -223,47 +245,58 @@ class PinnFusedStep:
             raise RuntimeError(f"{what} failed with code {rc}: {self.lib.ops_amd_last_error().decode()}")
 
     # ---- the step ----
-    def gather(self, X: torch.Tensor, idx: torch.Tensor, sigma: torch.Tensor, seed: int) -> int:
-        """x <- X[idx] + sigma * N(0, 1), both layouts (PINN:748-756).  Returns the number of live rows."""
+    def gather(self, X: torch.Tensor, Y: torch.Tensor, idx: torch.Tensor, sigma: torch.Tensor, seed: int) -> int:
+        """x <- X[idx] + sigma * N(0, 1) in both layouts, targets_t <- Y[idx]^T (PINN:748-756), one launch.  Returns the live rows."""
         B = int(idx.numel())
+        if X.dtype != torch.float32 or not X.is_contiguous() or Y.dtype != torch.float32 or not Y.is_contiguous() or Y.shape[1] != self.C:
+            raise ValueError("X and Y must be contiguous float32 matrices")
         s = torch.cuda.current_stream(self.dev).cuda_stream
         with torch.cuda.device(self.dev):
             self._check(self.lib.ops_mlp_gather_noise(B, self.F_in, X.data_ptr(), idx.data_ptr(), sigma.data_ptr() if sigma is not None else None,
                                                       int(seed) & 0x7FFFFFFFFFFFFFFF, self.prep_counter.data_ptr(), self.x.data_ptr(),
-                                                      self.x.shape[1], self.xt.data_ptr(), s), "ops_mlp_gather_noise")
+                                                      self.x.shape[1], self.xt.data_ptr(), Y.data_ptr(), self.C, self.targets_t.data_ptr(), s),
+                        "ops_mlp_gather_noise")
         return B
 
-    def set_input(self, Xb: torch.Tensor) -> int:
-        """Tests / eager callers: a ready batch [B, F_in] instead of gather()."""
+    def set_batch(self, Xb: torch.Tensor, Yb: torch.Tensor) -> int:
+        """Tests / eager callers: a ready batch [B, F_in], [B, C] instead of gather()."""
         B = Xb.shape[0]
-        self.x.zero_(); self.xt.zero_()
-        xb = Xb.to(torch.bfloat16)
-        self.x[:B, :self.F_in] = xb
-        self.xt[:self.F_in, :B] = xb.t()
+        R = _cabi.MLP_MAX_ROWS
+        xb = torch.zeros(R, self.x.shape[1], dtype=torch.bfloat16, device=self.dev)
+        xb[:B, :self.F_in] = Xb.to(torch.bfloat16)
+        self.x.copy_(to_tiled(xb))
+        self.xt.copy_(to_tiled(xb.t().contiguous()))
+        self.targets_t.zero_()
+        self.targets_t[:, :B] = Yb.to(torch.float32).t()
         return B
+
+    def read(self, buf: torch.Tensor, rows: int, cols: int) -> torch.Tensor:
+        """The live [rows, cols] corner of a tiled buffer, as a plain matrix."""
+        return from_tiled(buf)[:rows, :cols]
+
+    def repack_now(self) -> None:
+        """bf16 copies of the weights in both layouts from the float32 parameters.  The optimiser refreshes them in its own
+        update launch (FlatClipAdam.repack); call this after anything else changed the parameters (load_state_dict)."""
+        with torch.cuda.device(self.dev):
+            self._check(self.lib.ops_mlp_repack_weights(len(self._repack), self._repack, torch.cuda.current_stream(self.dev).cuda_stream),
+                        "ops_mlp_repack_weights")
 
     def forward(self, B: int, stream=None) -> None:
         s = stream if stream is not None else torch.cuda.current_stream(self.dev).cuda_stream
-        self._check(self.lib.ops_mlp_repack_weights(len(self._repack), self._repack, s), "ops_mlp_repack_weights")
         for a in self._fwd:
             a.B = B
             self._check(self.lib.ops_mlp_strip_launch(ctypes.byref(a), s), "ops_mlp_strip_launch (forward)")
 
-    def fwd_bwd(self, B: int, targets: torch.Tensor) -> torch.Tensor:
-        """Loss of the batch in x (mean over its B rows) and all parameter gradients.  targets: [>= B, C] float32, contiguous."""
-        crit, l1l2 = self.crit, self.crit.l1l2_loss
+    def fwd_bwd(self, B: int, repack: bool = False) -> torch.Tensor:
+        """Loss of the batch in x / targets_t (mean over its B rows; also added to `loss_sum`) and all parameter gradients.
+        `repack`: refresh the weight copies first (callers without an optimiser that does it)."""
         if B < 2:
             raise ValueError("Expected more than 1 value per channel when training (BatchNorm1d batch statistics)")
         s = torch.cuda.current_stream(self.dev).cuda_stream
         with torch.cuda.device(self.dev):
+            if repack:
+                self.repack_now()
             self.forward(B, s)
-            self._check(self.lib.ops_mlp_loss_grad(B, self.C, crit.nelem, crit.deflection_dim, self.preds.data_ptr(), self.preds.shape[1],
-                                                   targets.data_ptr(), self._alpha.data_ptr(), float("nan"),
-                                                   self._minc.data_ptr() if self._minc is not None else None,
-                                                   self._maxc.data_ptr() if self._maxc is not None else None, float(l1l2.penalty_weight),
-                                                   float(crit.penalty_pinn), self.loss.data_ptr(), self.gp.data_ptr(), self.gp.shape[1],
-                                                   self.gpt.data_ptr(), self.model.output_fc.bias.grad.data_ptr(), self.loss_ws.data_ptr(), s),
-                        "ops_mlp_loss_grad")
             for a in self._bwd:
                 a.B = B
                 self._check(self.lib.ops_mlp_strip_launch(ctypes.byref(a), s), "ops_mlp_strip_launch (backward)")

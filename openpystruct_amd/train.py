@@ -140,6 +140,7 @@ class FlatClipAdam:
         self.ws = torch.empty(int(self._lib.ops_flat_adam_workspace_bytes()), dtype=torch.uint8, device=dev)
         self.betas, self.eps, self.weight_decay, self.max_norm, self.decoupled = betas, eps, weight_decay, max_norm, decoupled
         self.p_bf16: Optional[torch.Tensor] = None      # bfloat16 shadow of the parameters (enable_shadow)
+        self.repack = None          # ctypes array of MlpRepackEntry: padded bf16 weight copies the update refreshes too (pinn_fused.py)
 
     def enable_shadow(self) -> torch.Tensor:
         """A bfloat16 copy of the flat parameter buffer that every step refreshes in the Adam kernel itself: layers that
@@ -154,12 +155,15 @@ class FlatClipAdam:
 
     def step(self, grad_scale: float = 1.0) -> None:
         dev = self.g.device
+        args = (self.g.numel(), self.p.data_ptr(), self.g.data_ptr(), self.m.data_ptr(), self.v.data_ptr(), self.lr.data_ptr(),
+                self.step_count.data_ptr(), self.max_norm, grad_scale, self.betas[0], self.betas[1], self.eps, self.weight_decay,
+                int(self.decoupled), self.p_bf16.data_ptr() if self.p_bf16 is not None else None, self.ws.data_ptr())
         with torch.cuda.device(dev):
-            rc = self._lib.ops_flat_clip_adam_step_f32(self.g.numel(), self.p.data_ptr(), self.g.data_ptr(), self.m.data_ptr(),
-                                                       self.v.data_ptr(), self.lr.data_ptr(), self.step_count.data_ptr(), self.max_norm,
-                                                       grad_scale, self.betas[0], self.betas[1], self.eps, self.weight_decay,
-                                                       int(self.decoupled), self.p_bf16.data_ptr() if self.p_bf16 is not None else None,
-                                                       self.ws.data_ptr(), torch.cuda.current_stream(dev).cuda_stream)
+            s = torch.cuda.current_stream(dev).cuda_stream
+            if self.repack is not None:
+                rc = self._lib.ops_flat_clip_adam_step_repack_f32(*args, len(self.repack), self.repack, s)
+            else:
+                rc = self._lib.ops_flat_clip_adam_step_f32(*args, s)
         if rc != self._cabi.OK:
             raise RuntimeError(f"ops_flat_clip_adam_step_f32 failed with code {rc}")
 
@@ -403,6 +407,7 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
         from . import pinn_fused
         if pinn_fused.eligible(model, crit, cfg.batch_size):
             engine = pinn_fused.PinnFusedStep(model, crit, seed=seed * 7919 + 101 + rank)
+            opt.repack = engine._repack      # the Adam launch refreshes the engine's bf16 weight copies
     Xtr, Ytr, Xva, Yva = (t.to(device) for t in (data.X_train, data.Y_train, data.X_val, data.Y_val))
     nb_tr = max(1, (Xtr.shape[0] + cfg.batch_size - 1) // cfg.batch_size)
     if world > 1:   # every rank must run the same number of steps (collectives inside backward)
@@ -454,8 +459,8 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
     def fwd_bwd(Xb, Yb, noise_t, pin=None, prenoised=False):
         """Segment A: local gradients of the mean batch loss into `flat`.  `prenoised`: Xb already is the gathered, noisy
         (and, under autocast, bfloat16) batch written by `gather_noise` -- one launch outside the graph instead of six nodes."""
-        if engine is not None:           # the batch sits in the engine's buffers (engine.gather); every gradient is assigned
-            return engine.fwd_bwd(int(Yb.shape[0]), Yb)
+        if engine is not None:           # batch and targets sit in the engine's buffers (engine.gather); every gradient is assigned
+            return engine.fwd_bwd(int(Yb.shape[0]))
         Xn = Xb if prenoised else Xb + torch.randn_like(Xb) * noise_t   # PINN:756
         flat.zero_()                                                     # optimizer.zero_grad()
         with torch.autocast(device_type=device.type, dtype=autocast_dtype, enabled=use_ac):
@@ -485,8 +490,7 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
 
     def train_step(Xb, Yb, noise_t, rows=None):
         if engine is not None:
-            engine.gather(Xtr, rows, noise_t, engine_seed)
-            Yb = Yb.contiguous()
+            engine.gather(Xtr, Ytr, rows, noise_t, engine_seed)
         loss = fwd_bwd(Xb, Yb, noise_t, physics_inputs(rows) if physics is not None else None)
         if world > 1:
             dist.all_reduce(flat)                                        # the step's only collective (RCCL over xGMI)
@@ -509,8 +513,8 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
     engine_seed = (seed * 7919 + 13 + rank) & 0x7FFFFFFFFFFFFFFF
 
     def gather_noise(idx, out):
-        if engine is not None:           # straight into the engine's two layouts
-            engine.gather(Xtr, idx, s_noise, engine_seed)
+        if engine is not None:           # batch AND targets straight into the engine's layouts
+            engine.gather(Xtr, Ytr, idx, s_noise, engine_seed)
             return
         lib = opt._lib
         Fdim = 1
@@ -541,7 +545,7 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
             if sP is not None:
                 physics_inputs(torch.arange(bs, device=device), out=sP)
             if engine is not None:
-                engine.gather(Xtr, torch.arange(bs, device=device), s_noise, engine_seed)
+                engine.gather(Xtr, Ytr, torch.arange(bs, device=device), s_noise, engine_seed)
             for _ in range(3):
                 fwd_bwd(sX, sY, s_noise, sP, prenoised=_FUSED_PREP)
                 apply_update()                   # warm-up only: no collective needed for capture-readiness
@@ -565,6 +569,8 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
         model.load_state_dict(snap[0]); opt.load_state_dict(snap[1])     # the warm-up steps never happened
         if on_gpu:
             opt.refresh_shadow()
+            if engine is not None:
+                engine.repack_now()
         # the validation pass as a graph too: one full batch in eval mode, loss accumulated into v_acc
         if graph is not None and Xva.shape[0] >= bs:
             vX, vY = torch.zeros_like(Xva[:bs]), torch.zeros_like(Yva[:bs])
@@ -601,6 +607,8 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
         else:
             order = torch.randperm(Xtr.shape[0], device=device)              # DataLoader(shuffle=True), PINN:701
         tot = torch.zeros((), device=device)
+        if engine is not None:
+            engine.loss_sum.zero_()                                          # the output launch adds every step's loss to it
         noise_t = torch.tensor(noise, device=device)
         if graph is not None:
             s_noise.copy_(noise_t)                                           # constant within the epoch
@@ -613,16 +621,22 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
                     gather_noise(idx, sX)                                    # gather + noise (+ bf16 cast) in one launch
                 else:
                     torch.index_select(Xtr, 0, idx, out=sX)                  # gather straight into the graph's input buffers
-                torch.index_select(Ytr, 0, idx, out=sY)
+                if engine is None:
+                    torch.index_select(Ytr, 0, idx, out=sY)
                 if sP is not None:
                     physics_inputs(idx, out=sP)
                 graph.replay()
                 if graph_b is not None:
                     dist.all_reduce(flat)
                     graph_b.replay()
-                tot += s_loss
+                if engine is None:
+                    tot += s_loss
+            elif engine is not None:
+                train_step(None, Ytr[:idx.numel()], noise_t, idx)            # Yb only carries the row count here
             else:
                 tot += train_step(Xtr[idx], Ytr[idx], noise_t, idx)
+        if engine is not None:
+            tot = engine.loss_sum.clone()
         train_loss = _allreduce_mean(tot / nb_tr, world)
         if world > 1:   # BatchNorm running statistics are per rank during the epoch: average them before evaluating
             for buf in model.buffers():

@@ -68,11 +68,10 @@ def test_argument_validation_without_gpu(lib):
     assert lib.ops_mlp_strip_launch(a, z) == _cabi.ERR_INVALID_ARG       # more rows than a workgroup owns
     a.B, a.lda = 128, 24
     assert lib.ops_mlp_strip_launch(a, z) == _cabi.ERR_INVALID_ARG       # reduction not padded to whole 32-column steps
-    assert lib.ops_mlp_spart_doubles(350) >= 22 * 12
+    assert lib.ops_mlp_spart_doubles(350) == 44 * 12
     assert lib.ops_mlp_wgrad_group(0, None, z) == _cabi.ERR_INVALID_ARG and lib.ops_mlp_wgrad_group(9, (_cabi.MlpWgradProblem * 9)(), z) == _cabi.ERR_INVALID_ARG
     assert lib.ops_mlp_repack_weights(1, (_cabi.MlpRepackEntry * 1)(), z) == _cabi.ERR_INVALID_ARG
-    assert lib.ops_mlp_gather_noise(200, 684, z, z, z, 1, z, z, 704, z, z) == _cabi.ERR_INVALID_ARG
-    assert lib.ops_mlp_loss_grad(128, 302, 100, 101, z, 320, z, z, 0.5, z, z, 0.1, 0.0, z, z, 320, z, z, z, z) == _cabi.ERR_INVALID_ARG
+    assert lib.ops_mlp_gather_noise(200, 684, z, z, z, 1, z, z, 704, z, z, 0, z, z) == _cabi.ERR_INVALID_ARG
     assert lib.ops_mlp_loss_workspace_bytes() > 0
     sched = (ctypes.c_float * 20)()
     lib.ops_sizing_schedule_f32(ctypes.byref(hp), ctypes.cast(sched, ctypes.c_void_p))       # host-only helper

@@ -115,12 +115,12 @@ def test_step_matches_module_autograd(B, p_drop, seed):
     y = (0.8 * torch.randn(B, 302, generator=g)).to(dev)
     eng = PinnFusedStep(model, crit, seed=1234 + seed)
     model.train()
-    eng.set_input(x)
-    loss = eng.fwd_bwd(B, y)
+    eng.set_batch(x, y)
+    loss = eng.fwd_bwd(B)
     torch.cuda.synchronize()
     masks = None
     if p_drop > 0:
-        masks = [eng.o[0][0][:B, :350] != 0] + [eng.h[k][0][:B, :175] != 0 for k in range(2)]
+        masks = [eng.read(eng.o[0][0], B, 350) != 0] + [eng.read(eng.h[k][0], B, 175) != 0 for k in range(2)]
         for m in masks:
             assert abs(float(m.float().mean()) - (1 - p_drop)) < 0.03
     ref, preds_ref, loss_ref = _reference(before, crit, x, y, masks, p_drop)
@@ -152,13 +152,18 @@ def test_step_matches_module_autograd(B, p_drop, seed):
         else:
             assert float((b.cpu().double() - br).abs().max()) <= 1e-2 * max(1e-3, float(br.abs().max())), name
     # dead rows / columns of every buffer stay zero (the layout contract the next product relies on)
+    from openpystruct_amd.pinn_fused import from_tiled
     if B < 128:
         for t in [eng.o[0][0], eng.o[1][0], eng.o[2][0], eng.h[0][0], eng.dz[0][0], eng.dh[1][0], eng.gp]:
-            assert float(t[B:].float().abs().max()) == 0.0
+            assert float(from_tiled(t)[B:].float().abs().max()) == 0.0
         for t in [eng.o[0][1], eng.h[1][1], eng.dz[2][1], eng.gpt]:
-            assert float(t[:, B:].float().abs().max()) == 0.0
-    assert float(eng.h[0][0][:, 175:].float().abs().max()) == 0.0
-    assert float(eng.o[1][1][350:].float().abs().max()) == 0.0
+            assert float(from_tiled(t)[:, B:].float().abs().max()) == 0.0
+    assert float(from_tiled(eng.h[0][0])[:, 175:].float().abs().max()) == 0.0
+    assert float(from_tiled(eng.o[1][1])[350:].float().abs().max()) == 0.0
+    # both copies of a matrix hold the same numbers
+    for a_, at_ in (eng.o[1], eng.h[0], eng.dz[1], eng.dh[0]):
+        assert torch.equal(from_tiled(a_), from_tiled(at_).t())
+    assert float(eng.loss_sum) == pytest.approx(float(loss), rel=1e-6)
 
 
 def test_dropout_masks_change_between_calls_and_under_graph_replay():
@@ -172,25 +177,26 @@ def test_dropout_masks_change_between_calls_and_under_graph_replay():
     y = torch.randn(128, 302, generator=g).to(dev)
     eng = PinnFusedStep(model, crit, seed=99)
     model.train()
-    eng.set_input(x)
+    eng.set_batch(x, y)
+    live = lambda: (eng.read(eng.o[0][0], 128, 350) != 0).clone()      # noqa: E731
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):
-        eng.fwd_bwd(128, y)
-        m1 = (eng.o[0][0] != 0).clone()
-        eng.fwd_bwd(128, y)
-        m2 = (eng.o[0][0] != 0).clone()
+        eng.fwd_bwd(128)
+        m1 = live()
+        eng.fwd_bwd(128)
+        m2 = live()
         side.synchronize()
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph, stream=side):
-            eng.fwd_bwd(128, y)
+            eng.fwd_bwd(128)
     torch.cuda.current_stream().wait_stream(side)
     graph.replay(); torch.cuda.synchronize()
-    m3 = (eng.o[0][0] != 0).clone()
+    m3 = live()
     graph.replay(); torch.cuda.synchronize()
-    m4 = (eng.o[0][0] != 0).clone()
+    m4 = live()
     for a, b in ((m1, m2), (m2, m3), (m3, m4)):
-        assert 0.4 < float((a != b).float()[:, :350].mean()) < 0.6
+        assert 0.4 < float((a != b).float().mean()) < 0.6
     assert torch.isfinite(eng.loss)
 
 
@@ -206,3 +212,40 @@ def test_invalid_layouts_are_refused():
     assert lib.ops_mlp_strip_launch(a, None) == _cabi.ERR_INVALID_ARG          # leading dimension not a multiple of 8
     a.lda, a.tail = 64, _cabi.MLP_TAIL_BN
     assert lib.ops_mlp_strip_launch(a, None) == _cabi.ERR_INVALID_ARG          # normalisation without its parameters
+
+
+def test_gather_writes_both_layouts_and_the_targets():
+    from openpystruct_amd.pinn_fused import PinnFusedStep, from_tiled
+    dev = torch.device("cuda:0")
+    model, crit = _make(6, 0.0)
+    model, crit = model.to(dev), crit.to(dev)
+    _attach_flat(model)
+    eng = PinnFusedStep(model, crit, seed=3)
+    g = torch.Generator().manual_seed(8)
+    X = torch.randn(500, 684, generator=g).to(dev)
+    Y = torch.randn(500, 302, generator=g).to(dev)
+    idx = torch.randperm(500, generator=g)[:93].to(dev)
+    B = eng.gather(X, Y, idx, torch.zeros((), device=dev), 17)
+    torch.cuda.synchronize()
+    xb = X[idx].to(torch.bfloat16)
+    assert torch.equal(from_tiled(eng.x)[:B, :684], xb) and torch.equal(from_tiled(eng.xt)[:684, :B], xb.t())
+    assert float(from_tiled(eng.x)[B:].float().abs().max()) == 0.0 and float(from_tiled(eng.x)[:, 684:].float().abs().max()) == 0.0
+    assert torch.equal(eng.targets_t[:, :B], Y[idx].t()) and float(eng.targets_t[:, B:].abs().max()) == 0.0
+    # noise: N(0, sigma^2) on top, a fresh stream per call
+    sig = torch.tensor(0.05, device=dev)
+    eng.gather(X, Y, idx, sig, 17)
+    n1 = (from_tiled(eng.x)[:B, :684].float() - X[idx]).clone()
+    eng.gather(X, Y, idx, sig, 17)
+    n2 = from_tiled(eng.x)[:B, :684].float() - X[idx]
+    assert abs(float(n1.std()) - 0.05) < 0.005 and abs(float(n1.mean())) < 0.002 and float((n1 - n2).abs().mean()) > 0.02
+
+
+def test_tiled_layout_helpers_roundtrip():
+    from openpystruct_amd.pinn_fused import from_tiled, to_tiled
+    x = torch.arange(48 * 96, dtype=torch.float32).reshape(48, 96)
+    t = to_tiled(x)
+    assert torch.equal(from_tiled(t), x)
+    # element (row, k) sits at tile * 512 + ((k >> 3) & 3) * 128 + (row & 15) * 8 + (k & 7)
+    for row, k in ((0, 0), (17, 40), (47, 95), (5, 33)):
+        off = ((row >> 4) * 3 + (k >> 5)) * 512 + ((k >> 3) & 3) * 128 + (row & 15) * 8 + (k & 7)
+        assert float(t.reshape(-1)[off]) == float(x[row, k])
