@@ -299,7 +299,8 @@ int ops_gather_rows_noise_f32(int B, long F, const float* X, const long long* id
 #define OPS_MLP_TAIL_BWD_ACT_DROP 4    /* gradient through TAIL_ACT_DROP of the layer below; dbias = column sums */
 #define OPS_MLP_TAIL_BWD_BN 5          /* gradient through TAIL_BN of the layer below; dgamma, dbeta, dbias */
 #define OPS_MLP_TAIL_BWD_BN_ACT_DROP 6 /* gradient through TAIL_BN_ACT_DROP of the layer below; dgamma, dbeta, dbias */
-#define OPS_MLP_TAIL_LOSS 7            /* output layer + training loss: predictions -> P, Y / Yt = d loss / d predictions, dbias */
+#define OPS_MLP_TAIL_LOSS 7            /* output layer + training loss: predictions -> P, Y / Yt = d loss / d predictions, dbias;
+                                          the loss VALUE is completed by the next launch (loss_finish_rows) */
 /* addends (`add_mode`) joined to the product before the tail */
 #define OPS_MLP_ADD_NONE 0
 #define OPS_MLP_ADD_FWD_BLOCK 1        /* + bn1(conv1(O)) + O: the ResidualBlock's stencil path and identity (O = block input) */
@@ -338,8 +339,11 @@ typedef struct ops_mlp_strip_args {
   const float* targets_t;          /* [N, 128] float32, TRANSPOSED targets (ops_mlp_gather_noise writes them), rows >= B ignored */
   int32_t nI, nD;
   const float* alpha; float alpha0; const float* min_constraint; const float* max_constraint; float box_weight, rel_penalty;
-  float* loss; void* loss_ws;      /* one float; ops_mlp_loss_workspace_bytes() bytes zeroed ONCE by the caller */
-  float* loss_sum;                 /* optional: += loss (a running total the caller zeroes, e.g. per epoch) */
+  void* loss_ws;                   /* ops_mlp_loss_workspace_bytes() bytes: TAIL_LOSS leaves per-strip partial sums there ... */
+  /* ... and the NEXT launch (any tail) adds them when loss_finish_rows = strips of the loss launch = (C + 15) / 16 (with the same
+   * nI, nD, alpha, alpha0, box_weight, rel_penalty and loss_C = C): loss[0] = value, loss_sum[0] += value (optional running total) */
+  int32_t loss_finish_rows, loss_C;
+  float* loss; float* loss_sum;
 } ops_mlp_strip_args;
 
 /* One strip launch: workgroup = 128 rows x 16 output columns.  Returns OPS_AMD_ERR_INVALID_ARG on a broken layout contract. */

@@ -26,12 +26,19 @@ __global__ __launch_bounds__(FA_THREADS) void flat_grad_norm_kernel(long n, cons
                                                                      double* __restrict__ part, int32_t* __restrict__ step, float beta1,
                                                                      float beta2) {
   __shared__ double s_red[FA_THREADS / 64];
-  float acc = 0.0f;
-  for (long i = (long)blockIdx.x * FA_THREADS + threadIdx.x; i < n; i += (long)gridDim.x * FA_THREADS) {
-    const float v = g[i] * grad_scale;
-    acc = __builtin_fmaf(v, v, acc);
+  // 16-byte loads, four independent partial sums per thread (the flat buffer is 16-byte aligned: a framework allocation)
+  float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+  const long n4 = ((uintptr_t)g & 15) == 0 ? n >> 2 : 0;
+  for (long i = (long)blockIdx.x * FA_THREADS + threadIdx.x; i < n4; i += (long)gridDim.x * FA_THREADS) {
+    const float4 q = ((const float4*)g)[i];
+    const float x = q.x * grad_scale, y = q.y * grad_scale, z = q.z * grad_scale, w = q.w * grad_scale;
+    a0 = __builtin_fmaf(x, x, a0); a1 = __builtin_fmaf(y, y, a1); a2 = __builtin_fmaf(z, z, a2); a3 = __builtin_fmaf(w, w, a3);
   }
-  double d = acc;
+  for (long i = 4 * n4 + (long)blockIdx.x * FA_THREADS + threadIdx.x; i < n; i += (long)gridDim.x * FA_THREADS) {
+    const float v = g[i] * grad_scale;
+    a0 = __builtin_fmaf(v, v, a0);
+  }
+  double d = (double)a0 + (double)a1 + (double)a2 + (double)a3;
   for (int s = 32; s >= 1; s >>= 1) d += __shfl_xor(d, s, 64);
   if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = d;
   __syncthreads();

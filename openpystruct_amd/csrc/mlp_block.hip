@@ -133,6 +133,30 @@ __device__ __forceinline__ float mb_conv_at(const void* Ot, int No, int q, int r
   return __builtin_fmaf(w0, xm, __builtin_fmaf(w1, xc, __builtin_fmaf(w2, xp, b)));
 }
 
+// sums NV floats over the workgroup -- float inside a wave (64 terms), double across the waves; thread 0 gets the totals in `out`
+template <int NV>
+__device__ __forceinline__ void mb_block_sum_f(const float (&v)[NV], double (&out)[NV], double* s_red /*[8][NV]*/) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  float w[NV];
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    w[k] = v[k];
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) w[k] += __shfl_xor(w[k], s, 64);
+  }
+  __syncthreads();
+  if (lane == 0)
+#pragma unroll
+    for (int k = 0; k < NV; ++k) s_red[wave * NV + k] = (double)w[k];
+  __syncthreads();
+  if (threadIdx.x == 0)
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      double t = 0.0;
+      for (int wv = 0; wv < MB_THREADS / 64; ++wv) t += s_red[wv * NV + k];
+      out[k] = t;
+    }
+}
 // sums NV doubles over the workgroup; thread 0 gets the totals
 template <int NV>
 __device__ __forceinline__ void mb_block_sum(double (&v)[NV], double* s_red /*[8][NV]*/) {
@@ -184,8 +208,9 @@ __device__ __forceinline__ void mb_side_job(const ops_mlp_strip_args& a, int row
         p0 += y;
         p1 = __builtin_fmaf(y, y, p1);
       }
-    double acc[2] = {(double)p0, (double)p1};
-    mb_block_sum<2>(acc, s_red);
+    const float pv[2] = {p0, p1};
+    double acc[2];
+    mb_block_sum_f<2>(pv, acc, s_red);
     if (tid == 0) { a.spart[row * 2] = acc[0]; a.spart[row * 2 + 1] = acc[1]; }
   } else {
     // 0: sum g   1: sum g yhat   2: sum yhat   3..5: sum g x_s   6..8: sum x_s   9..11: sum yhat x_s   (x_s = O shifted by s - 1)
@@ -209,9 +234,7 @@ __device__ __forceinline__ void mb_side_job(const ops_mlp_strip_args& a, int row
         }
       }
     double acc[MB_NSUM];
-#pragma unroll
-    for (int k = 0; k < MB_NSUM; ++k) acc[k] = (double)t[k];
-    mb_block_sum<MB_NSUM>(acc, s_red);
+    mb_block_sum_f<MB_NSUM>(t, acc, s_red);
     if (tid == 0)
 #pragma unroll
       for (int k = 0; k < MB_NSUM; ++k) a.spart[row * MB_NSUM + k] = acc[k];
@@ -222,9 +245,9 @@ __global__ __launch_bounds__(MB_THREADS) void mlp_strip_kernel(const ops_mlp_str
   __shared__ float s_t[MB_ROWS][MB_COLS + 1];
   __shared__ __attribute__((aligned(16))) uint16_t s_y[MB_ROWS][MB_COLS];
   __shared__ __attribute__((aligned(16))) uint16_t s_z[MB_ROWS][MB_COLS];
+  __shared__ __attribute__((aligned(16))) uint16_t s_stage[70][MB_ROWS];      // transposed epilogue operands: [column slot][row]
   __shared__ double s_red[(MB_THREADS / 64) * MB_NSUM];
   __shared__ double s_tot[16];
-  __shared__ bool s_last;
   if ((int)blockIdx.x >= nstrips) {      // workgroup-uniform
     mb_side_job(a, (int)blockIdx.x - nstrips, s_red);
     return;
@@ -252,35 +275,34 @@ __global__ __launch_bounds__(MB_THREADS) void mlp_strip_kernel(const ops_mlp_str
       if (!fwd) { mean_c = a.mean[c]; rstd_c = a.rstd[c]; }
     }
   }
-  float po[5][4], pg[3][4], pz[4], py[4], pt[4];
+  // the transposed operands of the epilogue arrive as 16-byte chunks (column, 8 rows) -- up to 70 columns x 16 chunks per
+  // workgroup, at most three per thread -- and are parked in LDS after the product; slots (columns) of the staging area:
+  //   0..19  block input O, columns n0 - 2 .. n0 + 17        20..37  dZ, columns n0 - 1 .. n0 + 16
+  //   38..53 saved pre-normalisation values, n0 .. n0 + 15   54..69  forward output of the activation tail, n0 .. n0 + 15
+  uint4 ch[3];
+  bool chv[3];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int r = q + 32 * i;
-#pragma unroll
-    for (int d = 0; d < 5; ++d) po[d][i] = 0.0f;
-#pragma unroll
-    for (int d = 0; d < 3; ++d) pg[d][i] = 0.0f;
-    pz[i] = 0.0f; py[i] = 0.0f; pt[i] = 0.0f;
-    if (rl[i]) {
-      if (a.add_mode != OPS_MLP_ADD_NONE) {
-        const int lo = a.add_mode == OPS_MLP_ADD_FWD_BLOCK ? 1 : 0, hi = a.add_mode == OPS_MLP_ADD_FWD_BLOCK ? 3 : 4;
-#pragma unroll
-        for (int d = 0; d < 5; ++d) {
-          const int qq = c + d - 2;
-          if (d >= lo && d <= hi && qq >= 0 && qq < No) po[d][i] = mb_ldt(a.Ot, qq, r);
-        }
-        if (a.add_mode == OPS_MLP_ADD_BWD_BLOCK)
-#pragma unroll
-          for (int d = 0; d < 3; ++d) {
-            const int qq = c + d - 1;
-            if (qq >= 0 && qq < No) pg[d][i] = mb_ldt(a.dZt, qq, r);
-          }
-      }
-      if (has_bn && !fwd) pz[i] = mb_ldt(a.Zt, c, r);
-      if (act_bwd) py[i] = mb_ldt(a.Yref_t, c, r);
-      if (a.tail == OPS_MLP_TAIL_LOSS) pt[i] = a.targets_t[(long)c * MB_ROWS + r];
-    }
+  for (int rep = 0; rep < 3; ++rep) {
+    const int j = tid + MB_THREADS * rep, slot = j >> 4, gq = j & 15;
+    const void* src = nullptr;
+    int col = 0, lim = 0;
+    if (slot < 20) { if (a.add_mode != OPS_MLP_ADD_NONE) { src = a.Ot; col = n0 - 2 + slot; lim = No; } }
+    else if (slot < 38) { if (a.add_mode == OPS_MLP_ADD_BWD_BLOCK) { src = a.dZt; col = n0 - 1 + (slot - 20); lim = No; } }
+    else if (slot < 54) { if (has_bn && !fwd) { src = a.Zt; col = n0 + (slot - 38); lim = N; } }
+    else if (slot < 70) { if (act_bwd) { src = a.Yref_t; col = n0 + (slot - 54); lim = N; } }
+    chv[rep] = slot < 70;
+    ch[rep] = uint4{0u, 0u, 0u, 0u};
+    if (src && col >= 0 && col < lim) ch[rep] = *(const uint4*)((const uint16_t*)src + mb_toff(col, 8 * gq, MB_ROWS / 32));
   }
+  float pt[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) pt[i] = (rl[i] && a.tail == OPS_MLP_TAIL_LOSS) ? a.targets_t[(long)c * MB_ROWS + q + 32 * i] : 0.0f;
+  // loss of the previous launch (TAIL_LOSS leaves per-strip partial sums): workgroup 0 adds them, one partial row per lane
+  double lp[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+  const bool fin = a.loss_finish_rows > 0 && blockIdx.x == 0 && wave == 0;
+  if (fin && lane < a.loss_finish_rows)
+#pragma unroll
+    for (int k = 0; k < 5; ++k) lp[k] = ((const double*)a.loss_ws)[lane * 5 + k];
   // partial sums of the stencil normalisation: lane = row of partials, wave = which sum (workgroup 0 needs all twelve backward)
   double pp0 = 0.0, pp1 = 0.0;
   if (a.add_mode != OPS_MLP_ADD_NONE) {
@@ -320,6 +342,24 @@ __global__ __launch_bounds__(MB_THREADS) void mlp_strip_kernel(const ops_mlp_str
     pp0 = mb_wsum_d(pp0); pp1 = mb_wsum_d(pp1);
     if (lane == 0) { s_tot[wave] = pp0; s_tot[wave + 8] = pp1; }
   }
+#pragma unroll
+  for (int rep = 0; rep < 3; ++rep)
+    if (chv[rep]) *(uint4*)&s_stage[(tid + MB_THREADS * rep) >> 4][8 * (tid & 15)] = ch[rep];
+  if (fin) {
+#pragma unroll
+    for (int k = 0; k < 5; ++k) lp[k] = mb_wsum_d(lp[k]);
+    if (lane == 0) {
+      const double al = fmin(fmax((double)a.alpha[0], 1e-6), 1.0);
+      const int nI = a.nI, nD = a.nD, nR = a.loss_C - nI - nD;
+      const double nIe = (double)B * nI;
+      double val = al * lp[0] / nIe + (1.0 - al) * lp[1] / nIe + (double)a.box_weight * lp[2];
+      if (nD > 0) val += (double)a.rel_penalty * lp[3] / ((double)B * nD);
+      if (nR > 0) val += (double)a.rel_penalty * lp[4] / ((double)B * nR);
+      const double da = a.alpha0 == a.alpha0 ? (double)a.alpha0 - (double)a.alpha[0] : 0.0;      // NaN alpha0: no such term
+      a.loss[0] = (float)(val + da * da);
+      if (a.loss_sum) a.loss_sum[0] += (float)(val + da * da);      // the epoch's running total (the caller zeroes it)
+    }
+  }
   __syncthreads();
 
   // ---- epilogue ----
@@ -348,9 +388,11 @@ __global__ __launch_bounds__(MB_THREADS) void mlp_strip_kernel(const ops_mlp_str
 #pragma unroll
       for (int i = 0; i < 4; ++i)
         if (rl[i]) {
-          const float conv = __builtin_fmaf(sc_w0, po[1][i], __builtin_fmaf(sc_w1, po[2][i], __builtin_fmaf(sc_w2, po[3][i], sc_b)));
+          const int r = q + 32 * i;
+          const float o = mb_bf2f(s_stage[cl + 2][r]);
+          const float conv = __builtin_fmaf(sc_w0, mb_bf2f(s_stage[cl + 1][r]), __builtin_fmaf(sc_w1, o, __builtin_fmaf(sc_w2, mb_bf2f(s_stage[cl + 3][r]), sc_b)));
           const float s = mb_round(__builtin_fmaf(conv, scale, shift));
-          v[i] = mb_round(v[i] + s + po[2][i]);
+          v[i] = mb_round(v[i] + s + o);
         }
     }
     if (has_bn) {
@@ -453,34 +495,42 @@ __global__ __launch_bounds__(MB_THREADS) void mlp_strip_kernel(const ops_mlp_str
 #pragma unroll
       for (int i = 0; i < 4; ++i)
         if (rl[i]) {
-          float dy[3];
+          const int r = q + 32 * i;
+          float dy[3], po[5], pg[3];
+#pragma unroll
+          for (int d = 0; d < 5; ++d) po[d] = mb_bf2f(s_stage[cl + d][r]);
+#pragma unroll
+          for (int d = 0; d < 3; ++d) pg[d] = mb_bf2f(s_stage[20 + cl + d][r]);
 #pragma unroll
           for (int d = 0; d < 3; ++d) {
             const int qq = c + d - 1;
             if (qq >= 0 && qq < No) {
               // columns outside [0, No) were prefetched as 0: the stencil's zero padding
-              const float conv = __builtin_fmaf(sc_w0, po[d][i], __builtin_fmaf(sc_w1, po[d + 1][i], __builtin_fmaf(sc_w2, po[d + 2][i], sc_b)));
+              const float conv = __builtin_fmaf(sc_w0, po[d], __builtin_fmaf(sc_w1, po[d + 1], __builtin_fmaf(sc_w2, po[d + 2], sc_b)));
               const float yh = (conv - sv_mean) * sv_inv;
-              dy[d] = kk * (pg[d][i] - mg - yh * mgy);
+              dy[d] = kk * (pg[d] - mg - yh * mgy);
             } else {
               dy[d] = 0.0f;
             }
           }
           const float sdx = __builtin_fmaf(sc_w0, dy[2], __builtin_fmaf(sc_w1, dy[1], sc_w2 * dy[0]));
-          v[i] = mb_round(v[i] + pg[1][i] + sdx);
+          v[i] = mb_round(v[i] + pg[1] + sdx);
         }
     }
     if (act_bwd) {
       // mask and LeakyReLU branch from the saved forward output: 0 = dropped, sign = sign of the pre-activation
 #pragma unroll
       for (int i = 0; i < 4; ++i)
-        if (rl[i]) v[i] *= py[i] == 0.0f ? 0.0f : (py[i] > 0.0f ? keep_scale : a.slope * keep_scale);
+        if (rl[i]) {
+          const float y = mb_bf2f(s_stage[54 + cl][q + 32 * i]);
+          v[i] *= y == 0.0f ? 0.0f : (y > 0.0f ? keep_scale : a.slope * keep_scale);
+        }
     }
     if (has_bn) {
       float xh[4], sg = 0.0f, sgx = 0.0f;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        xh[i] = rl[i] ? (pz[i] - mean_c) * rstd_c : 0.0f;
+        xh[i] = rl[i] ? (mb_bf2f(s_stage[38 + cl][q + 32 * i]) - mean_c) * rstd_c : 0.0f;
         sg += v[i];
         sgx = __builtin_fmaf(v[i], xh[i], sgx);
       }
@@ -525,40 +575,14 @@ __global__ __launch_bounds__(MB_THREADS) void mlp_strip_kernel(const ops_mlp_str
     atomicAdd(a.call_counter, 1ull);       // one increment per launch (a late reader draws from the next stream: as good a mask)
 
   if (a.tail == OPS_MLP_TAIL_LOSS) {
-    // loss value: per-strip partial sums; the strip that arrives last adds them (one wave, one partial row per lane)
-    double* part = (double*)a.loss_ws;
-    unsigned int* done = (unsigned int*)(part + ML_MAXG * 5);
+    // loss value: per-strip partial sums; workgroup 0 of the NEXT launch (loss_finish_rows) adds them -- no atomics, no fence here
     double accd[5];
 #pragma unroll
     for (int k = 0; k < 5; ++k) accd[k] = (double)lacc[k];
     mb_block_sum<5>(accd, s_red);
-    if (tid == 0) {
+    if (tid == 0)
 #pragma unroll
-      for (int k = 0; k < 5; ++k) part[blockIdx.x * 5 + k] = accd[k];
-      __threadfence();
-      s_last = atomicAdd(done, 1u) == (unsigned)nstrips - 1u;
-    }
-    __syncthreads();
-    if (s_last && wave == 0) {
-      __threadfence();
-      double t[5];
-#pragma unroll
-      for (int k = 0; k < 5; ++k) t[k] = lane < nstrips ? __builtin_nontemporal_load(&part[lane * 5 + k]) : 0.0;
-#pragma unroll
-      for (int k = 0; k < 5; ++k) t[k] = mb_wsum_d(t[k]);
-      if (lane == 0) {
-        const double al = fmin(fmax((double)a.alpha[0], 1e-6), 1.0);
-        const int nI = a.nI, nD = a.nD, nR = N - nI - nD;
-        const double nIe = (double)B * nI;
-        double val = al * t[0] / nIe + (1.0 - al) * t[1] / nIe + (double)a.box_weight * t[2];
-        if (nD > 0) val += (double)a.rel_penalty * t[3] / ((double)B * nD);
-        if (nR > 0) val += (double)a.rel_penalty * t[4] / ((double)B * nR);
-        const double da = a.alpha0 == a.alpha0 ? (double)a.alpha0 - (double)a.alpha[0] : 0.0;      // NaN alpha0: no such term
-        a.loss[0] = (float)(val + da * da);
-        if (a.loss_sum) a.loss_sum[0] += (float)(val + da * da);      // the epoch's running total (the caller zeroes it)
-        *done = 0u;                        // ready for the next launch (graph replay)
-      }
-    }
+      for (int k = 0; k < 5; ++k) ((double*)a.loss_ws)[blockIdx.x * 5 + k] = accd[k];
   }
 }
 
@@ -734,9 +758,11 @@ extern "C" int ops_mlp_strip_launch(const ops_mlp_strip_args* args, void* stream
     return OPS_AMD_ERR_INVALID_ARG;
   const int nstrips = (a.N + MB_COLS - 1) / MB_COLS;
   if (a.tail == OPS_MLP_TAIL_LOSS) {
-    if (!a.targets_t || !a.alpha || !a.loss || !a.loss_ws || !a.Yt || a.nI < 1 || a.nD < 0 || a.nI + a.nD > a.N || nstrips > ML_MAXG) return OPS_AMD_ERR_INVALID_ARG;
+    if (!a.targets_t || !a.alpha || !a.loss_ws || !a.Yt || a.nI < 1 || a.nD < 0 || a.nI + a.nD > a.N || nstrips > ML_MAXG) return OPS_AMD_ERR_INVALID_ARG;
     if (a.P && (a.ldp % 8 || a.ldp < ru(a.N, MB_COLS) || ((uintptr_t)a.P & 15))) return OPS_AMD_ERR_INVALID_ARG;
   }
+  if (a.loss_finish_rows < 0 || a.loss_finish_rows > ML_MAXG || (a.loss_finish_rows > 0 && (!a.loss_ws || !a.loss || !a.alpha || a.loss_C < 1)))
+    return OPS_AMD_ERR_INVALID_ARG;
   int nside = 0;
   if (a.add_mode != OPS_MLP_ADD_NONE || a.side != OPS_MLP_SIDE_NONE) {
     if (!a.Ot || a.No < 1 || !a.conv_w || !a.conv_b || !a.sgamma || !a.sbeta || !a.ssave || !a.spart) return OPS_AMD_ERR_INVALID_ARG;
@@ -812,4 +838,4 @@ extern "C" int ops_mlp_gather_noise(int B, int F, const float* X, const long lon
   return OPS_AMD_OK;
 }
 
-extern "C" size_t ops_mlp_loss_workspace_bytes(void) { return (size_t)ML_MAXG * 5 * sizeof(double) + 16; }
+extern "C" size_t ops_mlp_loss_workspace_bytes(void) { return (size_t)ML_MAXG * 5 * sizeof(double); }

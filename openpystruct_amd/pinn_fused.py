@@ -192,13 +192,16 @@ class PinnFusedStep:
                                bias=m.output_fc.bias, Y=self.gp, ldy=self.gp.shape[1], Yt=self.gpt, P=self.preds, ldp=self.preds.shape[1],
                                nI=crit.nelem, nD=crit.deflection_dim, alpha=self._alpha, alpha0=float("nan"), min_constraint=self._minc,
                                max_constraint=self._maxc, box_weight=float(l1l2.penalty_weight), rel_penalty=float(crit.penalty_pinn),
-                               loss=self.loss, loss_ws=self.loss_ws, loss_sum=self.loss_sum, targets_t=self.targets_t,
+                               loss_ws=self.loss_ws, targets_t=self.targets_t,
                                dbias=m.output_fc.bias.grad))
         # backward: d preds -> gradient at the last block's sum (through its norm)
         last_blk = m.residual_blocks[self.nblk - 1]
         bwd.append(self._strip(N=H, K=Co, tail=C.MLP_TAIL_BWD_BN, A=self.gp, lda=self.gp.shape[1], W=wot, ldw=wot.shape[1],
                                Y=self.dz[self.nblk][0], ldy=self.dz[self.nblk][0].shape[1], Yt=self.dz[self.nblk][1], Zt=self.zt[self.nblk - 1],
-                               dbias=last_blk[0].fc2.bias.grad, **self._bn_bwd(last_blk[1], self.nblk)))
+                               dbias=last_blk[0].fc2.bias.grad, loss_ws=self.loss_ws, loss_finish_rows=(Co + 15) // 16, loss_C=Co,
+                               nI=crit.nelem, nD=crit.deflection_dim, alpha=self._alpha, alpha0=float("nan"),
+                               box_weight=float(l1l2.penalty_weight), rel_penalty=float(crit.penalty_pinn), loss=self.loss,
+                               loss_sum=self.loss_sum, **self._bn_bwd(last_blk[1], self.nblk)))
         for k in range(self.nblk - 1, -1, -1):
             rb = m.residual_blocks[k][0]
             o_in, o_in_t = self.o[k]

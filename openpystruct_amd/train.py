@@ -400,7 +400,7 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
         opt = (torch.optim.AdamW if kind == "gnn" else torch.optim.Adam)(model.parameters(), lr=cfg.learning_rate,   # GNN:394
                                                                          weight_decay=cfg.weight_decay)
         sched = ExponentialLR(opt, gamma=cfg.gamma)
-    # PINN: forward + loss + backward as 17 hand-written launches without autograd (pinn_fused.py / csrc/mlp_block.hip);
+    # PINN: forward + loss + backward as 13 hand-written launches without autograd (pinn_fused.py / csrc/mlp_block.hip);
     # the module keeps owning parameters and buffers, evaluation keeps running it
     engine = None
     if on_gpu and kind == "pinn" and autocast_dtype == torch.bfloat16 and physics is None and not (sync_bn and world > 1):

@@ -233,17 +233,20 @@ def test_fused_tail_dropout_is_bernoulli_and_redrawn_on_graph_replay():
 
 
 def test_pinn_training_with_the_fused_kernels_follows_the_framework_path(monkeypatch):
-    """Eight epochs of the PINN loop with dropout 0.5 and input noise on: hand-written tails / batch assembly / stencil
-    (own counter-based dropout and noise streams) against the framework's modules and generators: the loss curves are two
-    draws of the same stochastic process -- within 5 % of each other, both decreasing."""
-    from openpystruct_amd import dataprep, sizing, surrogates as S, train
+    """Eight epochs of the PINN loop with dropout 0.5 and input noise on, three ways: the layer-block launches (pinn_fused.py: no
+    autograd), autograd over the hand-written tails / batch assembly / stencil, and the framework's modules and generators.  Own
+    counter-based dropout and noise streams: the loss curves are draws of the same stochastic process -- within 5 % of each
+    other, all decreasing."""
+    from openpystruct_amd import dataprep, pinn_fused, sizing, surrogates as S, train
     rec = sizing.generate_dataset(6000, sizing.SizingConfig(max_e=60), "cuda")
     d = dataprep.prepare(rec, kind="pinn", device="cuda")
     hist = {}
-    for fused in (True, False):
-        monkeypatch.setattr(S, "_FUSED_TAILS", fused)
-        monkeypatch.setenv("OPS_AMD_FUSED_PREP", "1" if fused else "0")
+    for mode in ("blocks", "tails", "framework"):
+        monkeypatch.setattr(pinn_fused, "ENABLED", mode == "blocks")
+        monkeypatch.setattr(S, "_FUSED_TAILS", mode != "framework")
+        monkeypatch.setenv("OPS_AMD_FUSED_PREP", "0" if mode == "framework" else "1")
         out = train.train_surrogate("pinn", d, device="cuda", max_epochs=8, seed=1)
-        hist[fused] = out["history"]["train"]
-        assert all(np.isfinite(hist[fused])) and hist[fused][-1] < 0.6 * hist[fused][0]
-    assert abs(hist[True][-1] - hist[False][-1]) < 0.05 * hist[False][-1], hist
+        hist[mode] = out["history"]["train"]
+        assert all(np.isfinite(hist[mode])) and hist[mode][-1] < 0.6 * hist[mode][0]
+    for mode in ("blocks", "tails"):
+        assert abs(hist[mode][-1] - hist["framework"][-1]) < 0.05 * hist["framework"][-1], hist
