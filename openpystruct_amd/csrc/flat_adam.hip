@@ -87,36 +87,57 @@ __global__ __launch_bounds__(FA_THREADS) void flat_adam_kernel(long n, float* __
   clip = clip < 1.0f ? clip : 1.0f;
   const float gs = clip * grad_scale;
   const float step_size = lr0 / bc1;
-  for (long i = (long)blockIdx.x * FA_THREADS + threadIdx.x; i < n; i += (long)gridDim.x * FA_THREADS) {
-    float pi = p[i];
-    float gi = g[i] * gs;
-    if (decoupled) pi *= 1.0f - lr0 * weight_decay;        // AdamW: p *= 1 - lr wd, the gradient stays clean
+  const float wdf = 1.0f - lr0 * weight_decay;
+  auto update = [&](float pi, float gr, float& mi, float& vi) -> float {
+    float gi = gr * gs;
+    if (decoupled) pi *= wdf;                              // AdamW: p *= 1 - lr wd, the gradient stays clean
     else gi = __builtin_fmaf(weight_decay, pi, gi);        // Adam: L2 term in the gradient
-    const float mi = __builtin_fmaf(beta1, m[i], (1.0f - beta1) * gi);
-    const float vi = __builtin_fmaf(beta2, v[i], (1.0f - beta2) * gi * gi);
-    m[i] = mi;
-    v[i] = vi;
-    const float pn = pi - step_size * (mi / (sqrtf(vi) / bc2s + eps));
-    p[i] = pn;
-    if (shadow || REPACK) {            // bfloat16 copy of the parameters (round to nearest even) for the GEMMs of the next step
-      uint32_t u = __float_as_uint(pn);
-      u += 0x7fffu + ((u >> 16) & 1u);
-      const uint16_t h = (uint16_t)(u >> 16);
-      if (shadow) shadow[i] = h;
-      if (REPACK) {
+    mi = __builtin_fmaf(beta1, mi, (1.0f - beta1) * gi);
+    vi = __builtin_fmaf(beta2, vi, (1.0f - beta2) * gi * gi);
+    return pi - step_size * (mi / (sqrtf(vi) / bc2s + eps));
+  };
+  auto to_bf16 = [](float f) -> uint16_t {                 // round to nearest even (parameters are finite)
+    uint32_t u = __float_as_uint(f);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+  };
+  auto repack = [&](long i, uint16_t h) {
+    // fragment-tiled storage (csrc/mlp_block.hip mb_toff): tile (row >> 4, k >> 5) = 512 elements in MFMA lane order
 #pragma unroll
-        for (int q = 0; q < OPS_MLP_MAX_WGRAD; ++q)
-          if (q < rp.nmat) {
-            const long le = i - rp.off[q];
-            if (le >= 0 && le < (long)rp.N[q] * rp.K[q]) {
-              const int r = (int)(le / rp.K[q]), c = (int)(le - (long)r * rp.K[q]);
-              // fragment-tiled storage (csrc/mlp_block.hip mb_toff): tile (row >> 4, k >> 5) = 512 elements in MFMA lane order
-              const int ksw = rp.ldw[q] >> 5, kst = rp.ldwt[q] >> 5;
-              rp.Wp[q][((long)(r >> 4) * ksw + (c >> 5)) * 512 + ((c >> 3) & 3) * 128 + (r & 15) * 8 + (c & 7)] = h;
-              rp.Wtp[q][((long)(c >> 4) * kst + (r >> 5)) * 512 + ((r >> 3) & 3) * 128 + (c & 15) * 8 + (r & 7)] = h;
-            }
-          }
+    for (int q = 0; q < OPS_MLP_MAX_WGRAD; ++q)
+      if (q < rp.nmat) {
+        const long le = i - rp.off[q];
+        if (le >= 0 && le < (long)rp.N[q] * rp.K[q]) {
+          const int r = (int)(le / rp.K[q]), c = (int)(le - (long)r * rp.K[q]);
+          const int ksw = rp.ldw[q] >> 5, kst = rp.ldwt[q] >> 5;
+          rp.Wp[q][((long)(r >> 4) * ksw + (c >> 5)) * 512 + ((c >> 3) & 3) * 128 + (r & 15) * 8 + (c & 7)] = h;
+          rp.Wtp[q][((long)(c >> 4) * kst + (r >> 5)) * 512 + ((r >> 3) & 3) * 128 + (c & 15) * 8 + (r & 7)] = h;
+        }
       }
+  };
+  // 16-byte groups (the four flat buffers are framework allocations: 16-byte aligned; otherwise everything takes the scalar loop)
+  const bool al = ((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0) && (!shadow || ((uintptr_t)shadow & 7) == 0);
+  const long n4 = al ? n >> 2 : 0;
+  for (long i4 = (long)blockIdx.x * FA_THREADS + threadIdx.x; i4 < n4; i4 += (long)gridDim.x * FA_THREADS) {
+    const float4 P = ((const float4*)p)[i4], G = ((const float4*)g)[i4];
+    float4 M = ((const float4*)m)[i4], V = ((const float4*)v)[i4];
+    float4 Q;
+    Q.x = update(P.x, G.x, M.x, V.x); Q.y = update(P.y, G.y, M.y, V.y); Q.z = update(P.z, G.z, M.z, V.z); Q.w = update(P.w, G.w, M.w, V.w);
+    ((float4*)m)[i4] = M; ((float4*)v)[i4] = V; ((float4*)p)[i4] = Q;
+    if (shadow || REPACK) {            // bfloat16 copies of the parameters for the GEMMs of the next step
+      const uint16_t h0 = to_bf16(Q.x), h1 = to_bf16(Q.y), h2 = to_bf16(Q.z), h3 = to_bf16(Q.w);
+      if (shadow) ((uint2*)shadow)[i4] = uint2{(uint32_t)h0 | ((uint32_t)h1 << 16), (uint32_t)h2 | ((uint32_t)h3 << 16)};
+      if (REPACK) { repack(4 * i4, h0); repack(4 * i4 + 1, h1); repack(4 * i4 + 2, h2); repack(4 * i4 + 3, h3); }
+    }
+  }
+  for (long i = 4 * n4 + (long)blockIdx.x * FA_THREADS + threadIdx.x; i < n; i += (long)gridDim.x * FA_THREADS) {
+    float mi = m[i], vi = v[i];
+    const float pn = update(p[i], g[i], mi, vi);
+    m[i] = mi; v[i] = vi; p[i] = pn;
+    if (shadow || REPACK) {
+      const uint16_t h = to_bf16(pn);
+      if (shadow) shadow[i] = h;
+      if (REPACK) repack(i, h);
     }
   }
 }
@@ -136,6 +157,7 @@ static int adam_step(long n, float* params, const float* grads, float* exp_avg, 
   const int nparts = (int)(nb < FA_NORM_BLOCKS ? nb : FA_NORM_BLOCKS);
   hipLaunchKernelGGL(flat_grad_norm_kernel, dim3(nparts), dim3(FA_THREADS), 0, s, n, grads, grad_scale, (double*)workspace, step, beta1,
                      beta2);
+  nb = (n / 4 + FA_THREADS - 1) / FA_THREADS + 1;     // one 16-byte group per thread
   if (nb > 4096) nb = 4096;
   if (rp)
     hipLaunchKernelGGL(flat_adam_kernel<true>, dim3((unsigned)nb), dim3(FA_THREADS), 0, s, n, params, grads, exp_avg, exp_avg_sq, lr, step,
