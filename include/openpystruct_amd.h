@@ -380,6 +380,40 @@ int ops_mlp_gather_noise(int B, int F, const float* X, const long long* idx, con
 /* bytes of ops_mlp_strip_args.loss_ws (TAIL_LOSS) */
 size_t ops_mlp_loss_workspace_bytes(void);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * Row-wise blocks of the Transformer-Diffusion surrogate's encoder layers (TransformerDiffusionModule_MultiCase.py:539-575,
+ * nn.TransformerEncoderLayer: post-norm, ReLU, dropout) for the training step, one launch per direction each (csrc/seq_block.hip).
+ * Dropout: counter-based hash of (seed, *counter, element); `counter` (one uint64 of device memory) is only READ -- the caller
+ * advances it between steps -- and the value a forward launch used is left in `used_call` (one uint64), from which the backward
+ * launch regenerates the mask.  All activations bfloat16 unless said.
+ * -----------------------------------------------------------------------------------------------------------------*/
+/* softmax(q k^T / sqrt(dh)) -> dropout(p) -> @ v per sample and head, for sequences of S <= 8 tokens: qkv [Bn * S, 3 * H * dh]
+ * (the in-projection's output: q | k | v per row), ctx [Bn * S, H * dh]; backward: dqkv from dctx. */
+int ops_seq_attention_fwd(int Bn, int S, int H, int dh, const void* qkv, void* ctx, float p_drop, unsigned long long seed,
+                          unsigned long long* counter, unsigned long long* used_call, void* stream);
+int ops_seq_attention_bwd(int Bn, int S, int H, int dh, const void* qkv, const void* dctx, void* dqkv, float p_drop,
+                          unsigned long long seed, unsigned long long* used_call, void* stream);
+/* y = LayerNorm(res + dropout(x)) over the d <= 256 columns of T rows: x bfloat16, res float32 or bfloat16, y in BOTH float32
+ * (the residual stream) and bfloat16 (the next product's operand); saves z = res + dropout(x) [T, d] float32, mean / rstd [T].
+ * Backward: dy32 and / or dy16 (summed) -> dx (bfloat16, through the dropout) and dres (float32); dgamma / dbeta [d] are ADDED to
+ * with float atomics -- the caller zeroes them (the training loop's flat gradient buffer is zeroed every step). */
+int ops_dropout_add_layernorm_fwd(int T, int d, const void* x, const void* res, int res_is_bf16, const float* gamma, const float* beta,
+                                  float eps, float p_drop, unsigned long long seed, unsigned long long* counter,
+                                  unsigned long long* used_call, float* y32, void* y16, float* z, float* mean, float* rstd, void* stream);
+int ops_dropout_add_layernorm_bwd(int T, int d, const float* dy32, const void* dy16, const float* z, const float* mean, const float* rstd,
+                                  const float* gamma, float p_drop, unsigned long long seed, unsigned long long* used_call, void* dx,
+                                  float* dres, float* dgamma, float* dbeta, void* stream);
+/* y = dropout(LeakyReLU_slope(x)) on n bfloat16 elements (slope 0: ReLU); backward from x and dy. */
+int ops_act_dropout_fwd(long n, const void* x, void* y, float slope, float p_drop, unsigned long long seed, unsigned long long* counter,
+                        unsigned long long* used_call, void* stream);
+int ops_act_dropout_bwd(long n, const void* x, const void* dy, void* dx, float slope, float p_drop, unsigned long long seed,
+                        unsigned long long* used_call, void* stream);
+
+/* Weight AND bias gradient of a Linear over many rows: dW [N, K] float32 += dY^T X, dbias [N] += column sums of dY (optional); dY
+ * [T, N] and X [T, K] bfloat16 row-major.  The rows are split over the grid and the partial results added with float atomics
+ * (dW / dbias: the caller's zeroed flat gradient slices). */
+int ops_linear_wgrad_accumulate(int T, int N, int K, const void* dY, const void* X, float* dW, float* dbias, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -49,6 +49,13 @@ EXPORTS = (
     "ops_flat_clip_adam_step_repack_f32",
     "ops_mlp_gather_noise",
     "ops_mlp_loss_workspace_bytes",
+    "ops_seq_attention_fwd",
+    "ops_seq_attention_bwd",
+    "ops_dropout_add_layernorm_fwd",
+    "ops_dropout_add_layernorm_bwd",
+    "ops_act_dropout_fwd",
+    "ops_act_dropout_bwd",
+    "ops_linear_wgrad_accumulate",
 )
 
 OK, ERR_INVALID_ARG, ERR_UNSUPPORTED, ERR_LAUNCH = 0, 1, 2, 3
@@ -188,6 +195,20 @@ def load():
     lib.ops_mlp_gather_noise.restype = it
     lib.ops_mlp_gather_noise.argtypes = [it, it, vp, vp, vp, ull, vp, vp, it, vp, vp, it, vp, vp]
     lib.ops_mlp_loss_workspace_bytes.restype = ctypes.c_size_t
+    lib.ops_seq_attention_fwd.restype = it
+    lib.ops_seq_attention_fwd.argtypes = [it, it, it, it, vp, vp, fl, ull, vp, vp, vp]
+    lib.ops_seq_attention_bwd.restype = it
+    lib.ops_seq_attention_bwd.argtypes = [it, it, it, it, vp, vp, vp, fl, ull, vp, vp]
+    lib.ops_dropout_add_layernorm_fwd.restype = it
+    lib.ops_dropout_add_layernorm_fwd.argtypes = [it, it, vp, vp, it, vp, vp, fl, fl, ull, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.ops_dropout_add_layernorm_bwd.restype = it
+    lib.ops_dropout_add_layernorm_bwd.argtypes = [it, it, vp, vp, vp, vp, vp, vp, fl, ull, vp, vp, vp, vp, vp, vp]
+    lib.ops_act_dropout_fwd.restype = it
+    lib.ops_act_dropout_fwd.argtypes = [lg, vp, vp, fl, fl, ull, vp, vp, vp]
+    lib.ops_linear_wgrad_accumulate.restype = it
+    lib.ops_linear_wgrad_accumulate.argtypes = [it, it, it, vp, vp, vp, vp, vp]
+    lib.ops_act_dropout_bwd.restype = it
+    lib.ops_act_dropout_bwd.argtypes = [lg, vp, vp, vp, fl, fl, ull, vp, vp]
     lib.ops_amd_max_elements.restype = it
     lib.ops_amd_abi_version.restype = it
     lib.ops_amd_last_error.restype = ctypes.c_char_p

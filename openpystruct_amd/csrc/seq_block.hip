@@ -1,0 +1,598 @@
+// Row-wise blocks of the Transformer-Diffusion surrogate's encoder (/root/reference/OpenPyStruct_TransformerDiffusionModule_MultiCase.py:
+// 539-575: nn.TransformerEncoderLayer, post-norm, ReLU, batch_first, dropout 0.1) for the training step, one launch per direction each:
+//
+//   ops_seq_attention_fwd / _bwd      softmax(q k^T / sqrt(dh)) -> dropout -> @ v   for sequences of S <= 8 tokens ([CLS] + 6 load cases)
+//   ops_dropout_add_layernorm_fwd / _bwd      LayerNorm(residual + dropout(x)), float32 AND bfloat16 copies of the result
+//   ops_act_dropout_fwd / _bwd        dropout(ReLU(x)) (LeakyReLU(slope) in general)
+//
+// Why: through the framework an encoder layer of this model is ~90 kernel nodes per training step (profiles/r02_notes.md section 8):
+// the attention of 7 tokens goes through a flash-attention kernel pair built for long sequences (8 us forward, 41 us backward) wrapped
+// in a dozen layout copies and fills, every "dropout -> add -> LayerNorm" is 3 nodes forward and 6 backward (plus a 43 us mixed-dtype
+// add), every ReLU / dropout a node each way.  These three kernels + the shadow GEMMs make it ~26.
+//
+// Dropout everywhere: keep-mask from a counter-based hash of (seed, call counter, element).  The counter lives in device memory and is
+// advanced by the CALLER between steps (one increment node per step; fresh masks under HIP-graph replay) -- never inside these
+// launches: every workgroup of a launch must read the same value, because the backward launch REGENERATES the mask from the value the
+// forward launch left in `used_call` instead of reading a stored one.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/openpystruct_amd.h"
+
+namespace opsamd {
+
+__device__ __forceinline__ float sq_bf2f(uint16_t h) { return __uint_as_float((uint32_t)h << 16); }
+__device__ __forceinline__ uint16_t sq_f2bf(float f) {
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40u);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+__device__ __forceinline__ float sq_uniform(uint64_t seed, uint64_t call, uint64_t idx) {
+  uint64_t z = seed + 0x9E3779B97F4A7C15ull * (call + 1) + idx * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z ^= z >> 31;
+  return (float)(z >> 40) * (1.0f / 16777216.0f);
+}
+__device__ __forceinline__ float sq_wsum(float v) {
+#pragma unroll
+  for (int s = 32; s >= 1; s >>= 1) v += __shfl_xor(v, s, 64);
+  return v;
+}
+
+// ================================================================================================================================
+// attention over short sequences: a workgroup stages the q|k|v rows of NB samples in LDS (coalesced 16-byte loads), one thread per
+// (sample, head, query) computes its row of the S x S problem from there
+// ================================================================================================================================
+constexpr int SA_MAXS = 8;
+constexpr int SA_THREADS = 512;
+
+struct SaArgs {
+  int Bn, S, H, dh;              // samples, tokens per sample, heads, head width (d = H * dh)
+  int NB;                        // samples per workgroup
+  const uint16_t* qkv;           // [Bn * S, 3 d] bf16
+  const uint16_t* dctx;          // backward: [Bn * S, d] bf16
+  uint16_t* ctx;                 // forward out [Bn * S, d]
+  uint16_t* dqkv;                // backward out [Bn * S, 3 d]
+  float p_drop; unsigned long long seed; unsigned long long* counter; unsigned long long* used_call;
+};
+
+// global -> LDS copy of n16 16-byte pieces by the whole workgroup, eight independent loads in flight per thread
+__device__ __forceinline__ void sa_stage(uint4* __restrict__ dst, const uint4* __restrict__ src, int n16) {
+  for (int e0 = threadIdx.x; e0 < n16; e0 += 8 * SA_THREADS) {
+    uint4 t[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { const int e = e0 + k * SA_THREADS; t[k] = e < n16 ? src[e] : uint4{0u, 0u, 0u, 0u}; }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { const int e = e0 + k * SA_THREADS; if (e < n16) dst[e] = t[k]; }
+  }
+}
+
+// this thread's attention row: probabilities p[j] (after softmax) and the keep-scaled ones pk[j]
+__device__ __forceinline__ void sa_row(const uint16_t* __restrict__ s_qkv, int d3, int d, int S, int dh, int row0, int i, int h, float scale,
+                                       float p_drop, uint64_t seed, uint64_t call, uint64_t eidx0, float (&p)[SA_MAXS], float (&pk)[SA_MAXS]) {
+  float sc[SA_MAXS];
+#pragma unroll
+  for (int j = 0; j < SA_MAXS; ++j) sc[j] = 0.0f;
+  const uint16_t* q = s_qkv + (row0 + i) * d3 + h * dh;
+  for (int t = 0; t < dh; ++t) {
+    const float qt = sq_bf2f(q[t]);
+#pragma unroll
+    for (int j = 0; j < SA_MAXS; ++j)
+      if (j < S) sc[j] = __builtin_fmaf(qt, sq_bf2f(s_qkv[(row0 + j) * d3 + d + h * dh + t]), sc[j]);
+  }
+  float mx = -3.0e38f;
+#pragma unroll
+  for (int j = 0; j < SA_MAXS; ++j)
+    if (j < S) { sc[j] *= scale; mx = fmaxf(mx, sc[j]); }
+  float den = 0.0f;
+#pragma unroll
+  for (int j = 0; j < SA_MAXS; ++j) { p[j] = j < S ? __expf(sc[j] - mx) : 0.0f; den += p[j]; }
+  const float inv = 1.0f / den, ks = p_drop > 0.0f ? 1.0f / (1.0f - p_drop) : 1.0f;
+#pragma unroll
+  for (int j = 0; j < SA_MAXS; ++j) {
+    p[j] *= inv;
+    const bool keep = !(p_drop > 0.0f) || sq_uniform(seed, call, eidx0 + j) >= p_drop;
+    pk[j] = (j < S && keep) ? p[j] * ks : 0.0f;
+  }
+}
+
+__global__ __launch_bounds__(SA_THREADS) void seq_attention_fwd_kernel(const SaArgs a) {
+  extern __shared__ __attribute__((aligned(16))) uint16_t s_mem[];
+  const int d = a.H * a.dh, d3 = 3 * d, S = a.S;
+  const int b0 = blockIdx.x * a.NB, nb = min(a.NB, a.Bn - b0), rows = nb * S;
+  uint16_t* s_qkv = s_mem;
+  // stage: rows x 3d bf16, contiguous in global memory
+  sa_stage((uint4*)s_qkv, (const uint4*)(a.qkv + (long)b0 * S * d3), rows * d3 / 8);      // d3 % 8 == 0 (checked on the host)
+  const unsigned long long call = a.p_drop > 0.0f ? *a.counter : 0ull;
+  __syncthreads();
+  const int tid = threadIdx.x, i = tid % S, h = (tid / S) % a.H, bl = tid / (S * a.H);
+  if (bl < nb) {
+    const float scale = rsqrtf((float)a.dh);
+    const uint64_t e0 = (((uint64_t)(b0 + bl) * a.H + h) * S + i) * S;
+    float p[SA_MAXS], pk[SA_MAXS];
+    sa_row(s_qkv, d3, d, S, a.dh, bl * S, i, h, scale, a.p_drop, a.seed, call, e0, p, pk);
+    uint16_t* out = a.ctx + ((long)(b0 + bl) * S + i) * d + h * a.dh;
+    for (int t = 0; t < a.dh; ++t) {
+      float o = 0.0f;
+#pragma unroll
+      for (int j = 0; j < SA_MAXS; ++j)
+        if (j < S) o = __builtin_fmaf(pk[j], sq_bf2f(s_qkv[(bl * S + j) * d3 + 2 * d + h * a.dh + t]), o);
+      out[t] = sq_f2bf(o);
+    }
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0 && a.used_call) *a.used_call = call;
+}
+
+__global__ __launch_bounds__(SA_THREADS) void seq_attention_bwd_kernel(const SaArgs a) {
+  extern __shared__ __attribute__((aligned(16))) uint16_t s_mem[];
+  const int d = a.H * a.dh, d3 = 3 * d, S = a.S;
+  const int b0 = blockIdx.x * a.NB, nb = min(a.NB, a.Bn - b0), rows = nb * S;
+  uint16_t* s_qkv = s_mem;                                       // [NB*S][3d]
+  uint16_t* s_do = s_qkv + a.NB * S * d3;                        // [NB*S][d]
+  float* s_ds = (float*)(s_do + a.NB * S * d);                   // [NB][H][S][S]  scale * dS
+  float* s_pk = s_ds + a.NB * a.H * S * S;                       // [NB][H][S][S]  keep-scaled probabilities
+  sa_stage((uint4*)s_qkv, (const uint4*)(a.qkv + (long)b0 * S * d3), rows * d3 / 8);
+  sa_stage((uint4*)s_do, (const uint4*)(a.dctx + (long)b0 * S * d), rows * d / 8);
+  const unsigned long long call = a.p_drop > 0.0f ? *a.used_call : 0ull;
+  __syncthreads();
+  const int tid = threadIdx.x, i = tid % S, h = (tid / S) % a.H, bl = tid / (S * a.H);
+  const float scale = rsqrtf((float)a.dh), ks = a.p_drop > 0.0f ? 1.0f / (1.0f - a.p_drop) : 1.0f;
+  if (bl < nb) {
+    const uint64_t e0 = (((uint64_t)(b0 + bl) * a.H + h) * S + i) * S;
+    float p[SA_MAXS], pk[SA_MAXS], dp[SA_MAXS];
+    sa_row(s_qkv, d3, d, S, a.dh, bl * S, i, h, scale, a.p_drop, a.seed, call, e0, p, pk);
+#pragma unroll
+    for (int j = 0; j < SA_MAXS; ++j) dp[j] = 0.0f;
+    const uint16_t* go = s_do + (bl * S + i) * d + h * a.dh;
+    for (int t = 0; t < a.dh; ++t) {
+      const float g = sq_bf2f(go[t]);
+#pragma unroll
+      for (int j = 0; j < SA_MAXS; ++j)
+        if (j < S) dp[j] = __builtin_fmaf(g, sq_bf2f(s_qkv[(bl * S + j) * d3 + 2 * d + h * a.dh + t]), dp[j]);
+    }
+    // through the dropout (dP = keep / (1 - p) dP~) and the softmax (dS = P (dP - sum_k dP_k P_k))
+    float D = 0.0f;
+#pragma unroll
+    for (int j = 0; j < SA_MAXS; ++j) {
+      dp[j] = pk[j] != 0.0f ? dp[j] * ks : (a.p_drop > 0.0f ? 0.0f : dp[j]);
+      D = __builtin_fmaf(dp[j], p[j], D);
+    }
+    float ds[SA_MAXS];
+#pragma unroll
+    for (int j = 0; j < SA_MAXS; ++j) {
+      ds[j] = j < S ? p[j] * (dp[j] - D) * scale : 0.0f;
+      if (j < S) {
+        s_ds[((bl * a.H + h) * S + i) * S + j] = ds[j];
+        s_pk[((bl * a.H + h) * S + i) * S + j] = pk[j];
+      }
+    }
+    uint16_t* dq = a.dqkv + ((long)(b0 + bl) * S + i) * d3 + h * a.dh;
+    for (int t = 0; t < a.dh; ++t) {
+      float o = 0.0f;
+#pragma unroll
+      for (int j = 0; j < SA_MAXS; ++j)
+        if (j < S) o = __builtin_fmaf(ds[j], sq_bf2f(s_qkv[(bl * S + j) * d3 + d + h * a.dh + t]), o);
+      dq[t] = sq_f2bf(o);
+    }
+  }
+  __syncthreads();
+  if (bl < nb) {
+    // this thread's token as KEY / VALUE j = i: dk_j = sum_i dS_ij q_i, dv_j = sum_i P~_ij dO_i
+    const int j = i;
+    float wds[SA_MAXS], wpk[SA_MAXS];
+#pragma unroll
+    for (int ii = 0; ii < SA_MAXS; ++ii) {
+      wds[ii] = ii < S ? s_ds[((bl * a.H + h) * S + ii) * S + j] : 0.0f;
+      wpk[ii] = ii < S ? s_pk[((bl * a.H + h) * S + ii) * S + j] : 0.0f;
+    }
+    uint16_t* dk = a.dqkv + ((long)(b0 + bl) * S + j) * d3 + d + h * a.dh;
+    uint16_t* dv = dk + d;
+    for (int t = 0; t < a.dh; ++t) {
+      float ok = 0.0f, ov = 0.0f;
+#pragma unroll
+      for (int ii = 0; ii < SA_MAXS; ++ii)
+        if (ii < S) {
+          ok = __builtin_fmaf(wds[ii], sq_bf2f(s_qkv[(bl * S + ii) * d3 + h * a.dh + t]), ok);
+          ov = __builtin_fmaf(wpk[ii], sq_bf2f(s_do[(bl * S + ii) * d + h * a.dh + t]), ov);
+        }
+      dk[t] = sq_f2bf(ok);
+      dv[t] = sq_f2bf(ov);
+    }
+  }
+}
+
+// ================================================================================================================================
+// LayerNorm(residual + dropout(x)): one wave per row, a lane's columns lane, lane + 64, ... (d <= 256)
+// ================================================================================================================================
+constexpr int LN_MAXC = 4;           // columns per lane
+constexpr int LN_THREADS = 256;      // 4 rows at a time
+constexpr int LN_BWD_THREADS = 1024; // backward: 16 waves ...
+constexpr int LN_ROWS_PER_WG = 64;   // ... x 4 rows: few workgroups add into gamma / beta's gradients (~40 ns per same-address atomic)
+
+struct LnArgs {
+  int T, d;
+  const uint16_t* x;                 // [T, d] bf16: the sublayer's output
+  const void* res; int res_bf16;     // [T, d] residual, float32 or bf16
+  const float* gamma; const float* beta; float eps;
+  float p_drop; unsigned long long seed; unsigned long long* counter; unsigned long long* used_call;
+  float* y32; uint16_t* y16;         // [T, d] both
+  float* z;                          // [T, d] float32: the normalisation's input, saved
+  float* mean; float* rstd;          // [T]
+  // backward
+  const float* dy32; const uint16_t* dy16;     // either may be NULL
+  uint16_t* dx; float* dres;
+  float* dgamma; float* dbeta;       // ADDED to (float atomics): the caller zeroes them
+};
+
+__global__ __launch_bounds__(LN_THREADS) void dropout_add_ln_fwd_kernel(const LnArgs a) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, d = a.d;
+  const unsigned long long call = a.p_drop > 0.0f ? *a.counter : 0ull;
+  const float ks = a.p_drop > 0.0f ? 1.0f / (1.0f - a.p_drop) : 1.0f;
+  float g[LN_MAXC], be[LN_MAXC];
+#pragma unroll
+  for (int k = 0; k < LN_MAXC; ++k) {
+    const int c = lane + 64 * k;
+    g[k] = c < d ? a.gamma[c] : 0.0f;
+    be[k] = c < d ? a.beta[c] : 0.0f;
+  }
+  for (int r = blockIdx.x * 4 + wave; r < a.T; r += gridDim.x * 4) {
+    float z[LN_MAXC], sum = 0.0f;
+#pragma unroll
+    for (int k = 0; k < LN_MAXC; ++k) {
+      const int c = lane + 64 * k;
+      z[k] = 0.0f;
+      if (c < d) {
+        const long e = (long)r * d + c;
+        float xv = sq_bf2f(a.x[e]);
+        if (a.p_drop > 0.0f) xv = sq_uniform(a.seed, call, (uint64_t)e) >= a.p_drop ? xv * ks : 0.0f;
+        const float rv = a.res_bf16 ? sq_bf2f(((const uint16_t*)a.res)[e]) : ((const float*)a.res)[e];
+        z[k] = rv + xv;
+        sum += z[k];
+      }
+    }
+    const float mean = sq_wsum(sum) / (float)d;
+    float sq = 0.0f;
+#pragma unroll
+    for (int k = 0; k < LN_MAXC; ++k) { const float dv = z[k] - mean; sq += (lane + 64 * k < d) ? dv * dv : 0.0f; }
+    const float rstd = rsqrtf(sq_wsum(sq) / (float)d + a.eps);
+    if (lane == 0) { a.mean[r] = mean; a.rstd[r] = rstd; }
+#pragma unroll
+    for (int k = 0; k < LN_MAXC; ++k) {
+      const int c = lane + 64 * k;
+      if (c < d) {
+        const long e = (long)r * d + c;
+        const float y = __builtin_fmaf((z[k] - mean) * rstd, g[k], be[k]);
+        a.z[e] = z[k];
+        a.y32[e] = y;
+        a.y16[e] = sq_f2bf(y);
+      }
+    }
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0 && a.used_call) *a.used_call = call;
+}
+
+__global__ __launch_bounds__(LN_BWD_THREADS) void dropout_add_ln_bwd_kernel(const LnArgs a) {
+  constexpr int NW = LN_BWD_THREADS / 64;
+  __shared__ float s_g[NW][LN_MAXC * 64], s_b[NW][LN_MAXC * 64];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, d = a.d;
+  const unsigned long long call = a.p_drop > 0.0f ? *a.used_call : 0ull;
+  const float ks = a.p_drop > 0.0f ? 1.0f / (1.0f - a.p_drop) : 1.0f;
+  float g[LN_MAXC], pg[LN_MAXC], pb[LN_MAXC];
+#pragma unroll
+  for (int k = 0; k < LN_MAXC; ++k) { g[k] = (lane + 64 * k < d) ? a.gamma[lane + 64 * k] : 0.0f; pg[k] = 0.0f; pb[k] = 0.0f; }
+  const int r0 = blockIdx.x * LN_ROWS_PER_WG;
+  // this wave's rows r0 + wave, + NW, ...: the next row's operands are requested before the current row's reductions
+  auto load_row = [&](int r, float (&gv)[LN_MAXC], float (&zv)[LN_MAXC], float& mean, float& rstd) {
+    mean = 0.0f; rstd = 0.0f;
+#pragma unroll
+    for (int k = 0; k < LN_MAXC; ++k) { gv[k] = 0.0f; zv[k] = 0.0f; }
+    if (r < a.T) {
+      mean = a.mean[r]; rstd = a.rstd[r];
+#pragma unroll
+      for (int k = 0; k < LN_MAXC; ++k) {
+        const int c = lane + 64 * k;
+        if (c < d) {
+          const long e = (long)r * d + c;
+          gv[k] = a.dy32 ? a.dy32[e] : 0.0f;
+          if (a.dy16) gv[k] += sq_bf2f(a.dy16[e]);
+          zv[k] = a.z[e];
+        }
+      }
+    }
+  };
+  float gv[LN_MAXC], zv[LN_MAXC], mean, rstd;
+  load_row(r0 + wave, gv, zv, mean, rstd);
+  for (int rr = wave; rr < LN_ROWS_PER_WG; rr += NW) {
+    const int r = r0 + rr;
+    if (r >= a.T) break;                                   // wave-uniform
+    float gn[LN_MAXC], zn[LN_MAXC], mean_n, rstd_n;
+    load_row(r + NW < r0 + LN_ROWS_PER_WG ? r + NW : a.T, gn, zn, mean_n, rstd_n);
+    float gy[LN_MAXC], xh[LN_MAXC], s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+    for (int k = 0; k < LN_MAXC; ++k) {
+      const bool live = lane + 64 * k < d;
+      xh[k] = live ? (zv[k] - mean) * rstd : 0.0f;
+      pg[k] = __builtin_fmaf(gv[k], xh[k], pg[k]);
+      pb[k] += gv[k];
+      gy[k] = gv[k] * g[k];
+      s1 += gy[k];
+      s2 = __builtin_fmaf(gy[k], xh[k], s2);
+    }
+    s1 = sq_wsum(s1) / (float)d; s2 = sq_wsum(s2) / (float)d;
+#pragma unroll
+    for (int k = 0; k < LN_MAXC; ++k) {
+      const int c = lane + 64 * k;
+      if (c < d) {
+        const long e = (long)r * d + c;
+        const float dz = rstd * (gy[k] - s1 - xh[k] * s2);
+        a.dres[e] = dz;
+        const bool keep = !(a.p_drop > 0.0f) || sq_uniform(a.seed, call, (uint64_t)e) >= a.p_drop;
+        a.dx[e] = sq_f2bf(keep ? dz * ks : 0.0f);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < LN_MAXC; ++k) { gv[k] = gn[k]; zv[k] = zn[k]; }
+    mean = mean_n; rstd = rstd_n;
+  }
+  // column sums over this workgroup's rows, then ONE hardware float atomic (unsafeAtomicAdd: global_atomic_add_f32, not the
+  // compare-and-swap loop plain atomicAdd compiles to) per column and workgroup into the (zeroed) gamma / beta gradients.  (A
+  // two-stage reduction of per-workgroup partial rows by one workgroup cost 40 us per launch; the order of these additions is not
+  // fixed: ~1e-7 relative run to run.)
+#pragma unroll
+  for (int k = 0; k < LN_MAXC; ++k) { s_g[wave][lane + 64 * k] = pg[k]; s_b[wave][lane + 64 * k] = pb[k]; }
+  __syncthreads();
+  for (int c = threadIdx.x; c < d; c += LN_BWD_THREADS) {
+    float tg = 0.0f, tb = 0.0f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) { tg += s_g[w][c]; tb += s_b[w][c]; }
+    unsafeAtomicAdd(&a.dgamma[c], tg);
+    unsafeAtomicAdd(&a.dbeta[c], tb);
+  }
+}
+
+// ================================================================================================================================
+// dropout(LeakyReLU_slope(x)) elementwise on bf16 (slope 0: ReLU)
+// ================================================================================================================================
+__global__ __launch_bounds__(256) void act_dropout_fwd_kernel(long n, const uint16_t* __restrict__ x, uint16_t* __restrict__ y, float slope,
+                                                               float p_drop, unsigned long long seed, unsigned long long* counter,
+                                                               unsigned long long* used_call) {
+  const unsigned long long call = p_drop > 0.0f ? *counter : 0ull;
+  const float ks = p_drop > 0.0f ? 1.0f / (1.0f - p_drop) : 1.0f;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256) {
+    float v = sq_bf2f(x[e]);
+    v = v > 0.0f ? v : v * slope;
+    if (p_drop > 0.0f) v = sq_uniform(seed, call, (uint64_t)e) >= p_drop ? v * ks : 0.0f;
+    y[e] = sq_f2bf(v);
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0 && used_call) *used_call = call;
+}
+__global__ __launch_bounds__(256) void act_dropout_bwd_kernel(long n, const uint16_t* __restrict__ x, const uint16_t* __restrict__ dy,
+                                                               uint16_t* __restrict__ dx, float slope, float p_drop, unsigned long long seed,
+                                                               const unsigned long long* used_call) {
+  const unsigned long long call = p_drop > 0.0f ? *used_call : 0ull;
+  const float ks = p_drop > 0.0f ? 1.0f / (1.0f - p_drop) : 1.0f;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256) {
+    float g = sq_bf2f(dy[e]);
+    if (p_drop > 0.0f) g = sq_uniform(seed, call, (uint64_t)e) >= p_drop ? g * ks : 0.0f;
+    g = sq_bf2f(x[e]) > 0.0f ? g : g * slope;
+    dx[e] = sq_f2bf(g);
+  }
+}
+
+void set_last_error(const char* msg);
+
+}  // namespace opsamd
+
+using namespace opsamd;
+
+static int sq_check(const char* what) {
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { set_last_error(hipGetErrorString(e)); return OPS_AMD_ERR_LAUNCH; }
+  (void)what;
+  return OPS_AMD_OK;
+}
+
+// samples per workgroup: as many as 512 threads (one per sample x head x token) and 64 KB of LDS hold
+static int sa_samples_per_wg(int S, int H, size_t lds_per_sample) {
+  int nb = SA_THREADS / (S * H);
+  const int cap = (int)((64 * 1024) / lds_per_sample);
+  if (nb > cap) nb = cap;
+  return nb < 1 ? 0 : (nb > 8 ? 8 : nb);
+}
+
+extern "C" int ops_seq_attention_fwd(int Bn, int S, int H, int dh, const void* qkv, void* ctx, float p_drop, unsigned long long seed,
+                                     unsigned long long* counter, unsigned long long* used_call, void* stream) {
+  if (Bn < 1 || S < 1 || H < 1 || dh < 1 || !qkv || !ctx || p_drop < 0.0f || p_drop >= 1.0f || (p_drop > 0.0f && (!counter || !used_call)))
+    return OPS_AMD_ERR_INVALID_ARG;
+  const int d = H * dh;
+  if (S > SA_MAXS || S * H > SA_THREADS) return OPS_AMD_ERR_UNSUPPORTED;
+  const int NB = sa_samples_per_wg(S, H, (size_t)S * 3 * d * 2);
+  if (NB < 1 || (3 * d) % 8 || ((uintptr_t)qkv & 15)) return OPS_AMD_ERR_UNSUPPORTED;
+  const size_t lds = (size_t)NB * S * 3 * d * 2;
+  const SaArgs a{Bn, S, H, dh, NB, (const uint16_t*)qkv, nullptr, (uint16_t*)ctx, nullptr, p_drop, seed, counter, used_call};
+  hipLaunchKernelGGL(seq_attention_fwd_kernel, dim3((unsigned)((Bn + NB - 1) / NB)), dim3(SA_THREADS), lds, (hipStream_t)stream, a);
+  return sq_check("seq_attention_fwd_kernel");
+}
+
+extern "C" int ops_seq_attention_bwd(int Bn, int S, int H, int dh, const void* qkv, const void* dctx, void* dqkv, float p_drop,
+                                     unsigned long long seed, unsigned long long* used_call, void* stream) {
+  if (Bn < 1 || S < 1 || H < 1 || dh < 1 || !qkv || !dctx || !dqkv || p_drop < 0.0f || p_drop >= 1.0f || (p_drop > 0.0f && !used_call))
+    return OPS_AMD_ERR_INVALID_ARG;
+  const int d = H * dh;
+  if (S > SA_MAXS || S * H > SA_THREADS) return OPS_AMD_ERR_UNSUPPORTED;
+  const int NB = sa_samples_per_wg(S, H, (size_t)S * 4 * d * 2 + (size_t)2 * H * S * S * 4);
+  if (NB < 1 || (3 * d) % 8 || d % 8 || (((uintptr_t)qkv | (uintptr_t)dctx) & 15)) return OPS_AMD_ERR_UNSUPPORTED;
+  const size_t lds = (size_t)NB * S * 4 * d * 2 + (size_t)2 * NB * H * S * S * 4;
+  const SaArgs a{Bn, S, H, dh, NB, (const uint16_t*)qkv, (const uint16_t*)dctx, nullptr, (uint16_t*)dqkv, p_drop, seed, nullptr, used_call};
+  hipLaunchKernelGGL(seq_attention_bwd_kernel, dim3((unsigned)((Bn + NB - 1) / NB)), dim3(SA_THREADS), lds, (hipStream_t)stream, a);
+  return sq_check("seq_attention_bwd_kernel");
+}
+
+extern "C" int ops_dropout_add_layernorm_fwd(int T, int d, const void* x, const void* res, int res_is_bf16, const float* gamma, const float* beta,
+                                             float eps, float p_drop, unsigned long long seed, unsigned long long* counter,
+                                             unsigned long long* used_call, float* y32, void* y16, float* z, float* mean, float* rstd,
+                                             void* stream) {
+  if (T < 1 || d < 1 || !x || !res || !gamma || !beta || !y32 || !y16 || !z || !mean || !rstd || p_drop < 0.0f || p_drop >= 1.0f ||
+      (p_drop > 0.0f && (!counter || !used_call)))
+    return OPS_AMD_ERR_INVALID_ARG;
+  if (d > 64 * LN_MAXC) return OPS_AMD_ERR_UNSUPPORTED;
+  LnArgs a{};
+  a.T = T; a.d = d; a.x = (const uint16_t*)x; a.res = res; a.res_bf16 = res_is_bf16; a.gamma = gamma; a.beta = beta; a.eps = eps;
+  a.p_drop = p_drop; a.seed = seed; a.counter = counter; a.used_call = used_call; a.y32 = y32; a.y16 = (uint16_t*)y16; a.z = z;
+  a.mean = mean; a.rstd = rstd;
+  int grid = (T + 3) / 4;
+  if (grid > 2048) grid = 2048;
+  hipLaunchKernelGGL(dropout_add_ln_fwd_kernel, dim3((unsigned)grid), dim3(LN_THREADS), 0, (hipStream_t)stream, a);
+  return sq_check("dropout_add_ln_fwd_kernel");
+}
+
+extern "C" int ops_dropout_add_layernorm_bwd(int T, int d, const float* dy32, const void* dy16, const float* z, const float* mean, const float* rstd,
+                                             const float* gamma, float p_drop, unsigned long long seed, unsigned long long* used_call, void* dx,
+                                             float* dres, float* dgamma, float* dbeta, void* stream) {
+  if (T < 1 || d < 1 || (!dy32 && !dy16) || !z || !mean || !rstd || !gamma || !dx || !dres || !dgamma || !dbeta ||
+      p_drop < 0.0f || p_drop >= 1.0f || (p_drop > 0.0f && !used_call))
+    return OPS_AMD_ERR_INVALID_ARG;
+  if (d > 64 * LN_MAXC) return OPS_AMD_ERR_UNSUPPORTED;
+  LnArgs a{};
+  a.T = T; a.d = d; a.gamma = gamma; a.p_drop = p_drop; a.seed = seed; a.used_call = used_call; a.z = (float*)z; a.mean = (float*)mean;
+  a.rstd = (float*)rstd; a.dy32 = dy32; a.dy16 = (const uint16_t*)dy16; a.dx = (uint16_t*)dx; a.dres = dres; a.dgamma = dgamma; a.dbeta = dbeta;
+  hipLaunchKernelGGL(dropout_add_ln_bwd_kernel, dim3((unsigned)((T + LN_ROWS_PER_WG - 1) / LN_ROWS_PER_WG)), dim3(LN_BWD_THREADS), 0,
+                     (hipStream_t)stream, a);
+  return sq_check("dropout_add_ln_bwd_kernel");
+}
+
+extern "C" int ops_act_dropout_fwd(long n, const void* x, void* y, float slope, float p_drop, unsigned long long seed, unsigned long long* counter,
+                                   unsigned long long* used_call, void* stream) {
+  if (n < 1 || !x || !y || p_drop < 0.0f || p_drop >= 1.0f || (p_drop > 0.0f && (!counter || !used_call))) return OPS_AMD_ERR_INVALID_ARG;
+  long nb = (n + 255) / 256;
+  if (nb > 2048) nb = 2048;
+  hipLaunchKernelGGL(act_dropout_fwd_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, n, (const uint16_t*)x, (uint16_t*)y, slope,
+                     p_drop, seed, counter, used_call);
+  return sq_check("act_dropout_fwd_kernel");
+}
+
+extern "C" int ops_act_dropout_bwd(long n, const void* x, const void* dy, void* dx, float slope, float p_drop, unsigned long long seed,
+                                   unsigned long long* used_call, void* stream) {
+  if (n < 1 || !x || !dy || !dx || p_drop < 0.0f || p_drop >= 1.0f || (p_drop > 0.0f && !used_call)) return OPS_AMD_ERR_INVALID_ARG;
+  long nb = (n + 255) / 256;
+  if (nb > 2048) nb = 2048;
+  hipLaunchKernelGGL(act_dropout_bwd_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, n, (const uint16_t*)x, (const uint16_t*)dy,
+                     (uint16_t*)dx, slope, p_drop, seed, (const unsigned long long*)used_call);
+  return sq_check("act_dropout_bwd_kernel");
+}
+
+// ================================================================================================================================
+// weight gradient of a Linear over MANY rows: dW [N, K] += dY^T X with dY [T, N], X [T, K] bf16 row-major, T in the thousands
+// (every token of the batch), N, K a few hundred.  The library runs this as a handful of 64 x 64 tiles that each walk all T rows
+// (25 us per product, ten products per Transformer-Diffusion step); here the rows are split over the grid as well: a workgroup owns
+// a 64 x 64 tile of dW and 256 rows, transposes 32-row slabs of both operands through LDS into MFMA fragments (both operands are
+// contiguous along the OUTPUT index in memory, the MFMA wants them contiguous along the reduction index), and adds its partial
+// tile to the float32 gradient with hardware float atomics (the caller's flat gradient buffer is zeroed every step).  The bias
+// gradient -- the column sums of dY -- comes out of the same pass (first column of tiles).  Same-address float atomics cost
+// ~40 ns each (measured: 448 adders per address 19 us, 224: 9 us): 28 row blocks per address here.
+// ================================================================================================================================
+namespace opsamd {
+
+typedef __bf16 wg_bf16x8 __attribute__((ext_vector_type(8)));
+typedef float wg_f32x4 __attribute__((ext_vector_type(4)));
+constexpr int WG_ROWS = 128;      // rows of T per workgroup
+constexpr int WG_SLAB = 32;       // rows per LDS slab = one MFMA reduction step
+
+// one 32-row slab of an operand: row lr, 8 columns from c0 + lc -- one 16-byte load when the matrix allows it
+__device__ __forceinline__ uint4 wg_load8(const uint16_t* __restrict__ M, int T, int C, int t, int c, bool vec) {
+  uint4 r = uint4{0u, 0u, 0u, 0u};
+  if (t >= T || c >= C) return r;
+  if (vec && c + 8 <= C) return *(const uint4*)(M + (long)t * C + c);
+  uint16_t v[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) v[j] = c + j < C ? M[(long)t * C + c + j] : (uint16_t)0;
+  return *(const uint4*)v;
+}
+
+__global__ __launch_bounds__(256) void wgrad_tn_kernel(int T, int N, int K, const uint16_t* __restrict__ dY, const uint16_t* __restrict__ X,
+                                                        float* __restrict__ dW, float* __restrict__ dbias) {
+  __shared__ __attribute__((aligned(16))) uint16_t s_a[WG_SLAB][64 + 4], s_b[WG_SLAB][64 + 4];      // [t][n], [t][k]; 136-byte rows: the four
+                                                                                                    // row groups of a fragment read land on two bank sets
+  __shared__ float s_cs[4][64];
+  const int n0 = blockIdx.x * 64, k0 = blockIdx.y * 64, t0 = blockIdx.z * WG_ROWS, t1 = min(t0 + WG_ROWS, T);
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int wn = (wave >> 1) * 32, wk = (wave & 1) * 32;               // this wave's 32 x 32 quarter of the tile
+  const bool va = (N & 7) == 0 && ((uintptr_t)dY & 15) == 0, vb = (K & 7) == 0 && ((uintptr_t)X & 15) == 0;
+  wg_f32x4 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = wg_f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+  const int lr = tid >> 3, lc = (tid & 7) * 8;                         // slab loader: row lr (0..31), 8 columns from lc
+  const bool bias_job = dbias != nullptr && blockIdx.y == 0;           // the first column of tiles also sums dY's columns
+  float csum[8];                                                       // this loader's 8 columns, summed over its rows
+#pragma unroll
+  for (int j = 0; j < 8; ++j) csum[j] = 0.0f;
+  uint4 ra = wg_load8(dY, t1, N, t0 + lr, n0 + lc, va), rb = wg_load8(X, t1, K, t0 + lr, k0 + lc, vb);
+  for (int ts = t0; ts < t1; ts += WG_SLAB) {
+    __syncthreads();                                                   // the previous slab's fragments have been read
+    *(uint2*)&s_a[lr][lc] = uint2{ra.x, ra.y}; *(uint2*)&s_a[lr][lc + 4] = uint2{ra.z, ra.w};
+    *(uint2*)&s_b[lr][lc] = uint2{rb.x, rb.y}; *(uint2*)&s_b[lr][lc + 4] = uint2{rb.z, rb.w};
+    if (bias_job) {
+      const uint16_t* pv = (const uint16_t*)&ra;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) csum[j] += sq_bf2f(pv[j]);
+    }
+    __syncthreads();
+    if (ts + WG_SLAB < t1) {                                           // next slab's loads fly while this one multiplies
+      ra = wg_load8(dY, t1, N, ts + WG_SLAB + lr, n0 + lc, va);
+      rb = wg_load8(X, t1, K, ts + WG_SLAB + lr, k0 + lc, vb);
+    }
+    // fragments: lane (o = lane & 15, tg = lane >> 4) holds rows 8 tg .. 8 tg + 7 of column o
+    wg_bf16x8 fa[2], fb[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      uint16_t ta[8], tb[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        ta[j] = s_a[8 * (lane >> 4) + j][wn + 16 * h + (lane & 15)];
+        tb[j] = s_b[8 * (lane >> 4) + j][wk + 16 * h + (lane & 15)];
+      }
+      fa[h] = __builtin_bit_cast(wg_bf16x8, *(const uint4*)ta);
+      fb[h] = __builtin_bit_cast(wg_bf16x8, *(const uint4*)tb);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+  }
+  // C layout: column (k) = lane & 15, rows (n) = 4 (lane >> 4) + e
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int k = k0 + wk + 16 * j + (lane & 15);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int n = n0 + wn + 16 * i + 4 * (lane >> 4) + e;
+        if (n < N && k < K) unsafeAtomicAdd(&dW[(long)n * K + k], acc[i][j][e]);
+      }
+    }
+  if (bias_job) {
+    // the 8 loaders of a column group inside a wave (lanes with equal lane & 7), then the four waves through LDS
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float v = csum[j];
+      v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);      // the wave's 8 rows (lr bits 0..2 of this wave)
+      if ((lane >> 3) == 0) s_cs[wave][lc + j] = v;
+    }
+    __syncthreads();
+    if (tid < 64 && n0 + tid < N) unsafeAtomicAdd(&dbias[n0 + tid], s_cs[0][tid] + s_cs[1][tid] + s_cs[2][tid] + s_cs[3][tid]);
+  }
+}
+
+}  // namespace opsamd
+
+extern "C" int ops_linear_wgrad_accumulate(int T, int N, int K, const void* dY, const void* X, float* dW, float* dbias, void* stream) {
+  if (T < 1 || N < 1 || K < 1 || !dY || !X || !dW) return OPS_AMD_ERR_INVALID_ARG;
+  const dim3 grid((unsigned)((N + 63) / 64), (unsigned)((K + 63) / 64), (unsigned)((T + opsamd::WG_ROWS - 1) / opsamd::WG_ROWS));
+  hipLaunchKernelGGL(opsamd::wgrad_tn_kernel, grid, dim3(256), 0, (hipStream_t)stream, T, N, K, (const uint16_t*)dY, (const uint16_t*)X, dW, dbias);
+  return sq_check("wgrad_tn_kernel");
+}

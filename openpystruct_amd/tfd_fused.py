@@ -1,0 +1,227 @@
+"""Training-step fast path of the Transformer-Diffusion surrogate's encoder: host side of csrc/seq_block.hip.
+
+`nn.TransformerEncoder` of post-norm ReLU layers (/root/reference/OpenPyStruct_TransformerDiffusionModule_MultiCase.py:539-575) over
+sequences of 7 tokens ([CLS] + 6 load cases), bf16 autocast, training mode: per layer
+
+    in-projection | attention (one launch) | out-projection | dropout + add + LayerNorm (one launch) |
+    linear1 | ReLU + dropout (one launch) | linear2 | dropout + add + LayerNorm (one launch)
+
+with the four products through the optimiser's bf16 shadow weights (train._ShadowLinearFn) -- ~26 kernel nodes per layer and
+training step (the products' weight and bias gradients: one split-row launch each) instead of ~90 through the framework's modules (flash-attention kernels built for long sequences, layout copies,
+separate dropout / add / LayerNorm nodes and their backward pieces).  Autograd still drives the step; every block is one
+autograd.Function whose backward is one launch.  Evaluation, masks, other activations: the framework's own forward.
+"""
+from __future__ import annotations
+
+import os
+import types
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from . import _cabi
+
+ENABLED = os.environ.get("OPS_AMD_TFD_FAST_ENCODER", "1") == "1"      # A/B switch: 0 = nn.TransformerEncoder's own forward
+
+
+class _State:
+    """The dropout stream of one encoder (its call counter must outlive a captured HIP graph) and how parameter gradients leave."""
+
+    def __init__(self, device, seed: int, direct_param_grads: bool = False):
+        self.device = device
+        self.direct = bool(direct_param_grads)      # LayerNorm gamma / beta gradients ASSIGNED into their .grad (a flat buffer zeroed per step)
+        self.seed = int(seed) & 0x7FFFFFFFFFFFFFFF
+        self.counter = torch.zeros(1, dtype=torch.int64, device=device)     # advanced once per encoder pass (`advance`), read by every launch
+
+    def advance(self) -> None:
+        self.counter.add_(1)
+
+    def used(self, site: int) -> torch.Tensor:
+        """Where a forward launch leaves the counter value it drew its mask from (one per call: its backward reads it)."""
+        return torch.empty(1, dtype=torch.int64, device=self.device)
+
+
+def _check(rc: int, what: str) -> None:
+    if rc != _cabi.OK:
+        raise RuntimeError(f"{what} failed with code {rc}: {_cabi.load().ops_amd_last_error().decode()}")
+
+
+def _stream(dev):
+    return torch.cuda.current_stream(dev).cuda_stream
+
+
+class SeqAttention(torch.autograd.Function):
+    """ctx = dropout(softmax(q k^T / sqrt(dh))) v per sample and head; qkv [B * S, 3 d] bf16 (q | k | v per row)."""
+
+    @staticmethod
+    def forward(ctx, qkv, Bn, S, H, p, st: _State, site: int):
+        lib = _cabi.load()
+        qkv = qkv.contiguous()
+        d = qkv.shape[1] // 3
+        out = torch.empty((Bn * S, d), dtype=torch.bfloat16, device=qkv.device)
+        used = st.used(site)
+        with torch.cuda.device(qkv.device):
+            _check(lib.ops_seq_attention_fwd(Bn, S, H, d // H, qkv.data_ptr(), out.data_ptr(), float(p), st.seed + 7919 * site,
+                                             st.counter.data_ptr(), used.data_ptr(), _stream(qkv.device)), "ops_seq_attention_fwd")
+        ctx.save_for_backward(qkv)
+        ctx.cfg = (Bn, S, H, d, float(p), st.seed + 7919 * site, used)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _cabi.load()
+        (qkv,) = ctx.saved_tensors
+        Bn, S, H, d, p, seed, used = ctx.cfg
+        g = g.contiguous()
+        if g.dtype != torch.bfloat16:
+            g = g.to(torch.bfloat16)
+        dqkv = torch.empty_like(qkv)
+        with torch.cuda.device(qkv.device):
+            _check(lib.ops_seq_attention_bwd(Bn, S, H, d // H, qkv.data_ptr(), g.data_ptr(), dqkv.data_ptr(), p, seed, used.data_ptr(),
+                                             _stream(qkv.device)), "ops_seq_attention_bwd")
+        return dqkv, None, None, None, None, None, None
+
+
+class DropoutAddLayerNorm(torch.autograd.Function):
+    """(y32, y16) = LayerNorm(res + dropout(x)): x [T, d] bf16, res float32 or bf16.  With `st.direct` the gradients of gamma / beta
+    are added straight into their `.grad` (float32 views of a buffer the caller zeroes every step: the training loop's flat one)."""
+
+    @staticmethod
+    def forward(ctx, x, res, gamma, beta, eps, p, st: _State, site: int):
+        lib = _cabi.load()
+        x, res = x.contiguous(), res.contiguous()
+        T, d = x.shape
+        dev = x.device
+        y32 = torch.empty((T, d), dtype=torch.float32, device=dev)
+        y16 = torch.empty((T, d), dtype=torch.bfloat16, device=dev)
+        z = torch.empty((T, d), dtype=torch.float32, device=dev)
+        mean = torch.empty(T, dtype=torch.float32, device=dev)
+        rstd = torch.empty(T, dtype=torch.float32, device=dev)
+        used = st.used(site)
+        with torch.cuda.device(dev):
+            _check(lib.ops_dropout_add_layernorm_fwd(T, d, x.data_ptr(), res.data_ptr(), int(res.dtype == torch.bfloat16), gamma.data_ptr(),
+                                                     beta.data_ptr(), float(eps), float(p), st.seed + 7919 * site, st.counter.data_ptr(),
+                                                     used.data_ptr(), y32.data_ptr(), y16.data_ptr(), z.data_ptr(), mean.data_ptr(),
+                                                     rstd.data_ptr(), _stream(dev)), "ops_dropout_add_layernorm_fwd")
+        ctx.save_for_backward(z, mean, rstd, gamma, beta)
+        ctx.cfg = (float(p), st.seed + 7919 * site, used, st, site, res.dtype)
+        return y32, y16
+
+    @staticmethod
+    def backward(ctx, g32, g16):
+        lib = _cabi.load()
+        z, mean, rstd, gamma, beta = ctx.saved_tensors
+        p, seed, used, st, site, res_dtype = ctx.cfg
+        T, d = z.shape
+        dev = z.device
+        if g32 is not None:
+            g32 = g32.contiguous()
+        if g16 is not None:
+            g16 = g16.contiguous()
+            if g16.dtype != torch.bfloat16:
+                g16 = g16.to(torch.bfloat16)
+        dx = torch.empty((T, d), dtype=torch.bfloat16, device=dev)
+        dres = torch.empty((T, d), dtype=torch.float32, device=dev)
+        direct = st.direct and all(t.grad is not None and t.grad.dtype == torch.float32 and t.grad.is_contiguous() for t in (gamma, beta))
+        dg = gamma.grad if direct else torch.zeros_like(gamma)        # the launch ADDS (float atomics)
+        db = beta.grad if direct else torch.zeros_like(beta)
+        with torch.cuda.device(dev):
+            _check(lib.ops_dropout_add_layernorm_bwd(T, d, g32.data_ptr() if g32 is not None else None, g16.data_ptr() if g16 is not None else None,
+                                                     z.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(), p, seed, used.data_ptr(),
+                                                     dx.data_ptr(), dres.data_ptr(), dg.data_ptr(), db.data_ptr(), _stream(dev)),
+                   "ops_dropout_add_layernorm_bwd")
+        if res_dtype != torch.float32:
+            dres = dres.to(res_dtype)
+        return dx, dres, None if direct else dg, None if direct else db, None, None, None, None
+
+
+class ActDropout(torch.autograd.Function):
+    """dropout(LeakyReLU_slope(x)) on bf16 (slope 0: ReLU)."""
+
+    @staticmethod
+    def forward(ctx, x, slope, p, st: _State, site: int):
+        lib = _cabi.load()
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        used = st.used(site)
+        with torch.cuda.device(x.device):
+            _check(lib.ops_act_dropout_fwd(x.numel(), x.data_ptr(), y.data_ptr(), float(slope), float(p), st.seed + 7919 * site,
+                                           st.counter.data_ptr(), used.data_ptr(), _stream(x.device)), "ops_act_dropout_fwd")
+        ctx.save_for_backward(x)
+        ctx.cfg = (float(slope), float(p), st.seed + 7919 * site, used)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _cabi.load()
+        (x,) = ctx.saved_tensors
+        slope, p, seed, used = ctx.cfg
+        g = g.contiguous()
+        if g.dtype != torch.bfloat16:
+            g = g.to(torch.bfloat16)
+        dx = torch.empty_like(x)
+        with torch.cuda.device(x.device):
+            _check(lib.ops_act_dropout_bwd(x.numel(), x.data_ptr(), g.data_ptr(), dx.data_ptr(), slope, p, seed, used.data_ptr(),
+                                           _stream(x.device)), "ops_act_dropout_bwd")
+        return dx, None, None, None, None
+
+
+def _layer_ok(layer: nn.Module) -> bool:
+    if type(layer) is not nn.TransformerEncoderLayer or layer.norm_first:
+        return False
+    mha = layer.self_attn
+    relu = getattr(layer, "activation_relu_or_gelu", 0) == 1
+    d = mha.embed_dim
+    return (relu and mha.batch_first and mha._qkv_same_embed_dim and mha.in_proj_bias is not None and mha.bias_k is None and not mha.add_zero_attn
+            and d % 8 == 0 and d <= 256 and d % mha.num_heads == 0 and hasattr(mha, "_ops_in_proj") and type(layer.norm1) is nn.LayerNorm
+            and type(layer.norm2) is nn.LayerNorm and layer.norm1.elementwise_affine and layer.norm2.elementwise_affine)
+
+
+def encoder_forward(enc: nn.TransformerEncoder, src: torch.Tensor, st: _State) -> torch.Tensor:
+    """The fast path proper: src [B, S, d] float32 -> [B, S, d] float32 (training mode, S <= 8)."""
+    B, S, d = src.shape
+    T = B * S
+    st.advance()                           # fresh dropout masks for this pass (the launches only read the counter)
+    res = src.reshape(T, d)
+    x16: Optional[torch.Tensor] = None
+    for li, layer in enumerate(enc.layers):
+        mha = layer.self_attn
+        qkv = mha._ops_in_proj(res if x16 is None else x16)                                         # [T, 3 d] bf16
+        ctx = SeqAttention.apply(qkv, B, S, mha.num_heads, mha.dropout, st, 4 * li)
+        a = mha._ops_out_proj(ctx)
+        res, x16 = DropoutAddLayerNorm.apply(a, res, layer.norm1.weight, layer.norm1.bias, layer.norm1.eps, layer.dropout1.p, st, 4 * li + 1)
+        h = ActDropout.apply(layer.linear1(x16), 0.0, layer.dropout.p, st, 4 * li + 2)
+        f = layer.linear2(h)
+        res, x16 = DropoutAddLayerNorm.apply(f, res, layer.norm2.weight, layer.norm2.bias, layer.norm2.eps, layer.dropout2.p, st, 4 * li + 3)
+    out = res.reshape(B, S, d)
+    return enc.norm(out) if enc.norm is not None else out
+
+
+def patch_encoder(enc: nn.TransformerEncoder, seed: int, direct_param_grads: bool = False) -> bool:
+    """Route `enc.forward` through the fast path whenever it applies (GPU, training, bf16 autocast, no masks, short sequences);
+    anything else falls through to the framework's forward.  Needs the shadow products registered on every layer's attention
+    (train.enable_shadow_linears).  `direct_param_grads`: the caller zeroes every parameter's `.grad` before each backward pass (the
+    training loop's flat buffer), so LayerNorm gradients may be assigned there.  Returns whether the encoder qualifies at all."""
+    if not (ENABLED and type(enc) is nn.TransformerEncoder and all(_layer_ok(l) for l in enc.layers)):
+        return False
+    state = {}
+
+    def forward(self, src, mask=None, src_key_padding_mask=None, is_causal=None):
+        fast = (self.training and src.is_cuda and src.dim() == 3 and src.shape[1] <= 8 and mask is None and src_key_padding_mask is None
+                and not is_causal and torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") == torch.bfloat16
+                and src.dtype == torch.float32)
+        if not fast:
+            return nn.TransformerEncoder.forward(self, src, mask=mask, src_key_padding_mask=src_key_padding_mask, is_causal=is_causal)
+        st = state.get(src.device)
+        if st is None:
+            st = state[src.device] = _State(src.device, seed, direct_param_grads)
+        return encoder_forward(self, src, st)
+
+    enc.forward = types.MethodType(forward, enc)
+    return True
+
+
+def unpatch_encoder(enc: nn.Module) -> None:
+    if "forward" in enc.__dict__:
+        del enc.__dict__["forward"]

@@ -228,14 +228,15 @@ class _ShadowLinearFn(torch.autograd.Function):
     without its per-step kernels: weight cast, bias cast, gradient cast back and accumulate -- four per parameter."""
 
     @staticmethod
-    def forward(ctx, x, w_sh, b_sh, stash, iw, ib, anchor):
+    def forward(ctx, x, w_sh, b_sh, stash, iw, ib, anchor, w_grad=None, b_grad=None):
         # `anchor` (the layer's float32 weight Parameter) is not read: it makes autograd record the node even when x
         # needs no gradient (first layer); its own gradient slot stays None -- the gradients travel through `stash`
+        # (or, for products over thousands of rows, straight into `w_grad`, the weight's slice of the zeroed flat gradient buffer)
         xb = x if x.dtype == torch.bfloat16 else x.to(torch.bfloat16)
         x2 = xb.reshape(-1, xb.shape[-1])
         y = torch.addmm(b_sh, x2, w_sh.t()) if b_sh is not None else x2 @ w_sh.t()
         ctx.save_for_backward(x2, w_sh)
-        ctx.stash, ctx.iw, ctx.ib, ctx.xshape, ctx.xdtype = stash, iw, ib, x.shape, x.dtype
+        ctx.stash, ctx.iw, ctx.ib, ctx.xshape, ctx.xdtype, ctx.w_grad, ctx.b_grad = stash, iw, ib, x.shape, x.dtype, w_grad, b_grad
         return y.reshape(*x.shape[:-1], w_sh.shape[0])
 
     @staticmethod
@@ -244,15 +245,34 @@ class _ShadowLinearFn(torch.autograd.Function):
         g2 = gy.reshape(-1, gy.shape[-1])
         if g2.dtype != torch.bfloat16:
             g2 = g2.to(torch.bfloat16)
-        ctx.stash[ctx.iw] = g2.t() @ x2
-        if ctx.ib is not None:
-            ctx.stash[ctx.ib] = g2.sum(0)
+        if ctx.w_grad is not None and x2.shape[0] >= _SPLIT_WGRAD_ROWS:
+            # many rows, small output: the library walks all rows inside a handful of tiles (25 us for 3584 x 360 x 120) and the bias
+            # gradient is another reduction pass (11 us); the split-row kernel of csrc/seq_block.hip adds partial tiles -- and the
+            # column sums of the slabs it reads anyway -- into the float32 gradients itself
+            from . import _cabi
+            g2, x2c = g2.contiguous(), x2.contiguous()
+            fused_bias = ctx.ib is not None and ctx.b_grad is not None
+            with torch.cuda.device(g2.device):
+                rc = _cabi.load().ops_linear_wgrad_accumulate(x2c.shape[0], g2.shape[1], x2c.shape[1], g2.data_ptr(), x2c.data_ptr(),
+                                                              ctx.w_grad.data_ptr(), ctx.b_grad.data_ptr() if fused_bias else None,
+                                                              torch.cuda.current_stream(g2.device).cuda_stream)
+            if rc != 0:
+                raise RuntimeError(f"ops_linear_wgrad_accumulate failed with code {rc}")
+            if ctx.ib is not None and not fused_bias:
+                ctx.stash[ctx.ib] = g2.sum(0)
+        else:
+            ctx.stash[ctx.iw] = g2.t() @ x2
+            if ctx.ib is not None:
+                ctx.stash[ctx.ib] = g2.sum(0)
         gx = None
         if ctx.needs_input_grad[0]:
             gx = (g2 @ w_sh).reshape(ctx.xshape)
             if gx.dtype != ctx.xdtype:
                 gx = gx.to(ctx.xdtype)
-        return gx, None, None, None, None, None, None
+        return gx, None, None, None, None, None, None, None, None
+
+
+_SPLIT_WGRAD_ROWS = int(os.environ.get("OPS_AMD_SPLIT_WGRAD_ROWS", "1024"))     # products over at least this many rows (0 rows: never)
 
 
 def enable_shadow_linears(model: nn.Module, opt: "FlatClipAdam", params, flat: torch.Tensor):
@@ -264,22 +284,39 @@ def enable_shadow_linears(model: nn.Module, opt: "FlatClipAdam", params, flat: t
         offs[id(q)] = off
         off += q.numel()
     stash, dst, patched = [], [], []
+
+    def register(weight, bias):
+        """y = x W^T + b through the shadow of (weight, bias); their gradients travel through `stash` (or, for products over
+        thousands of rows, are added straight into their slices of the zeroed flat gradient buffer)."""
+        ow = offs[id(weight)]
+        w_sh = sh[ow:ow + weight.numel()].view_as(weight)
+        w_grad = flat[ow:ow + weight.numel()].view_as(weight)
+        iw = len(stash); stash.append(None); dst.append(w_grad)
+        b_sh, ib, b_grad = None, None, None
+        if bias is not None:
+            ob = offs[id(bias)]
+            b_sh = sh[ob:ob + bias.numel()]
+            b_grad = flat[ob:ob + bias.numel()]
+            ib = len(stash); stash.append(None); dst.append(b_grad)
+        return lambda x: _ShadowLinearFn.apply(x, w_sh, b_sh, stash, iw, ib, weight, w_grad, b_grad)
+
     for mod in model.modules():
+        if isinstance(mod, nn.MultiheadAttention):
+            # the attention's projections are bare Parameters / a Linear subclass that its functional forward never calls: hand the
+            # shadow products to the encoder fast path (tfd_fused.py), which is their only user
+            if mod._qkv_same_embed_dim and mod.in_proj_bias is not None and id(mod.in_proj_weight) in offs and id(mod.out_proj.weight) in offs:
+                mod._ops_in_proj = register(mod.in_proj_weight, mod.in_proj_bias)
+                mod._ops_out_proj = register(mod.out_proj.weight, mod.out_proj.bias)
+                patched.append(mod)
+            continue
         if type(mod) is not nn.Linear or id(mod.weight) not in offs:
             continue
-        ow = offs[id(mod.weight)]
-        w_sh = sh[ow:ow + mod.weight.numel()].view_as(mod.weight)
-        iw = len(stash); stash.append(None); dst.append(flat[ow:ow + mod.weight.numel()].view_as(mod.weight))
-        b_sh, ib = None, None
-        if mod.bias is not None:
-            ob = offs[id(mod.bias)]
-            b_sh = sh[ob:ob + mod.bias.numel()]
-            ib = len(stash); stash.append(None); dst.append(flat[ob:ob + mod.bias.numel()])
+        prod = register(mod.weight, mod.bias)
 
-        def fwd(self, x, w_sh=w_sh, b_sh=b_sh, iw=iw, ib=ib):
+        def fwd(self, x, prod=prod):
             if not x.is_cuda:
                 return F_linear(x, self.weight, self.bias)
-            return _ShadowLinearFn.apply(x, w_sh, b_sh, stash, iw, ib, self.weight)
+            return prod(x)
 
         mod.forward = types.MethodType(fwd, mod)
         patched.append(mod)
@@ -290,6 +327,9 @@ def disable_shadow_linears(patched) -> None:
     for mod in patched:
         if "forward" in mod.__dict__:
             del mod.__dict__["forward"]
+        for name in ("_ops_in_proj", "_ops_out_proj"):
+            if name in mod.__dict__:
+                del mod.__dict__[name]
 
 
 F_linear = torch.nn.functional.linear
@@ -383,6 +423,7 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
         q.grad = flat[off:off + q.numel()].view_as(q)
         off += q.numel()
     g_stash, g_dst, patched = [], [], []
+    fast_encoder = None
     if hasattr(model, "direct_param_grads"):   # fused tails (csrc/fused_bn.hip) write BatchNorm parameter gradients into `flat` themselves
         model.direct_param_grads = device.type == "cuda"
     torch.manual_seed(seed + 1 + rank)  # different noise / shuffles per rank
@@ -396,6 +437,10 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
         sched = None
         if _SHADOW_LINEAR and autocast_dtype == torch.bfloat16:
             g_stash, g_dst, patched = enable_shadow_linears(model, opt, params, flat)
+            if kind == "tfd" and isinstance(getattr(model, "transformer_encoder", None), nn.TransformerEncoder):
+                from . import tfd_fused          # encoder layers through csrc/seq_block.hip (attention, dropout + add + LayerNorm, ReLU + dropout)
+                if tfd_fused.patch_encoder(model.transformer_encoder, seed=seed * 7919 + 211 + rank, direct_param_grads=True):
+                    fast_encoder = model.transformer_encoder
     else:
         opt = (torch.optim.AdamW if kind == "gnn" else torch.optim.Adam)(model.parameters(), lr=cfg.learning_rate,   # GNN:394
                                                                          weight_decay=cfg.weight_decay)
@@ -475,7 +520,10 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
             loss = loss + physics.weight * physics_loss(preds.float(), pin).float()
         loss.backward()
         if g_stash:                      # the shadow-linear weight / bias gradients: one multi-tensor cast-and-copy into `flat`
-            torch._foreach_copy_(g_dst, g_stash)
+            live = [(dd, ss) for dd, ss in zip(g_dst, g_stash) if ss is not None]      # (a product nobody called this step leaves None)
+            torch._foreach_copy_([dd for dd, _ in live], [ss for _, ss in live])
+            for k in range(len(g_stash)):
+                g_stash[k] = None
         return loss.detach()
 
     def apply_update():
@@ -675,6 +723,9 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
         if no_improve >= cfg.patience:
             break
     disable_shadow_linears(patched)      # the returned model is a plain module again
+    if fast_encoder is not None:
+        from . import tfd_fused
+        tfd_fused.unpatch_encoder(fast_encoder)
     if hasattr(model, "direct_param_grads"):
         model.direct_param_grads = False
     if best_state is not None:

@@ -1,0 +1,261 @@
+"""Row-wise encoder blocks of the Transformer-Diffusion surrogate (csrc/seq_block.hip, openpystruct_amd/tfd_fused.py) against the
+framework: scaled-dot-product attention, dropout + add + LayerNorm, ReLU + dropout, and the patched nn.TransformerEncoder
+(/root/reference/OpenPyStruct_TransformerDiffusionModule_MultiCase.py:539-575).  bf16 activations: bounds are bf16 bounds."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _rel(a, b):
+    a, b = a.detach().double(), b.detach().double()
+    return float((a - b).norm()) / (float(b.norm()) + 1e-30)
+
+
+def _attention_reference(qkv, B, S, H):
+    d = qkv.shape[1] // 3
+    q, k, v = (t.reshape(B, S, H, d // H).permute(0, 2, 1, 3) for t in qkv.float().split(d, dim=1))
+    o = torch.softmax(q @ k.transpose(-1, -2) / (d // H) ** 0.5, dim=-1) @ v
+    return o.permute(0, 2, 1, 3).reshape(B * S, d)
+
+
+@pytest.mark.parametrize("B,S,H,dh", [(37, 7, 8, 15), (512, 7, 8, 15), (5, 8, 4, 32), (3, 1, 2, 8)])
+def test_attention_matches_softmax_attention(B, S, H, dh):
+    from openpystruct_amd import tfd_fused as TF
+    g = torch.Generator().manual_seed(B + S)
+    d = H * dh
+    qkv = (1.5 * torch.randn(B * S, 3 * d, generator=g)).to(torch.bfloat16).to(DEV).requires_grad_()
+    go = torch.randn(B * S, d, generator=g).to(torch.bfloat16).to(DEV)
+    st = TF._State(torch.device(DEV), 1)
+    out = TF.SeqAttention.apply(qkv, B, S, H, 0.0, st, 0)
+    out.backward(go)
+    ref_in = qkv.detach().clone().requires_grad_()
+    ref = _attention_reference(ref_in, B, S, H)
+    ref.backward(go.float())
+    assert _rel(out, ref) < 6e-3
+    assert _rel(qkv.grad, ref_in.grad) < 1.5e-2
+
+
+def test_attention_dropout_is_consistent_between_the_passes():
+    """With dropout the map v -> ctx is linear for a fixed mask: <g, ctx(v)> = <dv(g), v> (the backward launch regenerates the mask of the
+    forward launch), the kept fraction is 1 - p, and a replay draws another mask."""
+    from openpystruct_amd import tfd_fused as TF
+    B, S, H, dh, p = 64, 7, 8, 15, 0.3
+    d = H * dh
+    g = torch.Generator().manual_seed(3)
+    qkv = torch.randn(B * S, 3 * d, generator=g).to(torch.bfloat16).to(DEV)
+    qkv[:, :2 * d] = 0                                                  # uniform attention: every probability 1 / S
+    qkv[:, 2 * d:] = 1                                                  # v = 1: ctx = sum of the kept, rescaled probabilities
+    st = TF._State(torch.device(DEV), 5)
+    o1 = TF.SeqAttention.apply(qkv, B, S, H, p, st, 0).float()
+    st.advance()
+    o2 = TF.SeqAttention.apply(qkv, B, S, H, p, st, 0).float()
+    kept = o1[:, ::dh] * (1 - p) * S                                    # number of kept keys per (row, head)
+    assert abs(float(kept.mean()) / S - (1 - p)) < 0.02 and float((o1 != o2).float().mean()) > 0.3
+    x = torch.randn(B * S, 3 * d, generator=g).to(torch.bfloat16).to(DEV).requires_grad_()
+    go = torch.randn(B * S, d, generator=g).to(torch.bfloat16).to(DEV)
+    out = TF.SeqAttention.apply(x, B, S, H, p, st, 0)
+    out.backward(go)
+    lhs = float((go.double() * out.detach().double()).sum())
+    rhs = float((x.grad[:, 2 * d:].double() * x.detach()[:, 2 * d:].double()).sum())
+    assert abs(lhs - rhs) < 2e-2 * (abs(lhs) + float(go.double().norm() * out.detach().double().norm()) * 1e-2)
+
+
+@pytest.mark.parametrize("T,d,res_bf16", [(3584, 120, False), (1027, 256, False), (77, 8, True)])
+def test_dropout_add_layernorm_matches_the_modules(T, d, res_bf16):
+    from openpystruct_amd import tfd_fused as TF
+    g = torch.Generator().manual_seed(T)
+    x = torch.randn(T, d, generator=g).to(torch.bfloat16).to(DEV).requires_grad_()
+    res = (2 * torch.randn(T, d, generator=g) + 0.5).to(DEV)
+    if res_bf16:
+        res = res.to(torch.bfloat16)
+    res.requires_grad_()
+    ln = nn.LayerNorm(d).to(DEV)
+    with torch.no_grad():
+        ln.weight.copy_(1 + 0.3 * torch.randn(d, generator=g)); ln.bias.copy_(0.2 * torch.randn(d, generator=g))
+    g32 = torch.randn(T, d, generator=g).to(DEV)
+    g16 = torch.randn(T, d, generator=g).to(torch.bfloat16).to(DEV)
+    st = TF._State(torch.device(DEV), 2)
+    y32, y16 = TF.DropoutAddLayerNorm.apply(x, res, ln.weight, ln.bias, ln.eps, 0.0, st, 1)
+    torch.autograd.backward([y32, y16], [g32, g16])
+    xr, rr = x.detach().float().requires_grad_(), res.detach().float().requires_grad_()
+    lr = copy.deepcopy(ln)
+    lr.weight.grad = lr.bias.grad = None
+    yr = lr(rr + xr)
+    yr.backward(g32 + g16.float())
+    assert _rel(y32, yr) < 1e-5 and _rel(y16.float(), yr) < 4e-3
+    assert _rel(x.grad.float(), xr.grad) < 4e-3 and _rel(res.grad.float(), rr.grad) < (4e-3 if res_bf16 else 1e-5)
+    assert _rel(ln.weight.grad, lr.weight.grad) < 1e-4 and _rel(ln.bias.grad, lr.bias.grad) < 1e-4
+    # only one of the two gradients present
+    ln.weight.grad = ln.bias.grad = None
+    x.grad = res.grad = None
+    y32, y16 = TF.DropoutAddLayerNorm.apply(x, res, ln.weight, ln.bias, ln.eps, 0.0, st, 1)
+    y16.backward(g16)
+    xr.grad = rr.grad = lr.weight.grad = lr.bias.grad = None
+    lr(rr + xr).backward(g16.float())
+    assert _rel(x.grad.float(), xr.grad) < 4e-3 and _rel(ln.weight.grad, lr.weight.grad) < 1e-4
+
+
+def test_dropout_add_layernorm_mask_is_shared_by_both_passes_and_redrawn_per_call():
+    from openpystruct_amd import tfd_fused as TF
+    T, d, p = 512, 120, 0.25
+    g = torch.Generator().manual_seed(9)
+    x = (torch.randn(T, d, generator=g).abs() + 0.5).to(torch.bfloat16).to(DEV).requires_grad_()      # > 0: a dropped entry is its row's minimum
+    res = torch.zeros(T, d, device=DEV)
+    ln = nn.LayerNorm(d).to(DEV)
+    st = TF._State(torch.device(DEV), 4)
+    masks = []
+    for _ in range(2):
+        x.grad = None
+        st.advance()
+        y32, _ = TF.DropoutAddLayerNorm.apply(x, res, ln.weight, ln.bias, ln.eps, p, st, 3)
+        y32.backward(torch.randn(T, d, generator=g).to(DEV))
+        z = (y32.detach() - ln.bias) / ln.weight                       # = (z - mean) rstd: dropped entries are the row's minimum (x > 0)
+        keep_fwd = z > z.min(dim=1, keepdim=True).values + 1e-6
+        keep_bwd = x.grad != 0
+        assert float((keep_fwd != keep_bwd).float().mean()) < 2e-3     # (a kept gradient can round to exactly zero)
+        assert abs(float(keep_bwd.float().mean()) - (1 - p)) < 0.02
+        masks.append(keep_bwd)
+    assert 0.2 < float((masks[0] != masks[1]).float().mean()) < 0.6
+
+
+def test_act_dropout():
+    from openpystruct_amd import tfd_fused as TF
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(3584, 256, generator=g).to(torch.bfloat16).to(DEV).requires_grad_()
+    go = torch.randn(3584, 256, generator=g).to(torch.bfloat16).to(DEV)
+    st = TF._State(torch.device(DEV), 6)
+    y = TF.ActDropout.apply(x, 0.0, 0.0, st, 2)
+    y.backward(go)
+    assert torch.equal(y, torch.relu(x.detach())) and torch.equal(x.grad, torch.where(x.detach() > 0, go, torch.zeros_like(go)))
+    x.grad = None
+    y = TF.ActDropout.apply(x, 0.0, 0.1, st, 2)
+    y.backward(go)
+    pos = x.detach() > 0
+    kept = (y != 0)[pos]
+    assert abs(float(kept.float().mean()) - 0.9) < 0.01
+    assert torch.equal((x.grad != 0)[pos & (go != 0)], (y != 0)[pos & (go != 0)])
+    assert _rel(y[y != 0].float(), (x.detach()[y != 0].float() / 0.9)) < 4e-3
+
+
+def _encoder(d=120, H=8, ff=256, layers=2, p=0.0, seed=0):
+    torch.manual_seed(seed)
+    layer = nn.TransformerEncoderLayer(d_model=d, nhead=H, dim_feedforward=ff, dropout=p, activation="relu", batch_first=True)
+    enc = nn.TransformerEncoder(layer, num_layers=layers)
+    with torch.no_grad():
+        for n, q in enc.named_parameters():
+            if "norm" in n and "weight" in n:
+                q.add_(0.2 * torch.randn_like(q))
+            elif "bias" in n:
+                q.add_(0.1 * torch.randn_like(q))
+    return enc.to(DEV)
+
+
+def test_patched_encoder_matches_the_framework_encoder_under_autocast():
+    from openpystruct_amd import tfd_fused as TF, train
+    enc = _encoder()
+    ref = copy.deepcopy(enc)
+    params = list(enc.parameters())
+    flat = torch.zeros(sum(q.numel() for q in params), device=DEV)
+    off = 0
+    for q in params:
+        q.grad = flat[off:off + q.numel()].view_as(q)
+        off += q.numel()
+    opt = train.FlatClipAdam(params, flat, 1e-3)
+    stash, dst, patched = train.enable_shadow_linears(enc, opt, params, flat)
+    assert TF.patch_encoder(enc, seed=11, direct_param_grads=True)
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(96, 7, 120, generator=g).to(DEV).requires_grad_()
+    w = torch.randn(96, 7, 120, generator=g).to(DEV)
+    enc.train(); ref.train()
+    flat.zero_()
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        out = enc(x)
+        (out * w).sum().backward()
+    live = [(dd, ss) for dd, ss in zip(dst, stash) if ss is not None]
+    assert len(live) == len(dst)                                        # every registered product ran (672 rows: the library path)
+    torch._foreach_copy_([a for a, _ in live], [b for _, b in live])
+    xr = x.detach().clone().requires_grad_()
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        outr = ref(xr)
+        (outr * w).sum().backward()
+    assert out.dtype == torch.float32 and _rel(out, outr) < 1e-2
+    assert _rel(x.grad, xr.grad) < 3e-2
+    for (n, q), (_, qr) in zip(enc.named_parameters(), ref.named_parameters()):
+        assert _rel(q.grad, qr.grad) < 4e-2, n
+    # evaluation keeps the framework's forward
+    enc.eval(); ref.eval()
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        assert _rel(enc(x), ref(x)) < 1e-2
+    train.disable_shadow_linears(patched)
+    TF.unpatch_encoder(enc)
+    assert "forward" not in enc.__dict__ and not hasattr(enc.layers[0].self_attn, "_ops_in_proj")
+
+
+def test_patched_encoder_with_thousands_of_rows_takes_the_split_row_gradient_path():
+    """Same comparison at the training batch (512 x 7 tokens): weight and bias gradients through ops_linear_wgrad_accumulate."""
+    from openpystruct_amd import tfd_fused as TF, train
+    enc = _encoder(seed=3)
+    ref = copy.deepcopy(enc)
+    params = list(enc.parameters())
+    flat = torch.zeros(sum(q.numel() for q in params), device=DEV)
+    off = 0
+    for q in params:
+        q.grad = flat[off:off + q.numel()].view_as(q)
+        off += q.numel()
+    opt = train.FlatClipAdam(params, flat, 1e-3)
+    stash, dst, patched = train.enable_shadow_linears(enc, opt, params, flat)
+    assert TF.patch_encoder(enc, seed=12, direct_param_grads=True)
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(512, 7, 120, generator=g).to(DEV).requires_grad_()
+    w = torch.randn(512, 7, 120, generator=g).to(DEV) / 512
+    enc.train(); ref.train()
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        (enc(x) * w).sum().backward()
+    assert all(ss is None for ss in stash)                              # nothing went through the stash
+    xr = x.detach().clone().requires_grad_()
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        (ref(xr) * w).sum().backward()
+    assert _rel(x.grad, xr.grad) < 3e-2
+    for (n, q), (_, qr) in zip(enc.named_parameters(), ref.named_parameters()):
+        assert _rel(q.grad, qr.grad) < 4e-2, n
+    train.disable_shadow_linears(patched)
+    TF.unpatch_encoder(enc)
+
+
+def test_tfd_training_with_the_fast_encoder_follows_the_framework_path(monkeypatch):
+    """Six epochs of the TFD loop (dropout 0.1, diffusion noise on) with the encoder blocks vs the framework's encoder: two draws of the
+    same stochastic process -- final training losses within 8 % of each other, both decreasing (800 groups: two steps per epoch)."""
+    from openpystruct_amd import dataprep, sizing, tfd_fused, train
+    rec = sizing.generate_dataset(6000, sizing.SizingConfig(max_e=60), "cuda")
+    d = dataprep.prepare(rec, kind="tfd", device="cuda")
+    hist = {}
+    for fast in (True, False):
+        monkeypatch.setattr(tfd_fused, "ENABLED", fast)
+        out = train.train_surrogate("tfd", d, device="cuda", max_epochs=6, seed=1)
+        hist[fast] = out["history"]["train"]
+        assert all(np.isfinite(hist[fast])) and hist[fast][-1] < 0.95 * hist[fast][0]
+    assert abs(hist[True][-1] - hist[False][-1]) < 0.08 * hist[False][-1], hist
+
+
+@pytest.mark.parametrize("T,N,K", [(3584, 360, 120), (3584, 120, 256), (1000, 302, 175), (257, 7, 33)])
+def test_split_row_weight_gradient(T, N, K):
+    from openpystruct_amd import _cabi
+    lib = _cabi.load()
+    g = torch.Generator().manual_seed(T + N)
+    dY = torch.randn(T, N, generator=g).to(torch.bfloat16).to(DEV)
+    X = torch.randn(T, K, generator=g).to(torch.bfloat16).to(DEV)
+    dW = torch.full((N, K), 0.5, device=DEV)                            # accumulates on top of what is there
+    db = torch.full((N,), -0.25, device=DEV)
+    assert lib.ops_linear_wgrad_accumulate(T, N, K, dY.data_ptr(), X.data_ptr(), dW.data_ptr(), db.data_ptr(), None) == _cabi.OK
+    torch.cuda.synchronize()
+    assert _rel(dW, dY.double().t() @ X.double() + 0.5) < 1e-5
+    assert _rel(db, dY.double().sum(0) - 0.25) < 1e-5
+    dW.zero_()
+    assert lib.ops_linear_wgrad_accumulate(T, N, K, dY.data_ptr(), X.data_ptr(), dW.data_ptr(), None, None) == _cabi.OK
+    assert _rel(dW, dY.double().t() @ X.double()) < 1e-5
