@@ -58,37 +58,75 @@ struct SaArgs {
   float p_drop; unsigned long long seed; unsigned long long* counter; unsigned long long* used_call;
 };
 
-// global -> LDS copy of n16 16-byte pieces by the whole workgroup, eight independent loads in flight per thread
-__device__ __forceinline__ void sa_stage(uint4* __restrict__ dst, const uint4* __restrict__ src, int n16) {
-  for (int e0 = threadIdx.x; e0 < n16; e0 += 8 * SA_THREADS) {
-    uint4 t[8];
+// Head vectors live in LDS padded to DHP (16 or 32) elements, 16-byte aligned: a thread reads a whole q / k / v / dO head vector
+// with one or two ds_read_b128 instead of dh two-byte reads (the 7-token problem is LDS-instruction bound otherwise: 225 reads per
+// thread forward, 650 backward, vs 30 / 74).  LDS image of a row: [q | k | v][H][DHP] (and [H][DHP] for dO rows).
+
+// stage `rows` rows of `nseg` head segments of `dh` elements each (global: contiguous rows of nseg * dh) into the padded image
+template <int DHP>
+__device__ __forceinline__ void sa_stage_padded(uint16_t* __restrict__ dst, const uint16_t* __restrict__ src, int rows, int nseg, int dh) {
+  const int rowlen = nseg * dh, n16 = rows * rowlen / 8;              // rowlen % 8 == 0 (checked on the host)
+  for (int e0 = threadIdx.x; e0 < n16; e0 += 4 * SA_THREADS) {
+    uint4 t[4];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) { const int e = e0 + k * SA_THREADS; t[k] = e < n16 ? src[e] : uint4{0u, 0u, 0u, 0u}; }
+    for (int k = 0; k < 4; ++k) { const int e = e0 + k * SA_THREADS; t[k] = e < n16 ? ((const uint4*)src)[e] : uint4{0u, 0u, 0u, 0u}; }
 #pragma unroll
-    for (int k = 0; k < 8; ++k) { const int e = e0 + k * SA_THREADS; if (e < n16) dst[e] = t[k]; }
+    for (int k = 0; k < 4; ++k) {
+      const int e = e0 + k * SA_THREADS;
+      if (e < n16) {
+        const uint16_t* v = (const uint16_t*)&t[k];
+        const int r = (e * 8) / rowlen, c0 = e * 8 - r * rowlen;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int c = c0 + j, seg = c / dh, tt = c - seg * dh;
+          dst[(r * nseg + seg) * DHP + tt] = v[j];
+        }
+      }
+    }
   }
 }
-
-// this thread's attention row: probabilities p[j] (after softmax) and the keep-scaled ones pk[j]
-__device__ __forceinline__ void sa_row(const uint16_t* __restrict__ s_qkv, int d3, int d, int S, int dh, int row0, int i, int h, float scale,
-                                       float p_drop, uint64_t seed, uint64_t call, uint64_t eidx0, float (&p)[SA_MAXS], float (&pk)[SA_MAXS]) {
-  float sc[SA_MAXS];
+// zero the padding lanes dh .. DHP - 1 of every head vector (once per launch; they take part in the vector dot products)
+template <int DHP>
+__device__ __forceinline__ void sa_zero_pad(uint16_t* __restrict__ dst, int nvec, int dh) {
+  const int np = DHP - dh;
+  for (int e = threadIdx.x; e < nvec * np; e += SA_THREADS) dst[(e / np) * DHP + dh + e % np] = 0;
+}
+template <int DHP>
+__device__ __forceinline__ void sa_ldvec(const uint16_t* __restrict__ p, float (&v)[DHP]) {
 #pragma unroll
-  for (int j = 0; j < SA_MAXS; ++j) sc[j] = 0.0f;
-  const uint16_t* q = s_qkv + (row0 + i) * d3 + h * dh;
-  for (int t = 0; t < dh; ++t) {
-    const float qt = sq_bf2f(q[t]);
+  for (int k = 0; k < DHP / 8; ++k) {
+    const uint4 u = ((const uint4*)p)[k];
+    const uint32_t w[4] = {u.x, u.y, u.z, u.w};
 #pragma unroll
-    for (int j = 0; j < SA_MAXS; ++j)
-      if (j < S) sc[j] = __builtin_fmaf(qt, sq_bf2f(s_qkv[(row0 + j) * d3 + d + h * dh + t]), sc[j]);
+    for (int j = 0; j < 4; ++j) { v[8 * k + 2 * j] = __uint_as_float(w[j] << 16); v[8 * k + 2 * j + 1] = __uint_as_float(w[j] & 0xffff0000u); }
   }
+}
+template <int DHP>
+__device__ __forceinline__ float sa_dot(const float (&a)[DHP], const float (&b)[DHP]) {
+  float s = 0.0f;
+#pragma unroll
+  for (int t = 0; t < DHP; ++t) s = __builtin_fmaf(a[t], b[t], s);
+  return s;
+}
+
+// this thread's attention row: probabilities p[j] (after softmax) and the keep-scaled ones pk[j]; kbase: the row block's k vectors
+template <int DHP>
+__device__ __forceinline__ void sa_row(const float (&q)[DHP], const uint16_t* __restrict__ krow0, int rowstride, int S, float scale, float p_drop,
+                                       uint64_t seed, uint64_t call, uint64_t eidx0, float (&p)[SA_MAXS], float (&pk)[SA_MAXS]) {
   float mx = -3.0e38f;
 #pragma unroll
-  for (int j = 0; j < SA_MAXS; ++j)
-    if (j < S) { sc[j] *= scale; mx = fmaxf(mx, sc[j]); }
+  for (int j = 0; j < SA_MAXS; ++j) {
+    p[j] = -3.0e38f;
+    if (j < S) {
+      float kv[DHP];
+      sa_ldvec<DHP>(krow0 + j * rowstride, kv);
+      p[j] = sa_dot<DHP>(q, kv) * scale;
+      mx = fmaxf(mx, p[j]);
+    }
+  }
   float den = 0.0f;
 #pragma unroll
-  for (int j = 0; j < SA_MAXS; ++j) { p[j] = j < S ? __expf(sc[j] - mx) : 0.0f; den += p[j]; }
+  for (int j = 0; j < SA_MAXS; ++j) { p[j] = j < S ? __expf(p[j] - mx) : 0.0f; den += p[j]; }
   const float inv = 1.0f / den, ks = p_drop > 0.0f ? 1.0f / (1.0f - p_drop) : 1.0f;
 #pragma unroll
   for (int j = 0; j < SA_MAXS; ++j) {
@@ -98,59 +136,73 @@ __device__ __forceinline__ void sa_row(const uint16_t* __restrict__ s_qkv, int d
   }
 }
 
+template <int DHP>
 __global__ __launch_bounds__(SA_THREADS) void seq_attention_fwd_kernel(const SaArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint16_t s_mem[];
-  const int d = a.H * a.dh, d3 = 3 * d, S = a.S;
+  const int H = a.H, dh = a.dh, d = H * dh, S = a.S;
   const int b0 = blockIdx.x * a.NB, nb = min(a.NB, a.Bn - b0), rows = nb * S;
+  const int rs = 3 * H * DHP;                                         // LDS row: [q | k | v][H][DHP]
   uint16_t* s_qkv = s_mem;
-  // stage: rows x 3d bf16, contiguous in global memory
-  sa_stage((uint4*)s_qkv, (const uint4*)(a.qkv + (long)b0 * S * d3), rows * d3 / 8);      // d3 % 8 == 0 (checked on the host)
+  sa_zero_pad<DHP>(s_qkv, a.NB * S * 3 * H, dh);
+  sa_stage_padded<DHP>(s_qkv, a.qkv + (long)b0 * S * 3 * d, rows, 3 * H, dh);
   const unsigned long long call = a.p_drop > 0.0f ? *a.counter : 0ull;
   __syncthreads();
-  const int tid = threadIdx.x, i = tid % S, h = (tid / S) % a.H, bl = tid / (S * a.H);
+  const int tid = threadIdx.x, i = tid % S, h = (tid / S) % H, bl = tid / (S * H);
   if (bl < nb) {
-    const float scale = rsqrtf((float)a.dh);
-    const uint64_t e0 = (((uint64_t)(b0 + bl) * a.H + h) * S + i) * S;
-    float p[SA_MAXS], pk[SA_MAXS];
-    sa_row(s_qkv, d3, d, S, a.dh, bl * S, i, h, scale, a.p_drop, a.seed, call, e0, p, pk);
-    uint16_t* out = a.ctx + ((long)(b0 + bl) * S + i) * d + h * a.dh;
-    for (int t = 0; t < a.dh; ++t) {
-      float o = 0.0f;
+    const float scale = rsqrtf((float)dh);
+    const uint64_t e0 = (((uint64_t)(b0 + bl) * H + h) * S + i) * S;
+    float q[DHP], p[SA_MAXS], pk[SA_MAXS], o[DHP];
+    sa_ldvec<DHP>(s_qkv + (bl * S + i) * rs + h * DHP, q);
+    sa_row<DHP>(q, s_qkv + (bl * S) * rs + (H + h) * DHP, rs, S, scale, a.p_drop, a.seed, call, e0, p, pk);
 #pragma unroll
-      for (int j = 0; j < SA_MAXS; ++j)
-        if (j < S) o = __builtin_fmaf(pk[j], sq_bf2f(s_qkv[(bl * S + j) * d3 + 2 * d + h * a.dh + t]), o);
-      out[t] = sq_f2bf(o);
-    }
+    for (int t = 0; t < DHP; ++t) o[t] = 0.0f;
+#pragma unroll
+    for (int j = 0; j < SA_MAXS; ++j)
+      if (j < S) {
+        float vv[DHP];
+        sa_ldvec<DHP>(s_qkv + (bl * S + j) * rs + (2 * H + h) * DHP, vv);
+#pragma unroll
+        for (int t = 0; t < DHP; ++t) o[t] = __builtin_fmaf(pk[j], vv[t], o[t]);
+      }
+    uint16_t* out = a.ctx + ((long)(b0 + bl) * S + i) * d + h * dh;
+#pragma unroll
+    for (int t = 0; t < DHP; ++t)
+      if (t < dh) out[t] = sq_f2bf(o[t]);
   }
   if (blockIdx.x == 0 && threadIdx.x == 0 && a.used_call) *a.used_call = call;
 }
 
+template <int DHP>
 __global__ __launch_bounds__(SA_THREADS) void seq_attention_bwd_kernel(const SaArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint16_t s_mem[];
-  const int d = a.H * a.dh, d3 = 3 * d, S = a.S;
+  const int H = a.H, dh = a.dh, d = H * dh, S = a.S;
   const int b0 = blockIdx.x * a.NB, nb = min(a.NB, a.Bn - b0), rows = nb * S;
-  uint16_t* s_qkv = s_mem;                                       // [NB*S][3d]
-  uint16_t* s_do = s_qkv + a.NB * S * d3;                        // [NB*S][d]
-  float* s_ds = (float*)(s_do + a.NB * S * d);                   // [NB][H][S][S]  scale * dS
-  float* s_pk = s_ds + a.NB * a.H * S * S;                       // [NB][H][S][S]  keep-scaled probabilities
-  sa_stage((uint4*)s_qkv, (const uint4*)(a.qkv + (long)b0 * S * d3), rows * d3 / 8);
-  sa_stage((uint4*)s_do, (const uint4*)(a.dctx + (long)b0 * S * d), rows * d / 8);
+  const int rs = 3 * H * DHP, rso = H * DHP;
+  uint16_t* s_qkv = s_mem;                                       // [NB*S][3][H][DHP]
+  uint16_t* s_do = s_qkv + a.NB * S * rs;                        // [NB*S][H][DHP]
+  float* s_ds = (float*)(s_do + a.NB * S * rso);                 // [NB][H][S][S]  scale * dS
+  float* s_pk = s_ds + a.NB * H * S * S;                         // [NB][H][S][S]  keep-scaled probabilities
+  sa_zero_pad<DHP>(s_qkv, a.NB * S * 4 * H, dh);                 // (s_do follows s_qkv: one run of head vectors)
+  sa_stage_padded<DHP>(s_qkv, a.qkv + (long)b0 * S * 3 * d, rows, 3 * H, dh);
+  sa_stage_padded<DHP>(s_do, a.dctx + (long)b0 * S * d, rows, H, dh);
   const unsigned long long call = a.p_drop > 0.0f ? *a.used_call : 0ull;
   __syncthreads();
-  const int tid = threadIdx.x, i = tid % S, h = (tid / S) % a.H, bl = tid / (S * a.H);
-  const float scale = rsqrtf((float)a.dh), ks = a.p_drop > 0.0f ? 1.0f / (1.0f - a.p_drop) : 1.0f;
+  const int tid = threadIdx.x, i = tid % S, h = (tid / S) % H, bl = tid / (S * H);
+  const float scale = rsqrtf((float)dh), ks = a.p_drop > 0.0f ? 1.0f / (1.0f - a.p_drop) : 1.0f;
   if (bl < nb) {
-    const uint64_t e0 = (((uint64_t)(b0 + bl) * a.H + h) * S + i) * S;
-    float p[SA_MAXS], pk[SA_MAXS], dp[SA_MAXS];
-    sa_row(s_qkv, d3, d, S, a.dh, bl * S, i, h, scale, a.p_drop, a.seed, call, e0, p, pk);
+    const uint64_t e0 = (((uint64_t)(b0 + bl) * H + h) * S + i) * S;
+    float q[DHP], go[DHP], p[SA_MAXS], pk[SA_MAXS], dp[SA_MAXS], ds[SA_MAXS];
+    sa_ldvec<DHP>(s_qkv + (bl * S + i) * rs + h * DHP, q);
+    sa_ldvec<DHP>(s_do + (bl * S + i) * rso + h * DHP, go);
+    sa_row<DHP>(q, s_qkv + (bl * S) * rs + (H + h) * DHP, rs, S, scale, a.p_drop, a.seed, call, e0, p, pk);
 #pragma unroll
-    for (int j = 0; j < SA_MAXS; ++j) dp[j] = 0.0f;
-    const uint16_t* go = s_do + (bl * S + i) * d + h * a.dh;
-    for (int t = 0; t < a.dh; ++t) {
-      const float g = sq_bf2f(go[t]);
-#pragma unroll
-      for (int j = 0; j < SA_MAXS; ++j)
-        if (j < S) dp[j] = __builtin_fmaf(g, sq_bf2f(s_qkv[(bl * S + j) * d3 + 2 * d + h * a.dh + t]), dp[j]);
+    for (int j = 0; j < SA_MAXS; ++j) {
+      dp[j] = 0.0f;
+      if (j < S) {
+        float vv[DHP];
+        sa_ldvec<DHP>(s_qkv + (bl * S + j) * rs + (2 * H + h) * DHP, vv);
+        dp[j] = sa_dot<DHP>(go, vv);
+      }
     }
     // through the dropout (dP = keep / (1 - p) dP~) and the softmax (dS = P (dP - sum_k dP_k P_k))
     float D = 0.0f;
@@ -159,47 +211,48 @@ __global__ __launch_bounds__(SA_THREADS) void seq_attention_bwd_kernel(const SaA
       dp[j] = pk[j] != 0.0f ? dp[j] * ks : (a.p_drop > 0.0f ? 0.0f : dp[j]);
       D = __builtin_fmaf(dp[j], p[j], D);
     }
-    float ds[SA_MAXS];
+    float dq[DHP];
+#pragma unroll
+    for (int t = 0; t < DHP; ++t) dq[t] = 0.0f;
 #pragma unroll
     for (int j = 0; j < SA_MAXS; ++j) {
       ds[j] = j < S ? p[j] * (dp[j] - D) * scale : 0.0f;
       if (j < S) {
-        s_ds[((bl * a.H + h) * S + i) * S + j] = ds[j];
-        s_pk[((bl * a.H + h) * S + i) * S + j] = pk[j];
+        s_ds[((bl * H + h) * S + i) * S + j] = ds[j];
+        s_pk[((bl * H + h) * S + i) * S + j] = pk[j];
+        float kv[DHP];
+        sa_ldvec<DHP>(s_qkv + (bl * S + j) * rs + (H + h) * DHP, kv);
+#pragma unroll
+        for (int t = 0; t < DHP; ++t) dq[t] = __builtin_fmaf(ds[j], kv[t], dq[t]);
       }
     }
-    uint16_t* dq = a.dqkv + ((long)(b0 + bl) * S + i) * d3 + h * a.dh;
-    for (int t = 0; t < a.dh; ++t) {
-      float o = 0.0f;
+    uint16_t* dqo = a.dqkv + ((long)(b0 + bl) * S + i) * 3 * d + h * dh;
 #pragma unroll
-      for (int j = 0; j < SA_MAXS; ++j)
-        if (j < S) o = __builtin_fmaf(ds[j], sq_bf2f(s_qkv[(bl * S + j) * d3 + d + h * a.dh + t]), o);
-      dq[t] = sq_f2bf(o);
-    }
+    for (int t = 0; t < DHP; ++t)
+      if (t < dh) dqo[t] = sq_f2bf(dq[t]);
   }
   __syncthreads();
   if (bl < nb) {
     // this thread's token as KEY / VALUE j = i: dk_j = sum_i dS_ij q_i, dv_j = sum_i P~_ij dO_i
     const int j = i;
-    float wds[SA_MAXS], wpk[SA_MAXS];
+    float dk[DHP], dv[DHP];
 #pragma unroll
-    for (int ii = 0; ii < SA_MAXS; ++ii) {
-      wds[ii] = ii < S ? s_ds[((bl * a.H + h) * S + ii) * S + j] : 0.0f;
-      wpk[ii] = ii < S ? s_pk[((bl * a.H + h) * S + ii) * S + j] : 0.0f;
-    }
-    uint16_t* dk = a.dqkv + ((long)(b0 + bl) * S + j) * d3 + d + h * a.dh;
-    uint16_t* dv = dk + d;
-    for (int t = 0; t < a.dh; ++t) {
-      float ok = 0.0f, ov = 0.0f;
+    for (int t = 0; t < DHP; ++t) { dk[t] = 0.0f; dv[t] = 0.0f; }
 #pragma unroll
-      for (int ii = 0; ii < SA_MAXS; ++ii)
-        if (ii < S) {
-          ok = __builtin_fmaf(wds[ii], sq_bf2f(s_qkv[(bl * S + ii) * d3 + h * a.dh + t]), ok);
-          ov = __builtin_fmaf(wpk[ii], sq_bf2f(s_do[(bl * S + ii) * d + h * a.dh + t]), ov);
-        }
-      dk[t] = sq_f2bf(ok);
-      dv[t] = sq_f2bf(ov);
-    }
+    for (int ii = 0; ii < SA_MAXS; ++ii)
+      if (ii < S) {
+        const float wds = s_ds[((bl * H + h) * S + ii) * S + j], wpk = s_pk[((bl * H + h) * S + ii) * S + j];
+        float qv[DHP], gv[DHP];
+        sa_ldvec<DHP>(s_qkv + (bl * S + ii) * rs + h * DHP, qv);
+        sa_ldvec<DHP>(s_do + (bl * S + ii) * rso + h * DHP, gv);
+#pragma unroll
+        for (int t = 0; t < DHP; ++t) { dk[t] = __builtin_fmaf(wds, qv[t], dk[t]); dv[t] = __builtin_fmaf(wpk, gv[t], dv[t]); }
+      }
+    uint16_t* dko = a.dqkv + ((long)(b0 + bl) * S + j) * 3 * d + d + h * dh;
+    uint16_t* dvo = dko + d;
+#pragma unroll
+    for (int t = 0; t < DHP; ++t)
+      if (t < dh) { dko[t] = sq_f2bf(dk[t]); dvo[t] = sq_f2bf(dv[t]); }
   }
 }
 
@@ -406,13 +459,15 @@ extern "C" int ops_seq_attention_fwd(int Bn, int S, int H, int dh, const void* q
                                      unsigned long long* counter, unsigned long long* used_call, void* stream) {
   if (Bn < 1 || S < 1 || H < 1 || dh < 1 || !qkv || !ctx || p_drop < 0.0f || p_drop >= 1.0f || (p_drop > 0.0f && (!counter || !used_call)))
     return OPS_AMD_ERR_INVALID_ARG;
-  const int d = H * dh;
-  if (S > SA_MAXS || S * H > SA_THREADS) return OPS_AMD_ERR_UNSUPPORTED;
-  const int NB = sa_samples_per_wg(S, H, (size_t)S * 3 * d * 2);
+  const int d = H * dh, DHP = dh <= 16 ? 16 : 32;
+  if (S > SA_MAXS || S * H > SA_THREADS || dh > 32) return OPS_AMD_ERR_UNSUPPORTED;
+  const int NB = sa_samples_per_wg(S, H, (size_t)S * 3 * H * DHP * 2);
   if (NB < 1 || (3 * d) % 8 || ((uintptr_t)qkv & 15)) return OPS_AMD_ERR_UNSUPPORTED;
-  const size_t lds = (size_t)NB * S * 3 * d * 2;
+  const size_t lds = (size_t)NB * S * 3 * H * DHP * 2;
   const SaArgs a{Bn, S, H, dh, NB, (const uint16_t*)qkv, nullptr, (uint16_t*)ctx, nullptr, p_drop, seed, counter, used_call};
-  hipLaunchKernelGGL(seq_attention_fwd_kernel, dim3((unsigned)((Bn + NB - 1) / NB)), dim3(SA_THREADS), lds, (hipStream_t)stream, a);
+  const dim3 grid((unsigned)((Bn + NB - 1) / NB));
+  if (DHP == 16) hipLaunchKernelGGL(seq_attention_fwd_kernel<16>, grid, dim3(SA_THREADS), lds, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(seq_attention_fwd_kernel<32>, grid, dim3(SA_THREADS), lds, (hipStream_t)stream, a);
   return sq_check("seq_attention_fwd_kernel");
 }
 
@@ -420,13 +475,16 @@ extern "C" int ops_seq_attention_bwd(int Bn, int S, int H, int dh, const void* q
                                      unsigned long long seed, unsigned long long* used_call, void* stream) {
   if (Bn < 1 || S < 1 || H < 1 || dh < 1 || !qkv || !dctx || !dqkv || p_drop < 0.0f || p_drop >= 1.0f || (p_drop > 0.0f && !used_call))
     return OPS_AMD_ERR_INVALID_ARG;
-  const int d = H * dh;
-  if (S > SA_MAXS || S * H > SA_THREADS) return OPS_AMD_ERR_UNSUPPORTED;
-  const int NB = sa_samples_per_wg(S, H, (size_t)S * 4 * d * 2 + (size_t)2 * H * S * S * 4);
+  const int d = H * dh, DHP = dh <= 16 ? 16 : 32;
+  if (S > SA_MAXS || S * H > SA_THREADS || dh > 32) return OPS_AMD_ERR_UNSUPPORTED;
+  const size_t per_sample = (size_t)S * 4 * H * DHP * 2 + (size_t)2 * H * S * S * 4;
+  const int NB = sa_samples_per_wg(S, H, per_sample);
   if (NB < 1 || (3 * d) % 8 || d % 8 || (((uintptr_t)qkv | (uintptr_t)dctx) & 15)) return OPS_AMD_ERR_UNSUPPORTED;
-  const size_t lds = (size_t)NB * S * 4 * d * 2 + (size_t)2 * NB * H * S * S * 4;
+  const size_t lds = (size_t)NB * per_sample;
   const SaArgs a{Bn, S, H, dh, NB, (const uint16_t*)qkv, (const uint16_t*)dctx, nullptr, (uint16_t*)dqkv, p_drop, seed, nullptr, used_call};
-  hipLaunchKernelGGL(seq_attention_bwd_kernel, dim3((unsigned)((Bn + NB - 1) / NB)), dim3(SA_THREADS), lds, (hipStream_t)stream, a);
+  const dim3 grid((unsigned)((Bn + NB - 1) / NB));
+  if (DHP == 16) hipLaunchKernelGGL(seq_attention_bwd_kernel<16>, grid, dim3(SA_THREADS), lds, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(seq_attention_bwd_kernel<32>, grid, dim3(SA_THREADS), lds, (hipStream_t)stream, a);
   return sq_check("seq_attention_bwd_kernel");
 }
 

@@ -174,7 +174,7 @@ def _layer_ok(layer: nn.Module) -> bool:
     relu = getattr(layer, "activation_relu_or_gelu", 0) == 1
     d = mha.embed_dim
     return (relu and mha.batch_first and mha._qkv_same_embed_dim and mha.in_proj_bias is not None and mha.bias_k is None and not mha.add_zero_attn
-            and d % 8 == 0 and d <= 256 and d % mha.num_heads == 0 and hasattr(mha, "_ops_in_proj") and type(layer.norm1) is nn.LayerNorm
+            and d % 8 == 0 and d <= 256 and d % mha.num_heads == 0 and d // mha.num_heads <= 32 and hasattr(mha, "_ops_in_proj") and type(layer.norm1) is nn.LayerNorm
             and type(layer.norm2) is nn.LayerNorm and layer.norm1.elementwise_affine and layer.norm2.elementwise_affine)
 
 

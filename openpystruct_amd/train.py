@@ -272,7 +272,7 @@ class _ShadowLinearFn(torch.autograd.Function):
         return gx, None, None, None, None, None, None, None, None
 
 
-_SPLIT_WGRAD_ROWS = int(os.environ.get("OPS_AMD_SPLIT_WGRAD_ROWS", "1024"))     # products over at least this many rows (0 rows: never)
+_SPLIT_WGRAD_ROWS = int(os.environ.get("OPS_AMD_SPLIT_WGRAD_ROWS", "512"))     # products over at least this many rows (0 rows: never)
 
 
 def enable_shadow_linears(model: nn.Module, opt: "FlatClipAdam", params, flat: torch.Tensor):
@@ -521,7 +521,8 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
         loss.backward()
         if g_stash:                      # the shadow-linear weight / bias gradients: one multi-tensor cast-and-copy into `flat`
             live = [(dd, ss) for dd, ss in zip(g_dst, g_stash) if ss is not None]      # (a product nobody called this step leaves None)
-            torch._foreach_copy_([dd for dd, _ in live], [ss for _, ss in live])
+            if live:
+                torch._foreach_copy_([dd for dd, _ in live], [ss for _, ss in live])
             for k in range(len(g_stash)):
                 g_stash[k] = None
         return loss.detach()
