@@ -414,6 +414,17 @@ int ops_act_dropout_bwd(long n, const void* x, const void* dy, void* dx, float s
  * (dW / dbias: the caller's zeroed flat gradient slices). */
 int ops_linear_wgrad_accumulate(int T, int N, int K, const void* dY, const void* X, float* dW, float* dbias, void* stream);
 
+/* Diffusion front end of the Transformer-Diffusion surrogate (TransformerDiffusionModule_MultiCase.py:443-478, :563-567) around its
+ * two-layer MLP: noise: x_noisy = sqrt(acp[t]) x + sqrt(1 - acp[t]) eps for `rows` = B * Nc rows of d features (t int64 [rows] and eps
+ * [rows, d] drawn by the caller), outputs float32 AND bfloat16 plus sa = sqrt(acp[t]), sb = sqrt(1 - acp[t]) [rows];
+ * combine: z [B, 1 + Nc, d] float32 = [cls | (x_noisy - sb mlp) / sa] + pe[:1 + Nc] with mlp [rows, d] bfloat16; its backward: dm
+ * (bfloat16) from g [B, 1 + Nc, d] and dcls [d] += column sums of g[:, 0, :] (float atomics; may be NULL). */
+int ops_diffusion_noise(long rows, int d, const float* x, const long long* t, const float* eps, const float* alpha_cumprod, float* xn32,
+                        void* xn16, float* sa, float* sb, void* stream);
+int ops_diffusion_combine_fwd(int B, int Nc, int d, const void* m, const float* xn32, const float* sa, const float* sb, const float* cls,
+                              const float* pe, float* z, void* stream);
+int ops_diffusion_combine_bwd(int B, int Nc, int d, const float* g, const float* sa, const float* sb, void* dm, float* dcls, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

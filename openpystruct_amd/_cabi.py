@@ -56,6 +56,9 @@ EXPORTS = (
     "ops_act_dropout_fwd",
     "ops_act_dropout_bwd",
     "ops_linear_wgrad_accumulate",
+    "ops_diffusion_noise",
+    "ops_diffusion_combine_fwd",
+    "ops_diffusion_combine_bwd",
 )
 
 OK, ERR_INVALID_ARG, ERR_UNSUPPORTED, ERR_LAUNCH = 0, 1, 2, 3
@@ -205,6 +208,12 @@ def load():
     lib.ops_dropout_add_layernorm_bwd.argtypes = [it, it, vp, vp, vp, vp, vp, vp, fl, ull, vp, vp, vp, vp, vp, vp]
     lib.ops_act_dropout_fwd.restype = it
     lib.ops_act_dropout_fwd.argtypes = [lg, vp, vp, fl, fl, ull, vp, vp, vp]
+    lib.ops_diffusion_noise.restype = it
+    lib.ops_diffusion_noise.argtypes = [lg, it, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.ops_diffusion_combine_fwd.restype = it
+    lib.ops_diffusion_combine_fwd.argtypes = [it, it, it, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.ops_diffusion_combine_bwd.restype = it
+    lib.ops_diffusion_combine_bwd.argtypes = [it, it, it, vp, vp, vp, vp, vp, vp]
     lib.ops_linear_wgrad_accumulate.restype = it
     lib.ops_linear_wgrad_accumulate.argtypes = [it, it, it, vp, vp, vp, vp, vp]
     lib.ops_act_dropout_bwd.restype = it

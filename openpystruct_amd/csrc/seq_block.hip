@@ -654,3 +654,101 @@ extern "C" int ops_linear_wgrad_accumulate(int T, int N, int K, const void* dY, 
   hipLaunchKernelGGL(opsamd::wgrad_tn_kernel, grid, dim3(256), 0, (hipStream_t)stream, T, N, K, (const uint16_t*)dY, (const uint16_t*)X, dW, dbias);
   return sq_check("wgrad_tn_kernel");
 }
+
+// ================================================================================================================================
+// diffusion front end of the Transformer-Diffusion surrogate (TransformerDiffusionModule_MultiCase.py:443-478, :563-567): the
+// arithmetic around its two-layer MLP, the [CLS] token and the positional encoding -- a dozen framework nodes forward -- as two launches
+//   noise   : x_noisy = sqrt(acp[t]) x + sqrt(1 - acp[t]) eps          (t, eps drawn by the caller: the framework's generators)
+//   combine : z[b, 0] = cls + pe[0];  z[b, 1 + n] = (x_noisy - sb mlp(x_noisy)) / sa + pe[1 + n]
+// ================================================================================================================================
+namespace opsamd {
+
+__global__ __launch_bounds__(256) void diffusion_noise_kernel(long rows, int d, const float* __restrict__ x, const long long* __restrict__ t,
+                                                               const float* __restrict__ eps, const float* __restrict__ acp,
+                                                               float* __restrict__ xn32, uint16_t* __restrict__ xn16, float* __restrict__ sa,
+                                                               float* __restrict__ sb) {
+  const long n = rows * d;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256) {
+    const long r = e / d;
+    const float a = acp[t[r]], s_a = sqrtf(a), s_b = sqrtf(1.0f - a);
+    const float v = s_a * x[e] + s_b * eps[e];
+    xn32[e] = v;
+    xn16[e] = sq_f2bf(v);
+    if (e - r * d == 0) { sa[r] = s_a; sb[r] = s_b; }
+  }
+}
+
+__global__ __launch_bounds__(256) void diffusion_combine_fwd_kernel(int B, int Nc, int d, const uint16_t* __restrict__ m, const float* __restrict__ xn32,
+                                                                     const float* __restrict__ sa, const float* __restrict__ sb,
+                                                                     const float* __restrict__ cls, const float* __restrict__ pe,
+                                                                     float* __restrict__ z) {
+  const int S = Nc + 1;
+  const long n = (long)B * S * d;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256) {
+    const int c = (int)(e % d);
+    const long bs = e / d;
+    const int s = (int)(bs % S);
+    const long b = bs / S;
+    float v;
+    if (s == 0) {
+      v = cls[c];
+    } else {
+      const long r = b * Nc + (s - 1), q = r * d + c;
+      v = (xn32[q] - sb[r] * sq_bf2f(m[q])) / sa[r];
+    }
+    z[e] = v + pe[(long)s * d + c];
+  }
+}
+
+// dm = -(sb / sa) g[:, 1:, :] (bf16);  dcls += sum_b g[b, 0, :]  (float atomics, one per column and workgroup)
+__global__ __launch_bounds__(256) void diffusion_combine_bwd_kernel(int B, int Nc, int d, const float* __restrict__ g, const float* __restrict__ sa,
+                                                                     const float* __restrict__ sb, uint16_t* __restrict__ dm,
+                                                                     float* __restrict__ dcls) {
+  const int S = Nc + 1;
+  const long n = (long)B * Nc * d;
+  for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < n; q += (long)gridDim.x * 256) {
+    const int c = (int)(q % d);
+    const long r = q / d, b = r / Nc;
+    const int s = (int)(r - b * Nc) + 1;
+    dm[q] = sq_f2bf(-(sb[r] / sa[r]) * g[(b * S + s) * d + c]);
+  }
+  if (dcls && (int)blockIdx.x < 8) {                       // eight workgroups share the [CLS] rows
+    for (int c = threadIdx.x; c < d; c += 256) {
+      float acc = 0.0f;
+      for (long b = blockIdx.x; b < B; b += 8) acc += g[(b * S) * d + c];
+      unsafeAtomicAdd(&dcls[c], acc);
+    }
+  }
+}
+
+}  // namespace opsamd
+
+extern "C" int ops_diffusion_noise(long rows, int d, const float* x, const long long* t, const float* eps, const float* alpha_cumprod,
+                                   float* xn32, void* xn16, float* sa, float* sb, void* stream) {
+  if (rows < 1 || d < 1 || !x || !t || !eps || !alpha_cumprod || !xn32 || !xn16 || !sa || !sb) return OPS_AMD_ERR_INVALID_ARG;
+  long nb = (rows * d + 255) / 256;
+  if (nb > 2048) nb = 2048;
+  hipLaunchKernelGGL(opsamd::diffusion_noise_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, rows, d, x, t, eps, alpha_cumprod, xn32,
+                     (uint16_t*)xn16, sa, sb);
+  return sq_check("diffusion_noise_kernel");
+}
+
+extern "C" int ops_diffusion_combine_fwd(int B, int Nc, int d, const void* m, const float* xn32, const float* sa, const float* sb, const float* cls,
+                                         const float* pe, float* z, void* stream) {
+  if (B < 1 || Nc < 1 || d < 1 || !m || !xn32 || !sa || !sb || !cls || !pe || !z) return OPS_AMD_ERR_INVALID_ARG;
+  long nb = ((long)B * (Nc + 1) * d + 255) / 256;
+  if (nb > 2048) nb = 2048;
+  hipLaunchKernelGGL(opsamd::diffusion_combine_fwd_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, B, Nc, d, (const uint16_t*)m, xn32,
+                     sa, sb, cls, pe, z);
+  return sq_check("diffusion_combine_fwd_kernel");
+}
+
+extern "C" int ops_diffusion_combine_bwd(int B, int Nc, int d, const float* g, const float* sa, const float* sb, void* dm, float* dcls, void* stream) {
+  if (B < 1 || Nc < 1 || d < 1 || !g || !sa || !sb || !dm) return OPS_AMD_ERR_INVALID_ARG;
+  long nb = ((long)B * Nc * d + 255) / 256;
+  if (nb > 2048) nb = 2048;
+  if (nb < 8) nb = 8;
+  hipLaunchKernelGGL(opsamd::diffusion_combine_bwd_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, B, Nc, d, g, sa, sb, (uint16_t*)dm,
+                     dcls);
+  return sq_check("diffusion_combine_bwd_kernel");
+}

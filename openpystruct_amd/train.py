@@ -437,10 +437,10 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
         sched = None
         if _SHADOW_LINEAR and autocast_dtype == torch.bfloat16:
             g_stash, g_dst, patched = enable_shadow_linears(model, opt, params, flat)
-            if kind == "tfd" and isinstance(getattr(model, "transformer_encoder", None), nn.TransformerEncoder):
-                from . import tfd_fused          # encoder layers through csrc/seq_block.hip (attention, dropout + add + LayerNorm, ReLU + dropout)
-                if tfd_fused.patch_encoder(model.transformer_encoder, seed=seed * 7919 + 211 + rank, direct_param_grads=True):
-                    fast_encoder = model.transformer_encoder
+            if kind == "tfd":
+                from . import tfd_fused          # csrc/seq_block.hip: attention, dropout + add + LayerNorm, ReLU + dropout, diffusion front end
+                if tfd_fused.patch_model(model, seed=seed * 7919 + 211 + rank, direct_param_grads=True):
+                    fast_encoder = model
     else:
         opt = (torch.optim.AdamW if kind == "gnn" else torch.optim.Adam)(model.parameters(), lr=cfg.learning_rate,   # GNN:394
                                                                          weight_decay=cfg.weight_decay)
@@ -726,7 +726,7 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
     disable_shadow_linears(patched)      # the returned model is a plain module again
     if fast_encoder is not None:
         from . import tfd_fused
-        tfd_fused.unpatch_encoder(fast_encoder)
+        tfd_fused.unpatch_model(fast_encoder)
     if hasattr(model, "direct_param_grads"):
         model.direct_param_grads = False
     if best_state is not None:

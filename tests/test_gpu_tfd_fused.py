@@ -228,6 +228,61 @@ def test_patched_encoder_with_thousands_of_rows_takes_the_split_row_gradient_pat
     TF.unpatch_encoder(enc)
 
 
+def test_patched_model_matches_the_module_with_the_same_noise(monkeypatch):
+    """ModelOnePassTransformerWithDiffusion through patch_model (fused diffusion front end, encoder blocks, fused head) vs its own
+    forward, both under bf16 autocast, dropout 0, and with torch.randint / torch.randn_like replaced by a replayable stream."""
+    from openpystruct_amd import tfd_fused as TF, train
+    from openpystruct_amd.surrogates import ModelOnePassTransformerWithDiffusion
+    torch.manual_seed(5)
+    model = ModelOnePassTransformerWithDiffusion(6, 120, 100, dropout=0.0).to(DEV)
+    ref = copy.deepcopy(model)
+    params = list(model.parameters())
+    flat = torch.zeros(sum(q.numel() for q in params), device=DEV)
+    off = 0
+    for q in params:
+        q.grad = flat[off:off + q.numel()].view_as(q)
+        off += q.numel()
+    opt = train.FlatClipAdam(params, flat, 1e-3)
+    stash, dst, patched = train.enable_shadow_linears(model, opt, params, flat)
+    assert TF.patch_model(model, seed=3, direct_param_grads=True) and "forward" in model.__dict__
+    B = 512
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(B, 6, 120, generator=g).to(DEV)
+    w = torch.randn(B, 100, generator=g).to(DEV) / B
+    draws = {}
+
+    def fake_randn_like(t, **kw):
+        if "e" not in draws:
+            draws["e"] = torch.randn(t.shape, generator=torch.Generator().manual_seed(8)).to(t.device)
+        return draws["e"]
+
+    orig_randint = torch.randint
+
+    def fake_randint(lo, hi, size, device=None, **kw):
+        if "t" not in draws:
+            draws["t"] = orig_randint(lo, hi, size, generator=torch.Generator().manual_seed(7)).to(device)
+        return draws["t"]
+
+    monkeypatch.setattr(torch, "randint", fake_randint)
+    monkeypatch.setattr(torch, "randn_like", fake_randn_like)
+    model.train(); ref.train()
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        out = model(x)
+        (out.float() * w).sum().backward()
+    live = [(dd, ss) for dd, ss in zip(dst, stash) if ss is not None]
+    if live:
+        torch._foreach_copy_([a for a, _ in live], [b for _, b in live])
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        outr = ref(x)
+        (outr.float() * w).sum().backward()
+    assert _rel(out.float(), outr.float()) < 1.5e-2
+    for (n, q), (_, qr) in zip(model.named_parameters(), ref.named_parameters()):
+        assert _rel(q.grad, qr.grad) < 8e-2, n                          # two bf16 evaluations of the same network
+    train.disable_shadow_linears(patched)
+    TF.unpatch_model(model)
+    assert "forward" not in model.__dict__ and "forward" not in model.transformer_encoder.__dict__
+
+
 def test_tfd_training_with_the_fast_encoder_follows_the_framework_path(monkeypatch):
     """Six epochs of the TFD loop (dropout 0.1, diffusion noise on) with the encoder blocks vs the framework's encoder: two draws of the
     same stochastic process -- final training losses within 8 % of each other, both decreasing (800 groups: two steps per epoch)."""
