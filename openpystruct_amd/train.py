@@ -723,6 +723,19 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
             log(f"Epoch {epoch}/{n_epochs} | Train Loss={tl:.6f}, Val Loss={vl:.6f}, Time={hist['epoch_s'][-1]:.2f}s")
         if no_improve >= cfg.patience:
             break
+    # the captured graphs (and their private memory pools) go before anything else runs on this device: the closures above form
+    # reference cycles that would otherwise keep them alive until some later garbage collection
+    graph = graph_b = vgraph = None
+    if on_gpu:
+        import gc
+        gc.collect()
+        torch.cuda.synchronize(device)
+        # BLAS workspaces that were allocated while capturing live in the graphs' private pools but stay cached per (handle, stream):
+        # a later run whose side stream gets the same id would hand that freed memory to its GEMMs as scratch space (seen as NaNs /
+        # drifting losses in a framework-path TFD run after a fast-path one in the same process)
+        clear = getattr(torch._C, "_cuda_clearCublasWorkspaces", None)
+        if clear is not None:
+            clear()
     disable_shadow_linears(patched)      # the returned model is a plain module again
     if fast_encoder is not None:
         from . import tfd_fused
