@@ -262,7 +262,7 @@ __global__ __launch_bounds__(SA_THREADS) void seq_attention_bwd_kernel(const SaA
 constexpr int LN_MAXC = 4;           // columns per lane
 constexpr int LN_THREADS = 256;      // 4 rows at a time
 constexpr int LN_BWD_THREADS = 1024; // backward: 16 waves ...
-constexpr int LN_ROWS_PER_WG = 64;   // ... x 4 rows: few workgroups add into gamma / beta's gradients (~40 ns per same-address atomic)
+constexpr int LN_ROWS_PER_WG = 32;   // ... x 2 rows: few workgroups add into gamma / beta's gradients (~40 ns per same-address atomic)
 
 struct LnArgs {
   int T, d;
@@ -573,7 +573,7 @@ __global__ __launch_bounds__(256) void wgrad_tn_kernel(int T, int N, int K, cons
                                                         float* __restrict__ dW, float* __restrict__ dbias) {
   __shared__ __attribute__((aligned(16))) uint16_t s_a[WG_SLAB][64 + 4], s_b[WG_SLAB][64 + 4];      // [t][n], [t][k]; 136-byte rows: the four
                                                                                                     // row groups of a fragment read land on two bank sets
-  __shared__ float s_cs[4][64];
+  __shared__ float s_cs[4][64];                                        // bias job: per-wave column sums
   const int n0 = blockIdx.x * 64, k0 = blockIdx.y * 64, t0 = blockIdx.z * WG_ROWS, t1 = min(t0 + WG_ROWS, T);
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int wn = (wave >> 1) * 32, wk = (wave & 1) * 32;               // this wave's 32 x 32 quarter of the tile
@@ -712,10 +712,16 @@ __global__ __launch_bounds__(256) void diffusion_combine_bwd_kernel(int B, int N
     const int s = (int)(r - b * Nc) + 1;
     dm[q] = sq_f2bf(-(sb[r] / sa[r]) * g[(b * S + s) * d + c]);
   }
-  if (dcls && (int)blockIdx.x < 8) {                       // eight workgroups share the [CLS] rows
+  if (dcls && (int)blockIdx.x < 64) {                      // 64 workgroups share the [CLS] rows, eight independent loads per trip
     for (int c = threadIdx.x; c < d; c += 256) {
       float acc = 0.0f;
-      for (long b = blockIdx.x; b < B; b += 8) acc += g[(b * S) * d + c];
+      for (long b0 = blockIdx.x; b0 < B; b0 += 64 * 8) {
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { const long b = b0 + 64 * k; v[k] = b < B ? g[(b * S) * d + c] : 0.0f; }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc += v[k];
+      }
       unsafeAtomicAdd(&dcls[c], acc);
     }
   }
@@ -747,7 +753,7 @@ extern "C" int ops_diffusion_combine_bwd(int B, int Nc, int d, const float* g, c
   if (B < 1 || Nc < 1 || d < 1 || !g || !sa || !sb || !dm) return OPS_AMD_ERR_INVALID_ARG;
   long nb = ((long)B * Nc * d + 255) / 256;
   if (nb > 2048) nb = 2048;
-  if (nb < 8) nb = 8;
+  if (nb < 64) nb = 64;
   hipLaunchKernelGGL(opsamd::diffusion_combine_bwd_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, B, Nc, d, g, sa, sb, (uint16_t*)dm,
                      dcls);
   return sq_check("diffusion_combine_bwd_kernel");
