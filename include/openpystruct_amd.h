@@ -413,6 +413,13 @@ int ops_act_dropout_bwd(long n, const void* x, const void* dy, void* dx, float s
  * [T, N] and X [T, K] bfloat16 row-major.  The rows are split over the grid and the partial results added with float atomics
  * (dW / dbias: the caller's zeroed flat gradient slices). */
 int ops_linear_wgrad_accumulate(int T, int N, int K, const void* dY, const void* X, float* dW, float* dbias, void* stream);
+/* ... and up to 16 such products in ONE launch (every weight gradient of a backward pass, once all output gradients exist). */
+typedef struct ops_wgrad_problem {
+  int32_t T, N, K;
+  const void* dY; const void* X; float* dW; float* dbias;
+} ops_wgrad_problem;
+#define OPS_WGRAD_MAX_GROUP 16
+int ops_linear_wgrad_accumulate_group(int nprob, const ops_wgrad_problem* problems, void* stream);
 
 /* Diffusion front end of the Transformer-Diffusion surrogate (TransformerDiffusionModule_MultiCase.py:443-478, :563-567) around its
  * two-layer MLP: noise: x_noisy = sqrt(acp[t]) x + sqrt(1 - acp[t]) eps for `rows` = B * Nc rows of d features (t int64 [rows] and eps

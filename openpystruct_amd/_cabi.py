@@ -56,6 +56,7 @@ EXPORTS = (
     "ops_act_dropout_fwd",
     "ops_act_dropout_bwd",
     "ops_linear_wgrad_accumulate",
+    "ops_linear_wgrad_accumulate_group",
     "ops_diffusion_noise",
     "ops_diffusion_combine_fwd",
     "ops_diffusion_combine_bwd",
@@ -106,6 +107,15 @@ class MlpWgradProblem(ctypes.Structure):
     """Mirror of `ops_mlp_wgrad_problem`."""
     _fields_ = [("At", ctypes.c_void_p), ("Bt", ctypes.c_void_p), ("out", ctypes.c_void_p), ("N", ctypes.c_int32), ("K", ctypes.c_int32),
                 ("ldo", ctypes.c_int32)]
+
+
+class WgradProblem(ctypes.Structure):
+    """Mirror of `ops_wgrad_problem`."""
+    _fields_ = [("T", ctypes.c_int32), ("N", ctypes.c_int32), ("K", ctypes.c_int32), ("dY", ctypes.c_void_p), ("X", ctypes.c_void_p),
+                ("dW", ctypes.c_void_p), ("dbias", ctypes.c_void_p)]
+
+
+WGRAD_MAX_GROUP = 16
 
 
 class MlpRepackEntry(ctypes.Structure):
@@ -214,6 +224,8 @@ def load():
     lib.ops_diffusion_combine_fwd.argtypes = [it, it, it, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.ops_diffusion_combine_bwd.restype = it
     lib.ops_diffusion_combine_bwd.argtypes = [it, it, it, vp, vp, vp, vp, vp, vp]
+    lib.ops_linear_wgrad_accumulate_group.restype = it
+    lib.ops_linear_wgrad_accumulate_group.argtypes = [it, ctypes.POINTER(WgradProblem), vp]
     lib.ops_linear_wgrad_accumulate.restype = it
     lib.ops_linear_wgrad_accumulate.argtypes = [it, it, it, vp, vp, vp, vp, vp]
     lib.ops_act_dropout_bwd.restype = it

@@ -569,12 +569,12 @@ __device__ __forceinline__ uint4 wg_load8(const uint16_t* __restrict__ M, int T,
   return *(const uint4*)v;
 }
 
-__global__ __launch_bounds__(256) void wgrad_tn_kernel(int T, int N, int K, const uint16_t* __restrict__ dY, const uint16_t* __restrict__ X,
-                                                        float* __restrict__ dW, float* __restrict__ dbias) {
+__device__ __forceinline__ void wgrad_tn_body(int T, int N, int K, const uint16_t* __restrict__ dY, const uint16_t* __restrict__ X,
+                                              float* __restrict__ dW, float* __restrict__ dbias, int bx, int by, int bz) {
   __shared__ __attribute__((aligned(16))) uint16_t s_a[WG_SLAB][64 + 4], s_b[WG_SLAB][64 + 4];      // [t][n], [t][k]; 136-byte rows: the four
                                                                                                     // row groups of a fragment read land on two bank sets
   __shared__ float s_cs[4][64];                                        // bias job: per-wave column sums
-  const int n0 = blockIdx.x * 64, k0 = blockIdx.y * 64, t0 = blockIdx.z * WG_ROWS, t1 = min(t0 + WG_ROWS, T);
+  const int n0 = bx * 64, k0 = by * 64, t0 = bz * WG_ROWS, t1 = min(t0 + WG_ROWS, T);
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int wn = (wave >> 1) * 32, wk = (wave & 1) * 32;               // this wave's 32 x 32 quarter of the tile
   const bool va = (N & 7) == 0 && ((uintptr_t)dY & 15) == 0, vb = (K & 7) == 0 && ((uintptr_t)X & 15) == 0;
@@ -584,7 +584,7 @@ __global__ __launch_bounds__(256) void wgrad_tn_kernel(int T, int N, int K, cons
 #pragma unroll
     for (int j = 0; j < 2; ++j) acc[i][j] = wg_f32x4{0.0f, 0.0f, 0.0f, 0.0f};
   const int lr = tid >> 3, lc = (tid & 7) * 8;                         // slab loader: row lr (0..31), 8 columns from lc
-  const bool bias_job = dbias != nullptr && blockIdx.y == 0;           // the first column of tiles also sums dY's columns
+  const bool bias_job = dbias != nullptr && by == 0;                   // the first column of tiles also sums dY's columns
   float csum[8];                                                       // this loader's 8 columns, summed over its rows
 #pragma unroll
   for (int j = 0; j < 8; ++j) csum[j] = 0.0f;
@@ -646,6 +646,25 @@ __global__ __launch_bounds__(256) void wgrad_tn_kernel(int T, int N, int K, cons
   }
 }
 
+__global__ __launch_bounds__(256) void wgrad_tn_kernel(int T, int N, int K, const uint16_t* __restrict__ dY, const uint16_t* __restrict__ X,
+                                                        float* __restrict__ dW, float* __restrict__ dbias) {
+  wgrad_tn_body(T, N, K, dY, X, dW, dbias, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// several products in one launch (all weight gradients of a backward pass, once every dY exists): workgroup -> (problem, tile, rows)
+struct WgGroup {
+  int nprob;
+  int wg0[OPS_WGRAD_MAX_GROUP + 1];
+  ops_wgrad_problem p[OPS_WGRAD_MAX_GROUP];
+};
+__global__ __launch_bounds__(256) void wgrad_tn_group_kernel(const WgGroup g) {
+  int pi = 0;
+  while (pi + 1 < g.nprob && (int)blockIdx.x >= g.wg0[pi + 1]) ++pi;
+  const ops_wgrad_problem pr = g.p[pi];
+  const int id = (int)blockIdx.x - g.wg0[pi], tn = (pr.N + 63) / 64, tk = (pr.K + 63) / 64;
+  wgrad_tn_body(pr.T, pr.N, pr.K, (const uint16_t*)pr.dY, (const uint16_t*)pr.X, pr.dW, pr.dbias, id % tn, (id / tn) % tk, id / (tn * tk));
+}
+
 }  // namespace opsamd
 
 extern "C" int ops_linear_wgrad_accumulate(int T, int N, int K, const void* dY, const void* X, float* dW, float* dbias, void* stream) {
@@ -653,6 +672,23 @@ extern "C" int ops_linear_wgrad_accumulate(int T, int N, int K, const void* dY, 
   const dim3 grid((unsigned)((N + 63) / 64), (unsigned)((K + 63) / 64), (unsigned)((T + opsamd::WG_ROWS - 1) / opsamd::WG_ROWS));
   hipLaunchKernelGGL(opsamd::wgrad_tn_kernel, grid, dim3(256), 0, (hipStream_t)stream, T, N, K, (const uint16_t*)dY, (const uint16_t*)X, dW, dbias);
   return sq_check("wgrad_tn_kernel");
+}
+
+extern "C" int ops_linear_wgrad_accumulate_group(int nprob, const ops_wgrad_problem* problems, void* stream) {
+  if (nprob < 1 || nprob > OPS_WGRAD_MAX_GROUP || !problems) return OPS_AMD_ERR_INVALID_ARG;
+  opsamd::WgGroup g;
+  g.nprob = nprob;
+  int tot = 0;
+  for (int i = 0; i < nprob; ++i) {
+    const ops_wgrad_problem& p = problems[i];
+    if (p.T < 1 || p.N < 1 || p.K < 1 || !p.dY || !p.X || !p.dW) return OPS_AMD_ERR_INVALID_ARG;
+    g.p[i] = p;
+    g.wg0[i] = tot;
+    tot += ((p.N + 63) / 64) * ((p.K + 63) / 64) * ((p.T + opsamd::WG_ROWS - 1) / opsamd::WG_ROWS);
+  }
+  g.wg0[nprob] = tot;
+  hipLaunchKernelGGL(opsamd::wgrad_tn_group_kernel, dim3((unsigned)tot), dim3(256), 0, (hipStream_t)stream, g);
+  return sq_check("wgrad_tn_group_kernel");
 }
 
 // ================================================================================================================================

@@ -252,12 +252,16 @@ class _ShadowLinearFn(torch.autograd.Function):
             from . import _cabi
             g2, x2c = g2.contiguous(), x2.contiguous()
             fused_bias = ctx.ib is not None and ctx.b_grad is not None
-            with torch.cuda.device(g2.device):
-                rc = _cabi.load().ops_linear_wgrad_accumulate(x2c.shape[0], g2.shape[1], x2c.shape[1], g2.data_ptr(), x2c.data_ptr(),
-                                                              ctx.w_grad.data_ptr(), ctx.b_grad.data_ptr() if fused_bias else None,
-                                                              torch.cuda.current_stream(g2.device).cuda_stream)
-            if rc != 0:
-                raise RuntimeError(f"ops_linear_wgrad_accumulate failed with code {rc}")
+            if _WGRAD_QUEUE is not None:
+                # deferred: the training step launches every queued product at once after backward (flush_wgrad_queue)
+                _WGRAD_QUEUE.append((g2, x2c, ctx.w_grad, ctx.b_grad if fused_bias else None))
+            else:
+                with torch.cuda.device(g2.device):
+                    rc = _cabi.load().ops_linear_wgrad_accumulate(x2c.shape[0], g2.shape[1], x2c.shape[1], g2.data_ptr(), x2c.data_ptr(),
+                                                                  ctx.w_grad.data_ptr(), ctx.b_grad.data_ptr() if fused_bias else None,
+                                                                  torch.cuda.current_stream(g2.device).cuda_stream)
+                if rc != 0:
+                    raise RuntimeError(f"ops_linear_wgrad_accumulate failed with code {rc}")
             if ctx.ib is not None and not fused_bias:
                 ctx.stash[ctx.ib] = g2.sum(0)
         else:
@@ -273,6 +277,28 @@ class _ShadowLinearFn(torch.autograd.Function):
 
 
 _SPLIT_WGRAD_ROWS = int(os.environ.get("OPS_AMD_SPLIT_WGRAD_ROWS", "512"))     # products over at least this many rows (0 rows: never)
+_WGRAD_QUEUE = None          # a list while a training step collects its split-row weight gradients for ONE grouped launch
+
+
+def flush_wgrad_queue(device) -> None:
+    """Launch everything `_ShadowLinearFn.backward` queued (operands stay alive in the queue until here), 16 products per launch."""
+    from . import _cabi
+    q = _WGRAD_QUEUE
+    if not q:
+        return
+    lib = _cabi.load()
+    with torch.cuda.device(device):
+        s = torch.cuda.current_stream(device).cuda_stream
+        for i0 in range(0, len(q), _cabi.WGRAD_MAX_GROUP):
+            part = q[i0:i0 + _cabi.WGRAD_MAX_GROUP]
+            arr = (_cabi.WgradProblem * len(part))()
+            for e, (g2, x2, wg, bg) in zip(arr, part):
+                e.T, e.N, e.K = x2.shape[0], g2.shape[1], x2.shape[1]
+                e.dY, e.X, e.dW, e.dbias = g2.data_ptr(), x2.data_ptr(), wg.data_ptr(), (bg.data_ptr() if bg is not None else None)
+            rc = lib.ops_linear_wgrad_accumulate_group(len(part), arr, s)
+            if rc != 0:
+                raise RuntimeError(f"ops_linear_wgrad_accumulate_group failed with code {rc}")
+    q.clear()
 
 
 def enable_shadow_linears(model: nn.Module, opt: "FlatClipAdam", params, flat: torch.Tensor):
@@ -332,6 +358,7 @@ def disable_shadow_linears(patched) -> None:
                 del mod.__dict__[name]
 
 
+_GROUP_WGRAD = os.environ.get("OPS_AMD_GROUP_WGRAD", "1") == "1"    # A/B switch: 0 = one launch per product, inside backward
 F_linear = torch.nn.functional.linear
 _SHADOW_LINEAR = os.environ.get("OPS_AMD_SHADOW_LINEAR", "1") == "1"   # A/B switch: 0 = nn.Linear under autocast
 
@@ -518,7 +545,13 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
                     loss = loss + (cfg.initial_alpha - crit.alpha) ** 2   # TFD:743 / FNN (constant 0: alpha never trains)
         if physics is not None:
             loss = loss + physics.weight * physics_loss(preds.float(), pin).float()
-        loss.backward()
+        global _WGRAD_QUEUE
+        _WGRAD_QUEUE = [] if (g_stash and _GROUP_WGRAD) else None       # split-row weight gradients: one grouped launch after backward
+        try:
+            loss.backward()
+            flush_wgrad_queue(device)
+        finally:
+            _WGRAD_QUEUE = None
         if g_stash:                      # the shadow-linear weight / bias gradients: one multi-tensor cast-and-copy into `flat`
             live = [(dd, ss) for dd, ss in zip(g_dst, g_stash) if ss is not None]      # (a product nobody called this step leaves None)
             if live:

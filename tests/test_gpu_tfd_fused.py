@@ -314,3 +314,27 @@ def test_split_row_weight_gradient(T, N, K):
     dW.zero_()
     assert lib.ops_linear_wgrad_accumulate(T, N, K, dY.data_ptr(), X.data_ptr(), dW.data_ptr(), None, None) == _cabi.OK
     assert _rel(dW, dY.double().t() @ X.double()) < 1e-5
+
+
+def test_grouped_split_row_weight_gradients():
+    from openpystruct_amd import _cabi
+    lib = _cabi.load()
+    g = torch.Generator().manual_seed(11)
+    shapes = [(3584, 360, 120), (3584, 120, 256), (512, 100, 256), (1000, 302, 175), (700, 7, 33)]
+    ops, arr = [], (_cabi.WgradProblem * len(shapes))()
+    for e, (T, N, K) in zip(arr, shapes):
+        dY = torch.randn(T, N, generator=g).to(torch.bfloat16).to(DEV)
+        X = torch.randn(T, K, generator=g).to(torch.bfloat16).to(DEV)
+        dW, db = torch.zeros(N, K, device=DEV), torch.zeros(N, device=DEV)
+        ops.append((dY, X, dW, db))
+        e.T, e.N, e.K, e.dY, e.X, e.dW, e.dbias = T, N, K, dY.data_ptr(), X.data_ptr(), dW.data_ptr(), db.data_ptr()
+    arr[3].dbias = None                                                 # one product without a bias
+    assert lib.ops_linear_wgrad_accumulate_group(len(shapes), arr, None) == _cabi.OK
+    torch.cuda.synchronize()
+    for i, (dY, X, dW, db) in enumerate(ops):
+        assert _rel(dW, dY.double().t() @ X.double()) < 1e-5
+        if i != 3:
+            assert _rel(db, dY.double().sum(0)) < 1e-5
+        else:
+            assert float(db.abs().max()) == 0.0
+    assert lib.ops_linear_wgrad_accumulate_group(17, arr, None) == _cabi.ERR_INVALID_ARG
