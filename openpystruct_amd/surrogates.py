@@ -337,7 +337,7 @@ class _FusedLoss(torch.autograd.Function):
     """csrc/fused_loss.hip: loss value and d loss / d preds in one pass; backward only scales the stored gradient."""
 
     @staticmethod
-    def forward(ctx, preds, targets, alpha, alpha0, minc, maxc, box_w, rel_pen, nI, nD):
+    def forward(ctx, preds, targets, alpha, alpha0, minc, maxc, box_w, rel_pen, nI, nD, unit_grad=False):
         from . import _cabi
         lib = _cabi.load()
         if preds.dtype not in (torch.float32, torch.bfloat16):
@@ -357,18 +357,23 @@ class _FusedLoss(torch.autograd.Function):
         if rc != _cabi.OK:
             raise RuntimeError(f"ops_surrogate_loss_grad_f32 failed with code {rc}")
         ctx.save_for_backward(grad)
+        ctx.unit_grad = bool(unit_grad)
         return loss
 
     @staticmethod
     def backward(ctx, go):
         (grad,) = ctx.saved_tensors
-        return (grad * go.to(grad.dtype),) + (None,) * 9
+        if ctx.unit_grad:        # the caller adds this loss with weight 1 to what it differentiates: d(total)/d(loss) = 1, no scaling pass
+            return (grad,) + (None,) * 10
+        return (grad * go.to(grad.dtype),) + (None,) * 10
 
 
-def fused_loss(crit: nn.Module, preds: torch.Tensor, targets: torch.Tensor, alpha0: float = None) -> torch.Tensor:
+def fused_loss(crit: nn.Module, preds: torch.Tensor, targets: torch.Tensor, alpha0: float = None, unit_grad: bool = False) -> torch.Tensor:
     """`crit(preds.float(), targets)` (+ `(alpha0 - alpha)^2` when alpha0 is given) for a CompositeLoss or a
     TrainableL1L2Loss through the fused HIP kernel: ~80 framework kernel nodes per training step become 3.  GPU tensors
-    only; the gradient w.r.t. the loss's own `alpha` is not produced (no optimiser ever holds it: PINN:696, TFD:678)."""
+    only; the gradient w.r.t. the loss's own `alpha` is not produced (no optimiser ever holds it: PINN:696, TFD:678).
+    `unit_grad`: the caller promises that the value enters the differentiated total with weight one (the training loops: loss
+    [+ weight * physics term]); the backward pass then hands out the stored gradient as it is (two nodes fewer per step)."""
     if isinstance(crit, CompositeLoss):
         l1l2, nI, nD, rel = crit.l1l2_loss, crit.nelem, crit.deflection_dim, crit.penalty_pinn
     else:
@@ -382,7 +387,7 @@ def fused_loss(crit: nn.Module, preds: torch.Tensor, targets: torch.Tensor, alph
 
     a = l1l2.alpha.detach()
     return _FusedLoss.apply(preds, targets.to(torch.float32), a, float("nan") if alpha0 is None else float(alpha0),   # NaN: no alpha term
-                            scalar(l1l2.min_constraint), scalar(l1l2.max_constraint), l1l2.penalty_weight, rel, nI, nD)
+                            scalar(l1l2.min_constraint), scalar(l1l2.max_constraint), l1l2.penalty_weight, rel, nI, nD, unit_grad)
 
 
 # ------------------------------------------------------------------------------------------------

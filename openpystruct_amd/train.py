@@ -538,7 +538,7 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
         with torch.autocast(device_type=device.type, dtype=autocast_dtype, enabled=use_ac):
             preds = net(Xn)
             if on_gpu and _FUSED_LOSS:       # value + d/d preds in one HIP pass instead of ~80 framework kernel nodes
-                loss = fused_loss(crit, preds, Yb, alpha0=cfg.initial_alpha if alpha_term else None)
+                loss = fused_loss(crit, preds, Yb, alpha0=cfg.initial_alpha if alpha_term else None, unit_grad=True)
             else:
                 loss = crit(preds.float(), Yb)
                 if alpha_term:
