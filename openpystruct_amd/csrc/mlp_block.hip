@@ -39,7 +39,7 @@
 
 namespace opsamd {
 
-#ifdef MB_EXP          // stand-alone experiment builds (scratch/mlp_exp.py)
+#ifdef MB_EXP          // stand-alone experiment builds (scripts/mlp_launch_bench.py: 1 = no product, 2 = one reduction step)
 inline void set_last_error(const char*) {}
 #else
 void set_last_error(const char* msg);   // beam_solve.hip: what ops_amd_last_error() reports
