@@ -549,13 +549,14 @@ extern "C" int ops_act_dropout_bwd(long n, const void* x, const void* dy, void* 
 // contiguous along the OUTPUT index in memory, the MFMA wants them contiguous along the reduction index), and adds its partial
 // tile to the float32 gradient with hardware float atomics (the caller's flat gradient buffer is zeroed every step).  The bias
 // gradient -- the column sums of dY -- comes out of the same pass (first column of tiles).  Same-address float atomics cost
-// ~40 ns each (measured: 448 adders per address 19 us, 224: 9 us): 28 row blocks per address here.
+// ~40 ns each (measured: 448 adders per address 19 us, 224: 9 us): 14 row blocks per address here.
 // ================================================================================================================================
 namespace opsamd {
 
 typedef __bf16 wg_bf16x8 __attribute__((ext_vector_type(8)));
 typedef float wg_f32x4 __attribute__((ext_vector_type(4)));
-constexpr int WG_ROWS = 128;      // rows of T per workgroup
+constexpr int WG_ROWS = 256;      // rows of T per workgroup: the float atomics of the partial tiles bound the launch (128 rows: 54 us for the twelve
+                                  // products of a TFD step, 256: 37, 512: 35 -- and fewer workgroups per small product)
 constexpr int WG_SLAB = 32;       // rows per LDS slab = one MFMA reduction step
 
 // one 32-row slab of an operand: row lr, 8 columns from c0 + lc -- one 16-byte load when the matrix allows it
@@ -571,8 +572,10 @@ __device__ __forceinline__ uint4 wg_load8(const uint16_t* __restrict__ M, int T,
 
 __device__ __forceinline__ void wgrad_tn_body(int T, int N, int K, const uint16_t* __restrict__ dY, const uint16_t* __restrict__ X,
                                               float* __restrict__ dW, float* __restrict__ dbias, int bx, int by, int bz) {
-  __shared__ __attribute__((aligned(16))) uint16_t s_a[WG_SLAB][64 + 4], s_b[WG_SLAB][64 + 4];      // [t][n], [t][k]; 136-byte rows: the four
-                                                                                                    // row groups of a fragment read land on two bank sets
+  // slabs TRANSPOSED in LDS, [column][t] with 72-byte rows: the loader scatters its 8 columns (two-byte writes), a fragment -- 8
+  // consecutive t of one column -- is then two 8-byte reads (row-major slabs needed 8 two-byte reads per fragment: 32 LDS reads per
+  // thread and slab against 8 + 16 writes here)
+  __shared__ __attribute__((aligned(16))) uint16_t s_a[64][WG_SLAB + 4], s_b[64][WG_SLAB + 4];
   __shared__ float s_cs[4][64];                                        // bias job: per-wave column sums
   const int n0 = bx * 64, k0 = by * 64, t0 = bz * WG_ROWS, t1 = min(t0 + WG_ROWS, T);
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -591,8 +594,12 @@ __device__ __forceinline__ void wgrad_tn_body(int T, int N, int K, const uint16_
   uint4 ra = wg_load8(dY, t1, N, t0 + lr, n0 + lc, va), rb = wg_load8(X, t1, K, t0 + lr, k0 + lc, vb);
   for (int ts = t0; ts < t1; ts += WG_SLAB) {
     __syncthreads();                                                   // the previous slab's fragments have been read
-    *(uint2*)&s_a[lr][lc] = uint2{ra.x, ra.y}; *(uint2*)&s_a[lr][lc + 4] = uint2{ra.z, ra.w};
-    *(uint2*)&s_b[lr][lc] = uint2{rb.x, rb.y}; *(uint2*)&s_b[lr][lc + 4] = uint2{rb.z, rb.w};
+    {
+      const uint16_t* pa = (const uint16_t*)&ra;
+      const uint16_t* pb = (const uint16_t*)&rb;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { s_a[lc + j][lr] = pa[j]; s_b[lc + j][lr] = pb[j]; }
+    }
     if (bias_job) {
       const uint16_t* pv = (const uint16_t*)&ra;
 #pragma unroll
@@ -607,14 +614,11 @@ __device__ __forceinline__ void wgrad_tn_body(int T, int N, int K, const uint16_
     wg_bf16x8 fa[2], fb[2];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      uint16_t ta[8], tb[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        ta[j] = s_a[8 * (lane >> 4) + j][wn + 16 * h + (lane & 15)];
-        tb[j] = s_b[8 * (lane >> 4) + j][wk + 16 * h + (lane & 15)];
-      }
-      fa[h] = __builtin_bit_cast(wg_bf16x8, *(const uint4*)ta);
-      fb[h] = __builtin_bit_cast(wg_bf16x8, *(const uint4*)tb);
+      const uint2* qa = (const uint2*)&s_a[wn + 16 * h + (lane & 15)][8 * (lane >> 4)];
+      const uint2* qb = (const uint2*)&s_b[wk + 16 * h + (lane & 15)][8 * (lane >> 4)];
+      const uint2 a0 = qa[0], a1 = qa[1], b0 = qb[0], b1 = qb[1];
+      fa[h] = __builtin_bit_cast(wg_bf16x8, uint4{a0.x, a0.y, a1.x, a1.y});
+      fb[h] = __builtin_bit_cast(wg_bf16x8, uint4{b0.x, b0.y, b1.x, b1.y});
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i)
