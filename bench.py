@@ -218,7 +218,9 @@ def surrogate_epoch_times(dev, rank, world, epochs, cases=50000):
             r = train.train_surrogate(kind, d, device=dev, max_epochs=epochs)
             ep = r["history"]["epoch_s"][1:] or r["history"]["epoch_s"]
             out[kind] = {"epoch_s": sum(ep) / len(ep), "steps_per_epoch": r["steps_per_epoch"], "train_groups_per_gpu": int(d.X_train.shape[0]),
-                         "dtype": "bf16"}
+                         "dtype": "bf16", "step_us": 1e6 * sum(ep) / len(ep) / max(1, r["steps_per_epoch"]),
+                         "path": {"pinn": "layer-block launches (pinn_fused.py, csrc/mlp_block.hip)",
+                                  "tfd": "autograd over block launches (tfd_fused.py, csrc/seq_block.hip)"}[kind]}
         # BASELINE config 4: the TFD surrogate with the physics loss through the HIP FE-residual kernels.  The residual needs
         # per-case targets (n_cases = 1: 40 000 training rows per GPU instead of 6 666 groups), see DESIGN.md section 8
         scfg = sizing.SizingConfig()
