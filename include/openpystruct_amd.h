@@ -74,6 +74,9 @@ extern "C" {
  * Never throws, never blocks.
  */
 #define OPS_AMD_TILING_STREAM_OUT 0x100
+/* OR-ed into `tiling` (with P = 16 or 8): the row-staged variant of that tiling (csrc/beam_fat.hip; shared geometry and
+ * constraint mask only, else OPS_AMD_ERR_UNSUPPORTED).  P = 6, the fat-wave tiling, exists only in that form. */
+#define OPS_AMD_TILING_ROWS 0x200
 int ops_beam_solve_batched_f64(int B, int Ne,
                                const double* x, long x_bstride,
                                const double* E, long E_bstride,

@@ -17,12 +17,12 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "lib", "libopenpystruct_amd.so")
-SOURCES = [os.path.join(CSRC, "beam_solve.hip"), os.path.join(CSRC, "sizing_step.hip"),
+SOURCES = [os.path.join(CSRC, "beam_solve.hip"), os.path.join(CSRC, "beam_fat.hip"), os.path.join(CSRC, "sizing_step.hip"),
            os.path.join(CSRC, "beam_residual.hip"), os.path.join(CSRC, "frame_solve.hip"),
            os.path.join(CSRC, "stencil_bn.hip"), os.path.join(CSRC, "flat_adam.hip"),
            os.path.join(CSRC, "fused_loss.hip"), os.path.join(CSRC, "beam_solve_lane.hip"), os.path.join(CSRC, "fused_bn.hip"), os.path.join(CSRC, "input_prep.hip"),
            os.path.join(CSRC, "mlp_block.hip"), os.path.join(CSRC, "seq_block.hip")]
-HEADERS = [os.path.join(CSRC, "beam_math.hpp"), os.path.join(CSRC, "sizing_math.hpp"), os.path.join(CSRC, "frame_wave.hpp"), os.path.join(ROOT, "include", "openpystruct_amd.h")]
+HEADERS = [os.path.join(CSRC, "beam_math.hpp"), os.path.join(CSRC, "beam_io.hpp"), os.path.join(CSRC, "sizing_math.hpp"), os.path.join(CSRC, "frame_wave.hpp"), os.path.join(ROOT, "include", "openpystruct_amd.h")]
 ARCH = "gfx950"
 
 

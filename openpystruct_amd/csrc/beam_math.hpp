@@ -130,6 +130,13 @@ BEAM_HD Flags<RZ> node_flags(unsigned long long bits, int node) {
   const bool fv = (bits >> (2 * node)) & 1ull, ft = RZ && ((bits >> (2 * node + 1)) & 1ull);
   return Flags<RZ>{fv ? 0.0 : 1.0, fv ? 1.0 : 0.0, ft ? 0.0 : 1.0, ft ? 1.0 : 0.0};
 }
+// the same flags from two separate bit fields (bit i of v / t: u_y / theta_z of local node i fixed; at most 32 nodes)
+struct FixPair { unsigned v, t; };
+template <bool RZ>
+BEAM_HD Flags<RZ> node_flags(const FixPair& bits, int node) {
+  const bool fv = (bits.v >> node) & 1u, ft = RZ && ((bits.t >> node) & 1u);
+  return Flags<RZ>{fv ? 0.0 : 1.0, fv ? 1.0 : 0.0, ft ? 0.0 : 1.0, ft ? 1.0 : 0.0};
+}
 template <bool RZ>
 BEAM_HD Sym2 mask_node(const Sym2& s, const Flags<RZ>& c) {  // identity on fixed DOFs
   if (RZ) return Sym2{__builtin_fma(c.v, s.a, c.dv), (c.v * c.t) * s.b, __builtin_fma(c.t, s.c, c.dt)};
@@ -159,6 +166,18 @@ BEAM_HD Sym2 proj_inv(const Sym2& s, const Flags<RZ>& c, int& bad) {
   if (RZ) return Sym2{c.v * g.a, g.b, c.t * g.c};
   return Sym2{c.v * g.a, g.b, g.c};
 }
+
+// "Compute this HERE": the left-boundary accumulators S_LL, g_L and the pivot test feed nothing inside the
+// condensation loop, and the compiler, left alone, sinks all M of their updates behind the loop -- keeping every
+// iteration's operands alive (measured at M = 17: ~10 doubles per iteration, 500 live registers, AGPR copies and
+// scratch).  An empty asm that takes the value as a read-write register operand pins it to its iteration.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define BEAM_PIN_F64(x) __asm__ volatile("" : "+v"(x))
+#define BEAM_PIN_I32(x) __asm__ volatile("" : "+v"(x))
+#else
+#define BEAM_PIN_F64(x) ((void)0)
+#define BEAM_PIN_I32(x) ((void)0)
+#endif
 
 // State a lane keeps across the phases.
 template <int M>
@@ -218,15 +237,15 @@ struct IfaceRow {
 
 // The lane's own coupling to the next boundary node, constrained on both sides; lane j+1
 // receives it (transposed) as its Alow.
-template <int M, bool RZ>
-BEAM_HD Mat2 masked_cup(const SegState<M>& s, unsigned long long fixbits) {
+template <int M, bool RZ, class Bits>
+BEAM_HD Mat2 masked_cup(const SegState<M>& s, const Bits& fixbits) {
   return mask_cols(mask_rows(s.SLc, node_flags<RZ>(fixbits, 0)), node_flags<RZ>(fixbits, M));
 }
 
 // prevC, prevg: Scc, gc of lane j-1; prevCup: masked_cup of lane j-1 (all zero for lane 0).
-template <int M, bool RZ>
+template <int M, bool RZ, class Bits>
 BEAM_HD IfaceRow make_row(const SegState<M>& s, const Mat2& ownCup, const Sym2& prevC, const Vec2& prevg,
-                          const Mat2& prevCup, unsigned long long fixbits) {
+                          const Mat2& prevCup, const Bits& fixbits) {
   const Flags<RZ> c = node_flags<RZ>(fixbits, 0);
   IfaceRow r;
   r.D = mask_node(Sym2{s.SLL.a + prevC.a, s.SLL.b + prevC.b, s.SLL.c + prevC.c}, c);
@@ -326,6 +345,187 @@ BEAM_HD void seg_solve(const SegState<M>& s, const Acc& acc, const Vec2& uL, con
     }
     out.node(i, ui.x, ui.y);
     un = ui;
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// Phases A and C once more for the "fat wave" tilings (beam_fat.hip: few lanes per beam, many elements per lane,
+// ONE wave per SIMD).  Same arithmetic, statement for statement, as seg_condense / seg_solve; what differs is how
+// the inputs arrive: with a single resident wave nothing hides the LDS latency of an element's inputs, so element
+// i + 1 is requested BEFORE element i is worked on (`acc.elem(i)` returns all inputs of one element at once; the
+// fence keeps the request in front of the arithmetic and stops the compiler from hoisting every request of the
+// unrolled loop to the top).
+// Acc: elem(i) -> ElemIn for local element i in [0, M); fixbits(); fence().
+// ---------------------------------------------------------------------------------------
+struct ElemIn { double c2, c6, c12, rl, pw, mw, Ie, Fy; };
+
+
+template <int M, bool RZ, class Acc>
+BEAM_HD void seg_condense_pf(SegState<M>& s, const Acc& acc, int& bad) {
+  const auto fb = acc.fixbits();
+  ElemIn nx = acc.elem(0);
+  {
+    const ElemIn e = nx;
+    if (M > 1) nx = acc.elem(1);
+    acc.fence();
+    const ElemK k = elem_k(e.c2, e.c6, e.c12, e.Ie);
+    s.SLL = Sym2{k.kA, k.kB, k.kC};
+    s.SLc = Mat2{-k.kA, k.kB, -k.kB, k.kD};
+    s.Scc = Sym2{k.kA, -k.kB, k.kC};
+    s.gL = Vec2{e.pw + e.Fy, e.mw};
+    s.gc = Vec2{e.pw, -e.mw};
+  }
+#pragma unroll
+  for (int i = 1; i < M; ++i) {
+    const ElemIn e = nx;
+    if (i + 1 < M) nx = acc.elem(i + 1);
+    acc.fence();
+    const Flags<RZ> c = node_flags<RZ>(fb, i);
+    const ElemK k = elem_k(e.c2, e.c6, e.c12, e.Ie);
+    const double pw = e.pw, mw = e.mw;
+    const Sym2 G = proj_inv(Sym2{s.Scc.a + k.kA, s.Scc.b + k.kB, s.Scc.c + k.kC}, c, bad);
+    const Vec2 gi{s.gc.x + pw + e.Fy, s.gc.y + mw};
+    const Mat2 Kr{-k.kA, k.kB, -k.kB, k.kD};
+    s.Ginv[i] = G;
+    const Mat2 Pm = mul(s.SLc, G);
+    const Mat2 Qm = mulT(Kr, G);
+    s.SLL = sub_mulT(s.SLL, Pm, s.SLc);
+    s.gL = sub_mul(s.gL, Pm, gi);
+    s.SLc = neg_mul(Pm, Kr);
+    s.Scc = sub_mul(Sym2{k.kA, -k.kB, k.kC}, Qm, Kr);
+    s.gc = sub_mul(Vec2{pw, -mw}, Qm, gi);
+    BEAM_PIN_F64(s.SLL.a); BEAM_PIN_F64(s.SLL.b); BEAM_PIN_F64(s.SLL.c); BEAM_PIN_F64(s.gL.x); BEAM_PIN_F64(s.gL.y);
+    BEAM_PIN_I32(bad);
+  }
+}
+
+// Hs: where the right-hand-side sweep parks h_i for the back substitution: put(i, h) / get(i) -- registers, or
+// (fat tilings, to stay inside 256 VGPRs) the LDS slots that the back substitution overwrites with its results.
+// PF: how many elements ahead the inputs are requested (an iteration of these two loops is 14 / 24 FP64 instructions,
+// shorter than one LDS round trip).
+template <int M, bool RZ, int PF, class Acc, class Out, class Hs>
+BEAM_HD void seg_solve_pf(const SegState<M>& s, const Acc& acc, const Vec2& uL, const Vec2& uR, Out& out, Hs& hs) {
+  static_assert(PF >= 1 && PF <= 4, "prefetch distance");
+  {
+    ElemIn q[PF];
+#pragma unroll
+    for (int d = 0; d < PF; ++d) q[d] = acc.elem(d < M ? d : M - 1);
+    const ElemIn e0 = q[0];
+    if (PF < M) q[0] = acc.elem(PF);
+    acc.fence();
+    const ElemK k0 = elem_k(e0.c2, e0.c6, e0.c12, e0.Ie);
+    Vec2 carry = sub_mulT(Vec2{e0.pw, -e0.mw}, Mat2{-k0.kA, k0.kB, -k0.kB, k0.kD}, uL);
+#pragma unroll
+    for (int i = 1; i < M; ++i) {
+      const ElemIn e = q[i % PF];
+      if (i + PF < M) q[i % PF] = acc.elem(i + PF);
+      acc.fence();
+      const double pw = e.pw, mw = e.mw;
+      const Vec2 hi{carry.x + pw + e.Fy, carry.y + mw};
+      hs.put(i, hi);
+      if (i + 1 < M) {
+        const ElemK k = elem_k(e.c2, e.c6, e.c12, e.Ie);
+        const Vec2 y = mul(s.Ginv[i], hi);
+        carry = sub_mulT(Vec2{pw, -mw}, Mat2{-k.kA, k.kB, -k.kB, k.kD}, y);
+      }
+    }
+  }
+  Vec2 un = uR;
+  ElemIn q[PF];
+  Vec2 hq[PF];
+#pragma unroll
+  for (int d = 0; d < PF; ++d) {
+    const int i = M - 1 - d;
+    q[(M - 1 - d + PF) % PF] = acc.elem(i >= 0 ? i : 0);
+    hq[(M - 1 - d + PF) % PF] = hs.get(i >= 1 ? i : (M > 1 ? 1 : 0));
+  }
+#pragma unroll
+  for (int i = M - 1; i >= 0; --i) {
+    const ElemIn e = q[i % PF];
+    const Vec2 hi = hq[i % PF];
+    if (i - PF >= 0) q[i % PF] = acc.elem(i - PF);
+    if (i - PF >= 1) hq[i % PF] = hs.get(i - PF);
+    acc.fence();
+    const ElemK k = elem_k(e.c2, e.c6, e.c12, e.Ie);
+    Vec2 ui;
+    if (i > 0) {
+      ui = mul(s.Ginv[i], sub_mul(hi, Mat2{-k.kA, k.kB, -k.kB, k.kD}, un));
+    } else {
+      ui = uL;
+    }
+    {
+      const double rl = e.rl, mw = e.mw;
+      const double chord = (un.x - ui.x) * rl;
+      const double p1 = ui.y - chord, p2 = un.y - chord;
+      const double q1 = __builtin_fma(k.kC, p1, __builtin_fma(k.kD, p2, -mw));
+      const double q2 = __builtin_fma(k.kD, p1, __builtin_fma(k.kC, p2, mw));
+      out.elem(i, __builtin_fma(q1 + q2, rl, -e.pw), q1);
+    }
+    out.node(i, ui.x, ui.y);
+    un = ui;
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// Interface solve for FEW rows (fat tilings: P = 6): every lane publishes its part of the interface system once,
+// every lane of the beam reads all P parts back (LDS broadcast reads) and runs the block-Thomas elimination over the P
+// rows by itself.  Same SPD block-tridiagonal system as make_row builds, same update formulas as cr_absorb, but
+// natural order and ONE exchange round instead of 2 log2 P + 2; the P lanes of a beam execute the identical
+// instruction sequence on identical data, so their boundary displacements agree bit for bit (what the force
+// recovery needs, see the cyclic-reduction note above).
+//   row k: K[k,k-1] = cup_{k-1}^T, K[k,k] = Dl_k + Dr_{k-1}, K[k,k+1] = cup_k, rhs fl_k + fr_{k-1}
+// ---------------------------------------------------------------------------------------
+struct alignas(16) IfacePiece {
+  Sym2 Dl; Vec2 fl;   // the lane's own left-boundary block and load, constrained (identity on fixed DOFs included)
+  Sym2 Dr; Vec2 fr;   // what it adds to the NEXT lane's left boundary node (its own right boundary), constrained
+  Mat2 cup;           // coupling left boundary -> right boundary, constrained on both sides
+};
+template <int M, bool RZ, class Bits>
+BEAM_HD IfacePiece make_piece(const SegState<M>& s, const Bits& fixbits) {
+  const Flags<RZ> c0 = node_flags<RZ>(fixbits, 0), cM = node_flags<RZ>(fixbits, M);
+  IfacePiece p;
+  p.Dl = mask_node(s.SLL, c0);
+  p.fl = mask_vec(s.gL, c0);
+  p.Dr = RZ ? Sym2{cM.v * s.Scc.a, (cM.v * cM.t) * s.Scc.b, cM.t * s.Scc.c} : Sym2{cM.v * s.Scc.a, cM.v * s.Scc.b, s.Scc.c};
+  p.fr = mask_vec(s.gc, cM);
+  p.cup = mask_cols(mask_rows(s.SLc, c0), cM);
+  return p;
+}
+// Rd: piece(k) -> IfacePiece of lane k of the reader's beam; cup(k) -> its coupling alone; fence().
+// The last lane's Dr / fr / cup belong to the clamped node behind the beam (u = 0) and are never read.
+template <int P, class Rd, class Bad>
+BEAM_HD void iface_thomas(const Rd& rd, Vec2 (&u)[P], Bad& bad) {
+  Sym2 G[P];
+  Vec2 fp[P];
+  IfacePiece nx = rd.piece(0);
+  Sym2 Dr{0.0, 0.0, 0.0};
+  Vec2 fr{0.0, 0.0};
+  Mat2 cp{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int k = 0; k < P; ++k) {
+    const IfacePiece e = nx;
+    if (k + 1 < P) nx = rd.piece(k + 1);
+    rd.fence();
+    Sym2 D{e.Dl.a + Dr.a, e.Dl.b + Dr.b, e.Dl.c + Dr.c};
+    Vec2 f{e.fl.x + fr.x, e.fl.y + fr.y};
+    if (k > 0) {
+      const Mat2 A{cp.a, cp.c, cp.b, cp.d};        // K[k,k-1] = cup_{k-1}^T
+      const Mat2 W = mul(A, G[k - 1]);
+      D = sub_mulT(D, W, A);
+      f = sub_mul(f, W, fp[k - 1]);
+    }
+    G[k] = inv_spd(D, bad);
+    fp[k] = f;
+    Dr = e.Dr; fr = e.fr; cp = e.cup;
+  }
+  u[P - 1] = mul(G[P - 1], fp[P - 1]);
+  Mat2 cn = P > 1 ? rd.cup(P - 2) : Mat2{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int k = P - 2; k >= 0; --k) {
+    const Mat2 c = cn;
+    if (k > 0) cn = rd.cup(k - 1);
+    rd.fence();
+    u[k] = mul(G[k], sub_mul(fp[k], c, u[k + 1]));
   }
 }
 

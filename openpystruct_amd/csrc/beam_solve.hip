@@ -18,34 +18,14 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include <mutex>
 #include <type_traits>
 
 #include "../../include/openpystruct_amd.h"
-#include "beam_math.hpp"
-#include "sizing_math.hpp"
+#include "beam_io.hpp"
 
 namespace opsamd {
 
-struct BeamParams {
-  int B, Ne;
-  const double* x;  long x_bs;
-  const double* E;  long E_bs;
-  const double* I;  long I_bs;
-  const uint8_t* fix; long fix_bs;
-  const double* Fy; long Fy_bs;
-  const double* wy; long wy_bs;
-  double* v; double* theta; double* V; double* M;
-  int32_t* status;
-  const float* I32;            // sizing epochs: the inertias are float32 rows (dense, stride Ne), widened while staging; I unused
-  const uint8_t* active;       // optional [B]: a wave whose beams are all inactive returns at once (sizing epochs)
-  int stream_out;              // OPS_AMD_TILING_STREAM_OUT: non-temporal output stores (buffers that will not be re-read from cache)
-  int f32_forces;              // V / M point to float rows (the sizing loop rounds them to float32 anyway, SingleCore.py:189-190)
-  // host-derived: rows of I/Fy/outputs are dense and every wave's chunk is 16-byte aligned, so
-  // the wave moves its beams as one flat run of 16-byte accesses; magic numbers for idx / Ne, idx / N
-  int dense;
-  unsigned long long* trace;   // diagnostic builds (-DOPS_AMD_TRACE) only
-  unsigned magic_ne, magic_n;
-};
 
 // lane-local view of the LDS-staged inputs (see beam_math.hpp "Acc")
 struct LdsAcc {
@@ -86,110 +66,6 @@ __device__ __forceinline__ void lds_store_desc(double* slot, unsigned last, cons
   for (int i = M - 1; i >= 0; --i) slot[(unsigned)i < last ? (unsigned)i : last] = val[i];
 }
 
-// ---- cross-lane exchange inside the P-lane group of a beam ------------------------------
-// from_minus<S>(x): value of lane-S (0.0 when j < S); from_plus<S>(x): value of lane+S (0.0 when
-// j + S >= P).  P <= 16: the group lies inside one 16-lane DPP row, so the fetch is a pair of
-// v_mov_b32 with a row_shr / row_shl modifier (bound_ctrl writes 0 for lanes shifted in from outside
-// the row); no LDS crossbar, no wait.  P = 8 shares its row with a second beam and masks the lanes
-// that would read across the group edge.  P >= 32: ds_bpermute (__shfl).
-template <int CTRL>
-__device__ __forceinline__ double dpp_mov(double x) {
-  const unsigned long long u = __builtin_bit_cast(unsigned long long, x);
-  const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)u, CTRL, 0xF, 0xF, true);
-  const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(u >> 32), CTRL, 0xF, 0xF, true);
-  return __builtin_bit_cast(double, ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
-}
-
-template <int P>
-struct Xch {
-  template <int S>
-  static __device__ __forceinline__ double from_minus(double x, int lane, int j) {
-    if constexpr (P <= 16 && S < 16) {
-      const double r = dpp_mov<0x110 + S>(x);  // row_shr:S
-      if constexpr (P < 16) return j >= S ? r : 0.0;
-      return r;
-    } else {
-      const double r = __shfl(x, lane - S, 64);
-      return j >= S ? r : 0.0;
-    }
-  }
-  template <int S>
-  static __device__ __forceinline__ double from_plus(double x, int lane, int j) {
-    if constexpr (P <= 16 && S < 16) {
-      const double r = dpp_mov<0x100 + S>(x);  // row_shl:S
-      if constexpr (P < 16) return j + S < P ? r : 0.0;
-      return r;
-    } else {
-      const double r = __shfl(x, lane + S, 64);
-      return j + S < P ? r : 0.0;
-    }
-  }
-  template <int S> static __device__ __forceinline__ Sym2 from_minus(const Sym2& s, int l, int j) {
-    return Sym2{from_minus<S>(s.a, l, j), from_minus<S>(s.b, l, j), from_minus<S>(s.c, l, j)};
-  }
-  template <int S> static __device__ __forceinline__ Mat2 from_minus(const Mat2& m, int l, int j) {
-    return Mat2{from_minus<S>(m.a, l, j), from_minus<S>(m.b, l, j), from_minus<S>(m.c, l, j), from_minus<S>(m.d, l, j)};
-  }
-  template <int S> static __device__ __forceinline__ Vec2 from_minus(const Vec2& u, int l, int j) {
-    return Vec2{from_minus<S>(u.x, l, j), from_minus<S>(u.y, l, j)};
-  }
-  template <int S> static __device__ __forceinline__ Sym2 from_plus(const Sym2& s, int l, int j) {
-    return Sym2{from_plus<S>(s.a, l, j), from_plus<S>(s.b, l, j), from_plus<S>(s.c, l, j)};
-  }
-  template <int S> static __device__ __forceinline__ Mat2 from_plus(const Mat2& m, int l, int j) {
-    return Mat2{from_plus<S>(m.a, l, j), from_plus<S>(m.b, l, j), from_plus<S>(m.c, l, j), from_plus<S>(m.d, l, j)};
-  }
-  template <int S> static __device__ __forceinline__ Vec2 from_plus(const Vec2& u, int l, int j) {
-    return Vec2{from_plus<S>(u.x, l, j), from_plus<S>(u.y, l, j)};
-  }
-};
-
-// cyclic reduction over the P rows of a beam (beam_math.hpp): levels S = 1, 2, 4, ..., P/2.  Every lane runs
-// the exchange (a DPP / bpermute fetch must not sit inside a divergent region: disabled source lanes read as 0);
-// only the rows that are active at the level apply the update -- exec-masked, the others keep their frozen row.
-template <int P, int S>
-__device__ __forceinline__ void cr_forward(IfaceRow& row, int lane, int j, int& bad) {
-  if constexpr (S < P) {
-    using X = Xch<P>;
-    constexpr bool LAST = (2 * S >= P);
-    const Sym2 G = inv_spd(row.D, bad);
-    const bool act = cr_active(j, S);
-    {   // the two sides one after the other: half the exchange registers live at a time
-      const Sym2 Gm = X::template from_minus<S>(G, lane, j);
-      const Vec2 fm = X::template from_minus<S>(row.f, lane, j);
-      Mat2 Am{0, 0, 0, 0};
-      if constexpr (!LAST) Am = X::template from_minus<S>(row.Alow, lane, j);
-      const Vec2 fp = X::template from_plus<S>(row.f, lane, j);      // fetched before the minus side rewrites row.f
-      if (act) cr_absorb<LAST>(row.D, row.f, row.Alow, Gm, Am, fm);
-      const Sym2 Gp = X::template from_plus<S>(G, lane, j);
-      Mat2 Cp{0, 0, 0, 0};
-      if constexpr (!LAST) Cp = X::template from_plus<S>(row.Cup, lane, j);
-      if (act) cr_absorb<LAST>(row.D, row.f, row.Cup, Gp, Cp, fp);
-    }
-    cr_forward<P, 2 * S>(row, lane, j, bad);
-  }
-}
-// back substitution from the top level down: the rows frozen at level S take their neighbours' displacements
-template <int P, int S>
-__device__ __forceinline__ void cr_backward(const IfaceRow& row, const Sym2& G, Vec2& u, int lane, int j) {
-  if constexpr (S >= 1) {
-    using X = Xch<P>;
-    const Vec2 um = X::template from_minus<S>(u, lane, j);
-    const Vec2 up = X::template from_plus<S>(u, lane, j);
-    if (cr_frozen(j, S)) u = cr_back(row, G, um, up);
-    cr_backward<P, S / 2>(row, G, u, lane, j);
-  }
-}
-
-// Orders LDS traffic inside ONE wavefront (the workgroup is a single wave): LDS instructions of a wave
-// execute in order, so all that is needed is to stop the compiler from moving LDS accesses across this
-// point and to have earlier LDS reads landed in registers.  Unlike __syncthreads() it does not wait for
-// outstanding global stores (vmcnt), which would serialise the store phases behind HBM write latency.
-__device__ __forceinline__ void wave_lds_fence() {
-  __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0) only
-  __asm__ volatile("" ::: "memory");
-  __builtin_amdgcn_wave_barrier();
-}
 
 // Stages 2-4 for one lane: condensation, interface reduction, interior solve.  RZ: see Flags<RZ>.
 template <int P, int M, bool RZ>
@@ -242,37 +118,6 @@ constexpr int waves_per_simd(int P, int M, bool shared) {
        : (P == 64 && M == 4) ? 3 : 1;
 }
 
-// ---- buffer-resource I/O: hardware bounds checking instead of tail branches --------------------
-// A raw buffer descriptor (base, num_records in bytes) makes out-of-range lanes of a buffer_load return 0
-// and out-of-range lanes of a buffer_store do nothing; offsets are 32-bit, the base sits in SGPRs.
-typedef int v4i __attribute__((ext_vector_type(4)));
-typedef int v2i __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned bytes) {
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
-}
-__device__ __forceinline__ double2 buf_load_d2(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
-#ifndef OPS_AMD_LD_AUX
-#define OPS_AMD_LD_AUX 0
-#endif
-  const v4i v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, OPS_AMD_LD_AUX);   // row loads (A/B: -DOPS_AMD_LD_AUX=2 nt)
-  return __builtin_bit_cast(double2, v);
-}
-__device__ __forceinline__ double buf_load_d(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
-  const v2i v = __builtin_amdgcn_raw_buffer_load_b64(r, (int)byte_off, 0, 0);
-  return __builtin_bit_cast(double, v);
-}
-// Output stores carry a cache policy (the `aux` immediate: 16 = sc1 write-through, 2 = nt).  Plain stores
-// leave up to an L2's worth of dirty lines behind that the end-of-kernel release has to write back; measured
-// per 10^4-beam launch (A/B, same device, profiles/r01_notes.md): plain 16.4 us, sc1 14.35, sc0+sc1 14.4,
-// nt 15.1; at 2^20 beams nt is the best (969 vs 983 sc1 vs 990 us plain).
-template <int AUX>
-__device__ __forceinline__ void buf_store_d2(__amdgpu_buffer_rsrc_t r, unsigned byte_off, double2 x) {
-  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i, x), r, (int)byte_off, 0, AUX);
-}
-template <int AUX>
-__device__ __forceinline__ void buf_store_d(__amdgpu_buffer_rsrc_t r, unsigned byte_off, double x) {
-  __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2i, x), r, (int)byte_off, 0, AUX);
-}
 
 // SHARED: x, E and wy are the same for every beam (strides 0): one element table per workgroup.
 // DENSE : rows of I / Fy / outputs are contiguous and every wave's run is 16-byte aligned (host-checked):
@@ -616,6 +461,16 @@ static const Tiling kTilings[] = {
 };
 static const int kNumTilings = sizeof(kTilings) / sizeof(kTilings[0]);
 
+// Default use of a row-staged tiling (measured on one box, profiles/r03_notes.md; us per launch, classic -> rows):
+// the 16-lane rows kernel wins or ties at every batch size (10^4 beams 13.9 -> 12.1, 3e4 33.2 -> 29.4, 1e5 94 -> 93,
+// 2^20 1022 -> 978 with streaming stores), the 8-lane ones never beat it.  The fat-wave tiling (P = 6) runs a third fewer
+// instructions per SIMD at 10^4 beams, but with ONE wave per SIMD every wave of the chip is in the same phase and the
+// store phase (32 MB, ~3.8 us from cache) overlaps nothing: 15.1 us.  It stays an explicit tiling.
+static bool fat_default(const FatTiling& f, int B, int Ne) {
+  (void)B;
+  return f.P == 16 && Ne + 1 <= f.P * f.M;
+}
+
 static const Tiling* choose_tiling(int B, int Ne, int tiling) {
   const int N = Ne + 1;
   if (tiling != 0) {
@@ -631,6 +486,53 @@ static const Tiling* choose_tiling(int B, int Ne, int tiling) {
   for (int t = 0; t < kNumTilings; ++t)
     if (kTilings[t].P * kTilings[t].M >= N) return &kTilings[t];
   return nullptr;
+}
+
+// Row-staged tilings (beam_fat.hip).  P = 6 (the fat-wave tiling) exists only there; P = 16 / 8 exist in both files and
+// an explicit `tiling` picks the beam_fat.hip variant with OPS_AMD_TILING_ROWS.  The default dispatch (tiling 0) uses one
+// where fat_default says so.
+static const FatTiling* choose_fat(int B, int Ne, int tiling) {
+  const int N = Ne + 1;
+  const bool rows = (tiling & OPS_AMD_TILING_ROWS) != 0;
+  tiling &= ~OPS_AMD_TILING_ROWS;
+  for (int t = 0; t < kNumFatTilings; ++t) {
+    const FatTiling& f = kFatTilings[t];
+    const bool serves = f.P * f.M >= N;
+    if (tiling == f.P && (rows || f.P == 6)) return serves ? &f : nullptr;
+    if (tiling == 0 && !rows && serves && fat_default(f, B, Ne)) return &f;
+  }
+  return nullptr;
+}
+static bool is_fat_tiling(int tiling) { return tiling == 6 || (tiling & OPS_AMD_TILING_ROWS) != 0; }
+
+// ---- automatic cache policy of the result stores ---------------------------------------------------------------
+// Write-through (sc1) stores are the best when the result buffers sit in the 256 MiB Infinity Cache and the worst when
+// they do not (10^4 beams: 13.8 / 18.4 us against 15.4 / 15.8 us with non-temporal stores, profiles/r02_notes.md).  The
+// kernel cannot see residency; the library can estimate it: it remembers when (in bytes moved by its own launches) each
+// result buffer was last written.  A buffer is taken as resident if the traffic since then plus this call's own bytes
+// fit the cache: a caller that re-solves into the same buffers gets sc1, one that cycles through more output than the
+// cache holds -- or a single launch bigger than the cache -- gets nt, no flag needed (OPS_AMD_TILING_STREAM_OUT still
+// forces nt).  Under HIP-graph capture the choice made at capture time is what replays.
+struct OutSeen { const void* p; unsigned long long stamp; };
+static std::mutex g_seen_mu;
+static OutSeen g_seen[64];
+static unsigned g_seen_pos = 0;
+static unsigned long long g_traffic = 0;
+static bool results_cache_resident(const void* out, unsigned long long call_bytes) {
+  constexpr unsigned long long kFits = 224ull << 20;
+  std::lock_guard<std::mutex> lock(g_seen_mu);
+  bool resident = false, found = false;
+  for (OutSeen& e : g_seen) {
+    if (e.p == out) {
+      resident = (g_traffic - e.stamp) + call_bytes <= kFits;
+      e.stamp = g_traffic + call_bytes;
+      found = true;
+      break;
+    }
+  }
+  if (!found) g_seen[g_seen_pos++ % 64] = OutSeen{out, g_traffic + call_bytes};
+  g_traffic += call_bytes;
+  return resident;
 }
 
 static thread_local char g_last_error[256] = {0};
@@ -683,7 +585,10 @@ int ops_amd_max_elements(void) { return 64 * 16 - 1; }
 const char* ops_amd_last_error(void) { return g_last_error; }
 
 const char* ops_beam_solve_kernel_name(int B, int Ne, int tiling) {
-  const Tiling* t = choose_tiling(B, Ne, tiling & ~OPS_AMD_TILING_STREAM_OUT);
+  tiling &= ~OPS_AMD_TILING_STREAM_OUT;
+  if (const FatTiling* f = choose_fat(B, Ne, tiling)) return f->name;   // shared geometry, dense rows (what the name is asked for)
+  if (is_fat_tiling(tiling)) return "";
+  const Tiling* t = choose_tiling(B, Ne, tiling & ~OPS_AMD_TILING_ROWS);
   return t ? t->name_shared : "";
 }
 
@@ -700,10 +605,26 @@ static int solve_impl(int B, int Ne, const double* x, long x_bstride, const doub
       (E_bstride != 0 && E_bstride < Ne) || (wy_bstride != 0 && wy_bstride < Ne))
     return OPS_AMD_ERR_INVALID_ARG;
   if (Ne > ops_amd_max_elements()) return OPS_AMD_ERR_UNSUPPORTED;
-  const int stream_out = (tiling & OPS_AMD_TILING_STREAM_OUT) ? 1 : 0;
+  int stream_out = (tiling & OPS_AMD_TILING_STREAM_OUT) ? 1 : 0;
   tiling &= ~OPS_AMD_TILING_STREAM_OUT;
-  const Tiling* t = choose_tiling(B, Ne, tiling);
-  if (!t) return tiling ? OPS_AMD_ERR_INVALID_ARG : OPS_AMD_ERR_UNSUPPORTED;
+  if (!sz && !f32_forces) {   // full-precision result rows: 4 925 B (or 3 309 B, forces only) per solve
+    const unsigned long long bytes = (unsigned long long)B * (v ? 4925ull : 3309ull) * (unsigned long long)Ne / 100ull;
+    if (!results_cache_resident(V, bytes)) stream_out = 1;
+  }
+  const bool shared = (x_bstride == 0 && E_bstride == 0 && wy_bstride == 0);
+  const uintptr_t align_bits = (uintptr_t)I | (uintptr_t)Fy | (uintptr_t)v | (uintptr_t)theta | (uintptr_t)V | (uintptr_t)M | (sz ? 2 * (uintptr_t)sz->I : 0);
+  const bool rows_dense = (I_bstride == Ne) && (Fy_bstride == Ne + 1) && ((align_bits & 15u) == 0);
+  // fat-wave tilings: shared geometry and constraint mask, plain double-precision solve (rows move one by one: any
+  // stride, 8-byte alignment)
+  const FatTiling* fat = nullptr;
+  {
+    const bool fat_ok = shared && fix_bstride == 0 && !sz && !active && !f32_forces;
+    const FatTiling* f = choose_fat(B, Ne, tiling);
+    if (f && fat_ok) fat = f;
+    else if (is_fat_tiling(tiling)) return f ? OPS_AMD_ERR_UNSUPPORTED : OPS_AMD_ERR_INVALID_ARG;
+  }
+  const Tiling* t = fat ? nullptr : choose_tiling(B, Ne, tiling & ~OPS_AMD_TILING_ROWS);
+  if (!t && !fat) return tiling ? OPS_AMD_ERR_INVALID_ARG : OPS_AMD_ERR_UNSUPPORTED;
 
   BeamParams p{B, Ne, x, x_bstride, E, E_bstride, I, I_bstride, fix, fix_bstride, Fy, Fy_bstride,
                wy, wy_bstride, v, theta, V, M, status, sz ? sz->I : nullptr, active, stream_out, f32_forces, 0, nullptr, 0u, 0u};
@@ -711,18 +632,16 @@ static int solve_impl(int B, int Ne, const double* x, long x_bstride, const doub
   { const char* e = getenv("OPS_AMD_TRACE_PTR"); if (e) p.trace = (unsigned long long*)strtoull(e, nullptr, 0); }
 #endif
   {
-    const int bpw = 64 / t->P;
+    const int bpw = 64 / (fat ? fat->P : t->P);
     // 16-byte aligned rows (8-byte for the float32 inertias of the sizing epoch, which are read in 8-byte pairs)
-    const uintptr_t bits = (uintptr_t)I | (uintptr_t)Fy | (uintptr_t)v | (uintptr_t)theta | (uintptr_t)V | (uintptr_t)M | (sz ? 2 * (uintptr_t)sz->I : 0);
-    p.dense = (I_bstride == Ne) && (Fy_bstride == Ne + 1) && ((bits & 15u) == 0) &&
-              ((bpw * Ne) % 2 == 0) && ((bpw * (Ne + 1)) % 2 == 0);
+    p.dense = rows_dense && ((bpw * Ne) % 2 == 0) && ((bpw * (Ne + 1)) % 2 == 0);
     p.magic_ne = ((1u << 20) + (unsigned)Ne - 1u) / (unsigned)Ne;
     p.magic_n = ((1u << 20) + (unsigned)Ne) / (unsigned)(Ne + 1);
   }
-  const bool shared = (x_bstride == 0 && E_bstride == 0 && wy_bstride == 0);
   hipStream_t s = (hipStream_t)stream;
   hipError_t err = hipSuccess;
-  if (sz) {
+  if (fat) err = launch_fat(p, fat->P, fat->M, s);
+  else if (sz) {
     if (t->P == 8 && t->M == 13) err = launch_sizing<8, 13>(p, *sz, shared, s);
     else if (t->P == 16 && t->M == 7) err = launch_sizing<16, 7>(p, *sz, shared, s);
     else if (t->P == 32 && t->M == 4) err = launch_sizing<32, 4>(p, *sz, shared, s);

@@ -14,14 +14,14 @@ d = sys.argv[1]
 res = {"dir": d}
 for f in glob.glob(os.path.join(d, "trace", "*", "*_kernel_stats.csv")):
     for r in csv.DictReader(open(f)):
-        if "beam_solve_kernel" in r["Name"]:
+        if "beam_solve_kernel" in r["Name"] or "beam_rows_kernel" in r["Name"]:
             res["kernel"] = r["Name"]
             res["trace"] = {k: float(r[k]) for k in ("Calls", "TotalDurationNs", "AverageNs", "MinNs", "MaxNs", "StdDev")}
 pmc = defaultdict(list)
 meta = {}
 for f in glob.glob(os.path.join(d, "pmc_*", "*", "*_counter_collection.csv")):
     for r in csv.DictReader(open(f)):
-        if "beam_solve_kernel" in r["Kernel_Name"]:
+        if "beam_solve_kernel" in r["Kernel_Name"] or "beam_rows_kernel" in r["Kernel_Name"]:
             pmc[r["Counter_Name"]].append(float(r["Counter_Value"]))
             meta = {k: r[k] for k in ("Grid_Size", "Workgroup_Size", "LDS_Block_Size", "VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "Scratch_Size")}
 res["dispatch"] = meta

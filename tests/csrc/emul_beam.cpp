@@ -29,13 +29,32 @@ struct HostAcc {
   unsigned long long fixbits() const { return bits; }
   void fence() const {}
 };
+// the fat-wave tilings' accessors (beam_fat.hip): one element's inputs per call, flags from two bit fields, h_i parked
+struct HostAccPf {
+  const double *t2, *t6, *t12, *trl, *tpw, *tmw, *sI, *sF;
+  FixPair bits;
+  ElemIn elem(int i) const { return ElemIn{t2[i], t6[i], t12[i], trl[i], tpw[i], tmw[i], sI[i], sF[i]}; }
+  FixPair fixbits() const { return bits; }
+  void fence() const {}
+};
+struct HostIface {
+  const IfacePiece* grp;
+  IfacePiece piece(int k) const { return grp[k]; }
+  Mat2 cup(int k) const { return grp[k].cup; }
+  void fence() const {}
+};
+struct HostH {
+  std::vector<Vec2> h;
+  void put(int i, const Vec2& v) { h[i] = v; }
+  Vec2 get(int i) const { return h[i]; }
+};
 struct HostOut {
   double *v, *th, *V, *Mz;
   void elem(int i, double a, double b) { V[i] = a; Mz[i] = b; }
   void node(int i, double a, double b) { v[i] = a; th[i] = b; }
 };
 
-template <int P, int M, bool RZ>
+template <int P, int M, bool RZ, bool FAT = false>
 int solve_one_rz(int Ne, const double* x, const double* E, bool E_pe, const double* I, const uint8_t* fix,
               const double* Fy, const double* wy, bool w_pe, double* v, double* th, double* V, double* Mz) {
   constexpr int PM = P * M;
@@ -56,14 +75,29 @@ int solve_one_rz(int Ne, const double* x, const double* E, bool E_pe, const doub
   for (int n = 0; n < N; ++n) { sF[n] = Fy[n]; sfix[n] = fix[n] & 3; }
   std::vector<SegState<M>> st(P);
   std::vector<HostAcc> acc(P);
+  std::vector<HostAccPf> accp(P);
   int bad = 0;
   for (int j = 0; j < P; ++j) {
     const int e0 = j * M;
     acc[j] = HostAcc{&tab[0 * PM + e0], &tab[1 * PM + e0], &tab[2 * PM + e0], &tab[3 * PM + e0],
                      &tab[4 * PM + e0], &tab[5 * PM + e0], &sI[e0], &sF[e0], 0};
-    for (int i = 0; i <= M; ++i) acc[j].bits |= (unsigned long long)sfix[e0 + i] << (2 * i);
-    seg_condense<M, RZ>(st[j], acc[j], bad);
+    accp[j] = HostAccPf{acc[j].t2, acc[j].t6, acc[j].t12, acc[j].trl, acc[j].tpw, acc[j].tmw, acc[j].sI, acc[j].sF, FixPair{0u, 0u}};
+    for (int i = 0; i <= M; ++i) {
+      acc[j].bits |= (unsigned long long)sfix[e0 + i] << (2 * i);
+      accp[j].bits.v |= (unsigned)(sfix[e0 + i] & 1) << i;
+      accp[j].bits.t |= (unsigned)((sfix[e0 + i] >> 1) & 1) << i;
+    }
+    if (FAT) seg_condense_pf<M, RZ>(st[j], accp[j], bad);
+    else seg_condense<M, RZ>(st[j], acc[j], bad);
   }
+  std::vector<Vec2> u(P, Vec2{0, 0});
+  if (FAT) {   // beam_fat.hip: publish the pieces, block-Thomas over the P rows in natural order
+    std::vector<IfacePiece> pieces(P);
+    for (int j = 0; j < P; ++j) pieces[j] = make_piece<M, RZ>(st[j], accp[j].bits);
+    Vec2 uu[P];
+    iface_thomas<P>(HostIface{pieces.data()}, uu, bad);
+    for (int j = 0; j < P; ++j) u[j] = uu[j];
+  } else {
   std::vector<IfaceRow> row(P), nxt(P);
   std::vector<Mat2> cup(P);
   const Sym2 z3{0, 0, 0}; const Mat2 z4{0, 0, 0, 0}; const Vec2 z2{0, 0};
@@ -87,30 +121,37 @@ int solve_one_rz(int Ne, const double* x, const double* E, bool E_pe, const doub
     }
     row = nxt;
   }
-  std::vector<Vec2> u(P, z2);
   std::vector<Sym2> Gf(P);
   for (int j = 0; j < P; ++j) Gf[j] = inv_spd(row[j].D, bad);
   u[0] = mul(Gf[0], row[0].f);
-  for (int s = P / 2; s >= 1; s /= 2)
+  int top = 1;
+  while (2 * top < P) top *= 2;   // cr_top_level(P)
+  for (int s = top; s >= 1; s /= 2)
     for (int j = 0; j < P; ++j)
       if (cr_frozen(j, s)) u[j] = cr_back(row[j], Gf[j], j >= s ? u[j - s] : z2, j + s < P ? u[j + s] : z2);
+  }
   for (int j = 0; j < P; ++j) {
     const int e0 = j * M;
     HostOut out{&ov[e0], &ot[e0], &oV[e0], &oM[e0]};
-    seg_solve<M, RZ>(st[j], acc[j], u[j], j + 1 < P ? u[j + 1] : z2, out);
+    if (FAT) {
+      HostH hs{std::vector<Vec2>(M)};
+      seg_solve_pf<M, RZ, 3>(st[j], accp[j], u[j], j + 1 < P ? u[j + 1] : Vec2{0, 0}, out, hs);
+    } else {
+      seg_solve<M, RZ>(st[j], acc[j], u[j], j + 1 < P ? u[j + 1] : Vec2{0, 0}, out);
+    }
   }
   for (int n = 0; n < N; ++n) { v[n] = bad ? NAN : ov[n]; th[n] = bad ? NAN : ot[n]; }
   for (int e = 0; e < Ne; ++e) { V[e] = bad ? NAN : oV[e]; Mz[e] = bad ? NAN : oM[e]; }
   return bad;
 }
 
-template <int P, int M>
+template <int P, int M, bool FAT = false>
 int solve_one(int Ne, const double* x, const double* E, bool E_pe, const double* I, const uint8_t* fix,
               const double* Fy, const double* wy, bool w_pe, double* v, double* th, double* V, double* Mz) {
   bool rz = false;   // the kernel takes the general path when any lane of the wave sees a fixed rotation
   for (int n = 0; n <= Ne; ++n) rz |= (fix[n] & 2) != 0;
-  return rz ? solve_one_rz<P, M, true>(Ne, x, E, E_pe, I, fix, Fy, wy, w_pe, v, th, V, Mz)
-            : solve_one_rz<P, M, false>(Ne, x, E, E_pe, I, fix, Fy, wy, w_pe, v, th, V, Mz);
+  return rz ? solve_one_rz<P, M, true, FAT>(Ne, x, E, E_pe, I, fix, Fy, wy, w_pe, v, th, V, Mz)
+            : solve_one_rz<P, M, false, FAT>(Ne, x, E, E_pe, I, fix, Fy, wy, w_pe, v, th, V, Mz);
 }
 }  // namespace
 
@@ -129,6 +170,9 @@ extern "C" int emul_beam_solve_batched_f64(int P, int M, int B, int Ne, const do
                           V + (long)b * Ne, Mz + (long)b * Ne);
     CASE(8, 13) CASE(16, 7) CASE(32, 4) CASE(64, 2) CASE(64, 4) CASE(64, 8) CASE(64, 16)
 #undef CASE
+    if (P == 6 && M == 17)   // fat-wave tiling: the prefetching phases, two-field flags, parked h_i
+      r = solve_one<6, 17, true>(Ne, x + b * x_bs, E + b * E_bs, E_bs != 0, I + b * I_bs, fix + b * fix_bs, Fy + b * Fy_bs,
+                                 wy + b * wy_bs, wy_bs != 0, v + (long)b * N, theta + (long)b * N, V + (long)b * Ne, Mz + (long)b * Ne);
     if (r == -2) return -2;
     if (status) status[b] = r;
   }

@@ -6,7 +6,10 @@ import subprocess
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-TILINGS = [(8, 13), (16, 7), (32, 4), (64, 2), (64, 4), (64, 8), (64, 16)]
+# (lanes per beam, elements per lane) of every compiled tiling; (6, 17) is the fat-wave tiling of beam_fat.hip
+# (shared geometry + one constraint mask only)
+TILINGS = [(6, 17), (8, 13), (16, 7), (32, 4), (64, 2), (64, 4), (64, 8), (64, 16)]
+FAT_P = (6,)
 _emul = None
 
 
