@@ -272,8 +272,9 @@ int ops_fused_bn_act_bwd(int B, int F, const void* dy, int act_is_bf16, const vo
 
 /* Batch assembly of the surrogate training loops in one launch: out[b, :] = X[idx[b], :] + (*sigma) * N(0, 1) for b < B, X
  * [N,F] float32 (F = product of the trailing dimensions), idx [B] int64, out float32 or bfloat16 -- DataLoader gather + input
- * noise + autocast cast (PINN_MultiCase.py:743-756).  sigma: device scalar (NULL or 0: no noise); counter: one uint64 of
- * device memory advanced by the call (NULL: a fixed stream). */
+ * noise + autocast cast (PINN_MultiCase.py:743-756).  sigma: device scalar (NULL or 0: no noise); counter: TWO uint64 of
+ * zero-initialised device memory ([0] = calls so far, advanced once per call by the last workgroup to finish, [1] = its
+ * tally; csrc/call_counter.hpp) (NULL: a fixed stream). */
 int ops_gather_rows_noise_f32(int B, long F, const float* X, const long long* idx, const float* sigma, unsigned long long seed,
                               unsigned long long* counter, void* out, int out_is_bf16, void* stream);
 

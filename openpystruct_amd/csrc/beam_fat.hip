@@ -146,8 +146,11 @@ __device__ __forceinline__ unsigned mask_window(unsigned long long lo, unsigned 
 }
 
 // FAT  (P = 6): four row sets, one wave per SIMD.      LEAN (P = 16 / 8): two row sets, WPS waves per SIMD.
-template <int P, int M, int WPS, bool FAT>
-__global__ __launch_bounds__(64, WPS) void beam_rows_kernel(const BeamParams p) {
+// SIZING (LEAN only): the inertias are the optimiser's float32 rows; after the solve the wave runs the optimiser epoch of
+// its cases on the shears / moments it holds in LDS (sizing_math.hpp) instead of storing them: the generator's fused
+// solve + step (SingleCore.py:174-219), as beam_solve.hip's beam_sizing_epoch_kernel.
+template <int P, int M, int WPS, bool FAT, bool SIZING>
+__device__ __forceinline__ void beam_rows_body(const BeamParams& p, const SizingArgs* sz) {
   constexpr int BPW = 64 / P;       // beams per wavefront
   constexpr int LIVE = BPW * P;     // lanes that own a segment
   constexpr int PM = P * M;         // padded nodes per beam (>= N); a row is one wave instruction of 16-byte lanes
@@ -177,6 +180,11 @@ __global__ __launch_bounds__(64, WPS) void beam_rows_kernel(const BeamParams p) 
   const int Ne = p.Ne, N = p.Ne + 1;
   const long beam0 = (long)blockIdx.x * BPW;
   const int nb = (p.B - beam0 < BPW) ? (int)(p.B - beam0) : BPW;   // live beams of this wave
+  if (p.active) {                   // wave-uniform: finished cases of a sizing run cost one scalar load each
+    unsigned any = 0;
+    for (int b = 0; b < nb; ++b) any |= p.active[beam0 + b];
+    if (!any) return;
+  }
 
   // ---- stage 1a: every global load is issued before anything waits; cache-resident ones first ----
   double tx0[NT], tx1[NT];
@@ -205,16 +213,29 @@ __global__ __launch_bounds__(64, WPS) void beam_rows_kernel(const BeamParams p) 
   double2 rI[BPW], rF[BPW];
   double tI = 0.0, tF = 0.0;
   {
-    const __amdgpu_buffer_rsrc_t rsI = make_rsrc(p.I + beam0 * p.I_bs, (unsigned)(((long)(nb - 1) * p.I_bs + Ne) * 8));
     const __amdgpu_buffer_rsrc_t rsF = make_rsrc(p.Fy + beam0 * p.Fy_bs, (unsigned)(((long)(nb - 1) * p.Fy_bs + N) * 8));
-    const unsigned oobI = (int)lane < hE ? lane * 16u : 0x40000000u, oobF = (int)lane < hN ? lane * 16u : 0x40000000u;
-#pragma unroll
-    for (int b = 0; b < BPW; ++b) {
-      rI[b] = buf_load_d2(rsI, (unsigned)(b * p.I_bs * 8) + oobI);     // rows of beams beyond B, lanes beyond the row: 0
-      rF[b] = buf_load_d2(rsF, (unsigned)(b * p.Fy_bs * 8) + oobF);
-    }
+    const unsigned oobF = (int)lane < hN ? lane * 16u : 0x40000000u;
     const unsigned tb = lane < (unsigned)nb ? lane : 0u;               // lane b fetches the odd tail of row b
-    if (Ne & 1) tI = buf_load_d(rsI, (unsigned)((tb * p.I_bs + Ne - 1) * 8));
+    if constexpr (SIZING) {          // float32 inertias (the reference's I_tensor, dense rows): 8-byte pairs, widened in registers
+      const __amdgpu_buffer_rsrc_t rsI = make_rsrc(p.I32 + beam0 * Ne, (unsigned)(nb * Ne) * 4u);
+      const unsigned oobI = (int)lane < hE ? lane * 8u : 0x40000000u;
+#pragma unroll
+      for (int b = 0; b < BPW; ++b) {
+        const float2 f = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rsI, (int)((unsigned)(b * Ne) * 4u + oobI), 0, 0));
+        rI[b] = make_double2((double)f.x, (double)f.y);
+        rF[b] = buf_load_d2(rsF, (unsigned)(b * p.Fy_bs * 8) + oobF);
+      }
+      if (Ne & 1) tI = (double)__builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsI, (int)((tb * Ne + Ne - 1) * 4u), 0, 0));
+    } else {
+      const __amdgpu_buffer_rsrc_t rsI = make_rsrc(p.I + beam0 * p.I_bs, (unsigned)(((long)(nb - 1) * p.I_bs + Ne) * 8));
+      const unsigned oobI = (int)lane < hE ? lane * 16u : 0x40000000u;
+#pragma unroll
+      for (int b = 0; b < BPW; ++b) {
+        rI[b] = buf_load_d2(rsI, (unsigned)(b * p.I_bs * 8) + oobI);     // rows of beams beyond B, lanes beyond the row: 0
+        rF[b] = buf_load_d2(rsF, (unsigned)(b * p.Fy_bs * 8) + oobF);
+      }
+      if (Ne & 1) tI = buf_load_d(rsI, (unsigned)((tb * p.I_bs + Ne - 1) * 8));
+    }
     if (N & 1) tF = buf_load_d(rsF, (unsigned)((tb * p.Fy_bs + N - 1) * 8));
   }
   FAT_STAMP(5);
@@ -303,6 +324,25 @@ __global__ __launch_bounds__(64, WPS) void beam_rows_kernel(const BeamParams p) 
     for (int i = 0; i < M; ++i) sth[i] = out.th[i];
   }
   wave_lds_fence();
+  if constexpr (SIZING) {           // V in s_b, M in s_a (padded rows): one optimiser epoch per live, active case
+    static_assert(!SIZING || !FAT, "the fused epoch uses the lean mapping");
+    // every case's state loads go out before the first one is used (a wave holds BPW cases: one HBM latency, not BPW)
+    CaseRegs<2> cr[BPW];            // host-checked: Ne <= 128
+    bool on[BPW];
+#pragma unroll
+    for (int gb = 0; gb < BPW; ++gb) {
+      on[gb] = gb < nb && sz->active[beam0 + gb] != 0;     // wave-uniform
+      if (on[gb]) load_case<2>((int)lane, beam0 + gb, Ne, *sz, cr[gb]);
+    }
+#pragma unroll
+    for (int gb = 0; gb < BPW; ++gb) {
+      if (!on[gb]) continue;
+      const double* Vb = &s_b[gb * PM];
+      const double* Mb = &s_a[gb * PM];
+      step_case<2>((int)lane, beam0 + gb, Ne, *sz, cr[gb], [&](int e) { return (float)Vb[e]; }, [&](int e) { return (float)Mb[e]; });
+    }
+    return;
+  }
 
   // ---- stage 5: rows out, one 16-byte store per lane and row.  All rows of an array are read from LDS before the
   //      first of them is stored (a store behind every read would pay one LDS round trip per row), and the next
@@ -368,6 +408,15 @@ __global__ __launch_bounds__(64, WPS) void beam_rows_kernel(const BeamParams p) 
 #endif
 }
 
+template <int P, int M, int WPS, bool FAT>
+__global__ __launch_bounds__(64, WPS) void beam_rows_kernel(const BeamParams p) {
+  beam_rows_body<P, M, WPS, FAT, false>(p, nullptr);
+}
+template <int P, int M, int WPS>
+__global__ __launch_bounds__(64, WPS) void beam_rows_sizing_kernel(const BeamParams p, const SizingArgs sz) {
+  beam_rows_body<P, M, WPS, false, true>(p, &sz);
+}
+
 // ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
@@ -377,6 +426,13 @@ const FatTiling kFatTilings[] = {
     {8, 13, "beam_rows_kernel<8, 13, 2, false>"},
 };
 const int kNumFatTilings = sizeof(kFatTilings) / sizeof(kFatTilings[0]);
+
+hipError_t launch_fat_sizing(const BeamParams& p, const SizingArgs& sz, int P, int M, hipStream_t stream) {
+  const unsigned grid = (unsigned)((p.B + 64 / P - 1) / (64 / P));
+  if (P == 16 && M == 7) hipLaunchKernelGGL((beam_rows_sizing_kernel<16, 7, 3>), dim3(grid), dim3(64), 0, stream, p, sz);
+  else return hipErrorInvalidValue;
+  return hipGetLastError();
+}
 
 hipError_t launch_fat(const BeamParams& p, int P, int M, hipStream_t stream) {
   const int bpw = 64 / P;

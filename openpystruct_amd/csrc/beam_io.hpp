@@ -36,6 +36,7 @@ struct FatTiling { int P, M; const char* name; };
 extern const FatTiling kFatTilings[];
 extern const int kNumFatTilings;
 hipError_t launch_fat(const BeamParams& p, int P, int M, hipStream_t stream);
+hipError_t launch_fat_sizing(const BeamParams& p, const SizingArgs& sz, int P, int M, hipStream_t stream);   // P = 16 only
 
 // ---- cross-lane exchange inside the P-lane group of a beam ------------------------------
 // from_minus<S>(x): value of lane-S (0.0 when j < S); from_plus<S>(x): value of lane+S (0.0 when

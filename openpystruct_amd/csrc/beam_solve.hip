@@ -461,14 +461,14 @@ static const Tiling kTilings[] = {
 };
 static const int kNumTilings = sizeof(kTilings) / sizeof(kTilings[0]);
 
-// Default use of a row-staged tiling (measured on one box, profiles/r03_notes.md; us per launch, classic -> rows):
-// the 16-lane rows kernel wins or ties at every batch size (10^4 beams 13.9 -> 12.1, 3e4 33.2 -> 29.4, 1e5 94 -> 93,
-// 2^20 1022 -> 978 with streaming stores), the 8-lane ones never beat it.  The fat-wave tiling (P = 6) runs a third fewer
-// instructions per SIMD at 10^4 beams, but with ONE wave per SIMD every wave of the chip is in the same phase and the
-// store phase (32 MB, ~3.8 us from cache) overlaps nothing: 15.1 us.  It stays an explicit tiling.
+// Default use of a row-staged tiling (same-box A/B, profiles/r03_notes.md; us per launch, classic 16 / rows 16 / rows 8 /
+// classic 8): 10^4 beams 13.1 / 12.7 / 13.1 / 14.8 eager (13.9 / 12.1 graph-replayed), 4e4 41.8 / 38.5 / 41.7 / 42.8,
+// 1e5 100 / 91 / 88 / 92, 3e5 306 / 279 / 282 / 274, 2^20 1067 / 993 / 987 / 951.  The 16-lane rows kernel serves every
+// batch below 2^17 beams; above, the flat 16-byte-aligned streams of beam_solve.hip's 8-lane kernel are worth 3-4 %.
+// The fat-wave tiling (P = 6) runs a third fewer instructions per SIMD at 10^4 beams, but with ONE wave per SIMD every
+// wave of the chip is in the same phase and the store phase (32 MB, ~3.8 us from cache) overlaps nothing: 15.1 us.
 static bool fat_default(const FatTiling& f, int B, int Ne) {
-  (void)B;
-  return f.P == 16 && Ne + 1 <= f.P * f.M;
+  return f.P == 16 && Ne + 1 <= f.P * f.M && B < (1 << 17);
 }
 
 static const Tiling* choose_tiling(int B, int Ne, int tiling) {
@@ -481,7 +481,7 @@ static const Tiling* choose_tiling(int B, int Ne, int tiling) {
   // default (measured, profiles/r01_notes.md): 16 lanes per beam while the batch is a single round of
   // waves (its short waves finish a 10^4-beam launch soonest); 8 lanes per beam (40 % less arithmetic per
   // beam, two waves per SIMD) once the batch is large enough to keep every SIMD busy for several rounds
-  if (N <= 8 * 13 && B >= 32768) return &kTilings[0];
+  if (N <= 8 * 13 && B >= 32768) return &kTilings[0];   // (reached for B >= 2^17 when the rows kernel is eligible)
   if (N <= 16 * 7) return &kTilings[1];
   for (int t = 0; t < kNumTilings; ++t)
     if (kTilings[t].P * kTilings[t].M >= N) return &kTilings[t];
@@ -618,9 +618,10 @@ static int solve_impl(int B, int Ne, const double* x, long x_bstride, const doub
   // stride, 8-byte alignment)
   const FatTiling* fat = nullptr;
   {
-    const bool fat_ok = shared && fix_bstride == 0 && !sz && !active && !f32_forces;
+    // (the fused sizing epoch: 16-lane rows kernel only; an `active` mask is the sizing epoch's, nobody else's)
+    const bool fat_ok = shared && fix_bstride == 0 && !f32_forces && (sz ? true : !active);
     const FatTiling* f = choose_fat(B, Ne, tiling);
-    if (f && fat_ok) fat = f;
+    if (f && fat_ok && (!sz || f->P == 16)) fat = f;
     else if (is_fat_tiling(tiling)) return f ? OPS_AMD_ERR_UNSUPPORTED : OPS_AMD_ERR_INVALID_ARG;
   }
   const Tiling* t = fat ? nullptr : choose_tiling(B, Ne, tiling & ~OPS_AMD_TILING_ROWS);
@@ -640,7 +641,8 @@ static int solve_impl(int B, int Ne, const double* x, long x_bstride, const doub
   }
   hipStream_t s = (hipStream_t)stream;
   hipError_t err = hipSuccess;
-  if (fat) err = launch_fat(p, fat->P, fat->M, s);
+  if (fat && sz) err = launch_fat_sizing(p, *sz, fat->P, fat->M, s);
+  else if (fat) err = launch_fat(p, fat->P, fat->M, s);
   else if (sz) {
     if (t->P == 8 && t->M == 13) err = launch_sizing<8, 13>(p, *sz, shared, s);
     else if (t->P == 16 && t->M == 7) err = launch_sizing<16, 7>(p, *sz, shared, s);
@@ -692,7 +694,10 @@ int ops_beam_sizing_epoch_f32(int B, int Ne, const double* x, long x_bstride, co
   const SizingArgs sz{I, nullptr, I_last, exp_avg, exp_avg_sq, best_loss, patience_cnt, epochs_run, active, last_loss, nullptr, nullptr, *hp, schedule};
   // the fused kernel carries the cases' optimiser state in registers next to the solve: the 16-lane tiling (three waves
   // per SIMD) beats the 8-lane one at every batch size here (2e5 cases: 0.095 vs 0.104 s), unlike the plain solve
-  if (tiling == 0 && Ne + 1 <= 16 * 7) tiling = 16;
+  if (tiling == 0 && Ne + 1 <= 16 * 7) {
+    const bool rows_ok = x_bstride == 0 && E_bstride == 0 && wy_bstride == 0 && fix_bstride == 0;   // else: per-case geometry (random bridges)
+    tiling = rows_ok ? (16 | OPS_AMD_TILING_ROWS) : 16;
+  }
   return solve_impl(B, Ne, x, x_bstride, E, E_bstride, nullptr, Ne, fix, fix_bstride, Fy, Fy_bstride, wy, wy_bstride, nullptr, nullptr,
                     nullptr, nullptr, status, active, 0, tiling, stream, &sz);
 }

@@ -566,14 +566,24 @@ static bool use_wave_kernel(int kd) {
 // the assembly fused into the solve (plan built per call, frame_wave.hpp); OPS_AMD_FRAME_FUSED_ASM=0: separate assembly kernel (A/B)
 static bool fused_assembly() { const char* e = getenv("OPS_AMD_FRAME_FUSED_ASM"); return !(e && atoi(e) == 0); }
 
+// Does the wave-per-frame kernel serve this size?  Its four waves' LDS (right-hand sides + parking areas) must fit one CU, its
+// plan kernel one workgroup's LDS.  Frames beyond that (tall and narrow: thousands of equations) take the workgroup-per-frame
+// kernels, whose band streams through an LDS ring -- ops_frame_workspace_bytes and the solve decide with this one function.
+static bool wave_kernel_serves(int n_eq, int kd) {
+  if (!use_wave_kernel(kd)) return false;
+  const int W = fw_width(kd);
+  if (4 * fw_lds_doubles(n_eq, W) * sizeof(double) > 160 * 1024 - 64) return false;
+  if (fused_assembly() ? (size_t)n_eq * sizeof(int) > 64 * 1024 : ((size_t)FW_SLAB * W + (size_t)n_eq) * sizeof(double) > LDS_MAX) return false;
+  return true;
+}
+
 template <int W>
 static hipError_t launch_wave(const FrameParams& p, double* ws, hipStream_t s) {
   static std::atomic<unsigned long long> done{0};
   int devid = 0;
   hipError_t e = hipGetDevice(&devid);
   if (e != hipSuccess) return e;
-  const size_t lds = 4 * fw_lds_doubles(p.n_eq, W) * sizeof(double);
-  if (lds > 160 * 1024 - 64) return hipErrorInvalidValue;
+  const size_t lds = 4 * fw_lds_doubles(p.n_eq, W) * sizeof(double);      // size limits: wave_kernel_serves (checked by the caller)
   const unsigned long long bit = 1ull << (devid & 63);
   if (!(done.load(std::memory_order_acquire) & bit)) {
     e = hipFuncSetAttribute((const void*)frame_wave_kernel<W, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
@@ -585,7 +595,6 @@ static hipError_t launch_wave(const FrameParams& p, double* ws, hipStream_t s) {
   const FwPlan pl = fw_plan_at(plan_base, p.n_eq, p.Ne);
   const dim3 grid((unsigned)((p.B + 3) / 4));
   if (fused_assembly()) {
-    if ((size_t)p.n_eq * sizeof(int) > 64 * 1024) return hipErrorInvalidValue;
     hipLaunchKernelGGL(frame_plan_kernel, dim3(1), dim3(1024), (size_t)p.n_eq * sizeof(int), s, p, W, plan_base);
     hipLaunchKernelGGL((frame_wave_kernel<W, true>), grid, dim3(256), lds, s, p, ws, pl);
   } else {
@@ -598,7 +607,7 @@ static hipError_t launch_wave(const FrameParams& p, double* ws, hipStream_t s) {
 
 extern "C" size_t ops_frame_workspace_bytes(int B, int n_eq, int half_bandwidth) {
   half_bandwidth = eff_kd(half_bandwidth);
-  if (use_wave_kernel(half_bandwidth))     // per frame: band / factor rows; once: the assembly plan (at most 21 entries and 72 coefficients per element)
+  if (wave_kernel_serves(n_eq, half_bandwidth))     // per frame: band / factor rows; once: the assembly plan (at most 21 entries and 72 coefficients per element)
     return B == 0 ? 0 : (size_t)B * fw_frame_doubles(n_eq, half_bandwidth) * sizeof(double) + fw_plan_bytes(n_eq, 4 * n_eq + 64);
   if (frame_lds_resident_bytes(n_eq, half_bandwidth) <= LDS_MAX && !force_ws()) return 0;   // the band lives in LDS
   return (size_t)B * frame_lds_resident_bytes(n_eq, half_bandwidth);
@@ -638,12 +647,10 @@ extern "C" int ops_frame_solve_batched_f64(int B, int n_nodes, int n_elems, int 
   if (const char* e = getenv("OPS_AMD_FRAME_TRACE_PTR")) p.trace = (unsigned long long*)strtoull(e, nullptr, 10);
 #endif
   hipStream_t s = (hipStream_t)stream;
-  if (use_wave_kernel(kd)) {
+  if (wave_kernel_serves(n_eq, kd)) {
     const int W = fw_width(kd);
     const size_t need = (size_t)B * fw_frame_doubles(n_eq, kd) * sizeof(double) + fw_plan_bytes(n_eq, n_elems);
     if (!workspace || workspace_bytes < need) return OPS_AMD_ERR_INVALID_ARG;
-    const size_t lds_asm = ((size_t)FW_SLAB * W + (size_t)n_eq) * sizeof(double);
-    if (lds_asm > LDS_MAX) return OPS_AMD_ERR_UNSUPPORTED;
     hipError_t e = hipSuccess;
     {
       switch (W) {
@@ -654,7 +661,6 @@ extern "C" int ops_frame_solve_batched_f64(int B, int n_nodes, int n_elems, int 
         default: e = launch_wave<56>(p, (double*)workspace, s); break;
       }
     }
-    if (e == hipErrorInvalidValue) return OPS_AMD_ERR_UNSUPPORTED;
     if (e != hipSuccess) { set_frame_error(hipGetErrorString(e)); return OPS_AMD_ERR_LAUNCH; }
     return OPS_AMD_OK;
   }

@@ -25,6 +25,7 @@
 #include <stdint.h>
 
 #include "../../include/openpystruct_amd.h"
+#include "call_counter.hpp"
 
 namespace opsamd {
 
@@ -177,9 +178,8 @@ __global__ __launch_bounds__(256) void fused_bn_fwd_kernel(const FbArgs a) {
       for (int r = rg; r < B; r += FB_RG) emit(0, r);
     }
   }
-  // one increment per launch; a workgroup that happens to read the counter after it draws from the next stream, which is as
-  // good a mask (the backward pass uses the STORED mask); streams of different call sites differ by their seeds
-  if (drop && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(a.call_counter, 1ull);
+  // one increment per launch, by the last workgroup to finish (call_counter.hpp); streams of different call sites differ by their seeds
+  if (drop && threadIdx.x == 0) call_counter_done(a.call_counter, gridDim.x);
 }
 
 struct FbBwdArgs {

@@ -7,6 +7,7 @@
 #include <stdint.h>
 
 #include "../../include/openpystruct_amd.h"
+#include "call_counter.hpp"
 
 namespace opsamd {
 
@@ -40,8 +41,8 @@ __global__ __launch_bounds__(256) void gather_noise_kernel(int B, long F, const 
     if (out_bf16) ((uint16_t*)out)[i] = ip_f2bf(v);
     else ((float*)out)[i] = v;
   }
-  // one increment per launch; a workgroup that reads the counter after it still draws a valid (different) stream
-  if (counter && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(counter, 1ull);
+  // one increment per launch, by the last workgroup to finish (call_counter.hpp)
+  if (counter && threadIdx.x == 0) call_counter_done(counter, gridDim.x);
 }
 
 }  // namespace opsamd
@@ -50,7 +51,7 @@ extern "C" int ops_gather_rows_noise_f32(int B, long F, const float* X, const lo
                                          unsigned long long* counter, void* out, int out_is_bf16, void* stream) {
   if (B < 1 || F < 1 || !X || !idx || !out) return OPS_AMD_ERR_INVALID_ARG;
   const long n = (long)B * F;
-  const unsigned grid = (unsigned)((n + 255) / 256 > 1024 ? 1024 : (n + 255) / 256);
+  const unsigned grid = (unsigned)((n + 255) / 256 > 128 ? 128 : (n + 255) / 256);   // grid-stride; <= 128 reports to the call counter
   hipLaunchKernelGGL(opsamd::gather_noise_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, B, F, X, idx, sigma, seed, counter, out, out_is_bf16);
   return hipGetLastError() == hipSuccess ? OPS_AMD_OK : OPS_AMD_ERR_LAUNCH;
 }

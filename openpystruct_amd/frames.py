@@ -128,11 +128,13 @@ def frame_solve(topo: FrameTopology, I: torch.Tensor, loads: Optional[torch.Tens
                             torch.empty((B,), dtype=torch.int32, device=dev))
     ws_bytes = int(lib.ops_frame_workspace_bytes(B, topo.n_eq, topo.kd))
     ws = None
-    if ws_bytes:       # band too large for LDS: HBM workspace, cached on the topology
-        ws = getattr(topo, "_ws", None)
-        if ws is None or ws.numel() < ws_bytes or ws.device != dev:
-            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-            topo._ws = ws
+    if ws_bytes:       # factor rows + the call's assembly plan: HBM workspace, cached on the topology PER STREAM (two solves on one
+        # topology from different streams or threads must not share factor rows or plan)
+        cache = topo.__dict__.setdefault("_ws", {})
+        key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+        ws = cache.get(key)
+        if ws is None or ws.numel() < ws_bytes:
+            ws = cache[key] = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
     with torch.cuda.device(dev):
         rc = lib.ops_frame_solve_batched_f64(
             B, topo.Nn, topo.Ne, topo.n_eq, topo.kd, topo.d_geo.data_ptr(), topo.d_EA.data_ptr(), topo.d_E.data_ptr(),

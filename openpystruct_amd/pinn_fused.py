@@ -117,7 +117,7 @@ class PinnFusedStep:
         self.targets_t = torch.zeros(C, R, dtype=torch.float32, device=dev)    # the batch's targets, transposed
         self.loss_ws = torch.zeros(int(self.lib.ops_mlp_loss_workspace_bytes()), dtype=torch.uint8, device=dev)
         self.drop_counter = torch.zeros(2, dtype=torch.int64, device=dev)
-        self.prep_counter = torch.zeros(1, dtype=torch.int64, device=dev)
+        self.prep_counter = torch.zeros(2, dtype=torch.int64, device=dev)     # [calls, workgroups done] (csrc/call_counter.hpp)
         self.seed = int(seed) & 0x7FFFFFFFFFFFFFFF
 
         lins = [model.input_fc] + [l for b in model.residual_blocks for l in (b[0].fc1, b[0].fc2)] + [model.output_fc]

@@ -242,14 +242,20 @@ _FUSED_EPOCH = os.environ.get("OPS_AMD_SIZING_FUSED", "1") == "1"     # A/B swit
 _EPOCH_TILING = int(os.environ.get("OPS_AMD_SIZING_TILING", "0"))      # lanes per beam of the sizing loop's solves (0 = rule below)
 
 
-def sizing_tiling(n_nodes: int) -> int:
-    """Lanes per beam of EVERY solve of the sizing loop (fused or not, per-epoch and final): a function of the mesh size only.
-    The library's own default switches from 16 to 8 lanes at 32 768 beams per launch; roundings -- hence early-stop epochs
-    and records -- would then depend on how many ranks or chunks share the cases.  16 lanes while they fit (N <= 112),
-    otherwise 0 = the library's first fitting tiling, which depends on N alone."""
+TILING_ROWS = 0x200            # include/openpystruct_amd.h OPS_AMD_TILING_ROWS: the row-staged kernels of csrc/beam_fat.hip
+
+
+def sizing_tiling(n_nodes: int, shared_geometry: bool = False) -> int:
+    """Lanes per beam of EVERY solve of the sizing loop (fused or not, per-epoch and final): a function of the mesh only.
+    The library's own default changes kernels with the number of beams per launch; roundings -- hence early-stop epochs
+    and records -- would then depend on how many ranks or chunks share the cases.  16 lanes while they fit (N <= 112):
+    the row-staged kernel when geometry and constraint mask are shared by all cases (the fixed bridge), beam_solve.hip's
+    otherwise (random bridges); beyond that 0 = the library's first fitting tiling, which depends on N alone."""
     if _EPOCH_TILING:
         return _EPOCH_TILING
-    return 16 if n_nodes <= 16 * 7 else 0
+    if n_nodes > 16 * 7:
+        return 0
+    return 16 | TILING_ROWS if shared_geometry else 16
 
 
 class SizingState:
@@ -305,7 +311,7 @@ class SizingState:
                     self.fix.data_ptr(), N if self.fix.dim() == 2 else 0, self.Fy.data_ptr(), N, self.wy.data_ptr(), 0,
                     self.I.data_ptr(), self.I_last.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(),
                     self.best_loss.data_ptr(), self.patience_cnt.data_ptr(), self.epochs_run.data_ptr(), self.active.data_ptr(),
-                    self.last_loss.data_ptr(), ctypes.byref(self._hp), self._schedule.data_ptr(), self._status.data_ptr(), sizing_tiling(N),
+                    self.last_loss.data_ptr(), ctypes.byref(self._hp), self._schedule.data_ptr(), self._status.data_ptr(), self._tiling(),
                     torch.cuda.current_stream(self.device).cuda_stream)
             if rc != _cabi.OK:
                 raise RuntimeError(f"ops_beam_sizing_epoch_f32 failed with code {rc}: {lib.ops_amd_last_error().decode()}")
@@ -315,7 +321,7 @@ class SizingState:
             rc = lib.ops_beam_solve_forces_f32(
                 self.B, Ne, self.x.data_ptr(), N if self.x.dim() == 2 else 0, self.E.data_ptr(), 0, self.I64.data_ptr(), Ne,
                 self.fix.data_ptr(), N if self.fix.dim() == 2 else 0, self.Fy.data_ptr(), N, self.wy.data_ptr(), 0,
-                self._V.data_ptr(), self._M.data_ptr(), self._status.data_ptr(), self.active.data_ptr(), sizing_tiling(N), stream)
+                self._V.data_ptr(), self._M.data_ptr(), self._status.data_ptr(), self.active.data_ptr(), sizing_tiling(N), stream)   # float32 forces: beam_solve.hip only
             if rc != _cabi.OK:
                 raise RuntimeError(f"ops_beam_solve_forces_f32 failed with code {rc}: {lib.ops_amd_last_error().decode()}")
             rc = lib.ops_beam_sizing_step_vm32_f32(
@@ -326,6 +332,9 @@ class SizingState:
         if rc != _cabi.OK:
             raise RuntimeError(f"ops_beam_sizing_step_vm32_f32 failed with code {rc}")
 
+    def _tiling(self) -> int:
+        return sizing_tiling(self.N, shared_geometry=self.x.dim() == 1 and self.fix.dim() == 1)
+
     def finalize(self) -> None:
         """What the reference reads after the loop (:224-232) and records (:239-249): the state of every case's LAST
         solve.  `I64` (separate launches) froze when a case stopped / `I_last` (fused epochs) recorded its inertias, so one full solve reproduces it -- displacements included -- and the
@@ -333,7 +342,8 @@ class SizingState:
         # same tiling as the epochs, whatever the shard size: the records do not depend on how many GPUs share the cases
         if self._fused:
             self.I64 = self.I_last.double()
-        self.sol = beam_solve(self.x, self.E, self.I64, self.fix, self.Fy, self.wy, tiling=sizing_tiling(self.N), out=self.sol)
+        self.sol = beam_solve(self.x, self.E, self.I64, self.fix, self.Fy, self.wy, tiling=self._tiling() if self._fused else sizing_tiling(self.N),
+                              out=self.sol)
         self.V32, self.M32 = self.sol.V.float(), self.sol.M.float()
 
 

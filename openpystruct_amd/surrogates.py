@@ -265,7 +265,10 @@ class FNNWithResidual(nn.Module):
     direct_param_grads = False
 
     def _fused_ok(self, x):
-        return (_FUSED_TAILS and x.is_cuda and x.dim() == 2 and self.norm_type == "batch" and type(self.input_norm) is nn.BatchNorm1d and
+        # the fused tails' backward is the batch-statistics one: training mode, or evaluation without autograd (an evaluation-mode
+        # pass that WILL be differentiated -- input sensitivities, fine-tuning with frozen BatchNorm -- takes the framework modules)
+        return (_FUSED_TAILS and x.is_cuda and x.dim() == 2 and (self.training or not torch.is_grad_enabled()) and
+                self.norm_type == "batch" and type(self.input_norm) is nn.BatchNorm1d and
                 all(isinstance(b[0], ResidualBlock) and b[0].conv1.kernel_size == (3,) if b[0].use_conv else True for b in self.residual_blocks))
 
     def forward(self, x):

@@ -242,7 +242,9 @@ class DiffusionCombine(torch.autograd.Function):
 def model_forward(model: nn.Module, x: torch.Tensor, st: _State) -> torch.Tensor:
     """ModelOnePassTransformerWithDiffusion.forward (TFD:539-575) for the training step: diffusion arithmetic in two launches around
     the MLP's shadow products, the patched encoder, the head's LayerNorm / ReLU / dropout in two.  The random step indices and the
-    noise come from the framework's generators in the module's order (torch.randint, then torch.randn_like)."""
+    noise come from the framework's generators in the module's order (torch.randint, then torch.randn_like).  `st` is the
+    ENCODER's dropout state: its pass below advances the counter before the head's dropout (the only site out here with p > 0,
+    TFD:573) draws its mask."""
     lib = _cabi.load()
     B, Nc, d = x.shape
     dm = model.diffusion
@@ -281,7 +283,10 @@ def patch_model(model: nn.Module, seed: int, direct_param_grads: bool = False) -
           and model.fc1.out_features <= 256 and model.pos_encoder.pe.shape[-1] == model.feat_dim)
     if not ok:
         return True                       # the encoder alone
-    state = {}
+    # ONE dropout stream for the model and its encoder: the encoder pass advances the call counter once per step (one captured
+    # add_), and the head's dropout (site 103, drawn after the encoder) reads the same counter -- a state of its own that nothing
+    # advanced gave it the same mask in every step of a run
+    state = model.transformer_encoder._ops_dropout_state
     cls = type(model)
 
     def forward(self, x):
@@ -291,7 +296,7 @@ def patch_model(model: nn.Module, seed: int, direct_param_grads: bool = False) -
             return cls.forward(self, x)
         st = state.get(x.device)
         if st is None:
-            st = state[x.device] = _State(x.device, seed + 17, direct_param_grads)
+            st = state[x.device] = _State(x.device, seed, direct_param_grads)
         return model_forward(self, x, st)
 
     model.forward = types.MethodType(forward, model)
@@ -313,6 +318,7 @@ def patch_encoder(enc: nn.TransformerEncoder, seed: int, direct_param_grads: boo
     if not (ENABLED and type(enc) is nn.TransformerEncoder and all(_layer_ok(l) for l in enc.layers)):
         return False
     state = {}
+    enc._ops_dropout_state = state          # device -> _State; patch_model's front end / head draw from the same stream
 
     def forward(self, src, mask=None, src_key_padding_mask=None, is_causal=None):
         fast = (self.training and src.is_cuda and src.dim() == 3 and src.shape[1] <= 8 and mask is None and src_key_padding_mask is None
@@ -332,3 +338,4 @@ def patch_encoder(enc: nn.TransformerEncoder, seed: int, direct_param_grads: boo
 def unpatch_encoder(enc: nn.Module) -> None:
     if "forward" in enc.__dict__:
         del enc.__dict__["forward"]
+    enc.__dict__.pop("_ops_dropout_state", None)

@@ -588,7 +588,7 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
 
     # batch assembly in one launch (csrc/input_prep.hip): gather + noise + cast straight into the graph's input buffer
     _FUSED_PREP = on_gpu and os.environ.get("OPS_AMD_FUSED_PREP", "1") == "1"
-    prep_counter = torch.zeros(1, dtype=torch.int64, device=device) if on_gpu else None
+    prep_counter = torch.zeros(2, dtype=torch.int64, device=device) if on_gpu else None     # [calls, workgroups done]
     # bf16 batches only where the first module is a (shadow) Linear, which casts its operand to bf16 anyway
     prep_bf16 = bool(on_gpu and use_ac and autocast_dtype == torch.bfloat16 and patched and kind in ("pinn", "fnn", "gnn"))
 

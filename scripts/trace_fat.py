@@ -3,7 +3,7 @@
 import os, sys, numpy as np, torch
 sys.path.insert(0, os.getcwd())
 B = int(sys.argv[1]); til = int(sys.argv[2]); nsets = int(sys.argv[3]) if len(sys.argv) > 3 else 1
-bpw = 64 // til
+bpw = 64 // (til & 0xff)
 buf = torch.zeros(8 * (B // bpw + 4), dtype=torch.int64, device='cuda')
 os.environ["OPS_AMD_TRACE_PTR"] = str(buf.data_ptr())
 import bench, openpystruct_amd as oa
@@ -26,3 +26,9 @@ for nm, k in names:
     d = "" if prev is None else "  (+%.2f med since previous)" % np.median(c - prev)
     print("%-15s min %.2f p10 %.2f med %.2f p90 %.2f max %.2f us%s" % (nm, c.min(), np.percentile(c, 10), np.median(c), np.percentile(c, 90), c.max(), d))
     prev = c
+hw = t[:, 4]; wid = hw & 15
+import collections
+print("wave_id hist", sorted(collections.Counter(wid.tolist()).items()))
+for w in sorted(set(wid.tolist())):
+    m = wid == w
+    print("slot", w, "n", int(m.sum()), " ".join("%s %.2f" % (nm, np.median(col(k)[m])) for nm, k in names))

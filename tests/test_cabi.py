@@ -30,7 +30,8 @@ def test_introspection_calls(lib):
     assert lib.ops_amd_abi_version() == 3      # 2: ops_beam_sizing_epoch_f32 takes I_last (float32) instead of I64; 3: ops_mlp_* layer blocks
     assert lib.ops_amd_max_elements() >= 100
     assert b"beam_rows_kernel<16, 7" in lib.ops_beam_solve_kernel_name(10000, 100, 0)       # default: the row-staged 16-lane kernel
-    assert b"beam_rows_kernel<16, 7" in lib.ops_beam_solve_kernel_name(1 << 20, 100, 0)
+    assert b"beam_rows_kernel<16, 7" in lib.ops_beam_solve_kernel_name(100000, 100, 0)
+    assert b"beam_solve_kernel<8, 13" in lib.ops_beam_solve_kernel_name(1 << 20, 100, 0)   # bandwidth-bound batches: flat aligned streams
     assert b"beam_solve_kernel<16, 7" in lib.ops_beam_solve_kernel_name(10000, 100, 16)     # explicit P without OPS_AMD_TILING_ROWS: beam_solve.hip
     assert b"beam_solve_kernel<32, 4" in lib.ops_beam_solve_kernel_name(10000, 120, 0)      # beyond 16 x 7 nodes: beam_solve.hip
     assert b"beam_rows_kernel<6, 17" in lib.ops_beam_solve_kernel_name(64, 100, 6)          # the fat-wave tiling (csrc/beam_fat.hip)

@@ -249,6 +249,28 @@ def test_frame_sizing_loop_vs_per_frame_oracle(bays, stories):
         np.testing.assert_allclose(I[b].cpu().numpy(), ref[b]["I"], rtol=2e-3)
 
 
+def test_frame_sizing_first_epochs_on_the_largest_frame_the_reference_draws():
+    """10 x 10 bays x stories (FR:17-18: the upper end of the script's random range; 210 elements, 330 equations): the first five
+    epochs of `optimize_frames` against the per-frame restatement of FR:141-206, inertias to float32 rounding."""
+    from openpystruct_amd import frames
+    from oracle import frame_sizing_oracle as fo
+    cfg = frames.FrameConfig()
+    topo = frames.grid_frame(10, 10, cfg)
+    rng = np.random.default_rng(1010)
+    B = 2
+    I0 = np.full((B, topo.Ne), cfg.I0)
+    I0[1] *= rng.uniform(0.5, 2.0, size=topo.Ne)
+    I0 = I0.astype(np.float32)
+    ref = [fo.optimize_frame(topo.coords, topo.conn, topo.fix3, topo.nodal_loads, topo.wy, topo.wx, A=cfg.A, E=cfg.E, nu=cfg.nu,
+                             I0=cfg.I0, alpha_moment=cfg.alpha_moment, alpha_shear=cfg.alpha_shear, k=cfg.k, num_epochs=5,
+                             lr=cfg.lr, tolerance=cfg.tolerance, patience=cfg.patience, I_init=I0[b]) for b in range(B)]
+    for n in (1, 2, 5):
+        I, sol, ep = frames.optimize_frames(topo, B, cfg, I0=torch.as_tensor(I0, device="cuda"), max_epochs=n, poll_every=1)
+        got = I.cpu().numpy()
+        for b in range(B):
+            np.testing.assert_allclose(got[b], ref[b]["I_history"][n - 1], rtol=2e-5 * n, atol=0)
+
+
 def _build_grid_frame_through_the_shim(ops, cfg, bays, stories, I, lateral):
     nb1 = bays + 1
     coords = {i * nb1 + j + 1: (j * cfg.bay_width, i * cfg.story_height) for i in range(stories + 1) for j in range(nb1)}
@@ -297,3 +319,44 @@ def test_ops_shim_deferred_batches_frames_by_topology():
         d, f, st, _, _ = _oracle(topo, I)
         np.testing.assert_allclose(dom.result["forces"], f, rtol=1e-7, atol=1e-6 * np.abs(f).max())
         np.testing.assert_allclose(dom.result["v"], d[:, 1], rtol=1e-7, atol=1e-12)
+
+
+def test_tall_narrow_frame_falls_back_to_the_workgroup_per_frame_kernels():
+    """3 bays x 420 stories: 5 040 equations at half bandwidth 14.  The wave-per-frame kernel keeps four right-hand sides in one CU's
+    LDS and cannot hold them; the dispatch (and ops_frame_workspace_bytes, consistently) must fall back to the LDS-ring kernels."""
+    from openpystruct_amd import frames
+    topo = frames.grid_frame(3, 420)
+    assert topo.n_eq == 3 * 4 * 420 and topo.kd == 14
+    rng = np.random.default_rng(1)
+    I = np.exp(rng.uniform(np.log(2e-3), np.log(5e-3), size=(2, topo.Ne)))
+    sol = frames.frame_solve(topo, torch.as_tensor(I, device="cuda"))
+    torch.cuda.synchronize()
+    assert int(sol.status.abs().sum()) == 0
+    for b in range(2):
+        d, f, st, neq, kd = _oracle(topo, I[b])
+        assert st == 0
+        assert relerr(sol.disp[b].cpu().numpy().ravel(), d.ravel()) < 1e-6      # a 420-story cantilever: cond ~ 1e10
+        assert relerr(sol.forces[b].cpu().numpy().ravel(), f.ravel()) < 1e-6
+
+
+def test_solves_on_one_topology_from_two_streams_do_not_share_a_workspace():
+    from openpystruct_amd import frames
+    topo = frames.grid_frame(10, 10)
+    g = torch.Generator(device="cuda").manual_seed(3)
+    Ia = torch.exp(torch.empty((4096, topo.Ne), dtype=torch.float64, device="cuda").uniform_(np.log(1e-4), np.log(5e-3), generator=g))
+    Ib = torch.exp(torch.empty((4096, topo.Ne), dtype=torch.float64, device="cuda").uniform_(np.log(1e-4), np.log(5e-3), generator=g))
+    ra = frames.frame_solve(topo, Ia)
+    rb = frames.frame_solve(topo, Ib)
+    torch.cuda.synchronize()
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    for _ in range(3):
+        with torch.cuda.stream(sa):
+            qa = frames.frame_solve(topo, Ia)
+        with torch.cuda.stream(sb):
+            qb = frames.frame_solve(topo, Ib)
+    torch.cuda.synchronize()
+    # (not bit for bit: the assembly adds element contributions with LDS atomics, whose order varies from run to run)
+    for q, r in ((qa, ra), (qb, rb)):
+        assert relerr(q.disp.cpu().numpy().reshape(4096, -1), r.disp.cpu().numpy().reshape(4096, -1)) < 1e-10
+        assert relerr(q.forces.cpu().numpy().reshape(4096, -1), r.forces.cpu().numpy().reshape(4096, -1)) < 1e-9
+    assert len(topo._ws) >= 2

@@ -22,7 +22,7 @@ class _FixedMask(nn.Module):
         return x if self.mask is None else x * self.mask * self.scale
 
 
-def _make(seed, p_drop, nblk=2, F=684, H=350, C=302, nel=100):
+def _make(seed, p_drop, nblk=2, F=684, H=350, C=302, nel=100, smooth=False):
     from openpystruct_amd.surrogates import CompositeLoss, FNNWithResidual
     torch.manual_seed(seed)
     model = FNNWithResidual(F, H, nblk, C, p_drop)
@@ -44,7 +44,11 @@ def _make(seed, p_drop, nblk=2, F=684, H=350, C=302, nel=100):
                 b.copy_(0.1 * torch.randn(b.shape, generator=g))
             elif "running_var" in name:
                 b.copy_(1.0 + 0.2 * torch.rand(b.shape, generator=g))
-    crit = CompositeLoss(nel, nel + 1, C - 2 * nel - 1, 0.5, 1e-1, -1.0, 1.2, 1.5e-2)
+    if smooth:      # pure mean-squared error on the inertia block: no |.|, no box penalty, no relative-L1 term -- a loss whose
+        # gradient does not flip sign with the bf16 rounding of a prediction
+        crit = CompositeLoss(nel, nel + 1, C - 2 * nel - 1, 0.0, 0.0, -1.0e6, 1.0e6, 0.0)
+    else:
+        crit = CompositeLoss(nel, nel + 1, C - 2 * nel - 1, 0.5, 1e-1, -1.0, 1.2, 1.5e-2)
     return model, crit
 
 
@@ -164,6 +168,85 @@ def test_step_matches_module_autograd(B, p_drop, seed):
     for a_, at_ in (eng.o[1], eng.h[0], eng.dz[1], eng.dh[0]):
         assert torch.equal(from_tiled(a_), from_tiled(at_).t())
     assert float(eng.loss_sum) == pytest.approx(float(loss), rel=1e-6)
+
+
+def _floor2(name, grads):
+    """Gradient scale of the layer a parameter belongs to.  Several parameters of this network have a mathematically zero or
+    nearly cancelling gradient (a bias in front of a mean-subtracting normalisation; the block norms' biases; with identity
+    activations every Linear bias; the stencil path's scalar BatchNorm pair and convolution bias): any bf16 evaluation returns
+    rounding noise there, so their error is measured against their layer's principal gradient -- the same module's weight, for the
+    stencil path's scalars its three convolution taps."""
+    if "bn1." in name or name.endswith("conv1.bias"):
+        return float(grads[name.rsplit(".", 2)[0] + ".conv1.weight"].norm())
+    if name.endswith(".bias"):
+        return float(grads[name[:-len("bias")] + "weight"].norm())
+    return 0.0
+
+
+def _run_engine(B, p_drop, seed, slope=None):
+    from openpystruct_amd.pinn_fused import PinnFusedStep, eligible
+    dev = torch.device("cuda:0")
+    model, crit = _make(seed, p_drop, smooth=True)
+    if slope is not None:
+        for m in model.modules():
+            if isinstance(m, nn.LeakyReLU):
+                m.negative_slope = slope
+    model, crit = model.to(dev), crit.to(dev)
+    _attach_flat(model)
+    assert eligible(model, crit, 128)
+    before = copy.deepcopy(model)
+    g = torch.Generator().manual_seed(200 + seed)
+    x = torch.randn(B, 684, generator=g).to(torch.bfloat16).float().to(dev)
+    y = (0.8 * torch.randn(B, 302, generator=g)).to(dev)
+    eng = PinnFusedStep(model, crit, seed=4321 + seed)
+    model.train()
+    eng.set_batch(x, y)
+    loss = eng.fwd_bwd(B)
+    torch.cuda.synchronize()
+    masks = None
+    if p_drop > 0:
+        masks = [eng.read(eng.o[0][0], B, 350) != 0] + [eng.read(eng.h[k][0], B, 175) != 0 for k in range(2)]
+    got = {n: q.grad.detach().cpu().double() for n, q in model.named_parameters()}
+    return before, crit, x, y, masks, float(loss), got
+
+
+@pytest.mark.parametrize("B,seed", [(128, 20), (77, 22), (16, 23)])
+def test_step_gradients_against_the_autocast_path_with_a_smooth_objective(B, seed):
+    """The tight guard on the MFMA backward launches.  With the module's own loss bf16 gradients cannot be matched to float64
+    tighter than 12-35 % (test above: sign flips of the L1 terms at bf16-rounded predictions).  A smooth objective -- the same
+    CompositeLoss configured as a pure mean-squared error -- removes those, and what remains is the arithmetic contract's own
+    error (LeakyReLU branches taken on bf16-rounded pre-activations: 2-8 % on the fc1 layers, measured equal on both bf16
+    paths).  So the launches are held to the OTHER implementation of that contract -- autograd under bf16 autocast over the
+    library products and csrc/fused_bn.hip / stencil_bn.hip tails -- parameter by parameter at 2 %: two independent
+    implementations agree to 0.1-0.8 % (profiles/r03_notes.md), a wrong factor in a backward tail is 10 % or more."""
+    before, crit, x, y, _, loss, got = _run_engine(B, 0.0, seed)
+    ref, _, loss_ref = _reference(before, crit, x, y, None, 0.0)
+    m2, loss2 = _autocast_reference(before, crit, x, y)
+    assert abs(loss - loss2) <= 2e-4 * abs(loss2) and abs(loss - loss_ref) <= 1e-2 * abs(loss_ref)
+    gref = {n: q.grad for n, q in ref.named_parameters()}
+    for n, q in m2.named_parameters():
+        ga = q.grad.detach().cpu().double()
+        fl = _floor2(n, gref)
+        same = float((got[n] - ga).norm()) / (max(float(ga.norm()), fl) + 1e-30)
+        e_blocks = float((got[n] - gref[n]).norm()) / (max(float(gref[n].norm()), fl) + 1e-30)
+        e_auto = float((ga - gref[n]).norm()) / (max(float(gref[n].norm()), fl) + 1e-30)
+        assert same <= 2e-2, (n, same, e_blocks, e_auto)
+        assert e_blocks <= 1.25 * e_auto + 1e-2, (n, e_blocks, e_auto)
+
+
+@pytest.mark.parametrize("B,p_drop,seed", [(128, 0.0, 30), (128, 0.5, 31), (77, 0.3, 32), (16, 0.2, 33)])
+def test_step_gradients_of_a_smooth_network_match_float64(B, p_drop, seed):
+    """Smooth objective AND smooth network (LeakyReLU slope 1 = identity: no branch to flip), dropout masks replayed: nothing is left
+    but bf16 rounding, and every parameter gradient of the launches must match float64 autograd to 3e-2 relative L2 -- biases,
+    stencil path and normalisations included (zero-gradient parameters against their layer's scale, _floor2)."""
+    before, crit, x, y, masks, loss, got = _run_engine(B, p_drop, seed, slope=1.0)
+    ref, _, loss_ref = _reference(before, crit, x, y, masks, p_drop)
+    assert abs(loss - loss_ref) <= 1e-2 * abs(loss_ref)
+    gref = {n: q.grad for n, q in ref.named_parameters()}
+    worst = {n: float((got[n] - gref[n]).norm()) / (max(float(gref[n].norm()), _floor2(n, gref)) + 1e-30) for n in got}
+    bound = 3e-2 if B >= 32 else 5e-2          # 16 rows: the stencil path's scalar statistics are sums over 5 600 values only
+    bad = {n: e for n, e in worst.items() if not (np.isfinite(e) and e <= bound)}
+    assert not bad, (bad, worst)
 
 
 def test_dropout_masks_change_between_calls_and_under_graph_replay():

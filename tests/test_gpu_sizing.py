@@ -70,14 +70,13 @@ def test_ops_shim_failure_code_and_deferred_batch(oa):
         assert relerr(d.result["v"], v) < 1e-9 and relerr(d.result["forces"][:, 2], M) < 1e-8
 
 
-@pytest.mark.parametrize("patience", [5, 10])
-def test_sizing_loop_vs_per_case_oracle(oa, patience):
+@pytest.mark.parametrize("patience,n", [(5, 32), (10, 6)])       # 32 cases at patience 5: BASELINE config 1 (SingleCore.py:257)
+def test_sizing_loop_vs_per_case_oracle(oa, patience, n):
     """Batched loop (HIP solve + HIP optimiser step) vs the reference's per-case torch-CPU loop restated in
     oracle/sizing_oracle.py.  float32 optimiser arithmetic: sums are ordered differently on the GPU, so the
     trajectories agree to float32 round-off accumulated over ~250 Adam steps, not bit for bit."""
     from openpystruct_amd import sizing
     cfg = sizing.SizingConfig(patience=patience)
-    n = 6
     cases = sizing.make_cases(n, cfg, seed=123)
     st = sizing.optimize_cases(cases, cfg, "cuda", poll_every=20)
     I = st.I.cpu().numpy(); ep = st.epochs_run.cpu().numpy()

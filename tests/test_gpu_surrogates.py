@@ -250,3 +250,34 @@ def test_pinn_training_with_the_fused_kernels_follows_the_framework_path(monkeyp
         assert all(np.isfinite(hist[mode])) and hist[mode][-1] < 0.6 * hist[mode][0]
     for mode in ("blocks", "tails"):
         assert abs(hist[mode][-1] - hist["framework"][-1]) < 0.05 * hist["framework"][-1], hist
+
+
+def test_evaluation_mode_backward_goes_through_the_framework_modules():
+    """An evaluation-mode pass that is differentiated (input sensitivities, fine-tuning with frozen BatchNorm) must not take the fused
+    tails, whose backward is the batch-statistics one: gradients equal those of a model with the fused tails switched off."""
+    import copy
+    from openpystruct_amd import surrogates as S
+    torch.manual_seed(0)
+    model = S.FNNWithResidual(684, 350, 2, 302, dropout_rate=0.1).cuda()
+    with torch.no_grad():       # running statistics away from (0, 1): evaluation mode really differs from batch statistics
+        for m in model.modules():
+            if isinstance(m, torch.nn.BatchNorm1d):
+                m.running_mean.uniform_(-0.5, 0.5); m.running_var.uniform_(0.5, 2.0)
+    model.eval()
+    x = torch.randn(64, 684, device="cuda", requires_grad=True)
+    y = model(x)
+    y.square().mean().backward()
+    gx = x.grad.clone()
+    ref = copy.deepcopy(model)
+    old = S._FUSED_TAILS
+    S._FUSED_TAILS = False
+    try:
+        x2 = x.detach().clone().requires_grad_()
+        y2 = ref(x2)
+        y2.square().mean().backward()
+    finally:
+        S._FUSED_TAILS = old
+    assert torch.allclose(y, y2, rtol=1e-5, atol=1e-6) and torch.allclose(gx, x2.grad, rtol=1e-4, atol=1e-7)
+    with torch.no_grad():       # ... while an evaluation pass without autograd still takes the fused tails and agrees
+        y3 = model(x.detach())
+    assert torch.allclose(y3, y2.detach(), rtol=2e-4, atol=2e-5)

@@ -283,6 +283,54 @@ def test_patched_model_matches_the_module_with_the_same_noise(monkeypatch):
     assert "forward" not in model.__dict__ and "forward" not in model.transformer_encoder.__dict__
 
 
+def test_head_dropout_mask_is_redrawn_every_step_and_every_graph_replay():
+    """The head's dropout (TFD:573, site 103 of the fast path) must draw a fresh mask per step.  With the encoder's dropout off, the
+    diffusion noise negligible (beta <= 1e-5) and fc2 replaced by the identity the output IS the dropped hidden vector: its zero
+    pattern is the mask.  Two eager passes and two replays of one captured pass must each show a different pattern."""
+    from openpystruct_amd import tfd_fused as TF, train
+    from openpystruct_amd.surrogates import ModelOnePassTransformerWithDiffusion
+    torch.manual_seed(5)
+    model = ModelOnePassTransformerWithDiffusion(6, 120, 100, dropout=0.0).to(DEV)
+    model.dropout.p = 0.5
+    params = list(model.parameters())
+    flat = torch.zeros(sum(q.numel() for q in params), device=DEV)
+    off = 0
+    for q in params:
+        q.grad = flat[off:off + q.numel()].view_as(q)
+        off += q.numel()
+    opt = train.FlatClipAdam(params, flat, 1e-3)
+    stash, dst, patched = train.enable_shadow_linears(model, opt, params, flat)
+    assert TF.patch_model(model, seed=3, direct_param_grads=True)
+    model.fc2 = nn.Identity()
+    model.train()
+    x = torch.randn(64, 6, 120, generator=torch.Generator().manual_seed(6)).to(DEV)
+
+    def zeros_of(t):
+        return (t.float() == 0)
+
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        m1 = zeros_of(model(x))
+        m2 = zeros_of(model(x))
+    for m in (m1, m2):
+        assert 0.35 < float(m.float().mean()) < 0.85            # ReLU zeros + p = 0.5 dropout zeros
+    assert float((m1 != m2).float().mean()) > 0.1                # another mask in the second pass
+    static = x.clone()
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side), torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        model(static)                                            # warm-up on the capture stream
+        side.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            out = model(static)
+    graph.replay(); torch.cuda.synchronize()
+    r1 = zeros_of(out).clone()
+    graph.replay(); torch.cuda.synchronize()
+    r2 = zeros_of(out).clone()
+    assert float((r1 != r2).float().mean()) > 0.1                # ... and in every replay of a captured step
+    train.disable_shadow_linears(patched)
+    TF.unpatch_model(model)
+
+
 def test_tfd_training_with_the_fast_encoder_follows_the_framework_path(monkeypatch):
     """Six epochs of the TFD loop (dropout 0.1, diffusion noise on) with the encoder blocks vs the framework's encoder: two draws of the
     same stochastic process -- final training losses within 8 % of each other, both decreasing (800 groups: two steps per epoch)."""

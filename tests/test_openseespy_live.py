@@ -73,3 +73,64 @@ def test_singular_model_returns_a_code():
     ops.system('BandSPD'); ops.numberer('RCM'); ops.constraints('Plain')
     ops.integrator('LoadControl', 1.0); ops.algorithm('Linear'); ops.analysis('Static')
     assert ops.analyze(1) != 0                           # MultiCore.py:182-186 relies on a code, not an exception
+
+
+def build_frame_and_analyze(topo, cfg, I):
+    """The frame script's command sequence (FrameOpt_Discrete_Beta.py:75-139), typed out from SURVEY.md 8(f1): ground row fully
+    fixed, lateral nodal loads on the left column line, `beamUniform(w, w)` on the beams (Wy AND the axial Wx = Wy quirk, FR:131),
+    BandGeneral + Newton."""
+    ops.wipe()
+    ops.model('basic', '-ndm', 2, '-ndf', 3)
+    ops.geomTransf('Linear', 1)
+    for n, (x, y) in enumerate(topo.coords):
+        ops.node(n + 1, float(x), float(y))
+    for n, f3 in enumerate(topo.fix3):
+        if f3.any():
+            ops.fix(n + 1, int(f3[0]), int(f3[1]), int(f3[2]))
+    for e, (a, b) in enumerate(topo.conn):
+        ops.element('elasticBeamColumn', e + 1, int(a) + 1, int(b) + 1, cfg.A, cfg.E, float(I[e]), 1)
+    ops.timeSeries('Linear', 1); ops.pattern('Plain', 1, 1)
+    for n, ld in enumerate(topo.nodal_loads):
+        if np.any(ld != 0):
+            ops.load(n + 1, float(ld[0]), float(ld[1]), float(ld[2]))
+    for e in range(len(topo.conn)):
+        if topo.wy[e] != 0.0 or topo.wx[e] != 0.0:
+            ops.eleLoad('-ele', e + 1, '-type', '-beamUniform', float(topo.wy[e]), float(topo.wx[e]))
+    ops.system('BandGeneral'); ops.numberer('RCM'); ops.constraints('Plain')
+    ops.integrator('LoadControl', 1.0); ops.algorithm('Newton'); ops.analysis('Static')
+    return ops.analyze(1)
+
+
+@pytest.mark.parametrize("bays,stories", [(1, 1), (3, 2), (10, 10)])
+def test_frame_oracle_equals_openseespy(bays, stories):
+    """Pins the 3-DOF frame oracle (global-Fy "shear" FR:151-153 and end moments FR:153 included) the day a box has the wheel."""
+    from openpystruct_amd import frames
+    cfg = frames.FrameConfig()
+    topo = frames.grid_frame(bays, stories, cfg, device="cpu")
+    rng = np.random.default_rng(bays * 100 + stories)
+    I = np.exp(rng.uniform(np.log(5e-5), np.log(5e-3), size=topo.Ne))
+    assert build_frame_and_analyze(topo, cfg, I) == 0
+    d, f, st, _, _ = bo.solve_model_3dof(topo.coords, topo.conn, topo.A, topo.E, I, topo.fix3, topo.nodal_loads, wy=topo.wy, wx=topo.wx)
+    assert st == 0
+    F = np.array([ops.eleResponse(e + 1, 'forces') for e in range(topo.Ne)])
+    U = np.array([[ops.nodeDisp(n + 1, j) for j in (1, 2, 3)] for n in range(topo.Nn)])
+    np.testing.assert_allclose(U, d, rtol=1e-8, atol=1e-9 * np.abs(d).max())
+    np.testing.assert_allclose(F, f, rtol=1e-8, atol=1e-9 * np.abs(f).max())
+
+
+def test_frame_mechanism_returns_a_code():
+    """A frame without any support is singular: `analyze` must answer with a non-zero code (what the build's status mirrors)."""
+    from openpystruct_amd import frames
+    cfg = frames.FrameConfig()
+    topo = frames.grid_frame(1, 1, cfg, device="cpu")
+    ops.wipe()
+    ops.model('basic', '-ndm', 2, '-ndf', 3)
+    ops.geomTransf('Linear', 1)
+    for n, (x, y) in enumerate(topo.coords):
+        ops.node(n + 1, float(x), float(y))
+    for e, (a, b) in enumerate(topo.conn):
+        ops.element('elasticBeamColumn', e + 1, int(a) + 1, int(b) + 1, cfg.A, cfg.E, cfg.I0, 1)
+    ops.timeSeries('Linear', 1); ops.pattern('Plain', 1, 1); ops.load(topo.Nn, 1.0, 0.0, 0.0)
+    ops.system('BandGeneral'); ops.numberer('RCM'); ops.constraints('Plain')
+    ops.integrator('LoadControl', 1.0); ops.algorithm('Newton'); ops.analysis('Static')
+    assert ops.analyze(1) != 0
