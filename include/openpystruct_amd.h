@@ -436,6 +436,11 @@ int ops_diffusion_combine_fwd(int B, int Nc, int d, const void* m, const float* 
                               const float* pe, float* z, void* stream);
 int ops_diffusion_combine_bwd(int B, int Nc, int d, const float* g, const float* sa, const float* sb, void* dm, float* dcls, void* stream);
 
+/* Measurement aid of bench.py, not a product call: device-to-device copy of `bytes` (a multiple of 16, both pointers 16-byte
+ * aligned) with one 16-byte access per lane and instruction -- the achievable HBM rate the roofline records quote next to the
+ * nominal 8 TB/s.  non_temporal != 0: nt stores. */
+int ops_hbm_copy16(const void* src, void* dst, size_t bytes, int non_temporal, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -60,6 +60,7 @@ EXPORTS = (
     "ops_diffusion_noise",
     "ops_diffusion_combine_fwd",
     "ops_diffusion_combine_bwd",
+    "ops_hbm_copy16",
 )
 
 OK, ERR_INVALID_ARG, ERR_UNSUPPORTED, ERR_LAUNCH = 0, 1, 2, 3
@@ -166,6 +167,8 @@ def load():
     rj = lib.ops_beam_residual_vjp_f64
     rj.restype = it
     rj.argtypes = [it, it, vp, lg, vp, lg, vp, vp, lg] + [vp] * 10
+    lib.ops_hbm_copy16.restype = it
+    lib.ops_hbm_copy16.argtypes = [vp, vp, ctypes.c_size_t, it, vp]
     fr = lib.ops_frame_solve_batched_f64
     fr.restype = it
     fr.argtypes = [it] * 5 + [vp] * 8 + [lg] + [vp] * 6 + [ctypes.c_size_t, vp]
