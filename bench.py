@@ -228,6 +228,8 @@ def surrogate_epoch_times(dev, rank, world, epochs, cases=50000):
     """Second half of BASELINE.json's metric: PINN / TFD epoch time (weak scaling: `cases` generated cases and the
     reference's batch size per GPU).  Returns a dict for the JSON line; never raises."""
     try:
+        if world > 1:     # HIP events around the segments of the data-parallel step: the first multi-GPU run explains its own scaling
+            os.environ.setdefault("OPS_AMD_DP_PROFILE", "1")
         from openpystruct_amd import dataprep, sizing, train
         t0 = time.perf_counter()
         rec = sizing.generate_dataset(cases * world, sizing.SizingConfig(), dev, rank=rank, world=world)
@@ -246,6 +248,8 @@ def surrogate_epoch_times(dev, rank, world, epochs, cases=50000):
                          "dtype": "bf16", "step_us": 1e6 * sum(ep) / len(ep) / max(1, r["steps_per_epoch"]),
                          "path": {"pinn": "layer-block launches (pinn_fused.py, csrc/mlp_block.hip)",
                                   "tfd": "autograd over block launches (tfd_fused.py, csrc/seq_block.hip)"}[kind]}
+            if "dp_segments" in r:       # N > 1: device time of [graph A | all-reduce | graph B] per step (HIP events, mean over the epochs after the first)
+                out[kind]["dp_segments"] = r["dp_segments"]
         # BASELINE config 4: the TFD surrogate with the physics loss through the HIP FE-residual kernels.  The residual needs
         # per-case targets (n_cases = 1: 40 000 training rows per GPU instead of 6 666 groups), see DESIGN.md section 8
         scfg = sizing.SizingConfig()
@@ -449,6 +453,17 @@ def main():
                 "distinct_bytes": n_sets * BYTES_PER_SOLVE * Bm, "kernel": kname, "kernel_us": us,
                 "value": world * Bm * Km / (dev_ms * 1e-3), "achieved": ach, "frac": ach / HBM_PEAK_GBS, "launch": mode}
 
+    import threading
+
+    def fe_bail():       # a stalled collective of the FE part (barrier / time all-reduce) must not hang the driver: exit non-zero
+        print(json.dumps({"metric": "beam FE solves/s (100-elem, batched)", "error": "a collective of the FE measurement stalled for 300 s",
+                          "n_gpus": world}), flush=True)
+        os._exit(3)
+
+    fe_guard = threading.Timer(300.0, fe_bail)
+    fe_guard.daemon = True
+    if world > 1:
+        fe_guard.start()
     dev_ms, wall, kname, mode = measure(B, K, W, max(1, args.sets), args.tiling)
 
     if rank == 0:
@@ -514,6 +529,7 @@ def main():
         # (12 untimed launches first: after the sub-millisecond launches above the first ~10 ms of 1 ms launches run 5-10 %
         #  slow -- clocks and TLBs of 5 GB of fresh buffers, measured with scripts/sat_ab.py)
         extras["saturating"] = sub_record(1 << 20, 10, 1, args.tiling, "2^20 beams per launch (5.2 GB per launch: HBM-resident by size)", warm=12)
+    fe_guard.cancel()
     if rank == 0:
         rec.update(extras)
         if "cold" in extras:
@@ -539,7 +555,6 @@ def main():
     # part ever stalls, rank 0 still prints the (already measured) FE line and every rank leaves.
     n_train = args.train_epochs if args.train_epochs is not None else (5 if world == 1 else 3)
     if n_train > 0:
-        import threading
 
         def bail():
             if rank == 0:

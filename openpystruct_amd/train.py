@@ -359,6 +359,14 @@ def disable_shadow_linears(patched) -> None:
 
 
 _GROUP_WGRAD = os.environ.get("OPS_AMD_GROUP_WGRAD", "1") == "1"    # A/B switch: 0 = one launch per product, inside backward
+# data-parallel step (world > 1).  Default: [graph A: noise, forward, loss, backward] -> gradient all-reduce -> [graph B: average, clip,
+# Adam], the collective enqueued asynchronously (the host never blocks on it: `wait()` only orders the compute stream behind the
+# collective's) -- OPS_AMD_DP_ASYNC=0 is the plain blocking-call form, bit for bit the same arithmetic (tests/test_surrogates.py).
+# OPS_AMD_DP_ONE_GRAPH=1: try to capture the collective too, the whole step as ONE graph (RCCL collectives can be captured; never run on
+# more than one MI355X here, hence opt-in); any failure while capturing falls back to the two-graph form.
+_DP_ASYNC = os.environ.get("OPS_AMD_DP_ASYNC", "1") == "1"
+_DP_ONE_GRAPH = os.environ.get("OPS_AMD_DP_ONE_GRAPH", "0") == "1"
+_DP_PROFILE = os.environ.get("OPS_AMD_DP_PROFILE", "0") == "1"       # HIP events around the step's segments, reported as out["dp_segments"]
 F_linear = torch.nn.functional.linear
 _SHADOW_LINEAR = os.environ.get("OPS_AMD_SHADOW_LINEAR", "1") == "1"   # A/B switch: 0 = nn.Linear under autocast
 
@@ -570,12 +578,19 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
         torch.nn.utils.clip_grad_norm_(params, 1.0)                      # PINN:766
         opt.step()
 
+    def allreduce_grads():
+        """ONE flat all-reduce of every parameter gradient (2.38 MB PINN / 1.44 MB TFD)."""
+        if _DP_ASYNC:
+            dist.all_reduce(flat, async_op=True).wait()                  # GPU: stream ordering only, the host does not block
+        else:
+            dist.all_reduce(flat)
+
     def train_step(Xb, Yb, noise_t, rows=None):
         if engine is not None:
             engine.gather(Xtr, Ytr, rows, noise_t, engine_seed)
         loss = fwd_bwd(Xb, Yb, noise_t, physics_inputs(rows) if physics is not None else None)
         if world > 1:
-            dist.all_reduce(flat)                                        # the step's only collective (RCCL over xGMI)
+            allreduce_grads()                                            # the step's only collective (RCCL over xGMI)
         apply_update()
         return loss
 
@@ -610,6 +625,7 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
             raise RuntimeError(f"ops_gather_rows_noise_f32 failed with code {rc}")
 
     graph = graph_b = vgraph = None
+    graph_mode_one = False
     bs = cfg.batch_size
     if use_graph and Xtr.shape[0] >= bs:
         # static buffers + a few eager warm-up steps on a side stream, then capture one full-batch step:
@@ -634,14 +650,30 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
             side.synchronize()
             try:
                 graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph, stream=side, capture_error_mode="thread_local"):
-                    s_loss = fwd_bwd(sX, sY, s_noise, sP, prenoised=_FUSED_PREP)
-                    if world == 1:
-                        apply_update()
-                if world > 1:
-                    graph_b = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(graph_b, stream=side, capture_error_mode="thread_local"):
-                        apply_update()
+                one_graph = False
+                if world > 1 and _DP_ONE_GRAPH and dist.get_backend() == "nccl":
+                    try:                 # the collective inside the capture: one replay per step, no host work between the segments
+                        g1 = torch.cuda.CUDAGraph()
+                        with torch.cuda.graph(g1, stream=side, capture_error_mode="thread_local"):
+                            s_loss = fwd_bwd(sX, sY, s_noise, sP, prenoised=_FUSED_PREP)
+                            dist.all_reduce(flat)
+                            apply_update()
+                        graph, one_graph = g1, True
+                        graph_mode_one = True
+                    except Exception as e:
+                        if log:
+                            log(f"capturing the gradient all-reduce failed ({e!r}); two graphs around an eager collective")
+                        torch.cuda.synchronize(device)
+                        graph = torch.cuda.CUDAGraph()
+                if not one_graph:
+                    with torch.cuda.graph(graph, stream=side, capture_error_mode="thread_local"):
+                        s_loss = fwd_bwd(sX, sY, s_noise, sP, prenoised=_FUSED_PREP)
+                        if world == 1:
+                            apply_update()
+                    if world > 1:
+                        graph_b = torch.cuda.CUDAGraph()
+                        with torch.cuda.graph(graph_b, stream=side, capture_error_mode="thread_local"):
+                            apply_update()
             except Exception as e:          # same arithmetic eagerly; the step is then launch-bound
                 if log:
                     log(f"HIP graph capture failed ({e!r}); training eagerly")
@@ -678,6 +710,7 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
 
     best_val, best_state, no_improve = float("inf"), None, 0
     n_epochs = max_epochs if max_epochs is not None else cfg.num_epochs
+    seg_ev = [] if (_DP_PROFILE and on_gpu and graph is not None) else None      # per-step event quadruples (first epoch excluded below)
     for epoch in range(1, n_epochs + 1):
         if device.type == "cuda":
             torch.cuda.synchronize(device)
@@ -707,10 +740,24 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
                     torch.index_select(Ytr, 0, idx, out=sY)
                 if sP is not None:
                     physics_inputs(idx, out=sP)
-                graph.replay()
-                if graph_b is not None:
-                    dist.all_reduce(flat)
-                    graph_b.replay()
+                if seg_ev is not None and len(seg_ev) < 4096:
+                    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+                    ev[0].record()
+                    graph.replay()
+                    ev[1].record()
+                    if graph_b is not None:
+                        allreduce_grads()
+                        ev[2].record()
+                        graph_b.replay()
+                    else:
+                        ev[2].record()
+                    ev[3].record()
+                    seg_ev.append(ev)
+                else:
+                    graph.replay()
+                    if graph_b is not None:
+                        allreduce_grads()
+                        graph_b.replay()
                 if engine is None:
                     tot += s_loss
             elif engine is not None:
@@ -784,8 +831,14 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
     sI = data.scalers_Y["I"]
     p = sI.inverse_transform(preds[:, :nel]).clamp(0.0, 1e10)                # PINN:843-848
     t = sI.inverse_transform(Yva[:, :nel]).clamp(0.0, 1e10)
-    return {"model": model, "history": hist, "best_val": best_val, "best_state": best_state, "r2_val_I": r2_score(t, p),
-            "epochs": len(hist["train"]), "steps_per_epoch": nb_tr}
+    out = {"model": model, "history": hist, "best_val": best_val, "best_state": best_state, "r2_val_I": r2_score(t, p),
+           "epochs": len(hist["train"]), "steps_per_epoch": nb_tr}
+    if seg_ev:                           # mean device time of the step's segments over the profiled steps (first epoch's excluded)
+        use = seg_ev[nb_tr:] or seg_ev
+        mean = lambda i, j: 1e3 * sum(e[i].elapsed_time(e[j]) for e in use) / len(use)      # noqa: E731
+        out["dp_segments"] = {"steps": len(use), "step_us": mean(0, 3), "graph_a_us": mean(0, 1), "allreduce_us": mean(1, 2),
+                              "graph_b_us": mean(2, 3), "one_graph": bool(graph_mode_one), "world": world}
+    return out
 
 
 def save_best(state: Dict[str, torch.Tensor], path: str) -> None:

@@ -283,3 +283,34 @@ def test_user_input_front_end_scales_like_training_rows():
     y = d.Y_train[:3]
     back = dataprep.predicted_inertia(d, y)
     assert torch.allclose(d.scalers_Y["I"].transform(back), y[:, :100], atol=1e-5)
+
+
+def _ddp_async_worker(rank, world, port, q):
+    import importlib
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=__import__("datetime").timedelta(seconds=180))
+    n = 60 * world + 7
+    rec = _fake_records(n, seed=5)
+    lo, hi = sizing.shard_range(n, rank, world)
+    shard = {k: (v[lo:hi] if torch.is_tensor(v) else v[lo:hi]) for k, v in rec.items()}
+    res = []
+    for async_op in ("1", "0"):
+        os.environ["OPS_AMD_DP_ASYNC"] = async_op
+        importlib.reload(train)
+        d = dataprep.prepare(shard, kind="pinn", seed=2, distributed=True)
+        out = train.train_surrogate("pinn", d, train.PinnConfig(batch_size=4, patience=3), device="cpu", autocast_dtype=None, max_epochs=2, seed=4)
+        res.append(torch.cat([p.detach().reshape(-1) for p in out["model"].parameters()]).numpy())
+    q.put((rank, res[0], res[1]))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_async_gradient_allreduce_equals_the_blocking_form_bit_for_bit(world):
+    """The data-parallel step enqueues its one collective asynchronously (train.allreduce_grads; OPS_AMD_DP_ASYNC=0 is the blocking
+    call): same arithmetic, so two epochs end with bit-identical weights, on every rank, at world 2 and 4."""
+    from tests.helpers import run_ranks
+    outs = sorted(run_ranks(_ddp_async_worker, world, timeout=600), key=lambda o: o[0])
+    for _, wa, wb in outs:
+        assert np.array_equal(wa, wb)
+        assert np.array_equal(wa, outs[0][1])
