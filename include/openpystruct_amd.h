@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define OPS_AMD_ABI_VERSION 3
+#define OPS_AMD_ABI_VERSION 4
 
 /* return codes of the launch functions (per-beam results are in `status`) */
 #define OPS_AMD_OK 0
@@ -433,8 +433,9 @@ int ops_linear_wgrad_accumulate_group(int nprob, const ops_wgrad_problem* proble
 int ops_diffusion_noise(long rows, int d, const float* x, const long long* t, const float* eps, const float* alpha_cumprod, float* xn32,
                         void* xn16, float* sa, float* sb, void* stream);
 int ops_diffusion_combine_fwd(int B, int Nc, int d, const void* m, const float* xn32, const float* sa, const float* sb, const float* cls,
-                              const float* pe, float* z, void* stream);
-int ops_diffusion_combine_bwd(int B, int Nc, int d, const float* g, const float* sa, const float* sb, void* dm, float* dcls, void* stream);
+                              const float* pe, float* z, void* z16 /* optional bfloat16 copy of z */, void* stream);
+int ops_diffusion_combine_bwd(int B, int Nc, int d, const float* g /* float32, may be NULL */, const void* g16 /* bfloat16, may be NULL: the
+                              gradient is g + g16 */, const float* sa, const float* sb, void* dm, float* dcls, void* stream);
 
 /* Measurement aid of bench.py, not a product call: device-to-device copy of `bytes` (a multiple of 16, both pointers 16-byte
  * aligned) with one 16-byte access per lane and instruction -- the achievable HBM rate the roofline records quote next to the

@@ -9,7 +9,7 @@ import ctypes
 import os
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-ABI_VERSION = 3      # include/openpystruct_amd.h OPS_AMD_ABI_VERSION
+ABI_VERSION = 4      # include/openpystruct_amd.h OPS_AMD_ABI_VERSION
 # OPS_AMD_LIB lets A/B kernel experiments point at another build of the same C ABI
 LIB_PATH = os.environ.get("OPS_AMD_LIB") or os.path.join(_PKG, "lib", "libopenpystruct_amd.so")
 
@@ -224,9 +224,9 @@ def load():
     lib.ops_diffusion_noise.restype = it
     lib.ops_diffusion_noise.argtypes = [lg, it, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.ops_diffusion_combine_fwd.restype = it
-    lib.ops_diffusion_combine_fwd.argtypes = [it, it, it, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.ops_diffusion_combine_fwd.argtypes = [it, it, it, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.ops_diffusion_combine_bwd.restype = it
-    lib.ops_diffusion_combine_bwd.argtypes = [it, it, it, vp, vp, vp, vp, vp, vp]
+    lib.ops_diffusion_combine_bwd.argtypes = [it, it, it, vp, vp, vp, vp, vp, vp, vp]
     lib.ops_linear_wgrad_accumulate_group.restype = it
     lib.ops_linear_wgrad_accumulate_group.argtypes = [it, ctypes.POINTER(WgradProblem), vp]
     lib.ops_linear_wgrad_accumulate.restype = it

@@ -23,23 +23,46 @@ __device__ __forceinline__ uint16_t ip_f2bf(float f) {
   return (uint16_t)(u >> 16);
 }
 
+__device__ __forceinline__ float ip_noisy(float v, float sg, unsigned long long seed, unsigned long long call, long i) {
+  if (sg == 0.0f) return v;
+  const uint64_t h = ip_mix(seed + 0x9E3779B97F4A7C15ull * (call + 1) + (uint64_t)i * 0xD1B54A32D192ED03ull);
+  const float u1 = ((float)(h >> 40) + 1.0f) * (1.0f / 16777216.0f);          // (0, 1]
+  const float u2 = (float)((h >> 16) & 0xFFFFFFull) * (1.0f / 16777216.0f);   // [0, 1)
+  return v + sg * sqrtf(-2.0f * __logf(u1)) * __cosf(6.28318530717958647692f * u2);
+}
+
+// VEC4: F % 4 == 0 and 16-byte aligned rows -- four consecutive features per thread and trip (one index load, one 16-byte row load,
+// one 8- or 16-byte store); the grid is at most 128 workgroups (call_counter.hpp), so the trips must be wide
+template <bool VEC4>
 __global__ __launch_bounds__(256) void gather_noise_kernel(int B, long F, const float* __restrict__ X, const long long* __restrict__ idx,
                                                             const float* __restrict__ sigma, unsigned long long seed,
                                                             unsigned long long* __restrict__ counter, void* __restrict__ out, int out_bf16) {
   const long n = (long)B * F;
   const float sg = sigma ? *sigma : 0.0f;
   const unsigned long long call = counter ? *counter : 0ull;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
-    const long b = i / F, f = i - b * F;
-    float v = X[idx[b] * F + f];
-    if (sg != 0.0f) {
-      const uint64_t h = ip_mix(seed + 0x9E3779B97F4A7C15ull * (call + 1) + (uint64_t)i * 0xD1B54A32D192ED03ull);
-      const float u1 = ((float)(h >> 40) + 1.0f) * (1.0f / 16777216.0f);          // (0, 1]
-      const float u2 = (float)((h >> 16) & 0xFFFFFFull) * (1.0f / 16777216.0f);   // [0, 1)
-      v += sg * sqrtf(-2.0f * __logf(u1)) * __cosf(6.28318530717958647692f * u2);
+  if (VEC4) {
+    const long F4 = F >> 2, n4 = n >> 2;
+    for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < n4; q += (long)gridDim.x * 256) {
+      const long b = q / F4, f = (q - b * F4) << 2, i = q << 2;
+      const float4 x = *(const float4*)(X + idx[b] * F + f);
+      const float v0 = ip_noisy(x.x, sg, seed, call, i), v1 = ip_noisy(x.y, sg, seed, call, i + 1);
+      const float v2 = ip_noisy(x.z, sg, seed, call, i + 2), v3 = ip_noisy(x.w, sg, seed, call, i + 3);
+      if (out_bf16) {
+        uint2 o;
+        o.x = (uint32_t)ip_f2bf(v0) | ((uint32_t)ip_f2bf(v1) << 16);
+        o.y = (uint32_t)ip_f2bf(v2) | ((uint32_t)ip_f2bf(v3) << 16);
+        *(uint2*)((uint16_t*)out + i) = o;
+      } else {
+        *(float4*)((float*)out + i) = make_float4(v0, v1, v2, v3);
+      }
     }
-    if (out_bf16) ((uint16_t*)out)[i] = ip_f2bf(v);
-    else ((float*)out)[i] = v;
+  } else {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+      const long b = i / F, f = i - b * F;
+      const float v = ip_noisy(X[idx[b] * F + f], sg, seed, call, i);
+      if (out_bf16) ((uint16_t*)out)[i] = ip_f2bf(v);
+      else ((float*)out)[i] = v;
+    }
   }
   // one increment per launch, by the last workgroup to finish (call_counter.hpp)
   if (counter && threadIdx.x == 0) call_counter_done(counter, gridDim.x);
@@ -51,7 +74,12 @@ extern "C" int ops_gather_rows_noise_f32(int B, long F, const float* X, const lo
                                          unsigned long long* counter, void* out, int out_is_bf16, void* stream) {
   if (B < 1 || F < 1 || !X || !idx || !out) return OPS_AMD_ERR_INVALID_ARG;
   const long n = (long)B * F;
-  const unsigned grid = (unsigned)((n + 255) / 256 > 128 ? 128 : (n + 255) / 256);   // grid-stride; <= 128 reports to the call counter
-  hipLaunchKernelGGL(opsamd::gather_noise_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, B, F, X, idx, sigma, seed, counter, out, out_is_bf16);
+  const bool vec4 = (F % 4 == 0) && ((((uintptr_t)X | (uintptr_t)out) & 15) == 0);
+  const long items = vec4 ? n / 4 : n;
+  const unsigned grid = (unsigned)((items + 255) / 256 > 128 ? 128 : (items + 255) / 256);   // grid-stride; <= 128 reports to the call counter
+  if (vec4)
+    hipLaunchKernelGGL(opsamd::gather_noise_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, B, F, X, idx, sigma, seed, counter, out, out_is_bf16);
+  else
+    hipLaunchKernelGGL(opsamd::gather_noise_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, B, F, X, idx, sigma, seed, counter, out, out_is_bf16);
   return hipGetLastError() == hipSuccess ? OPS_AMD_OK : OPS_AMD_ERR_LAUNCH;
 }

@@ -721,7 +721,7 @@ __global__ __launch_bounds__(256) void diffusion_noise_kernel(long rows, int d, 
 __global__ __launch_bounds__(256) void diffusion_combine_fwd_kernel(int B, int Nc, int d, const uint16_t* __restrict__ m, const float* __restrict__ xn32,
                                                                      const float* __restrict__ sa, const float* __restrict__ sb,
                                                                      const float* __restrict__ cls, const float* __restrict__ pe,
-                                                                     float* __restrict__ z) {
+                                                                     float* __restrict__ z, uint16_t* __restrict__ z16) {
   const int S = Nc + 1;
   const long n = (long)B * S * d;
   for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256) {
@@ -736,12 +736,16 @@ __global__ __launch_bounds__(256) void diffusion_combine_fwd_kernel(int B, int N
       const long r = b * Nc + (s - 1), q = r * d + c;
       v = (xn32[q] - sb[r] * sq_bf2f(m[q])) / sa[r];
     }
-    z[e] = v + pe[(long)s * d + c];
+    v += pe[(long)s * d + c];
+    z[e] = v;
+    if (z16) z16[e] = sq_f2bf(v);                           // the first in-projection's operand: no cast node
   }
 }
 
 // dm = -(sb / sa) g[:, 1:, :] (bf16);  dcls += sum_b g[b, 0, :]  (float atomics, one per column and workgroup)
-__global__ __launch_bounds__(256) void diffusion_combine_bwd_kernel(int B, int Nc, int d, const float* __restrict__ g, const float* __restrict__ sa,
+// g = g32 + g16 where both are given (the float32 residual stream's gradient and the bf16 in-projection's)
+__global__ __launch_bounds__(256) void diffusion_combine_bwd_kernel(int B, int Nc, int d, const float* __restrict__ g, const uint16_t* __restrict__ g16,
+                                                                     const float* __restrict__ sa,
                                                                      const float* __restrict__ sb, uint16_t* __restrict__ dm,
                                                                      float* __restrict__ dcls) {
   const int S = Nc + 1;
@@ -750,7 +754,8 @@ __global__ __launch_bounds__(256) void diffusion_combine_bwd_kernel(int B, int N
     const int c = (int)(q % d);
     const long r = q / d, b = r / Nc;
     const int s = (int)(r - b * Nc) + 1;
-    dm[q] = sq_f2bf(-(sb[r] / sa[r]) * g[(b * S + s) * d + c]);
+    const long gi = (b * S + s) * d + c;
+    dm[q] = sq_f2bf(-(sb[r] / sa[r]) * ((g ? g[gi] : 0.0f) + (g16 ? sq_bf2f(g16[gi]) : 0.0f)));
   }
   if (dcls && (int)blockIdx.x < 64) {                      // 64 workgroups share the [CLS] rows, eight independent loads per trip
     for (int c = threadIdx.x; c < d; c += 256) {
@@ -758,7 +763,10 @@ __global__ __launch_bounds__(256) void diffusion_combine_bwd_kernel(int B, int N
       for (long b0 = blockIdx.x; b0 < B; b0 += 64 * 8) {
         float v[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) { const long b = b0 + 64 * k; v[k] = b < B ? g[(b * S) * d + c] : 0.0f; }
+        for (int k = 0; k < 8; ++k) {
+          const long b = b0 + 64 * k, gi = (b * S) * d + c;
+          v[k] = b < B ? (g ? g[gi] : 0.0f) + (g16 ? sq_bf2f(g16[gi]) : 0.0f) : 0.0f;
+        }
 #pragma unroll
         for (int k = 0; k < 8; ++k) acc += v[k];
       }
@@ -780,21 +788,22 @@ extern "C" int ops_diffusion_noise(long rows, int d, const float* x, const long 
 }
 
 extern "C" int ops_diffusion_combine_fwd(int B, int Nc, int d, const void* m, const float* xn32, const float* sa, const float* sb, const float* cls,
-                                         const float* pe, float* z, void* stream) {
+                                         const float* pe, float* z, void* z16, void* stream) {
   if (B < 1 || Nc < 1 || d < 1 || !m || !xn32 || !sa || !sb || !cls || !pe || !z) return OPS_AMD_ERR_INVALID_ARG;
   long nb = ((long)B * (Nc + 1) * d + 255) / 256;
   if (nb > 2048) nb = 2048;
   hipLaunchKernelGGL(opsamd::diffusion_combine_fwd_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, B, Nc, d, (const uint16_t*)m, xn32,
-                     sa, sb, cls, pe, z);
+                     sa, sb, cls, pe, z, (uint16_t*)z16);
   return sq_check("diffusion_combine_fwd_kernel");
 }
 
-extern "C" int ops_diffusion_combine_bwd(int B, int Nc, int d, const float* g, const float* sa, const float* sb, void* dm, float* dcls, void* stream) {
-  if (B < 1 || Nc < 1 || d < 1 || !g || !sa || !sb || !dm) return OPS_AMD_ERR_INVALID_ARG;
+extern "C" int ops_diffusion_combine_bwd(int B, int Nc, int d, const float* g, const void* g16, const float* sa, const float* sb, void* dm, float* dcls,
+                                         void* stream) {
+  if (B < 1 || Nc < 1 || d < 1 || (!g && !g16) || !sa || !sb || !dm) return OPS_AMD_ERR_INVALID_ARG;
   long nb = ((long)B * Nc * d + 255) / 256;
   if (nb > 2048) nb = 2048;
   if (nb < 64) nb = 64;
-  hipLaunchKernelGGL(opsamd::diffusion_combine_bwd_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, B, Nc, d, g, sa, sb, (uint16_t*)dm,
-                     dcls);
+  hipLaunchKernelGGL(opsamd::diffusion_combine_bwd_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, B, Nc, d, g, (const uint16_t*)g16, sa, sb,
+                     (uint16_t*)dm, dcls);
   return sq_check("diffusion_combine_bwd_kernel");
 }

@@ -35,6 +35,9 @@ class _State:
         self.counter = torch.zeros(1, dtype=torch.int64, device=device)     # advanced once per encoder pass (`advance`), read by every launch
 
         self._zeros = {}
+        self._zeros16 = {}
+        self.src16 = None        # bf16 copy of the encoder's input, handed over by the model's front end (DiffusionCombine)
+        self.last16 = None       # bf16 copy of the encoder's output rows [T, d], for the model's head
 
     def advance(self) -> None:
         self.counter.add_(1)
@@ -45,6 +48,13 @@ class _State:
         if key not in self._zeros:
             self._zeros[key] = torch.zeros(key, dtype=torch.float32, device=self.device)
         return self._zeros[key]
+
+    def zeros16(self, shape) -> torch.Tensor:
+        """A persistent bfloat16 zero tensor (ClsRows.backward writes the [CLS] rows into it; every other row stays zero for good)."""
+        key = tuple(shape)
+        if key not in self._zeros16:
+            self._zeros16[key] = torch.zeros(key, dtype=torch.bfloat16, device=self.device)
+        return self._zeros16[key]
 
     def used(self, site: int) -> torch.Tensor:
         """Where a forward launch leaves the counter value it drew its mask from (one per call: its backward reads it)."""
@@ -115,6 +125,7 @@ class DropoutAddLayerNorm(torch.autograd.Function):
                                                      rstd.data_ptr(), _stream(dev)), "ops_dropout_add_layernorm_fwd")
         ctx.save_for_backward(z, mean, rstd, gamma, beta)
         ctx.cfg = (float(p), st.seed + 7919 * site, used, st, site, res.dtype)
+        ctx.set_materialize_grads(False)        # an unused output's gradient arrives as None, not as a freshly filled zero tensor (one node each)
         return y32, y16
 
     @staticmethod
@@ -124,6 +135,8 @@ class DropoutAddLayerNorm(torch.autograd.Function):
         p, seed, used, st, site, res_dtype = ctx.cfg
         T, d = z.shape
         dev = z.device
+        if g32 is None and g16 is None:
+            return None, None, None, None, None, None, None, None
         if g32 is not None:
             g32 = g32.contiguous()
         if g16 is not None:
@@ -194,6 +207,10 @@ def encoder_forward(enc: nn.TransformerEncoder, src: torch.Tensor, st: _State) -
     st.advance()                           # fresh dropout masks for this pass (the launches only read the counter)
     res = src.reshape(T, d)
     x16: Optional[torch.Tensor] = None
+    if st.src16 is not None:               # the front end's bf16 copy of src (tfd_fused.model_forward)
+        if tuple(st.src16.shape) == (T, d):
+            x16 = st.src16
+        st.src16 = None
     for li, layer in enumerate(enc.layers):
         mha = layer.self_attn
         qkv = mha._ops_in_proj(res if x16 is None else x16)                                         # [T, 3 d] bf16
@@ -204,12 +221,14 @@ def encoder_forward(enc: nn.TransformerEncoder, src: torch.Tensor, st: _State) -
         f = layer.linear2(h)
         res, x16 = DropoutAddLayerNorm.apply(f, res, layer.norm2.weight, layer.norm2.bias, layer.norm2.eps, layer.dropout2.p, st, 4 * li + 3)
     out = res.reshape(B, S, d)
+    st.last16 = x16
     return enc.norm(out) if enc.norm is not None else out
 
 
 class DiffusionCombine(torch.autograd.Function):
-    """z [B, 1 + Nc, d] = [cls | (x_noisy - sb m) / sa] + pe: the tail of DiffusionModule.forward (TFD:474-478), the [CLS] concatenation
-    and the positional encoding (TFD:563-567) in one launch each way.  m [B * Nc, d] bf16: the MLP's output."""
+    """(z, z16) with z [B, 1 + Nc, d] = [cls | (x_noisy - sb m) / sa] + pe: the tail of DiffusionModule.forward (TFD:474-478), the [CLS]
+    concatenation and the positional encoding (TFD:563-567) in one launch each way; z16 is the bfloat16 copy the first in-projection
+    multiplies (no cast node), and the backward launch adds the two gradients itself.  m [B * Nc, d] bf16: the MLP's output."""
 
     @staticmethod
     def forward(ctx, m, xn32, sa, sb, cls, pe, B, Nc, st: _State):
@@ -217,26 +236,55 @@ class DiffusionCombine(torch.autograd.Function):
         m = m.contiguous()
         d = m.shape[1]
         z = torch.empty((B, Nc + 1, d), dtype=torch.float32, device=m.device)
+        z16 = torch.empty((B * (Nc + 1), d), dtype=torch.bfloat16, device=m.device)
         with torch.cuda.device(m.device):
             _check(lib.ops_diffusion_combine_fwd(B, Nc, d, m.data_ptr(), xn32.data_ptr(), sa.data_ptr(), sb.data_ptr(), cls.data_ptr(),
-                                                 pe.data_ptr(), z.data_ptr(), _stream(m.device)), "ops_diffusion_combine_fwd")
+                                                 pe.data_ptr(), z.data_ptr(), z16.data_ptr(), _stream(m.device)), "ops_diffusion_combine_fwd")
         ctx.save_for_backward(sa, sb, cls)
         ctx.cfg = (B, Nc, d, st)
-        return z
+        ctx.set_materialize_grads(False)
+        return z, z16
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, g, g16):
         lib = _cabi.load()
         sa, sb, cls = ctx.saved_tensors
         B, Nc, d, st = ctx.cfg
-        g = g.contiguous().float()
-        dm = torch.empty((B * Nc, d), dtype=torch.bfloat16, device=g.device)
+        if g is None and g16 is None:
+            return (None,) * 9
+        if g is not None:
+            g = g.contiguous().float()
+        if g16 is not None:
+            g16 = g16.contiguous()
+            if g16.dtype != torch.bfloat16:
+                g16 = g16.to(torch.bfloat16)
+        dev = (g if g is not None else g16).device
+        dm = torch.empty((B * Nc, d), dtype=torch.bfloat16, device=dev)
         direct = st.direct and cls.grad is not None and cls.grad.dtype == torch.float32 and cls.grad.is_contiguous()
         dcls = cls.grad if direct else torch.zeros_like(cls)
-        with torch.cuda.device(g.device):
-            _check(lib.ops_diffusion_combine_bwd(B, Nc, d, g.data_ptr(), sa.data_ptr(), sb.data_ptr(), dm.data_ptr(), dcls.data_ptr(),
-                                                 _stream(g.device)), "ops_diffusion_combine_bwd")
+        with torch.cuda.device(dev):
+            _check(lib.ops_diffusion_combine_bwd(B, Nc, d, g.data_ptr() if g is not None else None, g16.data_ptr() if g16 is not None else None,
+                                                 sa.data_ptr(), sb.data_ptr(), dm.data_ptr(), dcls.data_ptr(), _stream(dev)),
+                   "ops_diffusion_combine_bwd")
         return dm, None, None, None, None if direct else dcls, None, None, None, None
+
+
+class ClsRows(torch.autograd.Function):
+    """rows 0, S, 2 S, ... of x16 [B * S, d] as a strided [B, d] view (the head's first product reads it in place: row stride S d);
+    backward: the gradient rows into a persistent zero tensor -- no fill, no cast."""
+
+    @staticmethod
+    def forward(ctx, x16, B, S, st: _State):
+        ctx.cfg = (B, S, st)
+        return x16.view(B, S, x16.shape[1])[:, 0, :]
+
+    @staticmethod
+    def backward(ctx, g):
+        B, S, st = ctx.cfg
+        d = g.shape[1]
+        full = st.zeros16((B * S, d))
+        full.view(B, S, d)[:, 0, :].copy_(g)
+        return full, None, None, None
 
 
 def model_forward(model: nn.Module, x: torch.Tensor, st: _State) -> torch.Tensor:
@@ -261,9 +309,14 @@ def model_forward(model: nn.Module, x: torch.Tensor, st: _State) -> torch.Tensor
                                        sa.data_ptr(), sb.data_ptr(), _stream(x.device)), "ops_diffusion_noise")
     h = ActDropout.apply(dm.mlp[0](xn16), 0.0, 0.0, st, 101)                      # ReLU
     m = dm.mlp[2](h)
-    z = DiffusionCombine.apply(m, xn32, sa, sb, model.cls_token, model.pos_encoder.pe, B, Nc, st)
+    z, z16 = DiffusionCombine.apply(m, xn32, sa, sb, model.cls_token, model.pos_encoder.pe, B, Nc, st)
+    st.src16, st.last16 = z16, None                                                # handed to / by the patched encoder pass below
     z = model.transformer_encoder(z)
-    a = model.fc1(z[:, 0, :])                                                      # bf16 [B, hidden]
+    if st.last16 is not None and model.transformer_encoder.norm is None:
+        a = model.fc1(ClsRows.apply(st.last16, B, Nc + 1, st))                     # bf16 [B, hidden], read in place (no slice copy / cast)
+        st.last16 = None
+    else:
+        a = model.fc1(z[:, 0, :])
     zero = st.zeros(a.shape)
     _, y16 = DropoutAddLayerNorm.apply(a, zero, model.norm1.weight, model.norm1.bias, model.norm1.eps, 0.0, st, 102)
     return model.fc2(ActDropout.apply(y16, 0.0, model.dropout.p, st, 103))

@@ -281,3 +281,33 @@ def test_evaluation_mode_backward_goes_through_the_framework_modules():
     with torch.no_grad():       # ... while an evaluation pass without autograd still takes the fused tails and agrees
         y3 = model(x.detach())
     assert torch.allclose(y3, y2.detach(), rtol=2e-4, atol=2e-5)
+
+
+@pytest.mark.parametrize("B,F,bf16", [(128, 684, True), (512, 720, True), (37, 684, False), (64, 103, False), (5, 7, True)])
+def test_gather_rows_noise_kernel(B, F, bf16):
+    """csrc/input_prep.hip: out[b] = X[idx[b]] + sigma * N(0, 1) (PINN:743-756 gather + noise + cast) -- exact gather at sigma = 0, on
+    the 16-byte path (F % 4 == 0) and the scalar one; with noise: unit normal statistics, another draw on every call (the call
+    counter is advanced by the launch's last workgroup), none at all with a NULL counter."""
+    from openpystruct_amd import _cabi
+    lib = _cabi.load()
+    dev = torch.device("cuda")
+    g = torch.Generator().manual_seed(B + F)
+    X = torch.randn(1000, F, generator=g).to(dev)
+    idx = torch.randint(0, 1000, (B,), generator=g).to(dev)
+    out = torch.empty((B, F), dtype=torch.bfloat16 if bf16 else torch.float32, device=dev)
+    cnt = torch.zeros(2, dtype=torch.int64, device=dev)
+    s = torch.cuda.current_stream().cuda_stream
+    sig0 = torch.zeros((), device=dev)
+    assert lib.ops_gather_rows_noise_f32(B, F, X.data_ptr(), idx.data_ptr(), sig0.data_ptr(), 11, cnt.data_ptr(), out.data_ptr(), int(bf16), s) == 0
+    want = X[idx].to(out.dtype)
+    assert torch.equal(out, want)
+    sig = torch.tensor(0.5, device=dev)
+    o1, o2 = torch.empty((B, F), device=dev), torch.empty((B, F), device=dev)
+    assert lib.ops_gather_rows_noise_f32(B, F, X.data_ptr(), idx.data_ptr(), sig.data_ptr(), 11, cnt.data_ptr(), o1.data_ptr(), 0, s) == 0
+    assert lib.ops_gather_rows_noise_f32(B, F, X.data_ptr(), idx.data_ptr(), sig.data_ptr(), 11, cnt.data_ptr(), o2.data_ptr(), 0, s) == 0
+    torch.cuda.synchronize()
+    assert int(cnt[0]) == 3 and int(cnt[1]) == 0
+    n1, n2 = (o1 - X[idx]) / 0.5, (o2 - X[idx]) / 0.5
+    if B * F > 5000:
+        assert abs(float(n1.mean())) < 0.03 and abs(float(n1.std()) - 1.0) < 0.03
+    assert float((n1 - n2).abs().mean()) > 0.5
