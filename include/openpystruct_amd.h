@@ -437,6 +437,34 @@ int ops_diffusion_combine_fwd(int B, int Nc, int d, const void* m, const float* 
 int ops_diffusion_combine_bwd(int B, int Nc, int d, const float* g /* float32, may be NULL */, const void* g16 /* bfloat16, may be NULL: the
                               gradient is g + g16 */, const float* sa, const float* sb, void* dm, float* dcls, void* stream);
 
+/* One post-norm encoder layer of the Transformer-Diffusion surrogate (TransformerDiffusionModule_MultiCase.py:539-575) for the training
+ * step's FORWARD pass as one launch (csrc/seq_layer.hip): in-projection, attention over S <= 8 tokens, out-projection, dropout + add +
+ * LayerNorm, feed-forward with ReLU + dropout, dropout + add + LayerNorm.  T = Bn * S rows; weights / biases: the bfloat16 shadow
+ * parameters, row-major [out, in], 16-byte aligned; d = H * dh <= 128, dh <= 16, ff <= 256, d and ff multiples of 8.  Everything the
+ * backward launches above (ops_seq_attention_bwd, ops_dropout_add_layernorm_bwd, ops_act_dropout_bwd) and the weight-gradient products
+ * read is saved in their formats; dropout masks: their stream, seeds per site, `counter` only read, `used_call` = the value used. */
+typedef struct ops_tfd_layer_args {
+  int32_t Bn, S, H, dh, d, ff;
+  const float* x32;                                   /* [T, d] layer input (residual stream) */
+  const void* W_in; const void* b_in;                 /* [3 d, d], [3 d] */
+  const void* W_out; const void* b_out;               /* [d, d], [d] */
+  const void* W_1; const void* b_1;                   /* [ff, d], [ff] */
+  const void* W_2; const void* b_2;                   /* [d, ff], [d] */
+  const float* gamma1; const float* beta1; float eps1;
+  const float* gamma2; const float* beta2; float eps2;
+  float p_attn, p_1, p_act, p_2;
+  unsigned long long seed_attn, seed_1, seed_act, seed_2;
+  const unsigned long long* counter; unsigned long long* used_call;
+  void* qkv;                                          /* [T, 3 d] bf16 */
+  void* ctx;                                          /* [T, d] bf16: attention output */
+  float* z1; float* mean1; float* rstd1; void* y1_16; /* LayerNorm1: input [T, d] f32, statistics [T], output bf16 */
+  void* u; void* h;                                   /* [T, ff] bf16: feed-forward pre-activation, and ReLU + dropout of it */
+  float* z2; float* mean2; float* rstd2;
+  float* y32; void* y16;                              /* [T, d] layer output, both precisions */
+  unsigned long long* trace;                          /* diagnostics: NULL, or 16 stage stamps per workgroup (100 MHz clock) */
+} ops_tfd_layer_args;
+int ops_tfd_encoder_layer_fwd(const ops_tfd_layer_args* args, void* stream);
+
 /* Measurement aid of bench.py, not a product call: device-to-device copy of `bytes` (a multiple of 16, both pointers 16-byte
  * aligned) with one 16-byte access per lane and instruction -- the achievable HBM rate the roofline records quote next to the
  * nominal 8 TB/s.  non_temporal != 0: nt stores. */

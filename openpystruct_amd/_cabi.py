@@ -61,6 +61,7 @@ EXPORTS = (
     "ops_diffusion_combine_fwd",
     "ops_diffusion_combine_bwd",
     "ops_hbm_copy16",
+    "ops_tfd_encoder_layer_fwd",
 )
 
 OK, ERR_INVALID_ARG, ERR_UNSUPPORTED, ERR_LAUNCH = 0, 1, 2, 3
@@ -116,6 +117,18 @@ class WgradProblem(ctypes.Structure):
                 ("dW", ctypes.c_void_p), ("dbias", ctypes.c_void_p)]
 
 
+class TfdLayerArgs(ctypes.Structure):
+    """Mirror of `ops_tfd_layer_args`."""
+    _vp, _i, _f, _u = ctypes.c_void_p, ctypes.c_int32, ctypes.c_float, ctypes.c_ulonglong
+    _fields_ = [("Bn", _i), ("S", _i), ("H", _i), ("dh", _i), ("d", _i), ("ff", _i), ("x32", _vp),
+                ("W_in", _vp), ("b_in", _vp), ("W_out", _vp), ("b_out", _vp), ("W_1", _vp), ("b_1", _vp), ("W_2", _vp), ("b_2", _vp),
+                ("gamma1", _vp), ("beta1", _vp), ("eps1", _f), ("gamma2", _vp), ("beta2", _vp), ("eps2", _f),
+                ("p_attn", _f), ("p_1", _f), ("p_act", _f), ("p_2", _f),
+                ("seed_attn", _u), ("seed_1", _u), ("seed_act", _u), ("seed_2", _u), ("counter", _vp), ("used_call", _vp),
+                ("qkv", _vp), ("ctx", _vp), ("z1", _vp), ("mean1", _vp), ("rstd1", _vp), ("y1_16", _vp), ("u", _vp), ("h", _vp),
+                ("z2", _vp), ("mean2", _vp), ("rstd2", _vp), ("y32", _vp), ("y16", _vp), ("trace", _vp)]
+
+
 WGRAD_MAX_GROUP = 16
 
 
@@ -167,6 +180,8 @@ def load():
     rj = lib.ops_beam_residual_vjp_f64
     rj.restype = it
     rj.argtypes = [it, it, vp, lg, vp, lg, vp, vp, lg] + [vp] * 10
+    lib.ops_tfd_encoder_layer_fwd.restype = it
+    lib.ops_tfd_encoder_layer_fwd.argtypes = [ctypes.POINTER(TfdLayerArgs), vp]
     lib.ops_hbm_copy16.restype = it
     lib.ops_hbm_copy16.argtypes = [vp, vp, ctypes.c_size_t, it, vp]
     fr = lib.ops_frame_solve_batched_f64

@@ -25,6 +25,7 @@
 #include <stdint.h>
 
 #include "../../include/openpystruct_amd.h"
+#include "dropout_stream.hpp"
 #include "call_counter.hpp"
 
 namespace opsamd {
@@ -47,13 +48,7 @@ __device__ __forceinline__ void fb_st(void* p, long i, int bf16, float v) {
   else ((float*)p)[i] = v;
 }
 // splitmix64 finaliser: a counter-based uniform in [0, 1)
-__device__ __forceinline__ float fb_uniform(uint64_t seed, uint64_t call, uint64_t idx) {
-  uint64_t z = seed + 0x9E3779B97F4A7C15ull * (call + 1) + idx * 0xBF58476D1CE4E5B9ull;
-  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-  z ^= z >> 31;
-  return (float)(z >> 40) * (1.0f / 16777216.0f);
-}
+__device__ __forceinline__ float fb_uniform(uint64_t seed, uint64_t call, uint64_t idx) { return drop_uniform(seed, call, idx); }   // csrc/dropout_stream.hpp
 // sum over the FB_RG row groups of a column (threads t, t + 32, ...): every thread of the column gets the total
 __device__ __forceinline__ float fb_colsum(float v, float* s_red, int col, int rg) {
   __syncthreads();

@@ -36,6 +36,7 @@
 #include <stdint.h>
 
 #include "../../include/openpystruct_amd.h"
+#include "dropout_stream.hpp"
 #include "call_counter.hpp"
 
 namespace opsamd {
@@ -83,13 +84,7 @@ __device__ __forceinline__ double mb_wsum_d(double v) {
   return v;
 }
 // splitmix64 finaliser: a counter-based uniform in [0, 1) (the stream of csrc/fused_bn.hip)
-__device__ __forceinline__ float mb_uniform(uint64_t seed, uint64_t call, uint64_t idx) {
-  uint64_t z = seed + 0x9E3779B97F4A7C15ull * (call + 1) + idx * 0xBF58476D1CE4E5B9ull;
-  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-  z ^= z >> 31;
-  return (float)(z >> 40) * (1.0f / 16777216.0f);
-}
+__device__ __forceinline__ float mb_uniform(uint64_t seed, uint64_t call, uint64_t idx) { return drop_uniform(seed, call, idx); }   // csrc/dropout_stream.hpp
 
 // ---- the product: one 16 x 16 tile per wave, reduction in steps of 32, fragments straight from global memory ----
 // lane l holds A[row l&15][k = 8 (l>>4) + j] and B[k][col l&15] (j = 0..7): 16 contiguous bytes of a row of either operand, and

@@ -18,6 +18,7 @@
 #include <stdint.h>
 
 #include "../../include/openpystruct_amd.h"
+#include "dropout_stream.hpp"
 
 namespace opsamd {
 
@@ -28,13 +29,7 @@ __device__ __forceinline__ uint16_t sq_f2bf(float f) {
   u += 0x7fffu + ((u >> 16) & 1u);
   return (uint16_t)(u >> 16);
 }
-__device__ __forceinline__ float sq_uniform(uint64_t seed, uint64_t call, uint64_t idx) {
-  uint64_t z = seed + 0x9E3779B97F4A7C15ull * (call + 1) + idx * 0xBF58476D1CE4E5B9ull;
-  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-  z ^= z >> 31;
-  return (float)(z >> 40) * (1.0f / 16777216.0f);
-}
+__device__ __forceinline__ float sq_uniform(uint64_t seed, uint64_t call, uint64_t idx) { return drop_uniform(seed, call, idx); }   // csrc/dropout_stream.hpp
 __device__ __forceinline__ float sq_wsum(float v) {
 #pragma unroll
   for (int s = 32; s >= 1; s >>= 1) v += __shfl_xor(v, s, 64);

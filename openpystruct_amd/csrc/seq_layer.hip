@@ -1,0 +1,497 @@
+// One post-norm Transformer encoder layer of the Transformer-Diffusion surrogate
+// (/root/reference/OpenPyStruct_TransformerDiffusionModule_MultiCase.py:539-575: nn.TransformerEncoderLayer, ReLU, batch_first, dropout 0.1)
+// for the TRAINING step's forward pass as ONE launch:
+//
+//   qkv = x W_in^T + b_in | softmax(q k^T / sqrt(dh)) -> dropout -> @ v | a = ctx W_out^T + b_out | y1 = LayerNorm1(x + dropout(a))
+//   u = y1 W_1^T + b_1    | h = dropout(ReLU(u))                        | f = h W_2^T + b_2      | y2 = LayerNorm2(y1 + dropout(f))
+//
+// Through csrc/seq_block.hip + the library's products this is eight kernel nodes of 5-12 us for ~0.9 MFLOP per sample.  Every step is
+// local to a SAMPLE (S <= 8 tokens: [CLS] + 6 load cases), so a wavefront that owns the 16-row tile of 16 / S samples can run the
+// local to a SAMPLE, so ONE WORKGROUP that owns the 16-row tile of 16 / S samples runs the whole layer: bf16 `v_mfma_f32_16x16x32_bf16`
+// products whose A operand sits in LDS and whose B operand -- the weights, 238 KB per layer -- comes straight from the row-major
+// bfloat16 shadow parameters (a lane's B fragment is 16 contiguous bytes of a weight row).  The workgroup's 8 waves split every
+// product's column tiles, which makes a wave's share of the weights 32 sixteen-byte loads per lane: ALL of them are requested at kernel
+// entry.  (First version: one wave per tile row, weights three tiles ahead of the multiplications: 63 tiles = 21 dependent round trips
+// beyond L2 per wave, 85 us per launch -- slower than the eight launches it replaced.)
+//
+// Arithmetic contract = bf16 autocast through the separate kernels: bf16 operands, fp32 accumulation, every product's result rounded to
+// bf16 before it is used, LayerNorm statistics and the residual stream in fp32.  Dropout masks: the counter-based hash of
+// csrc/seq_block.hip with the SAME seeds and element indices, so the backward launches of that file (which regenerate the masks) apply
+// unchanged; everything they read is saved in their formats.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/openpystruct_amd.h"
+#include "dropout_stream.hpp"
+
+namespace opsamd {
+
+void set_last_error(const char* msg);   // beam_solve.hip
+
+typedef __bf16 sl_bf16x8 __attribute__((ext_vector_type(8)));
+typedef float sl_f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned sl_u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float sl_bf2f(uint16_t h) { return __uint_as_float((uint32_t)h << 16); }
+__device__ __forceinline__ uint16_t sl_f2bf(float f) {
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40u);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+__device__ __forceinline__ float sl_round(float f) { return sl_bf2f(sl_f2bf(f)); }
+__device__ __forceinline__ float sl_uniform(uint64_t seed, uint64_t call, uint64_t idx) { return drop_uniform(seed, call, idx); }   // csrc/dropout_stream.hpp
+// lane exchange inside a 16-lane row by DPP (a `__shfl_xor` is a ds_bpermute: an LDS-pipe round trip of ~100 cycles per step; the
+// first version's two LayerNorms spent 2.6 us each in their 32 dependent ones)
+template <int CTRL>
+__device__ __forceinline__ float sl_dpp(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ unsigned sl_dpp_or_quad(unsigned v) {
+  v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);
+  v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true);
+  return v;
+}
+__device__ __forceinline__ float sl_quadsum(float v) {       // all four lanes of a quad get the quad's sum
+  v += sl_dpp<0xB1>(v);                                        // quad_perm [1, 0, 3, 2]
+  v += sl_dpp<0x4E>(v);                                        // quad_perm [2, 3, 0, 1]
+  return v;
+}
+// sum over the 16 lanes that hold one row group of an MFMA accumulator (lanes 16 g .. 16 g + 15): every lane gets the total
+__device__ __forceinline__ float sl_rowsum(float v) {
+  v = sl_quadsum(v);
+  v += sl_dpp<0x124>(v);                                       // row_ror:4
+  v += sl_dpp<0x128>(v);                                       // row_ror:8
+  return v;
+}
+
+// Workgroup barrier that orders LDS traffic only.  `__syncthreads()` also drains the wave's vector-memory counter -- i.e. waits for
+// every global STORE issued so far to complete (2-4 us to L2 / the Infinity Cache): with one store phase per stage that was ~4 us
+// per stage, 26 of this kernel's first 28 us.  Nothing in this kernel reads global memory that the kernel wrote.
+__device__ __forceinline__ void sl_lds_barrier() {
+  __asm__ volatile("" ::: "memory");
+  __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0) only
+  __builtin_amdgcn_s_barrier();
+  __asm__ volatile("" ::: "memory");
+}
+
+// The launch's argument block read AT THE POINT OF USE.  The 45-field struct held in scalar registers for the whole kernel is ~90 of the
+// 102 SGPRs: the first builds spilled scalars into VGPR lanes -- 1 600 v_writelane / v_readlane of the kernel's 7 900 instructions.
+// The kernarg segment is constant memory (scalar loads); the empty asm makes the pointer opaque so that the field loads stay behind it.
+typedef const __attribute__((opencl_constant)) ops_tfd_layer_args* sl_args_ptr;
+__device__ __forceinline__ sl_args_ptr sl_late_args() {
+  auto p = __builtin_amdgcn_kernarg_segment_ptr();
+  __asm__ volatile("" : "+s"(p));
+  return (sl_args_ptr)p;
+}
+
+constexpr int SL_DHP = 16;          // head vectors padded to 16 elements in LDS (dh <= 16)
+constexpr int SL_MAXS = 8;
+
+// B fragments of one 16-column tile of W [N, K] (row-major bf16): lane (c = lane & 15, g = lane >> 4) holds W[n0 + c][32 ks + 8 g ..+7].
+// Rows beyond N and the k-group beyond K are clamped to valid memory: those columns are discarded / multiply zero-padded A columns.
+template <int KS>
+struct WTile { uint4 f[KS]; };
+template <int KS>
+__device__ __forceinline__ void sl_load_tile(WTile<KS>& t, const uint16_t* __restrict__ W, int N, int K, int n0, int c, int g) {
+  const int n = n0 + c < N ? n0 + c : N - 1;
+  const uint16_t* row = W + (long)n * K;
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    int k = 32 * ks + 8 * g;
+    if (k + 8 > K) k = K - 8;
+    t.f[ks] = *(const uint4*)(row + k);
+  }
+}
+template <int KS>
+__device__ __forceinline__ sl_f32x4 sl_mma_tile(const WTile<KS>& t, const uint16_t* __restrict__ sA, int AS, int c, int g) {
+  sl_f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    const uint4 a = *(const uint4*)(sA + c * AS + 32 * ks + 8 * g);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(sl_bf16x8, a), __builtin_bit_cast(sl_bf16x8, t.f[ks]), acc, 0, 0, 0);
+  }
+  return acc;
+}
+
+// head-vector helpers (as csrc/seq_block.hip)
+__device__ __forceinline__ void sl_ldvec(const uint16_t* __restrict__ p, float (&v)[SL_DHP]) {
+#pragma unroll
+  for (int k = 0; k < SL_DHP / 8; ++k) {
+    const uint4 u = ((const uint4*)p)[k];
+    const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { v[8 * k + 2 * j] = __uint_as_float(w[j] << 16); v[8 * k + 2 * j + 1] = __uint_as_float(w[j] & 0xffff0000u); }
+  }
+}
+
+// LayerNorm statistics of the 16 float32 rows published in LDS (row stride fs, columns >= d hold zeros ... not relied upon: masked):
+// every wave recomputes them for its own accumulator rows -- lane (c, g) reads columns c, c + 16, ... of rows 4 g + i, the 16 lanes
+// of the row group add up by DPP.  Two-pass form (mean, then centred squares) as csrc/seq_block.hip, no workgroup reduction: the
+// first version's three barriers and 32 LDS-pipe shuffles per normalisation were 2.6 us.
+constexpr int SL_NW = 8;            // waves per workgroup: 8 x 16 columns = one d-wide (<= 128) result per round
+__device__ __forceinline__ void sl_row_stats(const float* __restrict__ s_rows, int fs, int d, int c, int g, float eps, float (&mean)[4], float (&rstd)[4]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float* row = s_rows + (4 * g + i) * fs;
+    float v[8], s = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { v[k] = row[c + 16 * k]; s += (c + 16 * k < d) ? v[k] : 0.0f; }
+    mean[i] = sl_rowsum(s) / (float)d;
+    float q = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { const float dv = v[k] - mean[i]; q += (c + 16 * k < d) ? dv * dv : 0.0f; }
+    rstd[i] = rsqrtf(sl_rowsum(q) / (float)d + eps);
+  }
+}
+
+// rows [16][ncols] of an LDS image (row stride `ls` elements of EB bytes) -> global rows [.., ncols] starting at row0: 16-byte pieces, all threads
+template <int EB>
+__device__ __forceinline__ void sl_store_rows(void* __restrict__ dst, const void* __restrict__ src, int ls, int ncols, long row0, int nrows, int tid) {
+  const int per = 16 / EB, ppr = ncols / per;          // pieces per row (ncols * EB is a multiple of 16: host-checked)
+  const float inv = 1.0f / (float)ppr;                 // idx < 16 * 64: (idx + 0.5) / ppr is >= 1 / 128 away from an integer, the product exact enough
+  // (a pointer read from the argument block is a generic one to the compiler: say "global", or the stores become flat_store)
+  __attribute__((address_space(1))) char* out = (__attribute__((address_space(1))) char*)dst + row0 * ncols * EB;   // scalar: the 64-bit part of the address
+  for (int idx = tid; idx < nrows * ppr; idx += 64 * SL_NW) {
+    const int r = (int)(((float)idx + 0.5f) * inv), q = idx - r * ppr;
+    const sl_u32x4 v = *(const sl_u32x4*)((const char*)src + (r * ls + q * per) * EB);
+    *(__attribute__((address_space(1))) sl_u32x4*)(out + (r * ncols + q * per) * EB) = v;
+  }
+}
+// zero the columns [c0, c1) of the 16 rows / all columns < nc of the rows [r0, 16) of a 2-byte LDS image: no integer divisions
+__device__ __forceinline__ void sl_zero_cols(uint16_t* s, int ls, int c0, int c1, int tid) {
+  const int r = tid >> 5;
+  for (int cc = c0 + (tid & 31); cc < c1; cc += 32) s[r * ls + cc] = 0;
+}
+__device__ __forceinline__ void sl_zero_rows(uint16_t* s, int ls, int r0, int nc, int tid) {
+  const int cc = tid & 127;
+  if (cc < nc)
+    for (int r = r0 + (tid >> 7); r < 16; r += SL_NW / 2) s[r * ls + cc] = 0;
+}
+
+// d <= 128, ff <= 256, dh <= 16, S <= 8, H <= 8 (host-checked).  One workgroup = 16 rows = 16 / S samples; its 8 waves split every
+// product's 16-column tiles (wave w: tiles w, w + 8, w + 16), so ALL of a wave's weight fragments -- 32 sixteen-byte loads per lane --
+// are requested at kernel entry (behind the layer input, in the order the products use them: vector-memory results return in order)
+// and no product waits for a dependent round trip to L2 / the Infinity Cache.  Everything that leaves the kernel is first collected in
+// LDS rows and stored in 16-byte pieces by all threads (2- and 4-byte stores straight from the accumulator layout cost 2-3 us per
+// stage); the attention of a (sample, head, query) is shared by four lanes, four head dimensions each.
+__global__ __launch_bounds__(64 * SL_NW) void tfd_layer_fwd_kernel(const ops_tfd_layer_args a) {
+  constexpr int XS = 128 + 8;        // LDS row stride of the d-wide bf16 operands: rows 4 banks apart
+  constexpr int HS = 256 + 8;        // ... of the ff-wide operand
+  constexpr int QS = 384 + 8;        // ... of the unpadded q|k|v rows kept for the store (3 d <= 384)
+  constexpr int FS = 128 + 4;        // ... of the float32 staging rows
+  __shared__ __attribute__((aligned(16))) uint16_t s_x[16 * XS];                 // x (bf16), later y1 (bf16), at the end y2 (bf16)
+  __shared__ __attribute__((aligned(16))) uint16_t s_ctx[16 * XS];               // attention output
+  __shared__ __attribute__((aligned(16))) uint16_t s_big[16 * 3 * 8 * SL_DHP > 16 * HS ? 16 * 3 * 8 * SL_DHP : 16 * HS];   // q|k|v padded image, later h
+  __shared__ __attribute__((aligned(16))) uint16_t s_st[16 * QS];                // q|k|v rows as stored, later u, at the end y2 (float32)
+  __shared__ __attribute__((aligned(16))) float s_f32[16 * FS];                  // z1, later z2 (float32)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 15, g = lane >> 4;
+  const int S = a.S, H = a.H, dh = a.dh, d = a.d, ff = a.ff;
+  const int spw = 16 / S;
+  const int b0 = blockIdx.x * spw, nsamp = (a.Bn - b0 < spw) ? a.Bn - b0 : spw, nrows = nsamp * S;
+  const long row0 = (long)b0 * S;
+  unsigned long long stamp[16];
+#define SL_STAMP(k) if (a.trace) stamp[k] = __builtin_amdgcn_s_memrealtime()
+  SL_STAMP(0);
+
+  // ---- requests.  The texture path moves 64 bytes per cycle: a wave's 16-byte-per-lane load occupies it for 16 cycles, the
+  //      workgroup's 256 KB of weight fragments for 4 100 cycles = 1.7 us, and a wave cannot go on before its loads are ISSUED.
+  //      So: the input rows, this lane's residual / bias / scale values and the in-projection's fragments first; the layer input is
+  //      staged as soon as it is there; the other 20 fragments per lane are requested behind the first barrier and arrive under the
+  //      in-projection and the attention.  (Everything at entry: 2.6 us of issue + 2.2 us at the first barrier.)
+  const int n = 16 * wave + c;                         // this lane's column of the d-wide results
+  const bool colok = n < d;
+  float4 xin = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  {
+    const int r = tid >> 5, q4 = tid & 31;             // 16 rows x 32 float4 = 128 columns per row: one piece per thread
+    if (r < nrows && 4 * q4 < d) xin = *(const float4*)(a.x32 + (row0 + r) * d + 4 * q4);
+  }
+  const unsigned long long call = *a.counter;
+  const int NTQ = (3 * d + 15) / 16, NT1 = (ff + 15) / 16;
+  // This lane's bias / scale / shift values of every stage: requested BEFORE the weights.  Vector-memory results return in order, so a
+  // bias read issued in a product's epilogue would wait for every weight fragment requested ahead of it.
+  float bq[3], b1v[2];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) { const int m = 16 * (wave + SL_NW * j) + c; bq[j] = sl_bf2f(((const uint16_t*)a.b_in)[m < 3 * d ? m : 3 * d - 1]); }
+  WTile<4> wq[3], wo, w1[2];
+  WTile<8> w2;
+  // (no branches around the loads: tiles beyond a product's last are clamped to it, so that the compiler can COUNT the outstanding
+  //  requests -- behind a conditional load or a loop of unknown length it falls back to "wait for everything")
+#pragma unroll
+  for (int j = 0; j < 3; ++j) { const int t = wave + SL_NW * j; sl_load_tile<4>(wq[j], (const uint16_t*)a.W_in, 3 * d, d, 16 * (t < NTQ ? t : NTQ - 1), c, g); }
+  SL_STAMP(7);
+
+  // ---- x -> bf16 operand rows (zero beyond the live rows and beyond column d) ----
+  {
+    const int r = tid >> 5, q4 = tid & 31;
+    uint2 o;
+    o.x = (uint32_t)sl_f2bf(xin.x) | ((uint32_t)sl_f2bf(xin.y) << 16);
+    o.y = (uint32_t)sl_f2bf(xin.z) | ((uint32_t)sl_f2bf(xin.w) << 16);
+    *(uint2*)(s_x + r * XS + 4 * q4) = o;
+  }
+  SL_STAMP(8);
+#pragma unroll
+  for (int k = 0; k < (16 * 3 * 8 * SL_DHP / 8 + 64 * SL_NW - 1) / (64 * SL_NW); ++k) {   // padding lanes of the head vectors
+    const int idx = tid + 64 * SL_NW * k;
+    if (idx < 16 * 3 * 8 * SL_DHP / 8) ((uint4*)s_big)[idx] = uint4{0u, 0u, 0u, 0u};
+  }
+  // the second wave of requests: residual values, the other stages' vectors, 20 weight fragments
+  float xres[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { const int r = 4 * g + i; xres[i] = a.x32[(row0 + (r < nrows ? r : 0)) * d + (colok ? n : 0)]; }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) { const int m = 16 * (wave + SL_NW * j) + c; b1v[j] = sl_bf2f(((const uint16_t*)a.b_1)[m < ff ? m : ff - 1]); }
+  const int nc = colok ? n : d - 1;
+  const float bo = sl_bf2f(((const uint16_t*)a.b_out)[nc]), b2v = sl_bf2f(((const uint16_t*)a.b_2)[nc]);
+  const float gm1 = a.gamma1[nc], be1 = a.beta1[nc], gm2 = a.gamma2[nc], be2 = a.beta2[nc];
+  sl_load_tile<4>(wo, (const uint16_t*)a.W_out, d, d, 16 * wave, c, g);
+#pragma unroll
+  for (int j = 0; j < 2; ++j) { const int t = wave + SL_NW * j; sl_load_tile<4>(w1[j], (const uint16_t*)a.W_1, ff, d, 16 * (t < NT1 ? t : NT1 - 1), c, g); }
+  sl_load_tile<8>(w2, (const uint16_t*)a.W_2, d, ff, 16 * wave, c, g);
+  sl_lds_barrier();
+  SL_STAMP(1);
+
+  // ---- in-projection: qkv = x W_in^T + b_in -> padded LDS image [row][q|k|v][H][16] and the rows as they are stored ----
+  {
+    const float inv_dh = 1.0f / (float)dh;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int t = wave + SL_NW * j;
+      if (t < NTQ) {                                   // wave-uniform
+        const sl_f32x4 acc = sl_mma_tile<4>(wq[j], s_x, XS, c, g);
+        const int m = 16 * t + c;
+        if (m < 3 * d) {
+          const float b = bq[j];
+          const int which = (m >= d) + (m >= 2 * d), w = m - which * d;
+          const int hh = (int)(((float)w + 0.5f) * inv_dh), tt = w - hh * dh;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int r = 4 * g + i;
+            const uint16_t v = sl_f2bf(acc[i] + b);
+            s_big[((r * 3 + which) * H + hh) * SL_DHP + tt] = v;
+            s_st[r * QS + m] = v;
+          }
+        }
+      }
+    }
+  }
+  sl_lds_barrier();
+  SL_STAMP(2);
+
+  // ---- attention: four lanes per (sample, head, query), four head dimensions each ----
+  {
+    const sl_args_ptr la = sl_late_args();
+    const DropKey key_attn = drop_key(la->seed_attn, call);   // scalar-unit work (csrc/dropout_stream.hpp)
+    const float p_attn = la->p_attn;
+    const float scale = rsqrtf((float)dh), ks = la->p_attn > 0.0f ? 1.0f / (1.0f - la->p_attn) : 1.0f;
+    const int rs = 3 * H * SL_DHP;
+    const int qd = tid & 3;                            // which quarter of the head vector
+    const float inv_S = 1.0f / (float)S, inv_H = 1.0f / (float)H;
+    for (int it = tid >> 2; it < spw * H * S; it += 16 * SL_NW) {     // it <= 127: the float quotients are exact
+      const int t1 = (int)(((float)it + 0.5f) * inv_S), i = it - t1 * S, bl = (int)(((float)t1 + 0.5f) * inv_H), hh = t1 - bl * H;
+      const uint16_t* base = s_big + (bl * S) * rs + hh * SL_DHP + 4 * qd;
+      float q[4], p[SL_MAXS], o[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+      { const uint2 uu = *(const uint2*)(base + i * rs); q[0] = __uint_as_float(uu.x << 16); q[1] = __uint_as_float(uu.x & 0xffff0000u);
+        q[2] = __uint_as_float(uu.y << 16); q[3] = __uint_as_float(uu.y & 0xffff0000u); }
+      float mx = -3.0e38f;
+#pragma unroll
+      for (int j = 0; j < SL_MAXS; ++j) {
+        p[j] = -3.0e38f;
+        if (j < S) {
+          const uint2 uu = *(const uint2*)(base + j * rs + H * SL_DHP);
+          float sc = q[0] * __uint_as_float(uu.x << 16);
+          sc = __builtin_fmaf(q[1], __uint_as_float(uu.x & 0xffff0000u), sc);
+          sc = __builtin_fmaf(q[2], __uint_as_float(uu.y << 16), sc);
+          sc = __builtin_fmaf(q[3], __uint_as_float(uu.y & 0xffff0000u), sc);
+          p[j] = sl_quadsum(sc) * scale;
+          mx = fmaxf(mx, p[j]);
+        }
+      }
+      float den = 0.0f;
+#pragma unroll
+      for (int j = 0; j < SL_MAXS; ++j) { p[j] = j < S ? __expf(p[j] - mx) : 0.0f; den += p[j]; }
+      const float inv = 1.0f / den;
+      const uint64_t e0 = (uint64_t)b0 * (uint64_t)(H * S * S) + (uint32_t)((((bl * H + hh) * S + i) * S));
+      // keep bits of the S keys: lane qd of the quad hashes keys qd and qd + 4, the quad ORs them together
+      unsigned keep = 0xffu;
+      if (p_attn > 0.0f) {
+        keep = 0u;
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+          const int j = qd + 4 * jj;
+          if (j < S && drop_uniform(key_attn, e0 + j) >= p_attn) keep |= 1u << j;
+        }
+        keep = sl_dpp_or_quad(keep);
+      }
+#pragma unroll
+      for (int j = 0; j < SL_MAXS; ++j)
+        if (j < S) {
+          const float pk = ((keep >> j) & 1u) ? p[j] * inv * ks : 0.0f;
+          const uint2 uu = *(const uint2*)(base + j * rs + 2 * H * SL_DHP);
+          o[0] = __builtin_fmaf(pk, __uint_as_float(uu.x << 16), o[0]);
+          o[1] = __builtin_fmaf(pk, __uint_as_float(uu.x & 0xffff0000u), o[1]);
+          o[2] = __builtin_fmaf(pk, __uint_as_float(uu.y << 16), o[2]);
+          o[3] = __builtin_fmaf(pk, __uint_as_float(uu.y & 0xffff0000u), o[3]);
+        }
+      const int r = bl * S + i;
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+        if (4 * qd + t < dh) s_ctx[r * XS + hh * dh + 4 * qd + t] = sl_f2bf(o[t]);
+    }
+    // columns d .. 127 of the attention rows and the rows beyond the samples: zero (they multiply clamped weight reads)
+    sl_zero_cols(s_ctx, XS, d, 128, tid);
+    sl_zero_rows(s_ctx, XS, spw * S, d, tid);
+  }
+  sl_lds_barrier();
+  // Every weight fragment has had the in-projection and the attention to arrive: ONE full wait here, BEFORE the first store is issued.
+  // From now on nothing this wave uses is pending, so no later wait can stall behind a store (vector-memory operations retire in
+  // order and the store loops below have trip counts the compiler cannot count through).
+  __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
+  SL_STAMP(3);
+  { const sl_args_ptr la = sl_late_args();
+  sl_store_rows<2>(la->qkv, s_st, QS, 3 * d, row0, nrows, tid);
+  sl_store_rows<2>(la->ctx, s_ctx, XS, d, row0, nrows, tid); }
+  SL_STAMP(9);
+
+  // ---- out-projection + dropout + residual + LayerNorm1: wave w owns columns 16 w .. 16 w + 15 ----
+  float y1[4];
+  {
+    float z[4];
+    const sl_f32x4 acc = sl_mma_tile<4>(wo, s_ctx, XS, c, g);
+    const sl_args_ptr la = sl_late_args();
+    const DropKey key_1 = drop_key(la->seed_1, call);
+    const float p_1 = la->p_1;
+    const float ks = la->p_1 > 0.0f ? 1.0f / (1.0f - la->p_1) : 1.0f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = 4 * g + i;
+      float zz = 0.0f;
+      if (colok && r < nrows) {
+        float xv = sl_round(acc[i] + bo);
+        if (p_1 > 0.0f) xv = drop_uniform(key_1, (uint64_t)(row0 * d) + (uint32_t)(r * d + n)) >= p_1 ? xv * ks : 0.0f;
+        zz = xres[i] + xv;
+      }
+      z[i] = zz;
+      s_f32[r * FS + n] = zz;
+    }
+    sl_zero_cols(s_big, HS, ff, 256, tid);
+    sl_lds_barrier();                                   // z1 rows published
+    SL_STAMP(10);
+    float mean[4], rstd[4];
+    sl_row_stats(s_f32, FS, d, c, g, la->eps1, mean, rstd);
+    SL_STAMP(11);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = 4 * g + i;
+      y1[i] = __builtin_fmaf((z[i] - mean[i]) * rstd[i], gm1, be1);
+      if (wave == 0 && c == 0 && r < nrows) { ((__attribute__((address_space(1))) float*)la->mean1)[row0 + r] = mean[i]; ((__attribute__((address_space(1))) float*)la->rstd1)[row0 + r] = rstd[i]; }
+      s_x[r * XS + n] = (colok && r < nrows) ? sl_f2bf(y1[i]) : (uint16_t)0;     // (x as an operand is dead since the in-projection)
+    }
+  }
+  sl_lds_barrier();
+  SL_STAMP(4);
+  { const sl_args_ptr la = sl_late_args();
+  sl_store_rows<4>(la->z1, s_f32, FS, d, row0, nrows, tid);
+  sl_store_rows<2>(la->y1_16, s_x, XS, d, row0, nrows, tid); }
+
+  // ---- feed-forward 1: u = y1 W_1^T + b_1 (saved), h = dropout(ReLU(u)) -> LDS operand rows ----
+  {
+    const sl_args_ptr la = sl_late_args();
+    const DropKey key_act = drop_key(la->seed_act, call);
+    const float p_act = la->p_act;
+    const float ks = la->p_act > 0.0f ? 1.0f / (1.0f - la->p_act) : 1.0f;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int t = wave + SL_NW * j;
+      if (t < NT1) {                                   // wave-uniform
+        const sl_f32x4 acc = sl_mma_tile<4>(w1[j], s_x, XS, c, g);
+        const int m = 16 * t + c;
+        if (m < ff) {
+          const float b = b1v[j];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int r = 4 * g + i;
+            const uint16_t ub = sl_f2bf(acc[i] + b);
+            float hv = sl_bf2f(ub);
+            hv = hv > 0.0f ? hv : 0.0f;
+            if (p_act > 0.0f && r < nrows) hv = drop_uniform(key_act, (uint64_t)(row0 * ff) + (uint32_t)(r * ff + m)) >= p_act ? hv * ks : 0.0f;
+            s_big[r * HS + m] = r < nrows ? sl_f2bf(hv) : (uint16_t)0;
+            s_st[r * QS + m] = ub;                     // (the q|k|v rows went out two barriers ago)
+          }
+        }
+      }
+    }
+  }
+  sl_lds_barrier();
+  SL_STAMP(5);
+  { const sl_args_ptr la = sl_late_args();
+  sl_store_rows<2>(la->u, s_st, QS, ff, row0, nrows, tid);
+  sl_store_rows<2>(la->h, s_big, HS, ff, row0, nrows, tid); }
+  SL_STAMP(12);
+
+  // ---- feed-forward 2 + dropout + residual + LayerNorm2 ----
+  {
+    float z[4];
+    const sl_f32x4 acc = sl_mma_tile<8>(w2, s_big, HS, c, g);
+    const sl_args_ptr la = sl_late_args();
+    const DropKey key_2 = drop_key(la->seed_2, call);
+    const float p_2 = la->p_2;
+    const float ks = la->p_2 > 0.0f ? 1.0f / (1.0f - la->p_2) : 1.0f;
+    float* s_y2 = (float*)s_st;                         // 16 x FS floats over the u rows, whose store was issued a barrier before the next one
+    static_assert(sizeof(float) * 16 * FS <= sizeof(uint16_t) * 16 * QS, "y2 rows fit over the u rows");
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = 4 * g + i;
+      float zz = 0.0f;
+      if (colok && r < nrows) {
+        float xv = sl_round(acc[i] + b2v);
+        if (p_2 > 0.0f) xv = drop_uniform(key_2, (uint64_t)(row0 * d) + (uint32_t)(r * d + n)) >= p_2 ? xv * ks : 0.0f;
+        zz = y1[i] + xv;
+      }
+      z[i] = zz;
+      s_f32[r * FS + n] = zz;                          // (z1 went out a barrier ago)
+    }
+    sl_lds_barrier();                                   // z2 rows published; the u / h pieces have been read
+    SL_STAMP(13);
+    sl_store_rows<4>(la->z2, s_f32, FS, d, row0, nrows, tid);
+    float mean[4], rstd[4];
+    sl_row_stats(s_f32, FS, d, c, g, la->eps2, mean, rstd);
+    SL_STAMP(14);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = 4 * g + i;
+      if (wave == 0 && c == 0 && r < nrows) { ((__attribute__((address_space(1))) float*)la->mean2)[row0 + r] = mean[i]; ((__attribute__((address_space(1))) float*)la->rstd2)[row0 + r] = rstd[i]; }
+      const float y2 = __builtin_fmaf((z[i] - mean[i]) * rstd[i], gm2, be2);
+      s_y2[r * FS + n] = y2;
+      s_x[r * XS + n] = sl_f2bf(y2);                   // (y1 as an operand is dead since feed-forward 1, its store is two barriers old)
+    }
+    sl_lds_barrier();
+    SL_STAMP(15);
+    sl_store_rows<4>(la->y32, s_y2, FS, d, row0, nrows, tid);
+    sl_store_rows<2>(la->y16, s_x, XS, d, row0, nrows, tid);
+  }
+  { const sl_args_ptr la = sl_late_args(); if (blockIdx.x == 0 && tid == 0 && la->used_call) *(__attribute__((address_space(1))) unsigned long long*)la->used_call = call; }
+  if (a.trace && tid == 0) {
+    SL_STAMP(6);
+    for (int k = 0; k < 16; ++k) a.trace[16 * (unsigned long long)blockIdx.x + k] = stamp[k];
+  }
+}
+
+}  // namespace opsamd
+
+extern "C" int ops_tfd_encoder_layer_fwd(const ops_tfd_layer_args* a, void* stream) {
+  if (!a || a->Bn < 1 || a->S < 1 || a->S > 8 || a->H < 1 || a->H > 8 || a->dh < 1 || a->dh > 16 || a->d != a->H * a->dh || a->d > 128 || a->d % 8 ||
+      a->ff < 16 || a->ff > 256 || a->ff % 8 || 3 * a->d > 16 * 3 * opsamd::SL_NW)
+    return OPS_AMD_ERR_UNSUPPORTED;
+  if ((((uintptr_t)a->W_in | (uintptr_t)a->W_out | (uintptr_t)a->W_1 | (uintptr_t)a->W_2 | (uintptr_t)a->x32) & 15) != 0) return OPS_AMD_ERR_UNSUPPORTED;
+  if (!a->x32 || !a->W_in || !a->b_in || !a->W_out || !a->b_out || !a->W_1 || !a->b_1 || !a->W_2 || !a->b_2 || !a->gamma1 || !a->beta1 || !a->gamma2 ||
+      !a->beta2 || !a->counter || !a->qkv || !a->ctx || !a->z1 || !a->mean1 || !a->rstd1 || !a->y1_16 || !a->u || !a->h || !a->z2 || !a->mean2 ||
+      !a->rstd2 || !a->y32 || !a->y16)
+    return OPS_AMD_ERR_INVALID_ARG;
+  const int spw = 16 / a->S;
+  const unsigned grid = (unsigned)((a->Bn + spw - 1) / spw);
+  hipLaunchKernelGGL(opsamd::tfd_layer_fwd_kernel, dim3(grid), dim3(64 * opsamd::SL_NW), 0, (hipStream_t)stream, *a);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { opsamd::set_last_error(hipGetErrorString(e)); return OPS_AMD_ERR_LAUNCH; }
+  return OPS_AMD_OK;
+}

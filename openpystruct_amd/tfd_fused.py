@@ -13,6 +13,7 @@ autograd.Function whose backward is one launch.  Evaluation, masks, other activa
 """
 from __future__ import annotations
 
+import ctypes
 import os
 import types
 from typing import Optional
@@ -23,6 +24,7 @@ import torch.nn as nn
 from . import _cabi
 
 ENABLED = os.environ.get("OPS_AMD_TFD_FAST_ENCODER", "1") == "1"      # A/B switch: 0 = nn.TransformerEncoder's own forward
+LAYER_FWD = os.environ.get("OPS_AMD_TFD_LAYER_FWD", "1") == "1"       # A/B switch: 0 = eight launches per layer forward instead of one
 
 
 class _State:
@@ -189,6 +191,113 @@ class ActDropout(torch.autograd.Function):
         return dx, None, None, None, None
 
 
+class EncoderLayerFn(torch.autograd.Function):
+    """One whole encoder layer.  Forward: ONE launch (csrc/seq_layer.hip: in-projection, attention, out-projection, dropout + add +
+    LayerNorm, feed-forward, dropout + add + LayerNorm; bf16 MFMA products on the shadow weights, everything else as the separate
+    launches compute it, same dropout streams).  Backward: the launches of csrc/seq_block.hip and the library's input-gradient products,
+    driven from here in the order autograd would run them; weight / bias gradients go where the shadow products send them
+    (train.shadow_param_grads), LayerNorm gradients straight into their `.grad` (the caller zeroes the flat buffer every step).
+    Inputs (x32, x16): the residual stream and its bf16 copy (the previous block's two outputs; x16's VALUES are bf16(x32)), so that
+    the two input gradients travel separately and no add node is needed."""
+
+    @staticmethod
+    def forward(ctx, x32, x16, layer, Bn, S, st: _State, li: int):
+        lib = _cabi.load()
+        mha = layer.self_attn
+        H, d = mha.num_heads, mha.embed_dim
+        dh, ff = d // H, layer.linear1.out_features
+        T = Bn * S
+        dev = x32.device
+        x32 = x32.contiguous()
+        rin, rout, r1, r2 = mha._ops_in_proj.rec, mha._ops_out_proj.rec, layer.linear1._ops_prod.rec, layer.linear2._ops_prod.rec
+        bf, f32 = dict(dtype=torch.bfloat16, device=dev), dict(dtype=torch.float32, device=dev)
+        qkv, ctxa = torch.empty((T, 3 * d), **bf), torch.empty((T, d), **bf)
+        z1, mean1, rstd1, y1_16 = torch.empty((T, d), **f32), torch.empty(T, **f32), torch.empty(T, **f32), torch.empty((T, d), **bf)
+        u, h = torch.empty((T, ff), **bf), torch.empty((T, ff), **bf)
+        z2, mean2, rstd2 = torch.empty((T, d), **f32), torch.empty(T, **f32), torch.empty(T, **f32)
+        y32, y16 = torch.empty((T, d), **f32), torch.empty((T, d), **bf)
+        used = st.used(4 * li)
+        seeds = [st.seed + 7919 * (4 * li + k) for k in range(4)]
+        ps = (float(mha.dropout), float(layer.dropout1.p), float(layer.dropout.p), float(layer.dropout2.p))
+        a = _cabi.TfdLayerArgs(
+            Bn=Bn, S=S, H=H, dh=dh, d=d, ff=ff, x32=x32.data_ptr(),
+            W_in=rin.w_sh.data_ptr(), b_in=rin.b_sh.data_ptr(), W_out=rout.w_sh.data_ptr(), b_out=rout.b_sh.data_ptr(),
+            W_1=r1.w_sh.data_ptr(), b_1=r1.b_sh.data_ptr(), W_2=r2.w_sh.data_ptr(), b_2=r2.b_sh.data_ptr(),
+            gamma1=layer.norm1.weight.data_ptr(), beta1=layer.norm1.bias.data_ptr(), eps1=float(layer.norm1.eps),
+            gamma2=layer.norm2.weight.data_ptr(), beta2=layer.norm2.bias.data_ptr(), eps2=float(layer.norm2.eps),
+            p_attn=ps[0], p_1=ps[1], p_act=ps[2], p_2=ps[3], seed_attn=seeds[0], seed_1=seeds[1], seed_act=seeds[2], seed_2=seeds[3],
+            counter=st.counter.data_ptr(), used_call=used.data_ptr(), qkv=qkv.data_ptr(), ctx=ctxa.data_ptr(), z1=z1.data_ptr(),
+            mean1=mean1.data_ptr(), rstd1=rstd1.data_ptr(), y1_16=y1_16.data_ptr(), u=u.data_ptr(), h=h.data_ptr(), z2=z2.data_ptr(),
+            mean2=mean2.data_ptr(), rstd2=rstd2.data_ptr(), y32=y32.data_ptr(), y16=y16.data_ptr())
+        with torch.cuda.device(dev):
+            _check(lib.ops_tfd_encoder_layer_fwd(ctypes.byref(a), _stream(dev)), "ops_tfd_encoder_layer_fwd")
+        ctx.save_for_backward(x16, qkv, ctxa, z1, mean1, rstd1, y1_16, u, h, z2, mean2, rstd2)
+        ctx.cfg = (layer, Bn, S, H, dh, d, ff, ps, seeds, used, (rin, rout, r1, r2))
+        ctx.set_materialize_grads(False)
+        return y32, y16
+
+    @staticmethod
+    def backward(ctx, g32, g16):
+        if g32 is None and g16 is None:
+            return (None,) * 7
+        from . import train
+        lib = _cabi.load()
+        x16, qkv, ctxa, z1, mean1, rstd1, y1_16, u, h, z2, mean2, rstd2 = ctx.saved_tensors
+        layer, Bn, S, H, dh, d, ff, ps, seeds, used, (rin, rout, r1, r2) = ctx.cfg
+        T = Bn * S
+        dev = z1.device
+        bf, f32 = dict(dtype=torch.bfloat16, device=dev), dict(dtype=torch.float32, device=dev)
+        ptr = lambda t: t.data_ptr() if t is not None else None      # noqa: E731
+        if g32 is not None:
+            g32 = g32.contiguous()
+        if g16 is not None:
+            g16 = g16.contiguous()
+        with torch.cuda.device(dev):
+            s = _stream(dev)
+            # LayerNorm2 <- (g32, g16)
+            d_f, dres2 = torch.empty((T, d), **bf), torch.empty((T, d), **f32)
+            _check(lib.ops_dropout_add_layernorm_bwd(T, d, ptr(g32), ptr(g16), z2.data_ptr(), mean2.data_ptr(), rstd2.data_ptr(),
+                                                     layer.norm2.weight.data_ptr(), ps[3], seeds[3], used.data_ptr(), d_f.data_ptr(), dres2.data_ptr(),
+                                                     layer.norm2.weight.grad.data_ptr(), layer.norm2.bias.grad.data_ptr(), s), "ops_dropout_add_layernorm_bwd")
+            train.shadow_param_grads(r2, d_f, h)
+            d_h = d_f @ r2.w_sh
+            d_u = torch.empty((T, ff), **bf)
+            _check(lib.ops_act_dropout_bwd(T * ff, u.data_ptr(), d_h.data_ptr(), d_u.data_ptr(), 0.0, ps[2], seeds[2], used.data_ptr(), s), "ops_act_dropout_bwd")
+            train.shadow_param_grads(r1, d_u, y1_16)
+            d_y1 = d_u @ r1.w_sh
+            # LayerNorm1 <- (dres2, d_y1)
+            d_a, dres1 = torch.empty((T, d), **bf), torch.empty((T, d), **f32)
+            _check(lib.ops_dropout_add_layernorm_bwd(T, d, dres2.data_ptr(), d_y1.data_ptr(), z1.data_ptr(), mean1.data_ptr(), rstd1.data_ptr(),
+                                                     layer.norm1.weight.data_ptr(), ps[1], seeds[1], used.data_ptr(), d_a.data_ptr(), dres1.data_ptr(),
+                                                     layer.norm1.weight.grad.data_ptr(), layer.norm1.bias.grad.data_ptr(), s), "ops_dropout_add_layernorm_bwd")
+            train.shadow_param_grads(rout, d_a, ctxa)
+            d_ctx = d_a @ rout.w_sh
+            dqkv = torch.empty((T, 3 * d), **bf)
+            _check(lib.ops_seq_attention_bwd(Bn, S, H, dh, qkv.data_ptr(), d_ctx.data_ptr(), dqkv.data_ptr(), ps[0], seeds[0], used.data_ptr(), s),
+                   "ops_seq_attention_bwd")
+            train.shadow_param_grads(rin, dqkv, x16)
+            d_x16 = dqkv @ rin.w_sh
+        return dres1, d_x16, None, None, None, None, None
+
+
+def _layer_fused_ok(layer: nn.Module, st: _State) -> bool:
+    """The one-launch forward applies: shadow products registered on all four Linear maps, sizes inside the kernel's limits, weights
+    16-byte aligned in the shadow buffer, LayerNorm gradients going straight into zeroed `.grad` views."""
+    mha = layer.self_attn
+    d, H = mha.embed_dim, mha.num_heads
+    recs = [getattr(getattr(mha, "_ops_in_proj", None), "rec", None), getattr(getattr(mha, "_ops_out_proj", None), "rec", None),
+            getattr(getattr(layer.linear1, "_ops_prod", None), "rec", None), getattr(getattr(layer.linear2, "_ops_prod", None), "rec", None)]
+    if not (LAYER_FWD and st.direct and all(r is not None and r.b_sh is not None for r in recs)):
+        return False
+    ff = layer.linear1.out_features
+    if not (d <= 128 and d % 8 == 0 and d // H <= 16 and H <= 8 and 16 <= ff <= 256 and ff % 8 == 0):
+        return False
+    if any(r.w_sh.data_ptr() % 16 for r in recs):
+        return False
+    return all(t.grad is not None and t.grad.dtype == torch.float32 and t.grad.is_contiguous()
+               for t in (layer.norm1.weight, layer.norm1.bias, layer.norm2.weight, layer.norm2.bias))
+
+
 def _layer_ok(layer: nn.Module) -> bool:
     if type(layer) is not nn.TransformerEncoderLayer or layer.norm_first:
         return False
@@ -213,6 +322,9 @@ def encoder_forward(enc: nn.TransformerEncoder, src: torch.Tensor, st: _State) -
         st.src16 = None
     for li, layer in enumerate(enc.layers):
         mha = layer.self_attn
+        if x16 is not None and _layer_fused_ok(layer, st):
+            res, x16 = EncoderLayerFn.apply(res, x16, layer, B, S, st, li)                          # the whole layer forward: one launch
+            continue
         qkv = mha._ops_in_proj(res if x16 is None else x16)                                         # [T, 3 d] bf16
         ctx = SeqAttention.apply(qkv, B, S, mha.num_heads, mha.dropout, st, 4 * li)
         a = mha._ops_out_proj(ctx)

@@ -276,6 +276,39 @@ class _ShadowLinearFn(torch.autograd.Function):
         return gx, None, None, None, None, None, None, None, None
 
 
+class ShadowRec:
+    """One shadow product's operands and gradient destinations (enable_shadow_linears)."""
+    __slots__ = ("w_sh", "b_sh", "w_grad", "b_grad", "stash", "iw", "ib")
+
+    def __init__(self, w_sh, b_sh, w_grad, b_grad, stash, iw, ib):
+        self.w_sh, self.b_sh, self.w_grad, self.b_grad, self.stash, self.iw, self.ib = w_sh, b_sh, w_grad, b_grad, stash, iw, ib
+
+
+def shadow_param_grads(rec: ShadowRec, g2: torch.Tensor, x2: torch.Tensor) -> None:
+    """Weight / bias gradients of y = x W^T + b given dY = g2 [T, N] and X = x2 [T, K] (bfloat16): exactly what
+    _ShadowLinearFn.backward does with them -- queued for the step's grouped split-row launch when the product has many rows, the
+    library's product into the stash otherwise."""
+    if rec.w_grad is not None and x2.shape[0] >= _SPLIT_WGRAD_ROWS and _SPLIT_WGRAD_ROWS > 0:
+        from . import _cabi
+        g2, x2c = g2.contiguous(), x2.contiguous()
+        fused_bias = rec.ib is not None and rec.b_grad is not None
+        if _WGRAD_QUEUE is not None:
+            _WGRAD_QUEUE.append((g2, x2c, rec.w_grad, rec.b_grad if fused_bias else None))
+        else:
+            with torch.cuda.device(g2.device):
+                rc = _cabi.load().ops_linear_wgrad_accumulate(x2c.shape[0], g2.shape[1], x2c.shape[1], g2.data_ptr(), x2c.data_ptr(),
+                                                              rec.w_grad.data_ptr(), rec.b_grad.data_ptr() if fused_bias else None,
+                                                              torch.cuda.current_stream(g2.device).cuda_stream)
+            if rc != 0:
+                raise RuntimeError(f"ops_linear_wgrad_accumulate failed with code {rc}")
+        if rec.ib is not None and not fused_bias:
+            rec.stash[rec.ib] = g2.sum(0)
+    else:
+        rec.stash[rec.iw] = g2.t() @ x2
+        if rec.ib is not None:
+            rec.stash[rec.ib] = g2.sum(0)
+
+
 _SPLIT_WGRAD_ROWS = int(os.environ.get("OPS_AMD_SPLIT_WGRAD_ROWS", "512"))     # products over at least this many rows (0 rows: never)
 _WGRAD_QUEUE = None          # a list while a training step collects its split-row weight gradients for ONE grouped launch
 
@@ -324,7 +357,12 @@ def enable_shadow_linears(model: nn.Module, opt: "FlatClipAdam", params, flat: t
             b_sh = sh[ob:ob + bias.numel()]
             b_grad = flat[ob:ob + bias.numel()]
             ib = len(stash); stash.append(None); dst.append(b_grad)
-        return lambda x: _ShadowLinearFn.apply(x, w_sh, b_sh, stash, iw, ib, weight, w_grad, b_grad)
+        def prod(x):
+            return _ShadowLinearFn.apply(x, w_sh, b_sh, stash, iw, ib, weight, w_grad, b_grad)
+
+        # what a fused block that runs this product itself needs: the shadow operands, and where its gradients go (shadow_param_grads)
+        prod.rec = ShadowRec(w_sh, b_sh, w_grad, b_grad, stash, iw, ib)
+        return prod
 
     for mod in model.modules():
         if isinstance(mod, nn.MultiheadAttention):
@@ -345,6 +383,7 @@ def enable_shadow_linears(model: nn.Module, opt: "FlatClipAdam", params, flat: t
             return prod(x)
 
         mod.forward = types.MethodType(fwd, mod)
+        mod._ops_prod = prod
         patched.append(mod)
     return stash, dst, patched
 
@@ -353,7 +392,7 @@ def disable_shadow_linears(patched) -> None:
     for mod in patched:
         if "forward" in mod.__dict__:
             del mod.__dict__["forward"]
-        for name in ("_ops_in_proj", "_ops_out_proj"):
+        for name in ("_ops_in_proj", "_ops_out_proj", "_ops_prod"):
             if name in mod.__dict__:
                 del mod.__dict__[name]
 

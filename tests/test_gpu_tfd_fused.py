@@ -331,6 +331,54 @@ def test_head_dropout_mask_is_redrawn_every_step_and_every_graph_replay():
     TF.unpatch_model(model)
 
 
+@pytest.mark.parametrize("B,p", [(512, 0.1), (37, 0.1), (3, 0.0)])
+def test_one_launch_layer_forward_equals_the_eight_launch_form(monkeypatch, B, p):
+    """csrc/seq_layer.hip (the whole encoder layer's forward as one MFMA launch) against the same layer through the separate launches +
+    library products: SAME dropout streams (seeds, element indices, call counter), so with dropout on the two forms drop the same
+    elements and differ only by the accumulation order of the bf16 products -- outputs and every gradient to 1e-2 relative L2."""
+    from openpystruct_amd import tfd_fused as TF, train
+    from openpystruct_amd.surrogates import ModelOnePassTransformerWithDiffusion
+
+    def run(layer_fwd):
+        monkeypatch.setattr(TF, "LAYER_FWD", layer_fwd)
+        torch.manual_seed(5)
+        model = ModelOnePassTransformerWithDiffusion(6, 120, 100, dropout=p).to(DEV)
+        params = list(model.parameters())
+        flat = torch.zeros(sum(q.numel() for q in params), device=DEV)
+        off = 0
+        for q in params:
+            q.grad = flat[off:off + q.numel()].view_as(q)
+            off += q.numel()
+        opt = train.FlatClipAdam(params, flat, 1e-3)
+        stash, dst, patched = train.enable_shadow_linears(model, opt, params, flat)
+        assert TF.patch_model(model, seed=3, direct_param_grads=True)
+        model.train()
+        g = torch.Generator().manual_seed(6)
+        x = torch.randn(B, 6, 120, generator=g).to(DEV)
+        w = torch.randn(B, 100, generator=g).to(DEV) / B
+        torch.manual_seed(11)                                   # the same diffusion steps / noise in both runs
+        train._WGRAD_QUEUE = []
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            out = model(x)
+            (out.float() * w).sum().backward()
+        train.flush_wgrad_queue(torch.device(DEV))
+        train._WGRAD_QUEUE = None
+        live = [(dd, ss) for dd, ss in zip(dst, stash) if ss is not None]
+        if live:
+            torch._foreach_copy_([a for a, _ in live], [b for _, b in live])
+        torch.cuda.synchronize()
+        res = out.float().clone(), {n: q.grad.clone() for n, q in model.named_parameters()}
+        train.disable_shadow_linears(patched)
+        TF.unpatch_model(model)
+        return res
+
+    out1, g1 = run(True)
+    out0, g0 = run(False)
+    assert _rel(out1, out0) < 1e-2
+    for n in g0:
+        assert _rel(g1[n], g0[n]) < 2e-2 or float(g0[n].norm()) < 1e-6, (n, _rel(g1[n], g0[n]))
+
+
 def test_tfd_training_with_the_fast_encoder_follows_the_framework_path(monkeypatch):
     """Six epochs of the TFD loop (dropout 0.1, diffusion noise on) with the encoder blocks vs the framework's encoder: two draws of the
     same stochastic process -- final training losses within 8 % of each other, both decreasing (800 groups: two steps per epoch)."""
