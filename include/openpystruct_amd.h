@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define OPS_AMD_ABI_VERSION 4
+#define OPS_AMD_ABI_VERSION 5
 
 /* return codes of the launch functions (per-beam results are in `status`) */
 #define OPS_AMD_OK 0
@@ -438,18 +438,21 @@ int ops_diffusion_combine_bwd(int B, int Nc, int d, const float* g /* float32, m
                               gradient is g + g16 */, const float* sa, const float* sb, void* dm, float* dcls, void* stream);
 
 /* One post-norm encoder layer of the Transformer-Diffusion surrogate (TransformerDiffusionModule_MultiCase.py:539-575) for the training
- * step's FORWARD pass as one launch (csrc/seq_layer.hip): in-projection, attention over S <= 8 tokens, out-projection, dropout + add +
- * LayerNorm, feed-forward with ReLU + dropout, dropout + add + LayerNorm.  T = Bn * S rows; weights / biases: the bfloat16 shadow
- * parameters, row-major [out, in], 16-byte aligned; d = H * dh <= 128, dh <= 16, ff <= 256, d and ff multiples of 8.  Everything the
- * backward launches above (ops_seq_attention_bwd, ops_dropout_add_layernorm_bwd, ops_act_dropout_bwd) and the weight-gradient products
- * read is saved in their formats; dropout masks: their stream, seeds per site, `counter` only read, `used_call` = the value used. */
+ * step as ONE launch per direction (csrc/seq_layer.hip).  Forward: in-projection, attention over S <= 8 tokens, out-projection,
+ * dropout + add + LayerNorm, feed-forward with ReLU + dropout, dropout + add + LayerNorm.  T = Bn * S rows; d = H * dh <= 128, dh <= 16,
+ * ff <= 256, d and ff multiples of 8.
+ * Weights: bfloat16 copies in the FRAGMENT-TILED layout of ops_mlp_repack_weights (ops_flat_clip_adam_step_repack_f32 refreshes them
+ * inside the optimiser launch): for W [N, K], `Wp` has ldw = K rounded up to 32 and `Wtp` (the transpose's tiles) ldwt = N rounded up
+ * to 32, zero padded, 16-byte aligned.  The forward pass reads the four Wp, the backward pass the four Wtp; biases: bfloat16 vectors.
+ * Everything the backward launch and the weight-gradient products read is saved by the forward launch; dropout masks: the stream
+ * of csrc/dropout_stream.hpp, one seed per site, `counter` only read, `used_call` = the value used (the backward launch reads it). */
 typedef struct ops_tfd_layer_args {
   int32_t Bn, S, H, dh, d, ff;
   const float* x32;                                   /* [T, d] layer input (residual stream) */
-  const void* W_in; const void* b_in;                 /* [3 d, d], [3 d] */
-  const void* W_out; const void* b_out;               /* [d, d], [d] */
-  const void* W_1; const void* b_1;                   /* [ff, d], [ff] */
-  const void* W_2; const void* b_2;                   /* [d, ff], [d] */
+  const void* W_in; const void* b_in;                 /* Wp of [3 d, d], [3 d] */
+  const void* W_out; const void* b_out;               /* Wp of [d, d], [d] */
+  const void* W_1; const void* b_1;                   /* Wp of [ff, d], [ff] */
+  const void* W_2; const void* b_2;                   /* Wp of [d, ff], [d] */
   const float* gamma1; const float* beta1; float eps1;
   const float* gamma2; const float* beta2; float eps2;
   float p_attn, p_1, p_act, p_2;
@@ -464,6 +467,26 @@ typedef struct ops_tfd_layer_args {
   unsigned long long* trace;                          /* diagnostics: NULL, or 16 stage stamps per workgroup (100 MHz clock) */
 } ops_tfd_layer_args;
 int ops_tfd_encoder_layer_fwd(const ops_tfd_layer_args* args, void* stream);
+
+/* The layer's BACKWARD pass as one launch: LayerNorm2 backward, d_h = d_f W_2, ReLU + dropout backward, d_y1 = d_u W_1 (+ the residual
+ * branch), LayerNorm1 backward, d_ctx = d_a W_out, attention backward, dx = residual branch + dqkv W_in.  The incoming gradient is
+ * g32 + g16 (either may be NULL, not both).  Written for the weight-gradient products (ops_linear_wgrad_accumulate_group): d_f, d_u,
+ * d_a, dqkv (bfloat16, gradients at the four products' outputs).  dgamma / dbeta: ADDED to (float atomics; the caller zeroes them). */
+typedef struct ops_tfd_layer_bwd_args {
+  int32_t Bn, S, H, dh, d, ff;
+  const float* g32; const void* g16;                  /* [T, d] gradient at the layer output */
+  const void* Wt_in; const void* Wt_out; const void* Wt_1; const void* Wt_2;   /* Wtp of the four weights */
+  const float* gamma1; const float* gamma2;
+  float p_attn, p_1, p_act, p_2;
+  unsigned long long seed_attn, seed_1, seed_act, seed_2;
+  const unsigned long long* used_call;                /* the forward launch's */
+  const void* qkv; const float* z1; const float* mean1; const float* rstd1; const void* u; const float* z2; const float* mean2; const float* rstd2;
+  void* d_f; void* d_u; void* d_a; void* dqkv;        /* [T, d], [T, ff], [T, d], [T, 3 d] bf16 */
+  float* dx32;                                        /* [T, d] gradient at the layer input (residual + in-projection branch) */
+  float* dgamma1; float* dbeta1; float* dgamma2; float* dbeta2;
+  unsigned long long* trace;
+} ops_tfd_layer_bwd_args;
+int ops_tfd_encoder_layer_bwd(const ops_tfd_layer_bwd_args* args, void* stream);
 
 /* Measurement aid of bench.py, not a product call: device-to-device copy of `bytes` (a multiple of 16, both pointers 16-byte
  * aligned) with one 16-byte access per lane and instruction -- the achievable HBM rate the roofline records quote next to the

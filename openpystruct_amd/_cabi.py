@@ -9,7 +9,7 @@ import ctypes
 import os
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-ABI_VERSION = 4      # include/openpystruct_amd.h OPS_AMD_ABI_VERSION
+ABI_VERSION = 5      # include/openpystruct_amd.h OPS_AMD_ABI_VERSION
 # OPS_AMD_LIB lets A/B kernel experiments point at another build of the same C ABI
 LIB_PATH = os.environ.get("OPS_AMD_LIB") or os.path.join(_PKG, "lib", "libopenpystruct_amd.so")
 
@@ -62,6 +62,7 @@ EXPORTS = (
     "ops_diffusion_combine_bwd",
     "ops_hbm_copy16",
     "ops_tfd_encoder_layer_fwd",
+    "ops_tfd_encoder_layer_bwd",
 )
 
 OK, ERR_INVALID_ARG, ERR_UNSUPPORTED, ERR_LAUNCH = 0, 1, 2, 3
@@ -129,6 +130,18 @@ class TfdLayerArgs(ctypes.Structure):
                 ("z2", _vp), ("mean2", _vp), ("rstd2", _vp), ("y32", _vp), ("y16", _vp), ("trace", _vp)]
 
 
+class TfdLayerBwdArgs(ctypes.Structure):
+    """Mirror of `ops_tfd_layer_bwd_args`."""
+    _vp, _i, _f, _u = ctypes.c_void_p, ctypes.c_int32, ctypes.c_float, ctypes.c_ulonglong
+    _fields_ = [("Bn", _i), ("S", _i), ("H", _i), ("dh", _i), ("d", _i), ("ff", _i), ("g32", _vp), ("g16", _vp),
+                ("Wt_in", _vp), ("Wt_out", _vp), ("Wt_1", _vp), ("Wt_2", _vp), ("gamma1", _vp), ("gamma2", _vp),
+                ("p_attn", _f), ("p_1", _f), ("p_act", _f), ("p_2", _f),
+                ("seed_attn", _u), ("seed_1", _u), ("seed_act", _u), ("seed_2", _u), ("used_call", _vp),
+                ("qkv", _vp), ("z1", _vp), ("mean1", _vp), ("rstd1", _vp), ("u", _vp), ("z2", _vp), ("mean2", _vp), ("rstd2", _vp),
+                ("d_f", _vp), ("d_u", _vp), ("d_a", _vp), ("dqkv", _vp), ("dx32", _vp),
+                ("dgamma1", _vp), ("dbeta1", _vp), ("dgamma2", _vp), ("dbeta2", _vp), ("trace", _vp)]
+
+
 WGRAD_MAX_GROUP = 16
 
 
@@ -182,6 +195,8 @@ def load():
     rj.argtypes = [it, it, vp, lg, vp, lg, vp, vp, lg] + [vp] * 10
     lib.ops_tfd_encoder_layer_fwd.restype = it
     lib.ops_tfd_encoder_layer_fwd.argtypes = [ctypes.POINTER(TfdLayerArgs), vp]
+    lib.ops_tfd_encoder_layer_bwd.restype = it
+    lib.ops_tfd_encoder_layer_bwd.argtypes = [ctypes.POINTER(TfdLayerBwdArgs), vp]
     lib.ops_hbm_copy16.restype = it
     lib.ops_hbm_copy16.argtypes = [vp, vp, ctypes.c_size_t, it, vp]
     fr = lib.ops_frame_solve_batched_f64

@@ -88,20 +88,17 @@ __device__ __forceinline__ sl_args_ptr sl_late_args() {
 constexpr int SL_DHP = 16;          // head vectors padded to 16 elements in LDS (dh <= 16)
 constexpr int SL_MAXS = 8;
 
-// B fragments of one 16-column tile of W [N, K] (row-major bf16): lane (c = lane & 15, g = lane >> 4) holds W[n0 + c][32 ks + 8 g ..+7].
-// Rows beyond N and the k-group beyond K are clamped to valid memory: those columns are discarded / multiply zero-padded A columns.
+// B fragments of one 16-column tile of a product x W^T: W [N, K] in the fragment-tiled copy of csrc/mlp_block.hip (mb_toff; written by
+// ops_mlp_repack_weights / the optimiser launch): tile (n >> 4, k >> 5) = 512 elements in MFMA lane order, i.e. lane l's eight values
+// of reduction step ks are the 16 bytes at ((tile * KSW + ks) * 512 + 8 l) -- a wave's load is ONE contiguous KB (row-major weights:
+// 16 rows x 64 bytes per instruction = twice the texture-path cycles), padding rows / columns are zeros.
 template <int KS>
 struct WTile { uint4 f[KS]; };
 template <int KS>
-__device__ __forceinline__ void sl_load_tile(WTile<KS>& t, const uint16_t* __restrict__ W, int N, int K, int n0, int c, int g) {
-  const int n = n0 + c < N ? n0 + c : N - 1;
-  const uint16_t* row = W + (long)n * K;
+__device__ __forceinline__ void sl_load_tile(WTile<KS>& t, const uint16_t* __restrict__ Wp, int ksw, int tile, int lane) {
+  const uint16_t* base = Wp + ((long)tile * ksw) * 512 + 8 * lane;
 #pragma unroll
-  for (int ks = 0; ks < KS; ++ks) {
-    int k = 32 * ks + 8 * g;
-    if (k + 8 > K) k = K - 8;
-    t.f[ks] = *(const uint4*)(row + k);
-  }
+  for (int ks = 0; ks < KS; ++ks) t.f[ks] = *(const uint4*)(base + (ks < ksw ? ks : ksw - 1) * 512);
 }
 template <int KS>
 __device__ __forceinline__ sl_f32x4 sl_mma_tile(const WTile<KS>& t, const uint16_t* __restrict__ sA, int AS, int c, int g) {
@@ -207,7 +204,7 @@ __global__ __launch_bounds__(64 * SL_NW) void tfd_layer_fwd_kernel(const ops_tfd
     if (r < nrows && 4 * q4 < d) xin = *(const float4*)(a.x32 + (row0 + r) * d + 4 * q4);
   }
   const unsigned long long call = *a.counter;
-  const int NTQ = (3 * d + 15) / 16, NT1 = (ff + 15) / 16;
+  const int NTQ = (3 * d + 15) / 16, NT1 = (ff + 15) / 16, NTD = (d + 15) / 16, KSD = (d + 31) / 32, KSF = (ff + 31) / 32;   // tiles / reduction steps
   // This lane's bias / scale / shift values of every stage: requested BEFORE the weights.  Vector-memory results return in order, so a
   // bias read issued in a product's epilogue would wait for every weight fragment requested ahead of it.
   float bq[3], b1v[2];
@@ -218,7 +215,7 @@ __global__ __launch_bounds__(64 * SL_NW) void tfd_layer_fwd_kernel(const ops_tfd
   // (no branches around the loads: tiles beyond a product's last are clamped to it, so that the compiler can COUNT the outstanding
   //  requests -- behind a conditional load or a loop of unknown length it falls back to "wait for everything")
 #pragma unroll
-  for (int j = 0; j < 3; ++j) { const int t = wave + SL_NW * j; sl_load_tile<4>(wq[j], (const uint16_t*)a.W_in, 3 * d, d, 16 * (t < NTQ ? t : NTQ - 1), c, g); }
+  for (int j = 0; j < 3; ++j) { const int t = wave + SL_NW * j; sl_load_tile<4>(wq[j], (const uint16_t*)a.W_in, KSD, t < NTQ ? t : NTQ - 1, lane); }
   SL_STAMP(7);
 
   // ---- x -> bf16 operand rows (zero beyond the live rows and beyond column d) ----
@@ -244,10 +241,10 @@ __global__ __launch_bounds__(64 * SL_NW) void tfd_layer_fwd_kernel(const ops_tfd
   const int nc = colok ? n : d - 1;
   const float bo = sl_bf2f(((const uint16_t*)a.b_out)[nc]), b2v = sl_bf2f(((const uint16_t*)a.b_2)[nc]);
   const float gm1 = a.gamma1[nc], be1 = a.beta1[nc], gm2 = a.gamma2[nc], be2 = a.beta2[nc];
-  sl_load_tile<4>(wo, (const uint16_t*)a.W_out, d, d, 16 * wave, c, g);
+  sl_load_tile<4>(wo, (const uint16_t*)a.W_out, KSD, wave < NTD ? wave : NTD - 1, lane);
 #pragma unroll
-  for (int j = 0; j < 2; ++j) { const int t = wave + SL_NW * j; sl_load_tile<4>(w1[j], (const uint16_t*)a.W_1, ff, d, 16 * (t < NT1 ? t : NT1 - 1), c, g); }
-  sl_load_tile<8>(w2, (const uint16_t*)a.W_2, d, ff, 16 * wave, c, g);
+  for (int j = 0; j < 2; ++j) { const int t = wave + SL_NW * j; sl_load_tile<4>(w1[j], (const uint16_t*)a.W_1, KSD, t < NT1 ? t : NT1 - 1, lane); }
+  sl_load_tile<8>(w2, (const uint16_t*)a.W_2, KSF, wave < NTD ? wave : NTD - 1, lane);
   sl_lds_barrier();
   SL_STAMP(1);
 
@@ -477,6 +474,382 @@ __global__ __launch_bounds__(64 * SL_NW) void tfd_layer_fwd_kernel(const ops_tfd
   }
 }
 
+
+// ================================================================================================================================
+// The layer's backward pass as one launch: the same decomposition (16 rows per workgroup, 8 waves split the column tiles, all weight
+// fragments -- here the TRANSPOSES' tiles -- requested at entry).  Arithmetic contract = the eight launches it replaces
+// (dropout_add_ln_bwd, act_dropout_bwd, seq_attention_bwd of csrc/seq_block.hip and four bf16 library products): bf16 operands, fp32
+// accumulation, every product rounded to bf16 before use, the residual stream's gradient in fp32.
+// ================================================================================================================================
+typedef const __attribute__((opencl_constant)) ops_tfd_layer_bwd_args* slb_args_ptr;
+__device__ __forceinline__ slb_args_ptr slb_late_args() {
+  auto p = __builtin_amdgcn_kernarg_segment_ptr();
+  __asm__ volatile("" : "+s"(p));
+  return (slb_args_ptr)p;
+}
+#define SL_GLOBAL(T, p) ((__attribute__((address_space(1))) T*)(p))
+
+// LayerNorm backward for the accumulator layout (lane (c, g) of wave w: rows 4 g + i, column n = 16 w + c).  dy, xhat in registers;
+// the two row means (of gamma dy and of gamma dy xhat) need all 8 waves: per-wave partial sums -> LDS [which][row][wave] -> ONE barrier.
+__device__ __forceinline__ void slb_ln_bwd(const float (&dy)[4], const float (&xh)[4], float gm, const float (&rstd)[4], int d, int wave, int c, int g,
+                                           float* s_red /*[2][16][SL_NW]*/, float (&dz)[4]) {
+  float gy[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    gy[i] = dy[i] * gm;
+    const float p1 = sl_rowsum(gy[i]), p2 = sl_rowsum(gy[i] * xh[i]);
+    if (c == 0) { s_red[(4 * g + i) * SL_NW + wave] = p1; s_red[(16 + 4 * g + i) * SL_NW + wave] = p2; }
+  }
+  sl_lds_barrier();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float4 a0 = *(const float4*)(s_red + (4 * g + i) * SL_NW), a1 = *(const float4*)(s_red + (4 * g + i) * SL_NW + 4);
+    const float4 b0 = *(const float4*)(s_red + (16 + 4 * g + i) * SL_NW), b1 = *(const float4*)(s_red + (16 + 4 * g + i) * SL_NW + 4);
+    const float s1 = (((a0.x + a0.y) + (a0.z + a0.w)) + ((a1.x + a1.y) + (a1.z + a1.w))) / (float)d;
+    const float s2 = (((b0.x + b0.y) + (b0.z + b0.w)) + ((b1.x + b1.y) + (b1.z + b1.w))) / (float)d;
+    dz[i] = rstd[i] * (gy[i] - s1 - xh[i] * s2);
+  }
+}
+// column sums over the workgroup's 16 rows of (dy xhat, dy) -> one float atomic per column into dgamma / dbeta
+__device__ __forceinline__ void slb_param_grads(const float (&dy)[4], const float (&xh)[4], bool colok, int n, int g, float* dgamma, float* dbeta) {
+  float pg = 0.0f, pb = 0.0f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { pg = __builtin_fmaf(dy[i], xh[i], pg); pb += dy[i]; }
+  pg += __shfl_xor(pg, 16, 64); pb += __shfl_xor(pb, 16, 64);
+  pg += __shfl_xor(pg, 32, 64); pb += __shfl_xor(pb, 32, 64);
+  if (g == 0 && colok) { unsafeAtomicAdd(dgamma + n, pg); unsafeAtomicAdd(dbeta + n, pb); }
+}
+
+template <bool HAS32, bool HAS16>
+__global__ __launch_bounds__(64 * SL_NW) void tfd_layer_bwd_kernel(const ops_tfd_layer_bwd_args a) {
+  constexpr int XS = 128 + 8, HS = 256 + 8, QS = 384 + 8, FS = 128 + 4;
+  __shared__ __attribute__((aligned(16))) uint16_t s_a[16 * XS];                  // d_f, later d_a (bf16 operand rows)
+  __shared__ __attribute__((aligned(16))) uint16_t s_du[16 * HS];                 // d_u
+  __shared__ __attribute__((aligned(16))) uint16_t s_u[16 * HS];                  // u (saved pre-activation)
+  __shared__ __attribute__((aligned(16))) uint16_t s_qkv[16 * 3 * 8 * SL_DHP];    // q|k|v padded image [row][q|k|v][H][16]
+  __shared__ __attribute__((aligned(16))) uint16_t s_do[16 * 8 * SL_DHP];         // d_ctx padded image [row][H][16]
+  __shared__ __attribute__((aligned(16))) uint16_t s_dq[16 * QS];                 // dqkv rows (operand of the last product, and as stored)
+  __shared__ __attribute__((aligned(16))) float s_g[16 * FS];                     // incoming gradient (float32), at the end dx
+  __shared__ __attribute__((aligned(16))) float s_z2[16 * FS];
+  __shared__ __attribute__((aligned(16))) float s_z1[16 * FS];
+  __shared__ __attribute__((aligned(16))) float s_ds[16 * 8 * SL_MAXS];           // [sample][head][query][key] scale * dS   (spw H S S <= 1024)
+  __shared__ __attribute__((aligned(16))) float s_pk[16 * 8 * SL_MAXS];           // ... keep-scaled probabilities
+  __shared__ __attribute__((aligned(16))) float s_red[2][2 * 16 * SL_NW];
+  __shared__ float s_stat[4][16];                                                 // mean2, rstd2, mean1, rstd1 of the 16 rows
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 15, g = lane >> 4;
+  const int S = a.S, H = a.H, dh = a.dh, d = a.d, ff = a.ff;
+  const int spw = 16 / S;
+  const int b0 = blockIdx.x * spw, nsamp = (a.Bn - b0 < spw) ? a.Bn - b0 : spw, nrows = nsamp * S;
+  const long row0 = (long)b0 * S;
+  unsigned long long stamp[16];
+#define SLB_STAMP(k) if (a.trace) stamp[k] = __builtin_amdgcn_s_memrealtime()
+  SLB_STAMP(0);
+  const int n = 16 * wave + c;
+  const bool colok = n < d;
+  const int nc = colok ? n : d - 1;
+  const int NT1 = (ff + 15) / 16, NTD = (d + 15) / 16, KSD = (d + 31) / 32, KSF = (ff + 31) / 32, KSQ = (3 * d + 31) / 32;
+
+  // ---- requests: coalesced row pieces of everything the elementwise stages read (one 16-byte piece per thread and array), the
+  //      statistics, then the 32 weight fragments of this wave in the order of use ----
+  const int pr = tid >> 5, pq = tid & 31;                 // float32 rows: 16 rows x 32 float4
+  const bool pok = pr < nrows && 4 * pq < d;
+  const long poff = (row0 + (pr < nrows ? pr : 0)) * d + (4 * pq < d ? 4 * pq : 0);
+  float4 gin = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  uint2 gin16 = uint2{0u, 0u};
+  if (HAS32) gin = *(const float4*)(a.g32 + poff);
+  if (HAS16) gin16 = *(const uint2*)((const uint16_t*)a.g16 + poff);
+  const float4 z2in = *(const float4*)(a.z2 + poff), z1in = *(const float4*)(a.z1 + poff);
+  const int ur = tid >> 5, uq = tid & 31;                 // u rows: 16 rows x 32 pieces of 8 bf16
+  const uint4 uin = *(const uint4*)((const uint16_t*)a.u + (row0 + (ur < nrows ? ur : 0)) * ff + (8 * uq < ff ? 8 * uq : 0));
+  const float stin = ((tid >> 4) == 0 ? a.mean2 : (tid >> 4) == 1 ? a.rstd2 : (tid >> 4) == 2 ? a.mean1 : a.rstd1)[row0 + ((tid & 15) < nrows ? (tid & 15) : 0)];
+  const float gm2 = a.gamma2[nc], gm1 = a.gamma1[nc];
+  const int qppr = 3 * d / 8;                              // 16-byte pieces per q|k|v row
+  uint4 qin[2];
+  int qidx[2];
+  {
+    const float inv = 1.0f / (float)qppr;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int idx = tid + 64 * SL_NW * k;
+      const int r = (int)(((float)idx + 0.5f) * inv);
+      qidx[k] = (idx < nrows * qppr) ? idx : -1;
+      qin[k] = *(const uint4*)((const uint16_t*)a.qkv + row0 * 3 * d + 8 * (long)(idx < nrows * qppr ? idx : 0));
+      (void)r;
+    }
+  }
+  const unsigned long long call = *a.used_call;
+  WTile<4> wt2[2], wto;
+  WTile<8> wt1;
+  WTile<12> wti;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) { const int t = wave + SL_NW * j; sl_load_tile<4>(wt2[j], (const uint16_t*)a.Wt_2, KSD, t < NT1 ? t : NT1 - 1, lane); }
+  sl_load_tile<8>(wt1, (const uint16_t*)a.Wt_1, KSF, wave < NTD ? wave : NTD - 1, lane);
+  sl_load_tile<4>(wto, (const uint16_t*)a.Wt_out, KSD, wave < NTD ? wave : NTD - 1, lane);
+  sl_load_tile<12>(wti, (const uint16_t*)a.Wt_in, KSQ, wave < NTD ? wave : NTD - 1, lane);
+  SLB_STAMP(1);
+
+  // ---- stage the row pieces in LDS (rows beyond the samples and columns beyond d: zeros) ----
+  {
+    float4 gs = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (pok) {
+      gs = gin;
+      if (HAS16) { gs.x += __uint_as_float(gin16.x << 16); gs.y += __uint_as_float(gin16.x & 0xffff0000u); gs.z += __uint_as_float(gin16.y << 16); gs.w += __uint_as_float(gin16.y & 0xffff0000u); }
+    }
+    *(float4*)(s_g + pr * FS + 4 * pq) = gs;
+    *(float4*)(s_z2 + pr * FS + 4 * pq) = pok ? z2in : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    *(float4*)(s_z1 + pr * FS + 4 * pq) = pok ? z1in : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    *(uint4*)(s_u + ur * HS + 8 * uq) = (ur < nrows && 8 * uq < ff) ? uin : uint4{0u, 0u, 0u, 0u};
+    if (tid < 64) s_stat[tid >> 4][tid & 15] = stin;
+    // q|k|v rows -> padded head vectors
+    const float inv_q = 1.0f / (float)qppr, inv_dh = 1.0f / (float)dh;
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+      if (qidx[k] >= 0) {
+        const int r = (int)(((float)qidx[k] + 0.5f) * inv_q), c0 = 8 * (qidx[k] - r * qppr);
+        const uint16_t* v = (const uint16_t*)&qin[k];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int cc = c0 + j, seg = (int)(((float)cc + 0.5f) * inv_dh), tt = cc - seg * dh;     // seg = which * H + head
+          s_qkv[(r * 3 * H + seg) * SL_DHP + tt] = v[j];
+        }
+      }
+    // padding lanes dh .. 15 of every head vector (q|k|v and d_ctx images; disjoint from what the scatters write), rows beyond the samples
+    const int np = SL_DHP - dh;
+    if (np > 0) {
+      const float inv_np = 1.0f / (float)np;
+      for (int e = tid; e < 16 * 4 * H * np; e += 64 * SL_NW) {
+        const int vec = (int)(((float)e + 0.5f) * inv_np), t = e - vec * np;
+        if (vec < 16 * 3 * H) s_qkv[vec * SL_DHP + dh + t] = 0; else s_do[(vec - 16 * 3 * H) * SL_DHP + dh + t] = 0;
+      }
+    }
+    for (int e = tid; e < (16 - nrows) * 3 * H * SL_DHP / 8; e += 64 * SL_NW) ((uint4*)(s_qkv + nrows * 3 * H * SL_DHP))[e] = uint4{0u, 0u, 0u, 0u};
+    for (int e = tid; e < (16 - nrows) * H * SL_DHP / 8; e += 64 * SL_NW) ((uint4*)(s_do + nrows * H * SL_DHP))[e] = uint4{0u, 0u, 0u, 0u};
+    for (int e = tid; e < 16 * QS / 8; e += 64 * SL_NW) ((uint4*)s_dq)[e] = uint4{0u, 0u, 0u, 0u};      // dqkv rows: columns 3 d .. 383 and dead rows stay zero
+    sl_zero_cols(s_du, HS, ff, 256, tid);
+  }
+  sl_lds_barrier();
+  SLB_STAMP(2);
+
+  // ---- LayerNorm2 backward -> dres2 (registers), d_f (bf16 operand rows) ----
+  float dres2[4];
+  {
+    const slb_args_ptr la = slb_late_args();
+    const DropKey key_2 = drop_key(la->seed_2, call);
+    const float p_2 = la->p_2, ks = p_2 > 0.0f ? 1.0f / (1.0f - p_2) : 1.0f;
+    float dy[4], xh[4], rstd[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = 4 * g + i;
+      dy[i] = s_g[r * FS + n];
+      rstd[i] = s_stat[1][r];
+      xh[i] = (colok && r < nrows) ? (s_z2[r * FS + n] - s_stat[0][r]) * rstd[i] : 0.0f;
+    }
+    slb_param_grads(dy, xh, colok, n, g, la->dgamma2, la->dbeta2);
+    slb_ln_bwd(dy, xh, gm2, rstd, d, wave, c, g, s_red[0], dres2);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = 4 * g + i;
+      const bool live = colok && r < nrows;
+      if (!live) dres2[i] = 0.0f;
+      float v = dres2[i];
+      if (p_2 > 0.0f) v = drop_uniform(key_2, (uint64_t)(row0 * d) + (uint32_t)(r * d + n)) >= p_2 ? v * ks : 0.0f;
+      s_a[r * XS + n] = live ? sl_f2bf(v) : (uint16_t)0;
+    }
+  }
+  sl_lds_barrier();
+  SLB_STAMP(3);
+
+  // ---- d_h = d_f W_2 (bf16), ReLU + dropout backward -> d_u ----
+  {
+    const slb_args_ptr la = slb_late_args();
+    const DropKey key_act = drop_key(la->seed_act, call);
+    const float p_act = la->p_act, ks = p_act > 0.0f ? 1.0f / (1.0f - p_act) : 1.0f;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int t = wave + SL_NW * j;
+      if (t < NT1) {                                   // wave-uniform
+        const sl_f32x4 acc = sl_mma_tile<4>(wt2[j], s_a, XS, c, g);
+        const int m = 16 * t + c;
+        if (m < ff) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int r = 4 * g + i;
+            float gv = sl_round(acc[i]);
+            if (p_act > 0.0f) gv = drop_uniform(key_act, (uint64_t)(row0 * ff) + (uint32_t)(r * ff + m)) >= p_act ? gv * ks : 0.0f;
+            gv = sl_bf2f(s_u[r * HS + m]) > 0.0f ? gv : 0.0f;
+            s_du[r * HS + m] = r < nrows ? sl_f2bf(gv) : (uint16_t)0;
+          }
+        }
+      }
+    }
+  }
+  sl_lds_barrier();
+  // every weight fragment has arrived by now (see the forward kernel): one full wait BEFORE the first store is issued
+  __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
+  SLB_STAMP(4);
+  { const slb_args_ptr la = slb_late_args();
+    sl_store_rows<2>(la->d_f, s_a, XS, d, row0, nrows, tid);
+    sl_store_rows<2>(la->d_u, s_du, HS, ff, row0, nrows, tid); }
+
+  // ---- d_y1 = d_u W_1 (bf16) + dres2, LayerNorm1 backward -> dres1 (registers), d_a ----
+  float dres1[4];
+  {
+    const slb_args_ptr la = slb_late_args();
+    const DropKey key_1 = drop_key(la->seed_1, call);
+    const float p_1 = la->p_1, ks = p_1 > 0.0f ? 1.0f / (1.0f - p_1) : 1.0f;
+    const sl_f32x4 acc = sl_mma_tile<8>(wt1, s_du, HS, c, g);
+    float dy[4], xh[4], rstd[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = 4 * g + i;
+      const bool live = colok && r < nrows;
+      dy[i] = live ? dres2[i] + sl_round(acc[i]) : 0.0f;
+      rstd[i] = s_stat[3][r];
+      xh[i] = live ? (s_z1[r * FS + n] - s_stat[2][r]) * rstd[i] : 0.0f;
+    }
+    slb_param_grads(dy, xh, colok, n, g, la->dgamma1, la->dbeta1);
+    slb_ln_bwd(dy, xh, gm1, rstd, d, wave, c, g, s_red[1], dres1);   // (its barrier: every thread has read its d_f pieces, s_a becomes d_a)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = 4 * g + i;
+      const bool live = colok && r < nrows;
+      if (!live) dres1[i] = 0.0f;
+      float v = dres1[i];
+      if (p_1 > 0.0f) v = drop_uniform(key_1, (uint64_t)(row0 * d) + (uint32_t)(r * d + n)) >= p_1 ? v * ks : 0.0f;
+      s_a[r * XS + n] = live ? sl_f2bf(v) : (uint16_t)0;
+    }
+  }
+  sl_lds_barrier();
+  SLB_STAMP(5);
+  { const slb_args_ptr la = slb_late_args(); sl_store_rows<2>(la->d_a, s_a, XS, d, row0, nrows, tid); }
+
+  // ---- d_ctx = d_a W_out (bf16) -> padded head vectors ----
+  {
+    const sl_f32x4 acc = sl_mma_tile<4>(wto, s_a, XS, c, g);
+    if (colok) {
+      const float inv_dh = 1.0f / (float)dh;
+      const int hh = (int)(((float)n + 0.5f) * inv_dh), tt = n - hh * dh;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { const int r = 4 * g + i; if (r < nrows) s_do[(r * H + hh) * SL_DHP + tt] = sl_f2bf(acc[i]); }
+    }
+  }
+  sl_lds_barrier();
+  SLB_STAMP(6);
+
+  // ---- attention backward: four lanes per (sample, head, token), four head dimensions each ----
+  {
+    const slb_args_ptr la = slb_late_args();
+    const DropKey key_attn = drop_key(la->seed_attn, call);
+    const float p_attn = la->p_attn, ks = p_attn > 0.0f ? 1.0f / (1.0f - p_attn) : 1.0f;
+    const float scale = rsqrtf((float)dh);
+    const int rs = 3 * H * SL_DHP, rso = H * SL_DHP;
+    const int qd = tid & 3;
+    const float inv_S = 1.0f / (float)S, inv_H = 1.0f / (float)H;
+    auto ld4 = [](const uint16_t* p, float (&v)[4]) {
+      const uint2 uu = *(const uint2*)p;
+      v[0] = __uint_as_float(uu.x << 16); v[1] = __uint_as_float(uu.x & 0xffff0000u); v[2] = __uint_as_float(uu.y << 16); v[3] = __uint_as_float(uu.y & 0xffff0000u);
+    };
+    // token as QUERY i: softmax row, dP, dS, dq
+    for (int it = tid >> 2; it < spw * H * S; it += 16 * SL_NW) {
+      const int t1 = (int)(((float)it + 0.5f) * inv_S), i = it - t1 * S, bl = (int)(((float)t1 + 0.5f) * inv_H), hh = t1 - bl * H;
+      const uint16_t* base = s_qkv + (bl * S) * rs + hh * SL_DHP + 4 * qd;
+      float q[4], go[4], p[SL_MAXS], dp[SL_MAXS], dq[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+      ld4(base + i * rs, q);
+      ld4(s_do + (bl * S + i) * rso + hh * SL_DHP + 4 * qd, go);
+      float mx = -3.0e38f;
+#pragma unroll
+      for (int j = 0; j < SL_MAXS; ++j) {
+        p[j] = -3.0e38f; dp[j] = 0.0f;
+        if (j < S) {
+          float kv[4], vv[4];
+          ld4(base + j * rs + H * SL_DHP, kv);
+          ld4(base + j * rs + 2 * H * SL_DHP, vv);
+          float sc = q[0] * kv[0]; sc = __builtin_fmaf(q[1], kv[1], sc); sc = __builtin_fmaf(q[2], kv[2], sc); sc = __builtin_fmaf(q[3], kv[3], sc);
+          float dd = go[0] * vv[0]; dd = __builtin_fmaf(go[1], vv[1], dd); dd = __builtin_fmaf(go[2], vv[2], dd); dd = __builtin_fmaf(go[3], vv[3], dd);
+          p[j] = sl_quadsum(sc) * scale;
+          dp[j] = sl_quadsum(dd);
+          mx = fmaxf(mx, p[j]);
+        }
+      }
+      float den = 0.0f;
+#pragma unroll
+      for (int j = 0; j < SL_MAXS; ++j) { p[j] = j < S ? __expf(p[j] - mx) : 0.0f; den += p[j]; }
+      const float inv = 1.0f / den;
+      const uint64_t e0 = (uint64_t)b0 * (uint64_t)(H * S * S) + (uint32_t)((((bl * H + hh) * S + i) * S));
+      unsigned keep = 0xffu;
+      if (p_attn > 0.0f) {
+        keep = 0u;
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+          const int j = qd + 4 * jj;
+          if (j < S && drop_uniform(key_attn, e0 + j) >= p_attn) keep |= 1u << j;
+        }
+        keep = sl_dpp_or_quad(keep);
+      }
+      // through the dropout (dP = keep / (1 - p) dP~) and the softmax (dS = P (dP - sum_k dP_k P_k))
+      float D = 0.0f, pkv[SL_MAXS];
+#pragma unroll
+      for (int j = 0; j < SL_MAXS; ++j) {
+        p[j] *= inv;
+        const bool kp = j < S && ((keep >> j) & 1u);
+        pkv[j] = kp ? p[j] * ks : 0.0f;
+        dp[j] = pkv[j] != 0.0f ? dp[j] * ks : (p_attn > 0.0f ? 0.0f : dp[j]);
+        D = __builtin_fmaf(dp[j], p[j], D);
+      }
+#pragma unroll
+      for (int j = 0; j < SL_MAXS; ++j)
+        if (j < S) {
+          const float ds = p[j] * (dp[j] - D) * scale;
+          if ((j & 3) == qd) { s_ds[(((bl * H + hh) * S + i) * SL_MAXS) + j] = ds; s_pk[(((bl * H + hh) * S + i) * SL_MAXS) + j] = pkv[j]; }
+          float kv[4];
+          ld4(base + j * rs + H * SL_DHP, kv);
+#pragma unroll
+          for (int t = 0; t < 4; ++t) dq[t] = __builtin_fmaf(ds, kv[t], dq[t]);
+        }
+      const int r = bl * S + i;
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+        if (4 * qd + t < dh) s_dq[r * QS + hh * dh + 4 * qd + t] = sl_f2bf(dq[t]);
+    }
+    sl_lds_barrier();
+    // token as KEY / VALUE j: dk_j = sum_i dS_ij q_i, dv_j = sum_i P~_ij dO_i
+    for (int it = tid >> 2; it < spw * H * S; it += 16 * SL_NW) {
+      const int t1 = (int)(((float)it + 0.5f) * inv_S), j = it - t1 * S, bl = (int)(((float)t1 + 0.5f) * inv_H), hh = t1 - bl * H;
+      float dk[4] = {0.0f, 0.0f, 0.0f, 0.0f}, dv[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+      for (int ii = 0; ii < SL_MAXS; ++ii)
+        if (ii < S) {
+          const float wds = s_ds[(((bl * H + hh) * S + ii) * SL_MAXS) + j], wpk = s_pk[(((bl * H + hh) * S + ii) * SL_MAXS) + j];
+          float qv[4], gv[4];
+          ld4(s_qkv + (bl * S + ii) * rs + hh * SL_DHP + 4 * qd, qv);
+          ld4(s_do + (bl * S + ii) * rso + hh * SL_DHP + 4 * qd, gv);
+#pragma unroll
+          for (int t = 0; t < 4; ++t) { dk[t] = __builtin_fmaf(wds, qv[t], dk[t]); dv[t] = __builtin_fmaf(wpk, gv[t], dv[t]); }
+        }
+      const int r = bl * S + j;
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+        if (4 * qd + t < dh) { s_dq[r * QS + d + hh * dh + 4 * qd + t] = sl_f2bf(dk[t]); s_dq[r * QS + 2 * d + hh * dh + 4 * qd + t] = sl_f2bf(dv[t]); }
+    }
+  }
+  sl_lds_barrier();
+  SLB_STAMP(7);
+  { const slb_args_ptr la = slb_late_args(); sl_store_rows<2>(la->dqkv, s_dq, QS, 3 * d, row0, nrows, tid); }
+
+  // ---- dx = dres1 + bf16(dqkv W_in) ----
+  {
+    const sl_f32x4 acc = sl_mma_tile<12>(wti, s_dq, QS, c, g);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { const int r = 4 * g + i; s_g[r * FS + n] = dres1[i] + sl_round(acc[i]); }
+  }
+  sl_lds_barrier();
+  { const slb_args_ptr la = slb_late_args(); sl_store_rows<4>(la->dx32, s_g, FS, d, row0, nrows, tid); }
+  if (a.trace && tid == 0) {
+    SLB_STAMP(8);
+    for (int k = 0; k < 16; ++k) a.trace[16 * (unsigned long long)blockIdx.x + k] = stamp[k];
+  }
+}
+
 }  // namespace opsamd
 
 extern "C" int ops_tfd_encoder_layer_fwd(const ops_tfd_layer_args* a, void* stream) {
@@ -491,6 +864,28 @@ extern "C" int ops_tfd_encoder_layer_fwd(const ops_tfd_layer_args* a, void* stre
   const int spw = 16 / a->S;
   const unsigned grid = (unsigned)((a->Bn + spw - 1) / spw);
   hipLaunchKernelGGL(opsamd::tfd_layer_fwd_kernel, dim3(grid), dim3(64 * opsamd::SL_NW), 0, (hipStream_t)stream, *a);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { opsamd::set_last_error(hipGetErrorString(e)); return OPS_AMD_ERR_LAUNCH; }
+  return OPS_AMD_OK;
+}
+
+extern "C" int ops_tfd_encoder_layer_bwd(const ops_tfd_layer_bwd_args* a, void* stream) {
+  if (!a || a->Bn < 1 || a->S < 1 || a->S > 8 || a->H < 1 || a->H > 8 || a->dh < 1 || a->dh > 16 || a->d != a->H * a->dh || a->d > 128 || a->d % 8 ||
+      a->ff < 16 || a->ff > 256 || a->ff % 8)
+    return OPS_AMD_ERR_UNSUPPORTED;
+  if (!a->g32 && !a->g16) return OPS_AMD_ERR_INVALID_ARG;
+  if (!a->Wt_in || !a->Wt_out || !a->Wt_1 || !a->Wt_2 || !a->gamma1 || !a->gamma2 || !a->used_call || !a->qkv || !a->z1 || !a->mean1 || !a->rstd1 || !a->u ||
+      !a->z2 || !a->mean2 || !a->rstd2 || !a->d_f || !a->d_u || !a->d_a || !a->dqkv || !a->dx32 || !a->dgamma1 || !a->dbeta1 || !a->dgamma2 || !a->dbeta2)
+    return OPS_AMD_ERR_INVALID_ARG;
+  if ((((uintptr_t)a->Wt_in | (uintptr_t)a->Wt_out | (uintptr_t)a->Wt_1 | (uintptr_t)a->Wt_2 | (uintptr_t)a->g32 | (uintptr_t)a->z1 | (uintptr_t)a->z2 |
+        (uintptr_t)a->u | (uintptr_t)a->qkv | (uintptr_t)a->d_f | (uintptr_t)a->d_u | (uintptr_t)a->d_a | (uintptr_t)a->dqkv | (uintptr_t)a->dx32) & 15) != 0 ||
+      ((uintptr_t)a->g16 & 7) != 0)
+    return OPS_AMD_ERR_UNSUPPORTED;
+  const int spw = 16 / a->S;
+  const dim3 grid((unsigned)((a->Bn + spw - 1) / spw)), block(64 * opsamd::SL_NW);
+  if (a->g32 && a->g16) hipLaunchKernelGGL((opsamd::tfd_layer_bwd_kernel<true, true>), grid, block, 0, (hipStream_t)stream, *a);
+  else if (a->g32) hipLaunchKernelGGL((opsamd::tfd_layer_bwd_kernel<true, false>), grid, block, 0, (hipStream_t)stream, *a);
+  else hipLaunchKernelGGL((opsamd::tfd_layer_bwd_kernel<false, true>), grid, block, 0, (hipStream_t)stream, *a);
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) { opsamd::set_last_error(hipGetErrorString(e)); return OPS_AMD_ERR_LAUNCH; }
   return OPS_AMD_OK;

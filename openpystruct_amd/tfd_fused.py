@@ -25,6 +25,7 @@ from . import _cabi
 
 ENABLED = os.environ.get("OPS_AMD_TFD_FAST_ENCODER", "1") == "1"      # A/B switch: 0 = nn.TransformerEncoder's own forward
 LAYER_FWD = os.environ.get("OPS_AMD_TFD_LAYER_FWD", "1") == "1"       # A/B switch: 0 = eight launches per layer forward instead of one
+LAYER_BWD = os.environ.get("OPS_AMD_TFD_LAYER_BWD", "1") == "1"       # A/B switch: 0 = eight launches per layer backward instead of one
 
 
 class _State:
@@ -210,6 +211,7 @@ class EncoderLayerFn(torch.autograd.Function):
         dev = x32.device
         x32 = x32.contiguous()
         rin, rout, r1, r2 = mha._ops_in_proj.rec, mha._ops_out_proj.rec, layer.linear1._ops_prod.rec, layer.linear2._ops_prod.rec
+        tiles = layer._ops_tiles
         bf, f32 = dict(dtype=torch.bfloat16, device=dev), dict(dtype=torch.float32, device=dev)
         qkv, ctxa = torch.empty((T, 3 * d), **bf), torch.empty((T, d), **bf)
         z1, mean1, rstd1, y1_16 = torch.empty((T, d), **f32), torch.empty(T, **f32), torch.empty(T, **f32), torch.empty((T, d), **bf)
@@ -221,8 +223,8 @@ class EncoderLayerFn(torch.autograd.Function):
         ps = (float(mha.dropout), float(layer.dropout1.p), float(layer.dropout.p), float(layer.dropout2.p))
         a = _cabi.TfdLayerArgs(
             Bn=Bn, S=S, H=H, dh=dh, d=d, ff=ff, x32=x32.data_ptr(),
-            W_in=rin.w_sh.data_ptr(), b_in=rin.b_sh.data_ptr(), W_out=rout.w_sh.data_ptr(), b_out=rout.b_sh.data_ptr(),
-            W_1=r1.w_sh.data_ptr(), b_1=r1.b_sh.data_ptr(), W_2=r2.w_sh.data_ptr(), b_2=r2.b_sh.data_ptr(),
+            W_in=tiles["in"][0].data_ptr(), b_in=rin.b_sh.data_ptr(), W_out=tiles["out"][0].data_ptr(), b_out=rout.b_sh.data_ptr(),
+            W_1=tiles["l1"][0].data_ptr(), b_1=r1.b_sh.data_ptr(), W_2=tiles["l2"][0].data_ptr(), b_2=r2.b_sh.data_ptr(),
             gamma1=layer.norm1.weight.data_ptr(), beta1=layer.norm1.bias.data_ptr(), eps1=float(layer.norm1.eps),
             gamma2=layer.norm2.weight.data_ptr(), beta2=layer.norm2.bias.data_ptr(), eps2=float(layer.norm2.eps),
             p_attn=ps[0], p_1=ps[1], p_act=ps[2], p_2=ps[3], seed_attn=seeds[0], seed_1=seeds[1], seed_act=seeds[2], seed_2=seeds[3],
@@ -254,6 +256,26 @@ class EncoderLayerFn(torch.autograd.Function):
             g16 = g16.contiguous()
         with torch.cuda.device(dev):
             s = _stream(dev)
+            if LAYER_BWD:
+                # the whole backward pass: one launch (csrc/seq_layer.hip tfd_layer_bwd_kernel) + the four weight-gradient registrations
+                tiles = layer._ops_tiles
+                d_f, d_u, d_a, dqkv = torch.empty((T, d), **bf), torch.empty((T, ff), **bf), torch.empty((T, d), **bf), torch.empty((T, 3 * d), **bf)
+                dx32 = torch.empty((T, d), **f32)
+                a = _cabi.TfdLayerBwdArgs(
+                    Bn=Bn, S=S, H=H, dh=dh, d=d, ff=ff, g32=ptr(g32), g16=ptr(g16),
+                    Wt_in=tiles["in"][1].data_ptr(), Wt_out=tiles["out"][1].data_ptr(), Wt_1=tiles["l1"][1].data_ptr(), Wt_2=tiles["l2"][1].data_ptr(),
+                    gamma1=layer.norm1.weight.data_ptr(), gamma2=layer.norm2.weight.data_ptr(),
+                    p_attn=ps[0], p_1=ps[1], p_act=ps[2], p_2=ps[3], seed_attn=seeds[0], seed_1=seeds[1], seed_act=seeds[2], seed_2=seeds[3],
+                    used_call=used.data_ptr(), qkv=qkv.data_ptr(), z1=z1.data_ptr(), mean1=mean1.data_ptr(), rstd1=rstd1.data_ptr(), u=u.data_ptr(),
+                    z2=z2.data_ptr(), mean2=mean2.data_ptr(), rstd2=rstd2.data_ptr(), d_f=d_f.data_ptr(), d_u=d_u.data_ptr(), d_a=d_a.data_ptr(),
+                    dqkv=dqkv.data_ptr(), dx32=dx32.data_ptr(), dgamma1=layer.norm1.weight.grad.data_ptr(), dbeta1=layer.norm1.bias.grad.data_ptr(),
+                    dgamma2=layer.norm2.weight.grad.data_ptr(), dbeta2=layer.norm2.bias.grad.data_ptr())
+                _check(lib.ops_tfd_encoder_layer_bwd(ctypes.byref(a), s), "ops_tfd_encoder_layer_bwd")
+                train.shadow_param_grads(r2, d_f, h)
+                train.shadow_param_grads(r1, d_u, y1_16)
+                train.shadow_param_grads(rout, d_a, ctxa)
+                train.shadow_param_grads(rin, dqkv, x16)
+                return dx32, None, None, None, None, None, None
             # LayerNorm2 <- (g32, g16)
             d_f, dres2 = torch.empty((T, d), **bf), torch.empty((T, d), **f32)
             _check(lib.ops_dropout_add_layernorm_bwd(T, d, ptr(g32), ptr(g16), z2.data_ptr(), mean2.data_ptr(), rstd2.data_ptr(),
@@ -280,6 +302,47 @@ class EncoderLayerFn(torch.autograd.Function):
         return dres1, d_x16, None, None, None, None, None
 
 
+def enable_layer_tiles(enc: nn.TransformerEncoder):
+    """Fragment-tiled bf16 copies (plain and transposed: include/openpystruct_amd.h ops_mlp_repack_weights) of the four weight matrices of
+    the encoder's layers, for the one-launch layer kernels.  Returns the ctypes array of repack entries -- hand it to the optimiser
+    (FlatClipAdam.repack: its launch refreshes the copies) and call `refresh_layer_tiles` after anything else changed the parameters --
+    or None when no layer qualifies.  One grouped launch carries 8 matrices: the first two layers."""
+    lib = _cabi.load()
+    ru = lambda v, m: (v + m - 1) // m * m      # noqa: E731
+    todo = []
+    for layer in enc.layers:
+        if not _layer_ok(layer) or len(todo) + 4 > _cabi.MLP_MAX_WGRAD:
+            break
+        mha = layer.self_attn
+        ws = {"in": mha.in_proj_weight, "out": mha.out_proj.weight, "l1": layer.linear1.weight, "l2": layer.linear2.weight}
+        if not all(w.is_cuda and w.dtype == torch.float32 and w.is_contiguous() for w in ws.values()):
+            break
+        tiles = {}
+        for k, w in ws.items():
+            N, K = w.shape
+            tiles[k] = (torch.zeros(ru(N, 16), ru(K, 32), dtype=torch.bfloat16, device=w.device), torch.zeros(ru(K, 16), ru(N, 32), dtype=torch.bfloat16, device=w.device))
+            todo.append((w, tiles[k]))
+        layer._ops_tiles = tiles
+    if not todo:
+        return None
+    ent = (_cabi.MlpRepackEntry * len(todo))()
+    for e, (w, (wp, wtp)) in zip(ent, todo):
+        e.W, e.N, e.K = w.data_ptr(), w.shape[0], w.shape[1]
+        e.Wp, e.ldw, e.Wtp, e.ldwt = wp.data_ptr(), wp.shape[1], wtp.data_ptr(), wtp.shape[1]
+    enc._ops_tile_entries = ent
+    refresh_layer_tiles(enc)
+    return ent
+
+
+def refresh_layer_tiles(enc: nn.Module) -> None:
+    ent = getattr(enc, "_ops_tile_entries", None)
+    if ent is None:
+        return
+    dev = enc.layers[0].linear1.weight.device
+    with torch.cuda.device(dev):
+        _check(_cabi.load().ops_mlp_repack_weights(len(ent), ent, _stream(dev)), "ops_mlp_repack_weights")
+
+
 def _layer_fused_ok(layer: nn.Module, st: _State) -> bool:
     """The one-launch forward applies: shadow products registered on all four Linear maps, sizes inside the kernel's limits, weights
     16-byte aligned in the shadow buffer, LayerNorm gradients going straight into zeroed `.grad` views."""
@@ -287,12 +350,10 @@ def _layer_fused_ok(layer: nn.Module, st: _State) -> bool:
     d, H = mha.embed_dim, mha.num_heads
     recs = [getattr(getattr(mha, "_ops_in_proj", None), "rec", None), getattr(getattr(mha, "_ops_out_proj", None), "rec", None),
             getattr(getattr(layer.linear1, "_ops_prod", None), "rec", None), getattr(getattr(layer.linear2, "_ops_prod", None), "rec", None)]
-    if not (LAYER_FWD and st.direct and all(r is not None and r.b_sh is not None for r in recs)):
+    if not (LAYER_FWD and st.direct and hasattr(layer, "_ops_tiles") and all(r is not None and r.b_sh is not None for r in recs)):
         return False
     ff = layer.linear1.out_features
     if not (d <= 128 and d % 8 == 0 and d // H <= 16 and H <= 8 and 16 <= ff <= 256 and ff % 8 == 0):
-        return False
-    if any(r.w_sh.data_ptr() % 16 for r in recs):
         return False
     return all(t.grad is not None and t.grad.dtype == torch.float32 and t.grad.is_contiguous()
                for t in (layer.norm1.weight, layer.norm1.bias, layer.norm2.weight, layer.norm2.bias))
@@ -497,6 +558,8 @@ def patch_encoder(enc: nn.TransformerEncoder, seed: int, direct_param_grads: boo
         return encoder_forward(self, src, st)
 
     enc.forward = types.MethodType(forward, enc)
+    if LAYER_FWD:
+        enable_layer_tiles(enc)              # weight tiles of the one-launch layer kernels (enc._ops_tile_entries: FlatClipAdam.repack)
     return True
 
 
@@ -504,3 +567,6 @@ def unpatch_encoder(enc: nn.Module) -> None:
     if "forward" in enc.__dict__:
         del enc.__dict__["forward"]
     enc.__dict__.pop("_ops_dropout_state", None)
+    enc.__dict__.pop("_ops_tile_entries", None)
+    for layer in getattr(enc, "layers", []):
+        layer.__dict__.pop("_ops_tiles", None)

@@ -515,6 +515,7 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
                 from . import tfd_fused          # csrc/seq_block.hip: attention, dropout + add + LayerNorm, ReLU + dropout, diffusion front end
                 if tfd_fused.patch_model(model, seed=seed * 7919 + 211 + rank, direct_param_grads=True):
                     fast_encoder = model
+                    opt.repack = getattr(model.transformer_encoder, "_ops_tile_entries", None)    # the Adam launch refreshes the layer kernels' weight tiles
     else:
         opt = (torch.optim.AdamW if kind == "gnn" else torch.optim.Adam)(model.parameters(), lr=cfg.learning_rate,   # GNN:394
                                                                          weight_decay=cfg.weight_decay)
@@ -724,6 +725,9 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
             opt.refresh_shadow()
             if engine is not None:
                 engine.repack_now()
+            if fast_encoder is not None:
+                from . import tfd_fused
+                tfd_fused.refresh_layer_tiles(fast_encoder.transformer_encoder)
         # the validation pass as a graph too: one full batch in eval mode, loss accumulated into v_acc
         if graph is not None and Xva.shape[0] >= bs:
             vX, vY = torch.zeros_like(Xva[:bs]), torch.zeros_like(Yva[:bs])

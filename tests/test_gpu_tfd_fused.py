@@ -339,8 +339,9 @@ def test_one_launch_layer_forward_equals_the_eight_launch_form(monkeypatch, B, p
     from openpystruct_amd import tfd_fused as TF, train
     from openpystruct_amd.surrogates import ModelOnePassTransformerWithDiffusion
 
-    def run(layer_fwd):
+    def run(layer_fwd, layer_bwd=False):
         monkeypatch.setattr(TF, "LAYER_FWD", layer_fwd)
+        monkeypatch.setattr(TF, "LAYER_BWD", layer_bwd)
         torch.manual_seed(5)
         model = ModelOnePassTransformerWithDiffusion(6, 120, 100, dropout=p).to(DEV)
         params = list(model.parameters())
@@ -372,11 +373,12 @@ def test_one_launch_layer_forward_equals_the_eight_launch_form(monkeypatch, B, p
         TF.unpatch_model(model)
         return res
 
-    out1, g1 = run(True)
     out0, g0 = run(False)
-    assert _rel(out1, out0) < 1e-2
-    for n in g0:
-        assert _rel(g1[n], g0[n]) < 2e-2 or float(g0[n].norm()) < 1e-6, (n, _rel(g1[n], g0[n]))
+    for fwd_bwd in ((True, False), (True, True)):          # one-launch forward with the eight backward launches / with the one-launch backward
+        out1, g1 = run(*fwd_bwd)
+        assert _rel(out1, out0) < 1e-2
+        for n in g0:
+            assert _rel(g1[n], g0[n]) < 2e-2 or float(g0[n].norm()) < 1e-6, (fwd_bwd, n, _rel(g1[n], g0[n]))
 
 
 def test_tfd_training_with_the_fast_encoder_follows_the_framework_path(monkeypatch):
