@@ -214,9 +214,12 @@ size_t ops_stencil3_bn1_workspace_bytes(void);
  * `clip_grad_norm_(params, max_norm)` + `optim.Adam(lr, weight_decay)`, OpenPyStruct_PINN_MultiCase.py:696, :766-768) in
  * two launches.  grads are scaled by grad_scale first (1 / world_size after a sum all-reduce); `lr` and `step` are device
  * scalars (step is advanced by the call); max_norm <= 0 disables clipping; weight decay is torch's L2 form (g += wd p)
- * or, with decoupled_weight_decay, AdamW's (p *= 1 - lr wd).  params_bf16 (optional, n bfloat16 values): refreshed with the
+ * or, with decoupled_weight_decay & OPS_ADAM_DECOUPLED, AdamW's (p *= 1 - lr wd); decoupled_weight_decay & OPS_ADAM_ZERO_GRADS: `grads` is
+ * ZEROED after use (the next step's optimizer.zero_grad(); the pointer is then written through despite its const).  params_bf16 (optional, n bfloat16 values): refreshed with the
  * rounded new parameters, so that bf16 GEMMs of the next step need no per-step cast kernels.
  * `workspace`: ops_flat_adam_workspace_bytes() bytes. */
+#define OPS_ADAM_DECOUPLED 1
+#define OPS_ADAM_ZERO_GRADS 2
 int ops_flat_clip_adam_step_f32(long n, float* params, const float* grads, float* exp_avg, float* exp_avg_sq, const float* lr,
                                 int32_t* step, float max_norm, float grad_scale, float beta1, float beta2, float eps,
                                 float weight_decay, int decoupled_weight_decay, void* params_bf16, void* workspace, void* stream);
@@ -277,6 +280,9 @@ int ops_fused_bn_act_bwd(int B, int F, const void* dy, int act_is_bf16, const vo
  * tally; csrc/call_counter.hpp) (NULL: a fixed stream). */
 int ops_gather_rows_noise_f32(int B, long F, const float* X, const long long* idx, const float* sigma, unsigned long long seed,
                               unsigned long long* counter, void* out, int out_is_bf16, void* stream);
+/* ... and the batch's targets in the same launch: Yout [B, C] = Y[idx] (float32, untouched; Y may be NULL). */
+int ops_gather_rows_noise_targets_f32(int B, long F, const float* X, const long long* idx, const float* sigma, unsigned long long seed,
+                                      unsigned long long* counter, void* out, int out_is_bf16, const float* Y, int C, float* Yout, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Layer blocks of the PINN's residual MLP (PINN_MultiCase.py:395-541) for batches of up to 128 rows: ONE launch per
@@ -432,6 +438,11 @@ int ops_linear_wgrad_accumulate_group(int nprob, const ops_wgrad_problem* proble
  * (bfloat16) from g [B, 1 + Nc, d] and dcls [d] += column sums of g[:, 0, :] (float atomics; may be NULL). */
 int ops_diffusion_noise(long rows, int d, const float* x, const long long* t, const float* eps, const float* alpha_cumprod, float* xn32,
                         void* xn16, float* sa, float* sb, void* stream);
+/* ops_diffusion_noise with t (uniform in [0, T)) and eps (standard normal) drawn inside the launch from the counter-based stream of
+ * (seed, *counter) -- `counter` is only read; t_out [rows] / eps_out [rows, d]: optional copies of the draws. */
+int ops_diffusion_noise_draw(long rows, int d, int T, const float* x, const float* alpha_cumprod, unsigned long long seed,
+                             const unsigned long long* counter, float* xn32, void* xn16, float* sa, float* sb, long long* t_out, float* eps_out,
+                             void* stream);
 int ops_diffusion_combine_fwd(int B, int Nc, int d, const void* m, const float* xn32, const float* sa, const float* sb, const float* cls,
                               const float* pe, float* z, void* z16 /* optional bfloat16 copy of z */, void* stream);
 int ops_diffusion_combine_bwd(int B, int Nc, int d, const float* g /* float32, may be NULL */, const void* g16 /* bfloat16, may be NULL: the

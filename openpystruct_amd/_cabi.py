@@ -62,6 +62,8 @@ EXPORTS = (
     "ops_diffusion_combine_bwd",
     "ops_hbm_copy16",
     "ops_tfd_encoder_layer_fwd",
+    "ops_diffusion_noise_draw",
+    "ops_gather_rows_noise_targets_f32",
     "ops_tfd_encoder_layer_bwd",
 )
 
@@ -221,6 +223,8 @@ def load():
     lib.ops_fused_bn_act_fwd.argtypes = [it, it, vp, vp, vp, it, vp, vp, fl, fl, it, vp, vp, vp, fl, it, fl, ull, vp, vp, vp, vp, vp, vp, vp]
     lib.ops_gather_rows_noise_f32.restype = it
     lib.ops_gather_rows_noise_f32.argtypes = [it, lg, vp, vp, vp, ull, vp, vp, it, vp]
+    lib.ops_gather_rows_noise_targets_f32.restype = it
+    lib.ops_gather_rows_noise_targets_f32.argtypes = [it, lg, vp, vp, vp, ull, vp, vp, it, vp, it, vp, vp]
     lib.ops_fused_bn_act_bwd.restype = it
     lib.ops_fused_bn_act_bwd.argtypes = [it, it, vp, it, vp, vp, vp, vp, vp, fl, it, fl, vp, vp, vp, vp, vp]
     lib.ops_beam_solve_lane_per_beam_f64.restype = it
@@ -253,6 +257,8 @@ def load():
     lib.ops_act_dropout_fwd.argtypes = [lg, vp, vp, fl, fl, ull, vp, vp, vp]
     lib.ops_diffusion_noise.restype = it
     lib.ops_diffusion_noise.argtypes = [lg, it, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.ops_diffusion_noise_draw.restype = it
+    lib.ops_diffusion_noise_draw.argtypes = [lg, it, it, vp, vp, ull, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.ops_diffusion_combine_fwd.restype = it
     lib.ops_diffusion_combine_fwd.argtypes = [it, it, it, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.ops_diffusion_combine_bwd.restype = it

@@ -36,7 +36,8 @@ __device__ __forceinline__ float ip_noisy(float v, float sg, unsigned long long 
 template <bool VEC4>
 __global__ __launch_bounds__(256) void gather_noise_kernel(int B, long F, const float* __restrict__ X, const long long* __restrict__ idx,
                                                             const float* __restrict__ sigma, unsigned long long seed,
-                                                            unsigned long long* __restrict__ counter, void* __restrict__ out, int out_bf16) {
+                                                            unsigned long long* __restrict__ counter, void* __restrict__ out, int out_bf16,
+                                                            const float* __restrict__ Y, int C, float* __restrict__ Yout) {
   const long n = (long)B * F;
   const float sg = sigma ? *sigma : 0.0f;
   const unsigned long long call = counter ? *counter : 0ull;
@@ -64,22 +65,36 @@ __global__ __launch_bounds__(256) void gather_noise_kernel(int B, long F, const 
       else ((float*)out)[i] = v;
     }
   }
+  // the batch's targets Y[idx] (float32, no noise): the framework's index_select was a node of its own per step
+  if (Y)
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < (long)B * C; i += (long)gridDim.x * 256) {
+      const long b = i / C;
+      Yout[i] = Y[idx[b] * C + (i - b * C)];
+    }
   // one increment per launch, by the last workgroup to finish (call_counter.hpp)
   if (counter && threadIdx.x == 0) call_counter_done(counter, gridDim.x);
 }
 
 }  // namespace opsamd
 
+extern "C" int ops_gather_rows_noise_targets_f32(int B, long F, const float* X, const long long* idx, const float* sigma, unsigned long long seed,
+                                                 unsigned long long* counter, void* out, int out_is_bf16, const float* Y, int C, float* Yout,
+                                                 void* stream);
 extern "C" int ops_gather_rows_noise_f32(int B, long F, const float* X, const long long* idx, const float* sigma, unsigned long long seed,
                                          unsigned long long* counter, void* out, int out_is_bf16, void* stream) {
-  if (B < 1 || F < 1 || !X || !idx || !out) return OPS_AMD_ERR_INVALID_ARG;
+  return ops_gather_rows_noise_targets_f32(B, F, X, idx, sigma, seed, counter, out, out_is_bf16, nullptr, 0, nullptr, stream);
+}
+extern "C" int ops_gather_rows_noise_targets_f32(int B, long F, const float* X, const long long* idx, const float* sigma, unsigned long long seed,
+                                                 unsigned long long* counter, void* out, int out_is_bf16, const float* Y, int C, float* Yout,
+                                                 void* stream) {
+  if (B < 1 || F < 1 || !X || !idx || !out || (Y && (C < 1 || !Yout))) return OPS_AMD_ERR_INVALID_ARG;
   const long n = (long)B * F;
   const bool vec4 = (F % 4 == 0) && ((((uintptr_t)X | (uintptr_t)out) & 15) == 0);
   const long items = vec4 ? n / 4 : n;
   const unsigned grid = (unsigned)((items + 255) / 256 > 128 ? 128 : (items + 255) / 256);   // grid-stride; <= 128 reports to the call counter
   if (vec4)
-    hipLaunchKernelGGL(opsamd::gather_noise_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, B, F, X, idx, sigma, seed, counter, out, out_is_bf16);
+    hipLaunchKernelGGL(opsamd::gather_noise_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, B, F, X, idx, sigma, seed, counter, out, out_is_bf16, Y, C, Yout);
   else
-    hipLaunchKernelGGL(opsamd::gather_noise_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, B, F, X, idx, sigma, seed, counter, out, out_is_bf16);
+    hipLaunchKernelGGL(opsamd::gather_noise_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, B, F, X, idx, sigma, seed, counter, out, out_is_bf16, Y, C, Yout);
   return hipGetLastError() == hipSuccess ? OPS_AMD_OK : OPS_AMD_ERR_LAUNCH;
 }

@@ -713,6 +713,32 @@ __global__ __launch_bounds__(256) void diffusion_noise_kernel(long rows, int d, 
   }
 }
 
+// The same with the step indices and the noise DRAWN HERE (counter-based: csrc/dropout_stream.hpp keys of (seed, call), element index):
+// t[r] = floor(u T), eps = Box-Muller of two uniforms.  The framework generators cost the captured step four kernel nodes (randint,
+// randn, and the two fills of the graph-safe generator's seed / offset tensors before every replay), ~20 us; the reference draws from
+// an unseeded generator (TFD:452-456), so only the distributions are reproduced.  t_out / eps_out: optional copies of the draws.
+__global__ __launch_bounds__(256) void diffusion_noise_draw_kernel(long rows, int d, int T, const float* __restrict__ x, const float* __restrict__ acp,
+                                                                    unsigned long long seed, const unsigned long long* __restrict__ counter,
+                                                                    float* __restrict__ xn32, uint16_t* __restrict__ xn16, float* __restrict__ sa,
+                                                                    float* __restrict__ sb, long long* __restrict__ t_out, float* __restrict__ eps_out) {
+  const long n = rows * d;
+  const unsigned long long call = *counter;
+  const DropKey kt = drop_key(seed, call), ke = drop_key(seed ^ 0x5851F42D4C957F2Dull, call);
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256) {
+    const long r = e / d;
+    int t = (int)(drop_uniform(kt, (uint64_t)r) * (float)T);
+    t = t < T ? t : T - 1;
+    const float a = acp[t], s_a = sqrtf(a), s_b = sqrtf(1.0f - a);
+    const float u1 = 1.0f - drop_uniform(ke, 2 * (uint64_t)e), u2 = drop_uniform(ke, 2 * (uint64_t)e + 1);      // (0, 1], [0, 1)
+    const float ep = sqrtf(-2.0f * __logf(u1)) * __cosf(6.28318530717958647692f * u2);
+    const float v = s_a * x[e] + s_b * ep;
+    xn32[e] = v;
+    xn16[e] = sq_f2bf(v);
+    if (eps_out) eps_out[e] = ep;
+    if (e - r * d == 0) { sa[r] = s_a; sb[r] = s_b; if (t_out) t_out[r] = t; }
+  }
+}
+
 __global__ __launch_bounds__(256) void diffusion_combine_fwd_kernel(int B, int Nc, int d, const uint16_t* __restrict__ m, const float* __restrict__ xn32,
                                                                      const float* __restrict__ sa, const float* __restrict__ sb,
                                                                      const float* __restrict__ cls, const float* __restrict__ pe,
@@ -780,6 +806,17 @@ extern "C" int ops_diffusion_noise(long rows, int d, const float* x, const long 
   hipLaunchKernelGGL(opsamd::diffusion_noise_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, rows, d, x, t, eps, alpha_cumprod, xn32,
                      (uint16_t*)xn16, sa, sb);
   return sq_check("diffusion_noise_kernel");
+}
+
+extern "C" int ops_diffusion_noise_draw(long rows, int d, int T, const float* x, const float* alpha_cumprod, unsigned long long seed,
+                                        const unsigned long long* counter, float* xn32, void* xn16, float* sa, float* sb, long long* t_out,
+                                        float* eps_out, void* stream) {
+  if (rows < 1 || d < 1 || T < 1 || !x || !alpha_cumprod || !counter || !xn32 || !xn16 || !sa || !sb) return OPS_AMD_ERR_INVALID_ARG;
+  long nb = (rows * d + 255) / 256;
+  if (nb > 2048) nb = 2048;
+  hipLaunchKernelGGL(opsamd::diffusion_noise_draw_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, rows, d, T, x, alpha_cumprod, seed,
+                     counter, xn32, (uint16_t*)xn16, sa, sb, t_out, eps_out);
+  return sq_check("diffusion_noise_draw_kernel");
 }
 
 extern "C" int ops_diffusion_combine_fwd(int B, int Nc, int d, const void* m, const float* xn32, const float* sa, const float* sb, const float* cls,

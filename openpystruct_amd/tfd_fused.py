@@ -25,25 +25,33 @@ from . import _cabi
 
 ENABLED = os.environ.get("OPS_AMD_TFD_FAST_ENCODER", "1") == "1"      # A/B switch: 0 = nn.TransformerEncoder's own forward
 LAYER_FWD = os.environ.get("OPS_AMD_TFD_LAYER_FWD", "1") == "1"       # A/B switch: 0 = eight launches per layer forward instead of one
+DRAW = os.environ.get("OPS_AMD_TFD_DRAW", "1") == "1"                 # A/B switch: 0 = diffusion steps / noise from the framework generators
+KEEP_DRAWS = False                                                    # tests: every state keeps its last draws (`_State.draws`)
 LAYER_BWD = os.environ.get("OPS_AMD_TFD_LAYER_BWD", "1") == "1"       # A/B switch: 0 = eight launches per layer backward instead of one
 
 
 class _State:
     """The dropout stream of one encoder (its call counter must outlive a captured HIP graph) and how parameter gradients leave."""
 
-    def __init__(self, device, seed: int, direct_param_grads: bool = False):
+    def __init__(self, device, seed: int, direct_param_grads: bool = False, counter: Optional[torch.Tensor] = None):
         self.device = device
         self.direct = bool(direct_param_grads)      # LayerNorm gamma / beta gradients ASSIGNED into their .grad (a flat buffer zeroed per step)
         self.seed = int(seed) & 0x7FFFFFFFFFFFFFFF
-        self.counter = torch.zeros(1, dtype=torch.int64, device=device)     # advanced once per encoder pass (`advance`), read by every launch
+        # advanced once per encoder pass (`advance`), read by every launch -- or the CALLER's counter, which something else advances once
+        # per training step (train.py: the batch-assembly launch's call counter, csrc/call_counter.hpp: no add node in the captured step)
+        self.external = counter is not None and counter.device == torch.device(device) and counter.dtype == torch.int64
+        self.counter = counter if self.external else torch.zeros(1, dtype=torch.int64, device=device)
 
         self._zeros = {}
         self._zeros16 = {}
         self.src16 = None        # bf16 copy of the encoder's input, handed over by the model's front end (DiffusionCombine)
         self.last16 = None       # bf16 copy of the encoder's output rows [T, d], for the model's head
+        self.keep_draws = False  # tests: keep the front end's draws (t [B, Nc], eps [B, Nc, d]) of the last pass in `draws`
+        self.draws = None
 
     def advance(self) -> None:
-        self.counter.add_(1)
+        if not self.external:
+            self.counter.add_(1)
 
     def zeros(self, shape) -> torch.Tensor:
         """A persistent float32 zero tensor (the `residual` of a plain LayerNorm through the dropout + add + LayerNorm launch)."""
@@ -334,6 +342,17 @@ def enable_layer_tiles(enc: nn.TransformerEncoder):
     return ent
 
 
+def share_step_counter(enc: nn.Module, counter: Optional[torch.Tensor]) -> None:
+    """Use the caller's device counter (int64, element 0 advanced once per training step by something the step runs anyway) as the
+    dropout / noise streams' call counter instead of an own one advanced by an add node per pass.  None: back to the own counter."""
+    if counter is None:
+        enc.__dict__.pop("_ops_step_counter", None)
+    else:
+        enc._ops_step_counter = counter
+    if hasattr(enc, "_ops_dropout_state"):
+        enc._ops_dropout_state.clear()       # states are rebuilt on the next pass
+
+
 def refresh_layer_tiles(enc: nn.Module) -> None:
     ent = getattr(enc, "_ops_tile_entries", None)
     if ent is None:
@@ -463,23 +482,33 @@ class ClsRows(torch.autograd.Function):
 def model_forward(model: nn.Module, x: torch.Tensor, st: _State) -> torch.Tensor:
     """ModelOnePassTransformerWithDiffusion.forward (TFD:539-575) for the training step: diffusion arithmetic in two launches around
     the MLP's shadow products, the patched encoder, the head's LayerNorm / ReLU / dropout in two.  The random step indices and the
-    noise come from the framework's generators in the module's order (torch.randint, then torch.randn_like).  `st` is the
+    noise are drawn inside the first launch (DRAW; or by the framework's generators in the module's order: torch.randint, torch.randn_like).  `st` is the
     ENCODER's dropout state: its pass below advances the counter before the head's dropout (the only site out here with p > 0,
     TFD:573) draws its mask."""
     lib = _cabi.load()
     B, Nc, d = x.shape
     dm = model.diffusion
     x = x.contiguous()
-    t = torch.randint(0, dm.T, (B, Nc), device=x.device)
-    eps = torch.randn_like(x)
     rows = B * Nc
     xn32 = torch.empty((rows, d), dtype=torch.float32, device=x.device)
     xn16 = torch.empty((rows, d), dtype=torch.bfloat16, device=x.device)
     sa = torch.empty(rows, dtype=torch.float32, device=x.device)
     sb = torch.empty(rows, dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device):
-        _check(lib.ops_diffusion_noise(rows, d, x.data_ptr(), t.data_ptr(), eps.data_ptr(), dm._acp.data_ptr(), xn32.data_ptr(), xn16.data_ptr(),
-                                       sa.data_ptr(), sb.data_ptr(), _stream(x.device)), "ops_diffusion_noise")
+        if DRAW:       # step indices and noise drawn inside the launch (the encoder pass below advances the counter: fresh draws every step)
+            keep = st.keep_draws or KEEP_DRAWS
+            t = torch.empty(rows, dtype=torch.int64, device=x.device) if keep else None
+            eps = torch.empty((rows, d), dtype=torch.float32, device=x.device) if keep else None
+            _check(lib.ops_diffusion_noise_draw(rows, d, int(dm.T), x.data_ptr(), dm._acp.data_ptr(), st.seed + 7919 * 100, st.counter.data_ptr(),
+                                                xn32.data_ptr(), xn16.data_ptr(), sa.data_ptr(), sb.data_ptr(), t.data_ptr() if keep else None,
+                                                eps.data_ptr() if keep else None, _stream(x.device)), "ops_diffusion_noise_draw")
+            if keep:
+                st.draws = (t.view(B, Nc), eps.view(B, Nc, d))
+        else:
+            t = torch.randint(0, dm.T, (B, Nc), device=x.device)
+            eps = torch.randn_like(x)
+            _check(lib.ops_diffusion_noise(rows, d, x.data_ptr(), t.data_ptr(), eps.data_ptr(), dm._acp.data_ptr(), xn32.data_ptr(), xn16.data_ptr(),
+                                           sa.data_ptr(), sb.data_ptr(), _stream(x.device)), "ops_diffusion_noise")
     h = ActDropout.apply(dm.mlp[0](xn16), 0.0, 0.0, st, 101)                      # ReLU
     m = dm.mlp[2](h)
     z, z16 = DiffusionCombine.apply(m, xn32, sa, sb, model.cls_token, model.pos_encoder.pe, B, Nc, st)
@@ -522,7 +551,7 @@ def patch_model(model: nn.Module, seed: int, direct_param_grads: bool = False) -
             return cls.forward(self, x)
         st = state.get(x.device)
         if st is None:
-            st = state[x.device] = _State(x.device, seed, direct_param_grads)
+            st = state[x.device] = _State(x.device, seed, direct_param_grads, getattr(self.transformer_encoder, "_ops_step_counter", None))
         return model_forward(self, x, st)
 
     model.forward = types.MethodType(forward, model)
@@ -554,7 +583,7 @@ def patch_encoder(enc: nn.TransformerEncoder, seed: int, direct_param_grads: boo
             return nn.TransformerEncoder.forward(self, src, mask=mask, src_key_padding_mask=src_key_padding_mask, is_causal=is_causal)
         st = state.get(src.device)
         if st is None:
-            st = state[src.device] = _State(src.device, seed, direct_param_grads)
+            st = state[src.device] = _State(src.device, seed, direct_param_grads, getattr(self, "_ops_step_counter", None))
         return encoder_forward(self, src, st)
 
     enc.forward = types.MethodType(forward, enc)
@@ -568,5 +597,6 @@ def unpatch_encoder(enc: nn.Module) -> None:
         del enc.__dict__["forward"]
     enc.__dict__.pop("_ops_dropout_state", None)
     enc.__dict__.pop("_ops_tile_entries", None)
+    enc.__dict__.pop("_ops_step_counter", None)
     for layer in getattr(enc, "layers", []):
         layer.__dict__.pop("_ops_tiles", None)

@@ -140,6 +140,7 @@ class FlatClipAdam:
         self.ws = torch.empty(int(self._lib.ops_flat_adam_workspace_bytes()), dtype=torch.uint8, device=dev)
         self.betas, self.eps, self.weight_decay, self.max_norm, self.decoupled = betas, eps, weight_decay, max_norm, decoupled
         self.p_bf16: Optional[torch.Tensor] = None      # bfloat16 shadow of the parameters (enable_shadow)
+        self.zero_grads = False     # zero the gradient buffer inside the update launch (the next step's zero_grad(): one fill node less)
         self.repack = None          # ctypes array of MlpRepackEntry: padded bf16 weight copies the update refreshes too (pinn_fused.py)
 
     def enable_shadow(self) -> torch.Tensor:
@@ -157,7 +158,7 @@ class FlatClipAdam:
         dev = self.g.device
         args = (self.g.numel(), self.p.data_ptr(), self.g.data_ptr(), self.m.data_ptr(), self.v.data_ptr(), self.lr.data_ptr(),
                 self.step_count.data_ptr(), self.max_norm, grad_scale, self.betas[0], self.betas[1], self.eps, self.weight_decay,
-                int(self.decoupled), self.p_bf16.data_ptr() if self.p_bf16 is not None else None, self.ws.data_ptr())
+                int(self.decoupled) | (2 if self.zero_grads else 0), self.p_bf16.data_ptr() if self.p_bf16 is not None else None, self.ws.data_ptr())
         with torch.cuda.device(dev):
             s = torch.cuda.current_stream(dev).cuda_stream
             if self.repack is not None:
@@ -498,6 +499,7 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
         off += q.numel()
     g_stash, g_dst, patched = [], [], []
     fast_encoder = None
+    shared_counter = False
     if hasattr(model, "direct_param_grads"):   # fused tails (csrc/fused_bn.hip) write BatchNorm parameter gradients into `flat` themselves
         model.direct_param_grads = device.type == "cuda"
     torch.manual_seed(seed + 1 + rank)  # different noise / shuffles per rank
@@ -506,6 +508,7 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
         use_graph = on_gpu                     # the step is launch-bound (~150 tiny kernels): replay it as HIP graphs
     # under graph replay the learning rate must live in a device tensor, or the scheduler's updates would
     # never reach the captured optimiser step
+    prep_counter = torch.zeros(2, dtype=torch.int64, device=device) if on_gpu else None     # batch assembly: [calls, workgroups done]
     if on_gpu:      # clip + Adam over the flat buffers in two HIP launches; loss.alpha NOT included (PINN:696)
         opt = FlatClipAdam(params, flat, cfg.learning_rate, weight_decay=cfg.weight_decay, max_norm=1.0, decoupled=kind == "gnn")
         sched = None
@@ -516,6 +519,10 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
                 if tfd_fused.patch_model(model, seed=seed * 7919 + 211 + rank, direct_param_grads=True):
                     fast_encoder = model
                     opt.repack = getattr(model.transformer_encoder, "_ops_tile_entries", None)    # the Adam launch refreshes the layer kernels' weight tiles
+                    if os.environ.get("OPS_AMD_FUSED_PREP", "1") == "1":
+                        # the batch-assembly launch advances its call counter once per step: the dropout / noise streams read that one
+                        tfd_fused.share_step_counter(model.transformer_encoder, prep_counter)
+                        shared_counter = True
     else:
         opt = (torch.optim.AdamW if kind == "gnn" else torch.optim.Adam)(model.parameters(), lr=cfg.learning_rate,   # GNN:394
                                                                          weight_decay=cfg.weight_decay)
@@ -576,13 +583,18 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
             v_p, t_p = pin[1], pin[2]
         return fe_residual_loss(I_p, v_p, t_p, px, pE, pfix, pin[0], pwy)
 
+    unit_seed = torch.ones((), dtype=torch.float32, device=device) if on_gpu else None
+    if on_gpu and engine is None:
+        opt.zero_grads = True            # `flat` starts zeroed (allocation) and every update leaves it zeroed
+
     def fwd_bwd(Xb, Yb, noise_t, pin=None, prenoised=False):
         """Segment A: local gradients of the mean batch loss into `flat`.  `prenoised`: Xb already is the gathered, noisy
         (and, under autocast, bfloat16) batch written by `gather_noise` -- one launch outside the graph instead of six nodes."""
         if engine is not None:           # batch and targets sit in the engine's buffers (engine.gather); every gradient is assigned
             return engine.fwd_bwd(int(Yb.shape[0]))
         Xn = Xb if prenoised else Xb + torch.randn_like(Xb) * noise_t   # PINN:756
-        flat.zero_()                                                     # optimizer.zero_grad()
+        if not (on_gpu and opt.zero_grads):
+            flat.zero_()                                                 # optimizer.zero_grad() (GPU: the update launch zeroes `flat` behind itself)
         with torch.autocast(device_type=device.type, dtype=autocast_dtype, enabled=use_ac):
             preds = net(Xn)
             if on_gpu and _FUSED_LOSS:       # value + d/d preds in one HIP pass instead of ~80 framework kernel nodes
@@ -596,7 +608,10 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
         global _WGRAD_QUEUE
         _WGRAD_QUEUE = [] if (g_stash and _GROUP_WGRAD) else None       # split-row weight gradients: one grouped launch after backward
         try:
-            loss.backward()
+            if unit_seed is not None and loss.shape == unit_seed.shape and loss.dtype == unit_seed.dtype:
+                loss.backward(unit_seed)                                 # (the implicit ones_like() is a fill node per step)
+            else:
+                loss.backward()
             flush_wgrad_queue(device)
         finally:
             _WGRAD_QUEUE = None
@@ -643,26 +658,32 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
 
     # batch assembly in one launch (csrc/input_prep.hip): gather + noise + cast straight into the graph's input buffer
     _FUSED_PREP = on_gpu and os.environ.get("OPS_AMD_FUSED_PREP", "1") == "1"
-    prep_counter = torch.zeros(2, dtype=torch.int64, device=device) if on_gpu else None     # [calls, workgroups done]
     # bf16 batches only where the first module is a (shadow) Linear, which casts its operand to bf16 anyway
     prep_bf16 = bool(on_gpu and use_ac and autocast_dtype == torch.bfloat16 and patched and kind in ("pinn", "fnn", "gnn"))
 
     engine_seed = (seed * 7919 + 13 + rank) & 0x7FFFFFFFFFFFFFFF
 
-    def gather_noise(idx, out):
+    y_in_prep = bool(on_gpu and Ytr.dtype == torch.float32 and Ytr.is_contiguous())      # the targets travel in the same launch
+
+    def gather_noise(idx, out, out_y=None):
+        """Returns whether the targets were gathered too (out_y given and float32)."""
         if engine is not None:           # batch AND targets straight into the engine's layouts
             engine.gather(Xtr, Ytr, idx, s_noise, engine_seed)
-            return
+            return True
         lib = opt._lib
         Fdim = 1
         for d_ in Xtr.shape[1:]:
             Fdim *= int(d_)
+        with_y = out_y is not None and y_in_prep and out_y.dtype == torch.float32 and out_y.is_contiguous()
+        Cdim = int(Ytr[0].numel()) if with_y else 0
         with torch.cuda.device(device):
-            rc = lib.ops_gather_rows_noise_f32(int(idx.numel()), Fdim, Xtr.data_ptr(), idx.data_ptr(), s_noise.data_ptr(),
-                                               (seed * 7919 + 13 + rank) & 0x7FFFFFFFFFFFFFFF, prep_counter.data_ptr(), out.data_ptr(),
-                                               int(out.dtype == torch.bfloat16), torch.cuda.current_stream(device).cuda_stream)
+            rc = lib.ops_gather_rows_noise_targets_f32(int(idx.numel()), Fdim, Xtr.data_ptr(), idx.data_ptr(), s_noise.data_ptr(),
+                                                       (seed * 7919 + 13 + rank) & 0x7FFFFFFFFFFFFFFF, prep_counter.data_ptr(), out.data_ptr(),
+                                                       int(out.dtype == torch.bfloat16), Ytr.data_ptr() if with_y else None, Cdim,
+                                                       out_y.data_ptr() if with_y else None, torch.cuda.current_stream(device).cuda_stream)
         if rc != 0:
-            raise RuntimeError(f"ops_gather_rows_noise_f32 failed with code {rc}")
+            raise RuntimeError(f"ops_gather_rows_noise_targets_f32 failed with code {rc}")
+        return with_y
 
     graph = graph_b = vgraph = None
     graph_mode_one = False
@@ -775,11 +796,12 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
             # changes neither the batch statistics nor the mean loss, so it is folded into `order`
             idx = order[b * bs:(b + 1) * bs]
             if graph is not None and idx.numel() == bs:
+                got_y = False
                 if _FUSED_PREP or engine is not None:
-                    gather_noise(idx, sX)                                    # gather + noise (+ bf16 cast) in one launch
+                    got_y = gather_noise(idx, sX, sY)                        # gather + noise (+ bf16 cast) + targets in one launch
                 else:
                     torch.index_select(Xtr, 0, idx, out=sX)                  # gather straight into the graph's input buffers
-                if engine is None:
+                if engine is None and not got_y:
                     torch.index_select(Ytr, 0, idx, out=sY)
                 if sP is not None:
                     physics_inputs(idx, out=sP)
@@ -806,6 +828,8 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
             elif engine is not None:
                 train_step(None, Ytr[:idx.numel()], noise_t, idx)            # Yb only carries the row count here
             else:
+                if shared_counter:
+                    prep_counter[0:1].add_(1)                                # (no batch-assembly launch on this path: advance the streams here)
                 tot += train_step(Xtr[idx], Ytr[idx], noise_t, idx)
         if engine is not None:
             tot = engine.loss_sum.clone()

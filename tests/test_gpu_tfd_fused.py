@@ -228,11 +228,56 @@ def test_patched_encoder_with_thousands_of_rows_takes_the_split_row_gradient_pat
     TF.unpatch_encoder(enc)
 
 
-def test_patched_model_matches_the_module_with_the_same_noise(monkeypatch):
+def test_diffusion_noise_drawn_inside_the_launch():
+    """ops_diffusion_noise_draw: step indices uniform over [0, T), noise standard normal (moments, neighbour correlation), the arithmetic
+    of ops_diffusion_noise on the draws it reports, the same draws for the same counter value and fresh ones for the next."""
+    from openpystruct_amd import _cabi
+    lib = _cabi.load()
+    rows, d, T = 3584, 120, 1000
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(rows, d, generator=g).to(DEV)
+    acp = torch.cumprod(1.0 - torch.linspace(1e-4, 0.02, T), 0).to(DEV)
+    counter = torch.zeros(1, dtype=torch.int64, device=DEV)
+
+    def draw():
+        xn32, xn16 = torch.empty(rows, d, device=DEV), torch.empty(rows, d, dtype=torch.bfloat16, device=DEV)
+        sa, sb = torch.empty(rows, device=DEV), torch.empty(rows, device=DEV)
+        t, eps = torch.empty(rows, dtype=torch.int64, device=DEV), torch.empty(rows, d, device=DEV)
+        rc = lib.ops_diffusion_noise_draw(rows, d, T, x.data_ptr(), acp.data_ptr(), 12345, counter.data_ptr(), xn32.data_ptr(), xn16.data_ptr(),
+                                          sa.data_ptr(), sb.data_ptr(), t.data_ptr(), eps.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        assert rc == 0
+        torch.cuda.synchronize()
+        return xn32, xn16, sa, sb, t, eps
+
+    xn32, xn16, sa, sb, t, eps = draw()
+    assert int(t.min()) >= 0 and int(t.max()) < T
+    hist = torch.bincount(t // 100, minlength=10).double().cpu().numpy()
+    assert np.all(np.abs(hist - rows / 10) < 5 * np.sqrt(rows / 10 * 0.9)), hist
+    e = eps.double().flatten()
+    n = e.numel()
+    assert abs(float(e.mean())) < 5 / np.sqrt(n) and abs(float(e.var()) - 1.0) < 5 * np.sqrt(2.0 / n)
+    assert abs(float((e ** 3).mean())) < 5 * np.sqrt(15.0 / n) and abs(float((e ** 4).mean()) - 3.0) < 5 * np.sqrt(96.0 / n)
+    assert abs(float((e[1:] * e[:-1]).mean())) < 5 / np.sqrt(n) and abs(float((eps[1:] * eps[:-1]).double().mean())) < 5 / np.sqrt(n)
+    torch.testing.assert_close(sa, acp[t].sqrt(), rtol=1e-6, atol=0)
+    torch.testing.assert_close(sb, (1 - acp[t]).sqrt(), rtol=1e-5, atol=1e-7)
+    torch.testing.assert_close(xn32, sa[:, None] * x + sb[:, None] * eps, rtol=1e-5, atol=1e-6)
+    assert torch.equal(xn16, xn32.to(torch.bfloat16))
+    again = draw()
+    assert torch.equal(again[4], t) and torch.equal(again[5], eps)                  # same (seed, counter): same draws
+    counter += 1
+    nxt = draw()
+    assert float((nxt[4] == t).float().mean()) < 0.01 and abs(float((nxt[5] * eps).mean())) < 5 / np.sqrt(n)
+
+
+@pytest.mark.parametrize("draw", [True, False])
+def test_patched_model_matches_the_module_with_the_same_noise(monkeypatch, draw):
     """ModelOnePassTransformerWithDiffusion through patch_model (fused diffusion front end, encoder blocks, fused head) vs its own
-    forward, both under bf16 autocast, dropout 0, and with torch.randint / torch.randn_like replaced by a replayable stream."""
+    forward, both under bf16 autocast, dropout 0, and with torch.randint / torch.randn_like replaced by a replayable stream:
+    draw = True: the step indices / noise the front-end launch drew itself (kept and replayed to the module); False: framework draws."""
     from openpystruct_amd import tfd_fused as TF, train
     from openpystruct_amd.surrogates import ModelOnePassTransformerWithDiffusion
+    monkeypatch.setattr(TF, "DRAW", draw)
+    monkeypatch.setattr(TF, "KEEP_DRAWS", True)
     torch.manual_seed(5)
     model = ModelOnePassTransformerWithDiffusion(6, 120, 100, dropout=0.0).to(DEV)
     ref = copy.deepcopy(model)
@@ -272,6 +317,10 @@ def test_patched_model_matches_the_module_with_the_same_noise(monkeypatch):
     live = [(dd, ss) for dd, ss in zip(dst, stash) if ss is not None]
     if live:
         torch._foreach_copy_([a for a, _ in live], [b for _, b in live])
+    if draw:
+        t_k, e_k = model.transformer_encoder._ops_dropout_state[x.device].draws
+        assert int(t_k.min()) >= 0 and int(t_k.max()) < model.diffusion.T and abs(float(e_k.mean())) < 0.01 and abs(float(e_k.std()) - 1.0) < 0.01
+        draws["t"], draws["e"] = t_k.clone(), e_k.clone()
     with torch.autocast("cuda", dtype=torch.bfloat16):
         outr = ref(x)
         (outr.float() * w).sum().backward()
