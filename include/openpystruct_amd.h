@@ -234,6 +234,10 @@ size_t ops_flat_adam_workspace_bytes(void);
 int ops_surrogate_loss_grad_f32(int B, int C, int nI, int nD, const void* preds, int preds_is_bf16, const float* targets,
                                 const float* alpha, float alpha0, const float* min_constraint, const float* max_constraint,
                                 float box_weight, float rel_penalty, float* loss, void* grad, void* workspace, void* stream);
+/* ... that also ADDS the loss value to *loss_sum (a training loop's per-epoch running sum; may be NULL). */
+int ops_surrogate_loss_grad_sum_f32(int B, int C, int nI, int nD, const void* preds, int preds_is_bf16, const float* targets,
+                                    const float* alpha, float alpha0, const float* min_constraint, const float* max_constraint,
+                                    float box_weight, float rel_penalty, float* loss, float* loss_sum, void* grad, void* workspace, void* stream);
 size_t ops_surrogate_loss_workspace_bytes(void);
 
 /* MEASURED ALTERNATIVE to ops_beam_solve_batched_f64 (not used by the product): one lane per beam, sequential block-Thomas
@@ -427,6 +431,7 @@ int ops_linear_wgrad_accumulate(int T, int N, int K, const void* dY, const void*
 typedef struct ops_wgrad_problem {
   int32_t T, N, K;
   const void* dY; const void* X; float* dW; float* dbias;
+  int32_t ldy, ldx;                                   /* row strides of dY / X in elements; 0: N / K (contiguous rows) */
 } ops_wgrad_problem;
 #define OPS_WGRAD_MAX_GROUP 16
 int ops_linear_wgrad_accumulate_group(int nprob, const ops_wgrad_problem* problems, void* stream);

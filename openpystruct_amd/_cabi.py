@@ -63,6 +63,7 @@ EXPORTS = (
     "ops_hbm_copy16",
     "ops_tfd_encoder_layer_fwd",
     "ops_diffusion_noise_draw",
+    "ops_surrogate_loss_grad_sum_f32",
     "ops_gather_rows_noise_targets_f32",
     "ops_tfd_encoder_layer_bwd",
 )
@@ -117,7 +118,7 @@ class MlpWgradProblem(ctypes.Structure):
 class WgradProblem(ctypes.Structure):
     """Mirror of `ops_wgrad_problem`."""
     _fields_ = [("T", ctypes.c_int32), ("N", ctypes.c_int32), ("K", ctypes.c_int32), ("dY", ctypes.c_void_p), ("X", ctypes.c_void_p),
-                ("dW", ctypes.c_void_p), ("dbias", ctypes.c_void_p)]
+                ("dW", ctypes.c_void_p), ("dbias", ctypes.c_void_p), ("ldy", ctypes.c_int32), ("ldx", ctypes.c_int32)]
 
 
 class TfdLayerArgs(ctypes.Structure):
@@ -217,6 +218,8 @@ def load():
     lib.ops_flat_adam_workspace_bytes.restype = ctypes.c_size_t
     lib.ops_surrogate_loss_grad_f32.restype = it
     lib.ops_surrogate_loss_grad_f32.argtypes = [it, it, it, it, vp, it, vp, vp, fl, vp, vp, fl, fl, vp, vp, vp, vp]
+    lib.ops_surrogate_loss_grad_sum_f32.restype = it
+    lib.ops_surrogate_loss_grad_sum_f32.argtypes = [it, it, it, it, vp, it, vp, vp, fl, vp, vp, fl, fl, vp, vp, vp, vp, vp]
     lib.ops_surrogate_loss_workspace_bytes.restype = ctypes.c_size_t
     ull = ctypes.c_ulonglong
     lib.ops_fused_bn_act_fwd.restype = it

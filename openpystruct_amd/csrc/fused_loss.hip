@@ -73,7 +73,7 @@ __global__ __launch_bounds__(FL_THREADS) void fused_loss_kernel(int B, int C, in
 }
 
 __global__ void fused_loss_finish_kernel(int B, int C, int nI, int nD, const double* __restrict__ part, int G, const float* __restrict__ alpha_p,
-                                         float alpha0, float w, float penalty, float* __restrict__ loss) {
+                                         float alpha0, float w, float penalty, float* __restrict__ loss, float* __restrict__ loss_sum) {
   double t[5] = {0, 0, 0, 0, 0};      // one wave: lane g sums partials g, g + 64, ...; butterfly over the lanes
   for (int g = threadIdx.x; g < G; g += 64)
     for (int k = 0; k < 5; ++k) t[k] += part[g * 5 + k];
@@ -88,6 +88,7 @@ __global__ void fused_loss_finish_kernel(int B, int C, int nI, int nD, const dou
   if (nR > 0) v += (double)penalty * t[4] / ((double)B * nR);
   const double da = alpha0 == alpha0 ? (double)alpha0 - (double)alpha_p[0] : 0.0;      // NaN alpha0: no such term
   loss[0] = (float)(v + da * da);
+  if (loss_sum) loss_sum[0] += loss[0];      // the epoch's running sum (one thread, one launch at a time: deterministic)
 }
 
 }  // namespace opsamd
@@ -96,9 +97,20 @@ using namespace opsamd;
 
 extern "C" size_t ops_surrogate_loss_workspace_bytes(void) { return (size_t)FL_MAXG * 5 * sizeof(double); }
 
+extern "C" int ops_surrogate_loss_grad_sum_f32(int B, int C, int nI, int nD, const void* preds, int preds_is_bf16, const float* targets,
+                                               const float* alpha, float alpha0, const float* min_constraint, const float* max_constraint,
+                                               float box_weight, float rel_penalty, float* loss, float* loss_sum, void* grad, void* workspace,
+                                               void* stream);
 extern "C" int ops_surrogate_loss_grad_f32(int B, int C, int nI, int nD, const void* preds, int preds_is_bf16, const float* targets,
                                            const float* alpha, float alpha0, const float* min_constraint, const float* max_constraint,
                                            float box_weight, float rel_penalty, float* loss, void* grad, void* workspace, void* stream) {
+  return ops_surrogate_loss_grad_sum_f32(B, C, nI, nD, preds, preds_is_bf16, targets, alpha, alpha0, min_constraint, max_constraint, box_weight,
+                                         rel_penalty, loss, nullptr, grad, workspace, stream);
+}
+extern "C" int ops_surrogate_loss_grad_sum_f32(int B, int C, int nI, int nD, const void* preds, int preds_is_bf16, const float* targets,
+                                               const float* alpha, float alpha0, const float* min_constraint, const float* max_constraint,
+                                               float box_weight, float rel_penalty, float* loss, float* loss_sum, void* grad, void* workspace,
+                                               void* stream) {
   if (B < 1 || C < 1 || nI < 1 || nD < 0 || nI + nD > C || !preds || !targets || !alpha || !loss || !grad || !workspace)
     return OPS_AMD_ERR_INVALID_ARG;
   const long n = (long)B * C;
@@ -108,6 +120,6 @@ extern "C" int ops_surrogate_loss_grad_f32(int B, int C, int nI, int nD, const v
   hipLaunchKernelGGL(fused_loss_kernel, dim3(G), dim3(FL_THREADS), 0, s, B, C, nI, nD, preds, preds_is_bf16, targets, alpha, min_constraint,
                      max_constraint, box_weight, rel_penalty, 1e-8f, grad, (double*)workspace);
   hipLaunchKernelGGL(fused_loss_finish_kernel, dim3(1), dim3(64), 0, s, B, C, nI, nD, (const double*)workspace, G, alpha, alpha0, box_weight,
-                     rel_penalty, loss);
+                     rel_penalty, loss, loss_sum);
   return hipGetLastError() == hipSuccess ? OPS_AMD_OK : OPS_AMD_ERR_LAUNCH;
 }

@@ -555,18 +555,19 @@ constexpr int WG_ROWS = 256;      // rows of T per workgroup: the float atomics 
 constexpr int WG_SLAB = 32;       // rows per LDS slab = one MFMA reduction step
 
 // one 32-row slab of an operand: row lr, 8 columns from c0 + lc -- one 16-byte load when the matrix allows it
-__device__ __forceinline__ uint4 wg_load8(const uint16_t* __restrict__ M, int T, int C, int t, int c, bool vec) {
+__device__ __forceinline__ uint4 wg_load8(const uint16_t* __restrict__ M, int T, int C, int ld, int t, int c, bool vec) {
   uint4 r = uint4{0u, 0u, 0u, 0u};
   if (t >= T || c >= C) return r;
-  if (vec && c + 8 <= C) return *(const uint4*)(M + (long)t * C + c);
+  if (vec && c + 8 <= C) return *(const uint4*)(M + (long)t * ld + c);
   uint16_t v[8];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) v[j] = c + j < C ? M[(long)t * C + c + j] : (uint16_t)0;
+  for (int j = 0; j < 8; ++j) v[j] = c + j < C ? M[(long)t * ld + c + j] : (uint16_t)0;
   return *(const uint4*)v;
 }
 
 __device__ __forceinline__ void wgrad_tn_body(int T, int N, int K, const uint16_t* __restrict__ dY, const uint16_t* __restrict__ X,
-                                              float* __restrict__ dW, float* __restrict__ dbias, int bx, int by, int bz) {
+                                              float* __restrict__ dW, float* __restrict__ dbias, int bx, int by, int bz, int ldy = 0, int ldx = 0) {
+  ldy = ldy > 0 ? ldy : N; ldx = ldx > 0 ? ldx : K;                    // row strides (elements) of dY / X: a strided row view needs no copy
   // slabs TRANSPOSED in LDS, [column][t] with 72-byte rows: the loader scatters its 8 columns (two-byte writes), a fragment -- 8
   // consecutive t of one column -- is then two 8-byte reads (row-major slabs needed 8 two-byte reads per fragment: 32 LDS reads per
   // thread and slab against 8 + 16 writes here)
@@ -575,7 +576,7 @@ __device__ __forceinline__ void wgrad_tn_body(int T, int N, int K, const uint16_
   const int n0 = bx * 64, k0 = by * 64, t0 = bz * WG_ROWS, t1 = min(t0 + WG_ROWS, T);
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int wn = (wave >> 1) * 32, wk = (wave & 1) * 32;               // this wave's 32 x 32 quarter of the tile
-  const bool va = (N & 7) == 0 && ((uintptr_t)dY & 15) == 0, vb = (K & 7) == 0 && ((uintptr_t)X & 15) == 0;
+  const bool va = (ldy & 7) == 0 && ((uintptr_t)dY & 15) == 0, vb = (ldx & 7) == 0 && ((uintptr_t)X & 15) == 0;
   wg_f32x4 acc[2][2];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -586,7 +587,7 @@ __device__ __forceinline__ void wgrad_tn_body(int T, int N, int K, const uint16_
   float csum[8];                                                       // this loader's 8 columns, summed over its rows
 #pragma unroll
   for (int j = 0; j < 8; ++j) csum[j] = 0.0f;
-  uint4 ra = wg_load8(dY, t1, N, t0 + lr, n0 + lc, va), rb = wg_load8(X, t1, K, t0 + lr, k0 + lc, vb);
+  uint4 ra = wg_load8(dY, t1, N, ldy, t0 + lr, n0 + lc, va), rb = wg_load8(X, t1, K, ldx, t0 + lr, k0 + lc, vb);
   for (int ts = t0; ts < t1; ts += WG_SLAB) {
     __syncthreads();                                                   // the previous slab's fragments have been read
     {
@@ -602,8 +603,8 @@ __device__ __forceinline__ void wgrad_tn_body(int T, int N, int K, const uint16_
     }
     __syncthreads();
     if (ts + WG_SLAB < t1) {                                           // next slab's loads fly while this one multiplies
-      ra = wg_load8(dY, t1, N, ts + WG_SLAB + lr, n0 + lc, va);
-      rb = wg_load8(X, t1, K, ts + WG_SLAB + lr, k0 + lc, vb);
+      ra = wg_load8(dY, t1, N, ldy, ts + WG_SLAB + lr, n0 + lc, va);
+      rb = wg_load8(X, t1, K, ldx, ts + WG_SLAB + lr, k0 + lc, vb);
     }
     // fragments: lane (o = lane & 15, tg = lane >> 4) holds rows 8 tg .. 8 tg + 7 of column o
     wg_bf16x8 fa[2], fb[2];
@@ -661,7 +662,7 @@ __global__ __launch_bounds__(256) void wgrad_tn_group_kernel(const WgGroup g) {
   while (pi + 1 < g.nprob && (int)blockIdx.x >= g.wg0[pi + 1]) ++pi;
   const ops_wgrad_problem pr = g.p[pi];
   const int id = (int)blockIdx.x - g.wg0[pi], tn = (pr.N + 63) / 64, tk = (pr.K + 63) / 64;
-  wgrad_tn_body(pr.T, pr.N, pr.K, (const uint16_t*)pr.dY, (const uint16_t*)pr.X, pr.dW, pr.dbias, id % tn, (id / tn) % tk, id / (tn * tk));
+  wgrad_tn_body(pr.T, pr.N, pr.K, (const uint16_t*)pr.dY, (const uint16_t*)pr.X, pr.dW, pr.dbias, id % tn, (id / tn) % tk, id / (tn * tk), pr.ldy, pr.ldx);
 }
 
 }  // namespace opsamd
@@ -680,7 +681,7 @@ extern "C" int ops_linear_wgrad_accumulate_group(int nprob, const ops_wgrad_prob
   int tot = 0;
   for (int i = 0; i < nprob; ++i) {
     const ops_wgrad_problem& p = problems[i];
-    if (p.T < 1 || p.N < 1 || p.K < 1 || !p.dY || !p.X || !p.dW) return OPS_AMD_ERR_INVALID_ARG;
+    if (p.T < 1 || p.N < 1 || p.K < 1 || !p.dY || !p.X || !p.dW || (p.ldy && p.ldy < p.N) || (p.ldx && p.ldx < p.K)) return OPS_AMD_ERR_INVALID_ARG;
     g.p[i] = p;
     g.wg0[i] = tot;
     tot += ((p.N + 63) / 64) * ((p.K + 63) / 64) * ((p.T + opsamd::WG_ROWS - 1) / opsamd::WG_ROWS);

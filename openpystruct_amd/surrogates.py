@@ -340,7 +340,7 @@ class _FusedLoss(torch.autograd.Function):
     """csrc/fused_loss.hip: loss value and d loss / d preds in one pass; backward only scales the stored gradient."""
 
     @staticmethod
-    def forward(ctx, preds, targets, alpha, alpha0, minc, maxc, box_w, rel_pen, nI, nD, unit_grad=False):
+    def forward(ctx, preds, targets, alpha, alpha0, minc, maxc, box_w, rel_pen, nI, nD, unit_grad=False, acc=None):
         from . import _cabi
         lib = _cabi.load()
         if preds.dtype not in (torch.float32, torch.bfloat16):
@@ -353,12 +353,13 @@ class _FusedLoss(torch.autograd.Function):
         loss = torch.empty((), dtype=torch.float32, device=dev)
         ws = torch.empty(int(lib.ops_surrogate_loss_workspace_bytes()), dtype=torch.uint8, device=dev)
         with torch.cuda.device(dev):
-            rc = lib.ops_surrogate_loss_grad_f32(B, C, nI, nD, preds.data_ptr(), int(preds.dtype == torch.bfloat16), targets.data_ptr(),
-                                                 alpha.data_ptr(), float(alpha0), minc.data_ptr() if minc is not None else None,
-                                                 maxc.data_ptr() if maxc is not None else None, float(box_w), float(rel_pen),
-                                                 loss.data_ptr(), grad.data_ptr(), ws.data_ptr(), torch.cuda.current_stream(dev).cuda_stream)
+            rc = lib.ops_surrogate_loss_grad_sum_f32(B, C, nI, nD, preds.data_ptr(), int(preds.dtype == torch.bfloat16), targets.data_ptr(),
+                                                     alpha.data_ptr(), float(alpha0), minc.data_ptr() if minc is not None else None,
+                                                     maxc.data_ptr() if maxc is not None else None, float(box_w), float(rel_pen),
+                                                     loss.data_ptr(), acc.data_ptr() if acc is not None else None, grad.data_ptr(), ws.data_ptr(),
+                                                     torch.cuda.current_stream(dev).cuda_stream)
         if rc != _cabi.OK:
-            raise RuntimeError(f"ops_surrogate_loss_grad_f32 failed with code {rc}")
+            raise RuntimeError(f"ops_surrogate_loss_grad_sum_f32 failed with code {rc}")
         ctx.save_for_backward(grad)
         ctx.unit_grad = bool(unit_grad)
         return loss
@@ -367,16 +368,18 @@ class _FusedLoss(torch.autograd.Function):
     def backward(ctx, go):
         (grad,) = ctx.saved_tensors
         if ctx.unit_grad:        # the caller adds this loss with weight 1 to what it differentiates: d(total)/d(loss) = 1, no scaling pass
-            return (grad,) + (None,) * 10
-        return (grad * go.to(grad.dtype),) + (None,) * 10
+            return (grad,) + (None,) * 11
+        return (grad * go.to(grad.dtype),) + (None,) * 11
 
 
-def fused_loss(crit: nn.Module, preds: torch.Tensor, targets: torch.Tensor, alpha0: float = None, unit_grad: bool = False) -> torch.Tensor:
+def fused_loss(crit: nn.Module, preds: torch.Tensor, targets: torch.Tensor, alpha0: float = None, unit_grad: bool = False,
+               acc: torch.Tensor = None) -> torch.Tensor:
     """`crit(preds.float(), targets)` (+ `(alpha0 - alpha)^2` when alpha0 is given) for a CompositeLoss or a
     TrainableL1L2Loss through the fused HIP kernel: ~80 framework kernel nodes per training step become 3.  GPU tensors
     only; the gradient w.r.t. the loss's own `alpha` is not produced (no optimiser ever holds it: PINN:696, TFD:678).
     `unit_grad`: the caller promises that the value enters the differentiated total with weight one (the training loops: loss
-    [+ weight * physics term]); the backward pass then hands out the stored gradient as it is (two nodes fewer per step)."""
+    [+ weight * physics term]); the backward pass then hands out the stored gradient as it is (two nodes fewer per step).
+    `acc`: a float32 device scalar the launch ADDS the value to (the training loop's per-epoch sum: no add node per step)."""
     if isinstance(crit, CompositeLoss):
         l1l2, nI, nD, rel = crit.l1l2_loss, crit.nelem, crit.deflection_dim, crit.penalty_pinn
     else:
@@ -390,7 +393,7 @@ def fused_loss(crit: nn.Module, preds: torch.Tensor, targets: torch.Tensor, alph
 
     a = l1l2.alpha.detach()
     return _FusedLoss.apply(preds, targets.to(torch.float32), a, float("nan") if alpha0 is None else float(alpha0),   # NaN: no alpha term
-                            scalar(l1l2.min_constraint), scalar(l1l2.max_constraint), l1l2.penalty_weight, rel, nI, nD, unit_grad)
+                            scalar(l1l2.min_constraint), scalar(l1l2.max_constraint), l1l2.penalty_weight, rel, nI, nD, unit_grad, acc)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -475,7 +475,9 @@ class ClsRows(torch.autograd.Function):
         B, S, st = ctx.cfg
         d = g.shape[1]
         full = st.zeros16((B * S, d))
-        full.view(B, S, d)[:, 0, :].copy_(g)
+        rows = full.view(B, S, d)[:, 0, :]
+        if not (g.data_ptr() == rows.data_ptr() and g.stride() == rows.stride() and g.dtype == rows.dtype):   # (the product wrote them there itself)
+            rows.copy_(g)
         return full, None, None, None
 
 
@@ -515,7 +517,10 @@ def model_forward(model: nn.Module, x: torch.Tensor, st: _State) -> torch.Tensor
     st.src16, st.last16 = z16, None                                                # handed to / by the patched encoder pass below
     z = model.transformer_encoder(z)
     if st.last16 is not None and model.transformer_encoder.norm is None:
+        from . import train
+        train.set_next_input_grad_dest(st.zeros16((B * (Nc + 1), d)).view(B, Nc + 1, d)[:, 0, :])   # fc1's input gradient lands in the [CLS] rows
         a = model.fc1(ClsRows.apply(st.last16, B, Nc + 1, st))                     # bf16 [B, hidden], read in place (no slice copy / cast)
+        train.set_next_input_grad_dest(None)
         st.last16 = None
     else:
         a = model.fc1(z[:, 0, :])

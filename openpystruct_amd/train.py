@@ -222,6 +222,45 @@ class FnoConfig:
     fno_width: int = 128
 
 
+_DEBUG_NAN = os.environ.get("OPS_AMD_DEBUG_NAN", "0") == "1"
+
+
+def clear_blas_workspaces() -> None:
+    """Drop the framework's cached BLAS workspaces at the END of a training run (the caller has synchronised).  One that was allocated
+    while a HIP graph was being captured lives in that graph's private pool but stays cached per (handle, stream): a later run whose
+    side stream gets the same id would hand the freed memory to its GEMMs as scratch space.  (Calling this at the START of a run as
+    well made things worse -- 4 NaN runs of 12 against 0 of 12, profiles/r03_notes.md 8 -- so it is not.)"""
+    clear = getattr(torch._C, "_cuda_clearCublasWorkspaces", None)
+    if clear is not None:
+        clear()
+
+
+def _debug_nan(model, opt, flat, s_loss, epoch, b, sX, sY):
+    """Diagnostics (OPS_AMD_DEBUG_NAN=1; run with OPS_AMD_ADAM_ZERO=0 to keep the gradients): first step with a non-finite value."""
+    torch.cuda.synchronize()
+    bad_p = [n for n, q in model.named_parameters() if not bool(torch.isfinite(q).all())]
+    bad_g = [n for n, q in model.named_parameters() if q.grad is not None and not bool(torch.isfinite(q.grad).all())]
+    if bad_p or bad_g or not bool(torch.isfinite(s_loss)):
+        print("DEBUG_NAN epoch", epoch, "batch", b, "loss", float(s_loss), "inputs finite", bool(torch.isfinite(sX.float()).all()), bool(torch.isfinite(sY).all()),
+              "gradnorm", float(flat.norm()), "\n  bad grads", bad_g[:12], "\n  bad params", bad_p[:6], flush=True)
+        for n, q in model.named_parameters():
+            if n in bad_g:
+                idx = (~torch.isfinite(q.grad)).nonzero().flatten()[:40].tolist()
+                print("   ", n, tuple(q.shape), "non-finite at", idx, "values", q.grad.flatten()[idx[:6]].tolist(), flush=True)
+        raise RuntimeError("non-finite value in the training step")
+
+
+_NEXT_GX_DEST = None      # see set_next_input_grad_dest
+
+
+def set_next_input_grad_dest(dest: Optional[torch.Tensor]) -> None:
+    """The NEXT shadow product's backward pass writes its input gradient straight into `dest` (a [rows, K] bfloat16 tensor, rows may be
+    strided) instead of a fresh tensor: the Transformer-Diffusion head hands the [CLS] rows of a persistent zero tensor, and the row
+    scatter that followed the product disappears from the step."""
+    global _NEXT_GX_DEST
+    _NEXT_GX_DEST = dest if os.environ.get("OPS_AMD_GX_DEST", "1") == "1" else None
+
+
 class _ShadowLinearFn(torch.autograd.Function):
     """y = x W^T + b with W, b taken from the optimiser's bfloat16 shadow; the weight / bias gradients are not returned to
     autograd but left (in bfloat16) in `stash`, from where ONE multi-tensor copy moves all of them into the flat float32
@@ -238,6 +277,8 @@ class _ShadowLinearFn(torch.autograd.Function):
         y = torch.addmm(b_sh, x2, w_sh.t()) if b_sh is not None else x2 @ w_sh.t()
         ctx.save_for_backward(x2, w_sh)
         ctx.stash, ctx.iw, ctx.ib, ctx.xshape, ctx.xdtype, ctx.w_grad, ctx.b_grad = stash, iw, ib, x.shape, x.dtype, w_grad, b_grad
+        global _NEXT_GX_DEST
+        ctx.gx_dest, _NEXT_GX_DEST = _NEXT_GX_DEST, None
         return y.reshape(*x.shape[:-1], w_sh.shape[0])
 
     @staticmethod
@@ -251,7 +292,9 @@ class _ShadowLinearFn(torch.autograd.Function):
             # gradient is another reduction pass (11 us); the split-row kernel of csrc/seq_block.hip adds partial tiles -- and the
             # column sums of the slabs it reads anyway -- into the float32 gradients itself
             from . import _cabi
-            g2, x2c = g2.contiguous(), x2.contiguous()
+            g2 = g2.contiguous()
+            rows_ok = os.environ.get("OPS_AMD_WGRAD_ROWS", "1") == "1" and _WGRAD_QUEUE is not None and x2.dim() == 2 and x2.stride(1) == 1 and x2.stride(0) >= x2.shape[1]
+            x2c = x2 if rows_ok else x2.contiguous()        # the grouped launch takes row strides (the head reads the [CLS] rows in place)
             fused_bias = ctx.ib is not None and ctx.b_grad is not None
             if _WGRAD_QUEUE is not None:
                 # deferred: the training step launches every queued product at once after backward (flush_wgrad_queue)
@@ -271,9 +314,13 @@ class _ShadowLinearFn(torch.autograd.Function):
                 ctx.stash[ctx.ib] = g2.sum(0)
         gx = None
         if ctx.needs_input_grad[0]:
-            gx = (g2 @ w_sh).reshape(ctx.xshape)
-            if gx.dtype != ctx.xdtype:
-                gx = gx.to(ctx.xdtype)
+            dest = ctx.gx_dest
+            if dest is not None and dest.dtype == torch.bfloat16 and tuple(dest.shape) == (g2.shape[0], w_sh.shape[1]) and ctx.xdtype == torch.bfloat16:
+                gx = torch.mm(g2, w_sh, out=dest)
+            else:
+                gx = (g2 @ w_sh).reshape(ctx.xshape)
+                if gx.dtype != ctx.xdtype:
+                    gx = gx.to(ctx.xdtype)
         return gx, None, None, None, None, None, None, None, None
 
 
@@ -329,6 +376,7 @@ def flush_wgrad_queue(device) -> None:
             for e, (g2, x2, wg, bg) in zip(arr, part):
                 e.T, e.N, e.K = x2.shape[0], g2.shape[1], x2.shape[1]
                 e.dY, e.X, e.dW, e.dbias = g2.data_ptr(), x2.data_ptr(), wg.data_ptr(), (bg.data_ptr() if bg is not None else None)
+                e.ldy, e.ldx = g2.stride(0), x2.stride(0)                # (row views with unit column stride travel without a copy)
             rc = lib.ops_linear_wgrad_accumulate_group(len(part), arr, s)
             if rc != 0:
                 raise RuntimeError(f"ops_linear_wgrad_accumulate_group failed with code {rc}")
@@ -505,7 +553,7 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
     torch.manual_seed(seed + 1 + rank)  # different noise / shuffles per rank
     on_gpu = device.type == "cuda"
     if use_graph is None:
-        use_graph = on_gpu                     # the step is launch-bound (~150 tiny kernels): replay it as HIP graphs
+        use_graph = on_gpu and os.environ.get("OPS_AMD_GRAPH", "1") == "1"    # the step is launch-bound (~150 tiny kernels): replay it as HIP graphs
     # under graph replay the learning rate must live in a device tensor, or the scheduler's updates would
     # never reach the captured optimiser step
     prep_counter = torch.zeros(2, dtype=torch.int64, device=device) if on_gpu else None     # batch assembly: [calls, workgroups done]
@@ -583,8 +631,9 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
             v_p, t_p = pin[1], pin[2]
         return fe_residual_loss(I_p, v_p, t_p, px, pE, pfix, pin[0], pwy)
 
-    unit_seed = torch.ones((), dtype=torch.float32, device=device) if on_gpu else None
-    if on_gpu and engine is None:
+    # the loss launch adds every step's value to the epoch's running sum itself (zeroed per epoch): no add node per step
+    loss_acc = torch.zeros((), dtype=torch.float32, device=device) if (on_gpu and _FUSED_LOSS and engine is None and physics is None and os.environ.get("OPS_AMD_LOSS_ACC", "1") == "1") else None
+    if on_gpu and engine is None and os.environ.get("OPS_AMD_ADAM_ZERO", "1") == "1":
         opt.zero_grads = True            # `flat` starts zeroed (allocation) and every update leaves it zeroed
 
     def fwd_bwd(Xb, Yb, noise_t, pin=None, prenoised=False):
@@ -598,7 +647,7 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
         with torch.autocast(device_type=device.type, dtype=autocast_dtype, enabled=use_ac):
             preds = net(Xn)
             if on_gpu and _FUSED_LOSS:       # value + d/d preds in one HIP pass instead of ~80 framework kernel nodes
-                loss = fused_loss(crit, preds, Yb, alpha0=cfg.initial_alpha if alpha_term else None, unit_grad=True)
+                loss = fused_loss(crit, preds, Yb, alpha0=cfg.initial_alpha if alpha_term else None, unit_grad=True, acc=loss_acc)
             else:
                 loss = crit(preds.float(), Yb)
                 if alpha_term:
@@ -608,10 +657,8 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
         global _WGRAD_QUEUE
         _WGRAD_QUEUE = [] if (g_stash and _GROUP_WGRAD) else None       # split-row weight gradients: one grouped launch after backward
         try:
-            if unit_seed is not None and loss.shape == unit_seed.shape and loss.dtype == unit_seed.dtype:
-                loss.backward(unit_seed)                                 # (the implicit ones_like() is a fill node per step)
-            else:
-                loss.backward()
+            loss.backward()      # (NOT backward(persistent ones): a root gradient that outlives the step made framework-path runs that
+                                 #  follow another run in the same process produce isolated NaNs -- 9 of 12 runs, profiles/r03_notes.md 8)
             flush_wgrad_queue(device)
         finally:
             _WGRAD_QUEUE = None
@@ -663,7 +710,7 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
 
     engine_seed = (seed * 7919 + 13 + rank) & 0x7FFFFFFFFFFFFFFF
 
-    y_in_prep = bool(on_gpu and Ytr.dtype == torch.float32 and Ytr.is_contiguous())      # the targets travel in the same launch
+    y_in_prep = bool(on_gpu and Ytr.dtype == torch.float32 and Ytr.is_contiguous() and os.environ.get("OPS_AMD_PREP_TARGETS", "1") == "1")      # the targets travel in the same launch
 
     def gather_noise(idx, out, out_y=None):
         """Returns whether the targets were gathered too (out_y given and float32)."""
@@ -788,6 +835,8 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
         tot = torch.zeros((), device=device)
         if engine is not None:
             engine.loss_sum.zero_()                                          # the output launch adds every step's loss to it
+        if loss_acc is not None:
+            loss_acc.zero_()                                                 # ... and so does the fused loss launch of the other loops
         noise_t = torch.tensor(noise, device=device)
         if graph is not None:
             s_noise.copy_(noise_t)                                           # constant within the epoch
@@ -823,16 +872,24 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
                     if graph_b is not None:
                         allreduce_grads()
                         graph_b.replay()
-                if engine is None:
+                if engine is None and loss_acc is None:
                     tot += s_loss
+                if _DEBUG_NAN and engine is None:
+                    _debug_nan(model, opt, flat, s_loss, epoch, b, sX, sY)
             elif engine is not None:
                 train_step(None, Ytr[:idx.numel()], noise_t, idx)            # Yb only carries the row count here
             else:
                 if shared_counter:
                     prep_counter[0:1].add_(1)                                # (no batch-assembly launch on this path: advance the streams here)
-                tot += train_step(Xtr[idx], Ytr[idx], noise_t, idx)
+                step_loss = train_step(Xtr[idx], Ytr[idx], noise_t, idx)
+                if loss_acc is None:
+                    tot += step_loss
+                if _DEBUG_NAN and engine is None:
+                    _debug_nan(model, opt, flat, step_loss, epoch, -b, Xtr[idx], Ytr[idx])
         if engine is not None:
             tot = engine.loss_sum.clone()
+        elif loss_acc is not None:
+            tot = loss_acc.clone()
         train_loss = _allreduce_mean(tot / nb_tr, world)
         if world > 1:   # BatchNorm running statistics are per rank during the epoch: average them before evaluating
             for buf in model.buffers():
@@ -880,9 +937,7 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
         # BLAS workspaces that were allocated while capturing live in the graphs' private pools but stay cached per (handle, stream):
         # a later run whose side stream gets the same id would hand that freed memory to its GEMMs as scratch space (seen as NaNs /
         # drifting losses in a framework-path TFD run after a fast-path one in the same process)
-        clear = getattr(torch._C, "_cuda_clearCublasWorkspaces", None)
-        if clear is not None:
-            clear()
+        clear_blas_workspaces()
     disable_shadow_linears(patched)      # the returned model is a plain module again
     if fast_encoder is not None:
         from . import tfd_fused

@@ -311,3 +311,74 @@ def test_gather_rows_noise_kernel(B, F, bf16):
     if B * F > 5000:
         assert abs(float(n1.mean())) < 0.03 and abs(float(n1.std()) - 1.0) < 0.03
     assert float((n1 - n2).abs().mean()) > 0.5
+
+
+def _untile(t, rows, cols):
+    """[rows, cols] matrix out of its fragment-tiled copy (include/openpystruct_amd.h: tile (row >> 4, k >> 5), lane order)."""
+    ld = t.shape[1]
+    r = torch.arange(rows, device=t.device)[:, None]
+    c = torch.arange(cols, device=t.device)[None, :]
+    off = ((r >> 4) * (ld >> 5) + (c >> 5)) * 512 + ((c >> 3) & 3) * 128 + (r & 15) * 8 + (c & 7)
+    return t.reshape(-1)[off]
+
+
+def test_adam_step_refreshes_the_tiled_weight_copies_and_zeroes_the_gradients():
+    """ops_flat_clip_adam_step_repack_f32: after the step every Wp / Wtp holds bf16(new W) / bf16(new W)^T in the tiled layout, zero in
+    the padding, identical to a fresh ops_mlp_repack_weights; with OPS_ADAM_ZERO_GRADS the gradient buffer is left zeroed; the
+    parameters equal the update without those extras.  Odd shapes included (rows / columns that are no multiples of 16 / 32 / 4)."""
+    from openpystruct_amd import _cabi, train
+    lib = _cabi.load()
+    torch.manual_seed(3)
+    shapes = [(360, 120), (120,), (120, 120), (256, 120), (120, 256), (7, 33), (13,), (350, 175), (302, 350)]
+    ps = [torch.nn.Parameter(torch.randn(s, device="cuda")) for s in shapes]
+    ref = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+    flat, flat_r = (torch.zeros(sum(p.numel() for p in ps), device="cuda") for _ in range(2))
+    for lst, fl in ((ps, flat), (ref, flat_r)):
+        off = 0
+        for p in lst:
+            p.grad = fl[off:off + p.numel()].view_as(p); off += p.numel()
+    opt, ropt = train.FlatClipAdam(ps, flat, 1e-2), train.FlatClipAdam(ref, flat_r, 1e-2)
+    ru = lambda v, m: (v + m - 1) // m * m      # noqa: E731
+    mats = [p for p in ps if p.dim() == 2]
+    tiles = [(torch.full((ru(N, 16), ru(K, 32)), 7.0, dtype=torch.bfloat16, device="cuda"),
+              torch.full((ru(K, 16), ru(N, 32)), 7.0, dtype=torch.bfloat16, device="cuda")) for N, K in (m.shape for m in mats)]
+    ent = (_cabi.MlpRepackEntry * len(mats))()
+    for e, w, (wp, wtp) in zip(ent, mats, tiles):
+        e.W, e.N, e.K, e.Wp, e.ldw, e.Wtp, e.ldwt = w.data_ptr(), w.shape[0], w.shape[1], wp.data_ptr(), wp.shape[1], wtp.data_ptr(), wtp.shape[1]
+    opt.repack, opt.zero_grads = ent, True
+    for step in range(2):
+        g = torch.randn_like(flat)
+        flat.copy_(g); flat_r.copy_(g)
+        opt.step(); ropt.step()
+        torch.cuda.synchronize()
+        assert float(flat.abs().max()) == 0.0 and float(flat_r.abs().max()) > 0.0
+        for p, r in zip(ps, ref):
+            assert torch.equal(p, r)
+        for w, (wp, wtp) in zip(mats, tiles):
+            N, K = w.shape
+            assert torch.equal(_untile(wp, N, K), w.detach().to(torch.bfloat16))
+            assert torch.equal(_untile(wtp, K, N), w.detach().t().to(torch.bfloat16))
+            assert int((wp != 0).sum()) == int((w.detach().to(torch.bfloat16) != 0).sum())          # padding: zeros
+            assert int((wtp != 0).sum()) == int((w.detach().to(torch.bfloat16) != 0).sum())
+            fresh = (torch.zeros_like(wp), torch.zeros_like(wtp))
+            e1 = (_cabi.MlpRepackEntry * 1)()
+            e1[0].W, e1[0].N, e1[0].K, e1[0].Wp, e1[0].ldw, e1[0].Wtp, e1[0].ldwt = w.data_ptr(), N, K, fresh[0].data_ptr(), wp.shape[1], fresh[1].data_ptr(), wtp.shape[1]
+            assert lib.ops_mlp_repack_weights(1, e1, torch.cuda.current_stream().cuda_stream) == 0
+            torch.cuda.synchronize()
+            assert torch.equal(fresh[0], wp) and torch.equal(fresh[1], wtp)
+
+
+def test_gather_rows_noise_gathers_the_targets_in_the_same_launch():
+    from openpystruct_amd import _cabi
+    lib = _cabi.load()
+    dev = torch.device("cuda")
+    g = torch.Generator().manual_seed(2)
+    X, Y = torch.randn(900, 720, generator=g).to(dev), torch.randn(900, 100, generator=g).to(dev)
+    idx = torch.randint(0, 900, (512,), generator=g).to(dev)
+    out, outy = torch.empty((512, 720), device=dev), torch.empty((512, 100), device=dev)
+    cnt = torch.zeros(2, dtype=torch.int64, device=dev)
+    sig0 = torch.zeros((), device=dev)
+    assert lib.ops_gather_rows_noise_targets_f32(512, 720, X.data_ptr(), idx.data_ptr(), sig0.data_ptr(), 5, cnt.data_ptr(), out.data_ptr(), 0,
+                                                 Y.data_ptr(), 100, outy.data_ptr(), torch.cuda.current_stream().cuda_stream) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(out, X[idx]) and torch.equal(outy, Y[idx]) and int(cnt[0]) == 1

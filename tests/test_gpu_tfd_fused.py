@@ -441,6 +441,7 @@ def test_tfd_training_with_the_fast_encoder_follows_the_framework_path(monkeypat
         monkeypatch.setattr(tfd_fused, "ENABLED", fast)
         out = train.train_surrogate("tfd", d, device="cuda", max_epochs=6, seed=1)
         hist[fast] = out["history"]["train"]
+        print("fast encoder" if fast else "framework encoder", ["%.5f" % v for v in hist[fast]])
         assert all(np.isfinite(hist[fast])) and hist[fast][-1] < 0.95 * hist[fast][0]
     assert abs(hist[True][-1] - hist[False][-1]) < 0.08 * hist[False][-1], hist
 
