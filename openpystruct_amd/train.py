@@ -657,8 +657,11 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
         global _WGRAD_QUEUE
         _WGRAD_QUEUE = [] if (g_stash and _GROUP_WGRAD) else None       # split-row weight gradients: one grouped launch after backward
         try:
-            loss.backward()      # (NOT backward(persistent ones): a root gradient that outlives the step made framework-path runs that
-                                 #  follow another run in the same process produce isolated NaNs -- 9 of 12 runs, profiles/r03_notes.md 8)
+            # NOT backward(gradient=...) to save the implicit ones_like() fill node: with an explicit root gradient -- a persistent ones
+            # tensor, or the loss launch's own d loss / d preds handed to preds.backward() -- framework-path runs that follow another run
+            # in the same process produced isolated NaNs in bias gradients at the first replay after an eager pass (9 of 12 runs against
+            # 0 of 12, profiles/r03_notes.md 8)
+            loss.backward()
             flush_wgrad_queue(device)
         finally:
             _WGRAD_QUEUE = None
