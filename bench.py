@@ -247,7 +247,7 @@ def surrogate_epoch_times(dev, rank, world, epochs, cases=50000):
             out[kind] = {"epoch_s": sum(ep) / len(ep), "steps_per_epoch": r["steps_per_epoch"], "train_groups_per_gpu": int(d.X_train.shape[0]),
                          "dtype": "bf16", "step_us": 1e6 * sum(ep) / len(ep) / max(1, r["steps_per_epoch"]),
                          "path": {"pinn": "layer-block launches (pinn_fused.py, csrc/mlp_block.hip)",
-                                  "tfd": "autograd over block launches (tfd_fused.py, csrc/seq_block.hip)"}[kind]}
+                                  "tfd": "one launch per encoder layer and direction + block launches (tfd_fused.py, csrc/seq_layer.hip, csrc/seq_block.hip)"}[kind]}
             if "dp_segments" in r:       # N > 1: device time of [graph A | all-reduce | graph B] per step (HIP events, mean over the epochs after the first)
                 out[kind]["dp_segments"] = r["dp_segments"]
         # BASELINE config 4: the TFD surrogate with the physics loss through the HIP FE-residual kernels.  The residual needs

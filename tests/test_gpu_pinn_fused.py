@@ -244,7 +244,7 @@ def test_step_gradients_of_a_smooth_network_match_float64(B, p_drop, seed):
     assert abs(loss - loss_ref) <= 1e-2 * abs(loss_ref)
     gref = {n: q.grad for n, q in ref.named_parameters()}
     worst = {n: float((got[n] - gref[n]).norm()) / (max(float(gref[n].norm()), _floor2(n, gref)) + 1e-30) for n in got}
-    # Bounds from a sweep over 12 mask draws per size (scratch/smooth_seeds.py, profiles/r03_notes.md 6): every matrix / vector
+    # Bounds from a sweep over 12 mask draws per size (scripts/pinn_smooth_seed_sweep.py, profiles/r03_notes.md 6): every matrix / vector
     # parameter <= 3e-2 (1.8e-2 worst seen); the stencil path's SCALARS (3 taps + a 1-channel norm: sums of B x 175 products of mixed
     # sign) 0.6-2.6e-2 at 128 rows, up to 4.2e-2 at 33 rows and 6.6e-2 at 16 rows.
     def bound(n):
