@@ -371,6 +371,7 @@ typedef struct ops_mlp_wgrad_problem {
   const void* At; const void* Bt; float* out; int32_t N, K, ldo;
 } ops_mlp_wgrad_problem;
 #define OPS_MLP_MAX_WGRAD 8
+#define OPS_MLP_MAX_REPACK 16   /* matrices per ops_flat_clip_adam_step_repack_f32 (ops_mlp_repack_weights: OPS_MLP_MAX_WGRAD per call) */
 int ops_mlp_wgrad_group(int nprob, const ops_mlp_wgrad_problem* problems, void* stream);
 
 /* Wp / Wtp of up to 8 weight matrices from the float32 parameters W_i [N_i, K_i] in one launch. */
@@ -378,8 +379,8 @@ typedef struct ops_mlp_repack_entry {
   const float* W; int32_t N, K; void* Wp; int32_t ldw; void* Wtp; int32_t ldwt;
 } ops_mlp_repack_entry;
 int ops_mlp_repack_weights(int nmat, const ops_mlp_repack_entry* entries, void* stream);
-/* ops_flat_clip_adam_step_f32 that also refreshes those copies (every entry's W must point into `params`): the training step
- * needs no repack launch. */
+/* ops_flat_clip_adam_step_f32 that also refreshes those copies (every entry's W must point into `params`; up to OPS_MLP_MAX_REPACK
+ * matrices): one coalesced launch behind the update, one wave per 1 KB tile. */
 int ops_flat_clip_adam_step_repack_f32(long n, float* params, const float* grads, float* exp_avg, float* exp_avg_sq, const float* lr,
                                        int32_t* step, float max_norm, float grad_scale, float beta1, float beta2, float eps,
                                        float weight_decay, int decoupled_weight_decay, void* params_bf16, void* workspace,
@@ -503,6 +504,29 @@ typedef struct ops_tfd_layer_bwd_args {
   unsigned long long* trace;
 } ops_tfd_layer_bwd_args;
 int ops_tfd_encoder_layer_bwd(const ops_tfd_layer_bwd_args* args, void* stream);
+
+/* The Transformer-Diffusion model's head (TransformerDiffusionModule_MultiCase.py:568-575) as one launch per direction: rows = the
+ * [CLS] rows of the last encoder layer's bf16 output (row b S of y16 [B S, d]), a = fc1 rows + b1 (bf16), LayerNorm over `hid` columns,
+ * ReLU, dropout, out = fc2 + b2 (bf16 [B, C]).  d <= 128, hid <= 256 (multiples of 8), C <= 128 (a multiple of 4); weights: fragment-tiled
+ * copies as for the layer launches (forward Wp, backward Wtp).  Saved for the backward launch and the weight-gradient products: a16,
+ * mean, rstd, h.  Backward: g [B, C] bf16 = d loss / d out -> d_a [B, hid] bf16 (gradient at fc1's output), dcls = d_a W_1 written into the
+ * [CLS] rows (row stride S d elements) of `dcls_rows` (a [B S, d] bf16 tensor whose other rows the caller keeps zero), dgamma / dbeta ADDED. */
+typedef struct ops_tfd_head_args {
+  int32_t B, S, d, hid, C;
+  const void* y16;
+  const void* W1; const void* b1; const float* gamma; const float* beta; float eps; const void* W2; const void* b2;
+  float p_drop; unsigned long long seed; const unsigned long long* counter; unsigned long long* used_call;
+  void* a16; float* mean; float* rstd; void* h; void* out;
+} ops_tfd_head_args;
+int ops_tfd_head_fwd(const ops_tfd_head_args* args, void* stream);
+typedef struct ops_tfd_head_bwd_args {
+  int32_t B, S, d, hid, C;
+  const void* g; const void* Wt2; const void* Wt1; const float* gamma;
+  float p_drop;
+  const void* a16; const float* mean; const float* rstd; const void* h;
+  void* d_a; void* dcls_rows; float* dgamma; float* dbeta;
+} ops_tfd_head_bwd_args;
+int ops_tfd_head_bwd(const ops_tfd_head_bwd_args* args, void* stream);
 
 /* Measurement aid of bench.py, not a product call: device-to-device copy of `bytes` (a multiple of 16, both pointers 16-byte
  * aligned) with one 16-byte access per lane and instruction -- the achievable HBM rate the roofline records quote next to the

@@ -66,6 +66,8 @@ EXPORTS = (
     "ops_surrogate_loss_grad_sum_f32",
     "ops_gather_rows_noise_targets_f32",
     "ops_tfd_encoder_layer_bwd",
+    "ops_tfd_head_fwd",
+    "ops_tfd_head_bwd",
 )
 
 OK, ERR_INVALID_ARG, ERR_UNSUPPORTED, ERR_LAUNCH = 0, 1, 2, 3
@@ -88,6 +90,7 @@ MLP_TAIL_BWD_ACT_DROP, MLP_TAIL_BWD_BN, MLP_TAIL_BWD_BN_ACT_DROP, MLP_TAIL_LOSS 
 MLP_ADD_NONE, MLP_ADD_FWD_BLOCK, MLP_ADD_BWD_BLOCK = 0, 1, 2
 MLP_SIDE_NONE, MLP_SIDE_FWD_STENCIL_STATS, MLP_SIDE_BWD_STENCIL_SUMS = 0, 1, 2
 MLP_MAX_WGRAD = 8
+MLP_MAX_REPACK = 16
 
 
 class MlpStripArgs(ctypes.Structure):
@@ -145,6 +148,21 @@ class TfdLayerBwdArgs(ctypes.Structure):
                 ("dgamma1", _vp), ("dbeta1", _vp), ("dgamma2", _vp), ("dbeta2", _vp), ("trace", _vp)]
 
 
+class TfdHeadArgs(ctypes.Structure):
+    """Mirror of `ops_tfd_head_args`."""
+    _vp, _i, _f, _u = ctypes.c_void_p, ctypes.c_int32, ctypes.c_float, ctypes.c_ulonglong
+    _fields_ = [("B", _i), ("S", _i), ("d", _i), ("hid", _i), ("C", _i), ("y16", _vp), ("W1", _vp), ("b1", _vp), ("gamma", _vp), ("beta", _vp),
+                ("eps", _f), ("W2", _vp), ("b2", _vp), ("p_drop", _f), ("seed", _u), ("counter", _vp), ("used_call", _vp),
+                ("a16", _vp), ("mean", _vp), ("rstd", _vp), ("h", _vp), ("out", _vp)]
+
+
+class TfdHeadBwdArgs(ctypes.Structure):
+    """Mirror of `ops_tfd_head_bwd_args`."""
+    _vp, _i, _f = ctypes.c_void_p, ctypes.c_int32, ctypes.c_float
+    _fields_ = [("B", _i), ("S", _i), ("d", _i), ("hid", _i), ("C", _i), ("g", _vp), ("Wt2", _vp), ("Wt1", _vp), ("gamma", _vp), ("p_drop", _f),
+                ("a16", _vp), ("mean", _vp), ("rstd", _vp), ("h", _vp), ("d_a", _vp), ("dcls_rows", _vp), ("dgamma", _vp), ("dbeta", _vp)]
+
+
 WGRAD_MAX_GROUP = 16
 
 
@@ -200,6 +218,10 @@ def load():
     lib.ops_tfd_encoder_layer_fwd.argtypes = [ctypes.POINTER(TfdLayerArgs), vp]
     lib.ops_tfd_encoder_layer_bwd.restype = it
     lib.ops_tfd_encoder_layer_bwd.argtypes = [ctypes.POINTER(TfdLayerBwdArgs), vp]
+    lib.ops_tfd_head_fwd.restype = it
+    lib.ops_tfd_head_fwd.argtypes = [ctypes.POINTER(TfdHeadArgs), vp]
+    lib.ops_tfd_head_bwd.restype = it
+    lib.ops_tfd_head_bwd.argtypes = [ctypes.POINTER(TfdHeadBwdArgs), vp]
     lib.ops_hbm_copy16.restype = it
     lib.ops_hbm_copy16.argtypes = [vp, vp, ctypes.c_size_t, it, vp]
     fr = lib.ops_frame_solve_batched_f64

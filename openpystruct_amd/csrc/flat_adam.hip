@@ -55,22 +55,21 @@ __global__ __launch_bounds__(FA_THREADS) void flat_grad_norm_kernel(long n, cons
   }
 }
 
-// bf16 copies of up to 8 weight matrices in the layout of csrc/mlp_block.hip (padded, plain and transposed), refreshed by the
-// update itself: the PINN's layer-block launches read them, no separate repack launch per step
+// bf16 copies of up to OPS_MLP_MAX_REPACK weight matrices in the layout of csrc/mlp_block.hip (padded, plain and transposed), rebuilt
+// by repack_tiles_kernel right behind the update: the PINN's and the TFD's layer-block launches read them
 struct AdamRepack {
   int nmat;
-  long off[OPS_MLP_MAX_WGRAD];        // first element of matrix i in the flat parameter buffer
-  int N[OPS_MLP_MAX_WGRAD], K[OPS_MLP_MAX_WGRAD], ldw[OPS_MLP_MAX_WGRAD], ldwt[OPS_MLP_MAX_WGRAD];
-  uint16_t* Wp[OPS_MLP_MAX_WGRAD];
-  uint16_t* Wtp[OPS_MLP_MAX_WGRAD];
+  long off[OPS_MLP_MAX_REPACK];        // first element of matrix i in the flat parameter buffer
+  int N[OPS_MLP_MAX_REPACK], K[OPS_MLP_MAX_REPACK], ldw[OPS_MLP_MAX_REPACK], ldwt[OPS_MLP_MAX_REPACK];
+  uint16_t* Wp[OPS_MLP_MAX_REPACK];
+  uint16_t* Wtp[OPS_MLP_MAX_REPACK];
 };
 
-template <bool REPACK>
 __global__ __launch_bounds__(FA_THREADS) void flat_adam_kernel(long n, float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
                                                                 float* __restrict__ v, const float* __restrict__ lr, const int32_t* __restrict__ step,
                                                                 const double* __restrict__ part, int nparts, float max_norm, float grad_scale,
                                                                 float beta1, float beta2, float eps, float weight_decay, int flags,
-                                                                uint16_t* __restrict__ shadow, const AdamRepack rp) {
+                                                                uint16_t* __restrict__ shadow) {
   // ||g||^2 from the norm pass's partial sums: one load per thread (nparts <= FA_NORM_BLOCKS <= FA_THREADS), not a serial chain
   __shared__ double s_red[FA_THREADS / 64];
   double d = (int)threadIdx.x < nparts ? part[threadIdx.x] : 0.0;
@@ -102,44 +101,6 @@ __global__ __launch_bounds__(FA_THREADS) void flat_adam_kernel(long n, float* __
     u += 0x7fffu + ((u >> 16) & 1u);
     return (uint16_t)(u >> 16);
   };
-  auto repack = [&](long i, uint16_t h) {
-    // fragment-tiled storage (csrc/mlp_block.hip mb_toff): tile (row >> 4, k >> 5) = 512 elements in MFMA lane order
-#pragma unroll
-    for (int q = 0; q < OPS_MLP_MAX_WGRAD; ++q)
-      if (q < rp.nmat) {
-        const long le = i - rp.off[q];
-        if (le >= 0 && le < (long)rp.N[q] * rp.K[q]) {
-          const int r = (int)(le / rp.K[q]), c = (int)(le - (long)r * rp.K[q]);
-          const int ksw = rp.ldw[q] >> 5, kst = rp.ldwt[q] >> 5;
-          rp.Wp[q][((long)(r >> 4) * ksw + (c >> 5)) * 512 + ((c >> 3) & 3) * 128 + (r & 15) * 8 + (c & 7)] = h;
-          rp.Wtp[q][((long)(c >> 4) * kst + (r >> 5)) * 512 + ((r >> 3) & 3) * 128 + (c & 15) * 8 + (r & 7)] = h;
-        }
-      }
-  };
-  // four consecutive elements: one matrix search and ONE division (32-bit: N K < 2^31) for the group when it lies inside one matrix --
-  // the per-element form (8 range checks + a 64-bit division each) made the update 12 us instead of 4.7 for the TFD model's 0.36 M parameters
-  auto repack4 = [&](long i0, uint16_t h0, uint16_t h1, uint16_t h2, uint16_t h3) {
-    int q = -1;
-#pragma unroll
-    for (int k = 0; k < OPS_MLP_MAX_WGRAD; ++k)
-      if (k < rp.nmat && i0 >= rp.off[k] && i0 < rp.off[k] + (long)rp.N[k] * rp.K[k]) q = k;
-    if (q < 0) {
-      // (the group may still straddle the START of a matrix)
-      repack(i0 + 1, h1); repack(i0 + 2, h2); repack(i0 + 3, h3);
-      return;
-    }
-    const unsigned le = (unsigned)(i0 - rp.off[q]), K = (unsigned)rp.K[q], NK = (unsigned)rp.N[q] * K;
-    if (le + 3 >= NK) { repack(i0, h0); repack(i0 + 1, h1); repack(i0 + 2, h2); repack(i0 + 3, h3); return; }
-    unsigned r = le / K, c = le - r * K;
-    const int ksw = rp.ldw[q] >> 5, kst = rp.ldwt[q] >> 5;
-    const uint16_t hv[4] = {h0, h1, h2, h3};
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      rp.Wp[q][((long)(r >> 4) * ksw + (c >> 5)) * 512 + ((c >> 3) & 3) * 128 + (r & 15) * 8 + (c & 7)] = hv[k];
-      rp.Wtp[q][((long)(c >> 4) * kst + (r >> 5)) * 512 + ((r >> 3) & 3) * 128 + (c & 15) * 8 + (r & 7)] = hv[k];
-      if (++c == K) { c = 0; ++r; }
-    }
-  };
   // 16-byte groups (the four flat buffers are framework allocations: 16-byte aligned; otherwise everything takes the scalar loop)
   const bool al = ((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0) && (!shadow || ((uintptr_t)shadow & 7) == 0);
   const long n4 = al ? n >> 2 : 0;
@@ -150,10 +111,9 @@ __global__ __launch_bounds__(FA_THREADS) void flat_adam_kernel(long n, float* __
     Q.x = update(P.x, G.x, M.x, V.x); Q.y = update(P.y, G.y, M.y, V.y); Q.z = update(P.z, G.z, M.z, V.z); Q.w = update(P.w, G.w, M.w, V.w);
     ((float4*)m)[i4] = M; ((float4*)v)[i4] = V; ((float4*)p)[i4] = Q;
     if (zero_g) ((float4*)g)[i4] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);        // optimizer.zero_grad() of the NEXT step (one fill node less per step)
-    if (shadow || REPACK) {            // bfloat16 copies of the parameters for the GEMMs of the next step
+    if (shadow) {                      // bfloat16 copy of the parameters for the GEMMs of the next step
       const uint16_t h0 = to_bf16(Q.x), h1 = to_bf16(Q.y), h2 = to_bf16(Q.z), h3 = to_bf16(Q.w);
-      if (shadow) ((uint2*)shadow)[i4] = uint2{(uint32_t)h0 | ((uint32_t)h1 << 16), (uint32_t)h2 | ((uint32_t)h3 << 16)};
-      if (REPACK) repack4(4 * i4, h0, h1, h2, h3);
+      ((uint2*)shadow)[i4] = uint2{(uint32_t)h0 | ((uint32_t)h1 << 16), (uint32_t)h2 | ((uint32_t)h3 << 16)};
     }
   }
   for (long i = 4 * n4 + (long)blockIdx.x * FA_THREADS + threadIdx.x; i < n; i += (long)gridDim.x * FA_THREADS) {
@@ -161,11 +121,7 @@ __global__ __launch_bounds__(FA_THREADS) void flat_adam_kernel(long n, float* __
     const float pn = update(p[i], g[i], mi, vi);
     m[i] = mi; v[i] = vi; p[i] = pn;
     if (zero_g) g[i] = 0.0f;
-    if (shadow || REPACK) {
-      const uint16_t h = to_bf16(pn);
-      if (shadow) shadow[i] = h;
-      if (REPACK) repack(i, h);
-    }
+    if (shadow) shadow[i] = to_bf16(pn);
   }
 }
 
@@ -177,19 +133,19 @@ __global__ __launch_bounds__(FA_THREADS) void flat_adam_kernel(long n, float* __
 // Cache hits) and stores 16 bytes at tile * 1024 + 16 l -- every store instruction of a wave is one contiguous KB.
 struct TileJobs {
   int nmat;
-  int first[2 * OPS_MLP_MAX_WGRAD + 1];       // first tile of (matrix q, plain) = first[2 q], (matrix q, transposed) = first[2 q + 1]
+  int first[2 * OPS_MLP_MAX_REPACK + 1];       // first tile of (matrix q, plain) = first[2 q], (matrix q, transposed) = first[2 q + 1]
 };
 __global__ __launch_bounds__(256) void repack_tiles_kernel(const float* __restrict__ p, const AdamRepack rp, const TileJobs tj) {
   const int lane = threadIdx.x & 63, tile = (int)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (tile >= tj.first[2 * tj.nmat]) return;                       // wave-uniform
   int job = 0;
 #pragma unroll
-  for (int k = 1; k < 2 * OPS_MLP_MAX_WGRAD; ++k)
+  for (int k = 1; k < 2 * OPS_MLP_MAX_REPACK; ++k)
     if (k < 2 * tj.nmat && tile >= tj.first[k]) job = k;
   const int q = job >> 1, tr = job & 1, t = tile - tj.first[job];
   long off = 0; int N = 0, K = 0, ldw = 0, ldwt = 0; uint16_t* Wp = nullptr; uint16_t* Wtp = nullptr;
 #pragma unroll
-  for (int k = 0; k < OPS_MLP_MAX_WGRAD; ++k)                       // (constant indices: the argument block stays in scalar registers)
+  for (int k = 0; k < OPS_MLP_MAX_REPACK; ++k)                       // (constant indices: the argument block stays in scalar registers)
     if (k == q) { off = rp.off[k]; N = rp.N[k]; K = rp.K[k]; ldw = rp.ldw[k]; ldwt = rp.ldwt[k]; Wp = rp.Wp[k]; Wtp = rp.Wtp[k]; }
   const float* W = p + off;
   const int ks = (tr ? ldwt : ldw) >> 5, tb = t / ks, tk = t - tb * ks;      // tile (block of 16 along the tile's "row" axis, reduction step)
@@ -229,9 +185,9 @@ static int adam_step(long n, float* params, const float* grads, float* exp_avg, 
                      beta2);
   nb = (n / 4 + FA_THREADS - 1) / FA_THREADS + 1;     // one 16-byte group per thread
   if (nb > 4096) nb = 4096;
-  hipLaunchKernelGGL(flat_adam_kernel<false>, dim3((unsigned)nb), dim3(FA_THREADS), 0, s, n, params, (float*)grads, exp_avg, exp_avg_sq, lr, step,
+  hipLaunchKernelGGL(flat_adam_kernel, dim3((unsigned)nb), dim3(FA_THREADS), 0, s, n, params, (float*)grads, exp_avg, exp_avg_sq, lr, step,
                      (const double*)workspace, nparts, max_norm, grad_scale, beta1, beta2, eps, weight_decay, decoupled_weight_decay,
-                     (uint16_t*)params_bf16, AdamRepack{});
+                     (uint16_t*)params_bf16);
   if (rp) {      // the tiled weight copies: one wave per 1 KB tile, behind the update
     TileJobs tj;
     tj.nmat = rp->nmat;
@@ -260,7 +216,7 @@ extern "C" int ops_flat_clip_adam_step_repack_f32(long n, float* params, const f
                                                   int32_t* step, float max_norm, float grad_scale, float beta1, float beta2, float eps,
                                                   float weight_decay, int decoupled_weight_decay, void* params_bf16, void* workspace,
                                                   int nmat, const ops_mlp_repack_entry* entries, void* stream) {
-  if (nmat < 1 || nmat > OPS_MLP_MAX_WGRAD || !entries || !params) return OPS_AMD_ERR_INVALID_ARG;
+  if (nmat < 1 || nmat > OPS_MLP_MAX_REPACK || !entries || !params) return OPS_AMD_ERR_INVALID_ARG;
   AdamRepack rp{};
   rp.nmat = nmat;
   for (int i = 0; i < nmat; ++i) {

@@ -850,6 +850,264 @@ __global__ __launch_bounds__(64 * SL_NW) void tfd_layer_bwd_kernel(const ops_tfd
   }
 }
 
+
+// ================================================================================================================================
+// The model's head around the encoder (TFD:568-575): fc1 -> LayerNorm -> ReLU -> dropout -> fc2 on the B [CLS] rows, one launch per
+// direction (was: product, dropout_add_ln, act_dropout, product forward and the four mirror images backward, ~5 us each for 512 rows).
+// Same decomposition as the layer launches: 16 rows per workgroup, 8 waves split the column tiles, tiled weights requested at entry.
+// ================================================================================================================================
+// rows of an LDS image -> global rows with a row stride of their own, in pieces of PB bytes (8 or 16)
+template <int EB, int PB>
+__device__ __forceinline__ void sl_store_rows_ld(void* __restrict__ dst, long ldd /*elements*/, const void* __restrict__ src, int ls, int ncols, long row0, int nrows, int tid) {
+  const int per = PB / EB, ppr = ncols / per;
+  const float inv = 1.0f / (float)ppr;
+  __attribute__((address_space(1))) char* out = (__attribute__((address_space(1))) char*)dst + row0 * ldd * EB;
+  for (int idx = tid; idx < nrows * ppr; idx += 64 * SL_NW) {
+    const int r = (int)(((float)idx + 0.5f) * inv), q = idx - r * ppr;
+    if (PB == 16) {
+      const sl_u32x4 v = *(const sl_u32x4*)((const char*)src + (r * ls + q * per) * EB);
+      *(__attribute__((address_space(1))) sl_u32x4*)(out + ((long)r * ldd + q * per) * EB) = v;
+    } else {
+      typedef unsigned sl_u32x2 __attribute__((ext_vector_type(2)));
+      const sl_u32x2 v = *(const sl_u32x2*)((const char*)src + (r * ls + q * per) * EB);
+      *(__attribute__((address_space(1))) sl_u32x2*)(out + ((long)r * ldd + q * per) * EB) = v;
+    }
+  }
+}
+
+typedef const __attribute__((opencl_constant)) ops_tfd_head_args* slh_args_ptr;
+__device__ __forceinline__ slh_args_ptr slh_late_args() {
+  auto p = __builtin_amdgcn_kernarg_segment_ptr();
+  __asm__ volatile("" : "+s"(p));
+  return (slh_args_ptr)p;
+}
+
+__global__ __launch_bounds__(64 * SL_NW) void tfd_head_fwd_kernel(const ops_tfd_head_args a) {
+  constexpr int XS = 128 + 8, HS = 256 + 8, FS2 = 256 + 4;
+  __shared__ __attribute__((aligned(16))) uint16_t s_x[16 * XS];      // [CLS] rows (bf16 operand), at the end the output rows
+  __shared__ __attribute__((aligned(16))) uint16_t s_a16[16 * HS];    // fc1 output as stored
+  __shared__ __attribute__((aligned(16))) uint16_t s_h[16 * HS];      // dropout(ReLU(LayerNorm)): operand of fc2
+  __shared__ __attribute__((aligned(16))) float s_f32[16 * FS2];      // fc1 output (bf16 values as float): LayerNorm input
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 15, g = lane >> 4;
+  const int S = a.S, d = a.d, hid = a.hid, C = a.C;
+  const int b0 = blockIdx.x * 16, nrows = (a.B - b0 < 16) ? a.B - b0 : 16;
+  const int NT1 = (hid + 15) / 16, NT2 = (C + 15) / 16, KSD = (d + 31) / 32, KSH = (hid + 31) / 32;
+  // ---- requests: the [CLS] rows, this lane's vectors, the weight fragments ----
+  const int pr = tid >> 5, pq = tid & 31;
+  const bool pok = pr < nrows && 8 * pq < d;
+  const uint4 xin = *(const uint4*)((const uint16_t*)a.y16 + ((long)(b0 + (pr < nrows ? pr : 0)) * S) * d + (8 * pq < d ? 8 * pq : 0));
+  const unsigned long long call = *a.counter;
+  float b1v[2], gmv[2], bev[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int m = 16 * (wave + SL_NW * j) + c, mc = m < hid ? m : hid - 1;
+    b1v[j] = sl_bf2f(((const uint16_t*)a.b1)[mc]); gmv[j] = a.gamma[mc]; bev[j] = a.beta[mc];
+  }
+  const int oc = 16 * wave + c;
+  const float b2v = sl_bf2f(((const uint16_t*)a.b2)[oc < C ? oc : C - 1]);
+  WTile<4> w1[2];
+  WTile<8> w2;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) { const int t = wave + SL_NW * j; sl_load_tile<4>(w1[j], (const uint16_t*)a.W1, KSD, t < NT1 ? t : NT1 - 1, lane); }
+  sl_load_tile<8>(w2, (const uint16_t*)a.W2, KSH, wave < NT2 ? wave : NT2 - 1, lane);
+  if (pq < 16) *(uint4*)(s_x + pr * XS + 8 * pq) = pok ? xin : uint4{0u, 0u, 0u, 0u};      // (16 pieces = the 128 operand columns of a row)
+  sl_zero_cols(s_h, HS, hid, 256, tid);
+  sl_lds_barrier();
+
+  // ---- a = x W_1^T + b_1 (bf16) ----
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int t = wave + SL_NW * j;
+    if (t < NT1) {
+      const sl_f32x4 acc = sl_mma_tile<4>(w1[j], s_x, XS, c, g);
+      const int m = 16 * t + c;
+      if (m < hid) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int r = 4 * g + i;
+          const uint16_t ab = sl_f2bf(acc[i] + b1v[j]);
+          s_a16[r * HS + m] = ab;
+          s_f32[r * FS2 + m] = r < nrows ? sl_bf2f(ab) : 0.0f;
+        }
+      }
+    }
+  }
+  sl_lds_barrier();
+
+  // ---- LayerNorm statistics (two passes over the published rows, every wave for its own rows), ReLU, dropout -> h ----
+  {
+    const slh_args_ptr la = slh_late_args();
+    const DropKey key = drop_key(la->seed, call);
+    const float p = la->p_drop, ks = p > 0.0f ? 1.0f / (1.0f - p) : 1.0f, eps = la->eps;
+    float mean[4], rstd[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float* row = s_f32 + (4 * g + i) * FS2;
+      float v[16], s = 0.0f;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) { v[k] = row[c + 16 * k]; s += (c + 16 * k < hid) ? v[k] : 0.0f; }
+      mean[i] = sl_rowsum(s) / (float)hid;
+      float q = 0.0f;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) { const float dv = v[k] - mean[i]; q += (c + 16 * k < hid) ? dv * dv : 0.0f; }
+      rstd[i] = rsqrtf(sl_rowsum(q) / (float)hid + eps);
+      if (wave == 0 && c == 0 && 4 * g + i < nrows) {
+        SL_GLOBAL(float, la->mean)[b0 + 4 * g + i] = mean[i];
+        SL_GLOBAL(float, la->rstd)[b0 + 4 * g + i] = rstd[i];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int m = 16 * (wave + SL_NW * j) + c;
+      if (m < hid) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int r = 4 * g + i;
+          float y = sl_round(__builtin_fmaf((s_f32[r * FS2 + m] - mean[i]) * rstd[i], gmv[j], bev[j]));     // the LayerNorm's bf16 output
+          y = y > 0.0f ? y : 0.0f;
+          if (p > 0.0f) y = drop_uniform(key, (uint64_t)((long)(b0 + r) * hid + m)) >= p ? y * ks : 0.0f;
+          s_h[r * HS + m] = r < nrows ? sl_f2bf(y) : (uint16_t)0;
+        }
+      }
+    }
+  }
+  sl_lds_barrier();
+  __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): every weight fragment is in; stores from here on
+  { const slh_args_ptr la = slh_late_args();
+    sl_store_rows<2>(la->a16, s_a16, HS, hid, b0, nrows, tid);
+    sl_store_rows<2>(la->h, s_h, HS, hid, b0, nrows, tid); }
+
+  // ---- out = h W_2^T + b_2 ----
+  if (wave < NT2) {
+    const sl_f32x4 acc = sl_mma_tile<8>(w2, s_h, HS, c, g);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) s_x[(4 * g + i) * XS + oc] = sl_f2bf(acc[i] + b2v);     // (the [CLS] rows as an operand are dead)
+  }
+  sl_lds_barrier();
+  { const slh_args_ptr la = slh_late_args();
+    sl_store_rows_ld<2, 8>(la->out, C, s_x, XS, C, b0, nrows, tid);
+    if (blockIdx.x == 0 && tid == 0 && la->used_call) *SL_GLOBAL(unsigned long long, la->used_call) = call; }
+}
+
+typedef const __attribute__((opencl_constant)) ops_tfd_head_bwd_args* slhb_args_ptr;
+__device__ __forceinline__ slhb_args_ptr slhb_late_args() {
+  auto p = __builtin_amdgcn_kernarg_segment_ptr();
+  __asm__ volatile("" : "+s"(p));
+  return (slhb_args_ptr)p;
+}
+
+__global__ __launch_bounds__(64 * SL_NW) void tfd_head_bwd_kernel(const ops_tfd_head_bwd_args a) {
+  constexpr int XS = 128 + 8, HS = 256 + 8;
+  __shared__ __attribute__((aligned(16))) uint16_t s_g[16 * XS];      // d loss / d out rows (operand), at the end the [CLS] gradient rows
+  __shared__ __attribute__((aligned(16))) uint16_t s_h[16 * HS];      // h (its zeros are the ReLU / dropout mask)
+  __shared__ __attribute__((aligned(16))) uint16_t s_a[16 * HS];      // fc1 output (LayerNorm input)
+  __shared__ __attribute__((aligned(16))) uint16_t s_da[16 * HS];     // gradient at fc1's output (operand of the last product, and as stored)
+  __shared__ __attribute__((aligned(16))) float s_red[2 * 16 * SL_NW];
+  __shared__ float s_stat[2][16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 15, g = lane >> 4;
+  const int S = a.S, d = a.d, hid = a.hid, C = a.C;
+  const int b0 = blockIdx.x * 16, nrows = (a.B - b0 < 16) ? a.B - b0 : 16;
+  const int NT1 = (hid + 15) / 16, NTD = (d + 15) / 16, KSC = (C + 31) / 32, KSH = (hid + 31) / 32;
+  // ---- requests ----
+  const int gpr = C / 4;                                   // 8-byte pieces per gradient row
+  const float inv_g = 1.0f / (float)gpr;
+  const int gr = (int)(((float)tid + 0.5f) * inv_g), gq = tid - gr * gpr;
+  const bool gok = gr < nrows;
+  const uint2 gin = *(const uint2*)((const uint16_t*)a.g + (long)(b0 + (gok ? gr : 0)) * C + 4 * (gok ? gq : 0));
+  const int pr = tid >> 5, pq = tid & 31;
+  const bool pok = pr < nrows && 8 * pq < hid;
+  const long poff = (long)(b0 + (pr < nrows ? pr : 0)) * hid + (8 * pq < hid ? 8 * pq : 0);
+  const uint4 hin = *(const uint4*)((const uint16_t*)a.h + poff), ain = *(const uint4*)((const uint16_t*)a.a16 + poff);
+  const float stin = ((tid >> 4) == 0 ? a.mean : a.rstd)[b0 + ((tid & 15) < nrows ? (tid & 15) : 0)];
+  float gmv[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) { const int m = 16 * (wave + SL_NW * j) + c; gmv[j] = a.gamma[m < hid ? m : hid - 1]; }
+  WTile<4> wt2[2];
+  WTile<8> wt1;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) { const int t = wave + SL_NW * j; sl_load_tile<4>(wt2[j], (const uint16_t*)a.Wt2, KSC, t < NT1 ? t : NT1 - 1, lane); }
+  sl_load_tile<8>(wt1, (const uint16_t*)a.Wt1, KSH, wave < NTD ? wave : NTD - 1, lane);
+  // ---- staging ----
+  for (int e = tid; e < 16 * XS / 8; e += 64 * SL_NW) ((uint4*)s_g)[e] = uint4{0u, 0u, 0u, 0u};
+  sl_zero_cols(s_da, HS, hid, 256, tid);
+  *(uint4*)(s_h + pr * HS + 8 * pq) = pok ? hin : uint4{0u, 0u, 0u, 0u};
+  *(uint4*)(s_a + pr * HS + 8 * pq) = pok ? ain : uint4{0u, 0u, 0u, 0u};
+  if (tid < 32) s_stat[tid >> 4][tid & 15] = stin;
+  sl_lds_barrier();                                        // (s_g zeroed before the rows go in: same array)
+  if (gok) *(uint2*)(s_g + gr * XS + 4 * gq) = gin;
+  sl_lds_barrier();
+
+  // ---- d_h = g W_2 (bf16), ReLU / dropout backward (h's zeros), LayerNorm backward ----
+  {
+    const slhb_args_ptr la = slhb_late_args();
+    const float p = la->p_drop, ks = p > 0.0f ? 1.0f / (1.0f - p) : 1.0f;
+    float dy[2][4], xh[2][4], rstd[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) rstd[i] = s_stat[1][4 * g + i];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int t = wave + SL_NW * j, m = 16 * t + c;
+      sl_f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+      if (t < NT1) acc = sl_mma_tile<4>(wt2[j], s_g, XS, c, g);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int r = 4 * g + i;
+        const bool live = t < NT1 && m < hid && r < nrows;
+        float gv = sl_round(acc[i]);
+        gv = (live && s_h[r * HS + (live ? m : 0)] != 0) ? sl_round(gv * ks) : 0.0f;
+        dy[j][i] = gv;
+        xh[j][i] = live ? (sl_bf2f(s_a[r * HS + m]) - s_stat[0][r]) * rstd[i] : 0.0f;
+      }
+    }
+    // row means of gamma dy and gamma dy xhat over the hid columns: per-wave partial sums -> LDS -> one barrier
+    float gy[2][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      gy[0][i] = dy[0][i] * gmv[0]; gy[1][i] = dy[1][i] * gmv[1];
+      const float p1 = sl_rowsum(gy[0][i] + gy[1][i]), p2 = sl_rowsum(gy[0][i] * xh[0][i] + gy[1][i] * xh[1][i]);
+      if (c == 0) { s_red[(4 * g + i) * SL_NW + wave] = p1; s_red[(16 + 4 * g + i) * SL_NW + wave] = p2; }
+    }
+    // gamma / beta gradients: column sums over the workgroup's rows
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int m = 16 * (wave + SL_NW * j) + c;
+      float pg = 0.0f, pb = 0.0f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { pg = __builtin_fmaf(dy[j][i], xh[j][i], pg); pb += dy[j][i]; }
+      pg += __shfl_xor(pg, 16, 64); pb += __shfl_xor(pb, 16, 64);
+      pg += __shfl_xor(pg, 32, 64); pb += __shfl_xor(pb, 32, 64);
+      if (g == 0 && m < hid) { unsafeAtomicAdd(la->dgamma + m, pg); unsafeAtomicAdd(la->dbeta + m, pb); }
+    }
+    sl_lds_barrier();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = 4 * g + i;
+      const float4 a0 = *(const float4*)(s_red + r * SL_NW), a1 = *(const float4*)(s_red + r * SL_NW + 4);
+      const float4 c0 = *(const float4*)(s_red + (16 + r) * SL_NW), c1 = *(const float4*)(s_red + (16 + r) * SL_NW + 4);
+      const float s1 = (((a0.x + a0.y) + (a0.z + a0.w)) + ((a1.x + a1.y) + (a1.z + a1.w))) / (float)hid;
+      const float s2 = (((c0.x + c0.y) + (c0.z + c0.w)) + ((c1.x + c1.y) + (c1.z + c1.w))) / (float)hid;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int m = 16 * (wave + SL_NW * j) + c;
+        if (m < hid) s_da[r * HS + m] = r < nrows ? sl_f2bf(rstd[i] * (gy[j][i] - s1 - xh[j][i] * s2)) : (uint16_t)0;
+      }
+    }
+  }
+  sl_lds_barrier();
+  __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
+  { const slhb_args_ptr la = slhb_late_args(); sl_store_rows<2>(la->d_a, s_da, HS, hid, b0, nrows, tid); }
+
+  // ---- gradient of the [CLS] rows: d_a W_1 (bf16) into row b S of the caller's [B S, d] tensor ----
+  {
+    const sl_f32x4 acc = sl_mma_tile<8>(wt1, s_da, HS, c, g);
+    const int n = 16 * wave + c;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) s_g[(4 * g + i) * XS + n] = sl_f2bf(acc[i]);       // (the incoming rows as an operand are dead)
+  }
+  sl_lds_barrier();
+  { const slhb_args_ptr la = slhb_late_args(); sl_store_rows_ld<2, 16>(la->dcls_rows, (long)S * d, s_g, XS, d, (long)b0, nrows, tid); }
+}
+
 }  // namespace opsamd
 
 extern "C" int ops_tfd_encoder_layer_fwd(const ops_tfd_layer_args* a, void* stream) {
@@ -886,6 +1144,32 @@ extern "C" int ops_tfd_encoder_layer_bwd(const ops_tfd_layer_bwd_args* a, void* 
   if (a->g32 && a->g16) hipLaunchKernelGGL((opsamd::tfd_layer_bwd_kernel<true, true>), grid, block, 0, (hipStream_t)stream, *a);
   else if (a->g32) hipLaunchKernelGGL((opsamd::tfd_layer_bwd_kernel<true, false>), grid, block, 0, (hipStream_t)stream, *a);
   else hipLaunchKernelGGL((opsamd::tfd_layer_bwd_kernel<false, true>), grid, block, 0, (hipStream_t)stream, *a);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { opsamd::set_last_error(hipGetErrorString(e)); return OPS_AMD_ERR_LAUNCH; }
+  return OPS_AMD_OK;
+}
+
+extern "C" int ops_tfd_head_fwd(const ops_tfd_head_args* a, void* stream) {
+  if (!a || a->B < 1 || a->S < 1 || a->d < 8 || a->d > 128 || a->d % 8 || a->hid < 16 || a->hid > 256 || a->hid % 8 || a->C < 4 || a->C > 128 || a->C % 4)
+    return OPS_AMD_ERR_UNSUPPORTED;
+  if (!a->y16 || !a->W1 || !a->b1 || !a->gamma || !a->beta || !a->W2 || !a->b2 || !a->counter || !a->a16 || !a->mean || !a->rstd || !a->h || !a->out)
+    return OPS_AMD_ERR_INVALID_ARG;
+  if ((((uintptr_t)a->y16 | (uintptr_t)a->W1 | (uintptr_t)a->W2 | (uintptr_t)a->a16 | (uintptr_t)a->h) & 15) != 0 || ((uintptr_t)a->out & 7) != 0)
+    return OPS_AMD_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(opsamd::tfd_head_fwd_kernel, dim3((unsigned)((a->B + 15) / 16)), dim3(64 * opsamd::SL_NW), 0, (hipStream_t)stream, *a);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { opsamd::set_last_error(hipGetErrorString(e)); return OPS_AMD_ERR_LAUNCH; }
+  return OPS_AMD_OK;
+}
+
+extern "C" int ops_tfd_head_bwd(const ops_tfd_head_bwd_args* a, void* stream) {
+  if (!a || a->B < 1 || a->S < 1 || a->d < 8 || a->d > 128 || a->d % 8 || a->hid < 16 || a->hid > 256 || a->hid % 8 || a->C < 4 || a->C > 128 || a->C % 4)
+    return OPS_AMD_ERR_UNSUPPORTED;
+  if (!a->g || !a->Wt2 || !a->Wt1 || !a->gamma || !a->a16 || !a->mean || !a->rstd || !a->h || !a->d_a || !a->dcls_rows || !a->dgamma || !a->dbeta)
+    return OPS_AMD_ERR_INVALID_ARG;
+  if ((((uintptr_t)a->Wt2 | (uintptr_t)a->Wt1 | (uintptr_t)a->a16 | (uintptr_t)a->h | (uintptr_t)a->d_a | (uintptr_t)a->dcls_rows) & 15) != 0 || ((uintptr_t)a->g & 7) != 0)
+    return OPS_AMD_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(opsamd::tfd_head_bwd_kernel, dim3((unsigned)((a->B + 15) / 16)), dim3(64 * opsamd::SL_NW), 0, (hipStream_t)stream, *a);
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) { opsamd::set_last_error(hipGetErrorString(e)); return OPS_AMD_ERR_LAUNCH; }
   return OPS_AMD_OK;

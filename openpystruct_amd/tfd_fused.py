@@ -27,6 +27,7 @@ ENABLED = os.environ.get("OPS_AMD_TFD_FAST_ENCODER", "1") == "1"      # A/B swit
 LAYER_FWD = os.environ.get("OPS_AMD_TFD_LAYER_FWD", "1") == "1"       # A/B switch: 0 = eight launches per layer forward instead of one
 DRAW = os.environ.get("OPS_AMD_TFD_DRAW", "1") == "1"                 # A/B switch: 0 = diffusion steps / noise from the framework generators
 KEEP_DRAWS = False                                                    # tests: every state keeps its last draws (`_State.draws`)
+HEAD = os.environ.get("OPS_AMD_TFD_HEAD", "1") == "1"                 # A/B switch: 0 = the head as four launches per direction
 LAYER_BWD = os.environ.get("OPS_AMD_TFD_LAYER_BWD", "1") == "1"       # A/B switch: 0 = eight launches per layer backward instead of one
 
 
@@ -310,36 +311,47 @@ class EncoderLayerFn(torch.autograd.Function):
         return dres1, d_x16, None, None, None, None, None
 
 
-def enable_layer_tiles(enc: nn.TransformerEncoder):
-    """Fragment-tiled bf16 copies (plain and transposed: include/openpystruct_amd.h ops_mlp_repack_weights) of the four weight matrices of
-    the encoder's layers, for the one-launch layer kernels.  Returns the ctypes array of repack entries -- hand it to the optimiser
-    (FlatClipAdam.repack: its launch refreshes the copies) and call `refresh_layer_tiles` after anything else changed the parameters --
-    or None when no layer qualifies.  One grouped launch carries 8 matrices: the first two layers."""
-    lib = _cabi.load()
+def _tile_pair(w: torch.Tensor):
     ru = lambda v, m: (v + m - 1) // m * m      # noqa: E731
-    todo = []
-    for layer in enc.layers:
-        if not _layer_ok(layer) or len(todo) + 4 > _cabi.MLP_MAX_WGRAD:
-            break
-        mha = layer.self_attn
-        ws = {"in": mha.in_proj_weight, "out": mha.out_proj.weight, "l1": layer.linear1.weight, "l2": layer.linear2.weight}
-        if not all(w.is_cuda and w.dtype == torch.float32 and w.is_contiguous() for w in ws.values()):
-            break
-        tiles = {}
-        for k, w in ws.items():
-            N, K = w.shape
-            tiles[k] = (torch.zeros(ru(N, 16), ru(K, 32), dtype=torch.bfloat16, device=w.device), torch.zeros(ru(K, 16), ru(N, 32), dtype=torch.bfloat16, device=w.device))
-            todo.append((w, tiles[k]))
-        layer._ops_tiles = tiles
-    if not todo:
-        return None
+    N, K = w.shape
+    return (torch.zeros(ru(N, 16), ru(K, 32), dtype=torch.bfloat16, device=w.device), torch.zeros(ru(K, 16), ru(N, 32), dtype=torch.bfloat16, device=w.device))
+
+
+def _tile_entries(todo):
     ent = (_cabi.MlpRepackEntry * len(todo))()
     for e, (w, (wp, wtp)) in zip(ent, todo):
         e.W, e.N, e.K = w.data_ptr(), w.shape[0], w.shape[1]
         e.Wp, e.ldw, e.Wtp, e.ldwt = wp.data_ptr(), wp.shape[1], wtp.data_ptr(), wtp.shape[1]
-    enc._ops_tile_entries = ent
-    refresh_layer_tiles(enc)
     return ent
+
+
+def enable_layer_tiles(enc: nn.TransformerEncoder, extra=None):
+    """Fragment-tiled bf16 copies (plain and transposed: include/openpystruct_amd.h ops_mlp_repack_weights) of the four weight matrices of
+    the encoder's layers -- and of `extra` = {name: weight} (the model's head), returned tile pairs in `enc._ops_extra_tiles` -- for the
+    one-launch kernels.  Returns the ctypes array of repack entries -- hand it to the optimiser (FlatClipAdam.repack: a launch behind
+    its update rebuilds the copies) and call `refresh_layer_tiles` after anything else changed the parameters -- or None when nothing
+    qualifies.  One optimiser launch carries OPS_MLP_MAX_REPACK = 16 matrices: the first two or three layers + the extras."""
+    todo = []
+    good = lambda w: w.is_cuda and w.dtype == torch.float32 and w.is_contiguous() and w.dim() == 2      # noqa: E731
+    extra = {k: w for k, w in (extra or {}).items() if good(w)}
+    for layer in enc.layers:
+        if not _layer_ok(layer) or len(todo) + 4 + len(extra) > _cabi.MLP_MAX_REPACK:
+            break
+        mha = layer.self_attn
+        ws = {"in": mha.in_proj_weight, "out": mha.out_proj.weight, "l1": layer.linear1.weight, "l2": layer.linear2.weight}
+        if not all(good(w) for w in ws.values()):
+            break
+        tiles = {k: _tile_pair(w) for k, w in ws.items()}
+        todo += [(w, tiles[k]) for k, w in ws.items()]
+        layer._ops_tiles = tiles
+    xt = {k: _tile_pair(w) for k, w in extra.items()}
+    todo += [(w, xt[k]) for k, w in extra.items()]
+    enc._ops_extra_tiles = xt
+    if not todo:
+        return None
+    enc._ops_tile_entries = _tile_entries(todo)
+    refresh_layer_tiles(enc)
+    return enc._ops_tile_entries
 
 
 def share_step_counter(enc: nn.Module, counter: Optional[torch.Tensor]) -> None:
@@ -358,8 +370,12 @@ def refresh_layer_tiles(enc: nn.Module) -> None:
     if ent is None:
         return
     dev = enc.layers[0].linear1.weight.device
+    lib = _cabi.load()
     with torch.cuda.device(dev):
-        _check(_cabi.load().ops_mlp_repack_weights(len(ent), ent, _stream(dev)), "ops_mlp_repack_weights")
+        for i0 in range(0, len(ent), _cabi.MLP_MAX_WGRAD):         # (the stand-alone repack call takes 8 matrices)
+            n = min(_cabi.MLP_MAX_WGRAD, len(ent) - i0)
+            part = (_cabi.MlpRepackEntry * n)(*[ent[i0 + k] for k in range(n)])
+            _check(lib.ops_mlp_repack_weights(n, part, _stream(dev)), "ops_mlp_repack_weights")
 
 
 def _layer_fused_ok(layer: nn.Module, st: _State) -> bool:
@@ -481,6 +497,72 @@ class ClsRows(torch.autograd.Function):
         return full, None, None, None
 
 
+class HeadFn(torch.autograd.Function):
+    """The model's head on the [CLS] rows -- fc1 -> LayerNorm -> ReLU -> dropout -> fc2 (TFD:568-575) -- as one launch per direction
+    (csrc/seq_layer.hip tfd_head_*_kernel; was four + four).  x16 [B S, d] bf16: the last encoder layer's output; returns [B, C] bf16.
+    Backward: the gradient of the [CLS] rows goes into a persistent zero tensor of x16's shape (every other row stays zero), weight /
+    bias gradients where the shadow products send them, LayerNorm gradients straight into their `.grad`."""
+
+    @staticmethod
+    def forward(ctx, x16, model, B, S, st: _State):
+        lib = _cabi.load()
+        r1, r2 = model.fc1._ops_prod.rec, model.fc2._ops_prod.rec
+        tiles = model.transformer_encoder._ops_extra_tiles
+        d, hid, C = x16.shape[1], model.fc1.out_features, model.fc2.out_features
+        dev = x16.device
+        x16 = x16.contiguous()
+        bf, f32 = dict(dtype=torch.bfloat16, device=dev), dict(dtype=torch.float32, device=dev)
+        a16, h, out = torch.empty((B, hid), **bf), torch.empty((B, hid), **bf), torch.empty((B, C), **bf)
+        mean, rstd = torch.empty(B, **f32), torch.empty(B, **f32)
+        used = st.used(103)
+        p = float(model.dropout.p)
+        a = _cabi.TfdHeadArgs(B=B, S=S, d=d, hid=hid, C=C, y16=x16.data_ptr(), W1=tiles["fc1"][0].data_ptr(), b1=r1.b_sh.data_ptr(),
+                              gamma=model.norm1.weight.data_ptr(), beta=model.norm1.bias.data_ptr(), eps=float(model.norm1.eps),
+                              W2=tiles["fc2"][0].data_ptr(), b2=r2.b_sh.data_ptr(), p_drop=p, seed=st.seed + 7919 * 103,
+                              counter=st.counter.data_ptr(), used_call=used.data_ptr(), a16=a16.data_ptr(), mean=mean.data_ptr(),
+                              rstd=rstd.data_ptr(), h=h.data_ptr(), out=out.data_ptr())
+        with torch.cuda.device(dev):
+            _check(lib.ops_tfd_head_fwd(ctypes.byref(a), _stream(dev)), "ops_tfd_head_fwd")
+        ctx.save_for_backward(x16, a16, mean, rstd, h)
+        ctx.cfg = (model, B, S, d, hid, C, p, st, (r1, r2))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        from . import train
+        lib = _cabi.load()
+        x16, a16, mean, rstd, h = ctx.saved_tensors
+        model, B, S, d, hid, C, p, st, (r1, r2) = ctx.cfg
+        tiles = model.transformer_encoder._ops_extra_tiles
+        dev = x16.device
+        g = g.contiguous()
+        if g.dtype != torch.bfloat16:
+            g = g.to(torch.bfloat16)
+        d_a = torch.empty((B, hid), dtype=torch.bfloat16, device=dev)
+        full = st.zeros16((B * S, d))
+        a = _cabi.TfdHeadBwdArgs(B=B, S=S, d=d, hid=hid, C=C, g=g.data_ptr(), Wt2=tiles["fc2"][1].data_ptr(), Wt1=tiles["fc1"][1].data_ptr(),
+                                 gamma=model.norm1.weight.data_ptr(), p_drop=p, a16=a16.data_ptr(), mean=mean.data_ptr(), rstd=rstd.data_ptr(),
+                                 h=h.data_ptr(), d_a=d_a.data_ptr(), dcls_rows=full.data_ptr(), dgamma=model.norm1.weight.grad.data_ptr(),
+                                 dbeta=model.norm1.bias.grad.data_ptr())
+        with torch.cuda.device(dev):
+            _check(lib.ops_tfd_head_bwd(ctypes.byref(a), _stream(dev)), "ops_tfd_head_bwd")
+        train.shadow_param_grads(r2, g, h)
+        train.shadow_param_grads(r1, d_a, x16.view(B, S, d)[:, 0, :])       # (row-strided operand: no copy of the [CLS] rows)
+        return full, None, None, None, None
+
+
+def _head_fused_ok(model: nn.Module, st: _State, d: int) -> bool:
+    enc = model.transformer_encoder
+    if type(model.fc1) is not nn.Linear or type(model.fc2) is not nn.Linear:
+        return False
+    tiles = getattr(enc, "_ops_extra_tiles", None) or {}
+    recs = [getattr(getattr(m, "_ops_prod", None), "rec", None) for m in (model.fc1, model.fc2)]
+    hid, C = model.fc1.out_features, model.fc2.out_features
+    return (HEAD and st.direct and "fc1" in tiles and "fc2" in tiles and all(r is not None and r.b_sh is not None for r in recs) and d % 8 == 0
+            and d <= 128 and 16 <= hid <= 256 and hid % 8 == 0 and 4 <= C <= 128 and C % 4 == 0 and model.fc1.in_features == d
+            and all(t.grad is not None and t.grad.dtype == torch.float32 and t.grad.is_contiguous() for t in (model.norm1.weight, model.norm1.bias)))
+
+
 def model_forward(model: nn.Module, x: torch.Tensor, st: _State) -> torch.Tensor:
     """ModelOnePassTransformerWithDiffusion.forward (TFD:539-575) for the training step: diffusion arithmetic in two launches around
     the MLP's shadow products, the patched encoder, the head's LayerNorm / ReLU / dropout in two.  The random step indices and the
@@ -516,6 +598,9 @@ def model_forward(model: nn.Module, x: torch.Tensor, st: _State) -> torch.Tensor
     z, z16 = DiffusionCombine.apply(m, xn32, sa, sb, model.cls_token, model.pos_encoder.pe, B, Nc, st)
     st.src16, st.last16 = z16, None                                                # handed to / by the patched encoder pass below
     z = model.transformer_encoder(z)
+    if st.last16 is not None and model.transformer_encoder.norm is None and _head_fused_ok(model, st, d):
+        last16, st.last16 = st.last16, None
+        return HeadFn.apply(last16, model, B, Nc + 1, st)                         # the whole head: one launch
     if st.last16 is not None and model.transformer_encoder.norm is None:
         from . import train
         train.set_next_input_grad_dest(st.zeros16((B * (Nc + 1), d)).view(B, Nc + 1, d)[:, 0, :])   # fc1's input gradient lands in the [CLS] rows
@@ -543,6 +628,9 @@ def patch_model(model: nn.Module, seed: int, direct_param_grads: bool = False) -
           and model.fc1.out_features <= 256 and model.pos_encoder.pe.shape[-1] == model.feat_dim)
     if not ok:
         return True                       # the encoder alone
+    if LAYER_FWD and HEAD and "forward" in model.fc2.__dict__:
+        # the head's two weight matrices join the layers' tiled copies (one-launch head: HeadFn)
+        enable_layer_tiles(model.transformer_encoder, extra={"fc1": model.fc1.weight, "fc2": model.fc2.weight})
     # ONE dropout stream for the model and its encoder: the encoder pass advances the call counter once per step (one captured
     # add_), and the head's dropout (site 103, drawn after the encoder) reads the same counter -- a state of its own that nothing
     # advanced gave it the same mask in every step of a run
@@ -602,6 +690,7 @@ def unpatch_encoder(enc: nn.Module) -> None:
         del enc.__dict__["forward"]
     enc.__dict__.pop("_ops_dropout_state", None)
     enc.__dict__.pop("_ops_tile_entries", None)
+    enc.__dict__.pop("_ops_extra_tiles", None)
     enc.__dict__.pop("_ops_step_counter", None)
     for layer in getattr(enc, "layers", []):
         layer.__dict__.pop("_ops_tiles", None)

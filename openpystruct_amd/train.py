@@ -338,7 +338,9 @@ def shadow_param_grads(rec: ShadowRec, g2: torch.Tensor, x2: torch.Tensor) -> No
     library's product into the stash otherwise."""
     if rec.w_grad is not None and x2.shape[0] >= _SPLIT_WGRAD_ROWS and _SPLIT_WGRAD_ROWS > 0:
         from . import _cabi
-        g2, x2c = g2.contiguous(), x2.contiguous()
+        g2 = g2.contiguous()
+        rows_ok = _WGRAD_QUEUE is not None and x2.dim() == 2 and x2.stride(1) == 1 and x2.stride(0) >= x2.shape[1]
+        x2c = x2 if rows_ok else x2.contiguous()          # (row-strided operands: the grouped launch takes the stride)
         fused_bias = rec.ib is not None and rec.b_grad is not None
         if _WGRAD_QUEUE is not None:
             _WGRAD_QUEUE.append((g2, x2c, rec.w_grad, rec.b_grad if fused_bias else None))

@@ -562,3 +562,83 @@ def test_fast_path_gradients_against_float64_autograd(monkeypatch, B):
     # bound: every parameter within 3e-2 of float64 OR no worse than 1.25 x the framework's own bf16 evaluation + 1e-2
     bad = {n: (e, e_auto[n]) for n, e in worst.items() if not (np.isfinite(e) and (e <= 3e-2 or e <= 1.25 * e_auto[n] + 1e-2))}
     assert not bad, bad
+
+
+def _tiled_pair(lib, W):
+    from openpystruct_amd import _cabi
+    N, K = W.shape
+    ru = lambda v, m: (v + m - 1) // m * m      # noqa: E731
+    wp = torch.zeros(ru(N, 16), ru(K, 32), dtype=torch.bfloat16, device=W.device)
+    wtp = torch.zeros(ru(K, 16), ru(N, 32), dtype=torch.bfloat16, device=W.device)
+    ent = (_cabi.MlpRepackEntry * 1)()
+    ent[0].W, ent[0].N, ent[0].K, ent[0].Wp, ent[0].ldw, ent[0].Wtp, ent[0].ldwt = W.data_ptr(), N, K, wp.data_ptr(), wp.shape[1], wtp.data_ptr(), wtp.shape[1]
+    assert lib.ops_mlp_repack_weights(1, ent, torch.cuda.current_stream().cuda_stream) == 0
+    torch.cuda.synchronize()
+    return wp, wtp
+
+
+@pytest.mark.parametrize("B,S,d,hid,C,p", [(512, 7, 120, 256, 100, 0.0), (37, 7, 120, 256, 100, 0.3), (5, 3, 64, 72, 12, 0.0)])
+def test_one_launch_head_against_the_framework_ops(B, S, d, hid, C, p):
+    """csrc/seq_layer.hip tfd_head_fwd / _bwd (fc1 -> LayerNorm -> ReLU -> dropout -> fc2 on the [CLS] rows, TFD:568-575) against the
+    same chain of framework ops with the launch's own dropout mask (read off h): outputs, every saved tensor, the gradient of the [CLS]
+    rows (and zeros everywhere else), d_a, gamma / beta gradients; with p > 0: keep fraction, another mask for another counter value."""
+    import ctypes
+    from openpystruct_amd import _cabi
+    lib = _cabi.load()
+    dev = torch.device(DEV)
+    g = torch.Generator().manual_seed(B + hid)
+    y16 = torch.randn(B * S, d, generator=g).to(torch.bfloat16).to(dev)
+    W1, W2 = (torch.randn(hid, d, generator=g) * 0.1).to(dev), (torch.randn(C, hid, generator=g) * 0.1).to(dev)
+    b1, b2 = (torch.randn(hid, generator=g) * 0.1).to(torch.bfloat16).to(dev), (torch.randn(C, generator=g) * 0.1).to(torch.bfloat16).to(dev)
+    gamma, beta = (1 + 0.1 * torch.randn(hid, generator=g)).to(dev), (0.1 * torch.randn(hid, generator=g)).to(dev)
+    (W1p, W1t), (W2p, W2t) = _tiled_pair(lib, W1), _tiled_pair(lib, W2)
+    cnt, used = torch.zeros(2, dtype=torch.int64, device=dev), torch.zeros(1, dtype=torch.int64, device=dev)
+    bf = dict(dtype=torch.bfloat16, device=dev)
+    s = torch.cuda.current_stream().cuda_stream
+
+    def fwd():
+        a16, h, out = torch.empty(B, hid, **bf), torch.empty(B, hid, **bf), torch.empty(B, C, **bf)
+        mean, rstd = torch.empty(B, device=dev), torch.empty(B, device=dev)
+        a = _cabi.TfdHeadArgs(B=B, S=S, d=d, hid=hid, C=C, y16=y16.data_ptr(), W1=W1p.data_ptr(), b1=b1.data_ptr(), gamma=gamma.data_ptr(),
+                              beta=beta.data_ptr(), eps=1e-5, W2=W2p.data_ptr(), b2=b2.data_ptr(), p_drop=p, seed=5, counter=cnt.data_ptr(),
+                              used_call=used.data_ptr(), a16=a16.data_ptr(), mean=mean.data_ptr(), rstd=rstd.data_ptr(), h=h.data_ptr(), out=out.data_ptr())
+        assert lib.ops_tfd_head_fwd(ctypes.byref(a), s) == 0
+        torch.cuda.synchronize()
+        return a16, mean, rstd, h, out
+
+    a16, mean, rstd, h, out = fwd()
+    x = y16.view(B, S, d)[:, 0, :].float().requires_grad_()
+    W1r, W2r = W1.to(torch.bfloat16).float(), W2.to(torch.bfloat16).float()
+    gr, br = gamma.clone().requires_grad_(), beta.clone().requires_grad_()
+    ar = (x @ W1r.t() + b1.float())
+    a_b = ar + (ar.to(torch.bfloat16).float() - ar).detach()                 # bf16 rounding, straight-through
+    yr = torch.nn.functional.layer_norm(a_b, (hid,), gr, br, 1e-5)
+    y_b = yr + (yr.to(torch.bfloat16).float() - yr).detach()
+    keep = (h.float() != 0) | (y_b.detach() <= 0)                              # where ReLU passed, h's zeros are the dropout's
+    hr = torch.relu(y_b) * keep / (1.0 - p)
+    h_b = hr + (hr.to(torch.bfloat16).float() - hr).detach()
+    outr = h_b @ W2r.t() + b2.float()
+    assert _rel(a16.float(), a_b) < 1e-4 and _rel(mean, a_b.mean(1)) < 1e-4 and _rel(rstd, (a_b.var(1, unbiased=False) + 1e-5).rsqrt()) < 1e-4
+    assert _rel(h.float(), h_b) < 3e-3 and _rel(out.float(), outr) < 4e-3
+    if p > 0:
+        pos = y_b.detach() > 0
+        assert abs(float((h.float() != 0)[pos].float().mean()) - (1 - p)) < 0.02
+        cnt[0] += 1
+        h2 = fwd()[3]
+        assert float(((h2.float() != 0) != (h.float() != 0))[pos].float().mean()) > 0.2
+        cnt[0] -= 1
+    # backward
+    go = (torch.randn(B, C, generator=g) * 0.1).to(torch.bfloat16).to(dev)
+    d_a, full = torch.empty(B, hid, **bf), torch.zeros(B * S, d, **bf)
+    dg, db = torch.zeros(hid, device=dev), torch.zeros(hid, device=dev)
+    ab = _cabi.TfdHeadBwdArgs(B=B, S=S, d=d, hid=hid, C=C, g=go.data_ptr(), Wt2=W2t.data_ptr(), Wt1=W1t.data_ptr(), gamma=gamma.data_ptr(), p_drop=p,
+                              a16=a16.data_ptr(), mean=mean.data_ptr(), rstd=rstd.data_ptr(), h=h.data_ptr(), d_a=d_a.data_ptr(), dcls_rows=full.data_ptr(),
+                              dgamma=dg.data_ptr(), dbeta=db.data_ptr())
+    assert lib.ops_tfd_head_bwd(ctypes.byref(ab), s) == 0
+    torch.cuda.synchronize()
+    a_b.retain_grad()
+    (outr * go.float()).sum().backward()
+    assert _rel(d_a.float(), a_b.grad) < 1.5e-2
+    assert _rel(full.view(B, S, d)[:, 0, :].float(), x.grad) < 1.5e-2
+    assert float(full.view(B, S, d)[:, 1:, :].float().abs().max()) == 0.0 if S > 1 else True
+    assert _rel(dg, gr.grad) < 1.5e-2 and _rel(db, br.grad) < 1.5e-2
