@@ -528,6 +528,30 @@ typedef struct ops_tfd_head_bwd_args {
 } ops_tfd_head_bwd_args;
 int ops_tfd_head_bwd(const ops_tfd_head_bwd_args* args, void* stream);
 
+/* The diffusion front end of the Transformer-Diffusion model (TransformerDiffusionModule_MultiCase.py:443-478, :563-567) as one launch
+ * per direction: step indices and noise drawn in the launch (ops_diffusion_noise_draw's stream), x_noisy, the two-layer MLP
+ * m = W_2 relu(W_0 x_noisy + b_0) + b_2 on bf16 MFMA (fragment-tiled weights: Wp forward, Wtp of W_2 backward), and the combine
+ * z[b, 0] = cls + pe[0], z[b, 1 + n] = (x_noisy - sb m) / sa + pe[1 + n] (float32 AND bfloat16).  rows = B Nc, d <= 128, hid <= 256
+ * (multiples of 8).  Saved for the backward launch / the weight-gradient products: xn16, h, sa, sb.  Backward: g32 + g16 [B, 1 + Nc, d]
+ * (either may be NULL) -> dm [rows, d] = -(sb / sa) g[:, 1:, :] and d_h [rows, hid] = relu'(h) (dm W_2), both bfloat16; dcls [d] +=
+ * column sums of g[:, 0, :] (float atomics; may be NULL). */
+typedef struct ops_tfd_front_args {
+  int32_t B, Nc, d, hid, T;
+  const float* x; const float* alpha_cumprod;
+  unsigned long long seed; const unsigned long long* counter;
+  const void* W0; const void* b0; const void* W2; const void* b2;
+  const float* cls; const float* pe;
+  void* xn16; void* h; float* sa; float* sb; float* z; void* z16;
+  long long* t_out; float* eps_out;
+} ops_tfd_front_args;
+int ops_tfd_front_fwd(const ops_tfd_front_args* args, void* stream);
+typedef struct ops_tfd_front_bwd_args {
+  int32_t B, Nc, d, hid;
+  const float* g32; const void* g16; const float* sa; const float* sb; const void* h; const void* Wt2;
+  void* dm; void* d_h; float* dcls;
+} ops_tfd_front_bwd_args;
+int ops_tfd_front_bwd(const ops_tfd_front_bwd_args* args, void* stream);
+
 /* Measurement aid of bench.py, not a product call: device-to-device copy of `bytes` (a multiple of 16, both pointers 16-byte
  * aligned) with one 16-byte access per lane and instruction -- the achievable HBM rate the roofline records quote next to the
  * nominal 8 TB/s.  non_temporal != 0: nt stores. */

@@ -68,6 +68,8 @@ EXPORTS = (
     "ops_tfd_encoder_layer_bwd",
     "ops_tfd_head_fwd",
     "ops_tfd_head_bwd",
+    "ops_tfd_front_fwd",
+    "ops_tfd_front_bwd",
 )
 
 OK, ERR_INVALID_ARG, ERR_UNSUPPORTED, ERR_LAUNCH = 0, 1, 2, 3
@@ -163,6 +165,21 @@ class TfdHeadBwdArgs(ctypes.Structure):
                 ("a16", _vp), ("mean", _vp), ("rstd", _vp), ("h", _vp), ("d_a", _vp), ("dcls_rows", _vp), ("dgamma", _vp), ("dbeta", _vp)]
 
 
+class TfdFrontArgs(ctypes.Structure):
+    """Mirror of `ops_tfd_front_args`."""
+    _vp, _i, _u = ctypes.c_void_p, ctypes.c_int32, ctypes.c_ulonglong
+    _fields_ = [("B", _i), ("Nc", _i), ("d", _i), ("hid", _i), ("T", _i), ("x", _vp), ("alpha_cumprod", _vp), ("seed", _u), ("counter", _vp),
+                ("W0", _vp), ("b0", _vp), ("W2", _vp), ("b2", _vp), ("cls", _vp), ("pe", _vp),
+                ("xn16", _vp), ("h", _vp), ("sa", _vp), ("sb", _vp), ("z", _vp), ("z16", _vp), ("t_out", _vp), ("eps_out", _vp)]
+
+
+class TfdFrontBwdArgs(ctypes.Structure):
+    """Mirror of `ops_tfd_front_bwd_args`."""
+    _vp, _i = ctypes.c_void_p, ctypes.c_int32
+    _fields_ = [("B", _i), ("Nc", _i), ("d", _i), ("hid", _i), ("g32", _vp), ("g16", _vp), ("sa", _vp), ("sb", _vp), ("h", _vp), ("Wt2", _vp),
+                ("dm", _vp), ("d_h", _vp), ("dcls", _vp)]
+
+
 WGRAD_MAX_GROUP = 16
 
 
@@ -222,6 +239,10 @@ def load():
     lib.ops_tfd_head_fwd.argtypes = [ctypes.POINTER(TfdHeadArgs), vp]
     lib.ops_tfd_head_bwd.restype = it
     lib.ops_tfd_head_bwd.argtypes = [ctypes.POINTER(TfdHeadBwdArgs), vp]
+    lib.ops_tfd_front_fwd.restype = it
+    lib.ops_tfd_front_fwd.argtypes = [ctypes.POINTER(TfdFrontArgs), vp]
+    lib.ops_tfd_front_bwd.restype = it
+    lib.ops_tfd_front_bwd.argtypes = [ctypes.POINTER(TfdFrontBwdArgs), vp]
     lib.ops_hbm_copy16.restype = it
     lib.ops_hbm_copy16.argtypes = [vp, vp, ctypes.c_size_t, it, vp]
     fr = lib.ops_frame_solve_batched_f64

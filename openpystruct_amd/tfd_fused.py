@@ -27,6 +27,7 @@ ENABLED = os.environ.get("OPS_AMD_TFD_FAST_ENCODER", "1") == "1"      # A/B swit
 LAYER_FWD = os.environ.get("OPS_AMD_TFD_LAYER_FWD", "1") == "1"       # A/B switch: 0 = eight launches per layer forward instead of one
 DRAW = os.environ.get("OPS_AMD_TFD_DRAW", "1") == "1"                 # A/B switch: 0 = diffusion steps / noise from the framework generators
 KEEP_DRAWS = False                                                    # tests: every state keeps its last draws (`_State.draws`)
+FRONT = os.environ.get("OPS_AMD_TFD_FRONT", "1") == "1"               # A/B switch: 0 = the diffusion front end as five + three launches
 HEAD = os.environ.get("OPS_AMD_TFD_HEAD", "1") == "1"                 # A/B switch: 0 = the head as four launches per direction
 LAYER_BWD = os.environ.get("OPS_AMD_TFD_LAYER_BWD", "1") == "1"       # A/B switch: 0 = eight launches per layer backward instead of one
 
@@ -497,6 +498,89 @@ class ClsRows(torch.autograd.Function):
         return full, None, None, None
 
 
+class FrontFn(torch.autograd.Function):
+    """The diffusion front end (TFD:443-478, :563-567) as one launch per direction (csrc/seq_layer.hip tfd_front_*_kernel): draws,
+    x_noisy, the two-layer MLP on the tiled weights, the combine with the [CLS] token and the positional encoding.  x [B, Nc, d]
+    float32 -> (z [B, 1 + Nc, d] float32, z16 [B (1 + Nc), d] bfloat16).  Backward: one launch; the MLP's weight / bias gradients where
+    the shadow products send them, the [CLS] token's gradient by float atomics."""
+
+    @staticmethod
+    def forward(ctx, x, anchor, model, st: _State):
+        # `anchor` (the [CLS] token Parameter) is not read through autograd: it makes the engine record the node although x needs no
+        # gradient; its gradient slot stays None -- dcls goes into cls_token.grad by the launch's atomics
+        lib = _cabi.load()
+        dm = model.diffusion
+        B, Nc, d = x.shape
+        hid = dm.mlp[0].out_features
+        r0, r2 = dm.mlp[0]._ops_prod.rec, dm.mlp[2]._ops_prod.rec
+        tiles = model.transformer_encoder._ops_extra_tiles
+        dev = x.device
+        x = x.contiguous()
+        rows = B * Nc
+        bf, f32 = dict(dtype=torch.bfloat16, device=dev), dict(dtype=torch.float32, device=dev)
+        xn16, h = torch.empty((rows, d), **bf), torch.empty((rows, hid), **bf)
+        sa, sb = torch.empty(rows, **f32), torch.empty(rows, **f32)
+        z, z16 = torch.empty((B, Nc + 1, d), **f32), torch.empty((B * (Nc + 1), d), **bf)
+        keep = st.keep_draws or KEEP_DRAWS
+        t = torch.empty(rows, dtype=torch.int64, device=dev) if keep else None
+        eps = torch.empty((rows, d), **f32) if keep else None
+        a = _cabi.TfdFrontArgs(B=B, Nc=Nc, d=d, hid=hid, T=int(dm.T), x=x.data_ptr(), alpha_cumprod=dm._acp.data_ptr(), seed=st.seed + 7919 * 100,
+                               counter=st.counter.data_ptr(), W0=tiles["mlp0"][0].data_ptr(), b0=r0.b_sh.data_ptr(), W2=tiles["mlp2"][0].data_ptr(),
+                               b2=r2.b_sh.data_ptr(), cls=model.cls_token.data_ptr(), pe=model.pos_encoder.pe.data_ptr(), xn16=xn16.data_ptr(),
+                               h=h.data_ptr(), sa=sa.data_ptr(), sb=sb.data_ptr(), z=z.data_ptr(), z16=z16.data_ptr(),
+                               t_out=t.data_ptr() if keep else None, eps_out=eps.data_ptr() if keep else None)
+        with torch.cuda.device(dev):
+            _check(lib.ops_tfd_front_fwd(ctypes.byref(a), _stream(dev)), "ops_tfd_front_fwd")
+        if keep:
+            st.draws = (t.view(B, Nc), eps.view(B, Nc, d))
+        ctx.save_for_backward(xn16, h, sa, sb)
+        ctx.cfg = (model, B, Nc, d, hid, st, (r0, r2))
+        ctx.set_materialize_grads(False)
+        return z, z16
+
+    @staticmethod
+    def backward(ctx, g, g16):
+        if g is None and g16 is None:
+            return None, None, None, None
+        from . import train
+        lib = _cabi.load()
+        xn16, h, sa, sb = ctx.saved_tensors
+        model, B, Nc, d, hid, st, (r0, r2) = ctx.cfg
+        tiles = model.transformer_encoder._ops_extra_tiles
+        dev = xn16.device
+        if g is not None:
+            g = g.contiguous().float()
+        if g16 is not None:
+            g16 = g16.contiguous()
+            if g16.dtype != torch.bfloat16:
+                g16 = g16.to(torch.bfloat16)
+        rows = B * Nc
+        dm_, d_h = torch.empty((rows, d), dtype=torch.bfloat16, device=dev), torch.empty((rows, hid), dtype=torch.bfloat16, device=dev)
+        cls = model.cls_token
+        a = _cabi.TfdFrontBwdArgs(B=B, Nc=Nc, d=d, hid=hid, g32=g.data_ptr() if g is not None else None, g16=g16.data_ptr() if g16 is not None else None,
+                                  sa=sa.data_ptr(), sb=sb.data_ptr(), h=h.data_ptr(), Wt2=tiles["mlp2"][1].data_ptr(), dm=dm_.data_ptr(), d_h=d_h.data_ptr(),
+                                  dcls=cls.grad.data_ptr())
+        with torch.cuda.device(dev):
+            _check(lib.ops_tfd_front_bwd(ctypes.byref(a), _stream(dev)), "ops_tfd_front_bwd")
+        train.shadow_param_grads(r2, dm_, h)
+        train.shadow_param_grads(r0, d_h, xn16)
+        return None, None, None, None
+
+
+def _front_fused_ok(model: nn.Module, st: _State, d: int) -> bool:
+    mlp = model.diffusion.mlp
+    tiles = getattr(model.transformer_encoder, "_ops_extra_tiles", None) or {}
+    if not (FRONT and DRAW and st.direct and "mlp0" in tiles and "mlp2" in tiles and type(mlp[0]) is nn.Linear and type(mlp[2]) is nn.Linear):
+        return False
+    recs = [getattr(getattr(m, "_ops_prod", None), "rec", None) for m in (mlp[0], mlp[2])]
+    hid = mlp[0].out_features
+    cls = model.cls_token
+    return (all(r is not None and r.b_sh is not None for r in recs) and d % 8 == 0 and d <= 128 and 16 <= hid <= 256 and hid % 8 == 0
+            and mlp[0].in_features == d and mlp[2].out_features == d and cls.dtype == torch.float32 and cls.is_contiguous() and cls.numel() == d
+            and cls.grad is not None and cls.grad.dtype == torch.float32 and cls.grad.is_contiguous()
+            and model.pos_encoder.pe.dtype == torch.float32 and model.pos_encoder.pe.is_contiguous())
+
+
 class HeadFn(torch.autograd.Function):
     """The model's head on the [CLS] rows -- fc1 -> LayerNorm -> ReLU -> dropout -> fc2 (TFD:568-575) -- as one launch per direction
     (csrc/seq_layer.hip tfd_head_*_kernel; was four + four).  x16 [B S, d] bf16: the last encoder layer's output; returns [B, C] bf16.
@@ -573,6 +657,9 @@ def model_forward(model: nn.Module, x: torch.Tensor, st: _State) -> torch.Tensor
     B, Nc, d = x.shape
     dm = model.diffusion
     x = x.contiguous()
+    if _front_fused_ok(model, st, d):
+        z, z16 = FrontFn.apply(x, model.cls_token, model, st)                                      # draws, x_noisy, MLP, combine: one launch
+        return _model_tail(model, z, z16, st, B, Nc, d)
     rows = B * Nc
     xn32 = torch.empty((rows, d), dtype=torch.float32, device=x.device)
     xn16 = torch.empty((rows, d), dtype=torch.bfloat16, device=x.device)
@@ -596,6 +683,11 @@ def model_forward(model: nn.Module, x: torch.Tensor, st: _State) -> torch.Tensor
     h = ActDropout.apply(dm.mlp[0](xn16), 0.0, 0.0, st, 101)                      # ReLU
     m = dm.mlp[2](h)
     z, z16 = DiffusionCombine.apply(m, xn32, sa, sb, model.cls_token, model.pos_encoder.pe, B, Nc, st)
+    return _model_tail(model, z, z16, st, B, Nc, d)
+
+
+def _model_tail(model: nn.Module, z: torch.Tensor, z16: torch.Tensor, st: _State, B: int, Nc: int, d: int) -> torch.Tensor:
+    """Encoder + head behind the front end."""
     st.src16, st.last16 = z16, None                                                # handed to / by the patched encoder pass below
     z = model.transformer_encoder(z)
     if st.last16 is not None and model.transformer_encoder.norm is None and _head_fused_ok(model, st, d):
@@ -630,7 +722,7 @@ def patch_model(model: nn.Module, seed: int, direct_param_grads: bool = False) -
         return True                       # the encoder alone
     if LAYER_FWD and HEAD and "forward" in model.fc2.__dict__:
         # the head's two weight matrices join the layers' tiled copies (one-launch head: HeadFn)
-        enable_layer_tiles(model.transformer_encoder, extra={"fc1": model.fc1.weight, "fc2": model.fc2.weight})
+        enable_layer_tiles(model.transformer_encoder, extra={"fc1": model.fc1.weight, "fc2": model.fc2.weight, "mlp0": mlp[0].weight, "mlp2": mlp[2].weight})
     # ONE dropout stream for the model and its encoder: the encoder pass advances the call counter once per step (one captured
     # add_), and the head's dropout (site 103, drawn after the encoder) reads the same counter -- a state of its own that nothing
     # advanced gave it the same mask in every step of a run

@@ -642,3 +642,62 @@ def test_one_launch_head_against_the_framework_ops(B, S, d, hid, C, p):
     assert _rel(full.view(B, S, d)[:, 0, :].float(), x.grad) < 1.5e-2
     assert float(full.view(B, S, d)[:, 1:, :].float().abs().max()) == 0.0 if S > 1 else True
     assert _rel(dg, gr.grad) < 1.5e-2 and _rel(db, br.grad) < 1.5e-2
+
+
+@pytest.mark.parametrize("B,Nc,d,hid", [(512, 6, 120, 256), (37, 6, 120, 256), (5, 3, 64, 72)])
+def test_one_launch_front_end_against_the_framework_ops(B, Nc, d, hid):
+    """csrc/seq_layer.hip tfd_front_fwd / _bwd (draws, x_noisy, the diffusion MLP, the combine with [CLS] token and positional encoding:
+    TFD:443-478, :563-567) against the same chain of framework ops on the draws the launch reports; backward against autograd."""
+    import ctypes
+    from openpystruct_amd import _cabi
+    lib = _cabi.load()
+    dev = torch.device(DEV)
+    S, T, rows = Nc + 1, 300, B * Nc
+    g = torch.Generator().manual_seed(B + d)
+    x = torch.randn(B, Nc, d, generator=g).to(dev)
+    acp = torch.cumprod(1.0 - torch.linspace(1e-4, 0.02, T), 0).to(dev)
+    W0, W2 = (torch.randn(hid, d, generator=g) * 0.1).to(dev), (torch.randn(d, hid, generator=g) * 0.1).to(dev)
+    b0, b2 = (torch.randn(hid, generator=g) * 0.1).to(torch.bfloat16).to(dev), (torch.randn(d, generator=g) * 0.1).to(torch.bfloat16).to(dev)
+    cls, pe = torch.randn(d, generator=g).to(dev), torch.randn(16, d, generator=g).to(dev)
+    (W0p, _), (W2p, W2t) = _tiled_pair(lib, W0), _tiled_pair(lib, W2)
+    cnt = torch.zeros(2, dtype=torch.int64, device=dev)
+    bf = dict(dtype=torch.bfloat16, device=dev)
+    s = torch.cuda.current_stream().cuda_stream
+    xn16, h = torch.empty(rows, d, **bf), torch.empty(rows, hid, **bf)
+    sa, sb = torch.empty(rows, device=dev), torch.empty(rows, device=dev)
+    z, z16 = torch.empty(B, S, d, device=dev), torch.empty(B * S, d, **bf)
+    t, eps = torch.empty(rows, dtype=torch.int64, device=dev), torch.empty(rows, d, device=dev)
+    a = _cabi.TfdFrontArgs(B=B, Nc=Nc, d=d, hid=hid, T=T, x=x.data_ptr(), alpha_cumprod=acp.data_ptr(), seed=77, counter=cnt.data_ptr(), W0=W0p.data_ptr(),
+                           b0=b0.data_ptr(), W2=W2p.data_ptr(), b2=b2.data_ptr(), cls=cls.data_ptr(), pe=pe.data_ptr(), xn16=xn16.data_ptr(), h=h.data_ptr(),
+                           sa=sa.data_ptr(), sb=sb.data_ptr(), z=z.data_ptr(), z16=z16.data_ptr(), t_out=t.data_ptr(), eps_out=eps.data_ptr())
+    assert lib.ops_tfd_front_fwd(ctypes.byref(a), s) == 0
+    torch.cuda.synchronize()
+    assert int(t.min()) >= 0 and int(t.max()) < T
+    if rows * d > 100000:
+        assert abs(float(eps.mean())) < 0.01 and abs(float(eps.std()) - 1.0) < 0.01
+    torch.testing.assert_close(sa, acp[t].sqrt(), rtol=1e-6, atol=0)
+    xn = sa[:, None] * x.reshape(rows, d) + sb[:, None] * eps
+    assert torch.equal(xn16, xn.to(torch.bfloat16)) or _rel(xn16.float(), xn) < 3e-3
+    W0r, W2r = W0.to(torch.bfloat16).float(), W2.to(torch.bfloat16).float()
+    hr = torch.relu((xn16.float() @ W0r.t() + b0.float()).to(torch.bfloat16).float())
+    assert _rel(h.float(), hr) < 2e-3
+    mr = (h.float() @ W2r.t() + b2.float()).to(torch.bfloat16).float()
+    zr = torch.empty(B, S, d, device=dev)
+    zr[:, 0, :] = cls + pe[0]
+    zr[:, 1:, :] = ((xn - sb[:, None] * mr) / sa[:, None]).view(B, Nc, d) + pe[1:S]
+    assert _rel(z, zr) < 2e-3 and float((z[:, 0, :] - zr[:, 0, :]).abs().max()) == 0.0
+    assert torch.equal(z16, z.reshape(B * S, d).to(torch.bfloat16))
+    # backward: g32 and g16 together
+    g32 = torch.randn(B, S, d, generator=g).to(dev)
+    g16 = (torch.randn(B * S, d, generator=g) * 0.5).to(torch.bfloat16).to(dev)
+    dm, d_h, dcls = torch.empty(rows, d, **bf), torch.empty(rows, hid, **bf), torch.zeros(d, device=dev)
+    ab = _cabi.TfdFrontBwdArgs(B=B, Nc=Nc, d=d, hid=hid, g32=g32.data_ptr(), g16=g16.data_ptr(), sa=sa.data_ptr(), sb=sb.data_ptr(), h=h.data_ptr(),
+                               Wt2=W2t.data_ptr(), dm=dm.data_ptr(), d_h=d_h.data_ptr(), dcls=dcls.data_ptr())
+    assert lib.ops_tfd_front_bwd(ctypes.byref(ab), s) == 0
+    torch.cuda.synchronize()
+    gt = g32 + g16.float().view(B, S, d)
+    dmr = (-(sb / sa)[:, None] * gt[:, 1:, :].reshape(rows, d)).to(torch.bfloat16)
+    assert torch.equal(dm, dmr) or _rel(dm.float(), dmr.float()) < 3e-3
+    dhr = ((dm.float() @ W2r).to(torch.bfloat16).float() * (h.float() > 0))
+    assert _rel(d_h.float(), dhr) < 3e-3
+    assert _rel(dcls, gt[:, 0, :].sum(0)) < 1e-5
