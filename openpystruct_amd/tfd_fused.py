@@ -27,6 +27,7 @@ ENABLED = os.environ.get("OPS_AMD_TFD_FAST_ENCODER", "1") == "1"      # A/B swit
 LAYER_FWD = os.environ.get("OPS_AMD_TFD_LAYER_FWD", "1") == "1"       # A/B switch: 0 = eight launches per layer forward instead of one
 DRAW = os.environ.get("OPS_AMD_TFD_DRAW", "1") == "1"                 # A/B switch: 0 = diffusion steps / noise from the framework generators
 KEEP_DRAWS = False                                                    # tests: every state keeps its last draws (`_State.draws`)
+EVAL_FAST = os.environ.get("OPS_AMD_TFD_EVAL_FAST", "1") == "1"       # A/B switch: 0 = validation passes through the module's own forward
 FRONT = os.environ.get("OPS_AMD_TFD_FRONT", "1") == "1"               # A/B switch: 0 = the diffusion front end as five + three launches
 HEAD = os.environ.get("OPS_AMD_TFD_HEAD", "1") == "1"                 # A/B switch: 0 = the head as four launches per direction
 LAYER_BWD = os.environ.get("OPS_AMD_TFD_LAYER_BWD", "1") == "1"       # A/B switch: 0 = eight launches per layer backward instead of one
@@ -48,12 +49,13 @@ class _State:
         self._zeros16 = {}
         self.src16 = None        # bf16 copy of the encoder's input, handed over by the model's front end (DiffusionCombine)
         self.last16 = None       # bf16 copy of the encoder's output rows [T, d], for the model's head
+        self.train_mode = True   # False: an evaluation pass through the one-launch kernels (every dropout probability 0)
         self.keep_draws = False  # tests: keep the front end's draws (t [B, Nc], eps [B, Nc, d]) of the last pass in `draws`
         self.draws = None
 
     def advance(self) -> None:
-        if not self.external:
-            self.counter.add_(1)
+        if not self.external or not self.train_mode:        # (an evaluation pass has no batch-assembly launch in front of it)
+            self.counter[0:1].add_(1)
 
     def zeros(self, shape) -> torch.Tensor:
         """A persistent float32 zero tensor (the `residual` of a plain LayerNorm through the dropout + add + LayerNorm launch)."""
@@ -230,7 +232,7 @@ class EncoderLayerFn(torch.autograd.Function):
         y32, y16 = torch.empty((T, d), **f32), torch.empty((T, d), **bf)
         used = st.used(4 * li)
         seeds = [st.seed + 7919 * (4 * li + k) for k in range(4)]
-        ps = (float(mha.dropout), float(layer.dropout1.p), float(layer.dropout.p), float(layer.dropout2.p))
+        ps = (float(mha.dropout), float(layer.dropout1.p), float(layer.dropout.p), float(layer.dropout2.p)) if st.train_mode else (0.0, 0.0, 0.0, 0.0)
         a = _cabi.TfdLayerArgs(
             Bn=Bn, S=S, H=H, dh=dh, d=d, ff=ff, x32=x32.data_ptr(),
             W_in=tiles["in"][0].data_ptr(), b_in=rin.b_sh.data_ptr(), W_out=tiles["out"][0].data_ptr(), b_out=rout.b_sh.data_ptr(),
@@ -599,7 +601,7 @@ class HeadFn(torch.autograd.Function):
         a16, h, out = torch.empty((B, hid), **bf), torch.empty((B, hid), **bf), torch.empty((B, C), **bf)
         mean, rstd = torch.empty(B, **f32), torch.empty(B, **f32)
         used = st.used(103)
-        p = float(model.dropout.p)
+        p = float(model.dropout.p) if st.train_mode else 0.0
         a = _cabi.TfdHeadArgs(B=B, S=S, d=d, hid=hid, C=C, y16=x16.data_ptr(), W1=tiles["fc1"][0].data_ptr(), b1=r1.b_sh.data_ptr(),
                               gamma=model.norm1.weight.data_ptr(), beta=model.norm1.bias.data_ptr(), eps=float(model.norm1.eps),
                               W2=tiles["fc2"][0].data_ptr(), b2=r2.b_sh.data_ptr(), p_drop=p, seed=st.seed + 7919 * 103,
@@ -730,13 +732,26 @@ def patch_model(model: nn.Module, seed: int, direct_param_grads: bool = False) -
     cls = type(model)
 
     def forward(self, x):
-        fast = (self.training and x.is_cuda and x.dim() == 3 and x.dtype == torch.float32 and x.shape[1] == self.n_cases and x.shape[1] < 8
-                and torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") == torch.bfloat16)
+        fast = ((self.training or (EVAL_FAST and not torch.is_grad_enabled())) and x.is_cuda and x.dim() == 3 and x.dtype == torch.float32
+                and x.shape[1] == self.n_cases and x.shape[1] < 8 and torch.is_autocast_enabled("cuda")
+                and torch.get_autocast_dtype("cuda") == torch.bfloat16)
         if not fast:
             return cls.forward(self, x)
         st = state.get(x.device)
         if st is None:
             st = state[x.device] = _State(x.device, seed, direct_param_grads, getattr(self.transformer_encoder, "_ops_step_counter", None))
+        if not self.training:
+            # evaluation (no gradients): the same launches with every dropout probability 0 (the diffusion noise is NOT gated on the
+            # mode, TFD:443-478) -- only when every block has its one-launch form; ~70 us per batch against ~500 through the modules
+            enc = self.transformer_encoder
+            if not (_front_fused_ok(self, st, x.shape[2]) and _head_fused_ok(self, st, x.shape[2]) and enc.norm is None
+                    and all(_layer_fused_ok(l, st) for l in enc.layers)):
+                return cls.forward(self, x)
+            st.train_mode = False
+            try:
+                return model_forward(self, x, st)
+            finally:
+                st.train_mode = True
         return model_forward(self, x, st)
 
     model.forward = types.MethodType(forward, model)
@@ -761,7 +776,9 @@ def patch_encoder(enc: nn.TransformerEncoder, seed: int, direct_param_grads: boo
     enc._ops_dropout_state = state          # device -> _State; patch_model's front end / head draw from the same stream
 
     def forward(self, src, mask=None, src_key_padding_mask=None, is_causal=None):
-        fast = (self.training and src.is_cuda and src.dim() == 3 and src.shape[1] <= 8 and mask is None and src_key_padding_mask is None
+        st0 = state.get(src.device)
+        eval_pass = st0 is not None and not st0.train_mode and not self.training and not torch.is_grad_enabled()    # (set by the model's patched forward)
+        fast = ((self.training or eval_pass) and src.is_cuda and src.dim() == 3 and src.shape[1] <= 8 and mask is None and src_key_padding_mask is None
                 and not is_causal and torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") == torch.bfloat16
                 and src.dtype == torch.float32)
         if not fast:

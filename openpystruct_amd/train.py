@@ -737,7 +737,7 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
             raise RuntimeError(f"ops_gather_rows_noise_targets_f32 failed with code {rc}")
         return with_y
 
-    graph = graph_b = vgraph = None
+    graph = graph_b = vgraph = graph_t = vgraph_t = None
     graph_mode_one = False
     bs = cfg.batch_size
     if use_graph and Xtr.shape[0] >= bs:
@@ -792,6 +792,27 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
                     log(f"HIP graph capture failed ({e!r}); training eagerly")
                 graph = graph_b = None
                 torch.cuda.synchronize(device)
+            # the epoch's LAST (partial) batch as a graph of its own: an eager step is ~25 launches' worth of host time (0.3-0.4 ms of a
+            # 5 ms TFD epoch), and eager model passes between replays are what the flaky-NaN hunt of r03 kept running into
+            nt = int(Xtr.shape[0]) % bs
+            if (graph is not None and world == 1 and engine is None and sP is None and nt >= 2 and nb_tr == Xtr.shape[0] // bs + 1
+                    and os.environ.get("OPS_AMD_TAIL_GRAPH", "1") == "1"):
+                try:
+                    sXt, sYt = torch.zeros_like(sX[:nt]), torch.zeros_like(sY[:nt])
+                    sXt.copy_(sX[:nt]); sYt.copy_(sY[:nt])
+                    for _ in range(2):
+                        fwd_bwd(sXt, sYt, s_noise, None, prenoised=_FUSED_PREP)
+                        apply_update()
+                    side.synchronize()
+                    graph_t = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(graph_t, stream=side, capture_error_mode="thread_local"):
+                        s_loss_t = fwd_bwd(sXt, sYt, s_noise, None, prenoised=_FUSED_PREP)
+                        apply_update()
+                except Exception as e:
+                    if log:
+                        log(f"HIP graph capture of the tail batch failed ({e!r}); that step runs eagerly")
+                    graph_t = None
+                    torch.cuda.synchronize(device)
         torch.cuda.current_stream(device).wait_stream(side)
         model.load_state_dict(snap[0]); opt.load_state_dict(snap[1])     # the warm-up steps never happened
         if on_gpu:
@@ -801,27 +822,37 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
             if fast_encoder is not None:
                 from . import tfd_fused
                 tfd_fused.refresh_layer_tiles(fast_encoder.transformer_encoder)
-        # the validation pass as a graph too: one full batch in eval mode, loss accumulated into v_acc
-        if graph is not None and Xva.shape[0] >= bs:
-            vX, vY = torch.zeros_like(Xva[:bs]), torch.zeros_like(Yva[:bs])
+        # the validation pass as graphs too (eval mode, loss accumulated into v_acc): one for the full batches, one for the last partial one
+        nvt = int(Xva.shape[0]) % bs
+        if graph is not None and (Xva.shape[0] >= bs or nvt >= 1):
             v_acc = torch.zeros((), device=device)
             net.eval()
-            try:
+
+            def capture_val(rows):
+                bx, by = torch.zeros_like(Xva[:rows]), torch.zeros_like(Yva[:rows])
                 side.wait_stream(torch.cuda.current_stream(device))
                 with torch.cuda.stream(side), torch.no_grad():
-                    vX.copy_(Xva[:bs]); vY.copy_(Yva[:bs])
+                    bx.copy_(Xva[:rows]); by.copy_(Yva[:rows])
                     for _ in range(2):
-                        val_batch(vX, vY)
+                        val_batch(bx, by)
                     side.synchronize()
-                    vgraph = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(vgraph, stream=side, capture_error_mode="thread_local"):
-                        v_acc += val_batch(vX, vY)
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):
+                        v_acc.add_(val_batch(bx, by))
                 torch.cuda.current_stream(device).wait_stream(side)
+                return g, bx, by
+
+            try:
+                if Xva.shape[0] >= bs:
+                    vgraph, vX, vY = capture_val(bs)
+                if nvt >= 1 and world == 1 and os.environ.get("OPS_AMD_TAIL_GRAPH", "1") == "1":
+                    vgraph_t, vXt, vYt = capture_val(nvt)
             except Exception as e:
                 if log:
                     log(f"HIP graph capture of the validation pass failed ({e!r}); evaluating eagerly")
-                vgraph = None
+                vgraph = vgraph_t = None
                 torch.cuda.synchronize(device)
+            v_acc.zero_()
             net.train()
 
     best_val, best_state, no_improve = float("inf"), None, 0
@@ -881,6 +912,19 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
                     tot += s_loss
                 if _DEBUG_NAN and engine is None:
                     _debug_nan(model, opt, flat, s_loss, epoch, b, sX, sY)
+            elif graph_t is not None and idx.numel() == sXt.shape[0]:
+                got_y = False
+                if _FUSED_PREP:
+                    got_y = gather_noise(idx, sXt, sYt)
+                else:
+                    torch.index_select(Xtr, 0, idx, out=sXt)
+                if not got_y:
+                    torch.index_select(Ytr, 0, idx, out=sYt)
+                graph_t.replay()
+                if loss_acc is None:
+                    tot += s_loss_t
+                if _DEBUG_NAN:
+                    _debug_nan(model, opt, flat, s_loss_t, epoch, -b, sXt, sYt)
             elif engine is not None:
                 train_step(None, Ytr[:idx.numel()], noise_t, idx)            # Yb only carries the row count here
             else:
@@ -909,9 +953,12 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
             if vgraph is not None and Xva[sl].shape[0] == bs:
                 vX.copy_(Xva[sl]); vY.copy_(Yva[sl])
                 vgraph.replay()
+            elif vgraph_t is not None and Xva[sl].shape[0] == vXt.shape[0]:
+                vXt.copy_(Xva[sl]); vYt.copy_(Yva[sl])
+                vgraph_t.replay()
             else:
                 vt += val_batch(Xva[sl], Yva[sl])
-        if vgraph is not None:
+        if vgraph is not None or vgraph_t is not None:
             vt += v_acc
             v_acc.zero_()
         val_loss = _allreduce_mean(vt / nb_va, world)
@@ -934,7 +981,7 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
             break
     # the captured graphs (and their private memory pools) go before anything else runs on this device: the closures above form
     # reference cycles that would otherwise keep them alive until some later garbage collection
-    graph = graph_b = vgraph = None
+    graph = graph_b = vgraph = graph_t = vgraph_t = None
     if on_gpu:
         import gc
         gc.collect()

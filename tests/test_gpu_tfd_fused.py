@@ -701,3 +701,40 @@ def test_one_launch_front_end_against_the_framework_ops(B, Nc, d, hid):
     dhr = ((dm.float() @ W2r).to(torch.bfloat16).float() * (h.float() > 0))
     assert _rel(d_h.float(), dhr) < 3e-3
     assert _rel(dcls, gt[:, 0, :].sum(0)) < 1e-5
+
+
+def test_evaluation_pass_through_the_one_launch_kernels_equals_the_module(monkeypatch):
+    """model.eval() + no_grad under bf16 autocast: the patched forward runs the same launches with every dropout probability 0 and the
+    draws of the front-end launch; against the module's own evaluation forward on those draws."""
+    from openpystruct_amd import tfd_fused as TF, train
+    from openpystruct_amd.surrogates import ModelOnePassTransformerWithDiffusion
+    monkeypatch.setattr(TF, "KEEP_DRAWS", True)
+    torch.manual_seed(5)
+    model = ModelOnePassTransformerWithDiffusion(6, 120, 100, dropout=0.1).to(DEV)
+    ref = copy.deepcopy(model)
+    params = list(model.parameters())
+    flat = torch.zeros(sum(q.numel() for q in params), device=DEV)
+    off = 0
+    for q in params:
+        q.grad = flat[off:off + q.numel()].view_as(q)
+        off += q.numel()
+    opt = train.FlatClipAdam(params, flat, 1e-3)
+    stash, dst, patched = train.enable_shadow_linears(model, opt, params, flat)
+    assert TF.patch_model(model, seed=3, direct_param_grads=True)
+    x = torch.randn(200, 6, 120, generator=torch.Generator().manual_seed(6)).to(DEV)
+    model.eval(); ref.eval()
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        out = model(x)
+        st = model.transformer_encoder._ops_dropout_state[x.device]
+        t_k, e_k = st.draws
+        assert t_k.shape == (200, 6) and st.train_mode
+        out2 = model(x)
+        assert not torch.equal(st.draws[1], e_k)                     # fresh noise for the next evaluation batch
+        monkeypatch.setattr(torch, "randint", lambda lo, hi, size, device=None, **kw: t_k)
+        monkeypatch.setattr(torch, "randn_like", lambda t, **kw: e_k.to(t.dtype))
+        outr = ref(x)
+    assert out.dtype == torch.bfloat16 and _rel(out.float(), outr.float()) < 1.5e-2 and _rel(out2.float(), out.float()) > 1e-4
+    with torch.autocast("cuda", dtype=torch.bfloat16):               # with gradients enabled the evaluation pass is the module's own
+        assert model(x).requires_grad
+    train.disable_shadow_linears(patched)
+    TF.unpatch_model(model)
