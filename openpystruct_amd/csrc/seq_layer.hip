@@ -1,23 +1,26 @@
-// One post-norm Transformer encoder layer of the Transformer-Diffusion surrogate
-// (/root/reference/OpenPyStruct_TransformerDiffusionModule_MultiCase.py:539-575: nn.TransformerEncoderLayer, ReLU, batch_first, dropout 0.1)
-// for the TRAINING step's forward pass as ONE launch:
+// The Transformer-Diffusion surrogate's training step as ONE LAUNCH PER BLOCK AND DIRECTION
+// (/root/reference/OpenPyStruct_TransformerDiffusionModule_MultiCase.py: diffusion front end :443-478 / :563-567, nn.TransformerEncoderLayer
+// (post-norm, ReLU, batch_first, dropout 0.1) :539-575, head :568-575):
 //
-//   qkv = x W_in^T + b_in | softmax(q k^T / sqrt(dh)) -> dropout -> @ v | a = ctx W_out^T + b_out | y1 = LayerNorm1(x + dropout(a))
-//   u = y1 W_1^T + b_1    | h = dropout(ReLU(u))                        | f = h W_2^T + b_2      | y2 = LayerNorm2(y1 + dropout(f))
+//   tfd_front_fwd / _bwd   draws -> x_noisy -> m = W_2 relu(W_0 x_noisy + b_0) + b_2 -> z = (x_noisy - sb m) / sa + pe, [CLS] rows
+//   tfd_layer_fwd / _bwd   qkv = x W_in^T + b_in | softmax(q k^T / sqrt(dh)) -> dropout -> @ v | a = ctx W_out^T + b_out | y1 = LN1(x + dropout(a))
+//                          u = y1 W_1^T + b_1    | h = dropout(ReLU(u))                        | f = h W_2^T + b_2      | y2 = LN2(y1 + dropout(f))
+//   tfd_head_fwd / _bwd    a = cls W_1^T + b_1 -> LayerNorm -> ReLU -> dropout -> out = h W_2^T + b_2 on the B [CLS] rows
 //
-// Through csrc/seq_block.hip + the library's products this is eight kernel nodes of 5-12 us for ~0.9 MFLOP per sample.  Every step is
-// local to a SAMPLE (S <= 8 tokens: [CLS] + 6 load cases), so a wavefront that owns the 16-row tile of 16 / S samples can run the
-// local to a SAMPLE, so ONE WORKGROUP that owns the 16-row tile of 16 / S samples runs the whole layer: bf16 `v_mfma_f32_16x16x32_bf16`
-// products whose A operand sits in LDS and whose B operand -- the weights, 238 KB per layer -- comes straight from the row-major
-// bfloat16 shadow parameters (a lane's B fragment is 16 contiguous bytes of a weight row).  The workgroup's 8 waves split every
-// product's column tiles, which makes a wave's share of the weights 32 sixteen-byte loads per lane: ALL of them are requested at kernel
-// entry.  (First version: one wave per tile row, weights three tiles ahead of the multiplications: 63 tiles = 21 dependent round trips
-// beyond L2 per wave, 85 us per launch -- slower than the eight launches it replaced.)
+// Through csrc/seq_block.hip + the library's products a layer was eight kernel nodes of 5-12 us each way for ~0.9 MFLOP per sample.
+// Every step is local to a SAMPLE (S <= 8 tokens: [CLS] + 6 load cases), so ONE WORKGROUP that owns a 16-row tile (16 / S samples)
+// runs the whole block: bf16 `v_mfma_f32_16x16x32_bf16` products whose A operand sits in LDS rows and whose B operand -- the weights,
+// 238 KB per layer -- comes from FRAGMENT-TILED bf16 copies (one contiguous KB per wave and load instruction; forward: the weights'
+// tiles, backward: their transposes' tiles; rebuilt behind every Adam update, csrc/flat_adam.hip repack_tiles_kernel).  The workgroup's
+// 8 waves split every product's column tiles, which makes a wave's share of a layer's weights 32 sixteen-byte loads per lane: all of
+// them are requested up front.  (First version: one wave per tile row, weights three tiles ahead of the multiplications: 63 tiles = 21
+// dependent round trips beyond L2 per wave, 85 us per launch -- slower than the eight launches it replaced.  What the stage stamps of
+// the later versions showed is listed in profiles/r03_notes.md 7.)
 //
-// Arithmetic contract = bf16 autocast through the separate kernels: bf16 operands, fp32 accumulation, every product's result rounded to
-// bf16 before it is used, LayerNorm statistics and the residual stream in fp32.  Dropout masks: the counter-based hash of
-// csrc/seq_block.hip with the SAME seeds and element indices, so the backward launches of that file (which regenerate the masks) apply
-// unchanged; everything they read is saved in their formats.
+// Arithmetic contract = bf16 autocast through separate kernels: bf16 operands, fp32 accumulation, every product's result rounded to
+// bf16 before it is used, LayerNorm statistics and the residual stream in fp32.  Dropout masks: the counter-based stream of
+// csrc/dropout_stream.hpp, one seed per site; the backward launches regenerate them from (seed, the call counter value the forward
+// launch used, element index) -- no mask is stored.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -567,14 +570,11 @@ __global__ __launch_bounds__(64 * SL_NW) void tfd_layer_bwd_kernel(const ops_tfd
   uint4 qin[2];
   int qidx[2];
   {
-    const float inv = 1.0f / (float)qppr;
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
       const int idx = tid + 64 * SL_NW * k;
-      const int r = (int)(((float)idx + 0.5f) * inv);
       qidx[k] = (idx < nrows * qppr) ? idx : -1;
       qin[k] = *(const uint4*)((const uint16_t*)a.qkv + row0 * 3 * d + 8 * (long)(idx < nrows * qppr ? idx : 0));
-      (void)r;
     }
   }
   const unsigned long long call = *a.used_call;
@@ -1128,7 +1128,7 @@ __global__ __launch_bounds__(64 * SL_NW) void tfd_front_fwd_kernel(const ops_tfd
   __shared__ __attribute__((aligned(16))) float s_f32[16 * FS];       // x_noisy (float32), at the end z (float32)
   __shared__ float s_ab[2][16];                                       // sa, sb of the 16 rows
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 15, g = lane >> 4;
-  const int Nc = a.Nc, d = a.d, hid = a.hid, S = Nc + 1;
+  const int Nc = a.Nc, d = a.d, hid = a.hid;
   const long rows = (long)a.B * Nc, r0 = (long)blockIdx.x * 16;
   const int nrows = (rows - r0 < 16) ? (int)(rows - r0) : 16;
   const int NT1 = (hid + 15) / 16, NTD = (d + 15) / 16, KSD = (d + 31) / 32, KSH = (hid + 31) / 32;

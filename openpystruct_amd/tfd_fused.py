@@ -1,15 +1,19 @@
-"""Training-step fast path of the Transformer-Diffusion surrogate's encoder: host side of csrc/seq_block.hip.
+"""Fast path of the Transformer-Diffusion surrogate (ModelOnePassTransformerWithDiffusion,
+/root/reference/OpenPyStruct_TransformerDiffusionModule_MultiCase.py:443-478, :539-575): host side of csrc/seq_layer.hip and csrc/seq_block.hip.
 
-`nn.TransformerEncoder` of post-norm ReLU layers (/root/reference/OpenPyStruct_TransformerDiffusionModule_MultiCase.py:539-575) over
-sequences of 7 tokens ([CLS] + 6 load cases), bf16 autocast, training mode: per layer
+Sequences of 7 tokens ([CLS] + 6 load cases), bf16 autocast.  Autograd still drives the step, but every BLOCK is one autograd.Function
+whose forward and backward are one launch each (r03):
 
-    in-projection | attention (one launch) | out-projection | dropout + add + LayerNorm (one launch) |
-    linear1 | ReLU + dropout (one launch) | linear2 | dropout + add + LayerNorm (one launch)
+    FrontFn          draws -> x_noisy -> diffusion MLP -> combine with [CLS] token and positional encoding
+    EncoderLayerFn   in-projection, attention, out-projection, dropout + add + LayerNorm, feed-forward, dropout + add + LayerNorm
+    HeadFn           fc1 -> LayerNorm -> ReLU -> dropout -> fc2 on the [CLS] rows
 
-with the four products through the optimiser's bf16 shadow weights (train._ShadowLinearFn) -- ~26 kernel nodes per layer and
-training step (the products' weight and bias gradients: one split-row launch each) instead of ~90 through the framework's modules (flash-attention kernels built for long sequences, layout copies,
-separate dropout / add / LayerNorm nodes and their backward pieces).  Autograd still drives the step; every block is one
-autograd.Function whose backward is one launch.  Evaluation, masks, other activations: the framework's own forward.
+on fragment-tiled bf16 weight copies (enable_layer_tiles; rebuilt behind every Adam update) -- 16 kernel nodes per captured training
+step where the framework's modules need ~260.  Weight / bias gradients leave through train.shadow_param_grads (one grouped split-row
+launch per step).  Evaluation passes without gradients run the same launches with every dropout probability 0.  Blocks whose sizes do
+not fit the one-launch kernels fall back to the r02 form: the separate launches of csrc/seq_block.hip (attention, dropout + add +
+LayerNorm, ReLU + dropout, diffusion noise / combine) between the optimiser's bf16 shadow products (train._ShadowLinearFn); masks,
+other activations, CPU: the framework's own forward.
 """
 from __future__ import annotations
 
