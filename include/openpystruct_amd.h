@@ -434,7 +434,9 @@ typedef struct ops_wgrad_problem {
   const void* dY; const void* X; float* dW; float* dbias;
   int32_t ldy, ldx;                                   /* row strides of dY / X in elements; 0: N / K (contiguous rows) */
 } ops_wgrad_problem;
-#define OPS_WGRAD_MAX_GROUP 16
+/* K = 0: a COLUMN-SUM job instead of a product: dW [N] += column sums of the FLOAT32 matrix dY [T, N] (row stride ldy; X, dbias unused) --
+ * per-workgroup partial sums of another launch, reduced without a launch of their own. */
+#define OPS_WGRAD_MAX_GROUP 24
 int ops_linear_wgrad_accumulate_group(int nprob, const ops_wgrad_problem* problems, void* stream);
 
 /* Diffusion front end of the Transformer-Diffusion surrogate (TransformerDiffusionModule_MultiCase.py:443-478, :563-567) around its
@@ -502,6 +504,10 @@ typedef struct ops_tfd_layer_bwd_args {
   float* dx32;                                        /* [T, d] gradient at the layer input (residual + in-projection branch) */
   float* dgamma1; float* dbeta1; float* dgamma2; float* dbeta2;
   unsigned long long* trace;
+  float* ln_part;                                     /* NULL, or [workgroups = ceil(Bn / (16 / S))][4][128] float32: the launch stores every
+                                                         workgroup's column sums (dgamma2 | dbeta2 | dgamma1 | dbeta1) there INSTEAD of adding
+                                                         them with atomics (224 workgroups on the same 480 addresses stalled the launch's memory
+                                                         pipeline for ~9 us); the caller sums the rows (ops_linear_wgrad_accumulate_group, K = 0) */
 } ops_tfd_layer_bwd_args;
 int ops_tfd_encoder_layer_bwd(const ops_tfd_layer_bwd_args* args, void* stream);
 

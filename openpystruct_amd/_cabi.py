@@ -147,7 +147,7 @@ class TfdLayerBwdArgs(ctypes.Structure):
                 ("seed_attn", _u), ("seed_1", _u), ("seed_act", _u), ("seed_2", _u), ("used_call", _vp),
                 ("qkv", _vp), ("z1", _vp), ("mean1", _vp), ("rstd1", _vp), ("u", _vp), ("z2", _vp), ("mean2", _vp), ("rstd2", _vp),
                 ("d_f", _vp), ("d_u", _vp), ("d_a", _vp), ("dqkv", _vp), ("dx32", _vp),
-                ("dgamma1", _vp), ("dbeta1", _vp), ("dgamma2", _vp), ("dbeta2", _vp), ("trace", _vp)]
+                ("dgamma1", _vp), ("dbeta1", _vp), ("dgamma2", _vp), ("dbeta2", _vp), ("trace", _vp), ("ln_part", _vp)]
 
 
 class TfdHeadArgs(ctypes.Structure):
@@ -180,7 +180,7 @@ class TfdFrontBwdArgs(ctypes.Structure):
                 ("dm", _vp), ("d_h", _vp), ("dcls", _vp)]
 
 
-WGRAD_MAX_GROUP = 16
+WGRAD_MAX_GROUP = 24
 
 
 class MlpRepackEntry(ctypes.Structure):

@@ -657,10 +657,32 @@ struct WgGroup {
   int wg0[OPS_WGRAD_MAX_GROUP + 1];
   ops_wgrad_problem p[OPS_WGRAD_MAX_GROUP];
 };
+// K = 0 job: out[c] += sum over the T rows of the float32 matrix M [T, N]; one workgroup per 64 columns x CS_ROWS rows: every thread has
+// its 8 loads in flight at once (one workgroup per 64 columns walking all rows: 56 dependent trips, the launch's long pole at 41 us)
+constexpr int CS_ROWS = 32;
+__device__ __forceinline__ void colsum_body(int T, int N, const float* __restrict__ M, int ld, float* __restrict__ out, int id) {
+  __shared__ float s_p[4][64];
+  const int nb = (N + 63) / 64, bx = id % nb, by = id / nb;
+  const int tid = threadIdx.x, c = bx * 64 + (tid & 63), stripe = tid >> 6, r0 = by * CS_ROWS;
+  float v[CS_ROWS / 4];
+#pragma unroll
+  for (int k = 0; k < CS_ROWS / 4; ++k) { const int r = r0 + stripe + 4 * k; v[k] = (c < N && r < T) ? M[(long)r * ld + c] : 0.0f; }
+  float acc = 0.0f;
+#pragma unroll
+  for (int k = 0; k < CS_ROWS / 4; ++k) acc += v[k];
+  s_p[stripe][tid & 63] = acc;
+  __syncthreads();
+  if (tid < 64 && c < N) unsafeAtomicAdd(&out[c], (s_p[0][tid] + s_p[1][tid]) + (s_p[2][tid] + s_p[3][tid]));
+}
+
 __global__ __launch_bounds__(256) void wgrad_tn_group_kernel(const WgGroup g) {
   int pi = 0;
   while (pi + 1 < g.nprob && (int)blockIdx.x >= g.wg0[pi + 1]) ++pi;
   const ops_wgrad_problem pr = g.p[pi];
+  if (pr.K == 0) {                                                     // workgroup-uniform
+    colsum_body(pr.T, pr.N, (const float*)pr.dY, pr.ldy > 0 ? pr.ldy : pr.N, pr.dW, (int)blockIdx.x - g.wg0[pi]);
+    return;
+  }
   const int id = (int)blockIdx.x - g.wg0[pi], tn = (pr.N + 63) / 64, tk = (pr.K + 63) / 64;
   wgrad_tn_body(pr.T, pr.N, pr.K, (const uint16_t*)pr.dY, (const uint16_t*)pr.X, pr.dW, pr.dbias, id % tn, (id / tn) % tk, id / (tn * tk), pr.ldy, pr.ldx);
 }
@@ -681,6 +703,13 @@ extern "C" int ops_linear_wgrad_accumulate_group(int nprob, const ops_wgrad_prob
   int tot = 0;
   for (int i = 0; i < nprob; ++i) {
     const ops_wgrad_problem& p = problems[i];
+    if (p.K == 0) {                 // column-sum job
+      if (p.T < 1 || p.N < 1 || !p.dY || !p.dW || (p.ldy && p.ldy < p.N)) return OPS_AMD_ERR_INVALID_ARG;
+      g.p[i] = p;
+      g.wg0[i] = tot;
+      tot += ((p.N + 63) / 64) * ((p.T + opsamd::CS_ROWS - 1) / opsamd::CS_ROWS);
+      continue;
+    }
     if (p.T < 1 || p.N < 1 || p.K < 1 || !p.dY || !p.X || !p.dW || (p.ldy && p.ldy < p.N) || (p.ldx && p.ldx < p.K)) return OPS_AMD_ERR_INVALID_ARG;
     g.p[i] = p;
     g.wg0[i] = tot;

@@ -514,13 +514,12 @@ __device__ __forceinline__ void slb_ln_bwd(const float (&dy)[4], const float (&x
   }
 }
 // column sums over the workgroup's 16 rows of (dy xhat, dy) -> one float atomic per column into dgamma / dbeta
-__device__ __forceinline__ void slb_param_grads(const float (&dy)[4], const float (&xh)[4], bool colok, int n, int g, float* dgamma, float* dbeta) {
-  float pg = 0.0f, pb = 0.0f;
+__device__ __forceinline__ void slb_param_sums(const float (&dy)[4], const float (&xh)[4], float& pg, float& pb) {
+  pg = 0.0f; pb = 0.0f;
 #pragma unroll
   for (int i = 0; i < 4; ++i) { pg = __builtin_fmaf(dy[i], xh[i], pg); pb += dy[i]; }
   pg += __shfl_xor(pg, 16, 64); pb += __shfl_xor(pb, 16, 64);
   pg += __shfl_xor(pg, 32, 64); pb += __shfl_xor(pb, 32, 64);
-  if (g == 0 && colok) { unsafeAtomicAdd(dgamma + n, pg); unsafeAtomicAdd(dbeta + n, pb); }
 }
 
 template <bool HAS32, bool HAS16>
@@ -631,7 +630,7 @@ __global__ __launch_bounds__(64 * SL_NW) void tfd_layer_bwd_kernel(const ops_tfd
   SLB_STAMP(2);
 
   // ---- LayerNorm2 backward -> dres2 (registers), d_f (bf16 operand rows) ----
-  float dres2[4];
+  float dres2[4], pg2, pb2;
   {
     const slb_args_ptr la = slb_late_args();
     const DropKey key_2 = drop_key(la->seed_2, call);
@@ -644,7 +643,8 @@ __global__ __launch_bounds__(64 * SL_NW) void tfd_layer_bwd_kernel(const ops_tfd
       rstd[i] = s_stat[1][r];
       xh[i] = (colok && r < nrows) ? (s_z2[r * FS + n] - s_stat[0][r]) * rstd[i] : 0.0f;
     }
-    slb_param_grads(dy, xh, colok, n, g, la->dgamma2, la->dbeta2);
+    slb_param_sums(dy, xh, pg2, pb2);        // (the atomics wait until every weight fragment is in: vector memory retires in order, and an
+                                             //  atomic issued here sat in front of the d_h product's weights -- LN2 stage 6.4 us in the step)
     slb_ln_bwd(dy, xh, gm2, rstd, d, wave, c, g, s_red[0], dres2);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -688,6 +688,10 @@ __global__ __launch_bounds__(64 * SL_NW) void tfd_layer_bwd_kernel(const ops_tfd
   __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
   SLB_STAMP(4);
   { const slb_args_ptr la = slb_late_args();
+    if (g == 0) {
+      if (la->ln_part) { SL_GLOBAL(float, la->ln_part)[((long)blockIdx.x * 4 + 0) * 128 + n] = colok ? pg2 : 0.0f; SL_GLOBAL(float, la->ln_part)[((long)blockIdx.x * 4 + 1) * 128 + n] = colok ? pb2 : 0.0f; }
+      else if (colok) { unsafeAtomicAdd(la->dgamma2 + n, pg2); unsafeAtomicAdd(la->dbeta2 + n, pb2); }
+    }
     sl_store_rows<2>(la->d_f, s_a, XS, d, row0, nrows, tid);
     sl_store_rows<2>(la->d_u, s_du, HS, ff, row0, nrows, tid); }
 
@@ -707,7 +711,12 @@ __global__ __launch_bounds__(64 * SL_NW) void tfd_layer_bwd_kernel(const ops_tfd
       rstd[i] = s_stat[3][r];
       xh[i] = live ? (s_z1[r * FS + n] - s_stat[2][r]) * rstd[i] : 0.0f;
     }
-    slb_param_grads(dy, xh, colok, n, g, la->dgamma1, la->dbeta1);
+    { float pg1, pb1;
+      slb_param_sums(dy, xh, pg1, pb1);
+      if (g == 0) {
+        if (la->ln_part) { SL_GLOBAL(float, la->ln_part)[((long)blockIdx.x * 4 + 2) * 128 + n] = colok ? pg1 : 0.0f; SL_GLOBAL(float, la->ln_part)[((long)blockIdx.x * 4 + 3) * 128 + n] = colok ? pb1 : 0.0f; }
+        else if (colok) { unsafeAtomicAdd(la->dgamma1 + n, pg1); unsafeAtomicAdd(la->dbeta1 + n, pb1); }
+      } }
     slb_ln_bwd(dy, xh, gm1, rstd, d, wave, c, g, s_red[1], dres1);   // (its barrier: every thread has read its d_f pieces, s_a becomes d_a)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {

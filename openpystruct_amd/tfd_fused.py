@@ -30,9 +30,11 @@ from . import _cabi
 ENABLED = os.environ.get("OPS_AMD_TFD_FAST_ENCODER", "1") == "1"      # A/B switch: 0 = nn.TransformerEncoder's own forward
 LAYER_FWD = os.environ.get("OPS_AMD_TFD_LAYER_FWD", "1") == "1"       # A/B switch: 0 = eight launches per layer forward instead of one
 DRAW = os.environ.get("OPS_AMD_TFD_DRAW", "1") == "1"                 # A/B switch: 0 = diffusion steps / noise from the framework generators
+_TRACE_BWD = [] if os.environ.get("OPS_AMD_TFD_TRACE_BWD") else None   # diagnostics: stage stamps of every backward layer launch
 KEEP_DRAWS = False                                                    # tests: every state keeps its last draws (`_State.draws`)
 EVAL_FAST = os.environ.get("OPS_AMD_TFD_EVAL_FAST", "1") == "1"       # A/B switch: 0 = validation passes through the module's own forward
 FRONT = os.environ.get("OPS_AMD_TFD_FRONT", "1") == "1"               # A/B switch: 0 = the diffusion front end as five + three launches
+LN_PARTIALS = os.environ.get("OPS_AMD_TFD_LN_PARTIALS", "1") == "1"   # A/B switch: 0 = LayerNorm gamma / beta gradients by float atomics in the layer launch
 HEAD = os.environ.get("OPS_AMD_TFD_HEAD", "1") == "1"                 # A/B switch: 0 = the head as four launches per direction
 LAYER_BWD = os.environ.get("OPS_AMD_TFD_LAYER_BWD", "1") == "1"       # A/B switch: 0 = eight launches per layer backward instead of one
 
@@ -286,7 +288,22 @@ class EncoderLayerFn(torch.autograd.Function):
                     z2=z2.data_ptr(), mean2=mean2.data_ptr(), rstd2=rstd2.data_ptr(), d_f=d_f.data_ptr(), d_u=d_u.data_ptr(), d_a=d_a.data_ptr(),
                     dqkv=dqkv.data_ptr(), dx32=dx32.data_ptr(), dgamma1=layer.norm1.weight.grad.data_ptr(), dbeta1=layer.norm1.bias.grad.data_ptr(),
                     dgamma2=layer.norm2.weight.grad.data_ptr(), dbeta2=layer.norm2.bias.grad.data_ptr())
+                nwg = (Bn + (16 // S) - 1) // (16 // S)
+                part = None
+                if train._WGRAD_QUEUE is not None and LN_PARTIALS:
+                    # LayerNorm gamma / beta gradients: per-workgroup column sums, reduced by four jobs of the grouped weight-gradient launch
+                    part = torch.empty((nwg, 4, 128), **f32)
+                    a.ln_part = part.data_ptr()
+                if _TRACE_BWD is not None:
+                    tr = torch.zeros(16 * ((Bn + (16 // S) - 1) // (16 // S)), dtype=torch.int64, device=dev)
+                    _TRACE_BWD.append(tr)
+                    a.trace = tr.data_ptr()
                 _check(lib.ops_tfd_encoder_layer_bwd(ctypes.byref(a), s), "ops_tfd_encoder_layer_bwd")
+                if part is not None:
+                    flatp = part.view(nwg, 512)
+                    for k, q in enumerate((layer.norm2.weight, layer.norm2.bias, layer.norm1.weight, layer.norm1.bias)):
+                        ok = train.queue_column_sums(flatp[:, 128 * k:128 * k + d], q.grad)
+                        assert ok
                 train.shadow_param_grads(r2, d_f, h)
                 train.shadow_param_grads(r1, d_u, y1_16)
                 train.shadow_param_grads(rout, d_a, ctxa)

@@ -332,6 +332,15 @@ class ShadowRec:
         self.w_sh, self.b_sh, self.w_grad, self.b_grad, self.stash, self.iw, self.ib = w_sh, b_sh, w_grad, b_grad, stash, iw, ib
 
 
+def queue_column_sums(rows: torch.Tensor, dest: torch.Tensor) -> bool:
+    """dest [N] (float32, a slice of the zeroed flat gradient buffer) += column sums of rows [T, N] (float32, unit column stride) as a job
+    of the step's grouped weight-gradient launch.  False when no grouped launch is being collected (the caller adds them itself)."""
+    if _WGRAD_QUEUE is None or rows.dtype != torch.float32 or rows.stride(1) != 1 or dest.dtype != torch.float32 or not dest.is_contiguous():
+        return False
+    _WGRAD_QUEUE.append((rows, None, dest, None))
+    return True
+
+
 def shadow_param_grads(rec: ShadowRec, g2: torch.Tensor, x2: torch.Tensor) -> None:
     """Weight / bias gradients of y = x W^T + b given dY = g2 [T, N] and X = x2 [T, K] (bfloat16): exactly what
     _ShadowLinearFn.backward does with them -- queued for the step's grouped split-row launch when the product has many rows, the
@@ -376,6 +385,10 @@ def flush_wgrad_queue(device) -> None:
             part = q[i0:i0 + _cabi.WGRAD_MAX_GROUP]
             arr = (_cabi.WgradProblem * len(part))()
             for e, (g2, x2, wg, bg) in zip(arr, part):
+                if x2 is None:                                           # column-sum job: wg [N] += column sums of the float32 rows g2 [T, N]
+                    e.T, e.N, e.K = g2.shape[0], g2.shape[1], 0
+                    e.dY, e.X, e.dW, e.dbias, e.ldy, e.ldx = g2.data_ptr(), None, wg.data_ptr(), None, g2.stride(0), 0
+                    continue
                 e.T, e.N, e.K = x2.shape[0], g2.shape[1], x2.shape[1]
                 e.dY, e.X, e.dW, e.dbias = g2.data_ptr(), x2.data_ptr(), wg.data_ptr(), (bg.data_ptr() if bg is not None else None)
                 e.ldy, e.ldx = g2.stride(0), x2.stride(0)                # (row views with unit column stride travel without a copy)

@@ -738,3 +738,30 @@ def test_evaluation_pass_through_the_one_launch_kernels_equals_the_module(monkey
         assert model(x).requires_grad
     train.disable_shadow_linears(patched)
     TF.unpatch_model(model)
+
+
+def test_grouped_launch_column_sum_jobs():
+    """K = 0 problems of ops_linear_wgrad_accumulate_group: out [N] += column sums of a float32 [T, N] matrix with a row stride (the
+    per-workgroup LayerNorm gamma / beta partial sums of the one-launch layer backward), next to an ordinary product in the same launch."""
+    from openpystruct_amd import _cabi
+    lib = _cabi.load()
+    g = torch.Generator().manual_seed(4)
+    part = torch.randn(224, 4, 128, generator=g).to(DEV)
+    dY = torch.randn(700, 72, generator=g).to(torch.bfloat16).to(DEV)
+    X = torch.randn(700, 40, generator=g).to(torch.bfloat16).to(DEV)
+    outs = [torch.full((120,), 0.5, device=DEV) for _ in range(4)]
+    dW = torch.zeros(72, 40, device=DEV)
+    arr = (_cabi.WgradProblem * 5)()
+    flatp = part.view(224, 512)
+    for k in range(4):
+        v = flatp[:, 128 * k:128 * k + 120]
+        arr[k].T, arr[k].N, arr[k].K, arr[k].dY, arr[k].dW, arr[k].ldy = 224, 120, 0, v.data_ptr(), outs[k].data_ptr(), v.stride(0)
+    arr[4].T, arr[4].N, arr[4].K, arr[4].dY, arr[4].X, arr[4].dW = 700, 72, 40, dY.data_ptr(), X.data_ptr(), dW.data_ptr()
+    assert lib.ops_linear_wgrad_accumulate_group(5, arr, torch.cuda.current_stream().cuda_stream) == 0
+    torch.cuda.synchronize()
+    for k in range(4):
+        torch.testing.assert_close(outs[k], 0.5 + part[:, k, :120].double().sum(0).float(), rtol=1e-5, atol=1e-5)
+    assert _rel(dW, dY.float().t() @ X.float()) < 1e-5
+    bad = (_cabi.WgradProblem * 1)()
+    bad[0].T, bad[0].N, bad[0].K, bad[0].dY, bad[0].dW, bad[0].ldy = 8, 120, 0, part.data_ptr(), outs[0].data_ptr(), 64      # stride < N
+    assert lib.ops_linear_wgrad_accumulate_group(1, bad, torch.cuda.current_stream().cuda_stream) == _cabi.ERR_INVALID_ARG
