@@ -489,8 +489,11 @@ def test_grouped_split_row_weight_gradients():
     assert lib.ops_linear_wgrad_accumulate_group(17, arr, None) == _cabi.ERR_INVALID_ARG
 
 
-@pytest.mark.parametrize("B", [512, 37])
-def test_fast_path_gradients_against_float64_autograd(monkeypatch, B):
+@pytest.mark.parametrize("B,cfg", [(512, None), (37, None),
+                                   (50, dict(n_cases=3, feat_dim=64, n_elem=12, hidden_units=72, num_heads=4, dim_feedforward=136, diffusion_hidden_dim=80)),
+                                   (21, dict(n_cases=7, feat_dim=96, n_elem=40, hidden_units=128, num_heads=8, dim_feedforward=256, diffusion_hidden_dim=64,
+                                             num_transformer_layers=3))])
+def test_fast_path_gradients_against_float64_autograd(monkeypatch, B, cfg):
     """The TFD fast path (fused front end, one-launch encoder layers forward AND backward, fused head, grouped weight gradients) against
     float64 autograd of the same module: dropout 0, the step indices / noise the front-end launch drew replayed to the module, a smooth
     (linear) objective -- nothing is left but bf16 rounding and ReLU branches taken on bf16-rounded pre-activations.  Bounds from the
@@ -500,7 +503,8 @@ def test_fast_path_gradients_against_float64_autograd(monkeypatch, B):
     from openpystruct_amd.surrogates import ModelOnePassTransformerWithDiffusion
     monkeypatch.setattr(TF, "KEEP_DRAWS", True)
     torch.manual_seed(5)
-    model = ModelOnePassTransformerWithDiffusion(6, 120, 100, dropout=0.0).to(DEV)
+    cfg = cfg or dict(n_cases=6, feat_dim=120, n_elem=100)         # default: the reference's sizes; the others: other tile counts / head widths
+    model = ModelOnePassTransformerWithDiffusion(dropout=0.0, **cfg).to(DEV)
     ref = copy.deepcopy(model).double()
     params = list(model.parameters())
     flat = torch.zeros(sum(q.numel() for q in params), device=DEV)
@@ -511,9 +515,12 @@ def test_fast_path_gradients_against_float64_autograd(monkeypatch, B):
     opt = train.FlatClipAdam(params, flat, 1e-3)
     stash, dst, patched = train.enable_shadow_linears(model, opt, params, flat)
     assert TF.patch_model(model, seed=3, direct_param_grads=True)
+    st_probe = TF._State(torch.device(DEV), 1, True)
+    assert TF._front_fused_ok(model, st_probe, cfg["feat_dim"]) and TF._head_fused_ok(model, st_probe, cfg["feat_dim"])     # the one-launch blocks are what runs
+    assert all(TF._layer_fused_ok(l, st_probe) for l in model.transformer_encoder.layers[:2])
     g = torch.Generator().manual_seed(6)
-    x = torch.randn(B, 6, 120, generator=g).to(DEV)
-    w = torch.randn(B, 100, generator=g).to(DEV) / B
+    x = torch.randn(B, cfg["n_cases"], cfg["feat_dim"], generator=g).to(DEV)
+    w = torch.randn(B, cfg["n_elem"], generator=g).to(DEV) / B
     model.train(); ref.train()
     train._WGRAD_QUEUE = []
     with torch.autocast("cuda", dtype=torch.bfloat16):
