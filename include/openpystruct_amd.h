@@ -358,6 +358,9 @@ typedef struct ops_mlp_strip_args {
    * nI, nD, alpha, alpha0, box_weight, rel_penalty and loss_C = C): loss[0] = value, loss_sum[0] += value (optional running total) */
   int32_t loss_finish_rows, loss_C;
   float* loss; float* loss_sum;
+  /* evaluation pass (model.eval()): forward BatchNorm tails and the stencil's BatchNorm1d(1) normalise with the RUNNING statistics
+   * (read only: nothing is updated or saved); pass p_drop = 0 and side = NONE with it */
+  int32_t eval_stats;
 } ops_mlp_strip_args;
 
 /* One strip launch: workgroup = 128 rows x 16 output columns.  Returns OPS_AMD_ERR_INVALID_ARG on a broken layout contract. */

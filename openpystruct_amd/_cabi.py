@@ -111,7 +111,8 @@ class MlpStripArgs(ctypes.Structure):
                 ("srunning_mean", _vp), ("srunning_var", _vp), ("snum_batches_tracked", _vp),
                 ("ssave", _vp), ("spart", _vp), ("sdparams", _vp),
                 ("P", _vp), ("ldp", _i), ("targets_t", _vp), ("nI", _i), ("nD", _i), ("alpha", _vp), ("alpha0", _f),
-                ("min_constraint", _vp), ("max_constraint", _vp), ("box_weight", _f), ("rel_penalty", _f), ("loss_ws", _vp), ("loss_finish_rows", _i), ("loss_C", _i), ("loss", _vp), ("loss_sum", _vp)]
+                ("min_constraint", _vp), ("max_constraint", _vp), ("box_weight", _f), ("rel_penalty", _f), ("loss_ws", _vp), ("loss_finish_rows", _i), ("loss_C", _i), ("loss", _vp), ("loss_sum", _vp),
+                ("eval_stats", _i)]
 
 
 class MlpWgradProblem(ctypes.Structure):

@@ -373,8 +373,9 @@ __global__ __launch_bounds__(MB_THREADS) void mlp_strip_kernel(const ops_mlp_str
     if (a.add_mode == OPS_MLP_ADD_FWD_BLOCK) {
       // whole-tensor statistics of conv1(O) from the previous launch's partial sums
       const double n = (double)B * (double)No, m = s_tot[0] / n, var = fmax(s_tot[1] / n - m * m, 0.0);
-      const float mean_s = (float)m, inv_s = (float)(1.0 / sqrt(var + (double)a.seps));
-      if (blockIdx.x == 0 && tid == 0) {
+      const float mean_s = a.eval_stats ? a.srunning_mean[0] : (float)m;
+      const float inv_s = a.eval_stats ? (float)(1.0 / sqrt((double)a.srunning_var[0] + (double)a.seps)) : (float)(1.0 / sqrt(var + (double)a.seps));
+      if (blockIdx.x == 0 && tid == 0 && !a.eval_stats) {
         a.ssave[0] = mean_s; a.ssave[1] = inv_s;
         a.srunning_mean[0] = (1.0f - a.smomentum) * a.srunning_mean[0] + a.smomentum * (float)m;
         a.srunning_var[0] = (1.0f - a.smomentum) * a.srunning_var[0] + a.smomentum * (float)(var * n / (n > 1.0 ? n - 1.0 : 1.0));
@@ -395,13 +396,17 @@ __global__ __launch_bounds__(MB_THREADS) void mlp_strip_kernel(const ops_mlp_str
       float sm = 0.0f;
 #pragma unroll
       for (int i = 0; i < 4; ++i) sm += v[i];                 // dead rows hold 0
-      const float mean = mb_hsum(sm) * invB;
+      float mean = mb_hsum(sm) * invB;
       float sq = 0.0f;
 #pragma unroll
       for (int i = 0; i < 4; ++i) { const float d = v[i] - mean; sq += rl[i] ? d * d : 0.0f; }
-      const float var = mb_hsum(sq) * invB;                   // biased: what normalises
-      const float rstd = rsqrtf(var + a.eps);
-      if (clive && q == 0) {
+      float var = mb_hsum(sq) * invB;                         // biased: what normalises
+      float rstd = rsqrtf(var + a.eps);
+      if (a.eval_stats) {                                     // model.eval(): the running statistics, read only
+        mean = clive ? a.running_mean[c] : 0.0f;
+        rstd = clive ? rsqrtf(a.running_var[c] + a.eps) : 1.0f;
+      }
+      if (clive && q == 0 && !a.eval_stats) {
         a.mean[c] = mean; a.rstd[c] = rstd;
         if (a.running_mean) {                                 // momentum update with the UNBIASED variance
           const float unb = var * ((float)B / (float)(B > 1 ? B - 1 : 1));
@@ -409,7 +414,7 @@ __global__ __launch_bounds__(MB_THREADS) void mlp_strip_kernel(const ops_mlp_str
           a.running_var[c] = (1.0f - a.momentum) * a.running_var[c] + a.momentum * unb;
         }
       }
-      if (blockIdx.x == 0 && tid == 0 && a.num_batches_tracked) a.num_batches_tracked[0] += 1;
+      if (blockIdx.x == 0 && tid == 0 && a.num_batches_tracked && !a.eval_stats) a.num_batches_tracked[0] += 1;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         s_z[q + 32 * i][cl] = mb_f2bf(v[i]);                 // exact: v is a bf16 value; leaves with the results below
@@ -748,6 +753,7 @@ extern "C" int ops_mlp_strip_launch(const ops_mlp_strip_args* args, void* stream
   const bool bn = a.tail == OPS_MLP_TAIL_BN || a.tail == OPS_MLP_TAIL_BN_ACT_DROP || a.tail == OPS_MLP_TAIL_BWD_BN || a.tail == OPS_MLP_TAIL_BWD_BN_ACT_DROP;
   const bool bwd = a.tail >= OPS_MLP_TAIL_BWD_ACT_DROP && a.tail <= OPS_MLP_TAIL_BWD_BN_ACT_DROP;
   if (bn && (!a.gamma || !a.beta || !a.mean || !a.rstd || !a.Zt)) return OPS_AMD_ERR_INVALID_ARG;
+  if (a.eval_stats && (bwd || a.p_drop > 0.0f || a.side != OPS_MLP_SIDE_NONE || (bn && (!a.running_mean || !a.running_var)))) return OPS_AMD_ERR_INVALID_ARG;
   if (bn && bwd && (!a.dgamma || !a.dbeta)) return OPS_AMD_ERR_INVALID_ARG;
   if ((a.tail == OPS_MLP_TAIL_BWD_ACT_DROP || a.tail == OPS_MLP_TAIL_BWD_BN_ACT_DROP) && !a.Yref_t) return OPS_AMD_ERR_INVALID_ARG;
   if ((a.tail == OPS_MLP_TAIL_ACT_DROP || a.tail == OPS_MLP_TAIL_BN_ACT_DROP) && a.p_drop > 0.0f && (!a.call_counter || a.p_drop >= 1.0f))

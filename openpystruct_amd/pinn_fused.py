@@ -116,6 +116,10 @@ class PinnFusedStep:
         self.loss_sum = torch.zeros((), dtype=torch.float32, device=dev)       # += loss per step; the caller zeroes it (per epoch)
         self.targets_t = torch.zeros(C, R, dtype=torch.float32, device=dev)    # the batch's targets, transposed
         self.loss_ws = torch.zeros(int(self.lib.ops_mlp_loss_workspace_bytes()), dtype=torch.uint8, device=dev)
+        self.loss_ws_eval = torch.zeros(int(self.lib.ops_mlp_loss_workspace_bytes()), dtype=torch.uint8, device=dev)
+        self.eval_loss = torch.zeros((), dtype=torch.float32, device=dev)
+        self.eval_loss_sum = torch.zeros((), dtype=torch.float32, device=dev)   # += loss per evaluated batch; the caller zeroes it
+        self.scratch16 = torch.zeros(R, 32, dtype=bf, device=dev)               # output of the evaluation pass's finish launch
         self.drop_counter = torch.zeros(2, dtype=torch.int64, device=dev)
         self.prep_counter = torch.zeros(2, dtype=torch.int64, device=dev)     # [calls, workgroups done] (csrc/call_counter.hpp)
         self.seed = int(seed) & 0x7FFFFFFFFFFFFFFF
@@ -225,6 +229,23 @@ class PinnFusedStep:
                                    ldw=w1t.shape[1], Y=self.dz[k][0], ldy=self.dz[k][0].shape[1], Yt=self.dz[k][1], Ot=o_in_t, dZt=dzk_t,
                                    spart=self.spart_b[k], sdparams=rb.conv1.weight.grad, **tail, **self._stencil(rb, k)))
         self._fwd, self._bwd = fwd, bwd
+        # evaluation pass (model.eval(): running statistics, no dropout, no stencil statistics) = the forward stages with eval_stats,
+        # its loss partial sums in a workspace of their own, and ONE more (dummy, one-strip) launch that adds them up
+        ev = []
+        for a in fwd:
+            e = _cabi.MlpStripArgs()
+            ctypes.memmove(ctypes.addressof(e), ctypes.addressof(a), ctypes.sizeof(_cabi.MlpStripArgs))
+            e.eval_stats, e.p_drop, e.side = 1, 0.0, C.MLP_SIDE_NONE
+            if e.tail == C.MLP_TAIL_LOSS:
+                e.loss_ws = self.loss_ws_eval.data_ptr()
+                e.dbias = None
+            ev.append(e)
+        ev.append(self._strip(N=16, K=32, tail=C.MLP_TAIL_NONE, A=self.x, lda=self.x.shape[1], W=wp, ldw=wp.shape[1], Y=self.scratch16,
+                              ldy=self.scratch16.shape[1], loss_ws=self.loss_ws_eval, loss_finish_rows=(Co + 15) // 16, loss_C=Co,
+                              nI=crit.nelem, nD=crit.deflection_dim, alpha=self._alpha, alpha0=float("nan"),
+                              box_weight=float(l1l2.penalty_weight), rel_penalty=float(crit.penalty_pinn), loss=self.eval_loss,
+                              loss_sum=self.eval_loss_sum))
+        self._eval = ev
         # grouped weight gradients
         probs = []
         probs.append((self.gpt, o_last[1], m.output_fc.weight))
@@ -305,6 +326,17 @@ class PinnFusedStep:
                 self._check(self.lib.ops_mlp_strip_launch(ctypes.byref(a), s), "ops_mlp_strip_launch (backward)")
             self._check(self.lib.ops_mlp_wgrad_group(len(self._wgrad), self._wgrad, s), "ops_mlp_wgrad_group")
         return self.loss
+
+    def evaluate(self, B: int) -> torch.Tensor:
+        """model.eval() forward of the batch in x / targets_t (gather with sigma = None) and its loss (CompositeLoss mean over the B rows;
+        also added to `eval_loss_sum`): BatchNorm layers normalise with their running statistics, no dropout, nothing is updated.
+        The predictions are in `predictions(B)` afterwards."""
+        s = torch.cuda.current_stream(self.dev).cuda_stream
+        with torch.cuda.device(self.dev):
+            for a in self._eval:
+                a.B = B
+                self._check(self.lib.ops_mlp_strip_launch(ctypes.byref(a), s), "ops_mlp_strip_launch (evaluation)")
+        return self.eval_loss
 
     def predictions(self, B: int) -> torch.Tensor:
         return self.preds[:B, :self.C]

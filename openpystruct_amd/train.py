@@ -225,6 +225,11 @@ class FnoConfig:
 _DEBUG_NAN = os.environ.get("OPS_AMD_DEBUG_NAN", "0") == "1"
 
 
+def _cabi_rows() -> int:
+    from . import _cabi
+    return _cabi.MLP_MAX_ROWS
+
+
 def clear_blas_workspaces() -> None:
     """Drop the framework's cached BLAS workspaces at the END of a training run (the caller has synchronised).  One that was allocated
     while a HIP graph was being captured lives in that graph's private pool but stays cached per (handle, stream): a later run whose
@@ -751,6 +756,11 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
         return with_y
 
     graph = graph_b = vgraph = graph_t = vgraph_t = None
+    ev_graphs, val_rows = {}, None
+    # PINN: validation through the engine's evaluation pass (running statistics, no dropout) when the validation set has its layout
+    engine_eval = bool(engine is not None and os.environ.get("OPS_AMD_PINN_ENGINE_EVAL", "1") == "1" and Xva.dtype == torch.float32
+                       and Xva.is_contiguous() and Yva.dtype == torch.float32 and Yva.is_contiguous() and Xva.dim() == 2
+                       and cfg.batch_size <= _cabi_rows())
     graph_mode_one = False
     bs = cfg.batch_size
     if use_graph and Xtr.shape[0] >= bs:
@@ -808,11 +818,14 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
             # the epoch's LAST (partial) batch as a graph of its own: an eager step is ~25 launches' worth of host time (0.3-0.4 ms of a
             # 5 ms TFD epoch), and eager model passes between replays are what the flaky-NaN hunt of r03 kept running into
             nt = int(Xtr.shape[0]) % bs
-            if (graph is not None and world == 1 and engine is None and sP is None and nt >= 2 and nb_tr == Xtr.shape[0] // bs + 1
+            if (graph is not None and world == 1 and sP is None and nt >= 2 and nb_tr == Xtr.shape[0] // bs + 1
                     and os.environ.get("OPS_AMD_TAIL_GRAPH", "1") == "1"):
                 try:
-                    sXt, sYt = torch.zeros_like(sX[:nt]), torch.zeros_like(sY[:nt])
-                    sXt.copy_(sX[:nt]); sYt.copy_(sY[:nt])
+                    sXt, sYt = (None if engine is not None else torch.zeros_like(sX[:nt])), torch.zeros_like(sY[:nt])
+                    if engine is not None:       # the engine's own buffers are the graph's inputs: Yb only carries the row count
+                        engine.gather(Xtr, Ytr, torch.arange(nt, device=device), s_noise, engine_seed)
+                    else:
+                        sXt.copy_(sX[:nt]); sYt.copy_(sY[:nt])
                     for _ in range(2):
                         fwd_bwd(sXt, sYt, s_noise, None, prenoised=_FUSED_PREP)
                         apply_update()
@@ -837,7 +850,27 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
                 tfd_fused.refresh_layer_tiles(fast_encoder.transformer_encoder)
         # the validation pass as graphs too (eval mode, loss accumulated into v_acc): one for the full batches, one for the last partial one
         nvt = int(Xva.shape[0]) % bs
-        if graph is not None and (Xva.shape[0] >= bs or nvt >= 1):
+        if engine_eval and graph is not None:
+            # PINN: the engine's own evaluation pass (forward stages on the running statistics + loss, 8 launches per batch) instead of
+            # the module's ~30-node forward; gather + evaluate captured per batch size, the row indices in a static buffer
+            val_rows = torch.arange(Xva.shape[0], device=device)
+            for n in sorted({bs if Xva.shape[0] >= bs else 0, nvt} - {0}):
+                try:
+                    vi = val_rows[:n].clone()
+                    side.wait_stream(torch.cuda.current_stream(device))
+                    with torch.cuda.stream(side):
+                        engine.gather(Xva, Yva, vi, None, 0); engine.evaluate(n)
+                        side.synchronize()
+                        g = torch.cuda.CUDAGraph()
+                        with torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):
+                            engine.gather(Xva, Yva, vi, None, 0); engine.evaluate(n)
+                    torch.cuda.current_stream(device).wait_stream(side)
+                    ev_graphs[n] = (g, vi)
+                except Exception as e:
+                    if log:
+                        log(f"HIP graph capture of the engine's evaluation pass failed ({e!r}); those batches run eagerly")
+                    torch.cuda.synchronize(device)
+        elif graph is not None and (Xva.shape[0] >= bs or nvt >= 1):
             v_acc = torch.zeros((), device=device)
             net.eval()
 
@@ -925,18 +958,20 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
                     tot += s_loss
                 if _DEBUG_NAN and engine is None:
                     _debug_nan(model, opt, flat, s_loss, epoch, b, sX, sY)
-            elif graph_t is not None and idx.numel() == sXt.shape[0]:
+            elif graph_t is not None and idx.numel() == sYt.shape[0]:
                 got_y = False
-                if _FUSED_PREP:
+                if engine is not None:
+                    got_y = gather_noise(idx, None)                          # into the engine's buffers
+                elif _FUSED_PREP:
                     got_y = gather_noise(idx, sXt, sYt)
                 else:
                     torch.index_select(Xtr, 0, idx, out=sXt)
                 if not got_y:
                     torch.index_select(Ytr, 0, idx, out=sYt)
                 graph_t.replay()
-                if loss_acc is None:
+                if loss_acc is None and engine is None:
                     tot += s_loss_t
-                if _DEBUG_NAN:
+                if _DEBUG_NAN and engine is None:
                     _debug_nan(model, opt, flat, s_loss_t, epoch, -b, sXt, sYt)
             elif engine is not None:
                 train_step(None, Ytr[:idx.numel()], noise_t, idx)            # Yb only carries the row count here
@@ -961,8 +996,22 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
         net.eval()
         vt = torch.zeros((), device=device)
         nb_va = max(1, (Xva.shape[0] + cfg.batch_size - 1) // cfg.batch_size)
+        if engine_eval:
+            engine.eval_loss_sum.zero_()
+            if val_rows is None:
+                val_rows = torch.arange(Xva.shape[0], device=device)
         for b in range(nb_va):
             sl = slice(b * cfg.batch_size, (b + 1) * cfg.batch_size)
+            if engine_eval:
+                rows = val_rows[sl]
+                gk = ev_graphs.get(int(rows.numel()))
+                if gk is not None:
+                    gk[1].copy_(rows)
+                    gk[0].replay()
+                else:
+                    engine.gather(Xva, Yva, rows, None, 0)
+                    engine.evaluate(int(rows.numel()))
+                continue
             if vgraph is not None and Xva[sl].shape[0] == bs:
                 vX.copy_(Xva[sl]); vY.copy_(Yva[sl])
                 vgraph.replay()
@@ -971,7 +1020,9 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
                 vgraph_t.replay()
             else:
                 vt += val_batch(Xva[sl], Yva[sl])
-        if vgraph is not None or vgraph_t is not None:
+        if engine_eval:
+            vt = engine.eval_loss_sum.clone()
+        elif vgraph is not None or vgraph_t is not None:
             vt += v_acc
             v_acc.zero_()
         val_loss = _allreduce_mean(vt / nb_va, world)
@@ -995,6 +1046,7 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
     # the captured graphs (and their private memory pools) go before anything else runs on this device: the closures above form
     # reference cycles that would otherwise keep them alive until some later garbage collection
     graph = graph_b = vgraph = graph_t = vgraph_t = None
+    ev_graphs.clear()
     if on_gpu:
         import gc
         gc.collect()

@@ -338,3 +338,45 @@ def test_tiled_layout_helpers_roundtrip():
     for row, k in ((0, 0), (17, 40), (47, 95), (5, 33)):
         off = ((row >> 4) * 3 + (k >> 5)) * 512 + ((k >> 3) & 3) * 128 + (row & 15) * 8 + (k & 7)
         assert float(t.reshape(-1)[off]) == float(x[row, k])
+
+
+@pytest.mark.parametrize("B", [128, 37])
+def test_evaluation_pass_of_the_engine_equals_the_module_in_eval_mode(B):
+    """PinnFusedStep.evaluate: the forward stages with running statistics (BatchNorm1d layers and the stencil's BatchNorm1d(1)), no
+    dropout, loss on the tile -- against model.eval() under bf16 autocast + the criterion, after two training steps have moved the
+    running statistics; nothing but the evaluation's own buffers changes."""
+    from openpystruct_amd.pinn_fused import PinnFusedStep
+    dev = torch.device("cuda:0")
+    model, crit = _make(7, 0.3)
+    model, crit = model.to(dev), crit.to(dev)
+    _attach_flat(model)
+    g = torch.Generator().manual_seed(3)
+    eng = PinnFusedStep(model, crit, seed=99)
+    model.train()
+    for _ in range(2):                                       # running statistics away from their initial values
+        xt = torch.randn(128, 684, generator=g).to(dev)
+        yt = (0.8 * torch.randn(128, 302, generator=g)).to(dev)
+        eng.set_batch(xt, yt)
+        eng.fwd_bwd(128)
+    torch.cuda.synchronize()
+    x = torch.randn(B, 684, generator=g).to(torch.bfloat16).float().to(dev)
+    y = (0.8 * torch.randn(B, 302, generator=g)).to(dev)
+    bufs = {n: b.clone() for n, b in model.named_buffers()}
+    grads = {n: q.grad.clone() for n, q in model.named_parameters()}
+    eng.eval_loss_sum.zero_()
+    eng.set_batch(x, y)
+    loss = float(eng.evaluate(B))
+    preds = eng.predictions(B).float()
+    loss2 = float(eng.evaluate(B))
+    torch.cuda.synchronize()
+    model.eval()
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        pr = model(x).float()
+        lr = float(crit(pr, y))
+    assert float((preds - pr).norm() / pr.norm()) < 2e-2
+    assert abs(loss - lr) <= 1e-2 * abs(lr) and loss2 == loss
+    assert float(eng.eval_loss_sum) == pytest.approx(2 * loss, rel=1e-6)
+    for n, b in model.named_buffers():
+        assert torch.equal(b, bufs[n]), n                    # running statistics / counters untouched
+    for n, q in model.named_parameters():
+        assert torch.equal(q.grad, grads[n]), n
