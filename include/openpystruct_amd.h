@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define OPS_AMD_ABI_VERSION 6
+#define OPS_AMD_ABI_VERSION 7
 
 /* return codes of the launch functions (per-beam results are in `status`) */
 #define OPS_AMD_OK 0
