@@ -40,7 +40,7 @@ __host__ __device__ inline int fw_width(int kd) {           // compiled register
 }
 __host__ __device__ inline int fw_rows(int n) { return n + 64 + 2 * FW_G; }      // allocated rows: unguarded group prefetch
 __host__ __device__ inline size_t fw_frame_doubles(int n, int kd) { return (size_t)fw_rows(n) * (fw_width(kd) + 1); }
-constexpr int FW_CB = 72;   // broadcast line: entry `rel` at index rel + 1 (pairs (t, t + 1), t odd, are 16-byte aligned), two buffers
+constexpr int FW_CB = 72;   // broadcast line: entry `rel` at index rel (pairs (t, t + 1), t even, are 16-byte aligned), two buffers
 __host__ __device__ inline size_t fw_lds_doubles(int n, int W) { return ((2 * FW_CB + (size_t)FW_G * (W + 1) + (size_t)(n + 64)) + 1) & ~(size_t)1; }
 
 __device__ __forceinline__ double fw_readlane(double v, int lane) {
@@ -202,38 +202,87 @@ __global__ __launch_bounds__(1024) void frame_plan_kernel(const FrameParams p, i
 }
 
 // ---- the solve: one wave per frame ----
+#ifndef FW_NO_BOUNDARY                                     // (phase ablation builds: no rows enter after the prologue)
+#define FW_NO_BOUNDARY 0
+#endif
+#ifndef FW_PF_36
+#define FW_PF_36 0
+#endif
+#ifndef FW_PF_52
+#define FW_PF_52 0
+#endif
+// broadcast reads of a step issued before its first multiply-add (0: the compiler's own schedule)
+constexpr int fw_reads_ahead(int W) { return W == 36 ? FW_PF_36 : W == 52 ? FW_PF_52 : 0; }
+
 template <int W>
 struct FwState {
   double reg[W];     // own row: A[R][C] at index C mod W
   double y;          // own right-hand side (forward), own w / x (backward)
 };
 
-// one factorisation step; S = j mod W at compile time
+// what step j needs from outside its own arithmetic, made one step AHEAD (the wave is latency-bound: reciprocal chain, LDS
+// round trip of the broadcast line): column j is final in every lane's reg[S] once step j - 1 has updated it, so the line is
+// written and the pivot reciprocal started while step j - 1 still has its kd - 1 other columns to update
 template <int W, int S>
-__device__ __forceinline__ void fw_step(FwState<W>& st, int j, int lane, int n, int kd, double* __restrict__ colbuf,
-                                        double* __restrict__ Lc, double* __restrict__ xs, int& bad) {
+__device__ __forceinline__ void fw_prepare(const FwState<W>& st, int j, int lane, int n, int kd, double* __restrict__ colbuf, double& rd,
+                                           int& bad) {
   const int rel = (lane - j) & 63, R = j + rel;
   const bool inwin = rel >= 1 && rel <= kd && R < n;
   const double a = st.reg[S];
+  colbuf[(j & 1) * FW_CB + rel] = inwin ? a : 0.0;          // double-buffered broadcast line
   const double d = fw_readlane(a, j & 63);
-  const double rd = frcp(d);
-  bad |= !(d > 0.0);
-  const double l = inwin ? a * rd : 0.0;
-  double* cb = colbuf + (j & 1) * FW_CB;                    // double-buffered broadcast line
-  cb[rel + 1] = inwin ? a : 0.0;
+  rd = frcp(d);
+  bad |= (j < n) & !(d > 0.0);                              // (called unconditionally, also for j = n: no branch in the step)
+}
+
+// one factorisation step; S = j mod W at compile time; `rd` = 1 / d_j on entry, 1 / d_(j+1) on return
+template <int W, int S>
+__device__ __forceinline__ void fw_step(FwState<W>& st, int j, int lane, int n, int kd, double* __restrict__ colbuf,
+                                        double* __restrict__ Lc, double* __restrict__ xs, double& rd, int& bad) {
+  const int rel = (lane - j) & 63, R = j + rel;
+  const bool inwin = rel >= 1 && rel <= kd && R < n;
+  const double a = st.reg[S], rdj = rd;
+  const double l = inwin ? a * rdj : 0.0;
   const double zj = fw_readlane(st.y, j & 63);              // the pivot row's right-hand side is final
-  fw_fence();
+  // column j + 1 first, its multiplier A[j + 1][j] through a readlane instead of the line: the next step's line and
+  // reciprocal start here
+  const double a1 = fw_readlane(a, (j + 1) & 63);
+  st.reg[(S + 1) % W] = __builtin_fma(-l, a1, st.reg[(S + 1) % W]);
+  fw_fence();                                               // line j (written one step ago) has landed
+  fw_prepare<W, (S + 1) % W>(st, j + 1, lane, n, kd, colbuf, rd, bad);
+  const double* cb = colbuf + (j & 1) * FW_CB;
 #ifndef FW_SKIP_LSTORE                                     // (phase ablation builds, scripts/frame_phase_ab.sh)
   if (inwin) Lc[(size_t)j * W + (rel - 1)] = l;             // column j of L: one coalesced store
 #endif
-  if (rel == 0) xs[j] = zj * rd;                            // w_j = z_j / d_j
+  if (rel == 0) xs[j] = zj * rdj;                           // w_j = z_j / d_j
   st.y = __builtin_fma(-l, zj, st.y);
+  // reg[(S + t) mod W] -= l * A[j + t][j], t = 2 .. W - 1: two columns per 16-byte broadcast read, PF reads in flight
+  constexpr int NT = (W - 1) / 2, PF = fw_reads_ahead(W) < NT ? fw_reads_ahead(W) : NT;
+  if constexpr (PF > 0) {
+    double2 q[PF];
 #pragma unroll
-  for (int t = 1; t < W; t += 2) {                          // reg[(S + t) mod W] -= l * A[j + t][j], two per 16-byte broadcast read
-    const double2 ac = *reinterpret_cast<const double2*>(cb + t + 1);
-    st.reg[(S + t) % W] = __builtin_fma(-l, ac.x, st.reg[(S + t) % W]);
-    if (t + 1 < W) st.reg[(S + t + 1) % W] = __builtin_fma(-l, ac.y, st.reg[(S + t + 1) % W]);
+    for (int i = 0; i < PF; ++i) q[i] = *reinterpret_cast<const double2*>(cb + 2 + 2 * i);
+    __builtin_amdgcn_sched_barrier(0);                      // (left alone, the scheduler keeps three reads in flight: the wave then
+#pragma unroll                                              //  waits a third of an LDS round trip per read)
+    for (int i = 0; i < NT; ++i) {
+      const int t = 2 + 2 * i;
+      const double2 ac = q[i % PF];
+      if (i + PF < NT) q[i % PF] = *reinterpret_cast<const double2*>(cb + t + 2 * PF);
+      st.reg[(S + t) % W] = __builtin_fma(-l, ac.x, st.reg[(S + t) % W]);
+      if (t + 1 < W) st.reg[(S + t + 1) % W] = __builtin_fma(-l, ac.y, st.reg[(S + t + 1) % W]);
+    }
+  } else {
+#pragma unroll
+    for (int t = 2; t < W; t += 2) {
+      const double2 ac = *reinterpret_cast<const double2*>(cb + t);
+      st.reg[(S + t) % W] = __builtin_fma(-l, ac.x, st.reg[(S + t) % W]);
+      if (t + 1 < W) st.reg[(S + t + 1) % W] = __builtin_fma(-l, ac.y, st.reg[(S + t + 1) % W]);
+    }
   }
+  // a step's multiply-adds stay in the step: left free (no branch between two steps), the compiler defers them until the
+  // column is next read and keeps -- spills -- the line values of several steps
+#pragma unroll
+  for (int c = 0; c < W; ++c) __asm__ volatile("" : "+v"(st.reg[c]));
 }
 
 // move one staged group (rows g0 .. g0 + G - 1: parked in `stage`) into the registers of the lanes that own them
@@ -253,7 +302,7 @@ __device__ __forceinline__ void frame_wave_body(const FrameParams& p, double* __
                                                 const FwPlan& pl) {
   constexpr int G = FW_G, K = (G * W + 63) / 64;
   const int n = p.n_eq, kd = p.kd;
-  const int KG = (kd + G - 1) / G * G;                      // registers hold the rows below j + KG + G at step j
+  const int KG = (kd / G + 1) * G;                          // > kd (column j + 1 is read during step j): registers hold the rows below j + KG + G at step j
   double* colbuf = lds;                                     // [2][FW_CB]
   double* stage = lds + 2 * FW_CB;                          // [G][W + 1]: rows + right-hand sides of one group
   double* xs = stage + (size_t)G * (W + 1);                 // [n + 64]: w, then x
@@ -337,6 +386,8 @@ __device__ __forceinline__ void frame_wave_body(const FrameParams& p, double* __
   fetch(KG + 2 * G);
 
   // ---- factorisation + forward substitution ----
+  double rd = 0.0;
+  fw_prepare<W, 0>(st, 0, lane, n, kd, colbuf, rd, bad);
   for (int j0 = 0; j0 < n; j0 += W) {
     auto boundary = [&](int j) {                            // j % G == 0, j > 0: rows [j + KG, j + KG + G) enter
       fw_take_group<W>(st, j + KG, lane, stage);
@@ -345,17 +396,23 @@ __device__ __forceinline__ void frame_wave_body(const FrameParams& p, double* __
       fw_fence();
       fetch(j + KG + 2 * G);
     };
-    // W-fold unrolled: the register index of column j is j mod W
+    // W-fold unrolled: the register index of column j is j mod W.  Guarded per FOUR steps (W % 4 == 0): a step past the
+    // last equation is a no-op (no lane is inside its window; xs has 64 spare entries), and a branch per step made the
+    // compiler split the step's reads from its multiply-adds (all kd / 2 reads live at once: +50 VGPRs)
 #define FW_STEP(S_)                                                                   \
-    if constexpr ((S_) < W) {                                                         \
+    {                                                                                 \
       const int j = j0 + (S_);                                                        \
-      if (j < n) {                                                                    \
-        if (j > 0 && (j % G) == 0) boundary(j);                                       \
-        fw_step<W, (S_)>(st, j, lane, n, kd, colbuf, rows, xs, bad);                  \
-      }                                                                               \
+      if constexpr (!FW_NO_BOUNDARY) if (j > 0 && (j % G) == 0 && j < n) boundary(j); \
+      fw_step<W, (S_)>(st, j, lane, n, kd, colbuf, rows, xs, rd, bad);                \
     }
-#define FW_STEP8(S_) FW_STEP(S_) FW_STEP(S_ + 1) FW_STEP(S_ + 2) FW_STEP(S_ + 3) FW_STEP(S_ + 4) FW_STEP(S_ + 5) FW_STEP(S_ + 6) FW_STEP(S_ + 7)
+#define FW_STEP4(S_)                                                                  \
+    if constexpr ((S_) < W) {                                                         \
+      if (j0 + (S_) < n) { FW_STEP(S_) FW_STEP(S_ + 1) FW_STEP(S_ + 2) FW_STEP(S_ + 3) } \
+    }
+#define FW_STEP8(S_) FW_STEP4(S_) FW_STEP4(S_ + 4)
+    static_assert(W % 4 == 0 && W <= 56, "frame_wave: window widths are multiples of four");
     FW_STEP8(0) FW_STEP8(8) FW_STEP8(16) FW_STEP8(24) FW_STEP8(32) FW_STEP8(40) FW_STEP8(48)
+#undef FW_STEP4
 #undef FW_STEP8
 #undef FW_STEP
   }
@@ -374,7 +431,11 @@ __device__ __forceinline__ void frame_wave_body(const FrameParams& p, double* __
     };
 #pragma unroll
     for (int u = 0; u < PDD; ++u) cq[u] = cfetch(n - 1 - u);
+#ifdef FW_SKIP_BACKWARD
+    for (int jb = -1; jb >= 0; jb -= PDD) {
+#else
     for (int jb = n - 1; jb >= 0; jb -= PDD) {
+#endif
 #pragma unroll
       for (int u = 0; u < PDD; ++u) {
         const int j = jb - u;
@@ -432,7 +493,13 @@ __device__ __forceinline__ void frame_wave_body(const FrameParams& p, double* __
 
 // waves per SIMD the register allocator is asked to make room for (the kernel is latency-bound per wave: rcp chain, LDS
 // round trip of the broadcast line): 2 W VGPRs of window + ~55
-constexpr int fw_waves(int W) { return W <= 36 ? 1 : W <= 52 ? 3 : 2; }   // measured: only the 52-wide window gains (170 -> 168 VGPRs: 3 waves)
+#ifndef FW_WAVES_36
+#define FW_WAVES_36 1
+#endif
+#ifndef FW_WAVES_52
+#define FW_WAVES_52 3
+#endif
+constexpr int fw_waves(int W) { return W < 36 ? 1 : W == 36 ? FW_WAVES_36 : W <= 52 ? FW_WAVES_52 : 2; }   // measured: only the 52-wide window gains (170 -> 168 VGPRs: 3 waves)
 
 template <int W, bool FUSED>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(fw_waves(W))))
