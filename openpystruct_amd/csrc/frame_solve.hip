@@ -573,7 +573,7 @@ static bool wave_kernel_serves(int n_eq, int kd) {
   if (!use_wave_kernel(kd)) return false;
   const int W = fw_width(kd);
   if (4 * fw_lds_doubles(n_eq, W) * sizeof(double) > 160 * 1024 - 64) return false;
-  if (fused_assembly() ? (size_t)n_eq * sizeof(int) > 64 * 1024 : ((size_t)FW_SLAB * W + (size_t)n_eq) * sizeof(double) > LDS_MAX) return false;
+  if (fused_assembly() ? n_eq > (1 << 20) : ((size_t)FW_SLAB * W + (size_t)n_eq) * sizeof(double) > LDS_MAX) return false;
   return true;
 }
 
@@ -595,7 +595,7 @@ static hipError_t launch_wave(const FrameParams& p, double* ws, hipStream_t s) {
   const FwPlan pl = fw_plan_at(plan_base, p.n_eq, p.Ne);
   const dim3 grid((unsigned)((p.B + 3) / 4));
   if (fused_assembly()) {
-    hipLaunchKernelGGL(frame_plan_kernel, dim3(1), dim3(1024), (size_t)p.n_eq * sizeof(int), s, p, W, plan_base);
+    hipLaunchKernelGGL(frame_plan_kernel, dim3(1), dim3(1024), (size_t)3 * (fw_groups(p.n_eq) + 2) * sizeof(int), s, p, W, plan_base);
     hipLaunchKernelGGL((frame_wave_kernel<W, true>), grid, dim3(256), lds, s, p, ws, pl);
   } else {
     const size_t lds_asm = ((size_t)FW_SLAB * W + (size_t)p.n_eq) * sizeof(double);

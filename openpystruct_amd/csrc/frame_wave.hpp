@@ -14,21 +14,25 @@
 //     entry A[R][C] sits in that lane's register  reg[C mod W]  (W >= kd + 1, a compile-time constant): the register
 //     index is the same for every lane, so the kernel is unrolled W-fold over (column mod W) and needs no dynamic register
 //     indexing;
-//   * step j: the pivot is one v_readlane, every window lane scales its own entry (l = A[R][j] / d_j), the unscaled column
-//     goes through a 64-entry LDS line as a BROADCAST (one ds_write + kd/2 conflict-free 16-byte broadcast reads), and
-//     each lane updates its row:  reg[C mod W] -= l * A[C][j]  -- one FMA per column of the window, operands in registers;
-//   * forward substitution rides along (one readlane + one FMA); column j of L leaves with ONE coalesced store, into the
-//     place of the assembled row j it no longer needs (the factor overwrites the band in the HBM workspace);
-//   * rows enter the window in groups of 8: the group's 8 x W doubles are contiguous in the workspace, fetched by the whole
-//     wave one group ahead, parked in LDS, and moved into the owners' registers when their lanes fall free;
-//   * backward substitution is the mirror image ("axpy" form): lane (R mod 64) carries w_R, x_j is one readlane, every
-//     lane reads ITS column of L as one contiguous run over kd consecutive steps (sector reuse in L1).
+//   * step j: every window lane scales its own entry (l = A[R][j] / d_j), the unscaled column goes through a 64-entry LDS
+//     line as a BROADCAST (one ds_write + kd/2 conflict-free 16-byte broadcast reads), and each lane updates its row:
+//     reg[C mod W] -= l * A[C][j]  -- one FMA per column of the window, operands in registers.  The line of step j + 1 and
+//     the reciprocal of its pivot (one v_readlane) are produced DURING step j, right after column j + 1 has taken its update
+//     (fw_prepare), so neither the reciprocal chain nor the LDS round trip sits between two steps;
+//   * forward substitution rides along (one readlane + one FMA); column j of L leaves with ONE coalesced store into the
+//     per-frame HBM workspace;
+//   * rows enter the window in groups of 8 through an LDS parking area: the group is ASSEMBLED there (fused assembly: plan
+//     blocks below, ds_add_f64) one boundary before its owners' lanes fall free and take it;
+//   * backward substitution: dot form for W >= 36 (column j of L = one coalesced load, DPP + readlane wave reduction), the
+//     mirror-image "axpy" form below that.
 //
-// Bound: HBM.  Per frame the workspace is written once by the assembly, read once and rewritten by the factorisation, read
-// once by the backward sweep: 4 n W 8 bytes (10 x 10 bays: 380 KB; 15 x 16: 1.28 MB) -- DESIGN.md section 8 f1 has the
-// measured numbers.  No MFMA: the update is rank-1 per column on a window that slides by one column per step; a
+// Bound (r03 phase ablation, 15 x 16: 4.0 ms per 12 288 frames): the elimination steps 2.5 ms = VALU issue (82 VALU + 25 LDS
+// instructions per step and wave, 54 of them FP64 FMAs, three waves per SIMD), group entry 0.5, L stores 0.3, backward sweep
+// 0.7 ms.  HBM: the factor workspace is written once and read once (2 n W 8 bytes per frame: 15 x 16 0.64 MB) -- 2 TB/s, not
+// the bound.  No MFMA: the update is rank-1 per column on a window that slides by one column per step; a
 // 16-column panel (what v_mfma_f64_16x16x4_f64 tiles would need to keep their tile <-> lane mapping fixed) is as wide as
-// the whole band of the reference's frames (kd = 3 (bays + 1) + 2 <= 35) and its panel factorisation is the serial part.
+// the whole band of the reference's frames (kd = 3 (bays + 1) + 2 <= 35) and its panel factorisation is the serial part
+// (and the FP64 matrix rate of the MI355X equals its vector rate).
 #pragma once
 
 namespace opsamd {
@@ -127,49 +131,68 @@ __global__ __launch_bounds__(256) void frame_assemble_rows_kernel(const FramePar
 // of its DOF.  With the plan the solve kernel builds every 8-row group directly in its LDS parking area one group ahead of
 // need: the assembled band never exists in HBM (r02 first version: assembly kernel writes it, solve kernel reads it back =
 // half of the solve's memory traffic and 20 % of its time).
+//
+// Layout (r03): the entries of row group gi (rows 8 gi .. 8 gi + 7) are a fixed block of FW_EPG = 192 slots -- entry word
+// (valid | element << 9 | parking slot) and its two coefficients at the SAME index -- zero-padded, so the solve kernel's loads are
+// coalesced, unconditional and depend on nothing but the group number: one entry-word load a group ahead, then ONE round
+// trip (inertia gather + coefficients) per group.  (r02: entry -> element -> three gathers behind per-row pointers = seven
+// serialised round trips per group, 17 % of the solve.)  A group with more than 192 entries (nodes with more than four
+// elements) continues in extra blocks; a padded all-zero block serves the groups past the last equation.
+constexpr int FW_KE = 3;                  // entry words a lane carries per group
+constexpr int FW_EPG = 64 * FW_KE;        // entries per block
 struct FwPlan {
-  const int* row_ptr;        // [n + 1]
-  const int* eq_dof;         // [n]   index into loads[Nn*3]
-  const uint2* ent;          // [row_ptr[n]]  .x = element, .y = kidx (r*6+q) | slot << 8 | row << 16
-  const double* ka;          // [Ne*36]
-  const double* kb;          // [Ne*36]
-  const double* rhs_base;    // [n]
+  const int* hdr;            // [4]   [0] = number of extra blocks (0 for the reference's grid frames)
+  const int* eq_dof;         // [n + 1]   index into loads[Nn*3]; [n] = 0
+  const int* xstart;         // [ng + 2]  first extra block of a group (prefix sums); groups past the end: no extra blocks
+  const unsigned* ent;       // [nblk][FW_EPG]  bit 31 (valid) | element << 9 | (row in group) * (W + 1) + column slot
+  const double* ka;          // [nblk][FW_EPG]
+  const double* kb;          // [nblk][FW_EPG]
+  const double* rhs_base;    // [n + 1]; [n] = 0
+  int ng;                    // row groups; block ng is the all-zero block
 };
+__host__ __device__ inline int fw_groups(int n) { return (n + FW_G - 1) / FW_G; }
+__host__ __device__ inline size_t fw_plan_blocks(int n, int Ne) { return (size_t)fw_groups(n) + 1 + ((size_t)Ne * 21 + FW_EPG - 1) / FW_EPG; }
 __host__ __device__ inline size_t fw_plan_bytes(int n, int Ne) {
-  return (size_t)(((n + 2) / 2) * 2 + ((n + 1) / 2) * 2) * 4 + (size_t)Ne * 21 * 8 + (size_t)Ne * 72 * 8 + (size_t)n * 8;
+  const size_t ints = 4 + (size_t)(n + 1) + (size_t)(fw_groups(n) + 2);
+  return ((ints + 1) / 2) * 8 + fw_plan_blocks(n, Ne) * FW_EPG * (4 + 8 + 8) + (size_t)(n + 1) * 8;
 }
 __host__ __device__ inline FwPlan fw_plan_at(void* base, int n, int Ne) {
   char* q = (char*)base;
+  const size_t nblk = fw_plan_blocks(n, Ne);
   FwPlan pl;
-  pl.row_ptr = (const int*)q;  q += (size_t)(((n + 2) / 2) * 2) * 4;
-  pl.eq_dof = (const int*)q;   q += (size_t)(((n + 1) / 2) * 2) * 4;
-  pl.ent = (const uint2*)q;    q += (size_t)Ne * 21 * 8;
-  pl.ka = (const double*)q;    q += (size_t)Ne * 36 * 8;
-  pl.kb = (const double*)q;    q += (size_t)Ne * 36 * 8;
-  pl.rhs_base = (const double*)q;
+  pl.ng = fw_groups(n);
+  pl.ka = (const double*)q;        q += nblk * FW_EPG * 8;
+  pl.kb = (const double*)q;        q += nblk * FW_EPG * 8;
+  pl.rhs_base = (const double*)q;  q += (size_t)(n + 1) * 8;
+  pl.ent = (const unsigned*)q;     q += nblk * FW_EPG * 4;
+  pl.hdr = (const int*)q;          q += 4 * 4;
+  pl.eq_dof = (const int*)q;       q += (size_t)(n + 1) * 4;
+  pl.xstart = (const int*)q;
   return pl;
 }
 
+// one workgroup; LDS: 3 * (ng + 2) ints
 __global__ __launch_bounds__(1024) void frame_plan_kernel(const FrameParams p, int W, void* plan_base) {
-  extern __shared__ int s_cnt[];            // [n] counts, then cursors
+  extern __shared__ int s_plan[];
   const FwPlan pl = fw_plan_at(plan_base, p.n_eq, p.Ne);
-  int* row_ptr = const_cast<int*>(pl.row_ptr);
+  const int n = p.n_eq, ng = pl.ng, tid = threadIdx.x, T = blockDim.x;
+  int* cnt = s_plan;                  // [ng + 1] entries per group
+  int* cur = s_plan + (ng + 2);       // [ng + 1] fill cursors
+  int* xs_ = s_plan + 2 * (ng + 2);   // [ng + 2] first extra block per group
+  int* hdr = const_cast<int*>(pl.hdr);
   int* eq_dof = const_cast<int*>(pl.eq_dof);
-  uint2* ent = const_cast<uint2*>(pl.ent);
+  int* xstart = const_cast<int*>(pl.xstart);
+  unsigned* ent = const_cast<unsigned*>(pl.ent);
   double* ka = const_cast<double*>(pl.ka);
   double* kb = const_cast<double*>(pl.kb);
   double* rhs_base = const_cast<double*>(pl.rhs_base);
-  const int n = p.n_eq, tid = threadIdx.x, T = blockDim.x;
-  for (int i = tid; i < n; i += T) { s_cnt[i] = 0; rhs_base[i] = 0.0; }
+  for (int i = tid; i <= ng; i += T) { cnt[i] = 0; cur[i] = 0; }
+  for (int i = tid; i <= n; i += T) { rhs_base[i] = 0.0; eq_dof[i] = 0; }
   __syncthreads();
   for (int i = tid; i < p.Nn * 3; i += T) { const int q = p.node_eq[i]; if (q >= 0) eq_dof[q] = i; }
+  // pass A: entries per group, consistent nodal loads of the element loads
   for (int e = tid; e < p.Ne; e += T) {
     const double L = p.elem_geo[3 * e], c = p.elem_geo[3 * e + 1], s = p.elem_geo[3 * e + 2];
-    double k[6][6];
-    elem_global_k(L, c, s, p.elem_EA[e], 0.0, k);
-    for (int r = 0; r < 6; ++r) for (int q = 0; q < 6; ++q) ka[e * 36 + r * 6 + q] = k[r][q];
-    elem_global_k(L, c, s, 0.0, p.elem_E[e], k);
-    for (int r = 0; r < 6; ++r) for (int q = 0; q < 6; ++q) kb[e * 36 + r * 6 + q] = k[r][q];
     const double wy = p.elem_w[2 * e], wx = p.elem_w[2 * e + 1];
     const double pl6[6] = {wx * L / 2, wy * L / 2, wy * L * L / 12, wx * L / 2, wy * L / 2, -wy * L * L / 12};
     const double pg[6] = {c * pl6[0] - s * pl6[1], s * pl6[0] + c * pl6[1], pl6[2], c * pl6[3] - s * pl6[4], s * pl6[3] + c * pl6[4], pl6[5]};
@@ -177,43 +200,49 @@ __global__ __launch_bounds__(1024) void frame_plan_kernel(const FrameParams p, i
       const int er = p.elem_eq[6 * e + r];
       if (er < 0) continue;
       atomicAdd(&rhs_base[er], pg[r]);
-      for (int q = 0; q < 6; ++q) { const int eq = p.elem_eq[6 * e + q]; if (eq >= 0 && eq <= er) atomicAdd(&s_cnt[er], 1); }
+      for (int q = 0; q < 6; ++q) { const int eq = p.elem_eq[6 * e + q]; if (eq >= 0 && eq <= er) atomicAdd(&cnt[er / FW_G], 1); }
     }
   }
   __syncthreads();
-  if (tid == 0) {                            // exclusive scan (n <= a few thousand)
+  if (tid == 0) {                            // extra blocks per group: exclusive scan (ng <= a few hundred)
     int acc = 0;
-    for (int i = 0; i < n; ++i) { const int c0 = s_cnt[i]; row_ptr[i] = acc; s_cnt[i] = acc; acc += c0; }
-    row_ptr[n] = acc;
+    for (int g = 0; g < ng; ++g) { xs_[g] = acc; acc += cnt[g] > FW_EPG ? (cnt[g] - 1) / FW_EPG : 0; }
+    xs_[ng] = acc; xs_[ng + 1] = acc;
+    hdr[0] = acc; hdr[1] = hdr[2] = hdr[3] = 0;
   }
   __syncthreads();
-  for (int e = tid; e < p.Ne; e += T)
+  const int nblk = ng + 1 + xs_[ng];
+  for (int i = tid; i < ng + 2; i += T) xstart[i] = xs_[i];
+  for (long i = tid; i < (long)nblk * FW_EPG; i += T) { ent[i] = 0u; ka[i] = 0.0; kb[i] = 0.0; }
+  __syncthreads();
+  // pass B: fill (the order inside a group is the order of arrival: the parking area accumulates with LDS atomics anyway)
+  for (int e = tid; e < p.Ne; e += T) {
+    const double L = p.elem_geo[3 * e], c = p.elem_geo[3 * e + 1], s = p.elem_geo[3 * e + 2];
+    double k_a[6][6], k_b[6][6];
+    elem_global_k(L, c, s, p.elem_EA[e], 0.0, k_a);
+    elem_global_k(L, c, s, 0.0, p.elem_E[e], k_b);
     for (int r = 0; r < 6; ++r) {
       const int er = p.elem_eq[6 * e + r];
       if (er < 0) continue;
+      const int g = er / FW_G;
       for (int q = 0; q < 6; ++q) {
         const int eq = p.elem_eq[6 * e + q];
         if (eq >= 0 && eq <= er) {
-          const int pos = atomicAdd(&s_cnt[er], 1);
-          ent[pos] = make_uint2((unsigned)e, (unsigned)(r * 6 + q) | ((unsigned)(eq % W) << 8) | ((unsigned)er << 16));
+          const int pos = atomicAdd(&cur[g], 1), blk = pos / FW_EPG;
+          const long idx = (long)(blk == 0 ? g : ng + 1 + xs_[g] + blk - 1) * FW_EPG + pos % FW_EPG;
+          ent[idx] = 0x80000000u | ((unsigned)e << 9) | (unsigned)((er % FW_G) * (W + 1) + eq % W);
+          ka[idx] = k_a[r][q];
+          kb[idx] = k_b[r][q];
         }
       }
     }
+  }
 }
 
 // ---- the solve: one wave per frame ----
 #ifndef FW_NO_BOUNDARY                                     // (phase ablation builds: no rows enter after the prologue)
 #define FW_NO_BOUNDARY 0
 #endif
-#ifndef FW_PF_36
-#define FW_PF_36 0
-#endif
-#ifndef FW_PF_52
-#define FW_PF_52 0
-#endif
-// broadcast reads of a step issued before its first multiply-add (0: the compiler's own schedule)
-constexpr int fw_reads_ahead(int W) { return W == 36 ? FW_PF_36 : W == 52 ? FW_PF_52 : 0; }
-
 template <int W>
 struct FwState {
   double reg[W];     // own row: A[R][C] at index C mod W
@@ -256,28 +285,13 @@ __device__ __forceinline__ void fw_step(FwState<W>& st, int j, int lane, int n, 
 #endif
   if (rel == 0) xs[j] = zj * rdj;                           // w_j = z_j / d_j
   st.y = __builtin_fma(-l, zj, st.y);
-  // reg[(S + t) mod W] -= l * A[j + t][j], t = 2 .. W - 1: two columns per 16-byte broadcast read, PF reads in flight
-  constexpr int NT = (W - 1) / 2, PF = fw_reads_ahead(W) < NT ? fw_reads_ahead(W) : NT;
-  if constexpr (PF > 0) {
-    double2 q[PF];
+  // reg[(S + t) mod W] -= l * A[j + t][j], t = 2 .. W - 1: two columns per 16-byte broadcast read.  (The compiler keeps three
+  // reads in flight; an explicit read-ahead of 5 .. 25 reads, at two or three waves per SIMD, measured slower: r03_notes 4.)
 #pragma unroll
-    for (int i = 0; i < PF; ++i) q[i] = *reinterpret_cast<const double2*>(cb + 2 + 2 * i);
-    __builtin_amdgcn_sched_barrier(0);                      // (left alone, the scheduler keeps three reads in flight: the wave then
-#pragma unroll                                              //  waits a third of an LDS round trip per read)
-    for (int i = 0; i < NT; ++i) {
-      const int t = 2 + 2 * i;
-      const double2 ac = q[i % PF];
-      if (i + PF < NT) q[i % PF] = *reinterpret_cast<const double2*>(cb + t + 2 * PF);
-      st.reg[(S + t) % W] = __builtin_fma(-l, ac.x, st.reg[(S + t) % W]);
-      if (t + 1 < W) st.reg[(S + t + 1) % W] = __builtin_fma(-l, ac.y, st.reg[(S + t + 1) % W]);
-    }
-  } else {
-#pragma unroll
-    for (int t = 2; t < W; t += 2) {
-      const double2 ac = *reinterpret_cast<const double2*>(cb + t);
-      st.reg[(S + t) % W] = __builtin_fma(-l, ac.x, st.reg[(S + t) % W]);
-      if (t + 1 < W) st.reg[(S + t + 1) % W] = __builtin_fma(-l, ac.y, st.reg[(S + t + 1) % W]);
-    }
+  for (int t = 2; t < W; t += 2) {
+    const double2 ac = *reinterpret_cast<const double2*>(cb + t);
+    st.reg[(S + t) % W] = __builtin_fma(-l, ac.x, st.reg[(S + t) % W]);
+    if (t + 1 < W) st.reg[(S + t + 1) % W] = __builtin_fma(-l, ac.y, st.reg[(S + t + 1) % W]);
   }
   // a step's multiply-adds stay in the step: left free (no branch between two steps), the compiler defers them until the
   // column is next read and keeps -- spills -- the line values of several steps
@@ -315,30 +329,59 @@ __device__ __forceinline__ void frame_wave_body(const FrameParams& p, double* __
   st.y = 0.0;
   int bad = 0;
 
-  constexpr int KE = 3;                                      // plan entries a lane carries between fetch and park (8 rows x 24 / 64)
-  double tmp[FUSED ? KE : K], tmpy;
-  int tslot[FUSED ? KE : 1], tbeg = 0, tend = 0;
+  // rows enter in groups of G: the group's values are parked in `stage` one boundary before the owners take them
   const double* Ib = p.I + b * p.Ne;
   const double* lb = p.loads + b * p.loads_bs;
-  auto entry = [&](int i, int g0, int& slot) -> double {    // value and LDS slot of plan entry i (a row of group g0)
-    const uint2 en = pl.ent[i];
-    const int kidx = en.y & 0xFF, c = (en.y >> 8) & 0xFF, R = (int)(en.y >> 16);
-    slot = (R - g0) * (W + 1) + c;
-    return __builtin_fma(Ib[en.x], pl.kb[en.x * 36 + kidx], pl.ka[en.x * 36 + kidx]);
-  };
-  auto fetch = [&](int g0) {                                // group g0: G rows + right-hand sides, one group ahead of need
-    if constexpr (FUSED) {
-      const int r0 = g0 < n ? g0 : n, r1 = g0 + G < n ? g0 + G : n;
-      tbeg = pl.row_ptr[r0]; tend = pl.row_ptr[r1];
+  // -- fused assembly (plan): entry words of the NEXT group to build travel in registers (loaded one boundary ahead);
+  //    build = one round trip (inertia gather, coefficients, right-hand side), issued before the boundary's LDS work
+  constexpr int KE = FW_KE;
+  unsigned eB[KE] = {0u, 0u, 0u};
+  int dofB = 0, gB = 0;
+  double bi[KE], ba[KE], bb[KE], by1 = 0.0, by2 = 0.0;
+  const int n_extra = FUSED ? pl.hdr[0] : 0;
+  auto ents = [&](int g0) {                                 // group g0 (a multiple of G): entry words + load index, no wait
+    const int gi = g0 / G < pl.ng ? g0 / G : pl.ng;         // past the last equation: the all-zero block
+    const unsigned* e = pl.ent + (size_t)gi * FW_EPG + lane;
 #pragma unroll
-      for (int k = 0; k < KE; ++k) {
-        const int i = tbeg + lane + 64 * k;
-        tslot[k] = 0;
-        tmp[k] = (i < tend) ? entry(i, g0, tslot[k]) : 0.0;
-      }
-      tmpy = (lane < G && g0 + lane < n) ? pl.rhs_base[g0 + lane] + lb[pl.eq_dof[g0 + lane]] : 0.0;
-      tbeg = g0;                                            // park() needs the group's first row for the overflow loop
-    } else {
+    for (int k = 0; k < KE; ++k) eB[k] = e[64 * k];
+    const int r = g0 + (lane < G ? lane : 0);
+    dofB = pl.eq_dof[r < n ? r : n];
+    gB = g0;
+  };
+  auto build_issue = [&]() {                                // the loads of group gB
+    const int gi = gB / G < pl.ng ? gB / G : pl.ng;
+    const double* ka = pl.ka + (size_t)gi * FW_EPG + lane;
+    const double* kb = pl.kb + (size_t)gi * FW_EPG + lane;
+#pragma unroll
+    for (int k = 0; k < KE; ++k) { bi[k] = Ib[(eB[k] >> 9) & 0x3FFFFF]; ba[k] = ka[64 * k]; bb[k] = kb[64 * k]; }
+    const int r = gB + (lane < G ? lane : 0);
+    by1 = pl.rhs_base[r < n ? r : n];
+    by2 = lb[dofB];
+  };
+  auto build_finish = [&]() {                               // ... accumulated into the (zeroed) stage
+#pragma unroll
+    for (int k = 0; k < KE; ++k)
+      if ((int)eB[k] < 0) atomicAdd(&stage[eB[k] & 511u], __builtin_fma(bi[k], bb[k], ba[k]));
+    if (n_extra != 0) {                                     // nodes with more than four elements: extra blocks, not prefetched
+      const int gi = gB / G < pl.ng ? gB / G : pl.ng;
+      for (int blk = pl.xstart[gi]; blk < pl.xstart[gi + 1]; ++blk)
+        for (int k = 0; k < KE; ++k) {
+          const size_t i = (size_t)(pl.ng + 1 + blk) * FW_EPG + lane + 64 * k;
+          const unsigned w = pl.ent[i];
+          if ((int)w < 0) atomicAdd(&stage[w & 511u], __builtin_fma(Ib[(w >> 9) & 0x3FFFFF], pl.kb[i], pl.ka[i]));
+        }
+    }
+    fw_fence();
+    if (lane < G) stage[lane * (W + 1) + W] = (gB + lane < n) ? by1 + by2 : 0.0;
+  };
+  auto zero_stage = [&]() {
+    for (int i = lane; i < G * (W + 1); i += 64) stage[i] = 0.0;
+    fw_fence();
+  };
+  // -- separate assembly kernel (A/B path): the group's G x W doubles are contiguous in the workspace
+  double tmp[FUSED ? 1 : K], tmpy = 0.0;
+  auto fetch = [&](int g0) {
+    if constexpr (!FUSED) {
 #pragma unroll
       for (int k = 0; k < K; ++k) {
         const int idx = lane + 64 * k;
@@ -347,23 +390,8 @@ __device__ __forceinline__ void frame_wave_body(const FrameParams& p, double* __
       tmpy = (lane < G && g0 + lane < n) ? rhs_g[g0 + lane] : 0.0;
     }
   };
-  auto park = [&]() {                                       // the fetched group -> LDS stage (row-major, pitch W + 1)
-    if constexpr (FUSED) {
-      for (int i = lane; i < G * (W + 1); i += 64) stage[i] = 0.0;
-      fw_fence();
-      const int g0 = tbeg, r0 = g0 < n ? g0 : n;
-      const int e0 = pl.row_ptr[r0];
-#pragma unroll
-      for (int k = 0; k < KE; ++k)
-        if (e0 + lane + 64 * k < tend) atomicAdd(&stage[tslot[k]], tmp[k]);
-      for (int i = e0 + lane + 64 * KE; i < tend; i += 64) {      // nodes with more than four elements: not prefetched
-        int slot;
-        const double v = entry(i, g0, slot);
-        atomicAdd(&stage[slot], v);
-      }
-      fw_fence();
-      if (lane < G) stage[lane * (W + 1) + W] = tmpy;
-    } else {
+  auto park = [&]() {
+    if constexpr (!FUSED) {
 #pragma unroll
       for (int k = 0; k < K; ++k) {
         const int idx = lane + 64 * k;
@@ -372,29 +400,51 @@ __device__ __forceinline__ void frame_wave_body(const FrameParams& p, double* __
       if (lane < G) stage[lane * (W + 1) + W] = tmpy;
     }
   };
-  // prologue: rows [0, KG + G) into registers, the next group parked, the one after in flight
-  for (int g0 = 0; g0 < KG + G; g0 += G) {
-    fetch(g0);
+  // prologue: rows [0, KG + G) into registers, the next group parked, the one after on its way
+  if constexpr (FUSED) {
+    for (int g0 = 0; g0 < KG + 2 * G; g0 += G) {
+      ents(g0);
+      build_issue();
+      zero_stage();
+      build_finish();
+      fw_fence();
+      if (g0 < KG + G) { fw_take_group<W>(st, g0, lane, stage); fw_fence(); }
+    }
+    ents(KG + 2 * G);
+  } else {
+    for (int g0 = 0; g0 < KG + G; g0 += G) {
+      fetch(g0);
+      park();
+      fw_fence();
+      fw_take_group<W>(st, g0, lane, stage);
+      fw_fence();
+    }
+    fetch(KG + G);
     park();
     fw_fence();
-    fw_take_group<W>(st, g0, lane, stage);
-    fw_fence();
+    fetch(KG + 2 * G);
   }
-  fetch(KG + G);
-  park();
-  fw_fence();
-  fetch(KG + 2 * G);
 
   // ---- factorisation + forward substitution ----
   double rd = 0.0;
   fw_prepare<W, 0>(st, 0, lane, n, kd, colbuf, rd, bad);
   for (int j0 = 0; j0 < n; j0 += W) {
     auto boundary = [&](int j) {                            // j % G == 0, j > 0: rows [j + KG, j + KG + G) enter
-      fw_take_group<W>(st, j + KG, lane, stage);
-      fw_fence();
-      park();                                               // the group fetched one boundary ago
-      fw_fence();
-      fetch(j + KG + 2 * G);
+      if constexpr (FUSED) {
+        build_issue();                                      // group j + KG + G: its round trip runs under the LDS work below
+        fw_take_group<W>(st, j + KG, lane, stage);
+        fw_fence();
+        zero_stage();
+        build_finish();
+        fw_fence();
+        ents(j + KG + 2 * G);
+      } else {
+        fw_take_group<W>(st, j + KG, lane, stage);
+        fw_fence();
+        park();                                             // the group fetched one boundary ago
+        fw_fence();
+        fetch(j + KG + 2 * G);
+      }
     };
     // W-fold unrolled: the register index of column j is j mod W.  Guarded per FOUR steps (W % 4 == 0): a step past the
     // last equation is a no-op (no lane is inside its window; xs has 64 spare entries), and a branch per step made the
@@ -402,7 +452,7 @@ __device__ __forceinline__ void frame_wave_body(const FrameParams& p, double* __
 #define FW_STEP(S_)                                                                   \
     {                                                                                 \
       const int j = j0 + (S_);                                                        \
-      if constexpr (!FW_NO_BOUNDARY) if (j > 0 && (j % G) == 0 && j < n) boundary(j); \
+      if constexpr (!FW_NO_BOUNDARY && (S_) % 4 == 0) if (j > 0 && (j % G) == 0 && j < n) boundary(j); /* j0 % 4 == 0 */ \
       fw_step<W, (S_)>(st, j, lane, n, kd, colbuf, rows, xs, rd, bad);                \
     }
 #define FW_STEP4(S_)                                                                  \

@@ -179,6 +179,41 @@ def test_general_topologies_vs_oracle(bays, stories, pinned, brace):
         assert relerr(sol.forces[b].cpu().numpy().ravel(), f.ravel()) < 1e-7
 
 
+def test_hub_node_with_eighteen_elements_takes_the_extra_plan_blocks():
+    """A node with eighteen incident elements: its row group holds more than the 192 assembly entries of one plan block
+    (csrc/frame_wave.hpp FW_EPG), so the solve walks the group's extra blocks -- the path the grid frames never take."""
+    from openpystruct_amd import frames
+    nn, hub = 19, 9
+    ang = np.linspace(0.0, 2 * np.pi, nn - 1, endpoint=False)
+    coords = np.zeros((nn, 2))
+    outer = [i for i in range(nn) if i != hub]
+    coords[outer, 0], coords[outer, 1] = 5.0 * np.cos(ang), 5.0 * np.sin(ang)
+    conn = [(hub, o) for o in outer] + [(outer[i], outer[i + 1]) for i in range(len(outer) - 1)]
+    conn = np.array(conn)
+    fix3 = np.zeros((nn, 3), dtype=bool)
+    fix3[0] = fix3[nn - 1] = True
+    loads = np.zeros((nn, 3)); loads[hub] = (3e4, -5e4, 2e3); loads[3] = (0.0, -1e4, 0.0)
+    w = np.zeros(len(conn)); w[:4] = -8e3
+    topo = frames.FrameTopology(coords, conn, fix3, 0.02, 200e9, w, 0.5 * w, loads, "cuda")
+    eq = topo.d_elem_eq.cpu().numpy()
+    per_group = np.zeros(topo.n_eq // 8 + 1, dtype=int)
+    for e in range(topo.Ne):
+        for r in range(6):
+            if eq[e, r] >= 0:
+                per_group[eq[e, r] // 8] += int(((eq[e] >= 0) & (eq[e] <= eq[e, r])).sum())
+    assert per_group.max() > 192 and topo.kd <= 55
+    rng = np.random.default_rng(11)
+    B = 6
+    I = np.exp(rng.uniform(np.log(5e-5), np.log(5e-3), size=(B, topo.Ne)))
+    sol = frames.frame_solve(topo, torch.as_tensor(I, device="cuda"))
+    assert int(sol.status.abs().sum()) == 0
+    for b in range(B):
+        d, f, st, neq, kd = _oracle(topo, I[b])
+        assert st == 0 and neq == topo.n_eq and kd == topo.kd
+        assert relerr(sol.disp[b].cpu().numpy().ravel(), d.ravel()) < 1e-8
+        assert relerr(sol.forces[b].cpu().numpy().ravel(), f.ravel()) < 1e-7
+
+
 def test_tiny_bandwidth_cantilever_chain():
     """A single cantilever of 40 collinear elements: half bandwidth 5; and a two-node model: half bandwidth 2 < 3."""
     from openpystruct_amd import frames
