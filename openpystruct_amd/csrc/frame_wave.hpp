@@ -60,12 +60,21 @@ __device__ __forceinline__ double fw_dpp(double x) {
   const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(u >> 32), CTRL, 0xF, 0xF, true);
   return __builtin_bit_cast(double, ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
 }
+template <int CTRL, int ROWS>
+__device__ __forceinline__ double fw_dpp_rows(double x) {   // lanes of the rows outside ROWS receive 0
+  const unsigned long long u = __builtin_bit_cast(unsigned long long, x);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)u, CTRL, ROWS, 0xF, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(u >> 32), CTRL, ROWS, 0xF, false);
+  return __builtin_bit_cast(double, ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
+}
 __device__ __forceinline__ double fw_wave_sum(double v) {
   v += fw_dpp<0xB1>(v);      // quad_perm [1,0,3,2]
   v += fw_dpp<0x4E>(v);      // quad_perm [2,3,0,1]
   v += fw_dpp<0x141>(v);     // row_half_mirror
-  v += fw_dpp<0x140>(v);     // row_mirror: every lane holds its row's total
-  return (fw_readlane(v, 0) + fw_readlane(v, 16)) + (fw_readlane(v, 32) + fw_readlane(v, 48));
+  v += fw_dpp<0x140>(v);     // row_mirror: every lane holds its row's total r0 .. r3
+  v += fw_dpp_rows<0x142, 0xA>(v);   // row_bcast:15 into rows 1, 3: r0 + r1, r2 + r3
+  v += fw_dpp_rows<0x143, 0xC>(v);   // row_bcast:31 into rows 2, 3: row 3 = (r0 + r1) + (r2 + r3)
+  return fw_readlane(v, 63);
 }
 // LDS operations of one wave execute in order; this pins the compiler and lands earlier reads
 __device__ __forceinline__ void fw_fence() {
@@ -475,27 +484,45 @@ __device__ __forceinline__ void frame_wave_body(const FrameParams& p, double* __
   if constexpr (W >= 36) {
     constexpr int PDD = 8;
     double xr = 0.0, cq[PDD];
+    // column j of L for this lane's row: an UNCONDITIONAL load from a clamped address, masked when it is USED eight columns
+    // later -- loads under branches (or masked on arrival) made the compiler wait for every outstanding load (vmcnt(0)) per
+    // column, i.e. the "prefetch" was none
     auto cfetch = [&](int j) -> double {
+      const int jj = j > 0 ? j : 0, rel = (lane - jj) & 63;
+      const int off = rel < 1 ? 0 : (rel <= W ? rel - 1 : W - 1);
+      return (rows + (size_t)jj * W)[off];
+    };
+    auto column = [&](int j, int u, double wv) {            // wv: lane u holds w_(jb - u)
       const int rel = (lane - j) & 63;
-      return (j >= 0 && rel >= 1 && rel <= kd && j + rel < n) ? rows[(size_t)j * W + (rel - 1)] : 0.0;
+      const double c = (rel >= 1 && rel <= kd && j + rel < n) ? cq[u] : 0.0;
+      const double s_ = fw_wave_sum(c * xr);
+      cq[u] = cfetch(j - PDD);
+      const double xj = fw_readlane(wv, u) - s_;
+      xr = rel == 0 ? xj : xr;
     };
 #pragma unroll
     for (int u = 0; u < PDD; ++u) cq[u] = cfetch(n - 1 - u);
 #ifdef FW_SKIP_BACKWARD
-    for (int jb = -1; jb >= 0; jb -= PDD) {
+    int jb = -1;
 #else
-    for (int jb = n - 1; jb >= 0; jb -= PDD) {
+    int jb = n - 1;
 #endif
+    for (; jb >= PDD - 1; jb -= PDD) {                      // full blocks of eight columns: no branch inside
+      const double wv = xs[jb - (lane & (PDD - 1))];
 #pragma unroll
-      for (int u = 0; u < PDD; ++u) {
-        const int j = jb - u;
-        if (j >= 0) {
-          const double s_ = fw_wave_sum(cq[u] * xr);
-          cq[u] = cfetch(j - PDD);
-          const double xj = xs[j] - s_;
-          if (((lane - j) & 63) == 0) { xr = xj; xs[j] = xj; }
-        }
-      }
+      for (int u = 0; u < PDD; ++u) column(jb - u, u, wv);
+      const int d = (jb - lane) & 63;
+      if (d < PDD) xs[jb - d] = xr;                         // the block's x, one masked write
+      fw_fence();
+    }
+    if (jb >= 0) {                                          // the last jb + 1 < 8 columns
+      const int lu = lane & (PDD - 1);
+      const double wv = xs[lu <= jb ? jb - lu : 0];
+#pragma unroll
+      for (int u = 0; u < PDD - 1; ++u)
+        if (u <= jb) column(jb - u, u, wv);
+      const int d = (jb - lane) & 63;
+      if (d <= jb) xs[jb - d] = xr;
     }
     fw_fence();
     write_results(p, b, xs, bad != 0, lane, 64);
