@@ -214,6 +214,34 @@ def test_hub_node_with_eighteen_elements_takes_the_extra_plan_blocks():
         assert relerr(sol.forces[b].cpu().numpy().ravel(), f.ravel()) < 1e-7
 
 
+@pytest.mark.parametrize("skip,kd", [(2, 8), (4, 14), (7, 23), (10, 32), (12, 38), (16, 50), (17, 53)])
+def test_ladder_frames_cover_every_window_width(skip, kd):
+    """Chains whose node i is also tied to node i + skip: half bandwidth 3 skip + 2, so every compiled register-window
+    width of the wave kernel (16, 24, 36, 52, 56) and the multiples of eight (a row group enters exactly when the window
+    reaches it) meet the oracle on a frame whose equation count is not a multiple of the group size."""
+    from openpystruct_amd import frames
+    nn = 3 * skip + 11
+    coords = np.array([(1.5 * i, 0.4 * np.sin(0.9 * i) + 0.05 * (i % 3)) for i in range(nn)])
+    conn = np.array([(i, i + 1) for i in range(nn - 1)] + [(i, i + skip) for i in range(nn - skip)])
+    fix3 = np.zeros((nn, 3), dtype=bool)
+    fix3[0] = True
+    fix3[nn - 1, :2] = True
+    loads = np.zeros((nn, 3)); loads[nn // 2] = (1e4, -3e4, 5e2); loads[nn // 3, 1] = -2e4
+    w = np.zeros(len(conn)); w[: nn - 1] = -5e3
+    topo = frames.FrameTopology(coords, conn, fix3, 0.02, 200e9, w, 0.5 * w, loads, "cuda")
+    assert topo.kd == kd and topo.n_eq == 3 * nn - 5
+    rng = np.random.default_rng(skip)
+    B = 5
+    I = np.exp(rng.uniform(np.log(5e-5), np.log(5e-3), size=(B, topo.Ne)))
+    sol = frames.frame_solve(topo, torch.as_tensor(I, device="cuda"))
+    assert int(sol.status.abs().sum()) == 0
+    for b in range(B):
+        d, f, st, neq, okd = _oracle(topo, I[b])
+        assert st == 0 and neq == topo.n_eq and okd == topo.kd
+        assert relerr(sol.disp[b].cpu().numpy().ravel(), d.ravel()) < 1e-8
+        assert relerr(sol.forces[b].cpu().numpy().ravel(), f.ravel()) < 1e-7
+
+
 def test_tiny_bandwidth_cantilever_chain():
     """A single cantilever of 40 collinear elements: half bandwidth 5; and a two-node model: half bandwidth 2 < 3."""
     from openpystruct_amd import frames
