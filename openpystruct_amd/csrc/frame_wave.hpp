@@ -23,8 +23,8 @@
 //     per-frame HBM workspace;
 //   * rows enter the window in groups of 8 through an LDS parking area: the group is ASSEMBLED there (fused assembly: plan
 //     blocks below, ds_add_f64) one boundary before its owners' lanes fall free and take it;
-//   * backward substitution: dot form for W >= 36 (column j of L = one coalesced load, DPP + readlane wave reduction), the
-//     mirror-image "axpy" form below that.
+//   * backward substitution: blocked dot form, eight columns per pass (8 x 8 lanes: strided runs of eight columns of L
+//     against x from LDS, 8-lane DPP sums, the block's own 8 x 8 triangle as a readlane + FMA chain).
 //
 // Bound (r03 phase ablation, 15 x 16: 4.0 ms per 12 288 frames): the elimination steps 2.5 ms = VALU issue (82 VALU + 25 LDS
 // instructions per step and wave, 54 of them FP64 FMAs, three waves per SIMD), group entry 0.5, L stores 0.3, backward sweep
@@ -51,30 +51,13 @@ __device__ __forceinline__ double fw_readlane(double v, int lane) {
   const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane), hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
   return __hiloint2double(hi, lo);
 }
-// sum over the 64 lanes, result in every lane: DPP butterflies inside the 16-lane rows (quad_perm, row_half_mirror,
-// row_mirror: no LDS), then the four row totals through SGPRs
+// DPP move of a double (quad_perm, row_half_mirror, ...: no LDS)
 template <int CTRL>
 __device__ __forceinline__ double fw_dpp(double x) {
   const unsigned long long u = __builtin_bit_cast(unsigned long long, x);
   const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)u, CTRL, 0xF, 0xF, true);
   const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(u >> 32), CTRL, 0xF, 0xF, true);
   return __builtin_bit_cast(double, ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
-}
-template <int CTRL, int ROWS>
-__device__ __forceinline__ double fw_dpp_rows(double x) {   // lanes of the rows outside ROWS receive 0
-  const unsigned long long u = __builtin_bit_cast(unsigned long long, x);
-  const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)u, CTRL, ROWS, 0xF, false);
-  const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(u >> 32), CTRL, ROWS, 0xF, false);
-  return __builtin_bit_cast(double, ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
-}
-__device__ __forceinline__ double fw_wave_sum(double v) {
-  v += fw_dpp<0xB1>(v);      // quad_perm [1,0,3,2]
-  v += fw_dpp<0x4E>(v);      // quad_perm [2,3,0,1]
-  v += fw_dpp<0x141>(v);     // row_half_mirror
-  v += fw_dpp<0x140>(v);     // row_mirror: every lane holds its row's total r0 .. r3
-  v += fw_dpp_rows<0x142, 0xA>(v);   // row_bcast:15 into rows 1, 3: r0 + r1, r2 + r3
-  v += fw_dpp_rows<0x143, 0xC>(v);   // row_bcast:31 into rows 2, 3: row 3 = (r0 + r1) + (r2 + r3)
-  return fw_readlane(v, 63);
 }
 // LDS operations of one wave execute in order; this pins the compiler and lands earlier reads
 __device__ __forceinline__ void fw_fence() {
@@ -477,94 +460,70 @@ __device__ __forceinline__ void frame_wave_body(const FrameParams& p, double* __
   }
   fw_fence();
 
-  // ---- backward substitution, dot form (W >= 36): x_j = w_j - sum_t L[j+t][j] x_{j+t}; lane (R mod 64) holds x_R; column j
-  // of L is ONE coalesced load (fetched eight steps ahead), the sum a DPP / readlane wave reduction.  Measured against the
-  // axpy form below (every lane walks its own column of L: up to kd distinct cache lines per load instruction):
-  // 15 x 16: 5.56 -> 4.46 ms per 12 288 frames, 10 x 10: 2.48 -> 2.35 ms per 16 384; 5 x 5 (kd = 20): 2 % slower, keeps axpy ----
-  if constexpr (W >= 36) {
-    constexpr int PDD = 8;
-    double xr = 0.0, cq[PDD];
-    // column j of L for this lane's row: an UNCONDITIONAL load from a clamped address, masked when it is USED eight columns
-    // later -- loads under branches (or masked on arrival) made the compiler wait for every outstanding load (vmcnt(0)) per
-    // column, i.e. the "prefetch" was none
-    auto cfetch = [&](int j) -> double {
-      const int jj = j > 0 ? j : 0, rel = (lane - jj) & 63;
-      const int off = rel < 1 ? 0 : (rel <= W ? rel - 1 : W - 1);
-      return (rows + (size_t)jj * W)[off];
-    };
-    auto column = [&](int j, int u, double wv) {            // wv: lane u holds w_(jb - u)
-      const int rel = (lane - j) & 63;
-      const double c = (rel >= 1 && rel <= kd && j + rel < n) ? cq[u] : 0.0;
-      const double s_ = fw_wave_sum(c * xr);
-      cq[u] = cfetch(j - PDD);
-      const double xj = fw_readlane(wv, u) - s_;
-      xr = rel == 0 ? xj : xr;
-    };
+  // ---- backward substitution, blocked dot form: eight columns per pass, x_j = w_j - sum_t L[j+t][j] x_(j+t) ----
+  // Lane (u, k) = (lane >> 3, lane & 7) works for column j_u = jb - u: it multiplies the rows  j_u + k + 1 + 8 m  of that
+  // column (m < (W + 7) / 8: strided 64-byte runs of the column, x from LDS) and an 8-lane DPP sum gives every column's
+  // contribution of the rows ABOVE the block (x known); the rows inside the block (L[j_v][j_u], v < u: loaded by all eight
+  // lanes of group u into register v) follow as a serial chain of seven readlane + FMA.  ~80 VALU instructions per EIGHT
+  // columns against 36 per column of the r02 form (one column per pass: coalesced column load, 64-lane DPP / readlane
+  // reduction) and ~12 of the axpy form the narrow windows used (every lane walking its own column of L: up to kd cache
+  // lines per load).  10 x 10: 1.93 -> 1.84 ms per 16 384 frames, 15 x 16: 3.94 -> 3.87 ms per 12 288, 5 x 5: 0.72 -> 0.66 ms
+  // per 32 768, 3 x 3: 0.64 -> 0.59 ms per 65 536: what remains of the sweep is the stream of L out of HBM (all waves of a
+  // round reach their sweep together), r03_notes section 4.
+  {
+    constexpr int MF = (W + 7) / 8;
+    const int u = lane >> 3, k = lane & 7;
+    xs[n + lane] = 0.0;                                     // rows past the last equation: x = 0 (the idle steps left garbage)
+    fw_fence();
+    double fA[MF], bA[7], fB[MF], bB[7];                   // the next block's L is in flight while a block is worked on (two
+                                                            // blocks ahead measured no faster: the sweep streams L from HBM)
+    auto issue = [&](int jb, double (&f)[MF], double (&bv)[7]) {      // unconditional loads from clamped addresses
+      const int ju = jb - u, jc = ju > 0 ? ju : 0;
+      const double* col = rows + (size_t)jc * W;
 #pragma unroll
-    for (int u = 0; u < PDD; ++u) cq[u] = cfetch(n - 1 - u);
+      for (int m = 0; m < MF; ++m) f[m] = col[k + 8 * m < W ? k + 8 * m : W - 1];
+#pragma unroll
+      for (int v = 0; v < 7; ++v) bv[v] = col[u - v - 1 > 0 ? u - v - 1 : 0];
+    };
+    auto block = [&](int jb, const double (&lf)[MF], const double (&lbv)[7]) {   // (jb < 0: every lane masked, no write)
+      const int ju = jb - u, jc = ju > 0 ? ju : 0;
+      const int kdj = ju >= 0 ? (kd < n - 1 - ju ? kd : n - 1 - ju) : 0;      // rows of this column below the diagonal
+      double acc0 = 0.0, acc1 = 0.0;
+#pragma unroll
+      for (int m = 0; m < MF; ++m) {
+        const int rel = k + 1 + 8 * m;
+        const bool far = rel <= kdj && (m > 0 || k >= u);   // rows above the block top (rel > u); inside the band
+        const double l = far ? lf[m] : 0.0;
+        const double x = xs[jc + rel];
+        if (m & 1) acc1 = __builtin_fma(l, x, acc1); else acc0 = __builtin_fma(l, x, acc0);
+      }
+      double s_ = acc0 + acc1;
+      s_ += fw_dpp<0xB1>(s_);                               // quad_perm [1,0,3,2]
+      s_ += fw_dpp<0x4E>(s_);                               // quad_perm [2,3,0,1]
+      s_ += fw_dpp<0x141>(s_);                              // row_half_mirror: the eight lanes of a group hold its sum
+      double t = xs[jc] - s_;
+#pragma unroll
+      for (int v = 0; v < 7; ++v) {                         // x of column j_v is final when its turn comes
+        const double xv = fw_readlane(t, 8 * v);
+        const double l = (v < u && u - v <= kdj) ? lbv[v] : 0.0;
+        t = __builtin_fma(-l, xv, t);
+      }
+      if (k == 0 && ju >= 0) xs[ju] = t;
+      fw_fence();
+    };
 #ifdef FW_SKIP_BACKWARD
     int jb = -1;
 #else
     int jb = n - 1;
 #endif
-    for (; jb >= PDD - 1; jb -= PDD) {                      // full blocks of eight columns: no branch inside
-      const double wv = xs[jb - (lane & (PDD - 1))];
-#pragma unroll
-      for (int u = 0; u < PDD; ++u) column(jb - u, u, wv);
-      const int d = (jb - lane) & 63;
-      if (d < PDD) xs[jb - d] = xr;                         // the block's x, one masked write
-      fw_fence();
-    }
-    if (jb >= 0) {                                          // the last jb + 1 < 8 columns
-      const int lu = lane & (PDD - 1);
-      const double wv = xs[lu <= jb ? jb - lu : 0];
-#pragma unroll
-      for (int u = 0; u < PDD - 1; ++u)
-        if (u <= jb) column(jb - u, u, wv);
-      const int d = (jb - lane) & 63;
-      if (d <= jb) xs[jb - d] = xr;
-    }
-    fw_fence();
-    write_results(p, b, xs, bad != 0, lane, 64);
-    return;
-  }
-  // ---- backward substitution, axpy form: lane (R mod 64) carries w_R while R is within kd of the current column ----
-  // x_j = w_j - sum_{R > j} L[R][j] x_R, processed as: x_j is final when step j starts; rows i = j - kd .. j - 1 then take
-  // w_i -= L[j][i] x_j.  Row i enters the window (picks up w_i from LDS) at step j = i + kd; the last kd rows start inside.
-  constexpr int PD = 8;                                     // L entries are fetched PD steps ahead
-  double wreg;
-  {
-    const int i = n - 1 - ((n - 1 - lane) & 63);            // the row of [n - 64, n - 1] that this lane owns
-    wreg = i >= 0 ? xs[i] : 0.0;
-  }
-  double lq[PD];
-  auto lfetch = [&](int j) -> double {                      // L[j][i] for this lane's row i = j - rel, rel in 1..kd
-    const int rel = (j - lane) & 63, i = j - rel;
-    return (j >= 0 && rel >= 1 && rel <= kd && i >= 0) ? rows[(size_t)i * W + (rel - 1)] : 0.0;
-  };
-#pragma unroll
-  for (int u = 0; u < PD; ++u) lq[u] = lfetch(n - 1 - u);
-#ifdef FW_SKIP_BACKWARD
-  for (int jb = -1; jb >= 0; jb -= PD) {
-#else
-  for (int jb = n - 1; jb >= 0; jb -= PD) {
-#endif
-#pragma unroll
-    for (int u = 0; u < PD; ++u) {
-      const int j = jb - u;
-      if (j >= 0) {
-        const int rel = (j - lane) & 63, ent = j - kd;
-        const double went = xs[ent >= 0 ? ent : 0];         // broadcast read; used by the one lane whose row enters now
-        if (rel == kd && ent >= 0) wreg = went;
-        const double xj = fw_readlane(wreg, j & 63);
-        const double lv = lq[u];
-        lq[u] = lfetch(j - PD);
-        if (rel != 0) wreg = __builtin_fma(-lv, xj, wreg);  // lanes outside the window: lv = 0
-        if (rel == 0) xs[j] = xj;
-      }
+    issue(jb, fA, bA);
+    for (; jb >= 0; jb -= 16) {                             // two blocks per pass: the buffers alternate without copies
+      issue(jb - 8, fB, bB);
+      block(jb, fA, bA);
+      issue(jb - 16, fA, bA);
+      block(jb - 8, fB, bB);
     }
   }
-  fw_fence();
   write_results(p, b, xs, bad != 0, lane, 64);
 }
 
