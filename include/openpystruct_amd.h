@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define OPS_AMD_ABI_VERSION 7
+#define OPS_AMD_ABI_VERSION 8
 
 /* return codes of the launch functions (per-beam results are in `status`) */
 #define OPS_AMD_OK 0
@@ -141,6 +141,20 @@ int ops_beam_sizing_step_vm32_f32(int B, int Ne, float* I, double* I64, const fl
                                   int32_t* epochs_run, uint8_t* active, float* last_loss, const ops_sizing_params* hp,
                                   const float* schedule, void* stream);
 void ops_sizing_schedule_f32(const ops_sizing_params* hp, float* schedule_host /* [max_epochs, 2] */);
+
+/* Case randomisation of the dataset generator (SingleCore.py:133-160 draws, :100-113 `ops.fix` / `ops.load`) as one launch,
+ * C-ABI version 8: cases first_case .. first_case + B - 1 of the list that `seed` defines (case i is a pure function of
+ * (seed, i): counter-based stream, csrc/case_draw.hip).  random_bridge = 1: L = L_min + U(0, 1) L_max and 1 .. n_rollers_max
+ * distinct rollers among nodes 2 .. num_nodes - 1; otherwise L = L_max and the `n_fixed` rollers of `fixed_rollers` (HOST
+ * array, 1-based node ids).  Then 1 .. m_forces_max distinct loaded nodes that are not rollers, loads U(max_force, min_force).
+ * Device outputs: L [B], roller_nodes [B, R] (R = n_rollers_max or n_fixed; 1-based, 0 = unused slot), n_rollers [B],
+ * force_nodes / force_values [B, m_forces_max], n_forces [B], fix [B, num_nodes] (node 1 and the rollers), Fy [B, num_nodes]. */
+#define OPS_CASE_MAX_PICKS 8
+int ops_sizing_draw_cases_f64(long B, unsigned long long first_case, unsigned long long seed, int num_nodes, int n_rollers_max,
+                              int m_forces_max, int random_bridge, const int32_t* fixed_rollers, int n_fixed, double L_min,
+                              double L_max, double max_force, double min_force, double* L, long long* roller_nodes,
+                              long long* n_rollers, long long* force_nodes, long long* n_forces, double* force_values,
+                              uint8_t* fix, double* Fy, void* stream);
 
 /* One WHOLE epoch of the reference's per-sample loop for B cases in one launch (SingleCore.py:176-219): the FE solve on
  * the float32 inertias I (widened to double while they are staged: `I_tensor[i].item()`, :107) followed, in the same

@@ -9,7 +9,7 @@ import ctypes
 import os
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-ABI_VERSION = 7      # include/openpystruct_amd.h OPS_AMD_ABI_VERSION
+ABI_VERSION = 8      # include/openpystruct_amd.h OPS_AMD_ABI_VERSION
 # OPS_AMD_LIB lets A/B kernel experiments point at another build of the same C ABI
 LIB_PATH = os.environ.get("OPS_AMD_LIB") or os.path.join(_PKG, "lib", "libopenpystruct_amd.so")
 
@@ -20,6 +20,7 @@ EXPORTS = (
     "ops_beam_solve_forces_f32",
     "ops_beam_sizing_step_vm32_f32",
     "ops_sizing_schedule_f32",
+    "ops_sizing_draw_cases_f64",
     "ops_beam_sizing_epoch_f32",
     "ops_beam_sizing_step_f32",
     "ops_beam_residual_f64",
@@ -221,6 +222,9 @@ def load():
     lib.ops_beam_sizing_step_vm32_f32.argtypes = [it, it] + [vp] * 11 + [ctypes.POINTER(SizingParams), vp, vp]
     lib.ops_sizing_schedule_f32.restype = None
     lib.ops_sizing_schedule_f32.argtypes = [ctypes.POINTER(SizingParams), vp]
+    lib.ops_sizing_draw_cases_f64.restype = it
+    _ull, _db = ctypes.c_ulonglong, ctypes.c_double
+    lib.ops_sizing_draw_cases_f64.argtypes = [lg, _ull, _ull, it, it, it, it, vp, it, _db, _db, _db, _db, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.ops_beam_sizing_epoch_f32.restype = it
     lib.ops_beam_sizing_epoch_f32.argtypes = [it, it, vp, lg, vp, lg, vp, lg, vp, lg, vp, lg] + [vp] * 9 + [ctypes.POINTER(SizingParams), vp, vp, it, vp]
     g = lib.ops_beam_sizing_step_f32

@@ -18,6 +18,7 @@ from __future__ import annotations
 import ctypes
 import os
 import json
+import threading
 from dataclasses import dataclass
 from typing import Dict, List, Optional, Tuple
 
@@ -139,6 +140,9 @@ def make_cases(n_cases: int, cfg: SizingConfig, seed: int = 20250307, device="cp
     O(hi - lo + CASE_BLOCK), not O(n_cases) (chunked generation of 10^7 cases no longer draws the whole list per chunk)."""
     hi = n_cases if hi is None else min(hi, n_cases)
     lo = max(0, min(lo, hi))
+    if (torch.device(device).type == "cuda" and max(cfg.M_forces_max, cfg.N_rollers_max if cfg.random_bridge == 1 else len(cfg.roller_nodes)) <= 8
+            and cfg.num_nodes >= 4):
+        return _draw_cases_device(cfg, seed, torch.device(device), lo, hi)      # one launch (csrc/case_draw.hip)
     parts = []
     for b in range(lo // CASE_BLOCK, max(lo // CASE_BLOCK + 1, (hi + CASE_BLOCK - 1) // CASE_BLOCK)):
         blk = _make_case_block(cfg, seed * 1000003 + b, device)
@@ -147,6 +151,34 @@ def make_cases(n_cases: int, cfg: SizingConfig, seed: int = 20250307, device="cp
     if len(parts) == 1:
         return parts[0]
     return Cases(*(torch.cat(ts, dim=0) for ts in zip(*(p.tensors() for p in parts))))
+
+
+def _draw_cases_device(cfg: SizingConfig, seed: int, dev: torch.device, lo: int, hi: int) -> Cases:
+    """Cases [lo, hi) of the list `seed` defines, drawn on the GPU by ONE launch (csrc/case_draw.hip: the same draws as
+    `_make_case_block`, SingleCore.py:133-160, from a counter-based stream keyed by (seed, case number) -- the ~25 framework
+    ops per block of the vectorised form are 8 % of a 50 000-case generator shard, host-bound)."""
+    B, N, F = hi - lo, cfg.num_nodes, cfg.M_forces_max
+    rb = int(cfg.random_bridge == 1)
+    fixed = np.asarray(cfg.roller_nodes, dtype=np.int32)
+    R = cfg.N_rollers_max if rb else int(fixed.size)
+    f64 = dict(dtype=torch.float64, device=dev)
+    i64 = dict(dtype=torch.int64, device=dev)
+    Ls, nr, k = torch.empty(B, **f64), torch.empty(B, **i64), torch.empty(B, **i64)
+    r_nodes, f_nodes, f_vals = torch.empty((B, R), **i64), torch.empty((B, F), **i64), torch.empty((B, F), **f64)
+    fix, Fy = torch.empty((B, N), dtype=torch.uint8, device=dev), torch.empty((B, N), **f64)
+    with torch.cuda.device(dev):
+        rc = _cabi.load().ops_sizing_draw_cases_f64(
+            B, lo, int(seed) & 0xFFFFFFFFFFFFFFFF, N, cfg.N_rollers_max, F, rb, fixed.ctypes.data, int(fixed.size),
+            float(cfg.L_min), float(cfg.L_max), float(cfg.max_force), float(cfg.min_force), Ls.data_ptr(), r_nodes.data_ptr(),
+            nr.data_ptr(), f_nodes.data_ptr(), k.data_ptr(), f_vals.data_ptr(), fix.data_ptr(), Fy.data_ptr(),
+            torch.cuda.current_stream(dev).cuda_stream)
+    if rc != _cabi.OK:
+        raise RuntimeError(f"ops_sizing_draw_cases_f64 failed with code {rc}: {_cabi.load().ops_amd_last_error().decode()}")
+    if rb:
+        xs = torch.linspace(0.0, 1.0, N, **f64)[None, :] * Ls[:, None]
+    else:
+        xs = torch.linspace(0, cfg.L_max, N, **f64).expand(B, -1).contiguous()                 # SingleCore.py:59
+    return Cases(xs, Ls, r_nodes, nr, f_nodes, k, f_vals, fix, Fy)
 
 
 def _make_case_block(cfg: SizingConfig, seed: int, device) -> Cases:
@@ -298,6 +330,30 @@ class SizingState:
         _cabi.load().ops_sizing_schedule_f32(ctypes.byref(self._hp), sched.ctypes.data)
         self._schedule = torch.as_tensor(sched, device=device)
 
+    def reset(self, cases: Cases, cfg: SizingConfig) -> bool:
+        """Re-arm this state IN PLACE for another shard of the same shape (the buffers a captured epoch graph points at stay
+        where they are).  False: the new cases do not fit these buffers (shape, shared geometry / supports, hyper-parameters)."""
+        if tuple(cases.Fy.shape) != (self.B, self.N) or bytes(cfg.c_params()) != bytes(self._hp) or int(cfg.max_e) != int(self.cfg.max_e):
+            return False
+        shared_geom = bool((cases.node_positions == cases.node_positions[:1]).all())
+        shared_fix = bool((cases.fix == cases.fix[:1]).all())
+        if shared_geom != (self.x.dim() == 1) or shared_fix != (self.fix.dim() == 1):
+            return False
+        self.cfg = cfg
+        self.x.copy_(cases.node_positions[0] if shared_geom else cases.node_positions)
+        self.fix.copy_(cases.fix[0] if shared_fix else cases.fix)
+        self.Fy.copy_(cases.Fy)
+        self.I.fill_(cfg.I_0)
+        if self.I_last is not None:
+            self.I_last.fill_(cfg.I_0)
+        else:
+            self.I64.fill_(float(np.float32(cfg.I_0)))
+        self.exp_avg.zero_(); self.exp_avg_sq.zero_()
+        self.best_loss.fill_(float("inf"))
+        self.patience_cnt.zero_(); self.epochs_run.zero_(); self.active.fill_(1); self.last_loss.zero_(); self._status.zero_()
+        self.V32 = self.M32 = None
+        return True
+
     def epoch(self) -> None:
         """One epoch for every case of the shard: FE solve (:176-190) then optimiser step (:195-219).  Inside the loop
         the reference reads only eleResponse: the solve writes forces only and skips wavefronts of finished cases."""
@@ -347,15 +403,32 @@ class SizingState:
         self.V32, self.M32 = self.sol.V.float(), self.sol.M.float()
 
 
-def optimize_cases(cases: Cases, cfg: SizingConfig, device, poll_every: int = 25, use_graph: bool = True) -> SizingState:
-    """Run the sizing loop of every case to its early stop (or max_e).  Returns the final device state."""
+# The most recent (state, captured epoch graph) per device and thread: a generator run is many shards of one shape
+# (`generate_dataset_to_files` chunks, the ranks' equal shards), and capture + instantiation of the 25-epoch graph costs
+# ~2.2 ms of a 27 ms shard of 50 000 cases (scripts/generator_breakdown.py).  One entry per key bounds the memory held.
+_EPOCH_GRAPHS: Dict[tuple, tuple] = {}
+
+
+def optimize_cases(cases: Cases, cfg: SizingConfig, device, poll_every: int = 25, use_graph: bool = True,
+                   reuse: bool = False) -> SizingState:
+    """Run the sizing loop of every case to its early stop (or max_e).  Returns the final device state.  With `reuse` the
+    state buffers and the captured graph of the previous shard of the same shape are re-armed in place: tensors of an
+    earlier returned state are then overwritten (`generate_dataset` copies what it hands out)."""
     device = torch.device(device)
-    st = SizingState(cases, cfg, device)
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device() if device.type == "cuda" else -1,
+           threading.get_ident(), int(poll_every))
+    st, graph = (None, None)
+    if reuse and use_graph and poll_every > 1 and key in _EPOCH_GRAPHS:
+        st, graph = _EPOCH_GRAPHS[key]
+        if not st.reset(cases, cfg):
+            st, graph = None, None
+            del _EPOCH_GRAPHS[key]
+    if st is None:
+        st = SizingState(cases, cfg, device)
     if st.B == 0:
         return st
     epochs_done = 0
-    graph = None
-    if use_graph and poll_every > 1:
+    if graph is None and use_graph and poll_every > 1:
         # the epoch body is launch-bound (two short kernels): replay `poll_every` epochs as one HIP graph
         side = torch.cuda.Stream(device=device)
         side.wait_stream(torch.cuda.current_stream(device))
@@ -368,17 +441,33 @@ def optimize_cases(cases: Cases, cfg: SizingConfig, device, poll_every: int = 25
                 for _ in range(poll_every):
                     st.epoch()
         torch.cuda.current_stream(device).wait_stream(side)
-    while epochs_done < cfg.max_e:
-        if graph is not None:
+        if reuse:
+            _EPOCH_GRAPHS[key] = (st, graph)
+    if graph is not None:
+        # The "any case still active?" poll lags one replay: its answer travels through a pinned flag behind an event, and the
+        # host reads the flag of replay k - 1 after it has queued replay k -- the device never waits for the host (a blocking
+        # poll drained the queue 13 times per 50 000-case shard, ~40 us each); the price is one replay of skipped wavefronts.
+        flags = torch.zeros(2, dtype=torch.uint8).pin_memory()
+        events = [torch.cuda.Event(), torch.cuda.Event()]
+        k = 0
+        while epochs_done < cfg.max_e:
             graph.replay()
             epochs_done += poll_every
-        else:
+            flags[k & 1: (k & 1) + 1].copy_(st.active.any().to(torch.uint8).reshape(1), non_blocking=True)
+            events[k & 1].record()
+            if k > 0:
+                events[(k - 1) & 1].synchronize()
+                if int(flags[(k - 1) & 1]) == 0:
+                    break
+            k += 1
+    else:
+        while epochs_done < cfg.max_e:
             st.epoch()
             epochs_done += 1
             if epochs_done % poll_every:
                 continue
-        if not bool(st.active.any()):       # the only host sync, once per `poll_every` epochs
-            break
+            if not bool(st.active.any()):       # host sync once per `poll_every` epochs
+                break
     # a case that is still active here ran out of max_e inside the step kernel already (it clears `active`)
     st.finalize()
     torch.cuda.synchronize(device)
@@ -400,7 +489,7 @@ def generate_dataset(n_cases: int, cfg: Optional[SizingConfig] = None, device="c
     if case_range is not None:               # a sub-range of this rank's shard (generate_dataset_to_files)
         lo, hi = lo + case_range[0], min(hi, lo + case_range[1])
     cases = make_cases(n_cases, cfg, seed, device=device, lo=lo, hi=hi)     # generated on the GPU: only the blocks this range touches
-    st = optimize_cases(cases, cfg, device, poll_every=poll_every)
+    st = optimize_cases(cases, cfg, device, poll_every=poll_every, reuse=True)     # everything handed out below is a copy
     sol = st.sol
     rot, defl = sol.theta.clone(), sol.v.clone()
     if cfg.zero_last_node:
@@ -414,7 +503,7 @@ def generate_dataset(n_cases: int, cfg: Optional[SizingConfig] = None, device="c
         "roller_x_locations": x_at(cases.roller_nodes_t),
         "force_x_locations": x_at(cases.force_nodes_t),
         "force_values": cases.force_values_t,
-        "I_values": st.I,                         # float32, AFTER the last Adam step (:239)
+        "I_values": st.I.clone(),                 # float32, AFTER the last Adam step (:239); (copies: the state is re-armed in place by the next shard)
         "shear_forces": st.V32,                   # float32, state of the last solve (:240)
         "bending_moments": st.M32,
         "node_positions": xs,
@@ -426,11 +515,11 @@ def generate_dataset(n_cases: int, cfg: Optional[SizingConfig] = None, device="c
         "deflections": defl,
         "n_rollers": cases.n_rollers,
         "n_forces": cases.n_forces,
-        "epochs_run": st.epochs_run,
-        "status": sol.status,
+        "epochs_run": st.epochs_run.clone(),
+        "status": sol.status.clone(),
         # not a reference field: the float64 inertias the recorded V / M / rotations / deflections were solved with
         # (the state BEFORE the last Adam step; `I_values` is the state after it -- the reference's one-step lag)
-        "I_solved": st.I64,
+        "I_solved": st.I64 if st._fused else st.I64.clone(),
         "case_ids": torch.arange(lo, hi),
     }
 

@@ -273,3 +273,47 @@ def test_chunked_generation_resumes_and_tiles_the_same_dataset(oa, tmp_path):
     rec = sizing.concat_records([sizing.load_records(f, device="cuda") for f in files])
     for k in ("I_values", "deflections", "bending_moments", "force_nodes", "epochs_run", "case_ids"):
         assert torch.equal(rec[k], whole[k].to(rec[k].device)), k
+
+
+def test_cases_drawn_on_the_gpu_distribution_determinism_and_ranges():
+    """csrc/case_draw.hip: the draws of SingleCore.py:133-160 as one launch -- same checks as the host-side list
+    (tests/test_host_logic.py), plus: a range of the list does not depend on what else is drawn."""
+    from openpystruct_amd import sizing
+    cfg = sizing.SizingConfig()
+    a = sizing.make_cases(3000, cfg, seed=1, device="cuda")
+    b = sizing.make_cases(3000, cfg, seed=1, device="cuda")
+    assert torch.equal(a.Fy, b.Fy) and a.force_nodes == b.force_nodes
+    c = sizing.make_cases(3000, cfg, seed=2, device="cuda")
+    assert not torch.equal(a.Fy, c.Fy)
+    k = np.array([len(f) for f in a.force_nodes])
+    assert k.min() >= 1 and k.max() <= 4 and set(k) == {1, 2, 3, 4}
+    assert abs(np.bincount(k)[1:] / len(k) - 0.25).max() < 0.04                      # SC:157: randint(1, 4)
+    vals = np.concatenate([np.array(f) for f in a.force_values])
+    assert vals.min() >= cfg.max_force and vals.max() <= cfg.min_force
+    assert abs(vals.mean() - 0.5 * (cfg.max_force + cfg.min_force)) < 0.02 * abs(cfg.min_force - cfg.max_force)
+    forbidden = set(cfg.roller_nodes) | {1, cfg.num_nodes}
+    assert all(not (set(f) & forbidden) and len(set(f)) == len(f) for f in a.force_nodes)
+    nodes = np.concatenate([np.array(f) for f in a.force_nodes])
+    cnt = np.bincount(nodes, minlength=cfg.num_nodes + 1)[2:cfg.num_nodes]
+    free = np.array([n not in forbidden for n in range(2, cfg.num_nodes)])
+    assert (cnt[~free] == 0).all() and cnt[free].min() > 0.5 * cnt[free].mean()      # every free candidate is drawn, about evenly
+    assert (a.fix.cpu().numpy() == bo.reference_fix_mask()[None, :]).all()
+    b0 = np.zeros(cfg.num_nodes); b0[np.array(a.force_nodes[0]) - 1] = a.force_values[0]
+    np.testing.assert_array_equal(a.Fy[0].cpu().numpy(), b0)
+    assert torch.equal(a.node_positions, sizing.make_cases(4, cfg, seed=1, device="cpu").node_positions[:1].cuda().expand(3000, -1))
+    # a range of the list: the same cases whatever else is drawn, whatever the list's length
+    part = sizing.make_cases(100000, cfg, seed=1, device="cuda", lo=1000, hi=1500)
+    assert torch.equal(part.Fy, a.Fy[1000:1500]) and part.force_nodes == a.force_nodes[1000:1500]
+    # random_bridge = 1 (SC:133-151)
+    cr = sizing.SizingConfig(random_bridge=1)
+    d = sizing.make_cases(2000, cr, seed=3, device="cuda")
+    assert float(d.L.min()) >= cr.L_min and float(d.L.max()) <= cr.L_min + cr.L_max
+    nr = np.array([len(r) for r in d.roller_nodes])
+    assert nr.min() >= 1 and nr.max() <= cr.N_rollers_max and set(nr) == set(range(1, cr.N_rollers_max + 1))
+    assert all(len(set(r)) == len(r) and min(r) >= 2 and max(r) <= cr.num_nodes - 1 for r in d.roller_nodes)
+    fx = d.fix.cpu().numpy()
+    assert all(int(fx[i].sum()) == 1 + len(d.roller_nodes[i]) and fx[i, 0] == 1 and all(fx[i, n - 1] for n in d.roller_nodes[i]) for i in range(2000))
+    assert all(not (set(f) & set(r)) for f, r in zip(d.force_nodes, d.roller_nodes))
+    assert torch.allclose(d.node_positions[:, -1], d.L) and float(d.node_positions[:, 0].abs().max()) == 0.0
+    unused = torch.arange(cr.N_rollers_max, device="cuda")[None, :] >= d.n_rollers[:, None]
+    assert bool((d.roller_nodes_t[unused] == 0).all()) and bool((d.roller_nodes_t[~unused] > 0).all())
