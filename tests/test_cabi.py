@@ -84,6 +84,11 @@ def test_argument_validation_without_gpu(lib):
     lib.ops_sizing_schedule_f32(ctypes.byref(hp), ctypes.cast(sched, ctypes.c_void_p))       # host-only helper
     assert sched[0] == pytest.approx(0.01 / (1 - 0.9), rel=1e-6) and sched[1] == pytest.approx((1 - 0.999) ** 0.5, rel=1e-6)
     assert sched[2] == pytest.approx(0.01 * 0.98 / (1 - 0.81), rel=1e-6)
+    # case draws of the generator: counts beyond the eight pick slots, too few nodes, missing outputs
+    draw = lambda B, N, R, F, rb, nf, out: lib.ops_sizing_draw_cases_f64(B, 0, 1, N, R, F, rb, z, nf, 15.0, 200.0, -1e6, -1e4, *([out] * 8), z)   # noqa: E731
+    assert draw(4, 101, 4, 9, 1, 0, 64) == _cabi.ERR_INVALID_ARG and draw(4, 101, 9, 4, 1, 0, 64) == _cabi.ERR_INVALID_ARG
+    assert draw(4, 3, 1, 1, 1, 0, 64) == _cabi.ERR_INVALID_ARG and draw(4, 101, 4, 4, 0, 3, 64) == _cabi.ERR_INVALID_ARG      # fixed rollers without their array
+    assert draw(4, 101, 4, 4, 1, 0, z) == _cabi.ERR_INVALID_ARG and draw(0, 101, 4, 4, 1, 0, z) == _cabi.OK
 
 
 def test_no_cpu_fallback():
