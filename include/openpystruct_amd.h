@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define OPS_AMD_ABI_VERSION 8
+#define OPS_AMD_ABI_VERSION 9
 
 /* return codes of the launch functions (per-beam results are in `status`) */
 #define OPS_AMD_OK 0
@@ -375,6 +375,14 @@ typedef struct ops_mlp_strip_args {
   /* evaluation pass (model.eval()): forward BatchNorm tails and the stencil's BatchNorm1d(1) normalise with the RUNNING statistics
    * (read only: nothing is updated or saved); pass p_drop = 0 and side = NONE with it */
   int32_t eval_stats;
+  /* evaluation slots, C-ABI version 9 (n_slots = 0: none).  The launch runs n_slots independent batches side by side (grid.y):
+   * slot s reads and writes every per-batch buffer -- A, Y, Yt, Zt, Ot, P, targets_t, loss_ws, loss, loss_sum -- at the given
+   * pointer + s * slot_stride BYTES (one arena per slot with the same layout; weights, biases, statistics are shared), and holds
+   * min(B, slot_total_rows - s * B) rows.  Evaluation / inference launches only (eval_stats, or a tail without statistics): a
+   * validation pass of 14 batches is 7 launches instead of 14 x 8 (profiles/r03_notes.md section 9). */
+  int32_t n_slots;
+  int32_t slot_total_rows;
+  int64_t slot_stride;
 } ops_mlp_strip_args;
 
 /* One strip launch: workgroup = 128 rows x 16 output columns.  Returns OPS_AMD_ERR_INVALID_ARG on a broken layout contract. */

@@ -9,7 +9,7 @@ import ctypes
 import os
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-ABI_VERSION = 8      # include/openpystruct_amd.h OPS_AMD_ABI_VERSION
+ABI_VERSION = 9      # include/openpystruct_amd.h OPS_AMD_ABI_VERSION
 # OPS_AMD_LIB lets A/B kernel experiments point at another build of the same C ABI
 LIB_PATH = os.environ.get("OPS_AMD_LIB") or os.path.join(_PKG, "lib", "libopenpystruct_amd.so")
 
@@ -113,7 +113,7 @@ class MlpStripArgs(ctypes.Structure):
                 ("ssave", _vp), ("spart", _vp), ("sdparams", _vp),
                 ("P", _vp), ("ldp", _i), ("targets_t", _vp), ("nI", _i), ("nD", _i), ("alpha", _vp), ("alpha0", _f),
                 ("min_constraint", _vp), ("max_constraint", _vp), ("box_weight", _f), ("rel_penalty", _f), ("loss_ws", _vp), ("loss_finish_rows", _i), ("loss_C", _i), ("loss", _vp), ("loss_sum", _vp),
-                ("eval_stats", _i)]
+                ("eval_stats", _i), ("n_slots", _i), ("slot_total_rows", _i), ("slot_stride", ctypes.c_int64)]
 
 
 class MlpWgradProblem(ctypes.Structure):

@@ -250,7 +250,20 @@ __global__ __launch_bounds__(MB_THREADS) void mlp_strip_kernel(const ops_mlp_str
   }
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int n0 = blockIdx.x * MB_COLS;
-  const int B = a.B, N = a.N, No = a.No;
+  // evaluation slots (grid.y): this workgroup's batch lives soff bytes behind every per-batch pointer
+  const long soff = (long)blockIdx.y * (long)a.slot_stride;
+  const auto in_slot = [soff](auto* p) { return p ? (decltype(p))((uintptr_t)p + (uintptr_t)soff) : p; };
+  const void* const sA = in_slot(a.A);
+  void* const sY = in_slot(a.Y);
+  void* const sYt = in_slot(a.Yt);
+  void* const sZt = in_slot(a.Zt);
+  const void* const sOt = in_slot(a.Ot);
+  void* const sP = in_slot(a.P);
+  const float* const s_targets_t = in_slot(a.targets_t);
+  void* const s_loss_ws = in_slot(a.loss_ws);
+  float* const s_loss = in_slot(a.loss);
+  float* const s_loss_sum = in_slot(a.loss_sum);
+  const int B = a.n_slots > 0 ? min(a.B, a.slot_total_rows - (int)blockIdx.y * a.B) : a.B, N = a.N, No = a.No;
   const bool fwd = a.tail <= OPS_MLP_TAIL_BN || a.tail == OPS_MLP_TAIL_LOSS;
   const bool has_bn = a.tail == OPS_MLP_TAIL_BN || a.tail == OPS_MLP_TAIL_BN_ACT_DROP || a.tail == OPS_MLP_TAIL_BWD_BN ||
                       a.tail == OPS_MLP_TAIL_BWD_BN_ACT_DROP;
@@ -282,9 +295,9 @@ __global__ __launch_bounds__(MB_THREADS) void mlp_strip_kernel(const ops_mlp_str
     const int j = tid + MB_THREADS * rep, slot = j >> 4, gq = j & 15;
     const void* src = nullptr;
     int col = 0, lim = 0;
-    if (slot < 20) { if (a.add_mode != OPS_MLP_ADD_NONE) { src = a.Ot; col = n0 - 2 + slot; lim = No; } }
+    if (slot < 20) { if (a.add_mode != OPS_MLP_ADD_NONE) { src = sOt; col = n0 - 2 + slot; lim = No; } }
     else if (slot < 38) { if (a.add_mode == OPS_MLP_ADD_BWD_BLOCK) { src = a.dZt; col = n0 - 1 + (slot - 20); lim = No; } }
-    else if (slot < 54) { if (has_bn && !fwd) { src = a.Zt; col = n0 + (slot - 38); lim = N; } }
+    else if (slot < 54) { if (has_bn && !fwd) { src = sZt; col = n0 + (slot - 38); lim = N; } }
     else if (slot < 70) { if (act_bwd) { src = a.Yref_t; col = n0 + (slot - 54); lim = N; } }
     chv[rep] = slot < 70;
     ch[rep] = uint4{0u, 0u, 0u, 0u};
@@ -292,13 +305,13 @@ __global__ __launch_bounds__(MB_THREADS) void mlp_strip_kernel(const ops_mlp_str
   }
   float pt[4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) pt[i] = (rl[i] && a.tail == OPS_MLP_TAIL_LOSS) ? a.targets_t[(long)c * MB_ROWS + q + 32 * i] : 0.0f;
+  for (int i = 0; i < 4; ++i) pt[i] = (rl[i] && a.tail == OPS_MLP_TAIL_LOSS) ? s_targets_t[(long)c * MB_ROWS + q + 32 * i] : 0.0f;
   // loss of the previous launch (TAIL_LOSS leaves per-strip partial sums): workgroup 0 adds them, one partial row per lane
   double lp[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
   const bool fin = a.loss_finish_rows > 0 && blockIdx.x == 0 && wave == 0;
   if (fin && lane < a.loss_finish_rows)
 #pragma unroll
-    for (int k = 0; k < 5; ++k) lp[k] = ((const double*)a.loss_ws)[lane * 5 + k];
+    for (int k = 0; k < 5; ++k) lp[k] = ((const double*)s_loss_ws)[lane * 5 + k];
   // partial sums of the stencil normalisation: lane = row of partials, wave = which sum (workgroup 0 needs all twelve backward)
   double pp0 = 0.0, pp1 = 0.0;
   if (a.add_mode != OPS_MLP_ADD_NONE) {
@@ -323,7 +336,7 @@ __global__ __launch_bounds__(MB_THREADS) void mlp_strip_kernel(const ops_mlp_str
     const int KS = (a.K + 31) >> 5;
 #endif
     // tile (row block, step) = 1 KB in lane order: this wave's row block of A, this strip's row block of W
-    const uint16_t* ap = (const uint16_t*)a.A + (long)wave * (a.lda >> 5) * 512 + lane * 8;
+    const uint16_t* ap = (const uint16_t*)sA + (long)wave * (a.lda >> 5) * 512 + lane * 8;
     const uint16_t* bp = (const uint16_t*)a.W + (long)blockIdx.x * (a.ldw >> 5) * 512 + lane * 8;
 #if defined(MB_EXP) && MB_EXP == 1
     const mb_f32x4 acc = {(float)(ap - bp), (float)KS, 0.0f, 0.0f};
@@ -352,8 +365,8 @@ __global__ __launch_bounds__(MB_THREADS) void mlp_strip_kernel(const ops_mlp_str
       if (nD > 0) val += (double)a.rel_penalty * lp[3] / ((double)B * nD);
       if (nR > 0) val += (double)a.rel_penalty * lp[4] / ((double)B * nR);
       const double da = a.alpha0 == a.alpha0 ? (double)a.alpha0 - (double)a.alpha[0] : 0.0;      // NaN alpha0: no such term
-      a.loss[0] = (float)(val + da * da);
-      if (a.loss_sum) a.loss_sum[0] += (float)(val + da * da);      // the epoch's running total (the caller zeroes it)
+      s_loss[0] = (float)(val + da * da);
+      if (s_loss_sum) s_loss_sum[0] += (float)(val + da * da);      // the epoch's running total (the caller zeroes it)
     }
   }
   __syncthreads();
@@ -435,13 +448,13 @@ __global__ __launch_bounds__(MB_THREADS) void mlp_strip_kernel(const ops_mlp_str
     }
     if (a.tail == OPS_MLP_TAIL_LOSS) {
       // the predictions leave through LDS first, then v becomes d loss / d predictions
-      if (a.P) {
+      if (sP) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) s_y[q + 32 * i][cl] = mb_f2bf(v[i]);
         __syncthreads();
         if (tid < 2 * MB_ROWS) {
           const int r = tid >> 1, h = tid & 1;
-          *(uint4*)((uint16_t*)a.P + (long)r * a.ldp + n0 + 8 * h) = *(const uint4*)&s_y[r][8 * h];
+          *(uint4*)((uint16_t*)sP + (long)r * a.ldp + n0 + 8 * h) = *(const uint4*)&s_y[r][8 * h];
         }
         __syncthreads();
       }
@@ -557,20 +570,20 @@ __global__ __launch_bounds__(MB_THREADS) void mlp_strip_kernel(const ops_mlp_str
   __syncthreads();
   if (tid < 2 * MB_ROWS) {
     const int r = tid >> 1, h = tid & 1;
-    *(uint4*)((uint16_t*)a.Y + mb_toff(r, n0 + 8 * h, a.ldy >> 5)) = *(const uint4*)&s_y[r][8 * h];
-  } else if (a.Yt) {
+    *(uint4*)((uint16_t*)sY + mb_toff(r, n0 + 8 * h, a.ldy >> 5)) = *(const uint4*)&s_y[r][8 * h];
+  } else if (sYt) {
     const int u = tid - 2 * MB_ROWS, c2 = u & 15, gq = u >> 4;
     uint16_t t8[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) t8[j] = s_y[8 * gq + j][c2];
-    *(uint4*)((uint16_t*)a.Yt + mb_toff(n0 + c2, 8 * gq, MB_ROWS / 32)) = *(const uint4*)t8;
+    *(uint4*)((uint16_t*)sYt + mb_toff(n0 + c2, 8 * gq, MB_ROWS / 32)) = *(const uint4*)t8;
   }
   if (fwd && has_bn && tid < 2 * MB_ROWS) {
     const int c2 = tid & 15, gq = tid >> 4;
     uint16_t t8[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) t8[j] = s_z[8 * gq + j][c2];
-    *(uint4*)((uint16_t*)a.Zt + mb_toff(n0 + c2, 8 * gq, MB_ROWS / 32)) = *(const uint4*)t8;
+    *(uint4*)((uint16_t*)sZt + mb_toff(n0 + c2, 8 * gq, MB_ROWS / 32)) = *(const uint4*)t8;
   }
   if (fwd && a.p_drop > 0.0f && (a.tail == OPS_MLP_TAIL_ACT_DROP || a.tail == OPS_MLP_TAIL_BN_ACT_DROP) && tid == 0)
     call_counter_done(a.call_counter, gridDim.x);   // one increment per launch, by the last workgroup to finish (call_counter.hpp)
@@ -583,7 +596,7 @@ __global__ __launch_bounds__(MB_THREADS) void mlp_strip_kernel(const ops_mlp_str
     mb_block_sum<5>(accd, s_red);
     if (tid == 0)
 #pragma unroll
-      for (int k = 0; k < 5; ++k) ((double*)a.loss_ws)[blockIdx.x * 5 + k] = accd[k];
+      for (int k = 0; k < 5; ++k) ((double*)s_loss_ws)[blockIdx.x * 5 + k] = accd[k];
   }
 }
 
@@ -777,7 +790,13 @@ extern "C" int ops_mlp_strip_launch(const ops_mlp_strip_args* args, void* stream
       nside = (a.No + MB_SIDE_COLS - 1) / MB_SIDE_COLS;
     }
   }
-  const dim3 grid((unsigned)(nstrips + nside)), block(MB_THREADS);
+  if (a.n_slots < 0 || a.n_slots > 65535) return OPS_AMD_ERR_INVALID_ARG;
+  if (a.n_slots > 0) {      // evaluation slots: no batch statistics are written, no side jobs, the last slot holds the remainder
+    if (bwd || nside || a.p_drop > 0.0f || (bn && !a.eval_stats) || (a.add_mode != OPS_MLP_ADD_NONE && !a.eval_stats)) return OPS_AMD_ERR_INVALID_ARG;
+    if (a.slot_stride < 0 || a.slot_stride % 16 || a.slot_total_rows <= a.B * (a.n_slots - 1) || a.slot_total_rows > a.B * a.n_slots)
+      return OPS_AMD_ERR_INVALID_ARG;
+  }
+  const dim3 grid((unsigned)(nstrips + nside), (unsigned)(a.n_slots > 0 ? a.n_slots : 1)), block(MB_THREADS);
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(mlp_strip_kernel, grid, block, 0, s, a, nstrips);
   const hipError_t e = hipGetLastError();

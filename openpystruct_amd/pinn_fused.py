@@ -340,3 +340,64 @@ class PinnFusedStep:
 
     def predictions(self, B: int) -> torch.Tensor:
         return self.preds[:B, :self.C]
+
+    # ---- evaluation slots: a whole validation set per launch sequence (grid.y = batches) ----
+    def make_eval_slots(self, X: torch.Tensor, Y: torch.Tensor, batch: int) -> int:
+        """The rows of (X, Y) as consecutive batches of `batch` rows, every batch in an arena ("slot") of its own that holds a copy
+        of each buffer the evaluation pass writes -- same layout in every slot, so one launch serves all of them (ops_mlp_strip_args
+        n_slots / slot_stride: the kernel adds blockIdx.y * slot_stride to the per-batch pointers).  The batches are gathered here, ONCE
+        (a validation set never changes); `evaluate_slots()` is then len(self._eval) launches for the whole set, and slot i's batch
+        loss lands in `eval_slot_losses()[i]`.  Returns the number of slots."""
+        n_rows = int(X.shape[0])
+        if not 1 <= batch <= _cabi.MLP_MAX_ROWS or n_rows < 1:
+            raise ValueError("evaluation slots need 1 .. 128 rows per batch")
+        S = (n_rows + batch - 1) // batch
+        written = [self.x, self.xt, self.v0t, self.preds, self.gp, self.gpt, self.targets_t, self.loss_ws_eval, self.scratch16, self.eval_loss, self.eval_loss_sum]
+        written += [t for pair in self.o for t in pair] + [t for pair in self.h for t in pair] + list(self.zt)
+        offs, total = {}, 0
+        for b in written:
+            offs[b.data_ptr()] = (total, b)
+            total += _ru(b.numel() * b.element_size(), 256)
+        self._arena = torch.zeros(S, total, dtype=torch.uint8, device=self.dev)
+        base = self._arena.data_ptr()
+        ptr_fields = [name for name, typ in _cabi.MlpStripArgs._fields_ if typ is ctypes.c_void_p]
+        slotted = {"A", "Y", "Yt", "Zt", "Ot", "P", "targets_t", "loss_ws", "loss", "loss_sum"}       # what the kernel offsets per slot
+        stages = []
+        for a in self._eval:
+            e = _cabi.MlpStripArgs()
+            ctypes.memmove(ctypes.addressof(e), ctypes.addressof(a), ctypes.sizeof(_cabi.MlpStripArgs))
+            for name in ptr_fields:
+                v = getattr(e, name)
+                if v is not None and v in offs:
+                    if name not in slotted:
+                        raise ValueError(f"evaluation stage field {name} points at a per-batch buffer the kernel does not offset")
+                    setattr(e, name, base + offs[v][0])
+                elif name in slotted and v is not None:
+                    raise ValueError(f"evaluation stage field {name} is not one of the engine's per-batch buffers")
+            e.B, e.n_slots, e.slot_total_rows, e.slot_stride = batch, S, n_rows, total
+            stages.append(e)
+        self._slot_stages, self._slot_count, self._slot_total = stages, S, total
+        view = lambda i, b: self._arena[i, offs[b.data_ptr()][0]: offs[b.data_ptr()][0] + b.numel() * b.element_size()].view(b.dtype).view(b.shape)   # noqa: E731
+        self._slot_loss_off = offs[self.eval_loss.data_ptr()][0]
+        rows = torch.arange(n_rows, device=self.dev)
+        s = torch.cuda.current_stream(self.dev).cuda_stream
+        with torch.cuda.device(self.dev):
+            for i in range(S):
+                idx = rows[i * batch:(i + 1) * batch]
+                x, xt, tt = view(i, self.x), view(i, self.xt), view(i, self.targets_t)
+                self._check(self.lib.ops_mlp_gather_noise(int(idx.numel()), self.F_in, X.data_ptr(), idx.data_ptr(), None, 0, None, x.data_ptr(),
+                                                          x.shape[1], xt.data_ptr(), Y.data_ptr(), self.C, tt.data_ptr(), s),
+                            "ops_mlp_gather_noise (evaluation slot)")
+        self._slot_preds = [view(i, self.preds) for i in range(S)]
+        return S
+
+    def evaluate_slots(self) -> None:
+        """The evaluation pass of every slot: one launch per stage for the whole set."""
+        s = torch.cuda.current_stream(self.dev).cuda_stream
+        with torch.cuda.device(self.dev):
+            for a in self._slot_stages:
+                self._check(self.lib.ops_mlp_strip_launch(ctypes.byref(a), s), "ops_mlp_strip_launch (evaluation slots)")
+
+    def eval_slot_losses(self) -> torch.Tensor:
+        """[slots] float32 view: the batch loss of each slot after `evaluate_slots()` (CompositeLoss mean over the slot's rows)."""
+        return self._arena[:, self._slot_loss_off:self._slot_loss_off + 4].view(torch.float32).reshape(-1)

@@ -755,7 +755,7 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
             raise RuntimeError(f"ops_gather_rows_noise_targets_f32 failed with code {rc}")
         return with_y
 
-    graph = graph_b = vgraph = graph_t = vgraph_t = None
+    graph = graph_b = vgraph = graph_t = vgraph_t = slot_graph = None
     ev_graphs, val_rows = {}, None
     # PINN: validation through the engine's evaluation pass (running statistics, no dropout) when the validation set has its layout
     engine_eval = bool(engine is not None and os.environ.get("OPS_AMD_PINN_ENGINE_EVAL", "1") == "1" and Xva.dtype == torch.float32
@@ -850,7 +850,27 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
                 tfd_fused.refresh_layer_tiles(fast_encoder.transformer_encoder)
         # the validation pass as graphs too (eval mode, loss accumulated into v_acc): one for the full batches, one for the last partial one
         nvt = int(Xva.shape[0]) % bs
-        if engine_eval and graph is not None:
+        if engine_eval and graph is not None and os.environ.get("OPS_AMD_PINN_EVAL_SLOTS", "1") == "1":
+            # PINN: the whole validation set per launch sequence -- every batch in an evaluation slot (pinn_fused.make_eval_slots:
+            # gathered once, the rows never change), the engine's 7 evaluation launches run all slots side by side (grid.y): 7 nodes
+            # per epoch instead of 14 batches x 8 launches of ~6 us
+            try:
+                side.wait_stream(torch.cuda.current_stream(device))
+                with torch.cuda.stream(side):
+                    engine.make_eval_slots(Xva, Yva, cfg.batch_size)
+                    engine.evaluate_slots()
+                    side.synchronize()
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):
+                        engine.evaluate_slots()
+                torch.cuda.current_stream(device).wait_stream(side)
+                slot_graph = g
+            except Exception as e:
+                if log:
+                    log(f"HIP graph capture of the slotted evaluation pass failed ({e!r}); one batch after the other")
+                slot_graph = None
+                torch.cuda.synchronize(device)
+        if engine_eval and graph is not None and slot_graph is None:
             # PINN: the engine's own evaluation pass (forward stages on the running statistics + loss, 8 launches per batch) instead of
             # the module's ~30-node forward; gather + evaluate captured per batch size, the row indices in a static buffer
             val_rows = torch.arange(Xva.shape[0], device=device)
@@ -996,11 +1016,15 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
         net.eval()
         vt = torch.zeros((), device=device)
         nb_va = max(1, (Xva.shape[0] + cfg.batch_size - 1) // cfg.batch_size)
-        if engine_eval:
+        nb_run = nb_va
+        if engine_eval and slot_graph is not None:
+            slot_graph.replay()
+            nb_run = 0
+        elif engine_eval:
             engine.eval_loss_sum.zero_()
             if val_rows is None:
                 val_rows = torch.arange(Xva.shape[0], device=device)
-        for b in range(nb_va):
+        for b in range(nb_run):
             sl = slice(b * cfg.batch_size, (b + 1) * cfg.batch_size)
             if engine_eval:
                 rows = val_rows[sl]
@@ -1020,7 +1044,9 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
                 vgraph_t.replay()
             else:
                 vt += val_batch(Xva[sl], Yva[sl])
-        if engine_eval:
+        if engine_eval and slot_graph is not None:
+            vt = engine.eval_slot_losses().sum()
+        elif engine_eval:
             vt = engine.eval_loss_sum.clone()
         elif vgraph is not None or vgraph_t is not None:
             vt += v_acc
@@ -1045,7 +1071,7 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
             break
     # the captured graphs (and their private memory pools) go before anything else runs on this device: the closures above form
     # reference cycles that would otherwise keep them alive until some later garbage collection
-    graph = graph_b = vgraph = graph_t = vgraph_t = None
+    graph = graph_b = vgraph = graph_t = vgraph_t = slot_graph = None
     ev_graphs.clear()
     if on_gpu:
         import gc

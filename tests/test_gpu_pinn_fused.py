@@ -380,3 +380,46 @@ def test_evaluation_pass_of_the_engine_equals_the_module_in_eval_mode(B):
         assert torch.equal(b, bufs[n]), n                    # running statistics / counters untouched
     for n, q in model.named_parameters():
         assert torch.equal(q.grad, grads[n]), n
+
+
+def test_evaluation_slots_equal_the_batch_by_batch_evaluation():
+    """make_eval_slots / evaluate_slots (one launch per stage for a whole validation set, grid.y = batches, the last one ragged)
+    against gather + evaluate of each batch on the engine's own buffers: the same arithmetic per batch, bit for bit -- losses and
+    predictions -- and neither the model's buffers nor the training batch in the engine's buffers are touched."""
+    from openpystruct_amd.pinn_fused import PinnFusedStep
+    dev = torch.device("cuda:0")
+    model, crit = _make(11, 0.3)
+    model, crit = model.to(dev), crit.to(dev)
+    _attach_flat(model)
+    g = torch.Generator().manual_seed(5)
+    eng = PinnFusedStep(model, crit, seed=1)
+    model.train()
+    for _ in range(2):
+        eng.set_batch(torch.randn(128, 684, generator=g).to(dev), (0.8 * torch.randn(128, 302, generator=g)).to(dev))
+        eng.fwd_bwd(128)
+    n, bs = 5 * 96 + 37, 96
+    X = torch.randn(n, 684, generator=g).to(dev).contiguous()
+    Y = (0.8 * torch.randn(n, 302, generator=g)).to(dev).contiguous()
+    bufs = {k: b.clone() for k, b in model.named_buffers()}
+    S = eng.make_eval_slots(X, Y, bs)
+    assert S == 6
+    x_before = eng.x.clone()
+    eng.evaluate_slots()
+    eng.evaluate_slots()                                     # idempotent: nothing accumulates into what the losses are read from
+    torch.cuda.synchronize()
+    slot_losses = eng.eval_slot_losses().clone()
+    slot_preds = [eng._slot_preds[i].clone() for i in range(S)]
+    assert torch.equal(eng.x, x_before)
+    rows = torch.arange(n, device=dev)
+    for i in range(S):
+        idx = rows[i * bs:(i + 1) * bs]
+        B = eng.gather(X, Y, idx, None, 0)
+        li = eng.evaluate(B).clone()
+        assert float(li) == float(slot_losses[i]), i
+        assert torch.equal(eng.predictions(B), slot_preds[i][:B, :eng.C]), i
+    for k, b in model.named_buffers():
+        assert torch.equal(b, bufs[k]), k
+    lib, a = eng.lib, eng._slot_stages[0]
+    a.slot_total_rows = n + bs                               # more rows than the slots hold: refused
+    assert lib.ops_mlp_strip_launch(__import__("ctypes").byref(a), None) == 1
+    a.slot_total_rows = n
