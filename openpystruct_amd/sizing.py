@@ -407,6 +407,7 @@ class SizingState:
 # (`generate_dataset_to_files` chunks, the ranks' equal shards), and capture + instantiation of the 25-epoch graph costs
 # ~2.2 ms of a 27 ms shard of 50 000 cases (scripts/generator_breakdown.py).  One entry per key bounds the memory held.
 _EPOCH_GRAPHS: Dict[tuple, tuple] = {}
+_POLL_FLAGS: Dict[tuple, tuple] = {}
 
 
 def optimize_cases(cases: Cases, cfg: SizingConfig, device, poll_every: int = 25, use_graph: bool = True,
@@ -447,17 +448,20 @@ def optimize_cases(cases: Cases, cfg: SizingConfig, device, poll_every: int = 25
         # The "any case still active?" poll lags one replay: its answer travels through a pinned flag behind an event, and the
         # host reads the flag of replay k - 1 after it has queued replay k -- the device never waits for the host (a blocking
         # poll drained the queue 13 times per 50 000-case shard, ~40 us each); the price is one replay of skipped wavefronts.
-        flags = torch.zeros(2, dtype=torch.uint8).pin_memory()
-        events = [torch.cuda.Event(), torch.cuda.Event()]
+        if key not in _POLL_FLAGS:          # (pinned allocations are slow: one pair of flags and events per device and thread)
+            _POLL_FLAGS[key] = (torch.zeros(2, dtype=torch.uint8).pin_memory(), [torch.cuda.Event(), torch.cuda.Event()])
+        flags, events = _POLL_FLAGS[key]
+        flags.zero_()
         k = 0
         while epochs_done < cfg.max_e:
             graph.replay()
             epochs_done += poll_every
             flags[k & 1: (k & 1) + 1].copy_(st.active.any().to(torch.uint8).reshape(1), non_blocking=True)
             events[k & 1].record()
-            if k > 0:
-                events[(k - 1) & 1].synchronize()
-                if int(flags[(k - 1) & 1]) == 0:
+            lag = 0 if os.environ.get("OPS_AMD_SIZING_POLL_LAG", "1") == "0" else 1
+            if k >= lag:
+                events[(k - lag) & 1].synchronize()
+                if int(flags[(k - lag) & 1]) == 0:
                     break
             k += 1
     else:
