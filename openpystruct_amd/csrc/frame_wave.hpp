@@ -38,6 +38,7 @@
 namespace opsamd {
 
 constexpr int FW_G = 8;     // rows per load group
+__host__ __device__ constexpr int fw_pitch(int W) { return W + 2; }   // doubles per parked row: W entries + right-hand side, even (16-byte reads)
 
 __host__ __device__ inline int fw_width(int kd) {           // compiled register-window widths
   return kd < 16 ? 16 : kd < 24 ? 24 : kd < 36 ? 36 : kd < 52 ? 52 : 56;
@@ -45,7 +46,7 @@ __host__ __device__ inline int fw_width(int kd) {           // compiled register
 __host__ __device__ inline int fw_rows(int n) { return n + 64 + 2 * FW_G; }      // allocated rows: unguarded group prefetch
 __host__ __device__ inline size_t fw_frame_doubles(int n, int kd) { return (size_t)fw_rows(n) * (fw_width(kd) + 1); }
 constexpr int FW_CB = 72;   // broadcast line: entry `rel` at index rel (pairs (t, t + 1), t even, are 16-byte aligned), two buffers
-__host__ __device__ inline size_t fw_lds_doubles(int n, int W) { return ((2 * FW_CB + (size_t)FW_G * (W + 1) + (size_t)(n + 64)) + 1) & ~(size_t)1; }
+__host__ __device__ inline size_t fw_lds_doubles(int n, int W) { return ((2 * FW_CB + (size_t)FW_G * fw_pitch(W) + (size_t)(n + 64)) + 1) & ~(size_t)1; }
 
 __device__ __forceinline__ double fw_readlane(double v, int lane) {
   const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane), hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
@@ -136,7 +137,7 @@ struct FwPlan {
   const int* hdr;            // [4]   [0] = number of extra blocks (0 for the reference's grid frames)
   const int* eq_dof;         // [n + 1]   index into loads[Nn*3]; [n] = 0
   const int* xstart;         // [ng + 2]  first extra block of a group (prefix sums); groups past the end: no extra blocks
-  const unsigned* ent;       // [nblk][FW_EPG]  bit 31 (valid) | element << 9 | (row in group) * (W + 1) + column slot
+  const unsigned* ent;       // [nblk][FW_EPG]  bit 31 (valid) | element << 9 | (row in group) * fw_pitch(W) + column slot
   const double* ka;          // [nblk][FW_EPG]
   const double* kb;          // [nblk][FW_EPG]
   const double* rhs_base;    // [n + 1]; [n] = 0
@@ -222,7 +223,7 @@ __global__ __launch_bounds__(1024) void frame_plan_kernel(const FrameParams p, i
         if (eq >= 0 && eq <= er) {
           const int pos = atomicAdd(&cur[g], 1), blk = pos / FW_EPG;
           const long idx = (long)(blk == 0 ? g : ng + 1 + xs_[g] + blk - 1) * FW_EPG + pos % FW_EPG;
-          ent[idx] = 0x80000000u | ((unsigned)e << 9) | (unsigned)((er % FW_G) * (W + 1) + eq % W);
+          ent[idx] = 0x80000000u | ((unsigned)e << 9) | (unsigned)((er % FW_G) * fw_pitch(W) + eq % W);
           ka[idx] = k_a[r][q];
           kb[idx] = k_b[r][q];
         }
@@ -296,10 +297,10 @@ template <int W>
 __device__ __forceinline__ void fw_take_group(FwState<W>& st, int g0, int lane, const double* __restrict__ stage) {
   const int slot = (lane - g0) & 63;                        // row g0 + slot belongs to this lane when slot < G
   if (slot < FW_G) {
-    const double* r = stage + (size_t)slot * (W + 1);
+    const double2* r = reinterpret_cast<const double2*>(stage + (size_t)slot * fw_pitch(W));      // W even: 16-byte reads
 #pragma unroll
-    for (int c = 0; c < W; ++c) st.reg[c] = r[c];
-    st.y = r[W];
+    for (int c = 0; c < W; c += 2) { const double2 v = r[c / 2]; st.reg[c] = v.x; st.reg[c + 1] = v.y; }
+    st.y = stage[(size_t)slot * fw_pitch(W) + W];
   }
 }
 
@@ -310,8 +311,8 @@ __device__ __forceinline__ void frame_wave_body(const FrameParams& p, double* __
   const int n = p.n_eq, kd = p.kd;
   const int KG = (kd / G + 1) * G;                          // > kd (column j + 1 is read during step j): registers hold the rows below j + KG + G at step j
   double* colbuf = lds;                                     // [2][FW_CB]
-  double* stage = lds + 2 * FW_CB;                          // [G][W + 1]: rows + right-hand sides of one group
-  double* xs = stage + (size_t)G * (W + 1);                 // [n + 64]: w, then x
+  double* stage = lds + 2 * FW_CB;                          // [G][fw_pitch(W)]: rows + right-hand sides of one group
+  double* xs = stage + (size_t)G * fw_pitch(W);                 // [n + 64]: w, then x
   double* rows = wsf;                                       // [fw_rows(n)][W], overwritten column by column with L
   const double* rhs_g = wsf + (size_t)fw_rows(n) * W;       // (unfused path)
   (void)rhs_g;
@@ -364,10 +365,10 @@ __device__ __forceinline__ void frame_wave_body(const FrameParams& p, double* __
         }
     }
     fw_fence();
-    if (lane < G) stage[lane * (W + 1) + W] = (gB + lane < n) ? by1 + by2 : 0.0;
+    if (lane < G) stage[lane * fw_pitch(W) + W] = (gB + lane < n) ? by1 + by2 : 0.0;
   };
   auto zero_stage = [&]() {
-    for (int i = lane; i < G * (W + 1); i += 64) stage[i] = 0.0;
+    for (int i = lane; i < G * fw_pitch(W); i += 64) stage[i] = 0.0;
     fw_fence();
   };
   // -- separate assembly kernel (A/B path): the group's G x W doubles are contiguous in the workspace
@@ -387,9 +388,9 @@ __device__ __forceinline__ void frame_wave_body(const FrameParams& p, double* __
 #pragma unroll
       for (int k = 0; k < K; ++k) {
         const int idx = lane + 64 * k;
-        if (idx < G * W) stage[(idx / W) * (W + 1) + idx % W] = tmp[k];
+        if (idx < G * W) stage[(idx / W) * fw_pitch(W) + idx % W] = tmp[k];
       }
-      if (lane < G) stage[lane * (W + 1) + W] = tmpy;
+      if (lane < G) stage[lane * fw_pitch(W) + W] = tmpy;
     }
   };
   // prologue: rows [0, KG + G) into registers, the next group parked, the one after on its way
