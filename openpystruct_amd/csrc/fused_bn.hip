@@ -174,7 +174,7 @@ __global__ __launch_bounds__(256) void fused_bn_fwd_kernel(const FbArgs a) {
     }
   }
   // one increment per launch, by the last workgroup to finish (call_counter.hpp); streams of different call sites differ by their seeds
-  if (drop && threadIdx.x == 0) call_counter_done(a.call_counter, gridDim.x);
+  if (drop) call_counter_done(a.call_counter, gridDim.x);   // every workgroup of this grid draws
 }
 
 struct FbBwdArgs {

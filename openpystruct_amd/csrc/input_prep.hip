@@ -72,7 +72,7 @@ __global__ __launch_bounds__(256) void gather_noise_kernel(int B, long F, const 
       Yout[i] = Y[idx[b] * C + (i - b * C)];
     }
   // one increment per launch, by the last workgroup to finish (call_counter.hpp)
-  if (counter && threadIdx.x == 0) call_counter_done(counter, gridDim.x);
+  if (counter) call_counter_done(counter, gridDim.x);   // every workgroup of this grid draws
 }
 
 }  // namespace opsamd

@@ -585,8 +585,10 @@ __global__ __launch_bounds__(MB_THREADS) void mlp_strip_kernel(const ops_mlp_str
     for (int j = 0; j < 8; ++j) t8[j] = s_z[8 * gq + j][c2];
     *(uint4*)((uint16_t*)sZt + mb_toff(n0 + c2, 8 * gq, MB_ROWS / 32)) = *(const uint4*)t8;
   }
-  if (fwd && a.p_drop > 0.0f && (a.tail == OPS_MLP_TAIL_ACT_DROP || a.tail == OPS_MLP_TAIL_BN_ACT_DROP) && tid == 0)
-    call_counter_done(a.call_counter, gridDim.x);   // one increment per launch, by the last workgroup to finish (call_counter.hpp)
+  // one increment per launch, by the last STRIP workgroup to finish: the side-job workgroups behind them left without reading the
+  // counter and do not report (call_counter.hpp)
+  if (fwd && a.p_drop > 0.0f && (a.tail == OPS_MLP_TAIL_ACT_DROP || a.tail == OPS_MLP_TAIL_BN_ACT_DROP))
+    call_counter_done(a.call_counter, (unsigned)nstrips * gridDim.y);
 
   if (a.tail == OPS_MLP_TAIL_LOSS) {
     // loss value: per-strip partial sums; workgroup 0 of the NEXT launch (loss_finish_rows) adds them -- no atomics, no fence here
@@ -745,7 +747,7 @@ __global__ __launch_bounds__(256) void mlp_gather_noise_kernel(int B, int F, con
       *(uint4*)(out_t + mb_toff(f0 + ff, 8 * bg, MB_ROWS / 32)) = *(const uint4*)&s_tile[ff][8 * bg];
     }
   }
-  if (counter && threadIdx.x == 0) call_counter_done(counter, gridDim.x);
+  if (counter) call_counter_done(counter, (unsigned)nfb);   // the target workgroups behind the nfb feature ones left early, unreported
 }
 
 }  // namespace opsamd

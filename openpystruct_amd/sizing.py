@@ -340,6 +340,9 @@ class SizingState:
         if shared_geom != (self.x.dim() == 1) or shared_fix != (self.fix.dim() == 1):
             return False
         self.cfg = cfg
+        # E and the line load are device scalars the captured launches read: c_params() carries neither the load nor (exactly) E
+        self.E.fill_(cfg.E)
+        self.wy.fill_(cfg.uniform_udl)
         self.x.copy_(cases.node_positions[0] if shared_geom else cases.node_positions)
         self.fix.copy_(cases.fix[0] if shared_fix else cases.fix)
         self.Fy.copy_(cases.Fy)

@@ -358,6 +358,10 @@ def enable_layer_tiles(enc: nn.TransformerEncoder, extra=None):
     todo = []
     good = lambda w: w.is_cuda and w.dtype == torch.float32 and w.is_contiguous() and w.dim() == 2      # noqa: E731
     extra = {k: w for k, w in (extra or {}).items() if good(w)}
+    # a second call (patch_model after patch_encoder: now with the head's extras) fits fewer layers into the 16 entries; a layer that
+    # kept the tiles of the first call would train on copies nothing refreshes any more -- only layers in THIS entry list carry tiles
+    for layer in enc.layers:
+        layer.__dict__.pop("_ops_tiles", None)
     for layer in enc.layers:
         if not _layer_ok(layer) or len(todo) + 4 + len(extra) > _cabi.MLP_MAX_REPACK:
             break

@@ -289,6 +289,44 @@ def test_dropout_masks_change_between_calls_and_under_graph_replay():
     assert torch.isfinite(eng.loss)
 
 
+@pytest.mark.parametrize("nblk,H,B", [(2, 350, 128), (3, 350, 77), (1, 64, 16)])
+def test_call_counters_advance_once_per_drawing_launch(nblk, H, B):
+    """csrc/call_counter.hpp: [calls, tally].  The fc1 launches carry side-job workgroups and the gather launch carries target workgroups
+    that never read the counter; only the drawing workgroups report, so after n steps the dropout counter stands at n * (1 + blocks)
+    with an empty tally, the gather's at n -- and every step draws new masks at every site (r03: the tally was compared with the
+    whole grid, the stream froze after a few steps and every later step repeated one mask)."""
+    from openpystruct_amd.pinn_fused import PinnFusedStep
+    dev = torch.device("cuda:0")
+    model, crit = _make(40 + nblk, 0.5, nblk=nblk, H=H)
+    model, crit = model.to(dev), crit.to(dev)
+    _attach_flat(model)
+    g = torch.Generator().manual_seed(9)
+    X = torch.randn(400, 684, generator=g).to(dev)
+    Y = torch.randn(400, 302, generator=g).to(dev)
+    eng = PinnFusedStep(model, crit, seed=5)
+    model.train()
+    sig = torch.tensor(0.05, device=dev)
+    idx = torch.arange(B, device=dev)
+    Hh = eng.Hh
+    sites = lambda: [(eng.read(eng.o[0][0], B, H) != 0).clone()] + [(eng.read(eng.h[k][0], B, Hh) != 0).clone() for k in range(nblk)]  # noqa: E731
+    prev, prev_x = None, None
+    n = 12
+    for step in range(1, n + 1):
+        eng.gather(X, Y, idx, sig, 17)
+        eng.fwd_bwd(B)
+        torch.cuda.synchronize()
+        assert eng.drop_counter.tolist() == [step * (1 + nblk), 0], (step, eng.drop_counter.tolist())
+        assert eng.prep_counter.tolist() == [step, 0], (step, eng.prep_counter.tolist())
+        cur, cur_x = sites(), eng.read(eng.x, B, 684).float().clone()
+        for m in cur:
+            assert 0.42 < float(m.float().mean()) < 0.58           # keep rate 0.5
+        if prev is not None:
+            for a, b in zip(prev, cur):
+                assert 0.4 < float((a != b).float().mean()) < 0.6    # independent masks: half the entries differ
+            assert float((cur_x - prev_x).abs().mean()) > 0.02      # the same rows, another noise field
+        prev, prev_x = cur, cur_x
+
+
 def test_invalid_layouts_are_refused():
     from openpystruct_amd import _cabi
     lib = _cabi.load()

@@ -156,6 +156,25 @@ def test_generate_dataset_records_and_json(oa, tmp_path):
     assert float(z["deflections"][:, -1].abs().max()) == 0.0 and float(z["rotations"][:, -1].abs().max()) == 0.0
 
 
+def test_second_dataset_with_another_line_load_is_not_solved_with_the_cached_one(oa):
+    """generate_dataset re-arms a cached state + epoch graph when shape and hyper-parameters repeat (SizingState.reset); the line load
+    (SingleCore.py:32, :117) is a device scalar of that state and not a hyper-parameter: a second run that differs only in it must
+    be solved with ITS load."""
+    from openpystruct_amd import sizing
+    a = sizing.generate_dataset(64, sizing.SizingConfig(max_e=30), "cuda", seed=3)
+    b = sizing.generate_dataset(64, sizing.SizingConfig(max_e=30, uniform_udl=-20000.0), "cuda", seed=3)
+    a2 = sizing.generate_dataset(64, sizing.SizingConfig(max_e=30), "cuda", seed=3)
+    assert torch.equal(a["I_values"], a2["I_values"]) and torch.equal(a["deflections"], a2["deflections"])
+    assert not torch.equal(a["deflections"], b["deflections"])
+    # ... and that load is the one the per-case oracle is given (max_e = 30: every case runs all 30 epochs on both sides)
+    for i in (0, 17, 63):
+        nr, nf = int(b["n_rollers"][i]), int(b["n_forces"][i])
+        ref = so.generate_sample(b["node_positions"][i].cpu().numpy(), b["roller_nodes"][i, :nr].tolist(), b["force_nodes"][i, :nf].tolist(),
+                                 b["force_values"][i, :nf].tolist(), udl=-20000.0, max_e=30)
+        assert int(b["epochs_run"][i]) == ref["epochs_run"]
+        assert relerr(b["deflections"][i].cpu().numpy(), np.array(ref["deflections"])) < 5e-3
+        assert relerr(a["deflections"][i].cpu().numpy(), np.array(ref["deflections"])) > 2e-2
+
 def test_beam_opt_variant_against_oracle(oa):
     """OpenPyStruct_BeamOpt.py's single-case optimiser (UDL -5000, 5 spaced rollers, 5 loads in [0.5, 1] * max,
     tolerance 1e-2, patience 10) as a batch; per-beam supports with shared geometry."""

@@ -232,24 +232,75 @@ def test_fused_tail_dropout_is_bernoulli_and_redrawn_on_graph_replay():
     assert not torch.equal(a, b) and abs((b != 0).float().mean().item() - 0.5) < 0.02
 
 
-def test_pinn_training_with_the_fused_kernels_follows_the_framework_path(monkeypatch):
-    """Eight epochs of the PINN loop with dropout 0.5 and input noise on, three ways: the layer-block launches (pinn_fused.py: no
-    autograd), autograd over the hand-written tails / batch assembly / stencil, and the framework's modules and generators.  Own
-    counter-based dropout and noise streams: the loss curves are draws of the same stochastic process -- within 5 % of each
-    other, all decreasing."""
-    from openpystruct_amd import dataprep, pinn_fused, sizing, surrogates as S, train
-    rec = sizing.generate_dataset(6000, sizing.SizingConfig(max_e=60), "cuda")
-    d = dataprep.prepare(rec, kind="pinn", device="cuda")
+def _pinn_three_ways(monkeypatch, d, cfg, seed, epochs):
+    """The PINN loop three ways -- the layer-block launches (pinn_fused.py: no autograd), autograd over the hand-written tails / batch
+    assembly / stencil, and the framework's modules and generators -- from the same initial weights (seed) and with the same batch
+    order per epoch (the reference's DataLoader shuffle is unseeded, PINN:701: any order is a valid draw, and a shared one removes
+    the largest common source of scatter between the runs)."""
+    from openpystruct_amd import pinn_fused, surrogates as S, train
+    n_tr, order = int(d.X_train.shape[0]), {}
+
+    def batch_order(epoch):
+        if epoch not in order:
+            order[epoch] = torch.randperm(n_tr, generator=torch.Generator().manual_seed(1000 * seed + epoch))
+        return order[epoch]
+
     hist = {}
     for mode in ("blocks", "tails", "framework"):
         monkeypatch.setattr(pinn_fused, "ENABLED", mode == "blocks")
         monkeypatch.setattr(S, "_FUSED_TAILS", mode != "framework")
         monkeypatch.setenv("OPS_AMD_FUSED_PREP", "0" if mode == "framework" else "1")
-        out = train.train_surrogate("pinn", d, device="cuda", max_epochs=8, seed=1)
-        hist[mode] = out["history"]["train"]
-        assert all(np.isfinite(hist[mode])) and hist[mode][-1] < 0.6 * hist[mode][0]
+        out = train.train_surrogate("pinn", d, cfg, device="cuda", max_epochs=epochs, seed=seed, batch_order=batch_order)
+        hist[mode] = out["history"]
+        assert all(np.isfinite(hist[mode]["train"])) and all(np.isfinite(hist[mode]["val"]))
+    return hist
+
+
+@pytest.fixture(scope="module")
+def pinn_data():
+    from openpystruct_amd import dataprep, sizing
+    rec = sizing.generate_dataset(6000, sizing.SizingConfig(max_e=60), "cuda")
+    return dataprep.prepare(rec, kind="pinn", device="cuda")
+
+
+@pytest.mark.parametrize("seed", [1, 2])
+def test_pinn_training_paths_agree_epoch_for_epoch_without_randomness(monkeypatch, pinn_data, seed):
+    """Dropout 0, input noise 0, one batch order: nothing random is left, and the three paths are three bf16 evaluations of the SAME
+    eight epochs (7 steps each: 6 full batches + a 32-row tail).  Step count, tail-batch weight, BatchNorm running statistics, the
+    evaluation pass, Adam, clipping and the learning-rate schedule all enter the curves, so a path that does any of them differently
+    departs at once.  Measured over 10 seeds (scripts/follow_spread.py, profiles/r04_pinn_follow_spread.log): worst epoch-wise
+    deviation from the framework path 1.3 % (training loss) / 2.7 % (validation loss); bounds 4 % / 6 %."""
+    from openpystruct_amd import train
+    cfg = train.PinnConfig()
+    cfg.dropout_rate, cfg.sigma_0 = 0.0, 0.0
+    hist = _pinn_three_ways(monkeypatch, pinn_data, cfg, seed, 8)
+    ref = hist["framework"]
+    assert ref["train"][-1] < 0.6 * ref["train"][0]
     for mode in ("blocks", "tails"):
-        assert abs(hist[mode][-1] - hist["framework"][-1]) < 0.05 * hist["framework"][-1], hist
+        tr = np.abs(np.array(hist[mode]["train"]) / np.array(ref["train"]) - 1.0)
+        va = np.abs(np.array(hist[mode]["val"]) / np.array(ref["val"]) - 1.0)
+        assert tr.max() < 0.04 and va.max() < 0.06, (mode, tr, va)
+
+
+@pytest.mark.stochastic
+def test_pinn_training_paths_draw_from_the_same_process(monkeypatch, pinn_data):
+    """The reference's configuration (dropout 0.5, input noise on): the paths draw masks and noise from different streams (own
+    counter-based ones vs torch generators), so only distributions can agree.  Five seeds, initial weights and batch order shared per
+    seed: the ratio of a path's final training loss to the framework path's has a measured sigma of 2 % and a mean of +0.3 % over 10
+    seeds (profiles/r04_pinn_follow_spread.log; the UNPAIRED final loss scatters by 7 %, which is what made the single-run 5 % form
+    of this test a coin flip).  Mean ratio within 4 % (> 4 sigma of the mean of five), every ratio within 10 % (5 sigma), every
+    curve decreasing.  A weaker effective dropout or a stream that repeats itself shows up as a mean well below 1."""
+    from openpystruct_amd import train
+    ratios = {"blocks": [], "tails": []}
+    for seed in (1, 2, 3, 4, 5):
+        hist = _pinn_three_ways(monkeypatch, pinn_data, train.PinnConfig(), seed, 8)
+        for mode in ("blocks", "tails", "framework"):
+            assert hist[mode]["train"][-1] < 0.6 * hist[mode]["train"][0]
+        for mode in ratios:
+            ratios[mode].append(hist[mode]["train"][-1] / hist["framework"]["train"][-1])
+    for mode, r in ratios.items():
+        r = np.array(r)
+        assert abs(r.mean() - 1.0) < 0.04 and np.abs(r - 1.0).max() < 0.10, (mode, r)
 
 
 def test_evaluation_mode_backward_goes_through_the_framework_modules():
