@@ -236,12 +236,13 @@ def surrogate_epoch_times(dev, rank, world, epochs, cases=50000):
         torch.cuda.synchronize()
         cold = time.perf_counter() - t0           # first call: library load, first-use kernel loads, graph capture
         runs = []                                 # warm calls: the shard's state buffers and captured epoch graph are re-armed in place
-        for _ in range(3):
+        for _ in range(9):
             t0 = time.perf_counter()
             rec = sizing.generate_dataset(cases * world, sizing.SizingConfig(), dev, rank=rank, world=world)
             torch.cuda.synchronize()
             runs.append(time.perf_counter() - t0)
-        out = {"generate_s": sorted(runs)[1], "generate_s_runs": runs, "generate_cold_s": cold, "cases_per_gpu": cases,
+        out = {"generate_s": sorted(runs)[len(runs) // 2], "generate_s_median": sorted(runs)[len(runs) // 2], "generate_s_mean": sum(runs) / len(runs),
+               "generate_s_max": max(runs), "generate_s_runs": runs, "generate_cold_s": cold, "cases_per_gpu": cases,
                "fe_solves_per_gpu": int(rec["epochs_run"].sum())}
         for kind in ("pinn", "tfd"):
             d = dataprep.prepare(rec, kind=kind, device=dev, distributed=world > 1)
@@ -268,15 +269,17 @@ def surrogate_epoch_times(dev, rank, world, epochs, cases=50000):
         return {"error": repr(e)}
 
 
-def bench_frames(args, rank, local_rank, world, dev):
-    """BASELINE config 5 (not the default workload): B frames of 15 x 16 bays x stories (496 elements, 768 equations,
-    half bandwidth 50) per GPU per step, independent shards, no collective."""
-    import torch.distributed as dist
-    from openpystruct_amd import frames
+FRAME_BATCH = {"15x16": 12288, "10x10": 16384}       # frames per launch per GPU (the batches of profiles/*frames*_pmc_summary.json)
 
-    bays, stories = (int(v) for v in args.frame.split("x"))
+
+def frames_measure(dev, rank, local_rank, world, bays, stories, B, K, W):
+    """BASELINE config 5: K launches of the batched frame solve over B frames of `bays` x `stories` per GPU (independent shards, no
+    collective), HIP events on the launch stream, barriers outside them, max over ranks.  Every rank calls it; returns the record
+    (the same on every rank)."""
+    import torch.distributed as dist
+    from openpystruct_amd import _cabi, frames
+
     topo = frames.grid_frame(bays, stories, device=dev)
-    B, K, W = args.batch if args.batch != 10000 else 12288, min(args.steps, 50), args.warmup
     g = torch.Generator(device=dev).manual_seed(20250307 + rank)
     I = torch.exp(torch.empty((B, topo.Ne), dtype=torch.float64, device=dev).uniform_(math.log(1e-4), math.log(5e-3), generator=g))
     sol = frames.frame_solve(topo, I)
@@ -305,35 +308,43 @@ def bench_frames(args, rank, local_rank, world, dev):
         tt = torch.tensor([wall, dev_ms], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         wall, dev_ms = float(tt[0]), float(tt[1])
+    lib = _cabi.load()
+    ws_frame = int(lib.ops_frame_workspace_bytes(2, topo.n_eq, topo.kd)) - int(lib.ops_frame_workspace_bytes(1, topo.n_eq, topo.kd))   # per frame (the call-wide assembly plan excluded)
+    # ALGORITHMIC bytes per frame: I in; disp [Nn,3], forces [Ne,6], V, M out -- what a solve that kept its factor on chip would move
+    io_frame = 8 * (topo.Ne + 3 * topo.Nn + 8 * topo.Ne)
+    us = dev_ms / K * 1e3
+    achieved = io_frame * B / (us * 1e-6) / 1e9
+    flops = 2.0 * topo.n_eq * topo.kd * topo.kd / 2.0            # band LDL^T multiply-adds (n kd^2 / 2), counted as 2 flop
+    tr = profiled_frame_traffic(B, bays, stories)
+    return {
+        "metric": f"frame FE solves/s ({topo.Ne}-elem, batched)", "value": world * B * K / (dev_ms * 1e-3), "unit": "frame FE solves/s",
+        "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": dev_ms / K, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f64", "data": "synthetic", "value_host_clock": world * B * K / wall,
+        "solves_per_s": world * B * K / (dev_ms * 1e-3),
+        "config": {"workload": f"BASELINE config 5: {B} frames of {bays}x{stories} bays x stories ({topo.Ne} elements, {topo.n_eq} "
+                               f"equations, half bandwidth {topo.kd}) per GPU per step", "frames_per_step_per_gpu": B,
+                   "workspace_bytes_per_frame": ws_frame,
+                   "parallelism": f"independent shards x{world}, no data-path collective"},
+        # headline of this workload: the FP64 vector rate (the factorisation is n kd^2 flops on 42 KB of algorithmic I/O: it is
+        # arithmetic-, not HBM-bound); the HBM record is on ALGORITHMIC bytes, with the measured (PMC) traffic named beside it
+        "fp64_vector_frac": flops * B / (us * 1e-6) / 78.6e12,
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": tr[0] if tr else None, "traffic_source": f"profiles/{tr[1]} (2*FETCH_SIZE + WRITE_SIZE, KiB)" if tr else None,
+                     "traffic_over_algorithmic": tr[0] / (io_frame * B) if tr else None,
+                     "algorithmic_bytes_per_frame": io_frame, "kernel_us": us,
+                     "fp64_vector_frac": flops * B / (us * 1e-6) / 78.6e12, "fp64_vector_peak_tflops": 78.6,
+                     "flop_per_frame": flops},
+    }
+
+
+def bench_frames(args, rank, local_rank, world, dev):
+    """`--workload frames`: the config-5 record as the line itself (the default line carries it under "frames")."""
+    import torch.distributed as dist
+    bays, stories = (int(v) for v in args.frame.split("x"))
+    B = args.batch if args.batch != 10000 else FRAME_BATCH.get(args.frame, 12288)
+    rec = frames_measure(dev, rank, local_rank, world, bays, stories, B, min(args.steps, 50), args.warmup)
     if rank == 0:
-        from openpystruct_amd import _cabi
-        ws_frame = int(_cabi.load().ops_frame_workspace_bytes(2, topo.n_eq, topo.kd)) - int(_cabi.load().ops_frame_workspace_bytes(1, topo.n_eq, topo.kd))   # per frame (the call-wide assembly plan excluded)
-        # ALGORITHMIC bytes per frame: I in; disp [Nn,3], forces [Ne,6], V, M out -- what a solve that kept its factor on chip would move
-        io_frame = 8 * (topo.Ne + 3 * topo.Nn + 8 * topo.Ne)
-        # what this kernel moves on top: the factor rows are written once by the factorisation and read once by the backward sweep
-        moved = 2 * ws_frame + io_frame
-        us = dev_ms / K * 1e3
-        achieved = io_frame * B / (us * 1e-6) / 1e9
-        flops = 2.0 * topo.n_eq * topo.kd * topo.kd / 2.0            # band LDL^T multiply-adds (n kd^2 / 2), counted as 2 flop
-        tr = profiled_frame_traffic(B, bays, stories)
-        print(json.dumps({
-            "metric": f"frame FE solves/s ({topo.Ne}-elem, batched)", "value": world * B * K / (dev_ms * 1e-3), "unit": "frame FE solves/s",
-            "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": dev_ms / K, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f64", "data": "synthetic", "value_host_clock": world * B * K / wall,
-            "config": {"workload": f"BASELINE config 5: {B} frames of {bays}x{stories} bays x stories ({topo.Ne} elements, {topo.n_eq} "
-                                   f"equations, half bandwidth {topo.kd}) per GPU per step", "frames_per_step_per_gpu": B,
-                       "workspace_bytes_per_frame": ws_frame, "parallelism": f"independent shards x{world}, no data-path collective"},
-            # headline of this workload: the FP64 vector rate (the factorisation is n kd^2 flops on 42 KB of algorithmic I/O: it is
-            # arithmetic-, not HBM-bound); the HBM record is on ALGORITHMIC bytes, with the factor-workspace traffic named beside it
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": tr[0] if tr else None, "traffic_source": f"profiles/{tr[1]} (2*FETCH_SIZE + WRITE_SIZE, KiB)" if tr else None,
-                         "algorithmic_bytes_per_frame": io_frame, "kernel_us": us,
-                         "fp64_vector_frac": flops * B / (us * 1e-6) / 78.6e12, "fp64_vector_peak_tflops": 78.6,
-                         "moved_bytes_per_frame": moved, "moved_over_algorithmic": moved / io_frame,
-                         "moved_gbs": moved * B / (us * 1e-6) / 1e9,
-                         "note": "wave-per-frame band LDL^T, window in registers, assembly fused (csrc/frame_wave.hpp): the factor rows make "
-                                 "2 passes over an HBM workspace (moved_over_algorithmic x the algorithmic bytes)"},
-        }), flush=True)
+        print(json.dumps(rec), flush=True)
     if world > 1:
         dist.destroy_process_group()
 
@@ -532,9 +543,23 @@ def main():
         # (12 untimed launches first: after the sub-millisecond launches above the first ~10 ms of 1 ms launches run 5-10 %
         #  slow -- clocks and TLBs of 5 GB of fresh buffers, measured with scripts/sat_ab.py)
         extras["saturating"] = sub_record(1 << 20, 10, 1, args.tiling, "2^20 beams per launch (5.2 GB per launch: HBM-resident by size)", warm=12)
+    # BASELINE config 5 on the same line: the batched frame solve at the reference's largest frame (10 x 10) and at the ~500-element one
+    # BASELINE names (15 x 16); <= 0.3 s each (20 launches of 1.5-4 ms)
+    frames_rec = {}
+    if not args.no_extras and args.sets <= 1 and B == 10000:
+        for fr in ("15x16", "10x10"):
+            try:
+                fb, fs = (int(v) for v in fr.split("x"))
+                frames_rec[fr] = frames_measure(dev, rank, local_rank, world, fb, fs, FRAME_BATCH[fr], 20, 3)
+            except Exception as e:       # the FE line must survive
+                frames_rec[fr] = {"error": repr(e)}
+                if world > 1:
+                    break                # the ranks may have diverged inside the collective timing: no further frame collectives
     fe_guard.cancel()
     if rank == 0:
         rec.update(extras)
+        if frames_rec:
+            rec["frames"] = frames_rec
         if "cold" in extras:
             rec["roofline"]["frac_hbm_resident"] = extras["cold"]["frac"]
             rec["roofline"]["kernel_us_hbm_resident"] = extras["cold"]["kernel_us"]

@@ -223,6 +223,15 @@ class FnoConfig:
 
 
 _DEBUG_NAN = os.environ.get("OPS_AMD_DEBUG_NAN", "0") == "1"
+_EXPLICIT_ROOT = os.environ.get("OPS_AMD_EXPLICIT_ROOT", "0") == "1"
+_ROOT_ONES = {}
+
+
+def _root_ones(device):
+    key = (device.type, device.index)
+    if key not in _ROOT_ONES:
+        _ROOT_ONES[key] = torch.ones((), dtype=torch.float32, device=device)
+    return _ROOT_ONES[key]
 
 
 def _cabi_rows() -> int:
@@ -681,7 +690,10 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
             # tensor, or the loss launch's own d loss / d preds handed to preds.backward() -- framework-path runs that follow another run
             # in the same process produced isolated NaNs in bias gradients at the first replay after an eager pass (9 of 12 runs against
             # 0 of 12, profiles/r03_notes.md 8)
-            loss.backward()
+            if _EXPLICIT_ROOT:           # diagnostics only (scripts/nan_hunt.sh): the form that exposed the r03 NaNs
+                loss.backward(gradient=_root_ones(device))
+            else:
+                loss.backward()
             flush_wgrad_queue(device)
         finally:
             _WGRAD_QUEUE = None
