@@ -24,6 +24,10 @@ import os
 import sys
 import time
 
+# HIP graph packet capture off before anything can touch the GPU (N > 1: the process group is created before the package is imported):
+# with it on, captured memset nodes replay garbage (openpystruct_amd/runtime.py item 2; no measurable cost, profiles/r04_notes.md)
+os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
+
 import numpy as np
 import torch
 
@@ -115,27 +119,8 @@ def _gen_one(seed):
 
 
 def usable_cores():
-    """Host cores this process may actually use: min(os.cpu_count(), scheduler affinity, cgroup CPU quota)."""
-    n = os.cpu_count() or 1
-    try:
-        n = min(n, len(os.sched_getaffinity(0)))
-    except Exception:
-        pass
-    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
-        try:
-            txt = open(path).read().split()
-            if path.endswith("cpu.max"):
-                if txt[0] != "max":
-                    n = min(n, max(1, int(math.ceil(int(txt[0]) / int(txt[1])))))
-            else:
-                q = int(txt[0])
-                if q > 0:
-                    per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
-                    n = min(n, max(1, int(math.ceil(q / per))))
-            break
-        except Exception:
-            continue
-    return n
+    from openpystruct_amd import runtime
+    return runtime.usable_cores()
 
 
 def generator_baseline(cores):
@@ -230,7 +215,8 @@ def surrogate_epoch_times(dev, rank, world, epochs, cases=50000):
     try:
         if world > 1:     # HIP events around the segments of the data-parallel step: the first multi-GPU run explains its own scaling
             os.environ.setdefault("OPS_AMD_DP_PROFILE", "1")
-        from openpystruct_amd import dataprep, sizing, train
+        from openpystruct_amd import dataprep, runtime, sizing, train
+        thr0 = runtime.cpu_throttle_counters()
         t0 = time.perf_counter()
         rec = sizing.generate_dataset(cases * world, sizing.SizingConfig(), dev, rank=rank, world=world)
         torch.cuda.synchronize()
@@ -244,6 +230,12 @@ def surrogate_epoch_times(dev, rank, world, epochs, cases=50000):
         out = {"generate_s": sorted(runs)[len(runs) // 2], "generate_s_median": sorted(runs)[len(runs) // 2], "generate_s_mean": sum(runs) / len(runs),
                "generate_s_max": max(runs), "generate_s_runs": runs, "generate_cold_s": cold, "cases_per_gpu": cases,
                "fe_solves_per_gpu": int(rec["epochs_run"].sum())}
+        thr1 = runtime.cpu_throttle_counters()
+        # the r03 "stalled replays" were CFS throttling of the container (runtime.py item 1): the counters of the generator leg
+        out["runtime"] = {"cpu_threads": torch.get_num_threads(), "usable_cores": runtime.usable_cores(),
+                          "cfs_throttled_periods_during_generate": (thr1.get("nr_throttled", 0) - thr0.get("nr_throttled", 0)) if thr0 and thr1 else None,
+                          "graph_memsets_replay_correctly": runtime.graph_memsets_replay_correctly(dev),
+                          "hip_graph_packet_capture_env": os.environ.get(runtime.PACKET_CAPTURE_ENV)}
         for kind in ("pinn", "tfd"):
             d = dataprep.prepare(rec, kind=kind, device=dev, distributed=world > 1)
             r = train.train_surrogate(kind, d, device=dev, max_epochs=epochs)
@@ -388,7 +380,10 @@ def main():
     if args.gpus != world and rank == 0 and world > 1:
         print(f"warning: --gpus {args.gpus} != WORLD_SIZE {world}", file=sys.stderr)
 
-    import openpystruct_amd as oa
+    import openpystruct_amd as oa       # (sets the HIP graph environment defaults before this process's first HIP call: runtime.py)
+    from openpystruct_amd import runtime
+
+    cpu_threads = runtime.fit_cpu_threads()      # the framework's CPU pool inside the container's CPU quota (runtime.py item 1)
 
     # the CPU legs run first: the generator leg forks a process pool, which must happen before this process touches the GPU
     cpu = None

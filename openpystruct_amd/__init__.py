@@ -2,6 +2,10 @@
 
 Host side in Python over a C-ABI HIP library; see DESIGN.md and INTEGRATION.md.
 """
+from . import runtime as _runtime
+
+_runtime.set_graph_env_defaults()      # before the process's first HIP call when this import comes first (runtime.py, item 2)
+
 from .beam import BeamSolution, beam_solve, kernel_name  # noqa: F401
 from . import torch_op  # noqa: F401  (registers torch.ops.openpystruct_amd.beam_solve)
 

@@ -527,7 +527,9 @@ def generate_dataset(n_cases: int, cfg: Optional[SizingConfig] = None, device="c
         # not a reference field: the float64 inertias the recorded V / M / rotations / deflections were solved with
         # (the state BEFORE the last Adam step; `I_values` is the state after it -- the reference's one-step lag)
         "I_solved": st.I64 if st._fused else st.I64.clone(),
-        "case_ids": torch.arange(lo, hi),
+        # (numpy: a framework arange over more than 32 768 elements wakes the whole CPU thread pool -- inside a container with a CPU
+        #  quota that froze the process for the rest of the scheduler period, once per shard: runtime.py item 1)
+        "case_ids": torch.from_numpy(np.arange(lo, hi, dtype=np.int64)),
     }
 
 

@@ -223,7 +223,7 @@ class FnoConfig:
 
 
 _DEBUG_NAN = os.environ.get("OPS_AMD_DEBUG_NAN", "0") == "1"
-_EXPLICIT_ROOT = os.environ.get("OPS_AMD_EXPLICIT_ROOT", "0") == "1"
+_EXPLICIT_ROOT = os.environ.get("OPS_AMD_EXPLICIT_ROOT", "1") == "1"      # A/B switch: 0 = loss.backward() with its implicit ones_like() fill node
 _ROOT_ONES = {}
 
 
@@ -612,6 +612,15 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
         if pinn_fused.eligible(model, crit, cfg.batch_size):
             engine = pinn_fused.PinnFusedStep(model, crit, seed=seed * 7919 + 101 + rank)
             opt.repack = engine._repack      # the Adam launch refreshes the engine's bf16 weight copies
+    if use_graph and on_gpu and engine is None and fast_encoder is None:
+        # a step the FRAMEWORK differentiates (comparator paths, the sibling surrogates): its multi-block reductions are only right under
+        # graph replay when captured memset nodes are (runtime.py item 2); the hand-written paths above contain none
+        from . import runtime
+        if not runtime.graph_memsets_replay_correctly(device):
+            use_graph = False
+            if log:
+                log(f"captured hipMemsetAsync nodes replay wrong values in this process ({runtime.PACKET_CAPTURE_ENV}=0 came after its "
+                    "first HIP call?): the framework-differentiated step runs eagerly")
     Xtr, Ytr, Xva, Yva = (t.to(device) for t in (data.X_train, data.Y_train, data.X_val, data.Y_val))
     nb_tr = max(1, (Xtr.shape[0] + cfg.batch_size - 1) // cfg.batch_size)
     if world > 1:   # every rank must run the same number of steps (collectives inside backward)
@@ -686,11 +695,11 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
         global _WGRAD_QUEUE
         _WGRAD_QUEUE = [] if (g_stash and _GROUP_WGRAD) else None       # split-row weight gradients: one grouped launch after backward
         try:
-            # NOT backward(gradient=...) to save the implicit ones_like() fill node: with an explicit root gradient -- a persistent ones
-            # tensor, or the loss launch's own d loss / d preds handed to preds.backward() -- framework-path runs that follow another run
-            # in the same process produced isolated NaNs in bias gradients at the first replay after an eager pass (9 of 12 runs against
-            # 0 of 12, profiles/r03_notes.md 8)
-            if _EXPLICIT_ROOT:           # diagnostics only (scripts/nan_hunt.sh): the form that exposed the r03 NaNs
+            # the root gradient is a persistent ones tensor: no ones_like() fill node per step.  (r03 kept the implicit form because the
+            # explicit one "produced" NaNs in bias gradients of framework-path runs; the NaNs were the HIP runtime's captured-memset
+            # defect under the framework's own bias-gradient reductions -- runtime.py item 2 -- and the root gradient only moved the
+            # memory layout that decided which garbage their semaphores saw)
+            if _EXPLICIT_ROOT:
                 loss.backward(gradient=_root_ones(device))
             else:
                 loss.backward()

@@ -26,3 +26,6 @@ print("shards", shards, "cases", n, "poll_every", pe, "replays", len(d), "median
 for i, ((a, b), t) in enumerate(zip(rt, d)):
     if t > 10 + 2 * med:
         print("STALL replay %d (shard %d, replay %d of it): %.1f ms, host clock %d .. %d ns (CLOCK_MONOTONIC)" % (i, i // (len(d) // shards), i % (len(d) // shards), t, a, b))
+import resource, threading
+ru = resource.getrusage(resource.RUSAGE_SELF)
+print("process CPU time: user %.2f s  sys %.2f s   threads now: %d" % (ru.ru_utime, ru.ru_stime, len(os.listdir("/proc/self/task"))))

@@ -61,3 +61,14 @@ long_h = sorted((r for r in h if r["e"] - r["s"] > 5e6), key=lambda r: r["s"])
 print("HIP calls longer than 5 ms:", len(long_h), "of", len(h))
 for r in long_h[:40]:
     print("  %.3f ms at +%.3f ms %s" % ((r["e"] - r["s"]) / 1e6, (r["s"] - t0) / 1e6, r.get("Function", "?")))
+# every long hipGraphLaunch: the HIP calls of all threads from 3 ms before its start to its end
+print("---- HIP calls around every hipGraphLaunch longer than 5 ms")
+h.sort(key=lambda r: r["s"])
+for L in [r for r in long_h if r.get("Function") == "hipGraphLaunch"][:6]:
+    print("hipGraphLaunch %.3f ms, thread %s, start +%.3f ms" % ((L["e"] - L["s"]) / 1e6, L.get("Thread_Id", "?"), (L["s"] - t0) / 1e6))
+    for r in h:
+        if r["e"] > L["s"] - 3e6 and r["s"] < L["e"] + 1e6 and r is not L:
+            print("    %-34s thread %s  start %+9.3f ms  dur %8.3f ms" % (r.get("Function", "?"), r.get("Thread_Id", "?"), (r["s"] - L["s"]) / 1e6, (r["e"] - r["s"]) / 1e6))
+    ks = [r for r in k if r["e"] > L["s"] - 3e6 and r["s"] < L["e"] + 1e6]
+    for r in ks[:3] + ks[-3:]:
+        print("    kernel %-40s start %+9.3f ms  dur %8.3f ms" % (r["Kernel_Name"][:40], (r["s"] - L["s"]) / 1e6, (r["e"] - r["s"]) / 1e6))

@@ -1,6 +1,9 @@
 import os
 import sys
 
+# before any test module can make this process's first HIP call (openpystruct_amd/runtime.py item 2: captured memset nodes)
+os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
+
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -19,6 +22,7 @@ _ORDER = (
     "test_oracle", "test_cabi", "test_emulation", "test_host_logic", "test_layer_block_host",      # CPU: oracle vs closed forms, ABI, host logic
     "test_gpu_parity", "test_force_truth", "test_surrogate_golden",                                # HIP path vs oracle / golden fixtures
     "test_gpu_fat", "test_gpu_sizing", "test_gpu_frames", "test_gpu_physics",                      # every tiling / the callers / frames / residual
+    "test_gpu_runtime",                                                                            # the process around the library
     "test_gpu_pinn_fused", "test_gpu_tfd_fused", "test_gpu_surrogates", "test_surrogates",         # training kernels vs autograd
     "test_openseespy_live",
 )

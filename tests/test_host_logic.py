@@ -217,3 +217,25 @@ def test_analysis_object_commands_reject_what_they_cannot_honour():
             bad()
     with pytest.raises(ValueError):
         ops.system('Mumps')
+
+
+def test_runtime_helpers_on_the_cpu(monkeypatch):
+    """openpystruct_amd/runtime.py: the import sets the HIP graph environment default without overriding a user's choice; the usable
+    core count honours affinity and quota; the throttle counters are a dict (empty where cgroup v2 is not mounted)."""
+    import importlib
+    import os
+    from openpystruct_amd import runtime
+    assert os.environ.get(runtime.PACKET_CAPTURE_ENV) is not None        # set by the package import (or by the user)
+    monkeypatch.setenv(runtime.PACKET_CAPTURE_ENV, "1")
+    runtime.set_graph_env_defaults()
+    assert os.environ[runtime.PACKET_CAPTURE_ENV] == "1"                 # setdefault: a user's value stays
+    n = runtime.usable_cores()
+    assert 1 <= n <= (os.cpu_count() or 1)
+    c = runtime.cpu_throttle_counters()
+    assert isinstance(c, dict) and all(isinstance(v, int) for v in c.values())
+    import torch
+    old = torch.get_num_threads()
+    try:
+        assert 1 <= runtime.fit_cpu_threads() <= max(1, n)
+    finally:
+        torch.set_num_threads(old)
