@@ -16,6 +16,7 @@
 // forward launch left in `used_call` instead of reading a stored one.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/openpystruct_amd.h"
 #include "dropout_stream.hpp"
@@ -550,13 +551,16 @@ namespace opsamd {
 
 typedef __bf16 wg_bf16x8 __attribute__((ext_vector_type(8)));
 typedef float wg_f32x4 __attribute__((ext_vector_type(4)));
-constexpr int WG_ROWS = 256;      // rows of T per workgroup: the float atomics of the partial tiles bound the launch (128 rows: 54 us for the twelve
-                                  // products of a TFD step, 256: 37, 512: 35 -- and fewer workgroups per small product)
 constexpr int WG_SLAB = 32;       // rows per LDS slab = one MFMA reduction step
+#define OPS_WG_MAX_UNITS 128
+#define OPS_WG_MAX_UNITS_PER_XCD 24
 
 // one 32-row slab of an operand: row lr, 8 columns from c0 + lc -- one 16-byte load when the matrix allows it
 __device__ __forceinline__ uint4 wg_load8(const uint16_t* __restrict__ M, int T, int C, int ld, int t, int c, bool vec) {
   uint4 r = uint4{0u, 0u, 0u, 0u};
+#if defined(OPS_WG_ABLATE) && OPS_WG_ABLATE == 3      /* no global loads */
+  r.x = (unsigned)t; return r;
+#endif
   if (t >= T || c >= C) return r;
   if (vec && c + 8 <= C) return *(const uint4*)(M + (long)t * ld + c);
   uint16_t v[8];
@@ -565,80 +569,152 @@ __device__ __forceinline__ uint4 wg_load8(const uint16_t* __restrict__ M, int T,
   return *(const uint4*)v;
 }
 
+// r04 form.  What the r03 launch (34-37 us for the twelve products of a Transformer-Diffusion step) spent, by phase ablation
+// (profiles/r04_notes.md 5): ~12 us float atomics (5 M of them: they execute at the memory side at ~1.3 TB/s of added bytes whatever
+// the XCD), ~12 us the operands' loads, ~12 us everything else (a barrier pair and sixteen 2-byte LDS scatter writes per thread and
+// slab, 1 218 workgroups).  Now:
+//   * a workgroup still owns a 64 x 64 tile of dW, but each of its four waves walks ITS OWN rows (rw rows, a multiple of 32) and keeps
+//     the whole tile in registers (16 accumulators); the four partial tiles meet in LDS once, at the end, and the workgroup adds one
+//     tile for 4 rw rows: a quarter of the atomics at the same number of waves in flight;
+//   * no workgroup barrier inside the row loop: a wave's slab lives in its own LDS region (LDS operations of one wave execute in order);
+//   * the slab sits ROW-major in LDS as it arrives (four 16-byte writes per lane and operand) and the fragments -- 8 consecutive t of
+//     one column -- are taken with gfx950's transposing LDS read (ds_read_b64_tr_b16: per 16-lane group a 4-row x 16-column block,
+//     delivered column-major), two per fragment.  Row pitch 96 elements with rows 8 .. 15 (mod 16) skewed by 16: the transposed reads of
+//     a 32-lane half then touch 64 distinct banks;
+//   * eight 16-byte loads per lane in flight (the next slab of both operands) while a slab is multiplied.
+constexpr int WG_P = 96;
+constexpr int WG_SKEW = 16;
+__device__ __forceinline__ int wg_lds_off(int r, int c) { return r * WG_P + c + (((r >> 3) & 1) ? WG_SKEW : 0); }
+typedef short wg_v4i16 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint2 wg_tr_read(const uint16_t* p) {      // EXEC must be all ones (every lane supplies an address)
+  const wg_v4i16 r = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) wg_v4i16*)p);
+  return __builtin_bit_cast(uint2, r);
+}
+// rows per WAVE for a product over T rows: workgroups of ~1 024 rows, the rows shared evenly by the splits (T = 3 584: 4 splits of 896)
+#ifndef OPS_WG_SPLIT_ROWS
+#define OPS_WG_SPLIT_ROWS 1024
+#endif
+__host__ __device__ inline int wg_rows_per_wave(int T) {
+  const int nsplit = (T + OPS_WG_SPLIT_ROWS - 1) / OPS_WG_SPLIT_ROWS;
+  const int per_wg = (T + nsplit - 1) / nsplit;
+  return (((per_wg + 3) / 4) + WG_SLAB - 1) / WG_SLAB * WG_SLAB;
+}
+__host__ __device__ inline int wg_row_splits(int T) { const int rw = wg_rows_per_wave(T); return (T + 4 * rw - 1) / (4 * rw); }
+
 __device__ __forceinline__ void wgrad_tn_body(int T, int N, int K, const uint16_t* __restrict__ dY, const uint16_t* __restrict__ X,
                                               float* __restrict__ dW, float* __restrict__ dbias, int bx, int by, int bz, int ldy = 0, int ldx = 0) {
   ldy = ldy > 0 ? ldy : N; ldx = ldx > 0 ? ldx : K;                    // row strides (elements) of dY / X: a strided row view needs no copy
-  // slabs TRANSPOSED in LDS, [column][t] with 72-byte rows: the loader scatters its 8 columns (two-byte writes), a fragment -- 8
-  // consecutive t of one column -- is then two 8-byte reads (row-major slabs needed 8 two-byte reads per fragment: 32 LDS reads per
-  // thread and slab against 8 + 16 writes here)
-  __shared__ __attribute__((aligned(16))) uint16_t s_a[64][WG_SLAB + 4], s_b[64][WG_SLAB + 4];
+  // [wave][operand][32 rows x pitch]: 48 KB; reused by the cross-wave reduction: [owner wave][source rank 0..2][tile 0..3][lane][4 floats]
+  __shared__ __attribute__((aligned(16))) uint16_t s_slab[4 * 2 * WG_SLAB * WG_P];
   __shared__ float s_cs[4][64];                                        // bias job: per-wave column sums
-  const int n0 = bx * 64, k0 = by * 64, t0 = bz * WG_ROWS, t1 = min(t0 + WG_ROWS, T);
+  static_assert(4 * 2 * WG_SLAB * WG_P * 2 == 4 * 3 * 4 * 64 * 16, "the reduction reuses the slab area exactly");
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int wn = (wave >> 1) * 32, wk = (wave & 1) * 32;               // this wave's 32 x 32 quarter of the tile
+  const int rw = wg_rows_per_wave(T);
+  const int n0 = bx * 64, k0 = by * 64, t0 = (bz * 4 + wave) * rw, t1 = min(t0 + rw, T);      // this WAVE's rows (possibly none)
+  uint16_t* const sa = s_slab + (size_t)wave * 2 * WG_SLAB * WG_P;
+  uint16_t* const sb = sa + WG_SLAB * WG_P;
   const bool va = (ldy & 7) == 0 && ((uintptr_t)dY & 15) == 0, vb = (ldx & 7) == 0 && ((uintptr_t)X & 15) == 0;
-  wg_f32x4 acc[2][2];
+  wg_f32x4 acc[4][4];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) acc[i][j] = wg_f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-  const int lr = tid >> 3, lc = (tid & 7) * 8;                         // slab loader: row lr (0..31), 8 columns from lc
+    for (int j = 0; j < 4; ++j) acc[i][j] = wg_f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+  const int lr = lane >> 3, lc = (lane & 7) * 8;                       // slab loader: rows lr + 8 i (i < 4), 8 columns from lc
+  int woff[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) woff[i] = wg_lds_off(lr + 8 * i, lc);
+  // fragment reads: lane (g, q, p) = (lane >> 4, (lane >> 2) & 3, lane & 3) supplies row 8 g + q (+ 4), columns 4 p .. 4 p + 3 of the
+  // 16-column block; lane i of the group receives column i, rows 8 g .. 8 g + 7 = the MFMA operand of lane (i, k group g)
+  const int fr_off = wg_lds_off(8 * (lane >> 4) + ((lane >> 2) & 3), 4 * (lane & 3));
   const bool bias_job = dbias != nullptr && by == 0;                   // the first column of tiles also sums dY's columns
   float csum[8];                                                       // this loader's 8 columns, summed over its rows
 #pragma unroll
   for (int j = 0; j < 8; ++j) csum[j] = 0.0f;
-  uint4 ra = wg_load8(dY, t1, N, ldy, t0 + lr, n0 + lc, va), rb = wg_load8(X, t1, K, ldx, t0 + lr, k0 + lc, vb);
-  for (int ts = t0; ts < t1; ts += WG_SLAB) {
-    __syncthreads();                                                   // the previous slab's fragments have been read
-    {
-      const uint16_t* pa = (const uint16_t*)&ra;
-      const uint16_t* pb = (const uint16_t*)&rb;
+  uint4 ra[4], rb[4];
+  auto load = [&](int ts) {                                            // (rows >= t1: zeros, no access)
 #pragma unroll
-      for (int j = 0; j < 8; ++j) { s_a[lc + j][lr] = pa[j]; s_b[lc + j][lr] = pb[j]; }
+    for (int i = 0; i < 4; ++i) {
+      ra[i] = wg_load8(dY, t1, N, ldy, ts + lr + 8 * i, n0 + lc, va);
+      rb[i] = wg_load8(X, t1, K, ldx, ts + lr + 8 * i, k0 + lc, vb);
     }
-    if (bias_job) {
-      const uint16_t* pv = (const uint16_t*)&ra;
+  };
+  auto park = [&]() {                                                  // registers -> this wave's slab (+ the bias job's tally)
 #pragma unroll
-      for (int j = 0; j < 8; ++j) csum[j] += sq_bf2f(pv[j]);
+    for (int i = 0; i < 4; ++i) {
+      *(uint4*)&sa[woff[i]] = ra[i];
+      *(uint4*)&sb[woff[i]] = rb[i];
+      if (bias_job) {
+        const uint16_t* pv = (const uint16_t*)&ra[i];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) csum[j] += sq_bf2f(pv[j]);
+      }
     }
-    __syncthreads();
-    if (ts + WG_SLAB < t1) {                                           // next slab's loads fly while this one multiplies
-      ra = wg_load8(dY, t1, N, ldy, ts + WG_SLAB + lr, n0 + lc, va);
-      rb = wg_load8(X, t1, K, ldx, ts + WG_SLAB + lr, k0 + lc, vb);
+  };
+  if (t0 < t1) {                                                       // wave-uniform
+    load(t0);
+    for (int ts = t0; ts < t1; ts += WG_SLAB) {
+      park();
+      if (ts + WG_SLAB < t1) load(ts + WG_SLAB);                       // the next slab's loads fly while this one multiplies
+      wg_bf16x8 fa[4], fb[4];
+#pragma unroll
+      for (int h = 0; h < 4; ++h) {
+        const uint16_t* qa = sa + fr_off + 16 * h;
+        const uint16_t* qb = sb + fr_off + 16 * h;
+        const uint2 a0 = wg_tr_read(qa), a1 = wg_tr_read(qa + 4 * WG_P), b0 = wg_tr_read(qb), b1 = wg_tr_read(qb + 4 * WG_P);
+        fa[h] = __builtin_bit_cast(wg_bf16x8, uint4{a0.x, a0.y, a1.x, a1.y});
+        fb[h] = __builtin_bit_cast(wg_bf16x8, uint4{b0.x, b0.y, b1.x, b1.y});
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
     }
-    // fragments: lane (o = lane & 15, tg = lane >> 4) holds rows 8 tg .. 8 tg + 7 of column o
-    wg_bf16x8 fa[2], fb[2];
+  }
+  // ---- the four partial tiles meet: wave w ends up with row block w (rows 16 w .. 16 w + 15 of the tile) summed over the waves ----
+  __syncthreads();                                                     // every wave is done with its slab region
+  float4* const red = (float4*)s_slab;                                 // [owner][source rank][tile j][lane]
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const uint2* qa = (const uint2*)&s_a[wn + 16 * h + (lane & 15)][8 * (lane >> 4)];
-      const uint2* qb = (const uint2*)&s_b[wk + 16 * h + (lane & 15)][8 * (lane >> 4)];
-      const uint2 a0 = qa[0], a1 = qa[1], b0 = qb[0], b1 = qb[1];
-      fa[h] = __builtin_bit_cast(wg_bf16x8, uint4{a0.x, a0.y, a1.x, a1.y});
-      fb[h] = __builtin_bit_cast(wg_bf16x8, uint4{b0.x, b0.y, b1.x, b1.y});
+  for (int i = 0; i < 4; ++i) {
+    if (i == wave) continue;                                           // (wave-uniform)
+    const int rank = wave < i ? wave : wave - 1;                       // this wave's place among the three sources of owner i
+#pragma unroll
+    for (int j = 0; j < 4; ++j) red[((i * 3 + rank) * 4 + j) * 64 + lane] = float4{acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+  }
+  __syncthreads();
+  wg_f32x4 mine[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    // (a dynamic first index into acc[][] would spill the accumulators: select by comparison)
+    wg_f32x4 v = wave == 0 ? acc[0][j] : wave == 1 ? acc[1][j] : wave == 2 ? acc[2][j] : acc[3][j];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {                                      // fixed order: the sum does not depend on timing
+      const float4 u = red[((wave * 3 + r) * 4 + j) * 64 + lane];
+      v[0] += u.x; v[1] += u.y; v[2] += u.z; v[3] += u.w;
     }
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    mine[j] = v;
   }
   // C layout: column (k) = lane & 15, rows (n) = 4 (lane >> 4) + e
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int j = 0; j < 4; ++j) {
+    const int k = k0 + 16 * j + (lane & 15);
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int k = k0 + wk + 16 * j + (lane & 15);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int n = n0 + wn + 16 * i + 4 * (lane >> 4) + e;
-        if (n < N && k < K) unsafeAtomicAdd(&dW[(long)n * K + k], acc[i][j][e]);
-      }
+    for (int e = 0; e < 4; ++e) {
+      const int n = n0 + 16 * wave + 4 * (lane >> 4) + e;
+#if defined(OPS_WG_ABLATE) && OPS_WG_ABLATE == 1      /* phase ablation builds (scripts/wgrad_ab.sh): plain stores instead of atomics */
+      if (n < N && k < K) dW[(long)n * K + k] = mine[j][e];
+#elif defined(OPS_WG_ABLATE) && OPS_WG_ABLATE == 2    /* no epilogue at all (one lane keeps the accumulators alive) */
+      if (mine[j][e] == 1.2345e30f) dW[0] = 1.0f;
+#else
+      if (n < N && k < K) unsafeAtomicAdd(&dW[(long)n * K + k], mine[j][e]);
+#endif
     }
+  }
   if (bias_job) {
     // the 8 loaders of a column group inside a wave (lanes with equal lane & 7), then the four waves through LDS
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       float v = csum[j];
-      v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);      // the wave's 8 rows (lr bits 0..2 of this wave)
+      v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
       if ((lane >> 3) == 0) s_cs[wave][lc + j] = v;
     }
     __syncthreads();
@@ -656,6 +732,14 @@ struct WgGroup {
   int nprob;
   int wg0[OPS_WGRAD_MAX_GROUP + 1];
   ops_wgrad_problem p[OPS_WGRAD_MAX_GROUP];
+  // XCD-aware placement (r04): a UNIT = the tiles of one product over one row split (they read the same rows of dY and X) or one
+  // column-sum job.  Workgroups are dealt round-robin over the 8 XCDs (blockIdx.x % 8 names the XCD's share, MI355X_MICROARCH.md:
+  // observed, for speed only), so unit u's workgroups get the ids  x + 8 q  of ONE residue x: the re-reads of its rows by its other
+  // tiles then come out of that XCD's L2 instead of the Infinity Cache.  nunit = 0: the flat order above (too many units).
+  int nunit, qmax;
+  unsigned char unit_prob[OPS_WG_MAX_UNITS], unit_split[OPS_WG_MAX_UNITS];
+  unsigned char xcnt[8], xunit[8][OPS_WG_MAX_UNITS_PER_XCD];
+  unsigned short xoff[8][OPS_WG_MAX_UNITS_PER_XCD + 1];
 };
 // K = 0 job: out[c] += sum over the T rows of the float32 matrix M [T, N]; one workgroup per 64 columns x CS_ROWS rows: every thread has
 // its 8 loads in flight at once (one workgroup per 64 columns walking all rows: 56 dependent trips, the launch's long pole at 41 us)
@@ -676,22 +760,35 @@ __device__ __forceinline__ void colsum_body(int T, int N, const float* __restric
 }
 
 __global__ __launch_bounds__(256) void wgrad_tn_group_kernel(const WgGroup g) {
-  int pi = 0;
-  while (pi + 1 < g.nprob && (int)blockIdx.x >= g.wg0[pi + 1]) ++pi;
+  int pi = 0, id, bz = -1;
+  if (g.nunit > 0) {                                                   // unit placement: blockIdx.x = x + 8 q
+    const int x = blockIdx.x & 7, q = blockIdx.x >> 3, cnt = g.xcnt[x];
+    int j = 0;
+    while (j < cnt && q >= (int)g.xoff[x][j + 1]) ++j;
+    if (j >= cnt) return;                                              // padding workgroup of a lighter XCD share (workgroup-uniform)
+    const int u = g.xunit[x][j];
+    pi = g.unit_prob[u];
+    bz = g.unit_split[u];
+    id = q - (int)g.xoff[x][j];                                        // tile within the unit
+  } else {
+    while (pi + 1 < g.nprob && (int)blockIdx.x >= g.wg0[pi + 1]) ++pi;
+    id = (int)blockIdx.x - g.wg0[pi];
+  }
   const ops_wgrad_problem pr = g.p[pi];
   if (pr.K == 0) {                                                     // workgroup-uniform
-    colsum_body(pr.T, pr.N, (const float*)pr.dY, pr.ldy > 0 ? pr.ldy : pr.N, pr.dW, (int)blockIdx.x - g.wg0[pi]);
+    colsum_body(pr.T, pr.N, (const float*)pr.dY, pr.ldy > 0 ? pr.ldy : pr.N, pr.dW, id);
     return;
   }
-  const int id = (int)blockIdx.x - g.wg0[pi], tn = (pr.N + 63) / 64, tk = (pr.K + 63) / 64;
-  wgrad_tn_body(pr.T, pr.N, pr.K, (const uint16_t*)pr.dY, (const uint16_t*)pr.X, pr.dW, pr.dbias, id % tn, (id / tn) % tk, id / (tn * tk), pr.ldy, pr.ldx);
+  const int tn = (pr.N + 63) / 64, tk = (pr.K + 63) / 64;
+  if (bz < 0) { bz = id / (tn * tk); id -= bz * tn * tk; }
+  wgrad_tn_body(pr.T, pr.N, pr.K, (const uint16_t*)pr.dY, (const uint16_t*)pr.X, pr.dW, pr.dbias, id % tn, id / tn, bz, pr.ldy, pr.ldx);
 }
 
 }  // namespace opsamd
 
 extern "C" int ops_linear_wgrad_accumulate(int T, int N, int K, const void* dY, const void* X, float* dW, float* dbias, void* stream) {
   if (T < 1 || N < 1 || K < 1 || !dY || !X || !dW) return OPS_AMD_ERR_INVALID_ARG;
-  const dim3 grid((unsigned)((N + 63) / 64), (unsigned)((K + 63) / 64), (unsigned)((T + opsamd::WG_ROWS - 1) / opsamd::WG_ROWS));
+  const dim3 grid((unsigned)((N + 63) / 64), (unsigned)((K + 63) / 64), (unsigned)opsamd::wg_row_splits(T));
   hipLaunchKernelGGL(opsamd::wgrad_tn_kernel, grid, dim3(256), 0, (hipStream_t)stream, T, N, K, (const uint16_t*)dY, (const uint16_t*)X, dW, dbias);
   return sq_check("wgrad_tn_kernel");
 }
@@ -713,10 +810,48 @@ extern "C" int ops_linear_wgrad_accumulate_group(int nprob, const ops_wgrad_prob
     if (p.T < 1 || p.N < 1 || p.K < 1 || !p.dY || !p.X || !p.dW || (p.ldy && p.ldy < p.N) || (p.ldx && p.ldx < p.K)) return OPS_AMD_ERR_INVALID_ARG;
     g.p[i] = p;
     g.wg0[i] = tot;
-    tot += ((p.N + 63) / 64) * ((p.K + 63) / 64) * ((p.T + opsamd::WG_ROWS - 1) / opsamd::WG_ROWS);
+    tot += ((p.N + 63) / 64) * ((p.K + 63) / 64) * opsamd::wg_row_splits(p.T);
   }
   g.wg0[nprob] = tot;
-  hipLaunchKernelGGL(opsamd::wgrad_tn_group_kernel, dim3((unsigned)tot), dim3(256), 0, (hipStream_t)stream, g);
+  // units, heaviest first onto the lightest of the eight shares
+  g.nunit = 0; g.qmax = 0;
+  static const bool flat_order = getenv("OPS_AMD_WGRAD_FLAT_ORDER") != nullptr;      // A/B switch
+  int nu = 0, wgs[OPS_WG_MAX_UNITS];
+  bool fits = !flat_order;
+  for (int i = 0; i < nprob && fits; ++i) {
+    const ops_wgrad_problem& p = problems[i];
+    const int splits = p.K == 0 ? 1 : opsamd::wg_row_splits(p.T);
+    const int per = p.K == 0 ? g.wg0[i + 1] - g.wg0[i] : ((p.N + 63) / 64) * ((p.K + 63) / 64);
+    for (int z = 0; z < splits; ++z) {
+      if (nu >= OPS_WG_MAX_UNITS || z > 255 || per > 60000) { fits = false; break; }
+      g.unit_prob[nu] = (unsigned char)i; g.unit_split[nu] = (unsigned char)z; wgs[nu] = per; ++nu;
+    }
+  }
+  if (fits) {
+    int order[OPS_WG_MAX_UNITS], load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int u = 0; u < nu; ++u) order[u] = u;
+    for (int a = 1; a < nu; ++a) {                                     // insertion sort, descending workgroup count (stable)
+      const int u = order[a]; int b = a;
+      while (b > 0 && wgs[order[b - 1]] < wgs[u]) { order[b] = order[b - 1]; --b; }
+      order[b] = u;
+    }
+    for (int x = 0; x < 8; ++x) { g.xcnt[x] = 0; g.xoff[x][0] = 0; }
+    for (int a = 0; a < nu && fits; ++a) {
+      const int u = order[a];
+      int x = 0;
+      for (int y = 1; y < 8; ++y) if (load[y] < load[x]) x = y;
+      if (g.xcnt[x] >= OPS_WG_MAX_UNITS_PER_XCD || load[x] + wgs[u] > 65535) { fits = false; break; }
+      g.xunit[x][g.xcnt[x]] = (unsigned char)u;
+      load[x] += wgs[u];
+      g.xoff[x][++g.xcnt[x]] = (unsigned short)load[x];
+    }
+    if (fits) {
+      for (int x = 0; x < 8; ++x) g.qmax = load[x] > g.qmax ? load[x] : g.qmax;
+      g.nunit = nu;
+    }
+  }
+  const unsigned grid = g.nunit > 0 ? 8u * (unsigned)g.qmax : (unsigned)tot;
+  hipLaunchKernelGGL(opsamd::wgrad_tn_group_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, g);
   return sq_check("wgrad_tn_group_kernel");
 }
 
