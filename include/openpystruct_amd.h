@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define OPS_AMD_ABI_VERSION 9
+#define OPS_AMD_ABI_VERSION 10
 
 /* return codes of the launch functions (per-beam results are in `status`) */
 #define OPS_AMD_OK 0
@@ -548,6 +548,12 @@ typedef struct ops_tfd_head_args {
   const void* W1; const void* b1; const float* gamma; const float* beta; float eps; const void* W2; const void* b2;
   float p_drop; unsigned long long seed; const unsigned long long* counter; unsigned long long* used_call;
   void* a16; float* mean; float* rstd; void* h; void* out;
+  /* r04 (ABI 10): the training loss ON the output tile (TrainableL1L2Loss, TFD:581-633: what ops_surrogate_loss_grad_sum_f32 computes for
+   * nI = C -- two launches of the step less).  targets != NULL: grad [B, C] bf16 = d loss / d out, loss_part [5 ceil(B / 16)] doubles =
+   * this launch's per-workgroup partial sums (|d|, d^2, box penalty, 0, 0); the NEXT launch of the step (ops_tfd_head_bwd) adds them
+   * up.  alpha: device scalar (clamped to [1e-6, 1] as the loss does); min_constraint / max_constraint: device scalars or NULL. */
+  const float* targets; void* grad; double* loss_part; const float* alpha; const float* min_constraint; const float* max_constraint;
+  float box_weight;
 } ops_tfd_head_args;
 int ops_tfd_head_fwd(const ops_tfd_head_args* args, void* stream);
 typedef struct ops_tfd_head_bwd_args {
@@ -556,6 +562,9 @@ typedef struct ops_tfd_head_bwd_args {
   float p_drop;
   const void* a16; const float* mean; const float* rstd; const void* h;
   void* d_a; void* dcls_rows; float* dgamma; float* dbeta;
+  /* r04 (ABI 10): loss_part != NULL: workgroup 0 finishes the loss of the forward launch: loss[0] = the value (+ (alpha0 - alpha)^2 unless
+   * alpha0 is NaN), loss_sum[0] += it (may be NULL). */
+  const double* loss_part; const float* alpha; float alpha0; float box_weight; float* loss; float* loss_sum;
 } ops_tfd_head_bwd_args;
 int ops_tfd_head_bwd(const ops_tfd_head_bwd_args* args, void* stream);
 

@@ -9,7 +9,7 @@ import ctypes
 import os
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-ABI_VERSION = 9      # include/openpystruct_amd.h OPS_AMD_ABI_VERSION
+ABI_VERSION = 10     # include/openpystruct_amd.h OPS_AMD_ABI_VERSION
 # OPS_AMD_LIB lets A/B kernel experiments point at another build of the same C ABI
 LIB_PATH = os.environ.get("OPS_AMD_LIB") or os.path.join(_PKG, "lib", "libopenpystruct_amd.so")
 
@@ -157,14 +157,17 @@ class TfdHeadArgs(ctypes.Structure):
     _vp, _i, _f, _u = ctypes.c_void_p, ctypes.c_int32, ctypes.c_float, ctypes.c_ulonglong
     _fields_ = [("B", _i), ("S", _i), ("d", _i), ("hid", _i), ("C", _i), ("y16", _vp), ("W1", _vp), ("b1", _vp), ("gamma", _vp), ("beta", _vp),
                 ("eps", _f), ("W2", _vp), ("b2", _vp), ("p_drop", _f), ("seed", _u), ("counter", _vp), ("used_call", _vp),
-                ("a16", _vp), ("mean", _vp), ("rstd", _vp), ("h", _vp), ("out", _vp)]
+                ("a16", _vp), ("mean", _vp), ("rstd", _vp), ("h", _vp), ("out", _vp),
+                ("targets", _vp), ("grad", _vp), ("loss_part", _vp), ("alpha", _vp), ("min_constraint", _vp), ("max_constraint", _vp),
+                ("box_weight", _f)]
 
 
 class TfdHeadBwdArgs(ctypes.Structure):
     """Mirror of `ops_tfd_head_bwd_args`."""
     _vp, _i, _f = ctypes.c_void_p, ctypes.c_int32, ctypes.c_float
     _fields_ = [("B", _i), ("S", _i), ("d", _i), ("hid", _i), ("C", _i), ("g", _vp), ("Wt2", _vp), ("Wt1", _vp), ("gamma", _vp), ("p_drop", _f),
-                ("a16", _vp), ("mean", _vp), ("rstd", _vp), ("h", _vp), ("d_a", _vp), ("dcls_rows", _vp), ("dgamma", _vp), ("dbeta", _vp)]
+                ("a16", _vp), ("mean", _vp), ("rstd", _vp), ("h", _vp), ("d_a", _vp), ("dcls_rows", _vp), ("dgamma", _vp), ("dbeta", _vp),
+                ("loss_part", _vp), ("alpha", _vp), ("alpha0", _f), ("box_weight", _f), ("loss", _vp), ("loss_sum", _vp)]
 
 
 class TfdFrontArgs(ctypes.Structure):

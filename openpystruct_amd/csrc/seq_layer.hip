@@ -897,6 +897,8 @@ __global__ __launch_bounds__(64 * SL_NW) void tfd_head_fwd_kernel(const ops_tfd_
   __shared__ __attribute__((aligned(16))) uint16_t s_a16[16 * HS];    // fc1 output as stored
   __shared__ __attribute__((aligned(16))) uint16_t s_h[16 * HS];      // dropout(ReLU(LayerNorm)): operand of fc2
   __shared__ __attribute__((aligned(16))) float s_f32[16 * FS2];      // fc1 output (bf16 values as float): LayerNorm input
+  __shared__ __attribute__((aligned(16))) uint16_t s_gr[16 * XS];     // (loss on the tile) d loss / d out rows
+  __shared__ float s_ls[SL_NW][3];                                    // (loss on the tile) per-wave partial sums
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 15, g = lane >> 4;
   const int S = a.S, d = a.d, hid = a.hid, C = a.C;
   const int b0 = blockIdx.x * 16, nrows = (a.B - b0 < 16) ? a.B - b0 : 16;
@@ -914,6 +916,12 @@ __global__ __launch_bounds__(64 * SL_NW) void tfd_head_fwd_kernel(const ops_tfd_
   }
   const int oc = 16 * wave + c;
   const float b2v = sl_bf2f(((const uint16_t*)a.b2)[oc < C ? oc : C - 1]);
+  const bool with_loss = a.targets != nullptr;                         // (kernel-uniform)
+  float tgv[4] = {0.0f, 0.0f, 0.0f, 0.0f};                             // this lane's four targets (rows 4 g + i, column oc): requested up front
+  if (with_loss) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { const int r = 4 * g + i; tgv[i] = a.targets[(long)(b0 + (r < nrows ? r : 0)) * C + (oc < C ? oc : 0)]; }
+  }
   WTile<4> w1[2];
   WTile<8> w2;
 #pragma unroll
@@ -986,15 +994,54 @@ __global__ __launch_bounds__(64 * SL_NW) void tfd_head_fwd_kernel(const ops_tfd_
     sl_store_rows<2>(la->a16, s_a16, HS, hid, b0, nrows, tid);
     sl_store_rows<2>(la->h, s_h, HS, hid, b0, nrows, tid); }
 
-  // ---- out = h W_2^T + b_2 ----
+  // ---- out = h W_2^T + b_2; with targets: the loss on the tile (csrc/fused_loss.hip's arithmetic for nI = C, operation for operation) ----
+  float ls0 = 0.0f, ls1 = 0.0f, ls2 = 0.0f;
   if (wave < NT2) {
     const sl_f32x4 acc = sl_mma_tile<8>(w2, s_h, HS, c, g);
+    const slh_args_ptr la = slh_late_args();
+    float alpha = 0.0f, lo = 0.0f, hi = 0.0f, inv_n = 0.0f, bw = 0.0f;
+    bool has_min = false, has_max = false;
+    if (with_loss) {
+      alpha = fminf(fmaxf(SL_GLOBAL(float, la->alpha)[0], 1e-6f), 1.0f);
+      has_min = la->min_constraint != nullptr; has_max = la->max_constraint != nullptr;
+      lo = has_min ? SL_GLOBAL(float, la->min_constraint)[0] : 0.0f;
+      hi = has_max ? SL_GLOBAL(float, la->max_constraint)[0] : 0.0f;
+      inv_n = 1.0f / ((float)la->B * (float)C);
+      bw = la->box_weight;
+    }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) s_x[(4 * g + i) * XS + oc] = sl_f2bf(acc[i] + b2v);     // (the [CLS] rows as an operand are dead)
+    for (int i = 0; i < 4; ++i) {
+      const int r = 4 * g + i;
+      const uint16_t pb = sl_f2bf(acc[i] + b2v);
+      s_x[r * XS + oc] = pb;                                           // (the [CLS] rows as an operand are dead)
+      if (with_loss) {
+        const bool live = r < nrows && oc < C;
+        const float p = sl_bf2f(pb), dd = p - tgv[i], sg = dd > 0.0f ? 1.0f : (dd < 0.0f ? -1.0f : 0.0f);
+        float gv = (alpha * sg + (1.0f - alpha) * 2.0f * dd) * inv_n;
+        float pen = 0.0f;
+        if (has_min && p < lo) { pen += lo - p; gv -= bw; }
+        if (has_max && p > hi) { pen += p - hi; gv += bw; }
+        if (live) { ls0 += fabsf(dd); ls1 = __builtin_fmaf(dd, dd, ls1); ls2 += pen; }
+        s_gr[r * XS + oc] = live ? sl_f2bf(gv) : (uint16_t)0;
+      }
+    }
+  }
+  if (with_loss) {
+    for (int sft = 32; sft >= 1; sft >>= 1) { ls0 += __shfl_xor(ls0, sft, 64); ls1 += __shfl_xor(ls1, sft, 64); ls2 += __shfl_xor(ls2, sft, 64); }
+    if (lane == 0) { s_ls[wave][0] = ls0; s_ls[wave][1] = ls1; s_ls[wave][2] = ls2; }
   }
   sl_lds_barrier();
   { const slh_args_ptr la = slh_late_args();
     sl_store_rows_ld<2, 8>(la->out, C, s_x, XS, C, b0, nrows, tid);
+    if (with_loss) {
+      sl_store_rows_ld<2, 8>(la->grad, C, s_gr, XS, C, b0, nrows, tid);
+      if (tid < 5) {                                                   // this workgroup's partial sums; the next launch adds the workgroups up
+        double t = 0.0;
+        if (tid < 3)
+          for (int wv = 0; wv < SL_NW; ++wv) t += (double)s_ls[wv][tid];
+        SL_GLOBAL(double, la->loss_part)[blockIdx.x * 5 + tid] = t;
+      }
+    }
     if (blockIdx.x == 0 && tid == 0 && la->used_call) *SL_GLOBAL(unsigned long long, la->used_call) = call; }
 }
 
@@ -1017,6 +1064,22 @@ __global__ __launch_bounds__(64 * SL_NW) void tfd_head_bwd_kernel(const ops_tfd_
   const int S = a.S, d = a.d, hid = a.hid, C = a.C;
   const int b0 = blockIdx.x * 16, nrows = (a.B - b0 < 16) ? a.B - b0 : 16;
   const int NT1 = (hid + 15) / 16, NTD = (d + 15) / 16, KSC = (C + 31) / 32, KSH = (hid + 31) / 32;
+  // ---- the forward launch's loss (r04): its per-workgroup partial sums, added up by the last wave of workgroup 0 (fused_loss_finish_kernel's arithmetic) ----
+  if (a.loss_part != nullptr && blockIdx.x == 0 && wave == SL_NW - 1) {                 // wave-uniform
+    const int G = (a.B + 15) / 16;
+    double t[3] = {0.0, 0.0, 0.0};
+    for (int q = lane; q < G; q += 64)
+      for (int k = 0; k < 3; ++k) t[k] += a.loss_part[q * 5 + k];
+    for (int k = 0; k < 3; ++k)
+      for (int sft = 32; sft >= 1; sft >>= 1) t[k] += __shfl_xor(t[k], sft, 64);
+    if (lane == 0) {
+      const double alpha = fmin(fmax((double)a.alpha[0], 1e-6), 1.0), nIe = (double)a.B * (double)C;
+      const double v = alpha * t[0] / nIe + (1.0 - alpha) * t[1] / nIe + (double)a.box_weight * t[2];
+      const double da = a.alpha0 == a.alpha0 ? (double)a.alpha0 - (double)a.alpha[0] : 0.0;       // NaN alpha0: no such term
+      a.loss[0] = (float)(v + da * da);
+      if (a.loss_sum) a.loss_sum[0] += a.loss[0];
+    }
+  }
   // ---- requests ----
   const int gpr = C / 4;                                   // 8-byte pieces per gradient row
   const float inv_g = 1.0f / (float)gpr;
@@ -1386,6 +1449,7 @@ extern "C" int ops_tfd_head_fwd(const ops_tfd_head_args* a, void* stream) {
     return OPS_AMD_ERR_INVALID_ARG;
   if ((((uintptr_t)a->y16 | (uintptr_t)a->W1 | (uintptr_t)a->W2 | (uintptr_t)a->a16 | (uintptr_t)a->h) & 15) != 0 || ((uintptr_t)a->out & 7) != 0)
     return OPS_AMD_ERR_UNSUPPORTED;
+  if (a->targets && (!a->grad || !a->loss_part || !a->alpha || ((uintptr_t)a->grad & 7) != 0)) return OPS_AMD_ERR_INVALID_ARG;
   hipLaunchKernelGGL(opsamd::tfd_head_fwd_kernel, dim3((unsigned)((a->B + 15) / 16)), dim3(64 * opsamd::SL_NW), 0, (hipStream_t)stream, *a);
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) { opsamd::set_last_error(hipGetErrorString(e)); return OPS_AMD_ERR_LAUNCH; }
@@ -1399,6 +1463,7 @@ extern "C" int ops_tfd_head_bwd(const ops_tfd_head_bwd_args* a, void* stream) {
     return OPS_AMD_ERR_INVALID_ARG;
   if ((((uintptr_t)a->Wt2 | (uintptr_t)a->Wt1 | (uintptr_t)a->a16 | (uintptr_t)a->h | (uintptr_t)a->d_a | (uintptr_t)a->dcls_rows) & 15) != 0 || ((uintptr_t)a->g & 7) != 0)
     return OPS_AMD_ERR_UNSUPPORTED;
+  if (a->loss_part && (!a->alpha || !a->loss)) return OPS_AMD_ERR_INVALID_ARG;
   hipLaunchKernelGGL(opsamd::tfd_head_bwd_kernel, dim3((unsigned)((a->B + 15) / 16)), dim3(64 * opsamd::SL_NW), 0, (hipStream_t)stream, *a);
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) { opsamd::set_last_error(hipGetErrorString(e)); return OPS_AMD_ERR_LAUNCH; }

@@ -36,6 +36,7 @@ EVAL_FAST = os.environ.get("OPS_AMD_TFD_EVAL_FAST", "1") == "1"       # A/B swit
 FRONT = os.environ.get("OPS_AMD_TFD_FRONT", "1") == "1"               # A/B switch: 0 = the diffusion front end as five + three launches
 LN_PARTIALS = os.environ.get("OPS_AMD_TFD_LN_PARTIALS", "1") == "1"   # A/B switch: 0 = LayerNorm gamma / beta gradients by float atomics in the layer launch
 HEAD = os.environ.get("OPS_AMD_TFD_HEAD", "1") == "1"                 # A/B switch: 0 = the head as four launches per direction
+HEAD_LOSS = os.environ.get("OPS_AMD_TFD_HEAD_LOSS", "1") == "1"       # A/B switch: 0 = the training loss as launches of its own behind the head
 LAYER_BWD = os.environ.get("OPS_AMD_TFD_LAYER_BWD", "1") == "1"       # A/B switch: 0 = eight launches per layer backward instead of one
 
 
@@ -615,7 +616,10 @@ class HeadFn(torch.autograd.Function):
     bias gradients where the shadow products send them, LayerNorm gradients straight into their `.grad`."""
 
     @staticmethod
-    def forward(ctx, x16, model, B, S, st: _State):
+    def forward(ctx, x16, model, B, S, st: _State, loss_spec=None):
+        """`loss_spec` = (targets [B, C] float32, TrainableL1L2Loss, alpha0 or None, running-sum tensor or None): the training loss is
+        computed ON the output tile by the same launch (value finished by the backward launch) and returned beside the predictions;
+        the backward pass then starts from the launch's own d loss / d out (the caller differentiates the loss with weight one)."""
         lib = _cabi.load()
         r1, r2 = model.fc1._ops_prod.rec, model.fc2._ops_prod.rec
         tiles = model.transformer_encoder._ops_extra_tiles
@@ -632,34 +636,79 @@ class HeadFn(torch.autograd.Function):
                               W2=tiles["fc2"][0].data_ptr(), b2=r2.b_sh.data_ptr(), p_drop=p, seed=st.seed + 7919 * 103,
                               counter=st.counter.data_ptr(), used_call=used.data_ptr(), a16=a16.data_ptr(), mean=mean.data_ptr(),
                               rstd=rstd.data_ptr(), h=h.data_ptr(), out=out.data_ptr())
+        ctx.loss = None
+        if loss_spec is not None:
+            targets, crit, alpha0, acc = loss_spec
+            sc = lambda v: None if v is None else (v if torch.is_tensor(v) else torch.tensor(float(v))).to(device=dev, dtype=torch.float32).reshape(())   # noqa: E731
+            grad, part = torch.empty((B, C), **bf), torch.empty(5 * ((B + 15) // 16), dtype=torch.float64, device=dev)
+            loss = torch.empty((), **f32)
+            alpha, minc, maxc = crit.alpha.detach(), sc(crit.min_constraint), sc(crit.max_constraint)
+            a.targets, a.grad, a.loss_part, a.alpha = targets.data_ptr(), grad.data_ptr(), part.data_ptr(), alpha.data_ptr()
+            a.min_constraint = minc.data_ptr() if minc is not None else None
+            a.max_constraint = maxc.data_ptr() if maxc is not None else None
+            a.box_weight = float(crit.penalty_weight)
+            ctx.loss = (grad, part, loss, alpha, float("nan") if alpha0 is None else float(alpha0), float(crit.penalty_weight), acc, targets, minc, maxc)
         with torch.cuda.device(dev):
             _check(lib.ops_tfd_head_fwd(ctypes.byref(a), _stream(dev)), "ops_tfd_head_fwd")
         ctx.save_for_backward(x16, a16, mean, rstd, h)
         ctx.cfg = (model, B, S, d, hid, C, p, st, (r1, r2))
+        if ctx.loss is not None:
+            ctx.mark_non_differentiable(out)
+            return out, ctx.loss[2]
         return out
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, g, g_loss=None):
         from . import train
         lib = _cabi.load()
         x16, a16, mean, rstd, h = ctx.saved_tensors
         model, B, S, d, hid, C, p, st, (r1, r2) = ctx.cfg
         tiles = model.transformer_encoder._ops_extra_tiles
         dev = x16.device
-        g = g.contiguous()
-        if g.dtype != torch.bfloat16:
-            g = g.to(torch.bfloat16)
+        if ctx.loss is not None:
+            g = ctx.loss[0]                     # the forward launch's own d loss / d out (the loss enters the total with weight one)
+        else:
+            g = g.contiguous()
+            if g.dtype != torch.bfloat16:
+                g = g.to(torch.bfloat16)
         d_a = torch.empty((B, hid), dtype=torch.bfloat16, device=dev)
         full = st.zeros16((B * S, d))
         a = _cabi.TfdHeadBwdArgs(B=B, S=S, d=d, hid=hid, C=C, g=g.data_ptr(), Wt2=tiles["fc2"][1].data_ptr(), Wt1=tiles["fc1"][1].data_ptr(),
                                  gamma=model.norm1.weight.data_ptr(), p_drop=p, a16=a16.data_ptr(), mean=mean.data_ptr(), rstd=rstd.data_ptr(),
                                  h=h.data_ptr(), d_a=d_a.data_ptr(), dcls_rows=full.data_ptr(), dgamma=model.norm1.weight.grad.data_ptr(),
                                  dbeta=model.norm1.bias.grad.data_ptr())
+        if ctx.loss is not None:                # workgroup 0 of this launch adds the forward launch's partial sums up
+            _, part, loss, alpha, alpha0, bw, acc = ctx.loss[:7]
+            a.loss_part, a.alpha, a.alpha0, a.box_weight, a.loss = part.data_ptr(), alpha.data_ptr(), alpha0, bw, loss.data_ptr()
+            a.loss_sum = acc.data_ptr() if acc is not None else None
         with torch.cuda.device(dev):
             _check(lib.ops_tfd_head_bwd(ctypes.byref(a), _stream(dev)), "ops_tfd_head_bwd")
         train.shadow_param_grads(r2, g, h)
         train.shadow_param_grads(r1, d_a, x16.view(B, S, d)[:, 0, :])       # (row-strided operand: no copy of the [CLS] rows)
-        return full, None, None, None, None
+        return full, None, None, None, None, None
+
+
+_PENDING_LOSS = None      # (targets, criterion, alpha0, running sum): armed by the training step for ITS next forward pass
+_TAKEN_LOSS = None
+
+
+def arm_head_loss(targets: torch.Tensor, crit: nn.Module, alpha0, acc) -> bool:
+    """The training step's next forward pass of a patched model may compute its TrainableL1L2Loss on the head's output tile (two launches
+    of the step less); `take_head_loss()` afterwards tells whether it did.  False: not this criterion / these targets."""
+    global _PENDING_LOSS, _TAKEN_LOSS
+    from .surrogates import TrainableL1L2Loss
+    _TAKEN_LOSS = None
+    ok = (HEAD_LOSS and type(crit) is TrainableL1L2Loss and torch.is_tensor(targets) and targets.is_cuda and targets.dtype == torch.float32
+          and targets.dim() == 2 and targets.is_contiguous())
+    _PENDING_LOSS = (targets, crit, alpha0, acc) if ok else None
+    return ok
+
+
+def take_head_loss():
+    """The loss the last forward pass computed on the head's tile (an autograd scalar), or None."""
+    global _PENDING_LOSS, _TAKEN_LOSS
+    loss, _TAKEN_LOSS, _PENDING_LOSS = _TAKEN_LOSS, None, None
+    return loss
 
 
 def _head_fused_ok(model: nn.Module, st: _State, d: int) -> bool:
@@ -719,7 +768,13 @@ def _model_tail(model: nn.Module, z: torch.Tensor, z16: torch.Tensor, st: _State
     z = model.transformer_encoder(z)
     if st.last16 is not None and model.transformer_encoder.norm is None and _head_fused_ok(model, st, d):
         last16, st.last16 = st.last16, None
-        return HeadFn.apply(last16, model, B, Nc + 1, st)                         # the whole head: one launch
+        global _PENDING_LOSS, _TAKEN_LOSS
+        spec, _PENDING_LOSS = _PENDING_LOSS, None
+        if (spec is not None and st.train_mode and torch.is_grad_enabled() and tuple(spec[0].shape) == (B, model.fc2.out_features)
+                and spec[0].device == last16.device):
+            out, _TAKEN_LOSS = HeadFn.apply(last16, model, B, Nc + 1, st, spec)   # ... and the loss on its output tile
+            return out
+        return HeadFn.apply(last16, model, B, Nc + 1, st, None)                      # the whole head: one launch
     if st.last16 is not None and model.transformer_encoder.norm is None:
         from . import train
         train.set_next_input_grad_dest(st.zeros16((B * (Nc + 1), d)).view(B, Nc + 1, d)[:, 0, :])   # fc1's input gradient lands in the [CLS] rows

@@ -683,8 +683,18 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
         if not (on_gpu and opt.zero_grads):
             flat.zero_()                                                 # optimizer.zero_grad() (GPU: the update launch zeroes `flat` behind itself)
         with torch.autocast(device_type=device.type, dtype=autocast_dtype, enabled=use_ac):
-            preds = net(Xn)
-            if on_gpu and _FUSED_LOSS:       # value + d/d preds in one HIP pass instead of ~80 framework kernel nodes
+            head_loss = None
+            if fast_encoder is not None and _FUSED_LOSS and physics is None:
+                # Transformer-Diffusion fast path: the loss on the head's output tile, finished by the head's backward launch
+                from . import tfd_fused
+                tfd_fused.arm_head_loss(Yb, crit, cfg.initial_alpha if alpha_term else None, loss_acc)
+                preds = net(Xn)
+                head_loss = tfd_fused.take_head_loss()
+            else:
+                preds = net(Xn)
+            if head_loss is not None:
+                loss = head_loss
+            elif on_gpu and _FUSED_LOSS:       # value + d/d preds in one HIP pass instead of ~80 framework kernel nodes
                 loss = fused_loss(crit, preds, Yb, alpha0=cfg.initial_alpha if alpha_term else None, unit_grad=True, acc=loss_acc)
             else:
                 loss = crit(preds.float(), Yb)

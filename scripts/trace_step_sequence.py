@@ -3,7 +3,7 @@
 import csv,sys,collections
 rows=list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r:int(r['Start_Timestamp']))
-idx=[i for i,r in enumerate(rows) if 'FusedOptimizer' in r['Kernel_Name'] or 'flat_adam_kernel' in r['Kernel_Name']]
+idx=[i for i,r in enumerate(rows) if 'FusedOptimizer' in r['Kernel_Name'] or 'flat_adam_kernel' in r['Kernel_Name'] or 'flat_adam_tiles_kernel' in r['Kernel_Name']]
 a,b=idx[-40],idx[-39]
 t0=int(rows[a]['Start_Timestamp'])
 import re

@@ -431,6 +431,62 @@ def test_one_launch_layer_forward_equals_the_eight_launch_form(monkeypatch, B, p
             assert _rel(g1[n], g0[n]) < 2e-2 or float(g0[n].norm()) < 1e-6, (fwd_bwd, n, _rel(g1[n], g0[n]))
 
 
+@pytest.mark.parametrize("B,p,alpha0", [(512, 0.1, 0.5), (288, 0.0, None), (37, 0.3, 0.5)])
+def test_loss_on_the_head_tile_equals_the_loss_launch(monkeypatch, B, p, alpha0):
+    """r04: the training loss of the fast path computed by the head's forward launch on its output tile and finished by the head's backward
+    launch (tfd_fused.arm_head_loss) against the same step with the loss as its own two launches behind the head (surrogates.fused_loss):
+    the same arithmetic on the same bf16 predictions -- value to float32 round-off (per-workgroup partial sums in another order), every
+    parameter gradient bit for bit, the running sum advanced."""
+    from openpystruct_amd import tfd_fused as TF, train
+    from openpystruct_amd.surrogates import ModelOnePassTransformerWithDiffusion, TrainableL1L2Loss, fused_loss
+
+    def run(on_tile):
+        torch.manual_seed(5)
+        model = ModelOnePassTransformerWithDiffusion(6, 120, 100, dropout=p).to(DEV)
+        crit = TrainableL1L2Loss(0.5, torch.tensor(-1.0, device=DEV), torch.tensor(0.4, device=DEV), 0.5).to(DEV)
+        params = list(model.parameters())
+        flat = torch.zeros(sum(q.numel() for q in params), device=DEV)
+        off = 0
+        for q in params:
+            q.grad = flat[off:off + q.numel()].view_as(q)
+            off += q.numel()
+        opt = train.FlatClipAdam(params, flat, 1e-3)
+        stash, dst, patched = train.enable_shadow_linears(model, opt, params, flat)
+        assert TF.patch_model(model, seed=3, direct_param_grads=True)
+        model.train()
+        g = torch.Generator().manual_seed(6)
+        x = torch.randn(B, 6, 120, generator=g).to(DEV)
+        y = torch.randn(B, 100, generator=g).to(DEV)
+        acc = torch.full((), 2.0, device=DEV)
+        train._WGRAD_QUEUE = []
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            if on_tile:
+                assert TF.arm_head_loss(y, crit, alpha0, acc)
+                out = model(x)
+                loss = TF.take_head_loss()
+                assert loss is not None and TF.take_head_loss() is None
+            else:
+                out = model(x)
+                loss = fused_loss(crit, out, y, alpha0=alpha0, unit_grad=True, acc=acc)
+        loss.backward(gradient=torch.ones((), device=DEV))
+        train.flush_wgrad_queue(torch.device(DEV))
+        train._WGRAD_QUEUE = None
+        live = [(dd, ss) for dd, ss in zip(dst, stash) if ss is not None]
+        if live:
+            torch._foreach_copy_([a for a, _ in live], [b for _, b in live])
+        torch.cuda.synchronize()
+        res = float(loss), float(acc), out.float().clone(), flat.clone()
+        train.disable_shadow_linears(patched)
+        TF.unpatch_model(model)
+        return res
+
+    l0, a0, o0, g0 = run(False)
+    l1, a1, o1, g1 = run(True)
+    assert torch.equal(o0, o1)
+    assert abs(l1 - l0) <= 2e-6 * abs(l0) and abs((a1 - 2.0) - l1) <= 1e-6 * abs(l1) and abs(a1 - a0) <= 4e-6 * abs(a0)
+    assert torch.equal(g0, g1) and float(g0.abs().max()) > 0
+
+
 def test_four_layer_encoder_keeps_training_on_fresh_weights(monkeypatch):
     """num_transformer_layers = 4: one optimiser launch refreshes 16 tiled weight copies, i.e. three layers + the head's four.  The
     fourth layer must then NOT take the one-launch form (r03: it kept the tiles of patch_encoder's first enable_layer_tiles call, which
