@@ -654,6 +654,7 @@ class HeadFn(torch.autograd.Function):
         ctx.cfg = (model, B, S, d, hid, C, p, st, (r1, r2))
         if ctx.loss is not None:
             ctx.mark_non_differentiable(out)
+            ctx.set_materialize_grads(False)        # (no zero tensor -- a fill node per step -- for the predictions' absent gradient)
             return out, ctx.loss[2]
         return out
 

@@ -301,7 +301,7 @@ class _ShadowLinearFn(torch.autograd.Function):
         g2 = gy.reshape(-1, gy.shape[-1])
         if g2.dtype != torch.bfloat16:
             g2 = g2.to(torch.bfloat16)
-        if ctx.w_grad is not None and x2.shape[0] >= _SPLIT_WGRAD_ROWS:
+        if ctx.w_grad is not None and x2.shape[0] >= _SPLIT_WGRAD_ROWS and _SPLIT_WGRAD_ROWS > 0:
             # many rows, small output: the library walks all rows inside a handful of tiles (25 us for 3584 x 360 x 120) and the bias
             # gradient is another reduction pass (11 us); the split-row kernel of csrc/seq_block.hip adds partial tiles -- and the
             # column sums of the slabs it reads anyway -- into the float32 gradients itself
@@ -382,7 +382,10 @@ def shadow_param_grads(rec: ShadowRec, g2: torch.Tensor, x2: torch.Tensor) -> No
             rec.stash[rec.ib] = g2.sum(0)
 
 
-_SPLIT_WGRAD_ROWS = int(os.environ.get("OPS_AMD_SPLIT_WGRAD_ROWS", "512"))     # products over at least this many rows (0 rows: never)
+# products over at least this many rows take the split-row kernel (0: never).  r04: 16 (was 512) -- the kernel now keeps a whole tile per wave and
+# reduces inside the workgroup, so a 10-sample tail batch (70 / 10 rows: twelve library GEMMs of ~16 us + twelve column sums per epoch)
+# is one grouped launch too; only products over fewer rows than one MFMA tile stay with the library
+_SPLIT_WGRAD_ROWS = int(os.environ.get("OPS_AMD_SPLIT_WGRAD_ROWS", "16"))
 _WGRAD_QUEUE = None          # a list while a training step collects its split-row weight gradients for ONE grouped launch
 
 

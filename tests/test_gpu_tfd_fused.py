@@ -157,8 +157,9 @@ def _encoder(d=120, H=8, ff=256, layers=2, p=0.0, seed=0):
     return enc.to(DEV)
 
 
-def test_patched_encoder_matches_the_framework_encoder_under_autocast():
+def test_patched_encoder_matches_the_framework_encoder_under_autocast(monkeypatch):
     from openpystruct_amd import tfd_fused as TF, train
+    monkeypatch.setattr(train, "_SPLIT_WGRAD_ROWS", 512)      # 448 rows through the LIBRARY products (r04's default sends them to the split-row kernel: next test)
     enc = _encoder()
     ref = copy.deepcopy(enc)
     params = list(enc.parameters())
@@ -435,8 +436,9 @@ def test_one_launch_layer_forward_equals_the_eight_launch_form(monkeypatch, B, p
 def test_loss_on_the_head_tile_equals_the_loss_launch(monkeypatch, B, p, alpha0):
     """r04: the training loss of the fast path computed by the head's forward launch on its output tile and finished by the head's backward
     launch (tfd_fused.arm_head_loss) against the same step with the loss as its own two launches behind the head (surrogates.fused_loss):
-    the same arithmetic on the same bf16 predictions -- value to float32 round-off (per-workgroup partial sums in another order), every
-    parameter gradient bit for bit, the running sum advanced."""
+    the same arithmetic on the same bf16 predictions -- value to float32 round-off (per-workgroup partial sums in another order), the
+    parameter gradients to the order of the float atomics that accumulate them (two runs of ONE path differ as much), the running sum
+    advanced."""
     from openpystruct_amd import tfd_fused as TF, train
     from openpystruct_amd.surrogates import ModelOnePassTransformerWithDiffusion, TrainableL1L2Loss, fused_loss
 
@@ -484,7 +486,7 @@ def test_loss_on_the_head_tile_equals_the_loss_launch(monkeypatch, B, p, alpha0)
     l1, a1, o1, g1 = run(True)
     assert torch.equal(o0, o1)
     assert abs(l1 - l0) <= 2e-6 * abs(l0) and abs((a1 - 2.0) - l1) <= 1e-6 * abs(l1) and abs(a1 - a0) <= 4e-6 * abs(a0)
-    assert torch.equal(g0, g1) and float(g0.abs().max()) > 0
+    assert float((g0 - g1).norm() / g0.norm()) < 1e-5 and float(g0.abs().max()) > 0
 
 
 def test_four_layer_encoder_keeps_training_on_fresh_weights(monkeypatch):
