@@ -509,6 +509,8 @@ typedef struct ops_tfd_layer_args {
   float* z2; float* mean2; float* rstd2;
   float* y32; void* y16;                              /* [T, d] layer output, both precisions */
   unsigned long long* trace;                          /* diagnostics: NULL, or 16 stage stamps per workgroup (100 MHz clock) */
+  int32_t identity_act;                               /* r04, verification only: 1 = the feed-forward activation is the identity instead of ReLU (a smooth
+                                                         network whose gradients can be compared with float64 to bf16 rounding); 0 = the reference */
 } ops_tfd_layer_args;
 int ops_tfd_encoder_layer_fwd(const ops_tfd_layer_args* args, void* stream);
 
@@ -533,6 +535,7 @@ typedef struct ops_tfd_layer_bwd_args {
                                                          workgroup's column sums (dgamma2 | dbeta2 | dgamma1 | dbeta1) there INSTEAD of adding
                                                          them with atomics (224 workgroups on the same 480 addresses stalled the launch's memory
                                                          pipeline for ~9 us); the caller sums the rows (ops_linear_wgrad_accumulate_group, K = 0) */
+  int32_t identity_act;                               /* as ops_tfd_layer_args */
 } ops_tfd_layer_bwd_args;
 int ops_tfd_encoder_layer_bwd(const ops_tfd_layer_bwd_args* args, void* stream);
 
@@ -554,6 +557,7 @@ typedef struct ops_tfd_head_args {
    * up.  alpha: device scalar (clamped to [1e-6, 1] as the loss does); min_constraint / max_constraint: device scalars or NULL. */
   const float* targets; void* grad; double* loss_part; const float* alpha; const float* min_constraint; const float* max_constraint;
   float box_weight;
+  int32_t identity_act;                               /* as ops_tfd_layer_args (the head's ReLU) */
 } ops_tfd_head_args;
 int ops_tfd_head_fwd(const ops_tfd_head_args* args, void* stream);
 typedef struct ops_tfd_head_bwd_args {
@@ -583,6 +587,7 @@ typedef struct ops_tfd_front_args {
   const float* cls; const float* pe;
   void* xn16; void* h; float* sa; float* sb; float* z; void* z16;
   long long* t_out; float* eps_out;
+  int32_t identity_act;                               /* as ops_tfd_layer_args (the diffusion MLP's ReLU) */
 } ops_tfd_front_args;
 int ops_tfd_front_fwd(const ops_tfd_front_args* args, void* stream);
 typedef struct ops_tfd_front_bwd_args {

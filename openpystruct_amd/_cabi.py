@@ -137,7 +137,7 @@ class TfdLayerArgs(ctypes.Structure):
                 ("p_attn", _f), ("p_1", _f), ("p_act", _f), ("p_2", _f),
                 ("seed_attn", _u), ("seed_1", _u), ("seed_act", _u), ("seed_2", _u), ("counter", _vp), ("used_call", _vp),
                 ("qkv", _vp), ("ctx", _vp), ("z1", _vp), ("mean1", _vp), ("rstd1", _vp), ("y1_16", _vp), ("u", _vp), ("h", _vp),
-                ("z2", _vp), ("mean2", _vp), ("rstd2", _vp), ("y32", _vp), ("y16", _vp), ("trace", _vp)]
+                ("z2", _vp), ("mean2", _vp), ("rstd2", _vp), ("y32", _vp), ("y16", _vp), ("trace", _vp), ("identity_act", _i)]
 
 
 class TfdLayerBwdArgs(ctypes.Structure):
@@ -149,7 +149,7 @@ class TfdLayerBwdArgs(ctypes.Structure):
                 ("seed_attn", _u), ("seed_1", _u), ("seed_act", _u), ("seed_2", _u), ("used_call", _vp),
                 ("qkv", _vp), ("z1", _vp), ("mean1", _vp), ("rstd1", _vp), ("u", _vp), ("z2", _vp), ("mean2", _vp), ("rstd2", _vp),
                 ("d_f", _vp), ("d_u", _vp), ("d_a", _vp), ("dqkv", _vp), ("dx32", _vp),
-                ("dgamma1", _vp), ("dbeta1", _vp), ("dgamma2", _vp), ("dbeta2", _vp), ("trace", _vp), ("ln_part", _vp)]
+                ("dgamma1", _vp), ("dbeta1", _vp), ("dgamma2", _vp), ("dbeta2", _vp), ("trace", _vp), ("ln_part", _vp), ("identity_act", _i)]
 
 
 class TfdHeadArgs(ctypes.Structure):
@@ -159,7 +159,7 @@ class TfdHeadArgs(ctypes.Structure):
                 ("eps", _f), ("W2", _vp), ("b2", _vp), ("p_drop", _f), ("seed", _u), ("counter", _vp), ("used_call", _vp),
                 ("a16", _vp), ("mean", _vp), ("rstd", _vp), ("h", _vp), ("out", _vp),
                 ("targets", _vp), ("grad", _vp), ("loss_part", _vp), ("alpha", _vp), ("min_constraint", _vp), ("max_constraint", _vp),
-                ("box_weight", _f)]
+                ("box_weight", _f), ("identity_act", _i)]
 
 
 class TfdHeadBwdArgs(ctypes.Structure):
@@ -175,7 +175,7 @@ class TfdFrontArgs(ctypes.Structure):
     _vp, _i, _u = ctypes.c_void_p, ctypes.c_int32, ctypes.c_ulonglong
     _fields_ = [("B", _i), ("Nc", _i), ("d", _i), ("hid", _i), ("T", _i), ("x", _vp), ("alpha_cumprod", _vp), ("seed", _u), ("counter", _vp),
                 ("W0", _vp), ("b0", _vp), ("W2", _vp), ("b2", _vp), ("cls", _vp), ("pe", _vp),
-                ("xn16", _vp), ("h", _vp), ("sa", _vp), ("sb", _vp), ("z", _vp), ("z16", _vp), ("t_out", _vp), ("eps_out", _vp)]
+                ("xn16", _vp), ("h", _vp), ("sa", _vp), ("sb", _vp), ("z", _vp), ("z16", _vp), ("t_out", _vp), ("eps_out", _vp), ("identity_act", _i)]
 
 
 class TfdFrontBwdArgs(ctypes.Structure):

@@ -17,7 +17,9 @@ namespace opsamd {
 
 // every thread of the workgroup calls this (workgroup-uniform control flow)
 __device__ __forceinline__ void call_counter_done(unsigned long long* counter, unsigned reporters) {
+#ifndef OPS_COUNTER_NO_BARRIER      /* (A/B builds only) */
   __syncthreads();
+#endif
   if (threadIdx.x == 0) {
     const unsigned long long done = atomicAdd(counter + 1, 1ull);
     if (done + 1ull == (unsigned long long)reporters) {

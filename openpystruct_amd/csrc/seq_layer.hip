@@ -413,7 +413,7 @@ __global__ __launch_bounds__(64 * SL_NW) void tfd_layer_fwd_kernel(const ops_tfd
             const int r = 4 * g + i;
             const uint16_t ub = sl_f2bf(acc[i] + b);
             float hv = sl_bf2f(ub);
-            hv = hv > 0.0f ? hv : 0.0f;
+            hv = (hv > 0.0f || la->identity_act) ? hv : 0.0f;
             if (p_act > 0.0f && r < nrows) hv = drop_uniform(key_act, (uint64_t)(row0 * ff) + (uint32_t)(r * ff + m)) >= p_act ? hv * ks : 0.0f;
             s_big[r * HS + m] = r < nrows ? sl_f2bf(hv) : (uint16_t)0;
             s_st[r * QS + m] = ub;                     // (the q|k|v rows went out two barriers ago)
@@ -676,7 +676,7 @@ __global__ __launch_bounds__(64 * SL_NW) void tfd_layer_bwd_kernel(const ops_tfd
             const int r = 4 * g + i;
             float gv = sl_round(acc[i]);
             if (p_act > 0.0f) gv = drop_uniform(key_act, (uint64_t)(row0 * ff) + (uint32_t)(r * ff + m)) >= p_act ? gv * ks : 0.0f;
-            gv = sl_bf2f(s_u[r * HS + m]) > 0.0f ? gv : 0.0f;
+            gv = (sl_bf2f(s_u[r * HS + m]) > 0.0f || la->identity_act) ? gv : 0.0f;
             s_du[r * HS + m] = r < nrows ? sl_f2bf(gv) : (uint16_t)0;
           }
         }
@@ -981,7 +981,7 @@ __global__ __launch_bounds__(64 * SL_NW) void tfd_head_fwd_kernel(const ops_tfd_
         for (int i = 0; i < 4; ++i) {
           const int r = 4 * g + i;
           float y = sl_round(__builtin_fmaf((s_f32[r * FS2 + m] - mean[i]) * rstd[i], gmv[j], bev[j]));     // the LayerNorm's bf16 output
-          y = y > 0.0f ? y : 0.0f;
+          y = (y > 0.0f || la->identity_act) ? y : 0.0f;
           if (p > 0.0f) y = drop_uniform(key, (uint64_t)((long)(b0 + r) * hid + m)) >= p ? y * ks : 0.0f;
           s_h[r * HS + m] = r < nrows ? sl_f2bf(y) : (uint16_t)0;
         }
@@ -1271,7 +1271,7 @@ __global__ __launch_bounds__(64 * SL_NW) void tfd_front_fwd_kernel(const ops_tfd
         for (int i = 0; i < 4; ++i) {
           const int r = 4 * g + i;
           const float hv = sl_round(acc[i] + b0v[j]);
-          s_h[r * HS + m] = (r < nrows && hv > 0.0f) ? sl_f2bf(hv) : (uint16_t)0;
+          s_h[r * HS + m] = (r < nrows && (hv > 0.0f || a.identity_act)) ? sl_f2bf(hv) : (uint16_t)0;
         }
       }
     }

@@ -36,6 +36,7 @@ EVAL_FAST = os.environ.get("OPS_AMD_TFD_EVAL_FAST", "1") == "1"       # A/B swit
 FRONT = os.environ.get("OPS_AMD_TFD_FRONT", "1") == "1"               # A/B switch: 0 = the diffusion front end as five + three launches
 LN_PARTIALS = os.environ.get("OPS_AMD_TFD_LN_PARTIALS", "1") == "1"   # A/B switch: 0 = LayerNorm gamma / beta gradients by float atomics in the layer launch
 HEAD = os.environ.get("OPS_AMD_TFD_HEAD", "1") == "1"                 # A/B switch: 0 = the head as four launches per direction
+IDENTITY_ACT = False      # verification only (tests): every ReLU of the one-launch kernels becomes the identity -- a smooth network
 HEAD_LOSS = os.environ.get("OPS_AMD_TFD_HEAD_LOSS", "1") == "1"       # A/B switch: 0 = the training loss as launches of its own behind the head
 LAYER_BWD = os.environ.get("OPS_AMD_TFD_LAYER_BWD", "1") == "1"       # A/B switch: 0 = eight launches per layer backward instead of one
 
@@ -240,7 +241,7 @@ class EncoderLayerFn(torch.autograd.Function):
         used = st.used(4 * li)
         seeds = [st.seed + 7919 * (4 * li + k) for k in range(4)]
         ps = (float(mha.dropout), float(layer.dropout1.p), float(layer.dropout.p), float(layer.dropout2.p)) if st.train_mode else (0.0, 0.0, 0.0, 0.0)
-        a = _cabi.TfdLayerArgs(
+        a = _cabi.TfdLayerArgs(identity_act=int(IDENTITY_ACT), 
             Bn=Bn, S=S, H=H, dh=dh, d=d, ff=ff, x32=x32.data_ptr(),
             W_in=tiles["in"][0].data_ptr(), b_in=rin.b_sh.data_ptr(), W_out=tiles["out"][0].data_ptr(), b_out=rout.b_sh.data_ptr(),
             W_1=tiles["l1"][0].data_ptr(), b_1=r1.b_sh.data_ptr(), W_2=tiles["l2"][0].data_ptr(), b_2=r2.b_sh.data_ptr(),
@@ -280,7 +281,7 @@ class EncoderLayerFn(torch.autograd.Function):
                 tiles = layer._ops_tiles
                 d_f, d_u, d_a, dqkv = torch.empty((T, d), **bf), torch.empty((T, ff), **bf), torch.empty((T, d), **bf), torch.empty((T, 3 * d), **bf)
                 dx32 = torch.empty((T, d), **f32)
-                a = _cabi.TfdLayerBwdArgs(
+                a = _cabi.TfdLayerBwdArgs(identity_act=int(IDENTITY_ACT), 
                     Bn=Bn, S=S, H=H, dh=dh, d=d, ff=ff, g32=ptr(g32), g16=ptr(g16),
                     Wt_in=tiles["in"][1].data_ptr(), Wt_out=tiles["out"][1].data_ptr(), Wt_1=tiles["l1"][1].data_ptr(), Wt_2=tiles["l2"][1].data_ptr(),
                     gamma1=layer.norm1.weight.data_ptr(), gamma2=layer.norm2.weight.data_ptr(),
@@ -552,7 +553,7 @@ class FrontFn(torch.autograd.Function):
         keep = st.keep_draws or KEEP_DRAWS
         t = torch.empty(rows, dtype=torch.int64, device=dev) if keep else None
         eps = torch.empty((rows, d), **f32) if keep else None
-        a = _cabi.TfdFrontArgs(B=B, Nc=Nc, d=d, hid=hid, T=int(dm.T), x=x.data_ptr(), alpha_cumprod=dm._acp.data_ptr(), seed=st.seed + 7919 * 100,
+        a = _cabi.TfdFrontArgs(identity_act=int(IDENTITY_ACT), B=B, Nc=Nc, d=d, hid=hid, T=int(dm.T), x=x.data_ptr(), alpha_cumprod=dm._acp.data_ptr(), seed=st.seed + 7919 * 100,
                                counter=st.counter.data_ptr(), W0=tiles["mlp0"][0].data_ptr(), b0=r0.b_sh.data_ptr(), W2=tiles["mlp2"][0].data_ptr(),
                                b2=r2.b_sh.data_ptr(), cls=model.cls_token.data_ptr(), pe=model.pos_encoder.pe.data_ptr(), xn16=xn16.data_ptr(),
                                h=h.data_ptr(), sa=sa.data_ptr(), sb=sb.data_ptr(), z=z.data_ptr(), z16=z16.data_ptr(),
@@ -631,7 +632,7 @@ class HeadFn(torch.autograd.Function):
         mean, rstd = torch.empty(B, **f32), torch.empty(B, **f32)
         used = st.used(103)
         p = float(model.dropout.p) if st.train_mode else 0.0
-        a = _cabi.TfdHeadArgs(B=B, S=S, d=d, hid=hid, C=C, y16=x16.data_ptr(), W1=tiles["fc1"][0].data_ptr(), b1=r1.b_sh.data_ptr(),
+        a = _cabi.TfdHeadArgs(identity_act=int(IDENTITY_ACT), B=B, S=S, d=d, hid=hid, C=C, y16=x16.data_ptr(), W1=tiles["fc1"][0].data_ptr(), b1=r1.b_sh.data_ptr(),
                               gamma=model.norm1.weight.data_ptr(), beta=model.norm1.bias.data_ptr(), eps=float(model.norm1.eps),
                               W2=tiles["fc2"][0].data_ptr(), b2=r2.b_sh.data_ptr(), p_drop=p, seed=st.seed + 7919 * 103,
                               counter=st.counter.data_ptr(), used_call=used.data_ptr(), a16=a16.data_ptr(), mean=mean.data_ptr(),

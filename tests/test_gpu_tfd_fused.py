@@ -729,6 +729,73 @@ def test_fast_path_gradients_against_float64_autograd(monkeypatch, B, cfg):
     assert not bad, bad
 
 
+@pytest.mark.parametrize("B", [512, 37])
+def test_fast_path_gradients_of_a_smooth_network_match_float64(monkeypatch, B):
+    """The absolute guard of the fast path's backward launches: with every ReLU replaced by the identity
+    (`identity_act`, verification only), dropout 0 and a linear objective the network is smooth -- no branch can be taken on the other
+    side of a bf16 rounding -- and every parameter gradient of the one-launch kernels must agree with float64 autograd of the same
+    module to bf16 rounding: <= 3 % relative L2 (zero-gradient biases against their weight's scale), no reference to how well the
+    framework's own bf16 evaluation does."""
+    from openpystruct_amd import tfd_fused as TF, train
+    from openpystruct_amd.surrogates import ModelOnePassTransformerWithDiffusion
+    monkeypatch.setattr(TF, "KEEP_DRAWS", True)
+    monkeypatch.setattr(TF, "IDENTITY_ACT", True)
+    torch.manual_seed(5)
+    cfg = dict(n_cases=6, feat_dim=120, n_elem=100)
+    model = ModelOnePassTransformerWithDiffusion(dropout=0.0, **cfg).to(DEV)
+    ref = copy.deepcopy(model).double()
+    for layer in ref.transformer_encoder.layers:             # the same smooth network in float64
+        layer.activation = lambda t: t
+        layer.activation_relu_or_gelu = 0
+    ref.diffusion.mlp[1] = torch.nn.Identity()
+    params = list(model.parameters())
+    flat = torch.zeros(sum(q.numel() for q in params), device=DEV)
+    off = 0
+    for q in params:
+        q.grad = flat[off:off + q.numel()].view_as(q)
+        off += q.numel()
+    opt = train.FlatClipAdam(params, flat, 1e-3)
+    stash, dst, patched = train.enable_shadow_linears(model, opt, params, flat)
+    assert TF.patch_model(model, seed=3, direct_param_grads=True)
+    st_probe = TF._State(torch.device(DEV), 1, True)
+    assert TF._front_fused_ok(model, st_probe, 120) and TF._head_fused_ok(model, st_probe, 120)
+    assert all(TF._layer_fused_ok(l, st_probe) for l in model.transformer_encoder.layers)
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(B, 6, 120, generator=g).to(DEV)
+    w = torch.randn(B, 100, generator=g).to(DEV) / B
+    model.train(); ref.train()
+    train._WGRAD_QUEUE = []
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        out = model(x)
+        (out.float() * w).sum().backward()
+    train.flush_wgrad_queue(torch.device(DEV))
+    train._WGRAD_QUEUE = None
+    live = [(dd, ss) for dd, ss in zip(dst, stash) if ss is not None]
+    if live:
+        torch._foreach_copy_([a for a, _ in live], [b for _, b in live])
+    t_k, e_k = model.transformer_encoder._ops_dropout_state[x.device].draws
+    monkeypatch.setattr(torch, "randint", lambda lo, hi, size, device=None, **kw: t_k)
+    monkeypatch.setattr(torch, "randn_like", lambda t, **kw: e_k.to(t.dtype))
+    monkeypatch.setattr(torch, "relu", lambda t: t)          # the head's ReLU (TFD:573) of the reference module
+    outr = ref(x.double())
+    (outr * w.double()).sum().backward()
+    monkeypatch.undo()
+    assert _rel(out.float(), outr) < 1e-2
+    gref = {n: q.grad for n, q in ref.named_parameters()}
+    worst = {}
+    for n, q in model.named_parameters():
+        scale = float(gref[n].norm())
+        if n.endswith("bias"):
+            wn = n[:-4] + "weight"
+            if wn in gref:
+                scale = max(scale, float(gref[wn].norm()) / np.sqrt(gref[wn].shape[-1]))
+        worst[n] = float((q.grad.double() - gref[n]).norm()) / (scale + 1e-30)
+    train.disable_shadow_linears(patched)
+    TF.unpatch_model(model)
+    bad = {n: e for n, e in worst.items() if not (np.isfinite(e) and e <= 3e-2)}
+    assert not bad, (bad, max(worst.values()))
+
+
 def _tiled_pair(lib, W):
     from openpystruct_amd import _cabi
     N, K = W.shape
