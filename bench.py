@@ -41,6 +41,23 @@ N_ELEM = 100
 SEED = 20250307
 
 
+CHIP_WARM_MS = 40.0      # untimed load in front of every timed region: from idle the chip needs ~25 ms of work before launch times settle
+                         # (power 300 -> 670 W; scripts/hot_series.py, scripts/sat_series.py, profiles/r04_notes.md 6: 10^4 beams 12.8 -> 11.5 us,
+                         # 2^20 beams 1 150 -> 934 us per launch over the first 30 launches) -- a generator runs for seconds, not for 6 ms
+
+
+def chip_warm(fn, stream=None, ms=CHIP_WARM_MS):
+    """Call `fn()` (which queues device work) until `ms` of wall time have passed, then drain.  Returns (calls, elapsed ms)."""
+    t0, n = time.perf_counter(), 0
+    while True:
+        fn()
+        n += 1
+        (stream.synchronize() if stream is not None else torch.cuda.synchronize())
+        el = (time.perf_counter() - t0) * 1e3
+        if el >= ms:
+            return n, el
+
+
 def synth_inputs(B, rank, device, inertia):
     """fixed bridge, 1-4 point loads per beam, UDL -1000, seeded per rank."""
     rng = np.random.default_rng(SEED + rank)
@@ -278,6 +295,7 @@ def frames_measure(dev, rank, local_rank, world, bays, stories, B, K, W):
     for _ in range(W):
         frames.frame_solve(topo, I, out=sol)
     torch.cuda.synchronize()
+    chip_warm(lambda: frames.frame_solve(topo, I, out=sol))      # untimed: the chip's power state settles (CHIP_WARM_MS)
 
     def barrier():
         if world > 1:
@@ -424,10 +442,14 @@ def main():
                             oa.beam_solve(**sets[i % n_sets], tiling=tiling, out=outs[i % n_sets], stream_out=stream_out)
                     graph.replay()   # untimed: instantiate + first replay
                     stream.synchronize()
+                    chip_warm(graph.replay, stream)      # untimed: the chip's power state settles (CHIP_WARM_MS)
                 except Exception as e:   # keep the bench alive: eager launches measure the same kernel, with host gaps
                     print(f"warning: HIP graph capture failed ({e}); falling back to eager launches", file=sys.stderr)
                     graph = None
                     torch.cuda.synchronize()
+        if graph is None:
+            with torch.cuda.stream(stream):
+                chip_warm(lambda: [oa.beam_solve(**sets[i % n_sets], tiling=tiling, out=outs[i % n_sets], stream_out=stream_out) for i in range(max(n_sets, 8))], stream)
         e0 = torch.cuda.Event(enable_timing=True)
         e1 = torch.cuda.Event(enable_timing=True)
         barrier()
@@ -508,6 +530,7 @@ def main():
                 "launch": mode,
                 "buffer_sets": max(1, args.sets),
                 "parallelism": f"independent shards x{world}, no data-path collective",
+                "untimed_chip_warm_ms": CHIP_WARM_MS,      # in front of EVERY timed region of this line, beside the W warm-up steps
             },
             "roofline": {
                 "bound": "hbm",
