@@ -186,6 +186,34 @@ int ops_beam_residual_vjp_f64(int B, int Ne, const double* x, long x_bstride, co
                               const double* theta, const double* gv, const double* gt, double* scratch_v,
                               double* scratch_t, double* dv, double* dt, double* dI, void* stream);
 
+/* The surrogates' FE-residual TERM (r04, ABI 10) in three launches -- what physics.py fe_residual_loss built from ~60 framework nodes around
+ * the two entry points above:
+ *   I_e = max(preds[b, e] * I_scale[e] + I_mean[e], I_min);   u = (v_rec, t_rec)[rows[b]]  (I-only models; rows NULL: row b)   or
+ *   v_n = preds[b, Ne + n] * v_scale[n] + v_mean[n], theta_n = preds[b, Ne + N + n] * t_scale[n] + t_mean[n]   (v_rec == NULL: the PINN);
+ *   r = D (K(I) u - f) with Fy [.., N] gathered by rows, shared x [N] / fix [N] / E / wy;   e = r / diag K(I)  (no gradient through the diagonal);
+ *   value[0] = weight * (mean e_v^2 / (mean v^2 + 1e-30) + mean e_t^2 / (mean theta^2 + 1e-30)),  value_sum[0] += it (optional).
+ * ops_physics_loss_fwd: residual + scaled errors (ev, et [B, N] float64, kept for the backward launch) + the value.
+ * ops_physics_loss_bwd: dpreds [B, ldp] (the predictions' dtype) = d value / d preds, ASSIGNED on the columns the term reads (Ne, or
+ * Ne + 2 N); the caller zeroes the rest.  part: ops_physics_loss_part_doubles(B, Ne) doubles shared by the two calls. */
+typedef struct ops_physics_loss_args {
+  int32_t B, Ne;
+  const void* preds; int32_t preds_bf16, ldp;
+  const float* I_scale; const float* I_mean; float I_min;
+  const double* v_rec; const double* t_rec;
+  const float* v_scale; const float* v_mean; const float* t_scale; const float* t_mean;
+  const long long* rows;
+  const double* Fy;
+  const double* x; const uint8_t* fix; double E, wy;
+  float weight;
+  double* ev; double* et; double* part;
+  float* value; float* value_sum;
+  void* dpreds;
+} ops_physics_loss_args;
+size_t ops_physics_loss_part_doubles(int B, int Ne);
+int ops_physics_loss_fwd(const ops_physics_loss_args* args, void* stream);
+int ops_physics_loss_bwd(const ops_physics_loss_args* args, void* stream);
+
+
 /* Batched 2-D frame solve (3 DOF per node; SURVEY 8(f1), BASELINE config 5): replaces, for B frames that share one
  * topology, `setup_frame_model` + `ops.analyze(1)` + `ops.eleResponse(e,'forces')` of
  * OpenPyStruct_FrameOpt_Discrete_Beta.py:75-139, :151, :181-183.  Host-prepared, shared by the batch:

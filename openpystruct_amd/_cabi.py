@@ -71,6 +71,9 @@ EXPORTS = (
     "ops_tfd_head_bwd",
     "ops_tfd_front_fwd",
     "ops_tfd_front_bwd",
+    "ops_physics_loss_part_doubles",
+    "ops_physics_loss_fwd",
+    "ops_physics_loss_bwd",
 )
 
 OK, ERR_INVALID_ARG, ERR_UNSUPPORTED, ERR_LAUNCH = 0, 1, 2, 3
@@ -170,6 +173,15 @@ class TfdHeadBwdArgs(ctypes.Structure):
                 ("loss_part", _vp), ("alpha", _vp), ("alpha0", _f), ("box_weight", _f), ("loss", _vp), ("loss_sum", _vp)]
 
 
+class PhysicsLossArgs(ctypes.Structure):
+    """Mirror of `ops_physics_loss_args`."""
+    _vp, _i, _f, _d = ctypes.c_void_p, ctypes.c_int32, ctypes.c_float, ctypes.c_double
+    _fields_ = [("B", _i), ("Ne", _i), ("preds", _vp), ("preds_bf16", _i), ("ldp", _i), ("I_scale", _vp), ("I_mean", _vp), ("I_min", _f),
+                ("v_rec", _vp), ("t_rec", _vp), ("v_scale", _vp), ("v_mean", _vp), ("t_scale", _vp), ("t_mean", _vp), ("rows", _vp),
+                ("Fy", _vp), ("x", _vp), ("fix", _vp), ("E", _d), ("wy", _d), ("weight", _f), ("ev", _vp), ("et", _vp), ("part", _vp),
+                ("value", _vp), ("value_sum", _vp), ("dpreds", _vp)]
+
+
 class TfdFrontArgs(ctypes.Structure):
     """Mirror of `ops_tfd_front_args`."""
     _vp, _i, _u = ctypes.c_void_p, ctypes.c_int32, ctypes.c_ulonglong
@@ -247,6 +259,12 @@ def load():
     lib.ops_tfd_head_fwd.argtypes = [ctypes.POINTER(TfdHeadArgs), vp]
     lib.ops_tfd_head_bwd.restype = it
     lib.ops_tfd_head_bwd.argtypes = [ctypes.POINTER(TfdHeadBwdArgs), vp]
+    lib.ops_physics_loss_part_doubles.restype = ctypes.c_size_t
+    lib.ops_physics_loss_part_doubles.argtypes = [it, it]
+    lib.ops_physics_loss_fwd.restype = it
+    lib.ops_physics_loss_fwd.argtypes = [ctypes.POINTER(PhysicsLossArgs), vp]
+    lib.ops_physics_loss_bwd.restype = it
+    lib.ops_physics_loss_bwd.argtypes = [ctypes.POINTER(PhysicsLossArgs), vp]
     lib.ops_tfd_front_fwd.restype = it
     lib.ops_tfd_front_fwd.argtypes = [ctypes.POINTER(TfdFrontArgs), vp]
     lib.ops_tfd_front_bwd.restype = it

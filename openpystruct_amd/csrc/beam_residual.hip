@@ -117,6 +117,199 @@ __global__ __launch_bounds__(256) void beam_dI_kernel(const ResParams p, const d
   dI[idx] = mv[o] * y0 + mt[o] * y1 + mv[o + 1] * y2 + mt[o + 1] * y3;
 }
 
+
+// ================================================================================================================================
+// The surrogates' FE-residual TERM as three launches (r04; physics.py fe_residual_loss was ~60 framework kernel nodes per training
+// step around ops_beam_residual_f64 / _vjp_f64 -- inverse scalers, clamp, casts, three row gathers, the stiffness diagonal's
+// concatenations, four mean reductions of 11-13 us each and everything's backward: 250 of the 390 us of a TFD + physics step):
+//
+//     I_e  = max(p[b, e] * sI_e + mI_e, I_min)                       inertias from the model's standardised predictions
+//     u    = recorded (v, theta)[rows[b]]   or   p[b, Ne + n] * s_n + m_n            (I-only models / the PINN's own displacement outputs)
+//     r    = D (K(I) u - f),  e_v = r_v / K_vv,  e_t = r_t / K_tt                     (Jacobi-scaled residual; K_ii from I, no gradient)
+//     term = weight * ( mean(e_v^2) / (mean(v^2) + 1e-30) + mean(e_t^2) / (mean(theta^2) + 1e-30) )     (means over all B N entries)
+//
+//   forward : one thread per node: residual, scaled errors (saved), per-workgroup partial sums of e_v^2, e_t^2, v^2, theta^2
+//   finish  : one workgroup adds the partial sums: the value (and the totals the backward launch needs)
+//   backward: one thread per node / element: m = D g with g = 2 weight e / (B N scale K_ii),  d term / d I_e = m_e^T (dk_e/dI_e) u_e and
+//             (predicted displacements) d term / d u = K m, chained to the predictions (x scaler, clamp mask), ASSIGNED to dpreds [B, ldp]
+// Shared geometry x [N] and constraint flags [N] (the fixed bridge of the training data); float64 inside.
+// ================================================================================================================================
+struct PhysArgs {
+  int B, Ne;
+  const void* preds; int bf16, ldp;
+  const float* I_scale; const float* I_mean; float I_min;
+  const double* v_rec; const double* t_rec;
+  const float* v_scale; const float* v_mean; const float* t_scale; const float* t_mean;
+  const long long* rows;
+  const double* Fy;
+  const double* x; const uint8_t* fix; double E, wy;
+  float weight;
+  double* ev; double* et; double* part;
+  float* value; float* value_sum;
+  void* dpreds;
+};
+
+__device__ __forceinline__ float ph_pred(const PhysArgs& a, long b, int c) {
+  return a.bf16 ? __uint_as_float((uint32_t)((const uint16_t*)a.preds)[b * a.ldp + c] << 16) : ((const float*)a.preds)[b * a.ldp + c];
+}
+__device__ __forceinline__ double ph_I(const PhysArgs& a, long b, int e, bool* clamped = nullptr) {      // 0 <= e < Ne
+  const float v = ph_pred(a, b, e) * a.I_scale[e] + a.I_mean[e];          // float32, as the scaler's inverse transform computes it
+  if (clamped) *clamped = !(v > a.I_min);
+  return (double)(v > a.I_min ? v : a.I_min);
+}
+__device__ __forceinline__ void ph_u(const PhysArgs& a, long b, long row, int n, double& v, double& t) {   // 0 <= n <= Ne
+  const int N = a.Ne + 1;
+  if (a.v_rec) { v = a.v_rec[row * N + n]; t = a.t_rec[row * N + n]; }
+  else {
+    v = (double)(ph_pred(a, b, a.Ne + n) * a.v_scale[n] + a.v_mean[n]);
+    t = (double)(ph_pred(a, b, a.Ne + N + n) * a.t_scale[n] + a.t_mean[n]);
+  }
+}
+// element e of beam b: stiffness coefficients per unit of EI
+struct PhEl { double k2, k4, k6, k12, L; };
+__device__ __forceinline__ PhEl ph_el(const PhysArgs& a, int e) {
+  const double L = a.x[e + 1] - a.x[e], r = 1.0 / L;
+  PhEl k; k.L = L; k.k2 = 2.0 * r; k.k4 = 4.0 * r; k.k6 = 6.0 * r * r; k.k12 = 12.0 * r * r * r;
+  return k;
+}
+
+template <int NV>
+__device__ __forceinline__ void ph_block_sum(double (&v)[NV], double* s_red) {      // thread 0 gets the totals
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+  for (int k = 0; k < NV; ++k)
+    for (int s = 32; s >= 1; s >>= 1) v[k] += __shfl_xor(v[k], s, 64);
+  if (lane == 0)
+#pragma unroll
+    for (int k = 0; k < NV; ++k) s_red[wave * NV + k] = v[k];
+  __syncthreads();
+  if (threadIdx.x == 0)
+#pragma unroll
+    for (int k = 0; k < NV; ++k) { double t = 0.0; for (int w = 0; w < 4; ++w) t += s_red[w * NV + k]; v[k] = t; }
+}
+
+__global__ __launch_bounds__(256) void phys_loss_fwd_kernel(const PhysArgs a) {
+  __shared__ double s_red[4 * 4];
+  const int N = a.Ne + 1;
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x, tot = (long)a.B * N;
+  double acc[4] = {0.0, 0.0, 0.0, 0.0};
+  if (idx < tot) {
+    const long b = idx / N;
+    const int n = (int)(idx - b * N);
+    const long row = a.rows ? a.rows[b] : b;
+    double v0, t0;
+    ph_u(a, b, row, n, v0, t0);
+    double yv = 0.0, yt = 0.0, dvv = 0.0, dtt = 0.0, fv = a.Fy[row * N + n], ft = 0.0;
+    if (n > 0) {          // element n - 1, this node is its end 2
+      const PhEl k = ph_el(a, n - 1);
+      const double EI = a.E * ph_I(a, b, n - 1);
+      double v1, t1;
+      ph_u(a, b, row, n - 1, v1, t1);
+      yv += EI * (-k.k12 * v1 - k.k6 * t1 + k.k12 * v0 - k.k6 * t0);
+      yt += EI * (k.k6 * v1 + k.k2 * t1 - k.k6 * v0 + k.k4 * t0);
+      dvv += EI * k.k12; dtt += EI * k.k4;
+      fv += 0.5 * a.wy * k.L; ft -= a.wy * k.L * k.L / 12.0;
+    }
+    if (n < a.Ne) {       // element n, this node is its end 1
+      const PhEl k = ph_el(a, n);
+      const double EI = a.E * ph_I(a, b, n);
+      double v2, t2;
+      ph_u(a, b, row, n + 1, v2, t2);
+      yv += EI * (k.k12 * v0 + k.k6 * t0 - k.k12 * v2 + k.k6 * t2);
+      yt += EI * (k.k6 * v0 + k.k4 * t0 - k.k6 * v2 + k.k2 * t2);
+      dvv += EI * k.k12; dtt += EI * k.k4;
+      fv += 0.5 * a.wy * k.L; ft += a.wy * k.L * k.L / 12.0;
+    }
+    const uint8_t f = a.fix[n];
+    const double ev = (f & 1) ? 0.0 : (yv - fv) / dvv, et = (f & 2) ? 0.0 : (yt - ft) / dtt;
+    a.ev[idx] = ev; a.et[idx] = et;
+    acc[0] = ev * ev; acc[1] = et * et; acc[2] = v0 * v0; acc[3] = t0 * t0;
+  }
+  ph_block_sum<4>(acc, s_red);
+  if (threadIdx.x == 0)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) a.part[(long)blockIdx.x * 4 + k] = acc[k];
+}
+
+// one workgroup: totals into part[4 nwg .. 4 nwg + 3], the weighted value
+__global__ __launch_bounds__(256) void phys_loss_finish_kernel(const PhysArgs a, int nwg) {
+  __shared__ double s_red[4 * 4];
+  double acc[4] = {0.0, 0.0, 0.0, 0.0};
+  for (int g = threadIdx.x; g < nwg; g += 256)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc[k] += a.part[(long)g * 4 + k];
+  ph_block_sum<4>(acc, s_red);
+  if (threadIdx.x == 0) {
+    const double n = (double)a.B * (double)(a.Ne + 1);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) a.part[(long)nwg * 4 + k] = acc[k];
+    const double val = (acc[0] / n) / (acc[2] / n + 1e-30) + (acc[1] / n) / (acc[3] / n + 1e-30);
+    a.value[0] = (float)((double)a.weight * val);
+    if (a.value_sum) a.value_sum[0] += a.value[0];
+  }
+}
+
+__global__ __launch_bounds__(256) void phys_loss_bwd_kernel(const PhysArgs a, int nwg) {
+  const int N = a.Ne + 1;
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x, tot = (long)a.B * N;
+  if (idx >= tot) return;
+  const long b = idx / N;
+  const int j = (int)(idx - b * N);
+  const long row = a.rows ? a.rows[b] : b;
+  const double n = (double)a.B * (double)N;
+  const double cv = 2.0 * (double)a.weight / (n * (a.part[(long)nwg * 4 + 2] / n + 1e-30));
+  const double ct = 2.0 * (double)a.weight / (n * (a.part[(long)nwg * 4 + 3] / n + 1e-30));
+  // m at node q: (cv e_v / K_vv, ct e_t / K_tt) (the saved errors are already zero at constrained DOFs)
+  auto diag = [&](int q, double& dvv, double& dtt) {
+    dvv = 0.0; dtt = 0.0;
+    if (q > 0) { const PhEl k = ph_el(a, q - 1); const double EI = a.E * ph_I(a, b, q - 1); dvv += EI * k.k12; dtt += EI * k.k4; }
+    if (q < a.Ne) { const PhEl k = ph_el(a, q); const double EI = a.E * ph_I(a, b, q); dvv += EI * k.k12; dtt += EI * k.k4; }
+  };
+  auto m_at = [&](int q, double& mv, double& mt) {
+    double dvv, dtt;
+    diag(q, dvv, dtt);
+    mv = cv * a.ev[b * N + q] / dvv; mt = ct * a.et[b * N + q] / dtt;
+  };
+  double mv0, mt0;
+  m_at(j, mv0, mt0);
+  auto put = [&](int c, double g) {
+    if (a.bf16) {
+      uint32_t u = __float_as_uint((float)g);
+      if ((u & 0x7fffffffu) > 0x7f800000u) u |= 0x400000u; else u += 0x7fffu + ((u >> 16) & 1u);
+      ((uint16_t*)a.dpreds)[b * a.ldp + c] = (uint16_t)(u >> 16);
+    } else ((float*)a.dpreds)[b * a.ldp + c] = (float)g;
+  };
+  if (j < a.Ne) {        // element j: d term / d I_j = m_j^T (dk_j / dI_j) u_j, chained through the clamp and the scaler
+    const PhEl k = ph_el(a, j);
+    double mv1, mt1, v1, t1, v2, t2;
+    m_at(j + 1, mv1, mt1);
+    ph_u(a, b, row, j, v1, t1); ph_u(a, b, row, j + 1, v2, t2);
+    const double y0 = k.k12 * v1 + k.k6 * t1 - k.k12 * v2 + k.k6 * t2, y1 = k.k6 * v1 + k.k4 * t1 - k.k6 * v2 + k.k2 * t2;
+    const double y2 = -y0, y3 = k.k6 * v1 + k.k2 * t1 - k.k6 * v2 + k.k4 * t2;
+    bool clamped;
+    ph_I(a, b, j, &clamped);
+    const double dI = a.E * (mv0 * y0 + mt0 * y1 + mv1 * y2 + mt1 * y3);
+    put(j, clamped ? 0.0 : dI * (double)a.I_scale[j]);
+  }
+  if (!a.v_rec) {        // predicted displacements: d term / d u = K m at node j
+    double yv = 0.0, yt = 0.0;
+    if (j > 0) {
+      const PhEl k = ph_el(a, j - 1); const double EI = a.E * ph_I(a, b, j - 1);
+      double mv1, mt1; m_at(j - 1, mv1, mt1);
+      yv += EI * (-k.k12 * mv1 - k.k6 * mt1 + k.k12 * mv0 - k.k6 * mt0);
+      yt += EI * (k.k6 * mv1 + k.k2 * mt1 - k.k6 * mv0 + k.k4 * mt0);
+    }
+    if (j < a.Ne) {
+      const PhEl k = ph_el(a, j); const double EI = a.E * ph_I(a, b, j);
+      double mv2, mt2; m_at(j + 1, mv2, mt2);
+      yv += EI * (k.k12 * mv0 + k.k6 * mt0 - k.k12 * mv2 + k.k6 * mt2);
+      yt += EI * (k.k6 * mv0 + k.k4 * mt0 - k.k6 * mv2 + k.k2 * mt2);
+    }
+    put(a.Ne + j, yv * (double)a.v_scale[j]);
+    put(a.Ne + N + j, yt * (double)a.t_scale[j]);
+  }
+}
+
 }  // namespace opsamd
 
 using namespace opsamd;
@@ -149,5 +342,38 @@ extern "C" int ops_beam_residual_vjp_f64(int B, int Ne, const double* x, long x_
   hipLaunchKernelGGL(beam_mask_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p, gv, gt, scratch_v, scratch_t);
   hipLaunchKernelGGL(beam_apply_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p, scratch_v, scratch_t, dv, dt);
   hipLaunchKernelGGL(beam_dI_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, s, p, scratch_v, scratch_t, v, theta, dI);
+  return hipGetLastError() == hipSuccess ? OPS_AMD_OK : OPS_AMD_ERR_LAUNCH;
+}
+
+static int phys_args(const ops_physics_loss_args* q, PhysArgs& a) {
+  if (!q || q->B < 1 || q->Ne < 1 || !q->preds || !q->I_scale || !q->I_mean || !q->Fy || !q->x || !q->fix || !q->ev || !q->et || !q->part) return OPS_AMD_ERR_INVALID_ARG;
+  const bool rec = q->v_rec != nullptr;
+  if (rec != (q->t_rec != nullptr)) return OPS_AMD_ERR_INVALID_ARG;
+  if (!rec && (!q->v_scale || !q->v_mean || !q->t_scale || !q->t_mean)) return OPS_AMD_ERR_INVALID_ARG;
+  if (q->ldp < q->Ne + (rec ? 0 : 2 * (q->Ne + 1))) return OPS_AMD_ERR_INVALID_ARG;
+  a = PhysArgs{q->B, q->Ne, q->preds, q->preds_bf16, q->ldp, q->I_scale, q->I_mean, q->I_min, q->v_rec, q->t_rec, q->v_scale, q->v_mean,
+               q->t_scale, q->t_mean, q->rows, q->Fy, q->x, q->fix, q->E, q->wy, q->weight, q->ev, q->et, q->part, q->value, q->value_sum,
+               q->dpreds};
+  return OPS_AMD_OK;
+}
+extern "C" size_t ops_physics_loss_part_doubles(int B, int Ne) { return (size_t)4 * (((size_t)B * (Ne + 1) + 255) / 256 + 1); }
+
+extern "C" int ops_physics_loss_fwd(const ops_physics_loss_args* q, void* stream) {
+  PhysArgs a;
+  const int rc = phys_args(q, a);
+  if (rc != OPS_AMD_OK) return rc;
+  if (!a.value) return OPS_AMD_ERR_INVALID_ARG;
+  const int nwg = (int)(((long)a.B * (a.Ne + 1) + 255) / 256);
+  hipLaunchKernelGGL(phys_loss_fwd_kernel, dim3((unsigned)nwg), dim3(256), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(phys_loss_finish_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, a, nwg);
+  return hipGetLastError() == hipSuccess ? OPS_AMD_OK : OPS_AMD_ERR_LAUNCH;
+}
+extern "C" int ops_physics_loss_bwd(const ops_physics_loss_args* q, void* stream) {
+  PhysArgs a;
+  const int rc = phys_args(q, a);
+  if (rc != OPS_AMD_OK) return rc;
+  if (!a.dpreds) return OPS_AMD_ERR_INVALID_ARG;
+  const int nwg = (int)(((long)a.B * (a.Ne + 1) + 255) / 256);
+  hipLaunchKernelGGL(phys_loss_bwd_kernel, dim3((unsigned)nwg), dim3(256), 0, (hipStream_t)stream, a, nwg);
   return hipGetLastError() == hipSuccess ? OPS_AMD_OK : OPS_AMD_ERR_LAUNCH;
 }

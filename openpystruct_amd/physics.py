@@ -100,3 +100,73 @@ def fe_residual_loss(I, v, theta, x, E, fix, Fy, wy):
     scale = (v.detach().to(torch.float64) ** 2).mean() + 1e-30
     scale_t = (theta.detach().to(torch.float64) ** 2).mean() + 1e-30
     return (ev ** 2).mean() / scale + (et ** 2).mean() / scale_t
+
+
+class _FusedResidualTerm(torch.autograd.Function):
+    """csrc/beam_residual.hip ops_physics_loss_fwd / _bwd: weight * fe_residual_loss of the inertias (and, for the PINN, the displacement
+    fields) the model PREDICTS in standardised form, in three launches; the value enters the differentiated total with weight one."""
+
+    @staticmethod
+    def forward(ctx, preds, spec):
+        import ctypes
+        lib = _cabi.load()
+        (nel, sI, disp, rows, Fy, x, E, fix, wy, weight, acc) = spec
+        dev = preds.device
+        if preds.dtype not in (torch.float32, torch.bfloat16) or preds.dim() != 2 or preds.stride(1) != 1:
+            raise ValueError("predictions must be a [B, C] float32 or bfloat16 matrix with unit column stride")
+        B, N = preds.shape[0], nel + 1
+        f64 = dict(dtype=torch.float64, device=dev)
+        ev, et = torch.empty((B, N), **f64), torch.empty((B, N), **f64)
+        part = torch.empty(int(lib.ops_physics_loss_part_doubles(B, nel)), **f64)
+        value = torch.empty((), dtype=torch.float32, device=dev)
+        f32 = lambda t: t.to(device=dev, dtype=torch.float32).contiguous()      # noqa: E731
+        keep = [f32(sI.scale_), f32(sI.mean_), Fy, x, fix, ev, et, part, value, preds]
+        a = _cabi.PhysicsLossArgs(B=B, Ne=nel, preds=preds.data_ptr(), preds_bf16=int(preds.dtype == torch.bfloat16), ldp=preds.stride(0),
+                                  I_scale=keep[0].data_ptr(), I_mean=keep[1].data_ptr(), I_min=1e-8, Fy=Fy.data_ptr(), x=x.data_ptr(),
+                                  fix=fix.data_ptr(), E=float(E), wy=float(wy), weight=float(weight), ev=ev.data_ptr(), et=et.data_ptr(),
+                                  part=part.data_ptr(), value=value.data_ptr(), value_sum=acc.data_ptr() if acc is not None else None)
+        if rows is not None:
+            keep.append(rows)
+            a.rows = rows.data_ptr()
+        if torch.is_tensor(disp[0]):            # recorded displacement fields (I-only models)
+            keep += [disp[0], disp[1]]
+            a.v_rec, a.t_rec = disp[0].data_ptr(), disp[1].data_ptr()
+        else:                                   # the PINN's own outputs: (scaler of the deflections, scaler of the rotations)
+            sc = [f32(disp[0].scale_), f32(disp[0].mean_), f32(disp[1].scale_), f32(disp[1].mean_)]
+            keep += sc
+            a.v_scale, a.v_mean, a.t_scale, a.t_mean = (t.data_ptr() for t in sc)
+        with torch.cuda.device(dev):
+            rc = lib.ops_physics_loss_fwd(ctypes.byref(a), torch.cuda.current_stream(dev).cuda_stream)
+        if rc != _cabi.OK:
+            raise RuntimeError(f"ops_physics_loss_fwd failed with code {rc}")
+        ctx.args, ctx.keep = a, keep
+        ctx.ncols = nel if torch.is_tensor(disp[0]) else nel + 2 * N
+        return value
+
+    @staticmethod
+    def backward(ctx, go):
+        import ctypes
+        lib = _cabi.load()
+        a, preds = ctx.args, ctx.keep[9]
+        dev = preds.device
+        dp = torch.empty_like(preds) if ctx.ncols == preds.shape[1] else torch.zeros_like(preds)
+        a.dpreds, a.ldp = dp.data_ptr(), dp.stride(0)
+        with torch.cuda.device(dev):
+            rc = lib.ops_physics_loss_bwd(ctypes.byref(a), torch.cuda.current_stream(dev).cuda_stream)
+        if rc != _cabi.OK:
+            raise RuntimeError(f"ops_physics_loss_bwd failed with code {rc}")
+        return dp, None
+
+
+def fused_residual_term(preds, nel, sI, disp, rows, Fy, x, E, fix, wy, weight, acc=None):
+    """weight * fe_residual_loss(I, v, theta, ...) with I = clamp(sI^-1(preds[:, :nel]), 1e-8) and the displacement fields either recorded
+    (`disp` = (v_rec, t_rec) float64 [G, N], row rows[b] for sample b; rows None: row b) or predicted (`disp` = (scaler of the
+    deflections, scaler of the rotations): the PINN's columns nel .. nel + 2 N - 1), Fy [G, N] gathered the same way: three launches.
+    The value enters the total with weight ONE (the gradient ignores the incoming one); `acc`: float32 device scalar the value is added
+    to.  Shared geometry: x [N] float64, fix [N] uint8, scalars E, wy."""
+    if not preds.is_cuda:
+        raise RuntimeError("fused_residual_term needs GPU tensors: openpystruct_amd has no CPU fallback")
+    dev = preds.device
+    spec = (int(nel), sI, disp, rows, _f64(Fy, dev), _f64(x, dev), float(E), torch.as_tensor(fix, dtype=torch.uint8, device=dev).contiguous(),
+            float(wy), float(weight), acc)
+    return _FusedResidualTerm.apply(preds, spec)

@@ -653,8 +653,17 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
         pE = torch.tensor(float(physics.E), dtype=torch.float64, device=device)      # device scalars: nothing crosses PCIe
         pwy = torch.tensor(float(physics.wy), dtype=torch.float64, device=device)    # inside a captured step
 
+    _FUSED_PHYS = on_gpu and os.environ.get("OPS_AMD_FUSED_PHYSICS", "1") == "1"      # A/B switch: 0 = physics.fe_residual_loss from framework ops
+    phys_acc = None      # (the step's total -- data loss + this term -- is accumulated by the loop below)
+
     def physics_inputs(rows, out=None):
-        """Per-batch loads (and, for the I-only models, recorded displacement fields); `out`: the graph's static buffers."""
+        """Per-batch loads (and, for the I-only models, recorded displacement fields); `out`: the graph's static buffers.
+        Fused term (csrc/beam_residual.hip ops_physics_loss_*): only the ROW INDICES travel -- the launches gather by them."""
+        if _FUSED_PHYS:
+            if out is None:
+                return (rows,)
+            out[0].copy_(rows)
+            return out
         srcs = (Fy_tr,) if kind == "pinn" else (Fy_tr, v_rec, t_rec)
         if out is None:
             return tuple(t[rows] for t in srcs)
@@ -664,13 +673,18 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
 
     def physics_loss(preds, pin):
         nel = cfg.nelem
+        if _FUSED_PHYS:          # three launches; the value is already weighted and enters the total with weight one
+            from .physics import fused_residual_term
+            disp = (sD, sR) if kind == "pinn" else (v_rec, t_rec)
+            return fused_residual_term(preds, nel, sI, disp, pin[0], Fy_tr, px, float(physics.E), pfix, float(physics.wy), physics.weight, phys_acc)
+        preds = preds.float()
         I_p = sI.inverse_transform(preds[:, :nel]).clamp_min(1e-8)
         if kind == "pinn":
             v_p = sD.inverse_transform(preds[:, nel:2 * nel + 1])
             t_p = sR.inverse_transform(preds[:, 2 * nel + 1:])
         else:
             v_p, t_p = pin[1], pin[2]
-        return fe_residual_loss(I_p, v_p, t_p, px, pE, pfix, pin[0], pwy)
+        return physics.weight * fe_residual_loss(I_p, v_p, t_p, px, pE, pfix, pin[0], pwy).float()
 
     # the loss launch adds every step's value to the epoch's running sum itself (zeroed per epoch): no add node per step
     loss_acc = torch.zeros((), dtype=torch.float32, device=device) if (on_gpu and _FUSED_LOSS and engine is None and physics is None and os.environ.get("OPS_AMD_LOSS_ACC", "1") == "1") else None
@@ -704,7 +718,7 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
                 if alpha_term:
                     loss = loss + (cfg.initial_alpha - crit.alpha) ** 2   # TFD:743 / FNN (constant 0: alpha never trains)
         if physics is not None:
-            loss = loss + physics.weight * physics_loss(preds.float(), pin).float()
+            loss = loss + physics_loss(preds, pin)
         global _WGRAD_QUEUE
         _WGRAD_QUEUE = [] if (g_stash and _GROUP_WGRAD) else None       # split-row weight gradients: one grouped launch after backward
         try:
