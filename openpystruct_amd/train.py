@@ -654,7 +654,6 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
         pwy = torch.tensor(float(physics.wy), dtype=torch.float64, device=device)    # inside a captured step
 
     _FUSED_PHYS = on_gpu and os.environ.get("OPS_AMD_FUSED_PHYSICS", "1") == "1"      # A/B switch: 0 = physics.fe_residual_loss from framework ops
-    phys_acc = None      # (the step's total -- data loss + this term -- is accumulated by the loop below)
 
     def physics_inputs(rows, out=None):
         """Per-batch loads (and, for the I-only models, recorded displacement fields); `out`: the graph's static buffers.
@@ -676,7 +675,7 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
         if _FUSED_PHYS:          # three launches; the value is already weighted and enters the total with weight one
             from .physics import fused_residual_term
             disp = (sD, sR) if kind == "pinn" else (v_rec, t_rec)
-            return fused_residual_term(preds, nel, sI, disp, pin[0], Fy_tr, px, float(physics.E), pfix, float(physics.wy), physics.weight, phys_acc)
+            return fused_residual_term(preds, nel, sI, disp, pin[0], Fy_tr, px, float(physics.E), pfix, float(physics.wy), physics.weight, loss_acc)
         preds = preds.float()
         I_p = sI.inverse_transform(preds[:, :nel]).clamp_min(1e-8)
         if kind == "pinn":
@@ -687,7 +686,8 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
         return physics.weight * fe_residual_loss(I_p, v_p, t_p, px, pE, pfix, pin[0], pwy).float()
 
     # the loss launch adds every step's value to the epoch's running sum itself (zeroed per epoch): no add node per step
-    loss_acc = torch.zeros((), dtype=torch.float32, device=device) if (on_gpu and _FUSED_LOSS and engine is None and physics is None and os.environ.get("OPS_AMD_LOSS_ACC", "1") == "1") else None
+    # (with the fused physics term both launches add into the same running sum: the epoch's total of data loss + term)
+    loss_acc = torch.zeros((), dtype=torch.float32, device=device) if (on_gpu and _FUSED_LOSS and engine is None and (physics is None or _FUSED_PHYS) and os.environ.get("OPS_AMD_LOSS_ACC", "1") == "1") else None
     if on_gpu and engine is None and os.environ.get("OPS_AMD_ADAM_ZERO", "1") == "1":
         opt.zero_grads = True            # `flat` starts zeroed (allocation) and every update leaves it zeroed
 
