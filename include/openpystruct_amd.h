@@ -586,6 +586,7 @@ typedef struct ops_tfd_head_args {
   const float* targets; void* grad; double* loss_part; const float* alpha; const float* min_constraint; const float* max_constraint;
   float box_weight;
   int32_t identity_act;                               /* as ops_tfd_layer_args (the head's ReLU) */
+  const long long* target_rows;                       /* NULL: row b of `targets`; else row target_rows[b] (the front end's idx_out) */
 } ops_tfd_head_args;
 int ops_tfd_head_fwd(const ops_tfd_head_args* args, void* stream);
 typedef struct ops_tfd_head_bwd_args {
@@ -616,6 +617,12 @@ typedef struct ops_tfd_front_args {
   void* xn16; void* h; float* sa; float* sb; float* z; void* z16;
   long long* t_out; float* eps_out;
   int32_t identity_act;                               /* as ops_tfd_layer_args (the diffusion MLP's ReLU) */
+  /* r04 (ABI 10): the launch assembles its own batch (what ops_gather_rows_noise_targets_f32 did in a launch of its own per step).
+   * order != NULL: sample b is row order[*cursor + b] of `src` [.., Nc d] float32, plus sigma[0] * N(0, 1) from the assembly's stream
+   * (in_seed, the counter's value c at entry; csrc/input_noise.hpp) -- `x` is not read; the diffusion draws use c + 1 (as if the
+   * assembly launch had run and advanced the counter); idx_out[b] = that row (the head's loss reads its targets by it); the last
+   * workgroup advances counter[0] (layout [calls, tally]: csrc/call_counter.hpp) and *cursor += B. */
+  const float* src; const long long* order; long long* cursor; long long* idx_out; const float* sigma; unsigned long long in_seed;
 } ops_tfd_front_args;
 int ops_tfd_front_fwd(const ops_tfd_front_args* args, void* stream);
 typedef struct ops_tfd_front_bwd_args {

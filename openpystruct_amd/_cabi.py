@@ -162,7 +162,7 @@ class TfdHeadArgs(ctypes.Structure):
                 ("eps", _f), ("W2", _vp), ("b2", _vp), ("p_drop", _f), ("seed", _u), ("counter", _vp), ("used_call", _vp),
                 ("a16", _vp), ("mean", _vp), ("rstd", _vp), ("h", _vp), ("out", _vp),
                 ("targets", _vp), ("grad", _vp), ("loss_part", _vp), ("alpha", _vp), ("min_constraint", _vp), ("max_constraint", _vp),
-                ("box_weight", _f), ("identity_act", _i)]
+                ("box_weight", _f), ("identity_act", _i), ("target_rows", _vp)]
 
 
 class TfdHeadBwdArgs(ctypes.Structure):
@@ -187,7 +187,8 @@ class TfdFrontArgs(ctypes.Structure):
     _vp, _i, _u = ctypes.c_void_p, ctypes.c_int32, ctypes.c_ulonglong
     _fields_ = [("B", _i), ("Nc", _i), ("d", _i), ("hid", _i), ("T", _i), ("x", _vp), ("alpha_cumprod", _vp), ("seed", _u), ("counter", _vp),
                 ("W0", _vp), ("b0", _vp), ("W2", _vp), ("b2", _vp), ("cls", _vp), ("pe", _vp),
-                ("xn16", _vp), ("h", _vp), ("sa", _vp), ("sb", _vp), ("z", _vp), ("z16", _vp), ("t_out", _vp), ("eps_out", _vp), ("identity_act", _i)]
+                ("xn16", _vp), ("h", _vp), ("sa", _vp), ("sb", _vp), ("z", _vp), ("z16", _vp), ("t_out", _vp), ("eps_out", _vp), ("identity_act", _i),
+                ("src", _vp), ("order", _vp), ("cursor", _vp), ("idx_out", _vp), ("sigma", _vp), ("in_seed", _u)]
 
 
 class TfdFrontBwdArgs(ctypes.Structure):

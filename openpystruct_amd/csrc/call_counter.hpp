@@ -29,4 +29,19 @@ __device__ __forceinline__ void call_counter_done(unsigned long long* counter, u
   }
 }
 
+// the same, and thread 0 of the LAST reporting workgroup gets true (it may then advance other per-launch state, e.g. a batch cursor)
+__device__ __forceinline__ bool call_counter_done_last(unsigned long long* counter, unsigned reporters) {
+  __syncthreads();
+  bool last = false;
+  if (threadIdx.x == 0) {
+    const unsigned long long done = atomicAdd(counter + 1, 1ull);
+    if (done + 1ull == (unsigned long long)reporters) {
+      atomicExch(counter + 1, 0ull);
+      atomicAdd(counter, 1ull);
+      last = true;
+    }
+  }
+  return last;
+}
+
 }  // namespace opsamd

@@ -37,6 +37,7 @@ FRONT = os.environ.get("OPS_AMD_TFD_FRONT", "1") == "1"               # A/B swit
 LN_PARTIALS = os.environ.get("OPS_AMD_TFD_LN_PARTIALS", "1") == "1"   # A/B switch: 0 = LayerNorm gamma / beta gradients by float atomics in the layer launch
 HEAD = os.environ.get("OPS_AMD_TFD_HEAD", "1") == "1"                 # A/B switch: 0 = the head as four launches per direction
 IDENTITY_ACT = False      # verification only (tests): every ReLU of the one-launch kernels becomes the identity -- a smooth network
+FRONT_GATHER = os.environ.get("OPS_AMD_TFD_FRONT_GATHER", "1") == "1"   # A/B switch: 0 = the batch assembly as a launch of its own per step
 HEAD_LOSS = os.environ.get("OPS_AMD_TFD_HEAD_LOSS", "1") == "1"       # A/B switch: 0 = the training loss as launches of its own behind the head
 LAYER_BWD = os.environ.get("OPS_AMD_TFD_LAYER_BWD", "1") == "1"       # A/B switch: 0 = eight launches per layer backward instead of one
 
@@ -553,11 +554,19 @@ class FrontFn(torch.autograd.Function):
         keep = st.keep_draws or KEEP_DRAWS
         t = torch.empty(rows, dtype=torch.int64, device=dev) if keep else None
         eps = torch.empty((rows, d), **f32) if keep else None
+        st.gathered = False
+        gs = _GATHER if (_GATHER is not None and st.train_mode and st.external and st.counter.numel() >= 2) else None
+        if gs is not None and not (gs["src"].shape[1] == Nc and gs["src"].shape[2] == d and gs["src"].device == dev):
+            gs = None
         a = _cabi.TfdFrontArgs(identity_act=int(IDENTITY_ACT), B=B, Nc=Nc, d=d, hid=hid, T=int(dm.T), x=x.data_ptr(), alpha_cumprod=dm._acp.data_ptr(), seed=st.seed + 7919 * 100,
                                counter=st.counter.data_ptr(), W0=tiles["mlp0"][0].data_ptr(), b0=r0.b_sh.data_ptr(), W2=tiles["mlp2"][0].data_ptr(),
                                b2=r2.b_sh.data_ptr(), cls=model.cls_token.data_ptr(), pe=model.pos_encoder.pe.data_ptr(), xn16=xn16.data_ptr(),
                                h=h.data_ptr(), sa=sa.data_ptr(), sb=sb.data_ptr(), z=z.data_ptr(), z16=z16.data_ptr(),
                                t_out=t.data_ptr() if keep else None, eps_out=eps.data_ptr() if keep else None)
+        if gs is not None:      # the launch assembles its own batch: rows order[cursor .. cursor + B) of the training set + the input noise
+            a.src, a.order, a.cursor, a.idx_out = gs["src"].data_ptr(), gs["order"].data_ptr(), gs["cursor"].data_ptr(), gs["idx_out"].data_ptr()
+            a.sigma, a.in_seed = gs["sigma"].data_ptr(), gs["seed"]
+            st.gathered = True
         with torch.cuda.device(dev):
             _check(lib.ops_tfd_front_fwd(ctypes.byref(a), _stream(dev)), "ops_tfd_front_fwd")
         if keep:
@@ -645,6 +654,8 @@ class HeadFn(torch.autograd.Function):
             loss = torch.empty((), **f32)
             alpha, minc, maxc = crit.alpha.detach(), sc(crit.min_constraint), sc(crit.max_constraint)
             a.targets, a.grad, a.loss_part, a.alpha = targets.data_ptr(), grad.data_ptr(), part.data_ptr(), alpha.data_ptr()
+            if getattr(st, "gathered", False) and _GATHER is not None:      # the front end assembled this batch: targets by its row indices
+                a.targets, a.target_rows = _GATHER["targets"].data_ptr(), _GATHER["idx_out"].data_ptr()
             a.min_constraint = minc.data_ptr() if minc is not None else None
             a.max_constraint = maxc.data_ptr() if maxc is not None else None
             a.box_weight = float(crit.penalty_weight)
@@ -688,6 +699,38 @@ class HeadFn(torch.autograd.Function):
         train.shadow_param_grads(r2, g, h)
         train.shadow_param_grads(r1, d_a, x16.view(B, S, d)[:, 0, :])       # (row-strided operand: no copy of the [CLS] rows)
         return full, None, None, None, None, None
+
+
+_GATHER = None            # dict(src, order, cursor, idx_out, sigma, seed): armed by the training loop for a whole run (arm_gather)
+
+
+def arm_gather(src: torch.Tensor, targets: torch.Tensor, order: torch.Tensor, cursor: torch.Tensor, idx_out: torch.Tensor, sigma: torch.Tensor,
+               seed: int) -> None:
+    """From now on the fused front end of a patched model in training mode assembles its own batch: sample b = row order[cursor + b] of
+    `src` [n, Nc, d] float32 + sigma * N(0, 1) from the batch-assembly stream (`seed`, the shared step counter), the tensor handed to
+    `model(x)` only gives the batch size; idx_out [>= B] receives the rows, through which the head's loss-on-the-tile reads rows of
+    `targets` [n, C] float32 (the step must arm it: arm_head_loss); the launch advances the step counter and `cursor` itself.
+    `disarm_gather()` ends it."""
+    global _GATHER
+    assert src.dtype == torch.float32 and src.is_contiguous() and src.dim() == 3 and order.dtype == torch.int64 and cursor.dtype == torch.int64
+    assert targets.dtype == torch.float32 and targets.is_contiguous() and targets.dim() == 2 and targets.shape[0] == src.shape[0]
+    _GATHER = dict(src=src, targets=targets, order=order, cursor=cursor, idx_out=idx_out, sigma=sigma, seed=int(seed) & 0x7FFFFFFFFFFFFFFF)
+
+
+def disarm_gather() -> None:
+    global _GATHER
+    _GATHER = None
+
+
+def gather_fusable(model: nn.Module, device, d: int) -> bool:
+    """Whether a patched model's training forward will run the fused front end AND the head with the loss on its tile (the two launches that
+    take over the batch assembly's work)."""
+    enc = getattr(model, "transformer_encoder", None)
+    if enc is None or "forward" not in model.__dict__ or getattr(enc, "_ops_step_counter", None) is None:
+        return False
+    st = _State(torch.device(device), 1, True, enc._ops_step_counter)
+    return bool(FRONT_GATHER and HEAD_LOSS and st.external and st.counter.numel() >= 2 and _front_fused_ok(model, st, d) and _head_fused_ok(model, st, d)
+                and enc.norm is None and all(_layer_fused_ok(l, st) for l in enc.layers))
 
 
 _PENDING_LOSS = None      # (targets, criterion, alpha0, running sum): armed by the training step for ITS next forward pass

@@ -636,6 +636,21 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
         nb_tr = int(t.item())
     use_ac = device.type == "cuda" and autocast_dtype is not None
     hist = {"train": [], "val": [], "epoch_s": []}
+    # Transformer-Diffusion fast path, r04: the front-end launch assembles its own batch (rows order[cursor ..] of the training set + the
+    # input noise) and the head's loss reads its targets through those rows: no batch-assembly launch per step.  The epoch's permutation
+    # lives in `g_order`, `g_cursor` is advanced by the launch itself (reset per epoch).
+    fuse_gather = False
+    g_order = g_cursor = g_noise = None
+    if (fast_encoder is not None and shared_counter and physics is None and _FUSED_LOSS and Xtr.dtype == torch.float32 and Xtr.dim() == 3
+            and Xtr.is_contiguous() and Ytr.dtype == torch.float32 and Ytr.is_contiguous() and Ytr.dim() == 2):
+        from . import tfd_fused
+        if tfd_fused.gather_fusable(model, device, int(Xtr.shape[2])):
+            fuse_gather = True
+            g_order = torch.arange(max(int(Xtr.shape[0]), cfg.batch_size), device=device) % int(Xtr.shape[0])
+            g_cursor = torch.zeros((), dtype=torch.int64, device=device)
+            g_noise = torch.zeros((), device=device)
+            g_idx = torch.zeros(max(cfg.batch_size, 1), dtype=torch.int64, device=device)
+            tfd_fused.arm_gather(Xtr, Ytr, g_order, g_cursor, g_idx, g_noise, (seed * 7919 + 13 + rank) & 0x7FFFFFFFFFFFFFFF)
 
     if physics is not None:
         if cfg.n_cases != 1 or data.Fy_train is None:
@@ -990,13 +1005,19 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
         noise_t = torch.tensor(noise, device=device)
         if graph is not None:
             s_noise.copy_(noise_t)                                           # constant within the epoch
+        if fuse_gather:                                                      # the front-end launch walks this permutation with its own cursor
+            g_order[:order.numel()].copy_(order)
+            g_cursor.zero_()
+            g_noise.copy_(noise_t)
         for b in range(nb_tr):
             # `order` is the DataLoader shuffle; permute_data (PINN:753) re-permutes inside the batch, which
             # changes neither the batch statistics nor the mean loss, so it is folded into `order`
             idx = order[b * bs:(b + 1) * bs]
             if graph is not None and idx.numel() == bs:
                 got_y = False
-                if _FUSED_PREP or engine is not None:
+                if fuse_gather:
+                    got_y = True                                             # (the captured step's first launch assembles the batch itself)
+                elif _FUSED_PREP or engine is not None:
                     got_y = gather_noise(idx, sX, sY)                        # gather + noise (+ bf16 cast) + targets in one launch
                 else:
                     torch.index_select(Xtr, 0, idx, out=sX)                  # gather straight into the graph's input buffers
@@ -1030,6 +1051,8 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
                 got_y = False
                 if engine is not None:
                     got_y = gather_noise(idx, None)                          # into the engine's buffers
+                elif fuse_gather:
+                    got_y = True
                 elif _FUSED_PREP:
                     got_y = gather_noise(idx, sXt, sYt)
                 else:
@@ -1044,7 +1067,7 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
             elif engine is not None:
                 train_step(None, Ytr[:idx.numel()], noise_t, idx)            # Yb only carries the row count here
             else:
-                if shared_counter:
+                if shared_counter and not fuse_gather:
                     prep_counter[0:1].add_(1)                                # (no batch-assembly launch on this path: advance the streams here)
                 step_loss = train_step(Xtr[idx], Ytr[idx], noise_t, idx)
                 if loss_acc is None:
@@ -1132,6 +1155,7 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
     disable_shadow_linears(patched)      # the returned model is a plain module again
     if fast_encoder is not None:
         from . import tfd_fused
+        tfd_fused.disarm_gather()
         tfd_fused.unpatch_model(fast_encoder)
     if hasattr(model, "direct_param_grads"):
         model.direct_param_grads = False

@@ -591,6 +591,32 @@ def test_tfd_training_paths_agree_epoch_for_epoch_without_randomness(monkeypatch
         assert dev.max() < 5e-3, (key, dev)
 
 
+def test_front_end_assembling_its_own_batch_reproduces_the_assembly_launch(monkeypatch, tfd_data):
+    """r04: the front-end launch gathers rows order[cursor ..] of the training set, adds the assembly's input noise (same stream: seed, step
+    counter, element index) and advances counter and cursor itself; the head's loss reads its targets through the gathered rows -- against
+    the same run with the batch assembly as a launch of its own per step (OPS_AMD_TFD_FRONT_GATHER=0's path).  Same draws everywhere, so
+    the loss histories agree to the order of the float atomics that accumulate the gradients (dropout and noise ON: any slip in a counter
+    or an index would change every mask)."""
+    from openpystruct_amd import tfd_fused, train
+    n_tr, order = int(tfd_data.X_train.shape[0]), {}
+
+    def batch_order(epoch):
+        if epoch not in order:
+            order[epoch] = torch.randperm(n_tr, generator=torch.Generator().manual_seed(77 + epoch))
+        return order[epoch]
+
+    hist = {}
+    for fused in (True, False):
+        monkeypatch.setattr(tfd_fused, "FRONT_GATHER", fused)
+        out = train.train_surrogate("tfd", tfd_data, device="cuda", max_epochs=4, seed=3, batch_order=batch_order)
+        hist[fused] = out["history"]
+        assert tfd_fused._GATHER is None                     # disarmed at the end of the run
+    for key in ("train", "val"):
+        a, b = np.array(hist[True][key]), np.array(hist[False][key])
+        assert np.all(np.isfinite(a)) and np.abs(a / b - 1.0).max() < 2e-3, (key, a, b)
+    assert hist[True]["train"][-1] < 0.97 * hist[True]["train"][0]
+
+
 @pytest.mark.stochastic
 def test_tfd_training_paths_draw_from_the_same_process(monkeypatch, tfd_data):
     """The reference's configuration (dropout 0.1, diffusion + input noise on), different random streams on the two paths: three seeds,
