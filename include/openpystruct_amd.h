@@ -598,6 +598,10 @@ typedef struct ops_tfd_head_bwd_args {
   /* r04 (ABI 10): loss_part != NULL: workgroup 0 finishes the loss of the forward launch: loss[0] = the value (+ (alpha0 - alpha)^2 unless
    * alpha0 is NaN), loss_sum[0] += it (may be NULL). */
   const double* loss_part; const float* alpha; float alpha0; float box_weight; float* loss; float* loss_sum;
+  /* g2 != NULL: the gradient is g + g2 (both bfloat16 [B, C], the sum rounded to bfloat16 as the framework's addition rounds it): the
+   * launch's own loss gradient plus what another term (the FE-residual one) put on the predictions; g_sum (may be NULL, may be g)
+   * receives the sum -- the weight-gradient product of the output layer reads it. */
+  const void* g2; void* g_sum;
 } ops_tfd_head_bwd_args;
 int ops_tfd_head_bwd(const ops_tfd_head_bwd_args* args, void* stream);
 

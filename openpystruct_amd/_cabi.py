@@ -170,7 +170,7 @@ class TfdHeadBwdArgs(ctypes.Structure):
     _vp, _i, _f = ctypes.c_void_p, ctypes.c_int32, ctypes.c_float
     _fields_ = [("B", _i), ("S", _i), ("d", _i), ("hid", _i), ("C", _i), ("g", _vp), ("Wt2", _vp), ("Wt1", _vp), ("gamma", _vp), ("p_drop", _f),
                 ("a16", _vp), ("mean", _vp), ("rstd", _vp), ("h", _vp), ("d_a", _vp), ("dcls_rows", _vp), ("dgamma", _vp), ("dbeta", _vp),
-                ("loss_part", _vp), ("alpha", _vp), ("alpha0", _f), ("box_weight", _f), ("loss", _vp), ("loss_sum", _vp)]
+                ("loss_part", _vp), ("alpha", _vp), ("alpha0", _f), ("box_weight", _f), ("loss", _vp), ("loss_sum", _vp), ("g2", _vp), ("g_sum", _vp)]
 
 
 class PhysicsLossArgs(ctypes.Structure):

@@ -1091,7 +1091,16 @@ __global__ __launch_bounds__(64 * SL_NW) void tfd_head_bwd_kernel(const ops_tfd_
   const float inv_g = 1.0f / (float)gpr;
   const int gr = (int)(((float)tid + 0.5f) * inv_g), gq = tid - gr * gpr;
   const bool gok = gr < nrows;
-  const uint2 gin = *(const uint2*)((const uint16_t*)a.g + (long)(b0 + (gok ? gr : 0)) * C + 4 * (gok ? gq : 0));
+  uint2 gin = *(const uint2*)((const uint16_t*)a.g + (long)(b0 + (gok ? gr : 0)) * C + 4 * (gok ? gq : 0));
+  if (a.g2) {                                              // a second gradient on the predictions: g + g2 as a bfloat16 addition rounds it
+    const uint2 g2 = *(const uint2*)((const uint16_t*)a.g2 + (long)(b0 + (gok ? gr : 0)) * C + 4 * (gok ? gq : 0));
+    const uint32_t s0 = sl_f2bf(__uint_as_float(gin.x << 16) + __uint_as_float(g2.x << 16));
+    const uint32_t s1 = sl_f2bf(__uint_as_float(gin.x & 0xffff0000u) + __uint_as_float(g2.x & 0xffff0000u));
+    const uint32_t s2 = sl_f2bf(__uint_as_float(gin.y << 16) + __uint_as_float(g2.y << 16));
+    const uint32_t s3 = sl_f2bf(__uint_as_float(gin.y & 0xffff0000u) + __uint_as_float(g2.y & 0xffff0000u));
+    gin = uint2{s0 | (s1 << 16), s2 | (s3 << 16)};
+    if (a.g_sum && gok) *(uint2*)((uint16_t*)a.g_sum + (long)(b0 + gr) * C + 4 * gq) = gin;      // (may be `g` itself: own elements only)
+  }
   const int pr = tid >> 5, pq = tid & 31;
   const bool pok = pr < nrows && 8 * pq < hid;
   const long poff = (long)(b0 + (pr < nrows ? pr : 0)) * hid + (8 * pq < hid ? 8 * pq : 0);

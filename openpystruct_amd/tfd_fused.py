@@ -555,7 +555,7 @@ class FrontFn(torch.autograd.Function):
         t = torch.empty(rows, dtype=torch.int64, device=dev) if keep else None
         eps = torch.empty((rows, d), **f32) if keep else None
         st.gathered = False
-        gs = _GATHER if (_GATHER is not None and st.train_mode and st.external and st.counter.numel() >= 2) else None
+        gs = _GATHER if (_GATHER is not None and _GATHER["owner"] is model and st.train_mode and st.external and st.counter.numel() >= 2) else None
         if gs is not None and not (gs["src"].shape[1] == Nc and gs["src"].shape[2] == d and gs["src"].device == dev):
             gs = None
         a = _cabi.TfdFrontArgs(identity_act=int(IDENTITY_ACT), B=B, Nc=Nc, d=d, hid=hid, T=int(dm.T), x=x.data_ptr(), alpha_cumprod=dm._acp.data_ptr(), seed=st.seed + 7919 * 100,
@@ -665,8 +665,9 @@ class HeadFn(torch.autograd.Function):
         ctx.save_for_backward(x16, a16, mean, rstd, h)
         ctx.cfg = (model, B, S, d, hid, C, p, st, (r1, r2))
         if ctx.loss is not None:
-            ctx.mark_non_differentiable(out)
-            ctx.set_materialize_grads(False)        # (no zero tensor -- a fill node per step -- for the predictions' absent gradient)
+            # (the predictions stay differentiable: a physics term may hang on them; without one their gradient is absent -- and with
+            #  materialisation off no zero tensor, i.e. no fill node per step, is made for it)
+            ctx.set_materialize_grads(False)
             return out, ctx.loss[2]
         return out
 
@@ -679,8 +680,13 @@ class HeadFn(torch.autograd.Function):
         tiles = model.transformer_encoder._ops_extra_tiles
         dev = x16.device
         if ctx.loss is not None:
-            g = ctx.loss[0]                     # the forward launch's own d loss / d out (the loss enters the total with weight one)
+            # the forward launch's own d loss / d out (the loss enters the total with weight one) + whatever else hangs on the predictions
+            g2 = None
+            if g is not None:
+                g2 = g.contiguous() if g.dtype == torch.bfloat16 else g.to(torch.bfloat16)
+            g = ctx.loss[0]                     # (g2: summed into it by the launch below, in place)
         else:
+            g2 = None
             g = g.contiguous()
             if g.dtype != torch.bfloat16:
                 g = g.to(torch.bfloat16)
@@ -694,6 +700,8 @@ class HeadFn(torch.autograd.Function):
             _, part, loss, alpha, alpha0, bw, acc = ctx.loss[:7]
             a.loss_part, a.alpha, a.alpha0, a.box_weight, a.loss = part.data_ptr(), alpha.data_ptr(), alpha0, bw, loss.data_ptr()
             a.loss_sum = acc.data_ptr() if acc is not None else None
+        if g2 is not None:
+            a.g2, a.g_sum = g2.data_ptr(), g.data_ptr()
         with torch.cuda.device(dev):
             _check(lib.ops_tfd_head_bwd(ctypes.byref(a), _stream(dev)), "ops_tfd_head_bwd")
         train.shadow_param_grads(r2, g, h)
@@ -704,9 +712,10 @@ class HeadFn(torch.autograd.Function):
 _GATHER = None            # dict(src, order, cursor, idx_out, sigma, seed): armed by the training loop for a whole run (arm_gather)
 
 
-def arm_gather(src: torch.Tensor, targets: torch.Tensor, order: torch.Tensor, cursor: torch.Tensor, idx_out: torch.Tensor, sigma: torch.Tensor,
-               seed: int) -> None:
-    """From now on the fused front end of a patched model in training mode assembles its own batch: sample b = row order[cursor + b] of
+def arm_gather(model: nn.Module, src: torch.Tensor, targets: torch.Tensor, order: torch.Tensor, cursor: torch.Tensor, idx_out: torch.Tensor,
+               sigma: torch.Tensor, seed: int) -> None:
+    """From now on the fused front end of THIS patched model in training mode assembles its own batch (any other model's passes are untouched:
+    a run that died before `disarm_gather` must not feed its tensors to the next one): sample b = row order[cursor + b] of
     `src` [n, Nc, d] float32 + sigma * N(0, 1) from the batch-assembly stream (`seed`, the shared step counter), the tensor handed to
     `model(x)` only gives the batch size; idx_out [>= B] receives the rows, through which the head's loss-on-the-tile reads rows of
     `targets` [n, C] float32 (the step must arm it: arm_head_loss); the launch advances the step counter and `cursor` itself.
@@ -714,7 +723,7 @@ def arm_gather(src: torch.Tensor, targets: torch.Tensor, order: torch.Tensor, cu
     global _GATHER
     assert src.dtype == torch.float32 and src.is_contiguous() and src.dim() == 3 and order.dtype == torch.int64 and cursor.dtype == torch.int64
     assert targets.dtype == torch.float32 and targets.is_contiguous() and targets.dim() == 2 and targets.shape[0] == src.shape[0]
-    _GATHER = dict(src=src, targets=targets, order=order, cursor=cursor, idx_out=idx_out, sigma=sigma, seed=int(seed) & 0x7FFFFFFFFFFFFFFF)
+    _GATHER = dict(owner=model, src=src, targets=targets, order=order, cursor=cursor, idx_out=idx_out, sigma=sigma, seed=int(seed) & 0x7FFFFFFFFFFFFFFF)
 
 
 def disarm_gather() -> None:

@@ -249,6 +249,18 @@ def clear_blas_workspaces() -> None:
         clear()
 
 
+class _TieTerms(torch.autograd.Function):
+    """Two scalar loss terms as one backward root without a launch: forward = a view of the first, backward = the root gradient to both."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        return a.view_as(a)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, g
+
+
 def _debug_nan(model, opt, flat, s_loss, epoch, b, sX, sY):
     """Diagnostics (OPS_AMD_DEBUG_NAN=1; run with OPS_AMD_ADAM_ZERO=0 to keep the gradients): first step with a non-finite value."""
     torch.cuda.synchronize()
@@ -565,6 +577,9 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
     rank = dist.get_rank() if world > 1 else 0
     torch.manual_seed(seed)            # identical initial weights on every rank
     model, crit = build_model_and_loss(kind, cfg, data, device)
+    if kind == "tfd" and device.type == "cuda":
+        from . import tfd_fused as _tf
+        _tf.disarm_gather()              # (whatever an earlier run that did not reach its end left armed)
     if init_fn is not None:
         init_fn(model)
     if sync_bn and world > 1:
@@ -641,7 +656,14 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
     # lives in `g_order`, `g_cursor` is advanced by the launch itself (reset per epoch).
     fuse_gather = False
     g_order = g_cursor = g_noise = None
-    if (fast_encoder is not None and shared_counter and physics is None and _FUSED_LOSS and Xtr.dtype == torch.float32 and Xtr.dim() == 3
+    _FUSED_PHYS = on_gpu and os.environ.get("OPS_AMD_FUSED_PHYSICS", "1") == "1"      # A/B switch: 0 = physics.fe_residual_loss from framework ops
+    # the loss launch adds every step's value to the epoch's running sum itself (zeroed per epoch): no add node per step
+    # (with the fused physics term both launches add into the same running sum: the epoch's total of data loss + term)
+    loss_acc = torch.zeros((), dtype=torch.float32, device=device) if (on_gpu and _FUSED_LOSS and engine is None and (physics is None or _FUSED_PHYS) and os.environ.get("OPS_AMD_LOSS_ACC", "1") == "1") else None
+    # the loss on the head's tile: its value exists once the head's backward launch has run, so a second term can only be tied to it
+    # (not added) -- which needs the running sum to carry the step values
+    head_loss_ok = fast_encoder is not None and _FUSED_LOSS and (physics is None or (_FUSED_PHYS and loss_acc is not None))
+    if (head_loss_ok and shared_counter and Xtr.dtype == torch.float32 and Xtr.dim() == 3
             and Xtr.is_contiguous() and Ytr.dtype == torch.float32 and Ytr.is_contiguous() and Ytr.dim() == 2):
         from . import tfd_fused
         if tfd_fused.gather_fusable(model, device, int(Xtr.shape[2])):
@@ -650,7 +672,7 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
             g_cursor = torch.zeros((), dtype=torch.int64, device=device)
             g_noise = torch.zeros((), device=device)
             g_idx = torch.zeros(max(cfg.batch_size, 1), dtype=torch.int64, device=device)
-            tfd_fused.arm_gather(Xtr, Ytr, g_order, g_cursor, g_idx, g_noise, (seed * 7919 + 13 + rank) & 0x7FFFFFFFFFFFFFFF)
+            tfd_fused.arm_gather(model, Xtr, Ytr, g_order, g_cursor, g_idx, g_noise, (seed * 7919 + 13 + rank) & 0x7FFFFFFFFFFFFFFF)
 
     if physics is not None:
         if cfg.n_cases != 1 or data.Fy_train is None:
@@ -668,12 +690,12 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
         pE = torch.tensor(float(physics.E), dtype=torch.float64, device=device)      # device scalars: nothing crosses PCIe
         pwy = torch.tensor(float(physics.wy), dtype=torch.float64, device=device)    # inside a captured step
 
-    _FUSED_PHYS = on_gpu and os.environ.get("OPS_AMD_FUSED_PHYSICS", "1") == "1"      # A/B switch: 0 = physics.fe_residual_loss from framework ops
-
     def physics_inputs(rows, out=None):
         """Per-batch loads (and, for the I-only models, recorded displacement fields); `out`: the graph's static buffers.
         Fused term (csrc/beam_residual.hip ops_physics_loss_*): only the ROW INDICES travel -- the launches gather by them."""
         if _FUSED_PHYS:
+            if fuse_gather:              # the front-end launch leaves the step's rows in g_idx
+                return (g_idx[:rows.numel()],)
             if out is None:
                 return (rows,)
             out[0].copy_(rows)
@@ -700,9 +722,6 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
             v_p, t_p = pin[1], pin[2]
         return physics.weight * fe_residual_loss(I_p, v_p, t_p, px, pE, pfix, pin[0], pwy).float()
 
-    # the loss launch adds every step's value to the epoch's running sum itself (zeroed per epoch): no add node per step
-    # (with the fused physics term both launches add into the same running sum: the epoch's total of data loss + term)
-    loss_acc = torch.zeros((), dtype=torch.float32, device=device) if (on_gpu and _FUSED_LOSS and engine is None and (physics is None or _FUSED_PHYS) and os.environ.get("OPS_AMD_LOSS_ACC", "1") == "1") else None
     if on_gpu and engine is None and os.environ.get("OPS_AMD_ADAM_ZERO", "1") == "1":
         opt.zero_grads = True            # `flat` starts zeroed (allocation) and every update leaves it zeroed
 
@@ -716,7 +735,7 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
             flat.zero_()                                                 # optimizer.zero_grad() (GPU: the update launch zeroes `flat` behind itself)
         with torch.autocast(device_type=device.type, dtype=autocast_dtype, enabled=use_ac):
             head_loss = None
-            if fast_encoder is not None and _FUSED_LOSS and physics is None:
+            if head_loss_ok:
                 # Transformer-Diffusion fast path: the loss on the head's output tile, finished by the head's backward launch
                 from . import tfd_fused
                 tfd_fused.arm_head_loss(Yb, crit, cfg.initial_alpha if alpha_term else None, loss_acc)
@@ -733,7 +752,10 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
                 if alpha_term:
                     loss = loss + (cfg.initial_alpha - crit.alpha) ** 2   # TFD:743 / FNN (constant 0: alpha never trains)
         if physics is not None:
-            loss = loss + physics_loss(preds, pin)
+            term = physics_loss(preds, pin)
+            # (with the running sum both launches have already added their values up: the step's scalar only roots the backward pass,
+            #  so the two terms are tied without an addition node -- its value is then the data loss alone)
+            loss = _TieTerms.apply(loss, term) if (loss_acc is not None and _FUSED_PHYS) else loss + term
         global _WGRAD_QUEUE
         _WGRAD_QUEUE = [] if (g_stash and _GROUP_WGRAD) else None       # split-row weight gradients: one grouped launch after backward
         try:
@@ -833,7 +855,9 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
         s_noise = torch.zeros((), device=device)
         sP = None
         if physics is not None:                  # static per-batch physics inputs, gathered before every replay
-            sP = tuple(torch.zeros_like(t[:bs]) for t in physics_inputs(torch.arange(bs, device=device)))
+            sP = physics_inputs(torch.arange(bs, device=device))
+            if not fuse_gather:          # (fused batch assembly: the rows are the front-end launch's own index output)
+                sP = tuple(torch.zeros_like(t[:bs]) for t in sP)
         snap = (copy.deepcopy(model.state_dict()), copy.deepcopy(opt.state_dict()))
         side = torch.cuda.Stream(device=device)
         side.wait_stream(torch.cuda.current_stream(device))
@@ -1023,7 +1047,7 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
                     torch.index_select(Xtr, 0, idx, out=sX)                  # gather straight into the graph's input buffers
                 if engine is None and not got_y:
                     torch.index_select(Ytr, 0, idx, out=sY)
-                if sP is not None:
+                if sP is not None and not fuse_gather:
                     physics_inputs(idx, out=sP)
                 if seg_ev is not None and len(seg_ev) < 4096:
                     ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
