@@ -522,6 +522,7 @@ __global__ __launch_bounds__(1024) void frame_factor_big_kernel(const FrameParam
 }  // namespace opsamd
 
 #include "frame_wave.hpp"
+#include "frame_tile.hpp"
 
 using namespace opsamd;
 
@@ -566,13 +567,22 @@ static bool use_wave_kernel(int kd) {
 // the assembly fused into the solve (plan built per call, frame_wave.hpp); OPS_AMD_FRAME_FUSED_ASM=0: separate assembly kernel (A/B)
 static bool fused_assembly() { const char* e = getenv("OPS_AMD_FRAME_FUSED_ASM"); return !(e && atoi(e) == 0); }
 
+// r04, measured alternative (frame_tile.hpp; fused assembly only): the window as an 8 x 8 lane grid of register tiles, OPS_AMD_FRAME_TILE=1.
+// Correct (same factor columns as the row-per-lane window up to the last bit of a few assembled entries) but slower on every size measured
+// (15 x 16: 4.2 - 5.2 ms against 3.7 - 3.9 per 12 288 frames; profiles/r04_notes.md 11), so the row-per-lane window stays the default.
+static bool use_tile_kernel() {
+  const char* e = getenv("OPS_AMD_FRAME_TILE");
+  return fused_assembly() && e && atoi(e) != 0;
+}
+
 // Does the wave-per-frame kernel serve this size?  Its four waves' LDS (right-hand sides + parking areas) must fit one CU, its
 // plan kernel one workgroup's LDS.  Frames beyond that (tall and narrow: thousands of equations) take the workgroup-per-frame
 // kernels, whose band streams through an LDS ring -- ops_frame_workspace_bytes and the solve decide with this one function.
 static bool wave_kernel_serves(int n_eq, int kd) {
   if (!use_wave_kernel(kd)) return false;
   const int W = fw_width(kd);
-  if (4 * fw_lds_doubles(n_eq, W) * sizeof(double) > 160 * 1024 - 64) return false;
+  const size_t per_wave = fw_lds_doubles(n_eq, W) > ft_lds_doubles(n_eq) ? fw_lds_doubles(n_eq, W) : ft_lds_doubles(n_eq);
+  if (4 * per_wave * sizeof(double) > 160 * 1024 - 64) return false;
   if (fused_assembly() ? n_eq > (1 << 20) : ((size_t)FW_SLAB * W + (size_t)n_eq) * sizeof(double) > LDS_MAX) return false;
   return true;
 }
@@ -588,14 +598,18 @@ static hipError_t launch_wave(const FrameParams& p, double* ws, hipStream_t s) {
   if (!(done.load(std::memory_order_acquire) & bit)) {
     e = hipFuncSetAttribute((const void*)frame_wave_kernel<W, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)frame_wave_kernel<W, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)frame_tile_kernel<W>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
     if (e != hipSuccess) return e;
     done.fetch_or(bit, std::memory_order_release);
   }
   void* plan_base = (char*)ws + (size_t)p.B * fw_frame_doubles(p.n_eq, p.kd) * sizeof(double);
   const FwPlan pl = fw_plan_at(plan_base, p.n_eq, p.Ne);
   const dim3 grid((unsigned)((p.B + 3) / 4));
-  if (fused_assembly()) {
-    hipLaunchKernelGGL(frame_plan_kernel, dim3(1), dim3(1024), (size_t)3 * (fw_groups(p.n_eq) + 2) * sizeof(int), s, p, W, plan_base);
+  if (use_tile_kernel()) {
+    hipLaunchKernelGGL(frame_plan_kernel, dim3(1), dim3(1024), (size_t)3 * (fw_groups(p.n_eq) + 2) * sizeof(int), s, p, W, plan_base, 8 * ft_M(W));
+    hipLaunchKernelGGL((frame_tile_kernel<W>), grid, dim3(256), 4 * ft_lds_doubles(p.n_eq) * sizeof(double), s, p, ws, pl);
+  } else if (fused_assembly()) {
+    hipLaunchKernelGGL(frame_plan_kernel, dim3(1), dim3(1024), (size_t)3 * (fw_groups(p.n_eq) + 2) * sizeof(int), s, p, W, plan_base, 0);
     hipLaunchKernelGGL((frame_wave_kernel<W, true>), grid, dim3(256), lds, s, p, ws, pl);
   } else {
     const size_t lds_asm = ((size_t)FW_SLAB * W + (size_t)p.n_eq) * sizeof(double);

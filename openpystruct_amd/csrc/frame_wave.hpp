@@ -131,13 +131,16 @@ __global__ __launch_bounds__(256) void frame_assemble_rows_kernel(const FramePar
 // trip (inertia gather + coefficients) per group.  (r02: entry -> element -> three gathers behind per-row pointers = seven
 // serialised round trips per group, 17 % of the solve.)  A group with more than 192 entries (nodes with more than four
 // elements) continues in extra blocks; a padded all-zero block serves the groups past the last equation.
+constexpr int FW_SLOT_BITS = 10;          // entry word: bit 31 valid | element << FW_SLOT_BITS | parking slot (r04: 10 bits -- the tile kernel parks rows at pitch 80)
+constexpr unsigned FW_SLOT_MASK = (1u << FW_SLOT_BITS) - 1u;
 constexpr int FW_KE = 3;                  // entry words a lane carries per group
 constexpr int FW_EPG = 64 * FW_KE;        // entries per block
 struct FwPlan {
   const int* hdr;            // [4]   [0] = number of extra blocks (0 for the reference's grid frames)
   const int* eq_dof;         // [n + 1]   index into loads[Nn*3]; [n] = 0
   const int* xstart;         // [ng + 2]  first extra block of a group (prefix sums); groups past the end: no extra blocks
-  const unsigned* ent;       // [nblk][FW_EPG]  bit 31 (valid) | element << 9 | (row in group) * fw_pitch(W) + column slot
+  const unsigned* ent;       // [nblk][FW_EPG]  bit 31 (valid) | element << FW_SLOT_BITS | parking slot: (row in group) * fw_pitch(W) + column slot
+                             //                  (tile kernel, frame_tile.hpp: (row in group) * FT_P + ft_col_slot(column mod ring))
   const double* ka;          // [nblk][FW_EPG]
   const double* kb;          // [nblk][FW_EPG]
   const double* rhs_base;    // [n + 1]; [n] = 0
@@ -164,8 +167,13 @@ __host__ __device__ inline FwPlan fw_plan_at(void* base, int n, int Ne) {
   return pl;
 }
 
-// one workgroup; LDS: 3 * (ng + 2) ints
-__global__ __launch_bounds__(1024) void frame_plan_kernel(const FrameParams p, int W, void* plan_base) {
+// parking slot of column `xc` (= equation mod ring) in a row of the tile kernel's parking area (frame_tile.hpp): lane (p, q) takes the
+// column slots 2 i, 2 i + 1 of residue q with one 16-byte read at 16 i + 2 q
+constexpr int FT_P = 80;                  // doubles per parked row: 64 permuted band slots, the right-hand side at 64
+__host__ __device__ inline int ft_col_slot(int xc) { return 16 * (xc >> 4) + 2 * (xc & 7) + ((xc >> 3) & 1); }
+
+// one workgroup; LDS: 3 * (ng + 2) ints.  ring > 0: parking slots of the tile kernel (ring = 8 M equations)
+__global__ __launch_bounds__(1024) void frame_plan_kernel(const FrameParams p, int W, void* plan_base, int ring) {
   extern __shared__ int s_plan[];
   const FwPlan pl = fw_plan_at(plan_base, p.n_eq, p.Ne);
   const int n = p.n_eq, ng = pl.ng, tid = threadIdx.x, T = blockDim.x;
@@ -196,6 +204,9 @@ __global__ __launch_bounds__(1024) void frame_plan_kernel(const FrameParams p, i
       for (int q = 0; q < 6; ++q) { const int eq = p.elem_eq[6 * e + q]; if (eq >= 0 && eq <= er) atomicAdd(&cnt[er / FW_G], 1); }
     }
   }
+  // rows between the last equation and the end of its group: unit diagonal (a pivot there divides nothing by zero; the row-per-lane
+  // kernel masks these rows anyway)
+  if (tid < FW_G && n + tid < FW_G * ng) atomicAdd(&cnt[(n + tid) / FW_G], 1);
   __syncthreads();
   if (tid == 0) {                            // extra blocks per group: exclusive scan (ng <= a few hundred)
     int acc = 0;
@@ -223,12 +234,22 @@ __global__ __launch_bounds__(1024) void frame_plan_kernel(const FrameParams p, i
         if (eq >= 0 && eq <= er) {
           const int pos = atomicAdd(&cur[g], 1), blk = pos / FW_EPG;
           const long idx = (long)(blk == 0 ? g : ng + 1 + xs_[g] + blk - 1) * FW_EPG + pos % FW_EPG;
-          ent[idx] = 0x80000000u | ((unsigned)e << 9) | (unsigned)((er % FW_G) * fw_pitch(W) + eq % W);
+          const int slot = ring > 0 ? (er % FW_G) * FT_P + ft_col_slot(eq % ring) : (er % FW_G) * fw_pitch(W) + eq % W;
+          ent[idx] = 0x80000000u | ((unsigned)e << FW_SLOT_BITS) | (unsigned)slot;
           ka[idx] = k_a[r][q];
           kb[idx] = k_b[r][q];
         }
       }
     }
+  }
+  if (tid < FW_G && n + tid < FW_G * ng) {
+    const int er = n + tid, g = er / FW_G;
+    const int pos = atomicAdd(&cur[g], 1), blk = pos / FW_EPG;
+    const long idx = (long)(blk == 0 ? g : ng + 1 + xs_[g] + blk - 1) * FW_EPG + pos % FW_EPG;
+    const int slot = ring > 0 ? (er % FW_G) * FT_P + ft_col_slot(er % ring) : (er % FW_G) * fw_pitch(W) + er % W;
+    ent[idx] = 0x80000000u | (unsigned)slot;                 // (element 0's inertia times kb = 0)
+    ka[idx] = 1.0;
+    kb[idx] = 0.0;
   }
 }
 
@@ -304,6 +325,72 @@ __device__ __forceinline__ void fw_take_group(FwState<W>& st, int g0, int lane, 
   }
 }
 
+// ---- backward substitution, blocked dot form: eight columns per pass, x_j = w_j - sum_t L[j+t][j] x_(j+t) ----
+// Lane (u, k) = (lane >> 3, lane & 7) works for column j_u = jb - u: it multiplies the rows  j_u + k + 1 + 8 m  of that
+// column (m < (W + 7) / 8: strided 64-byte runs of the column, x from LDS) and an 8-lane DPP sum gives every column's
+// contribution of the rows ABOVE the block (x known); the rows inside the block (L[j_v][j_u], v < u: loaded by all eight
+// lanes of group u into register v) follow as a serial chain of seven readlane + FMA.  ~80 VALU instructions per EIGHT
+// columns against 36 per column of the r02 form (one column per pass: coalesced column load, 64-lane DPP / readlane
+// reduction) and ~12 of the axpy form the narrow windows used (every lane walking its own column of L: up to kd cache
+// lines per load).  10 x 10: 1.93 -> 1.84 ms per 16 384 frames, 15 x 16: 3.94 -> 3.87 ms per 12 288, 5 x 5: 0.72 -> 0.66 ms
+// per 32 768, 3 x 3: 0.64 -> 0.59 ms per 65 536: what remains of the sweep is the stream of L out of HBM (all waves of a
+// round reach their sweep together), r03_notes section 4.
+template <int W>
+__device__ __forceinline__ void fw_backward(const double* __restrict__ rows, double* __restrict__ xs, int n, int kd, int lane) {
+  constexpr int MF = (W + 7) / 8;
+  const int u = lane >> 3, k = lane & 7;
+  xs[n + lane] = 0.0;                                     // rows past the last equation: x = 0 (the idle steps left garbage)
+  fw_fence();
+  double fA[MF], bA[7], fB[MF], bB[7];                   // the next block's L is in flight while a block is worked on (two
+                                                          // blocks ahead measured no faster: the sweep streams L from HBM)
+  auto issue = [&](int jb, double (&f)[MF], double (&bv)[7]) {      // unconditional loads from clamped addresses
+    const int ju = jb - u, jc = ju > 0 ? ju : 0;
+    const double* col = rows + (size_t)jc * W;
+#pragma unroll
+    for (int m = 0; m < MF; ++m) f[m] = col[k + 8 * m < W ? k + 8 * m : W - 1];
+#pragma unroll
+    for (int v = 0; v < 7; ++v) bv[v] = col[u - v - 1 > 0 ? u - v - 1 : 0];
+  };
+  auto block = [&](int jb, const double (&lf)[MF], const double (&lbv)[7]) {   // (jb < 0: every lane masked, no write)
+    const int ju = jb - u, jc = ju > 0 ? ju : 0;
+    const int kdj = ju >= 0 ? (kd < n - 1 - ju ? kd : n - 1 - ju) : 0;      // rows of this column below the diagonal
+    double acc0 = 0.0, acc1 = 0.0;
+#pragma unroll
+    for (int m = 0; m < MF; ++m) {
+      const int rel = k + 1 + 8 * m;
+      const bool far = rel <= kdj && (m > 0 || k >= u);   // rows above the block top (rel > u); inside the band
+      const double l = far ? lf[m] : 0.0;
+      const double x = xs[jc + rel];
+      if (m & 1) acc1 = __builtin_fma(l, x, acc1); else acc0 = __builtin_fma(l, x, acc0);
+    }
+    double s_ = acc0 + acc1;
+    s_ += fw_dpp<0xB1>(s_);                               // quad_perm [1,0,3,2]
+    s_ += fw_dpp<0x4E>(s_);                               // quad_perm [2,3,0,1]
+    s_ += fw_dpp<0x141>(s_);                              // row_half_mirror: the eight lanes of a group hold its sum
+    double t = xs[jc] - s_;
+#pragma unroll
+    for (int v = 0; v < 7; ++v) {                         // x of column j_v is final when its turn comes
+      const double xv = fw_readlane(t, 8 * v);
+      const double l = (v < u && u - v <= kdj) ? lbv[v] : 0.0;
+      t = __builtin_fma(-l, xv, t);
+    }
+    if (k == 0 && ju >= 0) xs[ju] = t;
+    fw_fence();
+  };
+#ifdef FW_SKIP_BACKWARD
+  int jb = -1;
+#else
+  int jb = n - 1;
+#endif
+  issue(jb, fA, bA);
+  for (; jb >= 0; jb -= 16) {                             // two blocks per pass: the buffers alternate without copies
+    issue(jb - 8, fB, bB);
+    block(jb, fA, bA);
+    issue(jb - 16, fA, bA);
+    block(jb - 8, fB, bB);
+  }
+}
+
 template <int W, bool FUSED>
 __device__ __forceinline__ void frame_wave_body(const FrameParams& p, double* __restrict__ wsf, double* __restrict__ lds, int lane, long b,
                                                 const FwPlan& pl) {
@@ -346,7 +433,7 @@ __device__ __forceinline__ void frame_wave_body(const FrameParams& p, double* __
     const double* ka = pl.ka + (size_t)gi * FW_EPG + lane;
     const double* kb = pl.kb + (size_t)gi * FW_EPG + lane;
 #pragma unroll
-    for (int k = 0; k < KE; ++k) { bi[k] = Ib[(eB[k] >> 9) & 0x3FFFFF]; ba[k] = ka[64 * k]; bb[k] = kb[64 * k]; }
+    for (int k = 0; k < KE; ++k) { bi[k] = Ib[(eB[k] >> FW_SLOT_BITS) & 0x1FFFFF]; ba[k] = ka[64 * k]; bb[k] = kb[64 * k]; }
     const int r = gB + (lane < G ? lane : 0);
     by1 = pl.rhs_base[r < n ? r : n];
     by2 = lb[dofB];
@@ -354,14 +441,14 @@ __device__ __forceinline__ void frame_wave_body(const FrameParams& p, double* __
   auto build_finish = [&]() {                               // ... accumulated into the (zeroed) stage
 #pragma unroll
     for (int k = 0; k < KE; ++k)
-      if ((int)eB[k] < 0) atomicAdd(&stage[eB[k] & 511u], __builtin_fma(bi[k], bb[k], ba[k]));
+      if ((int)eB[k] < 0) atomicAdd(&stage[eB[k] & FW_SLOT_MASK], __builtin_fma(bi[k], bb[k], ba[k]));
     if (n_extra != 0) {                                     // nodes with more than four elements: extra blocks, not prefetched
       const int gi = gB / G < pl.ng ? gB / G : pl.ng;
       for (int blk = pl.xstart[gi]; blk < pl.xstart[gi + 1]; ++blk)
         for (int k = 0; k < KE; ++k) {
           const size_t i = (size_t)(pl.ng + 1 + blk) * FW_EPG + lane + 64 * k;
           const unsigned w = pl.ent[i];
-          if ((int)w < 0) atomicAdd(&stage[w & 511u], __builtin_fma(Ib[(w >> 9) & 0x3FFFFF], pl.kb[i], pl.ka[i]));
+          if ((int)w < 0) atomicAdd(&stage[w & FW_SLOT_MASK], __builtin_fma(Ib[(w >> FW_SLOT_BITS) & 0x1FFFFF], pl.kb[i], pl.ka[i]));
         }
     }
     fw_fence();
@@ -461,70 +548,7 @@ __device__ __forceinline__ void frame_wave_body(const FrameParams& p, double* __
   }
   fw_fence();
 
-  // ---- backward substitution, blocked dot form: eight columns per pass, x_j = w_j - sum_t L[j+t][j] x_(j+t) ----
-  // Lane (u, k) = (lane >> 3, lane & 7) works for column j_u = jb - u: it multiplies the rows  j_u + k + 1 + 8 m  of that
-  // column (m < (W + 7) / 8: strided 64-byte runs of the column, x from LDS) and an 8-lane DPP sum gives every column's
-  // contribution of the rows ABOVE the block (x known); the rows inside the block (L[j_v][j_u], v < u: loaded by all eight
-  // lanes of group u into register v) follow as a serial chain of seven readlane + FMA.  ~80 VALU instructions per EIGHT
-  // columns against 36 per column of the r02 form (one column per pass: coalesced column load, 64-lane DPP / readlane
-  // reduction) and ~12 of the axpy form the narrow windows used (every lane walking its own column of L: up to kd cache
-  // lines per load).  10 x 10: 1.93 -> 1.84 ms per 16 384 frames, 15 x 16: 3.94 -> 3.87 ms per 12 288, 5 x 5: 0.72 -> 0.66 ms
-  // per 32 768, 3 x 3: 0.64 -> 0.59 ms per 65 536: what remains of the sweep is the stream of L out of HBM (all waves of a
-  // round reach their sweep together), r03_notes section 4.
-  {
-    constexpr int MF = (W + 7) / 8;
-    const int u = lane >> 3, k = lane & 7;
-    xs[n + lane] = 0.0;                                     // rows past the last equation: x = 0 (the idle steps left garbage)
-    fw_fence();
-    double fA[MF], bA[7], fB[MF], bB[7];                   // the next block's L is in flight while a block is worked on (two
-                                                            // blocks ahead measured no faster: the sweep streams L from HBM)
-    auto issue = [&](int jb, double (&f)[MF], double (&bv)[7]) {      // unconditional loads from clamped addresses
-      const int ju = jb - u, jc = ju > 0 ? ju : 0;
-      const double* col = rows + (size_t)jc * W;
-#pragma unroll
-      for (int m = 0; m < MF; ++m) f[m] = col[k + 8 * m < W ? k + 8 * m : W - 1];
-#pragma unroll
-      for (int v = 0; v < 7; ++v) bv[v] = col[u - v - 1 > 0 ? u - v - 1 : 0];
-    };
-    auto block = [&](int jb, const double (&lf)[MF], const double (&lbv)[7]) {   // (jb < 0: every lane masked, no write)
-      const int ju = jb - u, jc = ju > 0 ? ju : 0;
-      const int kdj = ju >= 0 ? (kd < n - 1 - ju ? kd : n - 1 - ju) : 0;      // rows of this column below the diagonal
-      double acc0 = 0.0, acc1 = 0.0;
-#pragma unroll
-      for (int m = 0; m < MF; ++m) {
-        const int rel = k + 1 + 8 * m;
-        const bool far = rel <= kdj && (m > 0 || k >= u);   // rows above the block top (rel > u); inside the band
-        const double l = far ? lf[m] : 0.0;
-        const double x = xs[jc + rel];
-        if (m & 1) acc1 = __builtin_fma(l, x, acc1); else acc0 = __builtin_fma(l, x, acc0);
-      }
-      double s_ = acc0 + acc1;
-      s_ += fw_dpp<0xB1>(s_);                               // quad_perm [1,0,3,2]
-      s_ += fw_dpp<0x4E>(s_);                               // quad_perm [2,3,0,1]
-      s_ += fw_dpp<0x141>(s_);                              // row_half_mirror: the eight lanes of a group hold its sum
-      double t = xs[jc] - s_;
-#pragma unroll
-      for (int v = 0; v < 7; ++v) {                         // x of column j_v is final when its turn comes
-        const double xv = fw_readlane(t, 8 * v);
-        const double l = (v < u && u - v <= kdj) ? lbv[v] : 0.0;
-        t = __builtin_fma(-l, xv, t);
-      }
-      if (k == 0 && ju >= 0) xs[ju] = t;
-      fw_fence();
-    };
-#ifdef FW_SKIP_BACKWARD
-    int jb = -1;
-#else
-    int jb = n - 1;
-#endif
-    issue(jb, fA, bA);
-    for (; jb >= 0; jb -= 16) {                             // two blocks per pass: the buffers alternate without copies
-      issue(jb - 8, fB, bB);
-      block(jb, fA, bA);
-      issue(jb - 16, fA, bA);
-      block(jb - 8, fB, bB);
-    }
-  }
+  fw_backward<W>(rows, xs, n, kd, lane);
   write_results(p, b, xs, bad != 0, lane, 64);
 }
 

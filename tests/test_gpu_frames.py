@@ -36,6 +36,39 @@ def test_grid_frames_vs_oracle(bays, stories):
         np.testing.assert_array_equal(sol.M[b].cpu().numpy(), sol.forces[b, :, 2].cpu().numpy())
 
 
+@pytest.mark.parametrize("bays,stories", [(2, 3), (5, 5), (10, 10), (15, 16), (16, 3)])
+def test_register_tile_mapping_of_the_window_vs_oracle(monkeypatch, bays, stories):
+    """The measured alternative of the wave-per-frame kernel (csrc/frame_tile.hpp, OPS_AMD_FRAME_TILE=1: the band window as an 8 x 8 lane
+    grid of register tiles; ring sizes 24 / 32 / 48 / 64 equations) against the oracle, and against the default kernel (same arithmetic per
+    entry: the displacements agree to the last bits -- the order of the LDS atomic additions of the assembly differs)."""
+    from openpystruct_amd import frames
+    topo = frames.grid_frame(bays, stories)
+    rng = np.random.default_rng(bays * 100 + stories)
+    B = 5
+    I = np.exp(rng.uniform(np.log(5e-5), np.log(5e-3), size=(B, topo.Ne)))
+    It = torch.as_tensor(I, device="cuda")
+    monkeypatch.setenv("OPS_AMD_FRAME_TILE", "0")
+    ref = frames.frame_solve(topo, It)
+    torch.cuda.synchronize()
+    monkeypatch.setenv("OPS_AMD_FRAME_TILE", "1")
+    sol = frames.frame_solve(topo, It)
+    torch.cuda.synchronize()
+    assert int(sol.status.abs().sum()) == 0
+    assert relerr(sol.disp.cpu().numpy().ravel(), ref.disp.cpu().numpy().ravel()) < 1e-12
+    for b in range(2):
+        d, f, st, neq, kd = _oracle(topo, I[b])
+        assert relerr(sol.disp[b].cpu().numpy().ravel(), d.ravel()) < 1e-8
+        assert relerr(sol.forces[b].cpu().numpy().ravel(), f.ravel()) < 1e-7
+    # a non-positive pivot is reported per frame, the others are untouched
+    Ib = It.clone()
+    Ib[1, 3] = -1.0
+    bad = frames.frame_solve(topo, Ib)
+    torch.cuda.synchronize()
+    st = bad.status.cpu().numpy()
+    assert st[1] == 1 and st[[0, 2, 3, 4]].sum() == 0
+    assert relerr(bad.disp[0].cpu().numpy().ravel(), sol.disp[0].cpu().numpy().ravel()) < 1e-12
+
+
 def test_frame_equilibrium_and_axial_udl_quirk():
     from openpystruct_amd import frames
     cfg = frames.FrameConfig()
