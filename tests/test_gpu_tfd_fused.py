@@ -628,11 +628,12 @@ def test_front_end_assembling_its_own_batch_reproduces_the_assembly_launch(monke
 def test_validation_as_one_forward_gives_the_per_batch_validation_loss(monkeypatch, tfd_data):
     """r04: the fast path's validation pass = one forward over all validation rows + the loss per reference batch on row slices, against
     the same run evaluating batch by batch (OPS_AMD_VAL_WHOLE=0).  No randomness (dropout 0, noise 0, alpha_cumprod 1), batch 32 so that
-    the validation set is several batches and a ragged last one: rows are independent in evaluation mode and each batch's loss is the same
-    arithmetic on the same bf16 predictions, so the validation history differs only as far as the training runs do (float atomics)."""
+    the validation set is several batches and a ragged last one, and learning rate 0 so that both runs evaluate the SAME weights (two
+    trainings drift apart by the order of their float atomics: up to 1 % after three epochs): rows are independent in evaluation mode and
+    each batch's loss is the same arithmetic on the same bf16 predictions -- the validation losses agree to float32 round-off."""
     from openpystruct_amd import train
     cfg = train.TfdConfig()
-    cfg.dropout_rate, cfg.sigma_0, cfg.batch_size = 0.0, 0.0, 32
+    cfg.dropout_rate, cfg.sigma_0, cfg.batch_size, cfg.learning_rate = 0.0, 0.0, 32, 0.0
     order = {}
 
     def batch_order(epoch):
@@ -644,13 +645,12 @@ def test_validation_as_one_forward_gives_the_per_batch_validation_loss(monkeypat
     hist = {}
     for whole in ("1", "0"):
         monkeypatch.setenv("OPS_AMD_VAL_WHOLE", whole)
-        out = train.train_surrogate("tfd", tfd_data, cfg, device="cuda", max_epochs=3, seed=4, batch_order=batch_order,
+        out = train.train_surrogate("tfd", tfd_data, cfg, device="cuda", max_epochs=2, seed=4, batch_order=batch_order,
                                     init_fn=lambda m: m.diffusion._acp.fill_(1.0))
         hist[whole] = out["history"]
-    for key in ("train", "val"):
-        a, b = np.array(hist["1"][key]), np.array(hist["0"][key])
-        assert np.all(np.isfinite(a)) and np.abs(a / b - 1.0).max() < 5e-3, (key, a, b)      # (later epochs: the runs' own atomic-order drift)
-    assert abs(hist["1"]["val"][0] / hist["0"]["val"][0] - 1.0) < 2e-5           # first epoch (measured: equal to the last digit)
+    a, b = np.array(hist["1"]["val"]), np.array(hist["0"]["val"])
+    assert np.all(np.isfinite(a)) and np.all(a > 0) and np.abs(a / b - 1.0).max() < 2e-6, (a, b)
+    assert abs(a[1] / a[0] - 1.0) < 2e-6                        # (nothing was learned: the two epochs evaluate the same weights)
 
 
 @pytest.mark.stochastic
