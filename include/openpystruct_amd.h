@@ -541,6 +541,9 @@ typedef struct ops_tfd_layer_args {
                                                          network whose gradients can be compared with float64 to bf16 rounding); 0 = the reference */
 } ops_tfd_layer_args;
 int ops_tfd_encoder_layer_fwd(const ops_tfd_layer_args* args, void* stream);
+/* Two consecutive layers (b->x32 == a->y32, same Bn / S / d) as ONE launch: a workgroup owns whole samples, so it runs layer b on the rows it
+ * has just written as layer a's output.  Same results as the two launches. */
+int ops_tfd_encoder_layer_pair_fwd(const ops_tfd_layer_args* a, const ops_tfd_layer_args* b, void* stream);
 
 /* The layer's BACKWARD pass as one launch: LayerNorm2 backward, d_h = d_f W_2, ReLU + dropout backward, d_y1 = d_u W_1 (+ the residual
  * branch), LayerNorm1 backward, d_ctx = d_a W_out, attention backward, dx = residual branch + dqkv W_in.  The incoming gradient is

@@ -63,6 +63,7 @@ EXPORTS = (
     "ops_diffusion_combine_bwd",
     "ops_hbm_copy16",
     "ops_tfd_encoder_layer_fwd",
+    "ops_tfd_encoder_layer_pair_fwd",
     "ops_diffusion_noise_draw",
     "ops_surrogate_loss_grad_sum_f32",
     "ops_gather_rows_noise_targets_f32",
@@ -254,6 +255,8 @@ def load():
     rj.argtypes = [it, it, vp, lg, vp, lg, vp, vp, lg] + [vp] * 10
     lib.ops_tfd_encoder_layer_fwd.restype = it
     lib.ops_tfd_encoder_layer_fwd.argtypes = [ctypes.POINTER(TfdLayerArgs), vp]
+    lib.ops_tfd_encoder_layer_pair_fwd.restype = it
+    lib.ops_tfd_encoder_layer_pair_fwd.argtypes = [ctypes.POINTER(TfdLayerArgs), ctypes.POINTER(TfdLayerArgs), vp]
     lib.ops_tfd_encoder_layer_bwd.restype = it
     lib.ops_tfd_encoder_layer_bwd.argtypes = [ctypes.POINTER(TfdLayerBwdArgs), vp]
     lib.ops_tfd_head_fwd.restype = it

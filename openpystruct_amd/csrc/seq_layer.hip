@@ -84,10 +84,11 @@ __device__ __forceinline__ void sl_lds_barrier() {
 // 102 SGPRs: the first builds spilled scalars into VGPR lanes -- 1 600 v_writelane / v_readlane of the kernel's 7 900 instructions.
 // The kernarg segment is constant memory (scalar loads); the empty asm makes the pointer opaque so that the field loads stay behind it.
 typedef const __attribute__((opencl_constant)) ops_tfd_layer_args* sl_args_ptr;
+template <int ARGOFF = 0>                  // byte offset of the argument block in the kernarg segment (the pair kernel carries two)
 __device__ __forceinline__ sl_args_ptr sl_late_args() {
   auto p = __builtin_amdgcn_kernarg_segment_ptr();
   __asm__ volatile("" : "+s"(p));
-  return (sl_args_ptr)p;
+  return (sl_args_ptr)((const __attribute__((opencl_constant)) char*)p + ARGOFF);
 }
 
 constexpr int SL_DHP = 16;          // head vectors padded to 16 elements in LDS (dh <= 16)
@@ -177,7 +178,8 @@ __device__ __forceinline__ void sl_zero_rows(uint16_t* s, int ls, int r0, int nc
 // and no product waits for a dependent round trip to L2 / the Infinity Cache.  Everything that leaves the kernel is first collected in
 // LDS rows and stored in 16-byte pieces by all threads (2- and 4-byte stores straight from the accumulator layout cost 2-3 us per
 // stage); the attention of a (sample, head, query) is shared by four lanes, four head dimensions each.
-__global__ __launch_bounds__(64 * SL_NW) void tfd_layer_fwd_kernel(const ops_tfd_layer_args a) {
+template <int ARGOFF>
+__device__ __forceinline__ void tfd_layer_fwd_body(const ops_tfd_layer_args& a) {
   constexpr int XS = 128 + 8;        // LDS row stride of the d-wide bf16 operands: rows 4 banks apart
   constexpr int HS = 256 + 8;        // ... of the ff-wide operand
   constexpr int QS = 384 + 8;        // ... of the unpadded q|k|v rows kept for the store (3 d <= 384)
@@ -282,7 +284,7 @@ __global__ __launch_bounds__(64 * SL_NW) void tfd_layer_fwd_kernel(const ops_tfd
 
   // ---- attention: four lanes per (sample, head, query), four head dimensions each ----
   {
-    const sl_args_ptr la = sl_late_args();
+    const sl_args_ptr la = sl_late_args<ARGOFF>();
     const DropKey key_attn = drop_key(la->seed_attn, call);   // scalar-unit work (csrc/dropout_stream.hpp)
     const float p_attn = la->p_attn;
     const float scale = rsqrtf((float)dh), ks = la->p_attn > 0.0f ? 1.0f / (1.0f - la->p_attn) : 1.0f;
@@ -350,7 +352,7 @@ __global__ __launch_bounds__(64 * SL_NW) void tfd_layer_fwd_kernel(const ops_tfd
   // order and the store loops below have trip counts the compiler cannot count through).
   __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
   SL_STAMP(3);
-  { const sl_args_ptr la = sl_late_args();
+  { const sl_args_ptr la = sl_late_args<ARGOFF>();
   sl_store_rows<2>(la->qkv, s_st, QS, 3 * d, row0, nrows, tid);
   sl_store_rows<2>(la->ctx, s_ctx, XS, d, row0, nrows, tid); }
   SL_STAMP(9);
@@ -360,7 +362,7 @@ __global__ __launch_bounds__(64 * SL_NW) void tfd_layer_fwd_kernel(const ops_tfd
   {
     float z[4];
     const sl_f32x4 acc = sl_mma_tile<4>(wo, s_ctx, XS, c, g);
-    const sl_args_ptr la = sl_late_args();
+    const sl_args_ptr la = sl_late_args<ARGOFF>();
     const DropKey key_1 = drop_key(la->seed_1, call);
     const float p_1 = la->p_1;
     const float ks = la->p_1 > 0.0f ? 1.0f / (1.0f - la->p_1) : 1.0f;
@@ -392,13 +394,13 @@ __global__ __launch_bounds__(64 * SL_NW) void tfd_layer_fwd_kernel(const ops_tfd
   }
   sl_lds_barrier();
   SL_STAMP(4);
-  { const sl_args_ptr la = sl_late_args();
+  { const sl_args_ptr la = sl_late_args<ARGOFF>();
   sl_store_rows<4>(la->z1, s_f32, FS, d, row0, nrows, tid);
   sl_store_rows<2>(la->y1_16, s_x, XS, d, row0, nrows, tid); }
 
   // ---- feed-forward 1: u = y1 W_1^T + b_1 (saved), h = dropout(ReLU(u)) -> LDS operand rows ----
   {
-    const sl_args_ptr la = sl_late_args();
+    const sl_args_ptr la = sl_late_args<ARGOFF>();
     const DropKey key_act = drop_key(la->seed_act, call);
     const float p_act = la->p_act;
     const float ks = la->p_act > 0.0f ? 1.0f / (1.0f - la->p_act) : 1.0f;
@@ -426,7 +428,7 @@ __global__ __launch_bounds__(64 * SL_NW) void tfd_layer_fwd_kernel(const ops_tfd
   }
   sl_lds_barrier();
   SL_STAMP(5);
-  { const sl_args_ptr la = sl_late_args();
+  { const sl_args_ptr la = sl_late_args<ARGOFF>();
   sl_store_rows<2>(la->u, s_st, QS, ff, row0, nrows, tid);
   sl_store_rows<2>(la->h, s_big, HS, ff, row0, nrows, tid); }
   SL_STAMP(12);
@@ -435,7 +437,7 @@ __global__ __launch_bounds__(64 * SL_NW) void tfd_layer_fwd_kernel(const ops_tfd
   {
     float z[4];
     const sl_f32x4 acc = sl_mma_tile<8>(w2, s_big, HS, c, g);
-    const sl_args_ptr la = sl_late_args();
+    const sl_args_ptr la = sl_late_args<ARGOFF>();
     const DropKey key_2 = drop_key(la->seed_2, call);
     const float p_2 = la->p_2;
     const float ks = la->p_2 > 0.0f ? 1.0f / (1.0f - la->p_2) : 1.0f;
@@ -472,11 +474,24 @@ __global__ __launch_bounds__(64 * SL_NW) void tfd_layer_fwd_kernel(const ops_tfd
     sl_store_rows<4>(la->y32, s_y2, FS, d, row0, nrows, tid);
     sl_store_rows<2>(la->y16, s_x, XS, d, row0, nrows, tid);
   }
-  { const sl_args_ptr la = sl_late_args(); if (blockIdx.x == 0 && tid == 0 && la->used_call) *(__attribute__((address_space(1))) unsigned long long*)la->used_call = call; }
+  { const sl_args_ptr la = sl_late_args<ARGOFF>(); if (blockIdx.x == 0 && tid == 0 && la->used_call) *(__attribute__((address_space(1))) unsigned long long*)la->used_call = call; }
   if (a.trace && tid == 0) {
     SL_STAMP(6);
     for (int k = 0; k < 16; ++k) a.trace[16 * (unsigned long long)blockIdx.x + k] = stamp[k];
   }
+}
+
+__global__ __launch_bounds__(64 * SL_NW) void tfd_layer_fwd_kernel(const ops_tfd_layer_args a) { tfd_layer_fwd_body<0>(a); }
+
+// Two consecutive layers in ONE launch (r04): a workgroup owns whole samples, so layer b's rows are the ones this workgroup has just
+// written as layer a's output -- no other workgroup's data is needed, only this workgroup's own stores have to have reached L2 (the
+// vector L1 of the CU holds no line of them: nothing here has read those addresses since the launch began).
+static_assert(sizeof(ops_tfd_layer_args) % 8 == 0, "second argument block of the pair kernel sits right behind the first");
+__global__ __launch_bounds__(64 * SL_NW) void tfd_layer_pair_fwd_kernel(const ops_tfd_layer_args a, const ops_tfd_layer_args b) {
+  tfd_layer_fwd_body<0>(a);
+  __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wave's stores of y32 are acknowledged
+  __syncthreads();
+  tfd_layer_fwd_body<(int)sizeof(ops_tfd_layer_args)>(b);
 }
 
 
@@ -1451,6 +1466,31 @@ extern "C" int ops_tfd_encoder_layer_fwd(const ops_tfd_layer_args* a, void* stre
   const int spw = 16 / a->S;
   const unsigned grid = (unsigned)((a->Bn + spw - 1) / spw);
   hipLaunchKernelGGL(opsamd::tfd_layer_fwd_kernel, dim3(grid), dim3(64 * opsamd::SL_NW), 0, (hipStream_t)stream, *a);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { opsamd::set_last_error(hipGetErrorString(e)); return OPS_AMD_ERR_LAUNCH; }
+  return OPS_AMD_OK;
+}
+
+static int tfd_layer_args_check(const ops_tfd_layer_args* a) {
+  if (!a || a->Bn < 1 || a->S < 1 || a->S > 8 || a->H < 1 || a->H > 8 || a->dh < 1 || a->dh > 16 || a->d != a->H * a->dh || a->d > 128 || a->d % 8 ||
+      a->ff < 16 || a->ff > 256 || a->ff % 8 || 3 * a->d > 16 * 3 * opsamd::SL_NW)
+    return OPS_AMD_ERR_UNSUPPORTED;
+  if ((((uintptr_t)a->W_in | (uintptr_t)a->W_out | (uintptr_t)a->W_1 | (uintptr_t)a->W_2 | (uintptr_t)a->x32) & 15) != 0) return OPS_AMD_ERR_UNSUPPORTED;
+  if (!a->x32 || !a->W_in || !a->b_in || !a->W_out || !a->b_out || !a->W_1 || !a->b_1 || !a->W_2 || !a->b_2 || !a->gamma1 || !a->beta1 || !a->gamma2 ||
+      !a->beta2 || !a->counter || !a->qkv || !a->ctx || !a->z1 || !a->mean1 || !a->rstd1 || !a->y1_16 || !a->u || !a->h || !a->z2 || !a->mean2 ||
+      !a->rstd2 || !a->y32 || !a->y16)
+    return OPS_AMD_ERR_INVALID_ARG;
+  return OPS_AMD_OK;
+}
+
+extern "C" int ops_tfd_encoder_layer_pair_fwd(const ops_tfd_layer_args* a, const ops_tfd_layer_args* b, void* stream) {
+  int rc = tfd_layer_args_check(a);
+  if (rc == OPS_AMD_OK) rc = tfd_layer_args_check(b);
+  if (rc != OPS_AMD_OK) return rc;
+  if (a->Bn != b->Bn || a->S != b->S || a->d != b->d || (const void*)b->x32 != (const void*)a->y32 || a->trace || b->trace) return OPS_AMD_ERR_INVALID_ARG;
+  const int spw = 16 / a->S;
+  const unsigned grid = (unsigned)((a->Bn + spw - 1) / spw);
+  hipLaunchKernelGGL(opsamd::tfd_layer_pair_fwd_kernel, dim3(grid), dim3(64 * opsamd::SL_NW), 0, (hipStream_t)stream, *a, *b);
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) { opsamd::set_last_error(hipGetErrorString(e)); return OPS_AMD_ERR_LAUNCH; }
   return OPS_AMD_OK;

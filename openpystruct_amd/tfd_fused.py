@@ -213,6 +213,10 @@ class ActDropout(torch.autograd.Function):
         return dx, None, None, None, None
 
 
+LAYER_PAIR_FWD = os.environ.get("OPS_AMD_TFD_LAYER_PAIR", "1") == "1"      # A/B switch: two consecutive layers' forward passes as one launch
+_PENDING_LAYER = None       # (argument block, output) of a layer whose forward launch waits for its successor
+
+
 class EncoderLayerFn(torch.autograd.Function):
     """One whole encoder layer.  Forward: ONE launch (csrc/seq_layer.hip: in-projection, attention, out-projection, dropout + add +
     LayerNorm, feed-forward, dropout + add + LayerNorm; bf16 MFMA products on the shadow weights, everything else as the separate
@@ -223,7 +227,8 @@ class EncoderLayerFn(torch.autograd.Function):
     the two input gradients travel separately and no add node is needed."""
 
     @staticmethod
-    def forward(ctx, x32, x16, layer, Bn, S, st: _State, li: int):
+    def forward(ctx, x32, x16, layer, Bn, S, st: _State, li: int, defer: bool = False):
+        global _PENDING_LAYER
         lib = _cabi.load()
         mha = layer.self_attn
         H, d = mha.num_heads, mha.embed_dim
@@ -253,7 +258,16 @@ class EncoderLayerFn(torch.autograd.Function):
             mean1=mean1.data_ptr(), rstd1=rstd1.data_ptr(), y1_16=y1_16.data_ptr(), u=u.data_ptr(), h=h.data_ptr(), z2=z2.data_ptr(),
             mean2=mean2.data_ptr(), rstd2=rstd2.data_ptr(), y32=y32.data_ptr(), y16=y16.data_ptr())
         with torch.cuda.device(dev):
-            _check(lib.ops_tfd_encoder_layer_fwd(ctypes.byref(a), _stream(dev)), "ops_tfd_encoder_layer_fwd")
+            if defer:                            # the next layer's call launches both (ops_tfd_encoder_layer_pair_fwd)
+                assert _PENDING_LAYER is None
+                _PENDING_LAYER = (a, y32)
+            elif _PENDING_LAYER is not None:
+                pa, py = _PENDING_LAYER
+                _PENDING_LAYER = None
+                assert py.data_ptr() == x32.data_ptr()
+                _check(lib.ops_tfd_encoder_layer_pair_fwd(ctypes.byref(pa), ctypes.byref(a), _stream(dev)), "ops_tfd_encoder_layer_pair_fwd")
+            else:
+                _check(lib.ops_tfd_encoder_layer_fwd(ctypes.byref(a), _stream(dev)), "ops_tfd_encoder_layer_fwd")
         ctx.save_for_backward(x16, qkv, ctxa, z1, mean1, rstd1, y1_16, u, h, z2, mean2, rstd2)
         ctx.cfg = (layer, Bn, S, H, dh, d, ff, ps, seeds, used, (rin, rout, r1, r2))
         ctx.set_materialize_grads(False)
@@ -262,7 +276,7 @@ class EncoderLayerFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g32, g16):
         if g32 is None and g16 is None:
-            return (None,) * 7
+            return (None,) * 8
         from . import train
         lib = _cabi.load()
         x16, qkv, ctxa, z1, mean1, rstd1, y1_16, u, h, z2, mean2, rstd2 = ctx.saved_tensors
@@ -311,7 +325,7 @@ class EncoderLayerFn(torch.autograd.Function):
                 train.shadow_param_grads(r1, d_u, y1_16)
                 train.shadow_param_grads(rout, d_a, ctxa)
                 train.shadow_param_grads(rin, dqkv, x16)
-                return dx32, None, None, None, None, None, None
+                return dx32, None, None, None, None, None, None, None
             # LayerNorm2 <- (g32, g16)
             d_f, dres2 = torch.empty((T, d), **bf), torch.empty((T, d), **f32)
             _check(lib.ops_dropout_add_layernorm_bwd(T, d, ptr(g32), ptr(g16), z2.data_ptr(), mean2.data_ptr(), rstd2.data_ptr(),
@@ -335,7 +349,7 @@ class EncoderLayerFn(torch.autograd.Function):
                    "ops_seq_attention_bwd")
             train.shadow_param_grads(rin, dqkv, x16)
             d_x16 = dqkv @ rin.w_sh
-        return dres1, d_x16, None, None, None, None, None
+        return dres1, d_x16, None, None, None, None, None, None
 
 
 def _tile_pair(w: torch.Tensor):
@@ -438,6 +452,8 @@ def _layer_ok(layer: nn.Module) -> bool:
 
 def encoder_forward(enc: nn.TransformerEncoder, src: torch.Tensor, st: _State) -> torch.Tensor:
     """The fast path proper: src [B, S, d] float32 -> [B, S, d] float32 (training mode, S <= 8)."""
+    global _PENDING_LAYER
+    _PENDING_LAYER = None                  # (a pass that died between a deferred launch and its successor leaves nothing behind)
     B, S, d = src.shape
     T = B * S
     st.advance()                           # fresh dropout masks for this pass (the launches only read the counter)
@@ -447,10 +463,13 @@ def encoder_forward(enc: nn.TransformerEncoder, src: torch.Tensor, st: _State) -
         if tuple(st.src16.shape) == (T, d):
             x16 = st.src16
         st.src16 = None
+    nl = len(enc.layers)
     for li, layer in enumerate(enc.layers):
         mha = layer.self_attn
         if x16 is not None and _layer_fused_ok(layer, st):
-            res, x16 = EncoderLayerFn.apply(res, x16, layer, B, S, st, li)                          # the whole layer forward: one launch
+            # the whole layer forward: one launch -- or, for two consecutive layers, one launch for both (the first one's is deferred)
+            defer = bool(LAYER_PAIR_FWD and _PENDING_LAYER is None and li + 1 < nl and _layer_fused_ok(enc.layers[li + 1], st) and _TRACE_BWD is None)
+            res, x16 = EncoderLayerFn.apply(res, x16, layer, B, S, st, li, defer)
             continue
         qkv = mha._ops_in_proj(res if x16 is None else x16)                                         # [T, 3 d] bf16
         ctx = SeqAttention.apply(qkv, B, S, mha.num_heads, mha.dropout, st, 4 * li)

@@ -432,6 +432,55 @@ def test_one_launch_layer_forward_equals_the_eight_launch_form(monkeypatch, B, p
             assert _rel(g1[n], g0[n]) < 2e-2 or float(g0[n].norm()) < 1e-6, (fwd_bwd, n, _rel(g1[n], g0[n]))
 
 
+@pytest.mark.parametrize("B,p,layers", [(512, 0.1, 2), (37, 0.1, 3), (3, 0.0, 2)])
+def test_two_layers_in_one_launch_equal_the_two_launches(monkeypatch, B, p, layers):
+    """r04: two consecutive encoder layers' forward passes as ONE launch (ops_tfd_encoder_layer_pair_fwd: a workgroup runs the second layer
+    on the rows it has just written as the first one's output) against one launch per layer: the same code on the same values -- outputs
+    bit-equal, and so is everything saved for the backward pass (the gradients differ only by their float atomics).  Three layers: a pair
+    and a single launch."""
+    from openpystruct_amd import tfd_fused as TF, train
+    from openpystruct_amd.surrogates import ModelOnePassTransformerWithDiffusion
+
+    def run(pair):
+        monkeypatch.setattr(TF, "LAYER_PAIR_FWD", pair)
+        torch.manual_seed(5)
+        model = ModelOnePassTransformerWithDiffusion(6, 120, 100, num_transformer_layers=layers, dropout=p).to(DEV)
+        params = list(model.parameters())
+        flat = torch.zeros(sum(q.numel() for q in params), device=DEV)
+        off = 0
+        for q in params:
+            q.grad = flat[off:off + q.numel()].view_as(q)
+            off += q.numel()
+        opt = train.FlatClipAdam(params, flat, 1e-3)
+        stash, dst, patched = train.enable_shadow_linears(model, opt, params, flat)
+        assert TF.patch_model(model, seed=3, direct_param_grads=True)
+        model.train()
+        g = torch.Generator().manual_seed(6)
+        x = torch.randn(B, 6, 120, generator=g).to(DEV)
+        w = torch.randn(B, 100, generator=g).to(DEV) / B
+        torch.manual_seed(11)
+        train._WGRAD_QUEUE = []
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            out = model(x)
+            (out.float() * w).sum().backward()
+        train.flush_wgrad_queue(torch.device(DEV))
+        train._WGRAD_QUEUE = None
+        live = [(dd, ss) for dd, ss in zip(dst, stash) if ss is not None]
+        if live:
+            torch._foreach_copy_([a for a, _ in live], [b for _, b in live])
+        torch.cuda.synchronize()
+        assert TF._PENDING_LAYER is None
+        res = out.float().clone(), flat.clone()
+        train.disable_shadow_linears(patched)
+        TF.unpatch_model(model)
+        return res
+
+    o0, g0 = run(False)
+    o1, g1 = run(True)
+    assert torch.equal(o0, o1) and float(o0.abs().max()) > 0
+    assert float((g0 - g1).norm() / g0.norm()) < 1e-5
+
+
 @pytest.mark.parametrize("B,p,alpha0,second", [(512, 0.1, 0.5, False), (288, 0.0, None, False), (37, 0.3, 0.5, False), (512, 0.1, 0.5, True), (37, 0.0, None, True)])
 def test_loss_on_the_head_tile_equals_the_loss_launch(monkeypatch, B, p, alpha0, second):
     """r04: the training loss of the fast path computed by the head's forward launch on its output tile and finished by the head's backward
