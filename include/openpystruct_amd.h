@@ -569,6 +569,9 @@ typedef struct ops_tfd_layer_bwd_args {
   int32_t identity_act;                               /* as ops_tfd_layer_args */
 } ops_tfd_layer_bwd_args;
 int ops_tfd_encoder_layer_bwd(const ops_tfd_layer_bwd_args* args, void* stream);
+/* The backward passes of two consecutive layers as ONE launch: `later` first, then `earlier` on the float32 dx the workgroup has just written
+ * (earlier->g32 == later->dx32, earlier->g16 == NULL).  Same results as the two launches. */
+int ops_tfd_encoder_layer_pair_bwd(const ops_tfd_layer_bwd_args* later, const ops_tfd_layer_bwd_args* earlier, void* stream);
 
 /* The Transformer-Diffusion model's head (TransformerDiffusionModule_MultiCase.py:568-575) as one launch per direction: rows = the
  * [CLS] rows of the last encoder layer's bf16 output (row b S of y16 [B S, d]), a = fc1 rows + b1 (bf16), LayerNorm over `hid` columns,

@@ -64,6 +64,7 @@ EXPORTS = (
     "ops_hbm_copy16",
     "ops_tfd_encoder_layer_fwd",
     "ops_tfd_encoder_layer_pair_fwd",
+    "ops_tfd_encoder_layer_pair_bwd",
     "ops_diffusion_noise_draw",
     "ops_surrogate_loss_grad_sum_f32",
     "ops_gather_rows_noise_targets_f32",
@@ -257,6 +258,8 @@ def load():
     lib.ops_tfd_encoder_layer_fwd.argtypes = [ctypes.POINTER(TfdLayerArgs), vp]
     lib.ops_tfd_encoder_layer_pair_fwd.restype = it
     lib.ops_tfd_encoder_layer_pair_fwd.argtypes = [ctypes.POINTER(TfdLayerArgs), ctypes.POINTER(TfdLayerArgs), vp]
+    lib.ops_tfd_encoder_layer_pair_bwd.restype = it
+    lib.ops_tfd_encoder_layer_pair_bwd.argtypes = [ctypes.POINTER(TfdLayerBwdArgs), ctypes.POINTER(TfdLayerBwdArgs), vp]
     lib.ops_tfd_encoder_layer_bwd.restype = it
     lib.ops_tfd_encoder_layer_bwd.argtypes = [ctypes.POINTER(TfdLayerBwdArgs), vp]
     lib.ops_tfd_head_fwd.restype = it

@@ -172,6 +172,19 @@ __device__ __forceinline__ void sl_zero_rows(uint16_t* s, int ls, int r0, int nc
     for (int r = r0 + (tid >> 7); r < 16; r += SL_NW / 2) s[r * ls + cc] = 0;
 }
 
+// LDS of the layer's forward pass (strides: see the body)
+struct SlFwdLds {
+  __attribute__((aligned(16))) uint16_t x[16 * (128 + 8)];
+  __attribute__((aligned(16))) uint16_t ctx[16 * (128 + 8)];
+  __attribute__((aligned(16))) uint16_t big[16 * 3 * 8 * SL_DHP > 16 * (256 + 8) ? 16 * 3 * 8 * SL_DHP : 16 * (256 + 8)];
+  __attribute__((aligned(16))) uint16_t st[16 * (384 + 8)];
+  __attribute__((aligned(16))) float f32[16 * (128 + 4)];
+};
+__device__ __forceinline__ SlFwdLds* sl_fwd_lds() {
+  __shared__ SlFwdLds lds;
+  return &lds;
+}
+
 // d <= 128, ff <= 256, dh <= 16, S <= 8, H <= 8 (host-checked).  One workgroup = 16 rows = 16 / S samples; its 8 waves split every
 // product's 16-column tiles (wave w: tiles w, w + 8, w + 16), so ALL of a wave's weight fragments -- 32 sixteen-byte loads per lane --
 // are requested at kernel entry (behind the layer input, in the order the products use them: vector-memory results return in order)
@@ -184,11 +197,12 @@ __device__ __forceinline__ void tfd_layer_fwd_body(const ops_tfd_layer_args& a) 
   constexpr int HS = 256 + 8;        // ... of the ff-wide operand
   constexpr int QS = 384 + 8;        // ... of the unpadded q|k|v rows kept for the store (3 d <= 384)
   constexpr int FS = 128 + 4;        // ... of the float32 staging rows
-  __shared__ __attribute__((aligned(16))) uint16_t s_x[16 * XS];                 // x (bf16), later y1 (bf16), at the end y2 (bf16)
-  __shared__ __attribute__((aligned(16))) uint16_t s_ctx[16 * XS];               // attention output
-  __shared__ __attribute__((aligned(16))) uint16_t s_big[16 * 3 * 8 * SL_DHP > 16 * HS ? 16 * 3 * 8 * SL_DHP : 16 * HS];   // q|k|v padded image, later h
-  __shared__ __attribute__((aligned(16))) uint16_t s_st[16 * QS];                // q|k|v rows as stored, later u, at the end y2 (float32)
-  __shared__ __attribute__((aligned(16))) float s_f32[16 * FS];                  // z1, later z2 (float32)
+  SlFwdLds* const L = sl_fwd_lds();                          // ONE instance, whichever kernels inline this body (the pair kernel: twice)
+  uint16_t* const s_x = L->x;                                // x (bf16), later y1 (bf16), at the end y2 (bf16)
+  uint16_t* const s_ctx = L->ctx;                            // attention output
+  uint16_t* const s_big = L->big;                            // q|k|v padded image, later h
+  uint16_t* const s_st = L->st;                              // q|k|v rows as stored, later u, at the end y2 (float32)
+  float* const s_f32 = L->f32;                               // z1, later z2 (float32)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 15, g = lane >> 4;
   const int S = a.S, H = a.H, dh = a.dh, d = a.d, ff = a.ff;
   const int spw = 16 / S;
@@ -502,10 +516,11 @@ __global__ __launch_bounds__(64 * SL_NW) void tfd_layer_pair_fwd_kernel(const op
 // accumulation, every product rounded to bf16 before use, the residual stream's gradient in fp32.
 // ================================================================================================================================
 typedef const __attribute__((opencl_constant)) ops_tfd_layer_bwd_args* slb_args_ptr;
+template <int ARGOFF = 0>
 __device__ __forceinline__ slb_args_ptr slb_late_args() {
   auto p = __builtin_amdgcn_kernarg_segment_ptr();
   __asm__ volatile("" : "+s"(p));
-  return (slb_args_ptr)p;
+  return (slb_args_ptr)((const __attribute__((opencl_constant)) char*)p + ARGOFF);
 }
 #define SL_GLOBAL(T, p) ((__attribute__((address_space(1))) T*)(p))
 
@@ -539,22 +554,44 @@ __device__ __forceinline__ void slb_param_sums(const float (&dy)[4], const float
   pg += __shfl_xor(pg, 32, 64); pb += __shfl_xor(pb, 32, 64);
 }
 
-template <bool HAS32, bool HAS16>
-__global__ __launch_bounds__(64 * SL_NW) void tfd_layer_bwd_kernel(const ops_tfd_layer_bwd_args a) {
+// LDS of the layer's backward pass
+struct SlBwdLds {
+  __attribute__((aligned(16))) uint16_t a[16 * (128 + 8)];                  // d_f, later d_a (bf16 operand rows)
+  __attribute__((aligned(16))) uint16_t du[16 * (256 + 8)];                 // d_u
+  __attribute__((aligned(16))) uint16_t u[16 * (256 + 8)];                  // u (saved pre-activation)
+  __attribute__((aligned(16))) uint16_t qkv[16 * 3 * 8 * SL_DHP];           // q|k|v padded image [row][q|k|v][H][16]
+  __attribute__((aligned(16))) uint16_t dob[16 * 8 * SL_DHP];               // d_ctx padded image [row][H][16]
+  __attribute__((aligned(16))) uint16_t dq[16 * (384 + 8)];                 // dqkv rows (operand of the last product, and as stored)
+  __attribute__((aligned(16))) float g[16 * (128 + 4)];                     // incoming gradient (float32), at the end dx
+  __attribute__((aligned(16))) float z2[16 * (128 + 4)];
+  __attribute__((aligned(16))) float z1[16 * (128 + 4)];
+  __attribute__((aligned(16))) float ds[16 * 8 * SL_MAXS];                  // [sample][head][query][key] scale * dS   (spw H S S <= 1024)
+  __attribute__((aligned(16))) float pk[16 * 8 * SL_MAXS];                  // ... keep-scaled probabilities
+  __attribute__((aligned(16))) float red[2][2 * 16 * SL_NW];
+  float stat[4][16];                                                        // mean2, rstd2, mean1, rstd1 of the 16 rows
+};
+__device__ __forceinline__ SlBwdLds* sl_bwd_lds() {
+  __shared__ SlBwdLds lds;
+  return &lds;
+}
+
+template <bool HAS32, bool HAS16, int ARGOFF>
+__device__ __forceinline__ void tfd_layer_bwd_body(const ops_tfd_layer_bwd_args& a) {
   constexpr int XS = 128 + 8, HS = 256 + 8, QS = 384 + 8, FS = 128 + 4;
-  __shared__ __attribute__((aligned(16))) uint16_t s_a[16 * XS];                  // d_f, later d_a (bf16 operand rows)
-  __shared__ __attribute__((aligned(16))) uint16_t s_du[16 * HS];                 // d_u
-  __shared__ __attribute__((aligned(16))) uint16_t s_u[16 * HS];                  // u (saved pre-activation)
-  __shared__ __attribute__((aligned(16))) uint16_t s_qkv[16 * 3 * 8 * SL_DHP];    // q|k|v padded image [row][q|k|v][H][16]
-  __shared__ __attribute__((aligned(16))) uint16_t s_do[16 * 8 * SL_DHP];         // d_ctx padded image [row][H][16]
-  __shared__ __attribute__((aligned(16))) uint16_t s_dq[16 * QS];                 // dqkv rows (operand of the last product, and as stored)
-  __shared__ __attribute__((aligned(16))) float s_g[16 * FS];                     // incoming gradient (float32), at the end dx
-  __shared__ __attribute__((aligned(16))) float s_z2[16 * FS];
-  __shared__ __attribute__((aligned(16))) float s_z1[16 * FS];
-  __shared__ __attribute__((aligned(16))) float s_ds[16 * 8 * SL_MAXS];           // [sample][head][query][key] scale * dS   (spw H S S <= 1024)
-  __shared__ __attribute__((aligned(16))) float s_pk[16 * 8 * SL_MAXS];           // ... keep-scaled probabilities
-  __shared__ __attribute__((aligned(16))) float s_red[2][2 * 16 * SL_NW];
-  __shared__ float s_stat[4][16];                                                 // mean2, rstd2, mean1, rstd1 of the 16 rows
+  SlBwdLds* const L = sl_bwd_lds();                          // ONE instance, whichever kernels inline this body
+  uint16_t* const s_a = L->a;
+  uint16_t* const s_du = L->du;
+  uint16_t* const s_u = L->u;
+  uint16_t* const s_qkv = L->qkv;
+  uint16_t* const s_do = L->dob;
+  uint16_t* const s_dq = L->dq;
+  float* const s_g = L->g;
+  float* const s_z2 = L->z2;
+  float* const s_z1 = L->z1;
+  float* const s_ds = L->ds;
+  float* const s_pk = L->pk;
+  float (*const s_red)[2 * 16 * SL_NW] = L->red;
+  float (*const s_stat)[16] = L->stat;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 15, g = lane >> 4;
   const int S = a.S, H = a.H, dh = a.dh, d = a.d, ff = a.ff;
   const int spw = 16 / S;
@@ -649,7 +686,7 @@ __global__ __launch_bounds__(64 * SL_NW) void tfd_layer_bwd_kernel(const ops_tfd
   // ---- LayerNorm2 backward -> dres2 (registers), d_f (bf16 operand rows) ----
   float dres2[4], pg2, pb2;
   {
-    const slb_args_ptr la = slb_late_args();
+    const slb_args_ptr la = slb_late_args<ARGOFF>();
     const DropKey key_2 = drop_key(la->seed_2, call);
     const float p_2 = la->p_2, ks = p_2 > 0.0f ? 1.0f / (1.0f - p_2) : 1.0f;
     float dy[4], xh[4], rstd[4];
@@ -678,7 +715,7 @@ __global__ __launch_bounds__(64 * SL_NW) void tfd_layer_bwd_kernel(const ops_tfd
 
   // ---- d_h = d_f W_2 (bf16), ReLU + dropout backward -> d_u ----
   {
-    const slb_args_ptr la = slb_late_args();
+    const slb_args_ptr la = slb_late_args<ARGOFF>();
     const DropKey key_act = drop_key(la->seed_act, call);
     const float p_act = la->p_act, ks = p_act > 0.0f ? 1.0f / (1.0f - p_act) : 1.0f;
 #pragma unroll
@@ -704,7 +741,7 @@ __global__ __launch_bounds__(64 * SL_NW) void tfd_layer_bwd_kernel(const ops_tfd
   // every weight fragment has arrived by now (see the forward kernel): one full wait BEFORE the first store is issued
   __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
   SLB_STAMP(4);
-  { const slb_args_ptr la = slb_late_args();
+  { const slb_args_ptr la = slb_late_args<ARGOFF>();
     if (g == 0) {
       if (la->ln_part) { SL_GLOBAL(float, la->ln_part)[((long)blockIdx.x * 4 + 0) * 128 + n] = colok ? pg2 : 0.0f; SL_GLOBAL(float, la->ln_part)[((long)blockIdx.x * 4 + 1) * 128 + n] = colok ? pb2 : 0.0f; }
       else if (colok) { unsafeAtomicAdd(la->dgamma2 + n, pg2); unsafeAtomicAdd(la->dbeta2 + n, pb2); }
@@ -715,7 +752,7 @@ __global__ __launch_bounds__(64 * SL_NW) void tfd_layer_bwd_kernel(const ops_tfd
   // ---- d_y1 = d_u W_1 (bf16) + dres2, LayerNorm1 backward -> dres1 (registers), d_a ----
   float dres1[4];
   {
-    const slb_args_ptr la = slb_late_args();
+    const slb_args_ptr la = slb_late_args<ARGOFF>();
     const DropKey key_1 = drop_key(la->seed_1, call);
     const float p_1 = la->p_1, ks = p_1 > 0.0f ? 1.0f / (1.0f - p_1) : 1.0f;
     const sl_f32x4 acc = sl_mma_tile<8>(wt1, s_du, HS, c, g);
@@ -747,7 +784,7 @@ __global__ __launch_bounds__(64 * SL_NW) void tfd_layer_bwd_kernel(const ops_tfd
   }
   sl_lds_barrier();
   SLB_STAMP(5);
-  { const slb_args_ptr la = slb_late_args(); sl_store_rows<2>(la->d_a, s_a, XS, d, row0, nrows, tid); }
+  { const slb_args_ptr la = slb_late_args<ARGOFF>(); sl_store_rows<2>(la->d_a, s_a, XS, d, row0, nrows, tid); }
 
   // ---- d_ctx = d_a W_out (bf16) -> padded head vectors ----
   {
@@ -764,7 +801,7 @@ __global__ __launch_bounds__(64 * SL_NW) void tfd_layer_bwd_kernel(const ops_tfd
 
   // ---- attention backward: four lanes per (sample, head, token), four head dimensions each ----
   {
-    const slb_args_ptr la = slb_late_args();
+    const slb_args_ptr la = slb_late_args<ARGOFF>();
     const DropKey key_attn = drop_key(la->seed_attn, call);
     const float p_attn = la->p_attn, ks = p_attn > 0.0f ? 1.0f / (1.0f - p_attn) : 1.0f;
     const float scale = rsqrtf((float)dh);
@@ -860,7 +897,7 @@ __global__ __launch_bounds__(64 * SL_NW) void tfd_layer_bwd_kernel(const ops_tfd
   }
   sl_lds_barrier();
   SLB_STAMP(7);
-  { const slb_args_ptr la = slb_late_args(); sl_store_rows<2>(la->dqkv, s_dq, QS, 3 * d, row0, nrows, tid); }
+  { const slb_args_ptr la = slb_late_args<ARGOFF>(); sl_store_rows<2>(la->dqkv, s_dq, QS, 3 * d, row0, nrows, tid); }
 
   // ---- dx = dres1 + bf16(dqkv W_in) ----
   {
@@ -869,11 +906,25 @@ __global__ __launch_bounds__(64 * SL_NW) void tfd_layer_bwd_kernel(const ops_tfd
     for (int i = 0; i < 4; ++i) { const int r = 4 * g + i; s_g[r * FS + n] = dres1[i] + sl_round(acc[i]); }
   }
   sl_lds_barrier();
-  { const slb_args_ptr la = slb_late_args(); sl_store_rows<4>(la->dx32, s_g, FS, d, row0, nrows, tid); }
+  { const slb_args_ptr la = slb_late_args<ARGOFF>(); sl_store_rows<4>(la->dx32, s_g, FS, d, row0, nrows, tid); }
   if (a.trace && tid == 0) {
     SLB_STAMP(8);
     for (int k = 0; k < 16; ++k) a.trace[16 * (unsigned long long)blockIdx.x + k] = stamp[k];
   }
+}
+
+template <bool HAS32, bool HAS16>
+__global__ __launch_bounds__(64 * SL_NW) void tfd_layer_bwd_kernel(const ops_tfd_layer_bwd_args a) { tfd_layer_bwd_body<HAS32, HAS16, 0>(a); }
+
+// The backward passes of two consecutive layers in ONE launch (r04; as tfd_layer_pair_fwd_kernel): `a` is the LATER layer, `b` the earlier
+// one, whose incoming gradient is the float32 dx this workgroup has just written for its own rows (b.g32 == a.dx32, b.g16 == NULL).
+static_assert(sizeof(ops_tfd_layer_bwd_args) % 8 == 0, "second argument block of the pair kernel sits right behind the first");
+template <bool HAS32, bool HAS16>
+__global__ __launch_bounds__(64 * SL_NW) void tfd_layer_pair_bwd_kernel(const ops_tfd_layer_bwd_args a, const ops_tfd_layer_bwd_args b) {
+  tfd_layer_bwd_body<HAS32, HAS16, 0>(a);
+  __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wave's stores of dx32 are acknowledged
+  __syncthreads();
+  tfd_layer_bwd_body<true, false, (int)sizeof(ops_tfd_layer_bwd_args)>(b);
 }
 
 
@@ -1513,6 +1564,31 @@ extern "C" int ops_tfd_encoder_layer_bwd(const ops_tfd_layer_bwd_args* a, void* 
   if (a->g32 && a->g16) hipLaunchKernelGGL((opsamd::tfd_layer_bwd_kernel<true, true>), grid, block, 0, (hipStream_t)stream, *a);
   else if (a->g32) hipLaunchKernelGGL((opsamd::tfd_layer_bwd_kernel<true, false>), grid, block, 0, (hipStream_t)stream, *a);
   else hipLaunchKernelGGL((opsamd::tfd_layer_bwd_kernel<false, true>), grid, block, 0, (hipStream_t)stream, *a);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { opsamd::set_last_error(hipGetErrorString(e)); return OPS_AMD_ERR_LAUNCH; }
+  return OPS_AMD_OK;
+}
+
+extern "C" int ops_tfd_encoder_layer_pair_bwd(const ops_tfd_layer_bwd_args* a, const ops_tfd_layer_bwd_args* b, void* stream) {
+  for (const ops_tfd_layer_bwd_args* q : {a, b}) {
+    if (!q || q->Bn < 1 || q->S < 1 || q->S > 8 || q->H < 1 || q->H > 8 || q->dh < 1 || q->dh > 16 || q->d != q->H * q->dh || q->d > 128 || q->d % 8 ||
+        q->ff < 16 || q->ff > 256 || q->ff % 8)
+      return OPS_AMD_ERR_UNSUPPORTED;
+    if (!q->Wt_in || !q->Wt_out || !q->Wt_1 || !q->Wt_2 || !q->gamma1 || !q->gamma2 || !q->used_call || !q->qkv || !q->z1 || !q->mean1 || !q->rstd1 || !q->u ||
+        !q->z2 || !q->mean2 || !q->rstd2 || !q->d_f || !q->d_u || !q->d_a || !q->dqkv || !q->dx32 || !q->dgamma1 || !q->dbeta1 || !q->dgamma2 || !q->dbeta2)
+      return OPS_AMD_ERR_INVALID_ARG;
+    if ((((uintptr_t)q->Wt_in | (uintptr_t)q->Wt_out | (uintptr_t)q->Wt_1 | (uintptr_t)q->Wt_2 | (uintptr_t)q->g32 | (uintptr_t)q->z1 | (uintptr_t)q->z2 |
+          (uintptr_t)q->u | (uintptr_t)q->qkv | (uintptr_t)q->d_f | (uintptr_t)q->d_u | (uintptr_t)q->d_a | (uintptr_t)q->dqkv | (uintptr_t)q->dx32) & 15) != 0 ||
+        ((uintptr_t)q->g16 & 7) != 0 || q->trace)
+      return OPS_AMD_ERR_UNSUPPORTED;
+  }
+  if (!a->g32 && !a->g16) return OPS_AMD_ERR_INVALID_ARG;
+  if (a->Bn != b->Bn || a->S != b->S || a->d != b->d || (const void*)b->g32 != (const void*)a->dx32 || b->g16) return OPS_AMD_ERR_INVALID_ARG;
+  const int spw = 16 / a->S;
+  const dim3 grid((unsigned)((a->Bn + spw - 1) / spw)), block(64 * opsamd::SL_NW);
+  if (a->g32 && a->g16) hipLaunchKernelGGL((opsamd::tfd_layer_pair_bwd_kernel<true, true>), grid, block, 0, (hipStream_t)stream, *a, *b);
+  else if (a->g32) hipLaunchKernelGGL((opsamd::tfd_layer_pair_bwd_kernel<true, false>), grid, block, 0, (hipStream_t)stream, *a, *b);
+  else hipLaunchKernelGGL((opsamd::tfd_layer_pair_bwd_kernel<false, true>), grid, block, 0, (hipStream_t)stream, *a, *b);
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) { opsamd::set_last_error(hipGetErrorString(e)); return OPS_AMD_ERR_LAUNCH; }
   return OPS_AMD_OK;

@@ -215,6 +215,20 @@ class ActDropout(torch.autograd.Function):
 
 LAYER_PAIR_FWD = os.environ.get("OPS_AMD_TFD_LAYER_PAIR", "1") == "1"      # A/B switch: two consecutive layers' forward passes as one launch
 _PENDING_LAYER = None       # (argument block, output) of a layer whose forward launch waits for its successor
+LAYER_PAIR_BWD = os.environ.get("OPS_AMD_TFD_LAYER_PAIR_BWD", "1") == "1"  # ... and their backward passes
+_PENDING_BWD = None         # (argument block, dx32, tensors to keep alive) of a later layer whose backward launch waits for its predecessor
+
+
+def flush_pending_backward() -> None:
+    """Launch a deferred backward pass whose predecessor never came (a first layer whose inputs need no gradient).  Called by the training
+    loop's weight-gradient flush, i.e. behind every backward pass."""
+    global _PENDING_BWD
+    if _PENDING_BWD is not None:
+        pb, pdx, keep = _PENDING_BWD
+        _PENDING_BWD = None
+        with torch.cuda.device(pdx.device):
+            _check(_cabi.load().ops_tfd_encoder_layer_bwd(ctypes.byref(pb), _stream(pdx.device)), "ops_tfd_encoder_layer_bwd")
+
 
 
 class EncoderLayerFn(torch.autograd.Function):
@@ -258,6 +272,7 @@ class EncoderLayerFn(torch.autograd.Function):
             mean1=mean1.data_ptr(), rstd1=rstd1.data_ptr(), y1_16=y1_16.data_ptr(), u=u.data_ptr(), h=h.data_ptr(), z2=z2.data_ptr(),
             mean2=mean2.data_ptr(), rstd2=rstd2.data_ptr(), y32=y32.data_ptr(), y16=y16.data_ptr())
         with torch.cuda.device(dev):
+            ctx.pair_later = False               # this layer is the LATER one of a pair launch (its backward may wait for its predecessor's)
             if defer:                            # the next layer's call launches both (ops_tfd_encoder_layer_pair_fwd)
                 assert _PENDING_LAYER is None
                 _PENDING_LAYER = (a, y32)
@@ -266,6 +281,7 @@ class EncoderLayerFn(torch.autograd.Function):
                 _PENDING_LAYER = None
                 assert py.data_ptr() == x32.data_ptr()
                 _check(lib.ops_tfd_encoder_layer_pair_fwd(ctypes.byref(pa), ctypes.byref(a), _stream(dev)), "ops_tfd_encoder_layer_pair_fwd")
+                ctx.pair_later = True
             else:
                 _check(lib.ops_tfd_encoder_layer_fwd(ctypes.byref(a), _stream(dev)), "ops_tfd_encoder_layer_fwd")
         ctx.save_for_backward(x16, qkv, ctxa, z1, mean1, rstd1, y1_16, u, h, z2, mean2, rstd2)
@@ -315,7 +331,20 @@ class EncoderLayerFn(torch.autograd.Function):
                     tr = torch.zeros(16 * ((Bn + (16 // S) - 1) // (16 // S)), dtype=torch.int64, device=dev)
                     _TRACE_BWD.append(tr)
                     a.trace = tr.data_ptr()
-                _check(lib.ops_tfd_encoder_layer_bwd(ctypes.byref(a), s), "ops_tfd_encoder_layer_bwd")
+                global _PENDING_BWD
+                if _PENDING_BWD is not None:
+                    pb, pdx, keep = _PENDING_BWD
+                    _PENDING_BWD = None
+                    if g32 is not None and g16 is None and pdx.data_ptr() == g32.data_ptr() and _TRACE_BWD is None:
+                        _check(lib.ops_tfd_encoder_layer_pair_bwd(ctypes.byref(pb), ctypes.byref(a), s), "ops_tfd_encoder_layer_pair_bwd")
+                    else:                        # (not the successor's gradient after all: the two launches)
+                        _check(lib.ops_tfd_encoder_layer_bwd(ctypes.byref(pb), s), "ops_tfd_encoder_layer_bwd")
+                        _check(lib.ops_tfd_encoder_layer_bwd(ctypes.byref(a), s), "ops_tfd_encoder_layer_bwd")
+                elif LAYER_PAIR_BWD and ctx.pair_later and _TRACE_BWD is None and train._WGRAD_QUEUE is not None:      # (queue mode: a flush follows)
+                    # the predecessor's backward call -- the next node autograd runs: this layer's inputs are its two outputs -- launches both
+                    _PENDING_BWD = (a, dx32, (g32, g16, d_f, d_u, d_a, dqkv, part))
+                else:
+                    _check(lib.ops_tfd_encoder_layer_bwd(ctypes.byref(a), s), "ops_tfd_encoder_layer_bwd")
                 if part is not None:
                     flatp = part.view(nwg, 512)
                     for k, q in enumerate((layer.norm2.weight, layer.norm2.bias, layer.norm1.weight, layer.norm1.bias)):
@@ -452,8 +481,9 @@ def _layer_ok(layer: nn.Module) -> bool:
 
 def encoder_forward(enc: nn.TransformerEncoder, src: torch.Tensor, st: _State) -> torch.Tensor:
     """The fast path proper: src [B, S, d] float32 -> [B, S, d] float32 (training mode, S <= 8)."""
-    global _PENDING_LAYER
+    global _PENDING_LAYER, _PENDING_BWD
     _PENDING_LAYER = None                  # (a pass that died between a deferred launch and its successor leaves nothing behind)
+    _PENDING_BWD = None
     B, S, d = src.shape
     T = B * S
     st.advance()                           # fresh dropout masks for this pass (the launches only read the counter)

@@ -25,6 +25,7 @@ from __future__ import annotations
 
 import copy
 import os
+import sys
 import time
 from dataclasses import dataclass
 from typing import Dict, Optional
@@ -404,6 +405,9 @@ _WGRAD_QUEUE = None          # a list while a training step collects its split-r
 def flush_wgrad_queue(device) -> None:
     """Launch everything `_ShadowLinearFn.backward` queued (operands stay alive in the queue until here), 16 products per launch."""
     from . import _cabi
+    tf = sys.modules.get(__package__ + ".tfd_fused")
+    if tf is not None:
+        tf.flush_pending_backward()        # a layer's backward launch that waited for a predecessor which never ran
     q = _WGRAD_QUEUE
     if not q:
         return

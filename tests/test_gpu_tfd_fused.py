@@ -436,13 +436,15 @@ def test_one_launch_layer_forward_equals_the_eight_launch_form(monkeypatch, B, p
 def test_two_layers_in_one_launch_equal_the_two_launches(monkeypatch, B, p, layers):
     """r04: two consecutive encoder layers' forward passes as ONE launch (ops_tfd_encoder_layer_pair_fwd: a workgroup runs the second layer
     on the rows it has just written as the first one's output) against one launch per layer: the same code on the same values -- outputs
-    bit-equal, and so is everything saved for the backward pass (the gradients differ only by their float atomics).  Three layers: a pair
+    bit-equal, and so is everything saved for the backward pass (the gradients differ only by their float atomics); likewise the two
+    backward passes (ops_tfd_encoder_layer_pair_bwd: the later layer's launch waits for its predecessor's call).  Three layers: a pair
     and a single launch."""
     from openpystruct_amd import tfd_fused as TF, train
     from openpystruct_amd.surrogates import ModelOnePassTransformerWithDiffusion
 
-    def run(pair):
+    def run(pair, pair_bwd=False):
         monkeypatch.setattr(TF, "LAYER_PAIR_FWD", pair)
+        monkeypatch.setattr(TF, "LAYER_PAIR_BWD", pair_bwd)
         torch.manual_seed(5)
         model = ModelOnePassTransformerWithDiffusion(6, 120, 100, num_transformer_layers=layers, dropout=p).to(DEV)
         params = list(model.parameters())
@@ -469,16 +471,17 @@ def test_two_layers_in_one_launch_equal_the_two_launches(monkeypatch, B, p, laye
         if live:
             torch._foreach_copy_([a for a, _ in live], [b for _, b in live])
         torch.cuda.synchronize()
-        assert TF._PENDING_LAYER is None
+        assert TF._PENDING_LAYER is None and TF._PENDING_BWD is None
         res = out.float().clone(), flat.clone()
         train.disable_shadow_linears(patched)
         TF.unpatch_model(model)
         return res
 
     o0, g0 = run(False)
-    o1, g1 = run(True)
-    assert torch.equal(o0, o1) and float(o0.abs().max()) > 0
-    assert float((g0 - g1).norm() / g0.norm()) < 1e-5
+    for pair_bwd in (False, True):                 # ... and the two backward passes as one launch too
+        o1, g1 = run(True, pair_bwd)
+        assert torch.equal(o0, o1) and float(o0.abs().max()) > 0
+        assert float((g0 - g1).norm() / g0.norm()) < 1e-5
 
 
 @pytest.mark.parametrize("B,p,alpha0,second", [(512, 0.1, 0.5, False), (288, 0.0, None, False), (37, 0.3, 0.5, False), (512, 0.1, 0.5, True), (37, 0.0, None, True)])
