@@ -91,6 +91,19 @@ __device__ __forceinline__ sl_args_ptr sl_late_args() {
   return (sl_args_ptr)((const __attribute__((opencl_constant)) char*)p + ARGOFF);
 }
 
+// Four floats that THIS launch has written (the pair kernels: a workgroup re-reads the rows it stored a moment ago): device-scope loads,
+// which do not look into the CU's vector L1.  A plain load is not enough although only the workgroup's own bytes are consumed: rows are
+// not multiples of the 128-byte line, so the first / last line of a workgroup's rows also holds a neighbour's bytes, and a neighbour that
+// shares the CU may have pulled that line into the L1 BEFORE this workgroup's store -- a plain load could then hit the stale copy.
+__device__ __forceinline__ float4 sl_load_f4_device_scope(const float* p) {
+  float4 v;
+  v.x = __hip_atomic_load(p + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  v.y = __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  v.z = __hip_atomic_load(p + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  v.w = __hip_atomic_load(p + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return v;
+}
+
 constexpr int SL_DHP = 16;          // head vectors padded to 16 elements in LDS (dh <= 16)
 constexpr int SL_MAXS = 8;
 
@@ -191,7 +204,7 @@ __device__ __forceinline__ SlFwdLds* sl_fwd_lds() {
 // and no product waits for a dependent round trip to L2 / the Infinity Cache.  Everything that leaves the kernel is first collected in
 // LDS rows and stored in 16-byte pieces by all threads (2- and 4-byte stores straight from the accumulator layout cost 2-3 us per
 // stage); the attention of a (sample, head, query) is shared by four lanes, four head dimensions each.
-template <int ARGOFF>
+template <int ARGOFF, bool OWN_INPUT = false>       // OWN_INPUT: x32 was written by this workgroup earlier in this launch
 __device__ __forceinline__ void tfd_layer_fwd_body(const ops_tfd_layer_args& a) {
   constexpr int XS = 128 + 8;        // LDS row stride of the d-wide bf16 operands: rows 4 banks apart
   constexpr int HS = 256 + 8;        // ... of the ff-wide operand
@@ -222,7 +235,7 @@ __device__ __forceinline__ void tfd_layer_fwd_body(const ops_tfd_layer_args& a) 
   float4 xin = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
   {
     const int r = tid >> 5, q4 = tid & 31;             // 16 rows x 32 float4 = 128 columns per row: one piece per thread
-    if (r < nrows && 4 * q4 < d) xin = *(const float4*)(a.x32 + (row0 + r) * d + 4 * q4);
+    if (r < nrows && 4 * q4 < d) xin = OWN_INPUT ? sl_load_f4_device_scope(a.x32 + (row0 + r) * d + 4 * q4) : *(const float4*)(a.x32 + (row0 + r) * d + 4 * q4);
   }
   const unsigned long long call = *a.counter;
   const int NTQ = (3 * d + 15) / 16, NT1 = (ff + 15) / 16, NTD = (d + 15) / 16, KSD = (d + 31) / 32, KSF = (ff + 31) / 32;   // tiles / reduction steps
@@ -498,14 +511,14 @@ __device__ __forceinline__ void tfd_layer_fwd_body(const ops_tfd_layer_args& a) 
 __global__ __launch_bounds__(64 * SL_NW) void tfd_layer_fwd_kernel(const ops_tfd_layer_args a) { tfd_layer_fwd_body<0>(a); }
 
 // Two consecutive layers in ONE launch (r04): a workgroup owns whole samples, so layer b's rows are the ones this workgroup has just
-// written as layer a's output -- no other workgroup's data is needed, only this workgroup's own stores have to have reached L2 (the
-// vector L1 of the CU holds no line of them: nothing here has read those addresses since the launch began).
+// written as layer a's output -- no other workgroup's data is needed: this workgroup's own stores have to have reached L2, and layer
+// b's input loads must not look into the CU's vector L1 (sl_load_f4_device_scope).
 static_assert(sizeof(ops_tfd_layer_args) % 8 == 0, "second argument block of the pair kernel sits right behind the first");
 __global__ __launch_bounds__(64 * SL_NW) void tfd_layer_pair_fwd_kernel(const ops_tfd_layer_args a, const ops_tfd_layer_args b) {
   tfd_layer_fwd_body<0>(a);
   __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wave's stores of y32 are acknowledged
   __syncthreads();
-  tfd_layer_fwd_body<(int)sizeof(ops_tfd_layer_args)>(b);
+  tfd_layer_fwd_body<(int)sizeof(ops_tfd_layer_args), true>(b);
 }
 
 
@@ -575,7 +588,7 @@ __device__ __forceinline__ SlBwdLds* sl_bwd_lds() {
   return &lds;
 }
 
-template <bool HAS32, bool HAS16, int ARGOFF>
+template <bool HAS32, bool HAS16, int ARGOFF, bool OWN_INPUT = false>       // OWN_INPUT: g32 was written by this workgroup earlier in this launch
 __device__ __forceinline__ void tfd_layer_bwd_body(const ops_tfd_layer_bwd_args& a) {
   constexpr int XS = 128 + 8, HS = 256 + 8, QS = 384 + 8, FS = 128 + 4;
   SlBwdLds* const L = sl_bwd_lds();                          // ONE instance, whichever kernels inline this body
@@ -612,7 +625,7 @@ __device__ __forceinline__ void tfd_layer_bwd_body(const ops_tfd_layer_bwd_args&
   const long poff = (row0 + (pr < nrows ? pr : 0)) * d + (4 * pq < d ? 4 * pq : 0);
   float4 gin = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
   uint2 gin16 = uint2{0u, 0u};
-  if (HAS32) gin = *(const float4*)(a.g32 + poff);
+  if (HAS32) gin = OWN_INPUT ? sl_load_f4_device_scope(a.g32 + poff) : *(const float4*)(a.g32 + poff);
   if (HAS16) gin16 = *(const uint2*)((const uint16_t*)a.g16 + poff);
   const float4 z2in = *(const float4*)(a.z2 + poff), z1in = *(const float4*)(a.z1 + poff);
   const int ur = tid >> 5, uq = tid & 31;                 // u rows: 16 rows x 32 pieces of 8 bf16
@@ -924,7 +937,7 @@ __global__ __launch_bounds__(64 * SL_NW) void tfd_layer_pair_bwd_kernel(const op
   tfd_layer_bwd_body<HAS32, HAS16, 0>(a);
   __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wave's stores of dx32 are acknowledged
   __syncthreads();
-  tfd_layer_bwd_body<true, false, (int)sizeof(ops_tfd_layer_bwd_args)>(b);
+  tfd_layer_bwd_body<true, false, (int)sizeof(ops_tfd_layer_bwd_args), true>(b);
 }
 
 

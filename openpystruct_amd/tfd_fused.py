@@ -214,7 +214,7 @@ class ActDropout(torch.autograd.Function):
 
 
 LAYER_PAIR_FWD = os.environ.get("OPS_AMD_TFD_LAYER_PAIR", "1") == "1"      # A/B switch: two consecutive layers' forward passes as one launch
-_PENDING_LAYER = None       # (argument block, output) of a layer whose forward launch waits for its successor
+_PENDING_LAYER = None       # (argument block, output, tensors to keep alive) of a layer whose forward launch waits for its successor
 LAYER_PAIR_BWD = os.environ.get("OPS_AMD_TFD_LAYER_PAIR_BWD", "1") == "1"  # ... and their backward passes
 _PENDING_BWD = None         # (argument block, dx32, tensors to keep alive) of a later layer whose backward launch waits for its predecessor
 
@@ -275,9 +275,11 @@ class EncoderLayerFn(torch.autograd.Function):
             ctx.pair_later = False               # this layer is the LATER one of a pair launch (its backward may wait for its predecessor's)
             if defer:                            # the next layer's call launches both (ops_tfd_encoder_layer_pair_fwd)
                 assert _PENDING_LAYER is None
-                _PENDING_LAYER = (a, y32)
+                # (everything the deferred launch writes stays alive until it is launched: in a no-grad pass nothing else holds these
+                #  tensors, and the caching allocator would hand their memory to the next layer's buffers -- whose launch is this same one)
+                _PENDING_LAYER = (a, y32, (x32, qkv, ctxa, z1, mean1, rstd1, y1_16, u, h, z2, mean2, rstd2, y16))
             elif _PENDING_LAYER is not None:
-                pa, py = _PENDING_LAYER
+                pa, py, _keep = _PENDING_LAYER
                 _PENDING_LAYER = None
                 assert py.data_ptr() == x32.data_ptr()
                 _check(lib.ops_tfd_encoder_layer_pair_fwd(ctypes.byref(pa), ctypes.byref(a), _stream(dev)), "ops_tfd_encoder_layer_pair_fwd")
@@ -342,7 +344,8 @@ class EncoderLayerFn(torch.autograd.Function):
                         _check(lib.ops_tfd_encoder_layer_bwd(ctypes.byref(a), s), "ops_tfd_encoder_layer_bwd")
                 elif LAYER_PAIR_BWD and ctx.pair_later and _TRACE_BWD is None and train._WGRAD_QUEUE is not None:      # (queue mode: a flush follows)
                     # the predecessor's backward call -- the next node autograd runs: this layer's inputs are its two outputs -- launches both
-                    _PENDING_BWD = (a, dx32, (g32, g16, d_f, d_u, d_a, dqkv, part))
+                    # (the saved tensors too: autograd releases them when this call returns, before the launch that reads them)
+                    _PENDING_BWD = (a, dx32, (g32, g16, d_f, d_u, d_a, dqkv, part, x16, qkv, ctxa, z1, mean1, rstd1, y1_16, u, h, z2, mean2, rstd2))
                 else:
                     _check(lib.ops_tfd_encoder_layer_bwd(ctypes.byref(a), s), "ops_tfd_encoder_layer_bwd")
                 if part is not None:

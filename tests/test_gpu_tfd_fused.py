@@ -484,6 +484,44 @@ def test_two_layers_in_one_launch_equal_the_two_launches(monkeypatch, B, p, laye
         assert float((g0 - g1).norm() / g0.norm()) < 1e-5
 
 
+def test_pair_launches_with_several_workgroups_per_cu(monkeypatch):
+    """The pair launches re-read rows they wrote in the same launch (device-scope loads: rows are not multiples of the 128-byte cache line, so
+    a workgroup's first / last line also holds a neighbour's bytes, and a neighbour on the same CU could leave a stale copy in the vector L1),
+    and the first layer's launch is DEFERRED to its successor's call: in a no-grad pass nothing but the pending record keeps the first
+    layer's buffers alive until then (without it the caching allocator handed their memory to the second layer's buffers: wrong evaluation
+    outputs, caught by test_evaluation_pass_through_the_one_launch_kernels_equals_the_module in full-suite order).  Evaluation-mode
+    forwards at several batch sizes with allocator churn in between: pair launch bit-equal to one launch per layer, every time."""
+    from openpystruct_amd import tfd_fused as TF, train
+    from openpystruct_amd.surrogates import ModelOnePassTransformerWithDiffusion
+    torch.manual_seed(5)
+    model = ModelOnePassTransformerWithDiffusion(6, 120, 100, dropout=0.1).to(DEV)
+    params = list(model.parameters())
+    flat = torch.zeros(sum(q.numel() for q in params), device=DEV)
+    opt = train.FlatClipAdam(params, flat, 1e-3)
+    stash, dst, patched = train.enable_shadow_linears(model, opt, params, flat)
+    assert TF.patch_model(model, seed=3, direct_param_grads=True)
+    model.diffusion._acp.fill_(1.0)                       # (x_noisy = x: the two passes see the same input whatever is drawn)
+    model.eval()
+    g = torch.Generator().manual_seed(6)
+    keep = []
+    bad = 0
+    for rep in range(6):
+        for B in (40, 100, 200, 300, 77):
+            x = torch.randn(B, 6, 120, generator=g).to(DEV)
+            outs = []
+            for pair in (False, True):
+                monkeypatch.setattr(TF, "LAYER_PAIR_FWD", pair)
+                with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+                    outs.append(model(x).float().clone())
+            bad += int(not torch.equal(outs[0], outs[1]))
+            keep.append(torch.empty(1000 * (rep + 1) + 8 * B, device=DEV))      # allocator churn: the next pass finds other free blocks
+            if rep % 2:
+                keep.pop(0)
+    train.disable_shadow_linears(patched)
+    TF.unpatch_model(model)
+    assert bad == 0, bad
+
+
 @pytest.mark.parametrize("B,p,alpha0,second", [(512, 0.1, 0.5, False), (288, 0.0, None, False), (37, 0.3, 0.5, False), (512, 0.1, 0.5, True), (37, 0.0, None, True)])
 def test_loss_on_the_head_tile_equals_the_loss_launch(monkeypatch, B, p, alpha0, second):
     """r04: the training loss of the fast path computed by the head's forward launch on its output tile and finished by the head's backward
