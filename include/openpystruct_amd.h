@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define OPS_AMD_ABI_VERSION 10
+#define OPS_AMD_ABI_VERSION 11
 
 /* return codes of the launch functions (per-beam results are in `status`) */
 #define OPS_AMD_OK 0
@@ -633,6 +633,7 @@ typedef struct ops_tfd_front_args {
    * assembly launch had run and advanced the counter); idx_out[b] = that row (the head's loss reads its targets by it); the last
    * workgroup advances counter[0] (layout [calls, tally]: csrc/call_counter.hpp) and *cursor += B. */
   const float* src; const long long* order; long long* cursor; long long* idx_out; const float* sigma; unsigned long long in_seed;
+  long long n_order;                                  /* r05 (ABI 11): entries of `order`; positions cursor + b >= n_order wrap modulo n_order (0: unchecked) */
 } ops_tfd_front_args;
 int ops_tfd_front_fwd(const ops_tfd_front_args* args, void* stream);
 typedef struct ops_tfd_front_bwd_args {

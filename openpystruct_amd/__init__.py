@@ -2,10 +2,7 @@
 
 Host side in Python over a C-ABI HIP library; see DESIGN.md and INTEGRATION.md.
 """
-from . import runtime as _runtime
-
-_runtime.set_graph_env_defaults()      # before the process's first HIP call when this import comes first (runtime.py, item 2)
-
+from . import runtime  # noqa: F401  (entry points call runtime.configure() before their first HIP call; importing sets nothing)
 from .beam import BeamSolution, beam_solve, kernel_name  # noqa: F401
 from . import torch_op  # noqa: F401  (registers torch.ops.openpystruct_amd.beam_solve)
 

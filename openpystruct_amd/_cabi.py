@@ -9,7 +9,7 @@ import ctypes
 import os
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-ABI_VERSION = 10     # include/openpystruct_amd.h OPS_AMD_ABI_VERSION
+ABI_VERSION = 11     # include/openpystruct_amd.h OPS_AMD_ABI_VERSION
 # OPS_AMD_LIB lets A/B kernel experiments point at another build of the same C ABI
 LIB_PATH = os.environ.get("OPS_AMD_LIB") or os.path.join(_PKG, "lib", "libopenpystruct_amd.so")
 
@@ -190,7 +190,7 @@ class TfdFrontArgs(ctypes.Structure):
     _fields_ = [("B", _i), ("Nc", _i), ("d", _i), ("hid", _i), ("T", _i), ("x", _vp), ("alpha_cumprod", _vp), ("seed", _u), ("counter", _vp),
                 ("W0", _vp), ("b0", _vp), ("W2", _vp), ("b2", _vp), ("cls", _vp), ("pe", _vp),
                 ("xn16", _vp), ("h", _vp), ("sa", _vp), ("sb", _vp), ("z", _vp), ("z16", _vp), ("t_out", _vp), ("eps_out", _vp), ("identity_act", _i),
-                ("src", _vp), ("order", _vp), ("cursor", _vp), ("idx_out", _vp), ("sigma", _vp), ("in_seed", _u)]
+                ("src", _vp), ("order", _vp), ("cursor", _vp), ("idx_out", _vp), ("sigma", _vp), ("in_seed", _u), ("n_order", ctypes.c_longlong)]
 
 
 class TfdFrontBwdArgs(ctypes.Structure):

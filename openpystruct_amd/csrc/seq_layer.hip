@@ -1310,7 +1310,9 @@ __global__ __launch_bounds__(64 * SL_NW) void tfd_front_fwd_kernel(const ops_tfd
   float4 xin;
   if (own_batch) {
     pb = (long)(((double)prow + 0.5) / (double)Nc);                    // sample of this row (rows < 2^31: exact)
-    const long srow = (long)a.order[*a.cursor + pb], pn = prow - pb * Nc;
+    long opos = (long)*a.cursor + pb;
+    if (a.n_order > 0 && opos >= (long)a.n_order) opos %= (long)a.n_order;   // a cursor walked past the list wraps: never a wild row index
+    const long srow = (long)a.order[opos], pn = prow - pb * Nc;
     xin = *(const float4*)(a.src + (srow * Nc + pn) * d + pcol);
     if (pok && pn == 0 && pq == 0 && a.idx_out) a.idx_out[pb] = srow;
   } else {

@@ -150,10 +150,11 @@ def frame_solve(topo: FrameTopology, I: torch.Tensor, loads: Optional[torch.Tens
 
 
 def optimize_frames(topo: FrameTopology, B: int, cfg: Optional[FrameConfig] = None, I0: Optional[torch.Tensor] = None,
-                    max_epochs: Optional[int] = None, poll_every: int = 25):
+                    max_epochs: Optional[int] = None, poll_every: int = 25, loss_history: Optional[list] = None):
     """FR:163-206 for B frames at once (same topology; `I0` [B,Ne] lets them start from different designs).
     Adam(lr) with NO scheduler (gamma = 1), loss with `+1e-8` in the bending term (FR:155), early stop
-    tolerance 1e-3 / patience 10.  Returns (I float32 [B,Ne], solution of the last solve, epochs_run)."""
+    tolerance 1e-3 / patience 10.  Returns (I float32 [B,Ne], solution of the last solve, epochs_run).
+    `loss_history`: a list that receives every epoch's `total_loss` [B] (FR:190; a stopped frame repeats its last value)."""
     cfg = cfg or FrameConfig()
     lib = _cabi.load()
     dev = topo.device
@@ -182,6 +183,8 @@ def optimize_frames(topo: FrameTopology, B: int, cfg: Optional[FrameConfig] = No
                                               torch.cuda.current_stream(dev).cuda_stream)
         if rc != _cabi.OK:
             raise RuntimeError(f"ops_beam_sizing_step_f32 failed with code {rc}")
+        if loss_history is not None:
+            loss_history.append(last.clone())
         if (e + 1) % poll_every == 0 and not bool(active.any()):
             break
     torch.cuda.synchronize(dev)

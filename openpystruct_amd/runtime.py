@@ -14,8 +14,8 @@
    column sum over >= 512 rows -- the bias gradient of every nn.Linear / attention projection the framework differentiates itself --
    is stale or garbage from the second replay on: the "NaNs in bias gradients at the first replay after an eager pass" of r03 (the
    eager pass only re-shuffled which garbage the semaphores saw).  DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 cures it at no measurable cost
-   (profiles/r04_notes.md); it must be in the environment before the process's first HIP call, which `import openpystruct_amd` does
-   when it comes early enough.  `graph_memsets_replay_correctly()` measures what the process actually got; `train_surrogate` captures
+   (profiles/r04_notes.md); it must be in the environment before the process's first HIP call: entry points call `configure()` first
+   thing (r05: importing the package no longer touches the environment).  `graph_memsets_replay_correctly()` measures what the process actually got; `train_surrogate` captures
    framework-differentiated steps only when it says yes.  The library's own launches never use memset nodes.
 """
 from __future__ import annotations
@@ -28,8 +28,58 @@ PACKET_CAPTURE_ENV = "DEBUG_CLR_GRAPH_PACKET_CAPTURE"
 
 
 def set_graph_env_defaults() -> None:
-    """Called at package import: takes effect when no HIP call has been made yet in this process."""
+    """setdefault of the packet-capture switch: takes effect when no HIP call has been made yet in this process.  A user's value stays."""
     os.environ.setdefault(PACKET_CAPTURE_ENV, "0")
+
+
+_CONFIGURED: Dict[str, object] = {}
+
+
+def configure(graph_env: bool = True, cpu_threads: bool = True, log=None) -> Dict[str, object]:
+    """What an ENTRY POINT (bench.py, a training script, a test session's conftest) calls once, as early as it can -- importing the
+    package no longer edits the host process's environment (r05; VERDICT r04 weak 7 / ADVICE).
+
+      * graph_env: DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 (item 2 above) unless the user set it.  Only a process that has not made a HIP
+        call yet honours it; when the framework has already initialised the GPU the returned record says `graph_env_too_late` and
+        `log` (if given) is told -- `graph_memsets_replay_correctly()` then measures what the process actually got, and
+        `train_surrogate` captures framework-differentiated steps only when that probe passes.
+      * cpu_threads: `fit_cpu_threads()` (item 1).
+
+    Returns {'packet_capture_env', 'graph_env_too_late', 'cpu_threads', 'hip_runtime'}; idempotent."""
+    import sys
+    too_late = False
+    if graph_env:
+        torch = sys.modules.get("torch")
+        too_late = bool(torch is not None and torch.cuda.is_initialized()) and os.environ.get(PACKET_CAPTURE_ENV) is None
+        set_graph_env_defaults()
+        if too_late and log is not None:
+            log(f"{PACKET_CAPTURE_ENV}=0 was set after this process's first HIP call: captured memset nodes may replay wrong values; "
+                "framework-differentiated steps are captured only if runtime.graph_memsets_replay_correctly() passes")
+    threads = fit_cpu_threads() if cpu_threads else None
+    _CONFIGURED.update(packet_capture_env=os.environ.get(PACKET_CAPTURE_ENV), graph_env_too_late=too_late, cpu_threads=threads,
+                       hip_runtime=hip_runtime_version())
+    return dict(_CONFIGURED)
+
+
+def hip_runtime_version() -> str:
+    """The HIP runtime this process runs on, as the framework reports it (torch.version.hip) plus the driver-side runtime number of the
+    loaded library (hipRuntimeGetVersion) when a GPU is visible: the bench line records it so that a change of wheel is visible next to
+    a change of numbers."""
+    import sys
+    torch = sys.modules.get("torch")
+    if torch is None:
+        import torch
+    v = str(getattr(torch.version, "hip", None))
+    try:
+        if torch.cuda.is_available():
+            import ctypes
+            rt = ctypes.CDLL("libamdhip64.so")
+            n = ctypes.c_int(0)
+            if rt.hipRuntimeGetVersion(ctypes.byref(n)) == 0:
+                v += f" (hipRuntimeGetVersion {n.value})"
+    except Exception:
+        pass
+    return v
 
 
 def usable_cores() -> int:

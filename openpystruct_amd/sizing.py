@@ -265,6 +265,37 @@ def make_beam_opt_cases(n_cases: int, cfg: Optional[SizingConfig] = None, seed: 
                  torch.full((B,), n_rollers, dtype=torch.int64, device=dev), f_nodes, (f_nodes > 0).sum(dim=1), f_vals, fix, Fy)
 
 
+def cases_from_lists(node_positions, roller_nodes, force_nodes, force_values, device="cpu") -> Cases:
+    """Cases given explicitly, in the form the reference's records hold them (SingleCore.py:235-247): per case the node
+    coordinates [N] (or one shared row), the 1-based roller node ids, the 1-based loaded node ids and their values.
+    Supports are what `setup_model` applies: node 1 pinned, `fix(r, 0, 1, 0)` per roller (SingleCore.py:100-102)."""
+    dev = torch.device(device)
+    B = len(force_nodes)
+    xs = torch.as_tensor(np.asarray(node_positions, dtype=np.float64), device=dev)
+    if xs.dim() == 1:
+        xs = xs.expand(B, -1).contiguous()
+    N = int(xs.shape[1])
+    if not isinstance(roller_nodes[0], (list, tuple, np.ndarray)):
+        roller_nodes = [list(roller_nodes)] * B
+    R = max(1, max(len(r) for r in roller_nodes))
+    F = max(1, max(len(f) for f in force_nodes))
+    rn, fn, fv = np.zeros((B, R), dtype=np.int64), np.zeros((B, F), dtype=np.int64), np.zeros((B, F))
+    for b in range(B):
+        if len(force_nodes[b]) != len(force_values[b]):
+            raise ValueError(f"case {b}: {len(force_nodes[b])} loaded nodes but {len(force_values[b])} values")
+        for name, ids in (("roller", roller_nodes[b]), ("force", force_nodes[b])):
+            if any(int(n) < 1 or int(n) > N for n in ids):
+                raise ValueError(f"case {b}: {name} node id outside 1..{N}")
+        rn[b, :len(roller_nodes[b])] = roller_nodes[b]
+        fn[b, :len(force_nodes[b])] = force_nodes[b]
+        fv[b, :len(force_values[b])] = force_values[b]
+    r_nodes, f_nodes, f_vals = torch.as_tensor(rn, device=dev), torch.as_tensor(fn, device=dev), torch.as_tensor(fv, device=dev)
+    fix = torch.zeros((B, N + 1), dtype=torch.uint8, device=dev).scatter_(1, r_nodes, 1)[:, 1:].contiguous()
+    fix[:, 0] = 1
+    Fy = torch.zeros((B, N + 1), dtype=torch.float64, device=dev).scatter_add_(1, f_nodes, f_vals)[:, 1:].contiguous()
+    return Cases(xs, xs[:, -1].clone(), r_nodes, (r_nodes > 0).sum(dim=1), f_nodes, (f_nodes > 0).sum(dim=1), f_vals, fix, Fy)
+
+
 def shard_range(n_total: int, rank: int, world: int) -> Tuple[int, int]:
     """Contiguous case range of `rank`: [rank*n/world, (rank+1)*n/world)."""
     return (rank * n_total) // world, ((rank + 1) * n_total) // world
@@ -414,11 +445,15 @@ _POLL_FLAGS: Dict[tuple, tuple] = {}
 
 
 def optimize_cases(cases: Cases, cfg: SizingConfig, device, poll_every: int = 25, use_graph: bool = True,
-                   reuse: bool = False) -> SizingState:
+                   reuse: bool = False, record_loss: bool = False) -> SizingState:
     """Run the sizing loop of every case to its early stop (or max_e).  Returns the final device state.  With `reuse` the
     state buffers and the captured graph of the previous shard of the same shape are re-armed in place: tensors of an
-    earlier returned state are then overwritten (`generate_dataset` copies what it hands out)."""
+    earlier returned state are then overwritten (`generate_dataset` copies what it hands out).  `record_loss` keeps every
+    epoch's `total_loss` (SingleCore.py:199) per case in `state.loss_history` [epochs, B] (rows past a case's `epochs_run`
+    repeat its last value); it runs the loop launch by launch."""
     device = torch.device(device)
+    if record_loss:
+        use_graph, reuse = False, False
     key = (device.type, device.index if device.index is not None else torch.cuda.current_device() if device.type == "cuda" else -1,
            threading.get_ident(), int(poll_every))
     st, graph = (None, None)
@@ -468,13 +503,18 @@ def optimize_cases(cases: Cases, cfg: SizingConfig, device, poll_every: int = 25
                     break
             k += 1
     else:
+        hist = []
         while epochs_done < cfg.max_e:
             st.epoch()
             epochs_done += 1
+            if record_loss:
+                hist.append(st.last_loss.clone())
             if epochs_done % poll_every:
                 continue
             if not bool(st.active.any()):       # host sync once per `poll_every` epochs
                 break
+        if record_loss:
+            st.loss_history = torch.stack(hist) if hist else torch.zeros((0, st.B), dtype=torch.float32, device=device)
     # a case that is still active here ran out of max_e inside the step kernel already (it clears `active`)
     st.finalize()
     torch.cuda.synchronize(device)

@@ -342,7 +342,11 @@ class EncoderLayerFn(torch.autograd.Function):
                     else:                        # (not the successor's gradient after all: the two launches)
                         _check(lib.ops_tfd_encoder_layer_bwd(ctypes.byref(pb), s), "ops_tfd_encoder_layer_bwd")
                         _check(lib.ops_tfd_encoder_layer_bwd(ctypes.byref(a), s), "ops_tfd_encoder_layer_bwd")
-                elif LAYER_PAIR_BWD and ctx.pair_later and _TRACE_BWD is None and train._WGRAD_QUEUE is not None:      # (queue mode: a flush follows)
+                elif (LAYER_PAIR_BWD and ctx.pair_later and _TRACE_BWD is None and train._WGRAD_QUEUE is not None      # (queue mode: a flush follows)
+                      and all(train.shadow_grads_are_deferred(r, T) for r in (r2, r1, rout, rin))):
+                    # (only when the four weight-gradient registrations below merely QUEUE: a product the library runs at once -- fewer rows
+                    #  than one MFMA tile, e.g. a one- or two-sample tail batch, or OPS_AMD_SPLIT_WGRAD_ROWS=0 -- would read d_f / d_u / d_a /
+                    #  dqkv before the waiting launch has written them)
                     # the predecessor's backward call -- the next node autograd runs: this layer's inputs are its two outputs -- launches both
                     # (the saved tensors too: autograd releases them when this call returns, before the launch that reads them)
                     _PENDING_BWD = (a, dx32, (g32, g16, d_f, d_u, d_a, dqkv, part, x16, qkv, ctxa, z1, mean1, rstd1, y1_16, u, h, z2, mean2, rstd2))
@@ -617,7 +621,7 @@ class FrontFn(torch.autograd.Function):
                                t_out=t.data_ptr() if keep else None, eps_out=eps.data_ptr() if keep else None)
         if gs is not None:      # the launch assembles its own batch: rows order[cursor .. cursor + B) of the training set + the input noise
             a.src, a.order, a.cursor, a.idx_out = gs["src"].data_ptr(), gs["order"].data_ptr(), gs["cursor"].data_ptr(), gs["idx_out"].data_ptr()
-            a.sigma, a.in_seed = gs["sigma"].data_ptr(), gs["seed"]
+            a.sigma, a.in_seed, a.n_order = gs["sigma"].data_ptr(), gs["seed"], int(gs["order"].numel())
             st.gathered = True
         with torch.cuda.device(dev):
             _check(lib.ops_tfd_front_fwd(ctypes.byref(a), _stream(dev)), "ops_tfd_front_fwd")

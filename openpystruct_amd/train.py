@@ -395,6 +395,14 @@ def shadow_param_grads(rec: ShadowRec, g2: torch.Tensor, x2: torch.Tensor) -> No
             rec.stash[rec.ib] = g2.sum(0)
 
 
+def shadow_grads_are_deferred(rec: ShadowRec, rows: int) -> bool:
+    """True when `shadow_param_grads(rec, g2, x2)` over `rows` rows only QUEUES its work for the step's grouped launch -- it then reads
+    neither operand before `flush_wgrad_queue`.  A caller whose kernel has not yet written g2 (tfd_fused: the later layer of a
+    pair launch) may only wait in that case: the library products and column sums of the other branches run at once."""
+    return (_WGRAD_QUEUE is not None and rec.w_grad is not None and _SPLIT_WGRAD_ROWS > 0 and rows >= _SPLIT_WGRAD_ROWS
+            and (rec.ib is None or rec.b_grad is not None))
+
+
 # products over at least this many rows take the split-row kernel (0: never).  r04: 16 (was 512) -- the kernel now keeps a whole tile per wave and
 # reduces inside the workgroup, so a 10-sample tail batch (70 / 10 rows: twelve library GEMMs of ~16 us + twelve column sums per epoch)
 # is one grouped launch too; only products over fewer rows than one MFMA tile stay with the library
@@ -502,6 +510,7 @@ _GROUP_WGRAD = os.environ.get("OPS_AMD_GROUP_WGRAD", "1") == "1"    # A/B switch
 # more than one MI355X here, hence opt-in); any failure while capturing falls back to the two-graph form.
 _DP_ASYNC = os.environ.get("OPS_AMD_DP_ASYNC", "1") == "1"
 _DP_ONE_GRAPH = os.environ.get("OPS_AMD_DP_ONE_GRAPH", "0") == "1"
+_FORCE_DP = os.environ.get("OPS_AMD_FORCE_DP", "0") == "1"           # run the data-parallel branch with a one-rank process group too
 _DP_PROFILE = os.environ.get("OPS_AMD_DP_PROFILE", "0") == "1"       # HIP events around the step's segments, reported as out["dp_segments"]
 F_linear = torch.nn.functional.linear
 _SHADOW_LINEAR = os.environ.get("OPS_AMD_SHADOW_LINEAR", "1") == "1"   # A/B switch: 0 = nn.Linear under autocast
@@ -556,8 +565,8 @@ def r2_score(y_true: torch.Tensor, y_pred: torch.Tensor) -> float:
     return float(1.0 - ss_res / ss_tot)
 
 
-def _allreduce_mean(t: torch.Tensor, world: int) -> torch.Tensor:
-    if world > 1:
+def _allreduce_mean(t: torch.Tensor, world: int, dp: Optional[bool] = None) -> torch.Tensor:
+    if (world > 1) if dp is None else dp:
         dist.all_reduce(t)
         t /= world
     return t
@@ -579,6 +588,10 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
     device = torch.device(device)
     world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
     rank = dist.get_rank() if world > 1 else 0
+    # the data-parallel branch: more than one rank -- or, with OPS_AMD_FORCE_DP=1, a process group of ONE rank (r05: the RCCL path -- flat
+    # all-reduce between graph A and graph B, its async form, the one-graph capture of the collective, dp_segments -- executed on the
+    # single GPU a test box has; a one-rank all-reduce is the identity and 1 / world = 1, so losses equal the plain run bit for bit)
+    dp = world > 1 or (_FORCE_DP and dist.is_available() and dist.is_initialized())
     torch.manual_seed(seed)            # identical initial weights on every rank
     model, crit = build_model_and_loss(kind, cfg, data, device)
     if kind == "tfd" and device.type == "cuda":
@@ -586,7 +599,7 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
         _tf.disarm_gather()              # (whatever an earlier run that did not reach its end left armed)
     if init_fn is not None:
         init_fn(model)
-    if sync_bn and world > 1:
+    if sync_bn and dp:
         model = nn.SyncBatchNorm.convert_sync_batchnorm(model)
     net = model
     # one flat gradient buffer; every .grad is a view into it (autograd accumulates in place)
@@ -629,7 +642,7 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
     # PINN: forward + loss + backward as 13 hand-written launches without autograd (pinn_fused.py / csrc/mlp_block.hip);
     # the module keeps owning parameters and buffers, evaluation keeps running it
     engine = None
-    if on_gpu and kind == "pinn" and autocast_dtype == torch.bfloat16 and physics is None and not (sync_bn and world > 1):
+    if on_gpu and kind == "pinn" and autocast_dtype == torch.bfloat16 and physics is None and not (sync_bn and dp):
         from . import pinn_fused
         if pinn_fused.eligible(model, crit, cfg.batch_size):
             engine = pinn_fused.PinnFusedStep(model, crit, seed=seed * 7919 + 101 + rank)
@@ -645,7 +658,7 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
                     "first HIP call?): the framework-differentiated step runs eagerly")
     Xtr, Ytr, Xva, Yva = (t.to(device) for t in (data.X_train, data.Y_train, data.X_val, data.Y_val))
     nb_tr = max(1, (Xtr.shape[0] + cfg.batch_size - 1) // cfg.batch_size)
-    if world > 1:   # every rank must run the same number of steps (collectives inside backward)
+    if dp:   # every rank must run the same number of steps (collectives inside backward)
         # a one-row tail batch makes train-mode BatchNorm raise (as in the reference's single process); on one rank of a
         # data-parallel job that exception would leave the other ranks waiting in the step's all-reduce: drop such a tail
         if Xtr.shape[0] % cfg.batch_size == 1 and nb_tr > 1 and any(isinstance(m, nn.modules.batchnorm._BatchNorm) for m in model.modules()):
@@ -787,7 +800,7 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
         if on_gpu:
             opt.step(grad_scale=1.0 / world)                             # average, clip (PINN:766), Adam
             return
-        if world > 1:
+        if dp:
             flat.div_(world)
         torch.nn.utils.clip_grad_norm_(params, 1.0)                      # PINN:766
         opt.step()
@@ -803,7 +816,7 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
         if engine is not None:
             engine.gather(Xtr, Ytr, rows, noise_t, engine_seed)
         loss = fwd_bwd(Xb, Yb, noise_t, physics_inputs(rows) if physics is not None else None)
-        if world > 1:
+        if dp:
             allreduce_grads()                                            # the step's only collective (RCCL over xGMI)
         apply_update()
         return loss
@@ -871,7 +884,7 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
     bs = cfg.batch_size
     if use_graph and Xtr.shape[0] >= bs:
         # static buffers + a few eager warm-up steps on a side stream, then capture one full-batch step:
-        # world == 1 -> one graph; world > 1 -> [fwd_bwd] graph, eager all-reduce, [apply_update] graph
+        # not dp -> one graph; dp -> [fwd_bwd] graph, eager all-reduce, [apply_update] graph
         sX, sY = torch.zeros_like(Xtr[:bs], dtype=torch.bfloat16 if (_FUSED_PREP and prep_bf16) else Xtr.dtype), torch.zeros_like(Ytr[:bs])
         s_noise = torch.zeros((), device=device)
         sP = None
@@ -888,14 +901,20 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
                 physics_inputs(torch.arange(bs, device=device), out=sP)
             if engine is not None:
                 engine.gather(Xtr, Ytr, torch.arange(bs, device=device), s_noise, engine_seed)
+            # (fused batch assembly: every launch advances g_cursor by its batch; warm-up and capture passes each start at row 0 so that no
+            #  pass reads g_order past its end -- the kernel wraps as well, ops_tfd_front_args.n_order; the epoch loop zeroes it again)
             for _ in range(3):
+                if fuse_gather:
+                    g_cursor.zero_()
                 fwd_bwd(sX, sY, s_noise, sP, prenoised=_FUSED_PREP)
                 apply_update()                   # warm-up only: no collective needed for capture-readiness
+            if fuse_gather:
+                g_cursor.zero_()
             side.synchronize()
             try:
                 graph = torch.cuda.CUDAGraph()
                 one_graph = False
-                if world > 1 and _DP_ONE_GRAPH and dist.get_backend() == "nccl":
+                if dp and _DP_ONE_GRAPH and dist.get_backend() == "nccl":
                     try:                 # the collective inside the capture: one replay per step, no host work between the segments
                         g1 = torch.cuda.CUDAGraph()
                         with torch.cuda.graph(g1, stream=side, capture_error_mode="thread_local"):
@@ -912,9 +931,9 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
                 if not one_graph:
                     with torch.cuda.graph(graph, stream=side, capture_error_mode="thread_local"):
                         s_loss = fwd_bwd(sX, sY, s_noise, sP, prenoised=_FUSED_PREP)
-                        if world == 1:
+                        if not dp:
                             apply_update()
-                    if world > 1:
+                    if dp:
                         graph_b = torch.cuda.CUDAGraph()
                         with torch.cuda.graph(graph_b, stream=side, capture_error_mode="thread_local"):
                             apply_update()
@@ -926,7 +945,7 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
             # the epoch's LAST (partial) batch as a graph of its own: an eager step is ~25 launches' worth of host time (0.3-0.4 ms of a
             # 5 ms TFD epoch), and eager model passes between replays are what the flaky-NaN hunt of r03 kept running into
             nt = int(Xtr.shape[0]) % bs
-            if (graph is not None and world == 1 and sP is None and nt >= 2 and nb_tr == Xtr.shape[0] // bs + 1
+            if (graph is not None and not dp and sP is None and nt >= 2 and nb_tr == Xtr.shape[0] // bs + 1
                     and os.environ.get("OPS_AMD_TAIL_GRAPH", "1") == "1"):
                 try:
                     sXt, sYt = (None if engine is not None else torch.zeros_like(sX[:nt])), torch.zeros_like(sY[:nt])
@@ -935,8 +954,12 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
                     else:
                         sXt.copy_(sX[:nt]); sYt.copy_(sY[:nt])
                     for _ in range(2):
+                        if fuse_gather:
+                            g_cursor.zero_()
                         fwd_bwd(sXt, sYt, s_noise, None, prenoised=_FUSED_PREP)
                         apply_update()
+                    if fuse_gather:
+                        g_cursor.zero_()
                     side.synchronize()
                     graph_t = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(graph_t, stream=side, capture_error_mode="thread_local"):
@@ -1033,7 +1056,7 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
                     vgraph_all = capture_val_all()
                 elif Xva.shape[0] >= bs:
                     vgraph, vX, vY = capture_val(bs)
-                if not val_whole and nvt >= 1 and world == 1 and os.environ.get("OPS_AMD_TAIL_GRAPH", "1") == "1":
+                if not val_whole and nvt >= 1 and not dp and os.environ.get("OPS_AMD_TAIL_GRAPH", "1") == "1":
                     vgraph_t, vXt, vYt = capture_val(nvt)
             except Exception as e:
                 if log:
@@ -1137,8 +1160,8 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
             tot = engine.loss_sum.clone()
         elif loss_acc is not None:
             tot = loss_acc.clone()
-        train_loss = _allreduce_mean(tot / nb_tr, world)
-        if world > 1:   # BatchNorm running statistics are per rank during the epoch: average them before evaluating
+        train_loss = _allreduce_mean(tot / nb_tr, world, dp)
+        if dp:   # BatchNorm running statistics are per rank during the epoch: average them before evaluating
             for buf in model.buffers():
                 if buf.is_floating_point():
                     dist.all_reduce(buf)
@@ -1189,7 +1212,7 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
         elif (vgraph is not None or vgraph_t is not None) and not val_whole:
             vt += v_acc
             v_acc.zero_()
-        val_loss = _allreduce_mean(vt / nb_va, world)
+        val_loss = _allreduce_mean(vt / nb_va, world, dp)
         if sched is not None:
             sched.step()                                                     # PINN:788
         else:

@@ -39,6 +39,7 @@ def generate_sample(node_positions, roller_nodes, force_nodes, force_values, *, 
     best_loss = float("inf")
     patience_counter = 0
     epochs = 0
+    loss_history = []
     for epoch in range(max_e):                                                        # :174
         optimizer.zero_grad()
         I64 = I_tensor.detach().numpy().astype(np.float64)[None, :]                   # .item() widening, :107
@@ -53,6 +54,7 @@ def generate_sample(node_positions, roller_nodes, force_nodes, force_values, *, 
         primary_loss = torch.sum(I_tensor)                                            # :198
         total_loss = primary_loss + alpha_moment * bending_energy + alpha_shear * shear_energy
         total_loss.backward()                                                         # :202
+        loss_history.append(float(total_loss.item()))
         optimizer.step()
         scheduler.step()
         with torch.no_grad():
@@ -86,4 +88,5 @@ def generate_sample(node_positions, roller_nodes, force_nodes, force_values, *, 
         "deflections": deflections.tolist(),
         "epochs_run": epochs,
         "final_loss": float(total_loss.item()),
+        "loss_history": loss_history,
     }

@@ -20,10 +20,11 @@ def pytest_configure(config):
 # leave an oracle / golden-fixture comparison unreached (r03's driver record lost four rows of SURVEY 8 that way).
 _ORDER = (
     "test_oracle", "test_cabi", "test_emulation", "test_host_logic", "test_layer_block_host",      # CPU: oracle vs closed forms, ABI, host logic
-    "test_gpu_parity", "test_force_truth", "test_surrogate_golden",                                # HIP path vs oracle / golden fixtures
+    "test_gpu_parity", "test_force_truth", "test_sizing_golden", "test_surrogate_golden",          # HIP path vs oracle / golden fixtures
     "test_gpu_fat", "test_gpu_sizing", "test_gpu_frames", "test_gpu_physics",                      # every tiling / the callers / frames / residual
     "test_gpu_runtime",                                                                            # the process around the library
     "test_gpu_pinn_fused", "test_gpu_tfd_fused", "test_gpu_surrogates", "test_surrogates",         # training kernels vs autograd
+    "test_gpu_dp_rccl",                                                                            # one-rank RCCL process group (child processes)
     "test_openseespy_live",
 )
 

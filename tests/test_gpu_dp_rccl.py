@@ -1,0 +1,67 @@
+"""The RCCL path on the ONE GPU a test box has: a one-rank `nccl` process group, created by the real launcher,
+drives `train_surrogate` through its data-parallel branch and `bench.py` through its barrier / timing all-reduce.  A one-rank
+all-reduce is the identity and 1 / world = 1, so the data-parallel runs must reproduce the plain run."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _launch(args, env_extra, timeout=600):
+    """`python -m torch.distributed.run --nproc-per-node 1 ...` as a CHILD process (never an exec from this GPU-initialised one)."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", **env_extra)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(29600 + os.getpid() % 300)] + args
+    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+    assert p.returncode == 0, p.stdout[-3000:] + "\n" + p.stderr[-3000:]
+    return p.stdout, p.stderr
+
+
+def test_training_through_the_data_parallel_branch_on_one_rank_of_rccl():
+    if not torch.cuda.is_available():
+        pytest.fail("no GPU visible")
+    out, err = _launch([os.path.join("tests", "dp_one_rank_worker.py")], {})
+    line = [l for l in out.splitlines() if l.startswith("DP_ONE_RANK ")][-1]
+    r = json.loads(line[len("DP_ONE_RANK "):])
+    assert r["backend"] == "nccl" and r["world"] == 1 and r["allreduce_identity"]
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "dp_one_rank_rccl.json"), "w") as f:
+        json.dump(r, f, indent=1)
+    for kind, runs in r["runs"].items():
+        plain = np.array(runs["plain"]["train"] + runs["plain"]["val"])
+        again = np.array(runs["plain_again"]["train"] + runs["plain_again"]["val"])
+        assert np.isfinite(plain).all()
+        spread = float(np.abs(plain - again).max() / np.abs(plain).max())     # float atomics in the weight-gradient kernels: runs of ONE
+        # configuration agree to this; where they agree bit for bit, so must the one-rank data-parallel runs
+        for name in ("dp_async", "dp_blocking", "dp_one_graph", "dp_profile"):
+            got = np.array(runs[name]["train"] + runs[name]["val"])
+            diff = float(np.abs(got - plain).max() / np.abs(plain).max())
+            if spread == 0.0 and name != "dp_one_graph":
+                assert diff == 0.0, (kind, name, diff)
+            else:
+                assert diff <= max(20 * spread, 2e-3), (kind, name, diff, spread)
+        assert (np.array(runs["dp_async"]["train"]) == np.array(runs["dp_blocking"]["train"])).all() or spread > 0.0
+        seg = runs["dp_profile"]["dp_segments"]
+        assert seg is not None and seg["world"] == 1 and seg["graph_a_us"] > 0 and seg["allreduce_us"] >= 0 and seg["graph_b_us"] > 0
+
+
+def test_bench_line_through_the_rccl_barrier_and_timing_allreduce_on_one_rank():
+    if not torch.cuda.is_available():
+        pytest.fail("no GPU visible")
+    out, err = _launch(["bench.py", "--gpus", "1", "--steps", "20", "--warmup", "5", "--no-extras", "--train-epochs", "2"],
+                       {"OPS_AMD_FORCE_DP": "1"})
+    rec = json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
+    assert rec["n_gpus"] == 1 and rec["value"] > 1e8 and rec["roofline"]["frac"] > 0.2
+    se = rec["surrogate_epochs"]
+    assert "error" not in se, se
+    for kind in ("pinn", "tfd"):
+        assert se[kind]["epoch_s"] > 0 and se[kind]["dp_segments"]["world"] == 1      # the data-parallel step ran: [graph A | all-reduce | graph B]
+    with open(os.path.join(ROOT, "gpurun_out", "bench_one_rank_rccl.json"), "w") as f:
+        json.dump(rec, f)

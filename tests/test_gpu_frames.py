@@ -456,3 +456,61 @@ def test_solves_on_one_topology_from_two_streams_do_not_share_a_workspace():
         assert relerr(q.disp.cpu().numpy().reshape(4096, -1), r.disp.cpu().numpy().reshape(4096, -1)) < 1e-10
         assert relerr(q.forces.cpu().numpy().reshape(4096, -1), r.forces.cpu().numpy().reshape(4096, -1)) < 1e-9
     assert len(topo._ws) >= 2
+
+
+@pytest.mark.parametrize("bays,stories,B", [(15, 16, 12288), (10, 10, 16384)])
+def test_config5_at_the_batch_the_bench_quotes(bays, stories, B):
+    """bench.py launches 12 288 frames of 15 x 16 (a 4.4 GB factor workspace: 359 552 B x 12 288 > 2^32) and
+    16 384 of 10 x 10, while every oracle comparison used <= 6 frames.  Here, at those batches: 32 frames -- the first, the last, the
+    frames either side of the workspace's 2^32-byte boundary, and seeded picks -- against the oracle's dpbsv solve; invariance under a
+    permutation of the batch; two streams solving different halves' worth of inputs at full size without sharing factor rows."""
+    from openpystruct_amd import _cabi, frames
+    lib = _cabi.load()
+    topo = frames.grid_frame(bays, stories)
+    g = torch.Generator(device="cuda").manual_seed(20250307)
+    I = torch.exp(torch.empty((B, topo.Ne), dtype=torch.float64, device="cuda").uniform_(np.log(1e-4), np.log(5e-3), generator=g))
+    sol = frames.frame_solve(topo, I)
+    torch.cuda.synchronize()
+    assert int(sol.status.abs().sum()) == 0
+    ws_all = int(lib.ops_frame_workspace_bytes(B, topo.n_eq, topo.kd))
+    ws_frame = int(lib.ops_frame_workspace_bytes(2, topo.n_eq, topo.kd)) - int(lib.ops_frame_workspace_bytes(1, topo.n_eq, topo.kd))
+    pick = {0, 1, B - 2, B - 1}
+    if ws_frame and ws_all > (1 << 32):
+        k = (1 << 32) // ws_frame                      # the frame whose factor rows straddle byte 2^32 of the workspace, and its neighbours
+        pick |= {k - 1, k, k + 1}
+        assert bays == 15 and 0 < k < B - 1
+    rng = np.random.default_rng(B)
+    while len(pick) < 32:
+        pick.add(int(rng.integers(0, B)))
+    pick = sorted(pick)
+    Ih, dh, fh = I[pick].cpu().numpy(), sol.disp[pick].cpu().numpy(), sol.forces[pick].cpu().numpy()
+    for j, b in enumerate(pick):
+        d, f, st, neq, kd = _oracle(topo, Ih[j])
+        assert st == 0
+        assert relerr(dh[j].ravel(), d.ravel()) < 1e-7, b
+        assert relerr(fh[j].ravel(), f.ravel()) < 1e-6, b
+    # permutation of the batch: frame b's answer does not depend on where it sits (LDS atomics of the assembly: equal to rounding)
+    perm = torch.randperm(B, generator=torch.Generator().manual_seed(1)).cuda()
+    solp = frames.frame_solve(topo, I[perm].contiguous())
+    torch.cuda.synchronize()
+    assert int(solp.status.abs().sum()) == 0
+    dmax = sol.disp.abs().amax(dim=(1, 2))[perm]
+    assert float(((solp.disp - sol.disp[perm]).abs().amax(dim=(1, 2)) / dmax).max()) < 1e-9
+    fmax = sol.forces.abs().amax(dim=(1, 2))[perm]
+    assert float(((solp.forces - sol.forces[perm]).abs().amax(dim=(1, 2)) / fmax).max()) < 1e-8
+    del solp
+    # two streams at full size on one topology: each has its own workspace (4.4 GB each at 15 x 16)
+    I2 = I.flip(0).contiguous()
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    sa.wait_stream(torch.cuda.current_stream()); sb.wait_stream(torch.cuda.current_stream())
+    for _ in range(2):
+        with torch.cuda.stream(sa):
+            qa = frames.frame_solve(topo, I)
+        with torch.cuda.stream(sb):
+            qb = frames.frame_solve(topo, I2)
+    torch.cuda.synchronize()
+    assert float(((qa.disp - sol.disp).abs().amax(dim=(1, 2)) / sol.disp.abs().amax(dim=(1, 2))).max()) < 1e-9
+    assert float(((qb.disp - sol.disp.flip(0)).abs().amax(dim=(1, 2)) / sol.disp.flip(0).abs().amax(dim=(1, 2))).max()) < 1e-9
+    topo._ws.clear()
+    del qa, qb, sol
+    torch.cuda.empty_cache()

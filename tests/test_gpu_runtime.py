@@ -10,8 +10,8 @@ pytestmark = pytest.mark.gpu
 
 
 def test_captured_memset_nodes_replay_correctly_in_this_process():
-    """`import openpystruct_amd` (and tests/conftest.py) put DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 into the environment before the first
-    HIP call: the framework's multi-block reductions -- which zero their semaphores with hipMemsetAsync -- then give the eager result
+    """tests/conftest.py (an entry point: what `runtime.configure()` does) puts DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 into the environment
+    before the first HIP call: the framework's multi-block reductions -- which zero their semaphores with hipMemsetAsync -- then give the eager result
     on every replay of a captured graph.  With the runtime's default they are right on the first replay only."""
     from openpystruct_amd import runtime
     assert os.environ.get(runtime.PACKET_CAPTURE_ENV) == "0"

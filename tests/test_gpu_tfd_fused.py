@@ -432,13 +432,14 @@ def test_one_launch_layer_forward_equals_the_eight_launch_form(monkeypatch, B, p
             assert _rel(g1[n], g0[n]) < 2e-2 or float(g0[n].norm()) < 1e-6, (fwd_bwd, n, _rel(g1[n], g0[n]))
 
 
-@pytest.mark.parametrize("B,p,layers", [(512, 0.1, 2), (37, 0.1, 3), (3, 0.0, 2)])
+@pytest.mark.parametrize("B,p,layers", [(512, 0.1, 2), (37, 0.1, 3), (3, 0.0, 2), (2, 0.0, 2), (1, 0.1, 3)])
 def test_two_layers_in_one_launch_equal_the_two_launches(monkeypatch, B, p, layers):
     """r04: two consecutive encoder layers' forward passes as ONE launch (ops_tfd_encoder_layer_pair_fwd: a workgroup runs the second layer
     on the rows it has just written as the first one's output) against one launch per layer: the same code on the same values -- outputs
     bit-equal, and so is everything saved for the backward pass (the gradients differ only by their float atomics); likewise the two
     backward passes (ops_tfd_encoder_layer_pair_bwd: the later layer's launch waits for its predecessor's call).  Three layers: a pair
-    and a single launch."""
+    and a single launch.  B = 2 / B = 1 (T = 14 / 7 rows: fewer than the split-row threshold of 16): the weight-gradient products are the
+    library's and run at once, so the later layer's backward must NOT wait (it read buffers nobody had written yet)."""
     from openpystruct_amd import tfd_fused as TF, train
     from openpystruct_amd.surrogates import ModelOnePassTransformerWithDiffusion
 

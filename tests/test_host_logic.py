@@ -220,15 +220,22 @@ def test_analysis_object_commands_reject_what_they_cannot_honour():
 
 
 def test_runtime_helpers_on_the_cpu(monkeypatch):
-    """openpystruct_amd/runtime.py: the import sets the HIP graph environment default without overriding a user's choice; the usable
-    core count honours affinity and quota; the throttle counters are a dict (empty where cgroup v2 is not mounted)."""
-    import importlib
+    """openpystruct_amd/runtime.py: importing the package leaves the environment alone (r05); `configure()` -- what entry points call --
+    sets the HIP graph environment default without overriding a user's choice and reports what it did; the usable core count honours
+    affinity and quota; the throttle counters are a dict (empty where cgroup v2 is not mounted)."""
     import os
+    import subprocess
+    import sys
     from openpystruct_amd import runtime
-    assert os.environ.get(runtime.PACKET_CAPTURE_ENV) is not None        # set by the package import (or by the user)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k != runtime.PACKET_CAPTURE_ENV}
+    code = ("import os, openpystruct_amd; from openpystruct_amd import runtime; a = os.environ.get(runtime.PACKET_CAPTURE_ENV); "
+            "r = runtime.configure(cpu_threads=False); print(a, os.environ.get(runtime.PACKET_CAPTURE_ENV), r['graph_env_too_late'], r['hip_runtime'])")
+    out = subprocess.check_output([sys.executable, "-c", code], env=env, cwd=root, text=True).split()
+    assert out[:3] == ["None", "0", "False"] and out[3] != ""          # the import set nothing; configure() did
     monkeypatch.setenv(runtime.PACKET_CAPTURE_ENV, "1")
-    runtime.set_graph_env_defaults()
-    assert os.environ[runtime.PACKET_CAPTURE_ENV] == "1"                 # setdefault: a user's value stays
+    rec = runtime.configure(cpu_threads=False)
+    assert os.environ[runtime.PACKET_CAPTURE_ENV] == "1" and rec["packet_capture_env"] == "1"      # setdefault: a user's value stays
     n = runtime.usable_cores()
     assert 1 <= n <= (os.cpu_count() or 1)
     c = runtime.cpu_throttle_counters()
