@@ -1066,8 +1066,21 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
             v_acc.zero_()
             net.train()
 
+    # "the warm-up steps never happened" for the dropout / noise streams too: their call counters go back to zero, so that a seeded run
+    # draws the same masks however many warm-up and capture passes its launch mode needed (one graph, two graphs around the collective,
+    # with or without a tail graph, eager) -- r05: the one-rank data-parallel run reproduces the plain run
+    if on_gpu:
+        prep_counter.zero_()
+        if engine is not None:
+            engine.drop_counter.zero_(); engine.prep_counter.zero_()
+        if fuse_gather:
+            g_cursor.zero_()
     best_val, best_state, no_improve = float("inf"), None, 0
     n_epochs = max_epochs if max_epochs is not None else cfg.num_epochs
+    # the epochs' shuffles come from a generator of their own: the framework's global one is consumed by eager steps (input noise,
+    # framework dropout) but not by graph replays, so the batch order of epoch 2 would depend on which steps happened to run eagerly
+    perm_gen = torch.Generator(device=device)
+    perm_gen.manual_seed(seed * 1000003 + 17 + rank)
     seg_ev = [] if (_DP_PROFILE and on_gpu and graph is not None) else None      # per-step event quadruples (first epoch excluded below)
     for epoch in range(1, n_epochs + 1):
         if device.type == "cuda":
@@ -1078,7 +1091,7 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
         if batch_order is not None:
             order = torch.as_tensor(batch_order(epoch), dtype=torch.long).reshape(-1).to(device)
         else:
-            order = torch.randperm(Xtr.shape[0], device=device)              # DataLoader(shuffle=True), PINN:701
+            order = torch.randperm(Xtr.shape[0], device=device, generator=perm_gen)      # DataLoader(shuffle=True), PINN:701
         tot = torch.zeros((), device=device)
         if engine is not None:
             engine.loss_sum.zero_()                                          # the output launch adds every step's loss to it
@@ -1232,6 +1245,7 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
             break
     # the captured graphs (and their private memory pools) go before anything else runs on this device: the closures above form
     # reference cycles that would otherwise keep them alive until some later garbage collection
+    step_was_captured = graph is not None
     graph = graph_b = vgraph = graph_t = vgraph_t = slot_graph = vgraph_all = None
     ev_graphs.clear()
     if on_gpu:
@@ -1258,8 +1272,14 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
     sI = data.scalers_Y["I"]
     p = sI.inverse_transform(preds[:, :nel]).clamp(0.0, 1e10)                # PINN:843-848
     t = sI.inverse_transform(Yva[:, :nel]).clamp(0.0, 1e10)
+    # (the reference's evaluation block, PINN:815-852 / TFD:800-829: best checkpoint reloaded, evaluation-mode pass over the validation
+    #  set in loader order, inertias un-standardised and clipped to [0, 1e10], r2_score on the raveled arrays)
     out = {"model": model, "history": hist, "best_val": best_val, "best_state": best_state, "r2_val_I": r2_score(t, p),
-           "epochs": len(hist["train"]), "steps_per_epoch": nb_tr}
+           "val_pred_I": p, "val_true_I": t, "epochs": len(hist["train"]), "steps_per_epoch": nb_tr}
+    if dp:
+        out["dp_mode"] = {"world": world, "forced_one_rank": bool(world == 1), "backend": dist.get_backend(), "async": bool(_DP_ASYNC),
+                          "step": ("one graph incl. the all-reduce" if graph_mode_one else "graph A | all-reduce | graph B" if step_was_captured
+                                   else "eager")}
     if seg_ev:                           # mean device time of the step's segments over the profiled steps (first epoch's excluded)
         use = seg_ev[nb_tr:] or seg_ev
         mean = lambda i, j: 1e3 * sum(e[i].elapsed_time(e[j]) for e in use) / len(use)      # noqa: E731

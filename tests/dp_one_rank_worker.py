@@ -44,7 +44,7 @@ def main():
             train._DP_PROFILE = v.get("profile", False)
             r = train.train_surrogate(kind, d, cfg, device=dev, max_epochs=3, seed=5, log=logs.append)
             runs[name] = {"train": [float(x) for x in r["history"]["train"]], "val": [float(x) for x in r["history"]["val"]],
-                          "r2_val_I": float(r["r2_val_I"]), "dp_segments": r.get("dp_segments")}
+                          "r2_val_I": float(r["r2_val_I"]), "dp_segments": r.get("dp_segments"), "dp_mode": r.get("dp_mode")}
         out["runs"][kind] = runs
     out["log"] = logs
     dist.barrier(device_ids=[local])

@@ -188,7 +188,7 @@ def unpack_records(z):
 # ------------------------------------------------------------------------------------------------------------------
 # the runner: executes a reference script's top-level statements one by one
 # ------------------------------------------------------------------------------------------------------------------
-def run_script(kind, workdir, before_loop, after_loop):
+def run_script(kind, workdir, before_loop, after_loop, after_eval=None):
     import matplotlib
     matplotlib.use("Agg")
     if "seaborn" not in sys.modules:        # styling only; absent from this image
@@ -198,9 +198,11 @@ def run_script(kind, workdir, before_loop, after_loop):
     ns = {"__name__": "__reference__", "__file__": path}
     cwd = os.getcwd()
     os.chdir(workdir)
+    done_loop = False
     try:
         for node in tree.body:
             is_loop = isinstance(node, ast.For) and isinstance(node.target, ast.Name) and node.target.id == "epoch"
+            is_loop = is_loop and not done_loop
             if is_loop:
                 before_loop(ns)
             code = compile(ast.Module(body=[node], type_ignores=[]), path, "exec")
@@ -211,6 +213,11 @@ def run_script(kind, workdir, before_loop, after_loop):
                     ns[name] = OVERRIDES[name]
             if is_loop:
                 after_loop(ns)
+                done_loop = True
+                if after_eval is None:
+                    break
+            if after_eval is not None and "r2_val" in ns:       # the script's evaluation block has run (PINN:815-852, TFD:800-829)
+                after_eval(ns)
                 break
     finally:
         os.chdir(cwd)
@@ -305,6 +312,17 @@ def generate(kind, records, out_path):
             out["final/" + k] = v
         out["loop_final_lr"] = np.array(ns["optimizer"].param_groups[0]["lr"])
 
+    def after_eval(ns):
+        """The script's own evaluation block: best checkpoint reloaded from the file its loop wrote, validation pass in evaluation mode,
+        un-standardised and clipped inertias, sklearn's r2_score on the raveled arrays."""
+        out["eval_r2_val"] = np.array(float(ns["r2_val"]))
+        pu = ns["all_preds_I_unstd"] if "all_preds_I_unstd" in ns else ns["all_preds_unstd"]
+        lu = ns["all_labels_I_unstd"] if "all_labels_I_unstd" in ns else ns["all_labels_unstd"]
+        out["eval_preds_unstd"], out["eval_labels_unstd"] = np.asarray(pu, dtype=np.float64), np.asarray(lu, dtype=np.float64)
+        out["eval_best_epoch"] = np.array(int(np.argmin(ns["val_losses"])) + 1)
+        for k, v in projections(ns["model"].state_dict().items()).items():      # the reloaded best state
+            out["best/" + k] = v
+
     with tempfile.TemporaryDirectory() as tmp:
         for name in ("StructDataLite.json", "StructDataMedium.json", "training_data_PINN_Case_two.json"):   # PINN:192, FNO:199, GNN:118
             with open(os.path.join(tmp, name), "w") as f:
@@ -313,9 +331,9 @@ def generate(kind, records, out_path):
             warnings.simplefilter("ignore")
             if noise is not None:
                 with noise:
-                    run_script(kind, tmp, before_loop, after_loop)
+                    run_script(kind, tmp, before_loop, after_loop, after_eval)
             else:
-                run_script(kind, tmp, before_loop, after_loop)
+                run_script(kind, tmp, before_loop, after_loop, after_eval)
     out["overrides"] = np.array(json.dumps(OVERRIDES))
     np.savez_compressed(out_path, **out)
     return out

@@ -103,3 +103,27 @@ def kappa_scaled(x, E, I, fix):
     Kf = K[np.ix_(free, free)]
     d = 1.0 / np.sqrt(np.diag(Kf))
     return float(np.linalg.cond(Kf * d[:, None] * d[None, :]))
+
+
+def marginal_stop_decisions(loss_history, tolerance, rel=2e-6):
+    """Replays the reference's early-stop bookkeeping (SingleCore.py:211-219) on a loss history and returns the epochs (1-based) whose
+    `loss < best_loss - tolerance` decision sat within `rel` * |loss| of the threshold -- float32 sums ordered differently (GPU vs CPU)
+    can take such a decision the other way, which moves the stopping epoch by up to `patience`."""
+    best, out = float("inf"), []
+    for e, l in enumerate(loss_history):
+        margin = (best - tolerance) - float(l)
+        if np.isfinite(margin) and abs(margin) <= rel * abs(float(l)):
+            out.append(e + 1)
+        if float(l) < best - tolerance:
+            best = float(l)
+    return out
+
+
+def assert_stop_epochs_agree(ep, ref_ep, ref_loss_history, tolerance, patience, what=""):
+    """Same stopping epoch -- or, when the reference's history holds a threshold decision within float32 round-off, one that differs by
+    at most `patience` epochs (one improvement counted / not counted resets or does not reset the patience counter once)."""
+    if int(ep) == int(ref_ep):
+        return True
+    marg = marginal_stop_decisions(ref_loss_history, tolerance)
+    assert marg and abs(int(ep) - int(ref_ep)) <= patience, (what, int(ep), int(ref_ep), marg[-5:])
+    return False

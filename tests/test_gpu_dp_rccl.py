@@ -48,6 +48,11 @@ def test_training_through_the_data_parallel_branch_on_one_rank_of_rccl():
             else:
                 assert diff <= max(20 * spread, 2e-3), (kind, name, diff, spread)
         assert (np.array(runs["dp_async"]["train"]) == np.array(runs["dp_blocking"]["train"])).all() or spread > 0.0
+        assert runs["plain"]["dp_mode"] is None
+        for name in ("dp_async", "dp_blocking", "dp_one_graph", "dp_profile"):
+            m = runs[name]["dp_mode"]
+            assert m["backend"] == "nccl" and m["world"] == 1 and m["forced_one_rank"] and m["async"] == (name != "dp_blocking")
+            assert m["step"] in ("graph A | all-reduce | graph B", "one graph incl. the all-reduce") and (name == "dp_one_graph" or m["step"][0] == "g")
         seg = runs["dp_profile"]["dp_segments"]
         assert seg is not None and seg["world"] == 1 and seg["graph_a_us"] > 0 and seg["allreduce_us"] >= 0 and seg["graph_b_us"] > 0
 

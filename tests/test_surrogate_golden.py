@@ -216,6 +216,14 @@ def _loop_check(kind, records, device, tol, autocast_dtype, use_graph=None):
         return res
     close(np.array(res["history"]["train"]), g["loop_train_losses"], tol, "train-loss history")
     close(np.array(res["history"]["val"]), g["loop_val_losses"], tol, "val-loss history")
+    # the reference's evaluation block (PINN:815-852, TFD:800-829, executed by make_surrogate_golden.py past the loop): best checkpoint
+    # reloaded, evaluation pass, un-standardised clipped inertias, R^2
+    assert int(np.argmin(res["history"]["val"])) + 1 == int(g["eval_best_epoch"])
+    close(res["val_true_I"].cpu().numpy(), g["eval_labels_unstd"], 1e-5, "un-standardised validation labels")
+    close(res["val_pred_I"].cpu().numpy(), g["eval_preds_unstd"], max(10 * tol, 2e-3), "un-standardised validation predictions")
+    ss_tot = float(((g["eval_labels_unstd"] - g["eval_labels_unstd"].mean()) ** 2).sum())
+    # R^2 = 1 - ss_res / ss_tot: its error is the error of ss_res / ss_tot, bounded through the prediction error just checked
+    assert abs(res["r2_val_I"] - float(g["eval_r2_val"])) <= max(10 * tol, 2e-3) * 4 * (1.0 - float(g["eval_r2_val"])) + 1e-4, (res["r2_val_I"], float(g["eval_r2_val"]), ss_tot)
     return res
 
 
