@@ -285,6 +285,10 @@ def surrogate_epoch_times(dev, rank, world, epochs, cases=50000):
             ep = r["history"]["epoch_s"][1:] or r["history"]["epoch_s"]
             out[kind] = {"epoch_s": sum(ep) / len(ep), "steps_per_epoch": r["steps_per_epoch"], "train_groups_per_gpu": int(d.X_train.shape[0]),
                          "dtype": "bf16", "step_us": 1e6 * sum(ep) / len(ep) / max(1, r["steps_per_epoch"]),
+                         # model quality of THIS short run (validation R^2 on un-standardised inertias, PINN:815-852 / TFD:800-829); trained to
+                         # the reference's early stop on the same data the fast path reaches 0.66 (PINN) / 0.80 (TFD) like the framework path:
+                         # profiles/r05_quality.json
+                         "r2_val_I": float(r["r2_val_I"]), "epochs_run": int(r["epochs"]), "val_loss": float(r["history"]["val"][-1]),
                          "path": {"pinn": "layer-block launches (pinn_fused.py, csrc/mlp_block.hip)",
                                   "tfd": "one launch per encoder layer and direction + block launches (tfd_fused.py, csrc/seq_layer.hip, csrc/seq_block.hip)"}[kind]}
             if "dp_segments" in r:       # N > 1: device time of [graph A | all-reduce | graph B] per step (HIP events, mean over the epochs after the first)
