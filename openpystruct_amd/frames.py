@@ -46,10 +46,70 @@ class FrameConfig:
         return self.E / (2 * (1 + self.nu))
 
 
-class FrameTopology:
-    """Shared description of a frame: what `setup_frame_model` rebuilds every epoch, minus the inertias."""
+def rcm_node_order(n_nodes: int, conn: np.ndarray, has_eq: np.ndarray) -> np.ndarray:
+    """Reverse Cuthill-McKee order of the nodes that carry equations (what `ops.numberer('RCM')`, FR:135 / SC:121, asks OpenSees
+    for): breadth-first levels from a pseudo-peripheral node (George-Liu: repeat from a minimum-degree node of the last level
+    while the eccentricity grows), neighbours by increasing degree, the whole order reversed; components one after the other.
+    Nodes without equations (fully fixed) keep their place at the end -- they number nothing."""
+    adj = [set() for _ in range(n_nodes)]
+    for a, b in conn:
+        a, b = int(a), int(b)
+        if a != b and has_eq[a] and has_eq[b]:
+            adj[a].add(b); adj[b].add(a)
+    deg = np.array([len(s) for s in adj])
+    todo = set(int(i) for i in np.nonzero(has_eq)[0])
 
-    def __init__(self, coords, conn, fix3, A, E, wy, wx, nodal_loads, device="cuda"):
+    def levels(root):
+        seen, order, frontier, depth = {root}, [root], [root], 0
+        while frontier:
+            nxt = []
+            for u in frontier:
+                for v in sorted(adj[u] - seen, key=lambda w: (deg[w], w)):
+                    seen.add(v); nxt.append(v)
+            if not nxt:
+                break
+            order += nxt; frontier = nxt; depth += 1
+        return order, frontier, depth
+
+    out = []
+    while todo:
+        root = min(todo, key=lambda w: (deg[w], w))
+        order, last, depth = levels(root)
+        while True:
+            cand = min(last, key=lambda w: (deg[w], w))
+            o2, l2, d2 = levels(cand)
+            if d2 <= depth:
+                break
+            root, order, last, depth = cand, o2, l2, d2
+        out += order[::-1]
+        todo -= set(order)
+    return np.array(out + [int(i) for i in np.nonzero(~has_eq)[0]], dtype=np.int64)
+
+
+def _number_equations(order: np.ndarray, fix3: np.ndarray, conn: np.ndarray):
+    """Equation numbers node by node along `order` (constrained DOFs get none: constraints('Plain')), and the half bandwidth."""
+    node_eq = -np.ones(fix3.shape, dtype=np.int32)
+    k = 0
+    for nd in order:
+        for dof in range(3):
+            if not fix3[nd, dof]:
+                node_eq[nd, dof] = k
+                k += 1
+    elem_eq = np.concatenate([node_eq[conn[:, 0]], node_eq[conn[:, 1]]], axis=1)
+    span = [int(q[q >= 0].max() - q[q >= 0].min()) for q in elem_eq if (q >= 0).any()]
+    return node_eq, elem_eq, (max(span) if span else 0)
+
+
+class FrameTopology:
+    """Shared description of a frame: what `setup_frame_model` rebuilds every epoch, minus the inertias.
+
+    `numbering`: "node" = equations in node order (what r01-r04 did: row by row on a grid); "rcm" = reverse Cuthill-McKee (the
+    reference's `numberer('RCM')`, FR:135); "auto" (default) = the narrowest of node order, reverse Cuthill-McKee and the two
+    coordinate sweeps (`self.numbering` says which), node order on a tie.  The solution does not depend on it beyond rounding; the work does (n kd^2): a 10-bay x 2-story frame of the reference's own
+    random range is kd 35 story by story and kd 8 along its column lines, and a 21 x 3 frame (kd 68 in node order: beyond the
+    kernels' 63) becomes solvable."""
+
+    def __init__(self, coords, conn, fix3, A, E, wy, wx, nodal_loads, device="cuda", numbering: str = "auto"):
         coords = np.asarray(coords, dtype=np.float64)
         conn = np.asarray(conn, dtype=np.int64)
         fix3 = np.asarray(fix3).astype(bool)
@@ -57,11 +117,23 @@ class FrameTopology:
         d = coords[conn[:, 1]] - coords[conn[:, 0]]
         L = np.hypot(d[:, 0], d[:, 1])
         geo = np.stack([L, d[:, 0] / L, d[:, 1] / L], axis=1)
-        node_eq = -np.ones((self.Nn, 3), dtype=np.int32)
-        node_eq[~fix3] = np.arange(int((~fix3).sum()), dtype=np.int32)       # node order (row-major on a grid)
-        elem_eq = np.concatenate([node_eq[conn[:, 0]], node_eq[conn[:, 1]]], axis=1)
-        span = [int(q[q >= 0].max() - q[q >= 0].min()) for q in elem_eq if (q >= 0).any()]
-        self.n_eq, self.kd = int((~fix3).sum()), max(span) if span else 0
+        if numbering not in ("auto", "node", "rcm"):
+            raise ValueError("numbering must be 'auto', 'node' or 'rcm'")
+        node_eq, elem_eq, kd = _number_equations(np.arange(self.Nn), fix3, conn)
+        self.numbering = "node"
+        if numbering == "rcm":
+            node_eq, elem_eq, kd = _number_equations(rcm_node_order(self.Nn, conn, ~fix3.all(axis=1)), fix3, conn)
+            self.numbering = "rcm"
+        elif numbering == "auto":
+            # candidates: reverse Cuthill-McKee, and the two coordinate sweeps (nodes sorted by (x, y) / by (y, x): on a rectangular grid
+            # the sweep along the shorter side is the optimum, which the breadth-first levels of RCM -- diagonals of the grid -- miss)
+            cands = [("rcm", rcm_node_order(self.Nn, conn, ~fix3.all(axis=1))),
+                     ("sweep-x", np.lexsort((coords[:, 1], coords[:, 0]))), ("sweep-y", np.lexsort((coords[:, 0], coords[:, 1])))]
+            for name, order in cands:
+                c_node_eq, c_elem_eq, c_kd = _number_equations(order, fix3, conn)
+                if c_kd < kd:
+                    node_eq, elem_eq, kd, self.numbering = c_node_eq, c_elem_eq, c_kd, name
+        self.n_eq, self.kd = int((~fix3).sum()), kd
         Ev = np.broadcast_to(np.asarray(E, dtype=np.float64), (self.Ne,))
         Av = np.broadcast_to(np.asarray(A, dtype=np.float64), (self.Ne,))
         w = np.stack([np.broadcast_to(np.asarray(wy, dtype=np.float64), (self.Ne,)),
@@ -81,7 +153,7 @@ class FrameTopology:
         return (n3 * ld + n3) * 8
 
 
-def grid_frame(num_bays: int, num_stories: int, cfg: Optional[FrameConfig] = None, device="cuda") -> FrameTopology:
+def grid_frame(num_bays: int, num_stories: int, cfg: Optional[FrameConfig] = None, device="cuda", numbering: str = "auto") -> FrameTopology:
     """The reference's rectangular frame (FR:50-69, :84-131): nodes row by row from the ground, columns then
     beams, ground row fully fixed, lateral loads on the left column line, beamUniform(w, w) on the beams."""
     cfg = cfg or FrameConfig()
@@ -95,7 +167,7 @@ def grid_frame(num_bays: int, num_stories: int, cfg: Optional[FrameConfig] = Non
     loads = np.zeros((coords.shape[0], 3))
     loads[(coords[:, 0] == 0.0) & (coords[:, 1] != 0.0), 0] = cfg.lateral_load                                 # FR:126-128
     w = np.zeros(len(conn)); w[len(cols):] = cfg.vertical_load                                                 # FR:130-131 (Wy = Wx)
-    return FrameTopology(coords, conn, fix3, cfg.A, cfg.E, w, w, loads, device)
+    return FrameTopology(coords, conn, fix3, cfg.A, cfg.E, w, w, loads, device, numbering=numbering)
 
 
 class FrameSolution(NamedTuple):

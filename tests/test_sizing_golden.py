@@ -350,7 +350,8 @@ def test_hip_frame_loop_reproduces_the_frame_opt_script(oa):
     for i in range(n):
         p = f"run{i}/"
         topo = frames.grid_frame(int(z[p + "num_bays"]), int(z[p + "num_stories"]), cfg, "cuda")
-        assert topo.n_eq == int(z[p + "n_eq"]) and topo.kd == int(z[p + "kd"])
+        # (the recorder numbers node by node; the product takes reverse Cuthill-McKee where that is narrower -- run 5, 10 x 2: 35 -> 8)
+        assert topo.n_eq == int(z[p + "n_eq"]) and (topo.kd == int(z[p + "kd"]) if topo.numbering == "node" else topo.kd < int(z[p + "kd"]))
         hist = []
         I, sol, ep = frames.optimize_frames(topo, 2, cfg, poll_every=10, loss_history=hist)
         ref_ep = int(z[p + "epochs_run"])
