@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define OPS_AMD_ABI_VERSION 11
+#define OPS_AMD_ABI_VERSION 12
 
 /* return codes of the launch functions (per-beam results are in `status`) */
 #define OPS_AMD_OK 0
@@ -262,6 +262,11 @@ size_t ops_stencil3_bn1_workspace_bytes(void);
  * `workspace`: ops_flat_adam_workspace_bytes() bytes. */
 #define OPS_ADAM_DECOUPLED 1
 #define OPS_ADAM_ZERO_GRADS 2
+/* r05 (ABI 12): the workspace ALREADY holds the step's (decoupled_weight_decay >> 16) partial sums of (g * grad_scale)^2, the advanced
+ * step count and its bias corrections -- written by the producers of the gradients (ops_mlp_wgrad_group_norm) -- so the call skips its
+ * norm launch (one kernel node and ~4.5 us less per step of the PINN's training graph). */
+#define OPS_ADAM_NORM_READY 4
+#define OPS_FLAT_ADAM_MAX_PARTS 1024   /* partial sums a workspace holds; the two bias corrections follow them */
 int ops_flat_clip_adam_step_f32(long n, float* params, const float* grads, float* exp_avg, float* exp_avg_sq, const float* lr,
                                 int32_t* step, float max_norm, float grad_scale, float beta1, float beta2, float eps,
                                 float weight_decay, int decoupled_weight_decay, void* params_bf16, void* workspace, void* stream);
@@ -426,6 +431,15 @@ typedef struct ops_mlp_wgrad_problem {
 #define OPS_MLP_MAX_WGRAD 8
 #define OPS_MLP_MAX_REPACK 16   /* matrices per ops_flat_clip_adam_step_repack_f32 (ops_mlp_repack_weights: OPS_MLP_MAX_WGRAD per call) */
 int ops_mlp_wgrad_group(int nprob, const ops_mlp_wgrad_problem* problems, void* stream);
+/* r05: the same launch also leaves what ops_flat_clip_adam_step_*_f32 needs of the gradient norm in the optimiser's `workspace`
+ * (ops_flat_adam_workspace_bytes()): every tile's workgroup the sum of the squares it stores, `nranges` extra one-wave workgroups the
+ * sums over the float32 ranges (range_ptr[i], range_len[i]) -- the gradients the matrices do not cover (biases, normalisation
+ * parameters: complete when this launch starts) -- each times grad_scale^2; workgroup 0 advances `step` and tabulates its bias
+ * corrections.  Returns the number of partial sums through *nparts (pass it on as OPS_ADAM_NORM_READY | nparts << 16). */
+#define OPS_MLP_MAX_NORM_RANGES 32
+int ops_mlp_wgrad_group_norm(int nprob, const ops_mlp_wgrad_problem* problems, int nranges, const float* const* range_ptr,
+                             const int32_t* range_len, float grad_scale, void* workspace, int32_t* step, float beta1, float beta2,
+                             int32_t* nparts, void* stream);
 
 /* Wp / Wtp of up to 8 weight matrices from the float32 parameters W_i [N_i, K_i] in one launch. */
 typedef struct ops_mlp_repack_entry {

@@ -9,7 +9,7 @@ import ctypes
 import os
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-ABI_VERSION = 11     # include/openpystruct_amd.h OPS_AMD_ABI_VERSION
+ABI_VERSION = 12     # include/openpystruct_amd.h OPS_AMD_ABI_VERSION
 # OPS_AMD_LIB lets A/B kernel experiments point at another build of the same C ABI
 LIB_PATH = os.environ.get("OPS_AMD_LIB") or os.path.join(_PKG, "lib", "libopenpystruct_amd.so")
 
@@ -46,6 +46,7 @@ EXPORTS = (
     "ops_mlp_strip_launch",
     "ops_mlp_spart_doubles",
     "ops_mlp_wgrad_group",
+    "ops_mlp_wgrad_group_norm",
     "ops_mlp_repack_weights",
     "ops_flat_clip_adam_step_repack_f32",
     "ops_mlp_gather_noise",
@@ -99,6 +100,9 @@ MLP_ADD_NONE, MLP_ADD_FWD_BLOCK, MLP_ADD_BWD_BLOCK = 0, 1, 2
 MLP_SIDE_NONE, MLP_SIDE_FWD_STENCIL_STATS, MLP_SIDE_BWD_STENCIL_SUMS = 0, 1, 2
 MLP_MAX_WGRAD = 8
 MLP_MAX_REPACK = 16
+MLP_MAX_NORM_RANGES = 32      # OPS_MLP_MAX_NORM_RANGES
+FLAT_ADAM_MAX_PARTS = 1024    # OPS_FLAT_ADAM_MAX_PARTS
+ADAM_NORM_READY = 4           # OPS_ADAM_NORM_READY
 
 
 class MlpStripArgs(ctypes.Structure):
@@ -316,6 +320,9 @@ def load():
     lib.ops_mlp_spart_doubles.argtypes = [it]
     lib.ops_mlp_wgrad_group.restype = it
     lib.ops_mlp_wgrad_group.argtypes = [it, ctypes.POINTER(MlpWgradProblem), vp]
+    lib.ops_mlp_wgrad_group_norm.restype = it
+    lib.ops_mlp_wgrad_group_norm.argtypes = [it, ctypes.POINTER(MlpWgradProblem), it, ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_int32), fl, vp, vp,
+                                             fl, fl, ctypes.POINTER(ctypes.c_int32), vp]
     lib.ops_mlp_repack_weights.restype = it
     lib.ops_mlp_repack_weights.argtypes = [it, ctypes.POINTER(MlpRepackEntry), vp]
     lib.ops_flat_clip_adam_step_repack_f32.restype = it

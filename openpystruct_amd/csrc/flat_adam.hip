@@ -49,8 +49,8 @@ __global__ __launch_bounds__(FA_THREADS) void flat_grad_norm_kernel(long n, cons
     if (blockIdx.x == 0) {               // advance the step and tabulate its bias corrections ONCE (two double pow() per thread of
       const int st = step[0] + 1;        // the update kernel had cost more than its memory traffic)
       step[0] = st;
-      part[FA_NORM_BLOCKS] = 1.0 - pow((double)beta1, (double)st);
-      part[FA_NORM_BLOCKS + 1] = sqrt(1.0 - pow((double)beta2, (double)st));
+      part[OPS_FLAT_ADAM_MAX_PARTS] = 1.0 - pow((double)beta1, (double)st);
+      part[OPS_FLAT_ADAM_MAX_PARTS + 1] = sqrt(1.0 - pow((double)beta2, (double)st));
     }
   }
 }
@@ -70,12 +70,18 @@ __global__ __launch_bounds__(FA_THREADS) void flat_adam_kernel(long n, float* __
                                                                 const double* __restrict__ part, int nparts, float max_norm, float grad_scale,
                                                                 float beta1, float beta2, float eps, float weight_decay, int flags,
                                                                 uint16_t* __restrict__ shadow) {
-  // ||g||^2 from the norm pass's partial sums: one load per thread (nparts <= FA_NORM_BLOCKS <= FA_THREADS), not a serial chain
+  // ||g||^2 from the partial sums (the norm pass's <= FA_NORM_BLOCKS, or the gradient producers' <= OPS_FLAT_ADAM_MAX_PARTS): up to four
+  // independent loads per thread, not a serial chain
   __shared__ double s_red[FA_THREADS / 64];
-  double d = (int)threadIdx.x < nparts ? part[threadIdx.x] : 0.0;
+  double d = 0.0;
+#pragma unroll
+  for (int k = 0; k < OPS_FLAT_ADAM_MAX_PARTS / FA_THREADS; ++k) {
+    const int i = (int)threadIdx.x + FA_THREADS * k;
+    d += i < nparts ? part[i] : 0.0;
+  }
   for (int s = 32; s >= 1; s >>= 1) d += __shfl_xor(d, s, 64);
   if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = d;
-  const float bc1 = (float)part[FA_NORM_BLOCKS], bc2s = (float)part[FA_NORM_BLOCKS + 1];
+  const float bc1 = (float)part[OPS_FLAT_ADAM_MAX_PARTS], bc2s = (float)part[OPS_FLAT_ADAM_MAX_PARTS + 1];
   const float lr0 = lr[0];
   __syncthreads();
   double tot = 0.0;
@@ -172,7 +178,7 @@ __global__ __launch_bounds__(256) void repack_tiles_kernel(const float* __restri
 
 using namespace opsamd;
 
-extern "C" size_t ops_flat_adam_workspace_bytes(void) { return (size_t)(FA_NORM_BLOCKS + 2) * sizeof(double); }
+extern "C" size_t ops_flat_adam_workspace_bytes(void) { return (size_t)(OPS_FLAT_ADAM_MAX_PARTS + 2) * sizeof(double); }
 
 static int adam_step(long n, float* params, const float* grads, float* exp_avg, float* exp_avg_sq, const float* lr, int32_t* step,
                      float max_norm, float grad_scale, float beta1, float beta2, float eps, float weight_decay, int decoupled_weight_decay,
@@ -180,13 +186,18 @@ static int adam_step(long n, float* params, const float* grads, float* exp_avg, 
   if (n < 1 || !params || !grads || !exp_avg || !exp_avg_sq || !lr || !step || !workspace) return OPS_AMD_ERR_INVALID_ARG;
   hipStream_t s = (hipStream_t)stream;
   long nb = (n + FA_THREADS - 1) / FA_THREADS;
-  const int nparts = (int)(nb < FA_NORM_BLOCKS ? nb : FA_NORM_BLOCKS);
-  hipLaunchKernelGGL(flat_grad_norm_kernel, dim3(nparts), dim3(FA_THREADS), 0, s, n, grads, grad_scale, (double*)workspace, step, beta1,
-                     beta2);
+  int nparts = (int)(nb < FA_NORM_BLOCKS ? nb : FA_NORM_BLOCKS);
+  if (decoupled_weight_decay & OPS_ADAM_NORM_READY) {      // the gradient producers left the partial sums, the step and its corrections
+    nparts = decoupled_weight_decay >> 16;
+    if (nparts < 1 || nparts > OPS_FLAT_ADAM_MAX_PARTS) return OPS_AMD_ERR_INVALID_ARG;
+  } else {
+    hipLaunchKernelGGL(flat_grad_norm_kernel, dim3(nparts), dim3(FA_THREADS), 0, s, n, grads, grad_scale, (double*)workspace, step, beta1,
+                       beta2);
+  }
   nb = (n / 4 + FA_THREADS - 1) / FA_THREADS + 1;     // one 16-byte group per thread
   if (nb > 4096) nb = 4096;
   hipLaunchKernelGGL(flat_adam_kernel, dim3((unsigned)nb), dim3(FA_THREADS), 0, s, n, params, (float*)grads, exp_avg, exp_avg_sq, lr, step,
-                     (const double*)workspace, nparts, max_norm, grad_scale, beta1, beta2, eps, weight_decay, decoupled_weight_decay,
+                     (const double*)workspace, nparts, max_norm, grad_scale, beta1, beta2, eps, weight_decay, decoupled_weight_decay & 0xFFFF,
                      (uint16_t*)params_bf16);
   if (rp) {      // the tiled weight copies: one wave per 1 KB tile, behind the update
     TileJobs tj;

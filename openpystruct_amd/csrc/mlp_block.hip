@@ -609,8 +609,46 @@ struct WgradTable {
   int tiles_k[OPS_MLP_MAX_WGRAD];
   ops_mlp_wgrad_problem p[OPS_MLP_MAX_WGRAD];
 };
+// r05: what the optimiser needs of the gradient norm, left by the launch that produces the gradients (ops_mlp_wgrad_group_norm)
+struct WgradNorm {
+  double* part;                            // [tiles + nrange] partial sums of (g * scale)^2, then the two bias corrections at OPS_FLAT_ADAM_MAX_PARTS
+  int32_t* step;
+  float scale, beta1, beta2;
+  int nrange;
+  const float* rptr[OPS_MLP_MAX_NORM_RANGES];
+  int rlen[OPS_MLP_MAX_NORM_RANGES];
+};
+__device__ __forceinline__ float mb_wsum_f(float v) {
+#pragma unroll
+  for (int s = 32; s >= 1; s >>= 1) v += __shfl_xor(v, s, 64);
+  return v;
+}
 
-__global__ __launch_bounds__(64) void mlp_wgrad_kernel(const WgradTable tb) {
+template <bool NORM>
+__global__ __launch_bounds__(64) void mlp_wgrad_kernel(const WgradTable tb, const WgradNorm nm) {
+  if constexpr (NORM) {
+    const int ntile = tb.tile0[tb.nprob];
+    if (blockIdx.x == 0 && threadIdx.x == 0) {      // the optimiser step this launch belongs to: count and bias corrections, once
+      const int st = nm.step[0] + 1;
+      nm.step[0] = st;
+      nm.part[OPS_FLAT_ADAM_MAX_PARTS] = 1.0 - pow((double)nm.beta1, (double)st);
+      nm.part[OPS_FLAT_ADAM_MAX_PARTS + 1] = sqrt(1.0 - pow((double)nm.beta2, (double)st));
+    }
+    if ((int)blockIdx.x >= ntile) {                 // a range of gradients no matrix covers (written by earlier launches)
+      const int r = (int)blockIdx.x - ntile;
+      const float* g = nullptr; int len = 0;
+#pragma unroll
+      for (int k = 0; k < OPS_MLP_MAX_NORM_RANGES; ++k) if (k == r) { g = nm.rptr[k]; len = nm.rlen[k]; }
+      float a0 = 0.0f, a1 = 0.0f;
+      for (int i = threadIdx.x; i < len; i += 128) {
+        const float x = g[i] * nm.scale, y = i + 64 < len ? g[i + 64] * nm.scale : 0.0f;
+        a0 = __builtin_fmaf(x, x, a0); a1 = __builtin_fmaf(y, y, a1);
+      }
+      const double d = mb_wsum_d((double)a0 + (double)a1);
+      if (threadIdx.x == 0) nm.part[blockIdx.x] = d;
+      return;
+    }
+  }
   int pi = 0;
   while (pi + 1 < tb.nprob && (int)blockIdx.x >= tb.tile0[pi + 1]) ++pi;
   const ops_mlp_wgrad_problem pr = tb.p[pi];
@@ -638,6 +676,7 @@ __global__ __launch_bounds__(64) void mlp_wgrad_kernel(const WgradTable tb) {
         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mb_bf16x8, fa[i][ks]), __builtin_bit_cast(mb_bf16x8, fb[j][ks]),
                                                             acc[i][j], 0, 0, 0);
     }
+  float sq = 0.0f;
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -646,9 +685,16 @@ __global__ __launch_bounds__(64) void mlp_wgrad_kernel(const WgradTable tb) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int n = tn * 32 + i * 16 + (lane >> 4) * 4 + e;
-        if (n < pr.N && k < pr.K) pr.out[(long)n * pr.ldo + k] = acc[i][j][e];
+        if (n < pr.N && k < pr.K) {
+          pr.out[(long)n * pr.ldo + k] = acc[i][j][e];
+          if constexpr (NORM) { const float v = acc[i][j][e] * nm.scale; sq = __builtin_fmaf(v, v, sq); }
+        }
       }
     }
+  if constexpr (NORM) {                     // 16 values per lane in float, the 64 lanes and everything after in double
+    const double d = mb_wsum_d((double)sq);
+    if (lane == 0) nm.part[blockIdx.x] = d;
+  }
 }
 
 // ---- padded bf16 copies of the weights, plain and transposed, from the float32 parameters ----
@@ -806,7 +852,7 @@ extern "C" int ops_mlp_strip_launch(const ops_mlp_strip_args* args, void* stream
   return OPS_AMD_OK;
 }
 
-extern "C" int ops_mlp_wgrad_group(int nprob, const ops_mlp_wgrad_problem* problems, void* stream) {
+static int wgrad_launch(int nprob, const ops_mlp_wgrad_problem* problems, const WgradNorm* nm, int32_t* nparts, void* stream) {
   if (nprob < 1 || nprob > OPS_MLP_MAX_WGRAD || !problems) return OPS_AMD_ERR_INVALID_ARG;
   WgradTable tb;
   tb.nprob = nprob;
@@ -821,10 +867,34 @@ extern "C" int ops_mlp_wgrad_group(int nprob, const ops_mlp_wgrad_problem* probl
     tiles += ((p.N + 31) / 32) * tb.tiles_k[i];
   }
   tb.tile0[nprob] = tiles;
-  hipLaunchKernelGGL(mlp_wgrad_kernel, dim3((unsigned)tiles), dim3(64), 0, (hipStream_t)stream, tb);
+  if (nm) {
+    if (tiles + nm->nrange > OPS_FLAT_ADAM_MAX_PARTS) return OPS_AMD_ERR_UNSUPPORTED;
+    *nparts = tiles + nm->nrange;
+    hipLaunchKernelGGL(mlp_wgrad_kernel<true>, dim3((unsigned)(tiles + nm->nrange)), dim3(64), 0, (hipStream_t)stream, tb, *nm);
+  } else {
+    hipLaunchKernelGGL(mlp_wgrad_kernel<false>, dim3((unsigned)tiles), dim3(64), 0, (hipStream_t)stream, tb, WgradNorm{});
+  }
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) { set_last_error(hipGetErrorString(e)); return OPS_AMD_ERR_LAUNCH; }
   return OPS_AMD_OK;
+}
+
+extern "C" int ops_mlp_wgrad_group(int nprob, const ops_mlp_wgrad_problem* problems, void* stream) {
+  return wgrad_launch(nprob, problems, nullptr, nullptr, stream);
+}
+
+extern "C" int ops_mlp_wgrad_group_norm(int nprob, const ops_mlp_wgrad_problem* problems, int nranges, const float* const* range_ptr,
+                                        const int32_t* range_len, float grad_scale, void* workspace, int32_t* step, float beta1, float beta2,
+                                        int32_t* nparts, void* stream) {
+  if (nranges < 0 || nranges > OPS_MLP_MAX_NORM_RANGES || (nranges > 0 && (!range_ptr || !range_len)) || !workspace || !step || !nparts)
+    return OPS_AMD_ERR_INVALID_ARG;
+  WgradNorm nm{};
+  nm.part = (double*)workspace; nm.step = step; nm.scale = grad_scale; nm.beta1 = beta1; nm.beta2 = beta2; nm.nrange = nranges;
+  for (int i = 0; i < nranges; ++i) {
+    if (!range_ptr[i] || range_len[i] < 1) return OPS_AMD_ERR_INVALID_ARG;
+    nm.rptr[i] = range_ptr[i]; nm.rlen[i] = range_len[i];
+  }
+  return wgrad_launch(nprob, problems, &nm, nparts, stream);
 }
 
 extern "C" int ops_mlp_repack_weights(int nmat, const ops_mlp_repack_entry* entries, void* stream) {

@@ -258,11 +258,47 @@ class PinnFusedStep:
         for e, (at, bt, w) in zip(wg, probs):
             e.At, e.Bt, e.out, e.N, e.K, e.ldo = at.data_ptr(), bt.data_ptr(), w.grad.data_ptr(), w.shape[0], w.shape[1], w.shape[1]
         self._wgrad = wg
+        self._norm = None        # (ranges ptr array, lengths, n, workspace, step, betas, nparts holder): enable_norm()
         covered = sum(p.numel() for p in m.parameters())
         named = sum(l.weight.numel() + l.bias.numel() for l in [m.input_fc, m.output_fc] + [x for b in m.residual_blocks for x in (b[0].fc1, b[0].fc2)])
         named += sum(2 * bn.weight.numel() for bn in [m.input_norm] + [b[1] for b in m.residual_blocks]) + 6 * self.nblk
         if covered != named:
             raise ValueError("the model has parameters the layer-block launches do not cover")
+
+    def enable_norm(self, flat_grad: torch.Tensor, workspace: torch.Tensor, step: torch.Tensor, betas, grad_scale: float = 1.0) -> int:
+        """r05: let the weight-gradient launch leave the optimiser's gradient-norm partial sums in `workspace`
+        (ops_flat_adam_workspace_bytes(); FlatClipAdam.ws) -- its own tiles' squares plus, in extra one-wave workgroups, the squares of
+        every gradient no matrix covers (biases, normalisation and stencil parameters: written by the strip launches before it) -- and
+        advance `step`: the optimiser then skips its norm launch (OPS_ADAM_NORM_READY).  `flat_grad`: the buffer every parameter's
+        .grad is a view of.  Returns the number of partial sums (what FlatClipAdam.norm_ready_parts takes).  Only where the gradients
+        are final when this launch ends: one rank (a data-parallel step all-reduces them afterwards)."""
+        m = self.model
+        base, n = flat_grad.data_ptr(), flat_grad.numel()
+        mats = sorted((l.weight.grad.data_ptr(), l.weight.numel()) for l in
+                      [m.input_fc, m.output_fc] + [x for b in m.residual_blocks for x in (b[0].fc1, b[0].fc2)])
+        ranges, cur = [], base
+        for ptr, cnt in mats:
+            if not (base <= ptr and ptr + 4 * cnt <= base + 4 * n):
+                raise ValueError("every weight gradient must be a view of the flat gradient buffer")
+            if ptr > cur:
+                ranges.append((cur, (ptr - cur) // 4))
+            cur = ptr + 4 * cnt
+        if cur < base + 4 * n:
+            ranges.append((cur, (base + 4 * n - cur) // 4))
+        if len(ranges) > _cabi.MLP_MAX_NORM_RANGES:
+            raise ValueError("too many gradient ranges outside the weight matrices")
+        rp = (ctypes.c_void_p * max(1, len(ranges)))(*[r[0] for r in ranges])
+        rl = (ctypes.c_int32 * max(1, len(ranges)))(*[r[1] for r in ranges])
+        self._norm = dict(rp=rp, rl=rl, nr=len(ranges), ws=workspace, step=step, betas=(float(betas[0]), float(betas[1])),
+                          scale=float(grad_scale), nparts=ctypes.c_int32(0), covered=sum(c for _, c in mats) + sum(r[1] for r in ranges))
+        assert self._norm["covered"] == n
+        # (the count is a function of the problem shapes alone: a dry computation of the launch geometry)
+        tiles = sum(((w.shape[0] + 31) // 32) * ((w.shape[1] + 31) // 32) for w in
+                    [l.weight for l in [m.input_fc, m.output_fc] + [x for b in m.residual_blocks for x in (b[0].fc1, b[0].fc2)]])
+        if tiles + len(ranges) > _cabi.FLAT_ADAM_MAX_PARTS:
+            self._norm = None
+            raise ValueError("more partial sums than the optimiser's workspace holds")
+        return tiles + len(ranges)
 
     def _check(self, rc: int, what: str) -> None:
         if rc != _cabi.OK:
@@ -324,7 +360,13 @@ class PinnFusedStep:
             for a in self._bwd:
                 a.B = B
                 self._check(self.lib.ops_mlp_strip_launch(ctypes.byref(a), s), "ops_mlp_strip_launch (backward)")
-            self._check(self.lib.ops_mlp_wgrad_group(len(self._wgrad), self._wgrad, s), "ops_mlp_wgrad_group")
+            if self._norm is not None:
+                nm = self._norm
+                self._check(self.lib.ops_mlp_wgrad_group_norm(len(self._wgrad), self._wgrad, nm["nr"], nm["rp"], nm["rl"], nm["scale"],
+                                                              nm["ws"].data_ptr(), nm["step"].data_ptr(), nm["betas"][0], nm["betas"][1],
+                                                              ctypes.byref(nm["nparts"]), s), "ops_mlp_wgrad_group_norm")
+            else:
+                self._check(self.lib.ops_mlp_wgrad_group(len(self._wgrad), self._wgrad, s), "ops_mlp_wgrad_group")
         return self.loss
 
     def evaluate(self, B: int) -> torch.Tensor:

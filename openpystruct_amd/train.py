@@ -143,6 +143,7 @@ class FlatClipAdam:
         self.p_bf16: Optional[torch.Tensor] = None      # bfloat16 shadow of the parameters (enable_shadow)
         self.zero_grads = False     # zero the gradient buffer inside the update launch (the next step's zero_grad(): one fill node less)
         self.repack = None          # ctypes array of MlpRepackEntry: padded bf16 weight copies the update refreshes too (pinn_fused.py)
+        self.norm_ready_parts = 0   # > 0: the gradient producers leave that many norm partial sums + the advanced step in `ws` (pinn_fused.enable_norm)
 
     def enable_shadow(self) -> torch.Tensor:
         """A bfloat16 copy of the flat parameter buffer that every step refreshes in the Adam kernel itself: layers that
@@ -159,7 +160,8 @@ class FlatClipAdam:
         dev = self.g.device
         args = (self.g.numel(), self.p.data_ptr(), self.g.data_ptr(), self.m.data_ptr(), self.v.data_ptr(), self.lr.data_ptr(),
                 self.step_count.data_ptr(), self.max_norm, grad_scale, self.betas[0], self.betas[1], self.eps, self.weight_decay,
-                int(self.decoupled) | (2 if self.zero_grads else 0), self.p_bf16.data_ptr() if self.p_bf16 is not None else None, self.ws.data_ptr())
+                int(self.decoupled) | (2 if self.zero_grads else 0) | ((self._cabi.ADAM_NORM_READY | (self.norm_ready_parts << 16)) if self.norm_ready_parts else 0),
+                self.p_bf16.data_ptr() if self.p_bf16 is not None else None, self.ws.data_ptr())
         with torch.cuda.device(dev):
             s = torch.cuda.current_stream(dev).cuda_stream
             if self.repack is not None:
@@ -647,6 +649,10 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
         if pinn_fused.eligible(model, crit, cfg.batch_size):
             engine = pinn_fused.PinnFusedStep(model, crit, seed=seed * 7919 + 101 + rank)
             opt.repack = engine._repack      # the Adam launch refreshes the engine's bf16 weight copies
+            if not dp and os.environ.get("OPS_AMD_PINN_NORM_FOLD", "1") == "1":
+                # one rank: the gradients are final when the weight-gradient launch ends, so that launch leaves the clip norm's partial
+                # sums and the optimiser skips its norm launch (a node and ~4.5 us per step; data parallel: the norm is the all-reduced one)
+                opt.norm_ready_parts = engine.enable_norm(flat, opt.ws, opt.step_count, opt.betas)
     if use_graph and on_gpu and engine is None and fast_encoder is None:
         # a step the FRAMEWORK differentiates (comparator paths, the sibling surrogates): its multi-block reductions are only right under
         # graph replay when captured memset nodes are (runtime.py item 2); the hand-written paths above contain none

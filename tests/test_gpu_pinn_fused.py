@@ -461,3 +461,52 @@ def test_evaluation_slots_equal_the_batch_by_batch_evaluation():
     a.slot_total_rows = n + bs                               # more rows than the slots hold: refused
     assert lib.ops_mlp_strip_launch(__import__("ctypes").byref(a), None) == 1
     a.slot_total_rows = n
+
+
+@pytest.mark.parametrize("B,p_drop", [(128, 0.5), (48, 0.0)])
+def test_gradient_norm_left_by_the_weight_gradient_launch(B, p_drop):
+    """r05: `PinnFusedStep.enable_norm` -- the grouped weight-gradient launch leaves the partial sums of ||g||^2 (its tiles' squares +
+    extra workgroups over the gradients no matrix covers), advances the optimiser's step and tabulates its bias corrections, and
+    `FlatClipAdam` skips its norm launch (OPS_ADAM_NORM_READY).  The partial sums add up to the flat buffer's squared norm; two
+    optimiser steps taken that way equal the two-launch form (norm launch + update) to float32 rounding of the clip factor."""
+    from openpystruct_amd import _cabi, train
+    from openpystruct_amd.pinn_fused import PinnFusedStep
+    dev = torch.device("cuda:0")
+
+    def run(fold):
+        model, crit = _make(3, p_drop)
+        model, crit = model.to(dev), crit.to(dev)
+        flat = _attach_flat(model)
+        params = list(model.parameters())
+        opt = train.FlatClipAdam(params, flat, 5e-4, weight_decay=1e-3, max_norm=0.25)     # (below the gradient norm: the clip factor is in play)
+        eng = PinnFusedStep(model, crit, seed=77)
+        opt.repack = eng._repack
+        if fold:
+            opt.norm_ready_parts = eng.enable_norm(flat, opt.ws, opt.step_count, opt.betas)
+            assert 0 < opt.norm_ready_parts <= _cabi.FLAT_ADAM_MAX_PARTS
+        g = torch.Generator().manual_seed(5)
+        x = torch.randn(B, 684, generator=g).to(torch.bfloat16).float().to(dev)
+        y = (0.8 * torch.randn(B, 302, generator=g)).to(dev)
+        model.train()
+        norms = []
+        for step in range(2):
+            eng.set_batch(x, y)
+            eng.fwd_bwd(B)
+            torch.cuda.synchronize()
+            if fold:
+                part = opt.ws.view(torch.float64)
+                tot = float(part[:opt.norm_ready_parts].sum())
+                want = float((flat.double() ** 2).sum())
+                assert abs(tot - want) <= 1e-6 * want, (tot, want)
+                assert int(opt.step_count) == step + 1
+                assert float(part[_cabi.FLAT_ADAM_MAX_PARTS]) == pytest.approx(1.0 - 0.9 ** (step + 1), rel=1e-6)      # (beta1 travels as float32)
+            norms.append(float(flat.double().norm()))
+            opt.step()
+            torch.cuda.synchronize()
+            assert int(opt.step_count) == step + 1
+        return opt.p.clone(), norms
+
+    p0, n0 = run(False)
+    p1, n1 = run(True)
+    assert n0[0] == n1[0] and n0[0] > 0.25             # the first step's gradients are the same launches' output (and the clip is active)
+    assert float((p0 - p1).abs().max()) <= 2e-6 * float(p0.abs().max())
