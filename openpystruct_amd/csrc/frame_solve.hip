@@ -581,7 +581,9 @@ static bool use_tile_kernel() {
 static bool wave_kernel_serves(int n_eq, int kd) {
   if (!use_wave_kernel(kd)) return false;
   const int W = fw_width(kd);
-  const size_t per_wave = fw_lds_doubles(n_eq, W) > ft_lds_doubles(n_eq) ? fw_lds_doubles(n_eq, W) : ft_lds_doubles(n_eq);
+  // (the opt-in tile variant parks rows at a wider pitch: its LDS need counts only when it is switched on -- sized by it unconditionally,
+  //  frames of ~4 100-4 700 equations that the default kernel serves fell back to the workgroup-per-frame kernels: ADVICE r04)
+  const size_t per_wave = use_tile_kernel() && ft_lds_doubles(n_eq) > fw_lds_doubles(n_eq, W) ? ft_lds_doubles(n_eq) : fw_lds_doubles(n_eq, W);
   if (4 * per_wave * sizeof(double) > 160 * 1024 - 64) return false;
   if (fused_assembly() ? n_eq > (1 << 20) : ((size_t)FW_SLAB * W + (size_t)n_eq) * sizeof(double) > LDS_MAX) return false;
   return true;

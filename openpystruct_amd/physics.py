@@ -125,10 +125,18 @@ class _FusedResidualTerm(torch.autograd.Function):
                                   I_scale=keep[0].data_ptr(), I_mean=keep[1].data_ptr(), I_min=1e-8, Fy=Fy.data_ptr(), x=x.data_ptr(),
                                   fix=fix.data_ptr(), E=float(E), wy=float(wy), weight=float(weight), ev=ev.data_ptr(), et=et.data_ptr(),
                                   part=part.data_ptr(), value=value.data_ptr(), value_sum=acc.data_ptr() if acc is not None else None)
+        G = int(Fy.shape[0])
+        if Fy.dim() != 2 or Fy.shape[1] != N or (rows is None and G < B):
+            raise ValueError(f"Fy must be [G, {N}] float64 with G >= the batch (or `rows` given)")
         if rows is not None:
+            if rows.dtype != torch.int64 or rows.device != dev or rows.dim() != 1 or rows.numel() < B or not rows.is_contiguous():
+                raise ValueError("rows must be a contiguous int64 vector on the predictions' device with one entry per sample")
             keep.append(rows)
             a.rows = rows.data_ptr()
-        if torch.is_tensor(disp[0]):            # recorded displacement fields (I-only models)
+        if torch.is_tensor(disp[0]):            # recorded displacement fields (I-only models): the kernels read raw float64 rows
+            for t in disp[:2]:
+                if not (torch.is_tensor(t) and t.dtype == torch.float64 and t.device == dev and t.dim() == 2 and t.shape == (G, N) and t.is_contiguous()):
+                    raise ValueError(f"recorded displacement fields must be contiguous float64 [{G}, {N}] tensors on the predictions' device")
             keep += [disp[0], disp[1]]
             a.v_rec, a.t_rec = disp[0].data_ptr(), disp[1].data_ptr()
         else:                                   # the PINN's own outputs: (scaler of the deflections, scaler of the rotations)
@@ -149,8 +157,12 @@ class _FusedResidualTerm(torch.autograd.Function):
         lib = _cabi.load()
         a, preds = ctx.args, ctx.keep[9]
         dev = preds.device
-        dp = torch.empty_like(preds) if ctx.ncols == preds.shape[1] else torch.zeros_like(preds)
-        a.dpreds, a.ldp = dp.data_ptr(), dp.stride(0)
+        # (the launch reads the predictions and writes their gradient with ONE row stride: the gradient takes the predictions' strides -- a
+        #  row view of a wider matrix included -- instead of empty_like's dense ones)
+        dp = torch.empty_strided(preds.shape, preds.stride(), dtype=preds.dtype, device=dev)
+        if ctx.ncols != preds.shape[1]:
+            dp.zero_()
+        a.dpreds, a.ldp = dp.data_ptr(), preds.stride(0)
         with torch.cuda.device(dev):
             rc = lib.ops_physics_loss_bwd(ctypes.byref(a), torch.cuda.current_stream(dev).cuda_stream)
         if rc != _cabi.OK:

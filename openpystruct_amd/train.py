@@ -708,7 +708,8 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
         if kind == "pinn":
             sD, sR = data.scalers_Y["deflections"], data.scalers_Y["rotations"]
         else:
-            v_rec, t_rec = data.v_train.to(device), data.theta_train.to(device)
+            v_rec = data.v_train.to(device=device, dtype=torch.float64).contiguous()        # (the fused term reads raw float64 rows)
+            t_rec = data.theta_train.to(device=device, dtype=torch.float64).contiguous()
         px, pfix = physics.x.to(device=device, dtype=torch.float64), physics.fix.to(device=device, dtype=torch.uint8)
         pE = torch.tensor(float(physics.E), dtype=torch.float64, device=device)      # device scalars: nothing crosses PCIe
         pwy = torch.tensor(float(physics.wy), dtype=torch.float64, device=device)    # inside a captured step
