@@ -765,6 +765,11 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
                 tfd_fused.arm_head_loss(Yb, crit, cfg.initial_alpha if alpha_term else None, loss_acc)
                 preds = net(Xn)
                 head_loss = tfd_fused.take_head_loss()
+                if head_loss is None and fuse_gather:
+                    # (with the batch assembled by the front-end launch the static target buffer `Yb` is never filled: the framework-side
+                    #  loss below would be evaluated against stale targets -- fail loudly instead)
+                    raise RuntimeError("the head's loss launch did not run although the front-end launch assembles the batch itself "
+                                       "(criterion / shape mismatch in tfd_fused.arm_head_loss)")
             else:
                 preds = net(Xn)
             if head_loss is not None:
