@@ -5,8 +5,10 @@ Follows /root/reference/OpenPyStruct_FrameOpt_Discrete_Beta.py:141-206 line by l
 accumulation), float32 `I_tensor` (:167), `torch.optim.Adam(lr)` WITHOUT a scheduler (:170), `clamp_(min=1e-8)` (:187),
 early stop on `best_loss - tolerance` with patience 10 (:192-203).  The OpenSees model build + `ops.analyze(1)` +
 `ops.eleResponse(e, 'forces')` (:75-139, :181-183, :151) are replaced by the oracle's 3-DOF band solve
-(oracle/beam_oracle.py::solve_model_3dof = LAPACK dpbsv).  PARITY UNPINNED for the FE part (openseespy is unavailable);
-the optimiser part is the reference's own torch calls.
+(oracle/beam_oracle.py::solve_model_3dof = LAPACK dpbsv).  PARITY UNPINNED for the FE part (openseespy is unavailable).
+The LOOP is checked against what the reference's own script did (r05, tests/golden/sizing_reference_fr.npz: six runs of
+OpenPyStruct_FrameOpt_Discrete_Beta.py executed under the recorder of tests/golden/opensees_stub.py, 1 x 2 ... 10 x 5 bays x
+stories; tests/test_sizing_golden.py: loss history to 2e-6, the run that stops early at its epoch, inertias to 5e-5).
 """
 from __future__ import annotations
 

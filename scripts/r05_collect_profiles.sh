@@ -1,0 +1,17 @@
+#!/bin/bash
+# copies the summaries of scripts/r05_profiles.sh from gpurun_out/ (scratch) into profiles/ (tracked)
+cd /root/repo
+for t in r05_hot10k r05_cold10k r05_sat2p20; do
+  d=gpurun_out/prof_$t
+  cp $d/summary.json profiles/${t}_pmc_summary.json
+  f=$(ls -S $d/trace/*/*_kernel_stats.csv | head -1); cp $f profiles/${t}_kernel_stats.csv
+  [ -f $d/trace.log ] && grep -h '^{"metric"' $d/trace.log | tail -1 > profiles/${t}_bench_under_trace.json
+done
+for fr in 15x16 10x10; do
+  d=gpurun_out/prof_frames_$fr
+  cp $d/summary.json profiles/r05_frames_${fr}_pmc_summary.json
+  f=$(ls -S $d/trace/*/*_kernel_stats.csv | head -1); cp $f profiles/r05_frames_${fr}_kernel_stats.csv
+  cp gpurun_out/r05_bench_frames_$fr.json profiles/r05_bench_frames_$fr.json
+done
+cp gpurun_out/r05_bench_default.json profiles/r05_bench_default.json
+ls -la profiles/r05_*summary.json profiles/r05_bench_default.json
