@@ -458,6 +458,14 @@ int ops_flat_clip_adam_step_repack_f32(long n, float* params, const float* grads
 int ops_mlp_gather_noise(int B, int F, const float* X, const long long* idx, const float* sigma, unsigned long long seed,
                          unsigned long long* counter, void* out, int ld, void* out_t, const float* Y, int C, float* targets_t,
                          void* stream);
+/* r05 (ABI 12): the same launch also rebuilds the tiled bf16 weight copies of `nmat` matrices from the float32 parameters (entries as in
+ * ops_flat_clip_adam_step_repack_f32: every W inside [params, params + n_params)) in extra workgroups -- the previous optimiser step's
+ * copies and this step's batch depend on nothing of each other, so the two adjacent launches are one.  The optimiser is then called
+ * WITHOUT its repack (ops_flat_clip_adam_step_f32); whoever reads the copies outside a training step (an evaluation pass) calls
+ * ops_mlp_repack_weights first. */
+int ops_mlp_gather_noise_repack(int B, int F, const float* X, const long long* idx, const float* sigma, unsigned long long seed,
+                                unsigned long long* counter, void* out, int ld, void* out_t, const float* Y, int C, float* targets_t,
+                                long n_params, const float* params, int nmat, const ops_mlp_repack_entry* entries, void* stream);
 
 /* bytes of ops_mlp_strip_args.loss_ws (TAIL_LOSS) */
 size_t ops_mlp_loss_workspace_bytes(void);

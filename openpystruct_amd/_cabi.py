@@ -47,6 +47,7 @@ EXPORTS = (
     "ops_mlp_spart_doubles",
     "ops_mlp_wgrad_group",
     "ops_mlp_wgrad_group_norm",
+    "ops_mlp_gather_noise_repack",
     "ops_mlp_repack_weights",
     "ops_flat_clip_adam_step_repack_f32",
     "ops_mlp_gather_noise",
@@ -330,6 +331,8 @@ def load():
                                                        ctypes.POINTER(MlpRepackEntry), vp]
     lib.ops_mlp_gather_noise.restype = it
     lib.ops_mlp_gather_noise.argtypes = [it, it, vp, vp, vp, ull, vp, vp, it, vp, vp, it, vp, vp]
+    lib.ops_mlp_gather_noise_repack.restype = it
+    lib.ops_mlp_gather_noise_repack.argtypes = [it, it, vp, vp, vp, ull, vp, vp, it, vp, vp, it, vp, lg, vp, it, ctypes.POINTER(MlpRepackEntry), vp]
     lib.ops_mlp_loss_workspace_bytes.restype = ctypes.c_size_t
     lib.ops_seq_attention_fwd.restype = it
     lib.ops_seq_attention_fwd.argtypes = [it, it, it, it, vp, vp, fl, ull, vp, vp, vp]

@@ -38,6 +38,7 @@
 #include "../../include/openpystruct_amd.h"
 #include "dropout_stream.hpp"
 #include "call_counter.hpp"
+#include "repack_tiles.hpp"
 
 namespace opsamd {
 
@@ -725,11 +726,22 @@ __device__ __forceinline__ uint64_t mb_mix(uint64_t z) {
   return z ^ (z >> 31);
 }
 
+// r05: REPACK -- the tiled bf16 weight copies of the PREVIOUS optimiser step are rebuilt by extra workgroups of this launch (four 1 KB
+// tiles each, repack_tiles.hpp): the step's last launch (the copies) and the next step's first (the batch) depend on nothing of each other,
+// so they are one launch -- one kernel boundary and the copies' 5 us (shorter than the assembly's 8) off every step.
+template <bool REPACK>
 __global__ __launch_bounds__(256) void mlp_gather_noise_kernel(int B, int F, const float* __restrict__ X, const long long* __restrict__ idx,
                                                                 const float* __restrict__ sigma, unsigned long long seed,
                                                                 unsigned long long* __restrict__ counter, uint16_t* __restrict__ out, int ld,
                                                                 uint16_t* __restrict__ out_t, int nfb, const float* __restrict__ Ysrc, int C,
-                                                                float* __restrict__ yout_t) {
+                                                                float* __restrict__ yout_t, int ngb, const float* __restrict__ params,
+                                                                const AdamRepack rp, const TileJobs tj) {
+  if constexpr (REPACK) {
+    if ((int)blockIdx.x >= ngb) {          // workgroup-uniform: a weight-copy workgroup
+      repack_tile_job(params, rp, tj, ((int)blockIdx.x - ngb) * 4 + (int)(threadIdx.x >> 6), (int)(threadIdx.x & 63));
+      return;
+    }
+  }
   __shared__ __attribute__((aligned(16))) uint16_t s_tile[32][MB_ROWS + 8];     // [feature][row]
   __shared__ float s_tt[32][MB_ROWS + 1];
   const int fl = threadIdx.x & 31;
@@ -918,17 +930,40 @@ extern "C" int ops_mlp_repack_weights(int nmat, const ops_mlp_repack_entry* entr
   return OPS_AMD_OK;
 }
 
-extern "C" int ops_mlp_gather_noise(int B, int F, const float* X, const long long* idx, const float* sigma, unsigned long long seed,
-                                    unsigned long long* counter, void* out, int ld, void* out_t, const float* Y, int C, float* targets_t,
-                                    void* stream) {
+static int gather_launch(int B, int F, const float* X, const long long* idx, const float* sigma, unsigned long long seed,
+                         unsigned long long* counter, void* out, int ld, void* out_t, const float* Y, int C, float* targets_t,
+                         const float* params, const AdamRepack* rp, void* stream) {
   if (B < 1 || B > MB_ROWS || F < 1 || !X || !idx || !out || !out_t || ld % 32 || ld < ru(F, 32)) return OPS_AMD_ERR_INVALID_ARG;
   if (Y && (C < 1 || !targets_t)) return OPS_AMD_ERR_INVALID_ARG;
   const int nfb = (F + 31) / 32, ntb = Y ? (C + 31) / 32 : 0;
-  hipLaunchKernelGGL(mlp_gather_noise_kernel, dim3((unsigned)(nfb + ntb)), dim3(256), 0, (hipStream_t)stream, B, F, X, idx, sigma, seed,
-                     counter, (uint16_t*)out, ld, (uint16_t*)out_t, nfb, Y, C, targets_t);
+  if (rp) {
+    const TileJobs tj = make_tile_jobs(*rp);
+    const int nrb = (tj.first[2 * rp->nmat] + 3) / 4;
+    hipLaunchKernelGGL(mlp_gather_noise_kernel<true>, dim3((unsigned)(nfb + ntb + nrb)), dim3(256), 0, (hipStream_t)stream, B, F, X, idx, sigma,
+                       seed, counter, (uint16_t*)out, ld, (uint16_t*)out_t, nfb, Y, C, targets_t, nfb + ntb, params, *rp, tj);
+  } else {
+    hipLaunchKernelGGL(mlp_gather_noise_kernel<false>, dim3((unsigned)(nfb + ntb)), dim3(256), 0, (hipStream_t)stream, B, F, X, idx, sigma, seed,
+                       counter, (uint16_t*)out, ld, (uint16_t*)out_t, nfb, Y, C, targets_t, nfb + ntb, nullptr, AdamRepack{}, TileJobs{});
+  }
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) { set_last_error(hipGetErrorString(e)); return OPS_AMD_ERR_LAUNCH; }
   return OPS_AMD_OK;
+}
+
+extern "C" int ops_mlp_gather_noise(int B, int F, const float* X, const long long* idx, const float* sigma, unsigned long long seed,
+                                    unsigned long long* counter, void* out, int ld, void* out_t, const float* Y, int C, float* targets_t,
+                                    void* stream) {
+  return gather_launch(B, F, X, idx, sigma, seed, counter, out, ld, out_t, Y, C, targets_t, nullptr, nullptr, stream);
+}
+
+extern "C" int ops_mlp_gather_noise_repack(int B, int F, const float* X, const long long* idx, const float* sigma, unsigned long long seed,
+                                           unsigned long long* counter, void* out, int ld, void* out_t, const float* Y, int C,
+                                           float* targets_t, long n_params, const float* params, int nmat, const ops_mlp_repack_entry* entries,
+                                           void* stream) {
+  AdamRepack rp{};
+  const int rc = make_adam_repack(n_params, params, nmat, entries, &rp);
+  if (rc != OPS_AMD_OK) return rc;
+  return gather_launch(B, F, X, idx, sigma, seed, counter, out, ld, out_t, Y, C, targets_t, params, &rp, stream);
 }
 
 extern "C" size_t ops_mlp_loss_workspace_bytes(void) { return (size_t)ML_MAXG * 5 * sizeof(double); }

@@ -259,6 +259,7 @@ class PinnFusedStep:
             e.At, e.Bt, e.out, e.N, e.K, e.ldo = at.data_ptr(), bt.data_ptr(), w.grad.data_ptr(), w.shape[0], w.shape[1], w.shape[1]
         self._wgrad = wg
         self._norm = None        # (ranges ptr array, lengths, n, workspace, step, betas, nparts holder): enable_norm()
+        self.repack_params = None   # flat float32 parameter buffer: training gathers also rebuild the bf16 weight copies (repack_in_gather)
         covered = sum(p.numel() for p in m.parameters())
         named = sum(l.weight.numel() + l.bias.numel() for l in [m.input_fc, m.output_fc] + [x for b in m.residual_blocks for x in (b[0].fc1, b[0].fc2)])
         named += sum(2 * bn.weight.numel() for bn in [m.input_norm] + [b[1] for b in m.residual_blocks]) + 6 * self.nblk
@@ -305,12 +306,29 @@ class PinnFusedStep:
             raise RuntimeError(f"{what} failed with code {rc}: {self.lib.ops_amd_last_error().decode()}")
 
     # ---- the step ----
+    def repack_in_gather(self, flat_params: torch.Tensor) -> None:
+        """r05: from now on every TRAINING gather (sigma given) also rebuilds the tiled bf16 weight copies from `flat_params` (the
+        optimiser's flat float32 parameter buffer, every Linear weight a view of it) in extra workgroups of its launch -- the optimiser is
+        then run WITHOUT its repack launch (FlatClipAdam.repack = None).  The copies are one optimiser step old between an update and the
+        next training gather: call `repack_now()` before reading them elsewhere (an evaluation pass)."""
+        if flat_params.dtype != torch.float32 or not flat_params.is_contiguous():
+            raise ValueError("flat_params must be the contiguous float32 parameter buffer")
+        self.repack_params = flat_params
+
     def gather(self, X: torch.Tensor, Y: torch.Tensor, idx: torch.Tensor, sigma: torch.Tensor, seed: int) -> int:
         """x <- X[idx] + sigma * N(0, 1) in both layouts, targets_t <- Y[idx]^T (PINN:748-756), one launch.  Returns the live rows."""
         B = int(idx.numel())
         if X.dtype != torch.float32 or not X.is_contiguous() or Y.dtype != torch.float32 or not Y.is_contiguous() or Y.shape[1] != self.C:
             raise ValueError("X and Y must be contiguous float32 matrices")
         s = torch.cuda.current_stream(self.dev).cuda_stream
+        if self.repack_params is not None and sigma is not None:        # a training step's batch: + the weight copies of the last update
+            with torch.cuda.device(self.dev):
+                self._check(self.lib.ops_mlp_gather_noise_repack(B, self.F_in, X.data_ptr(), idx.data_ptr(), sigma.data_ptr(),
+                                                                 int(seed) & 0x7FFFFFFFFFFFFFFF, self.prep_counter.data_ptr(), self.x.data_ptr(),
+                                                                 self.x.shape[1], self.xt.data_ptr(), Y.data_ptr(), self.C, self.targets_t.data_ptr(),
+                                                                 self.repack_params.numel(), self.repack_params.data_ptr(), len(self._repack),
+                                                                 self._repack, s), "ops_mlp_gather_noise_repack")
+            return B
         with torch.cuda.device(self.dev):
             self._check(self.lib.ops_mlp_gather_noise(B, self.F_in, X.data_ptr(), idx.data_ptr(), sigma.data_ptr() if sigma is not None else None,
                                                       int(seed) & 0x7FFFFFFFFFFFFFFF, self.prep_counter.data_ptr(), self.x.data_ptr(),

@@ -41,16 +41,19 @@ def test_training_through_the_data_parallel_branch_on_one_rank_of_rccl():
         plain = np.array(runs["plain"]["train"] + runs["plain"]["val"])
         again = np.array(runs["plain_again"]["train"] + runs["plain_again"]["val"])
         assert np.isfinite(plain).all()
-        spread = float(np.abs(plain - again).max() / np.abs(plain).max())     # float atomics in the weight-gradient kernels: runs of ONE
-        # configuration agree to this; where they agree bit for bit, so must the one-rank data-parallel runs
+        spread = float(np.abs(plain - again).max() / np.abs(plain).max())
         for name in ("dp_async", "dp_blocking", "dp_one_graph", "dp_profile"):
             got = np.array(runs[name]["train"] + runs[name]["val"])
             diff = float(np.abs(got - plain).max() / np.abs(plain).max())
-            if spread == 0.0 and name != "dp_one_graph":
-                assert diff == 0.0, (kind, name, diff)
+            if kind == "pinn":
+                # the PINN step's launches are deterministic (no float atomics): a one-rank all-reduce is the identity, bit for bit,
+                # in every form of the step
+                assert spread == 0.0 and diff == 0.0, (kind, name, diff, spread)
             else:
+                # the TFD step adds its split-row weight-gradient tiles with float atomics: two runs of ONE configuration land on one of
+                # a few nearby trajectories (ten suite runs: differences of 0 or ~1.3e-4 between any two runs, plain or data parallel), so
+                # the statement is a tolerance -- far below what a wrong average / missing all-reduce would show (O(1))
                 assert diff <= max(20 * spread, 2e-3), (kind, name, diff, spread)
-        assert (np.array(runs["dp_async"]["train"]) == np.array(runs["dp_blocking"]["train"])).all() or spread > 0.0
         assert runs["plain"]["dp_mode"] is None
         for name in ("dp_async", "dp_blocking", "dp_one_graph", "dp_profile"):
             m = runs[name]["dp_mode"]

@@ -510,3 +510,50 @@ def test_gradient_norm_left_by_the_weight_gradient_launch(B, p_drop):
     p1, n1 = run(True)
     assert n0[0] == n1[0] and n0[0] > 0.25             # the first step's gradients are the same launches' output (and the clip is active)
     assert float((p0 - p1).abs().max()) <= 2e-6 * float(p0.abs().max())
+
+
+def test_weight_copies_rebuilt_by_the_next_gather_equal_the_optimisers_repack_launch():
+    """r05: `PinnFusedStep.repack_in_gather` -- the tiled bf16 weight copies of optimiser step n are rebuilt by extra workgroups of the
+    batch-assembly launch of step n + 1 (ops_mlp_gather_noise_repack) instead of a launch of their own behind the update.  Three training
+    steps either way: the same float32 parameters bit for bit, the same copies after the closing `repack_now()`, and the copies a step
+    reads are the ones of the update before it."""
+    from openpystruct_amd import train
+    from openpystruct_amd.pinn_fused import PinnFusedStep
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(9)
+    X = torch.randn(300, 684, generator=g).to(dev)
+    Y = (0.8 * torch.randn(300, 302, generator=g)).to(dev)
+    sig = torch.tensor(0.01, device=dev)
+
+    def run(merged):
+        model, crit = _make(4, 0.5)
+        model, crit = model.to(dev), crit.to(dev)
+        flat = _attach_flat(model)
+        opt = train.FlatClipAdam(list(model.parameters()), flat, 5e-4, weight_decay=1e-3, max_norm=1.0)
+        eng = PinnFusedStep(model, crit, seed=21)
+        if merged:
+            eng.repack_in_gather(opt.p)
+        else:
+            opt.repack = eng._repack
+        model.train()
+        losses = []
+        for step in range(3):
+            idx = torch.arange(100 * step, 100 * step + 100, device=dev)
+            eng.gather(X, Y, idx, sig, 5)
+            if merged and step > 0:
+                # the copies this step reads are those of the update before it: equal to a fresh repack of the current parameters
+                torch.cuda.synchronize()
+                seen = [t.clone() for pair in eng.wp.values() for t in pair]
+                eng.repack_now()
+                torch.cuda.synchronize()
+                assert all(torch.equal(a, b) for a, b in zip(seen, [t for pair in eng.wp.values() for t in pair]))
+            losses.append(float(eng.fwd_bwd(100)))
+            opt.step()
+        eng.repack_now()
+        torch.cuda.synchronize()
+        return opt.p.clone(), [t.clone() for pair in eng.wp.values() for t in pair], losses
+
+    p0, w0, l0 = run(False)
+    p1, w1, l1 = run(True)
+    assert l0 == l1 and torch.equal(p0, p1)
+    assert all(torch.equal(a, b) for a, b in zip(w0, w1))
