@@ -362,73 +362,64 @@ __global__ __launch_bounds__(MB_THREADS) void mlp_strip_kernel(const ops_mlp_str
   const unsigned long long call = (fwd && a.p_drop > 0.0f && a.call_counter) ? *a.call_counter : 0ull;
 
   // ---- FUSED1, phase A: the hidden tile h = dropout(LeakyReLU(fc1(O) + bias1)) [128 x b.N], every workgroup all of it ----
-  // ONE exposed memory latency, like every other launch of this file: the whole tiled image of O (88 KB) is requested by the 512 threads
-  // at once (11 x 16 bytes each) and parked in LDS, and every wave requests ALL weight fragments of its one or two column tiles (wave w:
-  // tiles w and w + 8; 22 x 16 bytes per lane) in the same breath.  (First version: a wave walked the reduction with the fragments of
-  // one step in flight -- eleven dependent round trips to the Infinity Cache, 33 us per launch.)  The hidden tile then takes O's place in LDS.
   uint16_t* const s_h = s_dyn;
   if constexpr (FUSED1) {
     const unsigned long long call1 = (b.p_drop > 0.0f && b.call_counter) ? *b.call_counter : 0ull;
-    const int KS1 = (b.K + 31) >> 5, NT1 = (b.N + 15) >> 4, KS2 = b.ldy >> 5;       // reduction steps of fc1 (<= 16), column tiles of h (<= 12), steps of fc2
-    constexpr int MAXS = 11;                                                           // reduction steps held in registers (host-checked: KS1 <= 11)
-    const uint16_t* oimg = (const uint16_t*)in_slot(b.A);                              // [8 row blocks][lda / 32 steps][512]
-    const int ostep = b.lda >> 5;
-    uint4 oc[MAXS];
+    const int KS1 = (b.K + 31) >> 5, NT1 = (b.N + 15) >> 4, KS2 = b.ldy >> 5;       // reduction steps of fc1, column tiles of h, steps of fc2
+    const int rq = wave & 1, ct = wave >> 1;                                           // row blocks 4 rq .. 4 rq + 3, column tiles 3 ct .. 3 ct + 2
+    const uint16_t* ap = (const uint16_t*)in_slot(b.A) + (long)(4 * rq) * (b.lda >> 5) * 512 + lane * 8;
+    const uint16_t* wp = (const uint16_t*)b.W + (long)(3 * ct) * (b.ldw >> 5) * 512 + lane * 8;
+    const long astep = (long)(b.lda >> 5) * 512, wstep = (long)(b.ldw >> 5) * 512;
+    bool tv[3];
 #pragma unroll
-    for (int i = 0; i < MAXS; ++i) {                                                   // chunk (row block rb, step st, 16-byte piece pc) = tid + 512 i
-      const int ci = tid + MB_THREADS * i, rbk = ci / (KS1 * 64), rem = ci - rbk * (KS1 * 64);
-      oc[i] = rbk < 8 ? *(const uint4*)(oimg + ((long)(rbk * ostep + (rem >> 6)) * 512 + (rem & 63) * 8)) : uint4{0u, 0u, 0u, 0u};
-    }
-    const int dbg = b.loss_C;                                                          // (diagnostic skip mask: scripts/pinn_block_merge_probe.py)
-    const int tA = wave, tB = wave + 8;
-    const bool hasB = tB < NT1;                                                        // (wave-uniform)
-    const uint16_t* wpA = (const uint16_t*)b.W + (long)tA * (b.ldw >> 5) * 512 + lane * 8;
-    const uint16_t* wpB = (const uint16_t*)b.W + (long)(hasB ? tB : tA) * (b.ldw >> 5) * 512 + lane * 8;
-    uint4 fbA[MAXS], fbB[MAXS];
+    for (int j = 0; j < 3; ++j) tv[j] = 3 * ct + j < NT1;                               // (wave-uniform)
+    mb_f32x4 acc1[4][3];
 #pragma unroll
-    for (int st = 0; st < MAXS; ++st) {
-      const int ss = st < KS1 ? st : KS1 - 1;
-      fbA[st] = *(const uint4*)(wpA + ss * 512);
-      fbB[st] = *(const uint4*)(wpB + ss * 512);
-    }
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int i = 0; i < MAXS; ++i) {
-      const int ci = tid + MB_THREADS * i;
-      if (ci < 8 * KS1 * 64) *(uint4*)(s_dyn + (long)ci * 8) = oc[i];                  // O's image, packed [8][KS1][512]
-    }
-    __syncthreads();
-    mb_f32x4 accA[8], accB[8];
+      for (int j = 0; j < 3; ++j) acc1[i][j] = mb_f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    uint4 fa[2][4], fb[2][3];
+    auto load_step = [&](int buf, int s) {
+      const int ss = s < KS1 ? s : KS1 - 1;
 #pragma unroll
-    for (int rbk = 0; rbk < 8; ++rbk) { accA[rbk] = mb_f32x4{0.0f, 0.0f, 0.0f, 0.0f}; accB[rbk] = mb_f32x4{0.0f, 0.0f, 0.0f, 0.0f}; }
+      for (int i = 0; i < 4; ++i) fa[buf][i] = *(const uint4*)(ap + i * astep + ss * 512);
 #pragma unroll
-    for (int st = 0; st < MAXS; ++st)
-      if (st < KS1 && !(dbg & 1)) {
+      for (int j = 0; j < 3; ++j) fb[buf][j] = *(const uint4*)(wp + (tv[j] ? j : 0) * wstep + ss * 512);
+    };
+    load_step(0, 0);
+    for (int s = 0; s < KS1; s += 2) {
+      load_step(1, s + 1);
 #pragma unroll
-        for (int rbk = 0; rbk < 8; ++rbk) {
-          const uint4 fa = *(const uint4*)(s_dyn + ((long)(rbk * KS1 + st) * 512 + lane * 8));
-          accA[rbk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mb_bf16x8, fa), __builtin_bit_cast(mb_bf16x8, fbA[st]), accA[rbk], 0, 0, 0);
-          if (hasB)
-            accB[rbk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mb_bf16x8, fa), __builtin_bit_cast(mb_bf16x8, fbB[st]), accB[rbk], 0, 0, 0);
-        }
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+          acc1[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mb_bf16x8, fa[0][i]), __builtin_bit_cast(mb_bf16x8, fb[0][j]), acc1[i][j], 0, 0, 0);
+      if (s + 1 < KS1) {
+        load_step(0, s + 2);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 3; ++j)
+            acc1[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mb_bf16x8, fa[1][i]), __builtin_bit_cast(mb_bf16x8, fb[1][j]), acc1[i][j], 0, 0, 0);
       }
-    __syncthreads();                                                                    // every wave is done with O's image: h takes its place
+    }
     // tail of fc1 (TAIL_ACT_DROP, exactly as a launch of its own computes it) and the tile into LDS in the A-fragment layout
     const float keep1 = b.p_drop > 0.0f ? 1.0f / (1.0f - b.p_drop) : 1.0f;
     const bool drop1 = b.p_drop > 0.0f;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int tile = j == 0 ? tA : tB, col = tile * 16 + (lane & 15);
-      if (col - (lane & 15) >= KS2 * 32 || (dbg & 2)) continue;                         // (wave-uniform: a tile beyond the padded width)
-      const bool cok = tile < NT1 && col < b.N;
+    for (int j = 0; j < 3; ++j) {
+      const int col = (3 * ct + j) * 16 + (lane & 15);
+      if (col >= KS2 * 32) continue;                                                    // (wave-uniform: a tile beyond the padded width)
+      const bool cok = tv[j] && col < b.N;
       const float bias1 = (cok && b.bias) ? mb_round(b.bias[col]) : 0.0f;
 #pragma unroll
-      for (int rbk = 0; rbk < 8; ++rbk)
+      for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const int row = rbk * 16 + (lane >> 4) * 4 + e;
+          const int row = (4 * rq + i) * 16 + (lane >> 4) * 4 + e;
           float y = 0.0f;
           if (cok && row < B) {
-            const float v1 = mb_round((j == 0 ? accA[rbk][e] : accB[rbk][e]) + bias1);
+            const float v1 = mb_round(acc1[i][j][e] + bias1);
             y = v1 > 0.0f ? v1 : v1 * b.slope;
             if (drop1) y = mb_uniform(b.seed, call1, (uint64_t)row * (uint64_t)b.N + (uint64_t)col) >= b.p_drop ? y * keep1 : 0.0f;
           }
@@ -440,7 +431,7 @@ __global__ __launch_bounds__(MB_THREADS) void mlp_strip_kernel(const ops_mlp_str
     // workgroups between them; the transposed copy per column tile by workgroup = tile
     {
       const int nchunk = 8 * KS2 * 64;                                                  // 16-byte chunks of the image
-      const int per = (b.loss_C & 4) ? 0 : (nchunk + nstrips - 1) / nstrips, c0 = (int)blockIdx.x * per;
+      const int per = (nchunk + nstrips - 1) / nstrips, c0 = (int)blockIdx.x * per;
       for (int cidx = c0 + tid; cidx < c0 + per && cidx < nchunk; cidx += MB_THREADS)
         *(uint4*)((uint16_t*)in_slot(b.Y) + (long)cidx * 8) = *(const uint4*)(s_h + (long)cidx * 8);
       if ((int)blockIdx.x < NT1 && b.Yt && tid < 2 * MB_ROWS) {
@@ -493,8 +484,7 @@ __global__ __launch_bounds__(MB_THREADS) void mlp_strip_kernel(const ops_mlp_str
 #pragma unroll
   for (int rep = 0; rep < 3; ++rep)
     if (chv[rep]) *(uint4*)&s_stage[(tid + MB_THREADS * rep) >> 4][8 * (tid & 15)] = ch[rep];
-  // [boundary][4 columns][128 rows], behind the larger of the two images (O's, then h's) that share the front of the dynamic LDS
-  uint16_t* const s_bnd = s_dyn + (size_t)8 * (FUSED1 ? (((b.K + 31) >> 5) > (b.ldy >> 5) ? ((b.K + 31) >> 5) : (b.ldy >> 5)) : 0) * 512;
+  uint16_t* const s_bnd = s_dyn + (size_t)8 * (FUSED1 ? (b.ldy >> 5) : 0) * 512;      // [boundary][4 columns][128 rows]
   if constexpr (FUSED1) {
 #pragma unroll
     for (int rep = 0; rep < 3; ++rep)
@@ -520,7 +510,7 @@ __global__ __launch_bounds__(MB_THREADS) void mlp_strip_kernel(const ops_mlp_str
     // strip-boundary cross terms of the stencil statistics: boundary i = columns 16 i + 14 .. 16 i + 17 (slots 0 .. 3); thread = (boundary,
     // 8 rows): sum o15 o16 (adjacent), sum o14 o16 + o15 o17 (next to adjacent); columns >= No were parked as 0
     float pb[2] = {0.0f, 0.0f};
-    if (tid < 16 * (nstrips - 1) && !(b.loss_C & 8)) {
+    if (tid < 16 * (nstrips - 1)) {
       const uint16_t* q0 = s_bnd + (size_t)(tid >> 4) * MB_BND_COLS * MB_ROWS + 8 * (tid & 15);
 #pragma unroll
       for (int r = 0; r < 8; ++r) {
@@ -1083,9 +1073,7 @@ extern "C" int ops_mlp_block_fwd_launch(const ops_mlp_strip_args* fc1, const ops
   if (b.p_drop > 0.0f && (!b.call_counter || b.p_drop >= 1.0f)) return OPS_AMD_ERR_INVALID_ARG;
   const int nstrips = (a.N + MB_COLS - 1) / MB_COLS;
   if (nstrips > 64 || nstrips < 2 || 64 * (nstrips - 1) > 3 * MB_THREADS) return OPS_AMD_ERR_UNSUPPORTED;       // (strip = lane of the statistics; boundary chunks: three per thread)
-  const int ks1 = (b.K + 31) >> 5, ks2 = b.ldy >> 5;
-  if (ks1 > 11 || (b.N + 15) / 16 > 16) return OPS_AMD_ERR_UNSUPPORTED;                 // reduction steps held in registers; column tiles = two per wave
-  const size_t dyn = ((size_t)8 * (ks1 > ks2 ? ks1 : ks2) * 512 + (size_t)(nstrips - 1) * MB_BND_COLS * MB_ROWS) * sizeof(uint16_t);
+  const size_t dyn = ((size_t)8 * (b.ldy >> 5) * 512 + (size_t)(nstrips - 1) * MB_BND_COLS * MB_ROWS) * sizeof(uint16_t);
   static std::atomic<unsigned long long> attr_done{0};
   int devid = 0;
   if (hipGetDevice(&devid) != hipSuccess) return OPS_AMD_ERR_LAUNCH;
