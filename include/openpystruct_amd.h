@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define OPS_AMD_ABI_VERSION 13
+#define OPS_AMD_ABI_VERSION 12
 
 /* return codes of the launch functions (per-beam results are in `status`) */
 #define OPS_AMD_OK 0
@@ -416,19 +416,10 @@ typedef struct ops_mlp_strip_args {
   int32_t n_slots;
   int32_t slot_total_rows;
   int64_t slot_stride;
-  /* r05 (ABI 13): this (forward, training) launch's output is the input O of a residual block run by ops_mlp_block_fwd_launch: leave
-   * per-strip sufficient statistics of the stencil's whole-tensor normalisation there -- [strips][8] doubles (sum, sum of squares,
-   * adjacent / next-to-adjacent column products inside the strip, first / last column sum and sum of squares): the block's `spart`. */
-  double* stat_part;
 } ops_mlp_strip_args;
 
 /* One strip launch: workgroup = 128 rows x 16 output columns.  Returns OPS_AMD_ERR_INVALID_ARG on a broken layout contract. */
 int ops_mlp_strip_launch(const ops_mlp_strip_args* args, void* stream);
-/* r05 (ABI 13): a residual block's fc1 (TAIL_ACT_DROP) and fc2 (ADD_FWD_BLOCK + TAIL_BN) as ONE launch: every strip workgroup computes
- * the whole hidden tile itself, keeps it in LDS and multiplies from there; `fc1` / `fc2` are the argument blocks of the two launches it
- * replaces (fc2->A == fc1->Y; both of fc1's outputs are still written: the backward pass reads them).  The producer of the block input
- * must have been launched with stat_part = fc2->spart.  Training passes (no eval_stats, no slots); fc1->N <= 192, fc1->K <= 512. */
-int ops_mlp_block_fwd_launch(const ops_mlp_strip_args* fc1, const ops_mlp_strip_args* fc2, void* stream);
 /* doubles of `spart` for a block input of No columns (No <= 512) */
 size_t ops_mlp_spart_doubles(int No);
 

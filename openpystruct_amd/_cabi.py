@@ -9,7 +9,7 @@ import ctypes
 import os
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-ABI_VERSION = 13     # include/openpystruct_amd.h OPS_AMD_ABI_VERSION
+ABI_VERSION = 12     # include/openpystruct_amd.h OPS_AMD_ABI_VERSION
 # OPS_AMD_LIB lets A/B kernel experiments point at another build of the same C ABI
 LIB_PATH = os.environ.get("OPS_AMD_LIB") or os.path.join(_PKG, "lib", "libopenpystruct_amd.so")
 
@@ -48,7 +48,6 @@ EXPORTS = (
     "ops_mlp_wgrad_group",
     "ops_mlp_wgrad_group_norm",
     "ops_mlp_gather_noise_repack",
-    "ops_mlp_block_fwd_launch",
     "ops_mlp_repack_weights",
     "ops_flat_clip_adam_step_repack_f32",
     "ops_mlp_gather_noise",
@@ -124,7 +123,7 @@ class MlpStripArgs(ctypes.Structure):
                 ("ssave", _vp), ("spart", _vp), ("sdparams", _vp),
                 ("P", _vp), ("ldp", _i), ("targets_t", _vp), ("nI", _i), ("nD", _i), ("alpha", _vp), ("alpha0", _f),
                 ("min_constraint", _vp), ("max_constraint", _vp), ("box_weight", _f), ("rel_penalty", _f), ("loss_ws", _vp), ("loss_finish_rows", _i), ("loss_C", _i), ("loss", _vp), ("loss_sum", _vp),
-                ("eval_stats", _i), ("n_slots", _i), ("slot_total_rows", _i), ("slot_stride", ctypes.c_int64), ("stat_part", _vp)]
+                ("eval_stats", _i), ("n_slots", _i), ("slot_total_rows", _i), ("slot_stride", ctypes.c_int64)]
 
 
 class MlpWgradProblem(ctypes.Structure):
@@ -318,8 +317,6 @@ def load():
     lib.ops_beam_solve_lane_workspace_bytes.argtypes = [it, it]
     lib.ops_mlp_strip_launch.restype = it
     lib.ops_mlp_strip_launch.argtypes = [ctypes.POINTER(MlpStripArgs), vp]
-    lib.ops_mlp_block_fwd_launch.restype = it
-    lib.ops_mlp_block_fwd_launch.argtypes = [ctypes.POINTER(MlpStripArgs), ctypes.POINTER(MlpStripArgs), vp]
     lib.ops_mlp_spart_doubles.restype = ctypes.c_size_t
     lib.ops_mlp_spart_doubles.argtypes = [it]
     lib.ops_mlp_wgrad_group.restype = it

@@ -35,8 +35,6 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#include <atomic>
-
 #include "../../include/openpystruct_amd.h"
 #include "dropout_stream.hpp"
 #include "call_counter.hpp"
@@ -240,30 +238,16 @@ __device__ __forceinline__ void mb_side_job(const ops_mlp_strip_args& a, int row
   }
 }
 
-// r05, FUSED1: a residual block's fc1 AND fc2 (+ stencil + identity + norm) forward in ONE launch.  `a` is the fc2 launch as before, `b`
-// the fc1 launch it absorbs: every strip workgroup first computes the WHOLE hidden tile h = dropout(LeakyReLU(fc1(O))) [128 x b.N] itself
-// (b.N <= 192: 2 x 4 wave partition, 4 row blocks x 3 column tiles of accumulators per wave, operands straight from L2: 616 KB through the
-// CU's L1 per workgroup, ~4 us -- against a launch of its own of ~7.5 us + a kernel boundary), keeps it in LDS in the A-fragment layout
-// (= the tiled image of the global h buffer, which the workgroups copy out between them, with its transposed copy, for the backward pass)
-// and multiplies from there.  The stencil's whole-tensor statistics can no longer come from side workgroups of "the launch before" (that
-// launch is this one): the PRODUCER of O leaves per-strip sufficient statistics (stat_part: sum, sum of squares, adjacent- and
-// next-to-adjacent column products inside its 16 columns, first / last column sums) and every consumer adds the 21 strip-boundary cross
-// terms itself from 84 columns of O.
-constexpr int MB_BND_COLS = 4;              // columns 16 i + 14 .. 16 i + 17 around strip boundary i
-template <bool FUSED1>
-__global__ __launch_bounds__(MB_THREADS) void mlp_strip_kernel(const ops_mlp_strip_args a, const int nstrips, const ops_mlp_strip_args b) {
-  extern __shared__ __attribute__((aligned(16))) uint16_t s_dyn[];               // FUSED1: s_h [8 row blocks][KS2][512], then s_bnd [boundaries][4][128]
+__global__ __launch_bounds__(MB_THREADS) void mlp_strip_kernel(const ops_mlp_strip_args a, const int nstrips) {
   __shared__ float s_t[MB_ROWS][MB_COLS + 1];
   __shared__ __attribute__((aligned(16))) uint16_t s_y[MB_ROWS][MB_COLS];
   __shared__ __attribute__((aligned(16))) uint16_t s_z[MB_ROWS][MB_COLS];
   __shared__ __attribute__((aligned(16))) uint16_t s_stage[70][MB_ROWS];      // transposed epilogue operands: [column slot][row]
   __shared__ double s_red[(MB_THREADS / 64) * MB_NSUM];
   __shared__ double s_tot[16];
-  if constexpr (!FUSED1) {
-    if ((int)blockIdx.x >= nstrips) {      // workgroup-uniform
-      mb_side_job(a, (int)blockIdx.x - nstrips, s_red);
-      return;
-    }
+  if ((int)blockIdx.x >= nstrips) {      // workgroup-uniform
+    mb_side_job(a, (int)blockIdx.x - nstrips, s_red);
+    return;
   }
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int n0 = blockIdx.x * MB_COLS;
@@ -332,26 +316,10 @@ __global__ __launch_bounds__(MB_THREADS) void mlp_strip_kernel(const ops_mlp_str
   // partial sums of the stencil normalisation: lane = row of partials, wave = which sum (workgroup 0 needs all twelve backward)
   double pp0 = 0.0, pp1 = 0.0;
   if (a.add_mode != OPS_MLP_ADD_NONE) {
-    if constexpr (FUSED1) {                 // the producer's per-strip sufficient statistics: wave = which of the eight, lane = strip
-      if (lane < nstrips) pp0 = a.spart[lane * 8 + wave];
-    } else {
-      const int rows = (No + MB_SIDE_COLS - 1) / MB_SIDE_COLS, NS = fwd ? 2 : MB_NSUM;
-      if (lane < rows) {
-        if (wave < 2 || (blockIdx.x == 0 && wave < NS)) pp0 = a.spart[lane * NS + wave];
-        if (blockIdx.x == 0 && wave + 8 < NS) pp1 = a.spart[lane * NS + wave + 8];
-      }
-    }
-  }
-  // FUSED1: the four columns of O around every strip boundary (16-byte chunks: column, 8 rows), parked in LDS after the products
-  uint4 bch[3];
-  bool bchv[3] = {false, false, false};
-  if constexpr (FUSED1) {
-#pragma unroll
-    for (int rep = 0; rep < 3; ++rep) {
-      const int j = tid + MB_THREADS * rep, bi = j >> 6, k4 = (j >> 4) & 3, gq = j & 15, col = 16 * bi + 14 + k4;
-      bchv[rep] = bi < nstrips - 1;
-      bch[rep] = uint4{0u, 0u, 0u, 0u};
-      if (bchv[rep] && col < No) bch[rep] = *(const uint4*)((const uint16_t*)sOt + mb_toff(col, 8 * gq, MB_ROWS / 32));
+    const int rows = (No + MB_SIDE_COLS - 1) / MB_SIDE_COLS, NS = fwd ? 2 : MB_NSUM;
+    if (lane < rows) {
+      if (wave < 2 || (blockIdx.x == 0 && wave < NS)) pp0 = a.spart[lane * NS + wave];
+      if (blockIdx.x == 0 && wave + 8 < NS) pp1 = a.spart[lane * NS + wave + 8];
     }
   }
   float sc_w0 = 0.0f, sc_w1 = 0.0f, sc_w2 = 0.0f, sc_b = 0.0f, sc_g = 0.0f, sc_be = 0.0f, sv_mean = 0.0f, sv_inv = 1.0f;
@@ -360,89 +328,6 @@ __global__ __launch_bounds__(MB_THREADS) void mlp_strip_kernel(const ops_mlp_str
     if (a.add_mode == OPS_MLP_ADD_BWD_BLOCK) { sv_mean = a.ssave[0]; sv_inv = a.ssave[1]; }
   }
   const unsigned long long call = (fwd && a.p_drop > 0.0f && a.call_counter) ? *a.call_counter : 0ull;
-
-  // ---- FUSED1, phase A: the hidden tile h = dropout(LeakyReLU(fc1(O) + bias1)) [128 x b.N], every workgroup all of it ----
-  uint16_t* const s_h = s_dyn;
-  if constexpr (FUSED1) {
-    const unsigned long long call1 = (b.p_drop > 0.0f && b.call_counter) ? *b.call_counter : 0ull;
-    const int KS1 = (b.K + 31) >> 5, NT1 = (b.N + 15) >> 4, KS2 = b.ldy >> 5;       // reduction steps of fc1, column tiles of h, steps of fc2
-    const int rq = wave & 1, ct = wave >> 1;                                           // row blocks 4 rq .. 4 rq + 3, column tiles 3 ct .. 3 ct + 2
-    const uint16_t* ap = (const uint16_t*)in_slot(b.A) + (long)(4 * rq) * (b.lda >> 5) * 512 + lane * 8;
-    const uint16_t* wp = (const uint16_t*)b.W + (long)(3 * ct) * (b.ldw >> 5) * 512 + lane * 8;
-    const long astep = (long)(b.lda >> 5) * 512, wstep = (long)(b.ldw >> 5) * 512;
-    bool tv[3];
-#pragma unroll
-    for (int j = 0; j < 3; ++j) tv[j] = 3 * ct + j < NT1;                               // (wave-uniform)
-    mb_f32x4 acc1[4][3];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 3; ++j) acc1[i][j] = mb_f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-    uint4 fa[2][4], fb[2][3];
-    auto load_step = [&](int buf, int s) {
-      const int ss = s < KS1 ? s : KS1 - 1;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) fa[buf][i] = *(const uint4*)(ap + i * astep + ss * 512);
-#pragma unroll
-      for (int j = 0; j < 3; ++j) fb[buf][j] = *(const uint4*)(wp + (tv[j] ? j : 0) * wstep + ss * 512);
-    };
-    load_step(0, 0);
-    for (int s = 0; s < KS1; s += 2) {
-      load_step(1, s + 1);
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 3; ++j)
-          acc1[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mb_bf16x8, fa[0][i]), __builtin_bit_cast(mb_bf16x8, fb[0][j]), acc1[i][j], 0, 0, 0);
-      if (s + 1 < KS1) {
-        load_step(0, s + 2);
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int j = 0; j < 3; ++j)
-            acc1[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mb_bf16x8, fa[1][i]), __builtin_bit_cast(mb_bf16x8, fb[1][j]), acc1[i][j], 0, 0, 0);
-      }
-    }
-    // tail of fc1 (TAIL_ACT_DROP, exactly as a launch of its own computes it) and the tile into LDS in the A-fragment layout
-    const float keep1 = b.p_drop > 0.0f ? 1.0f / (1.0f - b.p_drop) : 1.0f;
-    const bool drop1 = b.p_drop > 0.0f;
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      const int col = (3 * ct + j) * 16 + (lane & 15);
-      if (col >= KS2 * 32) continue;                                                    // (wave-uniform: a tile beyond the padded width)
-      const bool cok = tv[j] && col < b.N;
-      const float bias1 = (cok && b.bias) ? mb_round(b.bias[col]) : 0.0f;
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int row = (4 * rq + i) * 16 + (lane >> 4) * 4 + e;
-          float y = 0.0f;
-          if (cok && row < B) {
-            const float v1 = mb_round(acc1[i][j][e] + bias1);
-            y = v1 > 0.0f ? v1 : v1 * b.slope;
-            if (drop1) y = mb_uniform(b.seed, call1, (uint64_t)row * (uint64_t)b.N + (uint64_t)col) >= b.p_drop ? y * keep1 : 0.0f;
-          }
-          s_h[mb_toff(row, col, KS2)] = mb_f2bf(y);
-        }
-    }
-    __syncthreads();
-    // h and h^T to global memory for the backward pass (what the fc1 launch wrote): the tiled image is s_h itself, copied out by the
-    // workgroups between them; the transposed copy per column tile by workgroup = tile
-    {
-      const int nchunk = 8 * KS2 * 64;                                                  // 16-byte chunks of the image
-      const int per = (nchunk + nstrips - 1) / nstrips, c0 = (int)blockIdx.x * per;
-      for (int cidx = c0 + tid; cidx < c0 + per && cidx < nchunk; cidx += MB_THREADS)
-        *(uint4*)((uint16_t*)in_slot(b.Y) + (long)cidx * 8) = *(const uint4*)(s_h + (long)cidx * 8);
-      if ((int)blockIdx.x < NT1 && b.Yt && tid < 2 * MB_ROWS) {
-        const int c2 = tid & 15, gq = tid >> 4, hc = 16 * (int)blockIdx.x + c2;
-        uint16_t t8[8];
-#pragma unroll
-        for (int jj = 0; jj < 8; ++jj) t8[jj] = s_h[mb_toff(8 * gq + jj, hc, KS2)];
-        *(uint4*)((uint16_t*)in_slot(b.Yt) + mb_toff(hc, 8 * gq, MB_ROWS / 32)) = *(const uint4*)t8;
-      }
-    }
-  }
 
   // ---- product ----
   {
@@ -457,21 +342,7 @@ __global__ __launch_bounds__(MB_THREADS) void mlp_strip_kernel(const ops_mlp_str
 #if defined(MB_EXP) && MB_EXP == 1
     const mb_f32x4 acc = {(float)(ap - bp), (float)KS, 0.0f, 0.0f};
 #else
-    mb_f32x4 acc;
-    if constexpr (FUSED1) {                 // A fragments from the hidden tile in LDS, B fragments of this strip from L2 (KS <= 8: all in flight)
-      acc = mb_f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-      uint4 fbw[8];
-#pragma unroll
-      for (int s = 0; s < 8; ++s) fbw[s] = *(const uint4*)(bp + (s < KS ? s : KS - 1) * 512);
-#pragma unroll
-      for (int s = 0; s < 8; ++s)
-        if (s < KS) {
-          const uint4 fah = *(const uint4*)(s_h + ((long)(wave * KS + s) * 512 + lane * 8));
-          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mb_bf16x8, fah), __builtin_bit_cast(mb_bf16x8, fbw[s]), acc, 0, 0, 0);
-        }
-    } else {
-      acc = mb_tile_product(ap, bp, KS);
-    }
+    const mb_f32x4 acc = mb_tile_product(ap, bp, KS);
 #endif
     // C layout: column lane & 15, rows 4 (lane >> 4) + i
 #pragma unroll
@@ -484,12 +355,6 @@ __global__ __launch_bounds__(MB_THREADS) void mlp_strip_kernel(const ops_mlp_str
 #pragma unroll
   for (int rep = 0; rep < 3; ++rep)
     if (chv[rep]) *(uint4*)&s_stage[(tid + MB_THREADS * rep) >> 4][8 * (tid & 15)] = ch[rep];
-  uint16_t* const s_bnd = s_dyn + (size_t)8 * (FUSED1 ? (b.ldy >> 5) : 0) * 512;      // [boundary][4 columns][128 rows]
-  if constexpr (FUSED1) {
-#pragma unroll
-    for (int rep = 0; rep < 3; ++rep)
-      if (bchv[rep]) *(uint4*)(s_bnd + (size_t)((tid + MB_THREADS * rep) >> 4) * MB_ROWS + 8 * (tid & 15)) = bch[rep];
-  }
   if (fin) {
 #pragma unroll
     for (int k = 0; k < 5; ++k) lp[k] = mb_wsum_d(lp[k]);
@@ -506,24 +371,6 @@ __global__ __launch_bounds__(MB_THREADS) void mlp_strip_kernel(const ops_mlp_str
     }
   }
   __syncthreads();
-  if constexpr (FUSED1) {
-    // strip-boundary cross terms of the stencil statistics: boundary i = columns 16 i + 14 .. 16 i + 17 (slots 0 .. 3); thread = (boundary,
-    // 8 rows): sum o15 o16 (adjacent), sum o14 o16 + o15 o17 (next to adjacent); columns >= No were parked as 0
-    float pb[2] = {0.0f, 0.0f};
-    if (tid < 16 * (nstrips - 1)) {
-      const uint16_t* q0 = s_bnd + (size_t)(tid >> 4) * MB_BND_COLS * MB_ROWS + 8 * (tid & 15);
-#pragma unroll
-      for (int r = 0; r < 8; ++r) {
-        const float o14 = mb_bf2f(q0[r]), o15 = mb_bf2f(q0[MB_ROWS + r]), o16 = mb_bf2f(q0[2 * MB_ROWS + r]), o17 = mb_bf2f(q0[3 * MB_ROWS + r]);
-        pb[0] = __builtin_fmaf(o15, o16, pb[0]);
-        pb[1] = __builtin_fmaf(o14, o16, __builtin_fmaf(o15, o17, pb[1]));
-      }
-    }
-    double pbt[2];
-    mb_block_sum_f<2>(pb, pbt, s_red);
-    if (tid == 0) { s_tot[12] = pbt[0]; s_tot[13] = pbt[1]; }
-    __syncthreads();
-  }
 
   // ---- epilogue ----
   float v[4];
@@ -539,18 +386,7 @@ __global__ __launch_bounds__(MB_THREADS) void mlp_strip_kernel(const ops_mlp_str
     for (int i = 0; i < 4; ++i) v[i] = rl[i] ? mb_round(v[i] + bias_b) : 0.0f;       // the Linear's bf16 output
     if (a.add_mode == OPS_MLP_ADD_FWD_BLOCK) {
       // whole-tensor statistics of conv1(O) from the previous launch's partial sums
-      double sum1 = s_tot[0], sum2 = s_tot[1];
-      if constexpr (FUSED1) {
-        // ... from the sufficient statistics of O: T = sum o, Q = sum o^2, P1 = sum o_c o_(c+1), P2 = sum o_c o_(c+2), first / last column
-        // (F1, Fq, L1, Lq); conv = w0 o_(c-1) + w1 o_c + w2 o_(c+1) + cb with zero padding at both ends
-        const double T = s_tot[0], Q = s_tot[1], P1 = s_tot[2] + s_tot[12], P2 = s_tot[3] + s_tot[13];
-        const double F1 = s_tot[4], Fq = s_tot[5], L1 = s_tot[6], Lq = s_tot[7];
-        const double w0 = sc_w0, w1 = sc_w1, w2 = sc_w2, cb = sc_b, nn = (double)B * (double)No;
-        const double lin = w0 * (T - L1) + w1 * T + w2 * (T - F1);
-        sum1 = lin + cb * nn;
-        sum2 = w0 * w0 * (Q - Lq) + w1 * w1 * Q + w2 * w2 * (Q - Fq) + 2.0 * (w0 * w1 + w1 * w2) * P1 + 2.0 * w0 * w2 * P2 + 2.0 * cb * lin + cb * cb * nn;
-      }
-      const double n = (double)B * (double)No, m = sum1 / n, var = fmax(sum2 / n - m * m, 0.0);
+      const double n = (double)B * (double)No, m = s_tot[0] / n, var = fmax(s_tot[1] / n - m * m, 0.0);
       const float mean_s = a.eval_stats ? a.srunning_mean[0] : (float)m;
       const float inv_s = a.eval_stats ? (float)(1.0 / sqrt((double)a.srunning_var[0] + (double)a.seps)) : (float)(1.0 / sqrt(var + (double)a.seps));
       if (blockIdx.x == 0 && tid == 0 && !a.eval_stats) {
@@ -733,24 +569,6 @@ __global__ __launch_bounds__(MB_THREADS) void mlp_strip_kernel(const ops_mlp_str
 #pragma unroll
   for (int i = 0; i < 4; ++i) s_y[q + 32 * i][cl] = rl[i] ? mb_f2bf(v[i]) : (uint16_t)0;
   __syncthreads();
-  if (a.stat_part) {
-    // this launch's output is the input O of a fused residual block: per-strip sufficient statistics of the stencil's whole-tensor
-    // normalisation (dead rows and columns hold 0).  0 T  1 Q  2 P1  3 P2 (pairs inside the strip)  4 / 5 first column  6 / 7 last column
-    float st[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int r = q + 32 * i;
-      const float x0 = mb_bf2f(s_y[r][cl]), x1 = cl + 1 < MB_COLS ? mb_bf2f(s_y[r][cl + 1]) : 0.0f, x2 = cl + 2 < MB_COLS ? mb_bf2f(s_y[r][cl + 2]) : 0.0f;
-      st[0] += x0; st[1] = __builtin_fmaf(x0, x0, st[1]); st[2] = __builtin_fmaf(x0, x1, st[2]); st[3] = __builtin_fmaf(x0, x2, st[3]);
-      if (c == 0) { st[4] += x0; st[5] = __builtin_fmaf(x0, x0, st[5]); }
-      if (c == N - 1) { st[6] += x0; st[7] = __builtin_fmaf(x0, x0, st[7]); }
-    }
-    double std_[8];
-    mb_block_sum_f<8>(st, std_, s_red);
-    if (tid == 0)
-#pragma unroll
-      for (int k = 0; k < 8; ++k) a.stat_part[blockIdx.x * 8 + k] = std_[k];
-  }
   if (tid < 2 * MB_ROWS) {
     const int r = tid >> 1, h = tid & 1;
     *(uint4*)((uint16_t*)sY + mb_toff(r, n0 + 8 * h, a.ldy >> 5)) = *(const uint4*)&s_y[r][8 * h];
@@ -772,9 +590,6 @@ __global__ __launch_bounds__(MB_THREADS) void mlp_strip_kernel(const ops_mlp_str
   // counter and do not report (call_counter.hpp)
   if (fwd && a.p_drop > 0.0f && (a.tail == OPS_MLP_TAIL_ACT_DROP || a.tail == OPS_MLP_TAIL_BN_ACT_DROP))
     call_counter_done(a.call_counter, (unsigned)nstrips * gridDim.y);
-  if constexpr (FUSED1) {
-    if (b.p_drop > 0.0f) call_counter_done(b.call_counter, (unsigned)nstrips * gridDim.y);        // the absorbed fc1 launch's dropout stream
-  }
 
   if (a.tail == OPS_MLP_TAIL_LOSS) {
     // loss value: per-strip partial sums; workgroup 0 of the NEXT launch (loss_finish_rows) adds them -- no atomics, no fence here
@@ -1041,49 +856,9 @@ extern "C" int ops_mlp_strip_launch(const ops_mlp_strip_args* args, void* stream
     if (a.slot_stride < 0 || a.slot_stride % 16 || a.slot_total_rows <= a.B * (a.n_slots - 1) || a.slot_total_rows > a.B * a.n_slots)
       return OPS_AMD_ERR_INVALID_ARG;
   }
-  if (a.stat_part && (bwd || a.n_slots > 0 || a.tail == OPS_MLP_TAIL_LOSS)) return OPS_AMD_ERR_INVALID_ARG;
   const dim3 grid((unsigned)(nstrips + nside), (unsigned)(a.n_slots > 0 ? a.n_slots : 1)), block(MB_THREADS);
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(mlp_strip_kernel<false>, grid, block, 0, s, a, nstrips, ops_mlp_strip_args{});
-  const hipError_t e = hipGetLastError();
-  if (e != hipSuccess) { set_last_error(hipGetErrorString(e)); return OPS_AMD_ERR_LAUNCH; }
-  return OPS_AMD_OK;
-}
-
-// r05: fc1 (TAIL_ACT_DROP) and fc2 (+ ADD_FWD_BLOCK + TAIL_BN) of one residual block as ONE launch (mlp_strip_kernel<true>).  `fc1` / `fc2`
-// are the argument blocks the two launches would take (fc2->A == fc1->Y, fc2->Ot = the transposed copy of fc1->A); fc1->side and
-// fc2->spart's producer change: the launch that produced the block input must have left its per-strip statistics in fc2->spart (its
-// stat_part).  Training passes only.
-extern "C" int ops_mlp_block_fwd_launch(const ops_mlp_strip_args* fc1, const ops_mlp_strip_args* fc2, void* stream) {
-  if (!fc1 || !fc2) return OPS_AMD_ERR_INVALID_ARG;
-  const ops_mlp_strip_args& b = *fc1;
-  const ops_mlp_strip_args& a = *fc2;
-  if (a.B < 2 || a.B > MB_ROWS || b.B != a.B || a.N < 1 || b.N < 1 || b.N > 192 || a.K != b.N || b.K < 1 || b.K > 512) return OPS_AMD_ERR_UNSUPPORTED;
-  if (!a.A || !a.W || !a.Y || !a.Yt || !b.A || !b.W || !b.Y || a.A != b.Y || a.lda != b.ldy) return OPS_AMD_ERR_INVALID_ARG;
-  if (a.lda % 32 || a.ldw % 32 || a.ldy % 32 || b.lda % 32 || b.ldw % 32 || b.ldy % 32 || a.lda < ru(a.K, 32) || a.ldw < ru(a.K, 32) ||
-      a.ldy < ru(a.N, 32) || b.lda < ru(b.K, 32) || b.ldw < ru(b.K, 32) || b.ldy > 256)
-    return OPS_AMD_ERR_INVALID_ARG;
-  if (((uintptr_t)a.A | (uintptr_t)a.W | (uintptr_t)a.Y | (uintptr_t)b.A | (uintptr_t)b.W | (uintptr_t)b.Yt) & 15) return OPS_AMD_ERR_INVALID_ARG;
-  if (a.tail != OPS_MLP_TAIL_BN || a.add_mode != OPS_MLP_ADD_FWD_BLOCK || b.tail != OPS_MLP_TAIL_ACT_DROP || b.add_mode != OPS_MLP_ADD_NONE)
-    return OPS_AMD_ERR_INVALID_ARG;
-  if (a.eval_stats || b.eval_stats || a.n_slots || b.n_slots || a.loss_finish_rows || b.loss_finish_rows) return OPS_AMD_ERR_UNSUPPORTED;
-  if (!a.gamma || !a.beta || !a.mean || !a.rstd || !a.Zt || !a.Ot || a.No != a.N || b.K != a.No || !a.conv_w || !a.conv_b || !a.sgamma || !a.sbeta ||
-      !a.ssave || !a.spart || !a.srunning_mean || !a.srunning_var)
-    return OPS_AMD_ERR_INVALID_ARG;
-  if (b.p_drop > 0.0f && (!b.call_counter || b.p_drop >= 1.0f)) return OPS_AMD_ERR_INVALID_ARG;
-  const int nstrips = (a.N + MB_COLS - 1) / MB_COLS;
-  if (nstrips > 64 || nstrips < 2 || 64 * (nstrips - 1) > 3 * MB_THREADS) return OPS_AMD_ERR_UNSUPPORTED;       // (strip = lane of the statistics; boundary chunks: three per thread)
-  const size_t dyn = ((size_t)8 * (b.ldy >> 5) * 512 + (size_t)(nstrips - 1) * MB_BND_COLS * MB_ROWS) * sizeof(uint16_t);
-  static std::atomic<unsigned long long> attr_done{0};
-  int devid = 0;
-  if (hipGetDevice(&devid) != hipSuccess) return OPS_AMD_ERR_LAUNCH;
-  const unsigned long long bit = 1ull << (devid & 63);
-  if (!(attr_done.load(std::memory_order_acquire) & bit)) {
-    if (hipFuncSetAttribute((const void*)mlp_strip_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 112 * 1024) != hipSuccess) return OPS_AMD_ERR_LAUNCH;
-    attr_done.fetch_or(bit, std::memory_order_release);
-  }
-  if (dyn > 112 * 1024) return OPS_AMD_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(mlp_strip_kernel<true>, dim3((unsigned)nstrips), dim3(MB_THREADS), dyn, (hipStream_t)stream, a, nstrips, b);
+  hipLaunchKernelGGL(mlp_strip_kernel, grid, block, 0, s, a, nstrips);
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) { set_last_error(hipGetErrorString(e)); return OPS_AMD_ERR_LAUNCH; }
   return OPS_AMD_OK;

@@ -25,7 +25,6 @@ from . import _cabi
 from .surrogates import CompositeLoss, FNNWithResidual, ResidualBlock
 
 ENABLED = os.environ.get("OPS_AMD_PINN_LAYER_BLOCKS", "1") == "1"      # A/B switch: 0 = autograd over the fused tails
-BLOCK_MERGE = os.environ.get("OPS_AMD_PINN_BLOCK_MERGE", "1") == "1"   # A/B switch: 0 = fc1 and fc2 of a residual block as two launches (r04)
 
 
 def _ru(v: int, m: int) -> int:
@@ -230,23 +229,6 @@ class PinnFusedStep:
                                    ldw=w1t.shape[1], Y=self.dz[k][0], ldy=self.dz[k][0].shape[1], Yt=self.dz[k][1], Ot=o_in_t, dZt=dzk_t,
                                    spart=self.spart_b[k], sdparams=rb.conv1.weight.grad, **tail, **self._stencil(rb, k)))
         self._fwd, self._bwd = fwd, bwd
-        # r05: training forward with every block's (fc1, fc2) pair as ONE launch (ops_mlp_block_fwd_launch).  The launch that produces a
-        # block's input leaves the stencil's per-strip statistics in that block's `spart` (stat_part); fc1 loses its side job.
-        self._fwd_merged = None
-        if BLOCK_MERGE and Hh <= 192 and H <= 512 and (H + 15) // 16 >= 2 and 64 * ((H + 15) // 16 - 1) <= 3 * 512:
-            def clone(a, **kw):
-                e = _cabi.MlpStripArgs()
-                ctypes.memmove(ctypes.addressof(e), ctypes.addressof(a), ctypes.sizeof(_cabi.MlpStripArgs))
-                for k_, v_ in kw.items():
-                    setattr(e, k_, v_.data_ptr() if torch.is_tensor(v_) else v_)
-                return e
-            seq = [("strip", clone(fwd[0], stat_part=self.spart_f[0]))]
-            for k in range(self.nblk):
-                f1 = clone(fwd[1 + 2 * k], side=C.MLP_SIDE_NONE)
-                f2 = clone(fwd[2 + 2 * k], **({"stat_part": self.spart_f[k + 1]} if k + 1 < self.nblk else {}))
-                seq.append(("block", f1, f2))
-            seq.append(("strip", clone(fwd[-1])))
-            self._fwd_merged = seq
         # evaluation pass (model.eval(): running statistics, no dropout, no stencil statistics) = the forward stages with eval_stats,
         # its loss partial sums in a workspace of their own, and ONE more (dummy, one-strip) launch that adds them up
         ev = []
@@ -379,15 +361,6 @@ class PinnFusedStep:
 
     def forward(self, B: int, stream=None) -> None:
         s = stream if stream is not None else torch.cuda.current_stream(self.dev).cuda_stream
-        if self._fwd_merged is not None and B >= 2:
-            for item in self._fwd_merged:
-                if item[0] == "strip":
-                    item[1].B = B
-                    self._check(self.lib.ops_mlp_strip_launch(ctypes.byref(item[1]), s), "ops_mlp_strip_launch (forward)")
-                else:
-                    item[1].B = item[2].B = B
-                    self._check(self.lib.ops_mlp_block_fwd_launch(ctypes.byref(item[1]), ctypes.byref(item[2]), s), "ops_mlp_block_fwd_launch")
-            return
         for a in self._fwd:
             a.B = B
             self._check(self.lib.ops_mlp_strip_launch(ctypes.byref(a), s), "ops_mlp_strip_launch (forward)")
