@@ -246,3 +246,50 @@ def test_runtime_helpers_on_the_cpu(monkeypatch):
         assert 1 <= runtime.fit_cpu_threads() <= max(1, n)
     finally:
         torch.set_num_threads(old)
+
+
+def test_frame_equation_numbering_candidates_on_the_host():
+    """frames.FrameTopology(numbering=...): every numbering is a permutation of the free DOFs that keeps a node's DOFs together; "auto"
+    takes the narrowest of node order / reverse Cuthill-McKee / the two coordinate sweeps (node order on a tie) -- the reference asks
+    OpenSees for numberer('RCM') (FR:135).  No GPU involved: the kernels take whatever elem_eq / node_eq they are given."""
+    from openpystruct_amd import frames
+    for bays, stories, kd_node, kd_auto in [(10, 10, 35, 32), (15, 16, 50, 50), (10, 2, 35, 8), (21, 3, 68, 11), (3, 10, 14, 14), (1, 1, 5, 5)]:
+        auto = frames.grid_frame(bays, stories, device="cpu")
+        node = frames.grid_frame(bays, stories, device="cpu", numbering="node")
+        rcm = frames.grid_frame(bays, stories, device="cpu", numbering="rcm")
+        assert (node.kd, auto.kd) == (kd_node, kd_auto) and rcm.kd <= kd_node + 3 and node.numbering == "node"
+        assert (auto.numbering == "node") == (kd_auto == kd_node)
+        for t in (auto, node, rcm):
+            eq = t.d_node_eq.numpy()
+            free = eq[eq >= 0]
+            assert sorted(free.tolist()) == list(range(t.n_eq)) and t.n_eq == 3 * (bays + 1) * stories
+            assert (eq[t.fix3] == -1).all()
+            live = eq[(eq >= 0).all(axis=1)]
+            assert (np.diff(live, axis=1) == 1).all()                     # a node's three equations are consecutive
+            span = max(int(q[q >= 0].max() - q[q >= 0].min()) for q in t.d_elem_eq.numpy() if (q >= 0).any())
+            assert span == t.kd
+    # a frame in two disconnected pieces + a fully fixed node: every free node is numbered exactly once
+    coords = np.array([(0, 0), (0, 3), (6, 3), (20, 0), (20, 3), (26, 3), (40, 0)], dtype=float)
+    conn = np.array([(0, 1), (1, 2), (3, 4), (4, 5)])
+    fix3 = np.zeros((7, 3), dtype=bool); fix3[0] = fix3[3] = fix3[6] = True
+    order = frames.rcm_node_order(7, conn, ~fix3.all(axis=1))
+    assert sorted(order.tolist()) == list(range(7)) and set(order[-3:].tolist()) == {0, 3, 6}
+    with pytest.raises(ValueError):
+        frames.grid_frame(2, 2, device="cpu", numbering="minimum-degree")
+
+
+def test_marginal_stop_decisions_helper():
+    """tests/helpers.py: the rule that replaced "+- 3 epochs" -- a stop may move by up to `patience` epochs only where the reference's own
+    loss history holds a decision within float32 round-off of its threshold."""
+    from tests.helpers import assert_stop_epochs_agree, marginal_stop_decisions
+    tol = 5e-3
+    clear = [10.0 - 0.1 * k for k in range(30)] + [7.1] * 6            # every decision far from the threshold
+    assert marginal_stop_decisions(clear, tol) == []
+    assert assert_stop_epochs_agree(36, 36, clear, tol, 5) is True
+    with pytest.raises(AssertionError):
+        assert_stop_epochs_agree(34, 36, clear, tol, 5)                 # two epochs off without a marginal decision: a real difference
+    hug = [100.0, 99.0, 99.0 - tol - 1e-5, 98.9, 98.9, 98.9, 98.9, 98.9]   # epoch 3 improves on 99.0 by tol + 1e-5: inside 2e-6 * |loss|
+    assert marginal_stop_decisions(hug, tol) == [3]
+    assert assert_stop_epochs_agree(6, 8, hug, tol, 5) is False          # allowed: within patience of a run with a marginal decision
+    with pytest.raises(AssertionError):
+        assert_stop_epochs_agree(1, 8, hug, tol, 5)                     # ... but not further than `patience`
