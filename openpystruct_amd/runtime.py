@@ -73,10 +73,18 @@ def hip_runtime_version() -> str:
     try:
         if torch.cuda.is_available():
             import ctypes
-            rt = ctypes.CDLL("libamdhip64.so")
-            n = ctypes.c_int(0)
-            if rt.hipRuntimeGetVersion(ctypes.byref(n)) == 0:
-                v += f" (hipRuntimeGetVersion {n.value})"
+            # the runtime THIS process has loaded (the framework's bundled copy), by the path it is mapped from: opening
+            # "libamdhip64.so" by name could pull a second HIP runtime (the system's) into the process
+            path = None
+            for line in open("/proc/self/maps"):
+                if "libamdhip64" in line:
+                    path = line.split()[-1]
+                    break
+            if path:
+                rt = ctypes.CDLL(path)
+                n = ctypes.c_int(0)
+                if rt.hipRuntimeGetVersion(ctypes.byref(n)) == 0:
+                    v += f" (hipRuntimeGetVersion {n.value})"
     except Exception:
         pass
     return v

@@ -275,8 +275,12 @@ def cases_from_lists(node_positions, roller_nodes, force_nodes, force_values, de
     if xs.dim() == 1:
         xs = xs.expand(B, -1).contiguous()
     N = int(xs.shape[1])
-    if not isinstance(roller_nodes[0], (list, tuple, np.ndarray)):
-        roller_nodes = [list(roller_nodes)] * B
+    if B == 0:
+        raise ValueError("no cases given")
+    if len(roller_nodes) == 0 or not isinstance(roller_nodes[0], (list, tuple, np.ndarray)):
+        roller_nodes = [list(roller_nodes)] * B          # one support list shared by every case (possibly empty: a cantilever-free beam is singular, the solve reports it)
+    if len(roller_nodes) != B or len(force_values) != B:
+        raise ValueError("roller_nodes / force_nodes / force_values must have one entry per case")
     R = max(1, max(len(r) for r in roller_nodes))
     F = max(1, max(len(f) for f in force_nodes))
     rn, fn, fv = np.zeros((B, R), dtype=np.int64), np.zeros((B, F), dtype=np.int64), np.zeros((B, F))
