@@ -570,6 +570,11 @@ static bool fused_assembly() { const char* e = getenv("OPS_AMD_FRAME_FUSED_ASM")
 // r04, measured alternative (frame_tile.hpp; fused assembly only): the window as an 8 x 8 lane grid of register tiles, OPS_AMD_FRAME_TILE=1.
 // Correct (same factor columns as the row-per-lane window up to the last bit of a few assembled entries) but slower on every size measured
 // (15 x 16: 4.2 - 5.2 ms against 3.7 - 3.9 per 12 288 frames; profiles/r04_notes.md 11), so the row-per-lane window stays the default.
+// r05, measured alternative: two columns per elimination step (frame_wave.hpp fw_step2; fused assembly, kd <= 54).  OPS_AMD_FRAME_PAIR=1.
+static bool use_pair_steps(int kd) {
+  const char* e = getenv("OPS_AMD_FRAME_PAIR");
+  return fused_assembly() && kd <= 54 && e && atoi(e) != 0;
+}
 static bool use_tile_kernel() {
   const char* e = getenv("OPS_AMD_FRAME_TILE");
   return fused_assembly() && e && atoi(e) != 0;
@@ -600,6 +605,7 @@ static hipError_t launch_wave(const FrameParams& p, double* ws, hipStream_t s) {
   if (!(done.load(std::memory_order_acquire) & bit)) {
     e = hipFuncSetAttribute((const void*)frame_wave_kernel<W, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)frame_wave_kernel<W, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)frame_wave_kernel<W, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)frame_tile_kernel<W>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
     if (e != hipSuccess) return e;
     done.fetch_or(bit, std::memory_order_release);
@@ -612,7 +618,8 @@ static hipError_t launch_wave(const FrameParams& p, double* ws, hipStream_t s) {
     hipLaunchKernelGGL((frame_tile_kernel<W>), grid, dim3(256), 4 * ft_lds_doubles(p.n_eq) * sizeof(double), s, p, ws, pl);
   } else if (fused_assembly()) {
     hipLaunchKernelGGL(frame_plan_kernel, dim3(1), dim3(1024), (size_t)3 * (fw_groups(p.n_eq) + 2) * sizeof(int), s, p, W, plan_base, 0);
-    hipLaunchKernelGGL((frame_wave_kernel<W, true>), grid, dim3(256), lds, s, p, ws, pl);
+    if (use_pair_steps(p.kd)) hipLaunchKernelGGL((frame_wave_kernel<W, true, true>), grid, dim3(256), lds, s, p, ws, pl);
+    else hipLaunchKernelGGL((frame_wave_kernel<W, true>), grid, dim3(256), lds, s, p, ws, pl);
   } else {
     const size_t lds_asm = ((size_t)FW_SLAB * W + (size_t)p.n_eq) * sizeof(double);
     hipLaunchKernelGGL(frame_assemble_rows_kernel, dim3((unsigned)p.B), dim3(256), lds_asm, s, p, ws, W);

@@ -46,7 +46,8 @@ __host__ __device__ inline int fw_width(int kd) {           // compiled register
 __host__ __device__ inline int fw_rows(int n) { return n + 64 + 2 * FW_G; }      // allocated rows: unguarded group prefetch
 __host__ __device__ inline size_t fw_frame_doubles(int n, int kd) { return (size_t)fw_rows(n) * (fw_width(kd) + 1); }
 constexpr int FW_CB = 72;   // broadcast line: entry `rel` at index rel (pairs (t, t + 1), t even, are 16-byte aligned), two buffers
-__host__ __device__ inline size_t fw_lds_doubles(int n, int W) { return ((2 * FW_CB + (size_t)FW_G * fw_pitch(W) + (size_t)(n + 64)) + 1) & ~(size_t)1; }
+// (4 FW_CB: two broadcast lines of PAIRS, the two-columns-per-step form of r05; the one-column form uses the first half)
+__host__ __device__ inline size_t fw_lds_doubles(int n, int W) { return ((4 * FW_CB + (size_t)FW_G * fw_pitch(W) + (size_t)(n + 64)) + 1) & ~(size_t)1; }
 
 __device__ __forceinline__ double fw_readlane(double v, int lane) {
   const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane), hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
@@ -313,6 +314,70 @@ __device__ __forceinline__ void fw_step(FwState<W>& st, int j, int lane, int n, 
   for (int c = 0; c < W; ++c) __asm__ volatile("" : "+v"(st.reg[c]));
 }
 
+// ---- r05: TWO columns per step.  Same arithmetic, operation for operation, as two one-column steps (the factor and the solution are
+// the same bits): what changes is that the two columns share ONE broadcast line -- entry `rel` = (A[j + rel][j], A'[j + rel][j + 1]), the
+// second already updated by column j, which every lane can do for its own row without the line (its multiplier times A[j + 1][j], one
+// readlane) -- so a pair of columns costs one LDS round trip, one fence, one set of window masks and one boundary test instead of two.
+// Column j + 1's window reaches one row further (rel <= kd + 1): rows enter one boundary earlier where kd + 1 is a multiple of eight
+// (KG from kd + 1), which the lane budget allows for kd <= 54.
+template <int W, int S>
+__device__ __forceinline__ void fw_prepare2(FwState<W>& st, int j, int lane, int n, int kd, double2* __restrict__ colbuf2, double& rd1,
+                                            double& rd2, int& bad) {
+  const int rel = (lane - j) & 63, R = j + rel;
+  const bool in1 = rel >= 1 && rel <= kd && R < n, in2 = rel >= 2 && rel <= kd + 1 && R < n;
+  const double a = st.reg[S];
+  const double d1 = fw_readlane(a, j & 63);
+  rd1 = frcp(d1);
+  bad |= (j < n) & !(d1 > 0.0);
+  const double l1 = in1 ? a * rd1 : 0.0;
+  const double a1 = fw_readlane(a, (j + 1) & 63);
+  st.reg[(S + 1) % W] = __builtin_fma(-l1, a1, st.reg[(S + 1) % W]);        // column j + 1 is final now
+  const double b = st.reg[(S + 1) % W];
+  const double d2 = fw_readlane(b, (j + 1) & 63);
+  rd2 = frcp(d2);
+  bad |= (j + 1 < n) & !(d2 > 0.0);
+  colbuf2[((j >> 1) & 1) * FW_CB + rel] = double2{in1 ? a : 0.0, in2 ? b : 0.0};
+}
+
+// one PAIR of factorisation steps (columns j, j + 1; S = j mod W, even); rd1 / rd2 = 1 / d_j, 1 / d_(j+1) on entry, those of the next pair
+// on return
+template <int W, int S>
+__device__ __forceinline__ void fw_step2(FwState<W>& st, int j, int lane, int n, int kd, double2* __restrict__ colbuf2,
+                                         double* __restrict__ Lc, double* __restrict__ xs, double& rd1, double& rd2, int& bad) {
+  const int rel = (lane - j) & 63, R = j + rel;
+  const bool in1 = rel >= 1 && rel <= kd && R < n, in2 = rel >= 2 && rel <= kd + 1 && R < n;
+  const double a = st.reg[S], b = st.reg[(S + 1) % W], r1 = rd1, r2 = rd2;
+  const double l1 = in1 ? a * r1 : 0.0, l2 = in2 ? b * r2 : 0.0;
+  const double z0 = fw_readlane(st.y, j & 63);
+  const double y1 = __builtin_fma(-l1, z0, st.y);
+  const double z1 = fw_readlane(y1, (j + 1) & 63);
+  st.y = __builtin_fma(-l2, z1, y1);
+  // columns j + 2 and j + 3 first, their multiplicands through readlanes (masked exactly as the line would have masked them): the next
+  // pair's line and reciprocals start here
+  const bool m2 = 2 <= kd && j + 2 < n, m3 = 3 <= kd && j + 3 < n, m3b = 2 <= kd && j + 3 < n;
+  const double a2 = m2 ? fw_readlane(a, (j + 2) & 63) : 0.0, b2 = fw_readlane(b, (j + 2) & 63);
+  st.reg[(S + 2) % W] = __builtin_fma(-l2, b2, __builtin_fma(-l1, a2, st.reg[(S + 2) % W]));
+  const double a3 = m3 ? fw_readlane(a, (j + 3) & 63) : 0.0, b3 = m3b ? fw_readlane(b, (j + 3) & 63) : 0.0;
+  st.reg[(S + 3) % W] = __builtin_fma(-l2, b3, __builtin_fma(-l1, a3, st.reg[(S + 3) % W]));
+  fw_fence();                                                         // the pair line of (j, j + 1), written one pair ago, has landed
+  fw_prepare2<W, (S + 2) % W>(st, j + 2, lane, n, kd, colbuf2, rd1, rd2, bad);
+  const double2* cb = colbuf2 + ((j >> 1) & 1) * FW_CB;
+#ifndef FW_SKIP_LSTORE
+  if (in1) Lc[(size_t)j * W + (rel - 1)] = l1;
+  if (in2) Lc[(size_t)(j + 1) * W + (rel - 2)] = l2;
+#endif
+  if (rel == 0) xs[j] = z0 * r1;
+  if (rel == 1) xs[j + 1] = z1 * r2;
+#pragma unroll
+  for (int t = 4; t < W; ++t) {
+    const double2 ab = cb[t];
+    st.reg[(S + t) % W] = __builtin_fma(-l2, ab.y, __builtin_fma(-l1, ab.x, st.reg[(S + t) % W]));
+  }
+  st.reg[S] = __builtin_fma(-l2, cb[W].y, st.reg[S]);                 // column j + W (this slot's next tenant): only column j + 1 reaches it
+#pragma unroll
+  for (int c = 0; c < W; ++c) __asm__ volatile("" : "+v"(st.reg[c]));
+}
+
 // move one staged group (rows g0 .. g0 + G - 1: parked in `stage`) into the registers of the lanes that own them
 template <int W>
 __device__ __forceinline__ void fw_take_group(FwState<W>& st, int g0, int lane, const double* __restrict__ stage) {
@@ -391,14 +456,17 @@ __device__ __forceinline__ void fw_backward(const double* __restrict__ rows, dou
   }
 }
 
-template <int W, bool FUSED>
+template <int W, bool FUSED, bool PAIR>
 __device__ __forceinline__ void frame_wave_body(const FrameParams& p, double* __restrict__ wsf, double* __restrict__ lds, int lane, long b,
                                                 const FwPlan& pl) {
   constexpr int G = FW_G, K = (G * W + 63) / 64;
   const int n = p.n_eq, kd = p.kd;
-  const int KG = (kd / G + 1) * G;                          // > kd (column j + 1 is read during step j): registers hold the rows below j + KG + G at step j
-  double* colbuf = lds;                                     // [2][FW_CB]
-  double* stage = lds + 2 * FW_CB;                          // [G][fw_pitch(W)]: rows + right-hand sides of one group
+  // > kd (column j + 1 is read during step j): registers hold the rows below j + KG + G at step j.  PAIR: column j + 1's window (rel <= kd + 1)
+  // is read during the pair step of column j
+  const int KG = ((PAIR ? kd + 1 : kd) / G + 1) * G;
+  double* colbuf = lds;                                     // [2][FW_CB] (PAIR: [2][FW_CB] pairs)
+  double2* colbuf2 = reinterpret_cast<double2*>(lds);
+  double* stage = lds + 4 * FW_CB;                          // [G][fw_pitch(W)]: rows + right-hand sides of one group
   double* xs = stage + (size_t)G * fw_pitch(W);                 // [n + 64]: w, then x
   double* rows = wsf;                                       // [fw_rows(n)][W], overwritten column by column with L
   const double* rhs_g = wsf + (size_t)fw_rows(n) * W;       // (unfused path)
@@ -506,8 +574,9 @@ __device__ __forceinline__ void frame_wave_body(const FrameParams& p, double* __
   }
 
   // ---- factorisation + forward substitution ----
-  double rd = 0.0;
-  fw_prepare<W, 0>(st, 0, lane, n, kd, colbuf, rd, bad);
+  double rd = 0.0, rd2 = 0.0;
+  if constexpr (PAIR) fw_prepare2<W, 0>(st, 0, lane, n, kd, colbuf2, rd, rd2, bad);
+  else fw_prepare<W, 0>(st, 0, lane, n, kd, colbuf, rd, bad);
   for (int j0 = 0; j0 < n; j0 += W) {
     auto boundary = [&](int j) {                            // j % G == 0, j > 0: rows [j + KG, j + KG + G) enter
       if constexpr (FUSED) {
@@ -533,7 +602,8 @@ __device__ __forceinline__ void frame_wave_body(const FrameParams& p, double* __
     {                                                                                 \
       const int j = j0 + (S_);                                                        \
       if constexpr (!FW_NO_BOUNDARY && (S_) % 4 == 0) if (j > 0 && (j % G) == 0 && j < n) boundary(j); /* j0 % 4 == 0 */ \
-      fw_step<W, (S_)>(st, j, lane, n, kd, colbuf, rows, xs, rd, bad);                \
+      if constexpr (PAIR) { if constexpr ((S_) % 2 == 0) fw_step2<W, (S_)>(st, j, lane, n, kd, colbuf2, rows, xs, rd, rd2, bad); } \
+      else fw_step<W, (S_)>(st, j, lane, n, kd, colbuf, rows, xs, rd, bad);           \
     }
 #define FW_STEP4(S_)                                                                  \
     if constexpr ((S_) < W) {                                                         \
@@ -562,14 +632,14 @@ __device__ __forceinline__ void frame_wave_body(const FrameParams& p, double* __
 #endif
 constexpr int fw_waves(int W) { return W < 36 ? 1 : W == 36 ? FW_WAVES_36 : W <= 52 ? FW_WAVES_52 : 2; }   // measured: only the 52-wide window gains (170 -> 168 VGPRs: 3 waves)
 
-template <int W, bool FUSED>
+template <int W, bool FUSED, bool PAIR = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(fw_waves(W))))
 void frame_wave_kernel(const FrameParams p, double* __restrict__ ws, const FwPlan pl) {
   extern __shared__ double lds[];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const long b = (long)blockIdx.x * 4 + wave;
   if (b >= p.B) return;
-  frame_wave_body<W, FUSED>(p, ws + b * fw_frame_doubles(p.n_eq, p.kd), lds + (size_t)wave * fw_lds_doubles(p.n_eq, W), lane, b, pl);
+  frame_wave_body<W, FUSED, PAIR>(p, ws + b * fw_frame_doubles(p.n_eq, p.kd), lds + (size_t)wave * fw_lds_doubles(p.n_eq, W), lane, b, pl);
 }
 
 }  // namespace opsamd

@@ -559,3 +559,36 @@ def test_config5_at_the_batch_the_bench_quotes(bays, stories, B):
     topo._ws.clear()
     del qa, qb, sol
     torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("bays,stories", [(2, 3), (5, 5), (10, 10), (15, 16), (16, 3), (1, 1)])
+def test_two_columns_per_elimination_step_vs_oracle_and_default(monkeypatch, bays, stories):
+    """The measured alternative of r05 (frame_wave.hpp fw_step2, OPS_AMD_FRAME_PAIR=1): two columns share one broadcast line, one fence,
+    one set of window masks.  Operation for operation the arithmetic of two one-column steps: against the default kernel the results
+    agree to the last bits (exactly, up to the order of the assembly's LDS atomic additions), and against the oracle as the default does.
+    Not the default: no faster (profiles/r05_notes.md 12)."""
+    from openpystruct_amd import frames
+    topo = frames.grid_frame(bays, stories)
+    rng = np.random.default_rng(bays * 100 + stories)
+    B = 6
+    I = np.exp(rng.uniform(np.log(5e-5), np.log(5e-3), size=(B, topo.Ne)))
+    It = torch.as_tensor(I, device="cuda")
+    monkeypatch.setenv("OPS_AMD_FRAME_PAIR", "0")
+    ref = frames.frame_solve(topo, It)
+    torch.cuda.synchronize()
+    monkeypatch.setenv("OPS_AMD_FRAME_PAIR", "1")
+    sol = frames.frame_solve(topo, It)
+    torch.cuda.synchronize()
+    assert int(sol.status.abs().sum()) == 0
+    assert relerr(sol.disp.cpu().numpy().ravel(), ref.disp.cpu().numpy().ravel()) < 1e-12
+    assert relerr(sol.forces.cpu().numpy().ravel(), ref.forces.cpu().numpy().ravel()) < 1e-11
+    for b in range(2):
+        d, f, st, neq, kd = _oracle(topo, I[b])
+        assert relerr(sol.disp[b].cpu().numpy().ravel(), d.ravel()) < 1e-8
+        assert relerr(sol.forces[b].cpu().numpy().ravel(), f.ravel()) < 1e-7
+    Ib = It.clone()
+    Ib[2, 1] = -1.0                               # a non-positive pivot is reported for that frame only
+    bad = frames.frame_solve(topo, Ib)
+    torch.cuda.synchronize()
+    st = bad.status.cpu().numpy()
+    assert st[2] == 1 and st[[0, 1, 3, 4, 5]].sum() == 0
