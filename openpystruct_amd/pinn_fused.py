@@ -1,4 +1,4 @@
-"""The PINN's training step as 15 launches: host side of csrc/mlp_block.hip.
+"""The PINN's training step as 14 launches (r05; r02: 15, r04: 16 with the optimiser's three): host side of csrc/mlp_block.hip.
 
 `FNNWithResidual` (/root/reference/OpenPyStruct_PINN_MultiCase.py:454-541) + `CompositeLoss` (:603-653), forward AND backward,
 for batches of up to 128 rows, without autograd: every `Linear -> [stencil + residual] -> BatchNorm1d -> LeakyReLU -> dropout`
@@ -6,7 +6,8 @@ group is one launch, so is each backward counterpart, all weight gradients are o
 gradient is written straight into the training loop's flat gradient buffer.  The module itself stays the owner of the
 parameters and BatchNorm buffers (the launches read and update them in place); evaluation keeps using the module.
 
-    gather | input | (fc1, fc2+stencil+norm) x blocks | output+loss || d output | (d fc2, d fc1) x blocks | weight gradients | norm | Adam+repack
+    gather (+ the last update's weight copies, r05) | input | (fc1, fc2+stencil+norm) x blocks | output+loss || d output | (d fc2, d fc1) x blocks |
+    weight gradients (+ the clip norm's partial sums, r05) | Adam
 
 Layout contract (include/openpystruct_amd.h): every activation / gradient exists as X (rows = batch) and as Xt (rows =
 columns of X) in bfloat16, both FRAGMENT-TILED (1 KB tiles in MFMA lane order: `to_tiled` / `from_tiled`), zero outside the
