@@ -65,7 +65,9 @@ def test_generator_shards_neither_stall_nor_get_the_container_throttled():
     """r03: every third warm 50 000-case shard took 60-70 ms instead of 22 -- one graph launch frozen for the rest of a 100 ms scheduler
     period.  Cause: `torch.arange(50 000)` on the CPU per shard woke the framework's 128-thread pool, whose spinning workers used up
     the container's CPU quota (cgroup cpu.max) within the period.  With the default thread count still in force: twelve warm shards,
-    none slower than twice the median, and the cgroup's throttle counter does not move."""
+    the cgroup's throttle counter does not move, and the shard times show no such pattern: at most ONE of the twelve above twice the
+    median and none above four times (r05: on a busy node a single shard is occasionally 2-3 x slow -- 2 of 10 full-suite runs on one
+    box, never when the file runs alone -- while the r03 pathology made every third shard 3 x slow)."""
     from openpystruct_amd import runtime, sizing
     cfg = sizing.SizingConfig()
     sizing.generate_dataset(50000, cfg, "cuda")
@@ -80,6 +82,6 @@ def test_generator_shards_neither_stall_nor_get_the_container_throttled():
         ts.append(time.perf_counter() - t0)
     after = runtime.cpu_throttle_counters()
     med = sorted(ts)[len(ts) // 2]
-    assert max(ts) < 2.0 * med, ts
+    assert sorted(ts)[-2] < 2.0 * med and max(ts) < 4.0 * med, ts
     if before and after:
         assert after["nr_throttled"] == before["nr_throttled"], (before, after, ts)
