@@ -14,11 +14,22 @@ torch = pytest.importorskip("torch")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+_LAUNCHES = [0]
+
+
+def _free_port():
+    """A port the kernel hands out as free right now (bind to 0), so that two launches of one test process never share a rendezvous port."""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
 def _launch(args, env_extra, timeout=600):
     """`python -m torch.distributed.run --nproc-per-node 1 ...` as a CHILD process (never an exec from this GPU-initialised one)."""
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", **env_extra)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
-           "--master-port", str(29600 + os.getpid() % 300)] + args
+           "--master-port", str(_free_port())] + args
     p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
     assert p.returncode == 0, p.stdout[-3000:] + "\n" + p.stderr[-3000:]
     return p.stdout, p.stderr
