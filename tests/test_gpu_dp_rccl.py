@@ -14,9 +14,6 @@ torch = pytest.importorskip("torch")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-_LAUNCHES = [0]
-
-
 def _free_port():
     """A port the kernel hands out as free right now (bind to 0), so that two launches of one test process never share a rendezvous port."""
     import socket
