@@ -60,15 +60,20 @@ def test_oracle_equals_openseespy_on_reference_cases(seed):
 
 
 def test_singular_model_returns_a_code():
+    """A model whose stiffness matrix is NOT positive definite (a negative inertia: the band Cholesky of `BandSPD` meets a negative
+    pivot whatever the rounding).  r05: the first version of this test left out every vertical support instead -- a rigid-body mode is
+    only semi-definite, and a Cholesky factorisation in floating point may well run through on a pivot of 1e-10 (the recorder run of
+    tests/test_sizing_golden.py showed exactly that), so the test could have failed against the real OpenSees for the wrong reason."""
     x = np.linspace(0.0, 10.0, 11)
     ops.wipe()
     ops.model('basic', '-ndm', 2, '-ndf', 3)
     for i, xi in enumerate(x):
         ops.node(i + 1, float(xi), 0.0)
-    ops.fix(1, 1, 0, 0)                                   # no vertical support at all: rigid-body mode
+    ops.fix(1, 1, 1, 0)
+    ops.fix(11, 0, 1, 0)
     ops.geomTransf('Linear', 1)
     for e in range(10):
-        ops.element('elasticBeamColumn', e + 1, e + 1, e + 2, 0.01, 200e9, 0.5, 1)
+        ops.element('elasticBeamColumn', e + 1, e + 1, e + 2, 0.01, 200e9, -0.1, 1)
     ops.timeSeries('Linear', 1); ops.pattern('Plain', 1, 1); ops.load(5, 0.0, -1.0, 0.0)
     ops.system('BandSPD'); ops.numberer('RCM'); ops.constraints('Plain')
     ops.integrator('LoadControl', 1.0); ops.algorithm('Linear'); ops.analysis('Static')
@@ -119,7 +124,10 @@ def test_frame_oracle_equals_openseespy(bays, stories):
 
 
 def test_frame_mechanism_returns_a_code():
-    """A frame without any support is singular: `analyze` must answer with a non-zero code (what the build's status mirrors)."""
+    """A frame without any support is singular.  Under `BandGeneral` (LU, FR:134) the solver either reports it (non-zero code) or runs
+    through on a rounding-sized pivot and returns displacements that are visibly garbage: one of the two must happen.  (The HIP path
+    factorises frames as SPD band matrices and reports a non-positive pivot as status 1; an INDEFINITE but regular system, which
+    `BandGeneral` would solve, is outside what the reference ever builds -- INTEGRATION.md.)"""
     from openpystruct_amd import frames
     cfg = frames.FrameConfig()
     topo = frames.grid_frame(1, 1, cfg, device="cpu")
@@ -133,4 +141,5 @@ def test_frame_mechanism_returns_a_code():
     ops.timeSeries('Linear', 1); ops.pattern('Plain', 1, 1); ops.load(topo.Nn, 1.0, 0.0, 0.0)
     ops.system('BandGeneral'); ops.numberer('RCM'); ops.constraints('Plain')
     ops.integrator('LoadControl', 1.0); ops.algorithm('Newton'); ops.analysis('Static')
-    assert ops.analyze(1) != 0
+    rc = ops.analyze(1)
+    assert rc != 0 or max(abs(ops.nodeDisp(n + 1, 1)) for n in range(topo.Nn)) > 1e3

@@ -371,3 +371,33 @@ def test_hip_frame_loop_reproduces_the_frame_opt_script(oa):
             Iref = z[p + "I_values"].astype(np.float64)
             assert np.abs(I[0].cpu().numpy() - Iref).max() / Iref.max() < 5e-3
     assert matched >= n - 2
+
+
+def test_the_live_openseespy_test_file_runs_against_the_recorder():
+    """tests/test_openseespy_live.py is skipped wherever the wheel is absent -- i.e. everywhere so far.  Run here with the recorder standing
+    in for the module, it cannot pin anything (the recorder's solve IS the oracle) but it proves that the file's command sequences are
+    well formed, that its read-outs index what it thinks they index, and that its singular-model cases come back as codes: the day a box
+    has OpenSeesPy, what fails there is a difference of arithmetic, not a typo."""
+    import importlib
+    import sys
+    sys.path.insert(0, GOLD)
+    import opensees_stub as stub
+    names = ("openseespy", "openseespy.opensees", "tests.test_openseespy_live")
+    saved = {k: sys.modules.get(k) for k in names}
+    try:
+        stub.install()
+        sys.modules.pop("tests.test_openseespy_live", None)
+        live = importlib.import_module("tests.test_openseespy_live")
+        assert live.ops is stub
+        for seed in range(6):
+            live.test_oracle_equals_openseespy_on_reference_cases(seed)
+        live.test_singular_model_returns_a_code()
+        for bays, stories in [(1, 1), (3, 2), (10, 10)]:
+            live.test_frame_oracle_equals_openseespy(bays, stories)
+        live.test_frame_mechanism_returns_a_code()
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
