@@ -55,13 +55,22 @@ CHIP_WARM_MS = 40.0      # untimed load in front of every timed region: from idl
                          # 2^20 beams 1 150 -> 934 us per launch over the first 30 launches) -- a generator runs for seconds, not for 6 ms
 
 
+OWN_LOAD_WARM_MS = 60.0  # ... and of THAT time the last part has to be the workload itself (r05, scripts/region_transient_probe.py,
+                         # profiles/r05_notes.md 14): behind 40 ms of the copy kernel the beam kernel starts at 12.9 us per launch and settles at
+                         # 11.8 only after ~15 ms of ITS OWN execution (a 20-launch region: 13.07 us behind the copy kernel alone, 11.79 behind 20 ms
+                         # more of the beam kernel, 11.86 behind 40 ms of the beam kernel and no copy kernel; 10 ms of idle undo it) -- the chip's
+                         # operating point follows the instruction mix.  A 500-launch region warmed itself (its prelude replays the region twice); a
+                         # 20-launch one at the driver's flags did not, which was the whole difference between the two on one box (12.7 / 11.5 us).
+                         # `copy_warm_only` keeps the old prelude on the line, `cold_chip` none at all.
+
+
 _WARM_BUF = {}
 
 
 def chip_warm(fn=None, stream=None, ms=CHIP_WARM_MS, fn_ms=0.0):
-    """`ms` of untimed load on the chip, then (optionally) two calls of `fn` (which queues the work about to be timed: caches, TLBs), then
-    drain.  The load is the library's own copy kernel (csrc/mem_bench.hip) over 256 MiB -- NOT the kernel under test, so that a
-    rocprofv3 `--stats` average of that kernel covers steady-state launches only and can be compared with the timed region."""
+    """`ms` of untimed load on the chip (the library's own copy kernel, csrc/mem_bench.hip, over 256 MiB: gets the chip out of idle whatever
+    comes next), then (optionally) `fn` -- which queues the work about to be timed -- at least twice and for `fn_ms` (the chip's operating
+    point follows the instruction mix: OWN_LOAD_WARM_MS), then drain."""
     from openpystruct_amd import _cabi
     lib = _cabi.load()
     dev = torch.cuda.current_device()
@@ -75,12 +84,16 @@ def chip_warm(fn=None, stream=None, ms=CHIP_WARM_MS, fn_ms=0.0):
             lib.ops_hbm_copy16(src.data_ptr(), dst.data_ptr(), src.numel(), 0, s.cuda_stream)
         n += 8
         s.synchronize()
-    if fn is not None:      # then the work itself: twice, or for `fn_ms` (millisecond-long launches over GBs of buffers settle on their own load only)
-        t1, k = time.perf_counter(), 0
+    if fn is not None:      # then the work itself: twice, or for `fn_ms`; short regions are queued several at a time (no idle between them)
+        t1, k, reps = time.perf_counter(), 0, 1
         while k < 2 or (time.perf_counter() - t1) * 1e3 < fn_ms:
-            fn()
-            k += 1
+            tb = time.perf_counter()
+            for _ in range(reps):
+                fn()
+            k += reps
             s.synchronize()
+            if (time.perf_counter() - tb) * 1e3 < 1.0 and reps < 64:
+                reps *= 2
     return n, (time.perf_counter() - t0) * 1e3
 
 
@@ -325,7 +338,7 @@ def frames_measure(dev, rank, local_rank, world, bays, stories, B, K, W):
     for _ in range(W):
         frames.frame_solve(topo, I, out=sol)
     torch.cuda.synchronize()
-    chip_warm(lambda: frames.frame_solve(topo, I, out=sol))      # untimed: the chip's power state settles (CHIP_WARM_MS)
+    chip_warm(lambda: frames.frame_solve(topo, I, out=sol), fn_ms=OWN_LOAD_WARM_MS)      # untimed: the chip's power state settles (copy kernel, then the solve itself)
 
     def barrier():
         if is_dp(world):
@@ -467,7 +480,7 @@ def main():
         if is_dp(world):
             dist.barrier(device_ids=[local_rank]) if dist.get_backend() == "nccl" else dist.barrier()
 
-    def measure(Bm, Km, Wm, n_sets, tiling, stream_out=False, warm_chip=True):
+    def measure(Bm, Km, Wm, n_sets, tiling, stream_out=False, warm_chip=True, own_warm=True):
         """K launches over `Bm` beams, rotating over `n_sets` distinct input / output buffer sets, captured in ONE HIP
         graph and replayed once between two HIP events on the launch stream.  Barriers and host synchronisation sit
         strictly OUTSIDE the event pair.  Returns (event ms, wall s, kernel name, launch mode)."""
@@ -492,7 +505,9 @@ def main():
                     graph.replay()   # untimed: instantiate + first replay
                     stream.synchronize()
                     if warm_chip:
-                        chip_warm(graph.replay, stream, fn_ms=CHIP_WARM_MS if Bm * BYTES_PER_SOLVE > (1 << 30) else 0.0)      # untimed (CHIP_WARM_MS)
+                        # untimed: CHIP_WARM_MS of the copy kernel, then OWN_LOAD_WARM_MS of the region itself (own_warm False: the region twice,
+                        # the prelude of r04 / early r05; launches over GBs always took the longer form)
+                        chip_warm(graph.replay, stream, fn_ms=OWN_LOAD_WARM_MS if own_warm else (CHIP_WARM_MS if Bm * BYTES_PER_SOLVE > (1 << 30) else 0.0))
                     else:            # `cold_chip`: exactly the driver's flags -- W warm-up launches, then let the chip fall back to idle
                         time.sleep(0.25)
                 except Exception as e:   # keep the bench alive: eager launches measure the same kernel, with host gaps
@@ -528,8 +543,8 @@ def main():
         del outs, sets
         return dev_ms, wall, oa.kernel_name(Bm, N_ELEM, tiling), ("eager" if graph is None else f"one HIP graph of {Km} kernel nodes")
 
-    def sub_record(Bm, Km, n_sets, tiling, what, stream_out=False, warm=None, warm_chip=True):
-        dev_ms, wall, kname, mode = measure(Bm, Km, min(W, 2 * n_sets) if warm is None else warm, n_sets, tiling, stream_out, warm_chip)
+    def sub_record(Bm, Km, n_sets, tiling, what, stream_out=False, warm=None, warm_chip=True, own_warm=True):
+        dev_ms, wall, kname, mode = measure(Bm, Km, min(W, 2 * n_sets) if warm is None else warm, n_sets, tiling, stream_out, warm_chip, own_warm)
         us = dev_ms / Km * 1e3
         ach = BYTES_PER_SOLVE * Bm / (us * 1e-6) / 1e9
         return {"what": what, "beams_per_launch_per_gpu": Bm, "launches": Km, "buffer_sets": n_sets,
@@ -583,6 +598,7 @@ def main():
                 "buffer_sets": max(1, args.sets),
                 "parallelism": f"independent shards x{world}, no data-path collective",
                 "untimed_chip_warm_ms": CHIP_WARM_MS,      # in front of EVERY timed region of this line (except `cold_chip`), beside the W warm-up steps
+                "untimed_own_load_warm_ms": OWN_LOAD_WARM_MS,   # ... followed by this much of the region's own launches (except `cold_chip`, `copy_warm_only`)
                 "hip_runtime": runtime_rec.get("hip_runtime"), "torch": torch.__version__,
                 "hip_graph_packet_capture_env": runtime_rec.get("packet_capture_env"), "cpu_threads": runtime_rec.get("cpu_threads"),
             },
@@ -623,6 +639,11 @@ def main():
         # 0.26 ms workload sees on a chip that was idle (the headline is the steady state of a chip under load)
         extras["cold_chip"] = sub_record(B, K, 1, args.tiling, f"the headline region without the {CHIP_WARM_MS:.0f} ms of untimed load: "
                                          f"{W} warm-up launches, 0.25 s idle, {K} timed launches", warm=W, warm_chip=False)
+        # copy_warm_only: the headline region behind the prelude every bench line up to BENCH_r04 / profiles/r05_bench_driver_flags.json had
+        # (40 ms of the copy kernel + the region twice): at the driver's K = 20 that is 0.5 ms of the beam kernel, and the region still sits in
+        # the transient of its own instruction mix (OWN_LOAD_WARM_MS above)
+        extras["copy_warm_only"] = sub_record(B, K, 1, args.tiling, f"the headline region behind {CHIP_WARM_MS:.0f} ms of the copy kernel and two "
+                                              f"untimed replays of itself only (the prelude of r04 / early r05)", warm=W, own_warm=False)
         # saturating: SURVEY 8(d) asks for B = 2^20 next to the contract batch (one round of waves at 10^4 beams)
         # (12 untimed launches first: after the sub-millisecond launches above the first ~10 ms of 1 ms launches run 5-10 %
         #  slow -- clocks and TLBs of 5 GB of fresh buffers, measured with scripts/sat_ab.py)

@@ -1,7 +1,7 @@
 #!/bin/bash
 # copies the summaries of scripts/r05_profiles.sh from gpurun_out/ (scratch) into profiles/ (tracked)
 cd /root/repo
-for t in r05_hot10k r05_cold10k r05_sat2p20; do
+for t in r05_drv20 r05_hot10k r05_cold10k r05_sat2p20; do
   d=gpurun_out/prof_$t
   cp $d/summary.json profiles/${t}_pmc_summary.json
   f=$(ls -S $d/trace/*/*_kernel_stats.csv | head -1); cp $f profiles/${t}_kernel_stats.csv
@@ -14,4 +14,6 @@ for fr in 15x16 10x10; do
   cp gpurun_out/r05_bench_frames_$fr.json profiles/r05_bench_frames_$fr.json
 done
 cp gpurun_out/r05_bench_default.json profiles/r05_bench_default.json
+grep -h '^{"metric"' gpurun_out/r05_bench_driver_flags.json | tail -1 > profiles/r05_bench_driver_flags.json
+cp gpurun_out/r05_train_trace.log /dev/null 2>&1
 ls -la profiles/r05_*summary.json profiles/r05_bench_default.json

@@ -1,7 +1,9 @@
 #!/bin/bash
 # Round-4 evidence run (GPU box): default bench line + rocprofv3 trace / PMC passes for the three FE measurements + frames.
 cd "$GRAFT_REPO_ROOT"
+python bench.py --steps 20 --warmup 5 > gpurun_out/r05_bench_driver_flags.json 2> gpurun_out/r05_bench_driver_flags.err
 python bench.py > gpurun_out/r05_bench_default.json 2> gpurun_out/r05_bench_default.err
+bash scripts/profile_gpu.sh r05_drv20 --steps 20 --warmup 5 > /dev/null 2>&1
 bash scripts/profile_gpu.sh r05_hot10k > /dev/null 2>&1
 PMC_STEPS=32 bash scripts/profile_gpu.sh r05_cold10k --sets 16 > /dev/null 2>&1
 PMC_STEPS=4 bash scripts/profile_gpu.sh r05_sat2p20 --batch 1048576 --steps 20 > /dev/null 2>&1
@@ -9,7 +11,7 @@ bash scripts/frames_prof.sh 15x16 12288 > /dev/null 2>&1
 bash scripts/frames_prof.sh 10x10 16384 > /dev/null 2>&1
 python bench.py --workload frames --frame 15x16 > gpurun_out/r05_bench_frames_15x16.json 2>/dev/null
 python bench.py --workload frames --frame 10x10 --batch 16384 > gpurun_out/r05_bench_frames_10x10.json 2>/dev/null
-for t in r05_hot10k r05_cold10k r05_sat2p20; do echo "== $t"; python3 - "$t" <<'PY'
+for t in r05_drv20 r05_hot10k r05_cold10k r05_sat2p20; do echo "== $t"; python3 - "$t" <<'PY'
 import json,sys
 r=json.load(open(f"gpurun_out/prof_{sys.argv[1]}/summary.json"))
 print(r.get("kernel"), r.get("trace"), r.get("hbm"), r.get("dispatch",{}).get("Grid_Size"), r.get("per_wave"))
@@ -17,5 +19,5 @@ PY
 done
 for f in 15x16 10x10; do echo "== frames $f"; python3 -c "
 import json; r=json.load(open('gpurun_out/prof_frames_$f/summary.json')); print(r.get('trace'), r.get('hbm'), r.get('per_wave'))"; tail -c 1500 gpurun_out/r05_bench_frames_$f.json; done
-tail -c 3000 gpurun_out/r05_bench_default.json
+tail -c 3000 gpurun_out/r05_bench_default.json; head -c 1500 gpurun_out/r05_bench_driver_flags.json
 bash scripts/train_trace.sh > gpurun_out/r05_train_trace.log 2>&1
