@@ -222,9 +222,12 @@ int ops_physics_loss_bwd(const ops_physics_loss_args* args, void* stream);
  * Per frame: I [B,Ne]; loads [Nn,3] (loads_bstride 0) or [B,Nn,3] (`ops.load(node, Fx, Fy, Mz)`).
  * Outputs: disp [B,Nn,3], forces [B,Ne,6] (global resisting forces = eleResponse 'forces'), V / M [B,Ne] = forces[..,1] /
  * forces[..,2] (FR:151-153), status [B] (non-zero: not positive definite, outputs NaN).
- * half_bandwidth <= 63.  The assembled band and, over it, the factor live in a caller-provided device workspace of
+ * The assembled band and, over it, the factor live in a caller-provided device workspace of
  * ops_frame_workspace_bytes(B, n_eq, half_bandwidth) bytes (about (n_eq + 80) * (half_bandwidth + 2) * 8 per frame; the
- * kernels keep the sliding window in registers, one wavefront per frame).  ERR_INVALID_ARG when it is NULL or too small. */
+ * kernels keep the sliding window in registers, one wavefront per frame).  ERR_INVALID_ARG when it is NULL or too small.
+ * half_bandwidth <= 55: the tuned path; 56..63: the workgroup-per-frame kernels; 64..1024 (more than 20 bays and stories: beyond
+ * the reference's range): a plain column-by-column fallback on the band in the workspace, milliseconds per frame;
+ * ERR_UNSUPPORTED beyond that or when one right-hand side and one column do not fit 160 KB of LDS. */
 int ops_frame_solve_batched_f64(int B, int n_nodes, int n_elems, int n_eq, int half_bandwidth,
                                 const double* elem_geo, const double* elem_EA, const double* elem_E,
                                 const double* elem_w, const int32_t* elem_eq, const int32_t* node_eq,

@@ -337,12 +337,13 @@ __global__ __launch_bounds__(1024) void frame_solve_kernel(const FrameParams p, 
 // Assembly for the workspace path: one workgroup per frame builds the band slab by slab (FRAME_SLAB columns at a time)
 // in LDS with ds_add_f64 and streams each finished slab to HBM with plain coalesced stores -- no global atomics and no
 // memset of the workspace (first version: 0.52 ms of a 1.8 ms launch for 1024 frames of 15 x 16).
-constexpr int FRAME_SLAB = 128;
+constexpr int FRAME_SLAB_MAX = 128;
 
-__global__ __launch_bounds__(256) void frame_assemble_kernel(const FrameParams p, double* __restrict__ ws) {
+__global__ __launch_bounds__(256) void frame_assemble_kernel(const FrameParams p, double* __restrict__ ws, int slab_cols) {
   extern __shared__ double lds[];
   const long b = blockIdx.x;
   const int ld = frame_ld(p.kd), n3 = frame_n3(p.n_eq), tid = threadIdx.x;
+  const int FRAME_SLAB = slab_cols;            // (FRAME_SLAB_MAX for the ring kernel; fewer, wider columns for frame_wide_kernel)
   double* slab = lds;                          // [FRAME_SLAB][ld]
   double* rhs = lds + (size_t)FRAME_SLAB * ld;   // [n3]
   double* ab = ws + b * ((long)n3 * ld + n3);
@@ -352,7 +353,8 @@ __global__ __launch_bounds__(256) void frame_assemble_kernel(const FrameParams p
     const int nc = (n3 - c0 < FRAME_SLAB) ? n3 - c0 : FRAME_SLAB;
     for (int i = tid; i < nc * ld; i += 256) slab[i] = 0.0;
     __syncthreads();
-    if (tid < nc && c0 + tid >= p.n_eq) slab[(size_t)tid * ld] = 1.0;     // padding equations
+    for (int i = tid; i < nc; i += 256)
+      if (c0 + i >= p.n_eq) slab[(size_t)i * ld] = 1.0;                    // padding equations
     for (int e = tid; e < p.Ne; e += 256) {
       int eq[6], lo = 1 << 30, hi = -1;
       for (int r = 0; r < 6; ++r) {
@@ -519,6 +521,81 @@ __global__ __launch_bounds__(1024) void frame_factor_big_kernel(const FrameParam
   write_results(p, b, rhs, s_bad != 0, tid, T);
 }
 
+// ------------------------------------------------------------------------------------------------------
+// Half bandwidths beyond 63 (r05; more than 20 bays AND more than 20 stories: outside the reference's random range, FR:17-18, and
+// outside BASELINE's ~500 elements): the plain column-by-column band LDL^T -- dpbsv's order, no blocking -- on the band in the HBM
+// workspace (the layout of frame_assemble_kernel), one workgroup per frame, two barriers per column; the trailing window is updated in
+// place through L2.  A FALLBACK so that the C ABI answers for any band (milliseconds per frame), not a tuned path: the window rows of the
+// block kernels are one 64-lane wave and the register window of the wave kernel ends at 55.
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void frame_wide_kernel(const FrameParams p, double* __restrict__ ws) {
+  extern __shared__ double lds[];
+  const int n = p.n_eq, kd = p.kd, ld = frame_ld(kd), n3 = frame_n3(n);
+  double* rhs = lds;                 // [n3]  right-hand side -> z -> x
+  double* col = rhs + n3;            // [ld]  column j, unscaled
+  __shared__ int s_bad;
+  const int tid = threadIdx.x, T = blockDim.x;
+  const long b = blockIdx.x;
+  double* ab = ws + b * ((long)n3 * ld + n3);
+  if (tid == 0) s_bad = 0;
+  for (int i = tid; i < n3; i += T) rhs[i] = ab[(long)n3 * ld + i];
+  __syncthreads();
+  for (int j = 0; j < n3; ++j) {
+    double* cj = ab + (long)j * ld;
+    for (int r = tid; r <= kd; r += T) col[r] = cj[r];
+    __syncthreads();
+    const double d = col[0], rd = frcp(d), zj = rhs[j];
+    if (tid == 0 && !(d > 0.0)) s_bad = 1;
+    // column j of L (the diagonal keeps d_j) and the forward substitution
+    for (int r = tid + 1; r <= kd; r += T) {
+      if (j + r < n3) {
+        const double l = col[r] * rd;
+        cj[r] = l;
+        rhs[j + r] = __builtin_fma(-l, zj, rhs[j + r]);
+      }
+    }
+    // trailing window: A[j + r][j + c] -= (A[j + r][j] / d_j) A[j + c][j], 1 <= c <= r <= kd (consecutive threads: consecutive r)
+    for (int idx = tid; idx < kd * kd; idx += T) {
+      const int c = idx / kd + 1, r = idx - (c - 1) * kd + 1;
+      if (r >= c && j + r < n3) {
+        double* t = ab + (long)(j + c) * ld + (r - c);
+        *t = __builtin_fma(-(col[r] * rd), col[c], *t);
+      }
+    }
+    __syncthreads();
+  }
+  // w = D^-1 z, then L^T x = w from the last equation up: wave 0, the next column's loads under way while a column is summed
+  if (tid < 64) {
+    const int lane = tid;
+    constexpr int MAXR = 16;         // kd <= 64 * MAXR
+    double la[MAXR], lb[MAXR], da = 1.0, db = 1.0;
+    auto issue = [&](int j, double (&l)[MAXR], double& dj) {
+      const double* cj = ab + (long)(j > 0 ? j : 0) * ld;
+      dj = cj[0];
+#pragma unroll
+      for (int m = 0; m < MAXR; ++m) { const int r = lane + 1 + 64 * m; l[m] = (m * 64 < kd && r <= kd) ? cj[r] : 0.0; }
+    };
+    auto solve = [&](int j, const double (&l)[MAXR], double dj) {
+      double s_ = 0.0;
+#pragma unroll
+      for (int m = 0; m < MAXR; ++m) { const int r = lane + 1 + 64 * m; if (m * 64 < kd && r <= kd && j + r < n3) s_ = __builtin_fma(l[m], rhs[j + r], s_); }
+      for (int sft = 32; sft >= 1; sft >>= 1) s_ += __shfl_xor(s_, sft, 64);
+      wave_lds_fence();
+      if (lane == 0) rhs[j] = rhs[j] * frcp(dj) - s_;
+      wave_lds_fence();
+    };
+    issue(n3 - 1, la, da);
+    for (int j = n3 - 1; j >= 0; j -= 2) {
+      issue(j - 1, lb, db);
+      solve(j, la, da);
+      if (j - 1 >= 0) { issue(j - 2, la, da); solve(j - 1, lb, db); }
+    }
+  }
+  __syncthreads();
+  write_results(p, b, rhs, s_bad != 0, tid, T);
+}
+constexpr int FRAME_WIDE_MAX_KD = 1024;      // frame_wide_kernel's backward sweep keeps a column in 16 registers per lane
+
 }  // namespace opsamd
 
 #include "frame_wave.hpp"
@@ -630,6 +707,7 @@ static hipError_t launch_wave(const FrameParams& p, double* ws, hipStream_t s) {
 
 extern "C" size_t ops_frame_workspace_bytes(int B, int n_eq, int half_bandwidth) {
   half_bandwidth = eff_kd(half_bandwidth);
+  if (half_bandwidth > 63) return (size_t)B * frame_lds_resident_bytes(n_eq, half_bandwidth);      // frame_wide_kernel: the band always lives in HBM
   if (wave_kernel_serves(n_eq, half_bandwidth))     // per frame: band / factor rows; once: the assembly plan (at most 21 entries and 72 coefficients per element)
     return B == 0 ? 0 : (size_t)B * fw_frame_doubles(n_eq, half_bandwidth) * sizeof(double) + fw_plan_bytes(n_eq, 4 * n_eq + 64);
   if (frame_lds_resident_bytes(n_eq, half_bandwidth) <= LDS_MAX && !force_ws()) return 0;   // the band lives in LDS
@@ -646,7 +724,7 @@ extern "C" int ops_frame_solve_batched_f64(int B, int n_nodes, int n_elems, int 
   if (B == 0) return OPS_AMD_OK;
   if (!elem_geo || !elem_EA || !elem_E || !elem_w || !elem_eq || !node_eq || !I || !loads || !disp || !forces || !V || !M)
     return OPS_AMD_ERR_INVALID_ARG;
-  if (half_bandwidth > 63) return OPS_AMD_ERR_UNSUPPORTED;    // the window rows of a block step are one 64-lane wave
+  if (half_bandwidth > FRAME_WIDE_MAX_KD) return OPS_AMD_ERR_UNSUPPORTED;
   const int kd = eff_kd(half_bandwidth);
   const size_t lds_bytes = frame_lds_resident_bytes(n_eq, kd);
   {
@@ -660,6 +738,7 @@ extern "C" int ops_frame_solve_batched_f64(int B, int n_nodes, int n_elems, int 
       hipError_t e = hipFuncSetAttribute((const void*)frame_solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX);
       if (e == hipSuccess) e = hipFuncSetAttribute((const void*)frame_assemble_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX);
       if (e == hipSuccess) e = hipFuncSetAttribute((const void*)frame_factor_big_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX);
+      if (e == hipSuccess) e = hipFuncSetAttribute((const void*)frame_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX);
       if (e != hipSuccess) { set_frame_error(hipGetErrorString(e)); return OPS_AMD_ERR_LAUNCH; }
       attr_done.fetch_or(bit, std::memory_order_release);      // idempotent: two threads racing here both set the same value
     }
@@ -670,6 +749,19 @@ extern "C" int ops_frame_solve_batched_f64(int B, int n_nodes, int n_elems, int 
   if (const char* e = getenv("OPS_AMD_FRAME_TRACE_PTR")) p.trace = (unsigned long long*)strtoull(e, nullptr, 10);
 #endif
   hipStream_t s = (hipStream_t)stream;
+  if (kd > 63) {
+    // the window rows of a block step are one 64-lane wave: beyond that, the plain column-by-column fallback on the band in HBM
+    const int ld = frame_ld(kd), n3 = frame_n3(n_eq);
+    const size_t need = (size_t)B * lds_bytes, lds_wide = ((size_t)n3 + ld) * sizeof(double);
+    if (lds_wide > LDS_MAX) return OPS_AMD_ERR_UNSUPPORTED;
+    long slab = ((long)(LDS_MAX / sizeof(double)) - n3) / ld;          // columns per LDS slab of the assembly
+    if (slab > FRAME_SLAB_MAX) slab = FRAME_SLAB_MAX;
+    if (slab < 4) return OPS_AMD_ERR_UNSUPPORTED;
+    if (!workspace || workspace_bytes < need) return OPS_AMD_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(frame_assemble_kernel, dim3((unsigned)B), dim3(256), ((size_t)slab * ld + (size_t)n3) * sizeof(double), s, p, (double*)workspace, (int)slab);
+    hipLaunchKernelGGL(frame_wide_kernel, dim3((unsigned)B), dim3(1024), lds_wide, s, p, (double*)workspace);
+    return hipGetLastError() == hipSuccess ? OPS_AMD_OK : OPS_AMD_ERR_LAUNCH;
+  }
   if (wave_kernel_serves(n_eq, kd)) {
     const int W = fw_width(kd);
     const size_t need = (size_t)B * fw_frame_doubles(n_eq, kd) * sizeof(double) + fw_plan_bytes(n_eq, n_elems);
@@ -697,8 +789,8 @@ extern "C" int ops_frame_solve_batched_f64(int B, int n_nodes, int n_elems, int 
     if (lds2 > LDS_MAX) return OPS_AMD_ERR_UNSUPPORTED;
     if (!workspace || workspace_bytes < need) return OPS_AMD_ERR_INVALID_ARG;
     if (T < 128 + 3 * ld) T = (128 + 3 * ld + 63) / 64 * 64;   // the column movers sit behind the two service waves
-    const size_t lds_asm = ((size_t)FRAME_SLAB * ld + (size_t)n3) * sizeof(double);
-    hipLaunchKernelGGL(frame_assemble_kernel, dim3((unsigned)B), dim3(256), lds_asm, s, p, (double*)workspace);
+    const size_t lds_asm = ((size_t)FRAME_SLAB_MAX * ld + (size_t)n3) * sizeof(double);
+    hipLaunchKernelGGL(frame_assemble_kernel, dim3((unsigned)B), dim3(256), lds_asm, s, p, (double*)workspace, FRAME_SLAB_MAX);
     hipLaunchKernelGGL(frame_factor_big_kernel, dim3((unsigned)B), dim3((unsigned)T), lds2, s, p, (double*)workspace, pp_use);
     return hipGetLastError() == hipSuccess ? OPS_AMD_OK : OPS_AMD_ERR_LAUNCH;
   }

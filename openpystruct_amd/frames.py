@@ -107,7 +107,7 @@ class FrameTopology:
     reference's `numberer('RCM')`, FR:135); "auto" (default) = the narrowest of node order, reverse Cuthill-McKee and the two
     coordinate sweeps (`self.numbering` says which), node order on a tie.  The solution does not depend on it beyond rounding; the work does (n kd^2): a 10-bay x 2-story frame of the reference's own
     random range is kd 35 story by story and kd 8 along its column lines, and a 21 x 3 frame (kd 68 in node order: beyond the
-    kernels' 63) becomes solvable."""
+    tuned kernels' 63, i.e. on the slow column-by-column fallback) stays on the wave kernel."""
 
     def __init__(self, coords, conn, fix3, A, E, wy, wx, nodal_loads, device="cuda", numbering: str = "auto"):
         coords = np.asarray(coords, dtype=np.float64)
@@ -214,8 +214,8 @@ def frame_solve(topo: FrameTopology, I: torch.Tensor, loads: Optional[torch.Tens
             out.disp.data_ptr(), out.forces.data_ptr(), out.V.data_ptr(), out.M.data_ptr(), out.status.data_ptr(),
             ws.data_ptr() if ws is not None else None, ws_bytes, torch.cuda.current_stream(dev).cuda_stream)
     if rc == _cabi.ERR_UNSUPPORTED:
-        raise NotImplementedError(f"frame too large: n_eq={topo.n_eq}, half bandwidth={topo.kd} (half bandwidth <= 63 and a "
-                                  f"(kd+6)-column ring, one n_eq vector and two 24-column chunks must fit 160 KB of LDS)")
+        raise NotImplementedError(f"frame too large: n_eq={topo.n_eq}, half bandwidth={topo.kd} (half bandwidth <= 63: a (kd+6)-column ring, one "
+                                  f"n_eq vector and two 24-column chunks must fit 160 KB of LDS; beyond 63, up to 1024: one n_eq vector and one column)")
     if rc != _cabi.OK:
         raise RuntimeError(f"ops_frame_solve_batched_f64 failed with code {rc}")
     return out

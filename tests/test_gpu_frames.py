@@ -91,7 +91,7 @@ def test_frame_equilibrium_and_axial_udl_quirk():
     assert base[:, 1].sum() == pytest.approx(-applied_y, rel=1e-9)
 
 
-def test_frame_status_and_unsupported_size():
+def test_frame_status_and_half_bandwidths_beyond_the_wave():
     from openpystruct_amd import frames
     topo = frames.grid_frame(2, 2)
     I = torch.full((3, topo.Ne), 5e-4, dtype=torch.float64, device="cuda")
@@ -99,14 +99,24 @@ def test_frame_status_and_unsupported_size():
     sol = frames.frame_solve(topo, I)
     st = sol.status.cpu().numpy()
     assert st[1] != 0 and st[0] == 0 and st[2] == 0 and torch.isnan(sol.disp[1]).all() and torch.isfinite(sol.disp[0]).all()
-    big = frames.grid_frame(21, 3, numbering="node")             # story by story: half bandwidth 3 * 22 + 2 = 68 > 63
-    with pytest.raises(NotImplementedError):
-        frames.frame_solve(big, torch.full((1, big.Ne), 5e-4, dtype=torch.float64, device="cuda"))
-    assert frames.grid_frame(21, 3).kd == 11               # ... and 11 along its column lines (numberer('RCM'), FR:135): solvable, see below
-    wide = frames.grid_frame(21, 21, numbering="auto")     # no numbering helps a square 21 x 21 grid below 63
-    assert wide.kd > 63
-    with pytest.raises(NotImplementedError):
-        frames.frame_solve(wide, torch.full((1, wide.Ne), 5e-4, dtype=torch.float64, device="cuda"))
+    # half bandwidths beyond 63 (r05: the column-by-column fallback, csrc/frame_solve.hip frame_wide_kernel; up to r04 these raised)
+    from oracle import beam_oracle as bo
+    rng = np.random.default_rng(63)
+    assert frames.grid_frame(21, 3).kd == 11               # (numberer('RCM'), FR:135: 11 along the column lines of what is 68 story by story)
+    for topo in (frames.grid_frame(21, 3, numbering="node"),            # story by story: half bandwidth 3 * 22 + 2 = 68
+                 frames.grid_frame(21, 21, numbering="auto"),           # no numbering helps a square 21 x 21 grid below 63
+                 frames.grid_frame(30, 2, numbering="node")):           # 95
+        assert topo.kd > 63
+        I = np.exp(rng.uniform(np.log(1e-4), np.log(5e-3), size=(3, topo.Ne)))
+        I[1, 5] = -1.0                                                   # not positive definite: status, NaN rows
+        sol = frames.frame_solve(topo, torch.as_tensor(I, device="cuda"))
+        st = sol.status.cpu().numpy()
+        assert st[0] == 0 and st[2] == 0 and st[1] != 0 and torch.isnan(sol.disp[1]).all()
+        for k in (0, 2):
+            d, f, s_, _, _ = bo.solve_model_3dof(topo.coords, topo.conn, topo.A, topo.E, I[k], topo.fix3, topo.nodal_loads, wy=topo.wy, wx=topo.wx)
+            assert s_ == 0
+            assert np.abs(sol.disp[k].cpu().numpy() - d).max() <= 1e-7 * np.abs(d).max(), (topo.kd, k)
+            assert np.abs(sol.forces[k].cpu().numpy() - f).max() <= 1e-6 * np.abs(f).max(), (topo.kd, k)
 
 
 @pytest.mark.parametrize("bays,stories,kd_node,kd_rcm", [(10, 2, 35, 8), (16, 3, 53, 11), (21, 3, 68, 11), (9, 4, 32, 14), (10, 10, 35, 32)])
