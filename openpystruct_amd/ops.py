@@ -52,6 +52,53 @@ _dom = _Domain()
 _queue: Optional[List[_Domain]] = None           # deferred mode
 
 
+class _Stage:
+    """Staging of the batch-of-one beam path (one per device and mesh size, reused by every `analyze`): ONE pinned host block and one
+    device block for the inputs, one of each for the results, so that a call is two copies in, one launch, two copies out and one stream
+    synchronisation -- it used to be six small host-to-device transfers, four device-to-host ones and a sync each (r05,
+    scripts/batch_of_one_latency.py: ~500 us per `analyze` of a 100-element beam, of which the launch is 50)."""
+
+    def __init__(self, dev, N):
+        Ne = N - 1
+        sizes_in = (("x", N), ("E", Ne), ("I", Ne), ("Fy", N), ("wy", Ne))
+        sizes_out = (("v", N), ("theta", N), ("V", Ne), ("M", Ne))
+        self.off_in, self.off_out, o = {}, {}, 0
+        for k, n in sizes_in:                                          # every segment starts 16-byte aligned
+            self.off_in[k] = (o, n); o += (n + 1) & ~1
+        self.h_in = torch.empty(o, dtype=torch.float64).pin_memory()
+        self.d_in = torch.empty(o, dtype=torch.float64, device=dev)
+        o = 0
+        for k, n in sizes_out:
+            self.off_out[k] = (o, n); o += (n + 1) & ~1
+        self.h_out = torch.empty(o, dtype=torch.float64).pin_memory()
+        self.d_out = torch.empty(o, dtype=torch.float64, device=dev)
+        self.h_fix, self.d_fix = torch.empty(N, dtype=torch.uint8).pin_memory(), torch.empty(N, dtype=torch.uint8, device=dev)
+        self.h_st, self.d_st = torch.empty(1, dtype=torch.int32).pin_memory(), torch.empty(1, dtype=torch.int32, device=dev)
+        self.np_in, self.np_out, self.np_fix = self.h_in.numpy(), self.h_out.numpy(), self.h_fix.numpy()
+        dv = lambda buf, off, k, two: buf[off[k][0]:off[k][0] + off[k][1]][None, :] if two else buf[off[k][0]:off[k][0] + off[k][1]]  # noqa: E731
+        self.args = dict(x=dv(self.d_in, self.off_in, "x", False), E=dv(self.d_in, self.off_in, "E", True), I=dv(self.d_in, self.off_in, "I", True),
+                         fix=self.d_fix, Fy=dv(self.d_in, self.off_in, "Fy", True), wy=dv(self.d_in, self.off_in, "wy", True))
+        from .beam import BeamSolution
+        self.sol = BeamSolution(*(dv(self.d_out, self.off_out, k, True) for k in ("v", "theta", "V", "M")), self.d_st)
+
+    def solve(self, a, dev):
+        for k in ("x", "E", "I", "Fy", "wy"):
+            o, n = self.off_in[k]
+            self.np_in[o:o + n] = a[k]
+        self.np_fix[:] = a["fix"]
+        self.d_in.copy_(self.h_in, non_blocking=True)
+        self.d_fix.copy_(self.h_fix, non_blocking=True)
+        beam_solve(**self.args, out=self.sol)
+        self.h_out.copy_(self.d_out, non_blocking=True)
+        self.h_st.copy_(self.d_st, non_blocking=True)
+        torch.cuda.current_stream(dev).synchronize()      # the per-case API hands results back as Python scalars
+        res = {k: self.np_out[o:o + n].copy() for k, (o, n) in self.off_out.items()}     # (the staging block is reused by the next call)
+        return res, int(self.h_st[0])
+
+
+_STAGES: Dict[tuple, _Stage] = {}
+
+
 def wipe():
     global _dom
     dev = _dom.device
@@ -231,10 +278,56 @@ def _solve_frames(arrs, device):
     return sol.disp.cpu().numpy(), sol.forces.cpu().numpy(), sol.status.cpu().numpy()
 
 
+class _FrameStage:
+    """As `_Stage`, for the batch-of-one frame path; kept on the cached topology (the script rebuilds the same frame every epoch)."""
+
+    def __init__(self, topo, dev):
+        from .frames import FrameSolution
+        Nn, Ne = topo.Nn, topo.Ne
+        r2 = lambda n: (n + 1) & ~1  # noqa: E731
+        self.oI, self.oL = 0, r2(Ne)
+        n_in = self.oL + 3 * Nn
+        self.h_in, self.d_in = torch.empty(n_in, dtype=torch.float64).pin_memory(), torch.empty(n_in, dtype=torch.float64, device=dev)
+        self.oD, self.oF = 0, r2(3 * Nn)
+        oV = self.oF + 6 * Ne
+        oM = oV + r2(Ne)
+        n_out = oM + Ne
+        self.h_out, self.d_out = torch.empty(n_out, dtype=torch.float64).pin_memory(), torch.empty(n_out, dtype=torch.float64, device=dev)
+        self.h_st, self.d_st = torch.empty(1, dtype=torch.int32).pin_memory(), torch.empty(1, dtype=torch.int32, device=dev)
+        self.np_in, self.np_out = self.h_in.numpy(), self.h_out.numpy()
+        self.I = self.d_in[:Ne][None, :]
+        self.loads = self.d_in[self.oL:self.oL + 3 * Nn].view(1, Nn, 3)
+        self.sol = FrameSolution(self.d_out[:3 * Nn].view(1, Nn, 3), self.d_out[self.oF:self.oF + 6 * Ne].view(1, Ne, 6),
+                                 self.d_out[oV:oV + Ne][None, :], self.d_out[oM:oM + Ne][None, :], self.d_st)
+        self.Nn, self.Ne = Nn, Ne
+
+    def solve(self, topo, a, dev):
+        from .frames import frame_solve
+        self.np_in[:self.Ne] = a["I"]
+        self.np_in[self.oL:self.oL + 3 * self.Nn] = a["loads"].reshape(-1)
+        self.d_in.copy_(self.h_in, non_blocking=True)
+        frame_solve(topo, self.I, loads=self.loads, out=self.sol)
+        self.h_out.copy_(self.d_out, non_blocking=True)
+        self.h_st.copy_(self.d_st, non_blocking=True)
+        torch.cuda.current_stream(dev).synchronize()
+        disp = self.np_out[:3 * self.Nn].reshape(self.Nn, 3).copy()
+        forces = self.np_out[self.oF:self.oF + 6 * self.Ne].reshape(self.Ne, 6).copy()
+        return disp, forces, int(self.h_st[0])
+
+
 def _analyze_frame(d: _Domain):
     """General 2-D frame: the batched frame kernel with a batch of one."""
-    disp, forces, status = _solve_frames([_frame_arrays(d)], d.device)
-    return _frame_finish(d, disp[0], forces[0], int(status[0]))
+    a = _frame_arrays(d)
+    dev = torch.device(d.device)
+    if dev.index is None:
+        dev = torch.device("cuda", torch.cuda.current_device())
+    topo = _topology(a, dev)
+    stage = topo.__dict__.get("_shim_stage")
+    if stage is None:
+        stage = topo.__dict__["_shim_stage"] = _FrameStage(topo, dev)
+    with torch.cuda.device(dev):
+        disp, forces, status = stage.solve(topo, a, dev)
+    return _frame_finish(d, disp, forces, status)
 
 
 def _arrays(d: _Domain):
@@ -275,22 +368,24 @@ def _axial(a, N):
     if fixed.size != 1:
         return None, None
     k = int(fixed[0])
-    # tension T just right of node n / just left: integrate applied axial load from the free ends
+    Ne = N - 1
+    # tension T just right of node n / just left: integrate applied axial load from the free ends (running sums: this runs once per
+    # `analyze`, i.e. once per epoch of the reference's loop -- a Python loop over the elements was a fifth of the call)
     q = a["wx"] * L                                   # total axial load per element
-    T_left = np.zeros(N - 1); T_right = np.zeros(N - 1)   # T at element ends 1 and 2
-    for e in range(N - 1):
-        if e >= k:    # right of the support: everything to the right hangs on this section
-            T_right[e] = q[e + 1:].sum() + a["Fx"][e + 1:].sum()
-            T_left[e] = T_right[e] + q[e]
-        else:         # left of the support
-            T_left[e] = -(q[:e].sum() + a["Fx"][:e + 1].sum())
-            T_right[e] = T_left[e] - q[e]
+    Fx = a["Fx"]
+    e = np.arange(Ne)
+    suf_q = np.concatenate([np.cumsum(q[::-1])[::-1], [0.0]])        # suf_q[i] = q[i:].sum()
+    suf_F = np.concatenate([np.cumsum(Fx[::-1])[::-1], [0.0]])       # suf_F[i] = Fx[i:].sum()
+    pre_q = np.concatenate([[0.0], np.cumsum(q)])                    # pre_q[i] = q[:i].sum()
+    pre_F = np.cumsum(Fx)                                            # pre_F[i] = Fx[:i + 1].sum()
+    right = e >= k       # right of the support: everything to the right hangs on this section; left of it: everything to the left
+    T_right = np.where(right, suf_q[e + 1] + suf_F[e + 1], -(pre_q[e] + pre_F[e]) - q)
+    T_left = np.where(right, T_right + q, -(pre_q[e] + pre_F[e]))
+    dux = 0.5 * (T_left + T_right) / (a["E"] * a["A"]) * L          # elongation per element
     ux = np.zeros(N)
-    strain = 0.5 * (T_left + T_right) / (a["E"] * a["A"])
-    for e in range(k, N - 1):
-        ux[e + 1] = ux[e] + strain[e] * L[e]
-    for e in range(k - 1, -1, -1):
-        ux[e] = ux[e + 1] - strain[e] * L[e]
+    ux[k + 1:] = np.cumsum(dux[k:])
+    if k > 0:
+        ux[:k] = -np.cumsum(dux[:k][::-1])[::-1]
     return (T_left, T_right), ux
 
 
@@ -326,13 +421,18 @@ def analyze(n_steps=1):
         d._arrays = a
         _queue.append(d)
         return 0
-    dev = d.device
-    t = lambda z, dt=torch.float64: torch.as_tensor(np.ascontiguousarray(z), dtype=dt, device=dev)  # noqa: E731
-    sol = beam_solve(t(a["x"]), t(a["E"][None, :]), t(a["I"][None, :]), t(a["fix"], torch.uint8), t(a["Fy"][None, :]),
-                     t(a["wy"][None, :]))
-    st = int(sol.status[0])     # device sync: the per-case API hands results back as Python scalars
-    return _finish(d, a, sol.v[0].cpu().numpy(), sol.theta[0].cpu().numpy(), sol.V[0].cpu().numpy(),
-                   sol.M[0].cpu().numpy(), st)
+    dev = torch.device(d.device)
+    if dev.index is None:
+        dev = torch.device("cuda", torch.cuda.current_device())
+    N = len(a["x"])
+    stage = _STAGES.get((dev, N))
+    if stage is None:
+        if len(_STAGES) >= 8:
+            _STAGES.clear()
+        stage = _STAGES[(dev, N)] = _Stage(dev, N)
+    with torch.cuda.device(dev):
+        r, st = stage.solve(a, dev)
+    return _finish(d, a, r["v"], r["theta"], r["V"], r["M"], st)
 
 
 def eleResponse(ele_tag, what):
