@@ -378,7 +378,7 @@ def frames_measure(dev, rank, local_rank, world, bays, stories, B, K, W):
             check_err = max(check_err, ed, ef)
             checked += 1
     lib = _cabi.load()
-    ws_frame = int(lib.ops_frame_workspace_bytes(2, topo.n_eq, topo.kd)) - int(lib.ops_frame_workspace_bytes(1, topo.n_eq, topo.kd))   # per frame (the call-wide assembly plan excluded)
+    ws_frame = int(lib.ops_frame_workspace_bytes(B + 1, topo.n_eq, topo.kd)) - int(lib.ops_frame_workspace_bytes(B, topo.n_eq, topo.kd))   # per frame (the call-wide assembly plan excluded)
     # ALGORITHMIC bytes per frame: I in; disp [Nn,3], forces [Ne,6], V, M out -- what a solve that kept its factor on chip would move
     io_frame = 8 * (topo.Ne + 3 * topo.Nn + 8 * topo.Ne)
     us = dev_ms / K * 1e3

@@ -660,8 +660,25 @@ static bool use_tile_kernel() {
 // Does the wave-per-frame kernel serve this size?  Its four waves' LDS (right-hand sides + parking areas) must fit one CU, its
 // plan kernel one workgroup's LDS.  Frames beyond that (tall and narrow: thousands of equations) take the workgroup-per-frame
 // kernels, whose band streams through an LDS ring -- ops_frame_workspace_bytes and the solve decide with this one function.
-static bool wave_kernel_serves(int n_eq, int kd) {
+// r05: batches of at most one frame per CU are LATENCY-bound, and there a workgroup per frame (r01 kernels: the whole workgroup works on
+// the one frame its CU has) answers sooner than a wave per frame (one wave works, the CU's other 15 wave slots idle): 10 x 10 118 us against
+// 207 - 221 us for 1 .. 256 frames, 5 x 5 47 / 84, 3 x 3 36 / 55, 15 x 16 (band in HBM) 472 - 492 / 535 - 576; at 1 024 frames the wave kernel is ahead
+// (10 x 10: 231 / 426 us) (scripts/frame_small_batch_ab.py).  That is the reference's own use of the frame solve -- ONE frame per epoch
+// (FR:178-183) -- and the command shim's.  OPS_AMD_FRAME_LATENCY_BATCH overrides the threshold (0: wave kernel for every batch).
+static int latency_batch() {
+  const char* e = getenv("OPS_AMD_FRAME_LATENCY_BATCH");
+  return e ? atoi(e) : 256;
+}
+static bool legacy_kernels_serve(int n_eq, int kd) {
+  if (kd > 63) return false;
+  if (frame_lds_resident_bytes(n_eq, kd) <= LDS_MAX) return true;
+  const size_t ring = ((size_t)(kd + 6) * frame_ld(kd) + (size_t)frame_n3(n_eq) + 2 * (size_t)FRAME_CH * frame_ld(kd)) * sizeof(double);
+  return ring <= LDS_MAX;
+}
+
+static bool wave_kernel_serves(int B, int n_eq, int kd) {
   if (!use_wave_kernel(kd)) return false;
+  if (B <= latency_batch() && legacy_kernels_serve(n_eq, kd)) return false;
   const int W = fw_width(kd);
   // (the opt-in tile variant parks rows at a wider pitch: its LDS need counts only when it is switched on -- sized by it unconditionally,
   //  frames of ~4 100-4 700 equations that the default kernel serves fell back to the workgroup-per-frame kernels: ADVICE r04)
@@ -708,7 +725,7 @@ static hipError_t launch_wave(const FrameParams& p, double* ws, hipStream_t s) {
 extern "C" size_t ops_frame_workspace_bytes(int B, int n_eq, int half_bandwidth) {
   half_bandwidth = eff_kd(half_bandwidth);
   if (half_bandwidth > 63) return (size_t)B * frame_lds_resident_bytes(n_eq, half_bandwidth);      // frame_wide_kernel: the band always lives in HBM
-  if (wave_kernel_serves(n_eq, half_bandwidth))     // per frame: band / factor rows; once: the assembly plan (at most 21 entries and 72 coefficients per element)
+  if (wave_kernel_serves(B, n_eq, half_bandwidth))     // per frame: band / factor rows; once: the assembly plan (at most 21 entries and 72 coefficients per element)
     return B == 0 ? 0 : (size_t)B * fw_frame_doubles(n_eq, half_bandwidth) * sizeof(double) + fw_plan_bytes(n_eq, 4 * n_eq + 64);
   if (frame_lds_resident_bytes(n_eq, half_bandwidth) <= LDS_MAX && !force_ws()) return 0;   // the band lives in LDS
   return (size_t)B * frame_lds_resident_bytes(n_eq, half_bandwidth);
@@ -762,7 +779,7 @@ extern "C" int ops_frame_solve_batched_f64(int B, int n_nodes, int n_elems, int 
     hipLaunchKernelGGL(frame_wide_kernel, dim3((unsigned)B), dim3(1024), lds_wide, s, p, (double*)workspace);
     return hipGetLastError() == hipSuccess ? OPS_AMD_OK : OPS_AMD_ERR_LAUNCH;
   }
-  if (wave_kernel_serves(n_eq, kd)) {
+  if (wave_kernel_serves(B, n_eq, kd)) {
     const int W = fw_width(kd);
     const size_t need = (size_t)B * fw_frame_doubles(n_eq, kd) * sizeof(double) + fw_plan_bytes(n_eq, n_elems);
     if (!workspace || workspace_bytes < need) return OPS_AMD_ERR_INVALID_ARG;

@@ -21,7 +21,7 @@ for bays, stories, B in cases:
         frames.frame_solve(topo, I, out=sol)
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps
-    wsb = int(_cabi.load().ops_frame_workspace_bytes(2, topo.n_eq, topo.kd)) - int(_cabi.load().ops_frame_workspace_bytes(1, topo.n_eq, topo.kd))
+    wsb = int(_cabi.load().ops_frame_workspace_bytes(4097, topo.n_eq, topo.kd)) - int(_cabi.load().ops_frame_workspace_bytes(4096, topo.n_eq, topo.kd))
     print(json.dumps({"frame": f"{bays}x{stories}", "elements": topo.Ne, "n_eq": topo.n_eq, "half_bandwidth": topo.kd, "B": B,
                       "ms_per_launch": round(ms, 4), "frame_solves_per_s": B / ms * 1e3, "workspace_bytes_per_frame": wsb,
                       "hbm_GBs_at_2x_workspace": 2 * wsb * B / ms / 1e6}))

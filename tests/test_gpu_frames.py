@@ -10,6 +10,21 @@ from oracle import beam_oracle as bo  # noqa: E402
 from tests.helpers import relerr  # noqa: E402
 
 
+@pytest.fixture(autouse=True)
+def _wave_kernel_for_every_batch(monkeypatch):
+    """The tests of this file launch 2-6 frames and were written for the wave-per-frame kernel; since r05 a batch of at most 256 frames
+    takes the workgroup-per-frame kernels (latency: csrc/frame_solve.hip latency_batch).  0 = wave kernel for every batch; the tests that
+    take `dispatch` run both ways."""
+    monkeypatch.setenv("OPS_AMD_FRAME_LATENCY_BATCH", "0")
+
+
+@pytest.fixture(params=["wave", "latency"])
+def dispatch(request, monkeypatch):
+    if request.param == "latency":
+        monkeypatch.delenv("OPS_AMD_FRAME_LATENCY_BATCH", raising=False)      # the library's default: B <= 256 -> a workgroup per frame
+    return request.param
+
+
 def _oracle(topo, I):
     return bo.solve_model_3dof(topo.coords, topo.conn, topo.A, topo.E, I, topo.fix3, topo.nodal_loads, wy=topo.wy, wx=topo.wx)
 
@@ -20,7 +35,7 @@ def _kd_ok(topo, oracle_kd):
 
 
 @pytest.mark.parametrize("bays,stories", [(1, 1), (2, 3), (4, 2), (7, 5), (10, 10)])
-def test_grid_frames_vs_oracle(bays, stories):
+def test_grid_frames_vs_oracle(dispatch, bays, stories):
     if not torch.cuda.is_available():
         pytest.fail("no GPU visible")
     from openpystruct_amd import frames
@@ -74,7 +89,7 @@ def test_register_tile_mapping_of_the_window_vs_oracle(monkeypatch, bays, storie
     assert relerr(bad.disp[0].cpu().numpy().ravel(), sol.disp[0].cpu().numpy().ravel()) < 1e-12
 
 
-def test_frame_equilibrium_and_axial_udl_quirk():
+def test_frame_equilibrium_and_axial_udl_quirk(dispatch):
     from openpystruct_amd import frames
     cfg = frames.FrameConfig()
     topo = frames.grid_frame(3, 2, cfg)
@@ -91,7 +106,7 @@ def test_frame_equilibrium_and_axial_udl_quirk():
     assert base[:, 1].sum() == pytest.approx(-applied_y, rel=1e-9)
 
 
-def test_frame_status_and_half_bandwidths_beyond_the_wave():
+def test_frame_status_and_half_bandwidths_beyond_the_wave(dispatch):
     from openpystruct_amd import frames
     topo = frames.grid_frame(2, 2)
     I = torch.full((3, topo.Ne), 5e-4, dtype=torch.float64, device="cuda")
@@ -155,7 +170,7 @@ def test_reverse_cuthill_mckee_numbering_vs_oracle(bays, stories, kd_node, kd_rc
 
 
 @pytest.mark.parametrize("bays,stories", [(15, 16), (13, 13), (18, 20)])
-def test_large_frames_band_in_hbm_workspace(bays, stories):
+def test_large_frames_band_in_hbm_workspace(dispatch, bays, stories):
     """BASELINE config 5 size (15 x 16 = 496 elements): the band no longer fits LDS and streams through a window."""
     from openpystruct_amd import _cabi, frames
     topo = frames.grid_frame(bays, stories)
@@ -184,7 +199,7 @@ def test_frame_sizing_loop_runs_like_the_reference():
     assert torch.allclose(I[0], I[7])          # identical problems -> identical trajectories, whatever the batch slot
 
 
-def test_ops_shim_runs_setup_frame_model():
+def test_ops_shim_runs_setup_frame_model(dispatch):
     """The reference's frame script drives the same command API (FR:75-139, :151, :181-183): re-typed here."""
     from openpystruct_amd import frames, ops
     cfg = frames.FrameConfig()
@@ -250,7 +265,7 @@ def _custom_frame(bays, stories, pinned, brace):
 
 @pytest.mark.parametrize("bays,stories,pinned,brace", [(1, 1, True, False), (2, 2, True, True), (3, 4, True, True),
                                                         (6, 5, True, False), (9, 9, True, True), (1, 5, False, True)])
-def test_general_topologies_vs_oracle(bays, stories, pinned, brace):
+def test_general_topologies_vs_oracle(dispatch, bays, stories, pinned, brace):
     from openpystruct_amd import frames
     topo = _custom_frame(bays, stories, pinned, brace)
     if pinned:
@@ -267,7 +282,7 @@ def test_general_topologies_vs_oracle(bays, stories, pinned, brace):
         assert relerr(sol.forces[b].cpu().numpy().ravel(), f.ravel()) < 1e-7
 
 
-def test_hub_node_with_eighteen_elements_takes_the_extra_plan_blocks():
+def test_hub_node_with_eighteen_elements_takes_the_extra_plan_blocks(dispatch):
     """A node with eighteen incident elements: its row group holds more than the 192 assembly entries of one plan block
     (csrc/frame_wave.hpp FW_EPG), so the solve walks the group's extra blocks -- the path the grid frames never take."""
     from openpystruct_amd import frames
@@ -303,7 +318,7 @@ def test_hub_node_with_eighteen_elements_takes_the_extra_plan_blocks():
 
 
 @pytest.mark.parametrize("skip,kd", [(2, 8), (4, 14), (7, 23), (10, 32), (12, 38), (16, 50), (17, 53)])
-def test_ladder_frames_cover_every_window_width(skip, kd):
+def test_ladder_frames_cover_every_window_width(dispatch, skip, kd):
     """Chains whose node i is also tied to node i + skip: half bandwidth 3 skip + 2, so every compiled register-window
     width of the wave kernel (16, 24, 36, 52, 56) and the multiples of eight (a row group enters exactly when the window
     reaches it) meet the oracle on a frame whose equation count is not a multiple of the group size."""
@@ -330,7 +345,7 @@ def test_ladder_frames_cover_every_window_width(skip, kd):
         assert relerr(sol.forces[b].cpu().numpy().ravel(), f.ravel()) < 1e-7
 
 
-def test_tiny_bandwidth_cantilever_chain():
+def test_tiny_bandwidth_cantilever_chain(dispatch):
     """A single cantilever of 40 collinear elements: half bandwidth 5; and a two-node model: half bandwidth 2 < 3."""
     from openpystruct_amd import frames
     for nel in (40, 1):
@@ -347,7 +362,7 @@ def test_tiny_bandwidth_cantilever_chain():
         assert relerr(sol.forces[1].cpu().numpy().ravel(), f.ravel()) < 1e-7
 
 
-def test_l_shaped_cantilever_closed_form_on_the_gpu():
+def test_l_shaped_cantilever_closed_form_on_the_gpu(dispatch):
     """Statically determinate L (clamped column + arm, vertical tip load): the HIP frame solve against the closed form."""
     from openpystruct_amd import frames
     h, a, P = 4.0, 3.0, -2.0e4
@@ -368,7 +383,7 @@ def test_l_shaped_cantilever_closed_form_on_the_gpu():
 
 
 @pytest.mark.parametrize("bays,stories", [(2, 2), (3, 2)])
-def test_frame_sizing_loop_vs_per_frame_oracle(bays, stories):
+def test_frame_sizing_loop_vs_per_frame_oracle(dispatch, bays, stories):
     """`frames.optimize_frames` against the per-frame restatement of FR:141-206 (oracle/frame_sizing_oracle.py: the
     reference's own torch calls around the 3-DOF band solve): inertias after each of the first epochs to float32 rounding
     (rtol 2e-5: float32 accumulation order differs -- the script adds element by element, the kernel reduces in a tree),
@@ -400,7 +415,7 @@ def test_frame_sizing_loop_vs_per_frame_oracle(bays, stories):
         np.testing.assert_allclose(I[b].cpu().numpy(), ref[b]["I"], rtol=2e-3)
 
 
-def test_frame_sizing_first_epochs_on_the_largest_frame_the_reference_draws():
+def test_frame_sizing_first_epochs_on_the_largest_frame_the_reference_draws(dispatch):
     """10 x 10 bays x stories (FR:17-18: the upper end of the script's random range; 210 elements, 330 equations): the first five
     epochs of `optimize_frames` against the per-frame restatement of FR:141-206, inertias to float32 rounding."""
     from openpystruct_amd import frames
@@ -602,3 +617,31 @@ def test_two_columns_per_elimination_step_vs_oracle_and_default(monkeypatch, bay
     torch.cuda.synchronize()
     st = bad.status.cpu().numpy()
     assert st[2] == 1 and st[[0, 1, 3, 4, 5]].sum() == 0
+
+
+def test_small_batches_take_a_workgroup_per_frame_and_large_ones_a_wave(monkeypatch):
+    """The dispatch itself (r05): <= 256 frames need no factor workspace when the band fits LDS (workgroup-per-frame kernels), 257 do
+    (wave-per-frame kernel); both agree with the oracle and with each other to rounding, frame by frame."""
+    if not torch.cuda.is_available():
+        pytest.fail("no GPU visible")
+    from openpystruct_amd import _cabi, frames
+    monkeypatch.delenv("OPS_AMD_FRAME_LATENCY_BATCH", raising=False)
+    lib = _cabi.load()
+    topo = frames.grid_frame(6, 5)
+    assert int(lib.ops_frame_workspace_bytes(256, topo.n_eq, topo.kd)) == 0 and int(lib.ops_frame_workspace_bytes(257, topo.n_eq, topo.kd)) > 0
+    rng = np.random.default_rng(256)
+    I = np.exp(rng.uniform(np.log(1e-4), np.log(5e-3), size=(257, topo.Ne)))
+    Id = torch.as_tensor(I, device="cuda")
+    big = frames.frame_solve(topo, Id)
+    small = frames.frame_solve(topo, Id[:256].contiguous())
+    assert int(big.status.abs().sum()) == 0 and int(small.status.abs().sum()) == 0
+    a, b = big.disp[:256].cpu().numpy(), small.disp.cpu().numpy()
+    assert np.abs(a - b).max() <= 1e-11 * np.abs(a).max()
+    for k in (0, 100, 255):
+        d, f, st, _, _ = _oracle(topo, I[k])
+        assert st == 0
+        for sol, kk in ((big, k), (small, k)):
+            assert np.abs(sol.disp[kk].cpu().numpy() - d).max() <= 1e-7 * np.abs(d).max()
+            assert np.abs(sol.forces[kk].cpu().numpy() - f).max() <= 1e-6 * np.abs(f).max()
+    monkeypatch.setenv("OPS_AMD_FRAME_LATENCY_BATCH", "0")
+    assert int(lib.ops_frame_workspace_bytes(1, topo.n_eq, topo.kd)) > 0
