@@ -665,9 +665,16 @@ static bool use_tile_kernel() {
 // 207 - 221 us for 1 .. 256 frames, 5 x 5 47 / 84, 3 x 3 36 / 55, 15 x 16 (band in HBM) 472 - 492 / 535 - 576; at 1 024 frames the wave kernel is ahead
 // (10 x 10: 231 / 426 us) (scripts/frame_small_batch_ab.py).  That is the reference's own use of the frame solve -- ONE frame per epoch
 // (FR:178-183) -- and the command shim's.  OPS_AMD_FRAME_LATENCY_BATCH overrides the threshold (0: wave kernel for every batch).
-static int latency_batch() {
-  const char* e = getenv("OPS_AMD_FRAME_LATENCY_BATCH");
-  return e ? atoi(e) : 256;
+// Above one frame per CU the workgroup kernels saturate at ~8.5e11 / (n kd^2) frames per second (10 x 10: 2.4e6, 5 x 5: 3.5e7) while a launch
+// of the wave kernel never takes less than ~25 us + 0.55 us per equation (one wave's chain: 10 x 10 207 us, 5 x 5 84 us): the batch at which
+// the two meet -- 10 x 10: ~500 frames, 5 x 5: ~2 500 -- is the threshold, at least 256 (one frame per CU) and at most 4 000 (the smallest
+// frames meet at ~4 096 whatever the model says).  scripts/frame_dispatch_sweep.py: the choice is within 6 % of the faster kernel for 3 x 3 ..
+// 15 x 16 frames and 128 .. 16 384 frames per launch.
+static int latency_batch(int n_eq, int kd) {
+  if (const char* e = getenv("OPS_AMD_FRAME_LATENCY_BATCH")) return atoi(e);
+  const double wave_floor_s = 25e-6 + 0.55e-6 * n_eq, legacy_rate = 8.5e11 / ((double)n_eq * kd * kd);
+  const double b = wave_floor_s * legacy_rate;
+  return b < 256.0 ? 256 : b > 4000.0 ? 4000 : (int)b;
 }
 static bool legacy_kernels_serve(int n_eq, int kd) {
   if (kd > 63) return false;
@@ -678,7 +685,7 @@ static bool legacy_kernels_serve(int n_eq, int kd) {
 
 static bool wave_kernel_serves(int B, int n_eq, int kd) {
   if (!use_wave_kernel(kd)) return false;
-  if (B <= latency_batch() && legacy_kernels_serve(n_eq, kd)) return false;
+  if (B <= latency_batch(n_eq, kd) && legacy_kernels_serve(n_eq, kd)) return false;
   const int W = fw_width(kd);
   // (the opt-in tile variant parks rows at a wider pitch: its LDS need counts only when it is switched on -- sized by it unconditionally,
   //  frames of ~4 100-4 700 equations that the default kernel serves fell back to the workgroup-per-frame kernels: ADVICE r04)

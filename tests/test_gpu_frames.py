@@ -620,17 +620,20 @@ def test_two_columns_per_elimination_step_vs_oracle_and_default(monkeypatch, bay
 
 
 def test_small_batches_take_a_workgroup_per_frame_and_large_ones_a_wave(monkeypatch):
-    """The dispatch itself (r05): <= 256 frames need no factor workspace when the band fits LDS (workgroup-per-frame kernels), 257 do
-    (wave-per-frame kernel); both agree with the oracle and with each other to rounding, frame by frame."""
+    """The dispatch itself (r05): <= 256 frames (and more of a small frame: the batch at which the two kernels meet, at most 4 000) need no
+    factor workspace when the band fits LDS (workgroup-per-frame kernels), 8 193 do (wave-per-frame kernel); both agree with the oracle and
+    with each other to rounding, frame by frame."""
     if not torch.cuda.is_available():
         pytest.fail("no GPU visible")
     from openpystruct_amd import _cabi, frames
     monkeypatch.delenv("OPS_AMD_FRAME_LATENCY_BATCH", raising=False)
     lib = _cabi.load()
     topo = frames.grid_frame(6, 5)
-    assert int(lib.ops_frame_workspace_bytes(256, topo.n_eq, topo.kd)) == 0 and int(lib.ops_frame_workspace_bytes(257, topo.n_eq, topo.kd)) > 0
+    assert int(lib.ops_frame_workspace_bytes(256, topo.n_eq, topo.kd)) == 0 and int(lib.ops_frame_workspace_bytes(8193, topo.n_eq, topo.kd)) > 0
+    big10 = frames.grid_frame(10, 10)                     # the largest frame the script draws: the two meet at ~500 frames
+    assert int(lib.ops_frame_workspace_bytes(256, big10.n_eq, big10.kd)) == 0 and int(lib.ops_frame_workspace_bytes(1024, big10.n_eq, big10.kd)) > 0
     rng = np.random.default_rng(256)
-    I = np.exp(rng.uniform(np.log(1e-4), np.log(5e-3), size=(257, topo.Ne)))
+    I = np.exp(rng.uniform(np.log(1e-4), np.log(5e-3), size=(8193, topo.Ne)))
     Id = torch.as_tensor(I, device="cuda")
     big = frames.frame_solve(topo, Id)
     small = frames.frame_solve(topo, Id[:256].contiguous())
