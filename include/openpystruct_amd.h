@@ -225,6 +225,9 @@ int ops_physics_loss_bwd(const ops_physics_loss_args* args, void* stream);
  * The assembled band and, over it, the factor live in a caller-provided device workspace of
  * ops_frame_workspace_bytes(B, n_eq, half_bandwidth) bytes (about (n_eq + 80) * (half_bandwidth + 2) * 8 per frame; the
  * kernels keep the sliding window in registers, one wavefront per frame).  ERR_INVALID_ARG when it is NULL or too small.
+ * Small batches (up to the batch at which the two kernel families meet: 256 .. 4 000 frames by frame size; the reference's one frame per
+ * epoch) take the workgroup-per-frame kernels, which keep the band in LDS when it fits: ops_frame_workspace_bytes is then 0 and
+ * `workspace` may be NULL -- always size the workspace with the B of the call.
  * half_bandwidth <= 55: the tuned path; 56..63: the workgroup-per-frame kernels; 64..1024 (more than 20 bays and stories: beyond
  * the reference's range): a plain column-by-column fallback on the band in the workspace, milliseconds per frame;
  * ERR_UNSUPPORTED beyond that or when one right-hand side and one column do not fit 160 KB of LDS. */
