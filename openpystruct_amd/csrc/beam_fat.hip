@@ -28,9 +28,6 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#include <stdlib.h>
-
-#include <atomic>
 #include <type_traits>
 
 #include "../../include/openpystruct_amd.h"
@@ -152,59 +149,37 @@ __device__ __forceinline__ unsigned mask_window(unsigned long long lo, unsigned 
 // SIZING (LEAN only): the inertias are the optimiser's float32 rows; after the solve the wave runs the optimiser epoch of
 // its cases on the shears / moments it holds in LDS (sizing_math.hpp) instead of storing them: the generator's fused
 // solve + step (SingleCore.py:174-219), as beam_solve.hip's beam_sizing_epoch_kernel.
-// LDS of one wave of a row tiling, in doubles (the mixed launch below carves its workgroup's LDS with it)
-template <int P, int M>
-struct RowsLds {
-  static constexpr int BPW = 64 / P, PM = P * M, ROWS = BPW * PM;
-  static constexpr int TAB = 0, A = 6 * PM, B = A + ROWS, MV = B + ROWS, DUMMY = MV + 4, TOTAL = (DUMMY + M + 1) & ~1;
-};
-
-// MULTI: the wave is one of several of a workgroup (beam_rows_mixed_kernel): its LDS is the slice `lds_wave`, its lane and first
-// beam come from the caller, and nothing synchronises across waves.
-template <int P, int M, int WPS, bool FAT, bool SIZING, bool MULTI = false>
-__device__ __forceinline__ void beam_rows_body(const BeamParams& p, const SizingArgs* sz, double* lds_wave = nullptr, unsigned lane_in = 0,
-                                               long beam0_in = 0) {
+template <int P, int M, int WPS, bool FAT, bool SIZING>
+__device__ __forceinline__ void beam_rows_body(const BeamParams& p, const SizingArgs* sz) {
   constexpr int BPW = 64 / P;       // beams per wavefront
   constexpr int LIVE = BPW * P;     // lanes that own a segment
   constexpr int PM = P * M;         // padded nodes per beam (>= N); a row is one wave instruction of 16-byte lanes
   constexpr int NT = (PM + 63) / 64;
   constexpr int ROWS = BPW * PM;
   static_assert(PM <= 128 && PM % 2 == 0 && M + 1 <= 32, "row tiling limits");
-  static_assert(FAT || ((16 % P == 0 || P == 32) && LIVE == 64), "the lean mapping exchanges over DPP rows (32 lanes: the LDS crossbar, Xch<32>)");
-  static_assert(!MULTI || (!FAT && !SIZING), "the mixed launch runs plain lean solves");
+  static_assert(FAT || (16 % P == 0 && LIVE == 64), "the lean mapping exchanges over DPP rows");
   constexpr int PF = FAT ? 3 : 1;   // prefetch distance of the interior solve (a lone wave hides nothing behind a partner)
 #ifdef OPS_AMD_ST
   constexpr int ST = OPS_AMD_ST;
 #else
   constexpr int ST = 16;            // sc1 (write-through); p.stream_out selects nt
 #endif
-  double *s_tab, *s_a, *s_b, *s_m, *s_v, *s_dummy;
-  if constexpr (MULTI) {
-    using L = RowsLds<P, M>;
-    s_tab = lds_wave + L::TAB; s_a = lds_wave + L::A; s_b = lds_wave + L::B; s_m = lds_wave + L::MV; s_v = lds_wave + L::MV + 2;
-    s_dummy = lds_wave + L::DUMMY;
-  } else {
-    __shared__ double t_tab[6 * PM];
-    __shared__ __attribute__((aligned(16))) double t_a[ROWS];   // I                  -> theta
-    __shared__ __attribute__((aligned(16))) double t_b[ROWS];   // Fy                 -> V
-    __shared__ __attribute__((aligned(16))) double t_m[FAT ? ROWS : 2];   // FAT: pieces, h.x of the sweep -> M   (LEAN: M -> s_a)
-    __shared__ __attribute__((aligned(16))) double t_v[FAT ? ROWS : 2];   // FAT: h.y of the sweep         -> v   (LEAN: v -> s_b)
-    __shared__ double t_dummy[M];                               // what the idle lanes write to
-    s_tab = t_tab; s_a = t_a; s_b = t_b; s_m = t_m; s_v = t_v; s_dummy = t_dummy;
-    // FAT: more than 32 KB and at most 40 KB per one-wave workgroup = four, never five, workgroups per CU
-    static_assert((6 * PM + (FAT ? 4 : 2) * ROWS + M + 4) * 8 <= 160 * 1024 / (4 * WPS), "LDS per one-wave workgroup");
-    static_assert(!FAT || (WPS == 1 && (6 * PM + 4 * ROWS) * 8 > 32 * 1024), "the fat tiling relies on LDS to keep a fifth wave off the CU");
-  }
+  __shared__ double s_tab[6 * PM];
+  __shared__ __attribute__((aligned(16))) double s_a[ROWS];   // I                  -> theta
+  __shared__ __attribute__((aligned(16))) double s_b[ROWS];   // Fy                 -> V
+  __shared__ __attribute__((aligned(16))) double s_m[FAT ? ROWS : 2];   // FAT: pieces, h.x of the sweep -> M   (LEAN: M -> s_a)
+  __shared__ __attribute__((aligned(16))) double s_v[FAT ? ROWS : 2];   // FAT: h.y of the sweep         -> v   (LEAN: v -> s_b)
+  __shared__ double s_dummy[M];                               // what the idle lanes write to
+  // FAT: more than 32 KB and at most 40 KB per one-wave workgroup = four, never five, workgroups per CU
+  static_assert((6 * PM + (FAT ? 4 : 2) * ROWS + M + 4) * 8 <= 160 * 1024 / (4 * WPS), "LDS per one-wave workgroup");
+  static_assert(!FAT || (WPS == 1 && (6 * PM + 4 * ROWS) * 8 > 32 * 1024), "the fat tiling relies on LDS to keep a fifth wave off the CU");
 
-  const unsigned lane = MULTI ? lane_in : threadIdx.x;
+  const unsigned lane = threadIdx.x;
   unsigned long long stamps[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // diagnostic builds (-DOPS_AMD_TRACE) only
   FAT_STAMP(0);
   const int Ne = p.Ne, N = p.Ne + 1;
-  const long beam0 = MULTI ? beam0_in : (long)blockIdx.x * BPW;
+  const long beam0 = (long)blockIdx.x * BPW;
   const int nb = (p.B - beam0 < BPW) ? (int)(p.B - beam0) : BPW;   // live beams of this wave
-  if constexpr (MULTI) {
-    if (nb <= 0) return;            // a wave past the last beam (no workgroup barrier anywhere in this body)
-  }
   if (p.active) {                   // wave-uniform: finished cases of a sizing run cost one scalar load each
     unsigned any = 0;
     for (int b = 0; b < nb; ++b) any |= p.active[beam0 + b];
@@ -307,7 +282,7 @@ __device__ __forceinline__ void beam_rows_body(const BeamParams& p, const Sizing
   }
   if ((Ne & 1) && (int)lane < nb) s_a[lane * PM + Ne - 1] = tI;
   if ((N & 1) && (int)lane < nb) s_b[lane * PM + N - 1] = tF;
-  if constexpr (MULTI) wave_lds_fence(); else __syncthreads();
+  __syncthreads();
   FAT_STAMP(1);
 
   // ---- stages 2-4 ----
@@ -442,37 +417,6 @@ __global__ __launch_bounds__(64, WPS) void beam_rows_sizing_kernel(const BeamPar
   beam_rows_body<P, M, WPS, false, true>(p, &sz);
 }
 
-// ---- r05: TWO wave sizes in one launch ----
-// 10^4 beams as 2 500 four-beam waves leave 452 of the 1 024 SIMDs with three waves and the rest with two: the launch lasts as long as
-// three waves' instructions (3 x 1 469 VALU).  Here a workgroup is TWELVE waves = 40 beams = what one CU should carry (250 workgroups for
-// 10^4 beams, one per CU): waves 0-7 are four-beam waves (16 lanes x 7 elements), waves 8-11 two-beam waves (32 lanes x 4 elements,
-// interface rows over the LDS crossbar, ~1 220 VALU).  The hardware deals a workgroup's waves round the four SIMDs, so every SIMD holds two
-// four-beam waves and one two-beam wave = 10 beams: 2 x 1 469 + 1 220 instead of 3 x 1 469 on the busiest SIMD, and no SIMD idles a third of
-// the launch.  Same arithmetic per beam as the tilings it is made of (beam_math.hpp); waves never synchronise with each other.
-constexpr int MIX_BIG = 8, MIX_SMALL = 4, MIX_BEAMS = 4 * MIX_BIG + 2 * MIX_SMALL;
-constexpr int MIX_LDS_DOUBLES = MIX_BIG * RowsLds<16, 7>::TOTAL + MIX_SMALL * RowsLds<32, 4>::TOTAL;
-static_assert(MIX_LDS_DOUBLES * 8 <= 160 * 1024 - 64, "one mixed workgroup per CU");
-__global__ __launch_bounds__(64 * (MIX_BIG + MIX_SMALL)) void beam_rows_mixed_kernel(const BeamParams p, int stagger, int order) {
-  extern __shared__ __attribute__((aligned(16))) double mix_lds[];
-  const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63u;
-  const long base = (long)blockIdx.x * MIX_BEAMS;
-  // the twelve waves of a workgroup start in the same cycle; one-wave workgroups are dealt out over time.  OPS_AMD_MIX_STAGGER (units of
-  // ~0.43 us) delays the second and third wave of every SIMD so that their load / arithmetic / store phases overlap as they do there
-  {
-    const unsigned slot = wave >> 2;                                      // 0, 1: four-beam waves, 2: the two-beam wave of the SIMD
-    const unsigned rank = order == 0 ? slot : order == 1 ? 2u - slot : (slot == 2u ? 0u : slot + 1u);
-    for (int i = 0; i < (int)rank * stagger; ++i) __builtin_amdgcn_s_sleep(16);
-    if (order == 10 && wave >= MIX_BIG) return;      // (diagnostic: only the four-beam waves / only the two-beam waves run -- results incomplete)
-    if (order == 11 && wave < MIX_BIG) return;
-    if (order == 12 && wave >= 4) return;            // one four-beam wave per SIMD
-  }
-  if (wave < MIX_BIG)
-    beam_rows_body<16, 7, 3, false, false, true>(p, nullptr, mix_lds + wave * RowsLds<16, 7>::TOTAL, lane, base + 4 * wave);
-  else
-    beam_rows_body<32, 4, 3, false, false, true>(p, nullptr, mix_lds + MIX_BIG * RowsLds<16, 7>::TOTAL + (wave - MIX_BIG) * RowsLds<32, 4>::TOTAL,
-                                                 lane, base + 4 * MIX_BIG + 2 * (wave - MIX_BIG));
-}
-
 // ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
@@ -480,7 +424,6 @@ const FatTiling kFatTilings[] = {
     {6, 17, "beam_rows_kernel<6, 17, 1, true>"},
     {16, 7, "beam_rows_kernel<16, 7, 3, false>"},
     {8, 13, "beam_rows_kernel<8, 13, 2, false>"},
-    {40, 0, "beam_rows_mixed_kernel (8 x <16, 7> + 4 x <32, 4> waves per workgroup)"},      // serves Ne + 1 <= 112; explicit `tiling = 40 | ROWS`
 };
 const int kNumFatTilings = sizeof(kFatTilings) / sizeof(kFatTilings[0]);
 
@@ -492,27 +435,11 @@ hipError_t launch_fat_sizing(const BeamParams& p, const SizingArgs& sz, int P, i
 }
 
 hipError_t launch_fat(const BeamParams& p, int P, int M, hipStream_t stream) {
-  const int bpw = P <= 64 ? 64 / P : 1;
+  const int bpw = 64 / P;
   const unsigned grid = (unsigned)((p.B + bpw - 1) / bpw);
   if (P == 6 && M == 17) hipLaunchKernelGGL((beam_rows_kernel<6, 17, 1, true>), dim3(grid), dim3(64), 0, stream, p);
   else if (P == 16 && M == 7) hipLaunchKernelGGL((beam_rows_kernel<16, 7, 3, false>), dim3(grid), dim3(64), 0, stream, p);
   else if (P == 8 && M == 13) hipLaunchKernelGGL((beam_rows_kernel<8, 13, 2, false>), dim3(grid), dim3(64), 0, stream, p);
-  else if (P == 40) {
-    static std::atomic<unsigned long long> done{0};
-    int devid = 0;
-    hipError_t e = hipGetDevice(&devid);
-    if (e != hipSuccess) return e;
-    const unsigned long long bit = 1ull << (devid & 63);
-    if (!(done.load(std::memory_order_acquire) & bit)) {
-      e = hipFuncSetAttribute((const void*)beam_rows_mixed_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, MIX_LDS_DOUBLES * 8);
-      if (e != hipSuccess) return e;
-      done.fetch_or(bit, std::memory_order_release);
-    }
-    const char* es = getenv("OPS_AMD_MIX_STAGGER");
-    const char* eo = getenv("OPS_AMD_MIX_ORDER");
-    hipLaunchKernelGGL(beam_rows_mixed_kernel, dim3((unsigned)((p.B + MIX_BEAMS - 1) / MIX_BEAMS)), dim3(64 * (MIX_BIG + MIX_SMALL)), MIX_LDS_DOUBLES * 8, stream, p,
-                       es ? atoi(es) : 0, eo ? atoi(eo) : 0);
-  }
   else return hipErrorInvalidValue;
   return hipGetLastError();
 }

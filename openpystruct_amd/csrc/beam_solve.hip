@@ -497,7 +497,7 @@ static const FatTiling* choose_fat(int B, int Ne, int tiling) {
   tiling &= ~OPS_AMD_TILING_ROWS;
   for (int t = 0; t < kNumFatTilings; ++t) {
     const FatTiling& f = kFatTilings[t];
-    const bool serves = f.P == 40 ? N <= 16 * 7 : f.P * f.M >= N;      // (40: the mixed launch of 16 x 7 and 32 x 4 waves, beam_fat.hip)
+    const bool serves = f.P * f.M >= N;
     if (tiling == f.P && (rows || f.P == 6)) return serves ? &f : nullptr;
     if (tiling == 0 && !rows && serves && fat_default(f, B, Ne)) return &f;
   }

@@ -17,8 +17,7 @@ from tests.helpers import kappa_scaled, relerr  # noqa: E402
 
 FAT = 6
 ROWS = 0x200     # OPS_AMD_TILING_ROWS: the row-staged variants of the 16- and 8-lane tilings
-MIXED = 40       # r05: 8 four-beam waves (16 x 7) + 4 two-beam waves (32 x 4) per workgroup
-VARIANTS = [FAT, 16 | ROWS, 8 | ROWS, MIXED | ROWS]
+VARIANTS = [FAT, 16 | ROWS, 8 | ROWS]
 
 
 @pytest.fixture(scope="module")
@@ -46,7 +45,6 @@ def test_kernel_names(oa):
     assert "beam_rows_kernel<6, 17, 1, true>" in oa.kernel_name(10000, 100, FAT)
     assert "beam_rows_kernel<16, 7, 3, false>" in oa.kernel_name(10000, 100, 16 | ROWS)
     assert "beam_rows_kernel<8, 13, 2, false>" in oa.kernel_name(10000, 100, 8 | ROWS)
-    assert "beam_rows_mixed_kernel" in oa.kernel_name(10000, 100, MIXED | ROWS)
 
 
 @pytest.mark.parametrize("til", VARIANTS)
