@@ -61,8 +61,8 @@ def test_argument_validation_without_gpu(lib):
     assert lib.ops_beam_sizing_epoch_f32(4, 200, z, 0, z, 0, z, 0, z, 201, z, 0, *([z] * 9), ctypes.byref(hp), z, z, 0, z) == _cabi.ERR_UNSUPPORTED
     assert lib.ops_frame_solve_batched_f64(2, 4, 3, 6, 5, *([z] * 8), 0, *([z] * 6), 0, z) == _cabi.ERR_INVALID_ARG
     # every frame size keeps its band / factor in the caller's workspace (wave-per-frame kernel): one row-major band + rhs per frame
-    assert lib.ops_frame_workspace_bytes(300, 330, 35) >= 300 * 330 * 37 * 8 and lib.ops_frame_workspace_bytes(3, 768, 50) >= 3 * 768 * 53 * 8
-    assert lib.ops_frame_workspace_bytes(3, 330, 35) == 0        # r05: <= 256 frames whose band fits LDS take the workgroup-per-frame kernels
+    assert lib.ops_frame_workspace_bytes(5000, 330, 35) >= 5000 * 330 * 37 * 8 and lib.ops_frame_workspace_bytes(3, 768, 50) >= 3 * 768 * 53 * 8
+    assert lib.ops_frame_workspace_bytes(3, 330, 35) == 0        # r05: small batches (<= 256 .. 4 000 frames by size) whose band fits LDS take the workgroup-per-frame kernels
     assert lib.ops_frame_workspace_bytes(0, 330, 35) == 0
     assert lib.ops_stencil3_bn1_fwd_f32(2, 3, z, z, z, z, z, 1e-5, 0.1, 1, z, z, z, z, 0, z, z, z) == _cabi.ERR_INVALID_ARG
     assert lib.ops_stencil3_bn1_bwd_f32(2, 3, z, z, 0, z, z, z, z, 1, z, z, z, z) == _cabi.ERR_INVALID_ARG
