@@ -70,6 +70,33 @@ def test_ops_shim_failure_code_and_deferred_batch(oa):
         assert relerr(d.result["v"], v) < 1e-9 and relerr(d.result["forces"][:, 2], M) < 1e-8
 
 
+def test_ops_shim_results_of_one_analyze_survive_the_next(oa):
+    """The batch-of-one path reuses one pinned staging block per mesh size (r05): what `analyze` hands to a domain must be a copy, so that
+    results read after a later `analyze` -- of another model of the same size, or of the same model with other inertias, the reference's
+    epoch loop -- are still the earlier model's; and a model of another size gets its own staging."""
+    from openpystruct_amd import ops
+    x = np.linspace(0, 10, 11)
+    fix = np.zeros(11, dtype=np.uint8); fix[0] = fix[10] = 1
+    Fy = np.zeros(11); Fy[4] = -1000.0
+    rng = np.random.default_rng(5)
+    kept = []
+    for k in range(4):
+        I = np.exp(rng.uniform(np.log(3e-3), np.log(0.75), size=10))
+        ops.wipe()
+        setup_model(I, x, [11], [5], [-1000.0], 0.01, 2e11, -10.0)
+        ops.analysis('Static')
+        assert ops.analyze(1) == 0
+        kept.append((I, ops._dom.result))
+        if k == 1:                                         # another mesh size in between
+            ops.wipe()
+            setup_model(np.full(20, 0.1), np.linspace(0, 10, 21), [21], [7], [-5.0], 0.01, 2e11, 0.0)
+            ops.analysis('Static')
+            assert ops.analyze(1) == 0 and len(ops._dom.result["v"]) == 21
+    for I, res in kept:
+        v, th, V, M, st = bo.solve_beam_dense(x, 2e11, I, fix, Fy, -10.0)
+        assert relerr(res["v"], v) < 1e-9 and relerr(res["th"], th) < 1e-9 and relerr(res["forces"][:, 2], M) < 1e-8
+
+
 @pytest.mark.parametrize("patience,n", [(5, 32), (10, 6)])       # 32 cases at patience 5: BASELINE config 1 (SingleCore.py:257)
 def test_sizing_loop_vs_per_case_oracle(oa, patience, n):
     """Batched loop (HIP solve + HIP optimiser step) vs the reference's per-case torch-CPU loop restated in
