@@ -331,7 +331,8 @@ def surrogate_epoch_times(dev, rank, world, epochs, cases=50000):
         return {"error": repr(e)}
 
 
-FRAME_BATCH = {"15x16": 12288, "10x10": 16384}       # frames per launch per GPU (the batches of profiles/*frames*_pmc_summary.json)
+FRAME_BATCH = {"15x16": 12288, "10x10": 16384, "5x5": 32768}       # frames per launch per GPU (the batches of profiles/*frames*_pmc_summary.json; 5 x 5: the
+                                                                    # middle of the script's random range, FR:17-18, one launch ~0.65 ms)
 
 
 def frames_measure(dev, rank, local_rank, world, bays, stories, B, K, W):
@@ -658,11 +659,11 @@ def main():
         # (12 untimed launches first: after the sub-millisecond launches above the first ~10 ms of 1 ms launches run 5-10 %
         #  slow -- clocks and TLBs of 5 GB of fresh buffers, measured with scripts/sat_ab.py)
         extras["saturating"] = sub_record(1 << 20, 10, 1, args.tiling, "2^20 beams per launch (5.2 GB per launch: HBM-resident by size)", warm=12)
-    # BASELINE config 5 on the same line: the batched frame solve at the reference's largest frame (10 x 10) and at the ~500-element one
-    # BASELINE names (15 x 16); <= 0.3 s each (20 launches of 1.5-4 ms)
+    # BASELINE config 5 on the same line: the batched frame solve at the reference's largest frame (10 x 10), at the ~500-element one
+    # BASELINE names (15 x 16) and at the middle of the script's range (5 x 5); <= 0.3 s each (20 launches of 0.65-4 ms)
     frames_rec = {}
     if not args.no_extras and args.sets <= 1 and B == 10000:
-        for fr in ("15x16", "10x10"):
+        for fr in ("15x16", "10x10", "5x5"):
             try:
                 fb, fs = (int(v) for v in fr.split("x"))
                 frames_rec[fr] = frames_measure(dev, rank, local_rank, world, fb, fs, FRAME_BATCH[fr], 20, 3)
