@@ -600,6 +600,7 @@ constexpr int FRAME_WIDE_MAX_KD = 1024;      // frame_wide_kernel's backward swe
 
 #include "frame_wave.hpp"
 #include "frame_tile.hpp"
+#include "frame_pack.hpp"
 
 using namespace opsamd;
 
@@ -695,6 +696,37 @@ static bool wave_kernel_serves(int B, int n_eq, int kd) {
   return true;
 }
 
+// r06: half bandwidths up to 27 -- 95 of the 100 (bays, stories) draws of FR:17-18 -- take the packed kernel (frame_pack.hpp: 16 or 32 lanes per
+// frame, 4 or 2 frames per wave) wherever the wave-per-frame kernel would have served.  OPS_AMD_FRAME_PACK=0: one wave per frame (A/B).
+static bool pack_kernel_serves(int B, int n_eq, int kd) {
+  int P, G, W;
+  if (!fp_config(kd, &P, &G, &W)) return false;
+  if (const char* e = getenv("OPS_AMD_FRAME_PACK")) if (atoi(e) == 0) return false;
+  if (!wave_kernel_serves(B, n_eq, kd) || !fused_assembly() || use_tile_kernel() || use_pair_steps(kd)) return false;
+  return 4 * (size_t)(64 / P) * fp_lds_doubles(n_eq, P, G, W) * sizeof(double) <= 160 * 1024 - 64;
+}
+
+template <int W, int P, int G>
+static hipError_t launch_pack(const FrameParams& p, double* ws, hipStream_t s) {
+  static std::atomic<unsigned long long> done{0};
+  int devid = 0;
+  hipError_t e = hipGetDevice(&devid);
+  if (e != hipSuccess) return e;
+  constexpr int F = 64 / P;
+  const size_t lds = 4 * (size_t)F * fp_lds_doubles(p.n_eq, P, G, W) * sizeof(double);
+  const unsigned long long bit = 1ull << (devid & 63);
+  if (!(done.load(std::memory_order_acquire) & bit)) {
+    e = hipFuncSetAttribute((const void*)frame_pack_kernel<W, P, G>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
+    if (e != hipSuccess) return e;
+    done.fetch_or(bit, std::memory_order_release);
+  }
+  void* plan_base = (char*)ws + (size_t)p.B * fp_frame_doubles(p.n_eq, W) * sizeof(double);
+  const FwPlan pl = fw_plan_at(plan_base, p.n_eq, p.Ne, G, fp_epg(G));
+  hipLaunchKernelGGL(frame_plan_kernel, dim3(1), dim3(1024), (size_t)3 * (fw_groups(p.n_eq, G) + 2) * sizeof(int), s, p, W, plan_base, 0, G, fp_epg(G));
+  hipLaunchKernelGGL((frame_pack_kernel<W, P, G>), dim3((unsigned)((p.B + 4 * F - 1) / (4 * F))), dim3(256), lds, s, p, ws, pl);
+  return hipGetLastError();
+}
+
 template <int W>
 static hipError_t launch_wave(const FrameParams& p, double* ws, hipStream_t s) {
   static std::atomic<unsigned long long> done{0};
@@ -715,10 +747,10 @@ static hipError_t launch_wave(const FrameParams& p, double* ws, hipStream_t s) {
   const FwPlan pl = fw_plan_at(plan_base, p.n_eq, p.Ne);
   const dim3 grid((unsigned)((p.B + 3) / 4));
   if (use_tile_kernel()) {
-    hipLaunchKernelGGL(frame_plan_kernel, dim3(1), dim3(1024), (size_t)3 * (fw_groups(p.n_eq) + 2) * sizeof(int), s, p, W, plan_base, 8 * ft_M(W));
+    hipLaunchKernelGGL(frame_plan_kernel, dim3(1), dim3(1024), (size_t)3 * (fw_groups(p.n_eq) + 2) * sizeof(int), s, p, W, plan_base, 8 * ft_M(W), FW_G, FW_EPG);
     hipLaunchKernelGGL((frame_tile_kernel<W>), grid, dim3(256), 4 * ft_lds_doubles(p.n_eq) * sizeof(double), s, p, ws, pl);
   } else if (fused_assembly()) {
-    hipLaunchKernelGGL(frame_plan_kernel, dim3(1), dim3(1024), (size_t)3 * (fw_groups(p.n_eq) + 2) * sizeof(int), s, p, W, plan_base, 0);
+    hipLaunchKernelGGL(frame_plan_kernel, dim3(1), dim3(1024), (size_t)3 * (fw_groups(p.n_eq) + 2) * sizeof(int), s, p, W, plan_base, 0, FW_G, FW_EPG);
     if (use_pair_steps(p.kd)) hipLaunchKernelGGL((frame_wave_kernel<W, true, true>), grid, dim3(256), lds, s, p, ws, pl);
     else hipLaunchKernelGGL((frame_wave_kernel<W, true>), grid, dim3(256), lds, s, p, ws, pl);
   } else {
@@ -732,6 +764,11 @@ static hipError_t launch_wave(const FrameParams& p, double* ws, hipStream_t s) {
 extern "C" size_t ops_frame_workspace_bytes(int B, int n_eq, int half_bandwidth) {
   half_bandwidth = eff_kd(half_bandwidth);
   if (half_bandwidth > 63) return (size_t)B * frame_lds_resident_bytes(n_eq, half_bandwidth);      // frame_wide_kernel: the band always lives in HBM
+  if (pack_kernel_serves(B, n_eq, half_bandwidth)) {   // per frame: the columns of L; once: the assembly plan
+    int P, G, W;
+    fp_config(half_bandwidth, &P, &G, &W);
+    return B == 0 ? 0 : (size_t)B * fp_frame_doubles(n_eq, W) * sizeof(double) + fw_plan_bytes(n_eq, 4 * n_eq + 64, G, fp_epg(G));
+  }
   if (wave_kernel_serves(B, n_eq, half_bandwidth))     // per frame: band / factor rows; once: the assembly plan (at most 21 entries and 72 coefficients per element)
     return B == 0 ? 0 : (size_t)B * fw_frame_doubles(n_eq, half_bandwidth) * sizeof(double) + fw_plan_bytes(n_eq, 4 * n_eq + 64);
   if (frame_lds_resident_bytes(n_eq, half_bandwidth) <= LDS_MAX && !force_ws()) return 0;   // the band lives in LDS
@@ -785,6 +822,22 @@ extern "C" int ops_frame_solve_batched_f64(int B, int n_nodes, int n_elems, int 
     hipLaunchKernelGGL(frame_assemble_kernel, dim3((unsigned)B), dim3(256), ((size_t)slab * ld + (size_t)n3) * sizeof(double), s, p, (double*)workspace, (int)slab);
     hipLaunchKernelGGL(frame_wide_kernel, dim3((unsigned)B), dim3(1024), lds_wide, s, p, (double*)workspace);
     return hipGetLastError() == hipSuccess ? OPS_AMD_OK : OPS_AMD_ERR_LAUNCH;
+  }
+  if (pack_kernel_serves(B, n_eq, kd)) {
+    int P, G, W;
+    fp_config(kd, &P, &G, &W);
+    const size_t need = (size_t)B * fp_frame_doubles(n_eq, W) * sizeof(double) + fw_plan_bytes(n_eq, n_elems, G, fp_epg(G));
+    if (!workspace || workspace_bytes < need) return OPS_AMD_ERR_INVALID_ARG;
+    hipError_t e = hipSuccess;
+    switch (W) {
+      case 8: e = launch_pack<8, 16, 4>(p, (double*)workspace, s); break;
+      case 12: e = launch_pack<12, 16, 4>(p, (double*)workspace, s); break;
+      case 16: e = launch_pack<16, 32, 8>(p, (double*)workspace, s); break;
+      case 24: e = launch_pack<24, 32, 8>(p, (double*)workspace, s); break;
+      default: e = launch_pack<28, 32, 4>(p, (double*)workspace, s); break;
+    }
+    if (e != hipSuccess) { set_frame_error(hipGetErrorString(e)); return OPS_AMD_ERR_LAUNCH; }
+    return OPS_AMD_OK;
   }
   if (wave_kernel_serves(B, n_eq, kd)) {
     const int W = fw_width(kd);

@@ -147,21 +147,22 @@ struct FwPlan {
   const double* rhs_base;    // [n + 1]; [n] = 0
   int ng;                    // row groups; block ng is the all-zero block
 };
-__host__ __device__ inline int fw_groups(int n) { return (n + FW_G - 1) / FW_G; }
-__host__ __device__ inline size_t fw_plan_blocks(int n, int Ne) { return (size_t)fw_groups(n) + 1 + ((size_t)Ne * 21 + FW_EPG - 1) / FW_EPG; }
-__host__ __device__ inline size_t fw_plan_bytes(int n, int Ne) {
-  const size_t ints = 4 + (size_t)(n + 1) + (size_t)(fw_groups(n) + 2);
-  return ((ints + 1) / 2) * 8 + fw_plan_blocks(n, Ne) * FW_EPG * (4 + 8 + 8) + (size_t)(n + 1) * 8;
+// (G rows per group, EPG entry slots per block: 8 / 192 for the wave-per-frame kernel, 4 / 96 or 8 / 192 for the packed kernel, frame_pack.hpp)
+__host__ __device__ inline int fw_groups(int n, int G = FW_G) { return (n + G - 1) / G; }
+__host__ __device__ inline size_t fw_plan_blocks(int n, int Ne, int G = FW_G, int EPG = FW_EPG) { return (size_t)fw_groups(n, G) + 1 + ((size_t)Ne * 21 + EPG - 1) / EPG; }
+__host__ __device__ inline size_t fw_plan_bytes(int n, int Ne, int G = FW_G, int EPG = FW_EPG) {
+  const size_t ints = 4 + (size_t)(n + 1) + (size_t)(fw_groups(n, G) + 2);
+  return ((ints + 1) / 2) * 8 + fw_plan_blocks(n, Ne, G, EPG) * EPG * (4 + 8 + 8) + (size_t)(n + 1) * 8;
 }
-__host__ __device__ inline FwPlan fw_plan_at(void* base, int n, int Ne) {
+__host__ __device__ inline FwPlan fw_plan_at(void* base, int n, int Ne, int G = FW_G, int EPG = FW_EPG) {
   char* q = (char*)base;
-  const size_t nblk = fw_plan_blocks(n, Ne);
+  const size_t nblk = fw_plan_blocks(n, Ne, G, EPG);
   FwPlan pl;
-  pl.ng = fw_groups(n);
-  pl.ka = (const double*)q;        q += nblk * FW_EPG * 8;
-  pl.kb = (const double*)q;        q += nblk * FW_EPG * 8;
+  pl.ng = fw_groups(n, G);
+  pl.ka = (const double*)q;        q += nblk * EPG * 8;
+  pl.kb = (const double*)q;        q += nblk * EPG * 8;
   pl.rhs_base = (const double*)q;  q += (size_t)(n + 1) * 8;
-  pl.ent = (const unsigned*)q;     q += nblk * FW_EPG * 4;
+  pl.ent = (const unsigned*)q;     q += nblk * EPG * 4;
   pl.hdr = (const int*)q;          q += 4 * 4;
   pl.eq_dof = (const int*)q;       q += (size_t)(n + 1) * 4;
   pl.xstart = (const int*)q;
@@ -174,9 +175,9 @@ constexpr int FT_P = 80;                  // doubles per parked row: 64 permuted
 __host__ __device__ inline int ft_col_slot(int xc) { return 16 * (xc >> 4) + 2 * (xc & 7) + ((xc >> 3) & 1); }
 
 // one workgroup; LDS: 3 * (ng + 2) ints.  ring > 0: parking slots of the tile kernel (ring = 8 M equations)
-__global__ __launch_bounds__(1024) void frame_plan_kernel(const FrameParams p, int W, void* plan_base, int ring) {
+__global__ __launch_bounds__(1024) void frame_plan_kernel(const FrameParams p, int W, void* plan_base, int ring, int G, int EPG) {
   extern __shared__ int s_plan[];
-  const FwPlan pl = fw_plan_at(plan_base, p.n_eq, p.Ne);
+  const FwPlan pl = fw_plan_at(plan_base, p.n_eq, p.Ne, G, EPG);
   const int n = p.n_eq, ng = pl.ng, tid = threadIdx.x, T = blockDim.x;
   int* cnt = s_plan;                  // [ng + 1] entries per group
   int* cur = s_plan + (ng + 2);       // [ng + 1] fill cursors
@@ -202,23 +203,23 @@ __global__ __launch_bounds__(1024) void frame_plan_kernel(const FrameParams p, i
       const int er = p.elem_eq[6 * e + r];
       if (er < 0) continue;
       atomicAdd(&rhs_base[er], pg[r]);
-      for (int q = 0; q < 6; ++q) { const int eq = p.elem_eq[6 * e + q]; if (eq >= 0 && eq <= er) atomicAdd(&cnt[er / FW_G], 1); }
+      for (int q = 0; q < 6; ++q) { const int eq = p.elem_eq[6 * e + q]; if (eq >= 0 && eq <= er) atomicAdd(&cnt[er / G], 1); }
     }
   }
   // rows between the last equation and the end of its group: unit diagonal (a pivot there divides nothing by zero; the row-per-lane
   // kernel masks these rows anyway)
-  if (tid < FW_G && n + tid < FW_G * ng) atomicAdd(&cnt[(n + tid) / FW_G], 1);
+  if (tid < G && n + tid < G * ng) atomicAdd(&cnt[(n + tid) / G], 1);
   __syncthreads();
   if (tid == 0) {                            // extra blocks per group: exclusive scan (ng <= a few hundred)
     int acc = 0;
-    for (int g = 0; g < ng; ++g) { xs_[g] = acc; acc += cnt[g] > FW_EPG ? (cnt[g] - 1) / FW_EPG : 0; }
+    for (int g = 0; g < ng; ++g) { xs_[g] = acc; acc += cnt[g] > EPG ? (cnt[g] - 1) / EPG : 0; }
     xs_[ng] = acc; xs_[ng + 1] = acc;
     hdr[0] = acc; hdr[1] = hdr[2] = hdr[3] = 0;
   }
   __syncthreads();
   const int nblk = ng + 1 + xs_[ng];
   for (int i = tid; i < ng + 2; i += T) xstart[i] = xs_[i];
-  for (long i = tid; i < (long)nblk * FW_EPG; i += T) { ent[i] = 0u; ka[i] = 0.0; kb[i] = 0.0; }
+  for (long i = tid; i < (long)nblk * EPG; i += T) { ent[i] = 0u; ka[i] = 0.0; kb[i] = 0.0; }
   __syncthreads();
   // pass B: fill (the order inside a group is the order of arrival: the parking area accumulates with LDS atomics anyway)
   for (int e = tid; e < p.Ne; e += T) {
@@ -229,13 +230,13 @@ __global__ __launch_bounds__(1024) void frame_plan_kernel(const FrameParams p, i
     for (int r = 0; r < 6; ++r) {
       const int er = p.elem_eq[6 * e + r];
       if (er < 0) continue;
-      const int g = er / FW_G;
+      const int g = er / G;
       for (int q = 0; q < 6; ++q) {
         const int eq = p.elem_eq[6 * e + q];
         if (eq >= 0 && eq <= er) {
-          const int pos = atomicAdd(&cur[g], 1), blk = pos / FW_EPG;
-          const long idx = (long)(blk == 0 ? g : ng + 1 + xs_[g] + blk - 1) * FW_EPG + pos % FW_EPG;
-          const int slot = ring > 0 ? (er % FW_G) * FT_P + ft_col_slot(eq % ring) : (er % FW_G) * fw_pitch(W) + eq % W;
+          const int pos = atomicAdd(&cur[g], 1), blk = pos / EPG;
+          const long idx = (long)(blk == 0 ? g : ng + 1 + xs_[g] + blk - 1) * EPG + pos % EPG;
+          const int slot = ring > 0 ? (er % G) * FT_P + ft_col_slot(eq % ring) : (er % G) * fw_pitch(W) + eq % W;
           ent[idx] = 0x80000000u | ((unsigned)e << FW_SLOT_BITS) | (unsigned)slot;
           ka[idx] = k_a[r][q];
           kb[idx] = k_b[r][q];
@@ -243,11 +244,11 @@ __global__ __launch_bounds__(1024) void frame_plan_kernel(const FrameParams p, i
       }
     }
   }
-  if (tid < FW_G && n + tid < FW_G * ng) {
-    const int er = n + tid, g = er / FW_G;
-    const int pos = atomicAdd(&cur[g], 1), blk = pos / FW_EPG;
-    const long idx = (long)(blk == 0 ? g : ng + 1 + xs_[g] + blk - 1) * FW_EPG + pos % FW_EPG;
-    const int slot = ring > 0 ? (er % FW_G) * FT_P + ft_col_slot(er % ring) : (er % FW_G) * fw_pitch(W) + er % W;
+  if (tid < G && n + tid < G * ng) {
+    const int er = n + tid, g = er / G;
+    const int pos = atomicAdd(&cur[g], 1), blk = pos / EPG;
+    const long idx = (long)(blk == 0 ? g : ng + 1 + xs_[g] + blk - 1) * EPG + pos % EPG;
+    const int slot = ring > 0 ? (er % G) * FT_P + ft_col_slot(er % ring) : (er % G) * fw_pitch(W) + er % W;
     ent[idx] = 0x80000000u | (unsigned)slot;                 // (element 0's inertia times kb = 0)
     ka[idx] = 1.0;
     kb[idx] = 0.0;
