@@ -38,57 +38,67 @@ __host__ __device__ inline bool fp_config(int kd, int* P, int* G, int* W) {
   if (kd <= 7) { *P = 16; *G = 4; *W = 8; return true; }
   if (kd <= 11) { *P = 16; *G = 4; *W = 12; return true; }
   if (kd <= 15) { *P = 32; *G = 8; *W = 16; return true; }
+  if (kd <= 19) { *P = 32; *G = 8; *W = 20; return true; }
   if (kd <= 23) { *P = 32; *G = 8; *W = 24; return true; }
   if (kd <= 27) { *P = 32; *G = 4; *W = 28; return true; }
   return false;
 }
-__host__ __device__ constexpr int fp_epg(int G) { return 24 * G; }            // entry slots per plan block (192 for G = 8, as frame_wave.hpp)
-__host__ __device__ constexpr int fp_tb(int P) { return P / 8 < 2 ? 2 : P / 8; }
-// per frame in LDS (doubles): two lines [P], the backward pass's partial results [P / 8], the parking area [G][W + 2], x [n + P]
-__host__ __device__ inline size_t fp_lds_doubles(int n, int P, int G, int W) {
-  size_t d = 2 * (size_t)P + fp_tb(P) + (size_t)G * (W + 2) + (size_t)(n + P);
+// entry slots per plan block: the grid frames of the reference's range need at most 60 (G = 4) / 116 (G = 8) entries per row group (nodes with
+// up to four elements); a group with more continues in extra blocks (frame_wave.hpp)
+__host__ __device__ constexpr int fp_epg(int G) { return 16 * G; }
+__host__ __device__ constexpr int fp_tb(int P);
+// per frame in LDS (doubles): two lines [P], the backward pass's partial results [P / 8], the parking area [G][W + 2], right-hand side -> w -> x
+// [n + P], the frame's inertias [Ne]
+__host__ __device__ inline size_t fp_lds_doubles(int n, int Ne, int P, int G, int W) {
+  size_t d = 2 * (size_t)P + fp_tb(P) + (size_t)G * (W + 2) + (size_t)(n + P) + (size_t)Ne;
   d = (d + 1) & ~(size_t)1;
   if (d % 32 < 2 || d % 32 > 30) d += 2;        // neighbouring frames' lines on distinct banks (P = 16: two frames per 16-byte read pass)
   return d;
 }
-// per frame in the HBM workspace: column j of L at [j * W, j * W + kd)
-__host__ __device__ inline size_t fp_frame_doubles(int n, int W) { return (size_t)n * W; }
+// per frame in the HBM workspace: column j of L at [j * W, j * W + kd); slot W - 1 of every column takes the (unconditional) stores of the
+// lanes outside the window; three spare columns for the idle steps past the last equation (steps are guarded four at a time)
+__host__ __device__ inline size_t fp_frame_doubles(int n, int W) { return (size_t)(n + 3) * W; }
 
 template <int W>
 struct FpState {
   double reg[W];     // own row: A[R][C] at index C mod W
   double y;          // own right-hand side (forward)
   double lp;         // own multiplier of the previous step (the forward substitution runs one column behind)
+  double w;          // w = z / d of the lane's last finished row (leaves for LDS at the next group boundary)
 };
 
 // line of column 0 (before the first step)
 template <int W, int P>
-__device__ __forceinline__ void fp_first_line(const FpState<W>& st, int r, int nl, int kd, double* __restrict__ line) {
+__device__ __forceinline__ void fp_first_line(const FpState<W>& st, int r, int kdl, int n, double* __restrict__ line) {
   const int idx = (r + 1) & (P - 1);                          // 1 + rel; lane P - 1: the z slot
-  const bool in = idx >= 1 && idx - 1 <= kd && idx - 1 < nl;
-  line[idx] = in ? st.reg[0] : 0.0;
+  const int lim = kdl + 1 < n ? kdl + 1 : n;                  // (dead lane group: kdl = -1: nothing)
+  line[idx] = (idx >= 1 && idx - 1 < lim) ? st.reg[0] : 0.0;
 }
 
-// one factorisation step; S = j mod W at compile time.  On entry: rd = 1 / d_j, zp = z_(j-1), a1 = A[j+1][j], a2 = A[j+2][j] (line
-// values); on return the same for step j + 1.
+// one factorisation step; S = j mod W at compile time (W even: S & 1 = j & 1).  On entry: rd = 1 / d_j, zp = z_(j-1), a1 = A[j+1][j],
+// a2 = A[j+2][j] (line values); on return the same for step j + 1.  kdl: kd for a live lane group, -1 for one past the end of the batch
+// (nothing in its window).  No branch: the column of L leaves with an unconditional store (lanes outside the window write slot W - 1 of the
+// column, which nothing reads), w stays in a register until the next group boundary.
+// Lw: this WAVE's first frame in the workspace (uniform), loff: the lane group's frame offset in doubles.
 template <int W, int P, int S>
-__device__ __forceinline__ void fp_step(FpState<W>& st, int j, int r, int nl, int n, int kd, double* __restrict__ line,
-                                        double* __restrict__ Lc, double* __restrict__ xs, double& rd, double& zp, double& a1, double& a2,
-                                        int& bad) {
-  const int rel = (r - j) & (P - 1), R = j + rel;
-  const bool inwin = rel >= 1 && rel <= kd && R < nl;
+__device__ __forceinline__ void fp_step(FpState<W>& st, int j, int r, int kdl, int n, double* __restrict__ line, double* __restrict__ Lw,
+                                        unsigned loff, double& rd, double& zp, double& a1, double& a2, int& bad) {
+  const int rel = (r - j) & (P - 1);
+  const int below = n - 1 - j > 0 ? n - 1 - j : 0;            // rows below the diagonal that exist (uniform)
+  const int lim = kdl < below ? kdl : below, lim1 = kdl + 1 < below ? kdl + 1 : below;
+  const bool inwin = (unsigned)(rel - 1) < (unsigned)(lim > 0 ? lim : 0);          // 1 <= rel <= min(kd, n - 1 - j)
+  const bool in1 = (unsigned)(rel - 1) < (unsigned)(lim1 > 0 ? lim1 : 0);          // row in column j + 1's line (rel = 1: the pivot d_(j+1))
   st.y = __builtin_fma(-st.lp, zp, st.y);                     // column j - 1's part of the forward substitution
   const double a = st.reg[S], rdj = rd;
   const double l = inwin ? a * rdj : 0.0;
   st.lp = l;
   st.reg[(S + 1) % W] = __builtin_fma(-l, a1, st.reg[(S + 1) % W]);      // column j + 1 is final: its line leaves now
-  {
-    const bool in1 = rel >= 1 && rel <= kd + 1 && R < nl;     // row R in column j + 1's line (rel = 1: the pivot d_(j+1) itself)
-    line[((j + 1) & 1) * P + rel] = rel == 0 ? st.y : (in1 ? st.reg[(S + 1) % W] : 0.0);
-  }
-  if (inwin) Lc[(size_t)j * W + (rel - 1)] = l;               // column j of L: one coalesced store per lane group
-  if (rel == 0) xs[j] = st.y * rdj;                           // w_j = z_j / d_j
-  const double* cb = line + (j & 1) * P;
+  line[((S + 1) & 1) * P + rel] = rel == 0 ? st.y : (in1 ? st.reg[(S + 1) % W] : 0.0);
+#ifndef FP_SKIP_LSTORE                                       // (phase ablation builds: wrong answers, scripts/frame_pack_ablation.sh)
+  (Lw + (size_t)j * W)[loff + (unsigned)(inwin ? rel - 1 : W - 1)] = l;  // column j of L: one coalesced store per lane group
+#endif
+  st.w = (rel == 0 && j < n) ? st.y * rdj : st.w;             // w_j = z_j / d_j
+  const double* cb = line + (S & 1) * P;
   if constexpr (W > 2) st.reg[(S + 2) % W] = __builtin_fma(-l, a2, st.reg[(S + 2) % W]);
   // reg[(S + t) mod W] -= l * A[j + t][j], t = 3 .. W - 1: line index t + 1, two columns per 16-byte broadcast read
 #pragma unroll
@@ -99,11 +109,11 @@ __device__ __forceinline__ void fp_step(FpState<W>& st, int j, int r, int nl, in
   }
   // the next step's early operands (this wave's LDS operations execute in order: the line written above is what these reads return)
   __asm__ volatile("" ::: "memory");
-  const double* nb = line + ((j + 1) & 1) * P;
+  const double* nb = line + ((S + 1) & 1) * P;
   const double2 p0 = *reinterpret_cast<const double2*>(nb), p1 = *reinterpret_cast<const double2*>(nb + 2);
   zp = p0.x;
   rd = frcp(p0.y);
-  bad |= (j + 1 < nl) & !(p0.y > 0.0);
+  bad |= (j + 1 < n) & !(p0.y > 0.0);
   a1 = p1.x;
   a2 = p1.y;
   // a step's multiply-adds stay in the step (frame_wave.hpp fw_step: left free, the compiler defers them and spills line values)
@@ -123,30 +133,42 @@ __device__ __forceinline__ void fp_take_group(FpState<W>& st, int g0, int r, con
   }
 }
 
+// LDS operations of one wave execute in issue order, atomics included: between a write and the read that wants it (or a read and the write
+// that replaces what it read) the compiler must not reorder, but the wave need not wait -- frame_wave.hpp's fw_fence also drains lgkmcnt
+__device__ __forceinline__ void fp_order() {
+  __asm__ volatile("" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+}
+
 // ---- backward substitution: U = P / 8 columns per pass, x_j = w_j - sum_t L[j+t][j] x_(j+t) ----
+// Lane (u, k) = (r >> 3, r & 7) works for column j_u = jb - u: the rows j_u + k + 1 + 8 m of that column against x from LDS, an 8-lane DPP sum
+// gives every column's contribution of the rows ABOVE the pass (x known).  The pass's own triangle -- L[jb - v][jb - w], v < w < U: the first
+// entries of the pass's columns, held by the lanes (w, k < w) -- goes through LDS with the U partial results, and every lane solves the
+// U x U triangle redundantly (no cross-lane chain).  L streams back from L2 / HBM (phase ablation, r06: the sweep was 24 % of the launch
+// with one pass in flight ahead of the work): the loads of the next FP_BD passes are in flight while FP_BD passes are worked on.
+#ifndef FP_BD
+#define FP_BD 6
+#endif
+__host__ __device__ constexpr int fp_tb(int P) { return (P / 8 + (P / 8) * (P / 8 - 1) / 2 + 1) & ~1; }      // partial results + triangle
 template <int W, int P>
 __device__ __forceinline__ void fp_backward(const double* __restrict__ Lc, double* __restrict__ xs, double* __restrict__ tb, int n, int nl,
                                             int kd, int r) {
-  constexpr int U = P / 8, MF = (W + 7) / 8, NT = U * (U - 1) / 2;
+  constexpr int U = P / 8, MF = (W + 7) / 8, NT = U * (U - 1) / 2, D = FP_BD;
+  static_assert(U >= 2, "frame_pack: at least 16 lanes per frame");
   const int u = r >> 3, k = r & 7;
   xs[n + r] = 0.0;                                        // rows past the last equation (the idle steps left garbage there)
-  fw_fence();
-  double fA[MF], fB[MF], tA[NT > 0 ? NT : 1], tB[NT > 0 ? NT : 1];
-  auto issue = [&](int jb, double (&f)[MF], double (&tr)[NT > 0 ? NT : 1]) {       // unconditional loads from clamped addresses
+  fp_order();
+  double fa[D][MF], fb[D][MF];
+  auto issue = [&](int jb, double (&f)[MF]) {             // unconditional loads from clamped addresses
     const int ju = jb - u, jc = ju > 0 ? ju : 0;
-    const double* col = Lc + (size_t)jc * W;
+    const double* col = Lc + (unsigned)(jc * W);
 #pragma unroll
     for (int m = 0; m < MF; ++m) f[m] = col[k + 8 * m < W ? k + 8 * m : W - 1];
-    // the pass's own triangle: L[jb - v][jb - w], v < w < U, at column (jb - w), offset w - v - 1 -- every lane loads all of them
-    int i = 0;
-#pragma unroll
-    for (int w = 1; w < U; ++w)
-#pragma unroll
-      for (int v = 0; v < w; ++v) { const int jw = jb - w > 0 ? jb - w : 0; tr[i++] = Lc[(size_t)jw * W + (w - v - 1)]; }
   };
-  auto block = [&](int jb, const double (&lf)[MF], const double (&tr)[NT > 0 ? NT : 1]) {
+  auto block = [&](int jb, const double (&lf)[MF]) {
     const int ju = jb - u, jc = ju > 0 ? ju : 0;
     const int kdj = ju >= 0 ? (kd < nl - 1 - ju ? kd : nl - 1 - ju) : 0;      // rows of this column below the diagonal
+    if (k < u) tb[U + u * (u - 1) / 2 + (u - 1 - k)] = (k + 1 <= kdj) ? lf[0] : 0.0;      // L[jb - v][jb - u], v = u - 1 - k: offset k
     double acc0 = 0.0, acc1 = 0.0;
 #pragma unroll
     for (int m = 0; m < MF; ++m) {
@@ -160,46 +182,53 @@ __device__ __forceinline__ void fp_backward(const double* __restrict__ Lc, doubl
     s_ += fw_dpp<0xB1>(s_);                               // quad_perm [1,0,3,2]
     s_ += fw_dpp<0x4E>(s_);                               // quad_perm [2,3,0,1]
     s_ += fw_dpp<0x141>(s_);                              // row_half_mirror: the eight lanes of a column hold its sum
-    const double t = xs[jc] - s_;
-    double x[U];
-    if constexpr (U == 1) {
-      x[0] = t;
-    } else {
-      if (k == 0) tb[u] = t;
-      fw_fence();
+    if (k == 0) tb[u] = xs[jc] - s_;
+    fp_order();
+    double x[U], tr[NT];
 #pragma unroll
-      for (int w = 0; w < U; w += 2) { const double2 q = *reinterpret_cast<const double2*>(tb + w); x[w] = q.x; x[w + 1] = q.y; }
+    for (int w = 0; w < U; w += 2) { const double2 q = *reinterpret_cast<const double2*>(tb + w); x[w] = q.x; x[w + 1] = q.y; }
+#pragma unroll
+    for (int i = 0; i < NT; i += 2) {
+      const double2 q = *reinterpret_cast<const double2*>(tb + U + i);
+      tr[i] = q.x;
+      if (i + 1 < NT) tr[i + 1] = q.y;
+    }
+    {
       int i = 0;
 #pragma unroll
-      for (int w = 1; w < U; ++w) {
-        const int jw = jb - w, kdw = jw >= 0 ? (kd < nl - 1 - jw ? kd : nl - 1 - jw) : 0;
+      for (int w = 1; w < U; ++w)
 #pragma unroll
-        for (int v = 0; v < w; ++v) { const double l = (w - v <= kdw) ? tr[i] : 0.0; ++i; x[w] = __builtin_fma(-l, x[v], x[w]); }
-      }
+        for (int v = 0; v < w; ++v) x[w] = __builtin_fma(-tr[i++], x[v], x[w]);
     }
     double mine = x[0];
 #pragma unroll
     for (int w = 1; w < U; ++w) mine = (r == w) ? x[w] : mine;
     if (r < U && jb - r >= 0 && jb - r < nl) xs[jb - r] = mine;
-    fw_fence();
+    fp_order();
   };
+#ifdef FP_SKIP_BACKWARD
+  int jb = -1;
+#else
   int jb = n - 1;
-  issue(jb, fA, tA);
-  for (; jb >= 0; jb -= 2 * U) {                          // two passes per trip: the buffers alternate without copies
-    issue(jb - U, fB, tB);
-    block(jb, fA, tA);
-    issue(jb - 2 * U, fA, tA);
-    block(jb - U, fB, tB);
+#endif
+#pragma unroll
+  for (int d = 0; d < D; ++d) issue(jb - d * U, fa[d]);
+  for (; jb >= 0; jb -= 2 * D * U) {                      // 2 D passes per trip: two register sets alternate without copies
+#pragma unroll
+    for (int d = 0; d < D; ++d) { issue(jb - (D + d) * U, fb[d]); block(jb - d * U, fa[d]); }
+#pragma unroll
+    for (int d = 0; d < D; ++d) { issue(jb - (2 * D + d) * U, fa[d]); block(jb - (D + d) * U, fb[d]); }
   }
 }
 
 template <int W, int P, int G>
-__device__ __forceinline__ void frame_pack_body(const FrameParams& p, double* __restrict__ Lc, double* __restrict__ lds, int r, long b, bool live,
-                                                const FwPlan& pl) {
+__device__ __forceinline__ void frame_pack_body(const FrameParams& p, double* __restrict__ Lw, unsigned loff, double* __restrict__ lds, int r, long b,
+                                                bool live, const FwPlan& pl) {
   constexpr int EPG = fp_epg(G), KE = EPG / P, PITCH = W + 2;
   static_assert(EPG % P == 0 && W % 4 == 0 && (P & (P - 1)) == 0, "frame_pack: sizes");
   const int n = p.n_eq, kd = p.kd;
-  const int nl = live ? n : 0;                              // a lane group past the end of the batch: nothing is in its window, nothing is stored
+  const int nl = live ? n : 0, kdl = live ? kd : -1;        // a lane group past the end of the batch: nothing is in its window
+  const double* Lc = Lw + loff;                             // this frame's columns of L
   const int KG = (kd / G + 1) * G;                          // > kd: registers hold the rows below j + KG + G at step j
   double* line = lds;                                       // [2][P]
   double* tb = lds + 2 * P;                                 // [fp_tb(P)]
@@ -210,94 +239,94 @@ __device__ __forceinline__ void frame_pack_body(const FrameParams& p, double* __
   for (int c = 0; c < W; ++c) st.reg[c] = 0.0;
   st.y = 0.0;
   st.lp = 0.0;
+  st.w = 0.0;
   int bad = 0;
 
-  const double* Ib = p.I + b * p.Ne;
-  const double* lb = p.loads + b * p.loads_bs;
+  // the frame's own data, ONE round trip to HBM for the whole solve: inertias and right-hand side (consistent element loads of the plan + the
+  // nodal load of each equation's DOF) into LDS.  xs[q] holds the right-hand side of row q until the row's group is built (long before step q
+  // overwrites it with w_q).  Everything the row groups need after this is the plan -- the same addresses for every frame of the launch: L2.
+  double* Il = xs + (n + P);                                // [Ne]
+  {
+    const double* Ib = p.I + b * p.Ne;
+    const double* lb = p.loads + b * p.loads_bs;
+    for (int e = r; e < p.Ne; e += P) Il[e] = Ib[e];
+    for (int q = r; q < n + P; q += P) xs[q] = q < n ? pl.rhs_base[q] + lb[pl.eq_dof[q]] : 0.0;
+  }
   unsigned eB[KE];
-  int dofB = 0, gB = 0;
-  double bi[KE], ba[KE], bb[KE], by1 = 0.0, by2 = 0.0;
+  int gB = 0;
+  double ba[KE], bb[KE];
 #pragma unroll
   for (int k = 0; k < KE; ++k) eB[k] = 0u;
   const int n_extra = pl.hdr[0];
-  auto ents = [&](int g0) {                                 // group g0 (a multiple of G): entry words + load index, no wait
+  auto ents = [&](int g0) {                                 // group g0 (a multiple of G): entry words and coefficients, no wait
     const int gi = g0 / G < pl.ng ? g0 / G : pl.ng;         // past the last equation: the all-zero block
     const unsigned* e = pl.ent + (size_t)gi * EPG + r;
-#pragma unroll
-    for (int k = 0; k < KE; ++k) eB[k] = e[P * k];
-    const int q = g0 + (r < G ? r : 0);
-    dofB = pl.eq_dof[q < n ? q : n];
-    gB = g0;
-  };
-  auto build_issue = [&]() {                                // the loads of group gB
-    const int gi = gB / G < pl.ng ? gB / G : pl.ng;
     const double* ka = pl.ka + (size_t)gi * EPG + r;
     const double* kb = pl.kb + (size_t)gi * EPG + r;
 #pragma unroll
-    for (int k = 0; k < KE; ++k) { bi[k] = Ib[(eB[k] >> FW_SLOT_BITS) & 0x1FFFFF]; ba[k] = ka[P * k]; bb[k] = kb[P * k]; }
-    const int q = gB + (r < G ? r : 0);
-    by1 = pl.rhs_base[q < n ? q : n];
-    by2 = lb[dofB];
+    for (int k = 0; k < KE; ++k) { eB[k] = e[P * k]; ba[k] = ka[P * k]; bb[k] = kb[P * k]; }
+    gB = g0;
   };
-  auto build_finish = [&]() {                               // ... accumulated into the (zeroed) parking area
+  auto build = [&]() {                                      // group gB accumulated into the (zeroed) parking area
 #pragma unroll
     for (int k = 0; k < KE; ++k)
-      if ((int)eB[k] < 0) atomicAdd(&stage[eB[k] & FW_SLOT_MASK], __builtin_fma(bi[k], bb[k], ba[k]));
+      if ((int)eB[k] < 0) atomicAdd(&stage[eB[k] & FW_SLOT_MASK], __builtin_fma(Il[(eB[k] >> FW_SLOT_BITS) & 0x1FFFFF], bb[k], ba[k]));
     if (n_extra != 0) {                                     // nodes with more than four elements: extra blocks, not prefetched
       const int gi = gB / G < pl.ng ? gB / G : pl.ng;
       for (int blk = pl.xstart[gi]; blk < pl.xstart[gi + 1]; ++blk)
         for (int k = 0; k < KE; ++k) {
           const size_t i = (size_t)(pl.ng + 1 + blk) * EPG + r + P * k;
           const unsigned w = pl.ent[i];
-          if ((int)w < 0) atomicAdd(&stage[w & FW_SLOT_MASK], __builtin_fma(Ib[(w >> FW_SLOT_BITS) & 0x1FFFFF], pl.kb[i], pl.ka[i]));
+          if ((int)w < 0) atomicAdd(&stage[w & FW_SLOT_MASK], __builtin_fma(Il[(w >> FW_SLOT_BITS) & 0x1FFFFF], pl.kb[i], pl.ka[i]));
         }
     }
-    fw_fence();
-    if (r < G) stage[r * PITCH + W] = (gB + r < n) ? by1 + by2 : 0.0;
+    if (r < G) stage[r * PITCH + W] = xs[gB + r];           // (rows past the last equation: zero, staged above)
   };
   auto zero_stage = [&]() {
     for (int i = r; i < G * PITCH; i += P) stage[i] = 0.0;
-    fw_fence();
+    fp_order();
   };
   // prologue: rows [0, KG + G) into registers, the next group parked, the one after on its way
+  ents(0);
   for (int g0 = 0; g0 < KG + 2 * G; g0 += G) {
-    ents(g0);
-    build_issue();
     zero_stage();
-    build_finish();
-    fw_fence();
-    if (g0 < KG + G) { fp_take_group<W, P, G>(st, g0, r, stage); fw_fence(); }
+    build();
+    ents(g0 + G);
+    fp_order();
+    if (g0 < KG + G) { fp_take_group<W, P, G>(st, g0, r, stage); fp_order(); }
   }
-  ents(KG + 2 * G);
 
   // ---- factorisation + forward substitution ----
   double rd, zp, a1, a2;
-  fp_first_line<W, P>(st, r, nl, kd, line);
-  fw_fence();
+  fp_first_line<W, P>(st, r, kdl, n, line);
+  fp_order();
   {
     const double2 p0 = *reinterpret_cast<const double2*>(line), p1 = *reinterpret_cast<const double2*>(line + 2);
     zp = 0.0;
     (void)p0.x;
     rd = frcp(p0.y);
-    bad |= (0 < nl) & !(p0.y > 0.0);
+    bad |= !(p0.y > 0.0);
     a1 = p1.x;
     a2 = p1.y;
   }
   for (int j0 = 0; j0 < n; j0 += W) {
     auto boundary = [&](int j) {                            // j % G == 0, j > 0: rows [j + KG, j + KG + G) enter
-      build_issue();                                        // group j + KG + G: its round trip runs under the LDS work below
+      { const int slot = (r - (j - G)) & (P - 1); if (slot < G) xs[j - G + slot] = st.w; }      // rows [j - G, j) are finished: their w
       fp_take_group<W, P, G>(st, j + KG, r, stage);
-      fw_fence();
+      fp_order();
       zero_stage();
-      build_finish();
-      fw_fence();
+      build();                                              // group j + KG + G, from the plan words loaded one boundary ago
+      fp_order();
       ents(j + KG + 2 * G);
     };
+#ifndef FP_NO_BOUNDARY
+#define FP_NO_BOUNDARY 0
+#endif
 #define FP_STEP(S_)                                                                   \
     {                                                                                 \
       const int j = j0 + (S_);                                                        \
-      if constexpr ((S_) % 4 == 0) if (j > 0 && (j % G) == 0 && j < n) boundary(j);   \
-      fp_step<W, P, (S_)>(st, j, r, nl, n, kd, line, Lc, xs, rd, zp, a1, a2, bad);    \
+      if constexpr (!FP_NO_BOUNDARY && (S_) % 4 == 0) if (j > 0 && (j % G) == 0 && j < n) boundary(j);   \
+      fp_step<W, P, (S_)>(st, j, r, kdl, n, line, Lw, loff, rd, zp, a1, a2, bad);     \
     }
 #define FP_STEP4(S_)                                                                  \
     if constexpr ((S_) < W) {                                                         \
@@ -308,23 +337,33 @@ __device__ __forceinline__ void frame_pack_body(const FrameParams& p, double* __
 #undef FP_STEP4
 #undef FP_STEP
   }
-  fw_fence();
+  {                                                         // the rows finished since the last boundary (and, again, up to P - G before)
+    const int Rl = n - 1 - ((n - 1 - r) & (P - 1));
+    if (Rl >= 0) xs[Rl] = st.w;
+  }
+  fp_order();
 
   fp_backward<W, P>(Lc, xs, tb, n, nl, kd, r);
   if (live) write_results(p, b, xs, bad != 0, r, P);
 }
 
+// waves per SIMD the register allocator is asked to make room for: the wave is latency-bound (LDS round trips of the line, reciprocal chain)
+#ifndef FP_WAVES
+#define FP_WAVES(W) ((W) <= 12 ? 4 : 3)
+#endif
 template <int W, int P, int G>
-__global__ __launch_bounds__(256)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FP_WAVES(W))))
 void frame_pack_kernel(const FrameParams p, double* __restrict__ ws, const FwPlan pl) {
   extern __shared__ double lds[];
   constexpr int F = 64 / P;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, sub = lane / P, r = lane & (P - 1);
-  const long slot = ((long)blockIdx.x * 4 + wave) * F + sub;
-  if (((long)blockIdx.x * 4 + wave) * F >= p.B) return;     // (wave-uniform)
+  const long first = ((long)blockIdx.x * 4 + wave) * F, slot = first + sub;
+  if (first >= p.B) return;                                 // (wave-uniform)
   const bool live = slot < p.B;
   const long b = live ? slot : (long)p.B - 1;
-  frame_pack_body<W, P, G>(p, ws + b * fp_frame_doubles(p.n_eq, W), lds + (size_t)(wave * F + sub) * fp_lds_doubles(p.n_eq, P, G, W), r, b, live, pl);
+  const size_t fd = fp_frame_doubles(p.n_eq, W);            // (F frames of at most a few hundred KB: the lane group's offset fits 32 bits)
+  frame_pack_body<W, P, G>(p, ws + first * fd, (unsigned)((b - first) * fd), lds + (size_t)(wave * F + sub) * fp_lds_doubles(p.n_eq, p.Ne, P, G, W), r, b,
+                           live, pl);
 }
 
 }  // namespace opsamd

@@ -698,12 +698,15 @@ static bool wave_kernel_serves(int B, int n_eq, int kd) {
 
 // r06: half bandwidths up to 27 -- 95 of the 100 (bays, stories) draws of FR:17-18 -- take the packed kernel (frame_pack.hpp: 16 or 32 lanes per
 // frame, 4 or 2 frames per wave) wherever the wave-per-frame kernel would have served.  OPS_AMD_FRAME_PACK=0: one wave per frame (A/B).
+// (ops_frame_workspace_bytes does not know the element count: both it and the solve decide with the bound the plan's workspace share is sized by)
+static int ne_bound(int n_eq) { return 4 * n_eq + 64; }
 static bool pack_kernel_serves(int B, int n_eq, int kd) {
+  const int n_elems = ne_bound(n_eq);
   int P, G, W;
   if (!fp_config(kd, &P, &G, &W)) return false;
   if (const char* e = getenv("OPS_AMD_FRAME_PACK")) if (atoi(e) == 0) return false;
   if (!wave_kernel_serves(B, n_eq, kd) || !fused_assembly() || use_tile_kernel() || use_pair_steps(kd)) return false;
-  return 4 * (size_t)(64 / P) * fp_lds_doubles(n_eq, P, G, W) * sizeof(double) <= 160 * 1024 - 64;
+  return 4 * (size_t)(64 / P) * fp_lds_doubles(n_eq, n_elems, P, G, W) * sizeof(double) <= 160 * 1024 - 64;
 }
 
 template <int W, int P, int G>
@@ -713,7 +716,7 @@ static hipError_t launch_pack(const FrameParams& p, double* ws, hipStream_t s) {
   hipError_t e = hipGetDevice(&devid);
   if (e != hipSuccess) return e;
   constexpr int F = 64 / P;
-  const size_t lds = 4 * (size_t)F * fp_lds_doubles(p.n_eq, P, G, W) * sizeof(double);
+  const size_t lds = 4 * (size_t)F * fp_lds_doubles(p.n_eq, p.Ne, P, G, W) * sizeof(double);
   const unsigned long long bit = 1ull << (devid & 63);
   if (!(done.load(std::memory_order_acquire) & bit)) {
     e = hipFuncSetAttribute((const void*)frame_pack_kernel<W, P, G>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
@@ -767,7 +770,7 @@ extern "C" size_t ops_frame_workspace_bytes(int B, int n_eq, int half_bandwidth)
   if (pack_kernel_serves(B, n_eq, half_bandwidth)) {   // per frame: the columns of L; once: the assembly plan
     int P, G, W;
     fp_config(half_bandwidth, &P, &G, &W);
-    return B == 0 ? 0 : (size_t)B * fp_frame_doubles(n_eq, W) * sizeof(double) + fw_plan_bytes(n_eq, 4 * n_eq + 64, G, fp_epg(G));
+    return B == 0 ? 0 : (size_t)B * fp_frame_doubles(n_eq, W) * sizeof(double) + fw_plan_bytes(n_eq, ne_bound(n_eq), G, fp_epg(G));
   }
   if (wave_kernel_serves(B, n_eq, half_bandwidth))     // per frame: band / factor rows; once: the assembly plan (at most 21 entries and 72 coefficients per element)
     return B == 0 ? 0 : (size_t)B * fw_frame_doubles(n_eq, half_bandwidth) * sizeof(double) + fw_plan_bytes(n_eq, 4 * n_eq + 64);
@@ -833,6 +836,7 @@ extern "C" int ops_frame_solve_batched_f64(int B, int n_nodes, int n_elems, int 
       case 8: e = launch_pack<8, 16, 4>(p, (double*)workspace, s); break;
       case 12: e = launch_pack<12, 16, 4>(p, (double*)workspace, s); break;
       case 16: e = launch_pack<16, 32, 8>(p, (double*)workspace, s); break;
+      case 20: e = launch_pack<20, 32, 8>(p, (double*)workspace, s); break;
       case 24: e = launch_pack<24, 32, 8>(p, (double*)workspace, s); break;
       default: e = launch_pack<28, 32, 4>(p, (double*)workspace, s); break;
     }

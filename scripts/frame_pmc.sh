@@ -9,7 +9,7 @@ import csv,glob,collections
 acc=collections.defaultdict(list)
 for f in glob.glob("gpurun_out/prof_frames_pmc/*/*/*_counter_collection.csv"):
     for r in csv.DictReader(open(f)):
-        if "frame_wave_kernel" in r["Kernel_Name"] or "frame_tile_kernel" in r["Kernel_Name"]: acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
+        if any(k in r["Kernel_Name"] for k in ("frame_wave_kernel", "frame_tile_kernel", "frame_pack_kernel")): acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
 p={k:sum(v)/len(v) for k,v in acc.items()}
 w=p.get("SQ_WAVES",1)
 print({k:round(v/w,1) for k,v in p.items()})
