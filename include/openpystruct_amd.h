@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define OPS_AMD_ABI_VERSION 12
+#define OPS_AMD_ABI_VERSION 13
 
 /* return codes of the launch functions (per-beam results are in `status`) */
 #define OPS_AMD_OK 0
@@ -238,6 +238,20 @@ int ops_frame_solve_batched_f64(int B, int n_nodes, int n_elems, int n_eq, int h
                                 double* forces, double* V, double* M, int32_t* status, void* workspace,
                                 size_t workspace_bytes, void* stream);
 size_t ops_frame_workspace_bytes(int B, int n_eq, int half_bandwidth);
+/* r06 (ABI 13).  The tuned kernels (a wavefront, or for half_bandwidth <= 27 -- 95 of the 100 (bays, stories) draws of FR:17-18 -- 16 or 32 lanes
+ * per frame) assemble each frame's rows from an ASSEMBLY PLAN: the topology-only part of `setup_frame_model` (which element entry goes where,
+ * FR:84-131), built by a small kernel at the start of the workspace.  ops_frame_solve_batched_f64 rebuilds it on every call (20-25 us: it cannot
+ * know whether the topology arrays changed).  A caller that KNOWS they did not -- same elem_* / node_eq contents, same n_eq / half_bandwidth, same
+ * workspace buffer, and ops_frame_plan_signature(B, n_eq, half_bandwidth) equal to that of the call that built it (non-zero; it changes where
+ * the batch size changes the kernel family) -- passes OPS_FRAME_REUSE_PLAN and the solve is one launch.  flags = 0: exactly the call above. */
+#define OPS_FRAME_REUSE_PLAN 1u
+int ops_frame_solve_batched_f64_ex(int B, int n_nodes, int n_elems, int n_eq, int half_bandwidth,
+                                   const double* elem_geo, const double* elem_EA, const double* elem_E,
+                                   const double* elem_w, const int32_t* elem_eq, const int32_t* node_eq,
+                                   const double* I, const double* loads, long loads_bstride, double* disp,
+                                   double* forces, double* V, double* M, int32_t* status, void* workspace,
+                                   size_t workspace_bytes, void* stream, unsigned flags);
+long ops_frame_plan_signature(int B, int n_eq, int half_bandwidth);
 
 /* Fused 3-tap stencil + single-channel batch normalisation of a [B,F] float32 tensor: the PINN ResidualBlock's
  * `bn1(conv1(x.unsqueeze(1))).squeeze(1)` (Conv1d(1,1,3,padding=1) + BatchNorm1d(1),

@@ -9,7 +9,8 @@ import ctypes
 import os
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-ABI_VERSION = 12     # include/openpystruct_amd.h OPS_AMD_ABI_VERSION
+FRAME_REUSE_PLAN = 1     # include/openpystruct_amd.h OPS_FRAME_REUSE_PLAN
+ABI_VERSION = 13     # include/openpystruct_amd.h OPS_AMD_ABI_VERSION
 # OPS_AMD_LIB lets A/B kernel experiments point at another build of the same C ABI
 LIB_PATH = os.environ.get("OPS_AMD_LIB") or os.path.join(_PKG, "lib", "libopenpystruct_amd.so")
 
@@ -27,6 +28,8 @@ EXPORTS = (
     "ops_beam_residual_vjp_f64",
     "ops_frame_solve_batched_f64",
     "ops_frame_workspace_bytes",
+    "ops_frame_solve_batched_f64_ex",
+    "ops_frame_plan_signature",
     "ops_stencil3_bn1_fwd_f32",
     "ops_stencil3_bn1_bwd_f32",
     "ops_stencil3_bn1_workspace_bytes",
@@ -286,6 +289,11 @@ def load():
     fr = lib.ops_frame_solve_batched_f64
     fr.restype = it
     fr.argtypes = [it] * 5 + [vp] * 8 + [lg] + [vp] * 6 + [ctypes.c_size_t, vp]
+    frx = lib.ops_frame_solve_batched_f64_ex
+    frx.restype = it
+    frx.argtypes = [it] * 5 + [vp] * 8 + [lg] + [vp] * 6 + [ctypes.c_size_t, vp, ctypes.c_uint]
+    lib.ops_frame_plan_signature.restype = lg
+    lib.ops_frame_plan_signature.argtypes = [it, it, it]
     lib.ops_frame_workspace_bytes.restype = ctypes.c_size_t
     lib.ops_frame_workspace_bytes.argtypes = [it, it, it]
     fl = ctypes.c_float

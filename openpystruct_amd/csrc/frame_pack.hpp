@@ -349,7 +349,7 @@ __device__ __forceinline__ void frame_pack_body(const FrameParams& p, double* __
 
 // waves per SIMD the register allocator is asked to make room for: the wave is latency-bound (LDS round trips of the line, reciprocal chain)
 #ifndef FP_WAVES
-#define FP_WAVES(W) ((W) <= 12 ? 4 : 3)
+#define FP_WAVES(W) ((W) <= 8 ? 4 : 3)
 #endif
 template <int W, int P, int G>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FP_WAVES(W))))
@@ -357,13 +357,25 @@ void frame_pack_kernel(const FrameParams p, double* __restrict__ ws, const FwPla
   extern __shared__ double lds[];
   constexpr int F = 64 / P;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, sub = lane / P, r = lane & (P - 1);
-  const long first = ((long)blockIdx.x * 4 + wave) * F, slot = first + sub;
-  if (first >= p.B) return;                                 // (wave-uniform)
-  const bool live = slot < p.B;
-  const long b = live ? slot : (long)p.B - 1;
+  // PERSISTENT waves: the launch has at most as many workgroups as the chip holds at once, and a wave walks over its share of the batch with ONE
+  // workspace slot (its own): the factor columns of all frames in flight are ~100 MB whatever the batch -- they stay in L2 / Infinity Cache
+  // between the forward and the backward sweep instead of streaming through HBM (per-frame slots: 2 x 15 KB of HBM traffic per 5 x 5 frame
+  // against 5 KB of inputs and results)
   const size_t fd = fp_frame_doubles(p.n_eq, W);            // (F frames of at most a few hundred KB: the lane group's offset fits 32 bits)
-  frame_pack_body<W, P, G>(p, ws + first * fd, (unsigned)((b - first) * fd), lds + (size_t)(wave * F + sub) * fp_lds_doubles(p.n_eq, p.Ne, P, G, W), r, b,
-                           live, pl);
+  const long wslot = (long)blockIdx.x * 4 + wave, stride = (long)gridDim.x * 4 * F;
+  const unsigned ldso = (unsigned)((wave * F + sub) * fp_lds_doubles(p.n_eq, p.Ne, P, G, W));
+  for (long first = wslot * F; first < p.B; first += stride) {      // (wave-uniform)
+    // the lane's coordinates are re-read "opaquely" per frame: left loop-invariant, every per-lane address of the body (plan, LDS areas, workspace)
+    // is hoisted out of this loop and kept in registers across it (+40 VGPRs, 100-250 bytes of scratch)
+    int r_ = r, sub_ = sub;
+    unsigned ldso_ = ldso;
+    __asm__ volatile("" : "+v"(r_), "+v"(sub_), "+v"(ldso_));
+    const long slot = first + sub_;
+    const bool live = slot < p.B;
+    const long b = live ? slot : (long)p.B - 1;
+    frame_pack_body<W, P, G>(p, ws + (size_t)wslot * F * fd, (unsigned)((live ? sub_ : 0) * fd), lds + ldso_, r_, b, live, pl);
+    fp_order();
+  }
 }
 
 }  // namespace opsamd

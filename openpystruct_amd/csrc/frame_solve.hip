@@ -700,6 +700,9 @@ static bool wave_kernel_serves(int B, int n_eq, int kd) {
 // frame, 4 or 2 frames per wave) wherever the wave-per-frame kernel would have served.  OPS_AMD_FRAME_PACK=0: one wave per frame (A/B).
 // (ops_frame_workspace_bytes does not know the element count: both it and the solve decide with the bound the plan's workspace share is sized by)
 static int ne_bound(int n_eq) { return 4 * n_eq + 64; }
+// the assembly plan sits at the START of the workspace (r06: where it is does not depend on the batch, so a caller that keeps the workspace may
+// keep the plan: OPS_FRAME_REUSE_PLAN), the per-frame / per-wave factor storage behind it
+static size_t plan_region_bytes(int n_eq, int G, int EPG) { return (fw_plan_bytes(n_eq, ne_bound(n_eq), G, EPG) + 255) & ~(size_t)255; }
 static bool pack_kernel_serves(int B, int n_eq, int kd) {
   const int n_elems = ne_bound(n_eq);
   int P, G, W;
@@ -710,7 +713,7 @@ static bool pack_kernel_serves(int B, int n_eq, int kd) {
 }
 
 template <int W, int P, int G>
-static hipError_t launch_pack(const FrameParams& p, double* ws, hipStream_t s) {
+static hipError_t launch_pack(const FrameParams& p, double* ws, hipStream_t s, bool reuse_plan) {
   static std::atomic<unsigned long long> done{0};
   int devid = 0;
   hipError_t e = hipGetDevice(&devid);
@@ -723,15 +726,35 @@ static hipError_t launch_pack(const FrameParams& p, double* ws, hipStream_t s) {
     if (e != hipSuccess) return e;
     done.fetch_or(bit, std::memory_order_release);
   }
-  void* plan_base = (char*)ws + (size_t)p.B * fp_frame_doubles(p.n_eq, W) * sizeof(double);
+  // persistent waves (frame_pack.hpp): as many workgroups as the chip holds at once (asked of the runtime once per device and LDS size)
+  static std::atomic<long long> cap_key[64];
+  static std::atomic<int> cap_val[64];
+  int cap = 0;
+  const long long key = ((long long)lds << 1) | 1;
+  if (cap_key[devid & 63].load(std::memory_order_acquire) == key) cap = cap_val[devid & 63].load(std::memory_order_relaxed);
+  if (cap <= 0) {
+    int per_cu = 0, cus = 0;
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)frame_pack_kernel<W, P, G>, 256, lds);
+    if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, devid);
+    if (e != hipSuccess) return e;
+    cap = (per_cu > 0 ? per_cu : 1) * (cus > 0 ? cus : 1);
+    cap_key[devid & 63].store(0, std::memory_order_release);
+    cap_val[devid & 63].store(cap, std::memory_order_relaxed);
+    cap_key[devid & 63].store(key, std::memory_order_release);
+  }
+  const long need = ((long)p.B + 4 * F - 1) / (4 * F);
+  const unsigned grid = (unsigned)(need < cap ? need : cap);
+  void* plan_base = ws;
+  double* factor = (double*)((char*)ws + plan_region_bytes(p.n_eq, G, fp_epg(G)));
   const FwPlan pl = fw_plan_at(plan_base, p.n_eq, p.Ne, G, fp_epg(G));
-  hipLaunchKernelGGL(frame_plan_kernel, dim3(1), dim3(1024), (size_t)3 * (fw_groups(p.n_eq, G) + 2) * sizeof(int), s, p, W, plan_base, 0, G, fp_epg(G));
-  hipLaunchKernelGGL((frame_pack_kernel<W, P, G>), dim3((unsigned)((p.B + 4 * F - 1) / (4 * F))), dim3(256), lds, s, p, ws, pl);
+  if (!reuse_plan)
+    hipLaunchKernelGGL(frame_plan_kernel, dim3(1), dim3(1024), (size_t)3 * (fw_groups(p.n_eq, G) + 2) * sizeof(int), s, p, W, plan_base, 0, G, fp_epg(G));
+  hipLaunchKernelGGL((frame_pack_kernel<W, P, G>), dim3(grid), dim3(256), lds, s, p, factor, pl);
   return hipGetLastError();
 }
 
 template <int W>
-static hipError_t launch_wave(const FrameParams& p, double* ws, hipStream_t s) {
+static hipError_t launch_wave(const FrameParams& p, double* ws_all, hipStream_t s, bool reuse_plan) {
   static std::atomic<unsigned long long> done{0};
   int devid = 0;
   hipError_t e = hipGetDevice(&devid);
@@ -746,14 +769,16 @@ static hipError_t launch_wave(const FrameParams& p, double* ws, hipStream_t s) {
     if (e != hipSuccess) return e;
     done.fetch_or(bit, std::memory_order_release);
   }
-  void* plan_base = (char*)ws + (size_t)p.B * fw_frame_doubles(p.n_eq, p.kd) * sizeof(double);
+  void* plan_base = ws_all;
+  double* ws = (double*)((char*)ws_all + plan_region_bytes(p.n_eq, FW_G, FW_EPG));
   const FwPlan pl = fw_plan_at(plan_base, p.n_eq, p.Ne);
   const dim3 grid((unsigned)((p.B + 3) / 4));
   if (use_tile_kernel()) {
     hipLaunchKernelGGL(frame_plan_kernel, dim3(1), dim3(1024), (size_t)3 * (fw_groups(p.n_eq) + 2) * sizeof(int), s, p, W, plan_base, 8 * ft_M(W), FW_G, FW_EPG);
     hipLaunchKernelGGL((frame_tile_kernel<W>), grid, dim3(256), 4 * ft_lds_doubles(p.n_eq) * sizeof(double), s, p, ws, pl);
   } else if (fused_assembly()) {
-    hipLaunchKernelGGL(frame_plan_kernel, dim3(1), dim3(1024), (size_t)3 * (fw_groups(p.n_eq) + 2) * sizeof(int), s, p, W, plan_base, 0, FW_G, FW_EPG);
+    if (!reuse_plan)
+      hipLaunchKernelGGL(frame_plan_kernel, dim3(1), dim3(1024), (size_t)3 * (fw_groups(p.n_eq) + 2) * sizeof(int), s, p, W, plan_base, 0, FW_G, FW_EPG);
     if (use_pair_steps(p.kd)) hipLaunchKernelGGL((frame_wave_kernel<W, true, true>), grid, dim3(256), lds, s, p, ws, pl);
     else hipLaunchKernelGGL((frame_wave_kernel<W, true>), grid, dim3(256), lds, s, p, ws, pl);
   } else {
@@ -770,12 +795,22 @@ extern "C" size_t ops_frame_workspace_bytes(int B, int n_eq, int half_bandwidth)
   if (pack_kernel_serves(B, n_eq, half_bandwidth)) {   // per frame: the columns of L; once: the assembly plan
     int P, G, W;
     fp_config(half_bandwidth, &P, &G, &W);
-    return B == 0 ? 0 : (size_t)B * fp_frame_doubles(n_eq, W) * sizeof(double) + fw_plan_bytes(n_eq, ne_bound(n_eq), G, fp_epg(G));
+    return B == 0 ? 0 : (size_t)B * fp_frame_doubles(n_eq, W) * sizeof(double) + plan_region_bytes(n_eq, G, fp_epg(G));
   }
   if (wave_kernel_serves(B, n_eq, half_bandwidth))     // per frame: band / factor rows; once: the assembly plan (at most 21 entries and 72 coefficients per element)
-    return B == 0 ? 0 : (size_t)B * fw_frame_doubles(n_eq, half_bandwidth) * sizeof(double) + fw_plan_bytes(n_eq, 4 * n_eq + 64);
+    return B == 0 ? 0 : (size_t)B * fw_frame_doubles(n_eq, half_bandwidth) * sizeof(double) + plan_region_bytes(n_eq, FW_G, FW_EPG);
   if (frame_lds_resident_bytes(n_eq, half_bandwidth) <= LDS_MAX && !force_ws()) return 0;   // the band lives in LDS
   return (size_t)B * frame_lds_resident_bytes(n_eq, half_bandwidth);
+}
+
+// which plan (if any) a call of this shape builds at the start of its workspace: 0 = none; equal values = interchangeable plans
+extern "C" long ops_frame_plan_signature(int B, int n_eq, int half_bandwidth) {
+  if (B <= 0 || n_eq < 1 || half_bandwidth < 0 || half_bandwidth > 63) return 0;
+  const int kd = eff_kd(half_bandwidth);
+  int P, G, W;
+  if (pack_kernel_serves(B, n_eq, kd)) { fp_config(kd, &P, &G, &W); return (2L << 24) | (W << 16) | (G << 8) | P; }
+  if (wave_kernel_serves(B, n_eq, kd) && fused_assembly()) return (1L << 24) | (fw_width(kd) << 16) | (FW_G << 8) | (use_tile_kernel() ? 65 : 64);
+  return 0;
 }
 
 extern "C" int ops_frame_solve_batched_f64(int B, int n_nodes, int n_elems, int n_eq, int half_bandwidth,
@@ -784,6 +819,17 @@ extern "C" int ops_frame_solve_batched_f64(int B, int n_nodes, int n_elems, int 
                                            const double* I, const double* loads, long loads_bstride, double* disp,
                                            double* forces, double* V, double* M, int32_t* status, void* workspace,
                                            size_t workspace_bytes, void* stream) {
+  return ops_frame_solve_batched_f64_ex(B, n_nodes, n_elems, n_eq, half_bandwidth, elem_geo, elem_EA, elem_E, elem_w, elem_eq, node_eq, I, loads,
+                                        loads_bstride, disp, forces, V, M, status, workspace, workspace_bytes, stream, 0u);
+}
+
+extern "C" int ops_frame_solve_batched_f64_ex(int B, int n_nodes, int n_elems, int n_eq, int half_bandwidth,
+                                              const double* elem_geo, const double* elem_EA, const double* elem_E,
+                                              const double* elem_w, const int32_t* elem_eq, const int32_t* node_eq,
+                                              const double* I, const double* loads, long loads_bstride, double* disp,
+                                              double* forces, double* V, double* M, int32_t* status, void* workspace,
+                                              size_t workspace_bytes, void* stream, unsigned flags) {
+  const bool reuse_plan = (flags & OPS_FRAME_REUSE_PLAN) != 0;
   if (B < 0 || n_nodes < 2 || n_elems < 1 || n_eq < 1 || half_bandwidth < 0) return OPS_AMD_ERR_INVALID_ARG;
   if (B == 0) return OPS_AMD_OK;
   if (!elem_geo || !elem_EA || !elem_E || !elem_w || !elem_eq || !node_eq || !I || !loads || !disp || !forces || !V || !M)
@@ -829,32 +875,32 @@ extern "C" int ops_frame_solve_batched_f64(int B, int n_nodes, int n_elems, int 
   if (pack_kernel_serves(B, n_eq, kd)) {
     int P, G, W;
     fp_config(kd, &P, &G, &W);
-    const size_t need = (size_t)B * fp_frame_doubles(n_eq, W) * sizeof(double) + fw_plan_bytes(n_eq, n_elems, G, fp_epg(G));
-    if (!workspace || workspace_bytes < need) return OPS_AMD_ERR_INVALID_ARG;
+    const size_t need = (size_t)B * fp_frame_doubles(n_eq, W) * sizeof(double) + plan_region_bytes(n_eq, G, fp_epg(G));
+    if (!workspace || workspace_bytes < need || n_elems > ne_bound(n_eq)) return OPS_AMD_ERR_INVALID_ARG;
     hipError_t e = hipSuccess;
     switch (W) {
-      case 8: e = launch_pack<8, 16, 4>(p, (double*)workspace, s); break;
-      case 12: e = launch_pack<12, 16, 4>(p, (double*)workspace, s); break;
-      case 16: e = launch_pack<16, 32, 8>(p, (double*)workspace, s); break;
-      case 20: e = launch_pack<20, 32, 8>(p, (double*)workspace, s); break;
-      case 24: e = launch_pack<24, 32, 8>(p, (double*)workspace, s); break;
-      default: e = launch_pack<28, 32, 4>(p, (double*)workspace, s); break;
+      case 8: e = launch_pack<8, 16, 4>(p, (double*)workspace, s, reuse_plan); break;
+      case 12: e = launch_pack<12, 16, 4>(p, (double*)workspace, s, reuse_plan); break;
+      case 16: e = launch_pack<16, 32, 8>(p, (double*)workspace, s, reuse_plan); break;
+      case 20: e = launch_pack<20, 32, 8>(p, (double*)workspace, s, reuse_plan); break;
+      case 24: e = launch_pack<24, 32, 8>(p, (double*)workspace, s, reuse_plan); break;
+      default: e = launch_pack<28, 32, 4>(p, (double*)workspace, s, reuse_plan); break;
     }
     if (e != hipSuccess) { set_frame_error(hipGetErrorString(e)); return OPS_AMD_ERR_LAUNCH; }
     return OPS_AMD_OK;
   }
   if (wave_kernel_serves(B, n_eq, kd)) {
     const int W = fw_width(kd);
-    const size_t need = (size_t)B * fw_frame_doubles(n_eq, kd) * sizeof(double) + fw_plan_bytes(n_eq, n_elems);
-    if (!workspace || workspace_bytes < need) return OPS_AMD_ERR_INVALID_ARG;
+    const size_t need = (size_t)B * fw_frame_doubles(n_eq, kd) * sizeof(double) + plan_region_bytes(n_eq, FW_G, FW_EPG);
+    if (!workspace || workspace_bytes < need || n_elems > ne_bound(n_eq)) return OPS_AMD_ERR_INVALID_ARG;
     hipError_t e = hipSuccess;
     {
       switch (W) {
-        case 16: e = launch_wave<16>(p, (double*)workspace, s); break;
-        case 24: e = launch_wave<24>(p, (double*)workspace, s); break;
-        case 36: e = launch_wave<36>(p, (double*)workspace, s); break;
-        case 52: e = launch_wave<52>(p, (double*)workspace, s); break;
-        default: e = launch_wave<56>(p, (double*)workspace, s); break;
+        case 16: e = launch_wave<16>(p, (double*)workspace, s, reuse_plan); break;
+        case 24: e = launch_wave<24>(p, (double*)workspace, s, reuse_plan); break;
+        case 36: e = launch_wave<36>(p, (double*)workspace, s, reuse_plan); break;
+        case 52: e = launch_wave<52>(p, (double*)workspace, s, reuse_plan); break;
+        default: e = launch_wave<56>(p, (double*)workspace, s, reuse_plan); break;
       }
     }
     if (e != hipSuccess) { set_frame_error(hipGetErrorString(e)); return OPS_AMD_ERR_LAUNCH; }

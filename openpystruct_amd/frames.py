@@ -199,20 +199,28 @@ def frame_solve(topo: FrameTopology, I: torch.Tensor, loads: Optional[torch.Tens
                             torch.empty((B, topo.Ne), **f64), torch.empty((B, topo.Ne), **f64),
                             torch.empty((B,), dtype=torch.int32, device=dev))
     ws_bytes = int(lib.ops_frame_workspace_bytes(B, topo.n_eq, topo.kd))
-    ws = None
-    if ws_bytes:       # factor rows + the call's assembly plan: HBM workspace, cached on the topology PER STREAM (two solves on one
-        # topology from different streams or threads must not share factor rows or plan)
+    ws, flags, entry = None, 0, None
+    if ws_bytes:       # factor storage + the topology's assembly plan: HBM workspace, cached on the topology PER STREAM (two solves on one
+        # topology from different streams or threads must not share factor columns or plan)
         cache = topo.__dict__.setdefault("_ws", {})
         key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
-        ws = cache.get(key)
-        if ws is None or ws.numel() < ws_bytes:
-            ws = cache[key] = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        entry = cache.get(key)
+        if entry is None or entry[0].numel() < ws_bytes:
+            entry = cache[key] = [torch.empty(ws_bytes, dtype=torch.uint8, device=dev), 0]
+        ws = entry[0]
+        # the plan (the topology-only part of the assembly, at the start of the workspace) is built by the first call that uses this buffer and
+        # kept: a FrameTopology's arrays never change (include/openpystruct_amd.h OPS_FRAME_REUSE_PLAN)
+        sig = int(lib.ops_frame_plan_signature(B, topo.n_eq, topo.kd))
+        if sig != 0 and entry[1] == sig:
+            flags = _cabi.FRAME_REUSE_PLAN
     with torch.cuda.device(dev):
-        rc = lib.ops_frame_solve_batched_f64(
+        rc = lib.ops_frame_solve_batched_f64_ex(
             B, topo.Nn, topo.Ne, topo.n_eq, topo.kd, topo.d_geo.data_ptr(), topo.d_EA.data_ptr(), topo.d_E.data_ptr(),
             topo.d_w.data_ptr(), topo.d_elem_eq.data_ptr(), topo.d_node_eq.data_ptr(), I.data_ptr(), loads.data_ptr(), lbs,
             out.disp.data_ptr(), out.forces.data_ptr(), out.V.data_ptr(), out.M.data_ptr(), out.status.data_ptr(),
-            ws.data_ptr() if ws is not None else None, ws_bytes, torch.cuda.current_stream(dev).cuda_stream)
+            ws.data_ptr() if ws is not None else None, ws_bytes, torch.cuda.current_stream(dev).cuda_stream, flags)
+    if entry is not None:
+        entry[1] = sig if rc == _cabi.OK else 0
     if rc == _cabi.ERR_UNSUPPORTED:
         raise NotImplementedError(f"frame too large: n_eq={topo.n_eq}, half bandwidth={topo.kd} (half bandwidth <= 63: a (kd+6)-column ring, one "
                                   f"n_eq vector and two 24-column chunks must fit 160 KB of LDS; beyond 63, up to 1024: one n_eq vector and one column)")

@@ -27,7 +27,7 @@ def test_header_symbols_are_exported(lib):
 
 
 def test_introspection_calls(lib):
-    assert lib.ops_amd_abi_version() == 12     # 12: ops_mlp_wgrad_group_norm, OPS_ADAM_NORM_READY; 11: ops_tfd_front_args.n_order (a walked-past cursor wraps); 10: loss on the TFD head's tile, identity_act of the TFD launches, ops_physics_loss_*; 2: ops_beam_sizing_epoch_f32 takes I_last (float32) instead of I64; 3: ops_mlp_* layer blocks; 4: diffusion combine with a bf16 copy / two gradients; 5: encoder-layer launches on tiled weights; 6: head / front-end launches, column-sum jobs and 24 problems in the grouped weight-gradient launch, ln_part; 7: ops_mlp_strip_args.eval_stats; 8: ops_sizing_draw_cases_f64; 9: evaluation slots of ops_mlp_strip_args
+    assert lib.ops_amd_abi_version() == 13     # 13: ops_frame_solve_batched_f64_ex (OPS_FRAME_REUSE_PLAN), ops_frame_plan_signature; 12: ops_mlp_wgrad_group_norm, OPS_ADAM_NORM_READY; 11: ops_tfd_front_args.n_order (a walked-past cursor wraps); 10: loss on the TFD head's tile, identity_act of the TFD launches, ops_physics_loss_*; 2: ops_beam_sizing_epoch_f32 takes I_last (float32) instead of I64; 3: ops_mlp_* layer blocks; 4: diffusion combine with a bf16 copy / two gradients; 5: encoder-layer launches on tiled weights; 6: head / front-end launches, column-sum jobs and 24 problems in the grouped weight-gradient launch, ln_part; 7: ops_mlp_strip_args.eval_stats; 8: ops_sizing_draw_cases_f64; 9: evaluation slots of ops_mlp_strip_args
     assert lib.ops_amd_max_elements() >= 100
     assert b"beam_rows_kernel<16, 7" in lib.ops_beam_solve_kernel_name(10000, 100, 0)       # default: the row-staged 16-lane kernel
     assert b"beam_rows_kernel<16, 7" in lib.ops_beam_solve_kernel_name(100000, 100, 0)

@@ -648,3 +648,99 @@ def test_small_batches_take_a_workgroup_per_frame_and_large_ones_a_wave(monkeypa
             assert np.abs(sol.forces[kk].cpu().numpy() - f).max() <= 1e-6 * np.abs(f).max()
     monkeypatch.setenv("OPS_AMD_FRAME_LATENCY_BATCH", "0")
     assert int(lib.ops_frame_workspace_bytes(1, topo.n_eq, topo.kd)) > 0
+
+
+# ---- r06: several frames per wavefront (csrc/frame_pack.hpp) ----
+_PACK_SHAPES = [(1, 1, 5, 8), (10, 1, 5, 8), (1, 10, 8, 12), (2, 2, 8, 12), (3, 3, 11, 12), (21, 3, 11, 12), (4, 4, 14, 16), (9, 4, 14, 16),
+                (5, 5, 17, 20), (10, 6, 20, 24), (7, 7, 23, 24), (8, 8, 26, 28), (10, 8, 26, 28)]
+
+
+@pytest.mark.parametrize("bays,stories,kd,W", _PACK_SHAPES)
+def test_packed_frames_vs_oracle_and_isolation(monkeypatch, bays, stories, kd, W):
+    """Half bandwidths up to 27 (95 of the 100 (bays, stories) draws of FR:17-18): 16 or 32 lanes per frame, 4 or 2 frames per wave -- every
+    compiled (window width, lanes, group size) against the oracle, with a frame that is not positive definite and a frame with a NaN load in the
+    SAME waves as healthy ones (nothing may cross between the lane groups of a wave), a batch that does not fill its last wave, and against one
+    wave per frame (OPS_AMD_FRAME_PACK=0: same arithmetic, so the displacements agree to the order of the assembly's LDS additions)."""
+    from openpystruct_amd import _cabi, frames
+    topo = frames.grid_frame(bays, stories)
+    assert topo.kd == kd
+    lib = _cabi.load()
+    B = 11
+    sig = int(lib.ops_frame_plan_signature(B, topo.n_eq, topo.kd))
+    assert sig >> 24 == 2 and (sig >> 16) & 0xFF == W               # the packed kernel, this window width
+    rng = np.random.default_rng(bays * 100 + stories)
+    I = np.exp(rng.uniform(np.log(5e-5), np.log(5e-3), size=(B, topo.Ne)))
+    I[6, min(3, topo.Ne - 1)] = -1.0
+    loads = np.broadcast_to(topo.nodal_loads, (B,) + topo.nodal_loads.shape).copy()
+    loads[9, -1, 0] = np.nan
+    It, Lt = torch.as_tensor(I, device="cuda"), torch.as_tensor(loads, device="cuda")
+    sol = frames.frame_solve(topo, It, Lt)
+    torch.cuda.synchronize()
+    st = sol.status.cpu().numpy()
+    healthy = [b for b in range(B) if b not in (6, 9)]
+    assert st[6] != 0 and st[healthy].sum() == 0 and torch.isnan(sol.disp[6]).all() and torch.isnan(sol.disp[9]).any()
+    for b in healthy:
+        d, f, s_, neq, _ = _oracle(topo, I[b])
+        assert s_ == 0 and neq == topo.n_eq
+        assert relerr(sol.disp[b].cpu().numpy().ravel(), d.ravel()) < 1e-8, b
+        assert relerr(sol.forces[b].cpu().numpy().ravel(), f.ravel()) < 1e-7, b
+    monkeypatch.setenv("OPS_AMD_FRAME_PACK", "0")
+    assert int(lib.ops_frame_plan_signature(B, topo.n_eq, topo.kd)) >> 24 == 1
+    ref = frames.frame_solve(topo, It, Lt)
+    torch.cuda.synchronize()
+    assert relerr(sol.disp[healthy].cpu().numpy().ravel(), ref.disp[healthy].cpu().numpy().ravel()) < 1e-11
+    np.testing.assert_array_equal(ref.status.cpu().numpy() != 0, st != 0)
+
+
+def test_packed_frames_keep_the_plan_between_calls(monkeypatch):
+    """The assembly plan at the start of the workspace is built by the first call on a FrameTopology and kept (OPS_FRAME_REUSE_PLAN): later calls
+    with other inertias, other loads and another batch size answer like the oracle; a batch size that changes the kernel family rebuilds; the plain
+    C entry point (no flag) rebuilds every time and gives the same answers."""
+    from openpystruct_amd import _cabi, frames
+    topo = frames.grid_frame(5, 5)
+    rng = np.random.default_rng(5)
+    calls = []
+    lib = _cabi.load()
+    real = lib.ops_frame_solve_batched_f64_ex
+
+    class Spy:
+        def __call__(self, *a):
+            calls.append(a[-1])
+            return real(*a)
+    monkeypatch.setattr(lib, "ops_frame_solve_batched_f64_ex", Spy())
+    for B in (9, 9, 4, 9):
+        I = np.exp(rng.uniform(np.log(5e-5), np.log(5e-3), size=(B, topo.Ne)))
+        loads = np.broadcast_to(topo.nodal_loads, (B,) + topo.nodal_loads.shape) * rng.uniform(0.5, 2.0, size=(B, 1, 1))
+        sol = frames.frame_solve(topo, torch.as_tensor(I, device="cuda"), torch.as_tensor(loads.copy(), device="cuda"))
+        torch.cuda.synchronize()
+        assert int(sol.status.abs().sum()) == 0
+        for b in (0, B - 1):
+            d, f, s_, _, _ = bo.solve_model_3dof(topo.coords, topo.conn, topo.A, topo.E, I[b], topo.fix3, loads[b], wy=topo.wy, wx=topo.wx)
+            assert relerr(sol.disp[b].cpu().numpy().ravel(), d.ravel()) < 1e-8
+            assert relerr(sol.forces[b].cpu().numpy().ravel(), f.ravel()) < 1e-7
+    assert calls == [0, _cabi.FRAME_REUSE_PLAN, _cabi.FRAME_REUSE_PLAN, _cabi.FRAME_REUSE_PLAN]
+    # the library's default dispatch sends small batches to the workgroup-per-frame kernels (no plan): the signature changes, the flag goes
+    monkeypatch.delenv("OPS_AMD_FRAME_LATENCY_BATCH", raising=False)
+    assert int(lib.ops_frame_plan_signature(9, topo.n_eq, topo.kd)) == 0 and int(lib.ops_frame_plan_signature(8192, topo.n_eq, topo.kd)) != 0
+
+
+def test_packed_frames_persistent_waves_walk_the_batch():
+    """More frames than the chip holds at once: every wave solves several sets of frames with ONE workspace slot (the launch is capped at the
+    resident workgroups).  Sampled frames against the oracle, and the whole batch against itself in another order (a frame's answer may not depend
+    on which wave, lane group or turn of the loop solves it)."""
+    from openpystruct_amd import frames
+    topo = frames.grid_frame(2, 2)
+    B = 70001                                           # 16 frames per workgroup: > 4 000 workgroups, a last wave with one frame
+    rng = np.random.default_rng(22)
+    I = np.exp(rng.uniform(np.log(5e-5), np.log(5e-3), size=(B, topo.Ne)))
+    It = torch.as_tensor(I, device="cuda")
+    sol = frames.frame_solve(topo, It)
+    assert int(sol.status.abs().sum()) == 0
+    for b in (0, 1, 15, 16, 4095, 16384, 40000, 65535, 65536, B - 2, B - 1):
+        d, f, s_, _, _ = _oracle(topo, I[b])
+        assert relerr(sol.disp[b].cpu().numpy().ravel(), d.ravel()) < 1e-8, b
+        assert relerr(sol.forces[b].cpu().numpy().ravel(), f.ravel()) < 1e-7, b
+    perm = torch.randperm(B, device="cuda")
+    sol2 = frames.frame_solve(topo, It[perm].contiguous())
+    scale = float(sol.disp.abs().max())
+    assert float((sol2.disp - sol.disp[perm]).abs().max()) < 1e-11 * scale
