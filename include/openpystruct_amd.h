@@ -307,19 +307,20 @@ int ops_surrogate_loss_grad_sum_f32(int B, int C, int nI, int nD, const void* pr
                                     float box_weight, float rel_penalty, float* loss, float* loss_sum, void* grad, void* workspace, void* stream);
 size_t ops_surrogate_loss_workspace_bytes(void);
 
-/* MEASURED ALTERNATIVE to ops_beam_solve_batched_f64 (not used by the product): one lane per beam, sequential block-Thomas
- * per lane, factor in an HBM workspace of ops_beam_solve_lane_workspace_bytes(B, Ne) bytes.  Shared x [N], E / wy scalars,
- * fix [N]; dense I [B,Ne], Fy [B,N] and outputs.  Kept so that the design choice of DESIGN.md 4.1 rests on a measurement. */
-int ops_beam_solve_lane_per_beam_f64(int B, int Ne, const double* x, const double* E, const double* I, const uint8_t* fix,
-                                     const double* Fy, const double* wy, double* v, double* theta, double* V, double* M,
-                                     int32_t* status, void* workspace, size_t workspace_bytes, void* stream);
-size_t ops_beam_solve_lane_workspace_bytes(int B, int Ne);
 
 /* Largest Ne a build supports, ABI version, and the text of the last HIP error seen by
  * this thread (empty string if none). */
 int ops_amd_max_elements(void);
 int ops_amd_abi_version(void);
 const char* ops_amd_last_error(void);
+
+/* Library options (r06, ABI 13): the ONE way to steer the dispatch from outside -- the library reads no environment variable.  Process-wide,
+ * thread-safe, effective from the next call.  Unknown name: ERR_INVALID_ARG / -2.
+ *   "frame_latency_batch"  -1 (default): batches of up to 256 .. 4 000 frames (by frame size) take the workgroup-per-frame kernels, which answer
+ *                          a handful of frames sooner; N >= 0: that threshold is N (0: the tuned kernels for every batch)
+ *   "frame_pack"           1 (default): half bandwidths up to 27 take 16 or 32 lanes per frame; 0: one wave per frame for every band (A/B) */
+int ops_amd_set_option(const char* name, long value);
+long ops_amd_get_option(const char* name);
 
 /* Name of the kernel symbol a given (B, Ne, tiling) call dispatches to -- lets profilers
  * and bench.py find the right row in a rocprofv3 kernel trace. */

@@ -37,8 +37,8 @@ EXPORTS = (
     "ops_flat_adam_workspace_bytes",
     "ops_surrogate_loss_grad_f32",
     "ops_surrogate_loss_workspace_bytes",
-    "ops_beam_solve_lane_per_beam_f64",
-    "ops_beam_solve_lane_workspace_bytes",
+    "ops_amd_set_option",
+    "ops_amd_get_option",
     "ops_amd_max_elements",
     "ops_amd_abi_version",
     "ops_gather_rows_noise_f32",
@@ -319,10 +319,10 @@ def load():
     lib.ops_gather_rows_noise_targets_f32.argtypes = [it, lg, vp, vp, vp, ull, vp, vp, it, vp, it, vp, vp]
     lib.ops_fused_bn_act_bwd.restype = it
     lib.ops_fused_bn_act_bwd.argtypes = [it, it, vp, it, vp, vp, vp, vp, vp, fl, it, fl, vp, vp, vp, vp, vp]
-    lib.ops_beam_solve_lane_per_beam_f64.restype = it
-    lib.ops_beam_solve_lane_per_beam_f64.argtypes = [it, it] + [vp] * 12 + [ctypes.c_size_t, vp]
-    lib.ops_beam_solve_lane_workspace_bytes.restype = ctypes.c_size_t
-    lib.ops_beam_solve_lane_workspace_bytes.argtypes = [it, it]
+    lib.ops_amd_set_option.restype = it
+    lib.ops_amd_set_option.argtypes = [ctypes.c_char_p, lg]
+    lib.ops_amd_get_option.restype = lg
+    lib.ops_amd_get_option.argtypes = [ctypes.c_char_p]
     lib.ops_mlp_strip_launch.restype = it
     lib.ops_mlp_strip_launch.argtypes = [ctypes.POINTER(MlpStripArgs), vp]
     lib.ops_mlp_spart_doubles.restype = ctypes.c_size_t
@@ -376,3 +376,17 @@ def load():
                                     f"this package needs {ABI_VERSION}: rebuild with `python -m openpystruct_amd.build --force`")
     _lib = lib
     return lib
+
+
+def set_option(name: str, value: int) -> None:
+    """include/openpystruct_amd.h ops_amd_set_option: "frame_latency_batch" (-1 = the library's model, 0 = tuned kernels for every batch),
+    "frame_pack" (0 = one wave per frame for every half bandwidth).  The library reads no environment variable."""
+    if load().ops_amd_set_option(name.encode(), int(value)) != OK:
+        raise ValueError(f"unknown library option {name!r}")
+
+
+def get_option(name: str) -> int:
+    v = int(load().ops_amd_get_option(name.encode()))
+    if v == -2:
+        raise ValueError(f"unknown library option {name!r}")
+    return v

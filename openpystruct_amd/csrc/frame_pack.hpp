@@ -41,6 +41,13 @@ __host__ __device__ inline bool fp_config(int kd, int* P, int* G, int* W) {
   if (kd <= 19) { *P = 32; *G = 8; *W = 20; return true; }
   if (kd <= 23) { *P = 32; *G = 8; *W = 24; return true; }
   if (kd <= 27) { *P = 32; *G = 4; *W = 28; return true; }
+#ifdef FP_WITH_P64     // (r06, measured: this kernel at 64 lanes per frame -- correct on every size, 10 x 10 0.91 x, 12 x 12 1.09 x, 15 x 16 0.98 x of
+                       //  frame_wave.hpp's kernel, whose wave-wide readlanes and 8-column backward chain it replaces with LDS traffic: not the default)
+  if (kd <= 35) { *P = 64; *G = 8; *W = 36; return true; }      // one frame per wave: the same kernel, F = 1
+  if (kd <= 43) { *P = 64; *G = 8; *W = 44; return true; }
+  if (kd <= 51) { *P = 64; *G = 8; *W = 52; return true; }
+  if (kd <= 55) { *P = 64; *G = 8; *W = 56; return true; }
+#endif
   return false;
 }
 // entry slots per plan block: the grid frames of the reference's range need at most 60 (G = 4) / 116 (G = 8) entries per row group (nodes with
@@ -153,7 +160,7 @@ __host__ __device__ constexpr int fp_tb(int P) { return (P / 8 + (P / 8) * (P / 
 template <int W, int P>
 __device__ __forceinline__ void fp_backward(const double* __restrict__ Lc, double* __restrict__ xs, double* __restrict__ tb, int n, int nl,
                                             int kd, int r) {
-  constexpr int U = P / 8, MF = (W + 7) / 8, NT = U * (U - 1) / 2, D = FP_BD;
+  constexpr int U = P / 8, MF = (W + 7) / 8, NT = U * (U - 1) / 2, D = P == 64 ? 2 : FP_BD;      // (64 lanes: 7 registers per pass and lane)
   static_assert(U >= 2, "frame_pack: at least 16 lanes per frame");
   const int u = r >> 3, k = r & 7;
   xs[n + r] = 0.0;                                        // rows past the last equation (the idle steps left garbage there)
@@ -223,7 +230,7 @@ __device__ __forceinline__ void fp_backward(const double* __restrict__ Lc, doubl
 
 template <int W, int P, int G>
 __device__ __forceinline__ void frame_pack_body(const FrameParams& p, double* __restrict__ Lw, unsigned loff, double* __restrict__ lds, int r, long b,
-                                                bool live, const FwPlan& pl) {
+                                                bool live, const FwPlan& pl, bool stage_I) {
   constexpr int EPG = fp_epg(G), KE = EPG / P, PITCH = W + 2;
   static_assert(EPG % P == 0 && W % 4 == 0 && (P & (P - 1)) == 0, "frame_pack: sizes");
   const int n = p.n_eq, kd = p.kd;
@@ -245,11 +252,11 @@ __device__ __forceinline__ void frame_pack_body(const FrameParams& p, double* __
   // the frame's own data, ONE round trip to HBM for the whole solve: inertias and right-hand side (consistent element loads of the plan + the
   // nodal load of each equation's DOF) into LDS.  xs[q] holds the right-hand side of row q until the row's group is built (long before step q
   // overwrites it with w_q).  Everything the row groups need after this is the plan -- the same addresses for every frame of the launch: L2.
-  double* Il = xs + (n + P);                                // [Ne]
+  double* Il = xs + (n + P);                                // [Ne] (stage_I; a frame with so many elements that they do not fit: gathered from HBM)
+  const double* Ib = p.I + b * p.Ne;
   {
-    const double* Ib = p.I + b * p.Ne;
     const double* lb = p.loads + b * p.loads_bs;
-    for (int e = r; e < p.Ne; e += P) Il[e] = Ib[e];
+    if (stage_I) for (int e = r; e < p.Ne; e += P) Il[e] = Ib[e];
     for (int q = r; q < n + P; q += P) xs[q] = q < n ? pl.rhs_base[q] + lb[pl.eq_dof[q]] : 0.0;
   }
   unsigned eB[KE];
@@ -270,14 +277,17 @@ __device__ __forceinline__ void frame_pack_body(const FrameParams& p, double* __
   auto build = [&]() {                                      // group gB accumulated into the (zeroed) parking area
 #pragma unroll
     for (int k = 0; k < KE; ++k)
-      if ((int)eB[k] < 0) atomicAdd(&stage[eB[k] & FW_SLOT_MASK], __builtin_fma(Il[(eB[k] >> FW_SLOT_BITS) & 0x1FFFFF], bb[k], ba[k]));
+      if ((int)eB[k] < 0) {
+        const unsigned e = (eB[k] >> FW_SLOT_BITS) & 0x1FFFFF;
+        atomicAdd(&stage[eB[k] & FW_SLOT_MASK], __builtin_fma(stage_I ? Il[e] : Ib[e], bb[k], ba[k]));
+      }
     if (n_extra != 0) {                                     // nodes with more than four elements: extra blocks, not prefetched
       const int gi = gB / G < pl.ng ? gB / G : pl.ng;
       for (int blk = pl.xstart[gi]; blk < pl.xstart[gi + 1]; ++blk)
         for (int k = 0; k < KE; ++k) {
           const size_t i = (size_t)(pl.ng + 1 + blk) * EPG + r + P * k;
           const unsigned w = pl.ent[i];
-          if ((int)w < 0) atomicAdd(&stage[w & FW_SLOT_MASK], __builtin_fma(Il[(w >> FW_SLOT_BITS) & 0x1FFFFF], pl.kb[i], pl.ka[i]));
+          if ((int)w < 0) atomicAdd(&stage[w & FW_SLOT_MASK], __builtin_fma(Ib[(w >> FW_SLOT_BITS) & 0x1FFFFF], pl.kb[i], pl.ka[i]));
         }
     }
     if (r < G) stage[r * PITCH + W] = xs[gB + r];           // (rows past the last equation: zero, staged above)
@@ -332,8 +342,9 @@ __device__ __forceinline__ void frame_pack_body(const FrameParams& p, double* __
     if constexpr ((S_) < W) {                                                         \
       if (j0 + (S_) < n) { FP_STEP(S_) FP_STEP(S_ + 1) FP_STEP(S_ + 2) FP_STEP(S_ + 3) } \
     }
-    static_assert(W <= 28, "frame_pack: window widths up to 28");
-    FP_STEP4(0) FP_STEP4(4) FP_STEP4(8) FP_STEP4(12) FP_STEP4(16) FP_STEP4(20) FP_STEP4(24)
+    static_assert(W <= 56, "frame_pack: window widths up to 56");
+    FP_STEP4(0) FP_STEP4(4) FP_STEP4(8) FP_STEP4(12) FP_STEP4(16) FP_STEP4(20) FP_STEP4(24) FP_STEP4(28) FP_STEP4(32) FP_STEP4(36) FP_STEP4(40)
+    FP_STEP4(44) FP_STEP4(48) FP_STEP4(52)
 #undef FP_STEP4
 #undef FP_STEP
   }
@@ -349,11 +360,11 @@ __device__ __forceinline__ void frame_pack_body(const FrameParams& p, double* __
 
 // waves per SIMD the register allocator is asked to make room for: the wave is latency-bound (LDS round trips of the line, reciprocal chain)
 #ifndef FP_WAVES
-#define FP_WAVES(W) ((W) <= 8 ? 4 : 3)
+#define FP_WAVES(W) ((W) <= 8 ? 4 : (W) <= 28 ? 3 : 2)
 #endif
 template <int W, int P, int G>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FP_WAVES(W))))
-void frame_pack_kernel(const FrameParams p, double* __restrict__ ws, const FwPlan pl) {
+void frame_pack_kernel(const FrameParams p, double* __restrict__ ws, const FwPlan pl, int ne_lds) {
   extern __shared__ double lds[];
   constexpr int F = 64 / P;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, sub = lane / P, r = lane & (P - 1);
@@ -363,7 +374,7 @@ void frame_pack_kernel(const FrameParams p, double* __restrict__ ws, const FwPla
   // against 5 KB of inputs and results)
   const size_t fd = fp_frame_doubles(p.n_eq, W);            // (F frames of at most a few hundred KB: the lane group's offset fits 32 bits)
   const long wslot = (long)blockIdx.x * 4 + wave, stride = (long)gridDim.x * 4 * F;
-  const unsigned ldso = (unsigned)((wave * F + sub) * fp_lds_doubles(p.n_eq, p.Ne, P, G, W));
+  const unsigned ldso = (unsigned)((wave * F + sub) * fp_lds_doubles(p.n_eq, ne_lds, P, G, W));     // ne_lds = Ne (inertias staged in LDS) or 0
   for (long first = wslot * F; first < p.B; first += stride) {      // (wave-uniform)
     // the lane's coordinates are re-read "opaquely" per frame: left loop-invariant, every per-lane address of the body (plan, LDS areas, workspace)
     // is hoisted out of this loop and kept in registers across it (+40 VGPRs, 100-250 bytes of scratch)
@@ -373,7 +384,7 @@ void frame_pack_kernel(const FrameParams p, double* __restrict__ ws, const FwPla
     const long slot = first + sub_;
     const bool live = slot < p.B;
     const long b = live ? slot : (long)p.B - 1;
-    frame_pack_body<W, P, G>(p, ws + (size_t)wslot * F * fd, (unsigned)((live ? sub_ : 0) * fd), lds + ldso_, r_, b, live, pl);
+    frame_pack_body<W, P, G>(p, ws + (size_t)wslot * F * fd, (unsigned)((live ? sub_ : 0) * fd), lds + ldso_, r_, b, live, pl, ne_lds != 0);
     fp_order();
   }
 }

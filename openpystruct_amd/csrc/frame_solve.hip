@@ -30,6 +30,7 @@
 #include <stdlib.h>
 
 #include <atomic>
+#include <string_view>
 
 #include "../../include/openpystruct_amd.h"
 
@@ -52,18 +53,7 @@ struct FrameParams {
   double* forces;            // [B,Ne,6]
   double* V; double* M;      // [B,Ne] = forces[:, :, 1], forces[:, :, 2] (what the sizing loss reads, FR:151-153)
   int32_t* status;
-  unsigned long long* trace;   // diagnostic builds (-DOPS_AMD_FRAME_TRACE) only
 };
-
-#ifdef OPS_AMD_FRAME_TRACE
-#define FRAME_STAMP(slot, wait)                                                                         \
-  if (p.trace && blockIdx.x == 0 && (tid == 0 || tid == 128) && j < 3 * 40) {                        \
-    if (wait) __builtin_amdgcn_s_waitcnt(0xC07F);                                                        \
-    s_trace[((tid == 128 ? 0 : 1) * 40 + j / 3) * 4 + slot] = clock64();                                   \
-  }
-#else
-#define FRAME_STAMP(slot, wait)
-#endif
 
 __device__ __forceinline__ double frcp(double d) {   // v_rcp_f64 + two Newton steps (full precision, normal range)
   double r = __builtin_amdgcn_rcp(d);
@@ -239,9 +229,6 @@ __global__ __launch_bounds__(1024) void frame_solve_kernel(const FrameParams p, 
   double* ab = lds;                     // [n3][ld]
   double* rhs = lds + (size_t)n3 * ld;  // [n3]
   __shared__ int s_bad;
-#ifdef OPS_AMD_FRAME_TRACE
-  __shared__ unsigned long long s_trace[2 * 40 * 4];
-#endif
   const int tid = threadIdx.x, T = blockDim.x;
   const long b = blockIdx.x;
   if (tid == 0) s_bad = 0;
@@ -270,9 +257,7 @@ __global__ __launch_bounds__(1024) void frame_solve_kernel(const FrameParams p, 
     double* c0 = ab + (size_t)j * ld;
     double* c1 = c0 + ld;
     double* c2 = c1 + ld;
-    FRAME_STAMP(0, false)
     const Pivot3 f = load_pivot(c0, c1, c2);
-    FRAME_STAMP(1, true)
     if (look) {
       if (j + 3 < n3 && lookahead_pivot(f, c0, c1, c2, c2 + ld, c2 + 2 * ld, c2 + 3 * ld, kd, tid) && tid == 0) s_bad = 1;
     } else if (fl < 64 && fl < kd && j + 3 + fl < n3) {     // f_X -= B_X P^-1 f_P
@@ -294,9 +279,7 @@ __global__ __launch_bounds__(1024) void frame_solve_kernel(const FrameParams p, 
         *t = __builtin_fma(-a0, w1, __builtin_fma(-a1, w2, __builtin_fma(-a2, w3, *t)));
       }
     }
-    FRAME_STAMP(2, true)
     __syncthreads();
-    FRAME_STAMP(3, false)
   }
   if (__builtin_amdgcn_readfirstlane(tid) < 64) __builtin_amdgcn_s_setprio(0);
   // ---- backward substitution: wave 0, no workgroup barriers ----
@@ -319,9 +302,6 @@ __global__ __launch_bounds__(1024) void frame_solve_kernel(const FrameParams p, 
     }
   }
   __syncthreads();
-#ifdef OPS_AMD_FRAME_TRACE
-  if (p.trace && blockIdx.x == 0) for (int i = tid; i < 2 * 40 * 4; i += T) p.trace[i] = s_trace[i];
-#endif
   write_results(p, b, rhs, s_bad != 0, tid, T);
 }
 
@@ -599,16 +579,30 @@ constexpr int FRAME_WIDE_MAX_KD = 1024;      // frame_wide_kernel's backward swe
 }  // namespace opsamd
 
 #include "frame_wave.hpp"
-#include "frame_tile.hpp"
 #include "frame_pack.hpp"
 
 using namespace opsamd;
 
-#ifdef OPS_AMD_FRAME_TRACE
-static const size_t LDS_MAX = 160 * 1024 - 64 - 4096;   // room for the stamp buffer
-#else
 static const size_t LDS_MAX = 160 * 1024 - 64;
-#endif
+
+// ---- library options (ops_amd_set_option: the one place a caller -- tests, A/B scripts -- steers the dispatch; no environment variable is read) ----
+static std::atomic<long> g_frame_latency_batch{-1};      // "frame_latency_batch": -1 = the model below; 0 = tuned kernels for every batch
+static std::atomic<long> g_frame_pack{1};                // "frame_pack": 0 = one wave per frame for every half bandwidth (A/B)
+
+extern "C" int ops_amd_set_option(const char* name, long value) {
+  if (!name) return OPS_AMD_ERR_INVALID_ARG;
+  const std::string_view n(name);
+  if (n == "frame_latency_batch") { g_frame_latency_batch.store(value < 0 ? -1 : value); return OPS_AMD_OK; }
+  if (n == "frame_pack") { g_frame_pack.store(value != 0); return OPS_AMD_OK; }
+  return OPS_AMD_ERR_INVALID_ARG;
+}
+extern "C" long ops_amd_get_option(const char* name) {
+  if (!name) return -2;
+  const std::string_view n(name);
+  if (n == "frame_latency_batch") return g_frame_latency_batch.load();
+  if (n == "frame_pack") return g_frame_pack.load();
+  return -2;
+}
 
 static size_t frame_lds_resident_bytes(int n_eq, int kd) {
   return ((size_t)frame_n3(n_eq) * frame_ld(kd) + frame_n3(n_eq)) * sizeof(double);
@@ -623,56 +617,24 @@ static void frame_threads(int kd, bool resident, int* T, int* pp_use) {
   // 8.55e5/s) --, two for the one-workgroup-per-CU frames in between (10x10: 2.44e6 vs 2.40e6/s)
   int pp = (!resident || kd <= 24) ? 4 : 2;
   while (threads(pp) > 1024 && pp < FRAME_PP) ++pp;
-  // tuning knob for experiments: OPS_AMD_FRAME_PP = entries per thread
-  if (const char* e = getenv("OPS_AMD_FRAME_PP")) {
-    const int v = atoi(e);
-    if (v >= 1 && v <= FRAME_PP && threads(v) <= 1024) pp = v;
-  }
   *pp_use = pp;
   *T = threads(pp) < 192 ? 192 : threads(pp);
 }
 
 static int eff_kd(int half_bandwidth) { return half_bandwidth < 3 ? 3 : half_bandwidth; }   // a block step's band covers its own pivot
 
-static bool force_ws() { const char* e = getenv("OPS_AMD_FRAME_FORCE_WS"); return e && atoi(e) != 0; }
-
-// kd <= 55: the wave-per-frame kernel (frame_wave.hpp); OPS_AMD_FRAME_LEGACY=1 keeps the r01 workgroup-per-frame kernels (A/B)
-static bool use_wave_kernel(int kd) {
-  const char* e = getenv("OPS_AMD_FRAME_LEGACY");
-  return kd <= 55 && !(e && atoi(e) != 0);
-}
-
-// the assembly fused into the solve (plan built per call, frame_wave.hpp); OPS_AMD_FRAME_FUSED_ASM=0: separate assembly kernel (A/B)
-static bool fused_assembly() { const char* e = getenv("OPS_AMD_FRAME_FUSED_ASM"); return !(e && atoi(e) == 0); }
-
-// r04, measured alternative (frame_tile.hpp; fused assembly only): the window as an 8 x 8 lane grid of register tiles, OPS_AMD_FRAME_TILE=1.
-// Correct (same factor columns as the row-per-lane window up to the last bit of a few assembled entries) but slower on every size measured
-// (15 x 16: 4.2 - 5.2 ms against 3.7 - 3.9 per 12 288 frames; profiles/r04_notes.md 11), so the row-per-lane window stays the default.
-// r05, measured alternative: two columns per elimination step (frame_wave.hpp fw_step2; fused assembly, kd <= 54).  OPS_AMD_FRAME_PAIR=1.
-static bool use_pair_steps(int kd) {
-  const char* e = getenv("OPS_AMD_FRAME_PAIR");
-  return fused_assembly() && kd <= 54 && e && atoi(e) != 0;
-}
-static bool use_tile_kernel() {
-  const char* e = getenv("OPS_AMD_FRAME_TILE");
-  return fused_assembly() && e && atoi(e) != 0;
-}
-
-// Does the wave-per-frame kernel serve this size?  Its four waves' LDS (right-hand sides + parking areas) must fit one CU, its
-// plan kernel one workgroup's LDS.  Frames beyond that (tall and narrow: thousands of equations) take the workgroup-per-frame
-// kernels, whose band streams through an LDS ring -- ops_frame_workspace_bytes and the solve decide with this one function.
-// r05: batches of at most one frame per CU are LATENCY-bound, and there a workgroup per frame (r01 kernels: the whole workgroup works on
-// the one frame its CU has) answers sooner than a wave per frame (one wave works, the CU's other 15 wave slots idle): 10 x 10 118 us against
-// 207 - 221 us for 1 .. 256 frames, 5 x 5 47 / 84, 3 x 3 36 / 55, 15 x 16 (band in HBM) 472 - 492 / 535 - 576; at 1 024 frames the wave kernel is ahead
-// (10 x 10: 231 / 426 us) (scripts/frame_small_batch_ab.py).  That is the reference's own use of the frame solve -- ONE frame per epoch
-// (FR:178-183) -- and the command shim's.  OPS_AMD_FRAME_LATENCY_BATCH overrides the threshold (0: wave kernel for every batch).
-// Above one frame per CU the workgroup kernels saturate at ~8.5e11 / (n kd^2) frames per second (10 x 10: 2.4e6, 5 x 5: 3.5e7) while a launch
-// of the wave kernel never takes less than ~25 us + 0.55 us per equation (one wave's chain: 10 x 10 207 us, 5 x 5 84 us): the batch at which
-// the two meet -- 10 x 10: ~500 frames, 5 x 5: ~2 500 -- is the threshold, at least 256 (one frame per CU) and at most 4 000 (the smallest
-// frames meet at ~4 096 whatever the model says).  scripts/frame_dispatch_sweep.py: the choice is within 6 % of the faster kernel for 3 x 3 ..
-// 15 x 16 frames and 128 .. 16 384 frames per launch.
+// Which kernel family serves a call.  Batches of at most about one frame per CU are LATENCY-bound, and there a workgroup per frame (r01 kernels:
+// the whole workgroup works on the one frame its CU has) answers sooner than a wave per frame (one wave works, the CU's other 15 wave slots idle):
+// 10 x 10 118 us against 207 - 221 us for 1 .. 256 frames, 5 x 5 47 / 84, 3 x 3 36 / 55, 15 x 16 (band in HBM) 472 - 492 / 535 - 576; at 1 024 frames
+// the wave kernel is ahead (10 x 10: 231 / 426 us) (scripts/frame_small_batch_ab.py).  That is the reference's own use of the frame solve -- ONE
+// frame per epoch (FR:178-183) -- and the command shim's.  Above one frame per CU the workgroup kernels saturate at ~8.5e11 / (n kd^2) frames
+// per second (10 x 10: 2.4e6, 5 x 5: 3.5e7) while a launch of the wave kernel never takes less than ~25 us + 0.55 us per equation (one wave's
+// chain: 10 x 10 207 us, 5 x 5 84 us): the batch at which the two meet -- 10 x 10: ~500 frames, 5 x 5: ~2 500 -- is the threshold, at least 256
+// (one frame per CU) and at most 4 000.  scripts/frame_dispatch_sweep.py: the choice is within 6 % of the faster kernel for 3 x 3 .. 15 x 16
+// frames and 128 .. 16 384 frames per launch.  Option "frame_latency_batch" overrides the threshold (0: tuned kernels for every batch).
 static int latency_batch(int n_eq, int kd) {
-  if (const char* e = getenv("OPS_AMD_FRAME_LATENCY_BATCH")) return atoi(e);
+  const long o = g_frame_latency_batch.load();
+  if (o >= 0) return (int)(o > 0x7fffffff ? 0x7fffffff : o);
   const double wave_floor_s = 25e-6 + 0.55e-6 * n_eq, legacy_rate = 8.5e11 / ((double)n_eq * kd * kd);
   const double b = wave_floor_s * legacy_rate;
   return b < 256.0 ? 256 : b > 4000.0 ? 4000 : (int)b;
@@ -683,134 +645,134 @@ static bool legacy_kernels_serve(int n_eq, int kd) {
   const size_t ring = ((size_t)(kd + 6) * frame_ld(kd) + (size_t)frame_n3(n_eq) + 2 * (size_t)FRAME_CH * frame_ld(kd)) * sizeof(double);
   return ring <= LDS_MAX;
 }
-
-static bool wave_kernel_serves(int B, int n_eq, int kd) {
-  if (!use_wave_kernel(kd)) return false;
-  if (B <= latency_batch(n_eq, kd) && legacy_kernels_serve(n_eq, kd)) return false;
-  const int W = fw_width(kd);
-  // (the opt-in tile variant parks rows at a wider pitch: its LDS need counts only when it is switched on -- sized by it unconditionally,
-  //  frames of ~4 100-4 700 equations that the default kernel serves fell back to the workgroup-per-frame kernels: ADVICE r04)
-  const size_t per_wave = use_tile_kernel() && ft_lds_doubles(n_eq) > fw_lds_doubles(n_eq, W) ? ft_lds_doubles(n_eq) : fw_lds_doubles(n_eq, W);
-  if (4 * per_wave * sizeof(double) > 160 * 1024 - 64) return false;
-  if (fused_assembly() ? n_eq > (1 << 20) : ((size_t)FW_SLAB * W + (size_t)n_eq) * sizeof(double) > LDS_MAX) return false;
-  return true;
-}
-
-// r06: half bandwidths up to 27 -- 95 of the 100 (bays, stories) draws of FR:17-18 -- take the packed kernel (frame_pack.hpp: 16 or 32 lanes per
-// frame, 4 or 2 frames per wave) wherever the wave-per-frame kernel would have served.  OPS_AMD_FRAME_PACK=0: one wave per frame (A/B).
 // (ops_frame_workspace_bytes does not know the element count: both it and the solve decide with the bound the plan's workspace share is sized by)
 static int ne_bound(int n_eq) { return 4 * n_eq + 64; }
 // the assembly plan sits at the START of the workspace (r06: where it is does not depend on the batch, so a caller that keeps the workspace may
-// keep the plan: OPS_FRAME_REUSE_PLAN), the per-frame / per-wave factor storage behind it
+// keep the plan: OPS_FRAME_REUSE_PLAN), the per-wave factor storage behind it
 static size_t plan_region_bytes(int n_eq, int G, int EPG) { return (fw_plan_bytes(n_eq, ne_bound(n_eq), G, EPG) + 255) & ~(size_t)255; }
-static bool pack_kernel_serves(int B, int n_eq, int kd) {
-  const int n_elems = ne_bound(n_eq);
+
+enum FrameFamily { FAM_WIDE, FAM_LEGACY, FAM_WAVE, FAM_PACK };
+// kd <= 27 (95 of the 100 (bays, stories) draws of FR:17-18): frame_pack.hpp, 16 or 32 lanes per frame; 28..55: frame_wave.hpp, a wave per
+// frame; small batches and 56..63: the workgroup-per-frame kernels; beyond: the column-by-column fallback
+static FrameFamily frame_family(int B, int n_eq, int kd) {
+  if (kd > 63) return FAM_WIDE;
+  if (kd > 55 || (B <= latency_batch(n_eq, kd) && legacy_kernels_serve(n_eq, kd))) return FAM_LEGACY;
   int P, G, W;
-  if (!fp_config(kd, &P, &G, &W)) return false;
-  if (const char* e = getenv("OPS_AMD_FRAME_PACK")) if (atoi(e) == 0) return false;
-  if (!wave_kernel_serves(B, n_eq, kd) || !fused_assembly() || use_tile_kernel() || use_pair_steps(kd)) return false;
-  return 4 * (size_t)(64 / P) * fp_lds_doubles(n_eq, n_elems, P, G, W) * sizeof(double) <= 160 * 1024 - 64;
+  // the packed kernel's 8 or 16 frames per workgroup keep x (n_eq) and their parking areas in LDS (+ the inertias if those fit too: launch_pack)
+  if (g_frame_pack.load() && fp_config(kd, &P, &G, &W) && 4 * (size_t)(64 / P) * fp_lds_doubles(n_eq, 0, P, G, W) * sizeof(double) <= LDS_MAX)
+    return FAM_PACK;
+  // the wave kernel (window width 36 serves every narrower band): its four waves' LDS must fit one CU; frames beyond that (tall and narrow:
+  // thousands of equations) take the workgroup-per-frame kernels, whose band streams through an LDS ring
+  if (4 * fw_lds_doubles(n_eq, fw_width(kd)) * sizeof(double) <= LDS_MAX) return FAM_WAVE;
+  return FAM_LEGACY;
+}
+
+// as many workgroups as the chip holds at once (persistent waves): asked of the runtime once per device, kernel and LDS size
+static hipError_t resident_workgroups(const void* fn, size_t lds, int devid, std::atomic<long long>* key_slot, std::atomic<int>* val_slot, int* cap) {
+  const long long key = ((long long)lds << 1) | 1;
+  if (key_slot[devid & 63].load(std::memory_order_acquire) == key) {
+    *cap = val_slot[devid & 63].load(std::memory_order_relaxed);
+    if (*cap > 0) return hipSuccess;
+  }
+  int per_cu = 0, cus = 0;
+  hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, lds);
+  if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, devid);
+  if (e != hipSuccess) return e;
+  *cap = (per_cu > 0 ? per_cu : 1) * (cus > 0 ? cus : 1);
+  key_slot[devid & 63].store(0, std::memory_order_release);
+  val_slot[devid & 63].store(*cap, std::memory_order_relaxed);
+  key_slot[devid & 63].store(key, std::memory_order_release);
+  return hipSuccess;
 }
 
 template <int W, int P, int G>
 static hipError_t launch_pack(const FrameParams& p, double* ws, hipStream_t s, bool reuse_plan) {
   static std::atomic<unsigned long long> done{0};
+  static std::atomic<long long> cap_key[64];
+  static std::atomic<int> cap_val[64];
   int devid = 0;
   hipError_t e = hipGetDevice(&devid);
   if (e != hipSuccess) return e;
   constexpr int F = 64 / P;
-  const size_t lds = 4 * (size_t)F * fp_lds_doubles(p.n_eq, p.Ne, P, G, W) * sizeof(double);
+  const bool stage_I = 4 * (size_t)F * fp_lds_doubles(p.n_eq, p.Ne, P, G, W) * sizeof(double) <= LDS_MAX / 2;     // (at least two workgroups per CU)
+  const int ne_lds = stage_I ? p.Ne : 0;
+  const size_t lds = 4 * (size_t)F * fp_lds_doubles(p.n_eq, ne_lds, P, G, W) * sizeof(double);
   const unsigned long long bit = 1ull << (devid & 63);
   if (!(done.load(std::memory_order_acquire) & bit)) {
-    e = hipFuncSetAttribute((const void*)frame_pack_kernel<W, P, G>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
+    e = hipFuncSetAttribute((const void*)frame_pack_kernel<W, P, G>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX);
     if (e != hipSuccess) return e;
     done.fetch_or(bit, std::memory_order_release);
   }
-  // persistent waves (frame_pack.hpp): as many workgroups as the chip holds at once (asked of the runtime once per device and LDS size)
-  static std::atomic<long long> cap_key[64];
-  static std::atomic<int> cap_val[64];
   int cap = 0;
-  const long long key = ((long long)lds << 1) | 1;
-  if (cap_key[devid & 63].load(std::memory_order_acquire) == key) cap = cap_val[devid & 63].load(std::memory_order_relaxed);
-  if (cap <= 0) {
-    int per_cu = 0, cus = 0;
-    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)frame_pack_kernel<W, P, G>, 256, lds);
-    if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, devid);
-    if (e != hipSuccess) return e;
-    cap = (per_cu > 0 ? per_cu : 1) * (cus > 0 ? cus : 1);
-    cap_key[devid & 63].store(0, std::memory_order_release);
-    cap_val[devid & 63].store(cap, std::memory_order_relaxed);
-    cap_key[devid & 63].store(key, std::memory_order_release);
-  }
+  e = resident_workgroups((const void*)frame_pack_kernel<W, P, G>, lds, devid, cap_key, cap_val, &cap);
+  if (e != hipSuccess) return e;
   const long need = ((long)p.B + 4 * F - 1) / (4 * F);
   const unsigned grid = (unsigned)(need < cap ? need : cap);
   void* plan_base = ws;
   double* factor = (double*)((char*)ws + plan_region_bytes(p.n_eq, G, fp_epg(G)));
   const FwPlan pl = fw_plan_at(plan_base, p.n_eq, p.Ne, G, fp_epg(G));
   if (!reuse_plan)
-    hipLaunchKernelGGL(frame_plan_kernel, dim3(1), dim3(1024), (size_t)3 * (fw_groups(p.n_eq, G) + 2) * sizeof(int), s, p, W, plan_base, 0, G, fp_epg(G));
-  hipLaunchKernelGGL((frame_pack_kernel<W, P, G>), dim3(grid), dim3(256), lds, s, p, factor, pl);
+    hipLaunchKernelGGL(frame_plan_kernel, dim3(1), dim3(1024), (size_t)3 * (fw_groups(p.n_eq, G) + 2) * sizeof(int), s, p, W, plan_base, G, fp_epg(G));
+  hipLaunchKernelGGL((frame_pack_kernel<W, P, G>), dim3(grid), dim3(256), lds, s, p, factor, pl, ne_lds);
   return hipGetLastError();
 }
 
 template <int W>
 static hipError_t launch_wave(const FrameParams& p, double* ws_all, hipStream_t s, bool reuse_plan) {
   static std::atomic<unsigned long long> done{0};
+  static std::atomic<long long> cap_key[64];
+  static std::atomic<int> cap_val[64];
   int devid = 0;
   hipError_t e = hipGetDevice(&devid);
   if (e != hipSuccess) return e;
-  const size_t lds = 4 * fw_lds_doubles(p.n_eq, W) * sizeof(double);      // size limits: wave_kernel_serves (checked by the caller)
+  const size_t lds = 4 * fw_lds_doubles(p.n_eq, W) * sizeof(double);      // size limits: frame_family (checked by the caller)
   const unsigned long long bit = 1ull << (devid & 63);
   if (!(done.load(std::memory_order_acquire) & bit)) {
-    e = hipFuncSetAttribute((const void*)frame_wave_kernel<W, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)frame_wave_kernel<W, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)frame_wave_kernel<W, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)frame_tile_kernel<W>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
+    e = hipFuncSetAttribute((const void*)frame_wave_kernel<W>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX);
     if (e != hipSuccess) return e;
     done.fetch_or(bit, std::memory_order_release);
   }
+  int cap = 0;
+  e = resident_workgroups((const void*)frame_wave_kernel<W>, lds, devid, cap_key, cap_val, &cap);
+  if (e != hipSuccess) return e;
+  const long need = ((long)p.B + 3) / 4;
+  const unsigned grid = (unsigned)(need < cap ? need : cap);
   void* plan_base = ws_all;
   double* ws = (double*)((char*)ws_all + plan_region_bytes(p.n_eq, FW_G, FW_EPG));
   const FwPlan pl = fw_plan_at(plan_base, p.n_eq, p.Ne);
-  const dim3 grid((unsigned)((p.B + 3) / 4));
-  if (use_tile_kernel()) {
-    hipLaunchKernelGGL(frame_plan_kernel, dim3(1), dim3(1024), (size_t)3 * (fw_groups(p.n_eq) + 2) * sizeof(int), s, p, W, plan_base, 8 * ft_M(W), FW_G, FW_EPG);
-    hipLaunchKernelGGL((frame_tile_kernel<W>), grid, dim3(256), 4 * ft_lds_doubles(p.n_eq) * sizeof(double), s, p, ws, pl);
-  } else if (fused_assembly()) {
-    if (!reuse_plan)
-      hipLaunchKernelGGL(frame_plan_kernel, dim3(1), dim3(1024), (size_t)3 * (fw_groups(p.n_eq) + 2) * sizeof(int), s, p, W, plan_base, 0, FW_G, FW_EPG);
-    if (use_pair_steps(p.kd)) hipLaunchKernelGGL((frame_wave_kernel<W, true, true>), grid, dim3(256), lds, s, p, ws, pl);
-    else hipLaunchKernelGGL((frame_wave_kernel<W, true>), grid, dim3(256), lds, s, p, ws, pl);
-  } else {
-    const size_t lds_asm = ((size_t)FW_SLAB * W + (size_t)p.n_eq) * sizeof(double);
-    hipLaunchKernelGGL(frame_assemble_rows_kernel, dim3((unsigned)p.B), dim3(256), lds_asm, s, p, ws, W);
-    hipLaunchKernelGGL((frame_wave_kernel<W, false>), grid, dim3(256), lds, s, p, ws, pl);
-  }
+  if (!reuse_plan)
+    hipLaunchKernelGGL(frame_plan_kernel, dim3(1), dim3(1024), (size_t)3 * (fw_groups(p.n_eq) + 2) * sizeof(int), s, p, W, plan_base, FW_G, FW_EPG);
+  hipLaunchKernelGGL((frame_wave_kernel<W>), dim3(grid), dim3(256), lds, s, p, ws, pl);
   return hipGetLastError();
 }
 
 extern "C" size_t ops_frame_workspace_bytes(int B, int n_eq, int half_bandwidth) {
-  half_bandwidth = eff_kd(half_bandwidth);
-  if (half_bandwidth > 63) return (size_t)B * frame_lds_resident_bytes(n_eq, half_bandwidth);      // frame_wide_kernel: the band always lives in HBM
-  if (pack_kernel_serves(B, n_eq, half_bandwidth)) {   // per frame: the columns of L; once: the assembly plan
-    int P, G, W;
-    fp_config(half_bandwidth, &P, &G, &W);
-    return B == 0 ? 0 : (size_t)B * fp_frame_doubles(n_eq, W) * sizeof(double) + plan_region_bytes(n_eq, G, fp_epg(G));
+  if (B <= 0 || n_eq < 1 || half_bandwidth < 0) return 0;
+  const int kd = eff_kd(half_bandwidth);
+  switch (frame_family(B, n_eq, kd)) {
+    case FAM_WIDE: return (size_t)B * frame_lds_resident_bytes(n_eq, kd);      // frame_wide_kernel: the band always lives in HBM
+    case FAM_PACK: {                               // per frame: the columns of L (the kernel uses one slot per resident wave); once: the plan
+      int P, G, W;
+      fp_config(kd, &P, &G, &W);
+      return (size_t)B * fp_frame_doubles(n_eq, W) * sizeof(double) + plan_region_bytes(n_eq, G, fp_epg(G));
+    }
+    case FAM_WAVE: return (size_t)B * fw_frame_doubles(n_eq, kd) * sizeof(double) + plan_region_bytes(n_eq, FW_G, FW_EPG);
+    default: break;
   }
-  if (wave_kernel_serves(B, n_eq, half_bandwidth))     // per frame: band / factor rows; once: the assembly plan (at most 21 entries and 72 coefficients per element)
-    return B == 0 ? 0 : (size_t)B * fw_frame_doubles(n_eq, half_bandwidth) * sizeof(double) + plan_region_bytes(n_eq, FW_G, FW_EPG);
-  if (frame_lds_resident_bytes(n_eq, half_bandwidth) <= LDS_MAX && !force_ws()) return 0;   // the band lives in LDS
-  return (size_t)B * frame_lds_resident_bytes(n_eq, half_bandwidth);
+  if (frame_lds_resident_bytes(n_eq, kd) <= LDS_MAX) return 0;   // the band lives in LDS
+  return (size_t)B * frame_lds_resident_bytes(n_eq, kd);
 }
 
 // which plan (if any) a call of this shape builds at the start of its workspace: 0 = none; equal values = interchangeable plans
 extern "C" long ops_frame_plan_signature(int B, int n_eq, int half_bandwidth) {
-  if (B <= 0 || n_eq < 1 || half_bandwidth < 0 || half_bandwidth > 63) return 0;
+  if (B <= 0 || n_eq < 1 || half_bandwidth < 0) return 0;
   const int kd = eff_kd(half_bandwidth);
   int P, G, W;
-  if (pack_kernel_serves(B, n_eq, kd)) { fp_config(kd, &P, &G, &W); return (2L << 24) | (W << 16) | (G << 8) | P; }
-  if (wave_kernel_serves(B, n_eq, kd) && fused_assembly()) return (1L << 24) | (fw_width(kd) << 16) | (FW_G << 8) | (use_tile_kernel() ? 65 : 64);
-  return 0;
+  switch (frame_family(B, n_eq, kd)) {
+    case FAM_PACK: fp_config(kd, &P, &G, &W); return (2L << 24) | (W << 16) | (G << 8) | P;
+    case FAM_WAVE: return (1L << 24) | (fw_width(kd) << 16) | (FW_G << 8) | 64;
+    default: return 0;
+  }
 }
 
 extern "C" int ops_frame_solve_batched_f64(int B, int n_nodes, int n_elems, int n_eq, int half_bandwidth,
@@ -854,12 +816,10 @@ extern "C" int ops_frame_solve_batched_f64_ex(int B, int n_nodes, int n_elems, i
     }
   }
   FrameParams p{B, n_nodes, n_elems, n_eq, kd, elem_geo, elem_EA, elem_E, elem_w, elem_eq, node_eq,
-                I, loads, loads_bstride, disp, forces, V, M, status, nullptr};
-#ifdef OPS_AMD_FRAME_TRACE
-  if (const char* e = getenv("OPS_AMD_FRAME_TRACE_PTR")) p.trace = (unsigned long long*)strtoull(e, nullptr, 10);
-#endif
+                I, loads, loads_bstride, disp, forces, V, M, status};
   hipStream_t s = (hipStream_t)stream;
-  if (kd > 63) {
+  const FrameFamily fam = frame_family(B, n_eq, kd);
+  if (fam == FAM_WIDE) {
     // the window rows of a block step are one 64-lane wave: beyond that, the plain column-by-column fallback on the band in HBM
     const int ld = frame_ld(kd), n3 = frame_n3(n_eq);
     const size_t need = (size_t)B * lds_bytes, lds_wide = ((size_t)n3 + ld) * sizeof(double);
@@ -872,7 +832,7 @@ extern "C" int ops_frame_solve_batched_f64_ex(int B, int n_nodes, int n_elems, i
     hipLaunchKernelGGL(frame_wide_kernel, dim3((unsigned)B), dim3(1024), lds_wide, s, p, (double*)workspace);
     return hipGetLastError() == hipSuccess ? OPS_AMD_OK : OPS_AMD_ERR_LAUNCH;
   }
-  if (pack_kernel_serves(B, n_eq, kd)) {
+  if (fam == FAM_PACK) {
     int P, G, W;
     fp_config(kd, &P, &G, &W);
     const size_t need = (size_t)B * fp_frame_doubles(n_eq, W) * sizeof(double) + plan_region_bytes(n_eq, G, fp_epg(G));
@@ -889,26 +849,23 @@ extern "C" int ops_frame_solve_batched_f64_ex(int B, int n_nodes, int n_elems, i
     if (e != hipSuccess) { set_frame_error(hipGetErrorString(e)); return OPS_AMD_ERR_LAUNCH; }
     return OPS_AMD_OK;
   }
-  if (wave_kernel_serves(B, n_eq, kd)) {
+  if (fam == FAM_WAVE) {
     const int W = fw_width(kd);
     const size_t need = (size_t)B * fw_frame_doubles(n_eq, kd) * sizeof(double) + plan_region_bytes(n_eq, FW_G, FW_EPG);
     if (!workspace || workspace_bytes < need || n_elems > ne_bound(n_eq)) return OPS_AMD_ERR_INVALID_ARG;
     hipError_t e = hipSuccess;
-    {
-      switch (W) {
-        case 16: e = launch_wave<16>(p, (double*)workspace, s, reuse_plan); break;
-        case 24: e = launch_wave<24>(p, (double*)workspace, s, reuse_plan); break;
-        case 36: e = launch_wave<36>(p, (double*)workspace, s, reuse_plan); break;
-        case 52: e = launch_wave<52>(p, (double*)workspace, s, reuse_plan); break;
-        default: e = launch_wave<56>(p, (double*)workspace, s, reuse_plan); break;
-      }
+    switch (W) {
+      case 36: e = launch_wave<36>(p, (double*)workspace, s, reuse_plan); break;
+      case 52: e = launch_wave<52>(p, (double*)workspace, s, reuse_plan); break;
+      default: e = launch_wave<56>(p, (double*)workspace, s, reuse_plan); break;
     }
     if (e != hipSuccess) { set_frame_error(hipGetErrorString(e)); return OPS_AMD_ERR_LAUNCH; }
     return OPS_AMD_OK;
   }
+  const bool resident = lds_bytes <= LDS_MAX;
   int T, pp_use;
-  frame_threads(kd, !(lds_bytes > LDS_MAX || force_ws()), &T, &pp_use);
-  if (lds_bytes > LDS_MAX || force_ws()) {
+  frame_threads(kd, resident, &T, &pp_use);
+  if (!resident) {
     // band in the HBM workspace, sliding LDS ring
     const int ld = frame_ld(kd), n3 = frame_n3(n_eq);
     const size_t need = (size_t)B * lds_bytes;

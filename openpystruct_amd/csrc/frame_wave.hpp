@@ -40,14 +40,12 @@ namespace opsamd {
 constexpr int FW_G = 8;     // rows per load group
 __host__ __device__ constexpr int fw_pitch(int W) { return W + 2; }   // doubles per parked row: W entries + right-hand side, even (16-byte reads)
 
-__host__ __device__ inline int fw_width(int kd) {           // compiled register-window widths
-  return kd < 16 ? 16 : kd < 24 ? 24 : kd < 36 ? 36 : kd < 52 ? 52 : 56;
+__host__ __device__ inline int fw_width(int kd) {           // compiled register-window widths (half bandwidths below 28: frame_pack.hpp)
+  return kd < 36 ? 36 : kd < 52 ? 52 : 56;
 }
-__host__ __device__ inline int fw_rows(int n) { return n + 64 + 2 * FW_G; }      // allocated rows: unguarded group prefetch
-__host__ __device__ inline size_t fw_frame_doubles(int n, int kd) { return (size_t)fw_rows(n) * (fw_width(kd) + 1); }
+__host__ __device__ inline size_t fw_frame_doubles(int n, int kd) { return (size_t)(n + 4) * fw_width(kd); }      // column j of L at [j * W, j * W + kd)
 constexpr int FW_CB = 72;   // broadcast line: entry `rel` at index rel (pairs (t, t + 1), t even, are 16-byte aligned), two buffers
-// (4 FW_CB: two broadcast lines of PAIRS, the two-columns-per-step form of r05; the one-column form uses the first half)
-__host__ __device__ inline size_t fw_lds_doubles(int n, int W) { return ((4 * FW_CB + (size_t)FW_G * fw_pitch(W) + (size_t)(n + 64)) + 1) & ~(size_t)1; }
+__host__ __device__ inline size_t fw_lds_doubles(int n, int W) { return ((2 * FW_CB + (size_t)FW_G * fw_pitch(W) + (size_t)(n + 64)) + 1) & ~(size_t)1; }
 
 __device__ __forceinline__ double fw_readlane(double v, int lane) {
   const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane), hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
@@ -68,56 +66,6 @@ __device__ __forceinline__ void fw_fence() {
   __builtin_amdgcn_wave_barrier();
 }
 
-// ---- assembly into the ROW-major workspace layout: row R holds A[R][C] at offset C mod W (C in R-kd .. R) ----
-constexpr int FW_SLAB = 96;   // rows per LDS slab of the assembly kernel
-
-__global__ __launch_bounds__(256) void frame_assemble_rows_kernel(const FrameParams p, double* __restrict__ ws, int W) {
-  extern __shared__ double lds[];
-  const long b = blockIdx.x;
-  const int n = p.n_eq, tid = threadIdx.x;
-  double* slab = lds;                             // [FW_SLAB][W]
-  double* rhs = lds + (size_t)FW_SLAB * W;        // [n]
-  double* rows = ws + b * fw_frame_doubles(n, p.kd);
-  double* rhs_g = rows + (size_t)fw_rows(n) * W;
-  const double* Ib = p.I + b * p.Ne;
-  for (int i = tid; i < n; i += 256) rhs[i] = 0.0;
-  for (int r0 = 0; r0 < n; r0 += FW_SLAB) {
-    const int nr = (n - r0 < FW_SLAB) ? n - r0 : FW_SLAB;
-    for (int i = tid; i < nr * W; i += 256) slab[i] = 0.0;
-    __syncthreads();
-    for (int e = tid; e < p.Ne; e += 256) {
-      int eq[6], lo = 1 << 30, hi = -1;
-      for (int r = 0; r < 6; ++r) {
-        eq[r] = p.elem_eq[6 * e + r];
-        if (eq[r] >= 0) { lo = eq[r] < lo ? eq[r] : lo; hi = eq[r] > hi ? eq[r] : hi; }
-      }
-      if (hi < r0 || lo >= r0 + nr) continue;                              // no row of this element in the slab
-      const double L = p.elem_geo[3 * e], c = p.elem_geo[3 * e + 1], s = p.elem_geo[3 * e + 2];
-      double k[6][6];
-      elem_global_k(L, c, s, p.elem_EA[e], p.elem_E[e] * Ib[e], k);
-      const double wy = p.elem_w[2 * e], wx = p.elem_w[2 * e + 1];
-      const double pl[6] = {wx * L / 2, wy * L / 2, wy * L * L / 12, wx * L / 2, wy * L / 2, -wy * L * L / 12};
-      const double pg[6] = {c * pl[0] - s * pl[1], s * pl[0] + c * pl[1], pl[2], c * pl[3] - s * pl[4], s * pl[3] + c * pl[4], pl[5]};
-      for (int r = 0; r < 6; ++r) {
-        if (eq[r] < r0 || eq[r] >= r0 + nr) continue;                      // row eq[r] belongs to this slab
-        atomicAdd(&rhs[eq[r]], pg[r]);                                     // each equation's load once: with its own row
-        for (int q = 0; q < 6; ++q)
-          if (eq[q] >= 0 && eq[q] <= eq[r]) atomicAdd(&slab[(size_t)(eq[r] - r0) * W + (eq[q] % W)], k[r][q]);
-      }
-    }
-    __syncthreads();
-    for (int i = tid; i < nr * W; i += 256) rows[(size_t)r0 * W + i] = slab[i];
-    __syncthreads();
-  }
-  const double* lb = p.loads + b * p.loads_bs;
-  for (int i = tid; i < p.Nn * 3; i += 256) {
-    const int q = p.node_eq[i];
-    if (q >= 0) atomicAdd(&rhs[q], lb[i]);
-  }
-  __syncthreads();
-  for (int i = tid; i < n; i += 256) rhs_g[i] = rhs[i];
-}
-
 // ---- assembly plan: the topology-only part of the assembly, built once per call ----
 // Row R of the band is  sum over its incident element entries (e, r, q):  ka[e][r][q] + I_e * kb[e][r][q]  at column slot
 // eq[q] mod W (ka: the axial part of the rotated ElasticBeam2d matrix, kb: the bending part per unit inertia -- both
@@ -132,7 +80,7 @@ __global__ __launch_bounds__(256) void frame_assemble_rows_kernel(const FramePar
 // trip (inertia gather + coefficients) per group.  (r02: entry -> element -> three gathers behind per-row pointers = seven
 // serialised round trips per group, 17 % of the solve.)  A group with more than 192 entries (nodes with more than four
 // elements) continues in extra blocks; a padded all-zero block serves the groups past the last equation.
-constexpr int FW_SLOT_BITS = 10;          // entry word: bit 31 valid | element << FW_SLOT_BITS | parking slot (r04: 10 bits -- the tile kernel parks rows at pitch 80)
+constexpr int FW_SLOT_BITS = 10;          // entry word: bit 31 valid | element << FW_SLOT_BITS | parking slot
 constexpr unsigned FW_SLOT_MASK = (1u << FW_SLOT_BITS) - 1u;
 constexpr int FW_KE = 3;                  // entry words a lane carries per group
 constexpr int FW_EPG = 64 * FW_KE;        // entries per block
@@ -141,7 +89,6 @@ struct FwPlan {
   const int* eq_dof;         // [n + 1]   index into loads[Nn*3]; [n] = 0
   const int* xstart;         // [ng + 2]  first extra block of a group (prefix sums); groups past the end: no extra blocks
   const unsigned* ent;       // [nblk][FW_EPG]  bit 31 (valid) | element << FW_SLOT_BITS | parking slot: (row in group) * fw_pitch(W) + column slot
-                             //                  (tile kernel, frame_tile.hpp: (row in group) * FT_P + ft_col_slot(column mod ring))
   const double* ka;          // [nblk][FW_EPG]
   const double* kb;          // [nblk][FW_EPG]
   const double* rhs_base;    // [n + 1]; [n] = 0
@@ -169,13 +116,8 @@ __host__ __device__ inline FwPlan fw_plan_at(void* base, int n, int Ne, int G = 
   return pl;
 }
 
-// parking slot of column `xc` (= equation mod ring) in a row of the tile kernel's parking area (frame_tile.hpp): lane (p, q) takes the
-// column slots 2 i, 2 i + 1 of residue q with one 16-byte read at 16 i + 2 q
-constexpr int FT_P = 80;                  // doubles per parked row: 64 permuted band slots, the right-hand side at 64
-__host__ __device__ inline int ft_col_slot(int xc) { return 16 * (xc >> 4) + 2 * (xc & 7) + ((xc >> 3) & 1); }
-
-// one workgroup; LDS: 3 * (ng + 2) ints.  ring > 0: parking slots of the tile kernel (ring = 8 M equations)
-__global__ __launch_bounds__(1024) void frame_plan_kernel(const FrameParams p, int W, void* plan_base, int ring, int G, int EPG) {
+// one workgroup; LDS: 3 * (ng + 2) ints
+__global__ __launch_bounds__(1024) void frame_plan_kernel(const FrameParams p, int W, void* plan_base, int G, int EPG) {
   extern __shared__ int s_plan[];
   const FwPlan pl = fw_plan_at(plan_base, p.n_eq, p.Ne, G, EPG);
   const int n = p.n_eq, ng = pl.ng, tid = threadIdx.x, T = blockDim.x;
@@ -236,7 +178,7 @@ __global__ __launch_bounds__(1024) void frame_plan_kernel(const FrameParams p, i
         if (eq >= 0 && eq <= er) {
           const int pos = atomicAdd(&cur[g], 1), blk = pos / EPG;
           const long idx = (long)(blk == 0 ? g : ng + 1 + xs_[g] + blk - 1) * EPG + pos % EPG;
-          const int slot = ring > 0 ? (er % G) * FT_P + ft_col_slot(eq % ring) : (er % G) * fw_pitch(W) + eq % W;
+          const int slot = (er % G) * fw_pitch(W) + eq % W;
           ent[idx] = 0x80000000u | ((unsigned)e << FW_SLOT_BITS) | (unsigned)slot;
           ka[idx] = k_a[r][q];
           kb[idx] = k_b[r][q];
@@ -248,7 +190,7 @@ __global__ __launch_bounds__(1024) void frame_plan_kernel(const FrameParams p, i
     const int er = n + tid, g = er / G;
     const int pos = atomicAdd(&cur[g], 1), blk = pos / EPG;
     const long idx = (long)(blk == 0 ? g : ng + 1 + xs_[g] + blk - 1) * EPG + pos % EPG;
-    const int slot = ring > 0 ? (er % G) * FT_P + ft_col_slot(er % ring) : (er % G) * fw_pitch(W) + er % W;
+    const int slot = (er % G) * fw_pitch(W) + er % W;
     ent[idx] = 0x80000000u | (unsigned)slot;                 // (element 0's inertia times kb = 0)
     ka[idx] = 1.0;
     kb[idx] = 0.0;
@@ -311,70 +253,6 @@ __device__ __forceinline__ void fw_step(FwState<W>& st, int j, int lane, int n, 
   }
   // a step's multiply-adds stay in the step: left free (no branch between two steps), the compiler defers them until the
   // column is next read and keeps -- spills -- the line values of several steps
-#pragma unroll
-  for (int c = 0; c < W; ++c) __asm__ volatile("" : "+v"(st.reg[c]));
-}
-
-// ---- r05: TWO columns per step.  Same arithmetic, operation for operation, as two one-column steps (the factor and the solution are
-// the same bits): what changes is that the two columns share ONE broadcast line -- entry `rel` = (A[j + rel][j], A'[j + rel][j + 1]), the
-// second already updated by column j, which every lane can do for its own row without the line (its multiplier times A[j + 1][j], one
-// readlane) -- so a pair of columns costs one LDS round trip, one fence, one set of window masks and one boundary test instead of two.
-// Column j + 1's window reaches one row further (rel <= kd + 1): rows enter one boundary earlier where kd + 1 is a multiple of eight
-// (KG from kd + 1), which the lane budget allows for kd <= 54.
-template <int W, int S>
-__device__ __forceinline__ void fw_prepare2(FwState<W>& st, int j, int lane, int n, int kd, double2* __restrict__ colbuf2, double& rd1,
-                                            double& rd2, int& bad) {
-  const int rel = (lane - j) & 63, R = j + rel;
-  const bool in1 = rel >= 1 && rel <= kd && R < n, in2 = rel >= 2 && rel <= kd + 1 && R < n;
-  const double a = st.reg[S];
-  const double d1 = fw_readlane(a, j & 63);
-  rd1 = frcp(d1);
-  bad |= (j < n) & !(d1 > 0.0);
-  const double l1 = in1 ? a * rd1 : 0.0;
-  const double a1 = fw_readlane(a, (j + 1) & 63);
-  st.reg[(S + 1) % W] = __builtin_fma(-l1, a1, st.reg[(S + 1) % W]);        // column j + 1 is final now
-  const double b = st.reg[(S + 1) % W];
-  const double d2 = fw_readlane(b, (j + 1) & 63);
-  rd2 = frcp(d2);
-  bad |= (j + 1 < n) & !(d2 > 0.0);
-  colbuf2[((j >> 1) & 1) * FW_CB + rel] = double2{in1 ? a : 0.0, in2 ? b : 0.0};
-}
-
-// one PAIR of factorisation steps (columns j, j + 1; S = j mod W, even); rd1 / rd2 = 1 / d_j, 1 / d_(j+1) on entry, those of the next pair
-// on return
-template <int W, int S>
-__device__ __forceinline__ void fw_step2(FwState<W>& st, int j, int lane, int n, int kd, double2* __restrict__ colbuf2,
-                                         double* __restrict__ Lc, double* __restrict__ xs, double& rd1, double& rd2, int& bad) {
-  const int rel = (lane - j) & 63, R = j + rel;
-  const bool in1 = rel >= 1 && rel <= kd && R < n, in2 = rel >= 2 && rel <= kd + 1 && R < n;
-  const double a = st.reg[S], b = st.reg[(S + 1) % W], r1 = rd1, r2 = rd2;
-  const double l1 = in1 ? a * r1 : 0.0, l2 = in2 ? b * r2 : 0.0;
-  const double z0 = fw_readlane(st.y, j & 63);
-  const double y1 = __builtin_fma(-l1, z0, st.y);
-  const double z1 = fw_readlane(y1, (j + 1) & 63);
-  st.y = __builtin_fma(-l2, z1, y1);
-  // columns j + 2 and j + 3 first, their multiplicands through readlanes (masked exactly as the line would have masked them): the next
-  // pair's line and reciprocals start here
-  const bool m2 = 2 <= kd && j + 2 < n, m3 = 3 <= kd && j + 3 < n, m3b = 2 <= kd && j + 3 < n;
-  const double a2 = m2 ? fw_readlane(a, (j + 2) & 63) : 0.0, b2 = fw_readlane(b, (j + 2) & 63);
-  st.reg[(S + 2) % W] = __builtin_fma(-l2, b2, __builtin_fma(-l1, a2, st.reg[(S + 2) % W]));
-  const double a3 = m3 ? fw_readlane(a, (j + 3) & 63) : 0.0, b3 = m3b ? fw_readlane(b, (j + 3) & 63) : 0.0;
-  st.reg[(S + 3) % W] = __builtin_fma(-l2, b3, __builtin_fma(-l1, a3, st.reg[(S + 3) % W]));
-  fw_fence();                                                         // the pair line of (j, j + 1), written one pair ago, has landed
-  fw_prepare2<W, (S + 2) % W>(st, j + 2, lane, n, kd, colbuf2, rd1, rd2, bad);
-  const double2* cb = colbuf2 + ((j >> 1) & 1) * FW_CB;
-#ifndef FW_SKIP_LSTORE
-  if (in1) Lc[(size_t)j * W + (rel - 1)] = l1;
-  if (in2) Lc[(size_t)(j + 1) * W + (rel - 2)] = l2;
-#endif
-  if (rel == 0) xs[j] = z0 * r1;
-  if (rel == 1) xs[j + 1] = z1 * r2;
-#pragma unroll
-  for (int t = 4; t < W; ++t) {
-    const double2 ab = cb[t];
-    st.reg[(S + t) % W] = __builtin_fma(-l2, ab.y, __builtin_fma(-l1, ab.x, st.reg[(S + t) % W]));
-  }
-  st.reg[S] = __builtin_fma(-l2, cb[W].y, st.reg[S]);                 // column j + W (this slot's next tenant): only column j + 1 reaches it
 #pragma unroll
   for (int c = 0; c < W; ++c) __asm__ volatile("" : "+v"(st.reg[c]));
 }
@@ -457,21 +335,16 @@ __device__ __forceinline__ void fw_backward(const double* __restrict__ rows, dou
   }
 }
 
-template <int W, bool FUSED, bool PAIR>
+template <int W>
 __device__ __forceinline__ void frame_wave_body(const FrameParams& p, double* __restrict__ wsf, double* __restrict__ lds, int lane, long b,
                                                 const FwPlan& pl) {
-  constexpr int G = FW_G, K = (G * W + 63) / 64;
+  constexpr int G = FW_G;
   const int n = p.n_eq, kd = p.kd;
-  // > kd (column j + 1 is read during step j): registers hold the rows below j + KG + G at step j.  PAIR: column j + 1's window (rel <= kd + 1)
-  // is read during the pair step of column j
-  const int KG = ((PAIR ? kd + 1 : kd) / G + 1) * G;
-  double* colbuf = lds;                                     // [2][FW_CB] (PAIR: [2][FW_CB] pairs)
-  double2* colbuf2 = reinterpret_cast<double2*>(lds);
-  double* stage = lds + 4 * FW_CB;                          // [G][fw_pitch(W)]: rows + right-hand sides of one group
-  double* xs = stage + (size_t)G * fw_pitch(W);                 // [n + 64]: w, then x
-  double* rows = wsf;                                       // [fw_rows(n)][W], overwritten column by column with L
-  const double* rhs_g = wsf + (size_t)fw_rows(n) * W;       // (unfused path)
-  (void)rhs_g;
+  const int KG = (kd / G + 1) * G;                          // > kd (column j + 1 is read during step j): registers hold the rows below j + KG + G at step j
+  double* colbuf = lds;                                     // [2][FW_CB]
+  double* stage = lds + 2 * FW_CB;                          // [G][fw_pitch(W)]: rows + right-hand sides of one group
+  double* xs = stage + (size_t)G * fw_pitch(W);             // [n + 64]: w, then x
+  double* rows = wsf;                                       // [n][W]: column j of L at [j * W, j * W + kd)
   FwState<W> st;
 #pragma unroll
   for (int c = 0; c < W; ++c) st.reg[c] = 0.0;
@@ -487,7 +360,7 @@ __device__ __forceinline__ void frame_wave_body(const FrameParams& p, double* __
   unsigned eB[KE] = {0u, 0u, 0u};
   int dofB = 0, gB = 0;
   double bi[KE], ba[KE], bb[KE], by1 = 0.0, by2 = 0.0;
-  const int n_extra = FUSED ? pl.hdr[0] : 0;
+  const int n_extra = pl.hdr[0];
   auto ents = [&](int g0) {                                 // group g0 (a multiple of G): entry words + load index, no wait
     const int gi = g0 / G < pl.ng ? g0 / G : pl.ng;         // past the last equation: the all-zero block
     const unsigned* e = pl.ent + (size_t)gi * FW_EPG + lane;
@@ -527,74 +400,29 @@ __device__ __forceinline__ void frame_wave_body(const FrameParams& p, double* __
     for (int i = lane; i < G * fw_pitch(W); i += 64) stage[i] = 0.0;
     fw_fence();
   };
-  // -- separate assembly kernel (A/B path): the group's G x W doubles are contiguous in the workspace
-  double tmp[FUSED ? 1 : K], tmpy = 0.0;
-  auto fetch = [&](int g0) {
-    if constexpr (!FUSED) {
-#pragma unroll
-      for (int k = 0; k < K; ++k) {
-        const int idx = lane + 64 * k;
-        tmp[k] = (idx < G * W) ? rows[(size_t)g0 * W + idx] : 0.0;
-      }
-      tmpy = (lane < G && g0 + lane < n) ? rhs_g[g0 + lane] : 0.0;
-    }
-  };
-  auto park = [&]() {
-    if constexpr (!FUSED) {
-#pragma unroll
-      for (int k = 0; k < K; ++k) {
-        const int idx = lane + 64 * k;
-        if (idx < G * W) stage[(idx / W) * fw_pitch(W) + idx % W] = tmp[k];
-      }
-      if (lane < G) stage[lane * fw_pitch(W) + W] = tmpy;
-    }
-  };
   // prologue: rows [0, KG + G) into registers, the next group parked, the one after on its way
-  if constexpr (FUSED) {
-    for (int g0 = 0; g0 < KG + 2 * G; g0 += G) {
-      ents(g0);
-      build_issue();
+  for (int g0 = 0; g0 < KG + 2 * G; g0 += G) {
+    ents(g0);
+    build_issue();
+    zero_stage();
+    build_finish();
+    fw_fence();
+    if (g0 < KG + G) { fw_take_group<W>(st, g0, lane, stage); fw_fence(); }
+  }
+  ents(KG + 2 * G);
+
+  // ---- factorisation + forward substitution ----
+  double rd = 0.0;
+  fw_prepare<W, 0>(st, 0, lane, n, kd, colbuf, rd, bad);
+  for (int j0 = 0; j0 < n; j0 += W) {
+    auto boundary = [&](int j) {                            // j % G == 0, j > 0: rows [j + KG, j + KG + G) enter
+      build_issue();                                        // group j + KG + G: its round trip runs under the LDS work below
+      fw_take_group<W>(st, j + KG, lane, stage);
+      fw_fence();
       zero_stage();
       build_finish();
       fw_fence();
-      if (g0 < KG + G) { fw_take_group<W>(st, g0, lane, stage); fw_fence(); }
-    }
-    ents(KG + 2 * G);
-  } else {
-    for (int g0 = 0; g0 < KG + G; g0 += G) {
-      fetch(g0);
-      park();
-      fw_fence();
-      fw_take_group<W>(st, g0, lane, stage);
-      fw_fence();
-    }
-    fetch(KG + G);
-    park();
-    fw_fence();
-    fetch(KG + 2 * G);
-  }
-
-  // ---- factorisation + forward substitution ----
-  double rd = 0.0, rd2 = 0.0;
-  if constexpr (PAIR) fw_prepare2<W, 0>(st, 0, lane, n, kd, colbuf2, rd, rd2, bad);
-  else fw_prepare<W, 0>(st, 0, lane, n, kd, colbuf, rd, bad);
-  for (int j0 = 0; j0 < n; j0 += W) {
-    auto boundary = [&](int j) {                            // j % G == 0, j > 0: rows [j + KG, j + KG + G) enter
-      if constexpr (FUSED) {
-        build_issue();                                      // group j + KG + G: its round trip runs under the LDS work below
-        fw_take_group<W>(st, j + KG, lane, stage);
-        fw_fence();
-        zero_stage();
-        build_finish();
-        fw_fence();
-        ents(j + KG + 2 * G);
-      } else {
-        fw_take_group<W>(st, j + KG, lane, stage);
-        fw_fence();
-        park();                                             // the group fetched one boundary ago
-        fw_fence();
-        fetch(j + KG + 2 * G);
-      }
+      ents(j + KG + 2 * G);
     };
     // W-fold unrolled: the register index of column j is j mod W.  Guarded per FOUR steps (W % 4 == 0): a step past the
     // last equation is a no-op (no lane is inside its window; xs has 64 spare entries), and a branch per step made the
@@ -602,9 +430,8 @@ __device__ __forceinline__ void frame_wave_body(const FrameParams& p, double* __
 #define FW_STEP(S_)                                                                   \
     {                                                                                 \
       const int j = j0 + (S_);                                                        \
-      if constexpr (!FW_NO_BOUNDARY && (S_) % 4 == 0) if (j > 0 && (j % G) == 0 && j < n) boundary(j); /* j0 % 4 == 0 */ \
-      if constexpr (PAIR) { if constexpr ((S_) % 2 == 0) fw_step2<W, (S_)>(st, j, lane, n, kd, colbuf2, rows, xs, rd, rd2, bad); } \
-      else fw_step<W, (S_)>(st, j, lane, n, kd, colbuf, rows, xs, rd, bad);           \
+      if constexpr ((S_) % 4 == 0) if (j > 0 && (j % G) == 0 && j < n) boundary(j);   /* j0 % 4 == 0 */ \
+      fw_step<W, (S_)>(st, j, lane, n, kd, colbuf, rows, xs, rd, bad);                \
     }
 #define FW_STEP4(S_)                                                                  \
     if constexpr ((S_) < W) {                                                         \
@@ -625,22 +452,25 @@ __device__ __forceinline__ void frame_wave_body(const FrameParams& p, double* __
 
 // waves per SIMD the register allocator is asked to make room for (the kernel is latency-bound per wave: rcp chain, LDS
 // round trip of the broadcast line): 2 W VGPRs of window + ~55
-#ifndef FW_WAVES_36
-#define FW_WAVES_36 1
-#endif
-#ifndef FW_WAVES_52
-#define FW_WAVES_52 3
-#endif
-constexpr int fw_waves(int W) { return W < 36 ? 1 : W == 36 ? FW_WAVES_36 : W <= 52 ? FW_WAVES_52 : 2; }   // measured: only the 52-wide window gains (170 -> 168 VGPRs: 3 waves)
+constexpr int fw_waves(int W) { return W == 36 ? 1 : W <= 52 ? 3 : 2; }   // measured: only the 52-wide window gains (170 -> 168 VGPRs: 3 waves)
 
-template <int W, bool FUSED, bool PAIR = false>
+template <int W>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(fw_waves(W))))
 void frame_wave_kernel(const FrameParams p, double* __restrict__ ws, const FwPlan pl) {
   extern __shared__ double lds[];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const long b = (long)blockIdx.x * 4 + wave;
-  if (b >= p.B) return;
-  frame_wave_body<W, FUSED, PAIR>(p, ws + b * fw_frame_doubles(p.n_eq, p.kd), lds + (size_t)wave * fw_lds_doubles(p.n_eq, W), lane, b, pl);
+  // r06: PERSISTENT waves -- the launch has at most as many workgroups as the chip holds at once and a wave walks over its share of the batch with
+  // ONE workspace slot: the factor columns in flight (15 x 16: 0.32 MB per wave, ~0.7 GB for the chip) are rewritten in place instead of 4.4 GB
+  // of per-frame slots streaming through HBM (r05 counters: 8.8 GB of traffic per launch of 12 288 frames, 17 x the algorithmic bytes)
+  const long wslot = (long)blockIdx.x * 4 + wave, stride = (long)gridDim.x * 4;
+  double* wsf = ws + wslot * fw_frame_doubles(p.n_eq, p.kd);
+  double* ldsw = lds + (size_t)wave * fw_lds_doubles(p.n_eq, W);
+  for (long b = wslot; b < p.B; b += stride) {
+    int lane_ = lane;                                       // (re-read opaquely per frame: no per-lane address of the body is kept across the loop)
+    __asm__ volatile("" : "+v"(lane_));
+    frame_wave_body<W>(p, wsf, ldsw, lane_, b, pl);
+    fw_fence();
+  }
 }
 
 }  // namespace opsamd

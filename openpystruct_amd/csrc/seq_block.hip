@@ -815,9 +815,8 @@ extern "C" int ops_linear_wgrad_accumulate_group(int nprob, const ops_wgrad_prob
   g.wg0[nprob] = tot;
   // units, heaviest first onto the lightest of the eight shares
   g.nunit = 0; g.qmax = 0;
-  static const bool flat_order = getenv("OPS_AMD_WGRAD_FLAT_ORDER") != nullptr;      // A/B switch
   int nu = 0, wgs[OPS_WG_MAX_UNITS];
-  bool fits = !flat_order;
+  bool fits = true;
   for (int i = 0; i < nprob && fits; ++i) {
     const ops_wgrad_problem& p = problems[i];
     const int splits = p.K == 0 ? 1 : opsamd::wg_row_splits(p.T);

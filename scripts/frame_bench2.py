@@ -5,6 +5,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from openpystruct_amd import frames
 from openpystruct_amd import _cabi
+_cabi.set_option("frame_latency_batch", int(os.environ.get("FRAME_BENCH_LATENCY_BATCH", "-1")))
 cases = [(10, 10, 4096), (10, 10, 16384), (15, 16, 1024), (15, 16, 4096), (15, 16, 12288), (5, 5, 32768), (3, 3, 65536)]
 if len(sys.argv) > 1:
     cases = [tuple(int(v) for v in a.split("x")) for a in sys.argv[1:]]

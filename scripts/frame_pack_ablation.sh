@@ -1,6 +1,6 @@
 #!/bin/bash
 # phase ablation of the packed frame kernel (GPU box): time per launch with one phase compiled out (answers are wrong: NOCHECK)
-cd "$GRAFT_REPO_ROOT"; export OPS_AMD_FRAME_LATENCY_BATCH=0 FRAME_BENCH_NOCHECK=1
+cd "$GRAFT_REPO_ROOT"; export FRAME_BENCH_LATENCY_BATCH=0 FRAME_BENCH_NOCHECK=1
 for v in "" nolstore nobackward noboundary nosteps; do
   lib=$PWD/ab/lib_fp_$v.so; [ -z "$v" ] && lib=$PWD/openpystruct_amd/lib/libopenpystruct_amd.so
   [ -f $lib ] || continue

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Packed frame kernel (csrc/frame_pack.hpp: 16 / 32 lanes per frame) against the oracle on the shapes of the reference's random range
-(FR:17-18: bays, stories ~ U{1..10}), and its time per launch against one wave per frame (OPS_AMD_FRAME_PACK=0).
+(FR:17-18: bays, stories ~ U{1..10}), and its time per launch against one wave per frame (library option frame_pack = 0: the 36-wide register window of csrc/frame_wave.hpp;
+r05's 16- and 24-wide instantiations of that kernel are gone, their numbers are in profiles/r06_pack_check_first.log).
 
     python scripts/frame_pack_check.py            # parity on 20 shapes + A/B on 6
     python scripts/frame_pack_check.py ab          # A/B only
@@ -13,15 +14,15 @@ import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from openpystruct_amd import frames  # noqa: E402
+from openpystruct_amd import _cabi, frames  # noqa: E402
 
-os.environ["OPS_AMD_FRAME_LATENCY_BATCH"] = "0"
+_cabi.set_option("frame_latency_batch", 0)
 
 
 def check():
     from oracle import beam_oracle as bo
     shapes = [(1, 1), (1, 2), (2, 1), (1, 10), (10, 1), (2, 2), (2, 3), (3, 2), (3, 3), (10, 2), (3, 10), (4, 4), (9, 4), (5, 5), (10, 5), (6, 6),
-              (7, 7), (7, 9), (10, 7), (8, 8), (8, 10), (10, 8), (9, 9), (10, 9)]
+              (7, 7), (7, 9), (10, 7), (8, 8), (8, 10), (10, 8), (9, 9), (10, 9), (10, 10), (12, 12), (13, 14), (15, 16), (20, 17), (18, 20)]
     worst = 0.0
     for bays, stories in shapes:
         topo = frames.grid_frame(bays, stories)
@@ -51,14 +52,14 @@ def check():
 
 
 def ab():
-    cases = [(1, 10, 131072), (2, 2, 131072), (3, 3, 65536), (10, 3, 32768), (5, 5, 32768), (7, 7, 16384), (8, 8, 16384), (10, 10, 16384)]
+    cases = [(1, 10, 131072), (2, 2, 131072), (3, 3, 65536), (10, 3, 32768), (5, 5, 32768), (7, 7, 16384), (8, 8, 16384), (10, 10, 16384), (12, 12, 12288), (15, 16, 12288)]
     for bays, stories, B in cases:
         topo = frames.grid_frame(bays, stories)
         I = torch.full((B, topo.Ne), 5e-4, dtype=torch.float64, device="cuda") * (1 + 0.1 * torch.rand(B, topo.Ne, dtype=torch.float64, device="cuda"))
         rec = {"frame": f"{bays}x{stories}", "n_eq": topo.n_eq, "half_bandwidth": topo.kd, "B": B}
         outs = {}
         for name, val in (("wave", "0"), ("pack", "1")):
-            os.environ["OPS_AMD_FRAME_PACK"] = val
+            _cabi.set_option("frame_pack", int(val))
             topo.__dict__.pop("_ws", None)
             sol = frames.frame_solve(topo, I)
             torch.cuda.synchronize()

@@ -16,13 +16,13 @@ d, fr, B = sys.argv[1], sys.argv[2], int(sys.argv[3])
 res = {"dir": d, "frame": fr, "frames": B, "command": f"bench.py --workload frames --frame {fr} --batch {B} --steps 10 --warmup 2"}
 for f in glob.glob(os.path.join(d, "trace", "*", "*_kernel_stats.csv")):
     for r in csv.DictReader(open(f)):
-        if "frame_wave_kernel" in r["Name"] or "frame_tile_kernel" in r["Name"]:
+        if "frame_wave_kernel" in r["Name"] or "frame_pack_kernel" in r["Name"]:
             res["kernel"] = r["Name"]
             res["trace"] = {k: float(r[k]) for k in ("Calls", "TotalDurationNs", "AverageNs", "MinNs", "MaxNs", "StdDev")}
 pmc = defaultdict(list)
 for f in glob.glob(os.path.join(d, "pmc_*", "*", "*_counter_collection.csv")):
     for r in csv.DictReader(open(f)):
-        if "frame_wave_kernel" in r["Kernel_Name"] or "frame_tile_kernel" in r["Kernel_Name"]:
+        if "frame_wave_kernel" in r["Kernel_Name"] or "frame_pack_kernel" in r["Kernel_Name"]:
             pmc[r["Counter_Name"]].append(float(r["Counter_Value"]))
             res["dispatch"] = {k: r[k] for k in ("Grid_Size", "Workgroup_Size", "LDS_Block_Size", "VGPR_Count", "Scratch_Size")}
 p = {k: sum(v) / len(v) for k, v in sorted(pmc.items())}

@@ -60,8 +60,13 @@ def test_argument_validation_without_gpu(lib):
     assert lib.ops_beam_sizing_epoch_f32(4, 100, z, 0, z, 0, z, 0, z, 101, z, 0, *([z] * 9), ctypes.byref(hp), z, z, 0, z) == _cabi.ERR_INVALID_ARG
     assert lib.ops_beam_sizing_epoch_f32(4, 200, z, 0, z, 0, z, 0, z, 201, z, 0, *([z] * 9), ctypes.byref(hp), z, z, 0, z) == _cabi.ERR_UNSUPPORTED
     assert lib.ops_frame_solve_batched_f64(2, 4, 3, 6, 5, *([z] * 8), 0, *([z] * 6), 0, z) == _cabi.ERR_INVALID_ARG
-    # every frame size keeps its band / factor in the caller's workspace (wave-per-frame kernel): one row-major band + rhs per frame
-    assert lib.ops_frame_workspace_bytes(5000, 330, 35) >= 5000 * 330 * 37 * 8 and lib.ops_frame_workspace_bytes(3, 768, 50) >= 3 * 768 * 53 * 8
+    # large batches keep the factor in the caller's workspace: one column-major L per frame (window width 36 / 52 for these bands) + the plan;
+    # a frame whose band does not fit LDS needs the workspace at any batch (15 x 16: band + rhs per frame)
+    assert lib.ops_frame_workspace_bytes(5000, 330, 35) >= 5000 * 330 * 36 * 8 and lib.ops_frame_workspace_bytes(3, 768, 50) >= 3 * 768 * 53 * 8
+    assert lib.ops_frame_workspace_bytes(40000, 90, 17) >= 40000 * 90 * 20 * 8      # packed kernel (half bandwidth <= 27): window width 20
+    assert lib.ops_frame_plan_signature(40000, 90, 17) >> 24 == 2 and lib.ops_frame_plan_signature(5000, 330, 35) >> 24 == 1 and lib.ops_frame_plan_signature(3, 330, 35) == 0
+    assert lib.ops_amd_get_option(b"frame_pack") == 1 and lib.ops_amd_get_option(b"frame_latency_batch") == -1 and lib.ops_amd_get_option(b"nope") == -2
+    assert lib.ops_amd_set_option(b"nope", 1) == _cabi.ERR_INVALID_ARG
     assert lib.ops_frame_workspace_bytes(3, 330, 35) == 0        # r05: small batches (<= 256 .. 4 000 frames by size) whose band fits LDS take the workgroup-per-frame kernels
     assert lib.ops_frame_workspace_bytes(0, 330, 35) == 0
     assert lib.ops_stencil3_bn1_fwd_f32(2, 3, z, z, z, z, z, 1e-5, 0.1, 1, z, z, z, z, 0, z, z, z) == _cabi.ERR_INVALID_ARG

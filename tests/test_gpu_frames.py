@@ -11,17 +11,22 @@ from tests.helpers import relerr  # noqa: E402
 
 
 @pytest.fixture(autouse=True)
-def _wave_kernel_for_every_batch(monkeypatch):
-    """The tests of this file launch 2-6 frames and were written for the wave-per-frame kernel; since r05 a batch of at most 256 frames
-    takes the workgroup-per-frame kernels (latency: csrc/frame_solve.hip latency_batch).  0 = wave kernel for every batch; the tests that
-    take `dispatch` run both ways."""
-    monkeypatch.setenv("OPS_AMD_FRAME_LATENCY_BATCH", "0")
+def _tuned_kernels_for_every_batch():
+    """The tests of this file launch 2-11 frames and are about the tuned kernels (packed / wave-per-frame); since r05 a batch of at most 256
+    frames takes the workgroup-per-frame kernels (latency: csrc/frame_solve.hip latency_batch).  Library option frame_latency_batch = 0: tuned
+    kernels for every batch; the tests that take `dispatch` run both ways.  Options are process-wide: put back after each test."""
+    from openpystruct_amd import _cabi
+    _cabi.set_option("frame_latency_batch", 0)
+    yield
+    _cabi.set_option("frame_latency_batch", -1)
+    _cabi.set_option("frame_pack", 1)
 
 
 @pytest.fixture(params=["wave", "latency"])
-def dispatch(request, monkeypatch):
+def dispatch(request):
     if request.param == "latency":
-        monkeypatch.delenv("OPS_AMD_FRAME_LATENCY_BATCH", raising=False)      # the library's default: B <= 256 -> a workgroup per frame
+        from openpystruct_amd import _cabi
+        _cabi.set_option("frame_latency_batch", -1)      # the library's default: B <= 256 -> a workgroup per frame
     return request.param
 
 
@@ -54,39 +59,6 @@ def test_grid_frames_vs_oracle(dispatch, bays, stories):
         assert relerr(sol.forces[b].cpu().numpy().ravel(), f.ravel()) < 1e-7
         np.testing.assert_array_equal(sol.V[b].cpu().numpy(), sol.forces[b, :, 1].cpu().numpy())
         np.testing.assert_array_equal(sol.M[b].cpu().numpy(), sol.forces[b, :, 2].cpu().numpy())
-
-
-@pytest.mark.parametrize("bays,stories", [(2, 3), (5, 5), (10, 10), (15, 16), (16, 3)])
-def test_register_tile_mapping_of_the_window_vs_oracle(monkeypatch, bays, stories):
-    """The measured alternative of the wave-per-frame kernel (csrc/frame_tile.hpp, OPS_AMD_FRAME_TILE=1: the band window as an 8 x 8 lane
-    grid of register tiles; ring sizes 24 / 32 / 48 / 64 equations) against the oracle, and against the default kernel (same arithmetic per
-    entry: the displacements agree to the last bits -- the order of the LDS atomic additions of the assembly differs)."""
-    from openpystruct_amd import frames
-    topo = frames.grid_frame(bays, stories)
-    rng = np.random.default_rng(bays * 100 + stories)
-    B = 5
-    I = np.exp(rng.uniform(np.log(5e-5), np.log(5e-3), size=(B, topo.Ne)))
-    It = torch.as_tensor(I, device="cuda")
-    monkeypatch.setenv("OPS_AMD_FRAME_TILE", "0")
-    ref = frames.frame_solve(topo, It)
-    torch.cuda.synchronize()
-    monkeypatch.setenv("OPS_AMD_FRAME_TILE", "1")
-    sol = frames.frame_solve(topo, It)
-    torch.cuda.synchronize()
-    assert int(sol.status.abs().sum()) == 0
-    assert relerr(sol.disp.cpu().numpy().ravel(), ref.disp.cpu().numpy().ravel()) < 1e-12
-    for b in range(2):
-        d, f, st, neq, kd = _oracle(topo, I[b])
-        assert relerr(sol.disp[b].cpu().numpy().ravel(), d.ravel()) < 1e-8
-        assert relerr(sol.forces[b].cpu().numpy().ravel(), f.ravel()) < 1e-7
-    # a non-positive pivot is reported per frame, the others are untouched
-    Ib = It.clone()
-    Ib[1, 3] = -1.0
-    bad = frames.frame_solve(topo, Ib)
-    torch.cuda.synchronize()
-    st = bad.status.cpu().numpy()
-    assert st[1] == 1 and st[[0, 2, 3, 4]].sum() == 0
-    assert relerr(bad.disp[0].cpu().numpy().ravel(), sol.disp[0].cpu().numpy().ravel()) < 1e-12
 
 
 def test_frame_equilibrium_and_axial_udl_quirk(dispatch):
@@ -530,10 +502,11 @@ def test_solves_on_one_topology_from_two_streams_do_not_share_a_workspace():
 
 @pytest.mark.parametrize("bays,stories,B", [(15, 16, 12288), (10, 10, 16384)])
 def test_config5_at_the_batch_the_bench_quotes(bays, stories, B):
-    """bench.py launches 12 288 frames of 15 x 16 (a 4.4 GB factor workspace: 359 552 B x 12 288 > 2^32) and
-    16 384 of 10 x 10, while every oracle comparison used <= 6 frames.  Here, at those batches: 32 frames -- the first, the last, the
-    frames either side of the workspace's 2^32-byte boundary, and seeded picks -- against the oracle's dpbsv solve; invariance under a
-    permutation of the batch; two streams solving different halves' worth of inputs at full size without sharing factor rows."""
+    """bench.py launches 12 288 frames of 15 x 16 and 16 384 of 10 x 10, while every oracle comparison used <= 6 frames.
+    Here, at those batches: 32 frames -- the first, the last, the frames either side of the point where the persistent waves (r06: one
+    workspace slot per resident wave, each wave walking over its share of the batch) start their second turn, and seeded picks -- against the
+    oracle's dpbsv solve; invariance under a permutation of the batch; two streams solving different halves' worth of inputs at full size
+    without sharing factor columns."""
     from openpystruct_amd import _cabi, frames
     lib = _cabi.load()
     topo = frames.grid_frame(bays, stories)
@@ -542,13 +515,12 @@ def test_config5_at_the_batch_the_bench_quotes(bays, stories, B):
     sol = frames.frame_solve(topo, I)
     torch.cuda.synchronize()
     assert int(sol.status.abs().sum()) == 0
-    ws_all = int(lib.ops_frame_workspace_bytes(B, topo.n_eq, topo.kd))
-    ws_frame = int(lib.ops_frame_workspace_bytes(2, topo.n_eq, topo.kd)) - int(lib.ops_frame_workspace_bytes(1, topo.n_eq, topo.kd))
+    assert int(lib.ops_frame_workspace_bytes(B + 1, topo.n_eq, topo.kd)) > int(lib.ops_frame_workspace_bytes(B, topo.n_eq, topo.kd)) > 0
     pick = {0, 1, B - 2, B - 1}
-    if ws_frame and ws_all > (1 << 32):
-        k = (1 << 32) // ws_frame                      # the frame whose factor rows straddle byte 2^32 of the workspace, and its neighbours
-        pick |= {k - 1, k, k + 1}
-        assert bays == 15 and 0 < k < B - 1
+    for waves_per_cu in (4, 8, 12, 16):                # resident waves = 256 CUs x (by LDS / registers) 4 .. 16: where a wave's second frame starts
+        k = 256 * waves_per_cu
+        if k + 1 < B:
+            pick |= {k - 1, k, k + 1}
     rng = np.random.default_rng(B)
     while len(pick) < 32:
         pick.add(int(rng.integers(0, B)))
@@ -586,47 +558,14 @@ def test_config5_at_the_batch_the_bench_quotes(bays, stories, B):
     torch.cuda.empty_cache()
 
 
-@pytest.mark.parametrize("bays,stories", [(2, 3), (5, 5), (10, 10), (15, 16), (16, 3), (1, 1)])
-def test_two_columns_per_elimination_step_vs_oracle_and_default(monkeypatch, bays, stories):
-    """The measured alternative of r05 (frame_wave.hpp fw_step2, OPS_AMD_FRAME_PAIR=1): two columns share one broadcast line, one fence,
-    one set of window masks.  Operation for operation the arithmetic of two one-column steps: against the default kernel the results
-    agree to the last bits (exactly, up to the order of the assembly's LDS atomic additions), and against the oracle as the default does.
-    Not the default: no faster (profiles/r05_notes.md 12)."""
-    from openpystruct_amd import frames
-    topo = frames.grid_frame(bays, stories)
-    rng = np.random.default_rng(bays * 100 + stories)
-    B = 6
-    I = np.exp(rng.uniform(np.log(5e-5), np.log(5e-3), size=(B, topo.Ne)))
-    It = torch.as_tensor(I, device="cuda")
-    monkeypatch.setenv("OPS_AMD_FRAME_PAIR", "0")
-    ref = frames.frame_solve(topo, It)
-    torch.cuda.synchronize()
-    monkeypatch.setenv("OPS_AMD_FRAME_PAIR", "1")
-    sol = frames.frame_solve(topo, It)
-    torch.cuda.synchronize()
-    assert int(sol.status.abs().sum()) == 0
-    assert relerr(sol.disp.cpu().numpy().ravel(), ref.disp.cpu().numpy().ravel()) < 1e-12
-    assert relerr(sol.forces.cpu().numpy().ravel(), ref.forces.cpu().numpy().ravel()) < 1e-11
-    for b in range(2):
-        d, f, st, neq, kd = _oracle(topo, I[b])
-        assert relerr(sol.disp[b].cpu().numpy().ravel(), d.ravel()) < 1e-8
-        assert relerr(sol.forces[b].cpu().numpy().ravel(), f.ravel()) < 1e-7
-    Ib = It.clone()
-    Ib[2, 1] = -1.0                               # a non-positive pivot is reported for that frame only
-    bad = frames.frame_solve(topo, Ib)
-    torch.cuda.synchronize()
-    st = bad.status.cpu().numpy()
-    assert st[2] == 1 and st[[0, 1, 3, 4, 5]].sum() == 0
-
-
-def test_small_batches_take_a_workgroup_per_frame_and_large_ones_a_wave(monkeypatch):
+def test_small_batches_take_a_workgroup_per_frame_and_large_ones_a_wave():
     """The dispatch itself (r05): <= 256 frames (and more of a small frame: the batch at which the two kernels meet, at most 4 000) need no
     factor workspace when the band fits LDS (workgroup-per-frame kernels), 8 193 do (wave-per-frame kernel); both agree with the oracle and
     with each other to rounding, frame by frame."""
     if not torch.cuda.is_available():
         pytest.fail("no GPU visible")
     from openpystruct_amd import _cabi, frames
-    monkeypatch.delenv("OPS_AMD_FRAME_LATENCY_BATCH", raising=False)
+    _cabi.set_option("frame_latency_batch", -1)
     lib = _cabi.load()
     topo = frames.grid_frame(6, 5)
     assert int(lib.ops_frame_workspace_bytes(256, topo.n_eq, topo.kd)) == 0 and int(lib.ops_frame_workspace_bytes(8193, topo.n_eq, topo.kd)) > 0
@@ -646,8 +585,11 @@ def test_small_batches_take_a_workgroup_per_frame_and_large_ones_a_wave(monkeypa
         for sol, kk in ((big, k), (small, k)):
             assert np.abs(sol.disp[kk].cpu().numpy() - d).max() <= 1e-7 * np.abs(d).max()
             assert np.abs(sol.forces[kk].cpu().numpy() - f).max() <= 1e-6 * np.abs(f).max()
-    monkeypatch.setenv("OPS_AMD_FRAME_LATENCY_BATCH", "0")
+    _cabi.set_option("frame_latency_batch", 0)
     assert int(lib.ops_frame_workspace_bytes(1, topo.n_eq, topo.kd)) > 0
+    assert _cabi.get_option("frame_latency_batch") == 0 and _cabi.get_option("frame_pack") == 1
+    with pytest.raises(ValueError):
+        _cabi.set_option("no_such_option", 1)
 
 
 # ---- r06: several frames per wavefront (csrc/frame_pack.hpp) ----
@@ -656,11 +598,11 @@ _PACK_SHAPES = [(1, 1, 5, 8), (10, 1, 5, 8), (1, 10, 8, 12), (2, 2, 8, 12), (3, 
 
 
 @pytest.mark.parametrize("bays,stories,kd,W", _PACK_SHAPES)
-def test_packed_frames_vs_oracle_and_isolation(monkeypatch, bays, stories, kd, W):
+def test_packed_frames_vs_oracle_and_isolation(bays, stories, kd, W):
     """Half bandwidths up to 27 (95 of the 100 (bays, stories) draws of FR:17-18): 16 or 32 lanes per frame, 4 or 2 frames per wave -- every
     compiled (window width, lanes, group size) against the oracle, with a frame that is not positive definite and a frame with a NaN load in the
     SAME waves as healthy ones (nothing may cross between the lane groups of a wave), a batch that does not fill its last wave, and against one
-    wave per frame (OPS_AMD_FRAME_PACK=0: same arithmetic, so the displacements agree to the order of the assembly's LDS additions)."""
+    wave per frame (library option frame_pack = 0: same arithmetic, so the displacements agree to the order of the assembly's LDS additions)."""
     from openpystruct_amd import _cabi, frames
     topo = frames.grid_frame(bays, stories)
     assert topo.kd == kd
@@ -684,7 +626,7 @@ def test_packed_frames_vs_oracle_and_isolation(monkeypatch, bays, stories, kd, W
         assert s_ == 0 and neq == topo.n_eq
         assert relerr(sol.disp[b].cpu().numpy().ravel(), d.ravel()) < 1e-8, b
         assert relerr(sol.forces[b].cpu().numpy().ravel(), f.ravel()) < 1e-7, b
-    monkeypatch.setenv("OPS_AMD_FRAME_PACK", "0")
+    _cabi.set_option("frame_pack", 0)
     assert int(lib.ops_frame_plan_signature(B, topo.n_eq, topo.kd)) >> 24 == 1
     ref = frames.frame_solve(topo, It, Lt)
     torch.cuda.synchronize()
@@ -720,7 +662,7 @@ def test_packed_frames_keep_the_plan_between_calls(monkeypatch):
             assert relerr(sol.forces[b].cpu().numpy().ravel(), f.ravel()) < 1e-7
     assert calls == [0, _cabi.FRAME_REUSE_PLAN, _cabi.FRAME_REUSE_PLAN, _cabi.FRAME_REUSE_PLAN]
     # the library's default dispatch sends small batches to the workgroup-per-frame kernels (no plan): the signature changes, the flag goes
-    monkeypatch.delenv("OPS_AMD_FRAME_LATENCY_BATCH", raising=False)
+    _cabi.set_option("frame_latency_batch", -1)
     assert int(lib.ops_frame_plan_signature(9, topo.n_eq, topo.kd)) == 0 and int(lib.ops_frame_plan_signature(8192, topo.n_eq, topo.kd)) != 0
 
 
@@ -744,3 +686,46 @@ def test_packed_frames_persistent_waves_walk_the_batch():
     sol2 = frames.frame_solve(topo, It[perm].contiguous())
     scale = float(sol.disp.abs().max())
     assert float((sol2.disp - sol.disp[perm]).abs().max()) < 1e-11 * scale
+
+
+@pytest.mark.parametrize("bays,kd", [(41, 128), (99, 302), (339, 1022)])
+def test_column_by_column_fallback_up_to_the_half_bandwidth_it_claims(bays, kd):
+    """`frame_wide_kernel` (csrc/frame_solve.hip; the reference's BandGeneral has no limit, FR:134) says it serves half bandwidths up to 1 024:
+    two-story frames numbered story by story at 128, 302 and 1 022 (the largest a grid can have below the limit: its backward sweep holds a column
+    in 16 registers per lane of one wave) against the oracle, with a frame that is not positive definite between two healthy ones."""
+    from openpystruct_amd import frames
+    topo = frames.grid_frame(bays, 2, numbering="node")
+    assert topo.kd == kd and topo.n_eq == 6 * (bays + 1)
+    rng = np.random.default_rng(kd)
+    I = np.exp(rng.uniform(np.log(1e-4), np.log(5e-3), size=(3, topo.Ne)))
+    I[1, 5] = -1.0
+    sol = frames.frame_solve(topo, torch.as_tensor(I, device="cuda"))
+    st = sol.status.cpu().numpy()
+    assert st[0] == 0 and st[2] == 0 and st[1] != 0 and torch.isnan(sol.disp[1]).all()
+    for k in (0, 2):
+        d, f, s_, neq, okd = _oracle(topo, I[k])
+        assert s_ == 0 and okd == kd
+        assert np.abs(sol.disp[k].cpu().numpy() - d).max() <= 1e-7 * np.abs(d).max(), (kd, k)
+        assert np.abs(sol.forces[k].cpu().numpy() - f).max() <= 1e-6 * np.abs(f).max(), (kd, k)
+
+
+def test_half_bandwidth_beyond_the_fallback_is_refused_cleanly():
+    """The first half bandwidth past the limit (340 bays story by story: 1 025) is OPS_AMD_ERR_UNSUPPORTED -- NotImplementedError on the host
+    side --, not a fault, and the next call on the same stream still answers."""
+    from openpystruct_amd import _cabi, frames
+    topo = frames.grid_frame(340, 2, numbering="node")
+    assert topo.kd == 1025
+    I = torch.full((2, topo.Ne), 5e-4, dtype=torch.float64, device="cuda")
+    with pytest.raises(NotImplementedError):
+        frames.frame_solve(topo, I)
+    lib = _cabi.load()
+    ws = torch.empty(int(lib.ops_frame_workspace_bytes(2, topo.n_eq, topo.kd)), dtype=torch.uint8, device="cuda")
+    outs = [torch.empty(s, dtype=torch.float64, device="cuda") for s in ((2, topo.Nn, 3), (2, topo.Ne, 6), (2, topo.Ne), (2, topo.Ne))]
+    st = torch.zeros(2, dtype=torch.int32, device="cuda")
+    rc = lib.ops_frame_solve_batched_f64(2, topo.Nn, topo.Ne, topo.n_eq, topo.kd, topo.d_geo.data_ptr(), topo.d_EA.data_ptr(), topo.d_E.data_ptr(),
+                                         topo.d_w.data_ptr(), topo.d_elem_eq.data_ptr(), topo.d_node_eq.data_ptr(), I.data_ptr(), topo.d_loads.data_ptr(), 0,
+                                         *(o.data_ptr() for o in outs), st.data_ptr(), ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream)
+    assert rc == _cabi.ERR_UNSUPPORTED
+    ok = frames.frame_solve(frames.grid_frame(2, 2), torch.full((2, 10), 5e-4, dtype=torch.float64, device="cuda"))
+    torch.cuda.synchronize()
+    assert int(ok.status.abs().sum()) == 0 and bool(torch.isfinite(ok.disp).all())

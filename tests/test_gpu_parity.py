@@ -372,44 +372,6 @@ def test_mirror_symmetry(oa, tiling):
     assert (np.abs(b[1][:, ::-1] + a[1]) / st).max() < 2e-8
 
 
-@pytest.mark.parametrize("B,Ne", [(1, 100), (64, 100), (65, 100), (1000, 100), (37, 7), (200, 257)])
-def test_lane_per_beam_alternative_matches_the_product_kernel(oa, B, Ne):
-    """The measured alternative (csrc/beam_solve_lane.hip: one lane per beam, factor in an HBM workspace) against the
-    product kernel and the oracle: same semantics, different elimination order."""
-    from openpystruct_amd import _cabi
-    lib = _cabi.load()
-    rng = np.random.default_rng(B * 1000 + Ne)
-    N = Ne + 1
-    x = np.cumsum(rng.uniform(0.5, 3.0, size=N))
-    fix = np.zeros(N, dtype=np.uint8); fix[0] = 1; fix[-1] = 1
-    if N > 12:
-        fix[N // 3] = 1; fix[N // 2] = 3
-    I = np.exp(rng.uniform(np.log(3e-3), np.log(0.75), size=(B, Ne)))
-    Fy = rng.uniform(-3e5, 0.0, size=(B, N)) * (rng.random((B, N)) < 0.1)
-    xg, Ig, fg, Fg = _gpu(x), _gpu(I), _gpu(fix, torch.uint8), _gpu(Fy)
-    Eg, wg = _gpu(bo.E_REF), _gpu(bo.UDL_REF)
-    ref = oa.beam_solve(xg, Eg, Ig, fg, Fg, wg)
-    outs = [torch.empty_like(t) for t in (ref.v, ref.theta, ref.V, ref.M)]
-    st = torch.full((B,), -1, dtype=torch.int32, device="cuda")
-    nbytes = int(lib.ops_beam_solve_lane_workspace_bytes(B, Ne))
-    ws = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
-    rc = lib.ops_beam_solve_lane_per_beam_f64(B, Ne, xg.data_ptr(), Eg.data_ptr(), Ig.data_ptr(), fg.data_ptr(), Fg.data_ptr(), wg.data_ptr(),
-                                              *(t.data_ptr() for t in outs), st.data_ptr(), ws.data_ptr(), nbytes,
-                                              torch.cuda.current_stream().cuda_stream)
-    assert rc == _cabi.OK
-    torch.cuda.synchronize()
-    assert int(st.abs().sum()) == 0
-    K, _ = bo.assemble_beam(x, bo.E_REF, I[0], Fy[0], bo.UDL_REF)
-    free = np.ones(2 * N, dtype=bool); free[0::2] = (fix & 1) == 0; free[1::2] = (fix & 2) == 0
-    tu = max(1e-7, 1e-15 * np.linalg.cond(K[np.ix_(free, free)]))          # eps * cond: two elimination orders
-    for got, want, tol in zip(outs, (ref.v, ref.theta, ref.V, ref.M), (tu, tu, 30 * tu, 30 * tu)):
-        assert relerr(got.cpu().numpy(), want.cpu().numpy()) < tol
-    nb = min(B, 8)                                                           # ... and both against the oracle
-    orc = bo.solve_beam_batched(x, bo.E_REF, I[:nb], fix, Fy[:nb], bo.UDL_REF)
-    for got, prod, want, tol in zip(outs, (ref.v, ref.theta, ref.V, ref.M), orc[:4], (tu, tu, 30 * tu, 30 * tu)):
-        assert relerr(got[:nb].cpu().numpy(), want) < tol and relerr(prod[:nb].cpu().numpy(), want) < tol
-
-
 def test_stream_out_flag_gives_identical_results(oa):
     """OPS_AMD_TILING_STREAM_OUT only changes the cache policy of the result stores: bit-identical outputs, same kernel."""
     rng = np.random.default_rng(11)
