@@ -720,8 +720,6 @@ static hipError_t launch_pack(const FrameParams& p, double* ws, hipStream_t s, b
 template <int W>
 static hipError_t launch_wave(const FrameParams& p, double* ws_all, hipStream_t s, bool reuse_plan) {
   static std::atomic<unsigned long long> done{0};
-  static std::atomic<long long> cap_key[64];
-  static std::atomic<int> cap_val[64];
   int devid = 0;
   hipError_t e = hipGetDevice(&devid);
   if (e != hipSuccess) return e;
@@ -732,17 +730,12 @@ static hipError_t launch_wave(const FrameParams& p, double* ws_all, hipStream_t 
     if (e != hipSuccess) return e;
     done.fetch_or(bit, std::memory_order_release);
   }
-  int cap = 0;
-  e = resident_workgroups((const void*)frame_wave_kernel<W>, lds, devid, cap_key, cap_val, &cap);
-  if (e != hipSuccess) return e;
-  const long need = ((long)p.B + 3) / 4;
-  const unsigned grid = (unsigned)(need < cap ? need : cap);
   void* plan_base = ws_all;
   double* ws = (double*)((char*)ws_all + plan_region_bytes(p.n_eq, FW_G, FW_EPG));
   const FwPlan pl = fw_plan_at(plan_base, p.n_eq, p.Ne);
   if (!reuse_plan)
     hipLaunchKernelGGL(frame_plan_kernel, dim3(1), dim3(1024), (size_t)3 * (fw_groups(p.n_eq) + 2) * sizeof(int), s, p, W, plan_base, FW_G, FW_EPG);
-  hipLaunchKernelGGL((frame_wave_kernel<W>), dim3(grid), dim3(256), lds, s, p, ws, pl);
+  hipLaunchKernelGGL((frame_wave_kernel<W>), dim3((unsigned)((p.B + 3) / 4)), dim3(256), lds, s, p, ws, pl);
   return hipGetLastError();
 }
 

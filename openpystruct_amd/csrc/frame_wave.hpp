@@ -459,18 +459,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(fw_waves(W)
 void frame_wave_kernel(const FrameParams p, double* __restrict__ ws, const FwPlan pl) {
   extern __shared__ double lds[];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  // r06: PERSISTENT waves -- the launch has at most as many workgroups as the chip holds at once and a wave walks over its share of the batch with
-  // ONE workspace slot: the factor columns in flight (15 x 16: 0.32 MB per wave, ~0.7 GB for the chip) are rewritten in place instead of 4.4 GB
-  // of per-frame slots streaming through HBM (r05 counters: 8.8 GB of traffic per launch of 12 288 frames, 17 x the algorithmic bytes)
-  const long wslot = (long)blockIdx.x * 4 + wave, stride = (long)gridDim.x * 4;
-  double* wsf = ws + wslot * fw_frame_doubles(p.n_eq, p.kd);
-  double* ldsw = lds + (size_t)wave * fw_lds_doubles(p.n_eq, W);
-  for (long b = wslot; b < p.B; b += stride) {
-    int lane_ = lane;                                       // (re-read opaquely per frame: no per-lane address of the body is kept across the loop)
-    __asm__ volatile("" : "+v"(lane_));
-    frame_wave_body<W>(p, wsf, ldsw, lane_, b, pl);
-    fw_fence();
-  }
+  // one frame per wave, its own workspace slot.  (r06, measured: persistent waves with one slot per resident wave -- what keeps the packed
+  // kernel's factor in cache, frame_pack.hpp -- buy nothing here: at 28 <= kd the factors in flight are 0.3 .. 1 GB, far beyond L2 and the
+  // Infinity Cache either way (15 x 16: 8.8 GB of fabric traffic per 12 288 frames = the factor written once and read once, before and after),
+  // and the loop around the body cost 30 bytes of scratch and 4 % of the time.)
+  const long b = (long)blockIdx.x * 4 + wave;
+  if (b >= p.B) return;
+  frame_wave_body<W>(p, ws + b * fw_frame_doubles(p.n_eq, p.kd), lds + (size_t)wave * fw_lds_doubles(p.n_eq, W), lane, b, pl);
 }
 
 }  // namespace opsamd
