@@ -33,6 +33,9 @@ def hipcc_path() -> str:
     raise RuntimeError("hipcc not found (set HIPCC or put /opt/rocm/bin on PATH)")
 
 
+_DEPS_CACHE = {}
+
+
 def _deps(path: str, seen=None) -> set:
     """`path` and every file it #includes with quotes, transitively (the library's own headers; system headers do not change)."""
     import re
@@ -66,7 +69,9 @@ def _stale_objects(force: bool) -> list:
             out.append(src)
             continue
         t = os.path.getmtime(o)
-        if any(os.path.getmtime(f) > t for f in _deps(src) | {os.path.abspath(__file__)}):
+        if src not in _DEPS_CACHE:                      # (the include scan once per process, not on every needs_build())
+            _DEPS_CACHE[src] = _deps(src)
+        if any(os.path.getmtime(f) > t for f in _DEPS_CACHE[src] | {os.path.abspath(__file__)}):
             out.append(src)
     return out
 

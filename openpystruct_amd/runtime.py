@@ -50,26 +50,33 @@ def configure(graph_env: bool = True, cpu_threads: bool = True, log=None) -> Dic
     too_late = False
     if graph_env:
         torch = sys.modules.get("torch")
+        # (only the framework's lazy initialisation is detected: an earlier torch.cuda.is_available() / ctypes call into the runtime also fixes
+        #  what the runtime read from the environment -- graph_memsets_replay_correctly() measures what the process actually got)
         too_late = bool(torch is not None and torch.cuda.is_initialized()) and os.environ.get(PACKET_CAPTURE_ENV) is None
         set_graph_env_defaults()
         if too_late and log is not None:
             log(f"{PACKET_CAPTURE_ENV}=0 was set after this process's first HIP call: captured memset nodes may replay wrong values; "
                 "framework-differentiated steps are captured only if runtime.graph_memsets_replay_correctly() passes")
     threads = fit_cpu_threads() if cpu_threads else None
+    # (r06, ADVICE r05: configure() itself makes NO HIP call -- it is documented as the call to make before the first one, and bench.py forks
+    #  its CPU baseline's process pool right after it.  The record carries the framework's HIP version string only; the runtime's own number
+    #  is `hip_runtime_version(query_runtime=True)`, for after the process has chosen its device.)
     _CONFIGURED.update(packet_capture_env=os.environ.get(PACKET_CAPTURE_ENV), graph_env_too_late=too_late, cpu_threads=threads,
-                       hip_runtime=hip_runtime_version())
+                       hip_runtime=hip_runtime_version(query_runtime=False))
     return dict(_CONFIGURED)
 
 
-def hip_runtime_version() -> str:
-    """The HIP runtime this process runs on, as the framework reports it (torch.version.hip) plus the driver-side runtime number of the
-    loaded library (hipRuntimeGetVersion) when a GPU is visible: the bench line records it so that a change of wheel is visible next to
-    a change of numbers."""
+def hip_runtime_version(query_runtime: bool = True) -> str:
+    """The HIP runtime this process runs on, as the framework reports it (torch.version.hip) plus -- `query_runtime`, which INITIALISES the HIP
+    runtime: only after the process has forked whatever it forks -- the driver-side runtime number of the loaded library
+    (hipRuntimeGetVersion) when a GPU is visible: the bench line records it so that a change of wheel is visible next to a change of numbers."""
     import sys
     torch = sys.modules.get("torch")
     if torch is None:
         import torch
     v = str(getattr(torch.version, "hip", None))
+    if not query_runtime:
+        return v
     try:
         if torch.cuda.is_available():
             import ctypes
