@@ -247,29 +247,47 @@ def _config(sizing, kind, c):
                                patience=PATIENCE[kind], random_bridge=int(kind.endswith("_rb")), zero_last_node=kind.startswith("mc"))
 
 
-def _compare_with_reference_runs(st, z, n, lag_tol, tolerance, patience):
+# what the HIP loop is held to against the reference's own runs (r06: set from the RECORDED deviations, profiles/r06_sizing_deviation.json --
+# 5 x the worst case of the 60 runs, rounded up; r05 held I to 2e-3 of its maximum and v / theta to 5e-3 without having measured them)
+TOL_I, TOL_MV, TOL_VT, TOL_LOSS, TOL_LOSS_20 = 2e-4, 2e-4, 5e-3, 1.5e-4, 5e-6      # recorded worst: 4.2e-5, 4.3e-5, 1.5e-3 (theta, random bridges), 2.9e-5, 3.1e-6
+
+
+def _compare_with_reference_runs(st, z, n, lag_tol, tolerance, patience, record=None):
     """Stopping epochs equal -- or within `patience` where the reference's own history has a stop decision inside float32 round-off of
     its threshold (sums are ordered differently on the GPU: such a decision can fall either way, tests/helpers.py); for EVERY case the
-    loss history over the common prefix; records where the counts coincide.  Returns that number."""
+    loss history over the common prefix; records where the counts coincide.  Returns that number.  `record`: a dict that receives the ACHIEVED
+    maximum deviations (what the tolerances above are set from)."""
     ep = st.epochs_run.cpu().numpy()
     I, hist = st.I.cpu().numpy(), st.loss_history.cpu().numpy()
     V32, M32 = st.V32.cpu().numpy(), st.M32.cpu().numpy()
     v, th = st.sol.v.cpu().numpy(), st.sol.theta.cpu().numpy()
     assert int(st.active.sum()) == 0 and int(st.sol.status.abs().sum()) == 0
     matched = 0
+    dev = {"I_rel_to_max": 0.0, "I_ulps_max": 0.0, "I_bit_equal_cases": 0, "M32": 0.0, "V32": 0.0, "v": 0.0, "theta": 0.0, "loss_prefix": 0.0, "loss_first20": 0.0}
     for i in range(n):
         ref_ep = int(z["epochs_run"][i])
         assert_stop_epochs_agree(ep[i], ref_ep, z["loss_history"][i, :ref_ep], tolerance, patience, what=i)
         m = min(int(ep[i]), ref_ep)
-        np.testing.assert_allclose(hist[:m, i], z["loss_history"][i, :m], rtol=2e-4)        # all of the common prefix, every case
-        np.testing.assert_allclose(hist[:20, i], z["loss_history"][i, :20], rtol=5e-6)      # the first epochs: float32 round-off only
+        ref_h = z["loss_history"][i, :m]
+        dev["loss_prefix"] = max(dev["loss_prefix"], float((np.abs(hist[:m, i] - ref_h) / np.abs(ref_h)).max()))
+        dev["loss_first20"] = max(dev["loss_first20"], float((np.abs(hist[:20, i] - z["loss_history"][i, :20]) / np.abs(z["loss_history"][i, :20])).max()))
+        np.testing.assert_allclose(hist[:m, i], ref_h, rtol=TOL_LOSS)                                  # all of the common prefix, every case
+        np.testing.assert_allclose(hist[:20, i], z["loss_history"][i, :20], rtol=TOL_LOSS_20)          # the first epochs: float32 round-off only
         if int(ep[i]) != ref_ep:
             continue
         matched += 1
         Iref = z["I_values"][i].astype(np.float64)
-        assert np.abs(I[i] - Iref).max() / Iref.max() < 2e-3
+        Iref32 = z["I_values"][i].astype(np.float32)
+        dev["I_rel_to_max"] = max(dev["I_rel_to_max"], float(np.abs(I[i] - Iref).max() / Iref.max()))
+        dev["I_ulps_max"] = max(dev["I_ulps_max"], float((np.abs(I[i].astype(np.float32) - Iref32) / np.spacing(Iref32)).max()))
+        dev["I_bit_equal_cases"] += int(np.array_equal(I[i].astype(np.float32), Iref32))
+        dev["M32"] = max(dev["M32"], relerr(M32[i], z["bending_moments"][i])); dev["V32"] = max(dev["V32"], relerr(V32[i], z["shear_forces"][i]))
+        dev["v"] = max(dev["v"], relerr(v[i], z["deflections"][i])); dev["theta"] = max(dev["theta"], relerr(th[i], z["rotations"][i]))
+        assert np.abs(I[i] - Iref).max() / Iref.max() < TOL_I
         assert relerr(M32[i], z["bending_moments"][i]) < lag_tol and relerr(V32[i], z["shear_forces"][i]) < lag_tol
-        assert relerr(v[i], z["deflections"][i]) < 5e-3 and relerr(th[i], z["rotations"][i]) < 5e-3
+        assert relerr(v[i], z["deflections"][i]) < TOL_VT and relerr(th[i], z["rotations"][i]) < TOL_VT
+    if record is not None:
+        record.update(dev, cases=n, stopped_at_the_reference_epoch=matched)
     return matched
 
 
@@ -287,14 +305,15 @@ def test_hip_sizing_loop_reproduces_the_reference_runs(oa, kind):
     st = sizing.optimize_cases(cases, cfg, "cuda", record_loss=True)
     if cfg.zero_last_node:                   # what generate_dataset does with the flag (MC:222-223)
         st.sol.v[:, -1] = 0.0; st.sol.theta[:, -1] = 0.0
-    matched = _compare_with_reference_runs(st, z, n, 2e-3, cfg.tolerance, cfg.patience)
+    rec = {}
+    matched = _compare_with_reference_runs(st, z, n, TOL_MV, cfg.tolerance, cfg.patience, record=rec)
     # (how many stop at the reference's very epoch depends on how many of its stop decisions sat within float32 round-off of the threshold:
     #  ~90 % with patience 5, 75-90 % with patience 10 on the flat loss tails of random bridges; every other case is covered above by its
     #  common prefix and by the marginal-decision check.  The counts go to gpurun_out/ for the notes.)
     os.makedirs(os.path.join(os.path.dirname(GOLD), "..", "gpurun_out"), exist_ok=True)
     with open(os.path.join(os.path.dirname(GOLD), "..", "gpurun_out", f"sizing_golden_matched_{kind}.json"), "w") as f:
-        json.dump({"kind": kind, "cases": n, "stopped_at_the_reference_epoch": matched, "epochs_gpu": st.epochs_run.cpu().tolist(),
-                   "epochs_reference": z["epochs_run"].tolist()}, f)
+        json.dump({"kind": kind, "cases": n, "stopped_at_the_reference_epoch": matched, "achieved_max_deviation": rec,
+                   "epochs_gpu": st.epochs_run.cpu().tolist(), "epochs_reference": z["epochs_run"].tolist()}, f)
     assert matched >= 0.7 * n, f"only {matched} of {n} cases stopped at the reference's epoch"
     # the graph-replayed loop the generator uses gives the same records as the launch-by-launch loop just checked
     st2 = sizing.optimize_cases(cases, cfg, "cuda", poll_every=25)
@@ -314,7 +333,10 @@ def test_hip_sizing_loop_reproduces_the_beam_opt_script(oa):
     st = sizing.optimize_cases(cases, cfg, "cuda", record_loss=True)
     zz = dict(epochs_run=z["epochs_run"], loss_history=z["loss_total"], I_values=z["I_values"], bending_moments=z["bending_moments"],
               shear_forces=z["shear_forces"], deflections=z["deflections"], rotations=z["rotations"])
-    matched = _compare_with_reference_runs(st, zz, n, 2e-3, cfg.tolerance, cfg.patience)
+    rec = {}
+    matched = _compare_with_reference_runs(st, zz, n, TOL_MV, cfg.tolerance, cfg.patience, record=rec)
+    with open(os.path.join(os.path.dirname(GOLD), "..", "gpurun_out", "sizing_golden_matched_bo.json"), "w") as f:
+        json.dump({"kind": "bo", "cases": n, "stopped_at_the_reference_epoch": matched, "achieved_max_deviation": rec}, f)
     assert matched >= n - 2
 
 
