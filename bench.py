@@ -279,6 +279,45 @@ def epoch_median(ep):
     return s[len(s) // 2] if len(s) % 2 else 0.5 * (s[len(s) // 2 - 1] + s[len(s) // 2])
 
 
+GRAD_BYTES = {"pinn": 593914 * 4, "tfd": 359876 * 4}          # ONE flat float32 all-reduce per step (2.38 MB / 1.44 MB)
+XGMI_LINKS, XGMI_LINK_GBS, XGMI_EFF = 7, 153.0, 0.7             # the task's figures: 7 point-to-point links x ~153 GB/s per GPU; 70 % of a link assumed usable
+
+
+def dp_projection(kind, step_plain_us, one_rank=None):
+    """Projected data-parallel step and weak scaling at 2 / 4 / 8 ranks -- ON PAPER: no multi-GPU run exists for this code (one-GPU boxes only).
+    Inputs: the plain step time measured in THIS run; the measured cost of the step's one-rank RCCL form over the plain step (this run's
+    dp_segments if it ran data parallel, else profiles/r06_dp_one_rank_timing.json); the xGMI figures above.  Model of the exposed collective
+    (S bytes, N ranks, per-step latency a):   ring  2 (N-1) (a + S / (N BW))   -- per-link bound, what a ring on point-to-point links costs;
+    direct  2 (a + S / (N BW))  -- reduce-scatter + all-gather with every peer at once over its own link (what the full mesh allows).
+    step_N = plain + max(one-rank overhead, collective); scaling_N = N plain / step_N.  `a` is NOT measured here: 2 and 5 us are shown."""
+    S = GRAD_BYTES[kind]
+    src = "this run (dp_segments)"
+    if one_rank is None:
+        try:
+            r = json.load(open(os.path.join(ROOT, "profiles", "r06_dp_one_rank_timing.json")))
+            one_rank = max(0.0, r[kind]["dp_one_graph_step_us"] - r[kind]["plain_step_us"])
+            src = "profiles/r06_dp_one_rank_timing.json (one-graph step - plain step, one rank of RCCL)"
+        except Exception:
+            one_rank, src = 20.0, "assumed (no one-rank profile committed)"
+    bw = XGMI_LINK_GBS * XGMI_EFF * 1e3           # bytes per us
+    out = {"kind": kind, "grad_bytes": S, "step_plain_us": step_plain_us, "one_rank_overhead_us": one_rank, "one_rank_overhead_source": src,
+           "assumptions": f"{XGMI_LINKS} xGMI links x {XGMI_LINK_GBS:.0f} GB/s per GPU at {XGMI_EFF:.0%}; per-step latency a in (2, 5) us: NOT measured; "
+                          "step_N = plain + max(one-rank overhead, collective_N); nothing overlapped (the collective needs the last weight gradient)",
+           "measured_multi_gpu": None, "ranks": {}}
+    for N in (2, 4, 8):
+        row = {}
+        for a in (2.0, 5.0):
+            ring = 2 * (N - 1) * (a + S / (N * bw))
+            direct = 2 * (a + S / (N * bw))
+            for name, c in (("ring", ring), ("direct", direct)):
+                step = step_plain_us + max(one_rank, c)
+                row[f"{name}_a{a:.0f}us"] = {"collective_us": round(c, 1), "step_us": round(step, 1), "scaling": round(N * step_plain_us / step, 2)}
+        out["ranks"][str(N)] = row
+    need = step_plain_us * (8.0 / 6.0 - 1.0)
+    out["exposed_collective_for_6x_at_8_ranks_us"] = round(need, 1)
+    return out
+
+
 def surrogate_epoch_times(dev, rank, world, epochs, cases=50000):
     """Second half of BASELINE.json's metric: PINN / TFD epoch time (weak scaling: `cases` generated cases and the
     reference's batch size per GPU).  Returns a dict for the JSON line; never raises."""
@@ -324,6 +363,8 @@ def surrogate_epoch_times(dev, rank, world, epochs, cases=50000):
                                   "tfd": "one launch per encoder layer and direction + block launches (tfd_fused.py, csrc/seq_layer.hip, csrc/seq_block.hip)"}[kind]}
             if "dp_segments" in r:       # N > 1: device time of [graph A | all-reduce | graph B] per step (HIP events, mean over the epochs after the first)
                 out[kind]["dp_segments"] = r["dp_segments"]
+            if world == 1 and not is_dp(world):       # r06: what the measured one-rank figures project to at 2 / 4 / 8 ranks (a model, labelled as one)
+                out[kind]["dp_projection"] = dp_projection(kind, out[kind]["step_us"])
         # BASELINE config 4: the TFD surrogate with the physics loss through the HIP FE-residual kernels.  The residual needs
         # per-case targets (n_cases = 1: 40 000 training rows per GPU instead of 6 666 groups), see DESIGN.md section 8
         scfg = sizing.SizingConfig()

@@ -508,10 +508,40 @@ _GROUP_WGRAD = os.environ.get("OPS_AMD_GROUP_WGRAD", "1") == "1"    # A/B switch
 # data-parallel step (world > 1).  Default: [graph A: noise, forward, loss, backward] -> gradient all-reduce -> [graph B: average, clip,
 # Adam], the collective enqueued asynchronously (the host never blocks on it: `wait()` only orders the compute stream behind the
 # collective's) -- OPS_AMD_DP_ASYNC=0 is the plain blocking-call form, bit for bit the same arithmetic (tests/test_surrogates.py).
-# OPS_AMD_DP_ONE_GRAPH=1: try to capture the collective too, the whole step as ONE graph (RCCL collectives can be captured; never run on
-# more than one MI355X here, hence opt-in); any failure while capturing falls back to the two-graph form.
+# r06: under `nccl` the collective is captured too -- the whole step is ONE graph, one replay per step and no host work between its segments
+# (one-rank RCCL timing, profiles/r05_notes.md 6: PINN 137.5 us against 169.1 us for two graphs around an eager collective, TFD 191.3 / 219.8;
+# the same bits as the plain run).  A failure while capturing falls back to the two-graph form; a captured collective that goes wrong on
+# N > 1 ranks would hang at REPLAY, past every fallback, so the first replay runs under a timer that ends the rank with exit code 17
+# (OPS_AMD_DP_STALL_S seconds, default 120: the launcher then takes the job down; a fresh job may set OPS_AMD_DP_ONE_GRAPH=0 -- never a re-exec
+# from a process that holds the GPU).  OPS_AMD_DP_ONE_GRAPH=0: [graph A | all-reduce | graph B].
 _DP_ASYNC = os.environ.get("OPS_AMD_DP_ASYNC", "1") == "1"
-_DP_ONE_GRAPH = os.environ.get("OPS_AMD_DP_ONE_GRAPH", "0") == "1"
+_DP_ONE_GRAPH = os.environ.get("OPS_AMD_DP_ONE_GRAPH", "1") == "1"
+_DP_STALL_S = float(os.environ.get("OPS_AMD_DP_STALL_S", "120"))
+
+
+class _StallGuard:
+    """`with _StallGuard(seconds, what):` -- if the block has not finished after `seconds`, the process ends with exit code 17 and a line on
+    stderr saying what stalled (a hung graph replay of a captured collective cannot be recovered inside the process)."""
+
+    def __init__(self, seconds: float, what: str):
+        self.seconds, self.what, self.timer = seconds, what, None
+
+    def _fire(self):
+        sys.stderr.write(f"openpystruct_amd: {self.what} did not finish within {self.seconds:.0f} s -- ending this rank (exit 17); "
+                         f"run again with OPS_AMD_DP_ONE_GRAPH=0 for the two-graph step\n")
+        sys.stderr.flush()
+        os._exit(17)
+
+    def __enter__(self):
+        import threading
+        self.timer = threading.Timer(self.seconds, self._fire)
+        self.timer.daemon = True
+        self.timer.start()
+        return self
+
+    def __exit__(self, *exc):
+        self.timer.cancel()
+        return False
 _FORCE_DP = os.environ.get("OPS_AMD_FORCE_DP", "0") == "1"           # run the data-parallel branch with a one-rank process group too
 _DP_PROFILE = os.environ.get("OPS_AMD_DP_PROFILE", "0") == "1"       # HIP events around the step's segments, reported as out["dp_segments"]
 F_linear = torch.nn.functional.linear
@@ -1099,6 +1129,7 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
     perm_gen = torch.Generator(device=device)
     perm_gen.manual_seed(seed * 1000003 + 17 + rank)
     seg_ev = [] if (_DP_PROFILE and on_gpu and graph is not None) else None      # per-step event quadruples (first epoch excluded below)
+    first_one_graph_replay = bool(graph_mode_one)        # the captured collective's first replay runs under the stall timer
     for epoch in range(1, n_epochs + 1):
         if device.type == "cuda":
             torch.cuda.synchronize(device)
@@ -1137,6 +1168,14 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
                     torch.index_select(Ytr, 0, idx, out=sY)
                 if sP is not None and not fuse_gather:
                     physics_inputs(idx, out=sP)
+                if first_one_graph_replay:
+                    first_one_graph_replay = False
+                    with _StallGuard(_DP_STALL_S, "the first replay of the data-parallel step graph (gradient all-reduce captured)"):
+                        graph.replay()
+                        torch.cuda.synchronize(device)
+                    if engine is None and loss_acc is None:
+                        tot += s_loss
+                    continue
                 if seg_ev is not None and len(seg_ev) < 4096:
                     ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
                     ev[0].record()

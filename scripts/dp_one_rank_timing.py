@@ -7,6 +7,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import torch.distributed as dist
 
+for k_, v_ in (("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29711"), ("RANK", "0"), ("WORLD_SIZE", "1"), ("LOCAL_RANK", "0")):
+    os.environ.setdefault(k_, v_)          # (without the launcher: the one-rank environment env:// needs)
 local = int(os.environ.get("LOCAL_RANK", "0"))
 torch.cuda.set_device(local)
 dev = torch.device("cuda", local)
@@ -26,3 +28,8 @@ for kind in ("pinn", "tfd"):
         print(kind, name, out[f"{kind}/{name}"], flush=True)
 dist.destroy_process_group()
 print("DP_TIMING " + json.dumps(out))
+summ = {k: {f"{n}_step_us": out[f"{k}/{n}"]["step_us"] for n in ("plain", "dp_two_graphs", "dp_one_graph")} for k in ("pinn", "tfd")}
+summ["what"] = ("epoch time / steps (validation pass included) of the surrogates' training loop on 50 000 generated cases, epochs 3-8, one rank of RCCL "
+                "(scripts/dp_one_rank_timing.py): plain single-process step, two graphs around an eager all-reduce, ONE graph incl. the all-reduce (r06 default)")
+os.makedirs("gpurun_out", exist_ok=True)
+json.dump(summ, open("gpurun_out/r06_dp_one_rank_timing.json", "w"), indent=1)

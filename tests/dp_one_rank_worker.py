@@ -30,13 +30,15 @@ def main():
     out["allreduce_identity"] = bool(torch.equal(t.cpu(), torch.arange(8, dtype=torch.float32)))
     rec = sizing.generate_dataset(1800, sizing.SizingConfig(max_e=30), dev, seed=11)      # 300 groups -> 240 training groups
     logs = []
+    default_one_graph = bool(train._DP_ONE_GRAPH)          # the module's default (r06: the collective captured, one graph per step)
+    out["default_one_graph"] = default_one_graph
     for kind in kinds:
         d = dataprep.prepare(rec, kind=kind, seed=0, device=dev, distributed=True)       # scaler moments through the (one-rank) all-reduce
         cfg = {"pinn": train.PinnConfig, "tfd": train.TfdConfig}[kind](batch_size=64)   # 240 rows: 3 full batches + a tail of 48
         runs = {}
         variants = [("plain", dict(force=False)), ("plain_again", dict(force=False)), ("dp_async", dict(force=True, async_=True)),
                     ("dp_blocking", dict(force=True, async_=False)), ("dp_one_graph", dict(force=True, async_=True, one_graph=True)),
-                    ("dp_profile", dict(force=True, async_=True, profile=True))]
+                    ("dp_profile", dict(force=True, async_=True, profile=True)), ("dp_default", dict(force=True, async_=True, one_graph=default_one_graph))]
         for name, v in variants:
             train._FORCE_DP = v["force"]
             train._DP_ASYNC = v.get("async_", True)

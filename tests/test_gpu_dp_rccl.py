@@ -50,7 +50,7 @@ def test_training_through_the_data_parallel_branch_on_one_rank_of_rccl():
         again = np.array(runs["plain_again"]["train"] + runs["plain_again"]["val"])
         assert np.isfinite(plain).all()
         spread = float(np.abs(plain - again).max() / np.abs(plain).max())
-        for name in ("dp_async", "dp_blocking", "dp_one_graph", "dp_profile"):
+        for name in ("dp_async", "dp_blocking", "dp_one_graph", "dp_profile", "dp_default"):
             got = np.array(runs[name]["train"] + runs[name]["val"])
             diff = float(np.abs(got - plain).max() / np.abs(plain).max())
             if kind == "pinn":
@@ -63,6 +63,8 @@ def test_training_through_the_data_parallel_branch_on_one_rank_of_rccl():
                 # the statement is a tolerance -- far below what a wrong average / missing all-reduce would show (O(1))
                 assert diff <= max(20 * spread, 2e-3), (kind, name, diff, spread)
         assert runs["plain"]["dp_mode"] is None
+        # r06: the DEFAULT data-parallel step under nccl is the one-graph form (the collective captured; first replay under the stall timer)
+        assert r["default_one_graph"] and runs["dp_default"]["dp_mode"]["step"] == "one graph incl. the all-reduce"
         for name in ("dp_async", "dp_blocking", "dp_one_graph", "dp_profile"):
             m = runs[name]["dp_mode"]
             assert m["backend"] == "nccl" and m["world"] == 1 and m["forced_one_rank"] and m["async"] == (name != "dp_blocking")
@@ -81,6 +83,6 @@ def test_bench_line_through_the_rccl_barrier_and_timing_allreduce_on_one_rank():
     se = rec["surrogate_epochs"]
     assert "error" not in se, se
     for kind in ("pinn", "tfd"):
-        assert se[kind]["epoch_s"] > 0 and se[kind]["dp_segments"]["world"] == 1      # the data-parallel step ran: [graph A | all-reduce | graph B]
+        assert se[kind]["epoch_s"] > 0 and se[kind]["dp_segments"]["world"] == 1 and se[kind]["dp_segments"]["one_graph"]      # the data-parallel step ran: ONE graph incl. the all-reduce
     with open(os.path.join(ROOT, "gpurun_out", "bench_one_rank_rccl.json"), "w") as f:
         json.dump(rec, f)

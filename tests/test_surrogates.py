@@ -314,3 +314,17 @@ def test_async_gradient_allreduce_equals_the_blocking_form_bit_for_bit(world):
     for _, wa, wb in outs:
         assert np.array_equal(wa, wb)
         assert np.array_equal(wa, outs[0][1])
+
+
+def test_stall_guard_ends_the_process_with_its_own_exit_code():
+    """r06: the data-parallel step's captured collective replays under `train._StallGuard` the first time -- a replay that hangs (possible only on
+    N > 1 ranks, past every in-process fallback) must turn into a non-zero exit of the rank, not a silent stall."""
+    import subprocess
+    import sys
+    code = ("import time\nfrom openpystruct_amd.train import _StallGuard\n"
+            "with _StallGuard(0.3, 'a test block'):\n    time.sleep(20)\n")
+    p = subprocess.run([sys.executable, "-c", code], cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), capture_output=True, text=True, timeout=120)
+    assert p.returncode == 17 and "a test block did not finish within" in p.stderr and "OPS_AMD_DP_ONE_GRAPH=0" in p.stderr
+    code_ok = "from openpystruct_amd.train import _StallGuard\nwith _StallGuard(5.0, 'x'):\n    pass\nprint('fine')\n"
+    p = subprocess.run([sys.executable, "-c", code_ok], cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0 and "fine" in p.stdout
