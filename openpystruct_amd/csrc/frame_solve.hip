@@ -627,16 +627,21 @@ static int eff_kd(int half_bandwidth) { return half_bandwidth < 3 ? 3 : half_ban
 // the whole workgroup works on the one frame its CU has) answers sooner than a wave per frame (one wave works, the CU's other 15 wave slots idle):
 // 10 x 10 118 us against 207 - 221 us for 1 .. 256 frames, 5 x 5 47 / 84, 3 x 3 36 / 55, 15 x 16 (band in HBM) 472 - 492 / 535 - 576; at 1 024 frames
 // the wave kernel is ahead (10 x 10: 231 / 426 us) (scripts/frame_small_batch_ab.py).  That is the reference's own use of the frame solve -- ONE
-// frame per epoch (FR:178-183) -- and the command shim's.  Above one frame per CU the workgroup kernels saturate at ~8.5e11 / (n kd^2) frames
-// per second (10 x 10: 2.4e6, 5 x 5: 3.5e7) while a launch of the wave kernel never takes less than ~25 us + 0.55 us per equation (one wave's
-// chain: 10 x 10 207 us, 5 x 5 84 us): the batch at which the two meet -- 10 x 10: ~500 frames, 5 x 5: ~2 500 -- is the threshold, at least 256
-// (one frame per CU) and at most 4 000.  scripts/frame_dispatch_sweep.py: the choice is within 6 % of the faster kernel for 3 x 3 .. 15 x 16
-// frames and 128 .. 16 384 frames per launch.  Option "frame_latency_batch" overrides the threshold (0: tuned kernels for every batch).
+// frame per epoch (FR:178-183) -- and the command shim's.  The batch at which the two families meet is the threshold (latency_batch below), at
+// least 256 (one frame per CU) and at most 4 000.  Option "frame_latency_batch" overrides it (0: tuned kernels for every batch).
 static int latency_batch(int n_eq, int kd) {
   const long o = g_frame_latency_batch.load();
   if (o >= 0) return (int)(o > 0x7fffffff ? 0x7fffffff : o);
-  const double wave_floor_s = 25e-6 + 0.55e-6 * n_eq, legacy_rate = 8.5e11 / ((double)n_eq * kd * kd);
-  const double b = wave_floor_s * legacy_rate;
+  // r06 fit (scripts/frame_dispatch_sweep.py on the packed kernel, profiles/r06_frame_dispatch_sweep.txt): a launch of the tuned kernels never
+  // takes less than one wave's chain -- packed (kd <= 27): ~10 us + 0.5 us per equation (2 x 2: 17 us, 5 x 5: 47, 8 x 8: 123); a wave per frame:
+  // (0.275 + 0.0075 kd) us per equation (10 x 10: 170 us, 15 x 16: 500) -- and the workgroup-per-frame kernels, flat up to a frame per CU, then
+  // cost max(n kd^2 / 8.5e11, 6 ns + 0.22 ns n) per frame (5 x 5: 30 ns, 3 x 3: 14 ns, 10 x 10: 0.40 us).  The two meet at the quotient: 2 x 2 ~1 700
+  // frames, 5 x 5 ~1 500, 10 x 10 ~430 (measured crossovers: between 1 024 and 2 048, 1 024 and 2 048, 256 and 512).
+  int P, G, W;
+  const bool pack = g_frame_pack.load() && fp_config(kd, &P, &G, &W);
+  const double tuned_floor_s = pack ? 10e-6 + 0.5e-6 * n_eq : (0.275e-6 + 0.0075e-6 * kd) * n_eq;
+  const double a = (double)n_eq * kd * kd / 8.5e11, c = 6e-9 + 0.22e-9 * n_eq;
+  const double b = tuned_floor_s / (a > c ? a : c);
   return b < 256.0 ? 256 : b > 4000.0 ? 4000 : (int)b;
 }
 static bool legacy_kernels_serve(int n_eq, int kd) {

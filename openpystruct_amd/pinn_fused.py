@@ -22,10 +22,10 @@ from typing import List
 import torch
 import torch.nn as nn
 
-from . import _cabi
+from . import _cabi, switches
 from .surrogates import CompositeLoss, FNNWithResidual, ResidualBlock
 
-ENABLED = os.environ.get("OPS_AMD_PINN_LAYER_BLOCKS", "1") == "1"      # A/B switch: 0 = autograd over the fused tails
+ENABLED = switches.get("pinn_layer_blocks") == "1"      # A/B switch: 0 = autograd over the fused tails
 
 
 def _ru(v: int, m: int) -> int:

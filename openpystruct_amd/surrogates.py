@@ -22,6 +22,8 @@ import math
 import os
 
 import torch
+
+from . import switches  # noqa: E402
 import torch.nn as nn
 import torch.nn.functional as F
 
@@ -32,7 +34,7 @@ import torch.nn.functional as F
 # ResidualBlock's Conv1d(1,1,3) + BatchNorm1d(1) pair through csrc/stencil_bn.hip (default) or through the framework modules
 # (OPS_AMD_PINN_FUSED_STENCIL=0, the A/B switch).  Measured on MI355X, same run: PINN epoch 0.0497 s fused vs 0.0541 s with
 # the modules; the step graph 0.870 vs 0.938 ms (profiles/r01_notes.md).
-_FUSED_STENCIL = os.environ.get("OPS_AMD_PINN_FUSED_STENCIL", "1") == "1"
+_FUSED_STENCIL = switches.get("pinn_fused_stencil") == "1"
 
 
 class _StencilBN(torch.autograd.Function):
@@ -136,7 +138,7 @@ def conv3_bn_single_channel(x: torch.Tensor, conv: nn.Conv1d, bn: nn.BatchNorm1d
 # fused elementwise tails (csrc/fused_bn.hip): [x1 + x2 + x3] -> BatchNorm1d -> LeakyReLU -> dropout in ONE launch each way
 # (OPS_AMD_PINN_FUSED_TAILS=0: the framework's modules, the A/B switch).  107 -> ~60 kernel nodes per captured PINN step.
 # ------------------------------------------------------------------------------------------------
-_FUSED_TAILS = os.environ.get("OPS_AMD_PINN_FUSED_TAILS", "1") == "1"
+_FUSED_TAILS = switches.get("pinn_fused_tails") == "1"
 
 
 class _FusedTail(torch.autograd.Function):

@@ -25,21 +25,21 @@ from typing import Optional
 import torch
 import torch.nn as nn
 
-from . import _cabi
+from . import _cabi, switches
 
-ENABLED = os.environ.get("OPS_AMD_TFD_FAST_ENCODER", "1") == "1"      # A/B switch: 0 = nn.TransformerEncoder's own forward
-LAYER_FWD = os.environ.get("OPS_AMD_TFD_LAYER_FWD", "1") == "1"       # A/B switch: 0 = eight launches per layer forward instead of one
-DRAW = os.environ.get("OPS_AMD_TFD_DRAW", "1") == "1"                 # A/B switch: 0 = diffusion steps / noise from the framework generators
-_TRACE_BWD = [] if os.environ.get("OPS_AMD_TFD_TRACE_BWD") else None   # diagnostics: stage stamps of every backward layer launch
+ENABLED = switches.get("tfd_fast_encoder") == "1"      # A/B switch: 0 = nn.TransformerEncoder's own forward
+LAYER_FWD = switches.get("tfd_layer_fwd") == "1"       # A/B switch: 0 = eight launches per layer forward instead of one
+DRAW = switches.get("tfd_draw") == "1"                 # A/B switch: 0 = diffusion steps / noise from the framework generators
+_TRACE_BWD = [] if switches.get("tfd_trace_bwd") else None   # diagnostics: stage stamps of every backward layer launch
 KEEP_DRAWS = False                                                    # tests: every state keeps its last draws (`_State.draws`)
-EVAL_FAST = os.environ.get("OPS_AMD_TFD_EVAL_FAST", "1") == "1"       # A/B switch: 0 = validation passes through the module's own forward
-FRONT = os.environ.get("OPS_AMD_TFD_FRONT", "1") == "1"               # A/B switch: 0 = the diffusion front end as five + three launches
-LN_PARTIALS = os.environ.get("OPS_AMD_TFD_LN_PARTIALS", "1") == "1"   # A/B switch: 0 = LayerNorm gamma / beta gradients by float atomics in the layer launch
-HEAD = os.environ.get("OPS_AMD_TFD_HEAD", "1") == "1"                 # A/B switch: 0 = the head as four launches per direction
+EVAL_FAST = switches.get("tfd_eval_fast") == "1"       # A/B switch: 0 = validation passes through the module's own forward
+FRONT = switches.get("tfd_front") == "1"               # A/B switch: 0 = the diffusion front end as five + three launches
+LN_PARTIALS = switches.get("tfd_ln_partials") == "1"   # A/B switch: 0 = LayerNorm gamma / beta gradients by float atomics in the layer launch
+HEAD = switches.get("tfd_head") == "1"                 # A/B switch: 0 = the head as four launches per direction
 IDENTITY_ACT = False      # verification only (tests): every ReLU of the one-launch kernels becomes the identity -- a smooth network
-FRONT_GATHER = os.environ.get("OPS_AMD_TFD_FRONT_GATHER", "1") == "1"   # A/B switch: 0 = the batch assembly as a launch of its own per step
-HEAD_LOSS = os.environ.get("OPS_AMD_TFD_HEAD_LOSS", "1") == "1"       # A/B switch: 0 = the training loss as launches of its own behind the head
-LAYER_BWD = os.environ.get("OPS_AMD_TFD_LAYER_BWD", "1") == "1"       # A/B switch: 0 = eight launches per layer backward instead of one
+FRONT_GATHER = switches.get("tfd_front_gather") == "1"   # A/B switch: 0 = the batch assembly as a launch of its own per step
+HEAD_LOSS = switches.get("tfd_head_loss") == "1"       # A/B switch: 0 = the training loss as launches of its own behind the head
+LAYER_BWD = switches.get("tfd_layer_bwd") == "1"       # A/B switch: 0 = eight launches per layer backward instead of one
 
 
 class _State:
@@ -213,9 +213,9 @@ class ActDropout(torch.autograd.Function):
         return dx, None, None, None, None
 
 
-LAYER_PAIR_FWD = os.environ.get("OPS_AMD_TFD_LAYER_PAIR", "1") == "1"      # A/B switch: two consecutive layers' forward passes as one launch
+LAYER_PAIR_FWD = switches.get("tfd_layer_pair") == "1"      # A/B switch: two consecutive layers' forward passes as one launch
 _PENDING_LAYER = None       # (argument block, output, tensors to keep alive) of a layer whose forward launch waits for its successor
-LAYER_PAIR_BWD = os.environ.get("OPS_AMD_TFD_LAYER_PAIR_BWD", "1") == "1"  # ... and their backward passes
+LAYER_PAIR_BWD = switches.get("tfd_layer_pair_bwd") == "1"  # ... and their backward passes
 _PENDING_BWD = None         # (argument block, dx32, tensors to keep alive) of a later layer whose backward launch waits for its predecessor
 
 

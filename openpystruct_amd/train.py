@@ -31,6 +31,8 @@ from dataclasses import dataclass
 from typing import Dict, Optional
 
 import torch
+
+from . import switches  # noqa: E402
 import torch.distributed as dist
 import torch.nn as nn
 from torch.optim.lr_scheduler import ExponentialLR
@@ -111,7 +113,7 @@ class FnnConfig:
     c: float = 1.0
 
 
-_FUSED_LOSS = os.environ.get("OPS_AMD_FUSED_LOSS", "1") == "1"      # A/B switch: 0 = the nn.Module losses
+_FUSED_LOSS = switches.get("fused_loss") == "1"      # A/B switch: 0 = the nn.Module losses
 
 
 class FlatClipAdam:
@@ -226,7 +228,7 @@ class FnoConfig:
 
 
 _DEBUG_NAN = os.environ.get("OPS_AMD_DEBUG_NAN", "0") == "1"
-_EXPLICIT_ROOT = os.environ.get("OPS_AMD_EXPLICIT_ROOT", "1") == "1"      # A/B switch: 0 = loss.backward() with its implicit ones_like() fill node
+_EXPLICIT_ROOT = switches.get("explicit_root") == "1"      # A/B switch: 0 = loss.backward() with its implicit ones_like() fill node
 _ROOT_ONES = {}
 
 
@@ -287,7 +289,7 @@ def set_next_input_grad_dest(dest: Optional[torch.Tensor]) -> None:
     strided) instead of a fresh tensor: the Transformer-Diffusion head hands the [CLS] rows of a persistent zero tensor, and the row
     scatter that followed the product disappears from the step."""
     global _NEXT_GX_DEST
-    _NEXT_GX_DEST = dest if os.environ.get("OPS_AMD_GX_DEST", "1") == "1" else None
+    _NEXT_GX_DEST = dest if switches.get("gx_dest") == "1" else None
 
 
 class _ShadowLinearFn(torch.autograd.Function):
@@ -322,7 +324,7 @@ class _ShadowLinearFn(torch.autograd.Function):
             # column sums of the slabs it reads anyway -- into the float32 gradients itself
             from . import _cabi
             g2 = g2.contiguous()
-            rows_ok = os.environ.get("OPS_AMD_WGRAD_ROWS", "1") == "1" and _WGRAD_QUEUE is not None and x2.dim() == 2 and x2.stride(1) == 1 and x2.stride(0) >= x2.shape[1]
+            rows_ok = switches.get("wgrad_rows") == "1" and _WGRAD_QUEUE is not None and x2.dim() == 2 and x2.stride(1) == 1 and x2.stride(0) >= x2.shape[1]
             x2c = x2 if rows_ok else x2.contiguous()        # the grouped launch takes row strides (the head reads the [CLS] rows in place)
             fused_bias = ctx.ib is not None and ctx.b_grad is not None
             if _WGRAD_QUEUE is not None:
@@ -408,7 +410,7 @@ def shadow_grads_are_deferred(rec: ShadowRec, rows: int) -> bool:
 # products over at least this many rows take the split-row kernel (0: never).  r04: 16 (was 512) -- the kernel now keeps a whole tile per wave and
 # reduces inside the workgroup, so a 10-sample tail batch (70 / 10 rows: twelve library GEMMs of ~16 us + twelve column sums per epoch)
 # is one grouped launch too; only products over fewer rows than one MFMA tile stay with the library
-_SPLIT_WGRAD_ROWS = int(os.environ.get("OPS_AMD_SPLIT_WGRAD_ROWS", "16"))
+_SPLIT_WGRAD_ROWS = int(switches.get("split_wgrad_rows"))
 _WGRAD_QUEUE = None          # a list while a training step collects its split-row weight gradients for ONE grouped launch
 
 
@@ -504,7 +506,7 @@ def disable_shadow_linears(patched) -> None:
                 del mod.__dict__[name]
 
 
-_GROUP_WGRAD = os.environ.get("OPS_AMD_GROUP_WGRAD", "1") == "1"    # A/B switch: 0 = one launch per product, inside backward
+_GROUP_WGRAD = switches.get("group_wgrad") == "1"    # A/B switch: 0 = one launch per product, inside backward
 # data-parallel step (world > 1).  Default: [graph A: noise, forward, loss, backward] -> gradient all-reduce -> [graph B: average, clip,
 # Adam], the collective enqueued asynchronously (the host never blocks on it: `wait()` only orders the compute stream behind the
 # collective's) -- OPS_AMD_DP_ASYNC=0 is the plain blocking-call form, bit for bit the same arithmetic (tests/test_surrogates.py).
@@ -545,7 +547,7 @@ class _StallGuard:
 _FORCE_DP = os.environ.get("OPS_AMD_FORCE_DP", "0") == "1"           # run the data-parallel branch with a one-rank process group too
 _DP_PROFILE = os.environ.get("OPS_AMD_DP_PROFILE", "0") == "1"       # HIP events around the step's segments, reported as out["dp_segments"]
 F_linear = torch.nn.functional.linear
-_SHADOW_LINEAR = os.environ.get("OPS_AMD_SHADOW_LINEAR", "1") == "1"   # A/B switch: 0 = nn.Linear under autocast
+_SHADOW_LINEAR = switches.get("shadow_linear") == "1"   # A/B switch: 0 = nn.Linear under autocast
 
 
 def build_model_and_loss(kind: str, cfg, data: SurrogateData, device):
@@ -663,7 +665,7 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
                 if tfd_fused.patch_model(model, seed=seed * 7919 + 211 + rank, direct_param_grads=True):
                     fast_encoder = model
                     opt.repack = getattr(model.transformer_encoder, "_ops_tile_entries", None)    # the Adam launch refreshes the layer kernels' weight tiles
-                    if os.environ.get("OPS_AMD_FUSED_PREP", "1") == "1":
+                    if switches.get("fused_prep") == "1":
                         # the batch-assembly launch advances its call counter once per step: the dropout / noise streams read that one
                         tfd_fused.share_step_counter(model.transformer_encoder, prep_counter)
                         shared_counter = True
@@ -679,11 +681,11 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
         if pinn_fused.eligible(model, crit, cfg.batch_size):
             engine = pinn_fused.PinnFusedStep(model, crit, seed=seed * 7919 + 101 + rank)
             opt.repack = engine._repack      # the Adam launch refreshes the engine's bf16 weight copies
-            if not dp and os.environ.get("OPS_AMD_PINN_NORM_FOLD", "1") == "1":
+            if not dp and switches.get("pinn_norm_fold") == "1":
                 # one rank: the gradients are final when the weight-gradient launch ends, so that launch leaves the clip norm's partial
                 # sums and the optimiser skips its norm launch (a node and ~4.5 us per step; data parallel: the norm is the all-reduced one)
                 opt.norm_ready_parts = engine.enable_norm(flat, opt.ws, opt.step_count, opt.betas)
-            if not dp and os.environ.get("OPS_AMD_PINN_REPACK_IN_GATHER", "1") == "1":
+            if not dp and switches.get("pinn_repack_in_gather") == "1":
                 # one rank: the weight copies of step n ride on the batch-assembly launch of step n + 1 (adjacent launches that depend on
                 # nothing of each other: one node and ~5 us less per step); the optimiser call no longer rebuilds them
                 opt.repack = None
@@ -714,10 +716,10 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
     # lives in `g_order`, `g_cursor` is advanced by the launch itself (reset per epoch).
     fuse_gather = False
     g_order = g_cursor = g_noise = None
-    _FUSED_PHYS = on_gpu and os.environ.get("OPS_AMD_FUSED_PHYSICS", "1") == "1"      # A/B switch: 0 = physics.fe_residual_loss from framework ops
+    _FUSED_PHYS = on_gpu and switches.get("fused_physics") == "1"      # A/B switch: 0 = physics.fe_residual_loss from framework ops
     # the loss launch adds every step's value to the epoch's running sum itself (zeroed per epoch): no add node per step
     # (with the fused physics term both launches add into the same running sum: the epoch's total of data loss + term)
-    loss_acc = torch.zeros((), dtype=torch.float32, device=device) if (on_gpu and _FUSED_LOSS and engine is None and (physics is None or _FUSED_PHYS) and os.environ.get("OPS_AMD_LOSS_ACC", "1") == "1") else None
+    loss_acc = torch.zeros((), dtype=torch.float32, device=device) if (on_gpu and _FUSED_LOSS and engine is None and (physics is None or _FUSED_PHYS) and switches.get("loss_acc") == "1") else None
     # the loss on the head's tile: its value exists once the head's backward launch has run, so a second term can only be tied to it
     # (not added) -- which needs the running sum to carry the step values
     head_loss_ok = fast_encoder is not None and _FUSED_LOSS and (physics is None or (_FUSED_PHYS and loss_acc is not None))
@@ -781,7 +783,7 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
             v_p, t_p = pin[1], pin[2]
         return physics.weight * fe_residual_loss(I_p, v_p, t_p, px, pE, pfix, pin[0], pwy).float()
 
-    if on_gpu and engine is None and os.environ.get("OPS_AMD_ADAM_ZERO", "1") == "1":
+    if on_gpu and engine is None and switches.get("adam_zero") == "1":
         opt.zero_grads = True            # `flat` starts zeroed (allocation) and every update leaves it zeroed
 
     def fwd_bwd(Xb, Yb, noise_t, pin=None, prenoised=False):
@@ -880,7 +882,7 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
     # itself.  The reference's value -- the mean over its batches of the batch losses (TFD:760-775) -- is kept; a step-sized forward
     # fills 1/18 of the chip, so 20 of them in a row cost ~8x what one 20-fold forward does.  (Rows are independent in evaluation mode;
     # the diffusion draws of the pass come from one call of the stream instead of one per batch.)
-    val_whole = bool(on_gpu and fast_encoder is not None and _FUSED_LOSS and os.environ.get("OPS_AMD_VAL_WHOLE", "1") == "1")
+    val_whole = bool(on_gpu and fast_encoder is not None and _FUSED_LOSS and switches.get("val_whole") == "1")
     _VAL_CHUNK = cfg.batch_size * max(1, 4096 // max(cfg.batch_size, 1))
 
     def val_all(acc):
@@ -893,13 +895,13 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
                     fused_loss(crit, preds[b0 - c0:b1 - c0], Yva[b0:b1], acc=acc)
 
     # batch assembly in one launch (csrc/input_prep.hip): gather + noise + cast straight into the graph's input buffer
-    _FUSED_PREP = on_gpu and os.environ.get("OPS_AMD_FUSED_PREP", "1") == "1"
+    _FUSED_PREP = on_gpu and switches.get("fused_prep") == "1"
     # bf16 batches only where the first module is a (shadow) Linear, which casts its operand to bf16 anyway
     prep_bf16 = bool(on_gpu and use_ac and autocast_dtype == torch.bfloat16 and patched and kind in ("pinn", "fnn", "gnn"))
 
     engine_seed = (seed * 7919 + 13 + rank) & 0x7FFFFFFFFFFFFFFF
 
-    y_in_prep = bool(on_gpu and Ytr.dtype == torch.float32 and Ytr.is_contiguous() and os.environ.get("OPS_AMD_PREP_TARGETS", "1") == "1")      # the targets travel in the same launch
+    y_in_prep = bool(on_gpu and Ytr.dtype == torch.float32 and Ytr.is_contiguous() and switches.get("prep_targets") == "1")      # the targets travel in the same launch
 
     def gather_noise(idx, out, out_y=None):
         """Returns whether the targets were gathered too (out_y given and float32)."""
@@ -924,7 +926,7 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
     graph = graph_b = vgraph = graph_t = vgraph_t = slot_graph = vgraph_all = None
     ev_graphs, val_rows = {}, None
     # PINN: validation through the engine's evaluation pass (running statistics, no dropout) when the validation set has its layout
-    engine_eval = bool(engine is not None and os.environ.get("OPS_AMD_PINN_ENGINE_EVAL", "1") == "1" and Xva.dtype == torch.float32
+    engine_eval = bool(engine is not None and switches.get("pinn_engine_eval") == "1" and Xva.dtype == torch.float32
                        and Xva.is_contiguous() and Yva.dtype == torch.float32 and Yva.is_contiguous() and Xva.dim() == 2
                        and cfg.batch_size <= _cabi_rows())
     graph_mode_one = False
@@ -993,7 +995,7 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
             # 5 ms TFD epoch), and eager model passes between replays are what the flaky-NaN hunt of r03 kept running into
             nt = int(Xtr.shape[0]) % bs
             if (graph is not None and not dp and sP is None and nt >= 2 and nb_tr == Xtr.shape[0] // bs + 1
-                    and os.environ.get("OPS_AMD_TAIL_GRAPH", "1") == "1"):
+                    and switches.get("tail_graph") == "1"):
                 try:
                     sXt, sYt = (None if engine is not None else torch.zeros_like(sX[:nt])), torch.zeros_like(sY[:nt])
                     if engine is not None:       # the engine's own buffers are the graph's inputs: Yb only carries the row count
@@ -1028,7 +1030,7 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
                 tfd_fused.refresh_layer_tiles(fast_encoder.transformer_encoder)
         # the validation pass as graphs too (eval mode, loss accumulated into v_acc): one for the full batches, one for the last partial one
         nvt = int(Xva.shape[0]) % bs
-        if engine_eval and graph is not None and os.environ.get("OPS_AMD_PINN_EVAL_SLOTS", "1") == "1":
+        if engine_eval and graph is not None and switches.get("pinn_eval_slots") == "1":
             # PINN: the whole validation set per launch sequence -- every batch in an evaluation slot (pinn_fused.make_eval_slots:
             # gathered once, the rows never change), the engine's 7 evaluation launches run all slots side by side (grid.y): 7 nodes
             # per epoch instead of 14 batches x 8 launches of ~6 us
@@ -1103,7 +1105,7 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
                     vgraph_all = capture_val_all()
                 elif Xva.shape[0] >= bs:
                     vgraph, vX, vY = capture_val(bs)
-                if not val_whole and nvt >= 1 and not dp and os.environ.get("OPS_AMD_TAIL_GRAPH", "1") == "1":
+                if not val_whole and nvt >= 1 and not dp and switches.get("tail_graph") == "1":
                     vgraph_t, vXt, vYt = capture_val(nvt)
             except Exception as e:
                 if log:

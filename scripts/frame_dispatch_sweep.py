@@ -5,10 +5,11 @@ import os, subprocess, sys, time
 if len(sys.argv) > 1:
     import torch
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    from openpystruct_amd import frames
-    for (b, s) in ((3, 3), (5, 5), (10, 2), (7, 5), (10, 10), (15, 16)):
+    from openpystruct_amd import _cabi, frames
+    _cabi.set_option("frame_latency_batch", {"wave": 0, "workgroup": 1000000, "auto": -1}[sys.argv[1]])
+    for (b, s) in ((1, 1), (2, 2), (3, 3), (5, 5), (10, 2), (7, 5), (8, 8), (10, 10), (15, 16)):
         topo = frames.grid_frame(b, s)
-        for B in (128, 256, 512, 1024, 2048, 4096, 8192, 16384):
+        for B in (64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384, 32768):
             I = torch.full((B, topo.Ne), 5e-4, dtype=torch.float64, device="cuda")
             sol = frames.frame_solve(topo, I); torch.cuda.synchronize()
             t0 = time.perf_counter()
@@ -18,9 +19,8 @@ if len(sys.argv) > 1:
             print(f"{sys.argv[1]} {b}x{s} {topo.n_eq} {topo.kd} {B} {1e6 * (time.perf_counter() - t0) / 20:.1f}", flush=True)
     sys.exit(0)
 rows = {}
-for mode, env in (("wave", {"OPS_AMD_FRAME_LATENCY_BATCH": "0"}), ("workgroup", {"OPS_AMD_FRAME_LATENCY_BATCH": "1000000"}), ("auto", {})):
-    e = dict(os.environ, **env)
-    out = subprocess.run([sys.executable, __file__, mode], env=e, capture_output=True, text=True).stdout
+for mode in ("wave", "workgroup", "auto"):      # (library option frame_latency_batch: 0 / 10^6 / the library's own model)
+    out = subprocess.run([sys.executable, __file__, mode], capture_output=True, text=True).stdout
     for l in out.splitlines():
         p = l.split()
         if len(p) == 6 and p[0] == mode:

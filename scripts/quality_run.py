@@ -13,9 +13,8 @@ import time
 
 path = sys.argv[1] if len(sys.argv) > 1 else "fast"
 if path == "framework":
-    for k in ("OPS_AMD_PINN_LAYER_BLOCKS", "OPS_AMD_TFD_FAST_ENCODER", "OPS_AMD_SHADOW_LINEAR", "OPS_AMD_FUSED_LOSS", "OPS_AMD_FUSED_PREP",
-              "OPS_AMD_PINN_FUSED_TAILS", "OPS_AMD_FUSED_STENCIL"):
-        os.environ[k] = "0"
+    # (openpystruct_amd/switches.py: the one variable, parsed at import)
+    os.environ["OPS_AMD_SWITCHES"] = "pinn_layer_blocks=0,tfd_fast_encoder=0,shadow_linear=0,fused_loss=0,fused_prep=0,pinn_fused_tails=0,pinn_fused_stencil=0"
 os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402

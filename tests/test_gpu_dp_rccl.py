@@ -35,10 +35,10 @@ def _launch(args, env_extra, timeout=600):
 def test_training_through_the_data_parallel_branch_on_one_rank_of_rccl():
     if not torch.cuda.is_available():
         pytest.fail("no GPU visible")
-    # (OPS_AMD_PINN_NORM_FOLD=0: the plain PINN run takes its clip norm from the norm launch like the data-parallel run does behind the
+    # (switch pinn_norm_fold = 0: the plain PINN run takes its clip norm from the norm launch like the data-parallel run does behind the
     #  all-reduce -- not from the weight-gradient launch's partial sums, the same sum in another order -- so that "a one-rank all-reduce
     #  is the identity" can be asserted bit for bit)
-    out, err = _launch([os.path.join("tests", "dp_one_rank_worker.py")], {"OPS_AMD_PINN_NORM_FOLD": "0"})
+    out, err = _launch([os.path.join("tests", "dp_one_rank_worker.py")], {"OPS_AMD_SWITCHES": "pinn_norm_fold=0"})
     line = [l for l in out.splitlines() if l.startswith("DP_ONE_RANK ")][-1]
     r = json.loads(line[len("DP_ONE_RANK "):])
     assert r["backend"] == "nccl" and r["world"] == 1 and r["allreduce_identity"]

@@ -49,7 +49,8 @@ def test_framework_differentiated_tfd_runs_stay_finite_with_eager_steps_between_
     epoch's tail batch and validation pass run EAGERLY between graph replays -> NaNs in the attention's bias gradients in 6-9 of 12
     runs (gpurun_out -> profiles/r04_nan_hunt.log).  Cause: captured memset nodes (see above), not the step.  Five framework runs."""
     from openpystruct_amd import dataprep, sizing, tfd_fused, train
-    monkeypatch.setenv("OPS_AMD_TAIL_GRAPH", "0")
+    from openpystruct_amd import switches
+    monkeypatch.setitem(switches._values, "tail_graph", "0")
     assert train._EXPLICIT_ROOT
     rec = sizing.generate_dataset(6000, sizing.SizingConfig(max_e=60), "cuda")
     d = dataprep.prepare(rec, kind="tfd", device="cuda")

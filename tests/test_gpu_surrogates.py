@@ -249,7 +249,8 @@ def _pinn_three_ways(monkeypatch, d, cfg, seed, epochs):
     for mode in ("blocks", "tails", "framework"):
         monkeypatch.setattr(pinn_fused, "ENABLED", mode == "blocks")
         monkeypatch.setattr(S, "_FUSED_TAILS", mode != "framework")
-        monkeypatch.setenv("OPS_AMD_FUSED_PREP", "0" if mode == "framework" else "1")
+        from openpystruct_amd import switches
+        monkeypatch.setitem(switches._values, "fused_prep", "0" if mode == "framework" else "1")
         out = train.train_surrogate("pinn", d, cfg, device="cuda", max_epochs=epochs, seed=seed, batch_order=batch_order)
         hist[mode] = out["history"]
         assert all(np.isfinite(hist[mode]["train"])) and all(np.isfinite(hist[mode]["val"]))

@@ -693,7 +693,7 @@ def test_tfd_training_paths_agree_epoch_for_epoch_without_randomness(monkeypatch
 def test_front_end_assembling_its_own_batch_reproduces_the_assembly_launch(monkeypatch, tfd_data):
     """r04: the front-end launch gathers rows order[cursor ..] of the training set, adds the assembly's input noise (same stream: seed, step
     counter, element index) and advances counter and cursor itself; the head's loss reads its targets through the gathered rows -- against
-    the same run with the batch assembly as a launch of its own per step (OPS_AMD_TFD_FRONT_GATHER=0's path).  Same draws everywhere, so
+    the same run with the batch assembly as a launch of its own per step (switch tfd_front_gather = 0's path).  Same draws everywhere, so
     the loss histories agree to the order of the float atomics that accumulate the gradients (dropout and noise ON: any slip in a counter
     or an index would change every mask)."""
     from openpystruct_amd import tfd_fused, train
@@ -718,7 +718,7 @@ def test_front_end_assembling_its_own_batch_reproduces_the_assembly_launch(monke
 
 def test_validation_as_one_forward_gives_the_per_batch_validation_loss(monkeypatch, tfd_data):
     """r04: the fast path's validation pass = one forward over all validation rows + the loss per reference batch on row slices, against
-    the same run evaluating batch by batch (OPS_AMD_VAL_WHOLE=0).  No randomness (dropout 0, noise 0, alpha_cumprod 1), batch 32 so that
+    the same run evaluating batch by batch (switch val_whole = 0).  No randomness (dropout 0, noise 0, alpha_cumprod 1), batch 32 so that
     the validation set is several batches and a ragged last one, and learning rate 0 so that both runs evaluate the SAME weights (two
     trainings drift apart by the order of their float atomics: up to 1 % after three epochs): rows are independent in evaluation mode and
     each batch's loss is the same arithmetic on the same bf16 predictions -- the validation losses agree to float32 round-off."""
@@ -735,7 +735,8 @@ def test_validation_as_one_forward_gives_the_per_batch_validation_loss(monkeypat
     assert int(tfd_data.X_val.shape[0]) > 2 * 32 and int(tfd_data.X_val.shape[0]) % 32 != 0
     hist = {}
     for whole in ("1", "0"):
-        monkeypatch.setenv("OPS_AMD_VAL_WHOLE", whole)
+        from openpystruct_amd import switches
+        monkeypatch.setitem(switches._values, "val_whole", whole)
         out = train.train_surrogate("tfd", tfd_data, cfg, device="cuda", max_epochs=2, seed=4, batch_order=batch_order,
                                     init_fn=lambda m: m.diffusion._acp.fill_(1.0))
         hist[whole] = out["history"]
