@@ -222,13 +222,14 @@ int ops_physics_loss_bwd(const ops_physics_loss_args* args, void* stream);
  * Per frame: I [B,Ne]; loads [Nn,3] (loads_bstride 0) or [B,Nn,3] (`ops.load(node, Fx, Fy, Mz)`).
  * Outputs: disp [B,Nn,3], forces [B,Ne,6] (global resisting forces = eleResponse 'forces'), V / M [B,Ne] = forces[..,1] /
  * forces[..,2] (FR:151-153), status [B] (non-zero: not positive definite, outputs NaN).
- * The assembled band and, over it, the factor live in a caller-provided device workspace of
- * ops_frame_workspace_bytes(B, n_eq, half_bandwidth) bytes (about (n_eq + 80) * (half_bandwidth + 2) * 8 per frame; the
- * kernels keep the sliding window in registers, one wavefront per frame).  ERR_INVALID_ARG when it is NULL or too small.
+ * The factor lives in a caller-provided device workspace of ops_frame_workspace_bytes(B, n_eq, half_bandwidth) bytes: the assembly plan at its
+ * start, then about (n_eq + 4) * (window width) * 8 per frame (window width: the half bandwidth rounded up to 8 / 12 / 16 / 20 / 24 / 28 / 36 /
+ * 52 / 56; the kernels keep the sliding window in registers).  ERR_INVALID_ARG when it is NULL or too small.
  * Small batches (up to the batch at which the two kernel families meet: 256 .. 4 000 frames by frame size; the reference's one frame per
  * epoch) take the workgroup-per-frame kernels, which keep the band in LDS when it fits: ops_frame_workspace_bytes is then 0 and
  * `workspace` may be NULL -- always size the workspace with the B of the call.
- * half_bandwidth <= 55: the tuned path; 56..63: the workgroup-per-frame kernels; 64..1024 (more than 20 bays and stories: beyond
+ * half_bandwidth <= 27 (95 of the 100 (bays, stories) draws of FR:17-18): 16 or 32 lanes per frame, 4 or 2 frames per wavefront, persistent waves;
+ * 28..55: a wavefront per frame; 56..63: the workgroup-per-frame kernels; 64..1024 (more than 20 bays and stories: beyond
  * the reference's range): a plain column-by-column fallback on the band in the workspace, milliseconds per frame;
  * ERR_UNSUPPORTED beyond that or when one right-hand side and one column do not fit 160 KB of LDS. */
 int ops_frame_solve_batched_f64(int B, int n_nodes, int n_elems, int n_eq, int half_bandwidth,
