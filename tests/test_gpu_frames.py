@@ -729,3 +729,26 @@ def test_half_bandwidth_beyond_the_fallback_is_refused_cleanly():
     ok = frames.frame_solve(frames.grid_frame(2, 2), torch.full((2, 10), 5e-4, dtype=torch.float64, device="cuda"))
     torch.cuda.synchronize()
     assert int(ok.status.abs().sum()) == 0 and bool(torch.isfinite(ok.disp).all())
+
+
+@pytest.mark.parametrize("bays,stories,family", [(60, 3, 2), (300, 3, 1)])
+def test_long_narrow_frames_take_the_fallbacks_of_the_packed_kernel(bays, stories, family):
+    """Half bandwidth 11 with hundreds to thousands of equations: (60, 3) still fits the packed kernel's LDS but not with its inertias staged there
+    (363 elements x 16 frames per workgroup: gathered from HBM instead, frame_pack.hpp `stage_I`); (300, 3) -- 2 709 equations -- does not fit
+    sixteen frames' solution vectors at all and takes the wave-per-frame kernel at its narrowest window (36).  Both against the oracle."""
+    from openpystruct_amd import _cabi, frames
+    topo = frames.grid_frame(bays, stories)
+    assert topo.kd == 11
+    B = 7
+    assert int(_cabi.load().ops_frame_plan_signature(B, topo.n_eq, topo.kd)) >> 24 == family
+    rng = np.random.default_rng(bays)
+    I = np.exp(rng.uniform(np.log(5e-5), np.log(5e-3), size=(B, topo.Ne)))
+    I[3, 2] = -1.0
+    sol = frames.frame_solve(topo, torch.as_tensor(I, device="cuda"))
+    st = sol.status.cpu().numpy()
+    assert st[3] != 0 and st[[0, 1, 2, 4, 5, 6]].sum() == 0
+    for b in (0, 2, 4, 6):
+        d, f, s_, neq, _ = _oracle(topo, I[b])
+        assert s_ == 0 and neq == topo.n_eq
+        assert relerr(sol.disp[b].cpu().numpy().ravel(), d.ravel()) < 1e-7, b
+        assert relerr(sol.forces[b].cpu().numpy().ravel(), f.ravel()) < 1e-6, b
