@@ -32,13 +32,17 @@
 
 namespace opsamd {
 
-// dispatch: lanes per frame, rows per entering group, register window width (multiples of four, > kd).  KG = (kd / G + 1) G rows are in
+// dispatch: lanes per frame, rows per entering group, register window width (even, > kd).  KG = (kd / G + 1) G rows are in
 // flight below the entering group: KG + G <= P.
 __host__ __device__ inline bool fp_config(int kd, int* P, int* G, int* W) {
-  if (kd <= 7) { *P = 16; *G = 4; *W = 8; return true; }
+  // window widths: kd + 1 rounded up to even for the half bandwidths of grid frames (kd = 3 m + 2: 5, 8, 11, 14, 17, 20, 23, 26); any other
+  // band takes the next wider one.  r06 first version: multiples of four (8, 12, 16, 20, 24, 28): two to four dead multiply-adds per step
+  if (kd <= 5) { *P = 16; *G = 4; *W = 6; return true; }
+  if (kd <= 9) { *P = 16; *G = 4; *W = 10; return true; }
   if (kd <= 11) { *P = 16; *G = 4; *W = 12; return true; }
   if (kd <= 15) { *P = 32; *G = 8; *W = 16; return true; }
-  if (kd <= 19) { *P = 32; *G = 8; *W = 20; return true; }
+  if (kd <= 17) { *P = 32; *G = 8; *W = 18; return true; }
+  if (kd <= 21) { *P = 32; *G = 8; *W = 22; return true; }
   if (kd <= 23) { *P = 32; *G = 8; *W = 24; return true; }
   if (kd <= 27) { *P = 32; *G = 4; *W = 28; return true; }
 #ifdef FP_WITH_P64     // (r06, measured: this kernel at 64 lanes per frame -- correct on every size, 10 x 10 0.91 x, 12 x 12 1.09 x, 15 x 16 0.98 x of
@@ -92,15 +96,18 @@ __device__ __forceinline__ void fp_step(FpState<W>& st, int j, int r, int kdl, i
                                         unsigned loff, double& rd, double& zp, double& a1, double& a2, int& bad) {
   const int rel = (r - j) & (P - 1);
   const int below = n - 1 - j > 0 ? n - 1 - j : 0;            // rows below the diagonal that exist (uniform)
-  const int lim = kdl < below ? kdl : below, lim1 = kdl + 1 < below ? kdl + 1 : below;
+  const int lim = kdl < below ? kdl : below;
   const bool inwin = (unsigned)(rel - 1) < (unsigned)(lim > 0 ? lim : 0);          // 1 <= rel <= min(kd, n - 1 - j)
-  const bool in1 = (unsigned)(rel - 1) < (unsigned)(lim1 > 0 ? lim1 : 0);          // row in column j + 1's line (rel = 1: the pivot d_(j+1))
   st.y = __builtin_fma(-st.lp, zp, st.y);                     // column j - 1's part of the forward substitution
   const double a = st.reg[S], rdj = rd;
   const double l = inwin ? a * rdj : 0.0;
   st.lp = l;
   st.reg[(S + 1) % W] = __builtin_fma(-l, a1, st.reg[(S + 1) % W]);      // column j + 1 is final: its line leaves now
-  line[((S + 1) & 1) * P + rel] = rel == 0 ? st.y : (in1 ? st.reg[(S + 1) % W] : 0.0);
+  // Line of column j + 1: the lane of row j its right-hand side, every other lane its row's entry of column j + 1 -- UNMASKED.  Entries from
+  // outside the band are finite leftovers (a row ahead of the window may hold a later column in that slot); they only ever multiply (i) a zero
+  // multiplier (lanes outside the window: l = 0) or (ii) into slots (column j + t, t > kd) that are dead for every window row (above its diagonal
+  // or already eliminated).  A row past the last equation contributes zeros (unit-diagonal / zero rows of the plan).
+  line[((S + 1) & 1) * P + rel] = rel == 0 ? st.y : st.reg[(S + 1) % W];
 #ifndef FP_SKIP_LSTORE                                       // (phase ablation builds: wrong answers, scripts/frame_pack_ablation.sh)
   (Lw + (size_t)j * W)[loff + (unsigned)(inwin ? rel - 1 : W - 1)] = l;  // column j of L: one coalesced store per lane group
 #endif
@@ -232,7 +239,7 @@ template <int W, int P, int G>
 __device__ __forceinline__ void frame_pack_body(const FrameParams& p, double* __restrict__ Lw, unsigned loff, double* __restrict__ lds, int r, long b,
                                                 bool live, const FwPlan& pl, bool stage_I) {
   constexpr int EPG = fp_epg(G), KE = EPG / P, PITCH = W + 2;
-  static_assert(EPG % P == 0 && W % 4 == 0 && (P & (P - 1)) == 0, "frame_pack: sizes");
+  static_assert(EPG % P == 0 && W % 2 == 0 && (P & (P - 1)) == 0, "frame_pack: sizes");
   const int n = p.n_eq, kd = p.kd;
   const int nl = live ? n : 0, kdl = live ? kd : -1;        // a lane group past the end of the batch: nothing is in its window
   const double* Lc = Lw + loff;                             // this frame's columns of L
@@ -332,17 +339,22 @@ __device__ __forceinline__ void frame_pack_body(const FrameParams& p, double* __
 #ifndef FP_NO_BOUNDARY
 #define FP_NO_BOUNDARY 0
 #endif
+    // W-fold unrolled (the register index of column j is j mod W), guarded per TWO steps (W even: j0 and every boundary -- a multiple of G --
+    // are even, so boundaries fall on even S): a step past the last equation is a no-op
 #define FP_STEP(S_)                                                                   \
     {                                                                                 \
       const int j = j0 + (S_);                                                        \
-      if constexpr (!FP_NO_BOUNDARY && (S_) % 4 == 0) if (j > 0 && (j % G) == 0 && j < n) boundary(j);   \
+      if constexpr (!FP_NO_BOUNDARY && (S_) % 2 == 0) if (j > 0 && (j % G) == 0 && j < n) boundary(j);   \
       fp_step<W, P, (S_)>(st, j, r, kdl, n, line, Lw, loff, rd, zp, a1, a2, bad);     \
     }
 #define FP_STEP4(S_)                                                                  \
     if constexpr ((S_) < W) {                                                         \
-      if (j0 + (S_) < n) { FP_STEP(S_) FP_STEP(S_ + 1) FP_STEP(S_ + 2) FP_STEP(S_ + 3) } \
+      if (j0 + (S_) < n) { FP_STEP(S_) FP_STEP(S_ + 1) }                              \
+    }                                                                                 \
+    if constexpr ((S_) + 2 < W) {                                                     \
+      if (j0 + (S_) + 2 < n) { FP_STEP(S_ + 2) FP_STEP(S_ + 3) }                      \
     }
-    static_assert(W <= 56, "frame_pack: window widths up to 56");
+    static_assert(W <= 56 && W % 2 == 0, "frame_pack: even window widths up to 56");
     FP_STEP4(0) FP_STEP4(4) FP_STEP4(8) FP_STEP4(12) FP_STEP4(16) FP_STEP4(20) FP_STEP4(24) FP_STEP4(28) FP_STEP4(32) FP_STEP4(36) FP_STEP4(40)
     FP_STEP4(44) FP_STEP4(48) FP_STEP4(52)
 #undef FP_STEP4
@@ -360,7 +372,7 @@ __device__ __forceinline__ void frame_pack_body(const FrameParams& p, double* __
 
 // waves per SIMD the register allocator is asked to make room for: the wave is latency-bound (LDS round trips of the line, reciprocal chain)
 #ifndef FP_WAVES
-#define FP_WAVES(W) ((W) <= 8 ? 4 : (W) <= 28 ? 3 : 2)
+#define FP_WAVES(W) ((W) <= 10 ? 4 : (W) <= 28 ? 3 : 2)
 #endif
 template <int W, int P, int G>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FP_WAVES(W))))

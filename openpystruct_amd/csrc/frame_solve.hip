@@ -837,10 +837,12 @@ extern "C" int ops_frame_solve_batched_f64_ex(int B, int n_nodes, int n_elems, i
     if (!workspace || workspace_bytes < need || n_elems > ne_bound(n_eq)) return OPS_AMD_ERR_INVALID_ARG;
     hipError_t e = hipSuccess;
     switch (W) {
-      case 8: e = launch_pack<8, 16, 4>(p, (double*)workspace, s, reuse_plan); break;
+      case 6: e = launch_pack<6, 16, 4>(p, (double*)workspace, s, reuse_plan); break;
+      case 10: e = launch_pack<10, 16, 4>(p, (double*)workspace, s, reuse_plan); break;
       case 12: e = launch_pack<12, 16, 4>(p, (double*)workspace, s, reuse_plan); break;
       case 16: e = launch_pack<16, 32, 8>(p, (double*)workspace, s, reuse_plan); break;
-      case 20: e = launch_pack<20, 32, 8>(p, (double*)workspace, s, reuse_plan); break;
+      case 18: e = launch_pack<18, 32, 8>(p, (double*)workspace, s, reuse_plan); break;
+      case 22: e = launch_pack<22, 32, 8>(p, (double*)workspace, s, reuse_plan); break;
       case 24: e = launch_pack<24, 32, 8>(p, (double*)workspace, s, reuse_plan); break;
       default: e = launch_pack<28, 32, 4>(p, (double*)workspace, s, reuse_plan); break;
     }

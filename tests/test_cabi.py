@@ -63,7 +63,7 @@ def test_argument_validation_without_gpu(lib):
     # large batches keep the factor in the caller's workspace: one column-major L per frame (window width 36 / 52 for these bands) + the plan;
     # a frame whose band does not fit LDS needs the workspace at any batch (15 x 16: band + rhs per frame)
     assert lib.ops_frame_workspace_bytes(5000, 330, 35) >= 5000 * 330 * 36 * 8 and lib.ops_frame_workspace_bytes(3, 768, 50) >= 3 * 768 * 53 * 8
-    assert lib.ops_frame_workspace_bytes(40000, 90, 17) >= 40000 * 90 * 20 * 8      # packed kernel (half bandwidth <= 27): window width 20
+    assert lib.ops_frame_workspace_bytes(40000, 90, 17) >= 40000 * 90 * 18 * 8      # packed kernel (half bandwidth <= 27): window width 18
     assert lib.ops_frame_plan_signature(40000, 90, 17) >> 24 == 2 and lib.ops_frame_plan_signature(5000, 330, 35) >> 24 == 1 and lib.ops_frame_plan_signature(3, 330, 35) == 0
     assert lib.ops_amd_get_option(b"frame_pack") == 1 and lib.ops_amd_get_option(b"frame_latency_batch") == -1 and lib.ops_amd_get_option(b"nope") == -2
     assert lib.ops_amd_set_option(b"nope", 1) == _cabi.ERR_INVALID_ARG

@@ -593,8 +593,8 @@ def test_small_batches_take_a_workgroup_per_frame_and_large_ones_a_wave():
 
 
 # ---- r06: several frames per wavefront (csrc/frame_pack.hpp) ----
-_PACK_SHAPES = [(1, 1, 5, 8), (10, 1, 5, 8), (1, 10, 8, 12), (2, 2, 8, 12), (3, 3, 11, 12), (21, 3, 11, 12), (4, 4, 14, 16), (9, 4, 14, 16),
-                (5, 5, 17, 20), (10, 6, 20, 24), (7, 7, 23, 24), (8, 8, 26, 28), (10, 8, 26, 28)]
+_PACK_SHAPES = [(1, 1, 5, 6), (10, 1, 5, 6), (1, 10, 8, 10), (2, 2, 8, 10), (3, 3, 11, 12), (21, 3, 11, 12), (4, 4, 14, 16), (9, 4, 14, 16),
+                (5, 5, 17, 18), (10, 6, 20, 22), (7, 7, 23, 24), (8, 8, 26, 28), (10, 8, 26, 28)]
 
 
 @pytest.mark.parametrize("bays,stories,kd,W", _PACK_SHAPES)
