@@ -319,7 +319,12 @@ const char* ops_amd_last_error(void);
  * thread-safe, effective from the next call.  Unknown name: ERR_INVALID_ARG / -2.
  *   "frame_latency_batch"  -1 (default): batches of up to 256 .. 4 000 frames (by frame size) take the workgroup-per-frame kernels, which answer
  *                          a handful of frames sooner; N >= 0: that threshold is N (0: the tuned kernels for every batch)
- *   "frame_pack"           1 (default): half bandwidths up to 27 take 16 or 32 lanes per frame; 0: one wave per frame for every band (A/B) */
+ *   "frame_pack"           1 (default): half bandwidths up to 27 take 16 or 32 lanes per frame; 0: one wave per frame for every band (A/B)
+ *   "deterministic"        0 (default); 1: the Transformer-Diffusion step's gradient launches reduce in a fixed order -- one row split per weight-
+ *                          gradient product and one workgroup per column-sum strip (ops_linear_wgrad_accumulate*), one workgroup for the [CLS]
+ *                          sums (ops_tfd_front_bwd), the head's LayerNorm sums in workgroup order (ops_tfd_head_bwd) -- so that two runs of one
+ *                          seed give the same bits (float atomics otherwise land in arrival order); slower.  Takes effect at launch: a captured
+ *                          graph keeps the mode it was captured in.  (The PINN step and the FE kernels have no float atomics.) */
 int ops_amd_set_option(const char* name, long value);
 long ops_amd_get_option(const char* name);
 

@@ -588,12 +588,23 @@ static const size_t LDS_MAX = 160 * 1024 - 64;
 // ---- library options (ops_amd_set_option: the one place a caller -- tests, A/B scripts -- steers the dispatch; no environment variable is read) ----
 static std::atomic<long> g_frame_latency_batch{-1};      // "frame_latency_batch": -1 = the model below; 0 = tuned kernels for every batch
 static std::atomic<long> g_frame_pack{1};                // "frame_pack": 0 = one wave per frame for every half bandwidth (A/B)
+static std::atomic<int> g_deterministic{0};              // "deterministic": 1 = fixed-order reductions in the Transformer-Diffusion step's gradient launches
+namespace opsamd {
+int deterministic_mode() { return g_deterministic.load(std::memory_order_relaxed); }
+void reset_head_ticket();              // seq_layer.hip
+}
 
 extern "C" int ops_amd_set_option(const char* name, long value) {
   if (!name) return OPS_AMD_ERR_INVALID_ARG;
   const std::string_view n(name);
   if (n == "frame_latency_batch") { g_frame_latency_batch.store(value < 0 ? -1 : value); return OPS_AMD_OK; }
   if (n == "frame_pack") { g_frame_pack.store(value != 0); return OPS_AMD_OK; }
+  if (n == "deterministic") {
+    g_deterministic.store(value != 0);
+    int ndev = 0;
+    if (value != 0 && hipGetDeviceCount(&ndev) == hipSuccess && ndev > 0) opsamd::reset_head_ticket();      // (current device; no GPU: nothing to re-arm)
+    return OPS_AMD_OK;
+  }
   return OPS_AMD_ERR_INVALID_ARG;
 }
 extern "C" long ops_amd_get_option(const char* name) {
@@ -601,6 +612,7 @@ extern "C" long ops_amd_get_option(const char* name) {
   const std::string_view n(name);
   if (n == "frame_latency_batch") return g_frame_latency_batch.load();
   if (n == "frame_pack") return g_frame_pack.load();
+  if (n == "deterministic") return g_deterministic.load();
   return -2;
 }
 

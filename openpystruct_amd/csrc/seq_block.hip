@@ -431,6 +431,7 @@ __global__ __launch_bounds__(256) void act_dropout_bwd_kernel(long n, const uint
 }
 
 void set_last_error(const char* msg);
+int deterministic_mode();              // frame_solve.hip: library option "deterministic" (ops_amd_set_option)
 
 }  // namespace opsamd
 
@@ -594,22 +595,24 @@ __device__ __forceinline__ uint2 wg_tr_read(const uint16_t* p) {      // EXEC mu
 #ifndef OPS_WG_SPLIT_ROWS
 #define OPS_WG_SPLIT_ROWS 1024
 #endif
-__host__ __device__ inline int wg_rows_per_wave(int T) {
-  const int nsplit = (T + OPS_WG_SPLIT_ROWS - 1) / OPS_WG_SPLIT_ROWS;
+// det (library option "deterministic"): ONE split -- a tile of dW has exactly one contributing workgroup, so the float atomics that add it
+// into the (zeroed) gradient cannot reorder anything; slower (a workgroup walks all T rows), bit-reproducible
+__host__ __device__ inline int wg_rows_per_wave(int T, int det = 0) {
+  const int nsplit = det ? 1 : (T + OPS_WG_SPLIT_ROWS - 1) / OPS_WG_SPLIT_ROWS;
   const int per_wg = (T + nsplit - 1) / nsplit;
   return (((per_wg + 3) / 4) + WG_SLAB - 1) / WG_SLAB * WG_SLAB;
 }
-__host__ __device__ inline int wg_row_splits(int T) { const int rw = wg_rows_per_wave(T); return (T + 4 * rw - 1) / (4 * rw); }
+__host__ __device__ inline int wg_row_splits(int T, int det = 0) { const int rw = wg_rows_per_wave(T, det); return (T + 4 * rw - 1) / (4 * rw); }
 
 __device__ __forceinline__ void wgrad_tn_body(int T, int N, int K, const uint16_t* __restrict__ dY, const uint16_t* __restrict__ X,
-                                              float* __restrict__ dW, float* __restrict__ dbias, int bx, int by, int bz, int ldy = 0, int ldx = 0) {
+                                              float* __restrict__ dW, float* __restrict__ dbias, int bx, int by, int bz, int ldy = 0, int ldx = 0, int det = 0) {
   ldy = ldy > 0 ? ldy : N; ldx = ldx > 0 ? ldx : K;                    // row strides (elements) of dY / X: a strided row view needs no copy
   // [wave][operand][32 rows x pitch]: 48 KB; reused by the cross-wave reduction: [owner wave][source rank 0..2][tile 0..3][lane][4 floats]
   __shared__ __attribute__((aligned(16))) uint16_t s_slab[4 * 2 * WG_SLAB * WG_P];
   __shared__ float s_cs[4][64];                                        // bias job: per-wave column sums
   static_assert(4 * 2 * WG_SLAB * WG_P * 2 == 4 * 3 * 4 * 64 * 16, "the reduction reuses the slab area exactly");
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int rw = wg_rows_per_wave(T);
+  const int rw = wg_rows_per_wave(T, det);
   const int n0 = bx * 64, k0 = by * 64, t0 = (bz * 4 + wave) * rw, t1 = min(t0 + rw, T);      // this WAVE's rows (possibly none)
   uint16_t* const sa = s_slab + (size_t)wave * 2 * WG_SLAB * WG_P;
   uint16_t* const sb = sa + WG_SLAB * WG_P;
@@ -723,13 +726,13 @@ __device__ __forceinline__ void wgrad_tn_body(int T, int N, int K, const uint16_
 }
 
 __global__ __launch_bounds__(256) void wgrad_tn_kernel(int T, int N, int K, const uint16_t* __restrict__ dY, const uint16_t* __restrict__ X,
-                                                        float* __restrict__ dW, float* __restrict__ dbias) {
-  wgrad_tn_body(T, N, K, dY, X, dW, dbias, blockIdx.x, blockIdx.y, blockIdx.z);
+                                                        float* __restrict__ dW, float* __restrict__ dbias, int det) {
+  wgrad_tn_body(T, N, K, dY, X, dW, dbias, blockIdx.x, blockIdx.y, blockIdx.z, 0, 0, det);
 }
 
 // several products in one launch (all weight gradients of a backward pass, once every dY exists): workgroup -> (problem, tile, rows)
 struct WgGroup {
-  int nprob;
+  int nprob, det;                      // det: library option "deterministic" (one row split per product, one workgroup per column-sum strip)
   int wg0[OPS_WGRAD_MAX_GROUP + 1];
   ops_wgrad_problem p[OPS_WGRAD_MAX_GROUP];
   // XCD-aware placement (r04): a UNIT = the tiles of one product over one row split (they read the same rows of dY and X) or one
@@ -744,16 +747,26 @@ struct WgGroup {
 // K = 0 job: out[c] += sum over the T rows of the float32 matrix M [T, N]; one workgroup per 64 columns x CS_ROWS rows: every thread has
 // its 8 loads in flight at once (one workgroup per 64 columns walking all rows: 56 dependent trips, the launch's long pole at 41 us)
 constexpr int CS_ROWS = 32;
-__device__ __forceinline__ void colsum_body(int T, int N, const float* __restrict__ M, int ld, float* __restrict__ out, int id) {
+__device__ __forceinline__ void colsum_body(int T, int N, const float* __restrict__ M, int ld, float* __restrict__ out, int id, int det) {
   __shared__ float s_p[4][64];
   const int nb = (N + 63) / 64, bx = id % nb, by = id / nb;
   const int tid = threadIdx.x, c = bx * 64 + (tid & 63), stripe = tid >> 6, r0 = by * CS_ROWS;
-  float v[CS_ROWS / 4];
-#pragma unroll
-  for (int k = 0; k < CS_ROWS / 4; ++k) { const int r = r0 + stripe + 4 * k; v[k] = (c < N && r < T) ? M[(long)r * ld + c] : 0.0f; }
   float acc = 0.0f;
+  if (det) {                           // one workgroup per 64 columns walks ALL rows in a fixed order (one contribution per column: nothing to reorder)
+    for (int rb = 0; rb < T; rb += CS_ROWS) {
+      float v[CS_ROWS / 4];
 #pragma unroll
-  for (int k = 0; k < CS_ROWS / 4; ++k) acc += v[k];
+      for (int k = 0; k < CS_ROWS / 4; ++k) { const int r = rb + stripe + 4 * k; v[k] = (c < N && r < T) ? M[(long)r * ld + c] : 0.0f; }
+#pragma unroll
+      for (int k = 0; k < CS_ROWS / 4; ++k) acc += v[k];
+    }
+  } else {
+    float v[CS_ROWS / 4];
+#pragma unroll
+    for (int k = 0; k < CS_ROWS / 4; ++k) { const int r = r0 + stripe + 4 * k; v[k] = (c < N && r < T) ? M[(long)r * ld + c] : 0.0f; }
+#pragma unroll
+    for (int k = 0; k < CS_ROWS / 4; ++k) acc += v[k];
+  }
   s_p[stripe][tid & 63] = acc;
   __syncthreads();
   if (tid < 64 && c < N) unsafeAtomicAdd(&out[c], (s_p[0][tid] + s_p[1][tid]) + (s_p[2][tid] + s_p[3][tid]));
@@ -776,20 +789,21 @@ __global__ __launch_bounds__(256) void wgrad_tn_group_kernel(const WgGroup g) {
   }
   const ops_wgrad_problem pr = g.p[pi];
   if (pr.K == 0) {                                                     // workgroup-uniform
-    colsum_body(pr.T, pr.N, (const float*)pr.dY, pr.ldy > 0 ? pr.ldy : pr.N, pr.dW, id);
+    colsum_body(pr.T, pr.N, (const float*)pr.dY, pr.ldy > 0 ? pr.ldy : pr.N, pr.dW, id, g.det);
     return;
   }
   const int tn = (pr.N + 63) / 64, tk = (pr.K + 63) / 64;
   if (bz < 0) { bz = id / (tn * tk); id -= bz * tn * tk; }
-  wgrad_tn_body(pr.T, pr.N, pr.K, (const uint16_t*)pr.dY, (const uint16_t*)pr.X, pr.dW, pr.dbias, id % tn, id / tn, bz, pr.ldy, pr.ldx);
+  wgrad_tn_body(pr.T, pr.N, pr.K, (const uint16_t*)pr.dY, (const uint16_t*)pr.X, pr.dW, pr.dbias, id % tn, id / tn, bz, pr.ldy, pr.ldx, g.det);
 }
 
 }  // namespace opsamd
 
 extern "C" int ops_linear_wgrad_accumulate(int T, int N, int K, const void* dY, const void* X, float* dW, float* dbias, void* stream) {
   if (T < 1 || N < 1 || K < 1 || !dY || !X || !dW) return OPS_AMD_ERR_INVALID_ARG;
-  const dim3 grid((unsigned)((N + 63) / 64), (unsigned)((K + 63) / 64), (unsigned)opsamd::wg_row_splits(T));
-  hipLaunchKernelGGL(opsamd::wgrad_tn_kernel, grid, dim3(256), 0, (hipStream_t)stream, T, N, K, (const uint16_t*)dY, (const uint16_t*)X, dW, dbias);
+  const int det = opsamd::deterministic_mode();
+  const dim3 grid((unsigned)((N + 63) / 64), (unsigned)((K + 63) / 64), (unsigned)opsamd::wg_row_splits(T, det));
+  hipLaunchKernelGGL(opsamd::wgrad_tn_kernel, grid, dim3(256), 0, (hipStream_t)stream, T, N, K, (const uint16_t*)dY, (const uint16_t*)X, dW, dbias, det);
   return sq_check("wgrad_tn_kernel");
 }
 
@@ -797,6 +811,7 @@ extern "C" int ops_linear_wgrad_accumulate_group(int nprob, const ops_wgrad_prob
   if (nprob < 1 || nprob > OPS_WGRAD_MAX_GROUP || !problems) return OPS_AMD_ERR_INVALID_ARG;
   opsamd::WgGroup g;
   g.nprob = nprob;
+  g.det = opsamd::deterministic_mode();
   int tot = 0;
   for (int i = 0; i < nprob; ++i) {
     const ops_wgrad_problem& p = problems[i];
@@ -804,13 +819,13 @@ extern "C" int ops_linear_wgrad_accumulate_group(int nprob, const ops_wgrad_prob
       if (p.T < 1 || p.N < 1 || !p.dY || !p.dW || (p.ldy && p.ldy < p.N)) return OPS_AMD_ERR_INVALID_ARG;
       g.p[i] = p;
       g.wg0[i] = tot;
-      tot += ((p.N + 63) / 64) * ((p.T + opsamd::CS_ROWS - 1) / opsamd::CS_ROWS);
+      tot += ((p.N + 63) / 64) * (g.det ? 1 : (p.T + opsamd::CS_ROWS - 1) / opsamd::CS_ROWS);
       continue;
     }
     if (p.T < 1 || p.N < 1 || p.K < 1 || !p.dY || !p.X || !p.dW || (p.ldy && p.ldy < p.N) || (p.ldx && p.ldx < p.K)) return OPS_AMD_ERR_INVALID_ARG;
     g.p[i] = p;
     g.wg0[i] = tot;
-    tot += ((p.N + 63) / 64) * ((p.K + 63) / 64) * opsamd::wg_row_splits(p.T);
+    tot += ((p.N + 63) / 64) * ((p.K + 63) / 64) * opsamd::wg_row_splits(p.T, g.det);
   }
   g.wg0[nprob] = tot;
   // units, heaviest first onto the lightest of the eight shares
@@ -819,7 +834,7 @@ extern "C" int ops_linear_wgrad_accumulate_group(int nprob, const ops_wgrad_prob
   bool fits = true;
   for (int i = 0; i < nprob && fits; ++i) {
     const ops_wgrad_problem& p = problems[i];
-    const int splits = p.K == 0 ? 1 : opsamd::wg_row_splits(p.T);
+    const int splits = p.K == 0 ? 1 : opsamd::wg_row_splits(p.T, g.det);
     const int per = p.K == 0 ? g.wg0[i + 1] - g.wg0[i] : ((p.N + 63) / 64) * ((p.K + 63) / 64);
     for (int z = 0; z < splits; ++z) {
       if (nu >= OPS_WG_MAX_UNITS || z > 255 || per > 60000) { fits = false; break; }

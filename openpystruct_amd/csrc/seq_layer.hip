@@ -32,6 +32,10 @@
 namespace opsamd {
 
 void set_last_error(const char* msg);   // beam_solve.hip
+int deterministic_mode();                // frame_solve.hip: library option "deterministic"
+// deterministic mode: the workgroups of the head's backward launch add their LayerNorm gamma / beta column sums IN WORKGROUP ORDER (a ticket:
+// workgroup i waits for i - 1, which the dispatcher started before it); the last one re-arms the ticket for the next launch
+__device__ unsigned int g_head_ticket = 0u;
 
 typedef __bf16 sl_bf16x8 __attribute__((ext_vector_type(8)));
 typedef float sl_f32x4 __attribute__((ext_vector_type(4)));
@@ -1137,7 +1141,7 @@ __device__ __forceinline__ slhb_args_ptr slhb_late_args() {
   return (slhb_args_ptr)p;
 }
 
-__global__ __launch_bounds__(64 * SL_NW) void tfd_head_bwd_kernel(const ops_tfd_head_bwd_args a) {
+__global__ __launch_bounds__(64 * SL_NW) void tfd_head_bwd_kernel(const ops_tfd_head_bwd_args a, const int det) {
   constexpr int XS = 128 + 8, HS = 256 + 8;
   __shared__ __attribute__((aligned(16))) uint16_t s_g[16 * XS];      // d loss / d out rows (operand), at the end the [CLS] gradient rows
   __shared__ __attribute__((aligned(16))) uint16_t s_h[16 * HS];      // h (its zeros are the ReLU / dropout mask)
@@ -1234,6 +1238,10 @@ __global__ __launch_bounds__(64 * SL_NW) void tfd_head_bwd_kernel(const ops_tfd_
       if (c == 0) { s_red[(4 * g + i) * SL_NW + wave] = p1; s_red[(16 + 4 * g + i) * SL_NW + wave] = p2; }
     }
     // gamma / beta gradients: column sums over the workgroup's rows
+    if (det) {                                            // (workgroup-uniform) wait for this workgroup's turn
+      if (tid == 0) while (__hip_atomic_load(&g_head_ticket, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != blockIdx.x) __builtin_amdgcn_s_sleep(2);
+      __syncthreads();
+    }
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int m = 16 * (wave + SL_NW * j) + c;
@@ -1243,6 +1251,11 @@ __global__ __launch_bounds__(64 * SL_NW) void tfd_head_bwd_kernel(const ops_tfd_
       pg += __shfl_xor(pg, 16, 64); pb += __shfl_xor(pb, 16, 64);
       pg += __shfl_xor(pg, 32, 64); pb += __shfl_xor(pb, 32, 64);
       if (g == 0 && m < hid) { unsafeAtomicAdd(la->dgamma + m, pg); unsafeAtomicAdd(la->dbeta + m, pb); }
+    }
+    if (det) {                                            // every add of this workgroup has landed before the next one starts
+      __threadfence();
+      __syncthreads();
+      if (tid == 0) __hip_atomic_store(&g_head_ticket, blockIdx.x + 1 == gridDim.x ? 0u : blockIdx.x + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
     sl_lds_barrier();
 #pragma unroll
@@ -1440,7 +1453,7 @@ __global__ __launch_bounds__(64 * SL_NW) void tfd_front_fwd_kernel(const ops_tfd
   }
 }
 
-__global__ __launch_bounds__(64 * SL_NW) void tfd_front_bwd_kernel(const ops_tfd_front_bwd_args a) {
+__global__ __launch_bounds__(64 * SL_NW) void tfd_front_bwd_kernel(const ops_tfd_front_bwd_args a, const int det) {
   constexpr int XS = 128 + 8, HS = 256 + 8;
   __shared__ __attribute__((aligned(16))) uint16_t s_dm[16 * XS];     // dm rows (operand, and as stored)
   __shared__ __attribute__((aligned(16))) uint16_t s_h[16 * HS];      // h (ReLU mask), then d_h rows
@@ -1468,7 +1481,7 @@ __global__ __launch_bounds__(64 * SL_NW) void tfd_front_bwd_kernel(const ops_tfd
   // dcls += sum_b g[b, 0, :]: the first 64 workgroups share the B [CLS] rows (one float atomic per column and workgroup: 64 same-address
   // atomics of ~40 ns each; one per sample and column -- the first version -- made this launch 53 us)
   __shared__ float s_cls[4][128];
-  const int ncw = gridDim.x < 64 ? (int)gridDim.x : 64;       // workgroups that share the [CLS] rows
+  const int ncw = det ? 1 : gridDim.x < 64 ? (int)gridDim.x : 64;       // workgroups that share the [CLS] rows (deterministic mode: one, fixed order)
   if (a.dcls && (int)blockIdx.x < ncw) {
     const int cc = tid & 127, part = tid >> 7;
     float acc = 0.0f;
@@ -1631,7 +1644,7 @@ extern "C" int ops_tfd_head_bwd(const ops_tfd_head_bwd_args* a, void* stream) {
   if ((((uintptr_t)a->Wt2 | (uintptr_t)a->Wt1 | (uintptr_t)a->a16 | (uintptr_t)a->h | (uintptr_t)a->d_a | (uintptr_t)a->dcls_rows) & 15) != 0 || ((uintptr_t)a->g & 7) != 0)
     return OPS_AMD_ERR_UNSUPPORTED;
   if (a->loss_part && (!a->alpha || !a->loss)) return OPS_AMD_ERR_INVALID_ARG;
-  hipLaunchKernelGGL(opsamd::tfd_head_bwd_kernel, dim3((unsigned)((a->B + 15) / 16)), dim3(64 * opsamd::SL_NW), 0, (hipStream_t)stream, *a);
+  hipLaunchKernelGGL(opsamd::tfd_head_bwd_kernel, dim3((unsigned)((a->B + 15) / 16)), dim3(64 * opsamd::SL_NW), 0, (hipStream_t)stream, *a, opsamd::deterministic_mode());
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) { opsamd::set_last_error(hipGetErrorString(e)); return OPS_AMD_ERR_LAUNCH; }
   return OPS_AMD_OK;
@@ -1658,8 +1671,17 @@ extern "C" int ops_tfd_front_bwd(const ops_tfd_front_bwd_args* a, void* stream) 
   if ((((uintptr_t)a->g32 | (uintptr_t)a->h | (uintptr_t)a->Wt2 | (uintptr_t)a->dm | (uintptr_t)a->d_h) & 15) != 0 || ((uintptr_t)a->g16 & 7) != 0)
     return OPS_AMD_ERR_UNSUPPORTED;
   const long rows = (long)a->B * a->Nc;
-  hipLaunchKernelGGL(opsamd::tfd_front_bwd_kernel, dim3((unsigned)((rows + 15) / 16)), dim3(64 * opsamd::SL_NW), 0, (hipStream_t)stream, *a);
+  hipLaunchKernelGGL(opsamd::tfd_front_bwd_kernel, dim3((unsigned)((rows + 15) / 16)), dim3(64 * opsamd::SL_NW), 0, (hipStream_t)stream, *a, opsamd::deterministic_mode());
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) { opsamd::set_last_error(hipGetErrorString(e)); return OPS_AMD_ERR_LAUNCH; }
   return OPS_AMD_OK;
 }
+
+// re-arms the ticket of the head's deterministic gradient sums (a launch that faulted half way must not leave later launches waiting): called
+// when the library option "deterministic" is set
+namespace opsamd {
+void reset_head_ticket() {
+  const unsigned int zero = 0u;
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(g_head_ticket), &zero, sizeof(zero));
+}
+}  // namespace opsamd

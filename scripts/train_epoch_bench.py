@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--cases", type=int, default=50000)
     ap.add_argument("--epochs", type=int, default=6)
     ap.add_argument("--gen-epochs", type=int, default=600, help="max_e of the sizing loop used to generate the data")
+    ap.add_argument("--deterministic", action="store_true", help="library option deterministic = 1 (fixed-order reductions in the TFD gradient launches)")
     a = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1")); rank = int(os.environ.get("RANK", "0")); lr = int(os.environ.get("LOCAL_RANK", "0"))
     lr %= max(1, torch.cuda.device_count())
@@ -38,6 +39,9 @@ def main():
         else:
             dist.init_process_group(backend)
     dev = torch.device("cuda", lr)
+    if a.deterministic:
+        from openpystruct_amd import _cabi
+        _cabi.set_option("deterministic", 1)
     t0 = time.perf_counter()
     rec = sizing.generate_dataset(a.cases * world, sizing.SizingConfig(max_e=a.gen_epochs), dev, rank=rank, world=world)
     torch.cuda.synchronize()

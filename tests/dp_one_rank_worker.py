@@ -47,6 +47,17 @@ def main():
             r = train.train_surrogate(kind, d, cfg, device=dev, max_epochs=3, seed=5, log=logs.append)
             runs[name] = {"train": [float(x) for x in r["history"]["train"]], "val": [float(x) for x in r["history"]["val"]],
                           "r2_val_I": float(r["r2_val_I"]), "dp_segments": r.get("dp_segments"), "dp_mode": r.get("dp_mode")}
+        if kind == "tfd":       # r06: library option "deterministic" -- fixed-order reductions, so the one-rank identity is bitwise for this model too
+            from openpystruct_amd import _cabi
+            _cabi.set_option("deterministic", 1)
+            try:
+                for name, v in (("plain_det", dict(force=False)), ("dp_det", dict(force=True, one_graph=default_one_graph))):
+                    train._FORCE_DP, train._DP_ASYNC, train._DP_ONE_GRAPH, train._DP_PROFILE = v["force"], True, v.get("one_graph", False), False
+                    r = train.train_surrogate(kind, d, cfg, device=dev, max_epochs=3, seed=5, log=logs.append)
+                    runs[name] = {"train": [float(x) for x in r["history"]["train"]], "val": [float(x) for x in r["history"]["val"]],
+                                  "r2_val_I": float(r["r2_val_I"]), "dp_segments": r.get("dp_segments"), "dp_mode": r.get("dp_mode")}
+            finally:
+                _cabi.set_option("deterministic", 0)
         out["runs"][kind] = runs
     out["log"] = logs
     dist.barrier(device_ids=[local])

@@ -62,6 +62,11 @@ def test_training_through_the_data_parallel_branch_on_one_rank_of_rccl():
                 # a few nearby trajectories (ten suite runs: differences of 0 or ~1.3e-4 between any two runs, plain or data parallel), so
                 # the statement is a tolerance -- far below what a wrong average / missing all-reduce would show (O(1))
                 assert diff <= max(20 * spread, 2e-3), (kind, name, diff, spread)
+        if kind == "tfd":       # deterministic mode (library option, r06): the one-rank all-reduce is the identity BIT FOR BIT for this model too
+            pd = np.array(runs["plain_det"]["train"] + runs["plain_det"]["val"])
+            dd = np.array(runs["dp_det"]["train"] + runs["dp_det"]["val"])
+            assert np.isfinite(pd).all() and np.array_equal(pd, dd), float(np.abs(pd - dd).max())
+            assert runs["dp_det"]["dp_mode"]["step"] == "one graph incl. the all-reduce"
         assert runs["plain"]["dp_mode"] is None
         # r06: the DEFAULT data-parallel step under nccl is the one-graph form (the collective captured; first replay under the stall timer)
         assert r["default_one_graph"] and runs["dp_default"]["dp_mode"]["step"] == "one graph incl. the all-reduce"

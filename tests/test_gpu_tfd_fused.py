@@ -1151,3 +1151,26 @@ def test_grouped_launch_column_sum_jobs():
     bad = (_cabi.WgradProblem * 1)()
     bad[0].T, bad[0].N, bad[0].K, bad[0].dY, bad[0].dW, bad[0].ldy = 8, 120, 0, part.data_ptr(), outs[0].data_ptr(), 64      # stride < N
     assert lib.ops_linear_wgrad_accumulate_group(1, bad, torch.cuda.current_stream().cuda_stream) == _cabi.ERR_INVALID_ARG
+
+
+def test_deterministic_mode_makes_the_tfd_step_bit_reproducible():
+    """Library option "deterministic" (r06): one row split per weight-gradient product, one workgroup per column-sum strip and for the [CLS] sums,
+    the head's LayerNorm sums in workgroup order -- two runs of one seed then give the SAME BITS (default mode: float atomics land in arrival
+    order and two runs sit on nearby trajectories, ~1e-4 apart), and the same trajectory as the default mode to that spread."""
+    from openpystruct_amd import _cabi, dataprep, sizing, train
+    rec = sizing.generate_dataset(1800, sizing.SizingConfig(max_e=30), "cuda", seed=11)
+    d = dataprep.prepare(rec, kind="tfd", seed=0, device="cuda")
+    cfg = train.TfdConfig(batch_size=64)
+
+    def run():
+        r = train.train_surrogate("tfd", d, cfg, device="cuda", max_epochs=3, seed=5)
+        return np.array([float(x) for x in r["history"]["train"]] + [float(x) for x in r["history"]["val"]])
+    base = run()
+    try:
+        _cabi.set_option("deterministic", 1)
+        assert _cabi.get_option("deterministic") == 1
+        a, b = run(), run()
+    finally:
+        _cabi.set_option("deterministic", 0)
+    assert np.isfinite(a).all() and np.array_equal(a, b), np.abs(a - b).max()
+    assert float(np.abs(a - base).max() / np.abs(base).max()) < 2e-3
