@@ -238,7 +238,13 @@ __device__ __forceinline__ void mb_side_job(const ops_mlp_strip_args& a, int row
   }
 }
 
+// r06: the launch's mode (tail, the block's addition, evaluation statistics) as TEMPLATE parameters for the combinations the PINN step uses --
+// the generic kernel decoded them per wave at run time (450-580 scalar instructions and 27 KB of code per strip launch, profiles/r06_notes.md 9);
+// TAIL_ = -1: the generic form (any valid combination of the C ABI)
+template <int TAIL_, int ADD_, int EVAL_>
 __global__ __launch_bounds__(MB_THREADS) void mlp_strip_kernel(const ops_mlp_strip_args a, const int nstrips) {
+  const int a_tail = TAIL_ >= 0 ? TAIL_ : a.tail, a_add_mode = TAIL_ >= 0 ? ADD_ : a.add_mode;
+  const bool a_eval_stats = TAIL_ >= 0 ? (EVAL_ != 0) : (a.eval_stats != 0);
   __shared__ float s_t[MB_ROWS][MB_COLS + 1];
   __shared__ __attribute__((aligned(16))) uint16_t s_y[MB_ROWS][MB_COLS];
   __shared__ __attribute__((aligned(16))) uint16_t s_z[MB_ROWS][MB_COLS];
@@ -265,10 +271,10 @@ __global__ __launch_bounds__(MB_THREADS) void mlp_strip_kernel(const ops_mlp_str
   float* const s_loss = in_slot(a.loss);
   float* const s_loss_sum = in_slot(a.loss_sum);
   const int B = a.n_slots > 0 ? min(a.B, a.slot_total_rows - (int)blockIdx.y * a.B) : a.B, N = a.N, No = a.No;
-  const bool fwd = a.tail <= OPS_MLP_TAIL_BN || a.tail == OPS_MLP_TAIL_LOSS;
-  const bool has_bn = a.tail == OPS_MLP_TAIL_BN || a.tail == OPS_MLP_TAIL_BN_ACT_DROP || a.tail == OPS_MLP_TAIL_BWD_BN ||
-                      a.tail == OPS_MLP_TAIL_BWD_BN_ACT_DROP;
-  const bool act_bwd = a.tail == OPS_MLP_TAIL_BWD_ACT_DROP || a.tail == OPS_MLP_TAIL_BWD_BN_ACT_DROP;
+  const bool fwd = a_tail <= OPS_MLP_TAIL_BN || a_tail == OPS_MLP_TAIL_LOSS;
+  const bool has_bn = a_tail == OPS_MLP_TAIL_BN || a_tail == OPS_MLP_TAIL_BN_ACT_DROP || a_tail == OPS_MLP_TAIL_BWD_BN ||
+                      a_tail == OPS_MLP_TAIL_BWD_BN_ACT_DROP;
+  const bool act_bwd = a_tail == OPS_MLP_TAIL_BWD_ACT_DROP || a_tail == OPS_MLP_TAIL_BWD_BN_ACT_DROP;
   // epilogue mapping: 32 lanes per column, 4 rows per lane
   const int cl = tid >> 5, q = tid & 31, c = n0 + cl;
   const bool clive = c < N;
@@ -296,8 +302,8 @@ __global__ __launch_bounds__(MB_THREADS) void mlp_strip_kernel(const ops_mlp_str
     const int j = tid + MB_THREADS * rep, slot = j >> 4, gq = j & 15;
     const void* src = nullptr;
     int col = 0, lim = 0;
-    if (slot < 20) { if (a.add_mode != OPS_MLP_ADD_NONE) { src = sOt; col = n0 - 2 + slot; lim = No; } }
-    else if (slot < 38) { if (a.add_mode == OPS_MLP_ADD_BWD_BLOCK) { src = a.dZt; col = n0 - 1 + (slot - 20); lim = No; } }
+    if (slot < 20) { if (a_add_mode != OPS_MLP_ADD_NONE) { src = sOt; col = n0 - 2 + slot; lim = No; } }
+    else if (slot < 38) { if (a_add_mode == OPS_MLP_ADD_BWD_BLOCK) { src = a.dZt; col = n0 - 1 + (slot - 20); lim = No; } }
     else if (slot < 54) { if (has_bn && !fwd) { src = sZt; col = n0 + (slot - 38); lim = N; } }
     else if (slot < 70) { if (act_bwd) { src = a.Yref_t; col = n0 + (slot - 54); lim = N; } }
     chv[rep] = slot < 70;
@@ -306,7 +312,7 @@ __global__ __launch_bounds__(MB_THREADS) void mlp_strip_kernel(const ops_mlp_str
   }
   float pt[4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) pt[i] = (rl[i] && a.tail == OPS_MLP_TAIL_LOSS) ? s_targets_t[(long)c * MB_ROWS + q + 32 * i] : 0.0f;
+  for (int i = 0; i < 4; ++i) pt[i] = (rl[i] && a_tail == OPS_MLP_TAIL_LOSS) ? s_targets_t[(long)c * MB_ROWS + q + 32 * i] : 0.0f;
   // loss of the previous launch (TAIL_LOSS leaves per-strip partial sums): workgroup 0 adds them, one partial row per lane
   double lp[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
   const bool fin = a.loss_finish_rows > 0 && blockIdx.x == 0 && wave == 0;
@@ -315,7 +321,7 @@ __global__ __launch_bounds__(MB_THREADS) void mlp_strip_kernel(const ops_mlp_str
     for (int k = 0; k < 5; ++k) lp[k] = ((const double*)s_loss_ws)[lane * 5 + k];
   // partial sums of the stencil normalisation: lane = row of partials, wave = which sum (workgroup 0 needs all twelve backward)
   double pp0 = 0.0, pp1 = 0.0;
-  if (a.add_mode != OPS_MLP_ADD_NONE) {
+  if (a_add_mode != OPS_MLP_ADD_NONE) {
     const int rows = (No + MB_SIDE_COLS - 1) / MB_SIDE_COLS, NS = fwd ? 2 : MB_NSUM;
     if (lane < rows) {
       if (wave < 2 || (blockIdx.x == 0 && wave < NS)) pp0 = a.spart[lane * NS + wave];
@@ -323,9 +329,9 @@ __global__ __launch_bounds__(MB_THREADS) void mlp_strip_kernel(const ops_mlp_str
     }
   }
   float sc_w0 = 0.0f, sc_w1 = 0.0f, sc_w2 = 0.0f, sc_b = 0.0f, sc_g = 0.0f, sc_be = 0.0f, sv_mean = 0.0f, sv_inv = 1.0f;
-  if (a.add_mode != OPS_MLP_ADD_NONE) {
+  if (a_add_mode != OPS_MLP_ADD_NONE) {
     sc_w0 = a.conv_w[0]; sc_w1 = a.conv_w[1]; sc_w2 = a.conv_w[2]; sc_b = a.conv_b[0]; sc_g = a.sgamma[0]; sc_be = a.sbeta[0];
-    if (a.add_mode == OPS_MLP_ADD_BWD_BLOCK) { sv_mean = a.ssave[0]; sv_inv = a.ssave[1]; }
+    if (a_add_mode == OPS_MLP_ADD_BWD_BLOCK) { sv_mean = a.ssave[0]; sv_inv = a.ssave[1]; }
   }
   const unsigned long long call = (fwd && a.p_drop > 0.0f && a.call_counter) ? *a.call_counter : 0ull;
 
@@ -348,7 +354,7 @@ __global__ __launch_bounds__(MB_THREADS) void mlp_strip_kernel(const ops_mlp_str
 #pragma unroll
     for (int i = 0; i < 4; ++i) s_t[wave * 16 + (lane >> 4) * 4 + i][lane & 15] = acc[i];
   }
-  if (a.add_mode != OPS_MLP_ADD_NONE) {
+  if (a_add_mode != OPS_MLP_ADD_NONE) {
     pp0 = mb_wsum_d(pp0); pp1 = mb_wsum_d(pp1);
     if (lane == 0) { s_tot[wave] = pp0; s_tot[wave + 8] = pp1; }
   }
@@ -384,12 +390,12 @@ __global__ __launch_bounds__(MB_THREADS) void mlp_strip_kernel(const ops_mlp_str
     const float bias_b = mb_round(bias);
 #pragma unroll
     for (int i = 0; i < 4; ++i) v[i] = rl[i] ? mb_round(v[i] + bias_b) : 0.0f;       // the Linear's bf16 output
-    if (a.add_mode == OPS_MLP_ADD_FWD_BLOCK) {
+    if (a_add_mode == OPS_MLP_ADD_FWD_BLOCK) {
       // whole-tensor statistics of conv1(O) from the previous launch's partial sums
       const double n = (double)B * (double)No, m = s_tot[0] / n, var = fmax(s_tot[1] / n - m * m, 0.0);
-      const float mean_s = a.eval_stats ? a.srunning_mean[0] : (float)m;
-      const float inv_s = a.eval_stats ? (float)(1.0 / sqrt((double)a.srunning_var[0] + (double)a.seps)) : (float)(1.0 / sqrt(var + (double)a.seps));
-      if (blockIdx.x == 0 && tid == 0 && !a.eval_stats) {
+      const float mean_s = a_eval_stats ? a.srunning_mean[0] : (float)m;
+      const float inv_s = a_eval_stats ? (float)(1.0 / sqrt((double)a.srunning_var[0] + (double)a.seps)) : (float)(1.0 / sqrt(var + (double)a.seps));
+      if (blockIdx.x == 0 && tid == 0 && !a_eval_stats) {
         a.ssave[0] = mean_s; a.ssave[1] = inv_s;
         a.srunning_mean[0] = (1.0f - a.smomentum) * a.srunning_mean[0] + a.smomentum * (float)m;
         a.srunning_var[0] = (1.0f - a.smomentum) * a.srunning_var[0] + a.smomentum * (float)(var * n / (n > 1.0 ? n - 1.0 : 1.0));
@@ -416,11 +422,11 @@ __global__ __launch_bounds__(MB_THREADS) void mlp_strip_kernel(const ops_mlp_str
       for (int i = 0; i < 4; ++i) { const float d = v[i] - mean; sq += rl[i] ? d * d : 0.0f; }
       float var = mb_hsum(sq) * invB;                         // biased: what normalises
       float rstd = rsqrtf(var + a.eps);
-      if (a.eval_stats) {                                     // model.eval(): the running statistics, read only
+      if (a_eval_stats) {                                     // model.eval(): the running statistics, read only
         mean = clive ? a.running_mean[c] : 0.0f;
         rstd = clive ? rsqrtf(a.running_var[c] + a.eps) : 1.0f;
       }
-      if (clive && q == 0 && !a.eval_stats) {
+      if (clive && q == 0 && !a_eval_stats) {
         a.mean[c] = mean; a.rstd[c] = rstd;
         if (a.running_mean) {                                 // momentum update with the UNBIASED variance
           const float unb = var * ((float)B / (float)(B > 1 ? B - 1 : 1));
@@ -428,14 +434,14 @@ __global__ __launch_bounds__(MB_THREADS) void mlp_strip_kernel(const ops_mlp_str
           a.running_var[c] = (1.0f - a.momentum) * a.running_var[c] + a.momentum * unb;
         }
       }
-      if (blockIdx.x == 0 && tid == 0 && a.num_batches_tracked && !a.eval_stats) a.num_batches_tracked[0] += 1;
+      if (blockIdx.x == 0 && tid == 0 && a.num_batches_tracked && !a_eval_stats) a.num_batches_tracked[0] += 1;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         s_z[q + 32 * i][cl] = mb_f2bf(v[i]);                 // exact: v is a bf16 value; leaves with the results below
         v[i] = rl[i] ? __builtin_fmaf((v[i] - mean) * rstd, g, be) : 0.0f;
       }
     }
-    if (a.tail == OPS_MLP_TAIL_ACT_DROP || a.tail == OPS_MLP_TAIL_BN_ACT_DROP) {
+    if (a_tail == OPS_MLP_TAIL_ACT_DROP || a_tail == OPS_MLP_TAIL_BN_ACT_DROP) {
       const bool drop = a.p_drop > 0.0f;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -447,7 +453,7 @@ __global__ __launch_bounds__(MB_THREADS) void mlp_strip_kernel(const ops_mlp_str
         v[i] = y;
       }
     }
-    if (a.tail == OPS_MLP_TAIL_LOSS) {
+    if (a_tail == OPS_MLP_TAIL_LOSS) {
       // the predictions leave through LDS first, then v becomes d loss / d predictions
       if (sP) {
 #pragma unroll
@@ -494,7 +500,7 @@ __global__ __launch_bounds__(MB_THREADS) void mlp_strip_kernel(const ops_mlp_str
   } else {
 #pragma unroll
     for (int i = 0; i < 4; ++i) v[i] = rl[i] ? mb_round(v[i]) : 0.0f;              // the input gradient's bf16 value
-    if (a.add_mode == OPS_MLP_ADD_BWD_BLOCK) {
+    if (a_add_mode == OPS_MLP_ADD_BWD_BLOCK) {
       // + dZ (identity path) + conv1^T( bn1 backward (dZ) ) (stencil path); the whole-tensor means from the partial sums
       const double n = (double)B * (double)No;
       const float mg = (float)(s_tot[0] / n), mgy = (float)(s_tot[1] / n);
@@ -588,10 +594,10 @@ __global__ __launch_bounds__(MB_THREADS) void mlp_strip_kernel(const ops_mlp_str
   }
   // one increment per launch, by the last STRIP workgroup to finish: the side-job workgroups behind them left without reading the
   // counter and do not report (call_counter.hpp)
-  if (fwd && a.p_drop > 0.0f && (a.tail == OPS_MLP_TAIL_ACT_DROP || a.tail == OPS_MLP_TAIL_BN_ACT_DROP))
+  if (fwd && a.p_drop > 0.0f && (a_tail == OPS_MLP_TAIL_ACT_DROP || a_tail == OPS_MLP_TAIL_BN_ACT_DROP))
     call_counter_done(a.call_counter, (unsigned)nstrips * gridDim.y);
 
-  if (a.tail == OPS_MLP_TAIL_LOSS) {
+  if (a_tail == OPS_MLP_TAIL_LOSS) {
     // loss value: per-strip partial sums; workgroup 0 of the NEXT launch (loss_finish_rows) adds them -- no atomics, no fence here
     double accd[5];
 #pragma unroll
@@ -858,7 +864,30 @@ extern "C" int ops_mlp_strip_launch(const ops_mlp_strip_args* args, void* stream
   }
   const dim3 grid((unsigned)(nstrips + nside), (unsigned)(a.n_slots > 0 ? a.n_slots : 1)), block(MB_THREADS);
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(mlp_strip_kernel, grid, block, 0, s, a, nstrips);
+  // the combinations of the PINN step (pinn_fused.py _build) are compiled with their mode folded in; anything else takes the generic kernel
+  const int key = a.tail * 100 + a.add_mode * 10 + (a.eval_stats ? 1 : 0);
+#ifdef OPS_MLP_GENERIC_ONLY
+  const int use_key = -1;
+#else
+  const int use_key = key;
+#endif
+#define MB_LAUNCH(T_, A_, E_) hipLaunchKernelGGL((mlp_strip_kernel<T_, A_, E_>), grid, block, 0, s, a, nstrips)
+  switch (use_key) {
+    case OPS_MLP_TAIL_BN_ACT_DROP * 100 + 0: MB_LAUNCH(OPS_MLP_TAIL_BN_ACT_DROP, OPS_MLP_ADD_NONE, 0); break;
+    case OPS_MLP_TAIL_ACT_DROP * 100 + 0: MB_LAUNCH(OPS_MLP_TAIL_ACT_DROP, OPS_MLP_ADD_NONE, 0); break;
+    case OPS_MLP_TAIL_BN * 100 + OPS_MLP_ADD_FWD_BLOCK * 10 + 0: MB_LAUNCH(OPS_MLP_TAIL_BN, OPS_MLP_ADD_FWD_BLOCK, 0); break;
+    case OPS_MLP_TAIL_LOSS * 100 + 0: MB_LAUNCH(OPS_MLP_TAIL_LOSS, OPS_MLP_ADD_NONE, 0); break;
+    case OPS_MLP_TAIL_BWD_BN * 100 + 0: MB_LAUNCH(OPS_MLP_TAIL_BWD_BN, OPS_MLP_ADD_NONE, 0); break;
+    case OPS_MLP_TAIL_BWD_ACT_DROP * 100 + 0: MB_LAUNCH(OPS_MLP_TAIL_BWD_ACT_DROP, OPS_MLP_ADD_NONE, 0); break;
+    case OPS_MLP_TAIL_BWD_BN * 100 + OPS_MLP_ADD_BWD_BLOCK * 10 + 0: MB_LAUNCH(OPS_MLP_TAIL_BWD_BN, OPS_MLP_ADD_BWD_BLOCK, 0); break;
+    case OPS_MLP_TAIL_BWD_BN_ACT_DROP * 100 + OPS_MLP_ADD_BWD_BLOCK * 10 + 0: MB_LAUNCH(OPS_MLP_TAIL_BWD_BN_ACT_DROP, OPS_MLP_ADD_BWD_BLOCK, 0); break;
+    case OPS_MLP_TAIL_BN_ACT_DROP * 100 + 1: MB_LAUNCH(OPS_MLP_TAIL_BN_ACT_DROP, OPS_MLP_ADD_NONE, 1); break;
+    case OPS_MLP_TAIL_ACT_DROP * 100 + 1: MB_LAUNCH(OPS_MLP_TAIL_ACT_DROP, OPS_MLP_ADD_NONE, 1); break;
+    case OPS_MLP_TAIL_BN * 100 + OPS_MLP_ADD_FWD_BLOCK * 10 + 1: MB_LAUNCH(OPS_MLP_TAIL_BN, OPS_MLP_ADD_FWD_BLOCK, 1); break;
+    case OPS_MLP_TAIL_LOSS * 100 + 1: MB_LAUNCH(OPS_MLP_TAIL_LOSS, OPS_MLP_ADD_NONE, 1); break;
+    default: MB_LAUNCH(-1, 0, 0); break;
+  }
+#undef MB_LAUNCH
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) { set_last_error(hipGetErrorString(e)); return OPS_AMD_ERR_LAUNCH; }
   return OPS_AMD_OK;
