@@ -8,7 +8,10 @@ backward, clip_grad_norm_(1.0), Adam step; then a validation pass, ExponentialLR
 the validation loss with best-state checkpointing; finally R^2 of the un-standardised inertias.
 
 What is different, and why (DESIGN.md "Training loops"):
-  * bf16 autocast without a GradScaler instead of fp16 + GradScaler (BASELINE config 4; MI355X bf16 MFMA);
+  * bf16 autocast without a GradScaler instead of fp16 + GradScaler (BASELINE config 4; MI355X bf16 MFMA) by default; the reference's own
+    mode -- `autocast(float16)` + `GradScaler` (PINN:706, :759-768) -- is `train_surrogate(..., autocast_dtype=torch.float16)` (r06): framework
+    modules under fp16 autocast, loss scaling with the GradScaler's rule (skip the step and halve the scale on a non-finite gradient, double it
+    after 2 000 clean steps), eager steps (the scale and the skip decision change from step to step);
   * the dataset is resident on the GPU: no per-batch host-to-device copies (PINN:749-750) and no per-step
     `.item()` (PINN:770) -- losses are accumulated on the device and reduced once per epoch;
   * data parallelism by hand instead of the DistributedDataParallel wrapper: every parameter's .grad is a
@@ -606,15 +609,36 @@ def _allreduce_mean(t: torch.Tensor, world: int, dp: Optional[bool] = None) -> t
     return t
 
 
-def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, autocast_dtype=torch.bfloat16,
-                    sync_bn: bool = False, max_epochs: Optional[int] = None, log=None, seed: int = 0,
-                    use_graph: Optional[bool] = None, physics: Optional[PhysicsTerm] = None,
-                    init_fn=None, batch_order=None) -> Dict[str, object]:
+def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, autocast_dtype=torch.bfloat16, **kw) -> Dict[str, object]:
+    """`_train_surrogate` (below: every argument is documented there).  With `autocast_dtype=torch.float16` -- the reference's own AMP mode,
+    fp16 autocast + GradScaler (PINN:706, :759-768; TFD:690, :744-753) -- the run takes the framework's modules throughout (the hand-written
+    launches are bf16): the module-level switches of the fused pieces are off for its duration."""
+    if autocast_dtype != torch.float16:
+        return _train_surrogate(kind, data, cfg, device, autocast_dtype=autocast_dtype, **kw)
+    from . import surrogates as _s
+    g = globals()
+    saved = (_s._FUSED_TAILS, _s._FUSED_STENCIL, g["_FUSED_LOSS"], switches.get("fused_prep"), switches.get("fused_physics"))
+    try:
+        _s._FUSED_TAILS = _s._FUSED_STENCIL = False
+        g["_FUSED_LOSS"] = False
+        switches.set("fused_prep", 0); switches.set("fused_physics", 0)
+        return _train_surrogate(kind, data, cfg, device, autocast_dtype=autocast_dtype, **kw)
+    finally:
+        _s._FUSED_TAILS, _s._FUSED_STENCIL, g["_FUSED_LOSS"] = saved[:3]
+        switches.set("fused_prep", saved[3]); switches.set("fused_physics", saved[4])
+
+
+def _train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, autocast_dtype=torch.bfloat16,
+                     sync_bn: bool = False, max_epochs: Optional[int] = None, log=None, seed: int = 0,
+                     use_graph: Optional[bool] = None, physics: Optional[PhysicsTerm] = None,
+                     init_fn=None, batch_order=None) -> Dict[str, object]:
     """Trains on THIS rank's `data` shard; uses DDP when torch.distributed is initialised with world_size > 1.
     Returns history, best state dict, validation R^2 (I only) and per-epoch times.
     `init_fn(model)`: called once on the freshly built model (load a checkpoint, deterministic test weights).
     `batch_order(epoch) -> LongTensor[n_train]`: the epoch's sample order instead of a random permutation (the
-    reference's DataLoader shuffle, PINN:701, is unseeded; the golden-fixture tests replay the order it drew)."""
+    reference's DataLoader shuffle, PINN:701, is unseeded; the golden-fixture tests replay the order it drew).
+    `autocast_dtype=torch.float16`: the reference's AMP mode (fp16 autocast + GradScaler, PINN:706, :759-768) on the framework modules; the
+    returned dict then carries `grad_scaler` = {"scale", "skipped_steps", "steps"}."""
     cfg = cfg or {"pinn": PinnConfig, "tfd": TfdConfig, "fnn": FnnConfig, "gnn": GnnConfig, "fno": FnoConfig}[kind]()
     alpha_term = kind in ("tfd", "fnn", "fno")          # (initial_alpha - alpha)^2 in the training loss (TFD:743, FNO:615)
     if kind == "fno":
@@ -650,6 +674,10 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
         model.direct_param_grads = device.type == "cuda"
     torch.manual_seed(seed + 1 + rank)  # different noise / shuffles per rank
     on_gpu = device.type == "cuda"
+    # the reference's AMP mode: GradScaler(init_scale 65536, growth 2, backoff 0.5, growth interval 2000) -- torch.cuda.amp.GradScaler's defaults
+    fp16_scaler = {"scale": 65536.0, "good": 0, "skipped": 0, "steps": 0} if (on_gpu and autocast_dtype == torch.float16) else None
+    if fp16_scaler is not None:
+        use_graph = False                # the scale and the skip decision are per-step host state, like `scaler.step` / `scaler.update`
     if use_graph is None:
         use_graph = on_gpu and os.environ.get("OPS_AMD_GRAPH", "1") == "1"    # the step is launch-bound (~150 tiny kernels): replay it as HIP graphs
     # under graph replay the learning rate must live in a device tensor, or the scheduler's updates would
@@ -829,7 +857,9 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
             # explicit one "produced" NaNs in bias gradients of framework-path runs; the NaNs were the HIP runtime's captured-memset
             # defect under the framework's own bias-gradient reductions -- runtime.py item 2 -- and the root gradient only moved the
             # memory layout that decided which garbage their semaphores saw)
-            if _EXPLICIT_ROOT:
+            if fp16_scaler is not None:          # scaler.scale(loss).backward() (PINN:761): the root gradient IS the scale
+                loss.backward(gradient=torch.full((), fp16_scaler["scale"], dtype=loss.dtype, device=device))
+            elif _EXPLICIT_ROOT:
                 loss.backward(gradient=_root_ones(device))
             else:
                 loss.backward()
@@ -846,6 +876,20 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
 
     def apply_update():
         """Segment B: average over ranks, clip, Adam."""
+        if fp16_scaler is not None:
+            # scaler.unscale_ + clip + scaler.step + scaler.update (PINN:763-768): a non-finite gradient skips the step and halves the scale,
+            # 2 000 clean steps in a row double it; the unscaling rides in the update launch's gradient scale
+            sc = fp16_scaler
+            sc["steps"] += 1
+            if bool(torch.isfinite(flat).all()):
+                opt.step(grad_scale=1.0 / (world * sc["scale"]))
+                sc["good"] += 1
+                if sc["good"] >= 2000:
+                    sc["scale"] *= 2.0; sc["good"] = 0
+            else:
+                flat.zero_()
+                sc["scale"] *= 0.5; sc["good"] = 0; sc["skipped"] += 1
+            return
         if on_gpu:
             opt.step(grad_scale=1.0 / world)                             # average, clip (PINN:766), Adam
             return
@@ -1336,6 +1380,8 @@ def train_surrogate(kind: str, data: SurrogateData, cfg=None, device="cuda", *, 
     #  set in loader order, inertias un-standardised and clipped to [0, 1e10], r2_score on the raveled arrays)
     out = {"model": model, "history": hist, "best_val": best_val, "best_state": best_state, "r2_val_I": r2_score(t, p),
            "val_pred_I": p, "val_true_I": t, "epochs": len(hist["train"]), "steps_per_epoch": nb_tr}
+    if fp16_scaler is not None:
+        out["grad_scaler"] = {"scale": fp16_scaler["scale"], "skipped_steps": fp16_scaler["skipped"], "steps": fp16_scaler["steps"]}
     if dp:
         out["dp_mode"] = {"world": world, "forced_one_rank": bool(world == 1), "backend": dist.get_backend(), "async": bool(_DP_ASYNC),
                           "step": ("one graph incl. the all-reduce" if graph_mode_one else "graph A | all-reduce | graph B" if step_was_captured

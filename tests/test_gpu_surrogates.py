@@ -434,3 +434,27 @@ def test_gather_rows_noise_gathers_the_targets_in_the_same_launch():
                                                  Y.data_ptr(), 100, outy.data_ptr(), torch.cuda.current_stream().cuda_stream) == 0
     torch.cuda.synchronize()
     assert torch.equal(out, X[idx]) and torch.equal(outy, Y[idx]) and int(cnt[0]) == 1
+
+
+@pytest.mark.parametrize("kind", ["pinn", "tfd"])
+def test_reference_amp_mode_fp16_autocast_with_grad_scaler(kind):
+    """The reference's own mixed-precision mode (fp16 autocast + GradScaler: PINN:706, :759-768; TFD:690, :744-753) as
+    `train_surrogate(..., autocast_dtype=torch.float16)`: framework modules, loss scaling with the GradScaler's rule, eager steps.  Trains like the
+    default bf16 path on the same data and seed (losses within 15 %), every step is either applied or skipped-and-backed-off, the scale stays a
+    power of two, and the module-level switches it turned off are back afterwards."""
+    from openpystruct_amd import dataprep, sizing, surrogates, switches, train
+    rec = sizing.generate_dataset(2400, sizing.SizingConfig(max_e=40), "cuda", seed=3)
+    d = dataprep.prepare(rec, kind=kind, seed=0, device="cuda")
+    cfg = {"pinn": train.PinnConfig, "tfd": train.TfdConfig}[kind](batch_size=64)
+    before = (surrogates._FUSED_TAILS, surrogates._FUSED_STENCIL, train._FUSED_LOSS, switches.get("fused_prep"))
+    ref = train.train_surrogate(kind, d, cfg, device="cuda", max_epochs=4, seed=9)
+    amp = train.train_surrogate(kind, d, cfg, device="cuda", max_epochs=4, seed=9, autocast_dtype=torch.float16)
+    assert (surrogates._FUSED_TAILS, surrogates._FUSED_STENCIL, train._FUSED_LOSS, switches.get("fused_prep")) == before
+    gs = amp["grad_scaler"]
+    assert gs["steps"] == 4 * amp["steps_per_epoch"] and 0 <= gs["skipped_steps"] <= 8
+    assert gs["scale"] > 0 and float(np.log2(gs["scale"])).is_integer() and gs["scale"] == 65536.0 * 0.5 ** gs["skipped_steps"]
+    a, r = np.array(amp["history"]["train"]), np.array(ref["history"]["train"])
+    assert np.isfinite(a).all() and np.isfinite(np.array(amp["history"]["val"])).all()
+    assert a[-1] < a[0]                                                   # it learns
+    assert abs(a[-1] - r[-1]) / r[-1] < 0.15, (a, r)
+    assert "grad_scaler" not in ref
