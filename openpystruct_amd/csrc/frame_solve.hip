@@ -669,7 +669,7 @@ static int ne_bound(int n_eq) { return 4 * n_eq + 64; }
 static size_t plan_region_bytes(int n_eq, int G, int EPG) { return (fw_plan_bytes(n_eq, ne_bound(n_eq), G, EPG) + 255) & ~(size_t)255; }
 
 enum FrameFamily { FAM_WIDE, FAM_LEGACY, FAM_WAVE, FAM_PACK };
-// kd <= 27 (95 of the 100 (bays, stories) draws of FR:17-18): frame_pack.hpp, 16 or 32 lanes per frame; 28..55: frame_wave.hpp, a wave per
+// kd <= 27 (94 of the 100 (bays, stories) draws of FR:17-18): frame_pack.hpp, 16 or 32 lanes per frame; 28..55: frame_wave.hpp, a wave per
 // frame; small batches and 56..63: the workgroup-per-frame kernels; beyond: the column-by-column fallback
 static FrameFamily frame_family(int B, int n_eq, int kd) {
   if (kd > 63) return FAM_WIDE;

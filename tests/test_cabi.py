@@ -132,3 +132,39 @@ def test_torch_library_op_is_registered_gpu_only():
     with pytest.raises(NotImplementedError):            # no CPU kernel behind the operator
         op(torch.zeros(3, dtype=torch.float64), torch.ones((), dtype=torch.float64), torch.ones(1, 2, dtype=torch.float64),
            torch.zeros(3, dtype=torch.uint8), torch.zeros(1, 3, dtype=torch.float64), torch.zeros((), dtype=torch.float64))
+
+
+def test_frame_dispatch_table_on_the_host():
+    """r06: which kernel family and register-window width a frame of the reference's random range takes (FR:17-18: bays, stories ~ U{1..10}; half
+    bandwidth 3 m + 2 along the short side m = min(stories, bays + 1)), the workspace the call asks for, and the plan signature a caller keeps its
+    plan by -- all host-side functions of the library (no GPU call)."""
+    from openpystruct_amd import _cabi
+    lib = _cabi.load()
+    B = 20000
+    packed = 0
+    for bays in range(1, 11):
+        for stories in range(1, 11):
+            m = min(stories, bays + 1)
+            kd, n_eq = 3 * m + 2, 3 * stories * (bays + 1)
+            sig = int(lib.ops_frame_plan_signature(B, n_eq, kd))
+            fam, W, G, P = sig >> 24, (sig >> 16) & 0xFF, (sig >> 8) & 0xFF, sig & 0xFF
+            if kd <= 27:
+                packed += 1
+                assert fam == 2 and W == (kd + 2) // 2 * 2 and P == (16 if kd <= 11 else 32) and G == (4 if (P == 16 or kd > 23) else 8), (bays, stories, sig)
+                assert (kd // G + 1) * G + G <= P                      # the rows in flight below an entering group fit the lane group
+                assert int(lib.ops_frame_workspace_bytes(B, n_eq, kd)) >= B * (n_eq + 3) * W * 8
+            else:
+                assert fam == 1 and W == 36 and P == 64, (bays, stories, sig)
+                assert int(lib.ops_frame_workspace_bytes(B, n_eq, kd)) >= B * (n_eq + 4) * W * 8
+    assert packed == 94                                               # 94 of the 100 draws
+    # beyond the tuned kernels: 56..63 the workgroup kernels (no plan), 64..1024 the column-by-column fallback, both with the band in the workspace
+    assert lib.ops_frame_plan_signature(B, 2000, 59) == 0 and lib.ops_frame_plan_signature(B, 2000, 300) == 0
+    assert lib.ops_frame_workspace_bytes(B, 2000, 300) >= B * 2000 * 301 * 8
+    # small batches: no plan; the option moves the threshold (and is put back)
+    assert lib.ops_frame_plan_signature(64, 90, 17) == 0
+    try:
+        assert lib.ops_amd_set_option(b"frame_latency_batch", 0) == _cabi.OK and lib.ops_frame_plan_signature(64, 90, 17) >> 24 == 2
+        assert lib.ops_amd_set_option(b"frame_pack", 0) == _cabi.OK and lib.ops_frame_plan_signature(64, 90, 17) >> 24 == 1
+    finally:
+        lib.ops_amd_set_option(b"frame_latency_batch", -1); lib.ops_amd_set_option(b"frame_pack", 1)
+    assert lib.ops_amd_get_option(b"deterministic") == 0

@@ -599,7 +599,7 @@ _PACK_SHAPES = [(1, 1, 5, 6), (10, 1, 5, 6), (1, 10, 8, 10), (2, 2, 8, 10), (3, 
 
 @pytest.mark.parametrize("bays,stories,kd,W", _PACK_SHAPES)
 def test_packed_frames_vs_oracle_and_isolation(bays, stories, kd, W):
-    """Half bandwidths up to 27 (95 of the 100 (bays, stories) draws of FR:17-18): 16 or 32 lanes per frame, 4 or 2 frames per wave -- every
+    """Half bandwidths up to 27 (94 of the 100 (bays, stories) draws of FR:17-18): 16 or 32 lanes per frame, 4 or 2 frames per wave -- every
     compiled (window width, lanes, group size) against the oracle, with a frame that is not positive definite and a frame with a NaN load in the
     SAME waves as healthy ones (nothing may cross between the lane groups of a wave), a batch that does not fill its last wave, and against one
     wave per frame (library option frame_pack = 0: same arithmetic, so the displacements agree to the order of the assembly's LDS additions)."""
