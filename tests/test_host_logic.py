@@ -318,3 +318,29 @@ def test_configure_makes_no_hip_call():
     body = "\n".join(ln.split("#")[0] for ln in inspect.getsource(runtime.configure).split('"""')[2].splitlines())     # code: no docstring, no comments
     assert "is_available(" not in body and "device_count(" not in body and "hip_runtime_version(query_runtime=False)" in body
     assert runtime.hip_runtime_version(query_runtime=False) == str(torch.version.hip)
+
+
+def test_switch_registry():
+    """r06: the A/B switches of the fused training pieces are entries of ONE registry (openpystruct_amd/switches.py), not ~50 environment variables:
+    unknown names raise, `set` returns the previous value, OPS_AMD_SWITCHES is parsed at import (checked in a child process)."""
+    import subprocess
+    import sys
+    from openpystruct_amd import switches
+    assert switches.get("fused_prep") == "1" and switches.on("tfd_front") and switches.get("split_wgrad_rows") == "16"
+    old = switches.set("fused_prep", 0)
+    try:
+        assert old == "1" and switches.get("fused_prep") == "0" and switches.snapshot() == {"fused_prep": "0"}
+    finally:
+        switches.set("fused_prep", old)
+    assert switches.snapshot() == {}
+    with pytest.raises(KeyError):
+        switches.get("fused_perp")
+    with pytest.raises(KeyError):
+        switches.set("no_such_switch", 1)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = "from openpystruct_amd import switches; print(sorted(switches.snapshot().items()))"
+    p = subprocess.run([sys.executable, "-c", code], cwd=root, env=dict(os.environ, OPS_AMD_SWITCHES="pinn_norm_fold=0, tfd_head=0;val_whole"),
+                       capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0 and p.stdout.strip() == "[('pinn_norm_fold', '0'), ('tfd_head', '0')]", p.stdout + p.stderr
+    p = subprocess.run([sys.executable, "-c", code], cwd=root, env=dict(os.environ, OPS_AMD_SWITCHES="tpyo=0"), capture_output=True, text=True, timeout=120)
+    assert p.returncode != 0 and "unknown switch" in p.stderr
