@@ -735,6 +735,7 @@ __device__ __forceinline__ uint64_t mb_mix(uint64_t z) {
 // r05: REPACK -- the tiled bf16 weight copies of the PREVIOUS optimiser step are rebuilt by extra workgroups of this launch (four 1 KB
 // tiles each, repack_tiles.hpp): the step's last launch (the copies) and the next step's first (the batch) depend on nothing of each other,
 // so they are one launch -- one kernel boundary and the copies' 5 us (shorter than the assembly's 8) off every step.
+constexpr int MB_RSPLIT = 4, MB_GROWS = MB_ROWS / MB_RSPLIT;      // row groups of the batch assembly (32 rows each)
 template <bool REPACK>
 __global__ __launch_bounds__(256) void mlp_gather_noise_kernel(int B, int F, const float* __restrict__ X, const long long* __restrict__ idx,
                                                                 const float* __restrict__ sigma, unsigned long long seed,
@@ -748,39 +749,42 @@ __global__ __launch_bounds__(256) void mlp_gather_noise_kernel(int B, int F, con
       return;
     }
   }
-  __shared__ __attribute__((aligned(16))) uint16_t s_tile[32][MB_ROWS + 8];     // [feature][row]
-  __shared__ float s_tt[32][MB_ROWS + 1];
-  const int fl = threadIdx.x & 31;
-  // 16 rows per thread: all row indices first, then all 16 gathers -- two exposed latencies, not thirty-two
-  long src[16];
-  float xv[16];
+  // r06: a workgroup assembles 32 features (or 32 target columns) x 32 ROWS -- a quarter of the 128-row batch (MB_GROWS), four rows per thread:
+  // the launch is one round of waves whose length is a thread's chain (indices -> rows -> noise -> stores), and sixteen rows per thread made
+  // that chain the longest thing in the step's first launch (8.2 us for the assembly alone against 5.2 for the weight copies riding with it)
+  __shared__ __attribute__((aligned(16))) uint16_t s_tile[32][MB_GROWS + 8];     // [feature][row of the group]
+  __shared__ float s_tt[32][MB_GROWS + 1];
+  const int fl = threadIdx.x & 31, wq = threadIdx.x >> 5;
+  const int tile = (int)blockIdx.x / MB_RSPLIT, rg = (int)blockIdx.x % MB_RSPLIT, b0 = rg * MB_GROWS;
+  long src[4];
+  float xv[4];
 #pragma unroll
-  for (int j = 0; j < 16; ++j) {
-    const int b = (threadIdx.x >> 5) + 8 * j;
+  for (int j = 0; j < 4; ++j) {
+    const int b = b0 + wq + 8 * j;
     src[j] = b < B ? (long)idx[b] : -1;
   }
-  if ((int)blockIdx.x >= nfb) {
+  if (tile >= nfb) {
     // targets: yout_t [C, 128] float32 (transposed: the loss tail reads a column's rows contiguously), rows >= B zero
-    const int c0 = ((int)blockIdx.x - nfb) * 32, c = c0 + fl;
+    const int c0 = (tile - nfb) * 32, c = c0 + fl;
 #pragma unroll
-    for (int j = 0; j < 16; ++j) xv[j] = (src[j] >= 0 && c < C) ? Ysrc[src[j] * (long)C + c] : 0.0f;
+    for (int j = 0; j < 4; ++j) xv[j] = (src[j] >= 0 && c < C) ? Ysrc[src[j] * (long)C + c] : 0.0f;
 #pragma unroll
-    for (int j = 0; j < 16; ++j) s_tt[fl][(threadIdx.x >> 5) + 8 * j] = xv[j];
+    for (int j = 0; j < 4; ++j) s_tt[fl][wq + 8 * j] = xv[j];
     __syncthreads();
-    for (int e = threadIdx.x; e < 32 * MB_ROWS; e += 256) {
-      const int cc = e / MB_ROWS, b = e % MB_ROWS;
-      if (c0 + cc < C) yout_t[(long)(c0 + cc) * MB_ROWS + b] = s_tt[cc][b];
+    for (int e = threadIdx.x; e < 32 * MB_GROWS; e += 256) {
+      const int cc = e / MB_GROWS, b = e % MB_GROWS;
+      if (c0 + cc < C) yout_t[(long)(c0 + cc) * MB_ROWS + b0 + b] = s_tt[cc][b];
     }
     return;
   }
-  const int f0 = blockIdx.x * 32, f = f0 + fl;
+  const int f0 = tile * 32, f = f0 + fl;
   const float sg = sigma ? *sigma : 0.0f;
   const unsigned long long call = counter ? *counter : 0ull;
 #pragma unroll
-  for (int j = 0; j < 16; ++j) xv[j] = (src[j] >= 0 && f < F) ? X[src[j] * (long)F + f] : 0.0f;
+  for (int j = 0; j < 4; ++j) xv[j] = (src[j] >= 0 && f < F) ? X[src[j] * (long)F + f] : 0.0f;
 #pragma unroll
-  for (int j = 0; j < 16; ++j) {
-    const int b = (threadIdx.x >> 5) + 8 * j;
+  for (int j = 0; j < 4; ++j) {
+    const int bl = wq + 8 * j, b = b0 + bl;
     uint16_t h = 0;
     if (b < B && f < F) {
       float v = xv[j];
@@ -792,26 +796,24 @@ __global__ __launch_bounds__(256) void mlp_gather_noise_kernel(int B, int F, con
       }
       h = mb_f2bf(v);
     }
-    s_tile[fl][b] = h;
+    s_tile[fl][bl] = h;
   }
   __syncthreads();
-  // both tiled copies in 16-byte chunks: 512 chunks (row, 8 features) of x and 512 chunks (feature, 8 rows) of x^T, two each per thread
-#pragma unroll
-  for (int rep = 0; rep < 2; ++rep) {
-    const int u = threadIdx.x + 256 * rep;
-    {
-      const int b = u >> 2, fg = u & 3;                       // row b, features f0 + 8 fg ..
+  // both tiled copies in 16-byte chunks: 128 chunks (row, 8 features) of x and 128 chunks (feature, 8 rows) of x^T, one per thread
+  {
+    const int u = threadIdx.x & 127;
+    if (threadIdx.x < 128) {
+      const int bl = u >> 2, fg = u & 3;                      // row b0 + bl, features f0 + 8 fg ..
       uint16_t t8[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) t8[j] = s_tile[8 * fg + j][b];
-      *(uint4*)(out + mb_toff(b, f0 + 8 * fg, ld >> 5)) = *(const uint4*)t8;
-    }
-    {
-      const int ff = u & 31, bg = u >> 5;                     // feature f0 + ff, rows 8 bg ..
-      *(uint4*)(out_t + mb_toff(f0 + ff, 8 * bg, MB_ROWS / 32)) = *(const uint4*)&s_tile[ff][8 * bg];
+      for (int j = 0; j < 8; ++j) t8[j] = s_tile[8 * fg + j][bl];
+      *(uint4*)(out + mb_toff(b0 + bl, f0 + 8 * fg, ld >> 5)) = *(const uint4*)t8;
+    } else {
+      const int ff = u & 31, bg = u >> 5;                     // feature f0 + ff, rows b0 + 8 bg ..
+      *(uint4*)(out_t + mb_toff(f0 + ff, b0 + 8 * bg, MB_ROWS / 32)) = *(const uint4*)&s_tile[ff][8 * bg];
     }
   }
-  if (counter) call_counter_done(counter, (unsigned)nfb);   // the target workgroups behind the nfb feature ones left early, unreported
+  if (counter) call_counter_done(counter, (unsigned)(nfb * MB_RSPLIT));   // the target workgroups behind the feature ones left early, unreported
 }
 
 }  // namespace opsamd
@@ -964,15 +966,15 @@ static int gather_launch(int B, int F, const float* X, const long long* idx, con
                          const float* params, const AdamRepack* rp, void* stream) {
   if (B < 1 || B > MB_ROWS || F < 1 || !X || !idx || !out || !out_t || ld % 32 || ld < ru(F, 32)) return OPS_AMD_ERR_INVALID_ARG;
   if (Y && (C < 1 || !targets_t)) return OPS_AMD_ERR_INVALID_ARG;
-  const int nfb = (F + 31) / 32, ntb = Y ? (C + 31) / 32 : 0;
+  const int nfb = (F + 31) / 32, ntb = Y ? (C + 31) / 32 : 0, ngb = (nfb + ntb) * MB_RSPLIT;      // assembly workgroups: (tile, row group)
   if (rp) {
     const TileJobs tj = make_tile_jobs(*rp);
     const int nrb = (tj.first[2 * rp->nmat] + 3) / 4;
-    hipLaunchKernelGGL(mlp_gather_noise_kernel<true>, dim3((unsigned)(nfb + ntb + nrb)), dim3(256), 0, (hipStream_t)stream, B, F, X, idx, sigma,
-                       seed, counter, (uint16_t*)out, ld, (uint16_t*)out_t, nfb, Y, C, targets_t, nfb + ntb, params, *rp, tj);
+    hipLaunchKernelGGL(mlp_gather_noise_kernel<true>, dim3((unsigned)(ngb + nrb)), dim3(256), 0, (hipStream_t)stream, B, F, X, idx, sigma,
+                       seed, counter, (uint16_t*)out, ld, (uint16_t*)out_t, nfb, Y, C, targets_t, ngb, params, *rp, tj);
   } else {
-    hipLaunchKernelGGL(mlp_gather_noise_kernel<false>, dim3((unsigned)(nfb + ntb)), dim3(256), 0, (hipStream_t)stream, B, F, X, idx, sigma, seed,
-                       counter, (uint16_t*)out, ld, (uint16_t*)out_t, nfb, Y, C, targets_t, nfb + ntb, nullptr, AdamRepack{}, TileJobs{});
+    hipLaunchKernelGGL(mlp_gather_noise_kernel<false>, dim3((unsigned)ngb), dim3(256), 0, (hipStream_t)stream, B, F, X, idx, sigma, seed,
+                       counter, (uint16_t*)out, ld, (uint16_t*)out_t, nfb, Y, C, targets_t, ngb, nullptr, AdamRepack{}, TileJobs{});
   }
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) { set_last_error(hipGetErrorString(e)); return OPS_AMD_ERR_LAUNCH; }
