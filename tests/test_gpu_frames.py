@@ -752,3 +752,45 @@ def test_long_narrow_frames_take_the_fallbacks_of_the_packed_kernel(bays, storie
         assert s_ == 0 and neq == topo.n_eq
         assert relerr(sol.disp[b].cpu().numpy().ravel(), d.ravel()) < 1e-7, b
         assert relerr(sol.forces[b].cpu().numpy().ravel(), f.ravel()) < 1e-6, b
+
+
+def test_every_draw_of_the_reference_range_at_a_batch_the_tuned_kernels_serve():
+    """FR:17-18, 50-52: bays, stories ~ U{1..10} -- all 100 frames of that range, each as a batch of 300 frames (beyond the library's small-batch
+    threshold wherever that threshold is 256, forced for the others by the option this file sets: every shape goes to the packed or the
+    wave-per-frame kernel), two frames of each batch against the oracle, plus the batch's own consistency: frames 0 and 299 carry the same inertias
+    and must answer bit for bit alike whichever wave and lane group they land in.  The worst deviations per kernel family go to gpurun_out/."""
+    import json
+    import os
+    from openpystruct_amd import _cabi, frames
+    lib = _cabi.load()
+    worst = {}
+    fams = {1: "wave", 2: "packed"}
+    B = 300
+    for bays in range(1, 11):
+        for stories in range(1, 11):
+            topo = frames.grid_frame(bays, stories)
+            sig = int(lib.ops_frame_plan_signature(B, topo.n_eq, topo.kd))
+            fam = fams[sig >> 24]
+            assert fam == ("packed" if topo.kd <= 27 else "wave"), (bays, stories, topo.kd)
+            rng = np.random.default_rng(1000 * bays + stories)
+            I = np.exp(rng.uniform(np.log(5e-5), np.log(5e-3), size=(B, topo.Ne)))
+            I[B - 1] = I[0]
+            sol = frames.frame_solve(topo, torch.as_tensor(I, device="cuda"))
+            torch.cuda.synchronize()
+            assert int(sol.status.abs().sum()) == 0, (bays, stories)
+            assert torch.equal(sol.disp[0], sol.disp[B - 1]) and torch.equal(sol.forces[0], sol.forces[B - 1]), (bays, stories)
+            for b in (0, 157):
+                d, f, st, neq, _ = _oracle(topo, I[b])
+                assert st == 0 and neq == topo.n_eq
+                ed = relerr(sol.disp[b].cpu().numpy().ravel(), d.ravel())
+                ef = relerr(sol.forces[b].cpu().numpy().ravel(), f.ravel())
+                assert ed < 1e-8 and ef < 1e-7, (bays, stories, b, ed, ef)
+                w = worst.setdefault(fam, {"shapes": 0, "disp": 0.0, "forces": 0.0, "at": None})
+                if ed > w["disp"]:
+                    w["disp"], w["at"] = ed, [bays, stories]
+                w["forces"] = max(w["forces"], ef)
+            worst[fam]["shapes"] += 1
+    assert worst["packed"]["shapes"] == 94 and worst["wave"]["shapes"] == 6
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/frames_full_range.json", "w") as fh:
+        json.dump(worst, fh, indent=1)
