@@ -777,6 +777,13 @@ def main():
         guard.daemon = True
         if is_dp(world):
             guard.start()
+            from openpystruct_amd import train as _train
+
+            def stalled(what):           # the library's own stall timer (first replay of the one-graph step, exit 17): the FE line goes out first
+                if rank == 0:
+                    rec["surrogate_epochs"] = {"error": f"{what} stalled; OPS_AMD_DP_ONE_GRAPH=0 selects the two-graph step"}
+                    print(json.dumps(rec), flush=True)
+            _train.stall_hook = stalled
         info = surrogate_epoch_times(dev, rank, world, n_train)
         guard.cancel()
         if rank == 0:

@@ -524,6 +524,9 @@ _DP_ONE_GRAPH = os.environ.get("OPS_AMD_DP_ONE_GRAPH", "1") == "1"
 _DP_STALL_S = float(os.environ.get("OPS_AMD_DP_STALL_S", "120"))
 
 
+stall_hook = None     # callable(what) run by a firing _StallGuard just before the process ends
+
+
 class _StallGuard:
     """`with _StallGuard(seconds, what):` -- if the block has not finished after `seconds`, the process ends with exit code 17 and a line on
     stderr saying what stalled (a hung graph replay of a captured collective cannot be recovered inside the process)."""
@@ -532,6 +535,11 @@ class _StallGuard:
         self.seconds, self.what, self.timer = seconds, what, None
 
     def _fire(self):
+        if stall_hook is not None:       # the caller's last words (bench.py: the FE record measured before the training part)
+            try:
+                stall_hook(self.what)
+            except Exception:
+                pass
         sys.stderr.write(f"openpystruct_amd: {self.what} did not finish within {self.seconds:.0f} s -- ending this rank (exit 17); "
                          f"run again with OPS_AMD_DP_ONE_GRAPH=0 for the two-graph step\n")
         sys.stderr.flush()

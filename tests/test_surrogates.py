@@ -325,6 +325,11 @@ def test_stall_guard_ends_the_process_with_its_own_exit_code():
             "with _StallGuard(0.3, 'a test block'):\n    time.sleep(20)\n")
     p = subprocess.run([sys.executable, "-c", code], cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), capture_output=True, text=True, timeout=120)
     assert p.returncode == 17 and "a test block did not finish within" in p.stderr and "OPS_AMD_DP_ONE_GRAPH=0" in p.stderr
+    # the caller's hook speaks first (bench.py prints the FE record it has already measured), then the exit
+    code_hook = ("import time\nfrom openpystruct_amd import train\ntrain.stall_hook = lambda what: print('last words: ' + what, flush=True)\n"
+                 "with train._StallGuard(0.3, 'a test block'):\n    time.sleep(20)\n")
+    p = subprocess.run([sys.executable, "-c", code_hook], cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), capture_output=True, text=True, timeout=120)
+    assert p.returncode == 17 and "last words: a test block" in p.stdout
     code_ok = "from openpystruct_amd.train import _StallGuard\nwith _StallGuard(5.0, 'x'):\n    pass\nprint('fine')\n"
     p = subprocess.run([sys.executable, "-c", code_ok], cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), capture_output=True, text=True, timeout=120)
     assert p.returncode == 0 and "fine" in p.stdout
