@@ -228,8 +228,8 @@ int ops_physics_loss_bwd(const ops_physics_loss_args* args, void* stream);
  * Small batches (up to the batch at which the two kernel families meet: 256 .. 4 000 frames by frame size; the reference's one frame per
  * epoch) take the workgroup-per-frame kernels, which keep the band in LDS when it fits: ops_frame_workspace_bytes is then 0 and
  * `workspace` may be NULL -- always size the workspace with the B of the call.
- * half_bandwidth <= 27 (94 of the 100 (bays, stories) draws of FR:17-18): 16 or 32 lanes per frame, 4 or 2 frames per wavefront, persistent waves;
- * 28..55: a wavefront per frame; 56..63: the workgroup-per-frame kernels; 64..1024 (more than 20 bays and stories: beyond
+ * half_bandwidth <= 29 (98 of the 100 (bays, stories) draws of FR:17-18): 16 or 32 lanes per frame, 4 or 2 frames per wavefront, persistent waves;
+ * 30..55: a wavefront per frame; 56..63: the workgroup-per-frame kernels; 64..1024 (more than 20 bays and stories: beyond
  * the reference's range): a plain column-by-column fallback on the band in the workspace, milliseconds per frame;
  * ERR_UNSUPPORTED beyond that or when one right-hand side and one column do not fit 160 KB of LDS. */
 int ops_frame_solve_batched_f64(int B, int n_nodes, int n_elems, int n_eq, int half_bandwidth,
@@ -239,7 +239,7 @@ int ops_frame_solve_batched_f64(int B, int n_nodes, int n_elems, int n_eq, int h
                                 double* forces, double* V, double* M, int32_t* status, void* workspace,
                                 size_t workspace_bytes, void* stream);
 size_t ops_frame_workspace_bytes(int B, int n_eq, int half_bandwidth);
-/* r06 (ABI 13).  The tuned kernels (a wavefront, or for half_bandwidth <= 27 -- 94 of the 100 (bays, stories) draws of FR:17-18 -- 16 or 32 lanes
+/* r06 (ABI 13).  The tuned kernels (a wavefront, or for half_bandwidth <= 29 -- 98 of the 100 (bays, stories) draws of FR:17-18 -- 16 or 32 lanes
  * per frame) assemble each frame's rows from an ASSEMBLY PLAN: the topology-only part of `setup_frame_model` (which element entry goes where,
  * FR:84-131), built by a small kernel at the start of the workspace.  ops_frame_solve_batched_f64 rebuilds it on every call (20-25 us: it cannot
  * know whether the topology arrays changed).  A caller that KNOWS they did not -- same elem_* / node_eq contents, same n_eq / half_bandwidth, same

@@ -45,6 +45,7 @@ __host__ __device__ inline bool fp_config(int kd, int* P, int* G, int* W) {
   if (kd <= 21) { *P = 32; *G = 8; *W = 22; return true; }
   if (kd <= 23) { *P = 32; *G = 8; *W = 24; return true; }
   if (kd <= 27) { *P = 32; *G = 4; *W = 28; return true; }
+  if (kd <= 29) { *P = 32; *G = 2; *W = 30; return true; }      // 9 x 9 .. 9 x 10: rows enter in pairs (KG + G = 32)
 #ifdef FP_WITH_P64     // (r06, measured: this kernel at 64 lanes per frame -- correct on every size, 10 x 10 0.91 x, 12 x 12 1.09 x, 15 x 16 0.98 x of
                        //  frame_wave.hpp's kernel, whose wave-wide readlanes and 8-column backward chain it replaces with LDS traffic: not the default)
   if (kd <= 35) { *P = 64; *G = 8; *W = 36; return true; }      // one frame per wave: the same kernel, F = 1
@@ -372,7 +373,7 @@ __device__ __forceinline__ void frame_pack_body(const FrameParams& p, double* __
 
 // waves per SIMD the register allocator is asked to make room for: the wave is latency-bound (LDS round trips of the line, reciprocal chain)
 #ifndef FP_WAVES
-#define FP_WAVES(W) ((W) <= 10 ? 4 : (W) <= 28 ? 3 : 2)
+#define FP_WAVES(W) ((W) <= 10 ? 4 : (W) <= 30 ? 3 : 2)
 #endif
 template <int W, int P, int G>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FP_WAVES(W))))

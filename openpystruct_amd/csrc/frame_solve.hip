@@ -645,7 +645,7 @@ static int latency_batch(int n_eq, int kd) {
   const long o = g_frame_latency_batch.load();
   if (o >= 0) return (int)(o > 0x7fffffff ? 0x7fffffff : o);
   // r06 fit (scripts/frame_dispatch_sweep.py on the packed kernel, profiles/r06_frame_dispatch_sweep.txt): a launch of the tuned kernels never
-  // takes less than one wave's chain -- packed (kd <= 27): ~10 us + 0.5 us per equation (2 x 2: 17 us, 5 x 5: 47, 8 x 8: 123); a wave per frame:
+  // takes less than one wave's chain -- packed (kd <= 29): ~10 us + 0.5 us per equation (2 x 2: 17 us, 5 x 5: 47, 8 x 8: 123); a wave per frame:
   // (0.275 + 0.0075 kd) us per equation (10 x 10: 170 us, 15 x 16: 500) -- and the workgroup-per-frame kernels, flat up to a frame per CU, then
   // cost max(n kd^2 / 8.5e11, 6 ns + 0.22 ns n) per frame (5 x 5: 30 ns, 3 x 3: 14 ns, 10 x 10: 0.40 us).  The two meet at the quotient: 2 x 2 ~1 700
   // frames, 5 x 5 ~1 500, 10 x 10 ~430 (measured crossovers: between 1 024 and 2 048, 1 024 and 2 048, 256 and 512).
@@ -669,7 +669,7 @@ static int ne_bound(int n_eq) { return 4 * n_eq + 64; }
 static size_t plan_region_bytes(int n_eq, int G, int EPG) { return (fw_plan_bytes(n_eq, ne_bound(n_eq), G, EPG) + 255) & ~(size_t)255; }
 
 enum FrameFamily { FAM_WIDE, FAM_LEGACY, FAM_WAVE, FAM_PACK };
-// kd <= 27 (94 of the 100 (bays, stories) draws of FR:17-18): frame_pack.hpp, 16 or 32 lanes per frame; 28..55: frame_wave.hpp, a wave per
+// kd <= 29 (98 of the 100 (bays, stories) draws of FR:17-18): frame_pack.hpp, 16 or 32 lanes per frame; 30..55: frame_wave.hpp, a wave per
 // frame; small batches and 56..63: the workgroup-per-frame kernels; beyond: the column-by-column fallback
 static FrameFamily frame_family(int B, int n_eq, int kd) {
   if (kd > 63) return FAM_WIDE;
@@ -856,7 +856,8 @@ extern "C" int ops_frame_solve_batched_f64_ex(int B, int n_nodes, int n_elems, i
       case 18: e = launch_pack<18, 32, 8>(p, (double*)workspace, s, reuse_plan); break;
       case 22: e = launch_pack<22, 32, 8>(p, (double*)workspace, s, reuse_plan); break;
       case 24: e = launch_pack<24, 32, 8>(p, (double*)workspace, s, reuse_plan); break;
-      default: e = launch_pack<28, 32, 4>(p, (double*)workspace, s, reuse_plan); break;
+      case 28: e = launch_pack<28, 32, 4>(p, (double*)workspace, s, reuse_plan); break;
+      default: e = launch_pack<30, 32, 2>(p, (double*)workspace, s, reuse_plan); break;
     }
     if (e != hipSuccess) { set_frame_error(hipGetErrorString(e)); return OPS_AMD_ERR_LAUNCH; }
     return OPS_AMD_OK;

@@ -52,7 +52,7 @@ def check():
 
 
 def ab():
-    cases = [(1, 10, 131072), (2, 2, 131072), (3, 3, 65536), (10, 3, 32768), (5, 5, 32768), (7, 7, 16384), (8, 8, 16384), (10, 10, 16384), (12, 12, 12288), (15, 16, 12288)]
+    cases = [(1, 10, 131072), (2, 2, 131072), (3, 3, 65536), (10, 3, 32768), (5, 5, 32768), (7, 7, 16384), (8, 8, 16384), (9, 9, 16384), (8, 10, 16384), (10, 10, 16384), (12, 12, 12288), (15, 16, 12288)]
     for bays, stories, B in cases:
         topo = frames.grid_frame(bays, stories)
         I = torch.full((B, topo.Ne), 5e-4, dtype=torch.float64, device="cuda") * (1 + 0.1 * torch.rand(B, topo.Ne, dtype=torch.float64, device="cuda"))

@@ -63,7 +63,7 @@ def test_argument_validation_without_gpu(lib):
     # large batches keep the factor in the caller's workspace: one column-major L per frame (window width 36 / 52 for these bands) + the plan;
     # a frame whose band does not fit LDS needs the workspace at any batch (15 x 16: band + rhs per frame)
     assert lib.ops_frame_workspace_bytes(5000, 330, 35) >= 5000 * 330 * 36 * 8 and lib.ops_frame_workspace_bytes(3, 768, 50) >= 3 * 768 * 53 * 8
-    assert lib.ops_frame_workspace_bytes(40000, 90, 17) >= 40000 * 90 * 18 * 8      # packed kernel (half bandwidth <= 27): window width 18
+    assert lib.ops_frame_workspace_bytes(40000, 90, 17) >= 40000 * 90 * 18 * 8      # packed kernel (half bandwidth <= 29): window width 18
     assert lib.ops_frame_plan_signature(40000, 90, 17) >> 24 == 2 and lib.ops_frame_plan_signature(5000, 330, 35) >> 24 == 1 and lib.ops_frame_plan_signature(3, 330, 35) == 0
     assert lib.ops_amd_get_option(b"frame_pack") == 1 and lib.ops_amd_get_option(b"frame_latency_batch") == -1 and lib.ops_amd_get_option(b"nope") == -2
     assert lib.ops_amd_set_option(b"nope", 1) == _cabi.ERR_INVALID_ARG
@@ -148,15 +148,15 @@ def test_frame_dispatch_table_on_the_host():
             kd, n_eq = 3 * m + 2, 3 * stories * (bays + 1)
             sig = int(lib.ops_frame_plan_signature(B, n_eq, kd))
             fam, W, G, P = sig >> 24, (sig >> 16) & 0xFF, (sig >> 8) & 0xFF, sig & 0xFF
-            if kd <= 27:
+            if kd <= 29:
                 packed += 1
-                assert fam == 2 and W == (kd + 2) // 2 * 2 and P == (16 if kd <= 11 else 32) and G == (4 if (P == 16 or kd > 23) else 8), (bays, stories, sig)
+                assert fam == 2 and W == (kd + 2) // 2 * 2 and P == (16 if kd <= 11 else 32) and G == (4 if (P == 16 or 23 < kd <= 27) else 2 if kd > 27 else 8), (bays, stories, sig)
                 assert (kd // G + 1) * G + G <= P                      # the rows in flight below an entering group fit the lane group
                 assert int(lib.ops_frame_workspace_bytes(B, n_eq, kd)) >= B * (n_eq + 3) * W * 8
             else:
                 assert fam == 1 and W == 36 and P == 64, (bays, stories, sig)
                 assert int(lib.ops_frame_workspace_bytes(B, n_eq, kd)) >= B * (n_eq + 4) * W * 8
-    assert packed == 94                                               # 94 of the 100 draws
+    assert packed == 98                                               # 98 of the 100 draws (r06, late: kd 29 -- 9 x 9 .. -- joined)
     # beyond the tuned kernels: 56..63 the workgroup kernels (no plan), 64..1024 the column-by-column fallback, both with the band in the workspace
     assert lib.ops_frame_plan_signature(B, 2000, 59) == 0 and lib.ops_frame_plan_signature(B, 2000, 300) == 0
     assert lib.ops_frame_workspace_bytes(B, 2000, 300) >= B * 2000 * 301 * 8

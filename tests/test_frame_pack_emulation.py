@@ -10,8 +10,8 @@ that are no multiple of anything -- for every compiled (W, P, G).  The HIP kerne
 import numpy as np
 import pytest
 
-CONFIGS = [(6, 16, 4), (10, 16, 4), (12, 16, 4), (16, 32, 8), (18, 32, 8), (22, 32, 8), (24, 32, 8), (28, 32, 4)]      # fp_config of frame_pack.hpp
-MAX_KD = {6: 5, 10: 9, 12: 11, 16: 15, 18: 17, 22: 21, 24: 23, 28: 27}
+CONFIGS = [(6, 16, 4), (10, 16, 4), (12, 16, 4), (16, 32, 8), (18, 32, 8), (22, 32, 8), (24, 32, 8), (28, 32, 4), (30, 32, 2)]      # fp_config of frame_pack.hpp
+MAX_KD = {6: 5, 10: 9, 12: 11, 16: 15, 18: 17, 22: 21, 24: 23, 28: 27, 30: 29}
 
 
 def spd_band(rng, n, kd):

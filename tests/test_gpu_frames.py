@@ -594,12 +594,12 @@ def test_small_batches_take_a_workgroup_per_frame_and_large_ones_a_wave():
 
 # ---- r06: several frames per wavefront (csrc/frame_pack.hpp) ----
 _PACK_SHAPES = [(1, 1, 5, 6), (10, 1, 5, 6), (1, 10, 8, 10), (2, 2, 8, 10), (3, 3, 11, 12), (21, 3, 11, 12), (4, 4, 14, 16), (9, 4, 14, 16),
-                (5, 5, 17, 18), (10, 6, 20, 22), (7, 7, 23, 24), (8, 8, 26, 28), (10, 8, 26, 28)]
+                (5, 5, 17, 18), (10, 6, 20, 22), (7, 7, 23, 24), (8, 8, 26, 28), (10, 8, 26, 28), (9, 9, 29, 30), (8, 10, 29, 30)]
 
 
 @pytest.mark.parametrize("bays,stories,kd,W", _PACK_SHAPES)
 def test_packed_frames_vs_oracle_and_isolation(bays, stories, kd, W):
-    """Half bandwidths up to 27 (94 of the 100 (bays, stories) draws of FR:17-18): 16 or 32 lanes per frame, 4 or 2 frames per wave -- every
+    """Half bandwidths up to 29 (98 of the 100 (bays, stories) draws of FR:17-18): 16 or 32 lanes per frame, 4 or 2 frames per wave -- every
     compiled (window width, lanes, group size) against the oracle, with a frame that is not positive definite and a frame with a NaN load in the
     SAME waves as healthy ones (nothing may cross between the lane groups of a wave), a batch that does not fill its last wave, and against one
     wave per frame (library option frame_pack = 0: same arithmetic, so the displacements agree to the order of the assembly's LDS additions)."""
@@ -771,7 +771,7 @@ def test_every_draw_of_the_reference_range_at_a_batch_the_tuned_kernels_serve():
             topo = frames.grid_frame(bays, stories)
             sig = int(lib.ops_frame_plan_signature(B, topo.n_eq, topo.kd))
             fam = fams[sig >> 24]
-            assert fam == ("packed" if topo.kd <= 27 else "wave"), (bays, stories, topo.kd)
+            assert fam == ("packed" if topo.kd <= 29 else "wave"), (bays, stories, topo.kd)
             rng = np.random.default_rng(1000 * bays + stories)
             I = np.exp(rng.uniform(np.log(5e-5), np.log(5e-3), size=(B, topo.Ne)))
             I[B - 1] = I[0]
@@ -790,7 +790,7 @@ def test_every_draw_of_the_reference_range_at_a_batch_the_tuned_kernels_serve():
                     w["disp"], w["at"] = ed, [bays, stories]
                 w["forces"] = max(w["forces"], ef)
             worst[fam]["shapes"] += 1
-    assert worst["packed"]["shapes"] == 94 and worst["wave"]["shapes"] == 6
+    assert worst["packed"]["shapes"] == 98 and worst["wave"]["shapes"] == 2
     os.makedirs("gpurun_out", exist_ok=True)
     with open("gpurun_out/frames_full_range.json", "w") as fh:
         json.dump(worst, fh, indent=1)
