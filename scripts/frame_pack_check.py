@@ -5,6 +5,7 @@ r05's 16- and 24-wide instantiations of that kernel are gone, their numbers are 
 
     python scripts/frame_pack_check.py            # parity on 20 shapes + A/B on 6
     python scripts/frame_pack_check.py ab          # A/B only
+    python scripts/frame_pack_check.py ab 4x4:32768 9x4:16384    # A/B on these (bays x stories : frames per launch)
 """
 import json
 import os
@@ -51,8 +52,8 @@ def check():
     print("worst", worst)
 
 
-def ab():
-    cases = [(1, 10, 131072), (2, 2, 131072), (3, 3, 65536), (10, 3, 32768), (5, 5, 32768), (7, 7, 16384), (8, 8, 16384), (9, 9, 16384), (8, 10, 16384), (10, 10, 16384), (12, 12, 12288), (15, 16, 12288)]
+def ab(cases=None):
+    cases = cases or [(1, 10, 131072), (2, 2, 131072), (3, 3, 65536), (10, 3, 32768), (5, 5, 32768), (7, 7, 16384), (8, 8, 16384), (9, 9, 16384), (8, 10, 16384), (10, 10, 16384), (12, 12, 12288), (15, 16, 12288)]
     for bays, stories, B in cases:
         topo = frames.grid_frame(bays, stories)
         I = torch.full((B, topo.Ne), 5e-4, dtype=torch.float64, device="cuda") * (1 + 0.1 * torch.rand(B, topo.Ne, dtype=torch.float64, device="cuda"))
@@ -83,4 +84,5 @@ def ab():
 if __name__ == "__main__":
     if len(sys.argv) < 2 or sys.argv[1] != "ab":
         check()
-    ab()
+    # python scripts/frame_pack_check.py ab 4x4:32768 9x4:16384      (A/B on the named shapes only; OPS_AMD_LIB=<variant> selects another build)
+    ab([(int(a.split("x")[0]), int(a.split("x")[1].split(":")[0]), int(a.split(":")[1])) for a in sys.argv[2:]] or None)
