@@ -81,24 +81,24 @@ struct FpState {
 
 // line of column 0 (before the first step)
 template <int W, int P>
-__device__ __forceinline__ void fp_first_line(const FpState<W>& st, int r, int kdl, int n, double* __restrict__ line) {
+__device__ __forceinline__ void fp_first_line(const FpState<W>& st, int r, int kd, int n, double* __restrict__ line) {
   const int idx = (r + 1) & (P - 1);                          // 1 + rel; lane P - 1: the z slot
-  const int lim = kdl + 1 < n ? kdl + 1 : n;                  // (dead lane group: kdl = -1: nothing)
+  const int lim = kd + 1 < n ? kd + 1 : n;
   line[idx] = (idx >= 1 && idx - 1 < lim) ? st.reg[0] : 0.0;
 }
 
 // one factorisation step; S = j mod W at compile time (W even: S & 1 = j & 1).  On entry: rd = 1 / d_j, zp = z_(j-1), a1 = A[j+1][j],
-// a2 = A[j+2][j] (line values); on return the same for step j + 1.  kdl: kd for a live lane group, -1 for one past the end of the batch
-// (nothing in its window).  No branch: the column of L leaves with an unconditional store (lanes outside the window write slot W - 1 of the
+// a2 = A[j+2][j] (line values); on return the same for step j + 1.  (A lane group past the end of the batch solves the batch's LAST frame once
+// more, into its own workspace slot, and writes no results: n, kd and every window bound are wave-uniform.)  No branch: the column of L leaves with an unconditional store (lanes outside the window write slot W - 1 of the
 // column, which nothing reads), w stays in a register until the next group boundary.
 // Lw: this WAVE's first frame in the workspace (uniform), loff: the lane group's frame offset in doubles.
 template <int W, int P, int S>
-__device__ __forceinline__ void fp_step(FpState<W>& st, int j, int r, int kdl, int n, double* __restrict__ line, double* __restrict__ Lw,
+__device__ __forceinline__ void fp_step(FpState<W>& st, int j, int r, int kd, int n, double* __restrict__ line, double* __restrict__ Lw,
                                         unsigned loff, double& rd, double& zp, double& a1, double& a2, int& bad) {
   const int rel = (r - j) & (P - 1);
   const int below = n - 1 - j > 0 ? n - 1 - j : 0;            // rows below the diagonal that exist (uniform)
-  const int lim = kdl < below ? kdl : below;
-  const bool inwin = (unsigned)(rel - 1) < (unsigned)(lim > 0 ? lim : 0);          // 1 <= rel <= min(kd, n - 1 - j)
+  const int lim = kd < below ? kd : below;                    // (uniform, >= 0)
+  const bool inwin = (unsigned)(rel - 1) < (unsigned)lim;     // 1 <= rel <= min(kd, n - 1 - j)
   st.y = __builtin_fma(-st.lp, zp, st.y);                     // column j - 1's part of the forward substitution
   const double a = st.reg[S], rdj = rd;
   const double l = inwin ? a * rdj : 0.0;
@@ -110,7 +110,8 @@ __device__ __forceinline__ void fp_step(FpState<W>& st, int j, int r, int kdl, i
   // or already eliminated).  A row past the last equation contributes zeros (unit-diagonal / zero rows of the plan).
   line[((S + 1) & 1) * P + rel] = rel == 0 ? st.y : st.reg[(S + 1) % W];
 #ifndef FP_SKIP_LSTORE                                       // (phase ablation builds: wrong answers, scripts/frame_pack_ablation.sh)
-  (Lw + (size_t)j * W)[loff + (unsigned)(inwin ? rel - 1 : W - 1)] = l;  // column j of L: one coalesced store per lane group
+  // column j of L: one coalesced store per lane group (scalar column address + a 32-bit byte offset: a frame slot is far below 4 GB)
+  *reinterpret_cast<double*>(reinterpret_cast<char*>(Lw + (size_t)j * W) + (size_t)((loff + (unsigned)(inwin ? rel - 1 : W - 1)) * 8u)) = l;
 #endif
   st.w = (rel == 0 && j < n) ? st.y * rdj : st.w;             // w_j = z_j / d_j
   const double* cb = line + (S & 1) * P;
@@ -166,7 +167,7 @@ __device__ __forceinline__ void fp_order() {
 #endif
 __host__ __device__ constexpr int fp_tb(int P) { return (P / 8 + (P / 8) * (P / 8 - 1) / 2 + 1) & ~1; }      // partial results + triangle
 template <int W, int P>
-__device__ __forceinline__ void fp_backward(const double* __restrict__ Lc, double* __restrict__ xs, double* __restrict__ tb, int n, int nl,
+__device__ __forceinline__ void fp_backward(const double* __restrict__ Lc, double* __restrict__ xs, double* __restrict__ tb, int n,
                                             int kd, int r) {
   constexpr int U = P / 8, MF = (W + 7) / 8, NT = U * (U - 1) / 2, D = P == 64 ? 2 : FP_BD;      // (64 lanes: 7 registers per pass and lane)
   static_assert(U >= 2, "frame_pack: at least 16 lanes per frame");
@@ -182,7 +183,7 @@ __device__ __forceinline__ void fp_backward(const double* __restrict__ Lc, doubl
   };
   auto block = [&](int jb, const double (&lf)[MF]) {
     const int ju = jb - u, jc = ju > 0 ? ju : 0;
-    const int kdj = ju >= 0 ? (kd < nl - 1 - ju ? kd : nl - 1 - ju) : 0;      // rows of this column below the diagonal
+    const int kdj = ju >= 0 ? (kd < n - 1 - ju ? kd : n - 1 - ju) : 0;       // rows of this column below the diagonal
     if (k < u) tb[U + u * (u - 1) / 2 + (u - 1 - k)] = (k + 1 <= kdj) ? lf[0] : 0.0;      // L[jb - v][jb - u], v = u - 1 - k: offset k
     double acc0 = 0.0, acc1 = 0.0;
 #pragma unroll
@@ -218,7 +219,7 @@ __device__ __forceinline__ void fp_backward(const double* __restrict__ Lc, doubl
     double mine = x[0];
 #pragma unroll
     for (int w = 1; w < U; ++w) mine = (r == w) ? x[w] : mine;
-    if (r < U && jb - r >= 0 && jb - r < nl) xs[jb - r] = mine;
+    if (r < U && jb - r >= 0) xs[jb - r] = mine;
     fp_order();
   };
 #ifdef FP_SKIP_BACKWARD
@@ -242,7 +243,6 @@ __device__ __forceinline__ void frame_pack_body(const FrameParams& p, double* __
   constexpr int EPG = fp_epg(G), KE = EPG / P, PITCH = W + 2;
   static_assert(EPG % P == 0 && W % 2 == 0 && (P & (P - 1)) == 0, "frame_pack: sizes");
   const int n = p.n_eq, kd = p.kd;
-  const int nl = live ? n : 0, kdl = live ? kd : -1;        // a lane group past the end of the batch: nothing is in its window
   const double* Lc = Lw + loff;                             // this frame's columns of L
   const int KG = (kd / G + 1) * G;                          // > kd: registers hold the rows below j + KG + G at step j
   double* line = lds;                                       // [2][P]
@@ -316,7 +316,7 @@ __device__ __forceinline__ void frame_pack_body(const FrameParams& p, double* __
 
   // ---- factorisation + forward substitution ----
   double rd, zp, a1, a2;
-  fp_first_line<W, P>(st, r, kdl, n, line);
+  fp_first_line<W, P>(st, r, kd, n, line);
   fp_order();
   {
     const double2 p0 = *reinterpret_cast<const double2*>(line), p1 = *reinterpret_cast<const double2*>(line + 2);
@@ -346,7 +346,7 @@ __device__ __forceinline__ void frame_pack_body(const FrameParams& p, double* __
     {                                                                                 \
       const int j = j0 + (S_);                                                        \
       if constexpr (!FP_NO_BOUNDARY && (S_) % 2 == 0) if (j > 0 && (j % G) == 0 && j < n) boundary(j);   \
-      fp_step<W, P, (S_)>(st, j, r, kdl, n, line, Lw, loff, rd, zp, a1, a2, bad);     \
+      fp_step<W, P, (S_)>(st, j, r, kd, n, line, Lw, loff, rd, zp, a1, a2, bad);      \
     }
 #define FP_STEP4(S_)                                                                  \
     if constexpr ((S_) < W) {                                                         \
@@ -367,20 +367,20 @@ __device__ __forceinline__ void frame_pack_body(const FrameParams& p, double* __
   }
   fp_order();
 
-  fp_backward<W, P>(Lc, xs, tb, n, nl, kd, r);
+  fp_backward<W, P>(Lc, xs, tb, n, kd, r);
   if (live) write_results(p, b, xs, bad != 0, r, P);
 }
 
 // waves per SIMD the register allocator is asked to make room for: the wave is latency-bound (LDS round trips of the line, reciprocal chain)
 #ifndef FP_WAVES
-#define FP_WAVES(W) ((W) <= 10 ? 4 : (W) <= 30 ? 3 : 2)
+#define FP_WAVES(W) ((W) <= 18 ? 4 : (W) <= 30 ? 3 : 2)       /* measured (scripts/experiments/frame_waves_ab.sh): four waves +5-8 % at W = 16, +2 % at 18 (36 B of scratch), -5 / -7 % at 22 / 24 */
 #endif
 template <int W, int P, int G>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FP_WAVES(W))))
 void frame_pack_kernel(const FrameParams p, double* __restrict__ ws, const FwPlan pl, int ne_lds) {
   extern __shared__ double lds[];
   constexpr int F = 64 / P;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, sub = lane / P, r = lane & (P - 1);
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, sub = lane / P, r = lane & (P - 1);      // (wave: an SGPR -- the workspace slot's address is scalar)
   // PERSISTENT waves: the launch has at most as many workgroups as the chip holds at once, and a wave walks over its share of the batch with ONE
   // workspace slot (its own): the factor columns of all frames in flight are ~100 MB whatever the batch -- they stay in L2 / Infinity Cache
   // between the forward and the backward sweep instead of streaming through HBM (per-frame slots: 2 x 15 KB of HBM traffic per 5 x 5 frame
@@ -397,7 +397,7 @@ void frame_pack_kernel(const FrameParams p, double* __restrict__ ws, const FwPla
     const long slot = first + sub_;
     const bool live = slot < p.B;
     const long b = live ? slot : (long)p.B - 1;
-    frame_pack_body<W, P, G>(p, ws + (size_t)wslot * F * fd, (unsigned)((live ? sub_ : 0) * fd), lds + ldso_, r_, b, live, pl, ne_lds != 0);
+    frame_pack_body<W, P, G>(p, ws + (size_t)wslot * F * fd, (unsigned)(sub_ * fd), lds + ldso_, r_, b, live, pl, ne_lds != 0);
     fp_order();
   }
 }

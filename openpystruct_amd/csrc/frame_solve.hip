@@ -669,6 +669,8 @@ static int ne_bound(int n_eq) { return 4 * n_eq + 64; }
 static size_t plan_region_bytes(int n_eq, int G, int EPG) { return (fw_plan_bytes(n_eq, ne_bound(n_eq), G, EPG) + 255) & ~(size_t)255; }
 
 enum FrameFamily { FAM_WIDE, FAM_LEGACY, FAM_WAVE, FAM_PACK };
+// frame slots of the packed kernel's factor storage: whole waves (a lane group past the end of the batch solves the last frame again, into its own slot)
+static size_t pack_slots(int B, int P) { const size_t F = 64 / P; return ((size_t)B + F - 1) / F * F; }
 // kd <= 29 (98 of the 100 (bays, stories) draws of FR:17-18): frame_pack.hpp, 16 or 32 lanes per frame; 30..55: frame_wave.hpp, a wave per
 // frame; small batches and 56..63: the workgroup-per-frame kernels; beyond: the column-by-column fallback
 static FrameFamily frame_family(int B, int n_eq, int kd) {
@@ -764,7 +766,7 @@ extern "C" size_t ops_frame_workspace_bytes(int B, int n_eq, int half_bandwidth)
     case FAM_PACK: {                               // per frame: the columns of L (the kernel uses one slot per resident wave); once: the plan
       int P, G, W;
       fp_config(kd, &P, &G, &W);
-      return (size_t)B * fp_frame_doubles(n_eq, W) * sizeof(double) + plan_region_bytes(n_eq, G, fp_epg(G));
+      return pack_slots(B, P) * fp_frame_doubles(n_eq, W) * sizeof(double) + plan_region_bytes(n_eq, G, fp_epg(G));
     }
     case FAM_WAVE: return (size_t)B * fw_frame_doubles(n_eq, kd) * sizeof(double) + plan_region_bytes(n_eq, FW_G, FW_EPG);
     default: break;
@@ -845,7 +847,7 @@ extern "C" int ops_frame_solve_batched_f64_ex(int B, int n_nodes, int n_elems, i
   if (fam == FAM_PACK) {
     int P, G, W;
     fp_config(kd, &P, &G, &W);
-    const size_t need = (size_t)B * fp_frame_doubles(n_eq, W) * sizeof(double) + plan_region_bytes(n_eq, G, fp_epg(G));
+    const size_t need = pack_slots(B, P) * fp_frame_doubles(n_eq, W) * sizeof(double) + plan_region_bytes(n_eq, G, fp_epg(G));
     if (!workspace || workspace_bytes < need || n_elems > ne_bound(n_eq)) return OPS_AMD_ERR_INVALID_ARG;
     hipError_t e = hipSuccess;
     switch (W) {

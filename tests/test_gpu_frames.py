@@ -794,3 +794,28 @@ def test_every_draw_of_the_reference_range_at_a_batch_the_tuned_kernels_serve():
     os.makedirs("gpurun_out", exist_ok=True)
     with open("gpurun_out/frames_full_range.json", "w") as fh:
         json.dump(worst, fh, indent=1)
+
+
+@pytest.mark.parametrize("bays,stories,B", [(2, 2, 3), (2, 2, 5), (5, 5, 1), (5, 5, 7), (9, 9, 3)])
+def test_packed_frames_stay_inside_the_workspace_the_library_asks_for(bays, stories, B):
+    """A batch that does not fill its last wave: the lane groups past the end solve the last frame once more into their OWN factor slot (r06: every
+    window bound is then wave-uniform), so ops_frame_workspace_bytes counts whole waves.  The call runs on a buffer of exactly that size followed
+    by a guard band; the guard must come back untouched (the first version of that change wrote one frame slot past a B-frame workspace)."""
+    from openpystruct_amd import _cabi, frames
+    topo = frames.grid_frame(bays, stories)
+    lib = _cabi.load()
+    assert int(lib.ops_frame_plan_signature(B, topo.n_eq, topo.kd)) >> 24 == 2
+    need = int(lib.ops_frame_workspace_bytes(B, topo.n_eq, topo.kd))
+    guard = 1 << 20
+    buf = torch.full((need + guard,), 0xA5, dtype=torch.uint8, device="cuda")
+    key = (torch.cuda.current_device(), torch.cuda.current_stream().cuda_stream)
+    topo.__dict__["_ws"] = {key: [buf, 0]}            # frames.frame_solve takes a cached buffer that is large enough and passes `need` as its size
+    rng = np.random.default_rng(7)
+    I = np.exp(rng.uniform(np.log(5e-5), np.log(5e-3), size=(B, topo.Ne)))
+    sol = frames.frame_solve(topo, torch.as_tensor(I, device="cuda"))
+    torch.cuda.synchronize()
+    assert topo.__dict__["_ws"][key][0] is buf
+    assert bool((buf[need:] == 0xA5).all()), "the solve wrote past the workspace it asked for"
+    assert int(sol.status.abs().sum()) == 0
+    d, f, st, _, _ = _oracle(topo, I[B - 1])
+    assert relerr(sol.disp[B - 1].cpu().numpy().ravel(), d.ravel()) < 1e-8
