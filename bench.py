@@ -777,6 +777,7 @@ def main():
         guard.daemon = True
         if is_dp(world):
             guard.start()
+            os.environ.setdefault("OPS_AMD_DP_PROFILE", "1")      # (read by train.py at import: before the import below, as surrogate_epoch_times does)
             from openpystruct_amd import train as _train
 
             def stalled(what):           # the library's own stall timer (first replay of the one-graph step, exit 17): the FE line goes out first

@@ -223,8 +223,8 @@ int ops_physics_loss_bwd(const ops_physics_loss_args* args, void* stream);
  * Outputs: disp [B,Nn,3], forces [B,Ne,6] (global resisting forces = eleResponse 'forces'), V / M [B,Ne] = forces[..,1] /
  * forces[..,2] (FR:151-153), status [B] (non-zero: not positive definite, outputs NaN).
  * The factor lives in a caller-provided device workspace of ops_frame_workspace_bytes(B, n_eq, half_bandwidth) bytes: the assembly plan at its
- * start, then about (n_eq + 4) * (window width) * 8 per frame (window width: the half bandwidth + 1 rounded up to 6 / 10 / 12 / 16 / 18 / 22 / 24 / 28 / 36 /
- * 52 / 56; the kernels keep the sliding window in registers).  ERR_INVALID_ARG when it is NULL or too small.
+ * start, then about (n_eq + 4) * (window width) * 8 per frame (window width: the half bandwidth + 1 rounded up to 6 / 10 / 12 / 16 / 18 / 22 / 24 / 28 / 30 /
+ * 36 / 52 / 56; the kernels keep the sliding window in registers; the packed kernel's share counts whole wavefronts: B rounded up to 4 or 2 frames).  ERR_INVALID_ARG when it is NULL or too small.
  * Small batches (up to the batch at which the two kernel families meet: 256 .. 4 000 frames by frame size; the reference's one frame per
  * epoch) take the workgroup-per-frame kernels, which keep the band in LDS when it fits: ops_frame_workspace_bytes is then 0 and
  * `workspace` may be NULL -- always size the workspace with the B of the call.
