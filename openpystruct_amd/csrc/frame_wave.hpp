@@ -452,13 +452,19 @@ __device__ __forceinline__ void frame_wave_body(const FrameParams& p, double* __
 
 // waves per SIMD the register allocator is asked to make room for (the kernel is latency-bound per wave: rcp chain, LDS
 // round trip of the broadcast line): 2 W VGPRs of window + ~55
-constexpr int fw_waves(int W) { return W == 36 ? 1 : W <= 52 ? 3 : 2; }   // measured: only the 52-wide window gains (170 -> 168 VGPRs: 3 waves)
+#ifndef FW_WAVES_36
+#define FW_WAVES_36 4      /* r06, late (profiles/r06_frame_wave_scalar_ab.txt): with the wave index in an SGPR the 36-wide kernel needs 133 VGPRs; held to 128 (28 B of scratch) four waves: 10 x 10 +2.5 % */
+#endif
+#ifndef FW_WAVES_56
+#define FW_WAVES_56 2
+#endif
+constexpr int fw_waves(int W) { return W == 36 ? FW_WAVES_36 : W <= 52 ? 3 : FW_WAVES_56; }   // (56-wide at three waves: 16 B of scratch, -4 %)   // measured: only the 52-wide window gains (170 -> 168 VGPRs: 3 waves)
 
 template <int W>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(fw_waves(W))))
 void frame_wave_kernel(const FrameParams p, double* __restrict__ ws, const FwPlan pl) {
   extern __shared__ double lds[];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;      // (wave: an SGPR -- frame number and workspace address are scalar)
   // one frame per wave, its own workspace slot.  (r06, measured: persistent waves with one slot per resident wave -- what keeps the packed
   // kernel's factor in cache, frame_pack.hpp -- buy nothing here: at 28 <= kd the factors in flight are 0.3 .. 1 GB, far beyond L2 and the
   // Infinity Cache either way (15 x 16: 8.8 GB of fabric traffic per 12 288 frames = the factor written once and read once, before and after),
