@@ -819,3 +819,37 @@ def test_packed_frames_stay_inside_the_workspace_the_library_asks_for(bays, stor
     assert int(sol.status.abs().sum()) == 0
     d, f, st, _, _ = _oracle(topo, I[B - 1])
     assert relerr(sol.disp[B - 1].cpu().numpy().ravel(), d.ravel()) < 1e-8
+
+
+@pytest.mark.parametrize("nn,hub,G,epg", [(9, 4, 4, 64), (12, 6, 8, 128), (14, 8, 8, 128), (18, 9, 4, 64), (18, 10, 2, 32)])
+def test_packed_kernel_walks_the_extra_plan_blocks_of_a_hub_node(nn, hub, G, epg):
+    """The packed kernel's plan blocks hold 16 G entries per row group (frame_pack.hpp fp_epg: what a four-element node needs); a node tied to
+    EVERY other node of a short chain overflows them at every group size (sixteen lanes: half bandwidth 11; G = 8 / 4 / 2 <-> 17 and 23 / 26 / 29), so the solve walks the
+    group's extra blocks -- the packed counterpart of the eighteen-element hub test above (which lands on the wave kernel)."""
+    from openpystruct_amd import _cabi, frames
+    coords = np.array([(1.2 * i, 0.5 * np.cos(1.3 * i) + (0.8 if i == hub else 0.0)) for i in range(nn)])
+    conn = np.array([(i, i + 1) for i in range(nn - 1) if hub not in (i, i + 1)] + [(hub, o) for o in range(nn) if o != hub])
+    fix3 = np.zeros((nn, 3), dtype=bool)
+    fix3[0] = fix3[nn - 1] = True
+    loads = np.zeros((nn, 3)); loads[hub] = (2e4, -3e4, 1e3); loads[2] = (0.0, -1e4, 0.0)
+    w = np.zeros(len(conn)); w[:3] = -6e3
+    topo = frames.FrameTopology(coords, conn, fix3, 0.02, 200e9, w, 0.5 * w, loads, "cuda", numbering="node")
+    sig = int(_cabi.load().ops_frame_plan_signature(300, topo.n_eq, topo.kd))
+    assert sig >> 24 == 2 and (sig >> 8) & 0xFF == G, (topo.kd, hex(sig))
+    eq = topo.d_elem_eq.cpu().numpy()
+    per_group = np.zeros(topo.n_eq // G + 1, dtype=int)
+    for e in range(topo.Ne):
+        for r in range(6):
+            if eq[e, r] >= 0:
+                per_group[eq[e, r] // G] += int(((eq[e] >= 0) & (eq[e] <= eq[e, r])).sum())
+    assert per_group.max() > epg, per_group.max()
+    rng = np.random.default_rng(nn)
+    B = 7
+    I = np.exp(rng.uniform(np.log(5e-5), np.log(5e-3), size=(B, topo.Ne)))
+    sol = frames.frame_solve(topo, torch.as_tensor(I, device="cuda"))
+    assert int(sol.status.abs().sum()) == 0
+    for b in range(B):
+        d, f, st, neq, kd = _oracle(topo, I[b])
+        assert st == 0 and neq == topo.n_eq and _kd_ok(topo, kd)
+        assert relerr(sol.disp[b].cpu().numpy().ravel(), d.ravel()) < 1e-8
+        assert relerr(sol.forces[b].cpu().numpy().ravel(), f.ravel()) < 1e-7
