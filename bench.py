@@ -444,7 +444,8 @@ def frames_measure(dev, rank, local_rank, world, bays, stories, B, K, W):
         except Exception as e:          # reported in the record: an assertion here would leave the other ranks in the barrier below
             check_fail = repr(e)
     lib = _cabi.load()
-    ws_frame = int(lib.ops_frame_workspace_bytes(B + 1, topo.n_eq, topo.kd)) - int(lib.ops_frame_workspace_bytes(B, topo.n_eq, topo.kd))   # per frame (the call-wide assembly plan excluded)
+    # per frame, the call-wide assembly plan excluded (the packed kernel's share counts whole waves of 2 or 4 frames: difference over four frames)
+    ws_frame = (int(lib.ops_frame_workspace_bytes(B + 4 - B % 4 + 4, topo.n_eq, topo.kd)) - int(lib.ops_frame_workspace_bytes(B + 4 - B % 4, topo.n_eq, topo.kd))) // 4
     # ALGORITHMIC bytes per frame: I in; disp [Nn,3], forces [Ne,6], V, M out -- what a solve that kept its factor on chip would move
     io_frame = 8 * (topo.Ne + 3 * topo.Nn + 8 * topo.Ne)
     us = dev_ms / K * 1e3
