@@ -468,6 +468,11 @@ def frames_measure(dev, rank, local_rank, world, bays, stories, B, K, W):
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": tr[0] if tr else None, "traffic_source": f"profiles/{tr[1]} (2*FETCH_SIZE + WRITE_SIZE, KiB)" if tr else None,
                      "traffic_over_algorithmic": tr[0] / (io_frame * B) if tr else None,
+                     # the factor does not stay on chip (profiles/r06_notes.md 20): written once, read once = 2 * workspace_bytes_per_frame;
+                     # the profiled traffic at THIS run's rate, as a fraction of the HBM peak (an upper reading: the Infinity Cache serves part of it)
+                     "factor_round_trip_bytes_per_frame": 2 * ws_frame,
+                     "traffic_rate_gbs": tr[0] / (us * 1e-6) / 1e9 if tr else None,
+                     "traffic_rate_frac_of_hbm_peak": tr[0] / (us * 1e-6) / 1e9 / HBM_PEAK_GBS if tr else None,
                      "algorithmic_bytes_per_frame": io_frame, "kernel_us": us,
                      "fp64_vector_frac": flops * B / (us * 1e-6) / 78.6e12, "fp64_vector_peak_tflops": 78.6,
                      "flop_per_frame": flops},
