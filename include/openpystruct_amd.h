@@ -225,9 +225,10 @@ int ops_physics_loss_bwd(const ops_physics_loss_args* args, void* stream);
  * The factor lives in a caller-provided device workspace of ops_frame_workspace_bytes(B, n_eq, half_bandwidth) bytes: the assembly plan at its
  * start, then about (n_eq + 4) * (window width) * 8 per frame (window width: the half bandwidth + 1 rounded up to 6 / 10 / 12 / 16 / 18 / 22 / 24 / 28 / 30 /
  * 36 / 52 / 56; the kernels keep the sliding window in registers; the packed kernel's share counts whole wavefronts: B rounded up to 4 or 2 frames).  ERR_INVALID_ARG when it is NULL or too small.
- * Small batches (up to the batch at which the two kernel families meet: 256 .. 4 000 frames by frame size; the reference's one frame per
- * epoch) take the workgroup-per-frame kernels, which keep the band in LDS when it fits: ops_frame_workspace_bytes is then 0 and
- * `workspace` may be NULL -- always size the workspace with the B of the call.
+ * Small batches (up to the batch at which the kernel families meet: 256 .. 4 000 frames by frame size; the reference's one frame per
+ * epoch) take the workgroup-per-frame kernels, which keep the band in LDS when it fits (ops_frame_workspace_bytes is then 0 and
+ * `workspace` may be NULL), or -- r06, csrc/frame_coop.hpp -- four wavefronts per frame with the window in registers where that band does not
+ * fit or fits a CU only once (workspace: plan + factor, as for the tuned kernels) -- always size the workspace with the B of the call.
  * half_bandwidth <= 29 (98 of the 100 (bays, stories) draws of FR:17-18): 16 or 32 lanes per frame, 4 or 2 frames per wavefront, persistent waves;
  * 30..55: a wavefront per frame; 56..63: the workgroup-per-frame kernels; 64..1024 (more than 20 bays and stories: beyond
  * the reference's range): a plain column-by-column fallback on the band in the workspace, milliseconds per frame;
@@ -319,7 +320,10 @@ const char* ops_amd_last_error(void);
  * thread-safe, effective from the next call.  Unknown name: ERR_INVALID_ARG / -2.
  *   "frame_latency_batch"  -1 (default): batches of up to 256 .. 4 000 frames (by frame size) take the workgroup-per-frame kernels, which answer
  *                          a handful of frames sooner; N >= 0: that threshold is N (0: the tuned kernels for every batch)
- *   "frame_pack"           1 (default): half bandwidths up to 27 take 16 or 32 lanes per frame; 0: one wave per frame for every band (A/B)
+ *   "frame_pack"           1 (default): half bandwidths up to 29 take 16 or 32 lanes per frame; 0: one wave per frame for every band (A/B)
+ *   "frame_coop"           1 (default): small batches take a workgroup of four wavefronts per frame where that was measured faster than the
+ *                          workgroup-per-frame kernels (their band not LDS-resident: half bandwidth 44 .. 55 up to 512 frames; or resident only once
+ *                          per CU: e.g. 10 x 10 at 257 .. 768 frames); 0: never; 2: for every small batch (A/B, tests)
  *   "deterministic"        0 (default); 1: the Transformer-Diffusion step's gradient launches reduce in a fixed order -- one row split per weight-
  *                          gradient product and one workgroup per column-sum strip (ops_linear_wgrad_accumulate*), one workgroup for the [CLS]
  *                          sums (ops_tfd_front_bwd), the head's LayerNorm sums in workgroup order (ops_tfd_head_bwd) -- so that two runs of one

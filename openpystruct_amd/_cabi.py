@@ -380,7 +380,8 @@ def load():
 
 def set_option(name: str, value: int) -> None:
     """include/openpystruct_amd.h ops_amd_set_option: "frame_latency_batch" (-1 = the library's model, 0 = tuned kernels for every batch),
-    "frame_pack" (0 = one wave per frame for every half bandwidth).  The library reads no environment variable."""
+    "frame_pack" (0 = one wave per frame for every half bandwidth), "frame_coop" (0 / 1 / 2: four waves per frame for small batches never / where
+    measured faster / always), "deterministic".  The library reads no environment variable."""
     if load().ops_amd_set_option(name.encode(), int(value)) != OK:
         raise ValueError(f"unknown library option {name!r}")
 

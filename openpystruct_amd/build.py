@@ -22,7 +22,7 @@ SOURCES = [os.path.join(CSRC, "beam_solve.hip"), os.path.join(CSRC, "beam_fat.hi
            os.path.join(CSRC, "stencil_bn.hip"), os.path.join(CSRC, "flat_adam.hip"),
            os.path.join(CSRC, "fused_loss.hip"), os.path.join(CSRC, "fused_bn.hip"), os.path.join(CSRC, "input_prep.hip"),
            os.path.join(CSRC, "mlp_block.hip"), os.path.join(CSRC, "seq_block.hip"), os.path.join(CSRC, "seq_layer.hip"), os.path.join(CSRC, "mem_bench.hip"), os.path.join(CSRC, "case_draw.hip")]
-HEADERS = [os.path.join(CSRC, "repack_tiles.hpp"), os.path.join(CSRC, "beam_math.hpp"), os.path.join(CSRC, "beam_io.hpp"), os.path.join(CSRC, "call_counter.hpp"), os.path.join(CSRC, "dropout_stream.hpp"), os.path.join(CSRC, "input_noise.hpp"), os.path.join(CSRC, "sizing_math.hpp"), os.path.join(CSRC, "frame_wave.hpp"), os.path.join(CSRC, "frame_pack.hpp"), os.path.join(ROOT, "include", "openpystruct_amd.h")]
+HEADERS = [os.path.join(CSRC, "repack_tiles.hpp"), os.path.join(CSRC, "beam_math.hpp"), os.path.join(CSRC, "beam_io.hpp"), os.path.join(CSRC, "call_counter.hpp"), os.path.join(CSRC, "dropout_stream.hpp"), os.path.join(CSRC, "input_noise.hpp"), os.path.join(CSRC, "sizing_math.hpp"), os.path.join(CSRC, "frame_wave.hpp"), os.path.join(CSRC, "frame_pack.hpp"), os.path.join(CSRC, "frame_coop.hpp"), os.path.join(ROOT, "include", "openpystruct_amd.h")]
 ARCH = "gfx950"
 
 

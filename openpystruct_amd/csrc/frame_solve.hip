@@ -580,6 +580,7 @@ constexpr int FRAME_WIDE_MAX_KD = 1024;      // frame_wide_kernel's backward swe
 
 #include "frame_wave.hpp"
 #include "frame_pack.hpp"
+#include "frame_coop.hpp"
 
 using namespace opsamd;
 
@@ -587,6 +588,7 @@ static const size_t LDS_MAX = 160 * 1024 - 64;
 
 // ---- library options (ops_amd_set_option: the one place a caller -- tests, A/B scripts -- steers the dispatch; no environment variable is read) ----
 static std::atomic<long> g_frame_latency_batch{-1};      // "frame_latency_batch": -1 = the model below; 0 = tuned kernels for every batch
+static std::atomic<long> g_frame_coop{1};                // "frame_coop": 0 = never four waves per frame; 1 = where measured faster (default); 2 = for every small batch (A/B, tests)
 static std::atomic<long> g_frame_pack{1};                // "frame_pack": 0 = one wave per frame for every half bandwidth (A/B)
 static std::atomic<int> g_deterministic{0};              // "deterministic": 1 = fixed-order reductions in the Transformer-Diffusion step's gradient launches
 namespace opsamd {
@@ -599,6 +601,7 @@ extern "C" int ops_amd_set_option(const char* name, long value) {
   const std::string_view n(name);
   if (n == "frame_latency_batch") { g_frame_latency_batch.store(value < 0 ? -1 : value); return OPS_AMD_OK; }
   if (n == "frame_pack") { g_frame_pack.store(value != 0); return OPS_AMD_OK; }
+  if (n == "frame_coop") { if (value < 0 || value > 2) return OPS_AMD_ERR_INVALID_ARG; g_frame_coop.store(value); return OPS_AMD_OK; }
   if (n == "deterministic") {
     g_deterministic.store(value != 0);
     int ndev = 0;
@@ -612,6 +615,7 @@ extern "C" long ops_amd_get_option(const char* name) {
   const std::string_view n(name);
   if (n == "frame_latency_batch") return g_frame_latency_batch.load();
   if (n == "frame_pack") return g_frame_pack.load();
+  if (n == "frame_coop") return g_frame_coop.load();
   if (n == "deterministic") return g_deterministic.load();
   return -2;
 }
@@ -641,6 +645,12 @@ static int eff_kd(int half_bandwidth) { return half_bandwidth < 3 ? 3 : half_ban
 // the wave kernel is ahead (10 x 10: 231 / 426 us) (scripts/frame_small_batch_ab.py).  That is the reference's own use of the frame solve -- ONE
 // frame per epoch (FR:178-183) -- and the command shim's.  The batch at which the two families meet is the threshold (latency_batch below), at
 // least 256 (one frame per CU) and at most 4 000.  Option "frame_latency_batch" overrides it (0: tuned kernels for every batch).
+// what one launch of the tuned kernels never takes less than (one wave's chain): fit of r06, see latency_batch
+static double tuned_floor_seconds(int n_eq, int kd) {
+  int P, G, W;
+  const bool pack = g_frame_pack.load() && fp_config(kd, &P, &G, &W);
+  return pack ? 10e-6 + 0.5e-6 * n_eq : (0.275e-6 + 0.0075e-6 * kd) * n_eq;
+}
 static int latency_batch(int n_eq, int kd) {
   const long o = g_frame_latency_batch.load();
   if (o >= 0) return (int)(o > 0x7fffffff ? 0x7fffffff : o);
@@ -649,9 +659,7 @@ static int latency_batch(int n_eq, int kd) {
   // (0.275 + 0.0075 kd) us per equation (10 x 10: 170 us, 15 x 16: 500) -- and the workgroup-per-frame kernels, flat up to a frame per CU, then
   // cost max(n kd^2 / 8.5e11, 6 ns + 0.22 ns n) per frame (5 x 5: 30 ns, 3 x 3: 14 ns, 10 x 10: 0.40 us).  The two meet at the quotient: 2 x 2 ~1 700
   // frames, 5 x 5 ~1 500, 10 x 10 ~430 (measured crossovers: between 1 024 and 2 048, 1 024 and 2 048, 256 and 512).
-  int P, G, W;
-  const bool pack = g_frame_pack.load() && fp_config(kd, &P, &G, &W);
-  const double tuned_floor_s = pack ? 10e-6 + 0.5e-6 * n_eq : (0.275e-6 + 0.0075e-6 * kd) * n_eq;
+  const double tuned_floor_s = tuned_floor_seconds(n_eq, kd);
   const double a = (double)n_eq * kd * kd / 8.5e11, c = 6e-9 + 0.22e-9 * n_eq;
   const double b = tuned_floor_s / (a > c ? a : c);
   return b < 256.0 ? 256 : b > 4000.0 ? 4000 : (int)b;
@@ -668,14 +676,37 @@ static int ne_bound(int n_eq) { return 4 * n_eq + 64; }
 // keep the plan: OPS_FRAME_REUSE_PLAN), the per-wave factor storage behind it
 static size_t plan_region_bytes(int n_eq, int G, int EPG) { return (fw_plan_bytes(n_eq, ne_bound(n_eq), G, EPG) + 255) & ~(size_t)255; }
 
-enum FrameFamily { FAM_WIDE, FAM_LEGACY, FAM_WAVE, FAM_PACK };
+enum FrameFamily { FAM_WIDE, FAM_LEGACY, FAM_WAVE, FAM_PACK, FAM_COOP };
 // frame slots of the packed kernel's factor storage: whole waves (a lane group past the end of the batch solves the last frame again, into its own slot)
 static size_t pack_slots(int B, int P) { const size_t F = 64 / P; return ((size_t)B + F - 1) / F * F; }
 // kd <= 29 (98 of the 100 (bays, stories) draws of FR:17-18): frame_pack.hpp, 16 or 32 lanes per frame; 30..55: frame_wave.hpp, a wave per
 // frame; small batches and 56..63: the workgroup-per-frame kernels; beyond: the column-by-column fallback
 static FrameFamily frame_family(int B, int n_eq, int kd) {
   if (kd > 63) return FAM_WIDE;
-  if (kd > 55 || (B <= latency_batch(n_eq, kd) && legacy_kernels_serve(n_eq, kd))) return FAM_LEGACY;
+  if (kd > 55) return FAM_LEGACY;
+  // Small batches (scripts/frame_coop_sweep.py, profiles/r06_frame_coop_sweep*.txt).  The r01 workgroup-per-frame kernels win while their band is
+  // LDS-resident and the batch is at most their share of the chip (10 x 10, 256 frames: 107 us against 123 for four waves per frame and 186 for a
+  // wave per frame).  Four waves per frame (frame_coop.hpp: 8 KB of LDS and 256 threads, three to a CU) win (i) where that band is NOT resident
+  // (15 x 16, up to 512 frames: 303-358 us against 471-646 and 503; two workgroups of the 52-wide kernel to a CU) and (ii) between one and three frames per CU where the r01 kernel fits only
+  // once per CU and needs a second round (10 x 10, 384-768 frames: 140-162 us against 204-306 and 189; 12 x 12, 512: 226 / 290 / 312); its cost
+  // ~0.37 us per equation, +15 % per further frame per CU, is held against the tuned kernels' floor.  An explicit "frame_latency_batch" option keeps
+  // its meaning: that many frames or fewer never take the tuned kernels.
+  const bool lat_forced = g_frame_latency_batch.load() >= 0;
+  const int lat = latency_batch(n_eq, kd);
+  const bool coop_ok = g_frame_coop.load() && fc_lds_doubles(n_eq, fc_width(kd)) * sizeof(double) <= LDS_MAX;
+  const bool legacy_ok = legacy_kernels_serve(n_eq, kd);
+  const size_t band = frame_lds_resident_bytes(n_eq, kd);
+  if (coop_ok && !lat_forced) {
+    const double coop_s = 0.37e-6 * n_eq * (1.0 + 0.15 * ((B - 1) / 256));
+    const int coop_max = fc_width(kd) >= 52 ? 512 : 768;      // (the 52- / 56-wide kernels: two workgroups to a CU -- 15 x 16 x 768: 630 us against 518)
+    if (band > LDS_MAX && B <= coop_max) return FAM_COOP;
+    if (band > LDS_MAX / 2 && B > 256 && B <= coop_max && coop_s < tuned_floor_seconds(n_eq, kd)) return FAM_COOP;
+  }
+  if (B <= lat) {
+    if (coop_ok && g_frame_coop.load() == 2) return FAM_COOP;
+    if (legacy_ok && (band <= LDS_MAX || !coop_ok)) return FAM_LEGACY;
+    if (coop_ok) return FAM_COOP;
+  }
   int P, G, W;
   // the packed kernel's 8 or 16 frames per workgroup keep x (n_eq) and their parking areas in LDS (+ the inertias if those fit too: launch_pack)
   if (g_frame_pack.load() && fp_config(kd, &P, &G, &W) && 4 * (size_t)(64 / P) * fp_lds_doubles(n_eq, 0, P, G, W) * sizeof(double) <= LDS_MAX)
@@ -758,6 +789,28 @@ static hipError_t launch_wave(const FrameParams& p, double* ws_all, hipStream_t 
   return hipGetLastError();
 }
 
+template <int W>
+static hipError_t launch_coop(const FrameParams& p, double* ws_all, hipStream_t s, bool reuse_plan) {
+  static std::atomic<unsigned long long> done{0};
+  int devid = 0;
+  hipError_t e = hipGetDevice(&devid);
+  if (e != hipSuccess) return e;
+  const size_t lds = fc_lds_doubles(p.n_eq, W) * sizeof(double);          // size limit: frame_family (checked by the caller)
+  const unsigned long long bit = 1ull << (devid & 63);
+  if (!(done.load(std::memory_order_acquire) & bit)) {
+    e = hipFuncSetAttribute((const void*)frame_coop_kernel<W>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX);
+    if (e != hipSuccess) return e;
+    done.fetch_or(bit, std::memory_order_release);
+  }
+  void* plan_base = ws_all;
+  double* ws = (double*)((char*)ws_all + plan_region_bytes(p.n_eq, FW_G, FW_EPG));
+  const FwPlan pl = fw_plan_at(plan_base, p.n_eq, p.Ne);
+  if (!reuse_plan)
+    hipLaunchKernelGGL(frame_plan_kernel, dim3(1), dim3(1024), (size_t)3 * (fw_groups(p.n_eq) + 2) * sizeof(int), s, p, W, plan_base, FW_G, FW_EPG);
+  hipLaunchKernelGGL((frame_coop_kernel<W>), dim3((unsigned)p.B), dim3(64 * FC_NW), lds, s, p, ws, pl);
+  return hipGetLastError();
+}
+
 extern "C" size_t ops_frame_workspace_bytes(int B, int n_eq, int half_bandwidth) {
   if (B <= 0 || n_eq < 1 || half_bandwidth < 0) return 0;
   const int kd = eff_kd(half_bandwidth);
@@ -769,6 +822,7 @@ extern "C" size_t ops_frame_workspace_bytes(int B, int n_eq, int half_bandwidth)
       return pack_slots(B, P) * fp_frame_doubles(n_eq, W) * sizeof(double) + plan_region_bytes(n_eq, G, fp_epg(G));
     }
     case FAM_WAVE: return (size_t)B * fw_frame_doubles(n_eq, kd) * sizeof(double) + plan_region_bytes(n_eq, FW_G, FW_EPG);
+    case FAM_COOP: return (size_t)B * fc_frame_doubles(n_eq, kd) * sizeof(double) + plan_region_bytes(n_eq, FW_G, FW_EPG);
     default: break;
   }
   if (frame_lds_resident_bytes(n_eq, kd) <= LDS_MAX) return 0;   // the band lives in LDS
@@ -783,6 +837,7 @@ extern "C" long ops_frame_plan_signature(int B, int n_eq, int half_bandwidth) {
   switch (frame_family(B, n_eq, kd)) {
     case FAM_PACK: fp_config(kd, &P, &G, &W); return (2L << 24) | (W << 16) | (G << 8) | P;
     case FAM_WAVE: return (1L << 24) | (fw_width(kd) << 16) | (FW_G << 8) | 64;
+    case FAM_COOP: return (3L << 24) | (fc_width(kd) << 16) | (FW_G << 8) | 64;
     default: return 0;
   }
 }
@@ -860,6 +915,20 @@ extern "C" int ops_frame_solve_batched_f64_ex(int B, int n_nodes, int n_elems, i
       case 24: e = launch_pack<24, 32, 8>(p, (double*)workspace, s, reuse_plan); break;
       case 28: e = launch_pack<28, 32, 4>(p, (double*)workspace, s, reuse_plan); break;
       default: e = launch_pack<30, 32, 2>(p, (double*)workspace, s, reuse_plan); break;
+    }
+    if (e != hipSuccess) { set_frame_error(hipGetErrorString(e)); return OPS_AMD_ERR_LAUNCH; }
+    return OPS_AMD_OK;
+  }
+  if (fam == FAM_COOP) {
+    const int W = fc_width(kd);
+    const size_t need = (size_t)B * fc_frame_doubles(n_eq, kd) * sizeof(double) + plan_region_bytes(n_eq, FW_G, FW_EPG);
+    if (!workspace || workspace_bytes < need || n_elems > ne_bound(n_eq)) return OPS_AMD_ERR_INVALID_ARG;
+    hipError_t e = hipSuccess;
+    switch (W) {
+      case 20: e = launch_coop<20>(p, (double*)workspace, s, reuse_plan); break;
+      case 36: e = launch_coop<36>(p, (double*)workspace, s, reuse_plan); break;
+      case 52: e = launch_coop<52>(p, (double*)workspace, s, reuse_plan); break;
+      default: e = launch_coop<56>(p, (double*)workspace, s, reuse_plan); break;
     }
     if (e != hipSuccess) { set_frame_error(hipGetErrorString(e)); return OPS_AMD_ERR_LAUNCH; }
     return OPS_AMD_OK;

@@ -66,6 +66,7 @@ def test_argument_validation_without_gpu(lib):
     assert lib.ops_frame_workspace_bytes(40000, 90, 17) >= 40000 * 90 * 18 * 8      # packed kernel (half bandwidth <= 29): window width 18
     assert lib.ops_frame_plan_signature(40000, 90, 17) >> 24 == 2 and lib.ops_frame_plan_signature(5000, 330, 35) >> 24 == 1 and lib.ops_frame_plan_signature(3, 330, 35) == 0
     assert lib.ops_amd_get_option(b"frame_pack") == 1 and lib.ops_amd_get_option(b"frame_latency_batch") == -1 and lib.ops_amd_get_option(b"nope") == -2
+    assert lib.ops_amd_get_option(b"frame_coop") == 1 and lib.ops_amd_set_option(b"frame_coop", 3) != _cabi.OK
     assert lib.ops_amd_set_option(b"nope", 1) == _cabi.ERR_INVALID_ARG
     assert lib.ops_frame_workspace_bytes(3, 330, 35) == 0        # r05: small batches (<= 256 .. 4 000 frames by size) whose band fits LDS take the workgroup-per-frame kernels
     assert lib.ops_frame_workspace_bytes(0, 330, 35) == 0

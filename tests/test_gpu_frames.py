@@ -20,6 +20,7 @@ def _tuned_kernels_for_every_batch():
     yield
     _cabi.set_option("frame_latency_batch", -1)
     _cabi.set_option("frame_pack", 1)
+    _cabi.set_option("frame_coop", 1)
 
 
 @pytest.fixture(params=["wave", "latency"])
@@ -853,3 +854,95 @@ def test_packed_kernel_walks_the_extra_plan_blocks_of_a_hub_node(nn, hub, G, epg
         assert st == 0 and neq == topo.n_eq and _kd_ok(topo, kd)
         assert relerr(sol.disp[b].cpu().numpy().ravel(), d.ravel()) < 1e-8
         assert relerr(sol.forces[b].cpu().numpy().ravel(), f.ravel()) < 1e-7
+
+
+@pytest.mark.parametrize("bays,stories,W", [(1, 1, 20), (2, 2, 20), (5, 5, 20), (7, 7, 36), (10, 10, 36), (12, 12, 52), (15, 16, 52), (20, 17, 56)])
+def test_four_waves_per_frame_vs_oracle(bays, stories, W):
+    """csrc/frame_coop.hpp (r06, late): a workgroup of four waves per frame, the register window split by columns -- the small-batch kernel where
+    the r01 kernels' band is not LDS-resident or fits a CU only once.  Library option frame_coop = 2 sends EVERY small batch to it: each compiled
+    window width (20, 36, 52, 56) against the oracle, one frame that is not positive definite and one with a NaN load in the batch (status and
+    NaN stay in their frames), and against the r01 kernels on the same inputs."""
+    from openpystruct_amd import _cabi, frames
+    _cabi.set_option("frame_latency_batch", -1)
+    _cabi.set_option("frame_coop", 2)
+    topo = frames.grid_frame(bays, stories)
+    lib = _cabi.load()
+    B = 6
+    sig = int(lib.ops_frame_plan_signature(B, topo.n_eq, topo.kd))
+    assert sig >> 24 == 3 and (sig >> 16) & 0xFF == W, hex(sig)
+    rng = np.random.default_rng(31 * bays + stories)
+    I = np.exp(rng.uniform(np.log(5e-5), np.log(5e-3), size=(B, topo.Ne)))
+    I[2, min(3, topo.Ne - 1)] = -1.0
+    loads = np.broadcast_to(topo.nodal_loads, (B,) + topo.nodal_loads.shape).copy()
+    loads[4, -1, 0] = np.nan
+    It, Lt = torch.as_tensor(I, device="cuda"), torch.as_tensor(loads, device="cuda")
+    sol = frames.frame_solve(topo, It, Lt)
+    torch.cuda.synchronize()
+    st = sol.status.cpu().numpy()
+    healthy = [0, 1, 3, 5]
+    assert st[2] != 0 and st[healthy].sum() == 0 and torch.isnan(sol.disp[2]).all() and torch.isnan(sol.disp[4]).any()
+    for b in healthy:
+        d, f, s_, neq, _ = _oracle(topo, I[b])
+        assert s_ == 0 and neq == topo.n_eq
+        assert relerr(sol.disp[b].cpu().numpy().ravel(), d.ravel()) < 1e-8, b
+        assert relerr(sol.forces[b].cpu().numpy().ravel(), f.ravel()) < 1e-7, b
+    _cabi.set_option("frame_coop", 0)
+    assert int(lib.ops_frame_plan_signature(B, topo.n_eq, topo.kd)) == 0
+    ref = frames.frame_solve(topo, It, Lt)
+    torch.cuda.synchronize()
+    assert relerr(sol.disp[healthy].cpu().numpy().ravel(), ref.disp[healthy].cpu().numpy().ravel()) < 1e-10
+    np.testing.assert_array_equal(ref.status.cpu().numpy() != 0, st != 0)
+
+
+def test_four_waves_per_frame_on_general_topologies_and_a_hub_node():
+    """Pinned bases, braces (equation count no multiple of three or eight) and a node with eighteen elements (extra plan blocks) through
+    csrc/frame_coop.hpp; a second call on the same topology reuses the plan."""
+    from openpystruct_amd import _cabi, frames
+    _cabi.set_option("frame_latency_batch", -1)
+    _cabi.set_option("frame_coop", 2)
+    topos = [_custom_frame(2, 2, True, True), _custom_frame(3, 4, True, True), _custom_frame(6, 5, True, False), _custom_frame(9, 9, True, True)]
+    nn, hub = 19, 9
+    ang = np.linspace(0.0, 2 * np.pi, nn - 1, endpoint=False)
+    coords = np.zeros((nn, 2))
+    outer = [i for i in range(nn) if i != hub]
+    coords[outer, 0], coords[outer, 1] = 5.0 * np.cos(ang), 5.0 * np.sin(ang)
+    conn = np.array([(hub, o) for o in outer] + [(outer[i], outer[i + 1]) for i in range(len(outer) - 1)])
+    fix3 = np.zeros((nn, 3), dtype=bool)
+    fix3[0] = fix3[nn - 1] = True
+    loads = np.zeros((nn, 3)); loads[hub] = (3e4, -5e4, 2e3)
+    w = np.zeros(len(conn)); w[:4] = -8e3
+    topos.append(frames.FrameTopology(coords, conn, fix3, 0.02, 200e9, w, 0.5 * w, loads, "cuda", numbering="node"))
+    lib = _cabi.load()
+    for topo in topos:
+        if topo.kd > 55:
+            continue
+        B = 3
+        assert int(lib.ops_frame_plan_signature(B, topo.n_eq, topo.kd)) >> 24 == 3
+        rng = np.random.default_rng(topo.n_eq)
+        for rep in range(2):                                   # second call: the plan kept at the start of the workspace
+            I = np.exp(rng.uniform(np.log(5e-5), np.log(5e-3), size=(B, topo.Ne)))
+            sol = frames.frame_solve(topo, torch.as_tensor(I, device="cuda"))
+            assert int(sol.status.abs().sum()) == 0
+            for b in range(B):
+                d, f, st, neq, kd = _oracle(topo, I[b])
+                assert st == 0 and neq == topo.n_eq
+                assert relerr(sol.disp[b].cpu().numpy().ravel(), d.ravel()) < 1e-8
+                assert relerr(sol.forces[b].cpu().numpy().ravel(), f.ravel()) < 1e-7
+
+
+def test_small_batch_dispatch_picks_the_family_the_sweep_measured():
+    """profiles/r06_frame_coop_sweep*.txt: up to a frame per CU the r01 kernels where their band is LDS-resident (10 x 10), four waves per frame
+    where it is not (15 x 16, up to 512 frames) and between one and three frames per CU where the r01 kernel fits a CU only once (10 x 10,
+    257 .. 768 frames); the tuned kernels beyond.  Host-side functions only."""
+    from openpystruct_amd import _cabi, frames
+    _cabi.set_option("frame_latency_batch", -1)
+    lib = _cabi.load()
+    fam = lambda t, B: int(lib.ops_frame_plan_signature(B, t.n_eq, t.kd)) >> 24       # 0: r01 workgroup kernels, 1: wave, 2: packed, 3: four waves per frame
+    t10, t15, t5, t9 = (frames.grid_frame(*s, device="cpu") for s in ((10, 10), (15, 16), (5, 5), (9, 9)))
+    assert [fam(t10, B) for B in (1, 256, 257, 512, 768, 769, 4096)] == [0, 0, 3, 3, 3, 1, 1]
+    assert [fam(t15, B) for B in (1, 256, 512, 513, 12288)] == [3, 3, 3, 1, 1]
+    assert [fam(t5, B) for B in (1, 256, 512, 1024, 4096)] == [0, 0, 0, 0, 2]
+    assert fam(t9, 256) == 0 and fam(t9, 4096) == 2
+    _cabi.set_option("frame_coop", 0)
+    assert [fam(t10, B) for B in (257, 512)] == [0, 1] and fam(t15, 64) == 0
+    _cabi.set_option("frame_coop", 1)
