@@ -444,6 +444,32 @@ def frames_measure(dev, rank, local_rank, world, bays, stories, B, K, W):
         except Exception as e:          # reported in the record: an assertion here would leave the other ranks in the barrier below
             check_fail = repr(e)
     lib = _cabi.load()
+    # the reference's own use of this solve is ONE frame per epoch (FR:178-183): time of a call on a batch of one (its own dispatch: the
+    # workgroup-per-frame or four-waves-per-frame kernels), ten calls in a HIP graph, best of three replays.  Not part of `value`.
+    one_us, one_family = None, None
+    try:
+        I1 = I[:1].contiguous()
+        s1 = frames.frame_solve(topo, I1)
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            frames.frame_solve(topo, I1, out=s1)
+            side.synchronize()
+            g1 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g1, stream=side):
+                for _ in range(10):
+                    frames.frame_solve(topo, I1, out=s1)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        g1.replay(); torch.cuda.synchronize()
+        a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        one_us = 1e9
+        for _ in range(3):
+            a0.record(); g1.replay(); a1.record(); torch.cuda.synchronize()
+            one_us = min(one_us, a0.elapsed_time(a1) / 10 * 1e3)
+        one_family = {0: "workgroup per frame (r01 kernels)", 3: "four waves per frame (csrc/frame_coop.hpp)"}.get(
+            int(lib.ops_frame_plan_signature(1, topo.n_eq, topo.kd)) >> 24, "tuned")
+    except Exception as e:              # the record must survive
+        one_family = repr(e)
     # per frame, the call-wide assembly plan excluded (the packed kernel's share counts whole waves of 2 or 4 frames: difference over four frames)
     ws_frame = (int(lib.ops_frame_workspace_bytes(B + 4 - B % 4 + 4, topo.n_eq, topo.kd)) - int(lib.ops_frame_workspace_bytes(B + 4 - B % 4, topo.n_eq, topo.kd))) // 4
     # ALGORITHMIC bytes per frame: I in; disp [Nn,3], forces [Ne,6], V, M out -- what a solve that kept its factor on chip would move
@@ -464,6 +490,7 @@ def frames_measure(dev, rank, local_rank, world, bays, stories, B, K, W):
         # headline of this workload: the FP64 vector rate (the factorisation is n kd^2 flops on 42 KB of algorithmic I/O: it is
         # arithmetic-, not HBM-bound); the HBM record is on ALGORITHMIC bytes, with the measured (PMC) traffic named beside it
         "fp64_vector_frac": flops * B / (us * 1e-6) / 78.6e12,
+        "batch_of_one": {"us_per_call": one_us, "kernel_family": one_family},
         "checked": checked, "checked_max_rel_err": check_err, "check_error": check_fail,     # frames of THIS batch compared with oracle.solve_model_3dof (disp 1e-7, forces 1e-6)
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": tr[0] if tr else None, "traffic_source": f"profiles/{tr[1]} (2*FETCH_SIZE + WRITE_SIZE, KiB)" if tr else None,
