@@ -2,9 +2,10 @@
 // (included by frame_solve.hip behind frame_wave.hpp: FwPlan, the parking-area layout, fw_readlane, fw_backward come from there)
 //
 // For the reference's own use of the frame solve -- ONE frame per epoch (/root/reference/OpenPyStruct_FrameOpt_Discrete_Beta.py:178-183) -- and
-// every batch too small to fill the chip, what counts is how long ONE frame takes.  A lone wave of the wave-per-frame kernel needs ~1 500
-// cycles per column (its ~90 vector instructions of a step issue one after the other, nothing else runs on its SIMD); the r01 workgroup kernels
-// ~790 (band in LDS, three columns per barrier).  Here the four waves of a workgroup sit on the four SIMDs of one CU and share one frame:
+// every batch too small to fill the chip, what counts is how long ONE frame takes.  A lone wave of the wave-per-frame kernel needs ~0.6 us
+// per column (its ~90 vector instructions of a step issue one after the other, nothing else runs on its SIMD); the r01 workgroup kernels
+// ~0.31 us while their band (n x (kd + 4) doubles) is LDS-resident, ~0.6 us through their LDS ring when it is not (BASELINE config 5: 15 x 16).
+// Here the four waves of a workgroup sit on the four SIMDs of one CU and share one frame, the window in REGISTERS whatever the frame's size:
 //
 //   * same arithmetic and same row mapping as frame_wave.hpp (column-by-column band LDL^T = dpbsv's, FR:134; row R in lane R mod 64 of EVERY
 //     wave), but wave q holds only the window columns whose slot (C mod W) lies in [q W/4, (q+1) W/4): W/4 multiply-adds per step and wave;
@@ -14,7 +15,10 @@
 //   * wave 0 also carries the right-hand side (forward substitution, w_j = z_j / d_j into LDS), wave 3 stores column j of L to the workspace;
 //   * rows enter in groups of eight through the same parking area and assembly plan as frame_wave.hpp, built by all 256 threads;
 //   * backward substitution: wave 0 alone (fw_backward), results by all 256 threads.
-// The chain of a step is LDS round trip + reciprocal + one multiply-add + barrier: ~300-400 cycles (measured: profiles/r06_notes.md 22).
+// Measured (profiles/r06_notes.md 22): 0.33-0.39 us per equation -- each wave's ~35 instructions per column issue one behind the other; two
+// columns per barrier changed nothing.  That equals the r01 kernels where their band is resident, so the dispatch (frame_solve.hip
+// frame_family) takes this kernel where it is not (15 x 16 x 1: 455 -> 294 us) or where the r01 workgroup fits a CU only once and the batch is
+// beyond one frame per CU (10 x 10 x 512: 192 -> 145 us).
 #pragma once
 
 namespace opsamd {
