@@ -169,7 +169,8 @@ __host__ __device__ constexpr int fp_tb(int P) { return (P / 8 + (P / 8) * (P / 
 template <int W, int P>
 __device__ __forceinline__ void fp_backward(const double* __restrict__ Lc, double* __restrict__ xs, double* __restrict__ tb, int n,
                                             int kd, int r) {
-  constexpr int U = P / 8, MF = (W + 7) / 8, NT = U * (U - 1) / 2, D = P == 64 ? 2 : FP_BD;      // (64 lanes: 7 registers per pass and lane)
+  // passes in flight: six at three waves per SIMD; four where four waves share the SIMD and the window is 12 .. 18 wide (measured late in r06: 4 x 4 +5 %, 5 x 5 / 3 x 3 +0.3 %, eight: -7 %)
+  constexpr int U = P / 8, MF = (W + 7) / 8, NT = U * (U - 1) / 2, D = P == 64 ? 2 : (W >= 12 && W <= 18 && FP_BD > 4) ? 4 : FP_BD;      // (W = 10: four passes -6 %)
   static_assert(U >= 2, "frame_pack: at least 16 lanes per frame");
   const int u = r >> 3, k = r & 7;
   xs[n + r] = 0.0;                                        // rows past the last equation (the idle steps left garbage there)
